@@ -1,0 +1,130 @@
+"""ctypes binding of libgdx.so (include/gdx.h, include/gdx_bench.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded the import of the
+query API fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdx.so")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+GDX_OK = 0
+GDX_ERR_INVALID_ARGUMENT = 1
+GDX_ERR_INVALID_TEXT_SYMBOL = 2
+GDX_ERR_TEXT_TOO_LONG = 3
+GDX_ERR_DEVICE = 4
+GDX_ERR_CAPACITY = 5
+GDX_ERR_QUERY_STATUS = 6
+GDX_ERR_UNSUPPORTED = 7
+
+GDX_Q_OK = 0
+GDX_Q_INVALID_SYMBOL = 1
+GDX_Q_UNSEARCHABLE_IN_LOOKUP = 2
+
+
+class GdxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"gdx status {status}: {message}")
+        self.status = status
+
+
+class HitStruct(C.Structure):
+    _fields_ = [("text_id", C.c_uint64), ("position", C.c_uint64)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("total_text_len", C.c_uint64), ("num_texts", C.c_uint64), ("sigma", C.c_int32),
+                ("n_searchable", C.c_int32), ("lookup_depth", C.c_int32), ("index_width", C.c_int32),
+                ("sa_rate", C.c_uint64), ("device_bytes", C.c_uint64), ("device_id", C.c_int32),
+                ("table_layout", C.c_int32)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("sa_initial_order", C.c_uint64), ("sa_pending_after_sort", C.c_uint64), ("sa_rounds", C.c_uint64),
+                ("seconds_encode", C.c_double), ("seconds_sa", C.c_double), ("seconds_bwt", C.c_double),
+                ("seconds_table", C.c_double), ("seconds_lookup", C.c_double)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "gdx_last_error": [],
+    "gdx_device_count": [],
+    "gdx_index_build": [u8p, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                        C.POINTER(vp)],
+    "gdx_index_build_dev": [vp, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                            C.POINTER(vp)],
+    "gdx_index_from_parts": [u64p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, u64p, C.c_uint64, u8p, C.c_int,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "gdx_index_free": [vp],
+    "gdx_index_info": [vp, C.POINTER(IndexInfo)],
+    "gdx_index_export_count": [vp, u64p],
+    "gdx_index_export_bwt": [vp, u8p],
+    "gdx_index_export_sa_samples": [vp, u32p],
+    "gdx_index_export_borders": [vp, u64p, u64p],
+    "gdx_index_export_sentinel_indices": [vp, u64p],
+    "gdx_index_export_lookup_table": [vp, C.c_int, u32p],
+    "gdx_index_export_condensed_table": [vp, u64p, u16p, u32p],
+    "gdx_rank_many": [vp, u8p, u64p, C.c_uint64, u64p],
+    "gdx_symbol_at_many": [vp, u64p, C.c_uint64, u8p],
+    "gdx_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
+    "gdx_cursors_for_many_queries": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],
+    "gdx_locate_many": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p, u8p],
+    "gdx_cursor_empty": [vp, u64p, u64p],
+    "gdx_cursor_extend_front_many": [vp, u64p, u64p, u8p, C.c_uint64, u8p],
+    "gdx_cursor_locate_many": [vp, u64p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p],
+    "gdx_cursors_for_many_queries_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_count_many_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_cursor_extend_front_many_dev": [vp, vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_hit_offsets_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_locate_workspace_bytes": [C.c_uint64],
+    "gdx_locate_intervals_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
+    "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    # gdx_bench.h
+    "gdx_index_build_stats": [vp, C.POINTER(BuildStats)],
+    "gdx_synth_text_dev": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp],
+    "gdx_synth_queries_dev": [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp,
+                              C.c_uint64, u64p, vp],
+    "gdx_bench_stream_copy": [vp, vp, C.c_uint64, vp],
+    "gdx_bench_random_gather": [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp],
+    "gdx_search_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
+}
+_RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_locate_workspace_bytes": C.c_uint64}
+
+_lib = None
+
+
+def load():
+    """Loads libgdx.so; raises if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"or `make -C genedex_amd/csrc`. genedex_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what gdx.h declares
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().gdx_last_error().decode(errors="replace")
+
+
+def check(status: int, allow=()):
+    if status != GDX_OK and status not in allow:
+        raise GdxError(status, last_error())
+    return status

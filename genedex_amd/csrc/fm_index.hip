@@ -1,0 +1,945 @@
+// fm_index.hip -- index construction kernels (everything but the suffix sorter) and the host-side
+// FmIndex object.  Construction follows the reference's data flow (construction/mod.rs:25-57):
+// concatenate + densely encode -> count -> suffix array -> BWT + text borders -> SA sampling ->
+// occurrence table -> lookup tables; every stage is a HIP kernel, nothing is computed on the host
+// except O(#texts) bookkeeping.
+#include "fm_index.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace gdx {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+unsigned grid_for_items(uint64_t items, uint64_t cap = 256u * 16u)
+{
+    const uint64_t blocks = (items + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+double now_seconds()
+{
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------
+// construction/mod.rs:255-308: text t occupies [sentinel[t-1]+1, sentinel[t]) of the concatenation and
+// is followed by one sentinel (dense 0).  hist[c] += occurrences; *error = 1 on a symbol outside the
+// alphabet (alphabet.rs:195-198 panics).
+__global__ __launch_bounds__(kBlock) void encode_concat_kernel(const uint8_t *__restrict__ io_text,
+                                                               const uint32_t *__restrict__ sentinels,
+                                                               uint32_t n_texts, uint64_t n,
+                                                               const uint8_t *__restrict__ io_to_dense,
+                                                               uint8_t *__restrict__ dense,
+                                                               unsigned long long *__restrict__ hist,
+                                                               uint32_t *__restrict__ error)
+{
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint8_t s_dense[256];
+    for (int i = threadIdx.x; i < 256; i += kBlock) {
+        s_hist[i] = 0;
+        s_dense[i] = io_to_dense[i];
+    }
+    __syncthreads();
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
+        const uint32_t t = lower_bound_u32(sentinels, n_texts, static_cast<uint32_t>(p));
+        uint8_t d = 0;
+        if (sentinels[t] != static_cast<uint32_t>(p)) {
+            d = s_dense[io_text[p - t]];  // t sentinels precede position p
+            if (d == 0) *error = 1;
+        }
+        dense[p] = d;
+        atomicAdd(&s_hist[d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        if (s_hist[i]) atomicAdd(&hist[i], static_cast<unsigned long long>(s_hist[i]));
+}
+
+__global__ __launch_bounds__(kBlock) void histogram_kernel(const uint8_t *__restrict__ text, uint64_t n,
+                                                           unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[256];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_hist[i] = 0;
+    __syncthreads();
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride)
+        atomicAdd(&s_hist[text[p]], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kBlock)
+        if (s_hist[i]) atomicAdd(&hist[i], static_cast<unsigned long long>(s_hist[i]));
+}
+
+// bwt.rs:93-116 (bwt[i] = text[SA[i]-1], SA[i]==0 wraps to the last symbol; the border map collects
+// {i -> SA[i]} for every BWT sentinel) fused with sampled_suffix_array.rs:37-43 (keep SA[i], i%rate==0)
+__global__ __launch_bounds__(kBlock) void bwt_samples_borders_kernel(const uint8_t *__restrict__ text,
+                                                                     const uint32_t *__restrict__ sa, uint64_t n,
+                                                                     uint32_t rate, uint8_t *__restrict__ bwt,
+                                                                     uint32_t *__restrict__ samples,
+                                                                     uint32_t *__restrict__ border_keys,
+                                                                     uint32_t *__restrict__ border_vals,
+                                                                     uint32_t *__restrict__ n_borders)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; j < n; j += stride) {
+        const uint32_t s = sa[j];
+        const uint64_t ti = s > 0 ? s : n;
+        const uint8_t b = text[ti - 1];
+        bwt[j] = b;
+        if (j % rate == 0) samples[j / rate] = s;
+        if (b == 0) {
+            const uint32_t at = atomicAdd(n_borders, 1u);
+            border_keys[at] = static_cast<uint32_t>(j);
+            border_vals[at] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank lines (layout 0).  One block per superblock of 65536 positions = 512 lines; thread t builds
+// lines 2t and 2t+1, then a block-wide exclusive scan of the per-line symbol counts yields the u16
+// block offsets (condensed.rs:365-415 fill_superblock, two Block64 fused per line).
+// bwt must be readable (zero padded) up to n_lines * 128 bytes.
+
+__device__ __forceinline__ void build_line_planes(const uint8_t *__restrict__ src, uint32_t (&x)[4],
+                                                  uint32_t (&y)[4], uint32_t (&z)[4])
+{
+    const uint4 *v = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t xx = 0, yy = 0, zz = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint4 w = v[2 * j + h];
+            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t s = (words[k] >> (8 * b)) & 0xffu;
+                    const int t = h * 16 + k * 4 + b;
+                    xx |= (s & 1u) << t;
+                    yy |= ((s >> 1) & 1u) << t;
+                    zz |= ((s >> 2) & 1u) << t;
+                }
+            }
+        }
+        x[j] = xx;
+        y[j] = yy;
+        z[j] = zz;
+    }
+}
+
+__device__ __forceinline__ uint32_t planes_count(const uint32_t (&x)[4], const uint32_t (&y)[4],
+                                                 const uint32_t (&z)[4], uint32_t c)
+{
+    const uint32_t n0 = (c & 1u) ? 0u : ~0u, n1 = (c & 2u) ? 0u : ~0u, n2 = (c & 4u) ? 0u : ~0u;
+    uint32_t pop = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) pop += __popc((x[j] ^ n0) & (y[j] ^ n1) & (z[j] ^ n2));
+    return pop;
+}
+
+__global__ __launch_bounds__(kBlock) void build_lines_kernel(const uint8_t *__restrict__ bwt, uint64_t n,
+                                                             uint64_t n_lines, u32x4 *__restrict__ lines,
+                                                             uint32_t *__restrict__ sb_totals)
+{
+    __shared__ uint32_t s_scan[8][kBlock];
+    const uint64_t sb = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    uint32_t x[2][4], y[2][4], z[2][4];
+    uint32_t cnt[2][8];
+    uint32_t pair_sum[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) pair_sum[c] = 0;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
+        if (line < n_lines) {
+            build_line_planes(bwt + line * 128, x[l], y[l], z[l]);
+            const uint64_t first = line * 128;
+            const uint32_t valid = first >= n ? 0u : (n - first >= 128 ? 128u : static_cast<uint32_t>(n - first));
+            uint32_t others = 0;
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+                cnt[l][c] = planes_count(x[l], y[l], z[l], c);
+                others += cnt[l][c];
+            }
+            cnt[l][0] = valid - others;  // padding decodes as 0 but is not text
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) x[l][j] = y[l][j] = z[l][j] = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) cnt[l][c] = 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) pair_sum[c] += cnt[l][c];
+    }
+    // inclusive Hillis-Steele scan over the 256 thread pairs, 8 symbols at once
+#pragma unroll
+    for (int c = 0; c < 8; c++) s_scan[c][t] = pair_sum[c];
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        uint32_t add[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) add[c] = t >= static_cast<uint32_t>(off) ? s_scan[c][t - off] : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_scan[c][t] += add[c];
+        __syncthreads();
+    }
+    uint32_t before[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) before[c] = s_scan[c][t] - pair_sum[c];
+    if (t == kBlock - 1) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) sb_totals[sb * 8 + c] = s_scan[c][t];
+    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
+        if (line < n_lines) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32x4 chunk;
+                chunk.x = x[l][j];
+                chunk.y = y[l][j];
+                chunk.z = z[l][j];
+                chunk.w = (before[2 * j] & 0xffffu) | (before[2 * j + 1] << 16);
+                lines[line * 4 + j] = chunk;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) before[c] += cnt[l][c];
+    }
+}
+
+// exclusive prefix sum over superblocks, one thread per symbol column (condensed.rs:104-115)
+__global__ void superblock_prefix_kernel(uint32_t *sb, uint64_t n_sb, uint32_t stride)
+{
+    const uint32_t c = threadIdx.x;
+    if (c >= stride) return;
+    uint32_t sum = 0;
+    for (uint64_t s = 0; s < n_sb; s++) {
+        const uint32_t v = sb[s * stride + c];
+        sb[s * stride + c] = sum;
+        sum += v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic planes (layout 1) = the reference's own arrays (condensed.rs:24-30), also used to export
+// the table of a line-layout index in the reference's logical form.
+
+__global__ __launch_bounds__(kBlock) void build_planes_kernel(const uint8_t *__restrict__ bwt, uint64_t n,
+                                                              uint64_t n_blocks, int nbits,
+                                                              uint64_t *__restrict__ planes)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; b < n_blocks; b += stride) {
+        uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t t = 0; t < 64; t++) {
+            const uint64_t p = b * 64 + t;
+            const uint32_t s = p < n ? bwt[p] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] |= static_cast<uint64_t>((s >> k) & 1u) << t;
+        }
+        for (int k = 0; k < nbits; k++) planes[b * nbits + k] = w[k];
+    }
+}
+
+// one thread per (superblock, symbol): walks the superblock once and writes the u16 offset of the
+// symbol at every 64-block start, plus the superblock total.  O(n * sigma) work; the generic layout
+// serves alphabets with more than 8 dense symbols on small and medium inputs.
+__global__ __launch_bounds__(kBlock) void build_generic_offsets_kernel(const uint8_t *__restrict__ bwt, uint64_t n,
+                                                                       uint64_t n_blocks, uint64_t n_sb, int sigma,
+                                                                       uint16_t *__restrict__ block_off,
+                                                                       uint32_t *__restrict__ sb_totals)
+{
+    const uint64_t total = n_sb * static_cast<uint64_t>(sigma);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; w < total; w += stride) {
+        const uint64_t sb = w / sigma;
+        const uint32_t c = static_cast<uint32_t>(w % sigma);
+        uint32_t sum = 0;
+        const uint64_t b0 = sb * 1024, b1 = (b0 + 1024 < n_blocks) ? b0 + 1024 : n_blocks;
+        for (uint64_t b = b0; b < b1; b++) {
+            block_off[b * sigma + c] = static_cast<uint16_t>(sum);
+            const uint64_t p0 = b * 64, p1 = (p0 + 64 < n) ? p0 + 64 : n;
+            for (uint64_t p = p0; p < p1; p++) sum += (bwt[p] == c);
+        }
+        sb_totals[sb * sigma + c] = sum;
+    }
+}
+
+template <class Table>
+__global__ __launch_bounds__(kBlock) void decode_bwt_kernel(IndexView ix, uint8_t *__restrict__ bwt)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride)
+        bwt[p] = static_cast<uint8_t>(Table::symbol_at(ix, static_cast<uint32_t>(p)));
+}
+
+// condensed.rs:343-362 symbol_at over the reference's interleaved plane words
+__global__ __launch_bounds__(kBlock) void decode_reference_planes_kernel(const uint64_t *__restrict__ planes,
+                                                                         int nbits, uint64_t n,
+                                                                         uint8_t *__restrict__ bwt)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
+        const uint64_t *w = planes + (p >> 6) * nbits;
+        uint32_t s = 0;
+        for (int k = 0; k < nbits; k++) s |= static_cast<uint32_t>((w[k] >> (p & 63u)) & 1ull) << k;
+        bwt[p] = static_cast<uint8_t>(s);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void widen_u32_kernel(const uint32_t *in, uint64_t *out, uint64_t m)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) out[i] = in[i];
+}
+
+__global__ __launch_bounds__(kBlock) void narrow_u64_kernel(const uint64_t *in, uint32_t *out, uint64_t m,
+                                                            uint64_t limit, uint32_t *error)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        const uint64_t v = in[i];
+        if (v > limit) *error = 1;
+        out[i] = static_cast<uint32_t>(v);
+    }
+}
+
+int ilog2_ceil(uint64_t v)  // condensed.rs:417-419
+{
+    int bits = 0;
+    while ((1ull << bits) < v) bits++;
+    return bits;
+}
+
+void validate_config(const IndexConfig &cfg)
+{
+    if (cfg.sigma < 2 || cfg.sigma > 256) fail(GDX_ERR_INVALID_ARGUMENT, "sigma must be in 2..=256 (condensed.rs:64)");
+    if (cfg.n_searchable < 1 || cfg.n_searchable > cfg.sigma - 1)
+        fail(GDX_ERR_INVALID_ARGUMENT, "n_searchable must be in 1..=sigma-1 (alphabet.rs:183-186)");
+    if (cfg.sa_rate == 0 || cfg.sa_rate > 0xffffffffull)
+        fail(GDX_ERR_INVALID_ARGUMENT, "suffix_array_sampling_rate must be > 0 (config.rs:28)");
+    if (cfg.index_width != 32 && cfg.index_width != -32 && cfg.index_width != 64)
+        fail(GDX_ERR_INVALID_ARGUMENT, "index_width must be 32 (u32), -32 (i32) or 64 (i64)");
+    if (cfg.lookup_depth < 0 || cfg.lookup_depth > kMaxLookupDepth)
+        fail(GDX_ERR_INVALID_ARGUMENT, "lookup_table_depth must be in 0..=%d", kMaxLookupDepth);
+    // all tables 0..=depth must fit comfortably: sum k^t < 2^31 entries
+    double total = 0, pw = 1;
+    for (int t = 0; t <= cfg.lookup_depth; t++) {
+        total += pw;
+        pw *= cfg.n_searchable;
+    }
+    if (total >= 2147483648.0) fail(GDX_ERR_INVALID_ARGUMENT, "lookup tables would need %.3g entries", total);
+    int dc = 0;
+    if (hipGetDeviceCount(&dc) != hipSuccess || dc <= 0) fail(GDX_ERR_DEVICE, "no HIP device available");
+    if (cfg.device_id < 0 || cfg.device_id >= dc) fail(GDX_ERR_INVALID_ARGUMENT, "device_id %d out of range", cfg.device_id);
+}
+
+void check_width(uint64_t n, int width)
+{
+    // construction/mod.rs:34 assert!(text.len() <= I::max_value())
+    const uint64_t limit = width == -32 ? 0x7fffffffull : 0xffffffffull;
+    if (n > limit)
+        fail(GDX_ERR_TEXT_TOO_LONG, "total text length %llu (incl. sentinels) exceeds the index storage type",
+             static_cast<unsigned long long>(n));
+}
+
+}  // namespace
+
+FmIndex::~FmIndex() = default;
+
+void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
+
+uint64_t FmIndex::device_bytes() const
+{
+    return lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+           io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
+           sentinels_.bytes() + lookup_.bytes();
+}
+
+// Builds the occurrence table from the (zero padded) BWT, the lookup tables, and the device view.
+// Expects n_, n_texts_, count_host_, sentinels_host_, border_*_host_ and sa_samples_ to be set.
+void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
+{
+    const int sigma = cfg_.sigma;
+    const int nbits = ilog2_ceil(static_cast<uint64_t>(sigma));
+    const uint64_t len = n_ + 1;  // condensed.rs:69: idx == n must be addressable
+    const uint64_t n_sb = div_ceil(len, 65536);
+    double t0 = now_seconds();
+
+    view_ = IndexView{};
+    view_.layout = sigma <= 8 ? 0 : 1;
+    if (view_.layout == 0) {
+        const uint64_t n_lines = div_ceil(len, 128);
+        lines_.alloc(n_lines * 4);
+        sb_offsets_.alloc(n_sb * 8);
+        hipLaunchKernelGGL(build_lines_kernel, dim3(static_cast<unsigned>(n_sb)), dim3(kBlock), 0, stream,
+                           d_bwt_padded, n_, n_lines, lines_.get(), sb_offsets_.get());
+        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(64), 0, stream, sb_offsets_.get(), n_sb, 8u);
+        view_.sb_stride = 8;
+    } else {
+        const uint64_t n_blocks = div_ceil(len, 64);
+        g_planes_.alloc(n_blocks * nbits);
+        g_block_off_.alloc(n_blocks * sigma);
+        sb_offsets_.alloc(n_sb * sigma);
+        hipLaunchKernelGGL(build_planes_kernel, dim3(grid_for_items(n_blocks)), dim3(kBlock), 0, stream,
+                           d_bwt_padded, n_, n_blocks, nbits, g_planes_.get());
+        hipLaunchKernelGGL(build_generic_offsets_kernel, dim3(grid_for_items(n_sb * sigma)), dim3(kBlock), 0, stream,
+                           d_bwt_padded, n_, n_blocks, n_sb, sigma, g_block_off_.get(), sb_offsets_.get());
+        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(256), 0, stream, sb_offsets_.get(), n_sb,
+                           static_cast<uint32_t>(sigma));
+        view_.sb_stride = static_cast<uint32_t>(sigma);
+    }
+
+    // small arrays
+    std::vector<uint32_t> count32(sigma + 1);
+    for (int c = 0; c <= sigma; c++) count32[c] = static_cast<uint32_t>(count_host_[c]);
+    count_.alloc(sigma + 1);
+    GDX_HIP(hipMemcpyAsync(count_.get(), count32.data(), count32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    io_to_dense_.alloc(256);
+    GDX_HIP(hipMemcpyAsync(io_to_dense_.get(), cfg_.io_to_dense, 256, hipMemcpyHostToDevice, stream));
+    std::vector<uint32_t> tmp(n_texts_);
+    sentinels_.alloc(n_texts_);
+    border_keys_.alloc(n_texts_);
+    border_vals_.alloc(n_texts_);
+    for (uint64_t t = 0; t < n_texts_; t++) tmp[t] = static_cast<uint32_t>(sentinels_host_[t]);
+    GDX_HIP(hipMemcpy(sentinels_.get(), tmp.data(), n_texts_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (uint64_t t = 0; t < n_texts_; t++) tmp[t] = static_cast<uint32_t>(border_keys_host_[t]);
+    GDX_HIP(hipMemcpy(border_keys_.get(), tmp.data(), n_texts_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (uint64_t t = 0; t < n_texts_; t++) tmp[t] = static_cast<uint32_t>(border_vals_host_[t]);
+    GDX_HIP(hipMemcpy(border_vals_.get(), tmp.data(), n_texts_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    // lookup tables, all depths concatenated (lookup_table.rs:163-181)
+    lookup_off_host_.assign(kMaxLookupDepth + 2, 0);
+    uint64_t entries = 0, pw = 1;
+    for (int t = 0; t <= cfg_.lookup_depth; t++) {
+        lookup_off_host_[t] = entries;
+        entries += pw;
+        pw *= static_cast<uint64_t>(cfg_.n_searchable);
+    }
+    for (int t = cfg_.lookup_depth + 1; t < kMaxLookupDepth + 2; t++) lookup_off_host_[t] = entries;
+    lookup_.alloc(entries);
+
+    view_.lines = lines_.get();
+    view_.sb_offsets = sb_offsets_.get();
+    view_.g_planes = g_planes_.get();
+    view_.g_block_off = g_block_off_.get();
+    view_.count = count_.get();
+    view_.io_to_dense = io_to_dense_.get();
+    view_.sa_samples = sa_samples_.get();
+    view_.border_keys = border_keys_.get();
+    view_.border_vals = border_vals_.get();
+    view_.sentinels = sentinels_.get();
+    view_.lookup = lookup_.get();
+    for (int t = 0; t < kMaxLookupDepth + 2; t++) view_.lookup_off[t] = static_cast<uint32_t>(lookup_off_host_[t]);
+    view_.n = static_cast<uint32_t>(n_);
+    view_.n_texts = static_cast<uint32_t>(n_texts_);
+    view_.sa_rate = static_cast<uint32_t>(cfg_.sa_rate);
+    const bool pow2 = (cfg_.sa_rate & (cfg_.sa_rate - 1)) == 0;
+    view_.sa_rate_pow2_mask = pow2 ? static_cast<uint32_t>(cfg_.sa_rate - 1) : 0xffffffffu;
+    view_.sa_rate_shift = 0;
+    while (pow2 && (1ull << view_.sa_rate_shift) < cfg_.sa_rate) view_.sa_rate_shift++;
+    view_.sigma = sigma;
+    view_.nbits = nbits;
+    view_.n_searchable = cfg_.n_searchable;
+    view_.depth = cfg_.lookup_depth;
+
+    GDX_HIP(hipStreamSynchronize(stream));
+    stats_.seconds_table = now_seconds() - t0;
+    t0 = now_seconds();
+    const uint2 root = make_uint2(0u, static_cast<uint32_t>(n_));  // lookup_table.rs:205-208
+    GDX_HIP(hipMemcpyAsync(lookup_.get(), &root, sizeof(root), hipMemcpyHostToDevice, stream));
+    for (int t = 1; t <= cfg_.lookup_depth; t++) launch_fill_lookup(view_, lookup_.get(), t, stream);
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+    stats_.seconds_lookup = now_seconds() - t0;
+}
+
+std::unique_ptr<FmIndex> FmIndex::construct_index(const uint8_t *texts_buf, bool texts_on_device,
+                                                  const uint64_t *text_offsets, uint64_t n_texts,
+                                                  const IndexConfig &cfg)
+{
+    validate_config(cfg);
+    if (n_texts == 0) fail(GDX_ERR_INVALID_ARGUMENT, "There should be at least one text (construction/mod.rs:303)");
+    if (!text_offsets) fail(GDX_ERR_INVALID_ARGUMENT, "text_offsets is null");
+    const uint64_t io_len = text_offsets[n_texts] - text_offsets[0];
+    for (uint64_t t = 0; t < n_texts; t++)
+        if (text_offsets[t + 1] < text_offsets[t]) fail(GDX_ERR_INVALID_ARGUMENT, "text_offsets must be non-decreasing");
+    if (io_len > 0 && !texts_buf) fail(GDX_ERR_INVALID_ARGUMENT, "texts_buf is null");
+    const uint64_t n = io_len + n_texts;
+    check_width(n, cfg.index_width);
+    if (n_texts > 0xffffffffull) fail(GDX_ERR_TEXT_TOO_LONG, "too many texts");
+
+    std::unique_ptr<FmIndex> ix(new FmIndex());
+    ix->cfg_ = cfg;
+    ix->n_ = n;
+    ix->n_texts_ = n_texts;
+    GDX_HIP(hipSetDevice(cfg.device_id));
+    hipStream_t stream = hipStreamPerThread;
+
+    // construction/mod.rs:266-273 sentinel_indices
+    ix->sentinels_host_.resize(n_texts);
+    std::vector<uint32_t> sent32(n_texts);
+    for (uint64_t t = 0; t < n_texts; t++) {
+        ix->sentinels_host_[t] = (text_offsets[t + 1] - text_offsets[0]) + t;
+        sent32[t] = static_cast<uint32_t>(ix->sentinels_host_[t]);
+    }
+
+    double t0 = now_seconds();
+    // ---- encode + concatenate + frequency table --------------------------------------------------
+    DeviceBuffer<uint8_t> io_owned;
+    const uint8_t *d_io = texts_buf ? texts_buf + (texts_on_device ? text_offsets[0] : 0) : nullptr;
+    if (!texts_on_device) {
+        io_owned.alloc(io_len ? io_len : 1);
+        if (io_len) GDX_HIP(hipMemcpy(io_owned.get(), texts_buf + text_offsets[0], io_len, hipMemcpyHostToDevice));
+        d_io = io_owned.get();
+    }
+    DeviceBuffer<uint32_t> d_sent(n_texts);
+    GDX_HIP(hipMemcpy(d_sent.get(), sent32.data(), n_texts * sizeof(uint32_t), hipMemcpyHostToDevice));
+    DeviceBuffer<uint8_t> d_tab(256);
+    GDX_HIP(hipMemcpy(d_tab.get(), cfg.io_to_dense, 256, hipMemcpyHostToDevice));
+    DeviceBuffer<uint8_t> d_text(n);
+    DeviceBuffer<unsigned long long> d_hist(256);
+    DeviceBuffer<uint32_t> d_flag(1);
+    GDX_HIP(hipMemsetAsync(d_hist.get(), 0, 256 * sizeof(unsigned long long), stream));
+    GDX_HIP(hipMemsetAsync(d_flag.get(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(encode_concat_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream, d_io, d_sent.get(),
+                       static_cast<uint32_t>(n_texts), n, d_tab.get(), d_text.get(), d_hist.get(), d_flag.get());
+    unsigned long long hist[256];
+    uint32_t flag = 0;
+    GDX_HIP(hipMemcpyAsync(hist, d_hist.get(), sizeof(hist), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(&flag, d_flag.get(), sizeof(flag), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+    if (flag) fail(GDX_ERR_INVALID_TEXT_SYMBOL, "symbol in io representation should be valid (alphabet.rs:195-198)");
+    for (int c = cfg.sigma; c < 256; c++)
+        if (hist[c]) fail(GDX_ERR_INVALID_ARGUMENT, "io_to_dense maps to dense symbol %d >= sigma", c);
+    io_owned.release();
+    // construction/mod.rs:318-336 frequency_table_to_count
+    std::vector<uint64_t> freq(cfg.sigma);
+    ix->count_host_.assign(cfg.sigma + 1, 0);
+    uint64_t sum = 0;
+    for (int c = 0; c < cfg.sigma; c++) {
+        freq[c] = hist[c];
+        ix->count_host_[c] = sum;
+        sum += hist[c];
+    }
+    ix->count_host_[cfg.sigma] = sum;
+    ix->stats_.seconds_encode = now_seconds() - t0;
+
+    // ---- suffix array ----------------------------------------------------------------------------------
+    t0 = now_seconds();
+    DeviceBuffer<uint32_t> d_sa(n);
+    build_suffix_array(d_text.get(), n, cfg.sigma, freq, d_sa.get(), stream, &ix->stats_);
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+    ix->stats_.seconds_sa = now_seconds() - t0;
+
+    // ---- BWT, SA samples, text borders -------------------------------------------------------------------
+    t0 = now_seconds();
+    const uint64_t padded = div_ceil(n + 1, 128) * 128;
+    DeviceBuffer<uint8_t> d_bwt(padded);
+    GDX_HIP(hipMemsetAsync(d_bwt.get(), 0, padded, stream));
+    const uint64_t n_samples = div_ceil(n, cfg.sa_rate);
+    ix->sa_samples_.alloc(n_samples);
+    DeviceBuffer<uint32_t> d_bk(n_texts), d_bv(n_texts), d_nb(1);
+    GDX_HIP(hipMemsetAsync(d_nb.get(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(bwt_samples_borders_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream, d_text.get(),
+                       d_sa.get(), n, static_cast<uint32_t>(cfg.sa_rate), d_bwt.get(), ix->sa_samples_.get(),
+                       d_bk.get(), d_bv.get(), d_nb.get());
+    std::vector<uint32_t> bk(n_texts), bv(n_texts);
+    uint32_t nb = 0;
+    GDX_HIP(hipMemcpy(&nb, d_nb.get(), sizeof(nb), hipMemcpyDeviceToHost));
+    if (nb != n_texts) fail(GDX_ERR_DEVICE, "internal: %u BWT sentinels for %llu texts", nb, (unsigned long long)n_texts);
+    GDX_HIP(hipMemcpy(bk.data(), d_bk.get(), n_texts * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    GDX_HIP(hipMemcpy(bv.data(), d_bv.get(), n_texts * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint32_t, uint32_t>> borders(n_texts);
+    for (uint64_t t = 0; t < n_texts; t++) borders[t] = {bk[t], bv[t]};
+    std::sort(borders.begin(), borders.end());
+    ix->border_keys_host_.resize(n_texts);
+    ix->border_vals_host_.resize(n_texts);
+    for (uint64_t t = 0; t < n_texts; t++) {
+        ix->border_keys_host_[t] = borders[t].first;
+        ix->border_vals_host_[t] = borders[t].second;
+    }
+    d_sa.release();
+    d_text.release();
+    ix->stats_.seconds_bwt = now_seconds() - t0;
+
+    ix->finish_from_bwt(d_bwt.get(), stream);
+    return ix;
+}
+
+std::unique_ptr<FmIndex> FmIndex::from_parts(const uint64_t *count, const uint64_t *interleaved_blocks, uint64_t n,
+                                             const uint32_t *sa_samples, const uint64_t *border_keys,
+                                             const uint64_t *border_vals, const uint64_t *sentinel_indices,
+                                             uint64_t n_texts, const IndexConfig &cfg)
+{
+    validate_config(cfg);
+    if (!count || !interleaved_blocks || !sa_samples || !border_keys || !border_vals || !sentinel_indices)
+        fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: null array");
+    if (n_texts == 0 || n < n_texts) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: need at least one text");
+    check_width(n, cfg.index_width);
+    std::unique_ptr<FmIndex> ix(new FmIndex());
+    ix->cfg_ = cfg;
+    ix->n_ = n;
+    ix->n_texts_ = n_texts;
+    GDX_HIP(hipSetDevice(cfg.device_id));
+    hipStream_t stream = hipStreamPerThread;
+    ix->count_host_.assign(count, count + cfg.sigma + 1);
+    ix->sentinels_host_.assign(sentinel_indices, sentinel_indices + n_texts);
+    ix->border_keys_host_.assign(border_keys, border_keys + n_texts);
+    ix->border_vals_host_.assign(border_vals, border_vals + n_texts);
+    if (ix->count_host_[0] != 0 || ix->count_host_[cfg.sigma] != n || ix->sentinels_host_[n_texts - 1] != n - 1)
+        fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: count / sentinel_indices do not describe a text of length n");
+    for (uint64_t t = 1; t < n_texts; t++)
+        if (border_keys[t] <= border_keys[t - 1]) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: border keys must be sorted");
+
+    const int nbits = ilog2_ceil(static_cast<uint64_t>(cfg.sigma));
+    const uint64_t n_words = div_ceil(n + 1, 64) * nbits;
+    DeviceBuffer<uint64_t> d_planes(n_words);
+    GDX_HIP(hipMemcpy(d_planes.get(), interleaved_blocks, n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const uint64_t padded = div_ceil(n + 1, 128) * 128;
+    DeviceBuffer<uint8_t> d_bwt(padded);
+    GDX_HIP(hipMemsetAsync(d_bwt.get(), 0, padded, stream));
+    hipLaunchKernelGGL(decode_reference_planes_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream,
+                       d_planes.get(), nbits, n, d_bwt.get());
+    // the given count must be the prefix sums of the BWT's symbol frequencies
+    DeviceBuffer<unsigned long long> d_hist(256);
+    GDX_HIP(hipMemsetAsync(d_hist.get(), 0, 256 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream, d_bwt.get(), n, d_hist.get());
+    unsigned long long hist[256];
+    GDX_HIP(hipMemcpyAsync(hist, d_hist.get(), sizeof(hist), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    uint64_t sum = 0;
+    for (int c = 0; c < 256; c++) {
+        if (c < cfg.sigma && ix->count_host_[c] != sum) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: count[%d] does not match the bit planes", c);
+        if (c >= cfg.sigma && hist[c]) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: planes hold symbol %d >= sigma", c);
+        sum += hist[c];
+    }
+    d_planes.release();
+    const uint64_t n_samples = div_ceil(n, cfg.sa_rate);
+    ix->sa_samples_.alloc(n_samples);
+    GDX_HIP(hipMemcpy(ix->sa_samples_.get(), sa_samples, n_samples * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ix->finish_from_bwt(d_bwt.get(), stream);
+    return ix;
+}
+
+// =============================================================================================
+// host-pointer query API
+
+namespace {
+
+struct DeviceQueries {
+    DeviceBuffer<uint8_t> qbuf;
+    DeviceBuffer<uint64_t> qoff;
+    DeviceQueries(const uint8_t *h_qbuf, const uint64_t *h_qoff, uint64_t nq, hipStream_t stream)
+    {
+        const uint64_t base = h_qoff[0];
+        const uint64_t bytes = h_qoff[nq] - base;
+        const uint64_t padded = div_ceil(bytes + 1, 8) * 8;  // 8-byte windows may read past the last query
+        qbuf.alloc(padded);
+        GDX_HIP(hipMemsetAsync(qbuf.get() + (padded - 8), 0, 8, stream));
+        if (bytes) GDX_HIP(hipMemcpyAsync(qbuf.get(), h_qbuf + base, bytes, hipMemcpyHostToDevice, stream));
+        qoff.alloc(nq + 1);
+        if (base == 0) {
+            GDX_HIP(hipMemcpyAsync(qoff.get(), h_qoff, (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        } else {
+            std::vector<uint64_t> rel(nq + 1);
+            for (uint64_t i = 0; i <= nq; i++) rel[i] = h_qoff[i] - base;
+            GDX_HIP(hipMemcpy(qoff.get(), rel.data(), (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
+    }
+};
+
+void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq)
+{
+    if (!qoff) fail(GDX_ERR_INVALID_ARGUMENT, "qoff is null");
+    if (nq >= 0xffffffffull) fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 queries in one call");
+    for (uint64_t i = 0; i < nq; i++)
+        if (qoff[i + 1] < qoff[i]) fail(GDX_ERR_INVALID_ARGUMENT, "qoff must be non-decreasing");
+    if (qoff[nq] > qoff[0] && !qbuf) fail(GDX_ERR_INVALID_ARGUMENT, "qbuf is null");
+}
+
+int any_status(const uint8_t *status, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++)
+        if (status[i]) return GDX_ERR_QUERY_STATUS;
+    return GDX_OK;
+}
+
+void download_widened(const uint32_t *d_in, uint64_t *h_out, uint64_t m, hipStream_t stream)
+{
+    if (!h_out || m == 0) return;
+    DeviceBuffer<uint64_t> wide(m);
+    hipLaunchKernelGGL(widen_u32_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_in, wide.get(), m);
+    GDX_HIP(hipMemcpyAsync(h_out, wide.get(), m * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+}
+
+}  // namespace
+
+int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const
+{
+    check_queries(qbuf, qoff, nq);
+    if (nq == 0) return GDX_OK;
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceQueries dq(qbuf, qoff, nq, stream);
+    DeviceBuffer<uint32_t> d_start(nq), d_end(nq), d_count(out_count ? nq : 0);
+    DeviceBuffer<uint8_t> d_status(nq);
+    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), d_count.get(), d_status.get(),
+                  stream);
+    GDX_HIP(hipGetLastError());
+    download_widened(d_start.get(), out_start, nq, stream);
+    download_widened(d_end.get(), out_end, nq, stream);
+    download_widened(d_count.get(), out_count, nq, stream);
+    std::vector<uint8_t> status(nq);
+    GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (out_status) std::memcpy(out_status, status.data(), nq);
+    return any_status(status.data(), nq);
+}
+
+void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
+                            gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc) const
+{
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint64_t> d_off(m + 1);
+    {
+        const size_t tb = hit_offsets_temp_bytes(m);
+        DeviceBuffer<uint8_t> temp(tb ? tb : 1);
+        launch_hit_offsets(d_start, d_end, m, d_off.get(), temp.get(), tb, stream);
+        GDX_HIP(hipStreamSynchronize(stream));
+    }
+    uint64_t total = 0;
+    GDX_HIP(hipMemcpy(&total, d_off.get() + m, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (out_total) *out_total = total;
+    if (out_hit_offsets)
+        GDX_HIP(hipMemcpy(out_hit_offsets, d_off.get(), (m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (total == 0) return;
+    if (!hits || hits_capacity < total) {
+        *rc = GDX_ERR_CAPACITY;
+        return;
+    }
+    DeviceBuffer<gdx_hit_t> d_hits(total);
+    DeviceBuffer<uint8_t> ws(locate_workspace_bytes(total));
+    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream);
+    GDX_HIP(hipGetLastError());
+    GDX_HIP(hipMemcpyAsync(hits, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+}
+
+int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                         gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const
+{
+    check_queries(qbuf, qoff, nq);
+    if (out_total) *out_total = 0;
+    if (nq == 0) {
+        if (out_hit_offsets) out_hit_offsets[0] = 0;
+        return GDX_OK;
+    }
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceQueries dq(qbuf, qoff, nq, stream);
+    DeviceBuffer<uint32_t> d_start(nq), d_end(nq);
+    DeviceBuffer<uint8_t> d_status(nq);
+    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), nullptr, d_status.get(), stream);
+    GDX_HIP(hipGetLastError());
+    std::vector<uint8_t> status(nq);
+    GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (out_status) std::memcpy(out_status, status.data(), nq);
+    int rc = any_status(status.data(), nq);
+    int lrc = GDX_OK;
+    locate_device(d_start.get(), d_end.get(), nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc);
+    return lrc != GDX_OK ? lrc : rc;
+}
+
+namespace {
+
+void upload_narrowed(const uint64_t *h_in, uint32_t *d_out, uint64_t m, uint64_t limit, const char *what,
+                     hipStream_t stream)
+{
+    DeviceBuffer<uint64_t> wide(m);
+    DeviceBuffer<uint32_t> flag(1);
+    GDX_HIP(hipMemcpyAsync(wide.get(), h_in, m * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    GDX_HIP(hipMemsetAsync(flag.get(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(narrow_u64_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, wide.get(), d_out, m,
+                       limit, flag.get());
+    uint32_t f = 0;
+    GDX_HIP(hipMemcpyAsync(&f, flag.get(), sizeof(f), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (f) fail(GDX_ERR_INVALID_ARGUMENT, "%s exceeds the text length", what);
+}
+
+}  // namespace
+
+int FmIndex::cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
+                                      uint8_t *out_status) const
+{
+    if (m == 0) return GDX_OK;
+    if (!start || !end || !io_symbols) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint32_t> d_start(m), d_end(m);
+    DeviceBuffer<uint8_t> d_sym(m), d_status(m);
+    upload_narrowed(start, d_start.get(), m, n_, "cursor start", stream);
+    upload_narrowed(end, d_end.get(), m, n_, "cursor end", stream);
+    GDX_HIP(hipMemcpyAsync(d_sym.get(), io_symbols, m, hipMemcpyHostToDevice, stream));
+    launch_extend_front(view_, d_start.get(), d_end.get(), d_sym.get(), m, d_status.get(), stream);
+    GDX_HIP(hipGetLastError());
+    download_widened(d_start.get(), start, m, stream);
+    download_widened(d_end.get(), end, m, stream);
+    std::vector<uint8_t> status(m);
+    GDX_HIP(hipMemcpy(status.data(), d_status.get(), m, hipMemcpyDeviceToHost));
+    if (out_status) std::memcpy(out_status, status.data(), m);
+    return any_status(status.data(), m);
+}
+
+int FmIndex::cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets,
+                                gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total) const
+{
+    if (out_total) *out_total = 0;
+    if (m == 0) {
+        if (out_hit_offsets) out_hit_offsets[0] = 0;
+        return GDX_OK;
+    }
+    if (!start || !end) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint64_t i = 0; i < m; i++)
+        if (start[i] > end[i]) fail(GDX_ERR_INVALID_ARGUMENT, "cursor %llu has start > end", (unsigned long long)i);
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint32_t> d_start(m), d_end(m);
+    upload_narrowed(start, d_start.get(), m, n_, "cursor start", stream);
+    upload_narrowed(end, d_end.get(), m, n_, "cursor end", stream);
+    int rc = GDX_OK;
+    locate_device(d_start.get(), d_end.get(), m, out_hit_offsets, hits, hits_capacity, out_total, &rc);
+    return rc;
+}
+
+int FmIndex::rank_many(const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out) const
+{
+    if (m == 0) return GDX_OK;
+    if (!symbols || !idx || !out) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint8_t> d_sym(m);
+    DeviceBuffer<uint32_t> d_idx(m), d_out(m), d_err(1);
+    GDX_HIP(hipMemcpyAsync(d_sym.get(), symbols, m, hipMemcpyHostToDevice, stream));
+    upload_narrowed(idx, d_idx.get(), m, n_, "rank index", stream);  // mod.rs:107-108 idx <= text_len
+    GDX_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(uint32_t), stream));
+    launch_rank_many(view_, d_sym.get(), d_idx.get(), m, d_out.get(), d_err.get(), stream);
+    GDX_HIP(hipGetLastError());
+    uint32_t err = 0;
+    GDX_HIP(hipMemcpyAsync(&err, d_err.get(), sizeof(err), hipMemcpyDeviceToHost, stream));
+    download_widened(d_out.get(), out, m, stream);
+    if (err) fail(GDX_ERR_INVALID_ARGUMENT, "rank: symbol >= alphabet size or idx > text_len (mod.rs:107-108)");
+    return GDX_OK;
+}
+
+int FmIndex::symbol_at_many(const uint64_t *idx, uint64_t m, uint8_t *out) const
+{
+    if (m == 0) return GDX_OK;
+    if (!idx || !out) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_ == 0) fail(GDX_ERR_INVALID_ARGUMENT, "symbol_at: idx >= text_len (condensed.rs:344)");
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint32_t> d_idx(m), d_err(1);
+    DeviceBuffer<uint8_t> d_out(m);
+    upload_narrowed(idx, d_idx.get(), m, n_ - 1, "symbol_at index", stream);
+    GDX_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(uint32_t), stream));
+    launch_symbol_at_many(view_, d_idx.get(), m, d_out.get(), d_err.get(), stream);
+    GDX_HIP(hipGetLastError());
+    GDX_HIP(hipMemcpyAsync(out, d_out.get(), m, hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    return GDX_OK;
+}
+
+// =============================================================================================
+// exports
+
+void FmIndex::export_count(uint64_t *count) const { std::memcpy(count, count_host_.data(), count_host_.size() * sizeof(uint64_t)); }
+
+void FmIndex::export_bwt(uint8_t *bwt) const
+{
+    if (n_ == 0) return;
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint8_t> d(n_);
+    if (view_.layout == 0)
+        hipLaunchKernelGGL(decode_bwt_kernel<LineTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d.get());
+    else
+        hipLaunchKernelGGL(decode_bwt_kernel<GenericTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d.get());
+    GDX_HIP(hipMemcpyAsync(bwt, d.get(), n_, hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+}
+
+void FmIndex::export_sa_samples(uint32_t *samples) const
+{
+    make_current();
+    GDX_HIP(hipMemcpy(samples, sa_samples_.get(), sa_samples_.bytes(), hipMemcpyDeviceToHost));
+}
+
+void FmIndex::export_borders(uint64_t *keys, uint64_t *vals) const
+{
+    std::memcpy(keys, border_keys_host_.data(), n_texts_ * sizeof(uint64_t));
+    std::memcpy(vals, border_vals_host_.data(), n_texts_ * sizeof(uint64_t));
+}
+
+void FmIndex::export_sentinel_indices(uint64_t *out) const { std::memcpy(out, sentinels_host_.data(), n_texts_ * sizeof(uint64_t)); }
+
+void FmIndex::export_lookup_table(int depth, uint32_t *pairs) const
+{
+    if (depth < 0 || depth > cfg_.lookup_depth) fail(GDX_ERR_INVALID_ARGUMENT, "lookup table depth out of range");
+    make_current();
+    const uint64_t entries = lookup_off_host_[depth + 1] - lookup_off_host_[depth];
+    GDX_HIP(hipMemcpy(pairs, lookup_.get() + lookup_off_host_[depth], entries * sizeof(uint2), hipMemcpyDeviceToHost));
+}
+
+void FmIndex::export_condensed_table(uint64_t *blocks, uint16_t *block_offsets, uint32_t *superblock_offsets) const
+{
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    const int sigma = cfg_.sigma, nbits = view_.nbits;
+    const uint64_t len = n_ + 1, n_blocks = div_ceil(len, 64), n_sb = div_ceil(len, 65536);
+    if (view_.layout == 1) {
+        GDX_HIP(hipMemcpy(blocks, g_planes_.get(), g_planes_.bytes(), hipMemcpyDeviceToHost));
+        GDX_HIP(hipMemcpy(block_offsets, g_block_off_.get(), g_block_off_.bytes(), hipMemcpyDeviceToHost));
+        GDX_HIP(hipMemcpy(superblock_offsets, sb_offsets_.get(), sb_offsets_.bytes(), hipMemcpyDeviceToHost));
+        return;
+    }
+    DeviceBuffer<uint8_t> d_bwt(n_ ? n_ : 1);
+    hipLaunchKernelGGL(decode_bwt_kernel<LineTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt.get());
+    DeviceBuffer<uint64_t> d_planes(n_blocks * nbits);
+    DeviceBuffer<uint16_t> d_bo(n_blocks * sigma);
+    DeviceBuffer<uint32_t> d_sb(n_sb * sigma);
+    hipLaunchKernelGGL(build_planes_kernel, dim3(grid_for_items(n_blocks)), dim3(kBlock), 0, stream, d_bwt.get(), n_,
+                       n_blocks, nbits, d_planes.get());
+    hipLaunchKernelGGL(build_generic_offsets_kernel, dim3(grid_for_items(n_sb * sigma)), dim3(kBlock), 0, stream,
+                       d_bwt.get(), n_, n_blocks, n_sb, sigma, d_bo.get(), d_sb.get());
+    hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(256), 0, stream, d_sb.get(), n_sb,
+                       static_cast<uint32_t>(sigma));
+    GDX_HIP(hipMemcpyAsync(blocks, d_planes.get(), d_planes.bytes(), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(block_offsets, d_bo.get(), d_bo.bytes(), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(superblock_offsets, d_sb.get(), d_sb.bytes(), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+}
+
+}  // namespace gdx

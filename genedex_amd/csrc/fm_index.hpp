@@ -1,0 +1,98 @@
+// fm_index.hpp -- host-side FM index object living in HBM.
+//
+// Mirrors the reference's FmIndex<I, CondensedTextWithRankSupport<I, Block64>> (lib.rs:89-100):
+// same members (alphabet table, count, occurrence table, sampled suffix array, text ids, lookup
+// tables), same query entry points (count_many / cursors_for_many_queries / locate_many, the cursor
+// operations), batched by construction.  The C ABI in include/gdx.h is a thin shim over this class.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "build.hpp"
+#include "common.hpp"
+#include "layout.hpp"
+
+namespace gdx {
+
+struct IndexConfig {
+    uint8_t io_to_dense[256];  // alphabet.rs:24-28
+    int sigma = 0;             // num_dense_symbols (incl. sentinel)
+    int n_searchable = 0;      // num_searchable_dense_symbols
+    uint64_t sa_rate = 4;      // config.rs:75 suffix_array_sampling_rate
+    int lookup_depth = 0;      // config.rs:76 lookup_table_depth
+    int index_width = 32;      // 32 = u32, -32 = i32, 64 = i64
+    int device_id = 0;
+};
+
+class FmIndex {
+public:
+    // FmIndexConfig::construct_index (config.rs:63-69).  texts_buf: concatenated IO symbols of all
+    // texts, on the host or already on the device.
+    static std::unique_ptr<FmIndex> construct_index(const uint8_t *texts_buf, bool texts_on_device,
+                                                    const uint64_t *text_offsets, uint64_t n_texts,
+                                                    const IndexConfig &cfg);
+    // import of the reference's logical arrays (host pointers)
+    static std::unique_ptr<FmIndex> from_parts(const uint64_t *count, const uint64_t *interleaved_blocks, uint64_t n,
+                                               const uint32_t *sa_samples, const uint64_t *border_keys,
+                                               const uint64_t *border_vals, const uint64_t *sentinel_indices,
+                                               uint64_t n_texts, const IndexConfig &cfg);
+    ~FmIndex();
+
+    const IndexView &view() const { return view_; }
+    const IndexConfig &config() const { return cfg_; }
+    const BuildStats &build_stats() const { return stats_; }
+    uint64_t total_text_len() const { return n_; }  // lib.rs:291-294
+    uint64_t num_texts() const { return n_texts_; }  // lib.rs:287-289
+    uint64_t device_bytes() const;
+    void make_current() const;  // hipSetDevice(device_id)
+
+    // ---- host-pointer query API (each call uploads, runs, downloads, synchronises) -------------
+    int cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+                                 uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const;
+    int locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                    gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
+    int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
+                                 uint8_t *out_status) const;
+    int cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets,
+                           gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total) const;
+    int rank_many(const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out) const;
+    int symbol_at_many(const uint64_t *idx, uint64_t m, uint8_t *out) const;
+
+    // ---- exports in the reference's logical layout ------------------------------------------------
+    void export_count(uint64_t *count) const;
+    void export_bwt(uint8_t *bwt) const;
+    void export_sa_samples(uint32_t *samples) const;
+    void export_borders(uint64_t *keys, uint64_t *vals) const;
+    void export_sentinel_indices(uint64_t *out) const;
+    void export_lookup_table(int depth, uint32_t *pairs) const;
+    void export_condensed_table(uint64_t *blocks, uint16_t *block_offsets, uint32_t *superblock_offsets) const;
+
+private:
+    FmIndex() = default;
+    void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
+    void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
+                       gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc) const;
+
+    IndexConfig cfg_;
+    BuildStats stats_;
+    uint64_t n_ = 0, n_texts_ = 0;
+    std::vector<uint64_t> count_host_;      // sigma+1
+    std::vector<uint64_t> sentinels_host_;  // n_texts
+    std::vector<uint64_t> border_keys_host_, border_vals_host_;
+    std::vector<uint64_t> lookup_off_host_;
+
+    DeviceBuffer<u32x4> lines_;
+    DeviceBuffer<uint32_t> sb_offsets_;
+    DeviceBuffer<uint64_t> g_planes_;
+    DeviceBuffer<uint16_t> g_block_off_;
+    DeviceBuffer<uint32_t> count_;
+    DeviceBuffer<uint8_t> io_to_dense_;
+    DeviceBuffer<uint32_t> sa_samples_;
+    DeviceBuffer<uint32_t> border_keys_, border_vals_, sentinels_;
+    DeviceBuffer<uint2> lookup_;
+    IndexView view_{};
+};
+
+}  // namespace gdx

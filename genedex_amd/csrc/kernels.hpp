@@ -1,0 +1,39 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (defined in the .hip files)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/gdx.h"
+#include "layout.hpp"
+
+namespace gdx {
+
+// ---- search.hip ---------------------------------------------------------------------------
+// Backward search of nq queries (lookup jump + LF loop), one lane per query.
+// Any of out_start/out_end/out_count/out_status may be null.
+void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
+                   uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
+                   hipStream_t stream, unsigned long long *d_step_stats = nullptr);
+void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
+                         uint64_t m, uint8_t *d_out_status, hipStream_t stream);
+// d_error (u32, pre-zeroed) is set to 1 when an argument is out of range
+void launch_rank_many(const IndexView &ix, const uint8_t *d_symbols, const uint32_t *d_idx, uint64_t m,
+                      uint32_t *d_out, uint32_t *d_error, hipStream_t stream);
+void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t m, uint8_t *d_out,
+                           uint32_t *d_error, hipStream_t stream);
+// fills lookup table `depth` (entries k^depth) of ix.lookup; d_lookup is the writable alias of ix.lookup
+void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream);
+
+// ---- locate.hip ---------------------------------------------------------------------------
+size_t hit_offsets_temp_bytes(uint64_t m);
+void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *d_hit_offsets,
+                        void *d_temp, size_t temp_bytes, hipStream_t stream);
+size_t locate_workspace_bytes(uint64_t total_hits);
+// HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
+void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
+                   const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
+                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr);
+
+}  // namespace gdx

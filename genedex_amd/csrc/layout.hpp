@@ -1,0 +1,219 @@
+// layout.hpp -- device-side view of the FM index and the rank / LF primitives.
+//
+// Data layout in HBM:
+//
+//  * rank lines (sigma <= 8, the DNA case): one 64-byte line per 128 BWT positions.  A line is
+//    four 16-byte chunks; chunk j holds, for positions [32j, 32j+32) of the line, the three
+//    bit planes as 32-bit words (x, y, z = plane 0, 1, 2; bit t <-> position 32j+t) and in w
+//    two u16 block offsets: symbol 2j in the low half, symbol 2j+1 in the high half
+//    (= number of occurrences of that symbol in the enclosing 65536-position superblock before
+//    this line).  So one rank touches exactly one aligned 64-byte line plus one u32 of the
+//    small superblock table (32 B per superblock, L2 resident).
+//    Logical content is the reference's CondensedTextWithRankSupport<I, Block64>
+//    (condensed.rs:24-30) with two 64-bit blocks fused per line.
+//
+//  * generic planes (sigma > 8): the reference's logical layout itself: interleaved 64-bit
+//    plane words, u16 block offsets per 64 positions, u32 superblock offsets.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gdx {
+
+// native clang vector: HIP's uint4 is a struct-with-union that defeats SROA and sends the
+// 64-byte line to scratch / LDS
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxLookupDepth = 15;
+constexpr uint32_t kSuperblockShift = 16;  // 65536 positions (condensed.rs:34)
+constexpr uint32_t kLineShift = 7;         // 128 positions per rank line
+constexpr uint32_t kLinesPerSuperblock = 1u << (kSuperblockShift - kLineShift);
+
+struct IndexView {
+    // --- occurrence table ------------------------------------------------------------
+    const u32x4 *lines;           // [n_lines][4]               (layout 0)
+    const uint32_t *sb_offsets;   // [n_superblocks][sb_stride] absolute counts before the superblock
+    const uint64_t *g_planes;     // generic: [n_blocks64][nbits]       (layout 1)
+    const uint16_t *g_block_off;  // generic: [n_blocks64][sigma]
+    uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
+    // --- C array, alphabet -------------------------------------------------------------
+    const uint32_t *count;        // [sigma+1]  (lib.rs:95)
+    const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
+    // --- sampled suffix array ------------------------------------------------------------
+    const uint32_t *sa_samples;   // SA[i] for i % sa_rate == 0
+    const uint32_t *border_keys;  // sorted SA indices whose BWT symbol is the sentinel
+    const uint32_t *border_vals;  // SA value there (= start of a text)
+    const uint32_t *sentinels;    // sentinel_indices (text_id_search_tree.rs:8)
+    // --- lookup tables -------------------------------------------------------------------
+    const uint2 *lookup;          // all depths 0..depth concatenated; table t starts at lookup_off[t]
+    uint32_t lookup_off[kMaxLookupDepth + 2];
+    // --- scalars ---------------------------------------------------------------------------
+    uint32_t n;                   // total text length incl. sentinels
+    uint32_t n_texts;
+    uint32_t sa_rate;
+    uint32_t sa_rate_pow2_mask;   // sa_rate-1 if sa_rate is a power of two, else 0xffffffff
+    uint32_t sa_rate_shift;
+    int32_t sigma;
+    int32_t nbits;
+    int32_t n_searchable;
+    int32_t depth;
+    int32_t layout;
+};
+
+// ---------------------------------------------------------------------------------------
+// rank lines (layout 0)
+
+struct RankLine {
+    u32x4 c0, c1, c2, c3;
+};
+
+__device__ __forceinline__ RankLine load_line(const IndexView &ix, uint32_t idx)
+{
+    const u32x4 *p = ix.lines + (static_cast<uint64_t>(idx >> kLineShift) << 2);
+    RankLine l;
+    l.c0 = p[0];
+    l.c1 = p[1];
+    l.c2 = p[2];
+    l.c3 = p[3];
+    return l;
+}
+
+// matches of the symbol among the first `bits` (may be <= 0 or >= 32) positions of one chunk
+__device__ __forceinline__ uint32_t chunk_popcount(const u32x4 c, uint32_t n0, uint32_t n1, uint32_t n2,
+                                                   int32_t bits)
+{
+    // block.rs:152-178 negate / set_to_self_and / count_ones_before, on 32 positions
+    const uint32_t m = (c.x ^ n0) & (c.y ^ n1) & (c.z ^ n2);
+    const uint32_t mask = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+    return __popc(m & mask);
+}
+
+// occurrences of `symbol` among the first `within` (0..127) positions of the line
+__device__ __forceinline__ uint32_t line_popcount(const RankLine &l, uint32_t symbol, uint32_t within)
+{
+    const uint32_t n0 = (symbol & 1u) ? 0u : 0xffffffffu;
+    const uint32_t n1 = (symbol & 2u) ? 0u : 0xffffffffu;
+    const uint32_t n2 = (symbol & 4u) ? 0u : 0xffffffffu;
+    const int32_t w = static_cast<int32_t>(within);
+    return chunk_popcount(l.c0, n0, n1, n2, w) + chunk_popcount(l.c1, n0, n1, n2, w - 32) +
+           chunk_popcount(l.c2, n0, n1, n2, w - 64) + chunk_popcount(l.c3, n0, n1, n2, w - 96);
+}
+
+__device__ __forceinline__ uint32_t line_block_offset(const RankLine &l, uint32_t symbol)
+{
+    const uint32_t j = symbol >> 1;
+    uint32_t w = l.c0.w;
+    w = (j == 1) ? l.c1.w : w;
+    w = (j == 2) ? l.c2.w : w;
+    w = (j == 3) ? l.c3.w : w;
+    return (symbol & 1u) ? (w >> 16) : (w & 0xffffu);
+}
+
+__device__ __forceinline__ uint32_t line_symbol_at(const RankLine &l, uint32_t within)
+{
+    const uint32_t j = within >> 5, t = within & 31u;
+    uint32_t x = l.c0.x, y = l.c0.y, z = l.c0.z;
+    x = (j == 1) ? l.c1.x : x;
+    y = (j == 1) ? l.c1.y : y;
+    z = (j == 1) ? l.c1.z : z;
+    x = (j == 2) ? l.c2.x : x;
+    y = (j == 2) ? l.c2.y : y;
+    z = (j == 2) ? l.c2.z : z;
+    x = (j == 3) ? l.c3.x : x;
+    y = (j == 3) ? l.c3.y : y;
+    z = (j == 3) ? l.c3.z : z;
+    return ((x >> t) & 1u) | (((y >> t) & 1u) << 1) | (((z >> t) & 1u) << 2);
+}
+
+struct LineTable {
+    // rank(symbol, idx) = #symbol in bwt[0..idx)   (condensed.rs:291-341)
+    static __device__ __forceinline__ uint32_t rank(const IndexView &ix, uint32_t symbol, uint32_t idx)
+    {
+        const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * 8u + symbol];
+        const RankLine l = load_line(ix, idx);
+        return sb + line_block_offset(l, symbol) + line_popcount(l, symbol, idx & 127u);
+    }
+    // both borders of one interval; loads are issued before any use
+    static __device__ __forceinline__ void rank2(const IndexView &ix, uint32_t symbol, uint32_t lo, uint32_t hi,
+                                                 uint32_t &rlo, uint32_t &rhi)
+    {
+        const uint32_t sb_lo = ix.sb_offsets[(lo >> kSuperblockShift) * 8u + symbol];
+        const uint32_t sb_hi = ix.sb_offsets[(hi >> kSuperblockShift) * 8u + symbol];
+        const RankLine l_lo = load_line(ix, lo);
+        const RankLine l_hi = load_line(ix, hi);
+        rlo = sb_lo + line_block_offset(l_lo, symbol) + line_popcount(l_lo, symbol, lo & 127u);
+        rhi = sb_hi + line_block_offset(l_hi, symbol) + line_popcount(l_hi, symbol, hi & 127u);
+    }
+    static __device__ __forceinline__ uint32_t symbol_at(const IndexView &ix, uint32_t idx)
+    {
+        return line_symbol_at(load_line(ix, idx), idx & 127u);
+    }
+    // symbol_at(idx) and, unless it is the sentinel, rank(symbol, idx) from the same line
+    static __device__ __forceinline__ uint32_t symbol_and_rank(const IndexView &ix, uint32_t idx, uint32_t &rank_out)
+    {
+        const RankLine l = load_line(ix, idx);
+        const uint32_t c = line_symbol_at(l, idx & 127u);
+        const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * 8u + c];
+        rank_out = sb + line_block_offset(l, c) + line_popcount(l, c, idx & 127u);
+        return c;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// generic planes (layout 1): the reference's own three arrays
+
+struct GenericTable {
+    static __device__ __forceinline__ uint32_t rank(const IndexView &ix, uint32_t symbol, uint32_t idx)
+    {
+        const uint32_t blk = idx >> 6;
+        const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * ix.sb_stride + symbol];
+        const uint32_t bo = ix.g_block_off[static_cast<uint64_t>(blk) * ix.sigma + symbol];
+        const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(blk) * ix.nbits;
+        uint64_t acc = ~0ull;
+        uint32_t s = symbol;
+        for (int b = 0; b < ix.nbits; b++) {
+            uint64_t p = planes[b];
+            acc &= (s & 1u) ? p : ~p;
+            s >>= 1;
+        }
+        const uint32_t t = idx & 63u;
+        const uint64_t mask = t ? (~0ull >> (64u - t)) : 0ull;
+        return sb + bo + __popcll(acc & mask);
+    }
+    static __device__ __forceinline__ void rank2(const IndexView &ix, uint32_t symbol, uint32_t lo, uint32_t hi,
+                                                 uint32_t &rlo, uint32_t &rhi)
+    {
+        rlo = rank(ix, symbol, lo);
+        rhi = rank(ix, symbol, hi);
+    }
+    static __device__ __forceinline__ uint32_t symbol_at(const IndexView &ix, uint32_t idx)
+    {
+        const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(idx >> 6) * ix.nbits;
+        const uint32_t t = idx & 63u;
+        uint32_t c = 0;
+        for (int b = 0; b < ix.nbits; b++) c |= static_cast<uint32_t>((planes[b] >> t) & 1ull) << b;
+        return c;
+    }
+    static __device__ __forceinline__ uint32_t symbol_and_rank(const IndexView &ix, uint32_t idx, uint32_t &rank_out)
+    {
+        const uint32_t c = symbol_at(ix, idx);
+        rank_out = rank(ix, c, idx);
+        return c;
+    }
+};
+
+// lower_bound over a small sorted u32 array (text ids, border keys)
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace gdx

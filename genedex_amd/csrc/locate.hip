@@ -1,0 +1,170 @@
+// locate.hip -- locate walk over the sampled suffix array (sampled_suffix_array.rs:110-138)
+// followed by the text-id resolution (text_id_search_tree.rs:35-64), one lane per hit.
+//
+// Two phases (hits per query are unbounded, e.g. poly-A): (1) exclusive scan of the interval
+// sizes -> hit_offsets, (2) every hit slot learns its query through a scattered head marker +
+// inclusive max-scan, then walks independently, so load balance does not depend on how the hits
+// are distributed over the queries.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace gdx {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct IntervalSize {
+    const uint32_t *start;
+    const uint32_t *end;
+    uint64_t m;
+    __host__ __device__ uint64_t operator()(uint64_t q) const
+    {
+        return q < m ? static_cast<uint64_t>(end[q] - start[q]) : 0ull;
+    }
+};
+
+using SizeIterator =
+    rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, IntervalSize, uint64_t>;
+
+__global__ __launch_bounds__(kBlock) void mark_heads_kernel(const uint32_t *__restrict__ start,
+                                                            const uint32_t *__restrict__ end, uint64_t m,
+                                                            const uint64_t *__restrict__ hit_offsets,
+                                                            uint32_t *__restrict__ heads)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < m; q += stride) {
+        if (end[q] != start[q]) heads[hit_offsets[q]] = static_cast<uint32_t>(q) + 1u;
+    }
+}
+
+template <class Table, bool kWide>
+__global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint32_t *__restrict__ start,
+                                                        const uint64_t *__restrict__ hit_offsets,
+                                                        const uint32_t *__restrict__ query_of_hit,
+                                                        uint64_t total, void *__restrict__ hits_out,
+                                                        unsigned long long *__restrict__ step_stats)
+{
+    __shared__ uint32_t s_count[257];
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    __syncthreads();
+
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
+    for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; h < total; h += stride) {
+        const uint32_t q = query_of_hit[h] - 1u;
+        uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);  // SA index of this hit
+        uint32_t steps = 0, pos;
+        for (;;) {
+            // sampled_suffix_array.rs:118 while i % sampling_rate != 0
+            const bool sampled =
+                ix.sa_rate_pow2_mask != 0xffffffffu ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
+            if (sampled) {
+                const uint32_t slot = ix.sa_rate_pow2_mask != 0xffffffffu ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate);
+                pos = ix.sa_samples[slot] + steps;  // :133-136
+                break;
+            }
+            uint32_t r;
+            const uint32_t c = Table::symbol_and_rank(ix, i, r);
+            if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
+                const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, i);
+                pos = ix.border_vals[b] + steps;
+                break;
+            }
+            i = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
+            steps++;
+        }
+        walk_steps += steps;
+        // text_id_search_tree.rs:35-64: smallest t with pos <= sentinel_indices[t]
+        const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
+        const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
+        if (kWide) {
+            gdx_hit_t out;
+            out.text_id = t;
+            out.position = in_text;
+            static_cast<gdx_hit_t *>(hits_out)[h] = out;
+        } else {
+            gdx_hit32_t out;
+            out.text_id = t;
+            out.position = in_text;
+            static_cast<gdx_hit32_t *>(hits_out)[h] = out;
+        }
+    }
+    if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
+}
+
+unsigned grid_for_items(uint64_t items)
+{
+    const uint64_t blocks = (items + kBlock - 1) / kBlock;
+    const uint64_t cap = 256u * 8u;
+    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+size_t max_scan_temp_bytes(uint64_t total)
+{
+    size_t bytes = 0;
+    uint32_t *p = nullptr;
+    (void)rocprim::inclusive_scan(nullptr, bytes, p, p, static_cast<size_t>(total), rocprim::maximum<uint32_t>());
+    return bytes;
+}
+
+}  // namespace
+
+size_t hit_offsets_temp_bytes(uint64_t m)
+{
+    size_t bytes = 0;
+    SizeIterator in(rocprim::counting_iterator<uint64_t>(0), IntervalSize{nullptr, nullptr, m});
+    uint64_t *out = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1),
+                                  rocprim::plus<uint64_t>());
+    return bytes;
+}
+
+void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *d_hit_offsets,
+                        void *d_temp, size_t temp_bytes, hipStream_t stream)
+{
+    SizeIterator in(rocprim::counting_iterator<uint64_t>(0), IntervalSize{d_start, d_end, m});
+    GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
+                                    static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
+}
+
+size_t locate_workspace_bytes(uint64_t total_hits)
+{
+    return align_up(total_hits * sizeof(uint32_t), 256) + align_up(max_scan_temp_bytes(total_hits), 256) + 256;
+}
+
+void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
+                   const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
+                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats)
+{
+    if (total_hits == 0 || m == 0) return;
+    uint32_t *heads = static_cast<uint32_t *>(d_workspace);
+    void *scan_temp = static_cast<char *>(d_workspace) + align_up(total_hits * sizeof(uint32_t), 256);
+    size_t scan_bytes = max_scan_temp_bytes(total_hits);
+
+    GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,
+                       d_hit_offsets, heads);
+    GDX_HIP(rocprim::inclusive_scan(scan_temp, scan_bytes, heads, heads, static_cast<size_t>(total_hits),
+                                    rocprim::maximum<uint32_t>(), stream));
+    const unsigned grid = grid_for_items(total_hits);
+#define GDX_LOCATE(TABLE, WIDE)                                                                              \
+    hipLaunchKernelGGL((locate_kernel<TABLE, WIDE>), dim3(grid), dim3(kBlock), 0, stream, ix, d_start, \
+                       d_hit_offsets, heads, total_hits, d_hits, d_step_stats)
+    if (ix.layout == 0) {
+        if (wide) GDX_LOCATE(LineTable, true);
+        else GDX_LOCATE(LineTable, false);
+    } else {
+        if (wide) GDX_LOCATE(GenericTable, true);
+        else GDX_LOCATE(GenericTable, false);
+    }
+#undef GDX_LOCATE
+}
+
+}  // namespace gdx

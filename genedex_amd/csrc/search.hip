@@ -1,0 +1,255 @@
+// search.hip -- backward search (lookup jump + LF loop), cursor extension and the operator-level
+// rank / symbol_at kernels.  One lane per query: a wavefront advances 64 backward searches in
+// lock-step, the same shape as the reference's 64-wide BatchComputedCursors
+// (batch_computed_cursors.rs:36-73) with the swap-compaction replaced by the exec mask.
+#include "kernels.hpp"
+
+namespace gdx {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// Reads the IO symbols of one query right-to-left through aligned 8-byte windows, so a lane
+// issues one global load per 8 LF steps; the next window is requested one window ahead.
+struct QueryWindow {
+    const uint64_t *words;
+    uint64_t cur;        // window holding byte `pos-1`
+    uint64_t next;       // window below it (prefetched)
+    uint64_t cur_word;   // index of `cur`
+    uint64_t first_word; // lowest word that belongs to this query
+
+    __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin, uint64_t pos)
+    {
+        words = reinterpret_cast<const uint64_t *>(qbuf);
+        first_word = begin >> 3;
+        const bool any = pos > begin;
+        cur_word = any ? ((pos - 1) >> 3) : first_word;
+        cur = any ? words[cur_word] : 0ull;
+        next = (any && cur_word > first_word) ? words[cur_word - 1] : 0ull;
+    }
+    // byte at absolute offset `at` (at must walk downwards)
+    __device__ __forceinline__ uint32_t get(uint64_t at)
+    {
+        const uint64_t w = at >> 3;
+        if (w != cur_word) {
+            cur_word = w;
+            cur = next;
+            next = (w > first_word) ? words[w - 1] : 0ull;
+        }
+        return static_cast<uint32_t>(cur >> ((at & 7u) * 8u)) & 0xffu;
+    }
+};
+
+template <class Table>
+__global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+                                                        const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                        uint32_t *__restrict__ out_start,
+                                                        uint32_t *__restrict__ out_end,
+                                                        uint32_t *__restrict__ out_count,
+                                                        uint8_t *__restrict__ out_status,
+                                                        unsigned long long *__restrict__ step_stats)
+{
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_count[257];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    __syncthreads();
+
+    const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    uint32_t lf_steps = 0;  // only reported through step_stats (bench accounting, null in normal calls)
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < nq; q += stride) {
+        const uint64_t begin = qoff[q], end = qoff[q + 1];
+        const uint64_t len = end - begin;
+        // lib.rs:277-281 split_query_for_lookup
+        const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                 : static_cast<uint32_t>(ix.depth);
+        uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
+        if (t > 0) {
+            // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
+            uint32_t idx = 0, factor = 1;
+            bool unsearchable = false;
+            for (uint32_t j = 0; j < t; j++) {
+                const uint32_t d = s_dense[qbuf[end - t + j]];
+                if (d == 0) status = GDX_Q_INVALID_SYMBOL;
+                unsearchable |= (d - 1u >= k);
+                idx += (d - 1u) * factor;
+                factor *= k;
+            }
+            if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
+            if (status == GDX_Q_OK) {
+                const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                lo = v.x;
+                hi = v.y;
+            } else {
+                lo = hi = 0;
+            }
+        }
+        uint64_t pos = end - t;  // symbols [begin, pos) are still to be consumed, right to left
+        QueryWindow win;
+        win.init(qbuf, begin, pos);
+        // lib.rs:226-232 / batch_computed_cursors.rs:62-70: stop at the empty interval
+        while (pos > begin && lo != hi) {
+            const uint32_t c = s_dense[win.get(pos - 1)];
+            if (c == 0) {  // alphabet.rs:195-198
+                status = GDX_Q_INVALID_SYMBOL;
+                lo = hi = 0;
+                break;
+            }
+            uint32_t rlo, rhi;
+            Table::rank2(ix, c, lo, hi, rlo, rhi);
+            const uint32_t cc = s_count[c];  // lib.rs:273-275
+            lo = cc + rlo;
+            hi = cc + rhi;
+            pos--;
+            lf_steps++;
+        }
+        if (out_start) out_start[q] = lo;
+        if (out_end) out_end[q] = hi;
+        if (out_count) out_count[q] = hi - lo;
+        if (out_status) out_status[q] = static_cast<uint8_t>(status);
+    }
+    if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+}
+
+template <class Table>
+__global__ __launch_bounds__(kBlock) void extend_front_kernel(IndexView ix, uint32_t *__restrict__ start,
+                                                              uint32_t *__restrict__ end,
+                                                              const uint8_t *__restrict__ io_symbols, uint64_t m,
+                                                              uint8_t *__restrict__ out_status)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        uint32_t lo = start[i], hi = end[i];
+        const uint32_t c = ix.io_to_dense[io_symbols[i]];  // cursor.rs:34-38: translated before anything else
+        uint32_t status = GDX_Q_OK;
+        if (c == 0) {
+            status = GDX_Q_INVALID_SYMBOL;
+        } else if (lo != hi) {  // cursor.rs:41-48
+            uint32_t rlo, rhi;
+            Table::rank2(ix, c, lo, hi, rlo, rhi);
+            const uint32_t cc = ix.count[c];
+            start[i] = cc + rlo;
+            end[i] = cc + rhi;
+        }
+        if (out_status) out_status[i] = static_cast<uint8_t>(status);
+    }
+}
+
+template <class Table>
+__global__ __launch_bounds__(kBlock) void rank_many_kernel(IndexView ix, const uint8_t *__restrict__ symbols,
+                                                           const uint32_t *__restrict__ idx, uint64_t m,
+                                                           uint32_t *__restrict__ out, uint32_t *error)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        const uint32_t c = symbols[i], p = idx[i];
+        if (c >= static_cast<uint32_t>(ix.sigma) || p > ix.n) {  // mod.rs:107-108
+            *error = 1;
+            out[i] = 0;
+            continue;
+        }
+        out[i] = Table::rank(ix, c, p);
+    }
+}
+
+template <class Table>
+__global__ __launch_bounds__(kBlock) void symbol_at_kernel(IndexView ix, const uint32_t *__restrict__ idx,
+                                                           uint64_t m, uint8_t *__restrict__ out, uint32_t *error)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        const uint32_t p = idx[i];
+        if (p >= ix.n) {  // condensed.rs:344
+            *error = 1;
+            out[i] = 0;
+            continue;
+        }
+        out[i] = static_cast<uint8_t>(Table::symbol_at(ix, p));
+    }
+}
+
+// lookup_table.rs:163-258: table[depth][idx] = interval of the depth-mer whose j-th symbol is digit j
+// of idx in base k (+1 to skip the sentinel).  Plain backward search with freeze-on-empty gives the
+// same (start, end) as the reference's recursive fill through the smaller tables.
+template <class Table>
+__global__ __launch_bounds__(kBlock) void fill_lookup_kernel(IndexView ix, uint2 *__restrict__ lookup, int depth,
+                                                             uint32_t entries)
+{
+    const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) {
+        uint32_t pw = 1;
+        for (int j = 1; j < depth; j++) pw *= k;  // k^(depth-1)
+        uint32_t lo = 0, hi = ix.n;
+        for (int j = depth - 1; j >= 0 && lo != hi; j--) {
+            const uint32_t c = (static_cast<uint32_t>(e) / pw) % k + 1u;
+            uint32_t rlo, rhi;
+            Table::rank2(ix, c, lo, hi, rlo, rhi);
+            const uint32_t cc = ix.count[c];
+            lo = cc + rlo;
+            hi = cc + rhi;
+            pw /= k;
+        }
+        lookup[ix.lookup_off[depth] + e] = make_uint2(lo, hi);
+    }
+}
+
+}  // namespace
+
+#define GDX_DISPATCH_TABLE(ix, KERNEL, grid, stream, ...)                                        \
+    do {                                                                                         \
+        if ((ix).layout == 0)                                                                    \
+            hipLaunchKernelGGL(KERNEL<LineTable>, dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); \
+        else                                                                                     \
+            hipLaunchKernelGGL(KERNEL<GenericTable>, dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); \
+    } while (0)
+
+static unsigned grid_for_items(uint64_t items)
+{
+    const uint64_t blocks = (items + kBlock - 1) / kBlock;
+    const uint64_t cap = 256u * 8u;  // 8 blocks of 256 threads per CU
+    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
+                   uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
+                   hipStream_t stream, unsigned long long *d_step_stats)
+{
+    if (nq == 0) return;
+    GDX_DISPATCH_TABLE(ix, search_kernel, grid_for_items(nq), stream, ix, d_qbuf, d_qoff, nq, d_out_start,
+                       d_out_end, d_out_count, d_out_status, d_step_stats);
+}
+
+void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
+                         uint64_t m, uint8_t *d_out_status, hipStream_t stream)
+{
+    if (m == 0) return;
+    GDX_DISPATCH_TABLE(ix, extend_front_kernel, grid_for_items(m), stream, ix, d_start, d_end, d_io_symbols, m,
+                       d_out_status);
+}
+
+void launch_rank_many(const IndexView &ix, const uint8_t *d_symbols, const uint32_t *d_idx, uint64_t m,
+                      uint32_t *d_out, uint32_t *d_error, hipStream_t stream)
+{
+    if (m == 0) return;
+    GDX_DISPATCH_TABLE(ix, rank_many_kernel, grid_for_items(m), stream, ix, d_symbols, d_idx, m, d_out, d_error);
+}
+
+void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t m, uint8_t *d_out,
+                           uint32_t *d_error, hipStream_t stream)
+{
+    if (m == 0) return;
+    GDX_DISPATCH_TABLE(ix, symbol_at_kernel, grid_for_items(m), stream, ix, d_idx, m, d_out, d_error);
+}
+
+void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream)
+{
+    uint64_t entries = 1;
+    for (int j = 0; j < depth; j++) entries *= static_cast<uint64_t>(ix.n_searchable);
+    GDX_DISPATCH_TABLE(ix, fill_lookup_kernel, grid_for_items(entries), stream, ix, d_lookup, depth,
+                       static_cast<uint32_t>(entries));
+}
+
+}  // namespace gdx

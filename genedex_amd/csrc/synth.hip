@@ -1,0 +1,220 @@
+// synth.hip -- synthetic DNA texts / query sets generated in HBM, and the two bandwidth
+// micro-benchmarks the roofline fractions are quoted against.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "layout.hpp"
+#include "synth.hpp"
+
+namespace gdx {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// output number i (0-based) of the splitmix64 stream seeded with `seed`
+__host__ __device__ inline uint64_t splitmix_at(uint64_t seed, uint64_t i) { return mix64(seed + (i + 1) * kGolden); }
+
+__host__ __device__ inline uint64_t hash3(uint64_t seed, uint64_t a, uint64_t b)
+{
+    return mix64(splitmix_at(seed, a) ^ (b * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull));
+}
+
+unsigned grid_for_items(uint64_t items, uint64_t cap = 256u * 16u)
+{
+    const uint64_t blocks = (items + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+__global__ __launch_bounds__(kBlock) void synth_text_kernel(uint8_t *__restrict__ out, uint64_t n, uint64_t seed,
+                                                            uint64_t n_threshold)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = splitmix_at(seed, i);
+        const char acgt[4] = {'A', 'C', 'G', 'T'};
+        out[i] = (r >> 32) < n_threshold ? 'N' : acgt[(r >> 8) & 3u];
+    }
+}
+
+struct QueryLength {
+    uint64_t seed, nq;
+    uint32_t len_min, span;
+    __host__ __device__ uint64_t operator()(uint64_t q) const
+    {
+        return q < nq ? len_min + (span ? hash3(seed, q, 0) % (span + 1ull) : 0ull) : 0ull;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void synth_queries_kernel(const uint8_t *__restrict__ io_text,
+                                                               const uint64_t *__restrict__ text_offsets,
+                                                               uint64_t n_texts, uint64_t nq,
+                                                               uint32_t sampled_per_million, uint64_t seed,
+                                                               const uint64_t *__restrict__ qoff,
+                                                               uint8_t *__restrict__ qbuf)
+{
+    const uint64_t io_len = text_offsets[n_texts] - text_offsets[0];
+    const uint64_t base = text_offsets[0];
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < nq; q += stride) {
+        const uint64_t b = qoff[q], len = qoff[q + 1] - b;
+        bool done = false;
+        if (len > 0 && len <= io_len && hash3(seed, q, 1) % 1000000ull < sampled_per_million) {
+            for (uint32_t a = 0; a < 8 && !done; a++) {
+                const uint64_t pos = base + hash3(seed, q, 2 + a) % (io_len - len + 1);
+                // the window must lie inside one text: first offset > pos
+                uint64_t lo = 0, hi = n_texts + 1;
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (text_offsets[mid] <= pos) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo > n_texts || pos + len > text_offsets[lo]) continue;
+                bool clean = true;
+                for (uint64_t j = 0; j < len; j++) {
+                    const uint8_t s = io_text[pos + j];
+                    clean &= (s != 'N' && s != 'n');
+                }
+                if (!clean) continue;
+                for (uint64_t j = 0; j < len; j++) qbuf[b + j] = io_text[pos + j];
+                done = true;
+            }
+        }
+        if (!done) {
+            const char acgt[4] = {'A', 'C', 'G', 'T'};
+            uint64_t r = 0;
+            for (uint64_t j = 0; j < len; j++) {
+                if ((j & 31u) == 0) r = hash3(seed, q, 16 + (j >> 5));
+                qbuf[b + j] = acgt[(r >> (2 * (j & 31u))) & 3u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void stream_copy_kernel(u32x4 *__restrict__ dst, const u32x4 *__restrict__ src,
+                                                             uint64_t n16)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+// mode 0: every lane reads whole random lines; kVecPerLine = line_bytes / 16
+template <int kVecPerLine>
+__global__ __launch_bounds__(kBlock) void gather_lane_kernel(const u32x4 *__restrict__ src, uint64_t n_lines,
+                                                             uint64_t per_thread, uint64_t seed,
+                                                             uint32_t *__restrict__ sink)
+{
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint64_t k = 0; k < per_thread; k += 2) {
+        const uint64_t l0 = hash3(seed, tid, k) % n_lines, l1 = hash3(seed, tid, k + 1) % n_lines;
+        u32x4 v0[kVecPerLine], v1[kVecPerLine];
+#pragma unroll
+        for (int j = 0; j < kVecPerLine; j++) {
+            v0[j] = src[l0 * kVecPerLine + j];
+            v1[j] = src[l1 * kVecPerLine + j];
+        }
+#pragma unroll
+        for (int j = 0; j < kVecPerLine; j++) acc ^= v0[j].x ^ v0[j].w ^ v1[j].y ^ v1[j].z;
+    }
+    if (acc == 0x12345u) *sink = acc;  // keeps the loads alive
+}
+
+// mode 1: kVecPerLine adjacent lanes read one line, 16 bytes each
+template <int kVecPerLine>
+__global__ __launch_bounds__(kBlock) void gather_group_kernel(const u32x4 *__restrict__ src, uint64_t n_lines,
+                                                              uint64_t per_group, uint64_t seed,
+                                                              uint32_t *__restrict__ sink)
+{
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t group = tid / kVecPerLine, sub = tid % kVecPerLine;
+    uint32_t acc = 0;
+    for (uint64_t k = 0; k < per_group; k += 2) {
+        const uint64_t l0 = hash3(seed, group, k) % n_lines, l1 = hash3(seed, group, k + 1) % n_lines;
+        const u32x4 v0 = src[l0 * kVecPerLine + sub];
+        const u32x4 v1 = src[l1 * kVecPerLine + sub];
+        acc ^= v0.x ^ v0.w ^ v1.y ^ v1.z;
+    }
+    if (acc == 0x12345u) *sink = acc;
+}
+
+}  // namespace
+
+void launch_synth_text(uint8_t *d_out, uint64_t n, uint64_t seed, uint32_t n_per_million, hipStream_t stream)
+{
+    if (n == 0) return;
+    const uint64_t threshold = (static_cast<uint64_t>(n_per_million) << 32) / 1000000ull;
+    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream, d_out, n, seed, threshold);
+}
+
+void synth_queries(const uint8_t *d_io_text, const uint64_t *d_text_offsets, uint64_t n_texts, uint64_t nq,
+                   uint32_t len_min, uint32_t len_max, uint32_t sampled_per_million, uint64_t seed, uint64_t *d_qoff,
+                   uint8_t *d_qbuf, uint64_t qbuf_capacity, uint64_t *out_total_bytes, hipStream_t stream)
+{
+    if (len_max < len_min) fail(GDX_ERR_INVALID_ARGUMENT, "len_max < len_min");
+    using LenIt = rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, QueryLength, uint64_t>;
+    LenIt in(rocprim::counting_iterator<uint64_t>(0), QueryLength{seed, nq, len_min, len_max - len_min});
+    size_t bytes = 0;
+    GDX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, d_qoff, uint64_t(0), static_cast<size_t>(nq + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    DeviceBuffer<uint8_t> temp(bytes ? bytes : 1);
+    GDX_HIP(rocprim::exclusive_scan(temp.get(), bytes, in, d_qoff, uint64_t(0), static_cast<size_t>(nq + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    uint64_t total = 0;
+    GDX_HIP(hipMemcpyAsync(&total, d_qoff + nq, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (out_total_bytes) *out_total_bytes = total;
+    if (total > qbuf_capacity)
+        fail(GDX_ERR_CAPACITY, "query buffer too small: need %llu bytes", static_cast<unsigned long long>(total));
+    if (nq == 0) return;
+    hipLaunchKernelGGL(synth_queries_kernel, dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, d_io_text,
+                       d_text_offsets, n_texts, nq, sampled_per_million, seed, d_qoff, d_qbuf);
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+}
+
+void launch_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, hipStream_t stream)
+{
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256u * 8u), dim3(kBlock), 0, stream, static_cast<u32x4 *>(d_dst),
+                       static_cast<const u32x4 *>(d_src), n16);
+}
+
+void launch_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
+                          uint64_t seed, uint32_t mode, uint32_t *d_sink, hipStream_t stream)
+{
+    if (line_bytes != 64 && line_bytes != 128) fail(GDX_ERR_INVALID_ARGUMENT, "line_bytes must be 64 or 128");
+    if (n_lines == 0 || n_accesses == 0) return;
+    const unsigned grid = 256u * 8u;
+    const uint64_t threads = static_cast<uint64_t>(grid) * kBlock;
+    const u32x4 *src = static_cast<const u32x4 *>(d_src);
+    if (mode == 0) {
+        uint64_t per_thread = div_ceil(n_accesses, threads);
+        per_thread += per_thread & 1u;
+        if (line_bytes == 64)
+            hipLaunchKernelGGL(gather_lane_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_thread, seed, d_sink);
+        else
+            hipLaunchKernelGGL(gather_lane_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_thread, seed, d_sink);
+    } else {
+        const uint64_t groups = threads / (line_bytes / 16);
+        uint64_t per_group = div_ceil(n_accesses, groups);
+        per_group += per_group & 1u;
+        if (line_bytes == 64)
+            hipLaunchKernelGGL(gather_group_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_group, seed, d_sink);
+        else
+            hipLaunchKernelGGL(gather_group_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_group, seed, d_sink);
+    }
+}
+
+}  // namespace gdx

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's public API for the query path.
+
+Names, argument meaning and error behaviour follow feldroop/genedex v0.2.2:
+``FmIndexConfig`` (src/config.rs:17-70), ``FmIndex`` (src/lib.rs:117-327), ``Cursor``
+(src/cursor.rs:16-73), ``Hit`` (src/lib.rs:331-335).  Every query runs in the HIP kernels of
+libgdx.so; a panic of the reference becomes a Python exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import GdxError, u8p, u16p, u32p, u64p
+from .alphabet import Alphabet
+
+
+class Hit(NamedTuple):
+    """src/lib.rs:331-335"""
+    text_id: int
+    position: int
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def pack_queries(queries):
+    """list of bytes-like -> (qbuf u8[...], qoff u64[nq+1])"""
+    queries = [bytes(q) for q in queries]
+    lens = np.fromiter((len(q) for q in queries), dtype=np.uint64, count=len(queries))
+    qoff = np.zeros(len(queries) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=qoff[1:])
+    joined = b"".join(queries)
+    qbuf = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(1, dtype=np.uint8)
+    return qbuf, qoff
+
+
+_WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
+
+
+class FmIndexConfig:
+    """Builder for the index (src/config.rs:17-82).  `index_storage` is the reference's generic `I`."""
+
+    def __init__(self, index_storage: str = "i32"):
+        if index_storage not in _WIDTHS:
+            raise ValueError("index_storage must be one of 'i32', 'u32', 'i64'")
+        self.index_storage = index_storage
+        self._sa_rate = 4    # config.rs:75
+        self._depth = 0      # config.rs:76
+        self._device = 0
+
+    def suffix_array_sampling_rate(self, rate: int) -> "FmIndexConfig":
+        assert rate > 0  # config.rs:28
+        self._sa_rate = int(rate)
+        return self
+
+    def lookup_table_depth(self, depth: int) -> "FmIndexConfig":
+        self._depth = int(depth)
+        return self
+
+    def construction_performance_priority(self, _priority) -> "FmIndexConfig":
+        # config.rs:53-61: selects CPU construction sub-algorithms; the built index is identical, so the
+        # GPU builder has nothing to choose.
+        return self
+
+    def device(self, device_id: int) -> "FmIndexConfig":
+        self._device = int(device_id)
+        return self
+
+    def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":
+        """src/config.rs:63-69"""
+        texts = [bytes(t) for t in texts]
+        tbuf, toff = pack_queries(texts)
+        lib = _lib.load()
+        handle = C.c_void_p()
+        tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
+        st = lib.gdx_index_build(_p(tbuf, u8p), _p(toff, u64p), len(texts), _p(tab, u8p),
+                                 alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
+                                 self._sa_rate, self._depth, _WIDTHS[self.index_storage], self._device,
+                                 C.byref(handle))
+        _lib.check(st)
+        return FmIndex(handle, alphabet)
+
+
+class FmIndex:
+    """src/lib.rs:89-100.  Owns a handle to the index in HBM."""
+
+    def __init__(self, handle, alphabet: Alphabet):
+        self._h = handle
+        self._lib = _lib.load()
+        self._alphabet = alphabet
+        info = _lib.IndexInfo()
+        _lib.check(self._lib.gdx_index_info(self._h, C.byref(info)))
+        self.info = info
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.gdx_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def from_parts(cls, count, interleaved_blocks, n, sa_samples, sa_rate, border_keys, border_vals,
+                   sentinel_indices, alphabet: Alphabet, lookup_depth=0, index_storage="u32", device=0):
+        """Import of the reference's logical arrays (include/gdx.h gdx_index_from_parts)."""
+        lib = _lib.load()
+        count = np.ascontiguousarray(count, dtype=np.uint64)
+        blocks = np.ascontiguousarray(interleaved_blocks, dtype=np.uint64)
+        sa_samples = np.ascontiguousarray(sa_samples, dtype=np.uint32)
+        bk = np.ascontiguousarray(border_keys, dtype=np.uint64)
+        bv = np.ascontiguousarray(border_vals, dtype=np.uint64)
+        si = np.ascontiguousarray(sentinel_indices, dtype=np.uint64)
+        tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
+        handle = C.c_void_p()
+        st = lib.gdx_index_from_parts(_p(count, u64p), _p(blocks, u64p), int(n), _p(sa_samples, u32p), int(sa_rate),
+                                      _p(bk, u64p), _p(bv, u64p), _p(si, u64p), si.size, _p(tab, u8p),
+                                      alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
+                                      int(lookup_depth), _WIDTHS[index_storage], int(device), C.byref(handle))
+        _lib.check(st)
+        return cls(handle, alphabet)
+
+    # ---- lib.rs:283-294 ----------------------------------------------------------------------
+    def alphabet(self) -> Alphabet:
+        return self._alphabet
+
+    def num_texts(self) -> int:
+        return int(self.info.num_texts)
+
+    def total_text_len(self) -> int:
+        return int(self.info.total_text_len)
+
+    # ---- raw (numpy) entry points -------------------------------------------------------------
+    def cursors_raw(self, qbuf, qoff, strict=True):
+        """-> (start u64[nq], end u64[nq], status u8[nq])"""
+        nq = qoff.size - 1
+        s = np.zeros(nq, dtype=np.uint64)
+        e = np.zeros(nq, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        st = self._lib.gdx_cursors_for_many_queries(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(s, u64p),
+                                                    _p(e, u64p), _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return s, e, status
+
+    def count_raw(self, qbuf, qoff, strict=True):
+        nq = qoff.size - 1
+        counts = np.zeros(nq, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        st = self._lib.gdx_count_many(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(counts, u64p), _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return counts, status
+
+    def locate_raw(self, qbuf, qoff, strict=True):
+        """-> (hit_offsets u64[nq+1], text_ids u64[total], positions u64[total], status)"""
+        nq = qoff.size - 1
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        total = C.c_uint64(0)
+        allow = (_lib.GDX_ERR_CAPACITY,) + (() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        st = self._lib.gdx_locate_many(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(off, u64p), None, 0,
+                                       C.byref(total), _p(status, u8p))
+        _lib.check(st, allow=allow)
+        hits = np.zeros((max(total.value, 1), 2), dtype=np.uint64)
+        if total.value:
+            st = self._lib.gdx_locate_many(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(off, u64p),
+                                           hits.ctypes.data_as(C.POINTER(_lib.HitStruct)), total.value,
+                                           C.byref(total), _p(status, u8p))
+            _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        hits = hits[: total.value]
+        return off, hits[:, 0].copy(), hits[:, 1].copy(), status
+
+    def locate_intervals_raw(self, starts, ends):
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        m = starts.size
+        off = np.zeros(m + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        st = self._lib.gdx_cursor_locate_many(self._h, _p(starts, u64p), _p(ends, u64p), m, _p(off, u64p), None, 0,
+                                              C.byref(total))
+        _lib.check(st, allow=(_lib.GDX_ERR_CAPACITY,))
+        hits = np.zeros((max(total.value, 1), 2), dtype=np.uint64)
+        if total.value:
+            st = self._lib.gdx_cursor_locate_many(self._h, _p(starts, u64p), _p(ends, u64p), m, _p(off, u64p),
+                                                  hits.ctypes.data_as(C.POINTER(_lib.HitStruct)), total.value,
+                                                  C.byref(total))
+            _lib.check(st)
+        hits = hits[: total.value]
+        return off, hits[:, 0].copy(), hits[:, 1].copy()
+
+    def extend_front_raw(self, starts, ends, io_symbols, strict=True):
+        s = np.array(starts, dtype=np.uint64)
+        e = np.array(ends, dtype=np.uint64)
+        sym = np.ascontiguousarray(io_symbols, dtype=np.uint8)
+        status = np.zeros(s.size, dtype=np.uint8)
+        st = self._lib.gdx_cursor_extend_front_many(self._h, _p(s, u64p), _p(e, u64p), _p(sym, u8p), s.size,
+                                                    _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return s, e, status
+
+    def rank_many(self, symbols, idx):
+        """TextWithRankSupport::rank (text_with_rank_support/mod.rs:106-110), batched."""
+        sym = np.ascontiguousarray(symbols, dtype=np.uint8)
+        ii = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros(sym.size, dtype=np.uint64)
+        _lib.check(self._lib.gdx_rank_many(self._h, _p(sym, u8p), _p(ii, u64p), sym.size, _p(out, u64p)))
+        return out
+
+    def symbol_at_many(self, idx):
+        ii = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros(ii.size, dtype=np.uint8)
+        _lib.check(self._lib.gdx_symbol_at_many(self._h, _p(ii, u64p), ii.size, _p(out, u8p)))
+        return out
+
+    # ---- lib.rs:147-246 -----------------------------------------------------------------------
+    def count(self, query) -> int:
+        return int(self.count_many([query])[0])
+
+    def count_many(self, queries):
+        qbuf, qoff = pack_queries(queries)
+        return self.count_raw(qbuf, qoff)[0]
+
+    def locate(self, query):
+        return self.locate_many([query])[0]
+
+    def locate_many(self, queries):
+        qbuf, qoff = pack_queries(queries)
+        off, t, p, _ = self.locate_raw(qbuf, qoff)
+        t, p = t.tolist(), p.tolist()
+        return [[Hit(t[h], p[h]) for h in range(int(off[q]), int(off[q + 1]))] for q in range(qoff.size - 1)]
+
+    def cursor_empty(self) -> "Cursor":
+        s = C.c_uint64(0)
+        e = C.c_uint64(0)
+        _lib.check(self._lib.gdx_cursor_empty(self._h, C.byref(s), C.byref(e)))
+        return Cursor(self, s.value, e.value)
+
+    def cursor_for_query(self, query) -> "Cursor":
+        return self.cursors_for_many_queries([query])[0]
+
+    def cursors_for_many_queries(self, queries):
+        qbuf, qoff = pack_queries(queries)
+        s, e, _ = self.cursors_raw(qbuf, qoff)
+        return [Cursor(self, int(a), int(b)) for a, b in zip(s, e)]
+
+    # ---- exports -------------------------------------------------------------------------------
+    def export_count(self):
+        out = np.zeros(self.info.sigma + 1, dtype=np.uint64)
+        _lib.check(self._lib.gdx_index_export_count(self._h, _p(out, u64p)))
+        return out
+
+    def export_bwt(self):
+        out = np.zeros(max(self.total_text_len(), 1), dtype=np.uint8)
+        _lib.check(self._lib.gdx_index_export_bwt(self._h, _p(out, u8p)))
+        return out[: self.total_text_len()]
+
+    def export_sa_samples(self):
+        m = -(-self.total_text_len() // int(self.info.sa_rate))
+        out = np.zeros(max(m, 1), dtype=np.uint32)
+        _lib.check(self._lib.gdx_index_export_sa_samples(self._h, _p(out, u32p)))
+        return out[:m]
+
+    def export_borders(self):
+        k = np.zeros(self.num_texts(), dtype=np.uint64)
+        v = np.zeros(self.num_texts(), dtype=np.uint64)
+        _lib.check(self._lib.gdx_index_export_borders(self._h, _p(k, u64p), _p(v, u64p)))
+        return k, v
+
+    def export_sentinel_indices(self):
+        out = np.zeros(self.num_texts(), dtype=np.uint64)
+        _lib.check(self._lib.gdx_index_export_sentinel_indices(self._h, _p(out, u64p)))
+        return out
+
+    def export_lookup_table(self, depth):
+        entries = int(self.info.n_searchable) ** depth
+        out = np.zeros((entries, 2), dtype=np.uint32)
+        _lib.check(self._lib.gdx_index_export_lookup_table(self._h, depth, _p(out, u32p)))
+        return out
+
+    def export_condensed_table(self):
+        n1 = self.total_text_len() + 1
+        sigma = int(self.info.sigma)
+        nbits = max(1, (sigma - 1).bit_length())
+        blocks = np.zeros(-(-n1 // 64) * nbits, dtype=np.uint64)
+        bo = np.zeros(-(-n1 // 64) * sigma, dtype=np.uint16)
+        sbo = np.zeros(-(-n1 // 65536) * sigma, dtype=np.uint32)
+        _lib.check(self._lib.gdx_index_export_condensed_table(self._h, _p(blocks, u64p), _p(bo, u16p), _p(sbo, u32p)))
+        return blocks, bo, sbo
+
+    def build_stats(self):
+        st = _lib.BuildStats()
+        _lib.check(self._lib.gdx_index_build_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+class Cursor:
+    """src/cursor.rs:16-73: the currently searched query as a half-open suffix-array interval."""
+
+    def __init__(self, index: FmIndex, start: int, end: int):
+        self.index = index
+        self.start = start
+        self.end = end
+
+    def extend_query_front(self, symbol) -> None:
+        """cursor.rs:34-38; raises where the reference panics (symbol not in the alphabet)."""
+        sym = symbol if isinstance(symbol, int) else bytes(symbol)[0]
+        s, e, _ = self.index.extend_front_raw([self.start], [self.end], [sym])
+        self.start, self.end = int(s[0]), int(e[0])
+
+    def count(self) -> int:
+        return self.end - self.start  # cursor.rs:61-63
+
+    def interval(self):
+        return self.start, self.end
+
+    def locate(self):
+        off, t, p = self.index.locate_intervals_raw([self.start], [self.end])
+        return [Hit(int(a), int(b)) for a, b in zip(t, p)]
+
+    def __copy__(self):
+        return Cursor(self.index, self.start, self.end)  # cursor.rs:22-28 Cursor is Copy

@@ -1,0 +1,196 @@
+/*
+ * gdx.h -- C ABI of the MI355X-native FM-index query engine (libgdx.so).
+ *
+ * Drop-in boundary for the query hot path of feldroop/genedex v0.2.2.  The reference is a
+ * pure-Rust crate with no FFI of its own, so each entry point below names the public Rust
+ * item (file:line relative to the reference root) it stands in for; INTEGRATION.md shows
+ * the `extern "C"` block and the safe wrappers a maintainer would add on the Rust side.
+ *
+ * Conventions
+ *  - every function returns a gdx_status (0 = ok); gdx_last_error() gives the text of the
+ *    last failure on the calling thread.  The reference panics instead.
+ *  - handles are immutable after construction: concurrent query calls on one handle are
+ *    allowed (FmIndex is Send+Sync in the reference, all query methods take &self).
+ *  - the caller owns every input and output buffer.  Plain entry points take HOST pointers;
+ *    `_dev` entry points take DEVICE pointers plus a hipStream_t (passed as void*) and
+ *    enqueue work without synchronising.
+ *  - counts, positions and SA indices are uint64_t at the host ABI (usize in the reference).
+ *    Inside, and in the `_dev` entry points, they are uint32_t: this build supports
+ *    index storage types i32 and u32 (n <= 2^32-1); i64 is accepted when n fits.
+ *  - a set of queries is one byte buffer `qbuf` plus `qoff[nq+1]` byte offsets
+ *    (query i = qbuf[qoff[i] .. qoff[i+1])), IO symbols (ASCII), any mix of lengths.
+ */
+#ifndef GDX_H
+#define GDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdx_index gdx_index_t;
+
+typedef enum {
+    GDX_OK = 0,
+    GDX_ERR_INVALID_ARGUMENT = 1,    /* reference: assert!/panic on the argument          */
+    GDX_ERR_INVALID_TEXT_SYMBOL = 2, /* alphabet.rs:195-198 while encoding the texts      */
+    GDX_ERR_TEXT_TOO_LONG = 3,       /* construction/mod.rs:34  n <= I::MAX               */
+    GDX_ERR_DEVICE = 4,              /* HIP runtime failure, no GPU, out of device memory */
+    GDX_ERR_CAPACITY = 5,            /* output buffer too small; required size reported   */
+    GDX_ERR_QUERY_STATUS = 6,        /* >= 1 query has a non-zero status (see below); the
+                                        outputs of all other queries are valid            */
+    GDX_ERR_UNSUPPORTED = 7
+} gdx_status;
+
+/* per-query status byte; the reference panics for 1 and silently aliases / panics for 2 */
+typedef enum {
+    GDX_Q_OK = 0,
+    GDX_Q_INVALID_SYMBOL = 1,        /* alphabet.rs:195-198: symbol not in the alphabet, reached
+                                        while the interval was still non-empty              */
+    GDX_Q_UNSEARCHABLE_IN_LOOKUP = 2 /* lookup_table.rs:154-158: a valid but non-searchable
+                                        symbol (e.g. N) inside the lookup-table suffix      */
+} gdx_query_status;
+
+/* lib.rs:331-335 Hit { text_id: usize, position: usize } */
+typedef struct {
+    uint64_t text_id;
+    uint64_t position;
+} gdx_hit_t;
+
+/* device-side hit record (index storage types i32/u32) */
+typedef struct {
+    uint32_t text_id;
+    uint32_t position;
+} gdx_hit32_t;
+
+/* lib.rs:283-294 alphabet(), num_texts(), total_text_len() + config.rs:72-82 knobs */
+typedef struct {
+    uint64_t total_text_len; /* n, includes one sentinel per text */
+    uint64_t num_texts;
+    int32_t sigma;        /* num_dense_symbols, includes the sentinel */
+    int32_t n_searchable; /* num_searchable_dense_symbols             */
+    int32_t lookup_depth;
+    int32_t index_width; /* 32 = u32, -32 = i32, 64 = i64 */
+    uint64_t sa_rate;
+    uint64_t device_bytes; /* HBM held by the handle */
+    int32_t device_id;
+    int32_t table_layout; /* 0 = 64-byte rank lines (sigma <= 8), 1 = generic planes */
+} gdx_index_info_t;
+
+const char *gdx_last_error(void);
+int gdx_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * construction   (FmIndexConfig::construct_index config.rs:63-69 -> FmIndex::new lib.rs:118-142)
+ * texts: concatenated IO symbols of all texts + text_offsets[n_texts+1]; io_to_dense = the
+ * alphabet's 256-entry table (alphabet.rs:24-28, 0 = not in the alphabet).  The index is
+ * built on the GPU `device_id` from scratch (own suffix sorter).                         */
+int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                    const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate,
+                    int lookup_depth, int index_width, int device_id, gdx_index_t **out);
+
+/* same, the concatenated IO text already resides in device memory (text_offsets on host) */
+int gdx_index_build_dev(const void *d_texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                        const uint8_t *io_to_dense, int sigma, int n_searchable,
+                        uint64_t sa_rate, int lookup_depth, int index_width, int device_id,
+                        gdx_index_t **out);
+
+/* Import of an index a Rust host already owns, in the REFERENCE's logical layout
+ * (condensed.rs:24-30 interleaved_blocks / Block64, lib.rs:95 count,
+ * sampled_suffix_array.rs:18-23, text_id_search_tree.rs:8).  Block and superblock offsets
+ * are recomputed on the device from the bit planes; lookup tables are refilled.  */
+int gdx_index_from_parts(const uint64_t *count /*sigma+1*/, const uint64_t *interleaved_blocks,
+                         uint64_t n /*text_len*/, const uint32_t *sa_samples, uint64_t sa_rate,
+                         const uint64_t *border_keys, const uint64_t *border_vals,
+                         const uint64_t *sentinel_indices, uint64_t n_texts,
+                         const uint8_t *io_to_dense, int sigma, int n_searchable,
+                         int lookup_depth, int index_width, int device_id, gdx_index_t **out);
+
+void gdx_index_free(gdx_index_t *ix);
+int gdx_index_info(const gdx_index_t *ix, gdx_index_info_t *out);
+
+/* exports in the reference's logical layout (host buffers), for interchange and parity checks */
+int gdx_index_export_count(const gdx_index_t *ix, uint64_t *count /*sigma+1*/);
+int gdx_index_export_bwt(const gdx_index_t *ix, uint8_t *bwt /*n*/);
+int gdx_index_export_sa_samples(const gdx_index_t *ix, uint32_t *samples /*ceil(n/rate)*/);
+int gdx_index_export_borders(const gdx_index_t *ix, uint64_t *keys, uint64_t *vals /*num_texts*/);
+int gdx_index_export_sentinel_indices(const gdx_index_t *ix, uint64_t *out /*num_texts*/);
+int gdx_index_export_lookup_table(const gdx_index_t *ix, int depth, uint32_t *pairs /*2*k^depth*/);
+/* condensed.rs:24-30: blocks ceil((n+1)/64)*nbits u64, block offsets ceil((n+1)/64)*sigma u16,
+ * superblock offsets ceil((n+1)/65536)*sigma u32 */
+int gdx_index_export_condensed_table(const gdx_index_t *ix, uint64_t *interleaved_blocks,
+                                     uint16_t *interleaved_block_offsets,
+                                     uint32_t *interleaved_superblock_offsets);
+
+/* ---------------------------------------------------------------------------------------
+ * operator level   (TextWithRankSupport, text_with_rank_support/mod.rs:88-133)           */
+/* rank (mod.rs:106-110): out[i] = #symbols[i] in bwt[0..idx[i]).  INVALID_ARGUMENT if any
+ * symbol >= sigma or idx > n (the reference asserts). */
+int gdx_rank_many(const gdx_index_t *ix, const uint8_t *symbols, const uint64_t *idx, uint64_t m,
+                  uint64_t *out);
+/* symbol_at (condensed.rs:343-362); INVALID_ARGUMENT if any idx >= n */
+int gdx_symbol_at_many(const gdx_index_t *ix, const uint64_t *idx, uint64_t m, uint8_t *out);
+
+/* ---------------------------------------------------------------------------------------
+ * queries                                                                                 */
+/* FmIndex::count_many lib.rs:155-161 (order preserving) */
+int gdx_count_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                   uint64_t *out_counts, uint8_t *out_status /*nq or NULL*/);
+/* FmIndex::cursors_for_many_queries lib.rs:241-246 / BatchComputedCursors: the half-open
+ * SA interval per query, bit-identical to the reference also for empty results */
+int gdx_cursors_for_many_queries(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff,
+                                 uint64_t nq, uint64_t *out_start, uint64_t *out_end,
+                                 uint8_t *out_status);
+/* FmIndex::locate_many lib.rs:179-185.  Hits of query i are hits[out_hit_offsets[i] ..
+ * out_hit_offsets[i+1]) in suffix-array order (lib.rs:187-197).  *out_total is always set;
+ * if hits == NULL or hits_capacity < total the call returns GDX_ERR_CAPACITY after filling
+ * out_hit_offsets (sizing call). */
+int gdx_locate_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                    uint64_t *out_hit_offsets /*nq+1*/, gdx_hit_t *hits, uint64_t hits_capacity,
+                    uint64_t *out_total, uint8_t *out_status);
+
+/* ---------------------------------------------------------------------------------------
+ * batched cursor API   (Cursor, cursor.rs:16-73; the reference has only the scalar form,
+ * ROADMAP.md:33 lists the batched one as future work)                                     */
+/* FmIndex::cursor_empty lib.rs:202-210: [0, n) */
+int gdx_cursor_empty(const gdx_index_t *ix, uint64_t *start, uint64_t *end);
+/* Cursor::extend_query_front cursor.rs:34-51 for m independent cursors, in place; a cursor
+ * whose interval is already empty is left untouched */
+int gdx_cursor_extend_front_many(const gdx_index_t *ix, uint64_t *start, uint64_t *end,
+                                 const uint8_t *io_symbols, uint64_t m, uint8_t *out_status);
+/* Cursor::locate cursor.rs:71-73 for m cursors; same output convention as gdx_locate_many */
+int gdx_cursor_locate_many(const gdx_index_t *ix, const uint64_t *start, const uint64_t *end,
+                           uint64_t m, uint64_t *out_hit_offsets, gdx_hit_t *hits,
+                           uint64_t hits_capacity, uint64_t *out_total);
+
+/* ---------------------------------------------------------------------------------------
+ * device-resident entry points: all pointers are DEVICE pointers on the handle's GPU, work
+ * is enqueued on `stream` (hipStream_t) and the call returns without synchronising.
+ * d_qbuf must be 8-byte aligned and its allocation padded to a multiple of 8 bytes.        */
+int gdx_cursors_for_many_queries_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff /*u64*/,
+                                     uint64_t nq, void *d_out_start /*u32*/, void *d_out_end /*u32*/,
+                                     void *d_out_status /*u8 or NULL*/, void *stream);
+int gdx_count_many_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                       void *d_out_counts /*u32*/, void *d_out_status, void *stream);
+int gdx_cursor_extend_front_many_dev(const gdx_index_t *ix, void *d_start /*u32*/, void *d_end /*u32*/,
+                                     const void *d_io_symbols, uint64_t m, void *d_out_status,
+                                     void *stream);
+/* exclusive scan of (end-start) into d_hit_offsets (u64[m+1]); needs no workspace sizing */
+int gdx_hit_offsets_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
+                        void *d_hit_offsets, void *stream);
+/* locate for m intervals whose offsets were produced by gdx_hit_offsets_dev; total =
+ * d_hit_offsets[m] (the caller reads it back to size d_hits and d_workspace:
+ * gdx_locate_workspace_bytes(total)). */
+uint64_t gdx_locate_workspace_bytes(uint64_t total_hits);
+int gdx_locate_intervals_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
+                             const void *d_hit_offsets, uint64_t total_hits, void *d_hits /*gdx_hit32_t*/,
+                             void *d_workspace, void *stream);
+int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx /*u32*/, uint64_t m,
+                      void *d_out /*u32*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

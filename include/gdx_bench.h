@@ -1,0 +1,60 @@
+/*
+ * gdx_bench.h -- measurement helpers exported by libgdx.so next to the query ABI of gdx.h:
+ * synthetic workloads generated directly in HBM, roofline
+ * micro-benchmarks (streaming copy, random line gather) and step counters that give the
+ * algorithmic byte counts of a run.  None of this is part of the
+ * drop-in boundary.
+ */
+#ifndef GDX_BENCH_H
+#define GDX_BENCH_H
+
+#include <stdint.h>
+
+#include "gdx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint64_t sa_initial_order;      /* symbols fixed by the first key sort of the suffix sorter */
+    uint64_t sa_pending_after_sort; /* suffixes still tied after it                             */
+    uint64_t sa_rounds;             /* prefix-doubling rounds that followed                     */
+    double seconds_encode, seconds_sa, seconds_bwt, seconds_table, seconds_lookup;
+} gdx_build_stats_t;
+
+int gdx_index_build_stats(const gdx_index_t *ix, gdx_build_stats_t *out);
+
+/* IO text of n symbols: symbol i depends only on (seed, i): r = splitmix64 output number i of the
+ * stream seeded with `seed`; 'N' if (r >> 32) * 1e6 < n_per_million * 2^32, else "ACGT"[(r >> 8) & 3]. */
+int gdx_synth_text_dev(void *d_out, uint64_t n, uint64_t seed, uint32_t n_per_million, void *stream);
+
+/* nq queries with lengths uniform in [len_min, len_max]; a query is, with probability
+ * sampled_per_million / 1e6, a substring of one text without 'N' (up to 8 draws, else random),
+ * otherwise uniform random over ACGT.  d_text_offsets: u64[n_texts+1] offsets into d_io_text.
+ * Writes d_qoff (u64[nq+1]) and d_qbuf; *out_total_bytes = qoff[nq].  Synchronises the stream. */
+int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uint64_t n_texts, uint64_t nq,
+                          uint32_t len_min, uint32_t len_max, uint32_t sampled_per_million, uint64_t seed,
+                          void *d_qoff, void *d_qbuf, uint64_t qbuf_capacity, uint64_t *out_total_bytes,
+                          void *stream);
+
+/* streaming copy of `bytes` (multiple of 16): the "measured HBM bandwidth" denominator */
+int gdx_bench_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, void *stream);
+/* n_accesses independent reads of random aligned lines of line_bytes (64 or 128) out of n_lines.
+ * mode 0: one lane reads a whole line (the access shape of the lane-per-query rank);
+ * mode 1: line_bytes/16 adjacent lanes read one line, 16 bytes each.  d_sink: u32[1]. */
+int gdx_bench_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
+                            uint64_t seed, uint32_t mode, void *d_sink, void *stream);
+
+/* d_steps (u64[1], pre-zeroed by the caller) += number of LF steps the search of these queries executes */
+int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                              void *d_steps, void *stream);
+/* same call as gdx_locate_intervals_dev; d_steps (u64[1], pre-zeroed) += locate walk steps executed */
+int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
+                              const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
+                              void *d_steps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,322 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/gdx.h) against the CPU oracle, the
+reference's known-answer vectors and naive search.  Bit-exact everywhere (integer work)."""
+import numpy as np
+import pytest
+
+from genedex_amd import alphabet as alph
+from helpers import alphabet_by_name, as_bytes, naive_occurrence_columns, naive_search, random_texts
+from oracle.oracle import OracleIndex, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+WIDTH = {"i32": -32, "u32": 32, "i64": 64}
+
+
+def gpu_index(texts, a, sa_rate=4, depth=0, storage="u32"):
+    from genedex_amd import FmIndexConfig
+
+    return (FmIndexConfig(storage).suffix_array_sampling_rate(sa_rate).lookup_table_depth(depth)
+            .construct_index(texts, a))
+
+
+def cpu_index(texts, a, sa_rate=4, depth=0, storage="u32"):
+    return OracleIndex.build(texts, a.io_to_dense_table, a.num_dense_symbols(), a.num_searchable_dense_symbols(),
+                             sa_rate=sa_rate, lookup_depth=depth, width=WIDTH[storage])
+
+
+def both(texts, a, **kw):
+    return gpu_index(texts, a, **kw), cpu_index(texts, a, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own known-answer tests, through the drop-in API
+
+def test_locate_kats(kat):
+    for case in kat["locate"]:
+        a = alphabet_by_name(case["alphabet"])
+        for w in case["widths"]:
+            storage = {32: "u32", -32: "i32"}[w]
+            ix = gpu_index([as_bytes(t) for t in case["texts"]], a, sa_rate=case["sa_rate"],
+                           depth=case["lookup_depth"], storage=storage)
+            q = as_bytes(case["query"])
+            want = {tuple(h) for h in case["hits"]}
+            assert {tuple(h) for h in ix.locate(q)} == want, case["source"]
+            assert {tuple(h) for h in ix.locate_many([q])[0]} == want, case["source"]
+            assert ix.count(q) == len(want)
+
+
+def test_count_cursor_kats(kat):
+    for case in kat["count"]:
+        a = alphabet_by_name(case["alphabet"])
+        ix = gpu_index([as_bytes(t) for t in case["texts"]], a, sa_rate=case["sa_rate"], depth=case["lookup_depth"],
+                       storage="i32")
+        assert ix.count(as_bytes(case["query"])) == case["count"], case["source"]
+    for case in kat["cursor"]:
+        a = alphabet_by_name(case["alphabet"])
+        ix = gpu_index([as_bytes(t) for t in case["texts"]], a, storage="i32")
+        cur = ix.cursor_for_query(as_bytes(case["query"]))
+        assert cur.count() == case["count"]
+        cur.extend_query_front(as_bytes(case["extend_front"]))
+        assert cur.count() == case["count_after"]
+        assert len(cur.locate()) == case["count_after"]
+    for case in kat["locate_many_runs"]:
+        a = alphabet_by_name(case["alphabet"])
+        ix = gpu_index([as_bytes(t) for t in case["texts"]], a, sa_rate=case["sa_rate"], storage="i32")
+        res = ix.locate_many([as_bytes(q) for q in case["queries"]])
+        assert [len(r) for r in res][2:] == [2, 1]
+
+
+def test_rank_kats(kat):
+    from genedex_amd import FmIndex
+
+    for case in kat["rank"] + kat["rank_vs_naive"]:
+        if "dense_text" in case:
+            text = np.array(case["dense_text"], dtype=np.uint8)
+        else:
+            text = np.full(case["dense_text_repeat"]["times"], case["dense_text_repeat"]["symbol"], dtype=np.uint8)
+        sigma = case["sigma"]
+        # operator-level construct(text, sigma): import the oracle-built planes as a bare table
+        o = OracleIndex.table_only(text, sigma)
+        a = alph.Alphabet.from_io_symbols(bytes(range(1, sigma)), 0)  # any alphabet with sigma dense symbols
+        count = np.zeros(sigma + 1, dtype=np.uint64)
+        count[1:] = np.cumsum(np.bincount(text, minlength=sigma))
+        if text.size == 0 or count[1] == 0:
+            continue  # from_parts needs >= 1 sentinel to describe texts; covered by test_rank_everywhere below
+        n_texts = int(count[1])
+        sent = np.flatnonzero(text == 0)
+        if sent[-1] != text.size - 1:
+            continue
+        samples = np.zeros(-(-text.size // 4), dtype=np.uint32)
+        ix = FmIndex.from_parts(count, o.blocks, text.size, samples, 4, np.arange(n_texts), np.zeros(n_texts), sent,
+                                a)
+        cols = naive_occurrence_columns(text, sigma)
+        step = 1 if text.size < 3000 else 53
+        idx = np.array(sorted(set(range(0, text.size + 1, step)) | {text.size}), dtype=np.uint64)
+        for c in range(sigma):
+            got = ix.rank_many(np.full(idx.size, c, dtype=np.uint8), idx)
+            assert got.tolist() == cols[c, idx.astype(np.int64)].tolist(), (case["source"], c)
+        pos = np.arange(0, text.size, step, dtype=np.uint64)
+        assert ix.symbol_at_many(pos).tolist() == text[pos.astype(np.int64)].tolist()
+
+
+# ------------------------------------------------------------------------------------------------
+# the built index itself equals the oracle's, array by array
+
+@pytest.mark.parametrize("seed", range(8))
+def test_index_arrays_equal_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    a = [alph.ascii_dna(), alph.ascii_dna_with_n(), alph.ascii_dna_iupac(), alph.u8_until(40)][seed % 4]
+    symbols = [b"ACGT", b"ACGTN", b"ACGTNRYKMSWBDHV", bytes(range(41))][seed % 4]
+    texts = random_texts(rng, len_max=[1500, 70000, 3000, 3000][seed % 4], symbols=symbols)
+    rate = int(rng.integers(1, 9))
+    depth = int(rng.integers(0, 4)) if seed % 4 < 3 else 1
+    g, c = both(texts, a, sa_rate=rate, depth=depth)
+    assert g.total_text_len() == c.n and g.num_texts() == c.num_texts
+    assert g.export_count().tolist() == c.count_array.tolist()
+    assert g.export_sentinel_indices().tolist() == c.sentinel_indices.tolist()
+    assert g.export_bwt().tolist() == c.bwt.tolist()
+    assert g.export_sa_samples().tolist() == c.sa_samples.tolist()
+    gk, gv = g.export_borders()
+    assert gk.tolist() == c.border_keys.tolist() and gv.tolist() == c.border_vals.tolist()
+    blocks, bo, sbo = g.export_condensed_table()
+    assert blocks.tolist() == c.blocks.tolist()
+    assert bo.tolist() == c.block_offsets.tolist()
+    assert sbo.tolist() == c.superblock_offsets.tolist()
+    for d in range(depth + 1):
+        assert g.export_lookup_table(d).tolist() == c.lookup_table(d).tolist(), d
+
+
+def test_repetitive_and_degenerate_texts():
+    a = alph.ascii_dna_with_n()
+    cases = [[b""], [b"", b""], [b"A"], [b"A" * 70000], [b"ACGT" * 5000, b"ACGT" * 5000], [b"N" * 300, b"", b"N"],
+             [b"AC" * 129, b"CA" * 64, b""]]
+    for texts in cases:
+        for rate in (1, 3, 4):
+            g, c = both(texts, a, sa_rate=rate, depth=2)
+            assert g.export_bwt().tolist() == c.bwt.tolist(), texts[0][:8]
+            assert g.export_sa_samples().tolist() == c.sa_samples.tolist()
+            qs = [b"", b"A", b"AC", b"CA", b"ACGT", b"N", b"NN", b"ACGTACGTA", b"TTTT"]
+            off, t, p, _ = g.locate_raw(*pack_queries(qs))
+            co, ct, cp = c.locate_many(qs)
+            assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
+# ------------------------------------------------------------------------------------------------
+# operator level
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rank_everywhere(seed):
+    rng = np.random.default_rng(200 + seed)
+    a = [alph.ascii_dna_with_n(), alph.u8_until(26)][seed % 2]
+    texts = random_texts(rng, len_max=[70000, 2000][seed % 2], symbols=[b"ACGTN", bytes(range(27))][seed % 2])
+    g, c = both(texts, a)
+    n, sigma = c.n, c.sigma
+    cols = naive_occurrence_columns(c.bwt, sigma)
+    idx = np.arange(n + 1, dtype=np.uint64)
+    for s in range(sigma):
+        got = g.rank_many(np.full(n + 1, s, dtype=np.uint8), idx)
+        assert np.array_equal(got, cols[s])
+    assert np.array_equal(g.symbol_at_many(np.arange(n, dtype=np.uint64)), c.bwt)
+    from genedex_amd import GdxError
+
+    with pytest.raises(GdxError):  # mod.rs:107-108
+        g.rank_many([sigma], [0])
+    with pytest.raises(GdxError):
+        g.rank_many([0], [n + 1])
+    with pytest.raises(GdxError):  # condensed.rs:344
+        g.symbol_at_many([n])
+
+
+# ------------------------------------------------------------------------------------------------
+# search: intervals bit-identical to the reference's batched path, incl. empty results
+
+def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
+    qs = []
+    nonempty = [t for t in texts if len(t) > 0]
+    for _ in range(n_sampled):
+        if not nonempty:
+            break
+        t = nonempty[int(rng.integers(0, len(nonempty)))]
+        pos = int(rng.integers(0, len(t)))
+        ln = int(rng.integers(0, min(max_len, len(t) - pos) + 1))
+        q = t[pos:pos + ln]
+        if allow_n or b"N" not in q:
+            qs.append(q)
+    for _ in range(n_random):
+        ln = int(rng.integers(0, max_len))
+        qs.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, ln)))
+    order = rng.permutation(len(qs))
+    return [qs[i] for i in order]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_cursors_equal_oracle_batched_path(seed):
+    rng = np.random.default_rng(300 + seed)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=20000, symbols=b"ACGTN" if seed % 2 else b"ACGT")
+    depth = [0, 1, 3, 5, 8][seed % 5]
+    g, c = both(texts, a, depth=depth)
+    qs = mixed_queries(rng, texts, 700, 700, 60)
+    qbuf, qoff = pack_queries(qs)
+    s, e, st = g.cursors_raw(qbuf, qoff)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    assert not st.any()
+    assert s.tolist() == cs.tolist() and e.tolist() == ce.tolist()
+    counts, _ = g.count_raw(qbuf, qoff)
+    assert counts.tolist() == (ce - cs).tolist()
+    # and the counts are right in the first place
+    fold = a.io_to_dense_table
+    for q, cnt in list(zip(qs, counts))[:200]:
+        assert int(cnt) == len(naive_search(texts, q, fold=fold))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_locate_equals_oracle_and_naive(seed):
+    rng = np.random.default_rng(400 + seed)
+    a = [alph.ascii_dna(), alph.ascii_dna_with_n(), alph.ascii_dna_iupac_as_dna_with_n()][seed % 3]
+    texts = random_texts(rng, len_max=1500)
+    rate = int(rng.integers(1, 65))
+    depth = int(rng.integers(0, 6))
+    storage = ["i32", "u32", "i64"][seed % 3]
+    g, c = both(texts, a, sa_rate=rate, depth=depth, storage=storage)
+    qs = mixed_queries(rng, texts, 40, 160, 20) + [b""]
+    off, t, p, st = g.locate_raw(*pack_queries(qs))
+    co, ct, cp = c.locate_many(qs)
+    # same hits in the same (suffix array) order
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    for k, q in enumerate(qs):
+        got = set(zip(t[off[k]:off[k + 1]].tolist(), p[off[k]:off[k + 1]].tolist()))
+        assert got == naive_search(texts, q), q
+    # Python mirror of the reference API
+    hits = g.locate_many(qs[:20])
+    for k in range(20):
+        assert {tuple(h) for h in hits[k]} == naive_search(texts, qs[k])
+        assert {tuple(h) for h in g.locate(qs[k])} == naive_search(texts, qs[k])
+
+
+def test_status_codes_match_the_reference_panics():
+    a = alph.ascii_dna_with_n()
+    texts = [b"ACGTNACGTTTGACA", b"NNACGT"]
+    qs = [b"TNA", b"NAC", b"AXG", b"XGGGGGGG", b"ACGT", b"", b"Z"]
+    for depth in (0, 2):
+        g, c = both(texts, a, depth=depth)
+        qbuf, qoff = pack_queries(qs)
+        s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+        cs, ce, cst = c.cursors_single(qbuf, qoff)
+        assert st.tolist() == cst.tolist()
+        ok = st == 0
+        assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+        from genedex_amd import GdxError
+
+        with pytest.raises(GdxError):
+            g.cursors_raw(qbuf, qoff)  # strict: a reference panic is an error of the call
+
+
+def test_cursor_api():
+    rng = np.random.default_rng(9)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=5000, symbols=b"ACGTN")
+    g, c = both(texts, a, depth=3)
+    cur = g.cursor_empty()
+    assert cur.interval() == (0, c.n)
+    # batched extension equals repeated scalar extension on the oracle
+    m = 500
+    starts = np.zeros(m, dtype=np.uint64)
+    ends = np.full(m, c.n, dtype=np.uint64)
+    want = [(0, c.n)] * m
+    for step in range(14):
+        syms = np.frombuffer(bytes(b"ACGTNacgtn"[i] for i in rng.integers(0, 10, m)), dtype=np.uint8)
+        starts, ends, st = g.extend_front_raw(starts, ends, syms)
+        want = [c.extend_front(s, e, int(sym))[:2] for (s, e), sym in zip(want, syms)]
+        assert not st.any()
+        assert list(zip(starts.tolist(), ends.tolist())) == want
+    off, t, p = g.locate_intervals_raw(starts, ends)
+    co, ct, cp = c.locate_intervals(starts, ends)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    _, _, st = g.extend_front_raw([0], [c.n], [ord("X")], strict=False)
+    assert st.tolist() == [1]
+
+
+def test_from_parts_round_trip():
+    from genedex_amd import FmIndex
+
+    rng = np.random.default_rng(11)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=30000, symbols=b"ACGTN")
+    c = cpu_index(texts, a, sa_rate=5, depth=2)
+    g = FmIndex.from_parts(c.count_array, c.blocks, c.n, c.sa_samples, 5, c.border_keys, c.border_vals,
+                           c.sentinel_indices, a, lookup_depth=2)
+    qs = mixed_queries(rng, texts, 300, 300, 40)
+    off, t, p, _ = g.locate_raw(*pack_queries(qs))
+    co, ct, cp = c.locate_many(qs)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    blocks, bo, sbo = g.export_condensed_table()
+    assert blocks.tolist() == c.blocks.tolist() and bo.tolist() == c.block_offsets.tolist()
+    assert sbo.tolist() == c.superblock_offsets.tolist()
+
+
+def test_invalid_construction_arguments():
+    from genedex_amd import FmIndexConfig, GdxError
+
+    with pytest.raises(GdxError):  # alphabet.rs:195-198 while encoding the text
+        FmIndexConfig("i32").construct_index([b"ACGX"], alph.ascii_dna())
+    with pytest.raises(GdxError):  # construction/mod.rs:303
+        FmIndexConfig("i32").construct_index([], alph.ascii_dna())
+
+
+def test_medium_text_against_oracle():
+    """4 Mi symbols, 200k queries: full equality of intervals and hits with the CPU restatement."""
+    from genedex_amd import synth
+
+    a = alph.ascii_dna_with_n()
+    texts = synth.host_texts(total=1 << 22, n_texts=3, seed=42)
+    g, c = both(texts, a, depth=6)
+    assert g.export_bwt().tobytes() == c.bwt.tobytes()
+    qbuf, qoff = synth.host_queries(texts, nq=200_000, len_min=50, len_max=50, sampled_fraction=0.9, seed=43)
+    s, e, st = g.cursors_raw(qbuf, qoff)
+    cs, ce = c.cursors_for_many(qbuf, qoff, n_threads=4)
+    assert np.array_equal(s, cs) and np.array_equal(e, ce)
+    off, t, p, _ = g.locate_raw(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce, n_threads=4)
+    assert np.array_equal(off, co) and np.array_equal(t, ct) and np.array_equal(p, cp)
+    assert (e - s)[:1000].sum() > 0
