@@ -23,7 +23,13 @@ template <class F>
 int guarded(F &&f)
 {
     try {
-        return f();
+        const int rc = f();
+        if (rc == GDX_ERR_QUERY_STATUS)
+            g_last_error = "at least one query has a non-zero status (symbol outside the alphabet, or a "
+                           "non-searchable symbol inside the lookup-table suffix); see out_status";
+        else if (rc == GDX_ERR_CAPACITY)
+            g_last_error = "output buffer too small; required size reported in out_total";
+        return rc;
     } catch (const gdx::Error &e) {
         g_last_error = e.what();
         return e.status;
