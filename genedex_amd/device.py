@@ -1,0 +1,184 @@
+"""Device-resident use of libgdx.so: indexes built from text that already sits in HBM, query sets
+generated in HBM, and the `_dev` entry points of include/gdx.h driven on a torch stream.
+
+torch is used for device memory, streams and events only (plumbing); every computation is a HIP
+kernel of libgdx.so.  torch must be imported before libgdx.so is loaded so that both share one HIP
+runtime (torch bundles its own libamdhip64.so.7).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .alphabet import Alphabet
+from .index import FmIndex, _WIDTHS, _p
+from .synth import split_lengths
+
+u8p, u64p = _lib.u8p, _lib.u64p
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def synth_text(total: int, seed: int = 42, n_per_million: int = 10_000, device="cuda") -> torch.Tensor:
+    """IO symbols of the synthetic text, generated in HBM (gdx_synth_text_dev)."""
+    lib = _lib.load()
+    out = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+    _lib.check(lib.gdx_synth_text_dev(_ptr(out), total, seed, n_per_million, _stream()))
+    return out
+
+
+def build_index_from_device_text(io_text: torch.Tensor, text_lengths, alphabet: Alphabet, sa_rate=4, lookup_depth=0,
+                                 index_storage="u32") -> FmIndex:
+    lib = _lib.load()
+    toff = np.zeros(len(text_lengths) + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(text_lengths, dtype=np.uint64), out=toff[1:])
+    tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
+    handle = C.c_void_p()
+    torch.cuda.synchronize()
+    st = lib.gdx_index_build_dev(_ptr(io_text), _p(toff, u64p), len(text_lengths), _p(tab, u8p),
+                                 alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(), sa_rate,
+                                 lookup_depth, _WIDTHS[index_storage], io_text.device.index or 0, C.byref(handle))
+    _lib.check(st)
+    return FmIndex(handle, alphabet)
+
+
+class DeviceQueries:
+    """A query set resident in HBM: qbuf (u8, padded to 8 bytes) + qoff (u64[nq+1])."""
+
+    def __init__(self, qbuf: torch.Tensor, qoff: torch.Tensor, nq: int, total_bytes: int):
+        self.qbuf, self.qoff, self.nq, self.total_bytes = qbuf, qoff, nq, total_bytes
+
+    @classmethod
+    def synth(cls, io_text: torch.Tensor, text_lengths, nq: int, len_min: int, len_max: int,
+              sampled_per_million: int, seed: int = 43) -> "DeviceQueries":
+        lib = _lib.load()
+        dev = io_text.device
+        toff_h = np.zeros(len(text_lengths) + 1, dtype=np.int64)
+        np.cumsum(np.asarray(text_lengths, dtype=np.int64), out=toff_h[1:])
+        toff = torch.from_numpy(toff_h).to(dev)
+        cap = (nq * len_max + 8 + 7) // 8 * 8
+        qbuf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        qoff = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        total = C.c_uint64(0)
+        _lib.check(lib.gdx_synth_queries_dev(_ptr(io_text), _ptr(toff), len(text_lengths), nq, len_min, len_max,
+                                             sampled_per_million, seed, _ptr(qoff), _ptr(qbuf), cap,
+                                             C.byref(total), _stream()))
+        return cls(qbuf, qoff, nq, total.value)
+
+    @classmethod
+    def from_host(cls, qbuf: np.ndarray, qoff: np.ndarray, device="cuda") -> "DeviceQueries":
+        nq = qoff.size - 1
+        total = int(qoff[-1])
+        pad = np.zeros((total + 8 + 7) // 8 * 8, dtype=np.uint8)
+        pad[:total] = qbuf[:total]
+        return cls(torch.from_numpy(pad).to(device), torch.from_numpy(qoff.astype(np.int64)).to(device), nq, total)
+
+    def host_slice(self, first: int, count: int):
+        """(qbuf, qoff) of queries [first, first+count) as numpy arrays (for the CPU baseline / checks)."""
+        off = self.qoff[first:first + count + 1].cpu().numpy().astype(np.uint64)
+        b0, b1 = int(off[0]), int(off[-1])
+        buf = self.qbuf[b0:b1].cpu().numpy() if b1 > b0 else np.zeros(1, dtype=np.uint8)
+        return buf, off - off[0]
+
+
+class DeviceEngine:
+    """count / locate passes over a DeviceQueries set, everything staying in HBM."""
+
+    def __init__(self, index: FmIndex):
+        self.index = index
+        self.lib = _lib.load()
+        self.h = index._h
+        self.dev = torch.device("cuda", int(index.info.device_id))
+
+    def alloc_outputs(self, nq: int):
+        d = self.dev
+        return {
+            "start": torch.empty(nq, dtype=torch.int32, device=d),
+            "end": torch.empty(nq, dtype=torch.int32, device=d),
+            "status": torch.empty(nq, dtype=torch.uint8, device=d),
+            "hit_offsets": torch.empty(nq + 1, dtype=torch.int64, device=d),
+        }
+
+    def search(self, q: DeviceQueries, out) -> None:
+        """cursors_for_many_queries: intervals + status (the dominant kernel)."""
+        _lib.check(self.lib.gdx_cursors_for_many_queries_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq,
+                                                             _ptr(out["start"]), _ptr(out["end"]),
+                                                             _ptr(out["status"]), _stream()))
+
+    def count(self, q: DeviceQueries, counts: torch.Tensor, status: torch.Tensor) -> None:
+        _lib.check(self.lib.gdx_count_many_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(counts),
+                                               _ptr(status), _stream()))
+
+    def hit_offsets(self, out, m: int) -> None:
+        _lib.check(self.lib.gdx_hit_offsets_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
+                                                _ptr(out["hit_offsets"]), _stream()))
+
+    def locate_workspace_bytes(self, total: int) -> int:
+        return int(self.lib.gdx_locate_workspace_bytes(total))
+
+    def locate(self, out, m: int, total: int, hits: torch.Tensor, workspace: torch.Tensor) -> None:
+        """hits: int32[total, 2] = (text_id, position) per hit, in suffix-array order per query."""
+        _lib.check(self.lib.gdx_locate_intervals_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
+                                                     _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
+                                                     _stream()))
+
+    def search_lf_steps(self, q: DeviceQueries) -> int:
+        steps = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        _lib.check(self.lib.gdx_search_step_stats_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(steps),
+                                                      _stream()))
+        return int(steps.item())
+
+    def locate_walk_steps(self, out, m: int, total: int, hits: torch.Tensor, workspace: torch.Tensor) -> int:
+        steps = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        _lib.check(self.lib.gdx_locate_step_stats_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
+                                                      _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
+                                                      _ptr(steps), _stream()))
+        return int(steps.item())
+
+
+def measure_bandwidth(device="cuda", gib: float = 4.0, reps: int = 3):
+    """Roofline denominators measured on this GPU: streaming copy and random line gathers (GB/s)."""
+    lib = _lib.load()
+    nbytes = int(gib * (1 << 30)) // 4096 * 4096
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    src.random_(0, 255)
+    dst = torch.empty_like(src)
+    sink = torch.zeros(1, dtype=torch.int32, device=device)
+    res = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None or ms < best else best
+        return best / 1e3
+
+    t = timed(lambda: _lib.check(lib.gdx_bench_stream_copy(_ptr(dst), _ptr(src), nbytes, _stream())))
+    res["stream_copy_GBps"] = 2 * nbytes / t / 1e9
+    n_acc = 1 << 27
+    for line in (64, 128):
+        for mode in (0, 1):
+            t = timed(lambda: _lib.check(lib.gdx_bench_random_gather(_ptr(src), nbytes // line, line, n_acc, 7, mode,
+                                                                     _ptr(sink), _stream())))
+            res[f"gather{line}_{'lane' if mode == 0 else 'group'}_GBps"] = n_acc * line / t / 1e9
+    return res
+
+
+def hg38_text_lengths(total: int, n_texts: int = 24):
+    return split_lengths(total, n_texts)
