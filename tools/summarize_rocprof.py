@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output into the small summaries kept under profiles/.
+
+    tools/summarize_rocprof.py stats  <dir with *_kernel_stats.csv>         -> markdown table on stdout
+    tools/summarize_rocprof.py pmc    <dir with *_counter_collection.csv>   -> json on stdout
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    m = re.search(r"(gdx::[A-Za-z0-9_]+(?:<[^>(]*>)?)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"rocprim::.*?wrapped_([a-z_]+)_config", name)
+    if m:
+        return "rocprim::" + m.group(1)
+    return name.split("(")[0][-60:]
+
+
+def stats(d):
+    f = glob.glob(f"{d}/**/*_kernel_stats.csv", recursive=True)[0]
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        a = agg.setdefault(k, [0, 0])
+        a[0] += int(r["Calls"])
+        a[1] += int(r["TotalDurationNs"])
+    total = sum(v[1] for v in agg.values())
+    print("| kernel | calls | total ms | avg ms | % |")
+    print("|---|---|---|---|---|")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"| {k} | {c} | {t / 1e6:.3f} | {t / c / 1e6:.4f} | {100 * t / total:.2f} |")
+
+
+def pmc(d):
+    out = {}
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+            out.setdefault(c, {})[k] = {"launches": n, "sum": s, "per_launch": s / n}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
