@@ -51,7 +51,7 @@ class IndexInfo(C.Structure):
 class BuildStats(C.Structure):
     _fields_ = [("sa_initial_order", C.c_uint64), ("sa_pending_after_sort", C.c_uint64), ("sa_rounds", C.c_uint64),
                 ("seconds_encode", C.c_double), ("seconds_sa", C.c_double), ("seconds_bwt", C.c_double),
-                ("seconds_table", C.c_double), ("seconds_lookup", C.c_double)]
+                ("seconds_table", C.c_double), ("seconds_lookup", C.c_double), ("seconds_pairs", C.c_double)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -93,7 +93,9 @@ SIGNATURES = {
     "gdx_synth_text_dev": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp],
     "gdx_synth_queries_dev": [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp,
                               C.c_uint64, u64p, vp],
+    "gdx_debug_set_search_variant": [C.c_int],
     "gdx_bench_stream_copy": [vp, vp, C.c_uint64, vp],
+    "gdx_bench_stream_read": [vp, C.c_uint64, vp, vp],
     "gdx_bench_random_gather": [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_search_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],

@@ -166,6 +166,7 @@ int gdx_index_build_stats(const gdx_index_t *ix, gdx_build_stats_t *out)
         out->seconds_bwt = s.seconds_bwt;
         out->seconds_table = s.seconds_table;
         out->seconds_lookup = s.seconds_lookup;
+        out->seconds_pairs = s.seconds_pairs;
         return (int)GDX_OK;
     });
 }
@@ -364,10 +365,26 @@ int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uin
     });
 }
 
+int gdx_debug_set_search_variant(int variant)
+{
+    if (variant < -1 || variant > 2) return GDX_ERR_INVALID_ARGUMENT;
+    gdx::set_search_variant(variant);
+    return GDX_OK;
+}
+
 int gdx_bench_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, void *stream)
 {
     return guarded([&] {
         gdx::launch_stream_copy(d_dst, d_src, bytes, as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_bench_stream_read(const void *d_src, uint64_t bytes, void *d_sink, void *stream)
+{
+    return guarded([&] {
+        gdx::launch_stream_read(d_src, bytes, static_cast<uint32_t *>(d_sink), as_stream(stream));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -236,6 +237,129 @@ __global__ void superblock_prefix_kernel(uint32_t *sb, uint64_t n_sb, uint32_t s
 }
 
 // ---------------------------------------------------------------------------------------------
+// pair lines (layout.hpp PairTable).  bwt0[i] = text[SA[i]-2] is recovered from the one-step table
+// itself, bwt0[i] = bwt1[LF(i)], so that imported indexes (from_parts) get pair lines too.  Rows whose
+// bwt1 is the sentinel keep bwt0 = 0: a pair with a sentinel is never searched.
+
+__global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8_t *__restrict__ bwt0)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
+        uint32_t r;
+        const uint32_t c = LineTable::symbol_and_rank(ix, static_cast<uint32_t>(p), r);
+        uint32_t prev = 0;
+        if (c != 0) prev = LineTable::symbol_at(ix, ix.count[c] + r);
+        bwt0[p] = static_cast<uint8_t>(prev);
+    }
+}
+
+// One block per superblock (512 lines); thread t builds lines 2t, 2t+1.  bwt1 / bwt0 must be readable
+// (zero padded) up to n_lines * 128 bytes.
+__global__ __launch_bounds__(kBlock) void build_pair_lines_kernel(const uint8_t *__restrict__ bwt1,
+                                                                  const uint8_t *__restrict__ bwt0, uint64_t n_lines,
+                                                                  u32x4 *__restrict__ pair_lines,
+                                                                  uint32_t *__restrict__ sb_totals)
+{
+    __shared__ uint32_t s_scan[16][kBlock];
+    const uint64_t sb = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    uint32_t px[2][8], py[2][8], pz[2][8];  // packed plane words per 16-position chunk
+    uint32_t pair_sum[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++) pair_sum[p] = 0;
+    uint32_t cnt0[16];  // pair counts of the first line
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
+        uint32_t cnt[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) cnt[p] = 0;
+        if (line < n_lines) {
+            const uint4 *v1 = reinterpret_cast<const uint4 *>(bwt1 + line * 128);
+            const uint4 *v0 = reinterpret_cast<const uint4 *>(bwt0 + line * 128);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint4 a = v1[j], b = v0[j];
+                const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+                uint32_t p1[3] = {0, 0, 0}, p0[3] = {0, 0, 0};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t s1 = (wa[w] >> (8 * k)) & 0xffu, s0 = (wb[w] >> (8 * k)) & 0xffu;
+                        const int bit = w * 4 + k;
+#pragma unroll
+                        for (int pl = 0; pl < 3; pl++) {
+                            p1[pl] |= ((s1 >> pl) & 1u) << bit;
+                            p0[pl] |= ((s0 >> pl) & 1u) << bit;
+                        }
+                    }
+                }
+                px[l][j] = p1[0] | (p1[1] << 16);
+                py[l][j] = p1[2] | (p0[0] << 16);
+                pz[l][j] = p0[1] | (p0[2] << 16);
+                // pair (c2, c1), both in 1..4: match masks from the planes
+#pragma unroll
+                for (int c1 = 1; c1 <= 4; c1++) {
+                    const uint32_t m1 = ((c1 & 1) ? p1[0] : ~p1[0]) & ((c1 & 2) ? p1[1] : ~p1[1]) &
+                                        ((c1 & 4) ? p1[2] : ~p1[2]) & 0xffffu;
+#pragma unroll
+                    for (int c2 = 1; c2 <= 4; c2++) {
+                        const uint32_t m0 = ((c2 & 1) ? p0[0] : ~p0[0]) & ((c2 & 2) ? p0[1] : ~p0[1]) &
+                                            ((c2 & 4) ? p0[2] : ~p0[2]);
+                        cnt[(c2 - 1) * 4 + (c1 - 1)] += __popc(m1 & m0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) px[l][j] = py[l][j] = pz[l][j] = 0;
+        }
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            pair_sum[p] += cnt[p];
+            if (l == 0) cnt0[p] = cnt[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 16; p++) s_scan[p][t] = pair_sum[p];
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        uint32_t add[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) add[p] = t >= static_cast<uint32_t>(off) ? s_scan[p][t - off] : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 16; p++) s_scan[p][t] += add[p];
+        __syncthreads();
+    }
+    uint32_t before[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++) before[p] = s_scan[p][t] - pair_sum[p];
+    if (t == kBlock - 1) {
+#pragma unroll
+        for (int p = 0; p < 16; p++) sb_totals[sb * 16 + p] = s_scan[p][t];
+    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
+        if (line < n_lines) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                u32x4 chunk;
+                chunk.x = px[l][j];
+                chunk.y = py[l][j];
+                chunk.z = pz[l][j];
+                chunk.w = (before[2 * j] & 0xffffu) | (before[2 * j + 1] << 16);
+                pair_lines[line * 8 + j] = chunk;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; p++) before[p] += cnt0[p];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic planes (layout 1) = the reference's own arrays (condensed.rs:24-30), also used to export
 // the table of a line-layout index in the reference's logical form.
 
@@ -366,7 +490,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return pair_lines_.bytes() + pair_sb_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -467,6 +591,45 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     GDX_HIP(hipStreamSynchronize(stream));
     GDX_HIP(hipGetLastError());
     stats_.seconds_lookup = now_seconds() - t0;
+
+    // ---- pair lines: two LF steps per line fetch (rank-line layout only) ------------------------------
+    const char *no_pairs = getenv("GDX_NO_PAIR_LINES");
+    if (view_.layout == 0 && n_ > 0 && !(no_pairs && no_pairs[0] == '1')) {
+        t0 = now_seconds();
+        const uint64_t n_lines = div_ceil(len, 128);
+        const uint64_t padded = n_lines * 128;
+        DeviceBuffer<uint8_t> d_bwt0(padded);
+        GDX_HIP(hipMemsetAsync(d_bwt0.get(), 0, padded, stream));
+        hipLaunchKernelGGL(derive_bwt0_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt0.get());
+        pair_lines_.alloc(n_lines * 8);
+        pair_sb_.alloc(n_sb * 16);
+        hipLaunchKernelGGL(build_pair_lines_kernel, dim3(static_cast<unsigned>(n_sb)), dim3(kBlock), 0, stream,
+                           d_bwt_padded, d_bwt0.get(), n_lines, pair_lines_.get(), pair_sb_.get());
+        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(64), 0, stream, pair_sb_.get(), n_sb, 16u);
+        // C2[c2 c1] = C[c2] + rank(c2, C[c1]): first SA slot of the 2-mer c2 c1
+        uint8_t sym[16];
+        uint32_t at[16], r[16];
+        for (int c2 = 1; c2 <= 4; c2++)
+            for (int c1 = 1; c1 <= 4; c1++) {
+                const int p = (c2 - 1) * 4 + (c1 - 1);
+                const bool ok = c1 < sigma && c2 < sigma;
+                sym[p] = static_cast<uint8_t>(ok ? c2 : 0);
+                at[p] = static_cast<uint32_t>(ok ? count_host_[c1] : 0);
+            }
+        DeviceBuffer<uint8_t> d_sym(16);
+        DeviceBuffer<uint32_t> d_at(16), d_r(16), d_err(1);
+        GDX_HIP(hipMemcpyAsync(d_sym.get(), sym, 16, hipMemcpyHostToDevice, stream));
+        GDX_HIP(hipMemcpyAsync(d_at.get(), at, sizeof(at), hipMemcpyHostToDevice, stream));
+        GDX_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(uint32_t), stream));
+        launch_rank_many(view_, d_sym.get(), d_at.get(), 16, d_r.get(), d_err.get(), stream);
+        GDX_HIP(hipMemcpyAsync(r, d_r.get(), sizeof(r), hipMemcpyDeviceToHost, stream));
+        GDX_HIP(hipStreamSynchronize(stream));
+        GDX_HIP(hipGetLastError());
+        for (int p = 0; p < 16; p++) view_.pair_count[p] = static_cast<uint32_t>(count_host_[sym[p]]) + r[p];
+        view_.pair_lines = pair_lines_.get();
+        view_.pair_sb = pair_sb_.get();
+        stats_.seconds_pairs = now_seconds() - t0;
+    }
 }
 
 std::unique_ptr<FmIndex> FmIndex::construct_index(const uint8_t *texts_buf, bool texts_on_device,

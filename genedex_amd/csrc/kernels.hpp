@@ -16,6 +16,7 @@ namespace gdx {
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
                    hipStream_t stream, unsigned long long *d_step_stats = nullptr);
+void set_search_variant(int v);  // 0 quad, 1 lane, 2 pair (default), -1 re-read the environment
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
                          uint64_t m, uint8_t *d_out_status, hipStream_t stream);
 // d_error (u32, pre-zeroed) is set to 1 when an argument is out of range

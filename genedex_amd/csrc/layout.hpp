@@ -38,6 +38,10 @@ struct IndexView {
     const uint64_t *g_planes;     // generic: [n_blocks64][nbits]       (layout 1)
     const uint16_t *g_block_off;  // generic: [n_blocks64][sigma]
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
+    // --- pair lines: two LF steps per line fetch (layout 0 with <= 4 searchable symbols) -----
+    const u32x4 *pair_lines;      // [n_lines][8], null when absent
+    const uint32_t *pair_sb;      // [n_superblocks][16] absolute pair counts before the superblock
+    uint32_t pair_count[16];      // C2[(c2-1)*4 + (c1-1)] = first SA slot of the 2-mer c2 c1
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -158,6 +162,99 @@ struct LineTable {
         const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * 8u + c];
         rank_out = sb + line_block_offset(l, c) + line_popcount(l, c, idx & 127u);
         return c;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// rank lines, four lanes per query: the quad fetches one 64-byte line with ONE coalesced 16-byte load
+// per lane (lane j owns chunk j), counts its own 32 positions and the quad sums with two DPP adds.
+// One L2 request per line instead of four, and no duplicate DRAM fetches of a line whose first miss
+// is still in flight.
+
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v)
+{
+    // quad_perm [1,0,3,2] then [2,3,0,1]: every lane of the quad ends up with the quad's total
+    v += static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true));
+    v += static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+struct QuadLineTable {
+    // contribution of this lane's chunk to rank-within-superblock of (symbol, idx)
+    static __device__ __forceinline__ uint32_t partial(const u32x4 c, uint32_t sub, uint32_t symbol, uint32_t idx)
+    {
+        const uint32_t n0 = (symbol & 1u) ? 0u : 0xffffffffu;
+        const uint32_t n1 = (symbol & 2u) ? 0u : 0xffffffffu;
+        const uint32_t n2 = (symbol & 4u) ? 0u : 0xffffffffu;
+        const uint32_t pop = chunk_popcount(c, n0, n1, n2, static_cast<int32_t>(idx & 127u) - 32 * static_cast<int32_t>(sub));
+        const uint32_t off = (symbol & 1u) ? (c.w >> 16) : (c.w & 0xffffu);
+        return pop + ((symbol >> 1) == sub ? off : 0u);
+    }
+    static __device__ __forceinline__ void rank2(const IndexView &ix, uint32_t symbol, uint32_t lo, uint32_t hi,
+                                                 uint32_t &rlo, uint32_t &rhi)
+    {
+        const uint32_t sub = threadIdx.x & 3u;
+        const uint32_t sb_lo = ix.sb_offsets[(lo >> kSuperblockShift) * 8u + symbol];
+        const uint32_t sb_hi = ix.sb_offsets[(hi >> kSuperblockShift) * 8u + symbol];
+        const uint32_t line_lo = lo >> kLineShift, line_hi = hi >> kLineShift;
+        const u32x4 a = ix.lines[(static_cast<uint64_t>(line_lo) << 2) + sub];
+        u32x4 b = a;
+        if (line_hi != line_lo) b = ix.lines[(static_cast<uint64_t>(line_hi) << 2) + sub];  // quad-uniform
+        rlo = sb_lo + quad_sum(partial(a, sub, symbol, lo));
+        rhi = sb_hi + quad_sum(partial(b, sub, symbol, hi));
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// pair lines: one 128-byte line per 128 BWT positions holds the bit planes of BOTH preceding symbols
+// (bwt1[i] = text[SA[i]-1], bwt0[i] = text[SA[i]-2]) and the block offsets of the 16 pairs of
+// searchable symbols, so that two LF steps cost one line fetch:
+//     LF(c2, LF(c1, i)) = C2[c2 c1] + #{ j < i : bwt0[j] = c2 and bwt1[j] = c1 }.
+// A random 128-byte line costs the memory system the same as a random 64-byte line (one DRAM row
+// activation either way), so this halves the activations of the deep levels of a search.
+// Chunk j (16 B, one lane of an 8-lane group) covers positions [16j, 16j+16):
+//   x = plane0(bwt1) | plane1(bwt1) << 16,  y = plane2(bwt1) | plane0(bwt0) << 16,
+//   z = plane1(bwt0) | plane2(bwt0) << 16,  w = offset[pair 2j] | offset[pair 2j+1] << 16.
+
+__device__ __forceinline__ uint32_t oct_sum(uint32_t v)
+{
+    v = quad_sum(v);
+    // row_half_mirror: lane i <-> lane 7-i inside each group of 8, i.e. the other quad's total
+    v += static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+struct PairTable {
+    static __device__ __forceinline__ uint32_t partial(const u32x4 c, uint32_t sub, uint32_t pair, uint32_t nx,
+                                                       uint32_t ny, uint32_t nz, uint32_t idx)
+    {
+        const uint32_t m32 = (c.x ^ nx) & (c.y ^ ny) & (c.z ^ nz);
+        const uint32_t m16 = m32 & (m32 >> 16) & 0xffffu;
+        const int32_t bits = static_cast<int32_t>(idx & 127u) - 16 * static_cast<int32_t>(sub);
+        const uint32_t mask = bits >= 16 ? 0xffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+        const uint32_t off = (pair & 1u) ? (c.w >> 16) : (c.w & 0xffffu);
+        return __popc(m16 & mask) + ((pair >> 1) == sub ? off : 0u);
+    }
+    // c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
+    static __device__ __forceinline__ void lf2(const IndexView &ix, const uint32_t *pair_count /*LDS copy*/,
+                                               uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi, uint32_t &nlo,
+                                               uint32_t &nhi)
+    {
+        const uint32_t sub = threadIdx.x & 7u;
+        const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
+        const uint32_t h = 0xffffu;
+        const uint32_t nx = ((c1 & 1u) ? 0u : h) | (((c1 & 2u) ? 0u : h) << 16);
+        const uint32_t ny = ((c1 & 4u) ? 0u : h) | (((c2 & 1u) ? 0u : h) << 16);
+        const uint32_t nz = ((c2 & 2u) ? 0u : h) | (((c2 & 4u) ? 0u : h) << 16);
+        const uint32_t sb_lo = ix.pair_sb[(lo >> kSuperblockShift) * 16u + pair];
+        const uint32_t sb_hi = ix.pair_sb[(hi >> kSuperblockShift) * 16u + pair];
+        const uint32_t line_lo = lo >> kLineShift, line_hi = hi >> kLineShift;
+        const u32x4 a = ix.pair_lines[(static_cast<uint64_t>(line_lo) << 3) + sub];
+        u32x4 b = a;
+        if (line_hi != line_lo) b = ix.pair_lines[(static_cast<uint64_t>(line_hi) << 3) + sub];  // group-uniform
+        const uint32_t base = pair_count[pair];
+        nlo = base + sb_lo + oct_sum(partial(a, sub, pair, nx, ny, nz, lo));
+        nhi = base + sb_hi + oct_sum(partial(b, sub, pair, nx, ny, nz, hi));
     }
 };
 

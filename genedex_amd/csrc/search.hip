@@ -2,6 +2,10 @@
 // rank / symbol_at kernels.  One lane per query: a wavefront advances 64 backward searches in
 // lock-step, the same shape as the reference's 64-wide BatchComputedCursors
 // (batch_computed_cursors.rs:36-73) with the swap-compaction replaced by the exec mask.
+#include <atomic>
+#include <cstdlib>
+#include <string>
+
 #include "kernels.hpp"
 
 namespace gdx {
@@ -41,7 +45,9 @@ struct QueryWindow {
     }
 };
 
-template <class Table>
+// kGroup lanes cooperate on one query (1: LineTable / GenericTable, 4: QuadLineTable); control flow is
+// uniform inside a group, lane 0 of the group writes the results.
+template <class Table, int kGroup>
 __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                         const uint64_t *__restrict__ qoff, uint64_t nq,
                                                         uint32_t *__restrict__ out_start,
@@ -57,9 +63,11 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
+    const bool writer = (threadIdx.x % kGroup) == 0;
     uint32_t lf_steps = 0;  // only reported through step_stats (bench accounting, null in normal calls)
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < nq; q += stride) {
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; q < nq;
+         q += stride) {
         const uint64_t begin = qoff[q], end = qoff[q + 1];
         const uint64_t len = end - begin;
         // lib.rs:277-281 split_query_for_lookup
@@ -105,12 +113,108 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
             pos--;
             lf_steps++;
         }
-        if (out_start) out_start[q] = lo;
-        if (out_end) out_end[q] = hi;
-        if (out_count) out_count[q] = hi - lo;
-        if (out_status) out_status[q] = static_cast<uint8_t>(status);
+        if (writer) {
+            if (out_start) out_start[q] = lo;
+            if (out_end) out_end[q] = hi;
+            if (out_count) out_count[q] = hi - lo;
+            if (out_status) out_status[q] = static_cast<uint8_t>(status);
+        }
     }
-    if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+}
+
+// Backward search on pair lines: eight lanes per query, two LF steps per line fetch while both next
+// symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
+// which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
+// one-step rank lines, so the result is identical to search_kernel's.
+__global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+                                                             const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                             uint32_t *__restrict__ out_start,
+                                                             uint32_t *__restrict__ out_end,
+                                                             uint32_t *__restrict__ out_count,
+                                                             uint8_t *__restrict__ out_status,
+                                                             unsigned long long *__restrict__ step_stats)
+{
+    constexpr int kGroup = 8;
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_count[257];
+    __shared__ uint32_t s_pair_count[16];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    if (threadIdx.x < 16) s_pair_count[threadIdx.x] = ix.pair_count[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    uint32_t lf_steps = 0;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; q < nq;
+         q += stride) {
+        const uint64_t begin = qoff[q], end = qoff[q + 1];
+        const uint64_t len = end - begin;
+        const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                 : static_cast<uint32_t>(ix.depth);
+        uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
+        if (t > 0) {
+            uint32_t idx = 0, factor = 1;
+            bool unsearchable = false;
+            for (uint32_t j = 0; j < t; j++) {
+                const uint32_t d = s_dense[qbuf[end - t + j]];
+                if (d == 0) status = GDX_Q_INVALID_SYMBOL;
+                unsearchable |= (d - 1u >= k);
+                idx += (d - 1u) * factor;
+                factor *= k;
+            }
+            if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
+            if (status == GDX_Q_OK) {
+                const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                lo = v.x;
+                hi = v.y;
+            } else {
+                lo = hi = 0;
+            }
+        }
+        uint64_t pos = end - t;
+        QueryWindow win;
+        win.init(qbuf, begin, pos);
+        while (pos > begin && lo != hi) {
+            const uint32_t c1 = s_dense[win.get(pos - 1)];
+            if (c1 == 0) {
+                status = GDX_Q_INVALID_SYMBOL;
+                lo = hi = 0;
+                break;
+            }
+            uint32_t c2 = 0;
+            if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
+            if (c1 <= 4u && c2 - 1u < 4u) {
+                uint32_t nlo, nhi;
+                PairTable::lf2(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
+                if (nlo != nhi) {
+                    lo = nlo;
+                    hi = nhi;
+                    pos -= 2;
+                    lf_steps += 2;
+                    continue;
+                }
+                // the interval empties within these two steps: fall through to single steps so that the
+                // frozen interval is the one the reference reports
+            }
+            uint32_t rlo, rhi;
+            QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+            const uint32_t cc = s_count[c1];
+            lo = cc + rlo;
+            hi = cc + rhi;
+            pos--;
+            lf_steps++;
+        }
+        if (writer) {
+            if (out_start) out_start[q] = lo;
+            if (out_end) out_end[q] = hi;
+            if (out_count) out_count[q] = hi - lo;
+            if (out_status) out_status[q] = static_cast<uint8_t>(status);
+        }
+    }
+    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
 template <class Table>
@@ -213,13 +317,55 @@ static unsigned grid_for_items(uint64_t items)
     return static_cast<unsigned>(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
 }
 
+// Kernel used on rank lines: 2 = pair lines when the index has them (default), 0 = quad, 1 = one lane
+// per query.  Settable through GDX_SEARCH_VARIANT=pair|quad|lane or gdx_debug_set_search_variant()
+// (A/B measurements and parity tests of every variant).
+static std::atomic<int> g_search_variant{-1};
+
+void set_search_variant(int v) { g_search_variant.store(v); }
+
+static int search_variant()
+{
+    int v = g_search_variant.load();
+    if (v >= 0) return v;
+    const char *e = getenv("GDX_SEARCH_VARIANT");
+    v = 2;
+    if (e && std::string(e) == "lane") v = 1;
+    if (e && std::string(e) == "quad") v = 0;
+    g_search_variant.store(v);
+    return v;
+}
+
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
                    hipStream_t stream, unsigned long long *d_step_stats)
 {
     if (nq == 0) return;
-    GDX_DISPATCH_TABLE(ix, search_kernel, grid_for_items(nq), stream, ix, d_qbuf, d_qoff, nq, d_out_start,
-                       d_out_end, d_out_count, d_out_status, d_step_stats);
+    // GDX_SEARCH_OCC=<blocks per CU> (experiments): limits residency with a dynamic-LDS pad
+    static const int occ = [] {
+        const char *e = getenv("GDX_SEARCH_OCC");
+        const int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    const unsigned lds_pad = occ == 8 ? 0u : (160u * 1024u / occ - 2048u);
+    if (ix.layout == 0 && search_variant() == 2 && ix.pair_lines != nullptr) {
+        uint64_t blocks = (nq * 8 + kBlock - 1) / kBlock;
+        if (blocks > 256ull * occ) blocks = 256ull * occ;
+        hipLaunchKernelGGL(search_pair_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad, stream, ix,
+                           d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
+    } else if (ix.layout == 0 && search_variant() != 1) {
+        uint64_t blocks = (nq * 4 + kBlock - 1) / kBlock;
+        if (blocks > 256ull * occ) blocks = 256ull * occ;
+        hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad,
+                           stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,
+                           d_step_stats);
+    } else if (ix.layout == 0) {
+        hipLaunchKernelGGL((search_kernel<LineTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix, d_qbuf,
+                           d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
+    } else {
+        hipLaunchKernelGGL((search_kernel<GenericTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix,
+                           d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
+    }
 }
 
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,

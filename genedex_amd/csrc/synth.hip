@@ -105,19 +105,41 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(u32x4 *__restrict__
                                                              uint64_t n16)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
-// mode 0: every lane reads whole random lines; kVecPerLine = line_bytes / 16
-template <int kVecPerLine>
+__device__ __forceinline__ uint32_t pcg_next(uint32_t &state)
+{
+    state = state * 747796405u + 2891336453u;
+    const uint32_t w = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+
+__device__ __forceinline__ uint64_t pick_line(uint32_t r, uint64_t n_lines)
+{
+    return (static_cast<uint64_t>(r) * n_lines) >> 32;  // n_lines < 2^32
+}
+
+// mode 0: every lane reads whole random lines (4 or 8 x 16 B), two independent lines in flight;
+// mode 2: the same, but the next line depends on the data just loaded (one dependent chain per lane)
+template <int kVecPerLine, bool kDependent>
 __global__ __launch_bounds__(kBlock) void gather_lane_kernel(const u32x4 *__restrict__ src, uint64_t n_lines,
                                                              uint64_t per_thread, uint64_t seed,
                                                              uint32_t *__restrict__ sink)
 {
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    uint32_t state = static_cast<uint32_t>(mix64(seed + tid));
     uint32_t acc = 0;
     for (uint64_t k = 0; k < per_thread; k += 2) {
-        const uint64_t l0 = hash3(seed, tid, k) % n_lines, l1 = hash3(seed, tid, k + 1) % n_lines;
+        const uint64_t l0 = pick_line(pcg_next(state), n_lines), l1 = pick_line(pcg_next(state), n_lines);
         u32x4 v0[kVecPerLine], v1[kVecPerLine];
 #pragma unroll
         for (int j = 0; j < kVecPerLine; j++) {
@@ -126,11 +148,12 @@ __global__ __launch_bounds__(kBlock) void gather_lane_kernel(const u32x4 *__rest
         }
 #pragma unroll
         for (int j = 0; j < kVecPerLine; j++) acc ^= v0[j].x ^ v0[j].w ^ v1[j].y ^ v1[j].z;
+        if (kDependent) state ^= acc;
     }
     if (acc == 0x12345u) *sink = acc;  // keeps the loads alive
 }
 
-// mode 1: kVecPerLine adjacent lanes read one line, 16 bytes each
+// mode 1: kVecPerLine adjacent lanes read one line, 16 bytes each, two independent lines in flight
 template <int kVecPerLine>
 __global__ __launch_bounds__(kBlock) void gather_group_kernel(const u32x4 *__restrict__ src, uint64_t n_lines,
                                                               uint64_t per_group, uint64_t seed,
@@ -138,13 +161,29 @@ __global__ __launch_bounds__(kBlock) void gather_group_kernel(const u32x4 *__res
 {
     const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint64_t group = tid / kVecPerLine, sub = tid % kVecPerLine;
+    uint32_t state = static_cast<uint32_t>(mix64(seed + group));
     uint32_t acc = 0;
     for (uint64_t k = 0; k < per_group; k += 2) {
-        const uint64_t l0 = hash3(seed, group, k) % n_lines, l1 = hash3(seed, group, k + 1) % n_lines;
+        const uint64_t l0 = pick_line(pcg_next(state), n_lines), l1 = pick_line(pcg_next(state), n_lines);
         const u32x4 v0 = src[l0 * kVecPerLine + sub];
         const u32x4 v1 = src[l1 * kVecPerLine + sub];
         acc ^= v0.x ^ v0.w ^ v1.y ^ v1.z;
     }
+    if (acc == 0x12345u) *sink = acc;
+}
+
+// streaming read: sums 16-byte words, 4 loads in flight per lane
+__global__ __launch_bounds__(kBlock) void stream_read_kernel(const u32x4 *__restrict__ src, uint64_t n16,
+                                                             uint32_t *__restrict__ sink)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    uint32_t acc = 0;
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n16; i += stride) acc ^= src[i].x;
     if (acc == 0x12345u) *sink = acc;
 }
 
@@ -191,21 +230,36 @@ void launch_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, hipStrea
                        static_cast<const u32x4 *>(d_src), n16);
 }
 
+void launch_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hipStream_t stream)
+{
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256u * 8u), dim3(kBlock), 0, stream,
+                       static_cast<const u32x4 *>(d_src), n16, d_sink);
+}
+
 void launch_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
                           uint64_t seed, uint32_t mode, uint32_t *d_sink, hipStream_t stream)
 {
     if (line_bytes != 64 && line_bytes != 128) fail(GDX_ERR_INVALID_ARGUMENT, "line_bytes must be 64 or 128");
+    if (n_lines >= (1ull << 32)) fail(GDX_ERR_INVALID_ARGUMENT, "n_lines must be < 2^32");
     if (n_lines == 0 || n_accesses == 0) return;
     const unsigned grid = 256u * 8u;
     const uint64_t threads = static_cast<uint64_t>(grid) * kBlock;
     const u32x4 *src = static_cast<const u32x4 *>(d_src);
-    if (mode == 0) {
+    if (mode == 0 || mode == 2) {
         uint64_t per_thread = div_ceil(n_accesses, threads);
         per_thread += per_thread & 1u;
-        if (line_bytes == 64)
-            hipLaunchKernelGGL(gather_lane_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_thread, seed, d_sink);
-        else
-            hipLaunchKernelGGL(gather_lane_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_thread, seed, d_sink);
+#define GDX_LANE(V, D) \
+    hipLaunchKernelGGL((gather_lane_kernel<V, D>), dim3(grid), dim3(kBlock), 0, stream, src, n_lines, per_thread, seed, d_sink)
+        if (line_bytes == 64) {
+            if (mode == 0) GDX_LANE(4, false);
+            else GDX_LANE(4, true);
+        } else {
+            if (mode == 0) GDX_LANE(8, false);
+            else GDX_LANE(8, true);
+        }
+#undef GDX_LANE
     } else {
         const uint64_t groups = threads / (line_bytes / 16);
         uint64_t per_group = div_ceil(n_accesses, groups);

@@ -171,12 +171,16 @@ def measure_bandwidth(device="cuda", gib: float = 4.0, reps: int = 3):
 
     t = timed(lambda: _lib.check(lib.gdx_bench_stream_copy(_ptr(dst), _ptr(src), nbytes, _stream())))
     res["stream_copy_GBps"] = 2 * nbytes / t / 1e9
+    t = timed(lambda: _lib.check(lib.gdx_bench_stream_read(_ptr(src), nbytes, _ptr(sink), _stream())))
+    res["stream_read_GBps"] = nbytes / t / 1e9
     n_acc = 1 << 27
+    names = {0: "lane", 1: "group", 2: "lane_dependent"}
     for line in (64, 128):
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             t = timed(lambda: _lib.check(lib.gdx_bench_random_gather(_ptr(src), nbytes // line, line, n_acc, 7, mode,
                                                                      _ptr(sink), _stream())))
-            res[f"gather{line}_{'lane' if mode == 0 else 'group'}_GBps"] = n_acc * line / t / 1e9
+            res[f"gather{line}_{names[mode]}_GBps"] = n_acc * line / t / 1e9
+            res[f"gather{line}_{names[mode]}_Glines_per_s"] = n_acc / t / 1e9
     return res
 
 

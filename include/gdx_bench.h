@@ -20,7 +20,7 @@ typedef struct {
     uint64_t sa_initial_order;      /* symbols fixed by the first key sort of the suffix sorter */
     uint64_t sa_pending_after_sort; /* suffixes still tied after it                             */
     uint64_t sa_rounds;             /* prefix-doubling rounds that followed                     */
-    double seconds_encode, seconds_sa, seconds_bwt, seconds_table, seconds_lookup;
+    double seconds_encode, seconds_sa, seconds_bwt, seconds_table, seconds_lookup, seconds_pairs;
 } gdx_build_stats_t;
 
 int gdx_index_build_stats(const gdx_index_t *ix, gdx_build_stats_t *out);
@@ -38,11 +38,20 @@ int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uin
                           void *d_qoff, void *d_qbuf, uint64_t qbuf_capacity, uint64_t *out_total_bytes,
                           void *stream);
 
+/* search kernel used on rank lines: 2 = pair lines (two LF steps per 128-byte line fetch; default),
+ * 0 = quad (four lanes fetch one 64-byte line), 1 = one lane per query, -1 = re-read GDX_SEARCH_VARIANT.
+ * All variants return identical results; the switch exists for A/B measurements and parity tests. */
+int gdx_debug_set_search_variant(int variant);
+
 /* streaming copy of `bytes` (multiple of 16): the "measured HBM bandwidth" denominator */
 int gdx_bench_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, void *stream);
+/* streaming read of `bytes` (multiple of 16) */
+int gdx_bench_stream_read(const void *d_src, uint64_t bytes, void *d_sink, void *stream);
 /* n_accesses independent reads of random aligned lines of line_bytes (64 or 128) out of n_lines.
  * mode 0: one lane reads a whole line (the access shape of the lane-per-query rank);
- * mode 1: line_bytes/16 adjacent lanes read one line, 16 bytes each.  d_sink: u32[1]. */
+ * mode 1: line_bytes/16 adjacent lanes read one line, 16 bytes each;
+ * mode 2: as mode 0 but every next line depends on the data just loaded (a dependent chain per lane,
+ *         the shape of an LF loop).  n_accesses should be a multiple of 2^20.  d_sink: u32[1]. */
 int gdx_bench_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
                             uint64_t seed, uint32_t mode, void *d_sink, void *stream);
 

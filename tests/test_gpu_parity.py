@@ -191,8 +191,19 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
     return [qs[i] for i in order]
 
 
+@pytest.fixture(params=["pair", "quad", "lane"])
+def search_variant(request):
+    """Every search kernel variant must give the same answers."""
+    from genedex_amd import _lib
+
+    lib = _lib.load()
+    lib.gdx_debug_set_search_variant({"quad": 0, "lane": 1, "pair": 2}[request.param])
+    yield request.param
+    lib.gdx_debug_set_search_variant(2)
+
+
 @pytest.mark.parametrize("seed", range(10))
-def test_cursors_equal_oracle_batched_path(seed):
+def test_cursors_equal_oracle_batched_path(seed, search_variant):
     rng = np.random.default_rng(300 + seed)
     a = alph.ascii_dna_with_n()
     texts = random_texts(rng, len_max=20000, symbols=b"ACGTN" if seed % 2 else b"ACGT")
@@ -236,7 +247,7 @@ def test_locate_equals_oracle_and_naive(seed):
         assert {tuple(h) for h in g.locate(qs[k])} == naive_search(texts, qs[k])
 
 
-def test_status_codes_match_the_reference_panics():
+def test_status_codes_match_the_reference_panics(search_variant):
     a = alph.ascii_dna_with_n()
     texts = [b"ACGTNACGTTTGACA", b"NNACGT"]
     qs = [b"TNA", b"NAC", b"AXG", b"XGGGGGGG", b"ACGT", b"", b"Z"]
@@ -306,7 +317,7 @@ def test_invalid_construction_arguments():
         FmIndexConfig("i32").construct_index([], alph.ascii_dna())
 
 
-def test_medium_text_against_oracle():
+def test_medium_text_against_oracle(search_variant):
     """4 Mi symbols, 200k queries: full equality of intervals and hits with the CPU restatement."""
     from genedex_amd import synth
 
