@@ -224,6 +224,31 @@ __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
     return v;
 }
 
+// Line loads with an explicit cache policy (experiments): 0 = plain, 1 = sc1 (bypass the CU's L1),
+// 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's own counters do not see them.
+template <int kPolicy>
+__device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb, bool second, u32x4 &a, u32x4 &b)
+{
+    if (kPolicy == 0) {
+        a = *pa;
+        b = a;
+        if (second) b = *pb;
+        return;
+    }
+    if (kPolicy == 1) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a) : "v"(pa) : "memory");
+        if (second) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(b) : "v"(pb) : "memory");
+    } else if (kPolicy == 2) {
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(a) : "v"(pa) : "memory");
+        if (second) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(b) : "v"(pb) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(a) : "v"(pa) : "memory");
+        if (second) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(b) : "v"(pb) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+    if (!second) b = a;
+}
+
 struct PairTable {
     static __device__ __forceinline__ uint32_t partial(const u32x4 c, uint32_t sub, uint32_t pair, uint32_t nx,
                                                        uint32_t ny, uint32_t nz, uint32_t idx)
@@ -236,6 +261,7 @@ struct PairTable {
         return __popc(m16 & mask) + ((pair >> 1) == sub ? off : 0u);
     }
     // c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
+    template <int kPolicy = 0>
     static __device__ __forceinline__ void lf2(const IndexView &ix, const uint32_t *pair_count /*LDS copy*/,
                                                uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi, uint32_t &nlo,
                                                uint32_t &nhi)
@@ -249,9 +275,9 @@ struct PairTable {
         const uint32_t sb_lo = ix.pair_sb[(lo >> kSuperblockShift) * 16u + pair];
         const uint32_t sb_hi = ix.pair_sb[(hi >> kSuperblockShift) * 16u + pair];
         const uint32_t line_lo = lo >> kLineShift, line_hi = hi >> kLineShift;
-        const u32x4 a = ix.pair_lines[(static_cast<uint64_t>(line_lo) << 3) + sub];
-        u32x4 b = a;
-        if (line_hi != line_lo) b = ix.pair_lines[(static_cast<uint64_t>(line_hi) << 3) + sub];  // group-uniform
+        u32x4 a, b;
+        load_two_lines<kPolicy>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
+                                ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub, line_hi != line_lo, a, b);
         const uint32_t base = pair_count[pair];
         nlo = base + sb_lo + oct_sum(partial(a, sub, pair, nx, ny, nz, lo));
         nhi = base + sb_hi + oct_sum(partial(b, sub, pair, nx, ny, nz, hi));

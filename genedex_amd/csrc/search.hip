@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "common.hpp"
 #include "kernels.hpp"
 
 namespace gdx {
@@ -123,18 +124,53 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
+// len_range = {min, max} query length of a batch (query_length_range_kernel).  Batches of (nearly)
+// equal lengths run the lock-step kernel: the waves stay level-synchronous, so the first levels of the
+// search, whose lines are cache resident, cost cache latency instead of DRAM latency for the whole
+// wave.  Mixed-length batches run the streaming kernel, which keeps every lane busy.
+__device__ __forceinline__ bool lengths_are_uniform(const uint32_t *len_range)
+{
+    const uint32_t mn = len_range[0], mx = len_range[1];
+    return mx - mn <= mn / 4u;
+}
+
+__global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                                    uint32_t *__restrict__ len_range)
+{
+    uint32_t mn = 0xffffffffu, mx = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < nq; q += stride) {
+        const uint64_t len = qoff[q + 1] - qoff[q];
+        const uint32_t l = len > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(len);
+        mn = l < mn ? l : mn;
+        mx = l > mx ? l : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t omn = __shfl_xor(mn, off), omx = __shfl_xor(mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMin(&len_range[0], mn);
+        atomicMax(&len_range[1], mx);
+    }
+}
+
 // Backward search on pair lines: eight lanes per query, two LF steps per line fetch while both next
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
+template <int kPolicy>
 __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
                                                              uint32_t *__restrict__ out_end,
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
-                                                             unsigned long long *__restrict__ step_stats)
+                                                             unsigned long long *__restrict__ step_stats,
+                                                             const uint32_t *__restrict__ len_range, int run_if_uniform)
 {
+    if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
     constexpr int kGroup = 8;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
             if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
             if (c1 <= 4u && c2 - 1u < 4u) {
                 uint32_t nlo, nhi;
-                PairTable::lf2(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
+                PairTable::lf2<kPolicy>(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
                 if (nlo != nhi) {
                     lo = nlo;
                     hi = nhi;
@@ -213,6 +249,154 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
         }
+    }
+    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+}
+
+// The same search as search_pair_kernel, organised as a stream: every 8-lane group walks its own
+// sequence of queries (q, q + stride, ...) and starts the next one in the very iteration the current one
+// ends, so lanes never idle while the longest query of a wave finishes (early-terminating and
+// mixed-length batches, BASELINE workload 5).  The next query's offsets and its last two 8-byte windows
+// are requested two iterations / one iteration after the current query started and are consumed some 20
+// line fetches later, so starting a query costs no memory wait (with a lookup table: one).
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+                                                                    const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                                    uint32_t *__restrict__ out_start,
+                                                                    uint32_t *__restrict__ out_end,
+                                                                    uint32_t *__restrict__ out_count,
+                                                                    uint8_t *__restrict__ out_status,
+                                                                    unsigned long long *__restrict__ step_stats,
+                                                                    const uint32_t *__restrict__ len_range, int run_if_uniform)
+{
+    if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
+    constexpr int kGroup = 8;
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_count[257];
+    __shared__ uint32_t s_pair_count[16];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    if (threadIdx.x < 16) s_pair_count[threadIdx.x] = ix.pair_count[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint64_t *words = reinterpret_cast<const uint64_t *>(qbuf);
+    uint32_t lf_steps = 0;
+
+    // the query being searched
+    uint64_t q = 0, begin = 0, pos = 0;
+    uint32_t lo = 0, hi = 0, status = GDX_Q_OK;
+    QueryWindow win;
+    win.words = words;
+    win.cur = win.next = win.cur_word = win.first_word = 0;
+    bool have = false;
+    // the query staged behind it
+    uint64_t nx_q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup;
+    uint64_t nx_begin = 0, nx_end = 0, nx_cur = 0, nx_next = 0;
+    int nx_stage = 0;  // 0 nothing requested, 1 offsets requested, 2 windows requested
+
+    for (;;) {
+        // ---- stage the next query (loads issued here are not needed before a later iteration) ----
+        if (nx_stage == 1) {
+            const uint64_t len = nx_end - nx_begin;
+            const uint64_t t = len < static_cast<uint64_t>(ix.depth) ? len : static_cast<uint64_t>(ix.depth);
+            const uint64_t p = nx_end - t;
+            const uint64_t first_word = nx_begin >> 3;
+            const bool any = p > nx_begin;
+            const uint64_t cw = any ? ((p - 1) >> 3) : first_word;
+            nx_cur = any ? words[cw] : 0ull;
+            nx_next = (any && cw > first_word) ? words[cw - 1] : 0ull;
+            nx_stage = 2;
+        } else if (nx_stage == 0 && nx_q < nq) {
+            nx_begin = qoff[nx_q];
+            nx_end = qoff[nx_q + 1];
+            nx_stage = 1;
+        }
+        // ---- start it when the slot is free -------------------------------------------------------------
+        if (!have && nx_stage == 2) {
+            q = nx_q;
+            begin = nx_begin;
+            const uint64_t end = nx_end;
+            const uint64_t len = end - begin;
+            const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                     : static_cast<uint32_t>(ix.depth);
+            lo = 0;
+            hi = ix.n;
+            status = GDX_Q_OK;
+            if (t > 0) {  // lookup_table.rs:99-113
+                uint32_t idx = 0, factor = 1;
+                bool unsearchable = false;
+                for (uint32_t j = 0; j < t; j++) {
+                    const uint32_t d = s_dense[qbuf[end - t + j]];
+                    if (d == 0) status = GDX_Q_INVALID_SYMBOL;
+                    unsearchable |= (d - 1u >= k);
+                    idx += (d - 1u) * factor;
+                    factor *= k;
+                }
+                if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
+                if (status == GDX_Q_OK) {
+                    const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                    lo = v.x;
+                    hi = v.y;
+                } else {
+                    lo = hi = 0;
+                }
+            }
+            pos = end - t;
+            win.first_word = begin >> 3;
+            win.cur_word = pos > begin ? ((pos - 1) >> 3) : win.first_word;
+            win.cur = nx_cur;
+            win.next = nx_next;
+            have = true;
+            nx_q += stride;
+            nx_stage = 0;
+        }
+        // ---- one (double) LF step of the current query -------------------------------------------------
+        if (have) {
+            if (pos > begin && lo != hi) {
+                const uint32_t c1 = s_dense[win.get(pos - 1)];
+                if (c1 == 0) {  // alphabet.rs:195-198
+                    status = GDX_Q_INVALID_SYMBOL;
+                    lo = hi = 0;
+                } else {
+                    uint32_t c2 = 0;
+                    if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
+                    bool stepped = false;
+                    if (c1 <= 4u && c2 - 1u < 4u) {
+                        uint32_t nlo, nhi;
+                        PairTable::lf2<kPolicy>(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
+                        if (nlo != nhi) {
+                            lo = nlo;
+                            hi = nhi;
+                            pos -= 2;
+                            lf_steps += 2;
+                            stepped = true;
+                        }
+                    }
+                    if (!stepped) {  // single step: odd tail, N, or the step at which the interval empties
+                        uint32_t rlo, rhi;
+                        QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+                        const uint32_t cc = s_count[c1];
+                        lo = cc + rlo;
+                        hi = cc + rhi;
+                        pos--;
+                        lf_steps++;
+                    }
+                }
+            }
+            if (!(pos > begin && lo != hi)) {  // lib.rs:226-232: finished, or frozen at the empty interval
+                if (writer) {
+                    if (out_start) out_start[q] = lo;
+                    if (out_end) out_end[q] = hi;
+                    if (out_count) out_count[q] = hi - lo;
+                    if (out_status) out_status[q] = static_cast<uint8_t>(status);
+                }
+                have = false;
+            }
+        }
+        if (!__any(have || nx_stage != 0 || nx_q < nq)) break;
     }
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
@@ -341,18 +525,55 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                    hipStream_t stream, unsigned long long *d_step_stats)
 {
     if (nq == 0) return;
-    // GDX_SEARCH_OCC=<blocks per CU> (experiments): limits residency with a dynamic-LDS pad
+    // Residency of the group kernels: 6 blocks of 256 threads per CU, enforced with a dynamic-LDS pad.
+    // Measured on MI355X (hg38-scale, 100 M reads): 8 blocks/CU is 15-20 % slower than 6, 4 is 20 % slower
+    // (profiles/r01/search_variants.md).  GDX_SEARCH_OCC overrides.
     static const int occ = [] {
         const char *e = getenv("GDX_SEARCH_OCC");
-        const int v = e ? atoi(e) : 8;
+        const int v = e ? atoi(e) : 6;
         return v < 1 ? 1 : (v > 8 ? 8 : v);
     }();
     const unsigned lds_pad = occ == 8 ? 0u : (160u * 1024u / occ - 2048u);
     if (ix.layout == 0 && search_variant() == 2 && ix.pair_lines != nullptr) {
         uint64_t blocks = (nq * 8 + kBlock - 1) / kBlock;
         if (blocks > 256ull * occ) blocks = 256ull * occ;
-        hipLaunchKernelGGL(search_pair_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad, stream, ix,
-                           d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
+        // pair lines are fetched with sc1 (served by L2, no allocation in the CU's L1): +5 % measured;
+        // GDX_LOAD_POLICY=0|1|2|3 overrides (plain, sc1, nt, sc0 sc1)
+        static const int policy = [] {
+            const char *e = getenv("GDX_LOAD_POLICY");
+            return e ? atoi(e) : 1;
+        }();
+        // GDX_SEARCH_STREAM=0|1 forces the lock-step / streaming kernel; default: decided on the device from
+        // the spread of the query lengths (both kernels are enqueued, one of them returns at once)
+        static const int forced = [] {
+            const char *e = getenv("GDX_SEARCH_STREAM");
+            return e ? (e[0] == '0' ? 0 : 1) : -1;
+        }();
+        uint32_t *d_range = nullptr;
+        if (forced < 0) {
+            const uint32_t init[2] = {0xffffffffu, 0u};
+            GDX_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_range), sizeof(init), stream));
+            GDX_HIP(hipMemcpyAsync(d_range, init, sizeof(init), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, d_qoff, nq,
+                               d_range);
+        }
+#define GDX_PAIR(P)                                                                                                 \
+    do {                                                                                                            \
+        if (forced != 1)                                                                                            \
+            hipLaunchKernelGGL(search_pair_kernel<P>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad,   \
+                               stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,   \
+                               d_step_stats, d_range, 1);                                                           \
+        if (forced != 0)                                                                                            \
+            hipLaunchKernelGGL(search_pair_stream_kernel<P>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),     \
+                               lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count,        \
+                               d_out_status, d_step_stats, d_range, 0);                                             \
+    } while (0)
+        if (policy == 1) GDX_PAIR(1);
+        else if (policy == 2) GDX_PAIR(2);
+        else if (policy == 3) GDX_PAIR(3);
+        else GDX_PAIR(0);
+        if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
+#undef GDX_PAIR
     } else if (ix.layout == 0 && search_variant() != 1) {
         uint64_t blocks = (nq * 4 + kBlock - 1) / kBlock;
         if (blocks > 256ull * occ) blocks = 256ull * occ;
