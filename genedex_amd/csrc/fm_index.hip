@@ -253,109 +253,150 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
     }
 }
 
-// One block per superblock (512 lines); thread t builds lines 2t, 2t+1.  bwt1 / bwt0 must be readable
-// (zero padded) up to n_lines * 128 bytes.
+// Bit planes of one 64-position block of bwt1 / bwt0 (zero padded input) and its 16 pair + 4 single counts.
+struct PairBlock {
+    uint64_t p1[3], p0[3];
+};
+
+__device__ __forceinline__ PairBlock load_pair_block(const uint8_t *__restrict__ bwt1,
+                                                     const uint8_t *__restrict__ bwt0, uint64_t block)
+{
+    PairBlock pb;
+#pragma unroll
+    for (int k = 0; k < 3; k++) pb.p1[k] = pb.p0[k] = 0;
+    const uint4 *v1 = reinterpret_cast<const uint4 *>(bwt1 + block * 64);
+    const uint4 *v0 = reinterpret_cast<const uint4 *>(bwt0 + block * 64);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 a = v1[j], b = v0[j];
+        const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t s1 = (wa[w] >> (8 * k)) & 0xffu, s0 = (wb[w] >> (8 * k)) & 0xffu;
+                const int bit = j * 16 + w * 4 + k;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    pb.p1[pl] |= ((s1 >> pl) & 1ull) << bit;
+                    pb.p0[pl] |= ((s0 >> pl) & 1ull) << bit;
+                }
+            }
+        }
+    }
+    return pb;
+}
+
+__device__ __forceinline__ uint64_t symbol_mask(const uint64_t (&p)[3], int c)
+{
+    return ((c & 1) ? p[0] : ~p[0]) & ((c & 2) ? p[1] : ~p[1]) & ((c & 4) ? p[2] : ~p[2]);
+}
+
+// counts[0..15] = pairs (c2-1)*4 + (c1-1), counts[16..19] = singles c1 = 1..4
+__device__ __forceinline__ void count_pair_block(const PairBlock &pb, uint32_t (&counts)[20])
+{
+#pragma unroll
+    for (int c1 = 1; c1 <= 4; c1++) {
+        const uint64_t m1 = symbol_mask(pb.p1, c1);
+        counts[16 + c1 - 1] = __popcll(m1);
+#pragma unroll
+        for (int c2 = 1; c2 <= 4; c2++) counts[(c2 - 1) * 4 + (c1 - 1)] = __popcll(m1 & symbol_mask(pb.p0, c2));
+    }
+}
+
+// One block per superblock of 65536 positions = 1024 pair lines; thread t owns lines 4t .. 4t+3.
+// Pass 1 counts, a block-wide scan turns the per-thread totals into offsets inside the superblock,
+// pass 2 writes the lines with superblock-relative counts; add_pair_bases_kernel makes them absolute.
 __global__ __launch_bounds__(kBlock) void build_pair_lines_kernel(const uint8_t *__restrict__ bwt1,
                                                                   const uint8_t *__restrict__ bwt0, uint64_t n_lines,
                                                                   u32x4 *__restrict__ pair_lines,
                                                                   uint32_t *__restrict__ sb_totals)
 {
-    __shared__ uint32_t s_scan[16][kBlock];
+    __shared__ uint32_t s_scan[20][kBlock];
     const uint64_t sb = blockIdx.x;
     const uint32_t t = threadIdx.x;
-    uint32_t px[2][8], py[2][8], pz[2][8];  // packed plane words per 16-position chunk
-    uint32_t pair_sum[16];
+    const uint64_t first = sb * 1024 + 4ull * t;
+    uint32_t total[20];
 #pragma unroll
-    for (int p = 0; p < 16; p++) pair_sum[p] = 0;
-    uint32_t cnt0[16];  // pair counts of the first line
+    for (int k = 0; k < 20; k++) total[k] = 0;
+    for (int l = 0; l < 4; l++) {
+        if (first + l < n_lines) {
+            uint32_t c[20];
+            count_pair_block(load_pair_block(bwt1, bwt0, first + l), c);
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
-        uint32_t cnt[16];
-#pragma unroll
-        for (int p = 0; p < 16; p++) cnt[p] = 0;
-        if (line < n_lines) {
-            const uint4 *v1 = reinterpret_cast<const uint4 *>(bwt1 + line * 128);
-            const uint4 *v0 = reinterpret_cast<const uint4 *>(bwt0 + line * 128);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint4 a = v1[j], b = v0[j];
-                const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
-                uint32_t p1[3] = {0, 0, 0}, p0[3] = {0, 0, 0};
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t s1 = (wa[w] >> (8 * k)) & 0xffu, s0 = (wb[w] >> (8 * k)) & 0xffu;
-                        const int bit = w * 4 + k;
-#pragma unroll
-                        for (int pl = 0; pl < 3; pl++) {
-                            p1[pl] |= ((s1 >> pl) & 1u) << bit;
-                            p0[pl] |= ((s0 >> pl) & 1u) << bit;
-                        }
-                    }
-                }
-                px[l][j] = p1[0] | (p1[1] << 16);
-                py[l][j] = p1[2] | (p0[0] << 16);
-                pz[l][j] = p0[1] | (p0[2] << 16);
-                // pair (c2, c1), both in 1..4: match masks from the planes
-#pragma unroll
-                for (int c1 = 1; c1 <= 4; c1++) {
-                    const uint32_t m1 = ((c1 & 1) ? p1[0] : ~p1[0]) & ((c1 & 2) ? p1[1] : ~p1[1]) &
-                                        ((c1 & 4) ? p1[2] : ~p1[2]) & 0xffffu;
-#pragma unroll
-                    for (int c2 = 1; c2 <= 4; c2++) {
-                        const uint32_t m0 = ((c2 & 1) ? p0[0] : ~p0[0]) & ((c2 & 2) ? p0[1] : ~p0[1]) &
-                                            ((c2 & 4) ? p0[2] : ~p0[2]);
-                        cnt[(c2 - 1) * 4 + (c1 - 1)] += __popc(m1 & m0);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) px[l][j] = py[l][j] = pz[l][j] = 0;
-        }
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            pair_sum[p] += cnt[p];
-            if (l == 0) cnt0[p] = cnt[p];
+            for (int k = 0; k < 20; k++) total[k] += c[k];
         }
     }
 #pragma unroll
-    for (int p = 0; p < 16; p++) s_scan[p][t] = pair_sum[p];
+    for (int k = 0; k < 20; k++) s_scan[k][t] = total[k];
     __syncthreads();
     for (int off = 1; off < kBlock; off <<= 1) {
-        uint32_t add[16];
+        uint32_t add[20];
 #pragma unroll
-        for (int p = 0; p < 16; p++) add[p] = t >= static_cast<uint32_t>(off) ? s_scan[p][t - off] : 0u;
+        for (int k = 0; k < 20; k++) add[k] = t >= static_cast<uint32_t>(off) ? s_scan[k][t - off] : 0u;
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 16; p++) s_scan[p][t] += add[p];
+        for (int k = 0; k < 20; k++) s_scan[k][t] += add[k];
         __syncthreads();
     }
-    uint32_t before[16];
+    uint32_t before[20];
 #pragma unroll
-    for (int p = 0; p < 16; p++) before[p] = s_scan[p][t] - pair_sum[p];
+    for (int k = 0; k < 20; k++) before[k] = s_scan[k][t] - total[k];
     if (t == kBlock - 1) {
 #pragma unroll
-        for (int p = 0; p < 16; p++) sb_totals[sb * 16 + p] = s_scan[p][t];
+        for (int k = 0; k < 20; k++) sb_totals[sb * 20 + k] = s_scan[k][t];
     }
+    for (int l = 0; l < 4; l++) {
+        const uint64_t line = first + l;
+        if (line >= n_lines) break;
+        const PairBlock pb = load_pair_block(bwt1, bwt0, line);
+        uint32_t c[20];
+        count_pair_block(pb, c);
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-        const uint64_t line = sb * kLinesPerSuperblock + 2 * t + l;
-        if (line < n_lines) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                u32x4 chunk;
-                chunk.x = px[l][j];
-                chunk.y = py[l][j];
-                chunk.z = pz[l][j];
-                chunk.w = (before[2 * j] & 0xffffu) | (before[2 * j + 1] << 16);
-                pair_lines[line * 8 + j] = chunk;
-            }
+        for (int j = 0; j < 8; j++) {
+            const uint32_t sh = 8 * j;
+            const uint32_t single = before[16 + (j >> 1)];
+            u32x4 chunk;
+            chunk.x = static_cast<uint32_t>((pb.p1[0] >> sh) & 0xff) | (static_cast<uint32_t>((pb.p1[1] >> sh) & 0xff) << 8) |
+                      (static_cast<uint32_t>((pb.p1[2] >> sh) & 0xff) << 16) |
+                      (static_cast<uint32_t>((pb.p0[0] >> sh) & 0xff) << 24);
+            chunk.y = static_cast<uint32_t>((pb.p0[1] >> sh) & 0xff) | (static_cast<uint32_t>((pb.p0[2] >> sh) & 0xff) << 8) |
+                      ((((j & 1) ? (single >> 16) : single) & 0xffffu) << 16);
+            chunk.z = before[2 * j];
+            chunk.w = before[2 * j + 1];
+            pair_lines[line * 8 + j] = chunk;
         }
 #pragma unroll
-        for (int p = 0; p < 16; p++) before[p] += cnt0[p];
+        for (int k = 0; k < 20; k++) before[k] += c[k];
+    }
+}
+
+// counts in the lines are relative to their superblock: add base[k] + (prefix of the superblock totals)
+// so that a line directly yields LF values (pairs: base = C2, singles: base = C).
+__global__ __launch_bounds__(kBlock) void add_pair_bases_kernel(u32x4 *__restrict__ pair_lines, uint64_t n_lines,
+                                                                const uint32_t *__restrict__ sb_prefix,
+                                                                const uint32_t *__restrict__ base)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t line = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; line < n_lines; line += stride) {
+        const uint32_t *pre = sb_prefix + (line >> 10) * 20;
+        u32x4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = pair_lines[line * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c[j].z += pre[2 * j] + base[2 * j];
+            c[j].w += pre[2 * j + 1] + base[2 * j + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {  // singles: 16-bit halves in chunks 2s (low) and 2s+1 (high)
+            const uint32_t rel = (c[2 * s].y >> 16) | ((c[2 * s + 1].y >> 16) << 16);
+            const uint32_t abs = rel + pre[16 + s] + base[16 + s];
+            c[2 * s].y = (c[2 * s].y & 0xffffu) | ((abs & 0xffffu) << 16);
+            c[2 * s + 1].y = (c[2 * s + 1].y & 0xffffu) | ((abs >> 16) << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) pair_lines[line * 8 + j] = c[j];
     }
 }
 
@@ -490,7 +531,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return pair_lines_.bytes() + pair_sb_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -601,14 +642,15 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         DeviceBuffer<uint8_t> d_bwt0(padded);
         GDX_HIP(hipMemsetAsync(d_bwt0.get(), 0, padded, stream));
         hipLaunchKernelGGL(derive_bwt0_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt0.get());
-        pair_lines_.alloc(n_lines * 8);
-        pair_sb_.alloc(n_sb * 16);
+        const uint64_t n_plines = div_ceil(len, 64);
+        pair_lines_.alloc(n_plines * 8);
+        DeviceBuffer<uint32_t> d_sbp(n_sb * 20);
         hipLaunchKernelGGL(build_pair_lines_kernel, dim3(static_cast<unsigned>(n_sb)), dim3(kBlock), 0, stream,
-                           d_bwt_padded, d_bwt0.get(), n_lines, pair_lines_.get(), pair_sb_.get());
-        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(64), 0, stream, pair_sb_.get(), n_sb, 16u);
-        // C2[c2 c1] = C[c2] + rank(c2, C[c1]): first SA slot of the 2-mer c2 c1
+                           d_bwt_padded, d_bwt0.get(), n_plines, pair_lines_.get(), d_sbp.get());
+        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(64), 0, stream, d_sbp.get(), n_sb, 20u);
+        // bases: C2[c2 c1] = C[c2] + rank(c2, C[c1]) (first SA slot of the 2-mer c2 c1) and C[c1]
         uint8_t sym[16];
-        uint32_t at[16], r[16];
+        uint32_t at[16], r[16], base[20];
         for (int c2 = 1; c2 <= 4; c2++)
             for (int c1 = 1; c1 <= 4; c1++) {
                 const int p = (c2 - 1) * 4 + (c1 - 1);
@@ -617,17 +659,21 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
                 at[p] = static_cast<uint32_t>(ok ? count_host_[c1] : 0);
             }
         DeviceBuffer<uint8_t> d_sym(16);
-        DeviceBuffer<uint32_t> d_at(16), d_r(16), d_err(1);
+        DeviceBuffer<uint32_t> d_at(16), d_r(16), d_err(1), d_base(20);
         GDX_HIP(hipMemcpyAsync(d_sym.get(), sym, 16, hipMemcpyHostToDevice, stream));
         GDX_HIP(hipMemcpyAsync(d_at.get(), at, sizeof(at), hipMemcpyHostToDevice, stream));
         GDX_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(uint32_t), stream));
         launch_rank_many(view_, d_sym.get(), d_at.get(), 16, d_r.get(), d_err.get(), stream);
         GDX_HIP(hipMemcpyAsync(r, d_r.get(), sizeof(r), hipMemcpyDeviceToHost, stream));
         GDX_HIP(hipStreamSynchronize(stream));
+        for (int p = 0; p < 16; p++) base[p] = static_cast<uint32_t>(count_host_[sym[p]]) + r[p];
+        for (int c = 1; c <= 4; c++) base[16 + c - 1] = c < sigma ? static_cast<uint32_t>(count_host_[c]) : 0u;
+        GDX_HIP(hipMemcpyAsync(d_base.get(), base, sizeof(base), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(add_pair_bases_kernel, dim3(grid_for_items(n_plines)), dim3(kBlock), 0, stream,
+                           pair_lines_.get(), n_plines, d_sbp.get(), d_base.get());
+        GDX_HIP(hipStreamSynchronize(stream));
         GDX_HIP(hipGetLastError());
-        for (int p = 0; p < 16; p++) view_.pair_count[p] = static_cast<uint32_t>(count_host_[sym[p]]) + r[p];
         view_.pair_lines = pair_lines_.get();
-        view_.pair_sb = pair_sb_.get();
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }

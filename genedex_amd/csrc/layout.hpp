@@ -38,10 +38,8 @@ struct IndexView {
     const uint64_t *g_planes;     // generic: [n_blocks64][nbits]       (layout 1)
     const uint16_t *g_block_off;  // generic: [n_blocks64][sigma]
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
-    // --- pair lines: two LF steps per line fetch (layout 0 with <= 4 searchable symbols) -----
-    const u32x4 *pair_lines;      // [n_lines][8], null when absent
-    const uint32_t *pair_sb;      // [n_superblocks][16] absolute pair counts before the superblock
-    uint32_t pair_count[16];      // C2[(c2-1)*4 + (c1-1)] = first SA slot of the 2-mer c2 c1
+    // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
+    const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -206,15 +204,22 @@ struct QuadLineTable {
 };
 
 // ---------------------------------------------------------------------------------------
-// pair lines: one 128-byte line per 128 BWT positions holds the bit planes of BOTH preceding symbols
-// (bwt1[i] = text[SA[i]-1], bwt0[i] = text[SA[i]-2]) and the block offsets of the 16 pairs of
-// searchable symbols, so that two LF steps cost one line fetch:
-//     LF(c2, LF(c1, i)) = C2[c2 c1] + #{ j < i : bwt0[j] = c2 and bwt1[j] = c1 }.
-// A random 128-byte line costs the memory system the same as a random 64-byte line (one DRAM row
-// activation either way), so this halves the activations of the deep levels of a search.
-// Chunk j (16 B, one lane of an 8-lane group) covers positions [16j, 16j+16):
-//   x = plane0(bwt1) | plane1(bwt1) << 16,  y = plane2(bwt1) | plane0(bwt0) << 16,
-//   z = plane1(bwt0) | plane2(bwt0) << 16,  w = offset[pair 2j] | offset[pair 2j+1] << 16.
+// pair lines: one 128-byte line per 64 BWT positions holds the bit planes of BOTH preceding symbols
+// (bwt1[i] = text[SA[i]-1], bwt0[i] = text[SA[i]-2]), the ABSOLUTE number of occurrences of each of the
+// 16 pairs of symbols 1..4 before the line -- with C2 already added -- and the same for the 4 single
+// symbols, so that
+//     two LF steps  LF(c2, LF(c1, i)) = pair[c2 c1] + #{ j in line, j < i : bwt0[j] = c2, bwt1[j] = c1 }
+//     one LF step   LF(c1, i)         = single[c1]  + #{ j in line, j < i : bwt1[j] = c1 }
+// each cost exactly one 128-byte fetch and nothing else (no superblock table).  Every DRAM request of
+// this GPU is 128 bytes wide whatever the load asked for (measured: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ
+// for 64-byte gathers), so the line is the natural unit, and the search of a read becomes ~len/2 + 6
+// line fetches.  8 bits per symbol; symbols outside 1..4 (sentinel, N) go through the rank lines.
+// Chunk j (16 B, one lane of an 8-lane group) covers positions [8j, 8j+8) of the line:
+//   x = b1p0 | b1p1 << 8 | b1p2 << 16 | b0p0 << 24      (b1pK / b0pK: plane K of bwt1 / bwt0, 8 positions)
+//   y = b0p1 | b0p2 << 8 | (16 bits of single[1 + j/2], low half if j is even) << 16
+//   z = pair[2j], w = pair[2j+1]                          (pair index = (c2-1)*4 + (c1-1))
+
+constexpr uint32_t kPairLineShift = 6;  // 64 positions per pair line
 
 __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
 {
@@ -224,8 +229,8 @@ __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
     return v;
 }
 
-// Line loads with an explicit cache policy (experiments): 0 = plain, 1 = sc1 (bypass the CU's L1),
-// 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's own counters do not see them.
+// Line loads with an explicit cache policy: 0 = plain, 1 = sc1 (served by L2, no allocation in the CU's
+// L1), 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's counters do not see them.
 template <int kPolicy>
 __device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb, bool second, u32x4 &a, u32x4 &b)
 {
@@ -250,37 +255,64 @@ __device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb,
 }
 
 struct PairTable {
-    static __device__ __forceinline__ uint32_t partial(const u32x4 c, uint32_t sub, uint32_t pair, uint32_t nx,
-                                                       uint32_t ny, uint32_t nz, uint32_t idx)
+    static __device__ __forceinline__ uint32_t low_mask(uint32_t idx, uint32_t sub)
     {
-        const uint32_t m32 = (c.x ^ nx) & (c.y ^ ny) & (c.z ^ nz);
-        const uint32_t m16 = m32 & (m32 >> 16) & 0xffffu;
-        const int32_t bits = static_cast<int32_t>(idx & 127u) - 16 * static_cast<int32_t>(sub);
-        const uint32_t mask = bits >= 16 ? 0xffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
-        const uint32_t off = (pair & 1u) ? (c.w >> 16) : (c.w & 0xffffu);
-        return __popc(m16 & mask) + ((pair >> 1) == sub ? off : 0u);
+        const int32_t bits = static_cast<int32_t>(idx & 63u) - 8 * static_cast<int32_t>(sub);
+        return bits >= 8 ? 0xffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
     }
-    // c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
-    template <int kPolicy = 0>
-    static __device__ __forceinline__ void lf2(const IndexView &ix, const uint32_t *pair_count /*LDS copy*/,
-                                               uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi, uint32_t &nlo,
-                                               uint32_t &nhi)
+    // two LF steps: c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
+    template <int kPolicy>
+    static __device__ __forceinline__ void lf2(const IndexView &ix, uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi,
+                                               uint32_t &nlo, uint32_t &nhi)
     {
         const uint32_t sub = threadIdx.x & 7u;
         const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
-        const uint32_t h = 0xffffu;
-        const uint32_t nx = ((c1 & 1u) ? 0u : h) | (((c1 & 2u) ? 0u : h) << 16);
-        const uint32_t ny = ((c1 & 4u) ? 0u : h) | (((c2 & 1u) ? 0u : h) << 16);
-        const uint32_t nz = ((c2 & 2u) ? 0u : h) | (((c2 & 4u) ? 0u : h) << 16);
-        const uint32_t sb_lo = ix.pair_sb[(lo >> kSuperblockShift) * 16u + pair];
-        const uint32_t sb_hi = ix.pair_sb[(hi >> kSuperblockShift) * 16u + pair];
-        const uint32_t line_lo = lo >> kLineShift, line_hi = hi >> kLineShift;
+        const uint32_t f = 0xffu;
+        const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16) |
+                            (((c2 & 1u) ? 0u : f) << 24);
+        const uint32_t ny = ((c2 & 2u) ? 0u : f) | (((c2 & 4u) ? 0u : f) << 8);
+        const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
         u32x4 a, b;
         load_two_lines<kPolicy>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
                                 ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub, line_hi != line_lo, a, b);
-        const uint32_t base = pair_count[pair];
-        nlo = base + sb_lo + oct_sum(partial(a, sub, pair, nx, ny, nz, lo));
-        nhi = base + sb_hi + oct_sum(partial(b, sub, pair, nx, ny, nz, hi));
+        const bool owner = (pair >> 1) == sub;
+        {
+            const uint32_t tx = a.x ^ nx, ty = a.y ^ ny;
+            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & (tx >> 24) & ty & (ty >> 8) & 0xffu;
+            const uint32_t cnt = (pair & 1u) ? a.w : a.z;
+            nlo = oct_sum(__popc(m & low_mask(lo, sub)) + (owner ? cnt : 0u));
+        }
+        {
+            const uint32_t tx = b.x ^ nx, ty = b.y ^ ny;
+            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & (tx >> 24) & ty & (ty >> 8) & 0xffu;
+            const uint32_t cnt = (pair & 1u) ? b.w : b.z;
+            nhi = oct_sum(__popc(m & low_mask(hi, sub)) + (owner ? cnt : 0u));
+        }
+    }
+    // one LF step with a symbol in 1..4
+    template <int kPolicy>
+    static __device__ __forceinline__ void lf1(const IndexView &ix, uint32_t c1, uint32_t lo, uint32_t hi,
+                                               uint32_t &nlo, uint32_t &nhi)
+    {
+        const uint32_t sub = threadIdx.x & 7u;
+        const uint32_t f = 0xffu;
+        const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16);
+        const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
+        u32x4 a, b;
+        load_two_lines<kPolicy>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
+                                ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub, line_hi != line_lo, a, b);
+        const bool owner = (sub >> 1) == (c1 - 1u);
+        const uint32_t shift = (sub & 1u) * 16u;
+        {
+            const uint32_t tx = a.x ^ nx;
+            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & 0xffu;
+            nlo = oct_sum(__popc(m & low_mask(lo, sub)) + (owner ? ((a.y >> 16) << shift) : 0u));
+        }
+        {
+            const uint32_t tx = b.x ^ nx;
+            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & 0xffu;
+            nhi = oct_sum(__popc(m & low_mask(hi, sub)) + (owner ? ((b.y >> 16) << shift) : 0u));
+        }
     }
 };
 

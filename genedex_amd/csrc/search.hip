@@ -174,10 +174,8 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
     constexpr int kGroup = 8;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
-    __shared__ uint32_t s_pair_count[16];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    if (threadIdx.x < 16) s_pair_count[threadIdx.x] = ix.pair_count[threadIdx.x];
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
             if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
             if (c1 <= 4u && c2 - 1u < 4u) {
                 uint32_t nlo, nhi;
-                PairTable::lf2<kPolicy>(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
+                PairTable::lf2<kPolicy>(ix, c2, c1, lo, hi, nlo, nhi);
                 if (nlo != nhi) {
                     lo = nlo;
                     hi = nhi;
@@ -235,11 +233,15 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
                 // the interval empties within these two steps: fall through to single steps so that the
                 // frozen interval is the one the reference reports
             }
-            uint32_t rlo, rhi;
-            QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
-            const uint32_t cc = s_count[c1];
-            lo = cc + rlo;
-            hi = cc + rhi;
+            if (c1 <= 4u) {
+                PairTable::lf1<kPolicy>(ix, c1, lo, hi, lo, hi);
+            } else {  // a symbol outside 1..4 (N): rank lines
+                uint32_t rlo, rhi;
+                QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+                const uint32_t cc = s_count[c1];
+                lo = cc + rlo;
+                hi = cc + rhi;
+            }
             pos--;
             lf_steps++;
         }
@@ -273,10 +275,8 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
     constexpr int kGroup = 8;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
-    __shared__ uint32_t s_pair_count[16];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    if (threadIdx.x < 16) s_pair_count[threadIdx.x] = ix.pair_count[threadIdx.x];
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
                     bool stepped = false;
                     if (c1 <= 4u && c2 - 1u < 4u) {
                         uint32_t nlo, nhi;
-                        PairTable::lf2<kPolicy>(ix, s_pair_count, c2, c1, lo, hi, nlo, nhi);
+                        PairTable::lf2<kPolicy>(ix, c2, c1, lo, hi, nlo, nhi);
                         if (nlo != nhi) {
                             lo = nlo;
                             hi = nhi;
@@ -376,11 +376,15 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
                         }
                     }
                     if (!stepped) {  // single step: odd tail, N, or the step at which the interval empties
-                        uint32_t rlo, rhi;
-                        QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
-                        const uint32_t cc = s_count[c1];
-                        lo = cc + rlo;
-                        hi = cc + rhi;
+                        if (c1 <= 4u) {
+                            PairTable::lf1<kPolicy>(ix, c1, lo, hi, lo, hi);
+                        } else {
+                            uint32_t rlo, rhi;
+                            QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+                            const uint32_t cc = s_count[c1];
+                            lo = cc + rlo;
+                            hi = cc + rhi;
+                        }
                         pos--;
                         lf_steps++;
                     }
@@ -525,18 +529,25 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                    hipStream_t stream, unsigned long long *d_step_stats)
 {
     if (nq == 0) return;
-    // Residency of the group kernels: 6 blocks of 256 threads per CU, enforced with a dynamic-LDS pad.
-    // Measured on MI355X (hg38-scale, 100 M reads): 8 blocks/CU is 15-20 % slower than 6, 4 is 20 % slower
-    // (profiles/r01/search_variants.md).  GDX_SEARCH_OCC overrides.
-    static const int occ = [] {
-        const char *e = getenv("GDX_SEARCH_OCC");
-        const int v = e ? atoi(e) : 6;
-        return v < 1 ? 1 : (v > 8 ? 8 : v);
-    }();
-    const unsigned lds_pad = occ == 8 ? 0u : (160u * 1024u / occ - 2048u);
+    // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
+    // profiles/r01/search_variants.md): many short-lived blocks beat a resident grid -- 65536 blocks: 78 ms,
+    // 1792 (7 per CU): 89 ms, 2048 (8 per CU, all resident, lock-step): 112 ms.  So: about 48 queries per
+    // group, at most 65536 blocks, never fewer blocks than groups need.
+    // Experiments: GDX_SEARCH_GRID = absolute number of blocks, GDX_SEARCH_PAD = dynamic LDS bytes per block.
+    static const long grid_override = [] { const char *e = getenv("GDX_SEARCH_GRID"); return e ? atol(e) : 0L; }();
+    static const long pad_override = [] { const char *e = getenv("GDX_SEARCH_PAD"); return e ? atol(e) : 0L; }();
+    const unsigned lds_pad = static_cast<unsigned>(pad_override);
+    auto group_grid = [&](uint64_t groups_per_block) {
+        const uint64_t needed = (nq + groups_per_block - 1) / groups_per_block;
+        uint64_t blocks = (nq + groups_per_block * 48 - 1) / (groups_per_block * 48);
+        if (blocks < 1792) blocks = 1792;
+        if (blocks > 65536) blocks = 65536;
+        if (blocks > needed) blocks = needed;
+        if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
+        return static_cast<unsigned>(blocks);
+    };
     if (ix.layout == 0 && search_variant() == 2 && ix.pair_lines != nullptr) {
-        uint64_t blocks = (nq * 8 + kBlock - 1) / kBlock;
-        if (blocks > 256ull * occ) blocks = 256ull * occ;
+        const unsigned blocks = group_grid(kBlock / 8);
         // pair lines are fetched with sc1 (served by L2, no allocation in the CU's L1): +5 % measured;
         // GDX_LOAD_POLICY=0|1|2|3 overrides (plain, sc1, nt, sc0 sc1)
         static const int policy = [] {
@@ -560,11 +571,11 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
 #define GDX_PAIR(P)                                                                                                 \
     do {                                                                                                            \
         if (forced != 1)                                                                                            \
-            hipLaunchKernelGGL(search_pair_kernel<P>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad,   \
+            hipLaunchKernelGGL(search_pair_kernel<P>, dim3(blocks), dim3(kBlock), lds_pad,   \
                                stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,   \
                                d_step_stats, d_range, 1);                                                           \
         if (forced != 0)                                                                                            \
-            hipLaunchKernelGGL(search_pair_stream_kernel<P>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),     \
+            hipLaunchKernelGGL(search_pair_stream_kernel<P>, dim3(blocks), dim3(kBlock),     \
                                lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count,        \
                                d_out_status, d_step_stats, d_range, 0);                                             \
     } while (0)
@@ -575,9 +586,8 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
 #undef GDX_PAIR
     } else if (ix.layout == 0 && search_variant() != 1) {
-        uint64_t blocks = (nq * 4 + kBlock - 1) / kBlock;
-        if (blocks > 256ull * occ) blocks = 256ull * occ;
-        hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds_pad,
+        const unsigned blocks = group_grid(kBlock / 4);
+        hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(blocks), dim3(kBlock), lds_pad,
                            stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,
                            d_step_stats);
     } else if (ix.layout == 0) {
