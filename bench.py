@@ -169,10 +169,15 @@ def main():
     # ---- algorithmic bytes, counted by an extra, untimed pass ------------------
     lf_steps = eng.search_lf_steps(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
-    roofline = {"bound": "hbm", "kernel": "search_kernel<LineTable>", "achieved": search_bytes / (search_ms / 1e3) / 1e9,
+    variant = os.environ.get("GDX_SEARCH_VARIANT", "pair")
+    uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
+    kernel_name = {"pair": "search_pair_kernel<sc1>" if uniform else "search_pair_stream_kernel<sc1>",
+                   "quad": "search_kernel<QuadLineTable,4>", "lane": "search_kernel<LineTable,1>"}[variant]
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": search_bytes, "lf_steps_per_launch": lf_steps,
                 "avg_launch_ms": search_ms}
+    roofline.update(pmc_traffic(kernel_name, args, wl, nq))
     locate_roofline = None
     if do_locate and total_hits:
         walk_steps = eng.locate_walk_steps(out, nq, total_hits, hits, workspace)
@@ -225,6 +230,26 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_name, args, wl, nq):
+    """HBM traffic of the search kernel per launch from the committed rocprofv3 PMC summary of this very
+    configuration (FETCH_SIZE cannot be read from inside the process).  Correction per
+    MI355X_MICROARCH.md section HBM and tools/calibrate_fetch_size.sh: every DRAM request of this GPU is
+    128 bytes (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ also for 64-byte gathers) and FETCH_SIZE tallies 64 bytes
+    per request, so read bytes = 2 * FETCH_SIZE[KB] * 1024.  The PMC pass runs fewer queries; traffic per
+    query is scaled to this launch."""
+    path = os.path.join(ROOT, "profiles", "r01", "search_pmc_final.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        if (pmc["workload"], pmc["lookup_depth"], pmc["kernel"]) != (args.workload, args.lookup_depth, kernel_name):
+            return {"traffic": None}
+        per_query = (2 * pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024 / pmc["queries_per_launch"]
+        return {"traffic": per_query * nq, "traffic_source": "profiles/r01/search_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / "
+                "WRITE_SIZE, separate passes, FETCH_SIZE doubled: all requests are 128 B)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
 
 
 def verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, n_check):

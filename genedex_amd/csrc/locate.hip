@@ -5,6 +5,7 @@
 // sizes -> hit_offsets, (2) every hit slot learns its query through a scattered head marker +
 // inclusive max-scan, then walks independently, so load balance does not depend on how the hits
 // are distributed over the queries.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -153,7 +154,9 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                        d_hit_offsets, heads);
     GDX_HIP(rocprim::inclusive_scan(scan_temp, scan_bytes, heads, heads, static_cast<size_t>(total_hits),
                                     rocprim::maximum<uint32_t>(), stream));
-    const unsigned grid = grid_for_items(total_hits);
+    // GDX_LOCATE_GRID (experiments): absolute number of blocks of the walk kernel
+    static const long grid_override = [] { const char *e = getenv("GDX_LOCATE_GRID"); return e ? atol(e) : 0L; }();
+    const unsigned grid = grid_override > 0 ? static_cast<unsigned>(grid_override) : grid_for_items(total_hits);
 #define GDX_LOCATE(TABLE, WIDE)                                                                              \
     hipLaunchKernelGGL((locate_kernel<TABLE, WIDE>), dim3(grid), dim3(kBlock), 0, stream, ix, d_start, \
                        d_hit_offsets, heads, total_hits, d_hits, d_step_stats)

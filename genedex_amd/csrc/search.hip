@@ -405,27 +405,38 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
-template <class Table>
+// Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
+// search_kernel; with pair lines (kPair) a symbol in 1..4 costs one 128-byte fetch and no table lookup.
+template <class Table, int kGroup, bool kPair>
 __global__ __launch_bounds__(kBlock) void extend_front_kernel(IndexView ix, uint32_t *__restrict__ start,
                                                               uint32_t *__restrict__ end,
                                                               const uint8_t *__restrict__ io_symbols, uint64_t m,
                                                               uint8_t *__restrict__ out_status)
 {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; i < m; i += stride) {
         uint32_t lo = start[i], hi = end[i];
         const uint32_t c = ix.io_to_dense[io_symbols[i]];  // cursor.rs:34-38: translated before anything else
         uint32_t status = GDX_Q_OK;
         if (c == 0) {
             status = GDX_Q_INVALID_SYMBOL;
         } else if (lo != hi) {  // cursor.rs:41-48
-            uint32_t rlo, rhi;
-            Table::rank2(ix, c, lo, hi, rlo, rhi);
-            const uint32_t cc = ix.count[c];
-            start[i] = cc + rlo;
-            end[i] = cc + rhi;
+            if (kPair && c <= 4u) {
+                PairTable::lf1<1>(ix, c, lo, hi, lo, hi);
+            } else {
+                uint32_t rlo, rhi;
+                Table::rank2(ix, c, lo, hi, rlo, rhi);
+                const uint32_t cc = ix.count[c];
+                lo = cc + rlo;
+                hi = cc + rhi;
+            }
+            if (writer) {
+                start[i] = lo;
+                end[i] = hi;
+            }
         }
-        if (out_status) out_status[i] = static_cast<uint8_t>(status);
+        if (out_status && writer) out_status[i] = static_cast<uint8_t>(status);
     }
 }
 
@@ -603,8 +614,16 @@ void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end
                          uint64_t m, uint8_t *d_out_status, hipStream_t stream)
 {
     if (m == 0) return;
-    GDX_DISPATCH_TABLE(ix, extend_front_kernel, grid_for_items(m), stream, ix, d_start, d_end, d_io_symbols, m,
-                       d_out_status);
+    if (ix.layout == 0 && ix.pair_lines != nullptr) {
+        hipLaunchKernelGGL((extend_front_kernel<QuadLineTable, 8, true>), dim3(grid_for_items(m * 8)), dim3(kBlock), 0,
+                           stream, ix, d_start, d_end, d_io_symbols, m, d_out_status);
+    } else if (ix.layout == 0) {
+        hipLaunchKernelGGL((extend_front_kernel<QuadLineTable, 4, false>), dim3(grid_for_items(m * 4)), dim3(kBlock), 0,
+                           stream, ix, d_start, d_end, d_io_symbols, m, d_out_status);
+    } else {
+        hipLaunchKernelGGL((extend_front_kernel<GenericTable, 1, false>), dim3(grid_for_items(m)), dim3(kBlock), 0,
+                           stream, ix, d_start, d_end, d_io_symbols, m, d_out_status);
+    }
 }
 
 void launch_rank_many(const IndexView &ix, const uint8_t *d_symbols, const uint32_t *d_idx, uint64_t m,
