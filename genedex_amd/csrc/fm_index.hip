@@ -253,6 +253,29 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
     }
 }
 
+// jump table (layout.hpp try_jump): jump[i] = {LF^8(i), codes of the 8 symbols preceding suffix SA[i]},
+// obtained by eight LF steps on the rank lines.  A row whose walk meets a sentinel gets code 0, which no
+// valid query can equal.
+__global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2 *__restrict__ jump)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
+        uint32_t row = static_cast<uint32_t>(p), code = 0;
+        bool ok = true;
+        for (uint32_t k = 0; k < kJumpSymbols; k++) {
+            uint32_t r;
+            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
+            if (c == 0) {
+                ok = false;
+                break;
+            }
+            code |= c << (3u * k);
+            row = ix.count[c] + r;
+        }
+        jump[p] = ok ? make_uint2(row, code) : make_uint2(0u, 0u);
+    }
+}
+
 // Bit planes of one 64-position block of bwt1 / bwt0 (zero padded input) and its 16 pair + 4 single counts.
 struct PairBlock {
     uint64_t p1[3], p0[3];
@@ -531,7 +554,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return jump_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -674,6 +697,14 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         GDX_HIP(hipStreamSynchronize(stream));
         GDX_HIP(hipGetLastError());
         view_.pair_lines = pair_lines_.get();
+        const char *no_jump = getenv("GDX_NO_JUMP_TABLE");
+        if (!(no_jump && no_jump[0] == '1')) {
+            jump_.alloc(n_);
+            hipLaunchKernelGGL(derive_jump_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, jump_.get());
+            GDX_HIP(hipStreamSynchronize(stream));
+            GDX_HIP(hipGetLastError());
+            view_.jump = jump_.get();
+        }
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }

@@ -40,6 +40,8 @@ struct IndexView {
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
+    // --- jump table: kJumpSymbols LF steps of a one-row interval per fetch ----------------------
+    const uint2 *jump;            // [n] {LF^8(i), 8 preceding symbols as 3-bit codes}, null when absent
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -220,6 +222,7 @@ struct QuadLineTable {
 //   z = pair[2j], w = pair[2j+1]                          (pair index = (c2-1)*4 + (c1-1))
 
 constexpr uint32_t kPairLineShift = 6;  // 64 positions per pair line
+constexpr uint32_t kJumpSymbols = 8;    // LF steps folded into one jump-table entry
 
 __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
 {

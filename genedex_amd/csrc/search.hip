@@ -44,7 +44,40 @@ struct QueryWindow {
         }
         return static_cast<uint32_t>(cur >> ((at & 7u) * 8u)) & 0xffu;
     }
+    // the 8 bytes [pos-8, pos) (byte k of the result = query byte pos-8+k) without moving the window;
+    // requires get(pos-1) to have been called and pos-8 >= begin of the query
+    __device__ __forceinline__ uint64_t peek8(uint64_t pos) const
+    {
+        const uint32_t s = static_cast<uint32_t>(pos - (cur_word << 3));  // 1..8
+        return s >= 8u ? cur : ((next >> (8u * s)) | (cur << (64u - 8u * s)));
+    }
 };
+
+// One-row intervals (the usual state of a read after ~16 symbols) advance kJumpSymbols LF steps with one
+// 8-byte fetch: jump[i] = {LF^8(i), the 8 symbols preceding suffix SA[i]}.  If the next 8 query symbols
+// equal the stored ones the interval becomes [LF^8(i), LF^8(i)+1); otherwise the interval empties within
+// these 8 steps and the caller finishes on the pair lines, which yields the reference's frozen interval.
+// Returns true when the jump was taken.
+__device__ __forceinline__ bool try_jump(const IndexView &ix, const uint8_t *s_dense, QueryWindow &win, uint64_t pos,
+                                         uint32_t &lo, uint32_t &hi)
+{
+    (void)win.get(pos - 1);  // bring the window to the current position (it only ever moves down)
+    const uint64_t bytes = win.peek8(pos);
+    uint32_t code = 0;
+    bool valid = true;
+#pragma unroll
+    for (uint32_t k = 0; k < kJumpSymbols; k++) {
+        const uint32_t d = s_dense[(bytes >> (8u * (7u - k))) & 0xffu];  // k = 0: symbol pos-1, consumed first
+        valid &= (d != 0u);
+        code |= d << (3u * k);
+    }
+    if (!valid) return false;
+    const uint2 j = ix.jump[lo];
+    if ((j.y & 0xffffffu) != code) return false;
+    lo = j.x;
+    hi = j.x + 1u;
+    return true;
+}
 
 // kGroup lanes cooperate on one query (1: LineTable / GenericTable, 4: QuadLineTable); control flow is
 // uniform inside a group, lane 0 of the group writes the results.
@@ -211,7 +244,16 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
         uint64_t pos = end - t;
         QueryWindow win;
         win.init(qbuf, begin, pos);
+        bool jump_ok = ix.jump != nullptr;
         while (pos > begin && lo != hi) {
+            if (jump_ok && hi - lo == 1u && pos - begin >= kJumpSymbols) {
+                if (try_jump(ix, s_dense, win, pos, lo, hi)) {
+                    pos -= kJumpSymbols;
+                    lf_steps += kJumpSymbols;
+                    continue;
+                }
+                jump_ok = false;  // mismatch or an invalid symbol ahead: the pair lines finish this query
+            }
             const uint32_t c1 = s_dense[win.get(pos - 1)];
             if (c1 == 0) {
                 status = GDX_Q_INVALID_SYMBOL;
@@ -291,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
     QueryWindow win;
     win.words = words;
     win.cur = win.next = win.cur_word = win.first_word = 0;
-    bool have = false;
+    bool have = false, jump_ok = false;
     // the query staged behind it
     uint64_t nx_q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup;
     uint64_t nx_begin = 0, nx_end = 0, nx_cur = 0, nx_next = 0;
@@ -350,12 +392,23 @@ __global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix
             win.cur = nx_cur;
             win.next = nx_next;
             have = true;
+            jump_ok = ix.jump != nullptr;
             nx_q += stride;
             nx_stage = 0;
         }
         // ---- one (double) LF step of the current query -------------------------------------------------
         if (have) {
-            if (pos > begin && lo != hi) {
+            bool jumped = false;
+            if (jump_ok && pos > begin && hi - lo == 1u && pos - begin >= kJumpSymbols) {
+                jumped = try_jump(ix, s_dense, win, pos, lo, hi);
+                if (jumped) {
+                    pos -= kJumpSymbols;
+                    lf_steps += kJumpSymbols;
+                } else {
+                    jump_ok = false;
+                }
+            }
+            if (!jumped && pos > begin && lo != hi) {
                 const uint32_t c1 = s_dense[win.get(pos - 1)];
                 if (c1 == 0) {  // alphabet.rs:195-198
                     status = GDX_Q_INVALID_SYMBOL;
@@ -565,11 +618,13 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 1;
         }();
-        // GDX_SEARCH_STREAM=0|1 forces the lock-step / streaming kernel; default: decided on the device from
-        // the spread of the query lengths (both kernels are enqueued, one of them returns at once)
+        // GDX_SEARCH_STREAM=0|1|auto: lock-step kernel (default: with the jump table it wins on uniform AND
+        // on mixed-length batches, profiles/r01/search_variants.md section 4), streaming kernel, or decided
+        // on the device from the spread of the query lengths (both kernels enqueued, one returns at once)
         static const int forced = [] {
             const char *e = getenv("GDX_SEARCH_STREAM");
-            return e ? (e[0] == '0' ? 0 : 1) : -1;
+            if (!e) return 0;
+            return e[0] == 'a' ? -1 : (e[0] == '0' ? 0 : 1);
         }();
         uint32_t *d_range = nullptr;
         if (forced < 0) {
