@@ -193,8 +193,10 @@ __global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
+// amdgpu_waves_per_eu(8, 8): 64 VGPRs and <= 80 SGPRs, so that 8 blocks per CU are really admitted (with the
+// default budget the kernel needs 99 SGPRs and the hardware admits 6-7 blocks, MI355X_MICROARCH.md residency).
 template <int kPolicy>
-__global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
                                                              uint32_t *__restrict__ out_end,
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void search_pair_kernel(IndexView ix, const
 // are requested two iterations / one iteration after the current query started and are consumed some 20
 // line fetches later, so starting a query costs no memory wait (with a lookup table: one).
 template <int kPolicy>
-__global__ __launch_bounds__(kBlock) void search_pair_stream_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_stream_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                                     const uint64_t *__restrict__ qoff, uint64_t nq,
                                                                     uint32_t *__restrict__ out_start,
                                                                     uint32_t *__restrict__ out_end,
