@@ -234,88 +234,121 @@ __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
 
 // Line loads with an explicit cache policy: 0 = plain, 1 = sc1 (served by L2, no allocation in the CU's
 // L1), 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's counters do not see them.
+// kChunks 16-byte chunks per lane and line, `step` chunks apart (a group of 8 / kChunks lanes covers a line).
 template <int kPolicy>
-__device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb, bool second, u32x4 &a, u32x4 &b)
+__device__ __forceinline__ void issue_chunk_load(const u32x4 *p, u32x4 &v)
+{
+    if (kPolicy == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    else if (kPolicy == 2) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+}
+
+template <int kPolicy, int kChunks>
+__device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb, bool second, int step,
+                                               u32x4 (&a)[kChunks], u32x4 (&b)[kChunks])
 {
     if (kPolicy == 0) {
-        a = *pa;
-        b = a;
-        if (second) b = *pb;
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) a[k] = pa[k * step];
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) b[k] = a[k];
+        if (second) {
+#pragma unroll
+            for (int k = 0; k < kChunks; k++) b[k] = pb[k * step];
+        }
         return;
     }
-    if (kPolicy == 1) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a) : "v"(pa) : "memory");
-        if (second) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(b) : "v"(pb) : "memory");
-    } else if (kPolicy == 2) {
-        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(a) : "v"(pa) : "memory");
-        if (second) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(b) : "v"(pb) : "memory");
-    } else {
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(a) : "v"(pa) : "memory");
-        if (second) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(b) : "v"(pb) : "memory");
+#pragma unroll
+    for (int k = 0; k < kChunks; k++) issue_chunk_load<kPolicy>(pa + k * step, a[k]);
+    if (second) {
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) issue_chunk_load<kPolicy>(pb + k * step, b[k]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory");
-    if (!second) b = a;
+    if (kChunks == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[kChunks - 1]), "+v"(b[kChunks - 1])::"memory");
+    if (!second) {
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) b[k] = a[k];
+    }
+}
+
+// kLanes = 8: one chunk per lane; kLanes = 4: two chunks per lane (sub and sub + 4), twice the queries per wave
+template <int kLanes>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v)
+{
+    return kLanes == 8 ? oct_sum(v) : quad_sum(v);
 }
 
 struct PairTable {
-    static __device__ __forceinline__ uint32_t low_mask(uint32_t idx, uint32_t sub)
+    static __device__ __forceinline__ uint32_t low_mask(uint32_t idx, uint32_t chunk)
     {
-        const int32_t bits = static_cast<int32_t>(idx & 63u) - 8 * static_cast<int32_t>(sub);
+        const int32_t bits = static_cast<int32_t>(idx & 63u) - 8 * static_cast<int32_t>(chunk);
         return bits >= 8 ? 0xffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
     }
+    static __device__ __forceinline__ uint32_t pair_partial(const u32x4 c, uint32_t chunk, uint32_t pair, uint32_t nx,
+                                                            uint32_t ny, uint32_t idx)
+    {
+        const uint32_t tx = c.x ^ nx, ty = c.y ^ ny;
+        const uint32_t m = tx & (tx >> 8) & (tx >> 16) & (tx >> 24) & ty & (ty >> 8) & 0xffu;
+        const uint32_t cnt = (pair & 1u) ? c.w : c.z;
+        return __popc(m & low_mask(idx, chunk)) + ((pair >> 1) == chunk ? cnt : 0u);
+    }
+    static __device__ __forceinline__ uint32_t single_partial(const u32x4 c, uint32_t chunk, uint32_t c1, uint32_t nx,
+                                                              uint32_t idx)
+    {
+        const uint32_t tx = c.x ^ nx;
+        const uint32_t m = tx & (tx >> 8) & (tx >> 16) & 0xffu;
+        const bool owner = (chunk >> 1) == (c1 - 1u);
+        return __popc(m & low_mask(idx, chunk)) + (owner ? ((c.y >> 16) << ((chunk & 1u) * 16u)) : 0u);
+    }
     // two LF steps: c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
-    template <int kPolicy>
+    template <int kPolicy, int kLanes>
     static __device__ __forceinline__ void lf2(const IndexView &ix, uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi,
                                                uint32_t &nlo, uint32_t &nhi)
     {
-        const uint32_t sub = threadIdx.x & 7u;
+        constexpr int kChunks = 8 / kLanes;
+        const uint32_t sub = threadIdx.x & (kLanes - 1u);
         const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
         const uint32_t f = 0xffu;
         const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16) |
                             (((c2 & 1u) ? 0u : f) << 24);
         const uint32_t ny = ((c2 & 2u) ? 0u : f) | (((c2 & 4u) ? 0u : f) << 8);
         const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
-        u32x4 a, b;
-        load_two_lines<kPolicy>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
-                                ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub, line_hi != line_lo, a, b);
-        const bool owner = (pair >> 1) == sub;
-        {
-            const uint32_t tx = a.x ^ nx, ty = a.y ^ ny;
-            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & (tx >> 24) & ty & (ty >> 8) & 0xffu;
-            const uint32_t cnt = (pair & 1u) ? a.w : a.z;
-            nlo = oct_sum(__popc(m & low_mask(lo, sub)) + (owner ? cnt : 0u));
+        u32x4 a[kChunks], b[kChunks];
+        load_two_lines<kPolicy, kChunks>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
+                                         ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub,
+                                         line_hi != line_lo, kLanes, a, b);
+        uint32_t plo = 0, phi = 0;
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) {
+            plo += pair_partial(a[k], sub + k * kLanes, pair, nx, ny, lo);
+            phi += pair_partial(b[k], sub + k * kLanes, pair, nx, ny, hi);
         }
-        {
-            const uint32_t tx = b.x ^ nx, ty = b.y ^ ny;
-            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & (tx >> 24) & ty & (ty >> 8) & 0xffu;
-            const uint32_t cnt = (pair & 1u) ? b.w : b.z;
-            nhi = oct_sum(__popc(m & low_mask(hi, sub)) + (owner ? cnt : 0u));
-        }
+        nlo = group_sum<kLanes>(plo);
+        nhi = group_sum<kLanes>(phi);
     }
     // one LF step with a symbol in 1..4
-    template <int kPolicy>
+    template <int kPolicy, int kLanes>
     static __device__ __forceinline__ void lf1(const IndexView &ix, uint32_t c1, uint32_t lo, uint32_t hi,
                                                uint32_t &nlo, uint32_t &nhi)
     {
-        const uint32_t sub = threadIdx.x & 7u;
+        constexpr int kChunks = 8 / kLanes;
+        const uint32_t sub = threadIdx.x & (kLanes - 1u);
         const uint32_t f = 0xffu;
         const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16);
         const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
-        u32x4 a, b;
-        load_two_lines<kPolicy>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
-                                ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub, line_hi != line_lo, a, b);
-        const bool owner = (sub >> 1) == (c1 - 1u);
-        const uint32_t shift = (sub & 1u) * 16u;
-        {
-            const uint32_t tx = a.x ^ nx;
-            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & 0xffu;
-            nlo = oct_sum(__popc(m & low_mask(lo, sub)) + (owner ? ((a.y >> 16) << shift) : 0u));
+        u32x4 a[kChunks], b[kChunks];
+        load_two_lines<kPolicy, kChunks>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
+                                         ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub,
+                                         line_hi != line_lo, kLanes, a, b);
+        uint32_t plo = 0, phi = 0;
+#pragma unroll
+        for (int k = 0; k < kChunks; k++) {
+            plo += single_partial(a[k], sub + k * kLanes, c1, nx, lo);
+            phi += single_partial(b[k], sub + k * kLanes, c1, nx, hi);
         }
-        {
-            const uint32_t tx = b.x ^ nx;
-            const uint32_t m = tx & (tx >> 8) & (tx >> 16) & 0xffu;
-            nhi = oct_sum(__popc(m & low_mask(hi, sub)) + (owner ? ((b.y >> 16) << shift) : 0u));
-        }
+        nlo = group_sum<kLanes>(plo);
+        nhi = group_sum<kLanes>(phi);
     }
 };
 

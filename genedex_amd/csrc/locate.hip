@@ -98,6 +98,97 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
+// The same walk on pair lines, eight lanes per hit: one 128-byte fetch at row i yields bwt1[i], bwt0[i],
+// LF(i) and LF(LF(i)), i.e. TWO walk steps (the second is taken only if the first did not land on a
+// sampled row), so a hit costs ~1.7 line fetches + the sample instead of 3 + the sample at rate 4.
+template <bool kWide>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_pair_kernel(
+    IndexView ix, const uint32_t *__restrict__ start, const uint64_t *__restrict__ hit_offsets,
+    const uint32_t *__restrict__ query_of_hit, uint64_t total, void *__restrict__ hits_out,
+    unsigned long long *__restrict__ step_stats)
+{
+    constexpr int kGroup = 8;
+    __shared__ uint32_t s_count[257];
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    __syncthreads();
+    const uint32_t sub = threadIdx.x & 7u;
+    const bool writer = sub == 0;
+    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
+    uint32_t walk_steps = 0;
+    for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; h < total;
+         h += stride) {
+        const uint32_t q = query_of_hit[h] - 1u;
+        uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);
+        uint32_t steps = 0, pos;
+        for (;;) {
+            const bool sampled = pow2 ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
+            if (sampled) {  // sampled_suffix_array.rs:133-136
+                pos = ix.sa_samples[pow2 ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate)] + steps;
+                break;
+            }
+            const u32x4 c = ix.pair_lines[(static_cast<uint64_t>(i >> kPairLineShift) << 3) + sub];
+            // the symbols of row i live in the chunk of lane (i & 63) / 8
+            const uint32_t bit = i & 7u;
+            const uint32_t mine = (((c.x >> bit) & 1u) | (((c.x >> (8u + bit)) & 1u) << 1) |
+                                   (((c.x >> (16u + bit)) & 1u) << 2) | (((c.x >> (24u + bit)) & 1u) << 3) |
+                                   (((c.y >> bit) & 1u) << 4) | (((c.y >> (8u + bit)) & 1u) << 5));
+            const uint32_t both = oct_sum(((i & 63u) >> 3) == sub ? mine : 0u);
+            const uint32_t c1 = both & 7u, c0 = both >> 3;
+            if (c1 == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
+                pos = ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, i)] + steps;
+                break;
+            }
+            if (c1 > 4u) {  // a symbol outside 1..4 (N): one step on the rank lines
+                uint32_t r, rdummy;
+                QuadLineTable::rank2(ix, c1, i, i, r, rdummy);
+                i = s_count[c1] + r;
+                steps++;
+                continue;
+            }
+            // LF(c1, i) and LF(c0, LF(c1, i)) from this line (layout.hpp PairTable)
+            const uint32_t f = 0xffu;
+            const uint32_t n1 = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16);
+            const uint32_t t1 = c.x ^ n1;
+            const uint32_t m1 = t1 & (t1 >> 8) & (t1 >> 16) & 0xffu;
+            const uint32_t mask = PairTable::low_mask(i, sub);  // chunk index == lane for 8 lanes
+            const bool own1 = (sub >> 1) == (c1 - 1u);
+            const uint32_t i1 = oct_sum(__popc(m1 & mask) + (own1 ? ((c.y >> 16) << ((sub & 1u) * 16u)) : 0u));
+            const bool sampled1 = pow2 ? ((i1 & ix.sa_rate_pow2_mask) == 0) : (i1 % ix.sa_rate == 0);
+            if (sampled1 || c0 - 1u >= 4u) {
+                i = i1;
+                steps++;
+                continue;
+            }
+            const uint32_t pair = (c0 - 1u) * 4u + (c1 - 1u);
+            const uint32_t n0x = ((c0 & 1u) ? 0u : f) << 24;
+            const uint32_t n0y = ((c0 & 2u) ? 0u : f) | (((c0 & 4u) ? 0u : f) << 8);
+            const uint32_t t0x = c.x ^ n0x, t0y = c.y ^ n0y;
+            const uint32_t m2 = m1 & (t0x >> 24) & t0y & (t0y >> 8) & 0xffu;
+            const bool own2 = (pair >> 1) == sub;
+            i = oct_sum(__popc(m2 & mask) + (own2 ? ((pair & 1u) ? c.w : c.z) : 0u));
+            steps += 2;
+        }
+        walk_steps += steps;
+        const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
+        const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
+        if (writer) {
+            if (kWide) {
+                gdx_hit_t out;
+                out.text_id = t;
+                out.position = in_text;
+                static_cast<gdx_hit_t *>(hits_out)[h] = out;
+            } else {
+                gdx_hit32_t out;
+                out.text_id = t;
+                out.position = in_text;
+                static_cast<gdx_hit32_t *>(hits_out)[h] = out;
+            }
+        }
+    }
+    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
+}
+
 unsigned grid_for_items(uint64_t items)
 {
     const uint64_t blocks = (items + kBlock - 1) / kBlock;
@@ -160,7 +251,24 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
 #define GDX_LOCATE(TABLE, WIDE)                                                                              \
     hipLaunchKernelGGL((locate_kernel<TABLE, WIDE>), dim3(grid), dim3(kBlock), 0, stream, ix, d_start, \
                        d_hit_offsets, heads, total_hits, d_hits, d_step_stats)
-    if (ix.layout == 0) {
+    // The walk is bound by DRAM requests, not by latency: one lane per hit on the 64-byte rank lines keeps 8x
+    // more hits in flight and measures 10.8 ms per 90 M hits against 16.6 ms for the 8-lane pair-line kernel,
+    // although the latter needs ~1.7 instead of 3 line fetches per hit.  GDX_LOCATE_VARIANT=pair selects it.
+    static const bool lane_variant = [] {
+        const char *e = getenv("GDX_LOCATE_VARIANT");
+        return !(e && e[0] == 'p');
+    }();
+    if (ix.layout == 0 && ix.pair_lines != nullptr && !lane_variant) {
+        uint64_t blocks = (total_hits + 31) / 32;
+        if (blocks > 65536) blocks = 65536;
+        if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
+        if (wide)
+            hipLaunchKernelGGL(locate_pair_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, ix,
+                               d_start, d_hit_offsets, heads, total_hits, d_hits, d_step_stats);
+        else
+            hipLaunchKernelGGL(locate_pair_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, ix,
+                               d_start, d_hit_offsets, heads, total_hits, d_hits, d_step_stats);
+    } else if (ix.layout == 0) {
         if (wide) GDX_LOCATE(LineTable, true);
         else GDX_LOCATE(LineTable, false);
     } else {

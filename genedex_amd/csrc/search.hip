@@ -193,10 +193,8 @@ __global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
-// amdgpu_waves_per_eu(8, 8): 64 VGPRs and <= 80 SGPRs, so that 8 blocks per CU are really admitted (with the
-// default budget the kernel needs 99 SGPRs and the hardware admits 6-7 blocks, MI355X_MICROARCH.md residency).
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+template <int kPolicy, int kGroup>
+__device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
                                                              uint32_t *__restrict__ out_end,
@@ -206,7 +204,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                              const uint32_t *__restrict__ len_range, int run_if_uniform)
 {
     if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
-    constexpr int kGroup = 8;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
@@ -266,7 +263,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
             if (c1 <= 4u && c2 - 1u < 4u) {
                 uint32_t nlo, nhi;
-                PairTable::lf2<kPolicy>(ix, c2, c1, lo, hi, nlo, nhi);
+                PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
                 if (nlo != nhi) {
                     lo = nlo;
                     hi = nhi;
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 // frozen interval is the one the reference reports
             }
             if (c1 <= 4u) {
-                PairTable::lf1<kPolicy>(ix, c1, lo, hi, lo, hi);
+                PairTable::lf1<kPolicy, kGroup>(ix, c1, lo, hi, lo, hi);
             } else {  // a symbol outside 1..4 (N): rank lines
                 uint32_t rlo, rhi;
                 QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
@@ -299,14 +296,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
+#define GDX_SEARCH_ARGS                                                                                      \
+    IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
+        uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
+        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats,                      \
+        const uint32_t *__restrict__ len_range, int run_if_uniform
+#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, run_if_uniform
+
+// Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
+// blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
+// The 4-lane kernel holds two chunks per lane and line: 72 VGPRs / 84 SGPRs at 7 waves per SIMD, no spills,
+// 7 x 16 = 112 queries per SIMD in flight instead of 8 x 8 = 64.
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
+{
+    search_pair_body<kPolicy, 8>(GDX_SEARCH_FWD);
+}
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_body<kPolicy, 4>(GDX_SEARCH_FWD);
+}
+
 // The same search as search_pair_kernel, organised as a stream: every 8-lane group walks its own
 // sequence of queries (q, q + stride, ...) and starts the next one in the very iteration the current one
 // ends, so lanes never idle while the longest query of a wave finishes (early-terminating and
 // mixed-length batches, BASELINE workload 5).  The next query's offsets and its last two 8-byte windows
 // are requested two iterations / one iteration after the current query started and are consumed some 20
 // line fetches later, so starting a query costs no memory wait (with a lookup table: one).
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_stream_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
+template <int kPolicy, int kGroup>
+__device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                                     const uint64_t *__restrict__ qoff, uint64_t nq,
                                                                     uint32_t *__restrict__ out_start,
                                                                     uint32_t *__restrict__ out_end,
@@ -316,7 +335,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                                     const uint32_t *__restrict__ len_range, int run_if_uniform)
 {
     if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
-    constexpr int kGroup = 8;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     bool stepped = false;
                     if (c1 <= 4u && c2 - 1u < 4u) {
                         uint32_t nlo, nhi;
-                        PairTable::lf2<kPolicy>(ix, c2, c1, lo, hi, nlo, nhi);
+                        PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
                         if (nlo != nhi) {
                             lo = nlo;
                             hi = nhi;
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     }
                     if (!stepped) {  // single step: odd tail, N, or the step at which the interval empties
                         if (c1 <= 4u) {
-                            PairTable::lf1<kPolicy>(ix, c1, lo, hi, lo, hi);
+                            PairTable::lf1<kPolicy, kGroup>(ix, c1, lo, hi, lo, hi);
                         } else {
                             uint32_t rlo, rhi;
                             QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
@@ -460,6 +478,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_stream_kernel8(GDX_SEARCH_ARGS)
+{
+    search_pair_stream_body<kPolicy, 8>(GDX_SEARCH_FWD);
+}
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_stream_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_stream_body<kPolicy, 4>(GDX_SEARCH_FWD);
+}
+
 // Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
 // search_kernel; with pair lines (kPair) a symbol in 1..4 costs one 128-byte fetch and no table lookup.
 template <class Table, int kGroup, bool kPair>
@@ -478,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void extend_front_kernel(IndexView ix, uint
             status = GDX_Q_INVALID_SYMBOL;
         } else if (lo != hi) {  // cursor.rs:41-48
             if (kPair && c <= 4u) {
-                PairTable::lf1<1>(ix, c, lo, hi, lo, hi);
+                PairTable::lf1<1, 8>(ix, c, lo, hi, lo, hi);
             } else {
                 uint32_t rlo, rhi;
                 Table::rank2(ix, c, lo, hi, rlo, rhi);
@@ -613,7 +642,13 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         return static_cast<unsigned>(blocks);
     };
     if (ix.layout == 0 && search_variant() == 2 && ix.pair_lines != nullptr) {
-        const unsigned blocks = group_grid(kBlock / 8);
+        // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
+        // GDX_SEARCH_LANES overrides
+        static const int lanes = [] {
+            const char *e = getenv("GDX_SEARCH_LANES");
+            return (e && atoi(e) == 8) ? 8 : 4;
+        }();
+        const unsigned blocks = group_grid(kBlock / lanes);
         // pair lines are fetched with sc1 (served by L2, no allocation in the CU's L1): +5 % measured;
         // GDX_LOAD_POLICY=0|1|2|3 overrides (plain, sc1, nt, sc0 sc1)
         static const int policy = [] {
@@ -636,21 +671,26 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, d_qoff, nq,
                                d_range);
         }
-#define GDX_PAIR(P)                                                                                                 \
+#define GDX_PAIR(P, L)                                                                                                 \
     do {                                                                                                            \
         if (forced != 1)                                                                                            \
-            hipLaunchKernelGGL(search_pair_kernel<P>, dim3(blocks), dim3(kBlock), lds_pad,   \
+            hipLaunchKernelGGL(search_pair_kernel##L<P>, dim3(blocks), dim3(kBlock), lds_pad,   \
                                stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,   \
                                d_step_stats, d_range, 1);                                                           \
         if (forced != 0)                                                                                            \
-            hipLaunchKernelGGL(search_pair_stream_kernel<P>, dim3(blocks), dim3(kBlock),     \
+            hipLaunchKernelGGL(search_pair_stream_kernel##L<P>, dim3(blocks), dim3(kBlock),     \
                                lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count,        \
                                d_out_status, d_step_stats, d_range, 0);                                             \
     } while (0)
-        if (policy == 1) GDX_PAIR(1);
-        else if (policy == 2) GDX_PAIR(2);
-        else if (policy == 3) GDX_PAIR(3);
-        else GDX_PAIR(0);
+        if (lanes == 8) {
+            if (policy == 1) GDX_PAIR(1, 8);
+            else if (policy == 2) GDX_PAIR(2, 8);
+            else if (policy == 3) GDX_PAIR(3, 8);
+            else GDX_PAIR(0, 8);
+        } else {
+            if (policy == 0) GDX_PAIR(0, 4);
+            else GDX_PAIR(1, 4);
+        }
         if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
 #undef GDX_PAIR
     } else if (ix.layout == 0 && search_variant() != 1) {
