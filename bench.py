@@ -171,7 +171,10 @@ def main():
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
     variant = os.environ.get("GDX_SEARCH_VARIANT", "pair")
     uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
-    kernel_name = {"pair": "search_pair_kernel<sc1>" if uniform else "search_pair_stream_kernel<sc1>",
+    lanes = os.environ.get("GDX_SEARCH_LANES", "4")
+    streamed = os.environ.get("GDX_SEARCH_STREAM", "0") == "1" or (os.environ.get("GDX_SEARCH_STREAM") == "auto"
+                                                                     and not uniform)
+    kernel_name = {"pair": f"search_pair_stream_kernel{lanes}<sc1>" if streamed else f"search_pair_kernel{lanes}<sc1>",
                    "quad": "search_kernel<QuadLineTable,4>", "lane": "search_kernel<LineTable,1>"}[variant]
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,

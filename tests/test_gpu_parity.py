@@ -333,3 +333,97 @@ def test_medium_text_against_oracle(search_variant):
     co, ct, cp = c.locate_intervals(cs, ce, n_threads=4)
     assert np.array_equal(off, co) and np.array_equal(t, ct) and np.array_equal(p, cp)
     assert (e - s)[:1000].sum() > 0
+
+
+def test_many_short_texts_and_sentinel_crossings(search_variant):
+    """Thousands of tiny texts: pair steps and 8-symbol jumps constantly run into text borders, N and sentinels."""
+    rng = np.random.default_rng(77)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, int(rng.integers(0, 60)), p=[.24, .24, .24, .24, .04]))
+             for _ in range(3000)]
+    for depth, rate in ((0, 4), (3, 3)):
+        g, c = both(texts, a, depth=depth, sa_rate=rate)
+        qs = mixed_queries(rng, texts, 3000, 500, 45, allow_n=(depth == 0))
+        qbuf, qoff = pack_queries(qs)
+        s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+        cs, ce, cst = c.cursors_single(qbuf, qoff)
+        assert st.tolist() == cst.tolist()
+        ok = st == 0
+        assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+        off, t, p, _ = g.locate_raw(qbuf, qoff, strict=False)
+        co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+        assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
+def test_long_repeats_and_long_queries(search_variant):
+    """Highly repetitive text (many doubling rounds in the suffix sorter, wide intervals deep into the search)
+    and queries much longer than the jump width."""
+    rng = np.random.default_rng(78)
+    a = alph.ascii_dna_with_n()
+    unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 997))
+    t1 = bytearray(unit * 300)
+    for pos in rng.integers(0, len(t1), 200):
+        t1[pos] = b"ACGT"[int(rng.integers(0, 4))]
+    texts = [bytes(t1), unit * 3, b"A" * 5000]
+    g, c = both(texts, a, depth=4, sa_rate=8)
+    assert g.export_bwt().tobytes() == c.bwt.tobytes()
+    qs = mixed_queries(rng, texts, 1500, 100, 400)
+    qbuf, qoff = pack_queries(qs)
+    s, e, st = g.cursors_raw(qbuf, qoff)
+    cs, ce = c.cursors_for_many(qbuf, qoff, n_threads=4)
+    assert s.tolist() == cs.tolist() and e.tolist() == ce.tolist()
+    few = (ce - cs) < 2000
+    off, t, p = g.locate_intervals_raw(cs[few], ce[few])
+    co, ct, cp = c.locate_intervals(cs[few], ce[few], n_threads=4)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
+def test_full_size_properties_workload2():
+    """BASELINE workload 2 at full size (256 MB text, 10 M len-50 reads) through size-independent properties:
+    every sampled read is found, every reported hit spells its query in the text, count == number of hits,
+    and a 200 k prefix equals the CPU oracle bit for bit."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries, build_index_from_device_text, synth_text
+
+    dev = torch.device("cuda", 0)
+    total, nq = 1 << 28, 10_000_000
+    a = alph.ascii_dna_with_n()
+    io_text = synth_text(total, device=dev)
+    g = build_index_from_device_text(io_text, [total], a, index_storage="i32")
+    q = DeviceQueries.synth(io_text, [total], nq, 50, 50, 900_000)
+    eng = DeviceEngine(g)
+    out = eng.alloc_outputs(nq)
+    eng.search(q, out)
+    eng.hit_offsets(out, nq)
+    torch.cuda.synchronize()
+    total_hits = int(out["hit_offsets"][nq].item())
+    assert int((out["status"] != 0).sum().item()) == 0
+    counts = (out["end"] - out["start"]).to(torch.int64)
+    assert int(counts.sum().item()) == total_hits
+    found = int((counts > 0).sum().item())
+    assert 0.895 * nq < found < 0.905 * nq  # 90 % sampled reads (all must be found) + a few random ones
+    hits = torch.empty((total_hits, 2), dtype=torch.int32, device=dev)
+    ws = torch.empty(eng.locate_workspace_bytes(total_hits), dtype=torch.uint8, device=dev)
+    eng.locate(out, nq, total_hits, hits, ws)
+    torch.cuda.synchronize()
+    # every hit spells its query (checked for all hits, on the device)
+    hq = torch.repeat_interleave(torch.arange(nq, device=dev), counts)
+    assert hq.numel() == total_hits
+    pos = hits[:, 1].to(torch.int64)
+    assert bool((hits[:, 0] == 0).all()) and bool(((pos >= 0) & (pos + 50 <= total)).all())
+    for j in range(0, 50, 10):
+        col = torch.arange(j, j + 10, device=dev)
+        same = io_text[pos[:, None] + col[None, :]] == q.qbuf[(q.qoff[hq])[:, None] + col[None, :]]
+        assert bool(same.all())
+    # a prefix against the oracle, on the same index
+    m = 200_000
+    cpu = OracleIndex.from_bwt(g.export_bwt(), g.export_sa_samples(), 4, *g.export_borders(),
+                               g.export_sentinel_indices(), a.io_to_dense_table, 6, 4, width=-32, n_threads=8)
+    qbuf, qoff = q.host_slice(0, m)
+    cs, ce = cpu.cursors_for_many(qbuf, qoff, n_threads=8)
+    assert np.array_equal(out["start"][:m].cpu().numpy().astype(np.uint64), cs)
+    assert np.array_equal(out["end"][:m].cpu().numpy().astype(np.uint64), ce)
+    co, ct, cp = cpu.locate_intervals(cs, ce, n_threads=8)
+    gh = hits[: int(co[-1])].cpu().numpy()
+    assert np.array_equal(gh[:, 0].astype(np.uint64), ct) and np.array_equal(gh[:, 1].astype(np.uint64), cp)
