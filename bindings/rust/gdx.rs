@@ -38,6 +38,13 @@ extern "C" {
         io_to_dense: *const u8, sigma: c_int, n_searchable: c_int, lookup_depth: c_int,
         index_width: c_int, device_id: c_int, out: *mut *mut gdx_index_t,
     ) -> c_int;
+    /// table_kind 0 = condensed, 1 = flat; block_bits 64 | 512 (FmIndexCondensed64/512, FmIndexFlat64/512)
+    pub fn gdx_index_from_parts_ex(
+        table_kind: c_int, block_bits: c_int, count: *const u64, interleaved_blocks: *const u64, n: u64,
+        sa_samples: *const u32, sa_rate: u64, border_keys: *const u64, border_vals: *const u64,
+        sentinel_indices: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int, n_searchable: c_int,
+        lookup_depth: c_int, index_width: c_int, device_id: c_int, out: *mut *mut gdx_index_t,
+    ) -> c_int;
     pub fn gdx_index_free(ix: *mut gdx_index_t);
     pub fn gdx_count_many(
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64,

@@ -107,21 +107,32 @@ int gdx_index_build_dev(const void *d_texts_buf, const uint64_t *text_offsets, u
     });
 }
 
+int gdx_index_from_parts_ex(int table_kind, int block_bits, const uint64_t *count, const uint64_t *interleaved_blocks,
+                            uint64_t n, const uint32_t *sa_samples, uint64_t sa_rate, const uint64_t *border_keys,
+                            const uint64_t *border_vals, const uint64_t *sentinel_indices, uint64_t n_texts,
+                            const uint8_t *io_to_dense, int sigma, int n_searchable, int lookup_depth,
+                            int index_width, int device_id, gdx_index_t **out)
+{
+    return guarded([&] {
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        *out = nullptr;
+        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id);
+        auto impl = gdx::FmIndex::from_parts(table_kind, block_bits, count, interleaved_blocks, n, sa_samples,
+                                             border_keys, border_vals, sentinel_indices, n_texts, cfg);
+        *out = new gdx_index{std::move(impl)};
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_index_from_parts(const uint64_t *count, const uint64_t *interleaved_blocks, uint64_t n,
                          const uint32_t *sa_samples, uint64_t sa_rate, const uint64_t *border_keys,
                          const uint64_t *border_vals, const uint64_t *sentinel_indices, uint64_t n_texts,
                          const uint8_t *io_to_dense, int sigma, int n_searchable, int lookup_depth, int index_width,
                          int device_id, gdx_index_t **out)
 {
-    return guarded([&] {
-        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
-        *out = nullptr;
-        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id);
-        auto impl = gdx::FmIndex::from_parts(count, interleaved_blocks, n, sa_samples, border_keys, border_vals,
-                                             sentinel_indices, n_texts, cfg);
-        *out = new gdx_index{std::move(impl)};
-        return (int)GDX_OK;
-    });
+    return gdx_index_from_parts_ex(0, 64, count, interleaved_blocks, n, sa_samples, sa_rate, border_keys, border_vals,
+                                   sentinel_indices, n_texts, io_to_dense, sigma, n_searchable, lookup_depth,
+                                   index_width, device_id, out);
 }
 
 void gdx_index_free(gdx_index_t *ix)

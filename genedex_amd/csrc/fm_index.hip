@@ -476,16 +476,35 @@ __global__ __launch_bounds__(kBlock) void decode_bwt_kernel(IndexView ix, uint8_
         bwt[p] = static_cast<uint8_t>(Table::symbol_at(ix, static_cast<uint32_t>(p)));
 }
 
-// condensed.rs:343-362 symbol_at over the reference's interleaved plane words
-__global__ __launch_bounds__(kBlock) void decode_reference_planes_kernel(const uint64_t *__restrict__ planes,
-                                                                         int nbits, uint64_t n,
-                                                                         uint8_t *__restrict__ bwt)
+// symbol_at over the reference's own arrays, all four variants:
+// condensed (condensed.rs:343-362): plane b of block k = words [(k * nbits + b) * wpb, +wpb), bit j of it;
+// flat (flat.rs:248-266): block of symbol c = words [(k * sigma + c) * wpb, +wpb), text bit j + 16.
+__global__ __launch_bounds__(kBlock) void decode_reference_blocks_kernel(const uint64_t *__restrict__ blocks,
+                                                                         int table_kind, int block_bits, int nbits,
+                                                                         int sigma, uint64_t n,
+                                                                         uint8_t *__restrict__ bwt,
+                                                                         uint32_t *__restrict__ error)
 {
+    const uint64_t wpb = static_cast<uint64_t>(block_bits) / 64;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
-        const uint64_t *w = planes + (p >> 6) * nbits;
         uint32_t s = 0;
-        for (int k = 0; k < nbits; k++) s |= static_cast<uint32_t>((w[k] >> (p & 63u)) & 1ull) << k;
+        if (table_kind == 0) {
+            const uint64_t k = p / block_bits, j = p % block_bits;
+            const uint64_t *w = blocks + k * nbits * wpb;
+            for (int b = 0; b < nbits; b++) s |= static_cast<uint32_t>((w[b * wpb + j / 64] >> (j % 64)) & 1ull) << b;
+        } else {
+            const uint64_t used = static_cast<uint64_t>(block_bits) - 16;
+            const uint64_t k = p / used, j = p % used + 16;
+            const uint64_t *w = blocks + k * sigma * wpb;
+            uint32_t found = 0;
+            for (int c = 0; c < sigma; c++)
+                if ((w[c * wpb + j / 64] >> (j % 64)) & 1ull) {
+                    s = static_cast<uint32_t>(c);
+                    found++;
+                }
+            if (found != 1) *error = 1;  // flat.rs:265 unreachable!(): exactly one indicator bit per position
+        }
         bwt[p] = static_cast<uint8_t>(s);
     }
 }
@@ -824,7 +843,8 @@ std::unique_ptr<FmIndex> FmIndex::construct_index(const uint8_t *texts_buf, bool
     return ix;
 }
 
-std::unique_ptr<FmIndex> FmIndex::from_parts(const uint64_t *count, const uint64_t *interleaved_blocks, uint64_t n,
+std::unique_ptr<FmIndex> FmIndex::from_parts(int table_kind, int block_bits, const uint64_t *count,
+                                             const uint64_t *interleaved_blocks, uint64_t n,
                                              const uint32_t *sa_samples, const uint64_t *border_keys,
                                              const uint64_t *border_vals, const uint64_t *sentinel_indices,
                                              uint64_t n_texts, const IndexConfig &cfg)
@@ -833,6 +853,8 @@ std::unique_ptr<FmIndex> FmIndex::from_parts(const uint64_t *count, const uint64
     if (!count || !interleaved_blocks || !sa_samples || !border_keys || !border_vals || !sentinel_indices)
         fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: null array");
     if (n_texts == 0 || n < n_texts) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: need at least one text");
+    if ((table_kind != 0 && table_kind != 1) || (block_bits != 64 && block_bits != 512))
+        fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: table_kind must be 0 (condensed) or 1 (flat), block_bits 64 or 512");
     check_width(n, cfg.index_width);
     std::unique_ptr<FmIndex> ix(new FmIndex());
     ix->cfg_ = cfg;
@@ -850,14 +872,20 @@ std::unique_ptr<FmIndex> FmIndex::from_parts(const uint64_t *count, const uint64
         if (border_keys[t] <= border_keys[t - 1]) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: border keys must be sorted");
 
     const int nbits = ilog2_ceil(static_cast<uint64_t>(cfg.sigma));
-    const uint64_t n_words = div_ceil(n + 1, 64) * nbits;
+    const uint64_t wpb = static_cast<uint64_t>(block_bits) / 64;
+    const uint64_t n_words = table_kind == 0 ? div_ceil(n + 1, block_bits) * nbits * wpb
+                                             : div_ceil(n + 1, block_bits - 16) * cfg.sigma * wpb;
     DeviceBuffer<uint64_t> d_planes(n_words);
     GDX_HIP(hipMemcpy(d_planes.get(), interleaved_blocks, n_words * sizeof(uint64_t), hipMemcpyHostToDevice));
     const uint64_t padded = div_ceil(n + 1, 128) * 128;
     DeviceBuffer<uint8_t> d_bwt(padded);
     GDX_HIP(hipMemsetAsync(d_bwt.get(), 0, padded, stream));
-    hipLaunchKernelGGL(decode_reference_planes_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream,
-                       d_planes.get(), nbits, n, d_bwt.get());
+    DeviceBuffer<uint32_t> d_bad(1);
+    GDX_HIP(hipMemsetAsync(d_bad.get(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(decode_reference_blocks_kernel, dim3(grid_for_items(n)), dim3(kBlock), 0, stream,
+                       d_planes.get(), table_kind, block_bits, nbits, cfg.sigma, n, d_bwt.get(), d_bad.get());
+    uint32_t bad = 0;
+    GDX_HIP(hipMemcpyAsync(&bad, d_bad.get(), sizeof(bad), hipMemcpyDeviceToHost, stream));
     // the given count must be the prefix sums of the BWT's symbol frequencies
     DeviceBuffer<unsigned long long> d_hist(256);
     GDX_HIP(hipMemsetAsync(d_hist.get(), 0, 256 * sizeof(unsigned long long), stream));
@@ -865,6 +893,7 @@ std::unique_ptr<FmIndex> FmIndex::from_parts(const uint64_t *count, const uint64
     unsigned long long hist[256];
     GDX_HIP(hipMemcpyAsync(hist, d_hist.get(), sizeof(hist), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
+    if (bad) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: flat blocks do not hold exactly one indicator bit per position");
     uint64_t sum = 0;
     for (int c = 0; c < 256; c++) {
         if (c < cfg.sigma && ix->count_host_[c] != sum) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: count[%d] does not match the bit planes", c);

@@ -34,7 +34,9 @@ public:
                                                     const uint64_t *text_offsets, uint64_t n_texts,
                                                     const IndexConfig &cfg);
     // import of the reference's logical arrays (host pointers)
-    static std::unique_ptr<FmIndex> from_parts(const uint64_t *count, const uint64_t *interleaved_blocks, uint64_t n,
+    // table_kind 0 = condensed, 1 = flat; block_bits 64 | 512 (the reference's four table variants)
+    static std::unique_ptr<FmIndex> from_parts(int table_kind, int block_bits, const uint64_t *count,
+                                               const uint64_t *interleaved_blocks, uint64_t n,
                                                const uint32_t *sa_samples, const uint64_t *border_keys,
                                                const uint64_t *border_vals, const uint64_t *sentinel_indices,
                                                uint64_t n_texts, const IndexConfig &cfg);

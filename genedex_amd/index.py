@@ -106,8 +106,10 @@ class FmIndex:
 
     @classmethod
     def from_parts(cls, count, interleaved_blocks, n, sa_samples, sa_rate, border_keys, border_vals,
-                   sentinel_indices, alphabet: Alphabet, lookup_depth=0, index_storage="u32", device=0):
-        """Import of the reference's logical arrays (include/gdx.h gdx_index_from_parts)."""
+                   sentinel_indices, alphabet: Alphabet, lookup_depth=0, index_storage="u32", device=0,
+                   table_kind="condensed", block_bits=64):
+        """Import of the reference's logical arrays (include/gdx.h gdx_index_from_parts[_ex]); table_kind
+        'condensed' | 'flat' and block_bits 64 | 512 select one of the reference's four table variants."""
         lib = _lib.load()
         count = np.ascontiguousarray(count, dtype=np.uint64)
         blocks = np.ascontiguousarray(interleaved_blocks, dtype=np.uint64)
@@ -117,7 +119,8 @@ class FmIndex:
         si = np.ascontiguousarray(sentinel_indices, dtype=np.uint64)
         tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
         handle = C.c_void_p()
-        st = lib.gdx_index_from_parts(_p(count, u64p), _p(blocks, u64p), int(n), _p(sa_samples, u32p), int(sa_rate),
+        st = lib.gdx_index_from_parts_ex({"condensed": 0, "flat": 1}[table_kind], int(block_bits),
+                                         _p(count, u64p), _p(blocks, u64p), int(n), _p(sa_samples, u32p), int(sa_rate),
                                       _p(bk, u64p), _p(bv, u64p), _p(si, u64p), si.size, _p(tab, u8p),
                                       alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
                                       int(lookup_depth), _WIDTHS[index_storage], int(device), C.byref(handle))

@@ -108,6 +108,17 @@ int gdx_index_from_parts(const uint64_t *count /*sigma+1*/, const uint64_t *inte
                          const uint8_t *io_to_dense, int sigma, int n_searchable,
                          int lookup_depth, int index_width, int device_id, gdx_index_t **out);
 
+/* The same import for the reference's other table variants (lib.rs:102-113): table_kind 0 =
+ * CondensedTextWithRankSupport (condensed.rs:24-30), 1 = FlatTextWithRankSupport (flat.rs:27-33: one
+ * indicator block per symbol, 16-bit block offset in the low bits of each block); block_bits 64 = Block64,
+ * 512 = Block512 (block.rs).  interleaved_blocks is passed as u64 words (a Block512 is 8 words). */
+int gdx_index_from_parts_ex(int table_kind, int block_bits, const uint64_t *count,
+                            const uint64_t *interleaved_blocks, uint64_t n, const uint32_t *sa_samples,
+                            uint64_t sa_rate, const uint64_t *border_keys, const uint64_t *border_vals,
+                            const uint64_t *sentinel_indices, uint64_t n_texts, const uint8_t *io_to_dense,
+                            int sigma, int n_searchable, int lookup_depth, int index_width, int device_id,
+                            gdx_index_t **out);
+
 void gdx_index_free(gdx_index_t *ix);
 int gdx_index_info(const gdx_index_t *ix, gdx_index_info_t *out);
 

@@ -931,6 +931,224 @@ void gdxo_free(gdxo_index *ix)
     free(ix);
 }
 
+/* ------------------------------------------------------------------------- */
+/* the four table variants (condensed / flat) x (Block64 / Block512) as stand-alone tables      */
+
+#define NUM_BLOCK_OFFSET_BITS 16u /* block.rs:3 */
+
+struct gdxo_table {
+    int kind, block_bits, sigma, nbits;
+    uint64_t n;               /* text_len */
+    uint64_t words_per_block; /* block.rs:24 NUM_U64 */
+    uint64_t superblock_size; /* condensed: 65536; flat: flat.rs:71-72 */
+    uint64_t *blocks;
+    uint64_t n_words;
+    uint16_t *block_offsets;
+    uint64_t n_block_offsets;
+    uint32_t *sbo;
+    uint64_t n_sbo;
+};
+
+/* block.rs:96-100 / :162-164 set_bit_assuming_zero */
+static inline void blk_set_bit(uint64_t *blk, uint64_t idx, uint64_t bit) { blk[idx / 64] |= bit << (idx % 64); }
+/* block.rs:90-94 / :158-160 get_bit */
+static inline uint8_t blk_get_bit(const uint64_t *blk, uint64_t idx) { return (uint8_t)((blk[idx / 64] >> (idx % 64)) & 1u); }
+/* block.rs:102-112 (BLOCK512_MASKS :194-226) and :175-178: ones among the first idx bits */
+static inline uint64_t blk_count_ones_before(const uint64_t *blk, uint64_t words, uint64_t idx)
+{
+    uint64_t sum = 0;
+    for (uint64_t w = 0; w < words; w++) {
+        uint64_t mask;
+        if (w < idx / 64) mask = UINT64_MAX;
+        else if (w == idx / 64) mask = ~(UINT64_MAX << (idx % 64));
+        else mask = 0;
+        sum += (uint64_t)__builtin_popcountll(blk[w] & mask);
+    }
+    return sum;
+}
+
+gdxo_table *gdxo_table_construct(const uint8_t *text, uint64_t n, int sigma, int kind, int block_bits)
+{
+    if (sigma < 2 || (kind != 0 && kind != 1) || (block_bits != 64 && block_bits != 512)) return NULL;
+    gdxo_table *t = calloc(1, sizeof(gdxo_table));
+    t->kind = kind;
+    t->block_bits = block_bits;
+    t->sigma = sigma;
+    t->nbits = ilog2_ceil((uint64_t)sigma);
+    t->n = n;
+    t->words_per_block = (uint64_t)block_bits / 64;
+    const uint64_t wpb = t->words_per_block;
+    const uint64_t len = n + 1;
+    if (kind == 0) {
+        /* condensed.rs:59-124 with B::NUM_BITS = block_bits */
+        const uint64_t bb = (uint64_t)block_bits;
+        t->superblock_size = SUPERBLOCK;
+        const uint64_t nblk = div_ceil(len, bb);
+        t->n_words = nblk * t->nbits * wpb;
+        t->n_block_offsets = nblk * sigma;
+        t->n_sbo = div_ceil(len, SUPERBLOCK) * sigma;
+        t->blocks = calloc(t->n_words ? t->n_words : 1, sizeof(uint64_t));
+        t->block_offsets = calloc(t->n_block_offsets ? t->n_block_offsets : 1, sizeof(uint16_t));
+        t->sbo = calloc(t->n_sbo ? t->n_sbo : 1, sizeof(uint32_t));
+        const uint64_t blocks_per_sb = SUPERBLOCK / bb;
+        for (uint64_t sb = 0; sb * SUPERBLOCK < n; sb++) {
+            const uint64_t t0 = sb * SUPERBLOCK, t1 = t0 + SUPERBLOCK < n ? t0 + SUPERBLOCK : n;
+            uint16_t sums[256];
+            memset(sums, 0, sizeof(sums));
+            const uint64_t first = sb * blocks_per_sb;
+            uint64_t here = nblk - first;
+            if (here > blocks_per_sb) here = blocks_per_sb;
+            const uint64_t text_blocks = div_ceil(t1 - t0, bb);
+            for (uint64_t k = 0; k < text_blocks; k++) {
+                uint16_t *bo = t->block_offsets + (first + k) * sigma;
+                for (int c = 0; c < sigma; c++) bo[c] = sums[c];
+                uint64_t *planes = t->blocks + (first + k) * t->nbits * wpb;
+                const uint64_t p0 = t0 + k * bb, p1 = p0 + bb < t1 ? p0 + bb : t1;
+                for (uint64_t p = p0; p < p1; p++) {
+                    uint8_t s = text[p];
+                    t->sbo[sb * sigma + s]++;
+                    sums[s] = (uint16_t)(sums[s] + 1u);
+                    for (int b = 0; b < t->nbits; b++) {
+                        blk_set_bit(planes + (uint64_t)b * wpb, p - p0, (uint64_t)(s & 1u));
+                        s >>= 1;
+                    }
+                }
+            }
+            if (text_blocks < here) {
+                uint16_t *bo = t->block_offsets + (first + here - 1) * sigma;
+                for (int c = 0; c < sigma; c++) bo[c] = sums[c];
+            }
+        }
+    } else {
+        /* flat.rs:59-126, fill_superblock :268-315 */
+        const uint64_t used = (uint64_t)block_bits - NUM_BLOCK_OFFSET_BITS;
+        t->superblock_size = ((1u << NUM_BLOCK_OFFSET_BITS) / used) * used;
+        const uint64_t nblk = div_ceil(len, used);
+        t->n_words = nblk * sigma * wpb;
+        t->n_sbo = div_ceil(len, t->superblock_size) * sigma;
+        t->blocks = calloc(t->n_words ? t->n_words : 1, sizeof(uint64_t));
+        t->sbo = calloc(t->n_sbo ? t->n_sbo : 1, sizeof(uint32_t));
+        const uint64_t blocks_per_sb = t->superblock_size / used;
+        for (uint64_t sb = 0; sb * t->superblock_size < n; sb++) {
+            const uint64_t t0 = sb * t->superblock_size;
+            const uint64_t t1 = t0 + t->superblock_size < n ? t0 + t->superblock_size : n;
+            uint64_t sums[256];
+            memset(sums, 0, sizeof(sums));
+            const uint64_t first = sb * blocks_per_sb;
+            uint64_t here = nblk - first;
+            if (here > blocks_per_sb) here = blocks_per_sb;
+            const uint64_t text_blocks = div_ceil(t1 - t0, used);
+            for (uint64_t k = 0; k < text_blocks; k++) {
+                uint64_t *blks = t->blocks + (first + k) * sigma * wpb;
+                for (int c = 0; c < sigma; c++) blks[(uint64_t)c * wpb] = sums[c]; /* integrate_block_offset */
+                const uint64_t p0 = t0 + k * used, p1 = p0 + used < t1 ? p0 + used : t1;
+                for (uint64_t p = p0; p < p1; p++) {
+                    const uint8_t s = text[p];
+                    t->sbo[sb * sigma + s]++;
+                    sums[s]++;
+                    blk_set_bit(blks + (uint64_t)s * wpb, p - p0 + NUM_BLOCK_OFFSET_BITS, 1);
+                }
+            }
+            if (text_blocks < here) {
+                uint64_t *blks = t->blocks + (first + here - 1) * sigma * wpb;
+                for (int c = 0; c < sigma; c++) blks[(uint64_t)c * wpb] = sums[c];
+            }
+        }
+    }
+    /* accumulate superblocks (condensed.rs:104-115, flat.rs:105-116) */
+    uint64_t prev[256];
+    memset(prev, 0, sizeof(prev));
+    for (uint64_t sb = 0; sb * sigma < t->n_sbo; sb++)
+        for (int c = 0; c < sigma; c++) {
+            const uint64_t tmp = t->sbo[sb * sigma + c];
+            t->sbo[sb * sigma + c] = (uint32_t)prev[c];
+            prev[c] += tmp;
+        }
+    return t;
+}
+
+void gdxo_table_free(gdxo_table *t)
+{
+    if (!t) return;
+    free(t->blocks);
+    free(t->block_offsets);
+    free(t->sbo);
+    free(t);
+}
+
+int gdxo_table_rank(const gdxo_table *t, int symbol, uint64_t idx, uint64_t *out)
+{
+    if (!(symbol >= 0 && symbol < t->sigma && idx <= t->n)) return -1; /* mod.rs:107-108 */
+    const uint64_t wpb = t->words_per_block;
+    if (t->kind == 0) { /* condensed.rs:291-341 */
+        const uint64_t bb = (uint64_t)t->block_bits;
+        const uint64_t sbo = t->sbo[(idx / SUPERBLOCK) * t->sigma + symbol];
+        const uint64_t bo = t->block_offsets[(idx / bb) * t->sigma + symbol];
+        const uint64_t *planes = t->blocks + (idx / bb) * t->nbits * wpb;
+        uint64_t acc[8];
+        uint8_t s = (uint8_t)symbol;
+        for (uint64_t w = 0; w < wpb; w++) acc[w] = (s & 1) ? planes[w] : ~planes[w];
+        for (int b = 1; b < t->nbits; b++) {
+            s >>= 1;
+            for (uint64_t w = 0; w < wpb; w++) {
+                const uint64_t v = planes[(uint64_t)b * wpb + w];
+                acc[w] &= (s & 1) ? v : ~v;
+            }
+        }
+        *out = sbo + bo + blk_count_ones_before(acc, wpb, idx % bb);
+    } else { /* flat.rs:221-246 */
+        const uint64_t used = (uint64_t)t->block_bits - NUM_BLOCK_OFFSET_BITS;
+        const uint64_t sbo = t->sbo[(idx / t->superblock_size) * t->sigma + symbol];
+        const uint64_t *blk = t->blocks + ((idx / used) * t->sigma + symbol) * wpb;
+        uint64_t copy[8];
+        memcpy(copy, blk, wpb * sizeof(uint64_t));
+        const uint64_t mask = ~(UINT64_MAX << NUM_BLOCK_OFFSET_BITS); /* block.rs:126-133 / :184-191 */
+        const uint64_t bo = copy[0] & mask;
+        copy[0] &= ~mask;
+        *out = sbo + bo + blk_count_ones_before(copy, wpb, idx % used + NUM_BLOCK_OFFSET_BITS);
+    }
+    return 0;
+}
+
+int gdxo_table_symbol_at(const gdxo_table *t, uint64_t idx, uint8_t *out)
+{
+    if (!(idx < t->n)) return -1;
+    const uint64_t wpb = t->words_per_block;
+    if (t->kind == 0) { /* condensed.rs:343-362 */
+        const uint64_t bb = (uint64_t)t->block_bits;
+        const uint64_t *planes = t->blocks + (idx / bb) * t->nbits * wpb;
+        uint8_t s = 0;
+        for (int b = 0; b < t->nbits; b++) s |= (uint8_t)(blk_get_bit(planes + (uint64_t)b * wpb, idx % bb) << b);
+        *out = s;
+    } else { /* flat.rs:248-266 */
+        const uint64_t used = (uint64_t)t->block_bits - NUM_BLOCK_OFFSET_BITS;
+        const uint64_t *blks = t->blocks + (idx / used) * t->sigma * wpb;
+        for (int c = 0; c < t->sigma; c++)
+            if (blk_get_bit(blks + (uint64_t)c * wpb, idx % used + NUM_BLOCK_OFFSET_BITS)) {
+                *out = (uint8_t)c;
+                return 0;
+            }
+        return -2; /* unreachable!() */
+    }
+    return 0;
+}
+
+const uint64_t *gdxo_table_blocks(const gdxo_table *t, uint64_t *n_words)
+{
+    *n_words = t->n_words;
+    return t->blocks;
+}
+const uint16_t *gdxo_table_block_offsets(const gdxo_table *t, uint64_t *len)
+{
+    *len = t->n_block_offsets;
+    return t->block_offsets;
+}
+const uint32_t *gdxo_table_superblock_offsets(const gdxo_table *t, uint64_t *len)
+{
+    *len = t->n_sbo;
+    return t->sbo;
+}
+
 /* accessors ---------------------------------------------------------------- */
 uint64_t gdxo_n(const gdxo_index *ix) { return ix->n; }
 uint64_t gdxo_num_texts(const gdxo_index *ix) { return ix->n_texts; }

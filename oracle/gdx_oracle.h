@@ -112,6 +112,20 @@ uint64_t gdxo_lookup_text_id(const gdxo_index *ix, uint64_t concatenated_text_in
 /* recover_range only: concatenated-text position per SA index */
 void gdxo_recover_range(const gdxo_index *ix, uint64_t start, uint64_t end, uint64_t *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * The four occurrence-table variants of the reference as stand-alone tables (lib.rs:102-113):
+ * kind 0 = CondensedTextWithRankSupport (condensed.rs), kind 1 = FlatTextWithRankSupport (flat.rs);
+ * block_bits 64 = Block64, 512 = Block512 (block.rs).  TextWithRankSupport::construct / rank / symbol_at. */
+typedef struct gdxo_table gdxo_table;
+gdxo_table *gdxo_table_construct(const uint8_t *dense_text, uint64_t n, int sigma, int kind, int block_bits);
+void gdxo_table_free(gdxo_table *t);
+int gdxo_table_rank(const gdxo_table *t, int symbol, uint64_t idx, uint64_t *out);
+int gdxo_table_symbol_at(const gdxo_table *t, uint64_t idx, uint8_t *out);
+/* interleaved_blocks as u64 words (Block512 = 8 words), block offsets (condensed only), superblock offsets */
+const uint64_t *gdxo_table_blocks(const gdxo_table *t, uint64_t *n_words);
+const uint16_t *gdxo_table_block_offsets(const gdxo_table *t, uint64_t *len);
+const uint32_t *gdxo_table_superblock_offsets(const gdxo_table *t, uint64_t *len);
+
 /* brute-force helpers used only to pin the oracle itself */
 void gdxo_naive_suffix_array(const uint8_t *text, uint64_t n, uint32_t *sa);
 

@@ -82,6 +82,17 @@ def load(path: str | None = None):
     lib.gdxo_lookup_text_id.argtypes = [vp, C.c_uint64]
     lib.gdxo_recover_range.restype = None
     lib.gdxo_recover_range.argtypes = [vp, C.c_uint64, C.c_uint64, u64p]
+    lib.gdxo_table_construct.restype = vp
+    lib.gdxo_table_construct.argtypes = [u8p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    lib.gdxo_table_free.argtypes = [vp]
+    lib.gdxo_table_rank.argtypes = [vp, C.c_int, C.c_uint64, u64p]
+    lib.gdxo_table_symbol_at.argtypes = [vp, C.c_uint64, u8p]
+    lib.gdxo_table_blocks.restype = u64p
+    lib.gdxo_table_blocks.argtypes = [vp, u64p]
+    lib.gdxo_table_block_offsets.restype = u16p
+    lib.gdxo_table_block_offsets.argtypes = [vp, u64p]
+    lib.gdxo_table_superblock_offsets.restype = u32p
+    lib.gdxo_table_superblock_offsets.argtypes = [vp, u64p]
     lib.gdxo_naive_suffix_array.restype = None
     lib.gdxo_naive_suffix_array.argtypes = [u8p, C.c_uint64, u32p]
     if path is None:
@@ -343,3 +354,58 @@ def naive_suffix_array(text: np.ndarray) -> np.ndarray:
     tt = t if t.size else np.zeros(1, dtype=np.uint8)
     lib.gdxo_naive_suffix_array(_p(tt, u8p), t.size, _p(sa, u32p))
     return sa[: t.size]
+
+
+class OracleTable:
+    """One of the reference's four occurrence-table variants (kind 'condensed' | 'flat', block 64 | 512)."""
+
+    KINDS = {"condensed": 0, "flat": 1}
+
+    def __init__(self, dense_text, sigma, kind="condensed", block_bits=64, lib=None):
+        self._lib = lib or load()
+        t = np.ascontiguousarray(dense_text, dtype=np.uint8)
+        tt = t if t.size else np.zeros(1, dtype=np.uint8)
+        h = self._lib.gdxo_table_construct(_p(tt, u8p), t.size, sigma, self.KINDS[kind], block_bits)
+        if not h:
+            raise ValueError("oracle table: invalid arguments")
+        self._h = C.c_void_p(h)
+        self.n, self.sigma, self.kind, self.block_bits = t.size, sigma, kind, block_bits
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.gdxo_table_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def rank(self, symbol, idx):
+        out = C.c_uint64(0)
+        if self._lib.gdxo_table_rank(self._h, int(symbol), int(idx), C.byref(out)) != 0:
+            raise AssertionError("rank: assert!(is_safe) failed")
+        return out.value
+
+    def symbol_at(self, idx):
+        out = C.c_uint8(0)
+        if self._lib.gdxo_table_symbol_at(self._h, int(idx), C.byref(out)) != 0:
+            raise AssertionError("symbol_at: assert failed")
+        return out.value
+
+    def _lenarr(self, fn, dtype):
+        ln = C.c_uint64(0)
+        ptr = fn(self._h, C.byref(ln))
+        if not ptr or ln.value == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(int(ln.value),)).copy()
+
+    @property
+    def blocks(self):
+        return self._lenarr(self._lib.gdxo_table_blocks, np.uint64)
+
+    @property
+    def block_offsets(self):
+        return self._lenarr(self._lib.gdxo_table_block_offsets, np.uint16)
+
+    @property
+    def superblock_offsets(self):
+        return self._lenarr(self._lib.gdxo_table_superblock_offsets, np.uint32)

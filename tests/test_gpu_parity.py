@@ -427,3 +427,53 @@ def test_full_size_properties_workload2():
     co, ct, cp = cpu.locate_intervals(cs, ce, n_threads=8)
     gh = hits[: int(co[-1])].cpu().numpy()
     assert np.array_equal(gh[:, 0].astype(np.uint64), ct) and np.array_equal(gh[:, 1].astype(np.uint64), cp)
+
+
+@pytest.mark.parametrize("kind,bits", [("condensed", 64), ("condensed", 512), ("flat", 64), ("flat", 512)])
+def test_import_of_all_four_table_variants(kind, bits):
+    """gdx_index_from_parts_ex: an index handed over in any of the reference's four occurrence-table variants
+    (FmIndexCondensed64/512, FmIndexFlat64/512, lib.rs:102-113) answers rank / symbol_at like the naive columns
+    (tests/text_with_rank_support.rs:46-75) and searches / locates like the oracle."""
+    from genedex_amd import FmIndex
+    from oracle.oracle import OracleTable
+
+    rng = np.random.default_rng(900 + bits + (kind == "flat"))
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=40000, symbols=b"ACGTN")
+    c = cpu_index(texts, a, sa_rate=3, depth=2)
+    table = OracleTable(c.bwt, c.sigma, kind, bits)
+    g = FmIndex.from_parts(c.count_array, table.blocks, c.n, c.sa_samples, 3, c.border_keys, c.border_vals,
+                           c.sentinel_indices, a, lookup_depth=2, table_kind=kind, block_bits=bits)
+    cols = naive_occurrence_columns(c.bwt, c.sigma)
+    idx = np.arange(c.n + 1, dtype=np.uint64)
+    for s in range(c.sigma):
+        assert np.array_equal(g.rank_many(np.full(c.n + 1, s, dtype=np.uint8), idx), cols[s])
+    assert np.array_equal(g.symbol_at_many(np.arange(c.n, dtype=np.uint64)), c.bwt)
+    qs = mixed_queries(rng, texts, 400, 200, 60)
+    off, t, p, _ = g.locate_raw(*pack_queries(qs))
+    co, ct, cp = c.locate_many(qs)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    blocks, bo, sbo = g.export_condensed_table()  # always exported as Condensed / Block64
+    assert np.array_equal(blocks, c.blocks) and np.array_equal(bo, c.block_offsets)
+    assert np.array_equal(sbo, c.superblock_offsets)
+
+
+def test_import_of_a_wide_alphabet_flat512_table():
+    from genedex_amd import FmIndex
+    from oracle.oracle import OracleTable
+
+    rng = np.random.default_rng(931)
+    a = alph.u8_until(26)
+    texts = random_texts(rng, len_max=3000, symbols=bytes(range(27)))
+    c = cpu_index(texts, a, sa_rate=2, depth=1)
+    table = OracleTable(c.bwt, c.sigma, "flat", 512)
+    g = FmIndex.from_parts(c.count_array, table.blocks, c.n, c.sa_samples, 2, c.border_keys, c.border_vals,
+                           c.sentinel_indices, a, lookup_depth=1, table_kind="flat", block_bits=512)
+    cols = naive_occurrence_columns(c.bwt, c.sigma)
+    idx = np.arange(c.n + 1, dtype=np.uint64)
+    for s in range(c.sigma):
+        assert np.array_equal(g.rank_many(np.full(c.n + 1, s, dtype=np.uint8), idx), cols[s])
+    qs = [bytes(q) for q in mixed_queries(rng, texts, 200, 0, 12)]
+    off, t, p, _ = g.locate_raw(*pack_queries(qs))
+    co, ct, cp = c.locate_many(qs)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
