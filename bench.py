@@ -128,34 +128,53 @@ def main():
 
     ev_search, ev_locate = [], []
 
+    # N > 1: results are gathered to rank 0 over RCCL asynchronously, double-buffered, so that the gather of
+    # batch k overlaps the kernels of batch k+1 (payloads padded to the largest shard up front).
+    slots = [(out, hits, counts)]
+    gather = None
+    if world > 1:
+        max_hits = gdist.max_int_over_ranks(total_hits, dev)
+        hits = torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev)
+        hits_b = torch.zeros_like(hits)
+        slots = [(out, hits, counts), (eng.alloc_outputs(nq), hits_b, torch.empty_like(counts))]
+        gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for (_, h, c) in slots], dst=0)
+    step_no = [0]
+
     def step(record):
+        slot = step_no[0] % len(slots)
+        step_no[0] += 1
+        o, h, cnt = slots[slot]
+        if gather:
+            gather.acquire(slot)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        eng.search(queries, out)
+        eng.search(queries, o)
         b.record()
         if record:
             ev_search.append((a, b))
         if do_locate:
-            eng.hit_offsets(out, nq)
+            eng.hit_offsets(o, nq)
             c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c.record()
-            eng.locate(out, nq, total_hits, hits, workspace)
+            eng.locate(o, nq, total_hits, h, workspace)
             d.record()
             if record:
                 ev_locate.append((c, d))
-        if world > 1:
-            torch.sub(out["end"], out["start"], out=counts)
-            gdist.gather_fixed(counts, dst=0)
-            if do_locate:
-                gdist.gather_variable(hits, total_hits, dst=0)
+        if gather:
+            torch.sub(o["end"], o["start"], out=cnt)
+            gather.submit(slot)
 
     for _ in range(args.warmup):
         step(False)
+    if gather:
+        gather.drain()
     gdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    if gather:
+        gather.drain()
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0

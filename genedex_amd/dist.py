@@ -69,3 +69,53 @@ def max_over_ranks(value: float, device) -> float:
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+class PipelinedGather:
+    """Result gather to `dst` that overlaps with the next batch's kernels.
+
+    Two slots of equal-shaped result tensors (double buffering): `submit(slot)` enqueues an asynchronous
+    gather of the slot's tensors (RCCL runs it on its own stream after the kernels that produced them);
+    `acquire(slot)` must be called before the slot's tensors are overwritten and waits for the gather that
+    last read them; `drain()` waits for everything.  Per-rank payloads are padded to the same shape up front
+    (`max_rows`), so no size exchange happens inside the timed loop.
+    """
+
+    def __init__(self, slots, dst: int = 0):
+        # slots: list (one per slot) of lists of tensors; same shapes/dtypes on every rank
+        self.slots = slots
+        self.dst = dst
+        self.rank, self.world = world()
+        self.pending = [[] for _ in slots]
+        self.recv = None
+        if self.world > 1 and self.rank == dst:
+            self.recv = [[[torch.empty_like(t) for _ in range(self.world)] for t in slot] for slot in slots]
+
+    def acquire(self, slot: int) -> None:
+        for w in self.pending[slot]:
+            w.wait()
+        self.pending[slot] = []
+
+    def submit(self, slot: int) -> None:
+        if self.world == 1:
+            return
+        for k, t in enumerate(self.slots[slot]):
+            out = self.recv[slot][k] if self.rank == self.dst else None
+            self.pending[slot].append(dist.gather(t, out, dst=self.dst, async_op=True))
+
+    def drain(self) -> None:
+        for slot in range(len(self.slots)):
+            self.acquire(slot)
+
+    def gathered(self, slot: int):
+        """On dst: per tensor of the slot the list of world tensors (after acquire/drain)."""
+        return self.recv[slot] if self.recv is not None else [[t] for t in self.slots[slot]]
+
+
+def max_int_over_ranks(value: int, device) -> int:
+    rank, n = world()
+    if n == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

@@ -47,6 +47,28 @@ def _worker(rank, world, port, result_path):
     got_counts = gdist.gather_variable(pad, counts.numel(), dst=0)
     hits = torch.from_numpy(np.stack([t.astype(np.int64), p.astype(np.int64)], axis=1))
     got_hits = gdist.gather_variable(hits, hits.shape[0], dst=0)
+    # pipelined (asynchronous, double-buffered) gather, the form bench.py uses between steps
+    max_hits = gdist.max_int_over_ranks(hits.shape[0], torch.device("cpu"))
+    slots = [[torch.zeros(nq // world + 1, dtype=torch.int64), torch.zeros((max_hits, 2), dtype=torch.int64)]
+             for _ in range(2)]
+    pg = gdist.PipelinedGather(slots, dst=0)
+    pipelined_ok = True
+    for step in range(5):
+        slot = step % 2
+        pg.acquire(slot)
+        slots[slot][0].zero_()
+        slots[slot][0][: counts.numel()] = counts + step
+        slots[slot][1].zero_()
+        slots[slot][1][: hits.shape[0]] = hits
+        pg.submit(slot)
+    pg.drain()
+    if rank == 0:
+        for slot, step in ((0, 4), (1, 3)):
+            got = pg.gathered(slot)
+            for r in range(world):
+                rlo, rhi = gdist.shard_range(nq, r, world)
+                pipelined_ok &= bool((got[0][r][: rhi - rlo] >= step).all())
+            pipelined_ok &= torch.equal(got[1][0][: hits.shape[0]], hits)
     fixed = gdist.gather_fixed(torch.tensor([rank, hi - lo]), dst=0)
     tmax = gdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     gdist.barrier()
@@ -57,7 +79,7 @@ def _worker(rank, world, port, result_path):
         foff, ft, fp = replica.locate_intervals(fs, fe)
         ok = (np.array_equal(all_counts, (fe - fs).astype(np.int64))
               and np.array_equal(all_hits[:, 0], ft.astype(np.int64)) and np.array_equal(all_hits[:, 1], fp.astype(np.int64))
-              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0)
+              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok)
         open(result_path, "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
 
