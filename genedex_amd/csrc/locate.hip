@@ -43,6 +43,50 @@ __global__ __launch_bounds__(kBlock) void mark_heads_kernel(const uint32_t *__re
     }
 }
 
+// sampled_suffix_array.rs:110-138 for one suffix-array index: concatenated-text position of SA[i]
+template <class Table>
+__device__ __forceinline__ uint32_t walk_to_sample(const IndexView &ix, const uint32_t *s_count, uint32_t i,
+                                                   uint32_t &steps)
+{
+    steps = 0;
+    for (;;) {
+        // :118 while i % sampling_rate != 0
+        const bool sampled =
+            ix.sa_rate_pow2_mask != 0xffffffffu ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
+        if (sampled) {
+            const uint32_t slot = ix.sa_rate_pow2_mask != 0xffffffffu ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate);
+            return ix.sa_samples[slot] + steps;  // :133-136
+        }
+        uint32_t r;
+        const uint32_t c = Table::symbol_and_rank(ix, i, r);
+        if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
+            const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, i);
+            return ix.border_vals[b] + steps;
+        }
+        i = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
+        steps++;
+    }
+}
+
+// text_id_search_tree.rs:35-64: smallest t with pos <= sentinel_indices[t], position inside that text
+template <bool kWide>
+__device__ __forceinline__ void store_hit(const IndexView &ix, uint32_t pos, void *hits_out, uint64_t at)
+{
+    const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
+    const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
+    if (kWide) {
+        gdx_hit_t out;
+        out.text_id = t;
+        out.position = in_text;
+        static_cast<gdx_hit_t *>(hits_out)[at] = out;
+    } else {
+        gdx_hit32_t out;
+        out.text_id = t;
+        out.position = in_text;
+        static_cast<gdx_hit32_t *>(hits_out)[at] = out;
+    }
+}
+
 template <class Table, bool kWide>
 __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint32_t *__restrict__ start,
                                                         const uint64_t *__restrict__ hit_offsets,
@@ -53,47 +97,15 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
     __shared__ uint32_t s_count[257];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
     __syncthreads();
-
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
     for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; h < total; h += stride) {
         const uint32_t q = query_of_hit[h] - 1u;
-        uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);  // SA index of this hit
-        uint32_t steps = 0, pos;
-        for (;;) {
-            // sampled_suffix_array.rs:118 while i % sampling_rate != 0
-            const bool sampled =
-                ix.sa_rate_pow2_mask != 0xffffffffu ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
-            if (sampled) {
-                const uint32_t slot = ix.sa_rate_pow2_mask != 0xffffffffu ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate);
-                pos = ix.sa_samples[slot] + steps;  // :133-136
-                break;
-            }
-            uint32_t r;
-            const uint32_t c = Table::symbol_and_rank(ix, i, r);
-            if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
-                const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, i);
-                pos = ix.border_vals[b] + steps;
-                break;
-            }
-            i = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
-            steps++;
-        }
+        const uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);  // SA index of this hit
+        uint32_t steps;
+        const uint32_t pos = walk_to_sample<Table>(ix, s_count, i, steps);
         walk_steps += steps;
-        // text_id_search_tree.rs:35-64: smallest t with pos <= sentinel_indices[t]
-        const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
-        const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
-        if (kWide) {
-            gdx_hit_t out;
-            out.text_id = t;
-            out.position = in_text;
-            static_cast<gdx_hit_t *>(hits_out)[h] = out;
-        } else {
-            gdx_hit32_t out;
-            out.text_id = t;
-            out.position = in_text;
-            static_cast<gdx_hit32_t *>(hits_out)[h] = out;
-        }
+        store_hit<kWide>(ix, pos, hits_out, h);
     }
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
@@ -254,6 +266,9 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     // The walk is bound by DRAM requests, not by latency: one lane per hit on the 64-byte rank lines keeps 8x
     // more hits in flight and measures 10.8 ms per 90 M hits against 16.6 ms for the 8-lane pair-line kernel,
     // although the latter needs ~1.7 instead of 3 line fetches per hit.  GDX_LOCATE_VARIANT=pair selects it.
+    // (Also tried: visiting the hits in suffix-array order after a radix sort of (row, slot) pairs.  The walk
+    // kernel drops only from 10.4 to 9.3 ms -- the sample reads and the now scattered hit stores stay random --
+    // and the sort costs 3 ms: 12.5 ms in total, removed again.)
     static const bool lane_variant = [] {
         const char *e = getenv("GDX_LOCATE_VARIANT");
         return !(e && e[0] == 'p');
