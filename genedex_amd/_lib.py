@@ -107,11 +107,36 @@ _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_locate_w
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A process must hold ONE HIP runtime.  torch wheels bundle their own libamdhip64.so.7; whichever copy is
+    loaded first serves every later DT_NEEDED of that soname.  If libgdx.so pulled in /opt/rocm's copy first, a
+    later `import torch` would find "No HIP GPUs".  So, when torch is installed (not necessarily imported),
+    its copy is loaded first, and libgdx.so and torch share it whatever the import order."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Loads libgdx.so; raises if it is absent (no fallback path exists)."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           f"or `make -C genedex_amd/csrc`. genedex_amd has no CPU fallback.")

@@ -1,0 +1,139 @@
+"""Contract of the C ABI (include/gdx.h) beyond the happy path: status codes where the reference panics, the
+two-phase locate protocol, device-resident entry points, concurrent use of one handle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from genedex_amd import alphabet as alph
+from oracle.oracle import OracleIndex, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from genedex_amd import FmIndexConfig, _lib
+
+    rng = np.random.default_rng(2024)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, 20000, p=[.2475, .2475, .2475, .2475, .01])) for _ in range(3)]
+    g = FmIndexConfig("u32").lookup_table_depth(3).construct_index(texts, a)
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=3, width=32)
+    return _lib, _lib.load(), g, c, texts, rng
+
+
+def test_invalid_arguments_are_reported_not_crashed(setup):
+    _lib, lib, g, c, texts, rng = setup
+    u8p, u64p = _lib.u8p, _lib.u64p
+    qbuf, qoff = pack_queries([b"ACGT", b"GG"])
+    out = np.zeros(2, dtype=np.uint64)
+    # null handle / null outputs / decreasing offsets
+    assert lib.gdx_count_many(None, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), 2, out.ctypes.data_as(u64p), None) == _lib.GDX_ERR_INVALID_ARGUMENT
+    assert lib.gdx_count_many(g._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), 2, None, None) == _lib.GDX_ERR_INVALID_ARGUMENT
+    bad = np.array([0, 4, 2], dtype=np.uint64)
+    assert lib.gdx_count_many(g._h, qbuf.ctypes.data_as(u8p), bad.ctypes.data_as(u64p), 2, out.ctypes.data_as(u64p), None) == _lib.GDX_ERR_INVALID_ARGUMENT
+    assert b"non-decreasing" in lib.gdx_last_error()
+    # construction: sigma / rate / width / depth / device
+    tab = alph.ascii_dna().io_to_dense_table
+    h = C.c_void_p()
+    tbuf, toff = pack_queries([b"ACGT"])
+
+    def build(sigma=5, k=4, rate=4, depth=0, width=32, device=0):
+        return lib.gdx_index_build(tbuf.ctypes.data_as(u8p), toff.ctypes.data_as(u64p), 1, tab.ctypes.data_as(u8p), sigma, k,
+                                   rate, depth, width, device, C.byref(h))
+
+    assert build(sigma=1) == _lib.GDX_ERR_INVALID_ARGUMENT      # condensed.rs:64
+    assert build(rate=0) == _lib.GDX_ERR_INVALID_ARGUMENT       # config.rs:28
+    assert build(width=16) == _lib.GDX_ERR_INVALID_ARGUMENT
+    assert build(depth=40) == _lib.GDX_ERR_INVALID_ARGUMENT
+    assert build(device=99) == _lib.GDX_ERR_INVALID_ARGUMENT
+    assert build(k=5) == _lib.GDX_ERR_INVALID_ARGUMENT          # alphabet.rs:183-186
+    assert build() == _lib.GDX_OK
+    lib.gdx_index_free(h)
+    # zero queries is fine
+    empty = np.zeros(1, dtype=np.uint64)
+    assert lib.gdx_count_many(g._h, None, empty.ctypes.data_as(u64p), 0, None, None) == _lib.GDX_OK
+
+
+def test_two_phase_locate_protocol(setup):
+    _lib, lib, g, c, texts, rng = setup
+    u8p, u64p = _lib.u8p, _lib.u64p
+    qs = [texts[0][100:130], b"A", texts[1][5:60], b"ACGTACGTACGTACGTACGTAAAA"]
+    qbuf, qoff = pack_queries(qs)
+    off = np.zeros(len(qs) + 1, dtype=np.uint64)
+    total = C.c_uint64(0)
+    rc = lib.gdx_locate_many(g._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), len(qs), off.ctypes.data_as(u64p),
+                             None, 0, C.byref(total), None)
+    assert rc == _lib.GDX_ERR_CAPACITY and total.value == off[-1] > 0
+    hits = np.zeros((total.value, 2), dtype=np.uint64)
+    rc = lib.gdx_locate_many(g._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), len(qs), off.ctypes.data_as(u64p),
+                             hits.ctypes.data_as(C.POINTER(_lib.HitStruct)), total.value - 1, C.byref(total), None)
+    assert rc == _lib.GDX_ERR_CAPACITY
+    rc = lib.gdx_locate_many(g._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), len(qs), off.ctypes.data_as(u64p),
+                             hits.ctypes.data_as(C.POINTER(_lib.HitStruct)), total.value, C.byref(total), None)
+    assert rc == _lib.GDX_OK
+    co, ct, cp = c.locate_many(qs)
+    assert off.tolist() == co.tolist() and hits[:, 0].tolist() == ct.tolist() and hits[:, 1].tolist() == cp.tolist()
+
+
+def test_one_handle_from_many_threads(setup):
+    """FmIndex is Send + Sync in the reference; handles are immutable here."""
+    _lib, lib, g, c, texts, rng = setup
+    qs = [texts[int(rng.integers(0, 3))][s:s + 40] for s in rng.integers(0, 19000, 4000)]
+    qs = [q for q in qs if b"N" not in q[-3:]]
+    want = c.count_many(qs).tolist()
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(3):
+                got = g.count_many(qs).tolist()
+                if got != want:
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[:3]
+
+
+def test_device_resident_entry_points(setup):
+    torch = pytest.importorskip("torch")
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    _lib, lib, g, c, texts, rng = setup
+    qs = [texts[int(rng.integers(0, 3))][s:s + int(rng.integers(1, 90))] for s in rng.integers(0, 19000, 5000)]
+    qs = [q for q in qs if b"N" not in q[-3:]] + [b"", b"T" * 300]
+    qbuf, qoff = pack_queries(qs)
+    dq = DeviceQueries.from_host(qbuf, qoff)
+    eng = DeviceEngine(g)
+    out = eng.alloc_outputs(dq.nq)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):  # a non-default stream: the ABI must enqueue on the stream it is given
+        eng.search(dq, out)
+        eng.hit_offsets(out, dq.nq)
+        stream.synchronize()
+        total = int(out["hit_offsets"][dq.nq].item())
+        hits = torch.empty((total, 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(eng.locate_workspace_bytes(total), dtype=torch.uint8, device="cuda")
+        eng.locate(out, dq.nq, total, hits, ws)
+        counts = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+        status = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+        eng.count(dq, counts, status)
+        stream.synchronize()
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    assert (out["start"].cpu().numpy().astype(np.uint32) == cs.astype(np.uint32)).all()
+    assert (out["end"].cpu().numpy().astype(np.uint32) == ce.astype(np.uint32)).all()
+    assert (counts.cpu().numpy().astype(np.uint32) == (ce - cs).astype(np.uint32)).all()
+    co, ct, cp = c.locate_intervals(cs, ce)
+    h = hits.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(out["hit_offsets"].cpu().numpy().astype(np.uint64), co)
+    assert np.array_equal(h[:, 0], ct.astype(np.uint32)) and np.array_equal(h[:, 1], cp.astype(np.uint32))
+    # unaligned device query buffer is rejected (gdx.h: 8-byte alignment)
+    rc = lib.gdx_count_many_dev(g._h, C.c_void_p(dq.qbuf.data_ptr() + 1), C.c_void_p(dq.qoff.data_ptr()), 1,
+                                C.c_void_p(counts.data_ptr()), None, None)
+    assert rc == _lib.GDX_ERR_INVALID_ARGUMENT
