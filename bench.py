@@ -186,7 +186,7 @@ def main():
     locate_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_locate])) if ev_locate else None
 
     # ---- algorithmic bytes, counted by an extra, untimed pass ------------------
-    lf_steps = eng.search_lf_steps(queries)
+    lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
     variant = os.environ.get("GDX_SEARCH_VARIANT", "pair")
     uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
@@ -198,7 +198,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": search_bytes, "lf_steps_per_launch": lf_steps,
-                "avg_launch_ms": search_ms}
+                "avg_launch_ms": search_ms,
+                "line_fetches_per_query": fetches / nq if fetches else None,
+                "active_lane_fraction": fetches / fetch_slots if fetch_slots else None}
     roofline.update(pmc_traffic(kernel_name, args, wl, nq))
     locate_roofline = None
     if do_locate and total_hits:

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
-template <int kPolicy, int kGroup>
+template <int kPolicy, int kGroup, bool kStats>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
@@ -214,6 +214,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
     const bool writer = (threadIdx.x % kGroup) == 0;
     uint32_t lf_steps = 0;
+    unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; q < nq;
          q += stride) {
         const uint64_t begin = qoff[q], end = qoff[q + 1];
@@ -244,11 +245,13 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         QueryWindow win;
         win.init(qbuf, begin, pos);
         bool jump_ok = ix.jump != nullptr;
+        uint32_t iters = 0;  // line fetches of this query (divergence accounting, step_stats only)
         while (pos > begin && lo != hi) {
+            if (kStats) iters++;
             if (jump_ok && hi - lo == 1u && pos - begin >= kJumpSymbols) {
                 if (try_jump(ix, s_dense, win, pos, lo, hi)) {
                     pos -= kJumpSymbols;
-                    lf_steps += kJumpSymbols;
+                    if (kStats) lf_steps += kJumpSymbols;
                     continue;
                 }
                 jump_ok = false;  // mismatch or an invalid symbol ahead: the pair lines finish this query
@@ -268,7 +271,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     lo = nlo;
                     hi = nhi;
                     pos -= 2;
-                    lf_steps += 2;
+                    if (kStats) lf_steps += 2;
                     continue;
                 }
                 // the interval empties within these two steps: fall through to single steps so that the
@@ -284,7 +287,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 hi = cc + rhi;
             }
             pos--;
-            lf_steps++;
+            if (kStats) lf_steps++;
         }
         if (writer) {
             if (out_start) out_start[q] = lo;
@@ -292,8 +295,21 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
         }
+        if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
+            uint32_t wave_max = iters;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(wave_max, off);
+                wave_max = o > wave_max ? o : wave_max;
+            }
+            group_iters += iters;
+            wave_slots += wave_max;
+        }
     }
-    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+    if (kStats && step_stats && writer) {
+        atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+        atomicAdd(step_stats + 1, group_iters);
+        atomicAdd(step_stats + 2, wave_slots);
+    }
 }
 
 #define GDX_SEARCH_ARGS                                                                                      \
@@ -310,12 +326,24 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 template <int kPolicy>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, false>(GDX_SEARCH_FWD);
 }
 template <int kPolicy>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, false>(GDX_SEARCH_FWD);
+}
+// accounting variants (gdx_search_step_stats_dev): the counters cost registers, so they are kept out of the
+// kernels that are timed
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) void search_pair_stats_kernel8(GDX_SEARCH_ARGS)
+{
+    search_pair_body<kPolicy, 8, true>(GDX_SEARCH_FWD);
+}
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) void search_pair_stats_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_body<kPolicy, 4, true>(GDX_SEARCH_FWD);
 }
 
 // The same search as search_pair_kernel, organised as a stream: every 8-lane group walks its own
@@ -324,7 +352,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 // mixed-length batches, BASELINE workload 5).  The next query's offsets and its last two 8-byte windows
 // are requested two iterations / one iteration after the current query started and are consumed some 20
 // line fetches later, so starting a query costs no memory wait (with a lookup table: one).
-template <int kPolicy, int kGroup>
+template <int kPolicy, int kGroup, bool kStats>
 __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                                     const uint64_t *__restrict__ qoff, uint64_t nq,
                                                                     uint32_t *__restrict__ out_start,
@@ -346,6 +374,7 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint64_t *words = reinterpret_cast<const uint64_t *>(qbuf);
     uint32_t lf_steps = 0;
+    unsigned long long active_iters = 0, loop_iters = 0;  // step_stats[1], [2]
 
     // the query being searched
     uint64_t q = 0, begin = 0, pos = 0;
@@ -417,13 +446,15 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
             nx_stage = 0;
         }
         // ---- one (double) LF step of the current query -------------------------------------------------
+        if (kStats) loop_iters++;
         if (have) {
+            if (kStats) active_iters++;
             bool jumped = false;
             if (jump_ok && pos > begin && hi - lo == 1u && pos - begin >= kJumpSymbols) {
                 jumped = try_jump(ix, s_dense, win, pos, lo, hi);
                 if (jumped) {
                     pos -= kJumpSymbols;
-                    lf_steps += kJumpSymbols;
+                    if (kStats) lf_steps += kJumpSymbols;
                 } else {
                     jump_ok = false;
                 }
@@ -444,7 +475,7 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
                             lo = nlo;
                             hi = nhi;
                             pos -= 2;
-                            lf_steps += 2;
+                            if (kStats) lf_steps += 2;
                             stepped = true;
                         }
                     }
@@ -459,7 +490,7 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
                             hi = cc + rhi;
                         }
                         pos--;
-                        lf_steps++;
+                        if (kStats) lf_steps++;
                     }
                 }
             }
@@ -475,18 +506,32 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
         }
         if (!__any(have || nx_stage != 0 || nx_q < nq)) break;
     }
-    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+    if (kStats && step_stats && writer) {
+        atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
+        atomicAdd(step_stats + 1, active_iters);
+        atomicAdd(step_stats + 2, loop_iters);
+    }
 }
 
 template <int kPolicy>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_stream_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_stream_body<kPolicy, 8>(GDX_SEARCH_FWD);
+    search_pair_stream_body<kPolicy, 8, false>(GDX_SEARCH_FWD);
 }
 template <int kPolicy>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_stream_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_stream_body<kPolicy, 4>(GDX_SEARCH_FWD);
+    search_pair_stream_body<kPolicy, 4, false>(GDX_SEARCH_FWD);
+}
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) void search_pair_stream_stats_kernel8(GDX_SEARCH_ARGS)
+{
+    search_pair_stream_body<kPolicy, 8, true>(GDX_SEARCH_FWD);
+}
+template <int kPolicy>
+__global__ __launch_bounds__(kBlock) void search_pair_stream_stats_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_stream_body<kPolicy, 4, true>(GDX_SEARCH_FWD);
 }
 
 // Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
@@ -670,6 +715,27 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             GDX_HIP(hipMemcpyAsync(d_range, init, sizeof(init), hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, d_qoff, nq,
                                d_range);
+        }
+        if (d_step_stats != nullptr) {
+            if (lanes == 8) {
+                if (forced != 1)
+                    hipLaunchKernelGGL(search_pair_stats_kernel8<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf,
+                                       d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, 1);
+                if (forced != 0)
+                    hipLaunchKernelGGL(search_pair_stream_stats_kernel8<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix,
+                                       d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats,
+                                       d_range, 0);
+            } else {
+                if (forced != 1)
+                    hipLaunchKernelGGL(search_pair_stats_kernel4<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf,
+                                       d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, 1);
+                if (forced != 0)
+                    hipLaunchKernelGGL(search_pair_stream_stats_kernel4<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix,
+                                       d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats,
+                                       d_range, 0);
+            }
+            if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
+            return;
         }
 #define GDX_PAIR(P, L)                                                                                                 \
     do {                                                                                                            \

@@ -131,11 +131,15 @@ class DeviceEngine:
                                                      _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
                                                      _stream()))
 
-    def search_lf_steps(self, q: DeviceQueries) -> int:
-        steps = torch.zeros(1, dtype=torch.int64, device=self.dev)
+    def search_step_stats(self, q: DeviceQueries):
+        """(LF steps, line fetches of all queries, fetch slots their wavefronts spent)"""
+        steps = torch.zeros(3, dtype=torch.int64, device=self.dev)
         _lib.check(self.lib.gdx_search_step_stats_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(steps),
                                                       _stream()))
-        return int(steps.item())
+        return [int(x) for x in steps.tolist()]
+
+    def search_lf_steps(self, q: DeviceQueries) -> int:
+        return self.search_step_stats(q)[0]
 
     def locate_walk_steps(self, out, m: int, total: int, hits: torch.Tensor, workspace: torch.Tensor) -> int:
         steps = torch.zeros(1, dtype=torch.int64, device=self.dev)
