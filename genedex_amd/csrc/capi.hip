@@ -2,6 +2,7 @@
 // helpers of include/gdx_bench.h).  Exceptions never cross it: they become a gdx_status plus a
 // thread-local message.
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 
@@ -10,6 +11,57 @@
 #include "fm_index.hpp"
 #include "kernels.hpp"
 #include "synth.hpp"
+
+namespace gdx {
+
+namespace {
+struct Arena {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+};
+struct ArenaKey {
+    hipStream_t stream;
+    int slot;
+    int device;
+    bool operator<(const ArenaKey &o) const
+    {
+        if (stream != o.stream) return stream < o.stream;
+        if (slot != o.slot) return slot < o.slot;
+        return device < o.device;
+    }
+};
+struct ArenaMap {
+    std::map<ArenaKey, Arena> arenas;
+    ~ArenaMap()
+    {
+        for (auto &kv : arenas)
+            if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    }
+};
+}  // namespace
+
+void *stream_scratch(hipStream_t stream, int slot, size_t bytes)
+{
+    thread_local ArenaMap map;
+    int dev = 0;
+    GDX_HIP(hipGetDevice(&dev));
+    Arena &a = map.arenas[ArenaKey{stream, slot, dev}];
+    if (a.bytes < bytes) {
+        if (a.ptr) {
+            GDX_HIP(hipStreamSynchronize(stream));
+            GDX_HIP(hipFree(a.ptr));
+            a.ptr = nullptr;
+            a.bytes = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        GDX_HIP(hipMalloc(&a.ptr, want));
+        a.bytes = want;
+    }
+    return a.ptr;
+}
+
+}  // namespace gdx
 
 struct gdx_index {
     std::unique_ptr<gdx::FmIndex> impl;
@@ -313,11 +365,9 @@ int gdx_hit_offsets_dev(const gdx_index_t *ix, const void *d_start, const void *
     return guarded([&] {
         (void)deref(ix);
         const size_t tb = gdx::hit_offsets_temp_bytes(m);
-        void *temp = nullptr;
-        GDX_HIP(hipMallocAsync(&temp, tb ? tb : 1, as_stream(stream)));
+        void *temp = gdx::stream_scratch(as_stream(stream), 8, tb ? tb : 1);
         gdx::launch_hit_offsets(static_cast<const uint32_t *>(d_start), static_cast<const uint32_t *>(d_end), m,
                                 static_cast<uint64_t *>(d_hit_offsets), temp, tb, as_stream(stream));
-        GDX_HIP(hipFreeAsync(temp, as_stream(stream)));
         return (int)GDX_OK;
     });
 }
@@ -342,12 +392,10 @@ int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *
 {
     return guarded([&] {
         const gdx::FmIndex &f = deref(ix);
-        uint32_t *d_err = nullptr;
-        GDX_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_err), sizeof(uint32_t), as_stream(stream)));
+        uint32_t *d_err = static_cast<uint32_t *>(gdx::stream_scratch(as_stream(stream), 9, sizeof(uint32_t)));
         GDX_HIP(hipMemsetAsync(d_err, 0, sizeof(uint32_t), as_stream(stream)));
         gdx::launch_rank_many(f.view(), static_cast<const uint8_t *>(d_symbols), static_cast<const uint32_t *>(d_idx),
                               m, static_cast<uint32_t *>(d_out), d_err, as_stream(stream));
-        GDX_HIP(hipFreeAsync(d_err, as_stream(stream)));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

@@ -81,6 +81,12 @@ struct DeviceBuffer {
 
 inline uint64_t div_ceil(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Grow-only scratch memory for the `_dev` entry points, one arena per (calling thread, stream, slot).
+// Work on one stream is ordered, so a later call may reuse the bytes of an earlier one without waiting;
+// hipMallocAsync / hipFreeAsync per call cost ~0.1 ms each on this runtime.  Growing an arena waits for the
+// stream once.  Arenas live until the thread exits.
+void *stream_scratch(hipStream_t stream, int slot, size_t bytes);
+
 // grid size for a grid-stride kernel: enough blocks to fill 256 CUs several times over
 inline unsigned grid_for(uint64_t work_items, unsigned block, unsigned max_blocks = 256u * 16u)
 {

@@ -170,9 +170,10 @@ __device__ __forceinline__ bool lengths_are_uniform(const uint32_t *len_range)
 __global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
                                                                     uint32_t *__restrict__ len_range)
 {
+    // a sample is enough (every 61st query): the range only picks a schedule, never affects results
     uint32_t mn = 0xffffffffu, mx = 0;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < nq; q += stride) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock * 61u;
+    for (uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * 61u; q < nq; q += stride) {
         const uint64_t len = qoff[q + 1] - qoff[q];
         const uint32_t l = len > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(len);
         mn = l < mn ? l : mn;
@@ -189,6 +190,89 @@ __global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64
     }
 }
 
+// ---- length-ordered schedule for mixed-length batches -----------------------------------------------
+// The lock-step kernel idles the lanes of a finished query until the longest query of its wavefront ends.
+// When the lengths of a batch are spread out, the queries are bucketed by length (4 symbols per bucket,
+// longest first) and the kernel walks that permutation, so that the queries of a wavefront have nearly
+// the same length; results are still written at the original query index.  Everything is decided and
+// done on the device: for a uniform batch the three kernels return at once.
+constexpr uint32_t kLenBuckets = 64;
+constexpr uint32_t kLenChunk = 4096;  // queries per histogram block
+
+__device__ __forceinline__ uint32_t length_bucket(uint64_t len)
+{
+    const uint64_t b = len >> 2;
+    return kLenBuckets - 1u - static_cast<uint32_t>(b < kLenBuckets - 1u ? b : kLenBuckets - 1u);
+}
+
+// counts[bucket * n_chunks + chunk]
+__global__ __launch_bounds__(kBlock) void length_hist_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                             const uint32_t *__restrict__ len_range, uint32_t n_chunks,
+                                                             uint32_t *__restrict__ counts)
+{
+    if (lengths_are_uniform(len_range)) return;
+    __shared__ uint32_t s_cnt[kLenBuckets];
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < kLenChunk; t += kBlock) {
+            const uint64_t q = static_cast<uint64_t>(chunk) * kLenChunk + t;
+            if (q < nq) atomicAdd(&s_cnt[length_bucket(qoff[q + 1] - qoff[q])], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < kLenBuckets) counts[threadIdx.x * n_chunks + chunk] = s_cnt[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// in-place exclusive scan of `cells` u32 values by one block (cells is a few million at most)
+__global__ __launch_bounds__(1024) void length_scan_kernel(uint32_t *__restrict__ cells, uint64_t n_cells,
+                                                           const uint32_t *__restrict__ len_range)
+{
+    if (lengths_are_uniform(len_range)) return;
+    __shared__ uint32_t s_sum[1024];
+    const uint64_t per = (n_cells + 1023) / 1024;
+    const uint64_t lo = threadIdx.x * per, hi = lo + per < n_cells ? lo + per : n_cells;
+    uint32_t sum = 0;
+    for (uint64_t i = lo; i < hi; i++) sum += cells[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = threadIdx.x >= static_cast<uint32_t>(off) ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint64_t i = lo; i < hi; i++) {
+        const uint32_t v = cells[i];
+        cells[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void length_scatter_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                                const uint32_t *__restrict__ len_range,
+                                                                uint32_t n_chunks, const uint32_t *__restrict__ offsets,
+                                                                uint32_t *__restrict__ perm)
+{
+    if (lengths_are_uniform(len_range)) return;
+    __shared__ uint32_t s_cnt[kLenBuckets];
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < kLenChunk; t += kBlock) {
+            const uint64_t q = static_cast<uint64_t>(chunk) * kLenChunk + t;
+            if (q < nq) {
+                const uint32_t b = length_bucket(qoff[q + 1] - qoff[q]);
+                const uint32_t r = atomicAdd(&s_cnt[b], 1u);
+                perm[offsets[b * n_chunks + chunk] + r] = static_cast<uint32_t>(q);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Backward search on pair lines: eight lanes per query, two LF steps per line fetch while both next
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
@@ -201,9 +285,12 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
-                                                             const uint32_t *__restrict__ len_range, int run_if_uniform)
+                                                             const uint32_t *__restrict__ len_range, int run_if_uniform,
+                                                             const uint32_t *__restrict__ perm)
 {
-    if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
+    // run_if_uniform: 1 / 0 = run only for uniform / non-uniform batches, -1 = always
+    if (len_range && run_if_uniform >= 0 && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
+    const bool use_perm = perm != nullptr && len_range != nullptr && !lengths_are_uniform(len_range);
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
@@ -215,8 +302,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     const bool writer = (threadIdx.x % kGroup) == 0;
     uint32_t lf_steps = 0;
     unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; q < nq;
-         q += stride) {
+    for (uint64_t slot = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; slot < nq;
+         slot += stride) {
+        const uint64_t q = use_perm ? perm[slot] : slot;
         const uint64_t begin = qoff[q], end = qoff[q + 1];
         const uint64_t len = end - begin;
         const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
@@ -316,8 +404,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
         uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
         uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats,                      \
-        const uint32_t *__restrict__ len_range, int run_if_uniform
-#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, run_if_uniform
+        const uint32_t *__restrict__ len_range, int run_if_uniform, const uint32_t *__restrict__ perm
+#define GDX_SEARCH_FWD \
+    ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, run_if_uniform, perm
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
@@ -360,9 +449,11 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
                                                                     uint32_t *__restrict__ out_count,
                                                                     uint8_t *__restrict__ out_status,
                                                                     unsigned long long *__restrict__ step_stats,
-                                                                    const uint32_t *__restrict__ len_range, int run_if_uniform)
+                                                                    const uint32_t *__restrict__ len_range, int run_if_uniform,
+                                                                    const uint32_t *__restrict__ perm)
 {
-    if (len_range && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
+    (void)perm;
+    if (len_range && run_if_uniform >= 0 && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
@@ -700,65 +791,59 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 1;
         }();
-        // GDX_SEARCH_STREAM=0|1|auto: lock-step kernel (default: with the jump table it wins on uniform AND
-        // on mixed-length batches, profiles/r01/search_variants.md section 4), streaming kernel, or decided
-        // on the device from the spread of the query lengths (both kernels enqueued, one returns at once)
-        static const int forced = [] {
+        // GDX_SEARCH_STREAM: unset = lock-step kernel walking a length-ordered schedule when the lengths of the
+        // batch are spread out (default); 0 = lock-step in query order; 1 = streaming kernel; auto = lock-step
+        // or streaming decided on the device (both enqueued, one returns at once).
+        static const int mode = [] {
             const char *e = getenv("GDX_SEARCH_STREAM");
-            if (!e) return 0;
+            if (!e) return 2;
             return e[0] == 'a' ? -1 : (e[0] == '0' ? 0 : 1);
         }();
-        uint32_t *d_range = nullptr;
-        if (forced < 0) {
-            const uint32_t init[2] = {0xffffffffu, 0u};
-            GDX_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_range), sizeof(init), stream));
-            GDX_HIP(hipMemcpyAsync(d_range, init, sizeof(init), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, d_qoff, nq,
-                               d_range);
+        uint32_t *d_range = nullptr, *d_perm = nullptr, *d_cells = nullptr;
+        if (mode == -1 || mode == 2) {
+            d_range = static_cast<uint32_t *>(stream_scratch(stream, 0, 2 * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range), 0xffffffff, 1, stream));
+            GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range + 1), 0, 1, stream));
+            hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq / 61 + 1)), dim3(kBlock), 0, stream,
+                               d_qoff, nq, d_range);
         }
-        if (d_step_stats != nullptr) {
-            if (lanes == 8) {
-                if (forced != 1)
-                    hipLaunchKernelGGL(search_pair_stats_kernel8<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf,
-                                       d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, 1);
-                if (forced != 0)
-                    hipLaunchKernelGGL(search_pair_stream_stats_kernel8<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix,
-                                       d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats,
-                                       d_range, 0);
-            } else {
-                if (forced != 1)
-                    hipLaunchKernelGGL(search_pair_stats_kernel4<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf,
-                                       d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, 1);
-                if (forced != 0)
-                    hipLaunchKernelGGL(search_pair_stream_stats_kernel4<1>, dim3(blocks), dim3(kBlock), lds_pad, stream, ix,
-                                       d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats,
-                                       d_range, 0);
-            }
-            if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
-            return;
+        if (mode == 2) {
+            const uint32_t n_chunks = static_cast<uint32_t>((nq + kLenChunk - 1) / kLenChunk);
+            const uint64_t n_cells = static_cast<uint64_t>(kLenBuckets) * n_chunks;
+            d_perm = static_cast<uint32_t *>(stream_scratch(stream, 1, nq * sizeof(uint32_t)));
+            d_cells = static_cast<uint32_t *>(stream_scratch(stream, 2, n_cells * sizeof(uint32_t)));
+            const unsigned hist_grid = n_chunks < 16384u ? n_chunks : 16384u;
+            hipLaunchKernelGGL(length_hist_kernel, dim3(hist_grid), dim3(kBlock), 0, stream, d_qoff, nq, d_range, n_chunks,
+                               d_cells);
+            hipLaunchKernelGGL(length_scan_kernel, dim3(1), dim3(1024), 0, stream, d_cells, n_cells, d_range);
+            hipLaunchKernelGGL(length_scatter_kernel, dim3(hist_grid), dim3(kBlock), 0, stream, d_qoff, nq, d_range,
+                               n_chunks, d_cells, d_perm);
         }
-#define GDX_PAIR(P, L)                                                                                                 \
-    do {                                                                                                            \
-        if (forced != 1)                                                                                            \
-            hipLaunchKernelGGL(search_pair_kernel##L<P>, dim3(blocks), dim3(kBlock), lds_pad,   \
-                               stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,   \
-                               d_step_stats, d_range, 1);                                                           \
-        if (forced != 0)                                                                                            \
-            hipLaunchKernelGGL(search_pair_stream_kernel##L<P>, dim3(blocks), dim3(kBlock),     \
-                               lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count,        \
-                               d_out_status, d_step_stats, d_range, 0);                                             \
+        const int lock_flag = mode == -1 ? 1 : -1;  // auto: lock-step only for uniform batches
+#define GDX_PAIR_LAUNCH(LOCK, STREAM)                                                                              \
+    do {                                                                                                           \
+        if (mode != 1)                                                                                             \
+            hipLaunchKernelGGL(LOCK, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq,          \
+                               d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, lock_flag, \
+                               d_perm);                                                                            \
+        if (mode == 1 || mode == -1)                                                                               \
+            hipLaunchKernelGGL(STREAM, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq,        \
+                               d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range,           \
+                               mode == 1 ? -1 : 0, d_perm);                                                        \
     } while (0)
-        if (lanes == 8) {
-            if (policy == 1) GDX_PAIR(1, 8);
-            else if (policy == 2) GDX_PAIR(2, 8);
-            else if (policy == 3) GDX_PAIR(3, 8);
-            else GDX_PAIR(0, 8);
+        if (d_step_stats != nullptr) {
+            if (lanes == 8) GDX_PAIR_LAUNCH(search_pair_stats_kernel8<1>, search_pair_stream_stats_kernel8<1>);
+            else GDX_PAIR_LAUNCH(search_pair_stats_kernel4<1>, search_pair_stream_stats_kernel4<1>);
+        } else if (lanes == 8) {
+            if (policy == 1) GDX_PAIR_LAUNCH(search_pair_kernel8<1>, search_pair_stream_kernel8<1>);
+            else if (policy == 2) GDX_PAIR_LAUNCH(search_pair_kernel8<2>, search_pair_stream_kernel8<2>);
+            else if (policy == 3) GDX_PAIR_LAUNCH(search_pair_kernel8<3>, search_pair_stream_kernel8<3>);
+            else GDX_PAIR_LAUNCH(search_pair_kernel8<0>, search_pair_stream_kernel8<0>);
         } else {
-            if (policy == 0) GDX_PAIR(0, 4);
-            else GDX_PAIR(1, 4);
+            if (policy == 0) GDX_PAIR_LAUNCH(search_pair_kernel4<0>, search_pair_stream_kernel4<0>);
+            else GDX_PAIR_LAUNCH(search_pair_kernel4<1>, search_pair_stream_kernel4<1>);
         }
-        if (d_range) GDX_HIP(hipFreeAsync(d_range, stream));
-#undef GDX_PAIR
+#undef GDX_PAIR_LAUNCH
     } else if (ix.layout == 0 && search_variant() != 1) {
         const unsigned blocks = group_grid(kBlock / 4);
         hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(blocks), dim3(kBlock), lds_pad,
