@@ -34,6 +34,9 @@ def load(path: str | None = None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
+    explicit = path is not None
+    # GDX_ORACLE_LIB: alternative build of the oracle (e.g. libgdx_oracle_asan.so under LD_PRELOAD=libasan)
+    path = path or os.environ.get("GDX_ORACLE_LIB")
     p = path or os.path.join(_HERE, "libgdx_oracle.so")
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("gdx_oracle.c", "gdx_oracle.h"))
     if path is None and (not os.path.exists(p) or os.path.getmtime(p) < src_m):
@@ -95,7 +98,7 @@ def load(path: str | None = None):
     lib.gdxo_table_superblock_offsets.argtypes = [vp, u64p]
     lib.gdxo_naive_suffix_array.restype = None
     lib.gdxo_naive_suffix_array.argtypes = [u8p, C.c_uint64, u32p]
-    if path is None:
+    if not explicit:
         _LIB = lib
     return lib
 
