@@ -45,6 +45,8 @@ extern "C" {
         sentinel_indices: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int, n_searchable: c_int,
         lookup_depth: c_int, index_width: c_int, device_id: c_int, out: *mut *mut gdx_index_t,
     ) -> c_int;
+    pub fn gdx_index_save(ix: *const gdx_index_t, path: *const c_char) -> c_int;
+    pub fn gdx_index_load(path: *const c_char, device_id: c_int, out: *mut *mut gdx_index_t) -> c_int;
     pub fn gdx_index_free(ix: *mut gdx_index_t);
     pub fn gdx_count_many(
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64,

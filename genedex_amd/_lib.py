@@ -66,6 +66,8 @@ SIGNATURES = {
                              C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "gdx_index_from_parts_ex": [C.c_int, C.c_int, u64p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, u64p,
                                 C.c_uint64, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "gdx_index_save": [vp, C.c_char_p],
+    "gdx_index_load": [C.c_char_p, C.c_int, C.POINTER(vp)],
     "gdx_index_free": [vp],
     "gdx_index_info": [vp, C.POINTER(IndexInfo)],
     "gdx_index_export_count": [vp, u64p],

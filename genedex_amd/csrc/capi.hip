@@ -187,6 +187,25 @@ int gdx_index_from_parts(const uint64_t *count, const uint64_t *interleaved_bloc
                                    index_width, device_id, out);
 }
 
+int gdx_index_save(const gdx_index_t *ix, const char *path)
+{
+    return guarded([&] {
+        deref(ix).save(path);
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_load(const char *path, int device_id, gdx_index_t **out)
+{
+    return guarded([&] {
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        *out = nullptr;
+        auto impl = gdx::FmIndex::load(path, device_id);
+        *out = new gdx_index{std::move(impl)};
+        return (int)GDX_OK;
+    });
+}
+
 void gdx_index_free(gdx_index_t *ix)
 {
     if (!ix) return;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -1138,6 +1139,104 @@ int FmIndex::symbol_at_many(const uint64_t *idx, uint64_t m, uint8_t *out) const
     GDX_HIP(hipMemcpyAsync(out, d_out.get(), m, hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
     return GDX_OK;
+}
+
+// =============================================================================================
+// persistence: header + the reference's logical arrays
+
+namespace {
+
+constexpr char kMagic[8] = {'G', 'D', 'X', 'I', 'D', 'X', '0', '1'};
+
+struct FileHeader {
+    char magic[8];
+    uint64_t n, n_texts, sa_rate, n_plane_words, n_samples;
+    int32_t sigma, n_searchable, lookup_depth, index_width;
+    uint8_t io_to_dense[256];
+};
+
+struct File {
+    FILE *f;
+    explicit File(const char *path, const char *mode) : f(std::fopen(path, mode))
+    {
+        if (!f) fail(GDX_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    }
+    ~File()
+    {
+        if (f) std::fclose(f);
+    }
+    void write(const void *p, size_t bytes)
+    {
+        if (bytes && std::fwrite(p, 1, bytes, f) != bytes) fail(GDX_ERR_DEVICE, "short write");
+    }
+    void read(void *p, size_t bytes)
+    {
+        if (bytes && std::fread(p, 1, bytes, f) != bytes) fail(GDX_ERR_INVALID_ARGUMENT, "index file is truncated");
+    }
+};
+
+}  // namespace
+
+void FmIndex::save(const char *path) const
+{
+    if (!path) fail(GDX_ERR_INVALID_ARGUMENT, "path is null");
+    const int nbits = view_.nbits;
+    const uint64_t len = n_ + 1, n_blocks = div_ceil(len, 64);
+    FileHeader h{};
+    std::memcpy(h.magic, kMagic, 8);
+    h.n = n_;
+    h.n_texts = n_texts_;
+    h.sa_rate = cfg_.sa_rate;
+    h.n_plane_words = n_blocks * nbits;
+    h.n_samples = div_ceil(n_, cfg_.sa_rate);
+    h.sigma = cfg_.sigma;
+    h.n_searchable = cfg_.n_searchable;
+    h.lookup_depth = cfg_.lookup_depth;
+    h.index_width = cfg_.index_width;
+    std::memcpy(h.io_to_dense, cfg_.io_to_dense, 256);
+    std::vector<uint64_t> planes(h.n_plane_words);
+    std::vector<uint16_t> bo(n_blocks * cfg_.sigma);
+    std::vector<uint32_t> sbo(div_ceil(len, 65536) * cfg_.sigma), samples(h.n_samples);
+    export_condensed_table(planes.data(), bo.data(), sbo.data());
+    export_sa_samples(samples.data());
+    File out(path, "wb");
+    out.write(&h, sizeof(h));
+    out.write(count_host_.data(), count_host_.size() * sizeof(uint64_t));
+    out.write(sentinels_host_.data(), n_texts_ * sizeof(uint64_t));
+    out.write(border_keys_host_.data(), n_texts_ * sizeof(uint64_t));
+    out.write(border_vals_host_.data(), n_texts_ * sizeof(uint64_t));
+    out.write(samples.data(), samples.size() * sizeof(uint32_t));
+    out.write(planes.data(), planes.size() * sizeof(uint64_t));
+}
+
+std::unique_ptr<FmIndex> FmIndex::load(const char *path, int device_id)
+{
+    if (!path) fail(GDX_ERR_INVALID_ARGUMENT, "path is null");
+    File in(path, "rb");
+    FileHeader h;
+    in.read(&h, sizeof(h));
+    if (std::memcmp(h.magic, kMagic, 8) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "%s is not a gdx index file", path);
+    if (h.sigma < 2 || h.sigma > 256 || h.n_texts == 0 || h.n_texts > h.n || h.sa_rate == 0 ||
+        h.n_samples != div_ceil(h.n, h.sa_rate))
+        fail(GDX_ERR_INVALID_ARGUMENT, "index file header is inconsistent");
+    IndexConfig cfg;
+    std::memcpy(cfg.io_to_dense, h.io_to_dense, 256);
+    cfg.sigma = h.sigma;
+    cfg.n_searchable = h.n_searchable;
+    cfg.sa_rate = h.sa_rate;
+    cfg.lookup_depth = h.lookup_depth;
+    cfg.index_width = h.index_width;
+    cfg.device_id = device_id;
+    std::vector<uint64_t> count(h.sigma + 1), sent(h.n_texts), bk(h.n_texts), bv(h.n_texts), planes(h.n_plane_words);
+    std::vector<uint32_t> samples(h.n_samples);
+    in.read(count.data(), count.size() * sizeof(uint64_t));
+    in.read(sent.data(), sent.size() * sizeof(uint64_t));
+    in.read(bk.data(), bk.size() * sizeof(uint64_t));
+    in.read(bv.data(), bv.size() * sizeof(uint64_t));
+    in.read(samples.data(), samples.size() * sizeof(uint32_t));
+    in.read(planes.data(), planes.size() * sizeof(uint64_t));
+    return from_parts(0, 64, count.data(), planes.data(), h.n, samples.data(), bk.data(), bv.data(), sent.data(),
+                      h.n_texts, cfg);
 }
 
 // =============================================================================================

@@ -40,6 +40,9 @@ public:
                                                const uint32_t *sa_samples, const uint64_t *border_keys,
                                                const uint64_t *border_vals, const uint64_t *sentinel_indices,
                                                uint64_t n_texts, const IndexConfig &cfg);
+    // own file format around the reference's logical arrays (lib.rs:296-327 save_to_file / load_from_file)
+    void save(const char *path) const;
+    static std::unique_ptr<FmIndex> load(const char *path, int device_id);
     ~FmIndex();
 
     const IndexView &view() const { return view_; }

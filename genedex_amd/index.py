@@ -127,6 +127,20 @@ class FmIndex:
         _lib.check(st)
         return cls(handle, alphabet)
 
+    # ---- lib.rs:296-327 (own file format, see include/gdx.h) -------------------------------------
+    def save_to_file(self, path) -> None:
+        _lib.check(self._lib.gdx_index_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load_from_file(cls, path, alphabet: Alphabet, device=0) -> "FmIndex":
+        lib = _lib.load()
+        handle = C.c_void_p()
+        _lib.check(lib.gdx_index_load(str(path).encode(), int(device), C.byref(handle)))
+        ix = cls(handle, alphabet)
+        if ix.info.sigma != alphabet.num_dense_symbols():
+            raise ValueError("the file was written for a different alphabet")
+        return ix
+
     # ---- lib.rs:283-294 ----------------------------------------------------------------------
     def alphabet(self) -> Alphabet:
         return self._alphabet

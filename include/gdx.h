@@ -119,6 +119,13 @@ int gdx_index_from_parts_ex(int table_kind, int block_bits, const uint64_t *coun
                             int sigma, int n_searchable, int lookup_depth, int index_width, int device_id,
                             gdx_index_t **out);
 
+/* Persistence (FmIndex::save_to_file / load_from_file, lib.rs:296-327).  The reference's wire format belongs to
+ * the un-vendored `savefile` crate and no test of the reference inspects it, so this is an own format: a small
+ * header followed by the index in the REFERENCE's logical layout (count, Condensed/Block64 bit planes, sampled
+ * suffix array, text borders, sentinel positions); loading goes through the same path as gdx_index_from_parts. */
+int gdx_index_save(const gdx_index_t *ix, const char *path);
+int gdx_index_load(const char *path, int device_id, gdx_index_t **out);
+
 void gdx_index_free(gdx_index_t *ix);
 int gdx_index_info(const gdx_index_t *ix, gdx_index_info_t *out);
 

@@ -137,3 +137,29 @@ def test_device_resident_entry_points(setup):
     rc = lib.gdx_count_many_dev(g._h, C.c_void_p(dq.qbuf.data_ptr() + 1), C.c_void_p(dq.qoff.data_ptr()), 1,
                                 C.c_void_p(counts.data_ptr()), None, None)
     assert rc == _lib.GDX_ERR_INVALID_ARGUMENT
+
+
+def test_save_and_load_round_trip(setup, tmp_path):
+    """FmIndex::save_to_file / load_from_file (lib.rs:296-327), own format around the reference's logical arrays."""
+    from genedex_amd import FmIndex, GdxError
+
+    _lib, lib, g, c, texts, rng = setup
+    path = tmp_path / "index.gdx"
+    g.save_to_file(path)
+    h = FmIndex.load_from_file(path, alph.ascii_dna_with_n())
+    assert h.total_text_len() == g.total_text_len() and h.num_texts() == g.num_texts()
+    assert int(h.info.lookup_depth) == 3 and int(h.info.sa_rate) == 4
+    qs = [texts[int(rng.integers(0, 3))][s:s + 35] for s in rng.integers(0, 19000, 2000)]
+    qs = [q for q in qs if b"N" not in q[-3:]] + [b"", b"ACGTTGCA"]
+    a = g.locate_raw(*pack_queries(qs))
+    b = h.locate_raw(*pack_queries(qs))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert np.array_equal(h.export_bwt(), g.export_bwt())
+    # a truncated or foreign file is an error, not a crash
+    data = path.read_bytes()
+    (tmp_path / "short.gdx").write_bytes(data[: len(data) // 2])
+    (tmp_path / "junk.gdx").write_bytes(b"not an index" * 100)
+    for name in ("short.gdx", "junk.gdx", "missing.gdx"):
+        with pytest.raises(GdxError):
+            FmIndex.load_from_file(tmp_path / name, alph.ascii_dna_with_n())
