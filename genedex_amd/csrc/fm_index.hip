@@ -254,9 +254,9 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
     }
 }
 
-// jump table (layout.hpp try_jump): jump[i] = {LF^8(i), codes of the 8 symbols preceding suffix SA[i]},
-// obtained by eight LF steps on the rank lines.  A row whose walk meets a sentinel gets code 0, which no
-// valid query can equal.
+// jump table (search.hip try_jump): jump[i] = {LF^8(i), nibble codes of the 8 symbols preceding suffix SA[i],
+// nibble 7 = text[SA[i]-1] ... nibble 0 = text[SA[i]-8]}, obtained by eight LF steps on the rank lines.  A row
+// whose walk meets a sentinel gets code 0, which no valid query (all nibbles non-zero) can equal.
 __global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2 *__restrict__ jump)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2
                 ok = false;
                 break;
             }
-            code |= c << (3u * k);
+            code |= c << (4u * (kJumpSymbols - 1u - k));
             row = ix.count[c] + r;
         }
         jump[p] = ok ? make_uint2(row, code) : make_uint2(0u, 0u);

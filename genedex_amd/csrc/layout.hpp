@@ -41,7 +41,7 @@ struct IndexView {
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
     // --- jump table: kJumpSymbols LF steps of a one-row interval per fetch ----------------------
-    const uint2 *jump;            // [n] {LF^8(i), 8 preceding symbols as 3-bit codes}, null when absent
+    const uint2 *jump;            // [n] {LF^8(i), 8 preceding symbols as nibble codes}, null when absent
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)

@@ -53,27 +53,72 @@ struct QueryWindow {
     }
 };
 
-// One-row intervals (the usual state of a read after ~16 symbols) advance kJumpSymbols LF steps with one
-// 8-byte fetch: jump[i] = {LF^8(i), the 8 symbols preceding suffix SA[i]}.  If the next 8 query symbols
-// equal the stored ones the interval becomes [LF^8(i), LF^8(i)+1); otherwise the interval empties within
-// these 8 steps and the caller finishes on the pair lines, which yields the reference's frozen interval.
-// Returns true when the jump was taken.
-__device__ __forceinline__ bool try_jump(const IndexView &ix, const uint8_t *s_dense, QueryWindow &win, uint64_t pos,
-                                         uint32_t &lo, uint32_t &hi)
-{
-    (void)win.get(pos - 1);  // bring the window to the current position (it only ever moves down)
-    const uint64_t bytes = win.peek8(pos);
-    uint32_t code = 0;
-    bool valid = true;
+// The query as the pair kernels see it: dense codes, one nibble per symbol, eight symbols per 32-bit word,
+// read right-to-left.  A window word is fetched two words ahead (raw) and translated through the alphabet
+// table in LDS once, when it becomes the lower word of the window, so a symbol costs one LDS read however
+// often it is looked at, and all position arithmetic is 32-bit and relative to the query.
+struct CodeWindow {
+    const uint64_t *base;  // words of the query buffer; base[0] holds the first byte of the query
+    uint32_t off0;         // byte offset of the query inside base[0]
+    uint32_t cur_w;        // index of the word translated in `cur`
+    uint32_t cur, next;    // translated words cur_w and cur_w - 1 (nibble k = dense code of byte k, 0 = invalid)
+    uint64_t raw;          // word cur_w - 2, requested ahead
+
+    static __device__ __forceinline__ uint32_t translate(uint64_t w, const uint8_t *s_dense)
+    {
+        uint32_t t = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kJumpSymbols; k++) {
-        const uint32_t d = s_dense[(bytes >> (8u * (7u - k))) & 0xffu];  // k = 0: symbol pos-1, consumed first
-        valid &= (d != 0u);
-        code |= d << (3u * k);
+        for (uint32_t k = 0; k < 8; k++) t |= static_cast<uint32_t>(s_dense[(w >> (8u * k)) & 0xffu]) << (4u * k);
+        return t;
     }
-    if (!valid) return false;
+    __device__ __forceinline__ void set(const uint8_t *qbuf, uint64_t begin, uint32_t rem, uint64_t w0, uint64_t w1,
+                                        const uint8_t *s_dense)
+    {
+        base = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+        off0 = static_cast<uint32_t>(begin & 7u);
+        cur_w = rem ? ((off0 + rem - 1u) >> 3) : 0u;
+        raw = cur_w >= 2u ? base[cur_w - 2u] : 0ull;
+        cur = translate(w0, s_dense);
+        next = translate(w1, s_dense);
+    }
+    // rem = symbols of the query not consumed yet
+    __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin, uint32_t rem, const uint8_t *s_dense)
+    {
+        const uint64_t *b = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+        const uint32_t w = rem ? ((static_cast<uint32_t>(begin & 7u) + rem - 1u) >> 3) : 0u;
+        const uint64_t w0 = rem ? b[w] : 0ull;
+        const uint64_t w1 = w >= 1u ? b[w - 1u] : 0ull;
+        set(qbuf, begin, rem, w0, w1, s_dense);
+    }
+    // codes of the 8 symbols that end with symbol rem-1 (nibble 7 = symbol rem-1, the next one to consume);
+    // moves the window one word down when the position has left it.  rem >= 1.  Nibbles of symbols before
+    // the start of the query are garbage and must not be used (callers check rem).
+    __device__ __forceinline__ uint32_t code8(uint32_t rem, const uint8_t *s_dense)
+    {
+        const uint32_t b = off0 + rem - 1u, w = b >> 3;
+        if (w != cur_w) {
+            cur_w = w;
+            cur = next;
+            next = translate(raw, s_dense);
+            raw = w >= 2u ? base[w - 2u] : 0ull;
+        }
+        const uint32_t s = (b & 7u) + 1u;  // nibbles taken from `cur`
+        return s == 8u ? cur : __builtin_amdgcn_alignbit(cur, next, 4u * s);
+    }
+};
+
+__device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x11111111u) & ~x & 0x88888888u) != 0u; }
+
+// One-row intervals (the usual state of a read after ~16 symbols) advance kJumpSymbols LF steps with one
+// 8-byte fetch: jump[i] = {LF^8(i), codes of the 8 symbols preceding suffix SA[i] (nibble 7 = text[SA[i]-1])}.
+// If the next 8 query symbols equal the stored ones the interval becomes [LF^8(i), LF^8(i)+1); otherwise the
+// interval empties within these 8 steps and the caller finishes on the pair lines, which yields the
+// reference's frozen interval.  `code` = CodeWindow::code8 at the current position (rem >= 8).
+__device__ __forceinline__ bool try_jump(const IndexView &ix, uint32_t code, uint32_t &lo, uint32_t &hi)
+{
+    if (has_zero_nibble(code)) return false;  // a symbol outside the alphabet ahead: let the step path report it
     const uint2 j = ix.jump[lo];
-    if ((j.y & 0xffffffu) != code) return false;
+    if (j.y != code) return false;
     lo = j.x;
     hi = j.x + 1u;
     return true;
@@ -329,36 +374,36 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 lo = hi = 0;
             }
         }
-        uint64_t pos = end - t;
-        QueryWindow win;
-        win.init(qbuf, begin, pos);
+        uint32_t rem = static_cast<uint32_t>(len - t);  // symbols still to consume, right to left
+        CodeWindow win;
+        win.init(qbuf, begin, rem, s_dense);
         bool jump_ok = ix.jump != nullptr;
-        uint32_t iters = 0;  // line fetches of this query (divergence accounting, step_stats only)
-        while (pos > begin && lo != hi) {
+        uint32_t iters = 0;  // line fetches of this query (divergence accounting, kStats only)
+        while (rem > 0 && lo != hi) {
             if (kStats) iters++;
-            if (jump_ok && hi - lo == 1u && pos - begin >= kJumpSymbols) {
-                if (try_jump(ix, s_dense, win, pos, lo, hi)) {
-                    pos -= kJumpSymbols;
+            const uint32_t code = win.code8(rem, s_dense);
+            if (jump_ok && hi - lo == 1u && rem >= kJumpSymbols) {
+                if (try_jump(ix, code, lo, hi)) {
+                    rem -= kJumpSymbols;
                     if (kStats) lf_steps += kJumpSymbols;
                     continue;
                 }
                 jump_ok = false;  // mismatch or an invalid symbol ahead: the pair lines finish this query
             }
-            const uint32_t c1 = s_dense[win.get(pos - 1)];
-            if (c1 == 0) {
+            const uint32_t c1 = code >> 28;
+            if (c1 == 0) {  // alphabet.rs:195-198
                 status = GDX_Q_INVALID_SYMBOL;
                 lo = hi = 0;
                 break;
             }
-            uint32_t c2 = 0;
-            if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
+            const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
             if (c1 <= 4u && c2 - 1u < 4u) {
                 uint32_t nlo, nhi;
                 PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
                 if (nlo != nhi) {
                     lo = nlo;
                     hi = nhi;
-                    pos -= 2;
+                    rem -= 2;
                     if (kStats) lf_steps += 2;
                     continue;
                 }
@@ -374,7 +419,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 lo = cc + rlo;
                 hi = cc + rhi;
             }
-            pos--;
+            rem--;
             if (kStats) lf_steps++;
         }
         if (writer) {
@@ -410,15 +455,15 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
-// The 4-lane kernel holds two chunks per lane and line: 72 VGPRs / 84 SGPRs at 7 waves per SIMD, no spills,
-// 7 x 16 = 112 queries per SIMD in flight instead of 8 x 8 = 64.
+// The 4-lane kernel holds two chunks per lane and line; with the 32-bit nibble windows (CodeWindow) it also fits
+// 64 VGPRs / 78 SGPRs without spills: 8 x 16 = 128 queries per SIMD in flight instead of 8 x 8 = 64.
 template <int kPolicy>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
     search_pair_body<kPolicy, 8, false>(GDX_SEARCH_FWD);
 }
 template <int kPolicy>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
     search_pair_body<kPolicy, 4, false>(GDX_SEARCH_FWD);
 }
@@ -468,11 +513,12 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
     unsigned long long active_iters = 0, loop_iters = 0;  // step_stats[1], [2]
 
     // the query being searched
-    uint64_t q = 0, begin = 0, pos = 0;
-    uint32_t lo = 0, hi = 0, status = GDX_Q_OK;
-    QueryWindow win;
-    win.words = words;
-    win.cur = win.next = win.cur_word = win.first_word = 0;
+    uint64_t q = 0;
+    uint32_t rem = 0, lo = 0, hi = 0, status = GDX_Q_OK;
+    CodeWindow win;
+    win.base = words;
+    win.off0 = win.cur_w = win.cur = win.next = 0;
+    win.raw = 0;
     bool have = false, jump_ok = false;
     // the query staged behind it
     uint64_t nx_q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup;
@@ -484,12 +530,11 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
         if (nx_stage == 1) {
             const uint64_t len = nx_end - nx_begin;
             const uint64_t t = len < static_cast<uint64_t>(ix.depth) ? len : static_cast<uint64_t>(ix.depth);
-            const uint64_t p = nx_end - t;
-            const uint64_t first_word = nx_begin >> 3;
-            const bool any = p > nx_begin;
-            const uint64_t cw = any ? ((p - 1) >> 3) : first_word;
-            nx_cur = any ? words[cw] : 0ull;
-            nx_next = (any && cw > first_word) ? words[cw - 1] : 0ull;
+            const uint32_t r = static_cast<uint32_t>(len - t);
+            const uint64_t *b = words + (nx_begin >> 3);
+            const uint32_t w = r ? ((static_cast<uint32_t>(nx_begin & 7u) + r - 1u) >> 3) : 0u;
+            nx_cur = r ? b[w] : 0ull;
+            nx_next = w >= 1u ? b[w - 1u] : 0ull;
             nx_stage = 2;
         } else if (nx_stage == 0 && nx_q < nq) {
             nx_begin = qoff[nx_q];
@@ -499,8 +544,7 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
         // ---- start it when the slot is free -------------------------------------------------------------
         if (!have && nx_stage == 2) {
             q = nx_q;
-            begin = nx_begin;
-            const uint64_t end = nx_end;
+            const uint64_t begin = nx_begin, end = nx_end;
             const uint64_t len = end - begin;
             const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
                                                                      : static_cast<uint32_t>(ix.depth);
@@ -526,11 +570,8 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
                     lo = hi = 0;
                 }
             }
-            pos = end - t;
-            win.first_word = begin >> 3;
-            win.cur_word = pos > begin ? ((pos - 1) >> 3) : win.first_word;
-            win.cur = nx_cur;
-            win.next = nx_next;
+            rem = static_cast<uint32_t>(len - t);
+            win.set(qbuf, begin, rem, nx_cur, nx_next, s_dense);
             have = true;
             jump_ok = ix.jump != nullptr;
             nx_q += stride;
@@ -540,32 +581,33 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
         if (kStats) loop_iters++;
         if (have) {
             if (kStats) active_iters++;
-            bool jumped = false;
-            if (jump_ok && pos > begin && hi - lo == 1u && pos - begin >= kJumpSymbols) {
-                jumped = try_jump(ix, s_dense, win, pos, lo, hi);
-                if (jumped) {
-                    pos -= kJumpSymbols;
-                    if (kStats) lf_steps += kJumpSymbols;
-                } else {
-                    jump_ok = false;
+            if (rem > 0 && lo != hi) {
+                const uint32_t code = win.code8(rem, s_dense);
+                bool stepped = false;
+                if (jump_ok && hi - lo == 1u && rem >= kJumpSymbols) {
+                    stepped = try_jump(ix, code, lo, hi);
+                    if (stepped) {
+                        rem -= kJumpSymbols;
+                        if (kStats) lf_steps += kJumpSymbols;
+                    } else {
+                        jump_ok = false;
+                    }
                 }
-            }
-            if (!jumped && pos > begin && lo != hi) {
-                const uint32_t c1 = s_dense[win.get(pos - 1)];
-                if (c1 == 0) {  // alphabet.rs:195-198
+                const uint32_t c1 = code >> 28;
+                if (!stepped && c1 == 0) {  // alphabet.rs:195-198
                     status = GDX_Q_INVALID_SYMBOL;
                     lo = hi = 0;
-                } else {
-                    uint32_t c2 = 0;
-                    if (pos - begin >= 2) c2 = s_dense[win.get(pos - 2)];
-                    bool stepped = false;
+                    stepped = true;
+                }
+                if (!stepped) {
+                    const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
                     if (c1 <= 4u && c2 - 1u < 4u) {
                         uint32_t nlo, nhi;
                         PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
                         if (nlo != nhi) {
                             lo = nlo;
                             hi = nhi;
-                            pos -= 2;
+                            rem -= 2;
                             if (kStats) lf_steps += 2;
                             stepped = true;
                         }
@@ -580,12 +622,12 @@ __device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint
                             lo = cc + rlo;
                             hi = cc + rhi;
                         }
-                        pos--;
+                        rem--;
                         if (kStats) lf_steps++;
                     }
                 }
             }
-            if (!(pos > begin && lo != hi)) {  // lib.rs:226-232: finished, or frozen at the empty interval
+            if (!(rem > 0 && lo != hi)) {  // lib.rs:226-232: finished, or frozen at the empty interval
                 if (writer) {
                     if (out_start) out_start[q] = lo;
                     if (out_end) out_end[q] = hi;
