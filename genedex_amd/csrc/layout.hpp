@@ -282,8 +282,9 @@ __device__ __forceinline__ uint32_t group_sum(uint32_t v)
 struct PairTable {
     static __device__ __forceinline__ uint32_t low_mask(uint32_t idx, uint32_t chunk)
     {
-        const int32_t bits = static_cast<int32_t>(idx & 63u) - 8 * static_cast<int32_t>(chunk);
-        return bits >= 8 ? 0xffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+        int32_t bits = static_cast<int32_t>(idx & 63u) - 8 * static_cast<int32_t>(chunk);
+        bits = bits < 0 ? 0 : (bits > 8 ? 8 : bits);  // v_med3_i32
+        return (1u << bits) - 1u;
     }
     static __device__ __forceinline__ uint32_t pair_partial(const u32x4 c, uint32_t chunk, uint32_t pair, uint32_t nx,
                                                             uint32_t ny, uint32_t idx)
@@ -309,10 +310,12 @@ struct PairTable {
         constexpr int kChunks = 8 / kLanes;
         const uint32_t sub = threadIdx.x & (kLanes - 1u);
         const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
-        const uint32_t f = 0xffu;
-        const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16) |
-                            (((c2 & 1u) ? 0u : f) << 24);
-        const uint32_t ny = ((c2 & 2u) ? 0u : f) | (((c2 & 4u) ? 0u : f) << 8);
+        // byte k of nx / ny is 0xff where the symbol's bit k is 0 (the plane must be negated), else 0:
+        // spread the bits to byte lanes, multiply by 0xff, invert
+        const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14) | ((c2 & 1u) << 24);
+        const uint32_t bits_y = ((c2 >> 1) & 1u) | ((c2 & 4u) << 6);
+        const uint32_t nx = ~(bits_x * 0xffu);
+        const uint32_t ny = ~(bits_y * 0xffu) & 0xffffu;
         const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
         u32x4 a[kChunks], b[kChunks];
         load_two_lines<kPolicy, kChunks>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
@@ -334,8 +337,8 @@ struct PairTable {
     {
         constexpr int kChunks = 8 / kLanes;
         const uint32_t sub = threadIdx.x & (kLanes - 1u);
-        const uint32_t f = 0xffu;
-        const uint32_t nx = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16);
+        const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
+        const uint32_t nx = ~(bits_x * 0xffu) & 0xffffffu;
         const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
         u32x4 a[kChunks], b[kChunks];
         load_two_lines<kPolicy, kChunks>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
