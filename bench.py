@@ -361,12 +361,23 @@ def cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl):
                          and np.array_equal(gh[:, 1], p.astype(np.int64)))
     if not same_intervals or same_hits is False:
         raise SystemExit(f"PARITY FAILURE vs CPU oracle: intervals {same_intervals}, hits {same_hits}")
+    # the author's "batching gives about 2x" (src/lib.rs:37-40): batched vs single-query path on ONE thread
+    m1 = min(queries.nq, 100_000)
+    qbuf1, qoff1 = queries.host_slice(0, m1)
+    t0 = time.perf_counter()
+    cpu.cursors_for_many(qbuf1, qoff1, n_threads=1)
+    t_batched1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cpu.cursors_single(qbuf1, qoff1, n_threads=1)
+    t_single1 = time.perf_counter() - t0
     log(f"[bench] CPU baseline: {n_sample} queries, count {tc:.2f}s + locate {tl:.2f}s on {cores} threads "
         f"-> {value:.3e} q/s; GPU results identical: intervals {same_intervals}, hits {same_hits}")
     return {"value": value, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"first {n_sample} queries of the GPU batch, same index (BWT + samples exported from the GPU "
                       f"build, occurrence table rebuilt in the reference layout), count {tc:.2f}s + locate {tl:.2f}s",
-            "count_only_value": n_sample / tc, "bit_exact_vs_gpu": {"intervals": same_intervals, "hits": same_hits}}
+            "count_only_value": n_sample / tc, "bit_exact_vs_gpu": {"intervals": same_intervals, "hits": same_hits},
+            "one_thread": {"batched_path_count_qps": m1 / t_batched1, "single_query_path_count_qps": m1 / t_single1,
+                           "batching_speedup": t_single1 / t_batched1, "queries": m1}}
 
 
 if __name__ == "__main__":
