@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true")
     ap.add_argument("--verify-hits", type=int, default=1_000_000)
+    ap.add_argument("--secondary-depth", type=int, default=10,
+                    help="N=1 only: after the headline run (reference-default lookup depth), rebuild the index with "
+                         "this lookup-table depth, time the same step and check the counts are identical; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,9 +194,9 @@ def main():
     variant = os.environ.get("GDX_SEARCH_VARIANT", "pair")
     uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
     lanes = os.environ.get("GDX_SEARCH_LANES", "4")
-    streamed = os.environ.get("GDX_SEARCH_STREAM", "0") == "1" or (os.environ.get("GDX_SEARCH_STREAM") == "auto"
-                                                                     and not uniform)
-    kernel_name = {"pair": f"search_pair_stream_kernel{lanes}<sc1>" if streamed else f"search_pair_kernel{lanes}<sc1>",
+    aux = eng.aux_info()
+    policy = os.environ.get("GDX_LOAD_POLICY", "1")
+    kernel_name = {"pair": f"search_pair_kernel{lanes}<{policy}, {'true' if aux['jump_entry_bytes'] == 16 else 'false'}>",
                    "quad": "search_kernel<QuadLineTable,4>", "lane": "search_kernel<LineTable,1>"}[variant]
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
@@ -231,6 +234,7 @@ def main():
         "config": {"workload": wl["label"], "name": args.workload, "op": args.op, "queries_per_gpu": nq,
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
+                   "aux_structures": eng.aux_info(),
                    "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0"},
         "roofline": roofline,
         "locate_roofline": locate_roofline,
@@ -250,10 +254,86 @@ def main():
     else:
         result["cpu_baseline"] = None
 
+    if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
+        # Secondary design points, never `value`: (1) the reference's lookup-table knob at the depth BASELINE.md names;
+        # (2) the same step with every acceleration structure of this build switched off (rank lines in the
+        # reference's information content only), so the effect of the extra HBM spent on them is on record.
+        base_counts = (out["end"] - out["start"]).clone()
+        del eng, index
+        torch.cuda.empty_cache()
+        common = (torch, io_text, lengths, alpha, queries, out, hits, workspace, base_counts, nq, total_hits,
+                  do_locate, args, wl)
+        result["secondary"] = [
+            secondary_run(f"lookup_depth_{args.secondary_depth}", args.secondary_depth, {}, *common),
+            secondary_run("no_acceleration_structures", args.lookup_depth,
+                          {"GDX_TOP_DEPTH": "0", "GDX_NO_JUMP_TABLE": "1", "GDX_NO_PAIR_LINES": "1"}, *common),
+        ]
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_run(name, lookup_depth, env, torch, io_text, lengths, alpha, queries, out, hits, workspace, base_counts,
+                  nq, total_hits, do_locate, args, wl):
+    """Rebuild the index with another configuration, time the same step and require identical interval sizes.
+    `lookup_depth` is the reference's knob (config.rs:36-47; README.md:101-115 recommends a deeper table for large
+    texts); `env` switches build-time structures of this implementation (fm_index.hip)."""
+    from genedex_amd.device import DeviceEngine, build_index_from_device_text
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        t0 = time.time()
+        index = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=lookup_depth,
+                                             index_storage=wl["storage"])
+        t_build = time.time() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    eng = DeviceEngine(index)
+    ev_s, ev_l = [], []
+
+    def step(record):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.search(queries, out)
+        b.record()
+        if do_locate:
+            eng.hit_offsets(out, nq)
+            c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c.record()
+            eng.locate(out, nq, total_hits, hits, workspace)
+            d.record()
+            if record:
+                ev_l.append((c, d))
+        if record:
+            ev_s.append((a, b))
+
+    step(False)
+    torch.cuda.synchronize()
+    steps = min(args.steps, 3)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    same = bool(torch.equal(out["end"] - out["start"], base_counts))
+    if not same:
+        raise SystemExit(f"PARITY FAILURE: secondary configuration {name} changed interval sizes")
+    res = {"name": name, "lookup_depth": lookup_depth, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3),
+           "unit": "queries/s", "ms_per_step": ms, "search_ms": sum(a.elapsed_time(b) for a, b in ev_s) / len(ev_s),
+           "locate_ms": sum(a.elapsed_time(b) for a, b in ev_l) / len(ev_l) if ev_l else None,
+           "counts_identical_to_headline": same, "index_build_seconds": t_build,
+           "index_bytes": int(index.info.device_bytes)}
+    log(f"[bench] secondary {name}: {res}")
+    del eng, index
+    torch.cuda.empty_cache()
+    return res
 
 
 def pmc_traffic(kernel_name, args, wl, nq):

@@ -102,6 +102,7 @@ SIGNATURES = {
     "gdx_bench_stream_read": [vp, C.c_uint64, vp, vp],
     "gdx_bench_random_gather": [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_search_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_index_aux_info": [vp, C.POINTER(C.c_uint32)],
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_locate_workspace_bytes": C.c_uint64}

@@ -491,6 +491,19 @@ int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const v
     });
 }
 
+int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
+{
+    return guarded([&] {
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        const gdx::IndexView &v = deref(ix).view();
+        out[0] = v.pair_lines != nullptr;
+        out[1] = v.jump16 ? 16u : (v.jump ? 8u : 0u);
+        out[2] = v.top ? v.top_depth : 0u;
+        out[3] = 0;
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
                               const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
                               void *d_steps, void *stream)

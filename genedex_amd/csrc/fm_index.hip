@@ -277,6 +277,46 @@ __global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2
     }
 }
 
+// Wide entries {LF^8(i), codes 1-8, LF^16(i), codes 9-16} (search.hip try_jump_wide).  Pass 1 is
+// derive_jump_kernel's walk written into the first half of each entry; pass 2 completes entry i from the first
+// half of entry LF^8(i) (it only reads first halves and only writes second halves, so it runs in place).
+__global__ __launch_bounds__(kBlock) void derive_jump16_first_kernel(IndexView ix, u32x4 *__restrict__ jump16)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
+        uint32_t row = static_cast<uint32_t>(p), code = 0;
+        bool ok = true;
+        for (uint32_t k = 0; k < kJumpSymbols; k++) {
+            uint32_t r;
+            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
+            if (c == 0) {
+                ok = false;
+                break;
+            }
+            code |= c << (4u * (kJumpSymbols - 1u - k));
+            row = ix.count[c] + r;
+        }
+        u32x4 e = {0u, 0u, 0u, 0u};
+        if (ok) {
+            e.x = row;
+            e.y = code;
+        }
+        jump16[p] = e;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void derive_jump16_second_kernel(uint64_t n, u32x4 *__restrict__ jump16)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(jump16 + p);
+        if (a.y == 0u) continue;  // a sentinel within the first 8 steps: no jump from this row
+        const uint2 b = *reinterpret_cast<const uint2 *>(jump16 + a.x);
+        if (b.y == 0u) continue;
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(jump16 + p) + 2) = b;
+    }
+}
+
 // Bit planes of one 64-position block of bwt1 / bwt0 (zero padded input) and its 16 pair + 4 single counts.
 struct PairBlock {
     uint64_t p1[3], p0[3];
@@ -574,7 +614,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return jump_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return top_.bytes() + jump_.bytes() + jump16_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -718,12 +758,36 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         GDX_HIP(hipGetLastError());
         view_.pair_lines = pair_lines_.get();
         const char *no_jump = getenv("GDX_NO_JUMP_TABLE");
-        if (!(no_jump && no_jump[0] == '1')) {
+        const char *wide_jump = getenv("GDX_JUMP_WIDE");
+        if (no_jump && no_jump[0] == '1') {
+        } else if (!(wide_jump && wide_jump[0] == '0')) {  // default; GDX_JUMP_WIDE=0 builds the 8-byte entries
+            jump16_.alloc(n_);
+            hipLaunchKernelGGL(derive_jump16_first_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_,
+                               jump16_.get());
+            hipLaunchKernelGGL(derive_jump16_second_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, n_,
+                               jump16_.get());
+            GDX_HIP(hipStreamSynchronize(stream));
+            GDX_HIP(hipGetLastError());
+            view_.jump16 = jump16_.get();
+        } else {
             jump_.alloc(n_);
             hipLaunchKernelGGL(derive_jump_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, jump_.get());
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             view_.jump = jump_.get();
+        }
+        // top table: the first symbols of a DNA query in one fetch.  Depth: even (the pair steps that follow consume
+        // two symbols each), at least 4 rows per entry on average, at most 14 (2 GB); GDX_TOP_DEPTH=0..16 overrides.
+        uint32_t top_depth = 0;
+        while (top_depth < 14 && (1ull << (2u * (top_depth + 2u))) <= n_ / 4) top_depth += 2;
+        if (const char *e = getenv("GDX_TOP_DEPTH")) top_depth = static_cast<uint32_t>(atoi(e)) > 16u ? 16u : atoi(e);
+        if (top_depth > 0 && view_.sigma >= 5) {
+            top_.alloc(1ull << (2u * top_depth));
+            launch_fill_top(view_, top_.get(), top_depth, stream);
+            GDX_HIP(hipStreamSynchronize(stream));
+            GDX_HIP(hipGetLastError());
+            view_.top = top_.get();
+            view_.top_depth = top_depth;
         }
         stats_.seconds_pairs = now_seconds() - t0;
     }

@@ -92,6 +92,8 @@ private:
     DeviceBuffer<uint32_t> sb_offsets_;
     DeviceBuffer<u32x4> pair_lines_;
     DeviceBuffer<uint2> jump_;
+    DeviceBuffer<u32x4> jump16_;
+    DeviceBuffer<uint2> top_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;
     DeviceBuffer<uint32_t> count_;

@@ -26,6 +26,8 @@ void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t 
                            uint32_t *d_error, hipStream_t stream);
 // fills lookup table `depth` (entries k^depth) of ix.lookup; d_lookup is the writable alias of ix.lookup
 void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream);
+// Top table of the pair kernels (IndexView::top): 4^depth entries, dense symbols 1..4 only, rank-line layout.
+void launch_fill_top(const IndexView &ix, uint2 *d_top, uint32_t depth, hipStream_t stream);
 
 // ---- locate.hip ---------------------------------------------------------------------------
 size_t hit_offsets_temp_bytes(uint64_t m);

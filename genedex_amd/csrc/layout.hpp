@@ -42,6 +42,11 @@ struct IndexView {
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
     // --- jump table: kJumpSymbols LF steps of a one-row interval per fetch ----------------------
     const uint2 *jump;            // [n] {LF^8(i), 8 preceding symbols as nibble codes}, null when absent
+    const u32x4 *jump16;          // [n] {LF^8(i), codes 1-8, LF^16(i), codes 9-16}: replaces `jump` when present
+    // --- top table: interval after the first top_depth symbols of a DNA query, one cache-resident fetch ----
+    const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); empty
+                                  // entries (x == y) send the query down the ordinary path; null when absent
+    uint32_t top_depth;           // 1..16
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -232,15 +237,66 @@ __device__ __forceinline__ uint32_t oct_sum(uint32_t v)
     return v;
 }
 
+// minimum / maximum over the kLanes (4 or 8) lanes of a group; every lane gets the result
+template <int kLanes>
+__device__ __forceinline__ uint32_t group_min(uint32_t v)
+{
+    uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true));
+    v = o < v ? o : v;
+    o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xF, 0xF, true));
+    v = o < v ? o : v;
+    if (kLanes == 8) {
+        o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xF, 0xF, true));
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <int kLanes>
+__device__ __forceinline__ uint32_t group_max(uint32_t v)
+{
+    uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true));
+    v = o > v ? o : v;
+    o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xF, 0xF, true));
+    v = o > v ? o : v;
+    if (kLanes == 8) {
+        o = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xF, 0xF, true));
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 // Line loads with an explicit cache policy: 0 = plain, 1 = sc1 (served by L2, no allocation in the CU's
 // L1), 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's counters do not see them.
 // kChunks 16-byte chunks per lane and line, `step` chunks apart (a group of 8 / kChunks lanes covers a line).
 template <int kPolicy>
 __device__ __forceinline__ void issue_chunk_load(const u32x4 *p, u32x4 &v)
 {
-    if (kPolicy == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    if (kPolicy == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    else if (kPolicy == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
     else if (kPolicy == 2) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+}
+
+// The same load executed only by the lanes of `mask` (a subset of the active lanes); v is undefined in the other
+// lanes.  Done with the exec mask inside one asm statement, so the compiler sees a straight-line definition of v
+// and has no branch join at which it could place a copy of the still-pending register before the hand-written
+// wait.
+template <int kPolicy>
+__device__ __forceinline__ void issue_chunk_load_masked(const u32x4 *p, u32x4 &v, unsigned long long mask)
+{
+    unsigned long long saved;
+    if (kPolicy == 0)
+        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off\n\ts_mov_b64 exec, %1"
+                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
+    else if (kPolicy == 1)
+        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off sc1\n\ts_mov_b64 exec, %1"
+                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
+    else if (kPolicy == 2)
+        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off nt\n\ts_mov_b64 exec, %1"
+                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
+    else
+        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off sc0 sc1\n\ts_mov_b64 exec, %1"
+                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
 }
 
 template <int kPolicy, int kChunks>

@@ -117,10 +117,55 @@ __device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x111
 __device__ __forceinline__ bool try_jump(const IndexView &ix, uint32_t code, uint32_t &lo, uint32_t &hi)
 {
     if (has_zero_nibble(code)) return false;  // a symbol outside the alphabet ahead: let the step path report it
-    const uint2 j = ix.jump[lo];
+    // wide entries carry the 8-step pair in their first half
+    const uint2 j = ix.jump16 ? *reinterpret_cast<const uint2 *>(ix.jump16 + lo) : ix.jump[lo];
     if (j.y != code) return false;
     lo = j.x;
     hi = j.x + 1u;
+    return true;
+}
+
+// Wide entries (IndexView::jump16): {LF^8(i), codes of steps 1-8, LF^16(i), codes of steps 9-16} in one 16-byte
+// fetch.  `code` = code8(rem) (rem >= 8).  The codes of the 8 symbols after those are taken while the entry is in
+// flight, which moves the window one word down; that is where it has to be after any successful jump.  Returns
+// the number of symbols consumed (16, 8, or 0 = mismatch: the caller re-initialises the window and goes on with
+// single/pair steps, rare since a one-row interval of a read that occurs in the text always matches).
+__device__ __forceinline__ uint32_t try_jump_wide(const IndexView &ix, CodeWindow &win, uint32_t code, uint32_t rem,
+                                                  uint32_t &lo, uint32_t &hi, const uint8_t *s_dense)
+{
+    const u32x4 e = ix.jump16[lo];
+    uint32_t code_b = 0;
+    if (rem >= 2u * kJumpSymbols) code_b = win.code8(rem - kJumpSymbols, s_dense);
+    if (has_zero_nibble(code) || e.y != code) return 0u;
+    const bool both = rem >= 2u * kJumpSymbols && !has_zero_nibble(code_b) && e.w == code_b;
+    lo = both ? e.z : e.x;
+    hi = lo + 1u;
+    return both ? 2u * kJumpSymbols : kJumpSymbols;
+}
+
+// Top table (IndexView::top): the interval after the first D = top_depth symbols of the search, i.e. the last D
+// symbols of the query, when all of them are dense codes 1..4.  `a` = code8(rem), `b` = code8(rem - 8) (only its
+// top D - 8 nibbles are used).  Returns false when a symbol is outside 1..4 or the D-mer does not occur (empty
+// entry): the caller then runs the ordinary steps from the start, which also yields the reference's frozen interval.
+__device__ __forceinline__ bool top_lookup(const IndexView &ix, uint32_t a, uint32_t b, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t d = ix.top_depth;
+    const uint64_t all = (static_cast<uint64_t>(a) << 32) | b;
+    const uint64_t used = ~0ull << (4u * (16u - d));                  // the top d nibbles
+    const uint64_t v = (all & used) | (0x1111111111111111ull & ~used);  // unused nibbles := 1 (valid)
+    const uint64_t y = v - 0x1111111111111111ull;                     // per nibble c - 1 (no borrow if no zero nibble)
+    const bool zero = (y & ~v & 0x8888888888888888ull) != 0ull;
+    if (zero || (y & 0xccccccccccccccccull) != 0ull) return false;
+    uint64_t x = y;                                                   // 2 significant bits per nibble
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    const uint32_t idx = static_cast<uint32_t>(x) >> (32u - 2u * d);
+    const uint2 e = ix.top[idx];
+    if (e.x == e.y) return false;
+    lo = e.x;
+    hi = e.y;
     return true;
 }
 
@@ -202,10 +247,8 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
-// len_range = {min, max} query length of a batch (query_length_range_kernel).  Batches of (nearly)
-// equal lengths run the lock-step kernel: the waves stay level-synchronous, so the first levels of the
-// search, whose lines are cache resident, cost cache latency instead of DRAM latency for the whole
-// wave.  Mixed-length batches run the streaming kernel, which keeps every lane busy.
+// len_range = {min, max} query length of a batch (query_length_range_kernel).  Batches of (nearly) equal
+// lengths are searched in query order; for the others the length-ordered schedule below is built.
 __device__ __forceinline__ bool lengths_are_uniform(const uint32_t *len_range)
 {
     const uint32_t mn = len_range[0], mx = len_range[1];
@@ -322,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void length_scatter_kernel(const uint64_t *
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
-template <int kPolicy, int kGroup, bool kStats>
+template <int kPolicy, int kGroup, bool kStats, bool kWide>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
@@ -330,11 +373,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
-                                                             const uint32_t *__restrict__ len_range, int run_if_uniform,
+                                                             const uint32_t *__restrict__ len_range,
                                                              const uint32_t *__restrict__ perm)
 {
-    // run_if_uniform: 1 / 0 = run only for uniform / non-uniform batches, -1 = always
-    if (len_range && run_if_uniform >= 0 && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
     const bool use_perm = perm != nullptr && len_range != nullptr && !lengths_are_uniform(len_range);
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -355,8 +396,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
                                                                  : static_cast<uint32_t>(ix.depth);
         uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
+        uint32_t idx = 0;
         if (t > 0) {
-            uint32_t idx = 0, factor = 1;
+            uint32_t factor = 1;
             bool unsearchable = false;
             for (uint32_t j = 0; j < t; j++) {
                 const uint32_t d = s_dense[qbuf[end - t + j]];
@@ -366,40 +408,139 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 factor *= k;
             }
             if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
-            if (status == GDX_Q_OK) {
+            if (status != GDX_Q_OK) lo = hi = 0;
+        }
+        uint32_t rem = 0;  // symbols still to consume, right to left
+        CodeWindow win;
+        bool topped = false;
+        if (ix.top != nullptr && status == GDX_Q_OK && ix.top_depth > t && len >= ix.top_depth && len <= 0xffffffffull) {
+            // the top table is deeper than the configured lookup table: it answers for both
+            rem = static_cast<uint32_t>(len);
+            win.init(qbuf, begin, rem, s_dense);
+            const uint32_t a = win.code8(rem, s_dense);
+            const uint32_t b = ix.top_depth > 8u ? win.code8(rem - 8u, s_dense) : 0u;
+            topped = top_lookup(ix, a, b, lo, hi);
+            if (topped) {
+                rem -= ix.top_depth;
+                if (kStats) lf_steps += ix.top_depth;
+            }
+        }
+        if (!topped) {
+            if (t > 0 && status == GDX_Q_OK) {
                 const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
                 lo = v.x;
                 hi = v.y;
-            } else {
-                lo = hi = 0;
             }
+            rem = static_cast<uint32_t>(len - t);
+            win.init(qbuf, begin, rem, s_dense);
         }
-        uint32_t rem = static_cast<uint32_t>(len - t);  // symbols still to consume, right to left
-        CodeWindow win;
-        win.init(qbuf, begin, rem, s_dense);
-        bool jump_ok = ix.jump != nullptr;
-        uint32_t iters = 0;  // line fetches of this query (divergence accounting, kStats only)
+        bool jump_ok = kWide ? ix.jump16 != nullptr : ix.jump != nullptr;
+        uint32_t iters = 0;  // fetch rounds of this query (divergence accounting, kStats only)
+        // Every iteration is one round of loads for the whole wavefront, whatever its queries are doing: a group
+        // either reads its jump entry or the pair line(s) of its interval borders, all loads are issued, then
+        // waited for once, then each group interprets what it got (a wavefront whose groups took different
+        // branches, each with its own load and wait, would pay one DRAM latency per branch).
+        constexpr int kChunks = 8 / kGroup;
+        const uint32_t sub = threadIdx.x & (kGroup - 1u);
         while (rem > 0 && lo != hi) {
             if (kStats) iters++;
             const uint32_t code = win.code8(rem, s_dense);
-            if (jump_ok && hi - lo == 1u && rem >= kJumpSymbols) {
-                if (try_jump(ix, code, lo, hi)) {
-                    rem -= kJumpSymbols;
-                    if (kStats) lf_steps += kJumpSymbols;
-                    continue;
-                }
-                jump_ok = false;  // mismatch or an invalid symbol ahead: the pair lines finish this query
-            }
             const uint32_t c1 = code >> 28;
             if (c1 == 0) {  // alphabet.rs:195-198
                 status = GDX_Q_INVALID_SYMBOL;
                 lo = hi = 0;
                 break;
             }
+            if (c1 > 4u) {  // a valid symbol outside 1..4 (N): rank lines, rare
+                uint32_t rlo, rhi;
+                QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+                const uint32_t cc = s_count[c1];
+                lo = cc + rlo;
+                hi = cc + rhi;
+                rem--;
+                if (kStats) lf_steps++;
+                continue;
+            }
             const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
-            if (c1 <= 4u && c2 - 1u < 4u) {
-                uint32_t nlo, nhi;
-                PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
+            // Intervals of at most one row per lane of the group jump: lane j reads the entry of row lo + j.  The
+            // rows whose stored symbols equal the query's next 8 / 16 are exactly those that survive these LF steps,
+            // and LF keeps their order, so they map onto [min target, max target + 1).
+            const bool jumping = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols &&
+                                 !has_zero_nibble(code);
+            // wide entries: the codes of the 8 symbols after `code`; taking them moves the window one word
+            // down, which is where it has to be after a successful jump (a mismatch re-initialises it)
+            uint32_t code_b = 0;
+            if (kWide && jumping && rem >= 2u * kJumpSymbols) code_b = win.code8(rem - kJumpSymbols, s_dense);
+            const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
+            const bool second = !jumping && line_hi != line_lo;
+            const u32x4 *pa = ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub;
+            const u32x4 *pb = ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub;
+            const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
+            if (jumping) {
+                pa = kWide ? ix.jump16 + row
+                           : reinterpret_cast<const u32x4 *>(ix.jump + (row & ~1u));  // the aligned pair of entries
+            }
+            const unsigned long long m_pair = __ballot(!jumping), m_second = __ballot(second);
+            u32x4 a[kChunks], b[kChunks];
+            issue_chunk_load<kPolicy>(pa, a[0]);
+#pragma unroll
+            for (int k = 1; k < kChunks; k++) {
+                issue_chunk_load_masked<kPolicy>(pa + k * kGroup, a[k], m_pair);
+            }
+#pragma unroll
+            for (int k = 0; k < kChunks; k++) {
+                issue_chunk_load_masked<kPolicy>(pb + k * kGroup, b[k], m_second);
+            }
+            if (kChunks == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[kChunks - 1]), "+v"(b[kChunks - 1])::"memory");
+            if (jumping) {
+                uint32_t t8, ca, t16 = 0, cb = 0;
+                if (kWide) {
+                    t8 = a[0].x;
+                    ca = a[0].y;
+                    t16 = a[0].z;
+                    cb = a[0].w;
+                } else {
+                    t8 = (row & 1u) ? a[0].z : a[0].x;
+                    ca = (row & 1u) ? a[0].w : a[0].y;
+                }
+                const bool m8 = ca == code;
+                const bool m16 = kWide && m8 && rem >= 2u * kJumpSymbols && cb == code_b && !has_zero_nibble(code_b);
+                const bool any16 = kWide && group_max<kGroup>(m16 ? 1u : 0u) != 0u;
+                const bool any8 = any16 || group_max<kGroup>(m8 ? 1u : 0u) != 0u;
+                if (any8) {
+                    const bool mine = any16 ? m16 : m8;
+                    const uint32_t target = any16 ? t16 : t8;
+                    lo = group_min<kGroup>(mine ? target : 0xffffffffu);
+                    hi = group_max<kGroup>(mine ? target : 0u) + 1u;
+                    const uint32_t done = any16 ? 2u * kJumpSymbols : kJumpSymbols;
+                    rem -= done;
+                    if (kStats) lf_steps += done;
+                } else {
+                    // the interval empties within the next 8 steps: the pair lines find where, which yields the
+                    // reference's frozen interval (rare: a read that occurs in the text always matches)
+                    jump_ok = false;
+                    if (kWide) win.init(qbuf, begin, rem, s_dense);
+                }
+                continue;
+            }
+            if (!second) {
+#pragma unroll
+                for (int k = 0; k < kChunks; k++) b[k] = a[k];
+            }
+            if (c2 - 1u < 4u) {  // two LF steps: c1 is consumed first, then c2 (PairTable::lf2)
+                const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
+                const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14) | ((c2 & 1u) << 24);
+                const uint32_t bits_y = ((c2 >> 1) & 1u) | ((c2 & 4u) << 6);
+                const uint32_t nx = ~(bits_x * 0xffu);
+                const uint32_t ny = ~(bits_y * 0xffu) & 0xffffu;
+                uint32_t plo = 0, phi = 0;
+#pragma unroll
+                for (int k = 0; k < kChunks; k++) {
+                    plo += PairTable::pair_partial(a[k], sub + k * kGroup, pair, nx, ny, lo);
+                    phi += PairTable::pair_partial(b[k], sub + k * kGroup, pair, nx, ny, hi);
+                }
+                const uint32_t nlo = group_sum<kGroup>(plo), nhi = group_sum<kGroup>(phi);
                 if (nlo != nhi) {
                     lo = nlo;
                     hi = nhi;
@@ -407,20 +548,23 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     if (kStats) lf_steps += 2;
                     continue;
                 }
-                // the interval empties within these two steps: fall through to single steps so that the
+                // the interval empties within these two steps: take one step on the same lines so that the
                 // frozen interval is the one the reference reports
             }
-            if (c1 <= 4u) {
-                PairTable::lf1<kPolicy, kGroup>(ix, c1, lo, hi, lo, hi);
-            } else {  // a symbol outside 1..4 (N): rank lines
-                uint32_t rlo, rhi;
-                QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
-                const uint32_t cc = s_count[c1];
-                lo = cc + rlo;
-                hi = cc + rhi;
+            {  // one LF step (PairTable::lf1): odd tail, N next, or the step before the interval empties
+                const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
+                const uint32_t nx = ~(bits_x * 0xffu) & 0xffffffu;
+                uint32_t plo = 0, phi = 0;
+#pragma unroll
+                for (int k = 0; k < kChunks; k++) {
+                    plo += PairTable::single_partial(a[k], sub + k * kGroup, c1, nx, lo);
+                    phi += PairTable::single_partial(b[k], sub + k * kGroup, c1, nx, hi);
+                }
+                lo = group_sum<kGroup>(plo);
+                hi = group_sum<kGroup>(phi);
+                rem--;
+                if (kStats) lf_steps++;
             }
-            rem--;
-            if (kStats) lf_steps++;
         }
         if (writer) {
             if (out_start) out_start[q] = lo;
@@ -449,222 +593,34 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
         uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
         uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats,                      \
-        const uint32_t *__restrict__ len_range, int run_if_uniform, const uint32_t *__restrict__ perm
-#define GDX_SEARCH_FWD \
-    ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, run_if_uniform, perm
+        const uint32_t *__restrict__ len_range, const uint32_t *__restrict__ perm
+#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, perm
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
 // The 4-lane kernel holds two chunks per lane and line; with the 32-bit nibble windows (CodeWindow) it also fits
 // 64 VGPRs / 78 SGPRs without spills: 8 x 16 = 128 queries per SIMD in flight instead of 8 x 8 = 64.
-template <int kPolicy>
+template <int kPolicy, bool kWide>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, false>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, false, kWide>(GDX_SEARCH_FWD);
 }
-template <int kPolicy>
+template <int kPolicy, bool kWide>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, false>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, false, kWide>(GDX_SEARCH_FWD);
 }
 // accounting variants (gdx_search_step_stats_dev): the counters cost registers, so they are kept out of the
-// kernels that are timed
-template <int kPolicy>
+// timed kernels
+template <int kPolicy, bool kWide>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, true>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, true, kWide>(GDX_SEARCH_FWD);
 }
-template <int kPolicy>
+template <int kPolicy, bool kWide>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, true>(GDX_SEARCH_FWD);
-}
-
-// The same search as search_pair_kernel, organised as a stream: every 8-lane group walks its own
-// sequence of queries (q, q + stride, ...) and starts the next one in the very iteration the current one
-// ends, so lanes never idle while the longest query of a wave finishes (early-terminating and
-// mixed-length batches, BASELINE workload 5).  The next query's offsets and its last two 8-byte windows
-// are requested two iterations / one iteration after the current query started and are consumed some 20
-// line fetches later, so starting a query costs no memory wait (with a lookup table: one).
-template <int kPolicy, int kGroup, bool kStats>
-__device__ __forceinline__ void search_pair_stream_body(IndexView ix, const uint8_t *__restrict__ qbuf,
-                                                                    const uint64_t *__restrict__ qoff, uint64_t nq,
-                                                                    uint32_t *__restrict__ out_start,
-                                                                    uint32_t *__restrict__ out_end,
-                                                                    uint32_t *__restrict__ out_count,
-                                                                    uint8_t *__restrict__ out_status,
-                                                                    unsigned long long *__restrict__ step_stats,
-                                                                    const uint32_t *__restrict__ len_range, int run_if_uniform,
-                                                                    const uint32_t *__restrict__ perm)
-{
-    (void)perm;
-    if (len_range && run_if_uniform >= 0 && static_cast<int>(lengths_are_uniform(len_range)) != run_if_uniform) return;
-    __shared__ uint8_t s_dense[256];
-    __shared__ uint32_t s_count[257];
-    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
-    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    __syncthreads();
-
-    const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
-    const bool writer = (threadIdx.x % kGroup) == 0;
-    const uint64_t *words = reinterpret_cast<const uint64_t *>(qbuf);
-    uint32_t lf_steps = 0;
-    unsigned long long active_iters = 0, loop_iters = 0;  // step_stats[1], [2]
-
-    // the query being searched
-    uint64_t q = 0;
-    uint32_t rem = 0, lo = 0, hi = 0, status = GDX_Q_OK;
-    CodeWindow win;
-    win.base = words;
-    win.off0 = win.cur_w = win.cur = win.next = 0;
-    win.raw = 0;
-    bool have = false, jump_ok = false;
-    // the query staged behind it
-    uint64_t nx_q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup;
-    uint64_t nx_begin = 0, nx_end = 0, nx_cur = 0, nx_next = 0;
-    int nx_stage = 0;  // 0 nothing requested, 1 offsets requested, 2 windows requested
-
-    for (;;) {
-        // ---- stage the next query (loads issued here are not needed before a later iteration) ----
-        if (nx_stage == 1) {
-            const uint64_t len = nx_end - nx_begin;
-            const uint64_t t = len < static_cast<uint64_t>(ix.depth) ? len : static_cast<uint64_t>(ix.depth);
-            const uint32_t r = static_cast<uint32_t>(len - t);
-            const uint64_t *b = words + (nx_begin >> 3);
-            const uint32_t w = r ? ((static_cast<uint32_t>(nx_begin & 7u) + r - 1u) >> 3) : 0u;
-            nx_cur = r ? b[w] : 0ull;
-            nx_next = w >= 1u ? b[w - 1u] : 0ull;
-            nx_stage = 2;
-        } else if (nx_stage == 0 && nx_q < nq) {
-            nx_begin = qoff[nx_q];
-            nx_end = qoff[nx_q + 1];
-            nx_stage = 1;
-        }
-        // ---- start it when the slot is free -------------------------------------------------------------
-        if (!have && nx_stage == 2) {
-            q = nx_q;
-            const uint64_t begin = nx_begin, end = nx_end;
-            const uint64_t len = end - begin;
-            const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
-                                                                     : static_cast<uint32_t>(ix.depth);
-            lo = 0;
-            hi = ix.n;
-            status = GDX_Q_OK;
-            if (t > 0) {  // lookup_table.rs:99-113
-                uint32_t idx = 0, factor = 1;
-                bool unsearchable = false;
-                for (uint32_t j = 0; j < t; j++) {
-                    const uint32_t d = s_dense[qbuf[end - t + j]];
-                    if (d == 0) status = GDX_Q_INVALID_SYMBOL;
-                    unsearchable |= (d - 1u >= k);
-                    idx += (d - 1u) * factor;
-                    factor *= k;
-                }
-                if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
-                if (status == GDX_Q_OK) {
-                    const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
-                    lo = v.x;
-                    hi = v.y;
-                } else {
-                    lo = hi = 0;
-                }
-            }
-            rem = static_cast<uint32_t>(len - t);
-            win.set(qbuf, begin, rem, nx_cur, nx_next, s_dense);
-            have = true;
-            jump_ok = ix.jump != nullptr;
-            nx_q += stride;
-            nx_stage = 0;
-        }
-        // ---- one (double) LF step of the current query -------------------------------------------------
-        if (kStats) loop_iters++;
-        if (have) {
-            if (kStats) active_iters++;
-            if (rem > 0 && lo != hi) {
-                const uint32_t code = win.code8(rem, s_dense);
-                bool stepped = false;
-                if (jump_ok && hi - lo == 1u && rem >= kJumpSymbols) {
-                    stepped = try_jump(ix, code, lo, hi);
-                    if (stepped) {
-                        rem -= kJumpSymbols;
-                        if (kStats) lf_steps += kJumpSymbols;
-                    } else {
-                        jump_ok = false;
-                    }
-                }
-                const uint32_t c1 = code >> 28;
-                if (!stepped && c1 == 0) {  // alphabet.rs:195-198
-                    status = GDX_Q_INVALID_SYMBOL;
-                    lo = hi = 0;
-                    stepped = true;
-                }
-                if (!stepped) {
-                    const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
-                    if (c1 <= 4u && c2 - 1u < 4u) {
-                        uint32_t nlo, nhi;
-                        PairTable::lf2<kPolicy, kGroup>(ix, c2, c1, lo, hi, nlo, nhi);
-                        if (nlo != nhi) {
-                            lo = nlo;
-                            hi = nhi;
-                            rem -= 2;
-                            if (kStats) lf_steps += 2;
-                            stepped = true;
-                        }
-                    }
-                    if (!stepped) {  // single step: odd tail, N, or the step at which the interval empties
-                        if (c1 <= 4u) {
-                            PairTable::lf1<kPolicy, kGroup>(ix, c1, lo, hi, lo, hi);
-                        } else {
-                            uint32_t rlo, rhi;
-                            QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
-                            const uint32_t cc = s_count[c1];
-                            lo = cc + rlo;
-                            hi = cc + rhi;
-                        }
-                        rem--;
-                        if (kStats) lf_steps++;
-                    }
-                }
-            }
-            if (!(rem > 0 && lo != hi)) {  // lib.rs:226-232: finished, or frozen at the empty interval
-                if (writer) {
-                    if (out_start) out_start[q] = lo;
-                    if (out_end) out_end[q] = hi;
-                    if (out_count) out_count[q] = hi - lo;
-                    if (out_status) out_status[q] = static_cast<uint8_t>(status);
-                }
-                have = false;
-            }
-        }
-        if (!__any(have || nx_stage != 0 || nx_q < nq)) break;
-    }
-    if (kStats && step_stats && writer) {
-        atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
-        atomicAdd(step_stats + 1, active_iters);
-        atomicAdd(step_stats + 2, loop_iters);
-    }
-}
-
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_stream_kernel8(GDX_SEARCH_ARGS)
-{
-    search_pair_stream_body<kPolicy, 8, false>(GDX_SEARCH_FWD);
-}
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_stream_kernel4(GDX_SEARCH_ARGS)
-{
-    search_pair_stream_body<kPolicy, 4, false>(GDX_SEARCH_FWD);
-}
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) void search_pair_stream_stats_kernel8(GDX_SEARCH_ARGS)
-{
-    search_pair_stream_body<kPolicy, 8, true>(GDX_SEARCH_FWD);
-}
-template <int kPolicy>
-__global__ __launch_bounds__(kBlock) void search_pair_stream_stats_kernel4(GDX_SEARCH_ARGS)
-{
-    search_pair_stream_body<kPolicy, 4, true>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, true, kWide>(GDX_SEARCH_FWD);
 }
 
 // Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
@@ -761,6 +717,27 @@ __global__ __launch_bounds__(kBlock) void fill_lookup_kernel(IndexView ix, uint2
     }
 }
 
+// top[idx]: idx holds the 2-bit codes (dense - 1) of the D symbols in consumption order, first consumed symbol in
+// the highest bit pair (top_lookup builds the same index from the query's nibble codes).  Empty intervals are
+// stored as {0, 0}.
+__global__ __launch_bounds__(kBlock) void fill_top_kernel(IndexView ix, uint2 *__restrict__ top, uint32_t depth,
+                                                          uint64_t entries)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) {
+        uint32_t lo = 0, hi = ix.n;
+        for (uint32_t s = 0; s < depth && lo != hi; s++) {
+            const uint32_t c = (static_cast<uint32_t>(e >> (2u * (depth - 1u - s))) & 3u) + 1u;
+            uint32_t rlo, rhi;
+            LineTable::rank2(ix, c, lo, hi, rlo, rhi);
+            const uint32_t cc = ix.count[c];
+            lo = cc + rlo;
+            hi = cc + rhi;
+        }
+        top[e] = lo != hi ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+    }
+}
+
 }  // namespace
 
 #define GDX_DISPATCH_TABLE(ix, KERNEL, grid, stream, ...)                                        \
@@ -833,23 +810,19 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 1;
         }();
-        // GDX_SEARCH_STREAM: unset = lock-step kernel walking a length-ordered schedule when the lengths of the
-        // batch are spread out (default); 0 = lock-step in query order; 1 = streaming kernel; auto = lock-step
-        // or streaming decided on the device (both enqueued, one returns at once).
-        static const int mode = [] {
-            const char *e = getenv("GDX_SEARCH_STREAM");
-            if (!e) return 2;
-            return e[0] == 'a' ? -1 : (e[0] == '0' ? 0 : 1);
+        // Batches whose query lengths are spread out are walked in a length-ordered schedule decided on the device
+        // (see length_hist_kernel); GDX_SEARCH_SCHEDULE=0 keeps the query order.
+        static const bool schedule = [] {
+            const char *e = getenv("GDX_SEARCH_SCHEDULE");
+            return !(e && e[0] == '0');
         }();
         uint32_t *d_range = nullptr, *d_perm = nullptr, *d_cells = nullptr;
-        if (mode == -1 || mode == 2) {
+        if (schedule) {
             d_range = static_cast<uint32_t *>(stream_scratch(stream, 0, 2 * sizeof(uint32_t)));
             GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range), 0xffffffff, 1, stream));
             GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range + 1), 0, 1, stream));
             hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq / 61 + 1)), dim3(kBlock), 0, stream,
                                d_qoff, nq, d_range);
-        }
-        if (mode == 2) {
             const uint32_t n_chunks = static_cast<uint32_t>((nq + kLenChunk - 1) / kLenChunk);
             const uint64_t n_cells = static_cast<uint64_t>(kLenBuckets) * n_chunks;
             d_perm = static_cast<uint32_t *>(stream_scratch(stream, 1, nq * sizeof(uint32_t)));
@@ -861,30 +834,28 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             hipLaunchKernelGGL(length_scatter_kernel, dim3(hist_grid), dim3(kBlock), 0, stream, d_qoff, nq, d_range,
                                n_chunks, d_cells, d_perm);
         }
-        const int lock_flag = mode == -1 ? 1 : -1;  // auto: lock-step only for uniform batches
-#define GDX_PAIR_LAUNCH(LOCK, STREAM)                                                                              \
-    do {                                                                                                           \
-        if (mode != 1)                                                                                             \
-            hipLaunchKernelGGL(LOCK, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq,          \
-                               d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range, lock_flag, \
-                               d_perm);                                                                            \
-        if (mode == 1 || mode == -1)                                                                               \
-            hipLaunchKernelGGL(STREAM, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq,        \
-                               d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats, d_range,           \
-                               mode == 1 ? -1 : 0, d_perm);                                                        \
+#define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
+    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
+                       d_out_end, d_out_count, d_out_status, d_step_stats, d_range, d_perm)
+#define GDX_PAIR_LAUNCH_W(KERNEL, P)                      \
+    do {                                                  \
+        if (wide) GDX_PAIR_LAUNCH((KERNEL<P, true>));     \
+        else GDX_PAIR_LAUNCH((KERNEL<P, false>));         \
     } while (0)
+        const bool wide = ix.jump16 != nullptr;
         if (d_step_stats != nullptr) {
-            if (lanes == 8) GDX_PAIR_LAUNCH(search_pair_stats_kernel8<1>, search_pair_stream_stats_kernel8<1>);
-            else GDX_PAIR_LAUNCH(search_pair_stats_kernel4<1>, search_pair_stream_stats_kernel4<1>);
+            if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 1);
+            else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 1);
         } else if (lanes == 8) {
-            if (policy == 1) GDX_PAIR_LAUNCH(search_pair_kernel8<1>, search_pair_stream_kernel8<1>);
-            else if (policy == 2) GDX_PAIR_LAUNCH(search_pair_kernel8<2>, search_pair_stream_kernel8<2>);
-            else if (policy == 3) GDX_PAIR_LAUNCH(search_pair_kernel8<3>, search_pair_stream_kernel8<3>);
-            else GDX_PAIR_LAUNCH(search_pair_kernel8<0>, search_pair_stream_kernel8<0>);
+            if (policy == 1) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 1);
+            else if (policy == 2) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 2);
+            else if (policy == 3) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 3);
+            else GDX_PAIR_LAUNCH_W(search_pair_kernel8, 0);
         } else {
-            if (policy == 0) GDX_PAIR_LAUNCH(search_pair_kernel4<0>, search_pair_stream_kernel4<0>);
-            else GDX_PAIR_LAUNCH(search_pair_kernel4<1>, search_pair_stream_kernel4<1>);
+            if (policy == 0) GDX_PAIR_LAUNCH_W(search_pair_kernel4, 0);
+            else GDX_PAIR_LAUNCH_W(search_pair_kernel4, 1);
         }
+#undef GDX_PAIR_LAUNCH_W
 #undef GDX_PAIR_LAUNCH
     } else if (ix.layout == 0 && search_variant() != 1) {
         const unsigned blocks = group_grid(kBlock / 4);
@@ -936,6 +907,13 @@ void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStre
     for (int j = 0; j < depth; j++) entries *= static_cast<uint64_t>(ix.n_searchable);
     GDX_DISPATCH_TABLE(ix, fill_lookup_kernel, grid_for_items(entries), stream, ix, d_lookup, depth,
                        static_cast<uint32_t>(entries));
+}
+
+void launch_fill_top(const IndexView &ix, uint2 *d_top, uint32_t depth, hipStream_t stream)
+{
+    const uint64_t entries = 1ull << (2u * depth);
+    hipLaunchKernelGGL(fill_top_kernel, dim3(grid_for_items(entries)), dim3(kBlock), 0, stream, ix, d_top, depth,
+                       entries);
 }
 
 }  // namespace gdx

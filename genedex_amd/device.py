@@ -138,6 +138,14 @@ class DeviceEngine:
                                                       _stream()))
         return [int(x) for x in steps.tolist()]
 
+    def aux_info(self) -> dict:
+        """Acceleration structures of the index (gdx_index_aux_info)."""
+        import ctypes
+
+        out = (ctypes.c_uint32 * 4)()
+        _lib.check(self.lib.gdx_index_aux_info(self.h, out))
+        return {"pair_lines": bool(out[0]), "jump_entry_bytes": int(out[1]), "top_table_depth": int(out[2])}
+
     def search_lf_steps(self, q: DeviceQueries) -> int:
         return self.search_step_stats(q)[0]
 

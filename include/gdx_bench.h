@@ -66,6 +66,11 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
                               const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
                               void *d_steps, void *stream);
 
+/* Query acceleration structures the index carries beside the reference's arrays (DESIGN.md "HBM layout"):
+ * out[0] = 1 if pair lines are present, out[1] = bytes per jump-table entry (0 = none, 8 or 16),
+ * out[2] = depth of the top table (0 = none), out[3] = reserved (0). */
+int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,14 +191,39 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
     return [qs[i] for i in order]
 
 
-@pytest.fixture(params=["pair", "quad", "lane"])
+_VARIANT_ENV = {
+    # name: (kernel variant, GDX_JUMP_WIDE, GDX_TOP_DEPTH)
+    "pair": (2, None, None),            # defaults: 16-byte jump entries, top table sized from the text
+    "pair-narrow": (2, "0", "0"),       # 8-byte jump entries, no top table
+    "pair-top4": (2, None, "4"),        # forced top depths: on these small texts most deep entries are empty,
+    "pair-top9": (2, None, "9"),        # so the fall-back to the ordinary path runs constantly
+    "quad": (0, None, None),
+    "lane": (1, None, None),
+}
+
+
+@pytest.fixture(params=list(_VARIANT_ENV))
 def search_variant(request):
-    """Every search kernel variant must give the same answers."""
+    """Every search kernel variant and index acceleration structure must give the same answers."""
+    import os
+
     from genedex_amd import _lib
 
     lib = _lib.load()
-    lib.gdx_debug_set_search_variant({"quad": 0, "lane": 1, "pair": 2}[request.param])
+    variant, wide, top = _VARIANT_ENV[request.param]
+    lib.gdx_debug_set_search_variant(variant)
+    saved = {k: os.environ.get(k) for k in ("GDX_JUMP_WIDE", "GDX_TOP_DEPTH")}
+    for k, v in (("GDX_JUMP_WIDE", wide), ("GDX_TOP_DEPTH", top)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     yield request.param
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     lib.gdx_debug_set_search_variant(2)
 
 

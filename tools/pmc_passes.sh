@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-bandwidth --verify-hits 0 $*"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-bandwidth --secondary-depth 0 --verify-hits 0 $*"
 i=0
 for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum" \

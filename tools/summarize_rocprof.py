@@ -46,7 +46,7 @@ def pmc(d):
             k = (short(r["Kernel_Name"]), r["Counter_Name"])
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
-        for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+        for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             out.setdefault(c, {})[k] = {"launches": n, "sum": s, "per_launch": s / n}
     print(json.dumps(out, indent=1))
 
