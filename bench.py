@@ -248,6 +248,16 @@ def main():
         result["roofline"]["frac_of_measured_stream"] = (result["roofline"]["achieved"]
                                                           / result["measured_bandwidth"]["stream_copy_GBps"])
         log(f"[bench] measured bandwidth: {result['measured_bandwidth']}")
+        # The kernel's own bound: it is made of dependent random 128-byte requests, whose measured ceiling on this
+        # GPU (gather128_group of measure_bandwidth) is well below the streaming peak.
+        rq = result["roofline"].get("dram_read_requests_per_query")
+        if rq:
+            rate = rq * nq / (search_ms / 1e3) / 1e9
+            ceiling = result["measured_bandwidth"]["gather128_group_Glines_per_s"]
+            result["roofline"]["random_request_model"] = {
+                "dram_requests_per_launch": rq * nq, "achieved_Greq_per_s": rate, "measured_ceiling_Greq_per_s": ceiling,
+                "frac_of_ceiling": rate / ceiling, "traffic_frac_of_hbm_peak": result["roofline"]["traffic"]
+                / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl)
@@ -256,8 +266,8 @@ def main():
 
     if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
         # Secondary design points, never `value`: (1) the reference's lookup-table knob at the depth BASELINE.md names;
-        # (2) the same step with every acceleration structure of this build switched off (rank lines in the
-        # reference's information content only), so the effect of the extra HBM spent on them is on record.
+        # (2) pair lines but no jump / top table; (3) every acceleration structure of this build switched off (rank
+        # lines with the reference's information content only).  The HBM each rung spends is in `index_bytes`.
         base_counts = (out["end"] - out["start"]).clone()
         del eng, index
         torch.cuda.empty_cache()
@@ -265,6 +275,7 @@ def main():
                   do_locate, args, wl)
         result["secondary"] = [
             secondary_run(f"lookup_depth_{args.secondary_depth}", args.secondary_depth, {}, *common),
+            secondary_run("pair_lines_only", args.lookup_depth, {"GDX_TOP_DEPTH": "0", "GDX_NO_JUMP_TABLE": "1"}, *common),
             secondary_run("no_acceleration_structures", args.lookup_depth,
                           {"GDX_TOP_DEPTH": "0", "GDX_NO_JUMP_TABLE": "1", "GDX_NO_PAIR_LINES": "1"}, *common),
         ]
@@ -350,8 +361,11 @@ def pmc_traffic(kernel_name, args, wl, nq):
         if (pmc["workload"], pmc["lookup_depth"], pmc["kernel"]) != (args.workload, args.lookup_depth, kernel_name):
             return {"traffic": None}
         per_query = (2 * pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024 / pmc["queries_per_launch"]
-        return {"traffic": per_query * nq, "traffic_source": "profiles/r01/search_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / "
-                "WRITE_SIZE, separate passes, FETCH_SIZE doubled: all requests are 128 B)"}
+        res = {"traffic": per_query * nq, "traffic_source": "profiles/r01/search_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / "
+               "WRITE_SIZE, separate passes, FETCH_SIZE doubled: all requests are 128 B)"}
+        if "TCC_EA0_RDREQ_per_launch" in pmc:
+            res["dram_read_requests_per_query"] = pmc["TCC_EA0_RDREQ_per_launch"] / pmc["queries_per_launch"]
+        return res
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
 
