@@ -247,45 +247,16 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
 
-// len_range = {min, max} query length of a batch (query_length_range_kernel).  Batches of (nearly) equal
-// lengths are searched in query order; for the others the length-ordered schedule below is built.
-__device__ __forceinline__ bool lengths_are_uniform(const uint32_t *len_range)
-{
-    const uint32_t mn = len_range[0], mx = len_range[1];
-    return mx - mn <= mn / 4u;
-}
-
-__global__ __launch_bounds__(kBlock) void query_length_range_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
-                                                                    uint32_t *__restrict__ len_range)
-{
-    // a sample is enough (every 61st query): the range only picks a schedule, never affects results
-    uint32_t mn = 0xffffffffu, mx = 0;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock * 61u;
-    for (uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * 61u; q < nq; q += stride) {
-        const uint64_t len = qoff[q + 1] - qoff[q];
-        const uint32_t l = len > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(len);
-        mn = l < mn ? l : mn;
-        mx = l > mx ? l : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t omn = __shfl_xor(mn, off), omx = __shfl_xor(mx, off);
-        mn = omn < mn ? omn : mn;
-        mx = omx > mx ? omx : mx;
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        atomicMin(&len_range[0], mn);
-        atomicMax(&len_range[1], mx);
-    }
-}
-
-// ---- length-ordered schedule for mixed-length batches -----------------------------------------------
-// The lock-step kernel idles the lanes of a finished query until the longest query of its wavefront ends.
-// When the lengths of a batch are spread out, the queries are bucketed by length (4 symbols per bucket,
-// longest first) and the kernel walks that permutation, so that the queries of a wavefront have nearly
-// the same length; results are still written at the original query index.  Everything is decided and
-// done on the device: for a uniform batch the three kernels return at once.
+// ---- length-ordered schedule inside a block -----------------------------------------------------------
+// The lock-step kernel idles the lanes of a finished query until the longest query of its wavefront ends.  Every
+// block searches a contiguous range of the batch (at most kMaxRange queries); when the lengths in that range are
+// spread out it first orders the range by length (counting sort in LDS, 4 symbols per bucket, longest first) and
+// its wavefronts take runs of that order, so the queries of a wavefront have nearly the same length.  Results
+// are written at the original query index.  All reads and writes of a block stay inside its range, so the
+// order costs no DRAM locality (an earlier batch-wide permutation did: its gathers were slower than the idle
+// lanes it saved), and there is no pre-pass and no host round trip.  Ranges of (nearly) equal lengths skip it.
 constexpr uint32_t kLenBuckets = 64;
-constexpr uint32_t kLenChunk = 4096;  // queries per histogram block
+constexpr uint32_t kMaxRange = 3072;  // queries per block and range: u16 permutation, 6 KB of LDS
 
 __device__ __forceinline__ uint32_t length_bucket(uint64_t len)
 {
@@ -293,72 +264,54 @@ __device__ __forceinline__ uint32_t length_bucket(uint64_t len)
     return kLenBuckets - 1u - static_cast<uint32_t>(b < kLenBuckets - 1u ? b : kLenBuckets - 1u);
 }
 
-// counts[bucket * n_chunks + chunk]
-__global__ __launch_bounds__(kBlock) void length_hist_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
-                                                             const uint32_t *__restrict__ len_range, uint32_t n_chunks,
-                                                             uint32_t *__restrict__ counts)
+// Orders queries [base, base + cnt) of the batch by length bucket into s_perm (indices relative to base); returns
+// false (s_perm untouched) when the lengths are uniform enough: max - min <= min / 4.  Block-wide, all threads.
+__device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict__ qoff, uint64_t base, uint32_t cnt,
+                                                      uint16_t *s_perm, uint32_t *s_cnt, uint32_t *s_minmax)
 {
-    if (lengths_are_uniform(len_range)) return;
-    __shared__ uint32_t s_cnt[kLenBuckets];
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < kLenChunk; t += kBlock) {
-            const uint64_t q = static_cast<uint64_t>(chunk) * kLenChunk + t;
-            if (q < nq) atomicAdd(&s_cnt[length_bucket(qoff[q + 1] - qoff[q])], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < kLenBuckets) counts[threadIdx.x * n_chunks + chunk] = s_cnt[threadIdx.x];
-        __syncthreads();
+    if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_minmax[0] = 0xffffffffu;
+        s_minmax[1] = 0;
     }
-}
-
-// in-place exclusive scan of `cells` u32 values by one block (cells is a few million at most)
-__global__ __launch_bounds__(1024) void length_scan_kernel(uint32_t *__restrict__ cells, uint64_t n_cells,
-                                                           const uint32_t *__restrict__ len_range)
-{
-    if (lengths_are_uniform(len_range)) return;
-    __shared__ uint32_t s_sum[1024];
-    const uint64_t per = (n_cells + 1023) / 1024;
-    const uint64_t lo = threadIdx.x * per, hi = lo + per < n_cells ? lo + per : n_cells;
-    uint32_t sum = 0;
-    for (uint64_t i = lo; i < hi; i++) sum += cells[i];
-    s_sum[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t add = threadIdx.x >= static_cast<uint32_t>(off) ? s_sum[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += add;
-        __syncthreads();
+    uint32_t mn = 0xffffffffu, mx = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const uint64_t len = qoff[base + i + 1] - qoff[base + i];
+        const uint32_t l = len > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(len);
+        mn = l < mn ? l : mn;
+        mx = l > mx ? l : mx;
+        atomicAdd(&s_cnt[length_bucket(len)], 1u);
     }
-    uint32_t run = s_sum[threadIdx.x] - sum;
-    for (uint64_t i = lo; i < hi; i++) {
-        const uint32_t v = cells[i];
-        cells[i] = run;
-        run += v;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t omn = __shfl_xor(mn, off), omx = __shfl_xor(mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
     }
-}
-
-__global__ __launch_bounds__(kBlock) void length_scatter_kernel(const uint64_t *__restrict__ qoff, uint64_t nq,
-                                                                const uint32_t *__restrict__ len_range,
-                                                                uint32_t n_chunks, const uint32_t *__restrict__ offsets,
-                                                                uint32_t *__restrict__ perm)
-{
-    if (lengths_are_uniform(len_range)) return;
-    __shared__ uint32_t s_cnt[kLenBuckets];
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < kLenChunk; t += kBlock) {
-            const uint64_t q = static_cast<uint64_t>(chunk) * kLenChunk + t;
-            if (q < nq) {
-                const uint32_t b = length_bucket(qoff[q + 1] - qoff[q]);
-                const uint32_t r = atomicAdd(&s_cnt[b], 1u);
-                perm[offsets[b * n_chunks + chunk] + r] = static_cast<uint32_t>(q);
-            }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMin(&s_minmax[0], mn);
+        atomicMax(&s_minmax[1], mx);
+    }
+    __syncthreads();
+    mn = s_minmax[0];
+    mx = s_minmax[1];
+    if (mx - mn <= mn / 4u) return false;
+    if (threadIdx.x < kLenBuckets) {  // exclusive scan of the histogram by the first wavefront
+        const uint32_t v = s_cnt[threadIdx.x];
+        uint32_t x = v;
+        for (int off = 1; off < static_cast<int>(kLenBuckets); off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if (static_cast<int>(threadIdx.x) >= off) x += y;
         }
-        __syncthreads();
+        s_cnt[threadIdx.x] = x - v;
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const uint32_t r = atomicAdd(&s_cnt[length_bucket(qoff[base + i + 1] - qoff[base + i])], 1u);
+        s_perm[r] = static_cast<uint16_t>(i);
+    }
+    __syncthreads();
+    return true;
 }
 
 // Backward search on pair lines: eight lanes per query, two LF steps per line fetch while both next
@@ -373,24 +326,29 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
-                                                             const uint32_t *__restrict__ len_range,
-                                                             const uint32_t *__restrict__ perm)
+                                                             uint32_t range, int schedule)
 {
-    const bool use_perm = perm != nullptr && len_range != nullptr && !lengths_are_uniform(len_range);
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
+    __shared__ uint16_t s_perm[kMaxRange];
+    __shared__ uint32_t s_cnt[kLenBuckets];
+    __shared__ uint32_t s_minmax[2];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
     const bool writer = (threadIdx.x % kGroup) == 0;
     uint32_t lf_steps = 0;
     unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
-    for (uint64_t slot = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; slot < nq;
-         slot += stride) {
-        const uint64_t q = use_perm ? perm[slot] : slot;
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+    const uint64_t base = rg * range;
+    const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+    if (rg != blockIdx.x) __syncthreads();  // the previous range's order is no longer read
+    const bool ordered = schedule != 0 && order_range_by_length(qoff, base, cnt, s_perm, s_cnt, s_minmax);
+    for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
+        const uint64_t q = base + (ordered ? s_perm[slot] : slot);
         const uint64_t begin = qoff[q], end = qoff[q + 1];
         const uint64_t len = end - begin;
         const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
@@ -582,6 +540,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             wave_slots += wave_max;
         }
     }
+    }  // ranges
     if (kStats && step_stats && writer) {
         atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
         atomicAdd(step_stats + 1, group_iters);
@@ -592,9 +551,8 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #define GDX_SEARCH_ARGS                                                                                      \
     IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
         uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
-        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats,                      \
-        const uint32_t *__restrict__ len_range, const uint32_t *__restrict__ perm
-#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, len_range, perm
+        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats, uint32_t range, int schedule
+#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
@@ -803,40 +761,29 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             const char *e = getenv("GDX_SEARCH_LANES");
             return (e && atoi(e) == 8) ? 8 : 4;
         }();
-        const unsigned blocks = group_grid(kBlock / lanes);
+        // Every block searches contiguous ranges of `range` queries (a multiple of 64, at most kMaxRange): about
+        // 48 rounds per group at large batches, 1792+ blocks at small ones; GDX_SEARCH_GRID = number of blocks.
+        uint64_t per_block = (nq + 1791) / 1792;
+        per_block = (per_block + 63) / 64 * 64;
+        const uint32_t range = static_cast<uint32_t>(per_block > kMaxRange ? kMaxRange : per_block);
+        const uint64_t n_ranges = (nq + range - 1) / range;
+        const unsigned blocks = grid_override > 0 ? static_cast<unsigned>(grid_override)
+                                                  : static_cast<unsigned>(n_ranges < (1u << 20) ? n_ranges : (1u << 20));
         // pair lines are fetched with sc1 (served by L2, no allocation in the CU's L1): +5 % measured;
         // GDX_LOAD_POLICY=0|1|2|3 overrides (plain, sc1, nt, sc0 sc1)
         static const int policy = [] {
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 1;
         }();
-        // Batches whose query lengths are spread out are walked in a length-ordered schedule decided on the device
-        // (see length_hist_kernel); GDX_SEARCH_SCHEDULE=0 keeps the query order.
-        static const bool schedule = [] {
+        // Ranges whose query lengths are spread out are searched in length order (order_range_by_length);
+        // GDX_SEARCH_SCHEDULE=0 keeps the query order.
+        static const int schedule = [] {
             const char *e = getenv("GDX_SEARCH_SCHEDULE");
-            return !(e && e[0] == '0');
+            return (e && e[0] == '0') ? 0 : 1;
         }();
-        uint32_t *d_range = nullptr, *d_perm = nullptr, *d_cells = nullptr;
-        if (schedule) {
-            d_range = static_cast<uint32_t *>(stream_scratch(stream, 0, 2 * sizeof(uint32_t)));
-            GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range), 0xffffffff, 1, stream));
-            GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_range + 1), 0, 1, stream));
-            hipLaunchKernelGGL(query_length_range_kernel, dim3(grid_for_items(nq / 61 + 1)), dim3(kBlock), 0, stream,
-                               d_qoff, nq, d_range);
-            const uint32_t n_chunks = static_cast<uint32_t>((nq + kLenChunk - 1) / kLenChunk);
-            const uint64_t n_cells = static_cast<uint64_t>(kLenBuckets) * n_chunks;
-            d_perm = static_cast<uint32_t *>(stream_scratch(stream, 1, nq * sizeof(uint32_t)));
-            d_cells = static_cast<uint32_t *>(stream_scratch(stream, 2, n_cells * sizeof(uint32_t)));
-            const unsigned hist_grid = n_chunks < 16384u ? n_chunks : 16384u;
-            hipLaunchKernelGGL(length_hist_kernel, dim3(hist_grid), dim3(kBlock), 0, stream, d_qoff, nq, d_range, n_chunks,
-                               d_cells);
-            hipLaunchKernelGGL(length_scan_kernel, dim3(1), dim3(1024), 0, stream, d_cells, n_cells, d_range);
-            hipLaunchKernelGGL(length_scatter_kernel, dim3(hist_grid), dim3(kBlock), 0, stream, d_qoff, nq, d_range,
-                               n_chunks, d_cells, d_perm);
-        }
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
-                       d_out_end, d_out_count, d_out_status, d_step_stats, d_range, d_perm)
+                       d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule)
 #define GDX_PAIR_LAUNCH_W(KERNEL, P)                      \
     do {                                                  \
         if (wide) GDX_PAIR_LAUNCH((KERNEL<P, true>));     \
