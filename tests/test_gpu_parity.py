@@ -360,6 +360,57 @@ def test_medium_text_against_oracle(search_variant):
     assert (e - s)[:1000].sum() > 0
 
 
+_ALPHABETS = {
+    # name: (constructor, symbols texts are drawn from, symbols random queries are drawn from)
+    "ascii_dna": (alph.ascii_dna, b"ACGTacgt", b"ACGT"),
+    "ascii_dna_with_n": (alph.ascii_dna_with_n, b"ACGTNacgtn", b"ACGTN"),
+    "ascii_dna_iupac": (alph.ascii_dna_iupac, b"ACGTNRYKMSWBDHVacgtnry", b"ACGTNRYKMSWBDHV"),
+    "ascii_dna_iupac_as_dna_with_n": (alph.ascii_dna_iupac_as_dna_with_n, b"ACGTNRYKMSWBDHVacgt", b"ACGTN"),
+    "ascii_amino_acid": (alph.ascii_amino_acid, b"ACDEFGHIKLMNPQRSTVWYacdef", b"ACDEFGHIKLMNPQRSTVWY"),
+    "ascii_amino_acid_iupac": (alph.ascii_amino_acid_iupac, b"ACDEFGHIKLMNPQRSTVWYBZXacd", b"ACDEFGHIKLMNPQRSTVWYBZX"),
+    "u8_until": (lambda: alph.u8_until(200), bytes(range(201)), bytes(range(201))),
+    "ascii_printable": (alph.ascii_printable, bytes(range(0x20, 0x7f)), bytes(range(0x20, 0x7f))),
+}
+
+
+@pytest.mark.parametrize("name", list(_ALPHABETS))
+def test_every_reference_alphabet(name):
+    """alphabet.rs:251-345: all eight stock alphabets (case folding, ambiguity groups, non-searchable tails,
+    rank-line layout for sigma <= 8 and the generic planes above) through build, search and locate."""
+    make, text_symbols, query_symbols = _ALPHABETS[name]
+    a = make()
+    rng = np.random.default_rng(sum(name.encode()))
+    texts = [bytes(text_symbols[i] for i in rng.integers(0, len(text_symbols), int(rng.integers(0, 4000))))
+             for _ in range(5)]
+    for depth in (0, 2):
+        g, c = both(texts, a, depth=depth, sa_rate=3)
+        assert g.export_bwt().tolist() == c.bwt.tolist()
+        qs = []
+        for _ in range(400):
+            t = texts[int(rng.integers(0, len(texts)))]
+            if len(t) > 0:
+                pos = int(rng.integers(0, len(t)))
+                qs.append(t[pos:pos + int(rng.integers(0, 12))])
+            qs.append(bytes(query_symbols[i] for i in rng.integers(0, len(query_symbols), int(rng.integers(0, 6)))))
+        qbuf, qoff = pack_queries(qs)
+        s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+        cs, ce, cst = c.cursors_single(qbuf, qoff)
+        assert st.tolist() == cst.tolist()
+        ok = st == 0
+        assert ok.sum() > len(qs) // 2
+        assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+        off, t_, p_, _ = g.locate_raw(qbuf, qoff, strict=False)
+        co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+        # a naive count on the case-folded / group-folded dense texts pins a few of them independently of the oracle
+        dense_texts = [a.encode(t) for t in texts]
+        for q in [q for q, good in zip(qs, ok) if good and len(q) > 0][:40]:
+            dq = a.encode(q).tobytes()
+            want = sum(sum(1 for i in range(len(dt) - len(dq) + 1) if dt[i:i + len(dq)].tobytes() == dq)
+                       for dt in dense_texts)
+            assert g.count(q) == want, (name, q)
+
+
 def test_many_short_texts_and_sentinel_crossings(search_variant):
     """Thousands of tiny texts: pair steps and 8-symbol jumps constantly run into text borders, N and sentinels."""
     rng = np.random.default_rng(77)
