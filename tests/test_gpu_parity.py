@@ -454,6 +454,26 @@ def test_long_repeats_and_long_queries(search_variant):
     assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
 
 
+def test_genome_like_text_properties():
+    """A 32 M-symbol text with segmental duplications, tandem repeats, poly-A and long runs of N (tools/genome_like.py):
+    many doubling rounds in the suffix sorter, intervals of millions of rows, wide intervals deep into the search.
+    Checked without the oracle: every sampled read is found, located hits spell their query, counts equal a scan."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "genome_like.py")
+    spec = importlib.util.spec_from_file_location("genome_like", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(1 << 25, 200_000)
+    assert res["build_stats"]["sa_rounds"] >= 10
+    assert res["queries_with_status"] == 0
+    assert res["queries_found"] >= 180_000  # the 90 % drawn from the text
+    assert res["max_count"] > 10_000
+    assert res["hits_checked"] > 0 and res["hits_checked"] == res["hits_spelling_their_query"]
+    assert res["counts_checked_by_scan"] == res["counts_equal_scan"] == 9
+
+
 def test_full_size_properties_workload2():
     """BASELINE workload 2 at full size (256 MB text, 10 M len-50 reads) through size-independent properties:
     every sampled read is found, every reported hit spells its query in the text, count == number of hits,
