@@ -358,34 +358,6 @@ struct PairTable {
         const bool owner = (chunk >> 1) == (c1 - 1u);
         return __popc(m & low_mask(idx, chunk)) + (owner ? ((c.y >> 16) << ((chunk & 1u) * 16u)) : 0u);
     }
-    // two LF steps: c1 is consumed first (it precedes the current suffix), then c2; both in 1..4
-    template <int kPolicy, int kLanes>
-    static __device__ __forceinline__ void lf2(const IndexView &ix, uint32_t c2, uint32_t c1, uint32_t lo, uint32_t hi,
-                                               uint32_t &nlo, uint32_t &nhi)
-    {
-        constexpr int kChunks = 8 / kLanes;
-        const uint32_t sub = threadIdx.x & (kLanes - 1u);
-        const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
-        // byte k of nx / ny is 0xff where the symbol's bit k is 0 (the plane must be negated), else 0:
-        // spread the bits to byte lanes, multiply by 0xff, invert
-        const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14) | ((c2 & 1u) << 24);
-        const uint32_t bits_y = ((c2 >> 1) & 1u) | ((c2 & 4u) << 6);
-        const uint32_t nx = ~(bits_x * 0xffu);
-        const uint32_t ny = ~(bits_y * 0xffu) & 0xffffu;
-        const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
-        u32x4 a[kChunks], b[kChunks];
-        load_two_lines<kPolicy, kChunks>(ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub,
-                                         ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub,
-                                         line_hi != line_lo, kLanes, a, b);
-        uint32_t plo = 0, phi = 0;
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) {
-            plo += pair_partial(a[k], sub + k * kLanes, pair, nx, ny, lo);
-            phi += pair_partial(b[k], sub + k * kLanes, pair, nx, ny, hi);
-        }
-        nlo = group_sum<kLanes>(plo);
-        nhi = group_sum<kLanes>(phi);
-    }
     // one LF step with a symbol in 1..4
     template <int kPolicy, int kLanes>
     static __device__ __forceinline__ void lf1(const IndexView &ix, uint32_t c1, uint32_t lo, uint32_t hi,

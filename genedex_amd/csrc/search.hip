@@ -44,13 +44,6 @@ struct QueryWindow {
         }
         return static_cast<uint32_t>(cur >> ((at & 7u) * 8u)) & 0xffu;
     }
-    // the 8 bytes [pos-8, pos) (byte k of the result = query byte pos-8+k) without moving the window;
-    // requires get(pos-1) to have been called and pos-8 >= begin of the query
-    __device__ __forceinline__ uint64_t peek8(uint64_t pos) const
-    {
-        const uint32_t s = static_cast<uint32_t>(pos - (cur_word << 3));  // 1..8
-        return s >= 8u ? cur : ((next >> (8u * s)) | (cur << (64u - 8u * s)));
-    }
 };
 
 // The query as the pair kernels see it: dense codes, one nibble per symbol, eight symbols per 32-bit word,
@@ -108,40 +101,6 @@ struct CodeWindow {
 };
 
 __device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x11111111u) & ~x & 0x88888888u) != 0u; }
-
-// One-row intervals (the usual state of a read after ~16 symbols) advance kJumpSymbols LF steps with one
-// 8-byte fetch: jump[i] = {LF^8(i), codes of the 8 symbols preceding suffix SA[i] (nibble 7 = text[SA[i]-1])}.
-// If the next 8 query symbols equal the stored ones the interval becomes [LF^8(i), LF^8(i)+1); otherwise the
-// interval empties within these 8 steps and the caller finishes on the pair lines, which yields the
-// reference's frozen interval.  `code` = CodeWindow::code8 at the current position (rem >= 8).
-__device__ __forceinline__ bool try_jump(const IndexView &ix, uint32_t code, uint32_t &lo, uint32_t &hi)
-{
-    if (has_zero_nibble(code)) return false;  // a symbol outside the alphabet ahead: let the step path report it
-    // wide entries carry the 8-step pair in their first half
-    const uint2 j = ix.jump16 ? *reinterpret_cast<const uint2 *>(ix.jump16 + lo) : ix.jump[lo];
-    if (j.y != code) return false;
-    lo = j.x;
-    hi = j.x + 1u;
-    return true;
-}
-
-// Wide entries (IndexView::jump16): {LF^8(i), codes of steps 1-8, LF^16(i), codes of steps 9-16} in one 16-byte
-// fetch.  `code` = code8(rem) (rem >= 8).  The codes of the 8 symbols after those are taken while the entry is in
-// flight, which moves the window one word down; that is where it has to be after any successful jump.  Returns
-// the number of symbols consumed (16, 8, or 0 = mismatch: the caller re-initialises the window and goes on with
-// single/pair steps, rare since a one-row interval of a read that occurs in the text always matches).
-__device__ __forceinline__ uint32_t try_jump_wide(const IndexView &ix, CodeWindow &win, uint32_t code, uint32_t rem,
-                                                  uint32_t &lo, uint32_t &hi, const uint8_t *s_dense)
-{
-    const u32x4 e = ix.jump16[lo];
-    uint32_t code_b = 0;
-    if (rem >= 2u * kJumpSymbols) code_b = win.code8(rem - kJumpSymbols, s_dense);
-    if (has_zero_nibble(code) || e.y != code) return 0u;
-    const bool both = rem >= 2u * kJumpSymbols && !has_zero_nibble(code_b) && e.w == code_b;
-    lo = both ? e.z : e.x;
-    hi = lo + 1u;
-    return both ? 2u * kJumpSymbols : kJumpSymbols;
-}
 
 // Top table (IndexView::top): the interval after the first D = top_depth symbols of the search, i.e. the last D
 // symbols of the query, when all of them are dense codes 1..4.  `a` = code8(rem), `b` = code8(rem - 8) (only its
@@ -486,7 +445,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #pragma unroll
                 for (int k = 0; k < kChunks; k++) b[k] = a[k];
             }
-            if (c2 - 1u < 4u) {  // two LF steps: c1 is consumed first, then c2 (PairTable::lf2)
+            if (c2 - 1u < 4u) {  // two LF steps: c1 is consumed first (it precedes the current suffix), then c2
                 const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
                 const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14) | ((c2 & 1u) << 24);
                 const uint32_t bits_y = ((c2 >> 1) & 1u) | ((c2 & 4u) << 6);
