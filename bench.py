@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true")
+    ap.add_argument("--no-hint", action="store_true", help="locate without the hints of the search (A/B)")
     ap.add_argument("--verify-hits", type=int, default=1_000_000)
     ap.add_argument("--secondary-depth", type=int, default=10,
                     help="N=1 only: after the headline run (reference-default lookup depth), rebuild the index with "
@@ -115,8 +116,8 @@ def main():
     log(f"[bench r{rank}] {nq} queries ({queries.total_bytes / 1e9:.2f} GB) generated in {time.time() - t0:.1f}s")
 
     eng = DeviceEngine(index)
-    out = eng.alloc_outputs(nq)
     do_locate = args.op == "count+locate"
+    out = eng.alloc_outputs(nq, hint=do_locate and not args.no_hint)
 
     # sizing pass (also the first warm-up of the kernels)
     eng.search(queries, out)
@@ -139,7 +140,7 @@ def main():
         max_hits = gdist.max_int_over_ranks(total_hits, dev)
         hits = torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev)
         hits_b = torch.zeros_like(hits)
-        slots = [(out, hits, counts), (eng.alloc_outputs(nq), hits_b, torch.empty_like(counts))]
+        slots = [(out, hits, counts), (eng.alloc_outputs(nq, hint="hint" in out), hits_b, torch.empty_like(counts))]
         gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for (_, h, c) in slots], dst=0)
     step_no = [0]
 

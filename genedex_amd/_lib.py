@@ -91,6 +91,8 @@ SIGNATURES = {
     "gdx_hit_offsets_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_locate_workspace_bytes": [C.c_uint64],
     "gdx_locate_intervals_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_intervals_hint_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_cursors_for_many_queries_hint_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp],
     "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     # gdx_bench.h
     "gdx_index_build_stats": [vp, C.POINTER(BuildStats)],

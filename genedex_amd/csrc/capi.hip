@@ -352,6 +352,24 @@ int gdx_cursors_for_many_queries_dev(const gdx_index_t *ix, const void *d_qbuf, 
     });
 }
 
+int gdx_cursors_for_many_queries_hint_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                          void *d_out_start, void *d_out_end, void *d_out_status, void *d_hint,
+                                          void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        if (!d_hint || (reinterpret_cast<uintptr_t>(d_hint) & 7u) != 0)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_hint must be a non-null 8-byte aligned device pointer");
+        gdx::launch_search(f.view(), static_cast<const uint8_t *>(d_qbuf), static_cast<const uint64_t *>(d_qoff), nq,
+                           static_cast<uint32_t *>(d_out_start), static_cast<uint32_t *>(d_out_end), nullptr,
+                           static_cast<uint8_t *>(d_out_status), as_stream(stream), nullptr,
+                           static_cast<uint2 *>(d_hint));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_count_many_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq, void *d_out_counts,
                        void *d_out_status, void *stream)
 {
@@ -401,6 +419,20 @@ int gdx_locate_intervals_dev(const gdx_index_t *ix, const void *d_start, const v
         gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
                            static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
                            total_hits, d_hits, false, d_workspace, as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
+                                  const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
+                                  const void *d_hint, void *stream)
+{
+    return guarded([&] {
+        gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
+                           static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
+                           total_hits, d_hits, false, d_workspace, as_stream(stream), nullptr,
+                           static_cast<const uint2 *>(d_hint));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

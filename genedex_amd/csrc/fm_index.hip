@@ -1051,7 +1051,8 @@ int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff,
 }
 
 void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
-                            gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc) const
+                            gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
+                            const uint2 *d_hint) const
 {
     hipStream_t stream = hipStreamPerThread;
     DeviceBuffer<uint64_t> d_off(m + 1);
@@ -1073,7 +1074,7 @@ void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint
     }
     DeviceBuffer<gdx_hit_t> d_hits(total);
     DeviceBuffer<uint8_t> ws(locate_workspace_bytes(total));
-    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream);
+    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream, nullptr, d_hint);
     GDX_HIP(hipGetLastError());
     GDX_HIP(hipMemcpyAsync(hits, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
@@ -1093,7 +1094,9 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
     DeviceQueries dq(qbuf, qoff, nq, stream);
     DeviceBuffer<uint32_t> d_start(nq), d_end(nq);
     DeviceBuffer<uint8_t> d_status(nq);
-    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), nullptr, d_status.get(), stream);
+    DeviceBuffer<uint2> d_hint(nq);  // sampled rows the search passed through: no walk for those hits
+    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), nullptr, d_status.get(), stream,
+                  nullptr, d_hint.get());
     GDX_HIP(hipGetLastError());
     std::vector<uint8_t> status(nq);
     GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
@@ -1101,7 +1104,7 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
     if (out_status) std::memcpy(out_status, status.data(), nq);
     int rc = any_status(status.data(), nq);
     int lrc = GDX_OK;
-    locate_device(d_start.get(), d_end.get(), nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc);
+    locate_device(d_start.get(), d_end.get(), nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc, d_hint.get());
     return lrc != GDX_OK ? lrc : rc;
 }
 

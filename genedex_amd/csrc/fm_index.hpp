@@ -78,7 +78,8 @@ private:
     FmIndex() = default;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
-                       gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc) const;
+                       gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
+                       const uint2 *d_hint = nullptr) const;
 
     IndexConfig cfg_;
     BuildStats stats_;

@@ -12,10 +12,11 @@ namespace gdx {
 
 // ---- search.hip ---------------------------------------------------------------------------
 // Backward search of nq queries (lookup jump + LF loop), one lane per query.
-// Any of out_start/out_end/out_count/out_status may be null.
+// Any of out_start/out_end/out_count/out_status may be null.  d_hint (optional, uint2[nq]): locate hints for
+// launch_locate of exactly these intervals ({0xffffffff, 0} = none; see locate_queue_kernel).
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
-                   hipStream_t stream, unsigned long long *d_step_stats = nullptr);
+                   hipStream_t stream, unsigned long long *d_step_stats = nullptr, uint2 *d_hint = nullptr);
 void set_search_variant(int v);  // 0 quad, 1 lane, 2 pair (default), -1 re-read the environment
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
                          uint64_t m, uint8_t *d_out_status, hipStream_t stream);
@@ -37,6 +38,7 @@ size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
-                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr);
+                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
+                   const uint2 *d_hint = nullptr);
 
 }  // namespace gdx

@@ -110,6 +110,103 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
+// The default locate kernel.  A block takes chunks of kLocateChunk consecutive hit slots.  Phase 0, one lane per
+// hit, coalesced: the hits that need no walk are finished at once with their single sample read -- the row is
+// sampled itself, or the search left a hint for this one-row interval (launch_search: a sampled row the query's
+// one-row interval passed through, and how many symbols were still to be consumed there, so that
+// SA[hit row] = SA[hint row] - symbols) -- and the others are queued in LDS.  Phase 1: every lane walks a queued
+// hit and takes the next one from the queue the moment it is done, so the geometric tail of the walk lengths
+// (mean 3 steps at rate 4, maximum over a wavefront ~15) does not idle the other lanes.
+constexpr uint32_t kLocateChunk = 2048;
+
+template <class Table, bool kWide>
+__global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, const uint32_t *__restrict__ start,
+                                                              const uint64_t *__restrict__ hit_offsets,
+                                                              const uint32_t *__restrict__ query_of_hit,
+                                                              const uint2 *__restrict__ hint, uint64_t total,
+                                                              void *__restrict__ hits_out,
+                                                              unsigned long long *__restrict__ step_stats)
+{
+    __shared__ uint32_t s_count[257];
+    __shared__ uint32_t s_row[kLocateChunk];
+    __shared__ uint16_t s_idx[kLocateChunk];
+    __shared__ uint32_t s_n, s_head;
+    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+    uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
+    const uint64_t n_chunks = (total + kLocateChunk - 1) / kLocateChunk;
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t base = chunk * kLocateChunk;
+        const uint32_t cnt = total - base < kLocateChunk ? static_cast<uint32_t>(total - base) : kLocateChunk;
+        __syncthreads();  // the previous chunk's queue is drained, s_count is loaded
+        if (threadIdx.x == 0) {
+            s_n = 0;
+            s_head = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
+            const uint64_t h = base + i;
+            const uint32_t q = query_of_hit[h] - 1u;
+            const uint64_t first = hit_offsets[q];
+            uint32_t row = start[q] + static_cast<uint32_t>(h - first);  // SA index of this hit
+            uint32_t back = 0;                                            // SA[hit row] = SA[row] - back
+            if (hint != nullptr && hit_offsets[q + 1] - first == 1u) {
+                const uint2 hv = hint[q];
+                if (hv.x != 0xffffffffu) {
+                    row = hv.x;
+                    back = hv.y;
+                }
+            }
+            const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
+            if (sampled) {  // sampled_suffix_array.rs:133-136 with zero steps
+                const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
+                store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h);
+            } else {
+                const uint32_t k = atomicAdd(&s_n, 1u);
+                s_row[k] = row;
+                s_idx[k] = static_cast<uint16_t>(i);
+            }
+        }
+        __syncthreads();
+        const uint32_t queued = s_n;
+        bool have = false;
+        uint32_t row = 0, steps = 0, idx = 0;
+        for (;;) {
+            if (!have) {
+                const uint32_t k = atomicAdd(&s_head, 1u);
+                if (k < queued) {
+                    row = s_row[k];
+                    idx = s_idx[k];
+                    steps = 0;
+                    have = true;
+                }
+            }
+            if (!__any(have)) break;
+            if (have) {  // one step of sampled_suffix_array.rs:118-131 (the row is known not to be sampled)
+                uint32_t r;
+                const uint32_t c = Table::symbol_and_rank(ix, row, r);
+                if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
+                    const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, row);
+                    store_hit<kWide>(ix, ix.border_vals[b] + steps, hits_out, base + idx);
+                    walk_steps += steps;
+                    have = false;
+                } else {
+                    row = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
+                    steps++;
+                    const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
+                    if (sampled) {
+                        const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
+                        store_hit<kWide>(ix, ix.sa_samples[slot] + steps, hits_out, base + idx);
+                        walk_steps += steps;
+                        have = false;
+                    }
+                }
+            }
+        }
+    }
+    if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
+}
+
 // The same walk on pair lines, eight lanes per hit: one 128-byte fetch at row i yields bwt1[i], bwt0[i],
 // LF(i) and LF(LF(i)), i.e. TWO walk steps (the second is taken only if the first did not land on a
 // sampled row), so a hit costs ~1.7 line fetches + the sample instead of 3 + the sample at rate 4.
@@ -245,7 +342,7 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
-                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats)
+                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -263,17 +360,30 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
 #define GDX_LOCATE(TABLE, WIDE)                                                                              \
     hipLaunchKernelGGL((locate_kernel<TABLE, WIDE>), dim3(grid), dim3(kBlock), 0, stream, ix, d_start, \
                        d_hit_offsets, heads, total_hits, d_hits, d_step_stats)
-    // The walk is bound by DRAM requests, not by latency: one lane per hit on the 64-byte rank lines keeps 8x
-    // more hits in flight and measures 10.8 ms per 90 M hits against 16.6 ms for the 8-lane pair-line kernel,
-    // although the latter needs ~1.7 instead of 3 line fetches per hit.  GDX_LOCATE_VARIANT=pair selects it.
-    // (Also tried: visiting the hits in suffix-array order after a radix sort of (row, slot) pairs.  The walk
-    // kernel drops only from 10.4 to 9.3 ms -- the sample reads and the now scattered hit stores stay random --
-    // and the sort costs 3 ms: 12.5 ms in total, removed again.)
-    static const bool lane_variant = [] {
+    // GDX_LOCATE_VARIANT: queue (default) = locate_queue_kernel; lane = one lane per hit in lock-step; pair = 8 lanes
+    // per hit on pair lines, two walk steps per fetch.  Measured per 90 M hits at rate 4 (search_variants.md):
+    // lane 10.0 ms, pair 16.6 ms (latency-bound with 8x fewer hits in flight); also tried: visiting the hits in
+    // suffix-array order after a radix sort of (row, slot) pairs, 12.5 ms including the sort.
+    static const int variant = [] {
         const char *e = getenv("GDX_LOCATE_VARIANT");
-        return !(e && e[0] == 'p');
+        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
     }();
-    if (ix.layout == 0 && ix.pair_lines != nullptr && !lane_variant) {
+    if (variant == 0) {
+        const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
+        const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
+                                                 : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
+#define GDX_LOCATE_Q(TABLE, WIDE)                                                                                  \
+    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,      \
+                       d_hit_offsets, heads, d_hint, total_hits, d_hits, d_step_stats)
+        if (ix.layout == 0) {
+            if (wide) GDX_LOCATE_Q(LineTable, true);
+            else GDX_LOCATE_Q(LineTable, false);
+        } else {
+            if (wide) GDX_LOCATE_Q(GenericTable, true);
+            else GDX_LOCATE_Q(GenericTable, false);
+        }
+#undef GDX_LOCATE_Q
+    } else if (ix.layout == 0 && ix.pair_lines != nullptr && variant == 2) {
         uint64_t blocks = (total_hits + 31) / 32;
         if (blocks > 65536) blocks = 65536;
         if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);

@@ -285,7 +285,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
-                                                             uint32_t range, int schedule)
+                                                             uint32_t range, int schedule, uint2 *__restrict__ out_hint)
 {
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -433,6 +433,28 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     const uint32_t done = any16 ? 2u * kJumpSymbols : kJumpSymbols;
                     rem -= done;
                     if (kStats) lf_steps += done;
+                    if (out_hint && hi - lo == 1u) {
+                        // Locate hint: the interval is one row, i.e. one occurrence at text position p, and the
+                        // suffix of row lo starts rem symbols after p (rem are still to be matched to its left), so
+                        // p = SA[lo] - rem; for a 16-step jump the row after 8 steps qualifies too, 8 symbols
+                        // earlier.  If one of them is a sampled row, locate needs no walk for this query.
+                        const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+                        uint32_t hr = 0xffffffffu, ho = 0;
+                        if (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u)) {
+                            hr = lo;
+                            ho = rem;
+                        } else if (any16) {
+                            const uint32_t mid = group_min<kGroup>(mine ? t8 : 0xffffffffu);
+                            if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
+                                hr = mid;
+                                ho = rem + kJumpSymbols;
+                            }
+                        }
+                        if (hr != 0xffffffffu) {
+                            if (writer) out_hint[q] = make_uint2(hr, ho);
+                            status |= 0x80000000u;  // hinted (kept out of the status byte below)
+                        }
+                    }
                 } else {
                     // the interval empties within the next 8 steps: the pair lines find where, which yields the
                     // reference's frozen interval (rare: a read that occurs in the text always matches)
@@ -488,6 +510,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_end) out_end[q] = hi;
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
+            if (out_hint && !(status >> 31)) out_hint[q] = make_uint2(0xffffffffu, 0u);  // no locate hint
         }
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;
@@ -510,8 +533,10 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #define GDX_SEARCH_ARGS                                                                                      \
     IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
         uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
-        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats, uint32_t range, int schedule
-#define GDX_SEARCH_FWD ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule
+        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats, uint32_t range, int schedule, \
+        uint2 *__restrict__ out_hint
+#define GDX_SEARCH_FWD \
+    ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule, out_hint
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
@@ -693,7 +718,7 @@ static int search_variant()
 
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
-                   hipStream_t stream, unsigned long long *d_step_stats)
+                   hipStream_t stream, unsigned long long *d_step_stats, uint2 *d_hint)
 {
     if (nq == 0) return;
     // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
@@ -742,7 +767,7 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         }();
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
-                       d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule)
+                       d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule, d_hint)
 #define GDX_PAIR_LAUNCH_W(KERNEL, P)                      \
     do {                                                  \
         if (wide) GDX_PAIR_LAUNCH((KERNEL<P, true>));     \
@@ -764,14 +789,17 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
 #undef GDX_PAIR_LAUNCH_W
 #undef GDX_PAIR_LAUNCH
     } else if (ix.layout == 0 && search_variant() != 1) {
+        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));  // only the pair kernels hint
         const unsigned blocks = group_grid(kBlock / 4);
         hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(blocks), dim3(kBlock), lds_pad,
                            stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,
                            d_step_stats);
     } else if (ix.layout == 0) {
+        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));
         hipLaunchKernelGGL((search_kernel<LineTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix, d_qbuf,
                            d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
     } else {
+        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));
         hipLaunchKernelGGL((search_kernel<GenericTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix,
                            d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
     }

@@ -99,17 +99,28 @@ class DeviceEngine:
         self.h = index._h
         self.dev = torch.device("cuda", int(index.info.device_id))
 
-    def alloc_outputs(self, nq: int):
+    def alloc_outputs(self, nq: int, hint: bool = False):
+        """hint=True adds the opaque locate-hint array: search() then fills it and locate() uses it (the device form
+        of the fused locate_many; only valid while start / end stay as search() wrote them)."""
         d = self.dev
-        return {
+        out = {
             "start": torch.empty(nq, dtype=torch.int32, device=d),
             "end": torch.empty(nq, dtype=torch.int32, device=d),
             "status": torch.empty(nq, dtype=torch.uint8, device=d),
             "hit_offsets": torch.empty(nq + 1, dtype=torch.int64, device=d),
         }
+        if hint:
+            out["hint"] = torch.empty(nq, dtype=torch.int64, device=d)
+        return out
 
     def search(self, q: DeviceQueries, out) -> None:
         """cursors_for_many_queries: intervals + status (the dominant kernel)."""
+        if "hint" in out:
+            _lib.check(self.lib.gdx_cursors_for_many_queries_hint_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq,
+                                                                      _ptr(out["start"]), _ptr(out["end"]),
+                                                                      _ptr(out["status"]), _ptr(out["hint"]),
+                                                                      _stream()))
+            return
         _lib.check(self.lib.gdx_cursors_for_many_queries_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq,
                                                              _ptr(out["start"]), _ptr(out["end"]),
                                                              _ptr(out["status"]), _stream()))
@@ -127,6 +138,11 @@ class DeviceEngine:
 
     def locate(self, out, m: int, total: int, hits: torch.Tensor, workspace: torch.Tensor) -> None:
         """hits: int32[total, 2] = (text_id, position) per hit, in suffix-array order per query."""
+        if "hint" in out:
+            _lib.check(self.lib.gdx_locate_intervals_hint_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
+                                                              _ptr(out["hit_offsets"]), total, _ptr(hits),
+                                                              _ptr(workspace), _ptr(out["hint"]), _stream()))
+            return
         _lib.check(self.lib.gdx_locate_intervals_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
                                                      _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
                                                      _stream()))

@@ -205,6 +205,19 @@ uint64_t gdx_locate_workspace_bytes(uint64_t total_hits);
 int gdx_locate_intervals_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
                              const void *d_hit_offsets, uint64_t total_hits, void *d_hits /*gdx_hit32_t*/,
                              void *d_workspace, void *stream);
+
+/* The same two calls with a locate hint carried from the search to the locate of the SAME intervals (the device
+ * form of the fused gdx_locate_many): d_hint is an opaque device array of 8 bytes per query (8-byte aligned),
+ * written by gdx_cursors_for_many_queries_hint_dev and read by gdx_locate_intervals_hint_dev.  For a query whose
+ * interval is one row wide it may name a sampled suffix-array row the search passed through and its distance
+ * to the hit, which saves the walk of sampled_suffix_array.rs:118-131; results are identical with or without it.
+ * The hint is only valid together with the d_start / d_end arrays of the call that produced it. */
+int gdx_cursors_for_many_queries_hint_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                          void *d_out_start, void *d_out_end, void *d_out_status, void *d_hint,
+                                          void *stream);
+int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
+                                  const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
+                                  const void *d_hint, void *stream);
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx /*u32*/, uint64_t m,
                       void *d_out /*u32*/, void *stream);
 

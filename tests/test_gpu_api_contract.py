@@ -101,7 +101,9 @@ def test_one_handle_from_many_threads(setup):
     assert not errors, errors[:3]
 
 
-def test_device_resident_entry_points(setup):
+@pytest.mark.parametrize("hint", [False, True])
+def test_device_resident_entry_points(setup, hint):
+    """hint=True: the search hands locate the sampled rows it passed through (gdx_*_hint_dev); same results."""
     torch = pytest.importorskip("torch")
     from genedex_amd.device import DeviceEngine, DeviceQueries
 
@@ -111,7 +113,7 @@ def test_device_resident_entry_points(setup):
     qbuf, qoff = pack_queries(qs)
     dq = DeviceQueries.from_host(qbuf, qoff)
     eng = DeviceEngine(g)
-    out = eng.alloc_outputs(dq.nq)
+    out = eng.alloc_outputs(dq.nq, hint=hint)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):  # a non-default stream: the ABI must enqueue on the stream it is given
         eng.search(dq, out)

@@ -489,12 +489,14 @@ def test_full_size_properties_workload2():
     g = build_index_from_device_text(io_text, [total], a, index_storage="i32")
     q = DeviceQueries.synth(io_text, [total], nq, 50, 50, 900_000)
     eng = DeviceEngine(g)
-    out = eng.alloc_outputs(nq)
+    out = eng.alloc_outputs(nq, hint=True)
     eng.search(q, out)
     eng.hit_offsets(out, nq)
     torch.cuda.synchronize()
     total_hits = int(out["hit_offsets"][nq].item())
     assert int((out["status"] != 0).sum().item()) == 0
+    hinted = int(((out["hint"] & 0xffffffff) != 0xffffffff).sum().item())
+    assert hinted > nq // 3  # most one-occurrence reads pass through a sampled row while they jump
     counts = (out["end"] - out["start"]).to(torch.int64)
     assert int(counts.sum().item()) == total_hits
     found = int((counts > 0).sum().item())
@@ -512,6 +514,12 @@ def test_full_size_properties_workload2():
         col = torch.arange(j, j + 10, device=dev)
         same = io_text[pos[:, None] + col[None, :]] == q.qbuf[(q.qoff[hq])[:, None] + col[None, :]]
         assert bool(same.all())
+    # the walk without the search's hints gives the same hits
+    plain = {k: v for k, v in out.items() if k != "hint"}
+    hits2 = torch.empty_like(hits)
+    eng.locate(plain, nq, total_hits, hits2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(hits, hits2)
     # a prefix against the oracle, on the same index
     m = 200_000
     cpu = OracleIndex.from_bwt(g.export_bwt(), g.export_sa_samples(), 4, *g.export_borders(),
