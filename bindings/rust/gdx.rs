@@ -77,6 +77,21 @@ extern "C" {
         ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64,
         d_out_counts: *mut c_void, d_out_status: *mut c_void, stream: *mut c_void,
     ) -> c_int;
+    // search + locate on device buffers: the search leaves an opaque 8-byte hint per query for the locate of the
+    // same intervals (a sampled suffix-array row the query passed through), which then needs no walk
+    pub fn gdx_cursors_for_many_queries_hint_dev(
+        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, d_out_start: *mut c_void,
+        d_out_end: *mut c_void, d_out_status: *mut c_void, d_hint: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_hit_offsets_dev(
+        ix: *const gdx_index_t, d_start: *const c_void, d_end: *const c_void, m: u64, d_hit_offsets: *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_locate_workspace_bytes(total_hits: u64) -> u64;
+    pub fn gdx_locate_intervals_hint_dev(
+        ix: *const gdx_index_t, d_start: *const c_void, d_end: *const c_void, m: u64, d_hit_offsets: *const c_void,
+        total_hits: u64, d_hits: *mut c_void, d_workspace: *mut c_void, d_hint: *const c_void, stream: *mut c_void,
+    ) -> c_int;
 }
 
 fn check(rc: c_int) {
