@@ -428,18 +428,25 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 if (any8) {
                     const bool mine = any16 ? m16 : m8;
                     const uint32_t target = any16 ? t16 : t8;
+                    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+                    // locate hint, candidate 1: the one-row interval this jump starts from (see below)
+                    uint32_t hr = 0xffffffffu, ho = 0;
+                    const bool want_hint = out_hint != nullptr && !(status >> 31);  // one hint per query is enough
+                    if (want_hint && hi - lo == 1u &&
+                        (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u))) {
+                        hr = lo;
+                        ho = rem;
+                    }
                     lo = group_min<kGroup>(mine ? target : 0xffffffffu);
                     hi = group_max<kGroup>(mine ? target : 0u) + 1u;
                     const uint32_t done = any16 ? 2u * kJumpSymbols : kJumpSymbols;
                     rem -= done;
                     if (kStats) lf_steps += done;
-                    if (out_hint && hi - lo == 1u) {
+                    if (want_hint && hi - lo == 1u && hr == 0xffffffffu) {
                         // Locate hint: the interval is one row, i.e. one occurrence at text position p, and the
                         // suffix of row lo starts rem symbols after p (rem are still to be matched to its left), so
                         // p = SA[lo] - rem; for a 16-step jump the row after 8 steps qualifies too, 8 symbols
                         // earlier.  If one of them is a sampled row, locate needs no walk for this query.
-                        const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
-                        uint32_t hr = 0xffffffffu, ho = 0;
                         if (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u)) {
                             hr = lo;
                             ho = rem;
@@ -450,10 +457,10 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                 ho = rem + kJumpSymbols;
                             }
                         }
-                        if (hr != 0xffffffffu) {
-                            if (writer) out_hint[q] = make_uint2(hr, ho);
-                            status |= 0x80000000u;  // hinted (kept out of the status byte below)
-                        }
+                    }
+                    if (hr != 0xffffffffu) {
+                        if (writer) out_hint[q] = make_uint2(hr, ho);
+                        status |= 0x80000000u;  // hinted (kept out of the status byte below)
                     }
                 } else {
                     // the interval empties within the next 8 steps: the pair lines find where, which yields the
