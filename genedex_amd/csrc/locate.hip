@@ -110,6 +110,24 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
+// first[c] = the query that owns hit slot c * chunk (the largest q with hit_offsets[q] <= c * chunk; empty
+// queries in between share the offset and are skipped by taking the largest).  One lane per chunk.
+__global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(const uint64_t *__restrict__ hit_offsets, uint64_t m,
+                                                                   uint64_t n_chunks, uint32_t chunk,
+                                                                   uint32_t *__restrict__ first)
+{
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t h0 = c * chunk;
+    uint64_t lo = 0, hi = m;  // upper_bound over hit_offsets[0 .. m): first q with hit_offsets[q] > h0
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (hit_offsets[mid] <= h0) lo = mid + 1;
+        else hi = mid;
+    }
+    first[c] = static_cast<uint32_t>(lo - 1);  // hit_offsets[0] = 0 <= h0, so lo >= 1
+}
+
 // The default locate kernel.  A block takes chunks of kLocateChunk consecutive hit slots.  Phase 0, one lane per
 // hit, coalesced: the hits that need no walk are finished at once with their single sample read -- the row is
 // sampled itself, or the search left a hint for this one-row interval (launch_search: a sampled row the query's
@@ -121,8 +139,8 @@ constexpr uint32_t kLocateChunk = 2048;
 
 template <class Table, bool kWide>
 __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, const uint32_t *__restrict__ start,
-                                                              const uint64_t *__restrict__ hit_offsets,
-                                                              const uint32_t *__restrict__ query_of_hit,
+                                                              const uint64_t *__restrict__ hit_offsets, uint64_t m,
+                                                              const uint32_t *__restrict__ first_query,
                                                               const uint2 *__restrict__ hint, uint64_t total,
                                                               void *__restrict__ hits_out,
                                                               unsigned long long *__restrict__ step_stats)
@@ -130,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
     __shared__ uint32_t s_count[257];
     __shared__ uint32_t s_row[kLocateChunk];
     __shared__ uint16_t s_idx[kLocateChunk];
+    __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first
     __shared__ uint32_t s_n, s_head;
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
     const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
@@ -143,10 +162,19 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
             s_n = 0;
             s_head = 0;
         }
+        // hit slot -> query: the chunk's slots belong to the queries qa .. qb (chunk_first_query_kernel); every
+        // query marks its own slots, so no batch-wide pass over the hits is needed for this
+        const uint32_t qa = first_query[chunk];
+        const uint32_t qb = chunk + 1 < n_chunks ? first_query[chunk + 1] : static_cast<uint32_t>(m - 1);
+        for (uint64_t q = static_cast<uint64_t>(qa) + threadIdx.x; q <= qb; q += kBlock) {
+            const uint64_t a = hit_offsets[q], b = hit_offsets[q + 1];
+            const uint64_t from = a > base ? a : base, to = b < base + cnt ? b : base + cnt;
+            for (uint64_t h = from; h < to; h++) s_query[h - base] = static_cast<uint32_t>(q - qa);
+        }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
             const uint64_t h = base + i;
-            const uint32_t q = query_of_hit[h] - 1u;
+            const uint32_t q = qa + s_query[i];
             const uint64_t first = hit_offsets[q];
             uint32_t row = start[q] + static_cast<uint32_t>(h - first);  // SA index of this hit
             uint32_t back = 0;                                            // SA[hit row] = SA[row] - back
@@ -349,11 +377,17 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     void *scan_temp = static_cast<char *>(d_workspace) + align_up(total_hits * sizeof(uint32_t), 256);
     size_t scan_bytes = max_scan_temp_bytes(total_hits);
 
-    GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,
-                       d_hit_offsets, heads);
-    GDX_HIP(rocprim::inclusive_scan(scan_temp, scan_bytes, heads, heads, static_cast<size_t>(total_hits),
-                                    rocprim::maximum<uint32_t>(), stream));
+    static const int variant = [] {
+        const char *e = getenv("GDX_LOCATE_VARIANT");
+        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
+    }();
+    if (variant != 0) {  // the lock-step variants map hit slots to queries with head marks + a max-scan over all hits
+        GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,
+                           d_hit_offsets, heads);
+        GDX_HIP(rocprim::inclusive_scan(scan_temp, scan_bytes, heads, heads, static_cast<size_t>(total_hits),
+                                        rocprim::maximum<uint32_t>(), stream));
+    }
     // GDX_LOCATE_GRID (experiments): absolute number of blocks of the walk kernel
     static const long grid_override = [] { const char *e = getenv("GDX_LOCATE_GRID"); return e ? atol(e) : 0L; }();
     const unsigned grid = grid_override > 0 ? static_cast<unsigned>(grid_override) : grid_for_items(total_hits);
@@ -364,17 +398,16 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     // per hit on pair lines, two walk steps per fetch.  Measured per 90 M hits at rate 4 (search_variants.md):
     // lane 10.0 ms, pair 16.6 ms (latency-bound with 8x fewer hits in flight); also tried: visiting the hits in
     // suffix-array order after a radix sort of (row, slot) pairs, 12.5 ms including the sort.
-    static const int variant = [] {
-        const char *e = getenv("GDX_LOCATE_VARIANT");
-        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
-    }();
     if (variant == 0) {
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
+        uint32_t *first = heads;  // n_chunks entries of the workspace
+        hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, first);
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE)                                                                                  \
     hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,      \
-                       d_hit_offsets, heads, d_hint, total_hits, d_hits, d_step_stats)
+                       d_hit_offsets, m, first, d_hint, total_hits, d_hits, d_step_stats)
         if (ix.layout == 0) {
             if (wide) GDX_LOCATE_Q(LineTable, true);
             else GDX_LOCATE_Q(LineTable, false);
