@@ -290,6 +290,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
     __shared__ uint16_t s_perm[kMaxRange];
+    __shared__ uint2 s_hint[kBlock / kGroup];  // locate hint of the query each group is searching
     __shared__ uint32_t s_cnt[kLenBuckets];
     __shared__ uint32_t s_minmax[2];
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
@@ -459,7 +460,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         }
                     }
                     if (hr != 0xffffffffu) {
-                        if (writer) out_hint[q] = make_uint2(hr, ho);
+                        // parked in LDS until the query's other results are written: a store of its own here made
+                        // the L2 fetch the line for a partial write (+0.5 DRAM reads per query measured)
+                        if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(hr, ho);
                         status |= 0x80000000u;  // hinted (kept out of the status byte below)
                     }
                 } else {
@@ -517,7 +520,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_end) out_end[q] = hi;
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
-            if (out_hint && !(status >> 31)) out_hint[q] = make_uint2(0xffffffffu, 0u);  // no locate hint
+            if (out_hint) out_hint[q] = (status >> 31) ? s_hint[threadIdx.x / kGroup] : make_uint2(0xffffffffu, 0u);
         }
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;

@@ -39,7 +39,7 @@ json.dump({
 }, open(os.path.join(out_dir, "search_pmc_final.json"), "w"), indent=1)
 both = {"search": {"kernel": search_name, "queries_per_launch": nq, "per_launch": search}, "command": cmd}
 if op != "count":
-    locate_name, locate = kernel_counters("locate_kernel")
+    locate_name, locate = kernel_counters("locate_queue_kernel")
     json.dump({"kernel": locate_name, "queries_per_launch": nq, "per_launch": locate, "command": cmd},
               open(os.path.join(out_dir, "locate_pmc_final.json"), "w"), indent=1)
     both["locate"] = {"kernel": locate_name, "per_launch": locate}
