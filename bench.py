@@ -210,7 +210,7 @@ def main():
     if do_locate and total_hits:
         walk_steps = eng.locate_walk_steps(out, nq, total_hits, hits, workspace)
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
-        locate_roofline = {"bound": "hbm", "kernel": "locate_kernel<LineTable> (+ head scan)",
+        locate_roofline = {"bound": "hbm", "kernel": "locate_queue_kernel<LineTable> (+ slot -> query map)",
                            "achieved": locate_bytes / (locate_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": locate_bytes / (locate_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
                            "algorithmic_bytes_per_launch": locate_bytes, "walk_steps_per_launch": walk_steps,

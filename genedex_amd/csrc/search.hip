@@ -314,25 +314,14 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
                                                                  : static_cast<uint32_t>(ix.depth);
         uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
-        uint32_t idx = 0;
-        if (t > 0) {
-            uint32_t factor = 1;
-            bool unsearchable = false;
-            for (uint32_t j = 0; j < t; j++) {
-                const uint32_t d = s_dense[qbuf[end - t + j]];
-                if (d == 0) status = GDX_Q_INVALID_SYMBOL;
-                unsearchable |= (d - 1u >= k);
-                idx += (d - 1u) * factor;
-                factor *= k;
-            }
-            if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
-            if (status != GDX_Q_OK) lo = hi = 0;
-        }
         uint32_t rem = 0;  // symbols still to consume, right to left
         CodeWindow win;
+        // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
+        // top_depth symbols are all in 1..4, hence (with at least four searchable symbols) valid and searchable,
+        // which is everything the reference checks for its t-symbol suffix (lookup_table.rs:99-113); the interval
+        // is the one the configured table plus the LF steps in between would give.
         bool topped = false;
-        if (ix.top != nullptr && status == GDX_Q_OK && ix.top_depth > t && len >= ix.top_depth && len <= 0xffffffffull) {
-            // the top table is deeper than the configured lookup table: it answers for both
+        if (ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull) {
             rem = static_cast<uint32_t>(len);
             win.init(qbuf, begin, rem, s_dense);
             const uint32_t a = win.code8(rem, s_dense);
@@ -344,10 +333,27 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             }
         }
         if (!topped) {
-            if (t > 0 && status == GDX_Q_OK) {
-                const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
-                lo = v.x;
-                hi = v.y;
+            lo = 0;
+            hi = ix.n;
+            if (t > 0) {
+                // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
+                uint32_t idx = 0, factor = 1;
+                bool unsearchable = false;
+                for (uint32_t j = 0; j < t; j++) {
+                    const uint32_t d = s_dense[qbuf[end - t + j]];
+                    if (d == 0) status = GDX_Q_INVALID_SYMBOL;
+                    unsearchable |= (d - 1u >= k);
+                    idx += (d - 1u) * factor;
+                    factor *= k;
+                }
+                if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
+                if (status == GDX_Q_OK) {
+                    const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                    lo = v.x;
+                    hi = v.y;
+                } else {
+                    lo = hi = 0;
+                }
             }
             rem = static_cast<uint32_t>(len - t);
             win.init(qbuf, begin, rem, s_dense);
