@@ -529,7 +529,7 @@ int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         const gdx::IndexView &v = deref(ix).view();
         out[0] = v.pair_lines != nullptr;
-        out[1] = v.jump16 ? 16u : (v.jump ? 8u : 0u);
+        out[1] = v.jump ? v.jump_bytes : 0u;
         out[2] = v.top ? v.top_depth : 0u;
         out[3] = 0;
         return (int)GDX_OK;

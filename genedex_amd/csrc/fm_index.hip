@@ -254,10 +254,14 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
     }
 }
 
-// jump table (search.hip try_jump): jump[i] = {LF^8(i), nibble codes of the 8 symbols preceding suffix SA[i],
-// nibble 7 = text[SA[i]-1] ... nibble 0 = text[SA[i]-8]}, obtained by eight LF steps on the rank lines.  A row
-// whose walk meets a sentinel gets code 0, which no valid query (all nibbles non-zero) can equal.
-__global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2 *__restrict__ jump)
+// Jump table (search.hip, IndexView::jump): entry i has levels j = 1 .. bytes / 8, level j = {row after 8j LF steps
+// from row i, nibble codes of the symbols of steps 8j-7 .. 8j (nibble 7 = the first of them)}.  A walk that meets a
+// sentinel leaves code 0 in that level and all later ones, which no valid query (all nibbles non-zero) can equal.
+// Level 1 comes from eight LF steps on the rank lines; level 2 of entry i is level 1 of the entry of its level-1
+// row; levels 3 and 4 are levels 1 and 2 of the entry of its level-2 row.  Every pass reads only levels that
+// earlier passes completed and writes only later ones, so the passes run in place.
+__global__ __launch_bounds__(kBlock) void derive_jump_level1_kernel(IndexView ix, uint32_t *__restrict__ jump,
+                                                                    uint32_t words)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
@@ -273,47 +277,27 @@ __global__ __launch_bounds__(kBlock) void derive_jump_kernel(IndexView ix, uint2
             code |= c << (4u * (kJumpSymbols - 1u - k));
             row = ix.count[c] + r;
         }
-        jump[p] = ok ? make_uint2(row, code) : make_uint2(0u, 0u);
+        uint32_t *e = jump + p * words;
+        *reinterpret_cast<uint2 *>(e) = ok ? make_uint2(row, code) : make_uint2(0u, 0u);
+        for (uint32_t w = 2; w < words; w++) e[w] = 0u;
     }
 }
 
-// Wide entries {LF^8(i), codes 1-8, LF^16(i), codes 9-16} (search.hip try_jump_wide).  Pass 1 is
-// derive_jump_kernel's walk written into the first half of each entry; pass 2 completes entry i from the first
-// half of entry LF^8(i) (it only reads first halves and only writes second halves, so it runs in place).
-__global__ __launch_bounds__(kBlock) void derive_jump16_first_kernel(IndexView ix, u32x4 *__restrict__ jump16)
-{
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
-        uint32_t row = static_cast<uint32_t>(p), code = 0;
-        bool ok = true;
-        for (uint32_t k = 0; k < kJumpSymbols; k++) {
-            uint32_t r;
-            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
-            if (c == 0) {
-                ok = false;
-                break;
-            }
-            code |= c << (4u * (kJumpSymbols - 1u - k));
-            row = ix.count[c] + r;
-        }
-        u32x4 e = {0u, 0u, 0u, 0u};
-        if (ok) {
-            e.x = row;
-            e.y = code;
-        }
-        jump16[p] = e;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void derive_jump16_second_kernel(uint64_t n, u32x4 *__restrict__ jump16)
+// levels [from, from + count) of entry i := levels [0, count) of the entry of the row in level `from - 1`
+__global__ __launch_bounds__(kBlock) void derive_jump_levels_kernel(uint64_t n, uint32_t *__restrict__ jump, uint32_t words,
+                                                                    uint32_t from, uint32_t count)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
-        const uint2 a = *reinterpret_cast<const uint2 *>(jump16 + p);
-        if (a.y == 0u) continue;  // a sentinel within the first 8 steps: no jump from this row
-        const uint2 b = *reinterpret_cast<const uint2 *>(jump16 + a.x);
-        if (b.y == 0u) continue;
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(jump16 + p) + 2) = b;
+        uint32_t *e = jump + p * words;
+        const uint2 last = *reinterpret_cast<const uint2 *>(e + 2u * (from - 1u));
+        if (last.y == 0u) continue;  // a sentinel on the way: the later levels stay invalid
+        const uint32_t *src = jump + static_cast<uint64_t>(last.x) * words;
+        for (uint32_t j = 0; j < count; j++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src + 2u * j);
+            if (v.y == 0u) break;
+            *reinterpret_cast<uint2 *>(e + 2u * (from + j)) = v;
+        }
     }
 }
 
@@ -614,7 +598,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return top_.bytes() + jump_.bytes() + jump16_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return top_.bytes() + jump_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -757,24 +741,27 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         GDX_HIP(hipStreamSynchronize(stream));
         GDX_HIP(hipGetLastError());
         view_.pair_lines = pair_lines_.get();
-        const char *no_jump = getenv("GDX_NO_JUMP_TABLE");
-        const char *wide_jump = getenv("GDX_JUMP_WIDE");
-        if (no_jump && no_jump[0] == '1') {
-        } else if (!(wide_jump && wide_jump[0] == '0')) {  // default; GDX_JUMP_WIDE=0 builds the 8-byte entries
-            jump16_.alloc(n_);
-            hipLaunchKernelGGL(derive_jump16_first_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_,
-                               jump16_.get());
-            hipLaunchKernelGGL(derive_jump16_second_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, n_,
-                               jump16_.get());
-            GDX_HIP(hipStreamSynchronize(stream));
-            GDX_HIP(hipGetLastError());
-            view_.jump16 = jump16_.get();
-        } else {
-            jump_.alloc(n_);
-            hipLaunchKernelGGL(derive_jump_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, jump_.get());
+        // jump table: 32-byte entries by default; GDX_JUMP_BYTES=8|16|32|0 or GDX_NO_JUMP_TABLE=1 (= 0) override
+        uint32_t jump_bytes = 32;
+        if (const char *e = getenv("GDX_JUMP_BYTES")) jump_bytes = static_cast<uint32_t>(atoi(e));
+        if (const char *e = getenv("GDX_NO_JUMP_TABLE")) jump_bytes = e[0] == '1' ? 0u : jump_bytes;
+        if (jump_bytes != 0 && jump_bytes != 8 && jump_bytes != 16 && jump_bytes != 32)
+            fail(GDX_ERR_INVALID_ARGUMENT, "GDX_JUMP_BYTES must be 0, 8, 16 or 32");
+        if (jump_bytes != 0) {
+            const uint32_t words = jump_bytes / 4;
+            jump_.alloc(static_cast<uint64_t>(n_) * words);
+            const unsigned grid = grid_for_items(n_);
+            hipLaunchKernelGGL(derive_jump_level1_kernel, dim3(grid), dim3(kBlock), 0, stream, view_, jump_.get(), words);
+            if (jump_bytes >= 16)
+                hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
+                                   1u, 1u);
+            if (jump_bytes == 32)
+                hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
+                                   2u, 2u);
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             view_.jump = jump_.get();
+            view_.jump_bytes = jump_bytes;
         }
         // top table: the first symbols of a DNA query in one fetch.  Depth: even (the pair steps that follow consume
         // two symbols each), at least 4 rows per entry on average, at most 14 (2 GB); GDX_TOP_DEPTH=0..16 overrides.

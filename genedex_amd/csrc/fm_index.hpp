@@ -92,8 +92,7 @@ private:
     DeviceBuffer<u32x4> lines_;
     DeviceBuffer<uint32_t> sb_offsets_;
     DeviceBuffer<u32x4> pair_lines_;
-    DeviceBuffer<uint2> jump_;
-    DeviceBuffer<u32x4> jump16_;
+    DeviceBuffer<uint32_t> jump_;
     DeviceBuffer<uint2> top_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;

@@ -40,9 +40,10 @@ struct IndexView {
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
-    // --- jump table: kJumpSymbols LF steps of a one-row interval per fetch ----------------------
-    const uint2 *jump;            // [n] {LF^8(i), 8 preceding symbols as nibble codes}, null when absent
-    const u32x4 *jump16;          // [n] {LF^8(i), codes 1-8, LF^16(i), codes 9-16}: replaces `jump` when present
+    // --- jump table: 8 / 16 / 32 LF steps of a narrow interval per fetch -------------------------------
+    const void *jump;             // [n] entries of jump_bytes: level j = {row after 8j LF steps, nibble codes of the
+                                  // symbols those 8 steps need}, j = 1 .. jump_bytes / 8; null when absent
+    uint32_t jump_bytes;          // 0, 8, 16 or 32
     // --- top table: interval after the first top_depth symbols of a DNA query, one cache-resident fetch ----
     const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); empty
                                   // entries (x == y) send the query down the ordinary path; null when absent

@@ -98,6 +98,14 @@ struct CodeWindow {
         const uint32_t s = (b & 7u) + 1u;  // nibbles taken from `cur`
         return s == 8u ? cur : __builtin_amdgcn_alignbit(cur, next, 4u * s);
     }
+    // the same codes for any r <= rem (r >= 8) read straight from the query bytes; the window does not move
+    __device__ __forceinline__ uint32_t peek8(uint32_t r, const uint8_t *s_dense) const
+    {
+        const uint32_t p = off0 + r - 8u, w = p >> 3, sh = (p & 7u) * 8u;
+        uint64_t v = base[w];
+        if (sh) v = (v >> sh) | (base[w + 1u] << (64u - sh));
+        return translate(v, s_dense);
+    }
 };
 
 __device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x11111111u) & ~x & 0x88888888u) != 0u; }
@@ -277,7 +285,7 @@ __device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict
 // symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
 // which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
 // one-step rank lines, so the result is identical to search_kernel's.
-template <int kPolicy, int kGroup, bool kStats, bool kWide>
+template <int kPolicy, int kGroup, bool kStats, int kJump>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qoff, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
@@ -358,7 +366,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             rem = static_cast<uint32_t>(len - t);
             win.init(qbuf, begin, rem, s_dense);
         }
-        bool jump_ok = kWide ? ix.jump16 != nullptr : ix.jump != nullptr;
+        bool jump_ok = ix.jump != nullptr && ix.jump_bytes == static_cast<uint32_t>(kJump);
         uint32_t iters = 0;  // fetch rounds of this query (divergence accounting, kStats only)
         // Every iteration is one round of loads for the whole wavefront, whatever its queries are doing: a group
         // either reads its jump entry or the pair line(s) of its interval borders, all loads are issued, then
@@ -391,26 +399,32 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             // and LF keeps their order, so they map onto [min target, max target + 1).
             const bool jumping = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols &&
                                  !has_zero_nibble(code);
-            // wide entries: the codes of the 8 symbols after `code`; taking them moves the window one word
-            // down, which is where it has to be after a successful jump (a mismatch re-initialises it)
-            uint32_t code_b = 0;
-            if (kWide && jumping && rem >= 2u * kJumpSymbols) code_b = win.code8(rem - kJumpSymbols, s_dense);
+            // entries of 16 / 32 bytes: the codes of the next 8-symbol groups after `code`, read straight from the
+            // query (the window stays; it is re-initialised after a jump of more than 8 symbols)
+            constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : (kChunks >= 2 ? 4 : 2));
+            uint32_t codes[4] = {code, 0u, 0u, 0u};
+            if (jumping) {
+#pragma unroll
+                for (int j = 1; j < kLevels; j++)
+                    if (rem >= (j + 1u) * kJumpSymbols) codes[j] = win.peek8(rem - j * kJumpSymbols, s_dense);
+            }
             const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
             const bool second = !jumping && line_hi != line_lo;
             const u32x4 *pa = ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub;
             const u32x4 *pb = ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub;
+            const u32x4 *pa1 = pa + kGroup;  // second chunk of the line (4 lanes per query)
             const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
             if (jumping) {
-                pa = kWide ? ix.jump16 + row
-                           : reinterpret_cast<const u32x4 *>(ix.jump + (row & ~1u));  // the aligned pair of entries
+                const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
+                if (kJump == 8) pa = tab + (row >> 1);  // the aligned pair of 8-byte entries
+                else pa = tab + static_cast<uint64_t>(row) * (kJump / 16);
+                pa1 = pa + 1;  // second half of a 32-byte entry
             }
-            const unsigned long long m_pair = __ballot(!jumping), m_second = __ballot(second);
+            const bool need_a1 = !jumping || kLevels == 4;
+            const unsigned long long m_a1 = __ballot(need_a1), m_second = __ballot(second);
             u32x4 a[kChunks], b[kChunks];
             issue_chunk_load<kPolicy>(pa, a[0]);
-#pragma unroll
-            for (int k = 1; k < kChunks; k++) {
-                issue_chunk_load_masked<kPolicy>(pa + k * kGroup, a[k], m_pair);
-            }
+            if (kChunks == 2) issue_chunk_load_masked<kPolicy>(pa1, a[kChunks - 1], m_a1);
 #pragma unroll
             for (int k = 0; k < kChunks; k++) {
                 issue_chunk_load_masked<kPolicy>(pb + k * kGroup, b[k], m_second);
@@ -418,23 +432,33 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (kChunks == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[kChunks - 1]), "+v"(b[kChunks - 1])::"memory");
             if (jumping) {
-                uint32_t t8, ca, t16 = 0, cb = 0;
-                if (kWide) {
-                    t8 = a[0].x;
-                    ca = a[0].y;
-                    t16 = a[0].z;
-                    cb = a[0].w;
+                // level j (1-based) of an entry: {row after 8j steps, codes of steps 8j-7 .. 8j}
+                uint32_t tgt[4] = {0u, 0u, 0u, 0u}, cod[4] = {0u, 0u, 0u, 0u};
+                if (kJump == 8) {
+                    tgt[0] = (row & 1u) ? a[0].z : a[0].x;
+                    cod[0] = (row & 1u) ? a[0].w : a[0].y;
                 } else {
-                    t8 = (row & 1u) ? a[0].z : a[0].x;
-                    ca = (row & 1u) ? a[0].w : a[0].y;
+                    tgt[0] = a[0].x;
+                    cod[0] = a[0].y;
+                    tgt[1] = a[0].z;
+                    cod[1] = a[0].w;
+                    if (kLevels == 4) {
+                        tgt[2] = a[kChunks - 1].x;
+                        cod[2] = a[kChunks - 1].y;
+                        tgt[3] = a[kChunks - 1].z;
+                        cod[3] = a[kChunks - 1].w;
+                    }
                 }
-                const bool m8 = ca == code;
-                const bool m16 = kWide && m8 && rem >= 2u * kJumpSymbols && cb == code_b && !has_zero_nibble(code_b);
-                const bool any16 = kWide && group_max<kGroup>(m16 ? 1u : 0u) != 0u;
-                const bool any8 = any16 || group_max<kGroup>(m8 ? 1u : 0u) != 0u;
-                if (any8) {
-                    const bool mine = any16 ? m16 : m8;
-                    const uint32_t target = any16 ? t16 : t8;
+                // how many levels this lane's row matches; a level needs all the levels before it
+                uint32_t lvl = cod[0] == code ? 1u : 0u;
+#pragma unroll
+                for (int j = 1; j < kLevels; j++)
+                    if (lvl == static_cast<uint32_t>(j) && rem >= (j + 1u) * kJumpSymbols && cod[j] == codes[j] &&
+                        !has_zero_nibble(codes[j]))
+                        lvl = j + 1u;
+                const uint32_t best = group_max<kGroup>(lvl);
+                if (best != 0u) {
+                    const bool mine = lvl == best;
                     const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
                     // locate hint, candidate 1: the one-row interval this jump starts from (see below)
                     uint32_t hr = 0xffffffffu, ho = 0;
@@ -444,24 +468,29 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         hr = lo;
                         ho = rem;
                     }
+                    const uint32_t target = best == 4u ? tgt[3] : (best == 3u ? tgt[2] : (best == 2u ? tgt[1] : tgt[0]));
                     lo = group_min<kGroup>(mine ? target : 0xffffffffu);
                     hi = group_max<kGroup>(mine ? target : 0u) + 1u;
-                    const uint32_t done = any16 ? 2u * kJumpSymbols : kJumpSymbols;
+                    const uint32_t done = best * kJumpSymbols;
                     rem -= done;
                     if (kStats) lf_steps += done;
                     if (want_hint && hi - lo == 1u && hr == 0xffffffffu) {
                         // Locate hint: the interval is one row, i.e. one occurrence at text position p, and the
                         // suffix of row lo starts rem symbols after p (rem are still to be matched to its left), so
-                        // p = SA[lo] - rem; for a 16-step jump the row after 8 steps qualifies too, 8 symbols
-                        // earlier.  If one of them is a sampled row, locate needs no walk for this query.
+                        // p = SA[lo] - rem; the rows this jump passed through after 8, 16, 24 steps qualify too,
+                        // that many symbols earlier.  If one of them is a sampled row, locate needs no walk.
                         if (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u)) {
                             hr = lo;
                             ho = rem;
-                        } else if (any16) {
-                            const uint32_t mid = group_min<kGroup>(mine ? t8 : 0xffffffffu);
-                            if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
-                                hr = mid;
-                                ho = rem + kJumpSymbols;
+                        }
+#pragma unroll
+                        for (int j = kLevels - 1; j >= 1; j--) {
+                            if (hr == 0xffffffffu && best > static_cast<uint32_t>(j)) {
+                                const uint32_t mid = group_min<kGroup>(mine ? tgt[j - 1] : 0xffffffffu);
+                                if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
+                                    hr = mid;
+                                    ho = rem + (best - j) * kJumpSymbols;
+                                }
                             }
                         }
                     }
@@ -471,11 +500,11 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(hr, ho);
                         status |= 0x80000000u;  // hinted (kept out of the status byte below)
                     }
+                    if (done > kJumpSymbols) win.init(qbuf, begin, rem, s_dense);
                 } else {
                     // the interval empties within the next 8 steps: the pair lines find where, which yields the
                     // reference's frozen interval (rare: a read that occurs in the text always matches)
                     jump_ok = false;
-                    if (kWide) win.init(qbuf, begin, rem, s_dense);
                 }
                 continue;
             }
@@ -558,27 +587,27 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
 // The 4-lane kernel holds two chunks per lane and line; with the 32-bit nibble windows (CodeWindow) it also fits
 // 64 VGPRs / 78 SGPRs without spills: 8 x 16 = 128 queries per SIMD in flight instead of 8 x 8 = 64.
-template <int kPolicy, bool kWide>
+template <int kPolicy, int kJump>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, false, kWide>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, false, kJump>(GDX_SEARCH_FWD);
 }
-template <int kPolicy, bool kWide>
+template <int kPolicy, int kJump>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, false, kWide>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, false, kJump>(GDX_SEARCH_FWD);
 }
 // accounting variants (gdx_search_step_stats_dev): the counters cost registers, so they are kept out of the
 // timed kernels
-template <int kPolicy, bool kWide>
+template <int kPolicy, int kJump>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, true, kWide>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, true, kJump>(GDX_SEARCH_FWD);
 }
-template <int kPolicy, bool kWide>
+template <int kPolicy, int kJump>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, true, kWide>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, true, kJump>(GDX_SEARCH_FWD);
 }
 
 // Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
@@ -784,12 +813,12 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
                        d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule, d_hint)
-#define GDX_PAIR_LAUNCH_W(KERNEL, P)                      \
-    do {                                                  \
-        if (wide) GDX_PAIR_LAUNCH((KERNEL<P, true>));     \
-        else GDX_PAIR_LAUNCH((KERNEL<P, false>));         \
+#define GDX_PAIR_LAUNCH_W(KERNEL, P)                                \
+    do {                                                            \
+        if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32>));  \
+        else if (ix.jump_bytes == 16) GDX_PAIR_LAUNCH((KERNEL<P, 16>)); \
+        else GDX_PAIR_LAUNCH((KERNEL<P, 8>));                       \
     } while (0)
-        const bool wide = ix.jump16 != nullptr;
         if (d_step_stats != nullptr) {
             if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 1);
             else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 1);

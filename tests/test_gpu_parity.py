@@ -192,9 +192,10 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
 
 
 _VARIANT_ENV = {
-    # name: (kernel variant, GDX_JUMP_WIDE, GDX_TOP_DEPTH)
-    "pair": (2, None, None),            # defaults: 16-byte jump entries, top table sized from the text
-    "pair-narrow": (2, "0", "0"),       # 8-byte jump entries, no top table
+    # name: (kernel variant, GDX_JUMP_BYTES, GDX_TOP_DEPTH)
+    "pair": (2, None, None),            # defaults: 32-byte jump entries, top table sized from the text
+    "pair-jump16": (2, "16", None),     # 16-byte jump entries
+    "pair-narrow": (2, "8", "0"),       # 8-byte jump entries, no top table
     "pair-top4": (2, None, "4"),        # forced top depths: on these small texts most deep entries are empty,
     "pair-top9": (2, None, "9"),        # so the fall-back to the ordinary path runs constantly
     "quad": (0, None, None),
@@ -212,8 +213,8 @@ def search_variant(request):
     lib = _lib.load()
     variant, wide, top = _VARIANT_ENV[request.param]
     lib.gdx_debug_set_search_variant(variant)
-    saved = {k: os.environ.get(k) for k in ("GDX_JUMP_WIDE", "GDX_TOP_DEPTH")}
-    for k, v in (("GDX_JUMP_WIDE", wide), ("GDX_TOP_DEPTH", top)):
+    saved = {k: os.environ.get(k) for k in ("GDX_JUMP_BYTES", "GDX_TOP_DEPTH")}
+    for k, v in (("GDX_JUMP_BYTES", wide), ("GDX_TOP_DEPTH", top)):
         if v is None:
             os.environ.pop(k, None)
         else:
