@@ -196,8 +196,8 @@ def main():
     uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
     lanes = os.environ.get("GDX_SEARCH_LANES", "4")
     aux = eng.aux_info()
-    policy = os.environ.get("GDX_LOAD_POLICY", "1")
-    kernel_name = {"pair": f"search_pair_kernel{lanes}<{policy}, {'true' if aux['jump_entry_bytes'] == 16 else 'false'}>",
+    policy = os.environ.get("GDX_LOAD_POLICY", "0")
+    kernel_name = {"pair": f"search_pair_kernel{lanes}<{policy}, {aux['jump_entry_bytes'] or 8}>",
                    "quad": "search_kernel<QuadLineTable,4>", "lane": "search_kernel<LineTable,1>"}[variant]
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,

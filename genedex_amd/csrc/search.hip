@@ -798,11 +798,13 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         const uint64_t n_ranges = (nq + range - 1) / range;
         const unsigned blocks = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                   : static_cast<unsigned>(n_ranges < (1u << 20) ? n_ranges : (1u << 20));
-        // pair lines are fetched with sc1 (served by L2, no allocation in the CU's L1): +5 % measured;
-        // GDX_LOAD_POLICY=0|1|2|3 overrides (plain, sc1, nt, sc0 sc1)
+        // Cache policy of the line / entry loads: plain by default.  sc1 (no allocation in the CU's L1) was worth
+        // +5 % while the first levels of the search were cache-resident pair lines; with the top table every load
+        // is a DRAM miss and plain loads measure 3 % faster.  GDX_LOAD_POLICY=0|1|2|3 = plain, sc1, nt, sc0 sc1
+        // (2 and 3 only exist for 8 lanes per query).
         static const int policy = [] {
             const char *e = getenv("GDX_LOAD_POLICY");
-            return e ? atoi(e) : 1;
+            return e ? atoi(e) : 0;
         }();
         // Ranges whose query lengths are spread out are searched in length order (order_range_by_length);
         // GDX_SEARCH_SCHEDULE=0 keeps the query order.
@@ -820,8 +822,8 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         else GDX_PAIR_LAUNCH((KERNEL<P, 8>));                       \
     } while (0)
         if (d_step_stats != nullptr) {
-            if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 1);
-            else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 1);
+            if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 0);
+            else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0);
         } else if (lanes == 8) {
             if (policy == 1) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 1);
             else if (policy == 2) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 2);
