@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the CPU oracle, wider than the pytest suite.
+
+Every round draws a configuration (alphabet, number and size of texts, repeat structure, sampling rate, lookup
+depth, jump entry size, forced top-table depth, lanes per query, index storage), builds the index with both
+implementations and compares intervals, statuses, hits (host API = fused search + hinted locate; device API with and
+without hints) bit for bit.  Test infrastructure: it uses oracle/ as the checker.
+
+usage: python tools/parity_sweep.py [rounds, default 60] [seed, default 1]  -> one JSON line
+Kernel variants chosen by environment variables read once per process (lanes) are swept by running the tool in
+several processes: GDX_SEARCH_LANES=8 python tools/parity_sweep.py ...
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from genedex_amd import FmIndexConfig, alphabet  # noqa: E402
+from genedex_amd.device import DeviceEngine, DeviceQueries  # noqa: E402
+from oracle.oracle import OracleIndex, pack_queries  # noqa: E402
+
+
+def draw_texts(rng, symbols, total, n_texts, mode):
+    cuts = np.sort(rng.integers(0, total + 1, n_texts - 1)) if n_texts > 1 else np.array([], dtype=np.int64)
+    lens = np.diff(np.concatenate([[0], cuts, [total]]))
+    texts = []
+    for ln in lens:
+        ln = int(ln)
+        if mode == "random":
+            t = bytes(symbols[i] for i in rng.integers(0, len(symbols), ln))
+        elif mode == "repeats":  # a short unit repeated with a few substitutions
+            unit = bytes(symbols[i] for i in rng.integers(0, len(symbols), int(rng.integers(1, 200))))
+            t = bytearray((unit * (ln // len(unit) + 1))[:ln])
+            for pos in rng.integers(0, max(ln, 1), ln // 300):
+                t[pos] = symbols[int(rng.integers(0, len(symbols)))]
+            t = bytes(t)
+        else:  # "runs": long runs of single symbols
+            t = bytearray()
+            while len(t) < ln:
+                t += bytes([symbols[int(rng.integers(0, len(symbols)))]]) * int(rng.integers(1, 400))
+            t = bytes(t[:ln])
+        texts.append(t)
+    return texts
+
+
+def draw_queries(rng, texts, symbols, n, max_len):
+    qs = []
+    nonempty = [t for t in texts if t]
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.7 and nonempty:
+            t = nonempty[int(rng.integers(0, len(nonempty)))]
+            pos = int(rng.integers(0, len(t)))
+            q = bytearray(t[pos:pos + int(rng.integers(0, max_len + 1))])
+            if q and rng.random() < 0.15:  # one substitution somewhere
+                q[int(rng.integers(0, len(q)))] = symbols[int(rng.integers(0, len(symbols)))]
+            qs.append(bytes(q))
+        else:
+            qs.append(bytes(symbols[i] for i in rng.integers(0, len(symbols), int(rng.integers(0, max_len + 1)))))
+    return qs
+
+
+ALPHABETS = [
+    ("ascii_dna", alphabet.ascii_dna, b"ACGT"),
+    ("ascii_dna_with_n", alphabet.ascii_dna_with_n, b"ACGTACGTACGTACGTN"),
+    ("ascii_dna_iupac_as_dna_with_n", alphabet.ascii_dna_iupac_as_dna_with_n, b"ACGTACGTACGTRYN"),
+    ("ascii_dna_iupac", alphabet.ascii_dna_iupac, b"ACGTNRYKMSWBDHV"),
+    ("ascii_amino_acid", alphabet.ascii_amino_acid, b"ACDEFGHIKLMNPQRSTVWY"),
+]
+
+
+def one_round(rng, stats):
+    name, make, symbols = ALPHABETS[int(rng.choice(len(ALPHABETS), p=[0.2, 0.45, 0.15, 0.1, 0.1]))]
+    a = make()
+    total = int(rng.choice([300, 5_000, 60_000, 400_000, 2_000_000], p=[0.15, 0.25, 0.3, 0.2, 0.1]))
+    n_texts = int(rng.choice([1, 2, 7, 60, 800], p=[0.3, 0.2, 0.2, 0.2, 0.1]))
+    mode = str(rng.choice(["random", "repeats", "runs"], p=[0.6, 0.25, 0.15]))
+    rate = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 33]))
+    k = a.num_searchable_dense_symbols()
+    depth = int(rng.integers(0, 6 if k <= 4 else 3))
+    env = {"GDX_JUMP_BYTES": str(rng.choice(["32", "32", "16", "8", "0"])),
+           "GDX_TOP_DEPTH": str(rng.choice(["", "", "0", "3", "6", "8", "10"])),
+           "GDX_NO_PAIR_LINES": str(rng.choice(["", "", "", "1"]))}
+    storage = str(rng.choice(["i32", "u32"]))
+    cfg = {"alphabet": name, "total": total, "n_texts": n_texts, "mode": mode, "sa_rate": rate, "depth": depth,
+           "storage": storage, **env}
+    saved = {key: os.environ.get(key) for key in env}
+    for key, v in env.items():
+        if v:
+            os.environ[key] = v
+        else:
+            os.environ.pop(key, None)
+    try:
+        texts = draw_texts(rng, symbols, total, n_texts, mode)
+        g = FmIndexConfig(storage).suffix_array_sampling_rate(rate).lookup_table_depth(depth).construct_index(texts, a)
+    finally:
+        for key, v in saved.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
+    c = OracleIndex.build(texts, a.io_to_dense_table, a.num_dense_symbols(), k, sa_rate=rate, lookup_depth=depth,
+                          width=-32 if storage == "i32" else 32)
+    qs = draw_queries(rng, texts, symbols, int(rng.integers(200, 3000)), int(rng.choice([8, 40, 70, 150, 400])))
+    qbuf, qoff = pack_queries(qs)
+    s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    assert st.tolist() == cst.tolist(), ("status", cfg)
+    ok = st == 0
+    assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist(), ("intervals", cfg)
+    small = ok & ((ce - cs) < 5000)
+    ls, le = np.where(small, cs, 0), np.where(small, ce, 0)
+    co, ct, cp = c.locate_intervals(ls, le)
+    off, t, p = g.locate_intervals_raw(ls, le)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist(), ("locate", cfg)
+    # device path: search with hints -> offsets -> hinted locate; and the same intervals without hints
+    keep = np.nonzero(small)[0]
+    sub = [qs[i] for i in keep]
+    if sub:
+        qb2, qo2 = pack_queries(sub)
+        dq = DeviceQueries.from_host(qb2, qo2)
+        eng = DeviceEngine(g)
+        for hint in (True, False):
+            out = eng.alloc_outputs(dq.nq, hint=hint)
+            eng.search(dq, out)
+            eng.hit_offsets(out, dq.nq)
+            torch.cuda.synchronize()
+            tot = int(out["hit_offsets"][dq.nq].item())
+            hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
+            ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+            if tot:
+                eng.locate(out, dq.nq, tot, hits, ws)
+            torch.cuda.synchronize()
+            assert out["start"].cpu().numpy().astype(np.uint32).tolist() == cs[keep].astype(np.uint32).tolist(), ("dev start", cfg)
+            assert out["end"].cpu().numpy().astype(np.uint32).tolist() == ce[keep].astype(np.uint32).tolist(), ("dev end", cfg)
+            h = hits[:tot].cpu().numpy().astype(np.uint32)
+            assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), \
+                ("dev hits", hint, cfg)
+            if hint:
+                stats["hinted_queries"] += int(((out["hint"] & 0xffffffff) != 0xffffffff).sum().item())
+    stats["queries"] += len(qs)
+    stats["hits"] += int(co[-1])
+    stats["status_nonzero"] += int((st != 0).sum())
+    return cfg
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    stats = {"queries": 0, "hits": 0, "status_nonzero": 0, "hinted_queries": 0}
+    t0 = time.time()
+    seen = {}
+    for _ in range(rounds):
+        cfg = one_round(rng, stats)
+        for key in ("alphabet", "mode", "GDX_JUMP_BYTES", "GDX_TOP_DEPTH", "GDX_NO_PAIR_LINES", "sa_rate", "depth"):
+            seen.setdefault(key, {}).setdefault(str(cfg[key]), 0)
+            seen[key][str(cfg[key])] += 1
+    print(json.dumps({"rounds": rounds, "seed": seed, "lanes": os.environ.get("GDX_SEARCH_LANES", "4"), "all_equal": True,
+                      "seconds": round(time.time() - t0, 1), **stats, "configurations_seen": seen}))
+
+
+if __name__ == "__main__":
+    main()
