@@ -6,16 +6,16 @@ depth, jump entry size, forced top-table depth, lanes per query, index storage),
 implementations and compares intervals, statuses, hits (host API = fused search + hinted locate; device API with and
 without hints) bit for bit.  Test infrastructure: it uses oracle/ as the checker.
 
-usage: python tools/parity_sweep.py [rounds, default 60] [seed, default 1]  -> one JSON line
+usage: python tests/parity_sweep.py [rounds, default 60] [seed, default 1]  -> one JSON line
 Kernel variants chosen by environment variables read once per process (lanes) are swept by running the tool in
-several processes: GDX_SEARCH_LANES=8 python tools/parity_sweep.py ...
+several processes: GDX_SEARCH_LANES=8 python tests/parity_sweep.py ...
 """
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
