@@ -203,6 +203,11 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": search_bytes, "lf_steps_per_launch": lf_steps,
                 "avg_launch_ms": search_ms,
+                "note": "achieved = algorithmic bytes of the reference's algorithm (60 B per LF step it would execute, "
+                        "BASELINE.md section 4) / kernel time; frac > 1 means the jump / top tables deliver those LF "
+                        "steps with fewer bytes than the reference layout needs, not that HBM exceeds its peak: see "
+                        "traffic (measured DRAM bytes per launch) and random_request_model for the bound of the kernel "
+                        "as built",
                 "line_fetches_per_query": fetches / nq if fetches else None,
                 "active_lane_fraction": fetches / fetch_slots if fetch_slots else None}
     roofline.update(pmc_traffic(kernel_name, args, wl, nq))
