@@ -1,7 +1,11 @@
-// search.hip -- backward search (lookup jump + LF loop), cursor extension and the operator-level
-// rank / symbol_at kernels.  One lane per query: a wavefront advances 64 backward searches in
-// lock-step, the same shape as the reference's 64-wide BatchComputedCursors
-// (batch_computed_cursors.rs:36-73) with the swap-compaction replaced by the exec mask.
+// search.hip -- backward search, cursor extension and the operator-level rank / symbol_at kernels.
+//
+// search_pair_kernel4/8 (the default on DNA-sized alphabets): 4 or 8 lanes per query, 16 or 8 queries per
+// wavefront advancing in lock-step -- the shape of the reference's 64-wide BatchComputedCursors
+// (batch_computed_cursors.rs:36-73) with the swap-compaction replaced by the exec mask -- over the pair lines, the
+// jump table and the top table.  search_kernel<Table, lanes>: the same search one LF step at
+// a time on the rank lines (1 or 4 lanes per query) or on the generic planes of wide alphabets; also the readable
+// statement of what the pair kernels compute.
 #include <atomic>
 #include <cstdlib>
 #include <string>

@@ -56,7 +56,7 @@ int gdx_bench_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_b
                             uint64_t seed, uint32_t mode, void *d_sink, void *stream);
 
 /* d_steps (u64[3], pre-zeroed by the caller): [0] += LF steps the search of these queries executes (the
- * reference's count: a pair step is 2, a jump is 8); on pair lines also [1] += line fetches summed over the
+ * reference's count: a pair step is 2, a jump is 8 to 32, the top table its depth); on pair lines also [1] += line fetches summed over the
  * queries and [2] += the fetch slots their wavefronts spent on them (lanes of a finished query idle until the
  * longest query of the wave ends), so [1] / [2] is the active-lane fraction of the search. */
 int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
