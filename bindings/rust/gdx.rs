@@ -9,6 +9,10 @@ use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
+pub struct gdx_fastx_t {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct gdx_index_t {
     _private: [u8; 0],
 }
@@ -88,6 +92,12 @@ extern "C" {
         stream: *mut c_void,
     ) -> c_int;
     pub fn gdx_locate_workspace_bytes(total_hits: u64) -> u64;
+    // FASTA / FASTQ ingestion into (qbuf, qoff) batches (host only)
+    pub fn gdx_fastx_open(path: *const c_char, out: *mut *mut gdx_fastx_t) -> c_int;
+    pub fn gdx_fastx_next_batch(
+        reader: *mut gdx_fastx_t, qbuf: *mut u8, qbuf_capacity: u64, qoff: *mut u64, max_records: u64, n_out: *mut u64,
+    ) -> c_int;
+    pub fn gdx_fastx_close(reader: *mut gdx_fastx_t);
     pub fn gdx_locate_intervals_hint_dev(
         ix: *const gdx_index_t, d_start: *const c_void, d_end: *const c_void, m: u64, d_hit_offsets: *const c_void,
         total_hits: u64, d_hits: *mut c_void, d_workspace: *mut c_void, d_hint: *const c_void, stream: *mut c_void,

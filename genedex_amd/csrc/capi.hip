@@ -8,6 +8,7 @@
 
 #include "../../include/gdx.h"
 #include "../../include/gdx_bench.h"
+#include "fastx.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
 #include "synth.hpp"
@@ -65,6 +66,10 @@ void *stream_scratch(hipStream_t stream, int slot, size_t bytes)
 
 struct gdx_index {
     std::unique_ptr<gdx::FmIndex> impl;
+};
+
+struct gdx_fastx {
+    std::unique_ptr<gdx::FastxReader> impl;
 };
 
 namespace {
@@ -549,5 +554,31 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
         return (int)GDX_OK;
     });
 }
+
+// ---- FASTA / FASTQ ingestion (host only) ------------------------------------------------------------------
+
+int gdx_fastx_open(const char *path, gdx_fastx_t **out)
+{
+    return guarded([&] {
+        if (!path || !out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "path / out is null");
+        auto r = std::make_unique<gdx_fastx>();
+        r->impl = std::make_unique<gdx::FastxReader>(path);
+        *out = r.release();
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
+                         uint64_t max_records, uint64_t *n_out)
+{
+    return guarded([&] {
+        if (!reader || !reader->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "reader handle is null");
+        if (!qoff || !n_out || (!qbuf && qbuf_capacity)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "output pointer is null");
+        *n_out = reader->impl->next_batch(qbuf, qbuf_capacity, qoff, max_records);
+        return (int)GDX_OK;
+    });
+}
+
+void gdx_fastx_close(gdx_fastx_t *reader) { delete reader; }
 
 }  // extern "C"

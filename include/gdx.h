@@ -221,6 +221,19 @@ int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, co
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx /*u32*/, uint64_t m,
                       void *d_out /*u32*/, void *stream);
 
+/* ---- query / text ingestion (host only) ---------------------------------------------------------------------
+ * Streaming FASTA / FASTQ reader that fills the layout the calls above take: sequences appended to qbuf, offsets
+ * to qoff[0 .. n] (qoff[0] = 0).  The reference leaves reading to its callers (ROADMAP.md:35-37 notes it can cost
+ * more than searching).  FASTA: '>' headers, sequences over any number of lines; FASTQ: '@' header, sequence
+ * lines, '+' line, as many quality characters as symbols; '\r' dropped; bytes copied as they are (the alphabet
+ * decides what is valid).  gdx_fastx_next_batch reads up to max_records records that fit into qbuf_capacity
+ * bytes, *n_out = 0 at the end of the file; a record larger than the whole buffer is GDX_ERR_CAPACITY. */
+typedef struct gdx_fastx gdx_fastx_t;
+int gdx_fastx_open(const char *path, gdx_fastx_t **out);
+int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
+                         uint64_t max_records, uint64_t *n_out);
+void gdx_fastx_close(gdx_fastx_t *reader);
+
 #ifdef __cplusplus
 }
 #endif
