@@ -804,8 +804,8 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                                                   : static_cast<unsigned>(n_ranges < (1u << 20) ? n_ranges : (1u << 20));
         // Cache policy of the line / entry loads: plain by default.  sc1 (no allocation in the CU's L1) was worth
         // +5 % while the first levels of the search were cache-resident pair lines; with the top table every load
-        // is a DRAM miss and plain loads measure 3 % faster.  GDX_LOAD_POLICY=0|1|2|3 = plain, sc1, nt, sc0 sc1
-        // (2 and 3 only exist for 8 lanes per query).
+        // is a DRAM miss and plain loads measure 3 % faster.  GDX_LOAD_POLICY=0|1 = plain, sc1 (nt and sc0 sc1 were
+        // tried on the pair lines too: plain 101.5, sc1 95.7, nt 98.7, sc0 sc1 96.5 ms at the time; search_variants.md).
         static const int policy = [] {
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 0;
@@ -830,8 +830,6 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
             else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0);
         } else if (lanes == 8) {
             if (policy == 1) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 1);
-            else if (policy == 2) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 2);
-            else if (policy == 3) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 3);
             else GDX_PAIR_LAUNCH_W(search_pair_kernel8, 0);
         } else {
             if (policy == 0) GDX_PAIR_LAUNCH_W(search_pair_kernel4, 0);
