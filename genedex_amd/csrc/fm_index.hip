@@ -764,9 +764,11 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
             view_.jump_bytes = jump_bytes;
         }
         // top table: the first symbols of a DNA query in one fetch.  Depth: even (the pair steps that follow consume
-        // two symbols each), at least 4 rows per entry on average, at most 14 (2 GB); GDX_TOP_DEPTH=0..16 overrides.
+        // two symbols each) and as deep as leaves about one row per entry (4^D <= 2 n), so that most reads can jump
+        // right after it; at most 16 (34 GB).  Measured (search_variants.md section 25): 3.1 G symbols: 16 beats
+        // 14 by 23 %; 2^28: 14 beats 12; 2^24: 12 beats 10.  GDX_TOP_DEPTH=0..16 overrides.
         uint32_t top_depth = 0;
-        while (top_depth < 14 && (1ull << (2u * (top_depth + 2u))) <= n_ / 4) top_depth += 2;
+        while (top_depth < 16 && (1ull << (2u * (top_depth + 2u))) <= 2ull * n_) top_depth += 2;
         if (const char *e = getenv("GDX_TOP_DEPTH")) top_depth = static_cast<uint32_t>(atoi(e)) > 16u ? 16u : atoi(e);
         if (top_depth > 0 && view_.sigma >= 5) {
             top_.alloc(1ull << (2u * top_depth));

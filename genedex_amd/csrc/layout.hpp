@@ -45,8 +45,8 @@ struct IndexView {
                                   // symbols those 8 steps need}, j = 1 .. jump_bytes / 8; null when absent
     uint32_t jump_bytes;          // 0, 8, 16 or 32
     // --- top table: interval after the first top_depth symbols of a DNA query, one cache-resident fetch ----
-    const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); empty
-                                  // entries (x == y) send the query down the ordinary path; null when absent
+    const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); the entry of
+                                  // an absent D-mer is its frozen empty interval; null when absent
     uint32_t top_depth;           // 1..16
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)

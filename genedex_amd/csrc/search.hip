@@ -116,8 +116,10 @@ __device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x111
 
 // Top table (IndexView::top): the interval after the first D = top_depth symbols of the search, i.e. the last D
 // symbols of the query, when all of them are dense codes 1..4.  `a` = code8(rem), `b` = code8(rem - 8) (only its
-// top D - 8 nibbles are used).  Returns false when a symbol is outside 1..4 or the D-mer does not occur (empty
-// entry): the caller then runs the ordinary steps from the start, which also yields the reference's frozen interval.
+// top D - 8 nibbles are used).  The entry of a D-mer that does not occur holds the frozen interval (start == end as
+// they stood at the step that emptied it, like the reference's lookup tables, lookup_table.rs:225-258), so such a
+// query is finished by the lookup.  Returns false when a symbol is outside 1..4: the caller then runs the ordinary
+// steps from the start, which validate symbols as lazily as the reference does.
 __device__ __forceinline__ bool top_lookup(const IndexView &ix, uint32_t a, uint32_t b, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t d = ix.top_depth;
@@ -134,7 +136,6 @@ __device__ __forceinline__ bool top_lookup(const IndexView &ix, uint32_t a, uint
     x = (x | (x >> 16)) & 0x00000000ffffffffull;
     const uint32_t idx = static_cast<uint32_t>(x) >> (32u - 2u * d);
     const uint2 e = ix.top[idx];
-    if (e.x == e.y) return false;
     lo = e.x;
     hi = e.y;
     return true;
@@ -709,8 +710,8 @@ __global__ __launch_bounds__(kBlock) void fill_lookup_kernel(IndexView ix, uint2
 }
 
 // top[idx]: idx holds the 2-bit codes (dense - 1) of the D symbols in consumption order, first consumed symbol in
-// the highest bit pair (top_lookup builds the same index from the query's nibble codes).  Empty intervals are
-// stored as {0, 0}.
+// the highest bit pair (top_lookup builds the same index from the query's nibble codes).  Plain backward search
+// with freeze-on-empty, exactly fill_lookup_kernel's.
 __global__ __launch_bounds__(kBlock) void fill_top_kernel(IndexView ix, uint2 *__restrict__ top, uint32_t depth,
                                                           uint64_t entries)
 {
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void fill_top_kernel(IndexView ix, uint2 *_
             lo = cc + rlo;
             hi = cc + rhi;
         }
-        top[e] = lo != hi ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+        top[e] = make_uint2(lo, hi);  // an empty interval stays as it was when it emptied (the loop stopped there)
     }
 }
 
