@@ -131,7 +131,14 @@ def main():
     n_status = int((out["status"] != 0).sum().item())
     hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
     workspace = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
-    counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    # Per-query counts travel to rank 0 in the narrowest integer type that holds the largest count of any rank
+    # (known from the sizing pass; lossless): 1 instead of 4 bytes per query on this workload, which keeps the
+    # gather of a batch (counts + 8 bytes per hit, over one xGMI link per peer) shorter than the step it hides behind.
+    max_count = int((out["end"] - out["start"]).max().item()) if nq else 0
+    if world > 1:
+        max_count = gdist.max_int_over_ranks(max_count, dev)
+    count_dtype = torch.uint8 if max_count <= 0xff else (torch.int16 if max_count <= 0x7fff else torch.int32)
+    counts = torch.empty(nq, dtype=count_dtype, device=dev)
     log(f"[bench r{rank}] {total_hits} hits, {n_status} queries with non-zero status")
 
     ev_search, ev_locate = [], []
@@ -183,7 +190,7 @@ def main():
                 if record:
                     ev_locate.append((c, d))
             if gather:
-                torch.sub(o["end"], o["start"], out=cnt)
+                cnt.copy_(torch.sub(o["end"], o["start"]))  # copy_ narrows to the gather's count type
                 gather.submit(slot)
             if overlap:
                 slot_free[slot] = torch.cuda.Event()
@@ -262,7 +269,9 @@ def main():
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
                    "aux_structures": eng.aux_info(),
-                   "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0"},
+                   "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0",
+                   "gathered_bytes_per_rank_and_step": (nq * counts.element_size() + (hits.numel() * 4 if do_locate else 0))
+                   if world > 1 else 0},
         "roofline": roofline,
         "locate_roofline": locate_roofline,
         "parity": parity,
