@@ -49,7 +49,8 @@ def _worker(rank, world, port, result_path):
     got_hits = gdist.gather_variable(hits, hits.shape[0], dst=0)
     # pipelined (asynchronous, double-buffered) gather, the form bench.py uses between steps
     max_hits = gdist.max_int_over_ranks(hits.shape[0], torch.device("cpu"))
-    slots = [[torch.zeros(nq // world + 1, dtype=torch.int64), torch.zeros((max_hits, 2), dtype=torch.int64)]
+    slots = [[torch.zeros(nq // world + 1, dtype=torch.int64), torch.zeros((max_hits, 2), dtype=torch.int64),
+              torch.zeros(nq // world + 1, dtype=torch.uint8)]  # bench.py ships counts as the narrowest type
              for _ in range(2)]
     pg = gdist.PipelinedGather(slots, dst=0)
     pipelined_ok = True
@@ -60,6 +61,8 @@ def _worker(rank, world, port, result_path):
         slots[slot][0][: counts.numel()] = counts + step
         slots[slot][1].zero_()
         slots[slot][1][: hits.shape[0]] = hits
+        slots[slot][2].zero_()
+        slots[slot][2][: counts.numel()].copy_(torch.clamp(counts, max=255))
         pg.submit(slot)
     pg.drain()
     if rank == 0:
@@ -69,6 +72,7 @@ def _worker(rank, world, port, result_path):
                 rlo, rhi = gdist.shard_range(nq, r, world)
                 pipelined_ok &= bool((got[0][r][: rhi - rlo] >= step).all())
             pipelined_ok &= torch.equal(got[1][0][: hits.shape[0]], hits)
+            pipelined_ok &= torch.equal(got[2][0][: counts.numel()].to(torch.int64), torch.clamp(counts, max=255))
     fixed = gdist.gather_fixed(torch.tensor([rank, hi - lo]), dst=0)
     tmax = gdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     gdist.barrier()
