@@ -590,15 +590,16 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
-// The 4-lane kernel holds two chunks per lane and line; with the 32-bit nibble windows (CodeWindow) it also fits
-// 64 VGPRs / 78 SGPRs without spills: 8 x 16 = 128 queries per SIMD in flight instead of 8 x 8 = 64.
+// The 4-lane kernel holds two chunks per lane and line.  With the jump levels, hints and ranges it no longer fits
+// 64 VGPRs without spilling 19 of them (whose scratch traffic showed up as a million DRAM writes per 10 M reads),
+// so it runs at 7 waves per SIMD (72 VGPRs, 5 spilled): 11.1 ms against 11.6 ms at 8 waves and 11.7 ms at 6.
 template <int kPolicy, int kJump>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
     search_pair_body<kPolicy, 8, false, kJump>(GDX_SEARCH_FWD);
 }
 template <int kPolicy, int kJump>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel4(GDX_SEARCH_ARGS)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
     search_pair_body<kPolicy, 4, false, kJump>(GDX_SEARCH_FWD);
 }
