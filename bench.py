@@ -82,11 +82,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the query path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Dry-run hooks for boxes with one GPU (tools/dryrun_two_ranks.sh): GDX_BENCH_ONE_GPU=1 puts every rank on device
+    # 0 and GDX_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; the N > 1 control flow
+    # (sharding, size exchange, double-buffered gather) is then exercised end to end on real kernels.
+    device_index = 0 if os.environ.get("GDX_BENCH_ONE_GPU") == "1" else local_rank
+    backend = os.environ.get("GDX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from genedex_amd import alphabet
     from genedex_amd import dist as gdist
