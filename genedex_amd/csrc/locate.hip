@@ -69,11 +69,14 @@ __device__ __forceinline__ uint32_t walk_to_sample(const IndexView &ix, const ui
 }
 
 // text_id_search_tree.rs:35-64: smallest t with pos <= sentinel_indices[t], position inside that text
+// `sentinels` is either the global array or the block's copy of it in LDS (locate_queue_kernel, few texts)
 template <bool kWide>
-__device__ __forceinline__ void store_hit(const IndexView &ix, uint32_t pos, void *hits_out, uint64_t at)
+__device__ __forceinline__ void store_hit(const IndexView &ix, uint32_t pos, void *hits_out, uint64_t at,
+                                          const uint32_t *sentinels = nullptr)
 {
-    const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
-    const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
+    if (!sentinels) sentinels = ix.sentinels;
+    const uint32_t t = lower_bound_u32(sentinels, ix.n_texts, pos);
+    const uint32_t in_text = t == 0 ? pos : pos - sentinels[t - 1] - 1u;
     if (kWide) {
         gdx_hit_t out;
         out.text_id = t;
@@ -150,6 +153,12 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
     __shared__ uint16_t s_idx[kLocateChunk];
     __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first
     __shared__ uint32_t s_n, s_head;
+    // the text-id search of every hit is a chain of dependent loads: from LDS when the sentinel array is small
+    constexpr uint32_t kLdsTexts = 256;
+    __shared__ uint32_t s_sentinels[kLdsTexts];
+    const uint32_t *sentinels = ix.n_texts <= kLdsTexts ? s_sentinels : ix.sentinels;
+    if (ix.n_texts <= kLdsTexts)
+        for (uint32_t i = threadIdx.x; i < ix.n_texts; i += kBlock) s_sentinels[i] = ix.sentinels[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
     const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
     uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
             const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
             if (sampled) {  // sampled_suffix_array.rs:133-136 with zero steps
                 const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
-                store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h);
+                store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
             } else {
                 const uint32_t k = atomicAdd(&s_n, 1u);
                 s_row[k] = row;
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 const uint32_t c = Table::symbol_and_rank(ix, row, r);
                 if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
                     const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, row);
-                    store_hit<kWide>(ix, ix.border_vals[b] + steps, hits_out, base + idx);
+                    store_hit<kWide>(ix, ix.border_vals[b] + steps, hits_out, base + idx, sentinels);
                     walk_steps += steps;
                     have = false;
                 } else {
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                     const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
                     if (sampled) {
                         const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
-                        store_hit<kWide>(ix, ix.sa_samples[slot] + steps, hits_out, base + idx);
+                        store_hit<kWide>(ix, ix.sa_samples[slot] + steps, hits_out, base + idx, sentinels);
                         walk_steps += steps;
                         have = false;
                     }
