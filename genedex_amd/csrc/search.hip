@@ -531,6 +531,21 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 }
                 const uint32_t nlo = group_sum<kGroup>(plo), nhi = group_sum<kGroup>(phi);
                 if (nlo != nhi) {
+                    if (out_hint != nullptr && !(status >> 31) && hi - lo == 1u && nhi - nlo == 1u) {
+                        // locate hint from a pair step of a one-row interval: the row in between, LF(c1, lo), comes
+                        // out of the same line; rem - 1 symbols are still unmatched there (see the jump above)
+                        const uint32_t bx1 = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
+                        const uint32_t nx1 = ~(bx1 * 0xffu) & 0xffffffu;
+                        uint32_t pm = 0;
+#pragma unroll
+                        for (int k = 0; k < kChunks; k++) pm += PairTable::single_partial(a[k], sub + k * kGroup, c1, nx1, lo);
+                        const uint32_t mid = group_sum<kGroup>(pm);
+                        const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+                        if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
+                            if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(mid, rem - 1u);
+                            status |= 0x80000000u;
+                        }
+                    }
                     lo = nlo;
                     hi = nhi;
                     rem -= 2;
