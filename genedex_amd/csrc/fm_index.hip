@@ -747,6 +747,41 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         if (const char *e = getenv("GDX_NO_JUMP_TABLE")) jump_bytes = e[0] == '1' ? 0u : jump_bytes;
         if (jump_bytes != 0 && jump_bytes != 8 && jump_bytes != 16 && jump_bytes != 32)
             fail(GDX_ERR_INVALID_ARGUMENT, "GDX_JUMP_BYTES must be 0, 8, 16 or 32");
+        // top table depth wanted: even (the pair steps that follow consume two symbols each) and as deep as leaves
+        // about one row per entry (4^D <= 2 n), so that most reads can jump right after it; at most 16 (34 GB).
+        // Measured (search_variants.md section 25): 3.1 G symbols: 16 beats 14 by 23 %; 2^28: 14 beats 12; 2^24: 12
+        // beats 10.  GDX_TOP_DEPTH=0..16 overrides.
+        uint32_t top_depth = 0;
+        while (top_depth < 16 && (1ull << (2u * (top_depth + 2u))) <= 2ull * n_) top_depth += 2;
+        if (const char *e = getenv("GDX_TOP_DEPTH")) top_depth = static_cast<uint32_t>(atoi(e)) > 16u ? 16u : atoi(e);
+        if (view_.sigma < 5) top_depth = 0;
+        // Both tables are optional: they have to fit into what the device has free (minus room for query batches and
+        // results: 1/16 of the memory, at least 4 GB), or into GDX_AUX_BUDGET_GB.  Otherwise they shrink in the
+        // order of what each step costs on the headline workload: top 16 -> 14, jump 32 -> 16, top -> 12,
+        // jump -> 8, top -> 0, jump -> 0.
+        {
+            size_t free_b = 0, total_b = 0;
+            GDX_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t reserve = total_b / 16 > (4ull << 30) ? total_b / 16 : (4ull << 30);
+            double budget = free_b > reserve ? static_cast<double>(free_b - reserve) : 0.0;
+            if (const char *e = getenv("GDX_AUX_BUDGET_GB")) {
+                const double b = atof(e) * 1e9;
+                budget = b < budget ? b : budget;
+            }
+            auto need = [&] {
+                return static_cast<double>(jump_bytes) * static_cast<double>(n_) +
+                       (top_depth ? 8.0 * static_cast<double>(1ull << (2u * top_depth)) : 0.0);
+            };
+            while (need() > budget) {
+                if (top_depth > 14) top_depth = 14;
+                else if (jump_bytes == 32) jump_bytes = 16;
+                else if (top_depth > 12) top_depth = 12;
+                else if (jump_bytes == 16) jump_bytes = 8;
+                else if (top_depth > 0) top_depth -= 2;
+                else if (jump_bytes != 0) jump_bytes = 0;
+                else break;
+            }
+        }
         if (jump_bytes != 0) {
             const uint32_t words = jump_bytes / 4;
             jump_.alloc(static_cast<uint64_t>(n_) * words);
@@ -763,13 +798,7 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
             view_.jump = jump_.get();
             view_.jump_bytes = jump_bytes;
         }
-        // top table: the first symbols of a DNA query in one fetch.  Depth: even (the pair steps that follow consume
-        // two symbols each) and as deep as leaves about one row per entry (4^D <= 2 n), so that most reads can jump
-        // right after it; at most 16 (34 GB).  Measured (search_variants.md section 25): 3.1 G symbols: 16 beats
-        // 14 by 23 %; 2^28: 14 beats 12; 2^24: 12 beats 10.  GDX_TOP_DEPTH=0..16 overrides.
-        uint32_t top_depth = 0;
-        while (top_depth < 16 && (1ull << (2u * (top_depth + 2u))) <= 2ull * n_) top_depth += 2;
-        if (const char *e = getenv("GDX_TOP_DEPTH")) top_depth = static_cast<uint32_t>(atoi(e)) > 16u ? 16u : atoi(e);
+        // top table: the first symbols of a DNA query in one fetch (depth chosen above)
         if (top_depth > 0 && view_.sigma >= 5) {
             top_.alloc(1ull << (2u * top_depth));
             launch_fill_top(view_, top_.get(), top_depth, stream);

@@ -455,6 +455,49 @@ def test_long_repeats_and_long_queries(search_variant):
     assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
 
 
+@pytest.mark.parametrize("budget_gb,want", [("0", (0, 0)), ("0.0003", None), (None, (32, None))])
+def test_acceleration_structures_shrink_to_the_memory_budget(budget_gb, want):
+    """The jump and top tables are optional: they shrink to what GDX_AUX_BUDGET_GB (or the free HBM) allows and the
+    answers do not change."""
+    import os
+
+    from genedex_amd.device import DeviceEngine
+
+    rng = np.random.default_rng(41)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=20000, symbols=b"ACGT")
+    old = os.environ.get("GDX_AUX_BUDGET_GB")
+    if budget_gb is None:
+        os.environ.pop("GDX_AUX_BUDGET_GB", None)
+    else:
+        os.environ["GDX_AUX_BUDGET_GB"] = budget_gb
+    try:
+        g, c = both(texts, a)
+    finally:
+        if old is None:
+            os.environ.pop("GDX_AUX_BUDGET_GB", None)
+        else:
+            os.environ["GDX_AUX_BUDGET_GB"] = old
+    aux = DeviceEngine(g).aux_info()
+    n = g.total_text_len()
+    if want is not None:
+        if want[0] is not None:
+            assert aux["jump_entry_bytes"] == want[0]
+        if want[1] is not None:
+            assert aux["top_table_depth"] == want[1]
+    else:  # 300 kB: whatever was kept fits
+        used = aux["jump_entry_bytes"] * n + (8 * 4 ** aux["top_table_depth"] if aux["top_table_depth"] else 0)
+        assert used <= 300_000
+    qs = mixed_queries(rng, texts, 600, 300, 70)
+    qbuf, qoff = pack_queries(qs)
+    s_, e_, st = g.cursors_raw(qbuf, qoff)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    assert s_.tolist() == cs.tolist() and e_.tolist() == ce.tolist()
+    off, t, p, _ = g.locate_raw(qbuf, qoff)
+    co, ct, cp = c.locate_many(qs)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
 def test_genome_like_text_properties():
     """A 32 M-symbol text with segmental duplications, tandem repeats, poly-A and long runs of N (tools/genome_like.py):
     many doubling rounds in the suffix sorter, intervals of millions of rows, wide intervals deep into the search.
