@@ -625,3 +625,20 @@ def test_import_of_a_wide_alphabet_flat512_table():
     off, t, p, _ = g.locate_raw(*pack_queries(qs))
     co, ct, cp = c.locate_many(qs)
     assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
+def test_randomised_configurations_sample():
+    """A short run of tests/parity_sweep.py (random alphabets, text shapes, sampling rates, table sizes, hinted and
+    un-hinted device path against the oracle); the committed profiles hold the long runs."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_sweep.py")
+    spec = importlib.util.spec_from_file_location("parity_sweep", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(2024)
+    stats = {"queries": 0, "hits": 0, "status_nonzero": 0, "hinted_queries": 0}
+    for _ in range(25):
+        mod.one_round(rng, stats)
+    assert stats["queries"] > 10_000 and stats["hits"] > 0
