@@ -122,7 +122,7 @@ def run(total: int, nq: int) -> dict:
            "search_ms": t_search * 1e3, "hits_of_all_queries": all_hits, "hits_located": total_hits, "max_count": int(counts.max().item()),
            "queries_found": int((counts > 0).sum().item()), "queries_with_status": int((out["status"] != 0).sum().item()),
            "aux": eng.aux_info()}
-    cap = 400_000_000
+    cap = 1_000_000_000
     if total_hits <= cap:
         hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
         ws = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
