@@ -38,7 +38,9 @@ VARIANTS = [("no outputs", call(None, None, None, None)),
             ("start", call(P(out["start"]), None, None, None)),
             ("start+end", call(P(out["start"]), P(out["end"]), None, None)),
             ("start+end+status", call(P(out["start"]), P(out["end"]), P(out["status"]), None)),
-            ("start+end+status+hint", call(P(out["start"]), P(out["end"]), P(out["status"]), P(out["hint"])))]
+            ("start+end+status+hint", call(P(out["start"]), P(out["end"]), P(out["status"]), P(out["hint"]))),
+            ("hint only", call(None, None, None, P(out["hint"]))),
+            ("status only", call(None, None, P(out["status"]), None))]
 for name, fn in VARIANTS:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if reps > 1:
