@@ -48,6 +48,22 @@ class IndexInfo(C.Structure):
                 ("table_layout", C.c_int32)]
 
 
+class BuildOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32),
+                ("top_table_depth", C.c_int32), ("aux_budget_bytes", C.c_uint64)]
+
+
+class QueryOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
+                ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32)]
+
+
+class IndexAux(C.Structure):
+    _fields_ = [("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32), ("top_table_depth", C.c_int32),
+                ("wanted_jump_entry_bytes", C.c_int32), ("wanted_top_table_depth", C.c_int32),
+                ("reserved", C.c_int32), ("aux_bytes", C.c_uint64), ("aux_budget_bytes", C.c_uint64)]
+
+
 class BuildStats(C.Structure):
     _fields_ = [("sa_initial_order", C.c_uint64), ("sa_pending_after_sort", C.c_uint64), ("sa_rounds", C.c_uint64),
                 ("seconds_encode", C.c_double), ("seconds_sa", C.c_double), ("seconds_bwt", C.c_double),
@@ -66,6 +82,20 @@ SIGNATURES = {
                              C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "gdx_index_from_parts_ex": [C.c_int, C.c_int, u64p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, u64p,
                                 C.c_uint64, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "gdx_build_options_init": [C.POINTER(BuildOptions)],
+    "gdx_query_options_init": [C.POINTER(QueryOptions)],
+    "gdx_index_build_ex": [u8p, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                           C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_index_build_dev_ex": [vp, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_index_from_parts_ex2": [C.c_int, C.c_int, u64p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, u64p,
+                                 C.c_uint64, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_index_load_ex": [C.c_char_p, C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_index_aux": [vp, C.POINTER(IndexAux)],
+    "gdx_index_set_query_options": [vp, C.POINTER(QueryOptions)],
+    "gdx_index_get_query_options": [vp, C.POINTER(QueryOptions)],
+    "gdx_index_rebuild_aux": [vp, C.POINTER(BuildOptions)],
     "gdx_index_save": [vp, C.c_char_p],
     "gdx_index_load": [C.c_char_p, C.c_int, C.POINTER(vp)],
     "gdx_index_free": [vp],
@@ -93,7 +123,7 @@ SIGNATURES = {
     "gdx_locate_intervals_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_intervals_hint_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_cursors_for_many_queries_hint_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp],
-    "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     # gdx_bench.h
     "gdx_index_build_stats": [vp, C.POINTER(BuildStats)],
     "gdx_synth_text_dev": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp],
@@ -111,6 +141,7 @@ SIGNATURES = {
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
+             "gdx_build_options_init": None, "gdx_query_options_init": None,
              "gdx_locate_workspace_bytes": C.c_uint64}
 
 _lib = None

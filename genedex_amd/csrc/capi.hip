@@ -99,8 +99,11 @@ int guarded(F &&f)
     }
 }
 
+gdx::BuildOptions make_build_options(const gdx_build_options_t *o);
+
 gdx::IndexConfig make_config(const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate,
-                             int lookup_depth, int index_width, int device_id)
+                             int lookup_depth, int index_width, int device_id,
+                             const gdx_build_options_t *opts = nullptr)
 {
     if (!io_to_dense) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "io_to_dense is null");
     gdx::IndexConfig cfg;
@@ -111,6 +114,7 @@ gdx::IndexConfig make_config(const uint8_t *io_to_dense, int sigma, int n_search
     cfg.lookup_depth = lookup_depth;
     cfg.index_width = index_width;
     cfg.device_id = device_id;
+    cfg.build = make_build_options(opts);
     return cfg;
 }
 
@@ -121,6 +125,46 @@ const gdx::FmIndex &deref(const gdx_index_t *ix)
 }
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+// makes the handle's device current for the duration of a call and restores the caller's afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev)
+    {
+        GDX_HIP(hipGetDevice(&prev));
+        if (prev != dev) {
+            GDX_HIP(hipSetDevice(dev));
+            changed = true;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
+{
+    gdx::BuildOptions b;
+    if (!o) return b;
+    if (o->struct_size < sizeof(gdx_build_options_t))
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_build_options_t.struct_size is %u, expected %zu (use gdx_build_options_init)",
+                  o->struct_size, sizeof(gdx_build_options_t));
+    if (o->pair_lines < -1 || o->pair_lines > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "pair_lines must be -1, 0 or 1");
+    if (o->jump_entry_bytes != -1 && o->jump_entry_bytes != 0 && o->jump_entry_bytes != 8 && o->jump_entry_bytes != 16 &&
+        o->jump_entry_bytes != 32)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "jump_entry_bytes must be -1, 0, 8, 16 or 32");
+    if (o->top_table_depth < -1 || o->top_table_depth > 16)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "top_table_depth must be in -1..=16");
+    b.pair_lines = o->pair_lines;
+    b.jump_bytes = o->jump_entry_bytes;
+    b.top_depth = o->top_table_depth;
+    b.aux_budget_bytes = o->aux_budget_bytes;
+    return b;
+}
 
 }  // namespace
 
@@ -135,14 +179,43 @@ int gdx_device_count(void)
     return n;
 }
 
+void gdx_build_options_init(gdx_build_options_t *opts)
+{
+    if (!opts) return;
+    opts->struct_size = sizeof(gdx_build_options_t);
+    opts->pair_lines = -1;
+    opts->jump_entry_bytes = -1;
+    opts->top_table_depth = -1;
+    opts->aux_budget_bytes = 0;
+}
+
+void gdx_query_options_init(gdx_query_options_t *opts)
+{
+    if (!opts) return;
+    opts->struct_size = sizeof(gdx_query_options_t);
+    opts->search_kernel = -1;
+    opts->search_lanes = 0;
+    opts->load_policy = -1;
+    opts->length_schedule = -1;
+    opts->locate_kernel = -1;
+}
+
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
                     const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
                     int index_width, int device_id, gdx_index_t **out)
 {
+    return gdx_index_build_ex(texts_buf, text_offsets, n_texts, io_to_dense, sigma, n_searchable, sa_rate, lookup_depth,
+                              index_width, device_id, nullptr, out);
+}
+
+int gdx_index_build_ex(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                       const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                       int index_width, int device_id, const gdx_build_options_t *opts, gdx_index_t **out)
+{
     return guarded([&] {
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
-        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id);
+        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
         auto impl = gdx::FmIndex::construct_index(texts_buf, false, text_offsets, n_texts, cfg);
         *out = new gdx_index{std::move(impl)};
         return (int)GDX_OK;
@@ -153,10 +226,18 @@ int gdx_index_build_dev(const void *d_texts_buf, const uint64_t *text_offsets, u
                         const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
                         int index_width, int device_id, gdx_index_t **out)
 {
+    return gdx_index_build_dev_ex(d_texts_buf, text_offsets, n_texts, io_to_dense, sigma, n_searchable, sa_rate,
+                                  lookup_depth, index_width, device_id, nullptr, out);
+}
+
+int gdx_index_build_dev_ex(const void *d_texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                           const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                           int index_width, int device_id, const gdx_build_options_t *opts, gdx_index_t **out)
+{
     return guarded([&] {
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
-        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id);
+        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
         auto impl = gdx::FmIndex::construct_index(static_cast<const uint8_t *>(d_texts_buf), true, text_offsets,
                                                   n_texts, cfg);
         *out = new gdx_index{std::move(impl)};
@@ -170,10 +251,21 @@ int gdx_index_from_parts_ex(int table_kind, int block_bits, const uint64_t *coun
                             const uint8_t *io_to_dense, int sigma, int n_searchable, int lookup_depth,
                             int index_width, int device_id, gdx_index_t **out)
 {
+    return gdx_index_from_parts_ex2(table_kind, block_bits, count, interleaved_blocks, n, sa_samples, sa_rate, border_keys,
+                                    border_vals, sentinel_indices, n_texts, io_to_dense, sigma, n_searchable, lookup_depth,
+                                    index_width, device_id, nullptr, out);
+}
+
+int gdx_index_from_parts_ex2(int table_kind, int block_bits, const uint64_t *count, const uint64_t *interleaved_blocks,
+                             uint64_t n, const uint32_t *sa_samples, uint64_t sa_rate, const uint64_t *border_keys,
+                             const uint64_t *border_vals, const uint64_t *sentinel_indices, uint64_t n_texts,
+                             const uint8_t *io_to_dense, int sigma, int n_searchable, int lookup_depth,
+                             int index_width, int device_id, const gdx_build_options_t *opts, gdx_index_t **out)
+{
     return guarded([&] {
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
-        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id);
+        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
         auto impl = gdx::FmIndex::from_parts(table_kind, block_bits, count, interleaved_blocks, n, sa_samples,
                                              border_keys, border_vals, sentinel_indices, n_texts, cfg);
         *out = new gdx_index{std::move(impl)};
@@ -202,10 +294,15 @@ int gdx_index_save(const gdx_index_t *ix, const char *path)
 
 int gdx_index_load(const char *path, int device_id, gdx_index_t **out)
 {
+    return gdx_index_load_ex(path, device_id, nullptr, out);
+}
+
+int gdx_index_load_ex(const char *path, int device_id, const gdx_build_options_t *opts, gdx_index_t **out)
+{
     return guarded([&] {
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
-        auto impl = gdx::FmIndex::load(path, device_id);
+        auto impl = gdx::FmIndex::load(path, device_id, make_build_options(opts));
         *out = new gdx_index{std::move(impl)};
         return (int)GDX_OK;
     });
@@ -215,8 +312,79 @@ void gdx_index_free(gdx_index_t *ix)
 {
     if (!ix) return;
     (void)guarded([&] {
-        if (ix->impl) ix->impl->make_current();
+        if (ix->impl) {
+            DeviceGuard guard(ix->impl->config().device_id);  // the caller's current device is left as it was
+            ix->impl.reset();
+        }
         delete ix;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_aux(const gdx_index_t *ix, gdx_index_aux_t *out)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        const gdx::IndexView &v = f.view();
+        const gdx::AuxReport &r = f.aux_report();
+        out->pair_lines = v.pair_lines != nullptr;
+        out->jump_entry_bytes = v.jump ? static_cast<int32_t>(v.jump_bytes) : 0;
+        out->top_table_depth = v.top ? static_cast<int32_t>(v.top_depth) : 0;
+        out->wanted_jump_entry_bytes = static_cast<int32_t>(r.wanted_jump_bytes);
+        out->wanted_top_table_depth = static_cast<int32_t>(r.wanted_top_depth);
+        out->reserved = 0;
+        out->aux_bytes = r.aux_bytes;
+        out->aux_budget_bytes = r.budget_bytes;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts)
+{
+    return guarded([&] {
+        if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
+        gdx::QueryOptions q;
+        if (opts) {
+            if (opts->struct_size < sizeof(gdx_query_options_t))
+                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t.struct_size is too small (use gdx_query_options_init)");
+            if (opts->search_kernel < -1 || opts->search_kernel > 2 ||
+                (opts->search_lanes != 0 && opts->search_lanes != 4 && opts->search_lanes != 8) || opts->load_policy < -1 ||
+                opts->load_policy > 3 || opts->length_schedule < -1 || opts->length_schedule > 1 ||
+                opts->locate_kernel < -1 || opts->locate_kernel > 2)
+                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            q.search_variant = opts->search_kernel;
+            q.search_lanes = opts->search_lanes;
+            q.load_policy = opts->load_policy;
+            q.length_schedule = opts->length_schedule;
+            q.locate_variant = opts->locate_kernel;
+        }
+        ix->impl->set_query_options(q);
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        const gdx::QueryOptions q = f.query_options();
+        out->struct_size = sizeof(gdx_query_options_t);
+        out->search_kernel = q.search_variant;
+        out->search_lanes = q.search_lanes;
+        out->load_policy = q.load_policy;
+        out->length_schedule = q.length_schedule;
+        out->locate_kernel = q.locate_variant;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_rebuild_aux(gdx_index_t *ix, const gdx_build_options_t *opts)
+{
+    return guarded([&] {
+        if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
+        ix->impl->rebuild_aux(make_build_options(opts));
         return (int)GDX_OK;
     });
 }
@@ -349,9 +517,10 @@ int gdx_cursors_for_many_queries_dev(const gdx_index_t *ix, const void *d_qbuf, 
     return guarded([&] {
         const gdx::FmIndex &f = deref(ix);
         if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        DeviceGuard guard(f.config().device_id);
         gdx::launch_search(f.view(), static_cast<const uint8_t *>(d_qbuf), static_cast<const uint64_t *>(d_qoff), nq,
                            static_cast<uint32_t *>(d_out_start), static_cast<uint32_t *>(d_out_end), nullptr,
-                           static_cast<uint8_t *>(d_out_status), as_stream(stream));
+                           static_cast<uint8_t *>(d_out_status), as_stream(stream), nullptr, nullptr, f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -366,10 +535,11 @@ int gdx_cursors_for_many_queries_hint_dev(const gdx_index_t *ix, const void *d_q
         if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
         if (!d_hint || (reinterpret_cast<uintptr_t>(d_hint) & 7u) != 0)
             gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_hint must be a non-null 8-byte aligned device pointer");
+        DeviceGuard guard(f.config().device_id);
         gdx::launch_search(f.view(), static_cast<const uint8_t *>(d_qbuf), static_cast<const uint64_t *>(d_qoff), nq,
                            static_cast<uint32_t *>(d_out_start), static_cast<uint32_t *>(d_out_end), nullptr,
                            static_cast<uint8_t *>(d_out_status), as_stream(stream), nullptr,
-                           static_cast<uint2 *>(d_hint));
+                           static_cast<uint2 *>(d_hint), f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -381,9 +551,10 @@ int gdx_count_many_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_
     return guarded([&] {
         const gdx::FmIndex &f = deref(ix);
         if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        DeviceGuard guard(f.config().device_id);
         gdx::launch_search(f.view(), static_cast<const uint8_t *>(d_qbuf), static_cast<const uint64_t *>(d_qoff), nq,
                            nullptr, nullptr, static_cast<uint32_t *>(d_out_counts),
-                           static_cast<uint8_t *>(d_out_status), as_stream(stream));
+                           static_cast<uint8_t *>(d_out_status), as_stream(stream), nullptr, nullptr, f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -393,6 +564,7 @@ int gdx_cursor_extend_front_many_dev(const gdx_index_t *ix, void *d_start, void 
                                      uint64_t m, void *d_out_status, void *stream)
 {
     return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
         gdx::launch_extend_front(deref(ix).view(), static_cast<uint32_t *>(d_start), static_cast<uint32_t *>(d_end),
                                  static_cast<const uint8_t *>(d_io_symbols), m, static_cast<uint8_t *>(d_out_status),
                                  as_stream(stream));
@@ -405,7 +577,7 @@ int gdx_hit_offsets_dev(const gdx_index_t *ix, const void *d_start, const void *
                         void *d_hit_offsets, void *stream)
 {
     return guarded([&] {
-        (void)deref(ix);
+        DeviceGuard guard(deref(ix).config().device_id);
         const size_t tb = gdx::hit_offsets_temp_bytes(m);
         void *temp = gdx::stream_scratch(as_stream(stream), 8, tb ? tb : 1);
         gdx::launch_hit_offsets(static_cast<const uint32_t *>(d_start), static_cast<const uint32_t *>(d_end), m,
@@ -421,9 +593,11 @@ int gdx_locate_intervals_dev(const gdx_index_t *ix, const void *d_start, const v
                              void *stream)
 {
     return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
         gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
                            static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
-                           total_hits, d_hits, false, d_workspace, as_stream(stream));
+                           total_hits, d_hits, false, d_workspace, as_stream(stream), nullptr, nullptr,
+                           deref(ix).query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -434,22 +608,24 @@ int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, co
                                   const void *d_hint, void *stream)
 {
     return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
         gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
                            static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
                            total_hits, d_hits, false, d_workspace, as_stream(stream), nullptr,
-                           static_cast<const uint2 *>(d_hint));
+                           static_cast<const uint2 *>(d_hint), deref(ix).query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
 }
 
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx, uint64_t m, void *d_out,
-                      void *stream)
+                      void *d_error, void *stream)
 {
     return guarded([&] {
         const gdx::FmIndex &f = deref(ix);
-        uint32_t *d_err = static_cast<uint32_t *>(gdx::stream_scratch(as_stream(stream), 9, sizeof(uint32_t)));
-        GDX_HIP(hipMemsetAsync(d_err, 0, sizeof(uint32_t), as_stream(stream)));
+        DeviceGuard guard(f.config().device_id);
+        uint32_t *d_err = static_cast<uint32_t *>(d_error);
+        if (!d_err) d_err = static_cast<uint32_t *>(gdx::stream_scratch(as_stream(stream), 9, sizeof(uint32_t)));
         gdx::launch_rank_many(f.view(), static_cast<const uint8_t *>(d_symbols), static_cast<const uint32_t *>(d_idx),
                               m, static_cast<uint32_t *>(d_out), d_err, as_stream(stream));
         GDX_HIP(hipGetLastError());
@@ -520,9 +696,11 @@ int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const v
                               void *d_steps, void *stream)
 {
     return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
         gdx::launch_search(deref(ix).view(), static_cast<const uint8_t *>(d_qbuf),
                            static_cast<const uint64_t *>(d_qoff), nq, nullptr, nullptr, nullptr, nullptr,
-                           as_stream(stream), static_cast<unsigned long long *>(d_steps));
+                           as_stream(stream), static_cast<unsigned long long *>(d_steps), nullptr,
+                           deref(ix).query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -546,10 +724,11 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
                               void *d_steps, void *stream)
 {
     return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
         gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
                            static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
                            total_hits, d_hits, false, d_workspace, as_stream(stream),
-                           static_cast<unsigned long long *>(d_steps));
+                           static_cast<unsigned long long *>(d_steps), nullptr, deref(ix).query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

@@ -551,6 +551,19 @@ __global__ __launch_bounds__(kBlock) void narrow_u64_kernel(const uint64_t *in, 
     }
 }
 
+// from_parts: flag |= 1 if a suffix-array sample is not a text position, |= 2 if a border key is not a BWT sentinel row
+__global__ __launch_bounds__(kBlock) void check_parts_kernel(const uint32_t *__restrict__ samples, uint64_t n_samples,
+                                                             uint32_t n, const uint32_t *__restrict__ border_keys,
+                                                             uint32_t n_texts, const uint8_t *__restrict__ bwt,
+                                                             uint32_t *__restrict__ flag)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_samples; i += stride)
+        if (samples[i] >= n) atomicOr(flag, 1u);
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_texts; i += stride)
+        if (bwt[border_keys[i]] != 0) atomicOr(flag, 2u);
+}
+
 int ilog2_ceil(uint64_t v)  // condensed.rs:417-419
 {
     int bits = 0;
@@ -700,10 +713,34 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     GDX_HIP(hipGetLastError());
     stats_.seconds_lookup = now_seconds() - t0;
 
-    // ---- pair lines: two LF steps per line fetch (rank-line layout only) ------------------------------
-    const char *no_pairs = getenv("GDX_NO_PAIR_LINES");
-    if (view_.layout == 0 && n_ > 0 && !(no_pairs && no_pairs[0] == '1')) {
-        t0 = now_seconds();
+    build_aux(d_bwt_padded, stream);
+}
+
+// ---- pair lines, jump table, top table (rank-line layout only): BuildOptions decide, the budget trims ----------
+void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
+{
+    const int sigma = cfg_.sigma;
+    const uint64_t len = n_ + 1;
+    const uint64_t n_sb = div_ceil(len, 65536);
+    const BuildOptions &bo = cfg_.build;
+    aux_report_ = AuxReport{};
+    view_.pair_lines = nullptr;
+    view_.jump = nullptr;
+    view_.jump_bytes = 0;
+    view_.top = nullptr;
+    view_.top_depth = 0;
+    pair_lines_.release();
+    jump_.release();
+    top_.release();
+    // environment variables are debug overrides of fields left at their default
+    auto env_int = [](const char *name, int fallback) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : fallback;
+    };
+    int want_pairs = bo.pair_lines;
+    if (want_pairs < 0) want_pairs = env_int("GDX_NO_PAIR_LINES", 0) == 1 ? 0 : 1;
+    if (view_.layout == 0 && n_ > 0 && want_pairs) {
+        double t0 = now_seconds();
         const uint64_t n_lines = div_ceil(len, 128);
         const uint64_t padded = n_lines * 128;
         DeviceBuffer<uint8_t> d_bwt0(padded);
@@ -741,33 +778,49 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         GDX_HIP(hipStreamSynchronize(stream));
         GDX_HIP(hipGetLastError());
         view_.pair_lines = pair_lines_.get();
-        // jump table: 32-byte entries by default; GDX_JUMP_BYTES=8|16|32|0 or GDX_NO_JUMP_TABLE=1 (= 0) override
+        // jump table: 32-byte entries by default (BuildOptions::jump_bytes; GDX_JUMP_BYTES / GDX_NO_JUMP_TABLE
+        // override the default only)
         uint32_t jump_bytes = 32;
-        if (const char *e = getenv("GDX_JUMP_BYTES")) jump_bytes = static_cast<uint32_t>(atoi(e));
-        if (const char *e = getenv("GDX_NO_JUMP_TABLE")) jump_bytes = e[0] == '1' ? 0u : jump_bytes;
+        if (bo.jump_bytes >= 0) {
+            jump_bytes = static_cast<uint32_t>(bo.jump_bytes);
+        } else {
+            jump_bytes = static_cast<uint32_t>(env_int("GDX_JUMP_BYTES", 32));
+            if (env_int("GDX_NO_JUMP_TABLE", 0) == 1) jump_bytes = 0;
+        }
         if (jump_bytes != 0 && jump_bytes != 8 && jump_bytes != 16 && jump_bytes != 32)
-            fail(GDX_ERR_INVALID_ARGUMENT, "GDX_JUMP_BYTES must be 0, 8, 16 or 32");
+            fail(GDX_ERR_INVALID_ARGUMENT, "jump entry bytes must be 0, 8, 16 or 32");
         // top table depth wanted: even (the pair steps that follow consume two symbols each) and as deep as leaves
         // about one row per entry (4^D <= 2 n), so that most reads can jump right after it; at most 16 (34 GB).
         // Measured (search_variants.md section 25): 3.1 G symbols: 16 beats 14 by 23 %; 2^28: 14 beats 12; 2^24: 12
-        // beats 10.  GDX_TOP_DEPTH=0..16 overrides.
+        // beats 10.
         uint32_t top_depth = 0;
         while (top_depth < 16 && (1ull << (2u * (top_depth + 2u))) <= 2ull * n_) top_depth += 2;
-        if (const char *e = getenv("GDX_TOP_DEPTH")) top_depth = static_cast<uint32_t>(atoi(e)) > 16u ? 16u : atoi(e);
+        if (bo.top_depth >= 0) top_depth = static_cast<uint32_t>(bo.top_depth);
+        else top_depth = static_cast<uint32_t>(env_int("GDX_TOP_DEPTH", static_cast<int>(top_depth)));
+        if (top_depth > 16u) top_depth = 16u;
         if (view_.sigma < 5) top_depth = 0;
-        // Both tables are optional: they have to fit into what the device has free (minus room for query batches and
-        // results: 1/16 of the memory, at least 4 GB), or into GDX_AUX_BUDGET_GB.  Otherwise they shrink in the
-        // order of what each step costs on the headline workload: top 16 -> 14, jump 32 -> 16, top -> 12,
-        // jump -> 8, top -> 0, jump -> 0.
+        aux_report_.wanted_jump_bytes = jump_bytes;
+        aux_report_.wanted_top_depth = top_depth;
+        // Both tables are optional and have to fit into a budget: BuildOptions::aux_budget_bytes, by default what
+        // the device has free minus room for query batches and results (1/16 of the memory, at least 4 GB) but
+        // never more than half of the device's memory.  Otherwise they shrink in the order of what each step costs
+        // on the headline workload: top 16 -> 14, jump 32 -> 16, top -> 12, jump -> 8, top -> 0, jump -> 0;
+        // gdx_index_aux reports what was wanted and what was built.
         {
             size_t free_b = 0, total_b = 0;
             GDX_HIP(hipMemGetInfo(&free_b, &total_b));
             const size_t reserve = total_b / 16 > (4ull << 30) ? total_b / 16 : (4ull << 30);
             double budget = free_b > reserve ? static_cast<double>(free_b - reserve) : 0.0;
-            if (const char *e = getenv("GDX_AUX_BUDGET_GB")) {
-                const double b = atof(e) * 1e9;
-                budget = b < budget ? b : budget;
+            if (bo.aux_budget_bytes != 0) {
+                budget = static_cast<double>(bo.aux_budget_bytes) < budget ? static_cast<double>(bo.aux_budget_bytes) : budget;
+            } else {
+                if (budget > static_cast<double>(total_b / 2)) budget = static_cast<double>(total_b / 2);
+                if (const char *e = getenv("GDX_AUX_BUDGET_GB")) {
+                    const double b = atof(e) * 1e9;
+                    budget = b < budget ? b : budget;
+                }
             }
+            aux_report_.budget_bytes = static_cast<uint64_t>(budget);
             auto need = [&] {
                 return static_cast<double>(jump_bytes) * static_cast<double>(n_) +
                        (top_depth ? 8.0 * static_cast<double>(1ull << (2u * top_depth)) : 0.0);
@@ -777,14 +830,15 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
                 else if (jump_bytes == 32) jump_bytes = 16;
                 else if (top_depth > 12) top_depth = 12;
                 else if (jump_bytes == 16) jump_bytes = 8;
-                else if (top_depth > 0) top_depth -= 2;
+                else if (top_depth > 0) top_depth -= top_depth >= 2 ? 2 : 1;
                 else if (jump_bytes != 0) jump_bytes = 0;
                 else break;
             }
         }
         if (jump_bytes != 0) {
             const uint32_t words = jump_bytes / 4;
-            jump_.alloc(static_cast<uint64_t>(n_) * words);
+            // padded to whole 16-byte loads (8-byte entries are read as aligned pairs)
+            jump_.alloc(div_ceil(static_cast<uint64_t>(n_) * words, 4) * 4);
             const unsigned grid = grid_for_items(n_);
             hipLaunchKernelGGL(derive_jump_level1_kernel, dim3(grid), dim3(kBlock), 0, stream, view_, jump_.get(), words);
             if (jump_bytes >= 16)
@@ -807,8 +861,51 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
             view_.top = top_.get();
             view_.top_depth = top_depth;
         }
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
     }
+}
+
+void FmIndex::rebuild_aux(const BuildOptions &opts)
+{
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    GDX_HIP(hipDeviceSynchronize());
+    cfg_.build = opts;
+    DeviceBuffer<uint8_t> d_bwt;
+    if (view_.layout == 0 && n_ > 0) {
+        const uint64_t padded = div_ceil(n_ + 1, 128) * 128;
+        // the rank lines stay; the pair lines are rebuilt from the BWT they encode
+        view_.pair_lines = nullptr;
+        pair_lines_.release();
+        jump_.release();
+        top_.release();
+        d_bwt.alloc(padded);
+        GDX_HIP(hipMemsetAsync(d_bwt.get(), 0, padded, stream));
+        hipLaunchKernelGGL(decode_bwt_kernel<LineTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt.get());
+    }
+    build_aux(d_bwt.get(), stream);
+    GDX_HIP(hipStreamSynchronize(stream));
+}
+
+void FmIndex::set_query_options(const QueryOptions &q)
+{
+    q_search_variant_.store(q.search_variant);
+    q_search_lanes_.store(q.search_lanes);
+    q_load_policy_.store(q.load_policy);
+    q_schedule_.store(q.length_schedule);
+    q_locate_variant_.store(q.locate_variant);
+}
+
+QueryOptions FmIndex::query_options() const
+{
+    QueryOptions q;
+    q.search_variant = q_search_variant_.load();
+    q.search_lanes = q_search_lanes_.load();
+    q.load_policy = q_load_policy_.load();
+    q.length_schedule = q_schedule_.load();
+    q.locate_variant = q_locate_variant_.load();
+    return q;
 }
 
 std::unique_ptr<FmIndex> FmIndex::construct_index(const uint8_t *texts_buf, bool texts_on_device,
@@ -953,6 +1050,15 @@ std::unique_ptr<FmIndex> FmIndex::from_parts(int table_kind, int block_bits, con
         fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: count / sentinel_indices do not describe a text of length n");
     for (uint64_t t = 1; t < n_texts; t++)
         if (border_keys[t] <= border_keys[t - 1]) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: border keys must be sorted");
+    // the arrays below are indexed by / produce text positions on the device: everything has to stay below n
+    for (uint64_t t = 0; t < n_texts; t++) {
+        if (sentinel_indices[t] >= n || (t > 0 && sentinel_indices[t] <= sentinel_indices[t - 1]))
+            fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: sentinel_indices must be strictly increasing and < n");
+        if (border_keys[t] >= n || border_vals[t] >= n)
+            fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: text border %llu is outside the text", (unsigned long long)t);
+    }
+    if (ix->count_host_[1] != n_texts)
+        fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: count[1] must equal the number of texts (one sentinel per text)");
 
     const int nbits = ilog2_ceil(static_cast<uint64_t>(cfg.sigma));
     const uint64_t wpb = static_cast<uint64_t>(block_bits) / 64;
@@ -987,6 +1093,23 @@ std::unique_ptr<FmIndex> FmIndex::from_parts(int table_kind, int block_bits, con
     const uint64_t n_samples = div_ceil(n, cfg.sa_rate);
     ix->sa_samples_.alloc(n_samples);
     GDX_HIP(hipMemcpy(ix->sa_samples_.get(), sa_samples, n_samples * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        // every sample is a text position; the border keys are exactly the BWT rows holding the sentinel (the keys
+        // are strictly increasing, each must hold a sentinel, and the BWT has n_texts of them: count[1] above)
+        DeviceBuffer<uint32_t> d_keys(n_texts), d_flag(1);
+        std::vector<uint32_t> keys32(n_texts);
+        for (uint64_t t = 0; t < n_texts; t++) keys32[t] = static_cast<uint32_t>(border_keys[t]);
+        GDX_HIP(hipMemcpyAsync(d_keys.get(), keys32.data(), n_texts * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        GDX_HIP(hipMemsetAsync(d_flag.get(), 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(check_parts_kernel, dim3(grid_for_items(n_samples > n_texts ? n_samples : n_texts)), dim3(kBlock),
+                           0, stream, ix->sa_samples_.get(), n_samples, static_cast<uint32_t>(n), d_keys.get(),
+                           static_cast<uint32_t>(n_texts), d_bwt.get(), d_flag.get());
+        uint32_t flag = 0;
+        GDX_HIP(hipMemcpyAsync(&flag, d_flag.get(), sizeof(flag), hipMemcpyDeviceToHost, stream));
+        GDX_HIP(hipStreamSynchronize(stream));
+        if (flag & 1u) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: a suffix array sample is >= n");
+        if (flag & 2u) fail(GDX_ERR_INVALID_ARGUMENT, "from_parts: border keys are not the BWT rows that hold the sentinel");
+    }
     ix->finish_from_bwt(d_bwt.get(), stream);
     return ix;
 }
@@ -1056,7 +1179,7 @@ int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff,
     DeviceBuffer<uint32_t> d_start(nq), d_end(nq), d_count(out_count ? nq : 0);
     DeviceBuffer<uint8_t> d_status(nq);
     launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), d_count.get(), d_status.get(),
-                  stream);
+                  stream, nullptr, nullptr, query_options());
     GDX_HIP(hipGetLastError());
     download_widened(d_start.get(), out_start, nq, stream);
     download_widened(d_end.get(), out_end, nq, stream);
@@ -1092,7 +1215,8 @@ void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint
     }
     DeviceBuffer<gdx_hit_t> d_hits(total);
     DeviceBuffer<uint8_t> ws(locate_workspace_bytes(total));
-    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream, nullptr, d_hint);
+    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream, nullptr, d_hint,
+                  query_options());
     GDX_HIP(hipGetLastError());
     GDX_HIP(hipMemcpyAsync(hits, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
@@ -1114,7 +1238,7 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
     DeviceBuffer<uint8_t> d_status(nq);
     DeviceBuffer<uint2> d_hint(nq);  // sampled rows the search passed through: no walk for those hits
     launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), nullptr, d_status.get(), stream,
-                  nullptr, d_hint.get());
+                  nullptr, d_hint.get(), query_options());
     GDX_HIP(hipGetLastError());
     std::vector<uint8_t> status(nq);
     GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
@@ -1294,16 +1418,29 @@ void FmIndex::save(const char *path) const
     out.write(planes.data(), planes.size() * sizeof(uint64_t));
 }
 
-std::unique_ptr<FmIndex> FmIndex::load(const char *path, int device_id)
+std::unique_ptr<FmIndex> FmIndex::load(const char *path, int device_id, const BuildOptions &build)
 {
     if (!path) fail(GDX_ERR_INVALID_ARGUMENT, "path is null");
     File in(path, "rb");
     FileHeader h;
     in.read(&h, sizeof(h));
     if (std::memcmp(h.magic, kMagic, 8) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "%s is not a gdx index file", path);
-    if (h.sigma < 2 || h.sigma > 256 || h.n_texts == 0 || h.n_texts > h.n || h.sa_rate == 0 ||
-        h.n_samples != div_ceil(h.n, h.sa_rate))
+    if (h.sigma < 2 || h.sigma > 256 || h.n_texts == 0 || h.n_texts > h.n || h.n > 0xffffffffull || h.sa_rate == 0 ||
+        h.sa_rate > 0xffffffffull || h.n_samples != div_ceil(h.n, h.sa_rate) ||
+        h.n_plane_words != div_ceil(h.n + 1, 64) * static_cast<uint64_t>(ilog2_ceil(static_cast<uint64_t>(h.sigma))))
         fail(GDX_ERR_INVALID_ARGUMENT, "index file header is inconsistent");
+    {
+        // the payload sizes follow from the header: compare with the file before allocating anything
+        const uint64_t payload = (static_cast<uint64_t>(h.sigma) + 1 + 3 * h.n_texts + h.n_plane_words) * sizeof(uint64_t) +
+                                 h.n_samples * sizeof(uint32_t);
+        const long at = std::ftell(in.f);
+        if (at < 0 || std::fseek(in.f, 0, SEEK_END) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "cannot seek in %s", path);
+        const long size = std::ftell(in.f);
+        if (size < 0 || std::fseek(in.f, at, SEEK_SET) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "cannot seek in %s", path);
+        if (static_cast<uint64_t>(size - at) != payload)
+            fail(GDX_ERR_INVALID_ARGUMENT, "index file is truncated or has trailing bytes (%lld payload bytes, header says %llu)",
+                 static_cast<long long>(size - at), static_cast<unsigned long long>(payload));
+    }
     IndexConfig cfg;
     std::memcpy(cfg.io_to_dense, h.io_to_dense, 256);
     cfg.sigma = h.sigma;
@@ -1312,6 +1449,7 @@ std::unique_ptr<FmIndex> FmIndex::load(const char *path, int device_id)
     cfg.lookup_depth = h.lookup_depth;
     cfg.index_width = h.index_width;
     cfg.device_id = device_id;
+    cfg.build = build;
     std::vector<uint64_t> count(h.sigma + 1), sent(h.n_texts), bk(h.n_texts), bv(h.n_texts), planes(h.n_plane_words);
     std::vector<uint32_t> samples(h.n_samples);
     in.read(count.data(), count.size() * sizeof(uint64_t));

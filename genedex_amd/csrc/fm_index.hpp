@@ -6,15 +6,33 @@
 // operations), batched by construction.  The C ABI in include/gdx.h is a thin shim over this class.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <vector>
 
 #include "build.hpp"
 #include "common.hpp"
+#include "kernels.hpp"
 #include "layout.hpp"
 
 namespace gdx {
+
+// Build-time choices of this implementation that the reference has no counterpart for (gdx_build_options_t).
+// Negative / zero = default.  The GDX_* environment variables named in fm_index.hip only override fields left
+// at their default (debugging aid).
+struct BuildOptions {
+    int pair_lines = -1;            // -1 default (on for sigma <= 8), 0 off, 1 on
+    int jump_bytes = -1;            // -1 default (32), 0 none, 8, 16, 32
+    int top_depth = -1;             // -1 default (largest even D <= 16 with 4^D <= 2n), 0 none, 1..16
+    uint64_t aux_budget_bytes = 0;  // cap for jump + top table; 0 = min(free HBM - reserve, half of the HBM)
+};
+
+// What the aux build decided (gdx_index_aux_t)
+struct AuxReport {
+    uint32_t wanted_jump_bytes = 0, wanted_top_depth = 0;  // before the budget was applied
+    uint64_t budget_bytes = 0, aux_bytes = 0;
+};
 
 struct IndexConfig {
     uint8_t io_to_dense[256];  // alphabet.rs:24-28
@@ -24,6 +42,7 @@ struct IndexConfig {
     int lookup_depth = 0;      // config.rs:76 lookup_table_depth
     int index_width = 32;      // 32 = u32, -32 = i32, 64 = i64
     int device_id = 0;
+    BuildOptions build;
 };
 
 class FmIndex {
@@ -42,7 +61,7 @@ public:
                                                uint64_t n_texts, const IndexConfig &cfg);
     // own file format around the reference's logical arrays (lib.rs:296-327 save_to_file / load_from_file)
     void save(const char *path) const;
-    static std::unique_ptr<FmIndex> load(const char *path, int device_id);
+    static std::unique_ptr<FmIndex> load(const char *path, int device_id, const BuildOptions &build = BuildOptions());
     ~FmIndex();
 
     const IndexView &view() const { return view_; }
@@ -52,6 +71,13 @@ public:
     uint64_t num_texts() const { return n_texts_; }  // lib.rs:287-289
     uint64_t device_bytes() const;
     void make_current() const;  // hipSetDevice(device_id)
+    const AuxReport &aux_report() const { return aux_report_; }
+    // kernel choices of the query calls on this handle (gdx_query_options_t); safe against concurrent queries
+    void set_query_options(const QueryOptions &q);
+    QueryOptions query_options() const;
+    // drops the pair lines / jump table / top table and builds them again with other options (bench ladder;
+    // not safe against concurrent queries)
+    void rebuild_aux(const BuildOptions &opts);
 
     // ---- host-pointer query API (each call uploads, runs, downloads, synchronises) -------------
     int cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
@@ -77,12 +103,15 @@ public:
 private:
     FmIndex() = default;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
+    void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                        gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
                        const uint2 *d_hint = nullptr) const;
 
     IndexConfig cfg_;
     BuildStats stats_;
+    AuxReport aux_report_;
+    std::atomic<int> q_search_variant_{-1}, q_search_lanes_{0}, q_load_policy_{-1}, q_schedule_{-1}, q_locate_variant_{-1};
     uint64_t n_ = 0, n_texts_ = 0;
     std::vector<uint64_t> count_host_;      // sigma+1
     std::vector<uint64_t> sentinels_host_;  // n_texts

@@ -10,13 +10,24 @@
 
 namespace gdx {
 
+// Kernel choices of a query call (gdx_query_options_t); every combination returns identical results.
+// Negative / zero = default; the GDX_* environment variables only override defaults (debugging aid).
+struct QueryOptions {
+    int search_variant = -1;   // -1 default (pair lines when present), 0 quad, 1 one lane per query, 2 pair
+    int search_lanes = 0;      // 0 default (4), 4 or 8 lanes per query in the pair kernels
+    int load_policy = -1;      // -1 default (0 plain), 1 sc1
+    int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
+    int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
+};
+
 // ---- search.hip ---------------------------------------------------------------------------
 // Backward search of nq queries (lookup jump + LF loop), one lane per query.
 // Any of out_start/out_end/out_count/out_status may be null.  d_hint (optional, uint2[nq]): locate hints for
 // launch_locate of exactly these intervals ({0xffffffff, 0} = none; see locate_queue_kernel).
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
-                   hipStream_t stream, unsigned long long *d_step_stats = nullptr, uint2 *d_hint = nullptr);
+                   hipStream_t stream, unsigned long long *d_step_stats = nullptr, uint2 *d_hint = nullptr,
+                   const QueryOptions &qo = QueryOptions());
 void set_search_variant(int v);  // 0 quad, 1 lane, 2 pair (default), -1 re-read the environment
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
                          uint64_t m, uint8_t *d_out_status, hipStream_t stream);
@@ -39,6 +50,6 @@ size_t locate_workspace_bytes(uint64_t total_hits);
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
-                   const uint2 *d_hint = nullptr);
+                   const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions());
 
 }  // namespace gdx

@@ -379,17 +379,19 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
-                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint)
+                   void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
+                   const QueryOptions &qo)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
     void *scan_temp = static_cast<char *>(d_workspace) + align_up(total_hits * sizeof(uint32_t), 256);
     size_t scan_bytes = max_scan_temp_bytes(total_hits);
 
-    static const int variant = [] {
+    static const int env_variant = [] {
         const char *e = getenv("GDX_LOCATE_VARIANT");
         return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
     }();
+    const int variant = (qo.locate_variant >= 0 && qo.locate_variant <= 2) ? qo.locate_variant : env_variant;
     if (variant != 0) {  // the lock-step variants map hit slots to queries with head marks + a max-scan over all hits
         GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,

@@ -784,9 +784,10 @@ static int search_variant()
 
 void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq,
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
-                   hipStream_t stream, unsigned long long *d_step_stats, uint2 *d_hint)
+                   hipStream_t stream, unsigned long long *d_step_stats, uint2 *d_hint, const QueryOptions &qo)
 {
     if (nq == 0) return;
+    const int variant = qo.search_variant >= 0 ? qo.search_variant : search_variant();
     // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
     // profiles/r01/search_variants.md): many short-lived blocks beat a resident grid -- 65536 blocks: 78 ms,
     // 1792 (7 per CU): 89 ms, 2048 (8 per CU, all resident, lock-step): 112 ms.  So: about 48 queries per
@@ -804,13 +805,14 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
         return static_cast<unsigned>(blocks);
     };
-    if (ix.layout == 0 && search_variant() == 2 && ix.pair_lines != nullptr) {
+    if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
         // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
-        // GDX_SEARCH_LANES overrides
-        static const int lanes = [] {
+        // QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
+        static const int env_lanes = [] {
             const char *e = getenv("GDX_SEARCH_LANES");
             return (e && atoi(e) == 8) ? 8 : 4;
         }();
+        const int lanes = (qo.search_lanes == 4 || qo.search_lanes == 8) ? qo.search_lanes : env_lanes;
         // Every block searches contiguous ranges of `range` queries (a multiple of 64, at most kMaxRange): about
         // 48 rounds per group at large batches, 1792+ blocks at small ones; GDX_SEARCH_GRID = number of blocks.
         uint64_t per_block = (nq + 1791) / 1792;
@@ -823,16 +825,18 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         // +5 % while the first levels of the search were cache-resident pair lines; with the top table every load
         // is a DRAM miss and plain loads measure 3 % faster.  GDX_LOAD_POLICY=0|1 = plain, sc1 (nt and sc0 sc1 were
         // tried on the pair lines too: plain 101.5, sc1 95.7, nt 98.7, sc0 sc1 96.5 ms at the time; search_variants.md).
-        static const int policy = [] {
+        static const int env_policy = [] {
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 0;
         }();
+        const int policy = qo.load_policy >= 0 ? qo.load_policy : env_policy;
         // Ranges whose query lengths are spread out are searched in length order (order_range_by_length);
         // GDX_SEARCH_SCHEDULE=0 keeps the query order.
-        static const int schedule = [] {
+        static const int env_schedule = [] {
             const char *e = getenv("GDX_SEARCH_SCHEDULE");
             return (e && e[0] == '0') ? 0 : 1;
         }();
+        const int schedule = qo.length_schedule >= 0 ? (qo.length_schedule != 0) : env_schedule;
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
                        d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule, d_hint)
@@ -854,7 +858,7 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         }
 #undef GDX_PAIR_LAUNCH_W
 #undef GDX_PAIR_LAUNCH
-    } else if (ix.layout == 0 && search_variant() != 1) {
+    } else if (ix.layout == 0 && variant != 1) {
         if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));  // only the pair kernels hint
         const unsigned blocks = group_grid(kBlock / 4);
         hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(blocks), dim3(kBlock), lds_pad,

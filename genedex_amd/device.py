@@ -37,16 +37,20 @@ def synth_text(total: int, seed: int = 42, n_per_million: int = 10_000, device="
 
 
 def build_index_from_device_text(io_text: torch.Tensor, text_lengths, alphabet: Alphabet, sa_rate=4, lookup_depth=0,
-                                 index_storage="u32") -> FmIndex:
+                                 index_storage="u32", options=None) -> FmIndex:
     lib = _lib.load()
     toff = np.zeros(len(text_lengths) + 1, dtype=np.uint64)
     np.cumsum(np.asarray(text_lengths, dtype=np.uint64), out=toff[1:])
     tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
     handle = C.c_void_p()
     torch.cuda.synchronize()
-    st = lib.gdx_index_build_dev(_ptr(io_text), _p(toff, u64p), len(text_lengths), _p(tab, u8p),
-                                 alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(), sa_rate,
-                                 lookup_depth, _WIDTHS[index_storage], io_text.device.index or 0, C.byref(handle))
+    from .index import build_options
+
+    opts = options if options is not None else build_options()
+    st = lib.gdx_index_build_dev_ex(_ptr(io_text), _p(toff, u64p), len(text_lengths), _p(tab, u8p),
+                                    alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(), sa_rate,
+                                    lookup_depth, _WIDTHS[index_storage], io_text.device.index or 0, C.byref(opts),
+                                    C.byref(handle))
     _lib.check(st)
     return FmIndex(handle, alphabet)
 
@@ -160,7 +164,11 @@ class DeviceEngine:
 
         out = (ctypes.c_uint32 * 4)()
         _lib.check(self.lib.gdx_index_aux_info(self.h, out))
-        return {"pair_lines": bool(out[0]), "jump_entry_bytes": int(out[1]), "top_table_depth": int(out[2])}
+        a = self.index.aux()
+        return {"pair_lines": bool(out[0]), "jump_entry_bytes": int(out[1]), "top_table_depth": int(out[2]),
+                "aux_bytes": a["aux_bytes"], "aux_budget_bytes": a["aux_budget_bytes"],
+                "shrunk_by_budget": (a["wanted_jump_entry_bytes"], a["wanted_top_table_depth"])
+                != (a["jump_entry_bytes"], a["top_table_depth"])}
 
     def search_lf_steps(self, q: DeviceQueries) -> int:
         return self.search_step_stats(q)[0]

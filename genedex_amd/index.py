@@ -41,6 +41,21 @@ def pack_queries(queries):
 _WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
 
 
+def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None):
+    """gdx_build_options_t (include/gdx.h); None = the library's default for that field."""
+    o = _lib.BuildOptions()
+    _lib.load().gdx_build_options_init(C.byref(o))
+    if pair_lines is not None:
+        o.pair_lines = int(bool(pair_lines))
+    if jump_entry_bytes is not None:
+        o.jump_entry_bytes = int(jump_entry_bytes)
+    if top_table_depth is not None:
+        o.top_table_depth = int(top_table_depth)
+    if aux_budget_bytes is not None:
+        o.aux_budget_bytes = int(aux_budget_bytes)
+    return o
+
+
 class FmIndexConfig:
     """Builder for the index (src/config.rs:17-82).  `index_storage` is the reference's generic `I`."""
 
@@ -51,6 +66,7 @@ class FmIndexConfig:
         self._sa_rate = 4    # config.rs:75
         self._depth = 0      # config.rs:76
         self._device = 0
+        self._build = {}     # gdx_build_options_t fields (this implementation's own knobs)
 
     def suffix_array_sampling_rate(self, rate: int) -> "FmIndexConfig":
         assert rate > 0  # config.rs:28
@@ -70,6 +86,14 @@ class FmIndexConfig:
         self._device = int(device_id)
         return self
 
+    def acceleration_structures(self, pair_lines=None, jump_entry_bytes=None, top_table_depth=None,
+                                aux_budget_bytes=None) -> "FmIndexConfig":
+        """gdx_build_options_t: which derived structures the index carries beside the reference's arrays
+        (results are identical with any combination); None keeps the default."""
+        self._build = dict(pair_lines=pair_lines, jump_entry_bytes=jump_entry_bytes, top_table_depth=top_table_depth,
+                           aux_budget_bytes=aux_budget_bytes)
+        return self
+
     def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":
         """src/config.rs:63-69"""
         texts = [bytes(t) for t in texts]
@@ -77,10 +101,11 @@ class FmIndexConfig:
         lib = _lib.load()
         handle = C.c_void_p()
         tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
-        st = lib.gdx_index_build(_p(tbuf, u8p), _p(toff, u64p), len(texts), _p(tab, u8p),
-                                 alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
-                                 self._sa_rate, self._depth, _WIDTHS[self.index_storage], self._device,
-                                 C.byref(handle))
+        opts = build_options(**self._build)
+        st = lib.gdx_index_build_ex(_p(tbuf, u8p), _p(toff, u64p), len(texts), _p(tab, u8p),
+                                    alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
+                                    self._sa_rate, self._depth, _WIDTHS[self.index_storage], self._device,
+                                    C.byref(opts), C.byref(handle))
         _lib.check(st)
         return FmIndex(handle, alphabet)
 
@@ -107,7 +132,7 @@ class FmIndex:
     @classmethod
     def from_parts(cls, count, interleaved_blocks, n, sa_samples, sa_rate, border_keys, border_vals,
                    sentinel_indices, alphabet: Alphabet, lookup_depth=0, index_storage="u32", device=0,
-                   table_kind="condensed", block_bits=64):
+                   table_kind="condensed", block_bits=64, options=None):
         """Import of the reference's logical arrays (include/gdx.h gdx_index_from_parts[_ex]); table_kind
         'condensed' | 'flat' and block_bits 64 | 512 select one of the reference's four table variants."""
         lib = _lib.load()
@@ -119,23 +144,56 @@ class FmIndex:
         si = np.ascontiguousarray(sentinel_indices, dtype=np.uint64)
         tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
         handle = C.c_void_p()
-        st = lib.gdx_index_from_parts_ex({"condensed": 0, "flat": 1}[table_kind], int(block_bits),
-                                         _p(count, u64p), _p(blocks, u64p), int(n), _p(sa_samples, u32p), int(sa_rate),
-                                      _p(bk, u64p), _p(bv, u64p), _p(si, u64p), si.size, _p(tab, u8p),
-                                      alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
-                                      int(lookup_depth), _WIDTHS[index_storage], int(device), C.byref(handle))
+        opts = options if options is not None else build_options()
+        st = lib.gdx_index_from_parts_ex2({"condensed": 0, "flat": 1}[table_kind], int(block_bits),
+                                          _p(count, u64p), _p(blocks, u64p), int(n), _p(sa_samples, u32p), int(sa_rate),
+                                          _p(bk, u64p), _p(bv, u64p), _p(si, u64p), si.size, _p(tab, u8p),
+                                          alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(),
+                                          int(lookup_depth), _WIDTHS[index_storage], int(device), C.byref(opts),
+                                          C.byref(handle))
         _lib.check(st)
         return cls(handle, alphabet)
+
+    # ---- this implementation's own knobs (include/gdx.h gdx_index_aux / gdx_query_options_t) ------
+    def aux(self) -> dict:
+        a = _lib.IndexAux()
+        _lib.check(self._lib.gdx_index_aux(self._h, C.byref(a)))
+        return {f: int(getattr(a, f)) for f, _ in a._fields_ if f != "reserved"}
+
+    def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
+                          locate_kernel=None) -> None:
+        """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
+        o = _lib.QueryOptions()
+        self._lib.gdx_query_options_init(C.byref(o))
+        names = {"pair": 2, "quad": 0, "lane": 1}
+        if search_kernel is not None:
+            o.search_kernel = names.get(search_kernel, search_kernel)
+        if search_lanes is not None:
+            o.search_lanes = int(search_lanes)
+        if load_policy is not None:
+            o.load_policy = int(load_policy)
+        if length_schedule is not None:
+            o.length_schedule = int(length_schedule)
+        if locate_kernel is not None:
+            o.locate_kernel = {"queue": 0, "lane": 1, "pair": 2}.get(locate_kernel, locate_kernel)
+        _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
+
+    def rebuild_aux(self, **kw) -> None:
+        """bench only (gdx_bench.h): rebuild pair lines / jump / top tables with other build options"""
+        o = build_options(**kw)
+        _lib.check(self._lib.gdx_index_rebuild_aux(self._h, C.byref(o)))
+        _lib.check(self._lib.gdx_index_info(self._h, C.byref(self.info)))
 
     # ---- lib.rs:296-327 (own file format, see include/gdx.h) -------------------------------------
     def save_to_file(self, path) -> None:
         _lib.check(self._lib.gdx_index_save(self._h, str(path).encode()))
 
     @classmethod
-    def load_from_file(cls, path, alphabet: Alphabet, device=0) -> "FmIndex":
+    def load_from_file(cls, path, alphabet: Alphabet, device=0, options=None) -> "FmIndex":
         lib = _lib.load()
         handle = C.c_void_p()
-        _lib.check(lib.gdx_index_load(str(path).encode(), int(device), C.byref(handle)))
+        opts = options if options is not None else build_options()
+        _lib.check(lib.gdx_index_load_ex(str(path).encode(), int(device), C.byref(opts), C.byref(handle)))
         ix = cls(handle, alphabet)
         if ix.info.sigma != alphabet.num_dense_symbols():
             raise ValueError("the file was written for a different alphabet")

@@ -119,6 +119,70 @@ int gdx_index_from_parts_ex(int table_kind, int block_bits, const uint64_t *coun
                             int sigma, int n_searchable, int lookup_depth, int index_width, int device_id,
                             gdx_index_t **out);
 
+/* ---- build options (FmIndexConfig is a value in the reference, config.rs:17-82; the knobs below are this
+ * implementation's own and have no counterpart there).  Besides the reference's arrays an index may carry three
+ * derived acceleration structures: pair lines (two LF steps per 128-byte fetch, 16 bits per
+ * symbol), a jump table (8 to 32 LF steps of a narrow interval per fetch, 8 to 32 bytes per symbol) and a top table
+ * (the first D symbols of a DNA query in one fetch, 8 * 4^D bytes).  Results are identical with any combination.
+ * A field left at -1 / 0 takes its default; the GDX_* environment variables documented in DESIGN.md only override
+ * fields left at their default (debugging aid).  Initialise with gdx_build_options_init(). */
+typedef struct {
+    uint32_t struct_size;      /* sizeof(gdx_build_options_t), lets the struct grow compatibly         */
+    int32_t pair_lines;        /* -1 default (on when sigma <= 8), 0 off, 1 on                         */
+    int32_t jump_entry_bytes;  /* -1 default (32), 0 no jump table, 8, 16 or 32                        */
+    int32_t top_table_depth;   /* -1 default (largest even D <= 16 with 4^D <= 2 n), 0 none, 1..16     */
+    uint64_t aux_budget_bytes; /* cap for jump + top table together; 0 = default: free device memory
+                                  minus a reserve for query batches, at most half of the device memory.
+                                  Tables that do not fit shrink (gdx_index_aux reports what was built). */
+} gdx_build_options_t;
+void gdx_build_options_init(gdx_build_options_t *opts);
+
+/* gdx_index_build / gdx_index_build_dev / gdx_index_from_parts_ex / gdx_index_load with build options
+ * (opts == NULL: defaults, i.e. exactly the plain calls) */
+int gdx_index_build_ex(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                       const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                       int index_width, int device_id, const gdx_build_options_t *opts, gdx_index_t **out);
+int gdx_index_build_dev_ex(const void *d_texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                           const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate,
+                           int lookup_depth, int index_width, int device_id, const gdx_build_options_t *opts,
+                           gdx_index_t **out);
+int gdx_index_from_parts_ex2(int table_kind, int block_bits, const uint64_t *count,
+                             const uint64_t *interleaved_blocks, uint64_t n, const uint32_t *sa_samples,
+                             uint64_t sa_rate, const uint64_t *border_keys, const uint64_t *border_vals,
+                             const uint64_t *sentinel_indices, uint64_t n_texts, const uint8_t *io_to_dense,
+                             int sigma, int n_searchable, int lookup_depth, int index_width, int device_id,
+                             const gdx_build_options_t *opts, gdx_index_t **out);
+int gdx_index_load_ex(const char *path, int device_id, const gdx_build_options_t *opts, gdx_index_t **out);
+
+/* what an index carries beside the reference's arrays, and what was asked for before the budget was applied */
+typedef struct {
+    int32_t pair_lines;              /* 1 if present                                  */
+    int32_t jump_entry_bytes;        /* 0 = no jump table                             */
+    int32_t top_table_depth;         /* 0 = no top table                              */
+    int32_t wanted_jump_entry_bytes; /* != jump_entry_bytes: the budget shrank it     */
+    int32_t wanted_top_table_depth;
+    int32_t reserved;
+    uint64_t aux_bytes;              /* jump + top table                              */
+    uint64_t aux_budget_bytes;       /* the budget that applied                       */
+} gdx_index_aux_t;
+int gdx_index_aux(const gdx_index_t *ix, gdx_index_aux_t *out);
+
+/* ---- query options: which kernel variant the query calls on this handle use.  Every combination returns
+ * identical results (the parity tests run them all); the defaults are the measured fastest.  The setting is
+ * per handle, takes effect for calls that start afterwards and may be changed while other threads query. */
+typedef struct {
+    uint32_t struct_size;    /* sizeof(gdx_query_options_t)                                                   */
+    int32_t search_kernel;   /* -1 default (2 when pair lines exist), 0 four lanes per query on rank lines,
+                                1 one lane per query on rank lines, 2 pair lines + jump / top tables          */
+    int32_t search_lanes;    /* 0 default (4), 4 or 8 lanes per query in the pair-line kernel                 */
+    int32_t load_policy;     /* -1 default (0 plain loads), 1 = sc1 (no L1 allocation)                        */
+    int32_t length_schedule; /* -1 default (1: a block orders its queries by length when they differ), 0 off  */
+    int32_t locate_kernel;   /* -1 default (0 queue kernel), 1 one lane per hit, 2 eight lanes per hit        */
+} gdx_query_options_t;
+void gdx_query_options_init(gdx_query_options_t *opts);
+int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);
+int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out);
+
 /* Persistence (FmIndex::save_to_file / load_from_file, lib.rs:296-327).  The reference's wire format belongs to
  * the un-vendored `savefile` crate and no test of the reference inspects it, so this is an own format: a small
  * header followed by the index in the REFERENCE's logical layout (count, Condensed/Block64 bit planes, sampled
@@ -186,7 +250,8 @@ int gdx_cursor_locate_many(const gdx_index_t *ix, const uint64_t *start, const u
 /* ---------------------------------------------------------------------------------------
  * device-resident entry points: all pointers are DEVICE pointers on the handle's GPU, work
  * is enqueued on `stream` (hipStream_t) and the call returns without synchronising.
- * d_qbuf must be 8-byte aligned and its allocation padded to a multiple of 8 bytes.        */
+ * d_qbuf must be 8-byte aligned and its allocation padded to a multiple of 8 bytes.
+ * The calls make the handle's device current for their duration and restore the caller's.   */
 int gdx_cursors_for_many_queries_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff /*u64*/,
                                      uint64_t nq, void *d_out_start /*u32*/, void *d_out_end /*u32*/,
                                      void *d_out_status /*u8 or NULL*/, void *stream);
@@ -218,8 +283,11 @@ int gdx_cursors_for_many_queries_hint_dev(const gdx_index_t *ix, const void *d_q
 int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
                                   const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
                                   const void *d_hint, void *stream);
+/* Unlike gdx_rank_many, which returns GDX_ERR_INVALID_ARGUMENT, the device form cannot report an argument
+ * error without synchronising: an entry with symbol >= sigma or idx > n yields d_out[i] = 0 and, if d_error
+ * (u32, may be NULL) is given, *d_error is set to 1 (the caller zeroes it beforehand). */
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx /*u32*/, uint64_t m,
-                      void *d_out /*u32*/, void *stream);
+                      void *d_out /*u32*/, void *d_error /*u32 or NULL*/, void *stream);
 
 /* ---- query / text ingestion (host only) ---------------------------------------------------------------------
  * Streaming FASTA / FASTQ reader that fills the layout the calls above take: sequences appended to qbuf, offsets

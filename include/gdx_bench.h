@@ -71,6 +71,10 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
  * out[2] = depth of the top table (0 = none), out[3] = reserved (0). */
 int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4]);
 
+/* Drops the pair lines / jump table / top table of an index and builds them again with other options, without
+ * repeating the suffix sort (the ladder of design points in bench.py).  NOT safe against concurrent queries. */
+int gdx_index_rebuild_aux(gdx_index_t *ix, const gdx_build_options_t *opts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,11 +12,22 @@ pytestmark = pytest.mark.gpu
 WIDTH = {"i32": -32, "u32": 32, "i64": 64}
 
 
-def gpu_index(texts, a, sa_rate=4, depth=0, storage="u32"):
+# build / query options (gdx_build_options_t, gdx_query_options_t) applied to every index gpu_index() makes;
+# the search_variant fixture sweeps them
+_BUILD_OPTIONS = {}
+_QUERY_OPTIONS = {}
+
+
+def gpu_index(texts, a, sa_rate=4, depth=0, storage="u32", **build_options):
     from genedex_amd import FmIndexConfig
 
-    return (FmIndexConfig(storage).suffix_array_sampling_rate(sa_rate).lookup_table_depth(depth)
-            .construct_index(texts, a))
+    opts = dict(_BUILD_OPTIONS)
+    opts.update(build_options)
+    ix = (FmIndexConfig(storage).suffix_array_sampling_rate(sa_rate).lookup_table_depth(depth)
+          .acceleration_structures(**opts).construct_index(texts, a))
+    if _QUERY_OPTIONS:
+        ix.set_query_options(**_QUERY_OPTIONS)
+    return ix
 
 
 def cpu_index(texts, a, sa_rate=4, depth=0, storage="u32"):
@@ -25,7 +36,8 @@ def cpu_index(texts, a, sa_rate=4, depth=0, storage="u32"):
 
 
 def both(texts, a, **kw):
-    return gpu_index(texts, a, **kw), cpu_index(texts, a, **kw)
+    cpu_kw = {k: v for k, v in kw.items() if k in ("sa_rate", "depth", "storage")}
+    return gpu_index(texts, a, **kw), cpu_index(texts, a, **cpu_kw)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -191,41 +203,33 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
     return [qs[i] for i in order]
 
 
-_VARIANT_ENV = {
-    # name: (kernel variant, GDX_JUMP_BYTES, GDX_TOP_DEPTH)
-    "pair": (2, None, None),            # defaults: 32-byte jump entries, top table sized from the text
-    "pair-jump16": (2, "16", None),     # 16-byte jump entries
-    "pair-narrow": (2, "8", "0"),       # 8-byte jump entries, no top table
-    "pair-top4": (2, None, "4"),        # forced top depths: on these small texts most deep entries are empty,
-    "pair-top9": (2, None, "9"),        # so the fall-back to the ordinary path runs constantly
-    "quad": (0, None, None),
-    "lane": (1, None, None),
+_VARIANTS = {
+    # name: (query options, build options)
+    "pair": (dict(search_kernel="pair"), {}),  # defaults: 32-byte jump entries, top table sized from the text
+    "pair-8lanes": (dict(search_kernel="pair", search_lanes=8), {}),
+    "pair-jump16": (dict(search_kernel="pair"), dict(jump_entry_bytes=16)),
+    "pair-narrow": (dict(search_kernel="pair"), dict(jump_entry_bytes=8, top_table_depth=0)),
+    # forced top depths: on these small texts most deep entries are empty, so the fall-back to the ordinary
+    # path runs constantly
+    "pair-top4": (dict(search_kernel="pair"), dict(top_table_depth=4)),
+    "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
+    "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
+    "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
+    "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 
 
-@pytest.fixture(params=list(_VARIANT_ENV))
+@pytest.fixture(params=list(_VARIANTS))
 def search_variant(request):
     """Every search kernel variant and index acceleration structure must give the same answers."""
-    import os
-
-    from genedex_amd import _lib
-
-    lib = _lib.load()
-    variant, wide, top = _VARIANT_ENV[request.param]
-    lib.gdx_debug_set_search_variant(variant)
-    saved = {k: os.environ.get(k) for k in ("GDX_JUMP_BYTES", "GDX_TOP_DEPTH")}
-    for k, v in (("GDX_JUMP_BYTES", wide), ("GDX_TOP_DEPTH", top)):
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    query, build = _VARIANTS[request.param]
+    _QUERY_OPTIONS.clear()
+    _QUERY_OPTIONS.update(query)
+    _BUILD_OPTIONS.clear()
+    _BUILD_OPTIONS.update(build)
     yield request.param
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
-    lib.gdx_debug_set_search_variant(2)
+    _QUERY_OPTIONS.clear()
+    _BUILD_OPTIONS.clear()
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -455,29 +459,20 @@ def test_long_repeats_and_long_queries(search_variant):
     assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
 
 
-@pytest.mark.parametrize("budget_gb,want", [("0", (0, 0)), ("0.0003", None), (None, (32, None))])
-def test_acceleration_structures_shrink_to_the_memory_budget(budget_gb, want):
-    """The jump and top tables are optional: they shrink to what GDX_AUX_BUDGET_GB (or the free HBM) allows and the
-    answers do not change."""
-    import os
-
+@pytest.mark.parametrize("budget,want", [(1, (0, 0)), (300_000, None), (None, (32, None))])
+def test_acceleration_structures_shrink_to_the_memory_budget(budget, want):
+    """The jump and top tables are optional: they shrink to gdx_build_options_t.aux_budget_bytes (or the free HBM) and
+    the answers do not change; gdx_index_aux reports what was wanted and what was built."""
     from genedex_amd.device import DeviceEngine
 
     rng = np.random.default_rng(41)
     a = alph.ascii_dna_with_n()
     texts = random_texts(rng, len_max=20000, symbols=b"ACGT")
-    old = os.environ.get("GDX_AUX_BUDGET_GB")
-    if budget_gb is None:
-        os.environ.pop("GDX_AUX_BUDGET_GB", None)
-    else:
-        os.environ["GDX_AUX_BUDGET_GB"] = budget_gb
-    try:
-        g, c = both(texts, a)
-    finally:
-        if old is None:
-            os.environ.pop("GDX_AUX_BUDGET_GB", None)
-        else:
-            os.environ["GDX_AUX_BUDGET_GB"] = old
+    g, c = both(texts, a, aux_budget_bytes=budget)
+    full = g.aux()
+    assert full["wanted_jump_entry_bytes"] == 32
+    assert (budget is None) == ((full["wanted_jump_entry_bytes"], full["wanted_top_table_depth"])
+                                == (full["jump_entry_bytes"], full["top_table_depth"]))
     aux = DeviceEngine(g).aux_info()
     n = g.total_text_len()
     if want is not None:
@@ -487,7 +482,7 @@ def test_acceleration_structures_shrink_to_the_memory_budget(budget_gb, want):
             assert aux["top_table_depth"] == want[1]
     else:  # 300 kB: whatever was kept fits
         used = aux["jump_entry_bytes"] * n + (8 * 4 ** aux["top_table_depth"] if aux["top_table_depth"] else 0)
-        assert used <= 300_000
+        assert used <= 300_000 and full["aux_bytes"] <= 300_016  # allocation padded to 16 bytes
     qs = mixed_queries(rng, texts, 600, 300, 70)
     qbuf, qoff = pack_queries(qs)
     s_, e_, st = g.cursors_raw(qbuf, qoff)
