@@ -65,6 +65,10 @@ def main():
                          "20.8 instead of 21.2 ms per step, both kernels contend for DRAM requests; off by default so "
                          "that the per-kernel durations stay those of the kernels alone)")
     ap.add_argument("--verify-hits", type=int, default=1_000_000)
+    ap.add_argument("--path", default="records", choices=["records", "arrays"],
+                    help="records: fused count + locate over 16-byte search records (gdx_locate_many_*_dev, lazy "
+                         "tails); arrays: exact intervals + hints (gdx_cursors_for_many_queries_hint_dev + "
+                         "gdx_locate_intervals_hint_dev), the round-1 path")
     ap.add_argument("--secondary-depth", type=int, default=10,
                     help="N=1 only: after the headline run (reference-default lookup depth), rebuild the index with "
                          "this lookup-table depth, time the same step and check the counts are identical; 0 = skip")
@@ -129,13 +133,40 @@ def main():
 
     eng = DeviceEngine(index)
     do_locate = args.op == "count+locate"
+    use_rec = args.path == "records" and do_locate
     out = eng.alloc_outputs(nq, hint=do_locate and not args.no_hint)
+    if use_rec:
+        out["rec"] = eng.alloc_records(nq)
+
+    def run_search(o):
+        if use_rec:
+            eng.locate_search(queries, o["rec"])
+        else:
+            eng.search(queries, o)
+
+    def run_offsets(o):
+        if use_rec:
+            eng.locate_offsets(o["rec"], nq, o["hit_offsets"])
+        else:
+            eng.hit_offsets(o, nq)
+
+    def run_locate(o, h, ws):
+        if use_rec:
+            eng.locate_hits(o["rec"], nq, o["hit_offsets"], total_hits, h, ws)
+        else:
+            eng.locate(o, nq, total_hits, h, ws)
 
     # sizing pass (also the first warm-up of the kernels)
-    eng.search(queries, out)
-    eng.hit_offsets(out, nq)
+    run_search(out)
+    run_offsets(out)
     torch.cuda.synchronize()
     total_hits = int(out["hit_offsets"][nq].item())
+    if use_rec:
+        cnt32 = torch.empty(nq, dtype=torch.int32, device=dev)
+        eng.unpack_records(out["rec"], nq, cnt32, out["status"])
+        out["start"].zero_()
+        out["end"].copy_(cnt32)  # end - start = count for the checks below (the exact intervals are not computed)
+        del cnt32
     n_status = int((out["status"] != 0).sum().item())
     hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
     workspace = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
@@ -163,8 +194,10 @@ def main():
         hits = torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev)
         slots = [(out, hits, counts, workspace)]
     if world > 1 or overlap:
-        slots.append((eng.alloc_outputs(nq, hint="hint" in out), torch.zeros_like(hits), torch.empty_like(counts),
-                      torch.empty_like(workspace)))
+        o2 = eng.alloc_outputs(nq, hint="hint" in out)
+        if use_rec:
+            o2["rec"] = eng.alloc_records(nq)
+        slots.append((o2, torch.zeros_like(hits), torch.empty_like(counts), torch.empty_like(workspace)))
     if world > 1:
         gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for (_, h, c, _w) in slots], dst=0)
     main_stream = torch.cuda.current_stream()
@@ -182,7 +215,7 @@ def main():
             main_stream.wait_event(slot_free[slot])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        eng.search(queries, o)
+        run_search(o)
         b.record()
         if record:
             ev_search.append((a, b))
@@ -190,15 +223,18 @@ def main():
             if overlap:
                 side_stream.wait_event(b)
             if do_locate:
-                eng.hit_offsets(o, nq)
+                run_offsets(o)
                 c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 c.record()
-                eng.locate(o, nq, total_hits, h, ws)
+                run_locate(o, h, ws)
                 d.record()
                 if record:
                     ev_locate.append((c, d))
             if gather:
-                cnt.copy_(torch.sub(o["end"], o["start"]))  # copy_ narrows to the gather's count type
+                if use_rec:
+                    cnt.copy_(torch.sub(o["rec"][:nq, 1], o["rec"][:nq, 0]))
+                else:
+                    cnt.copy_(torch.sub(o["end"], o["start"]))  # copy_ narrows to the gather's count type
                 gather.submit(slot)
             if overlap:
                 slot_free[slot] = torch.cuda.Event()
@@ -249,7 +285,14 @@ def main():
     roofline.update(pmc_traffic(kernel_name, args, wl, nq))
     locate_roofline = None
     if do_locate and total_hits:
-        walk_steps = eng.locate_walk_steps(out, nq, total_hits, hits, workspace)
+        acct = out
+        if use_rec:  # the accounting pass counts the reference's walk steps from the exact intervals, without hints
+            acct = eng.alloc_outputs(nq, hint=False)
+            eng.search(queries, acct)
+            eng.hit_offsets(acct, nq)
+        walk_steps = eng.locate_walk_steps(acct, nq, total_hits, hits, workspace)
+        if use_rec:
+            del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
         locate_roofline = {"bound": "hbm", "kernel": "locate_queue_kernel<LineTable> (+ slot -> query map)",
                            "achieved": locate_bytes / (locate_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -124,6 +124,12 @@ SIGNATURES = {
     "gdx_locate_intervals_hint_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_cursors_for_many_queries_hint_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp],
     "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_search_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_locate_many_offsets_dev": [vp, vp, C.c_uint64, vp, vp],
+    "gdx_locate_many_hits_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_unpack_dev": [vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],
+    "gdx_cursor_extend_front_strings": [vp, u64p, u64p, u8p, u64p, C.c_uint64, u8p],
     # gdx_bench.h
     "gdx_index_build_stats": [vp, C.POINTER(BuildStats)],
     "gdx_synth_text_dev": [vp, C.c_uint64, C.c_uint64, C.c_uint32, vp],

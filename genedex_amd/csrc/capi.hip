@@ -552,9 +552,15 @@ int gdx_count_many_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_
         const gdx::FmIndex &f = deref(ix);
         if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
         DeviceGuard guard(f.config().device_id);
-        gdx::launch_search(f.view(), static_cast<const uint8_t *>(d_qbuf), static_cast<const uint64_t *>(d_qoff), nq,
-                           nullptr, nullptr, static_cast<uint32_t *>(d_out_counts),
-                           static_cast<uint8_t *>(d_out_status), as_stream(stream), nullptr, nullptr, f.query_options());
+        gdx::SearchCall c;  // counts only: the search may end with the lazy tail (mode 1)
+        c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = c.d_qbeg + 1;
+        c.nq = nq;
+        c.d_count = static_cast<uint32_t *>(d_out_counts);
+        c.d_status = static_cast<uint8_t *>(d_out_status);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -616,6 +622,132 @@ int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, co
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
+}
+
+namespace {
+__global__ __launch_bounds__(256) void unpack_records_kernel(const uint4 *__restrict__ rec, uint64_t nq,
+                                                             uint32_t *__restrict__ counts, uint8_t *__restrict__ status)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; q < nq; q += stride) {
+        const uint4 r = rec[q];
+        if (counts) counts[q] = r.y - r.x;
+        if (status) status[q] = static_cast<uint8_t>(r.w >> 24);
+    }
+}
+
+void check_records(const void *d_records)
+{
+    if (!d_records || (reinterpret_cast<uintptr_t>(d_records) & 15u) != 0)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_records must be a non-null 16-byte aligned device pointer");
+}
+}  // namespace
+
+int gdx_locate_many_search_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                               void *d_records, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = c.d_qbeg + 1;
+        c.nq = nq;
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_offsets_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_hit_offsets,
+                                void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        const size_t tb = gdx::hit_offsets_rec_temp_bytes(nq);
+        void *temp = gdx::stream_scratch(as_stream(stream), 10, tb ? tb : 1);
+        gdx::launch_hit_offsets_rec(static_cast<const uint4 *>(d_records), nq, static_cast<uint64_t *>(d_hit_offsets),
+                                    temp, tb, as_stream(stream));
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                             uint64_t total_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits,
+                           d_hits, false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
+                           static_cast<const uint4 *>(d_records));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
+                               void *d_out_status, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (nq == 0) return (int)GDX_OK;
+        DeviceGuard guard(f.config().device_id);
+        const uint64_t blocks = (nq + 255) / 256;
+        hipLaunchKernelGGL(unpack_records_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                           as_stream(stream), static_cast<const uint4 *>(d_records), nq,
+                           static_cast<uint32_t *>(d_out_counts), static_cast<uint8_t *>(d_out_status));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start, void *d_end, const void *d_qbuf,
+                                        const void *d_qbeg, const void *d_qend, uint64_t m, void *d_status,
+                                        const void *d_active_in, const void *d_n_active_in, void *d_active_out,
+                                        void *d_n_active_out, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        if (m && (!d_start || !d_end || !d_qbeg || !d_qend)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+        if ((d_active_out == nullptr) != (d_n_active_out == nullptr) || (d_active_in != nullptr && d_n_active_in == nullptr))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "active lists need their counters");
+        if (m >= 0xffffffffull) gdx::fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 cursors in one call");
+        DeviceGuard guard(f.config().device_id);
+        if (d_n_active_out) GDX_HIP(hipMemsetAsync(d_n_active_out, 0, sizeof(uint32_t), as_stream(stream)));
+        gdx::SearchCall c;
+        c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qbeg);
+        c.d_qend = static_cast<const uint64_t *>(d_qend);
+        c.nq = m;
+        c.d_start = static_cast<uint32_t *>(d_start);
+        c.d_end = static_cast<uint32_t *>(d_end);
+        c.d_status = static_cast<uint8_t *>(d_status);
+        c.mode = 2;
+        c.cursors.active_in = static_cast<const uint32_t *>(d_active_in);
+        c.cursors.n_active_in = static_cast<const uint32_t *>(d_n_active_in);
+        c.cursors.active_out = static_cast<uint32_t *>(d_active_out);
+        c.cursors.n_active_out = static_cast<uint32_t *>(d_n_active_out);
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_cursor_extend_front_strings(const gdx_index_t *ix, uint64_t *start, uint64_t *end, const uint8_t *qbuf,
+                                    const uint64_t *qoff, uint64_t m, uint8_t *status)
+{
+    return guarded([&] { return deref(ix).cursor_extend_front_strings(start, end, qbuf, qoff, m, status); });
 }
 
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx, uint64_t m, void *d_out,

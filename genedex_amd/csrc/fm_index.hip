@@ -254,12 +254,24 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
     }
 }
 
-// Jump table (search.hip, IndexView::jump): entry i has levels j = 1 .. bytes / 8, level j = {row after 8j LF steps
-// from row i, nibble codes of the symbols of steps 8j-7 .. 8j (nibble 7 = the first of them)}.  A walk that meets a
-// sentinel leaves code 0 in that level and all later ones, which no valid query (all nibbles non-zero) can equal.
-// Level 1 comes from eight LF steps on the rank lines; level 2 of entry i is level 1 of the entry of its level-1
-// row; levels 3 and 4 are levels 1 and 2 of the entry of its level-2 row.  Every pass reads only levels that
-// earlier passes completed and writes only later ones, so the passes run in place.
+// Jump table (search.hip, IndexView::jump; format in layout.hpp): entry i has levels j = 1 .. L, level j = {row after
+// 8j LF steps from row i, 2-bit codes (dense symbol - 1) of the symbols of steps 8j-7 .. 8j, a valid bit}.  A level
+// is valid when its eight symbols are all in 1..4 (no sentinel, no N) and every earlier level is valid.  Level 1
+// comes from eight LF steps on the rank lines; later levels are copied from the entries of earlier targets:
+//   pass 2: level 2 of i = level 1 of entry t1(i)
+//   pass 3: levels 3, 4 of i = levels 1, 2 of entry t2(i)   (16-byte entries keep only the codes of level 3)
+//   pass 4: level 5 of i = level 1 of entry t4(i)
+// Every pass reads only fields that earlier passes completed and writes only its own entry, whole words at a
+// time, so the passes run in place.
+__device__ __forceinline__ uint32_t jump_valid(const uint32_t *e, uint32_t words)
+{
+    return words == 2 ? (e[1] >> 16) : (e[3] >> 16);
+}
+__device__ __forceinline__ uint32_t jump_code1(const uint32_t *e, uint32_t words)
+{
+    return words == 2 ? (e[1] & 0xffffu) : (e[2] & 0xffffu);
+}
+
 __global__ __launch_bounds__(kBlock) void derive_jump_level1_kernel(IndexView ix, uint32_t *__restrict__ jump,
                                                                     uint32_t words)
 {
@@ -270,33 +282,64 @@ __global__ __launch_bounds__(kBlock) void derive_jump_level1_kernel(IndexView ix
         for (uint32_t k = 0; k < kJumpSymbols; k++) {
             uint32_t r;
             const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
-            if (c == 0) {
+            if (c - 1u >= 4u) {  // sentinel or a symbol outside 1..4
                 ok = false;
                 break;
             }
-            code |= c << (4u * (kJumpSymbols - 1u - k));
+            code |= (c - 1u) << (2u * (kJumpSymbols - 1u - k));
             row = ix.count[c] + r;
         }
         uint32_t *e = jump + p * words;
-        *reinterpret_cast<uint2 *>(e) = ok ? make_uint2(row, code) : make_uint2(0u, 0u);
-        for (uint32_t w = 2; w < words; w++) e[w] = 0u;
+        for (uint32_t w = 0; w < words; w++) e[w] = 0u;
+        if (ok) {
+            e[0] = row;
+            if (words == 2) e[1] = code | (1u << 16);
+            else {
+                e[2] = code;
+                e[3] = 1u << 16;
+            }
+        }
     }
 }
 
-// levels [from, from + count) of entry i := levels [0, count) of the entry of the row in level `from - 1`
+// pass = 2, 3 or 4 (see above); words = 4 (16-byte entries) or 8 (32-byte entries)
 __global__ __launch_bounds__(kBlock) void derive_jump_levels_kernel(uint64_t n, uint32_t *__restrict__ jump, uint32_t words,
-                                                                    uint32_t from, uint32_t count)
+                                                                    uint32_t pass)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
         uint32_t *e = jump + p * words;
-        const uint2 last = *reinterpret_cast<const uint2 *>(e + 2u * (from - 1u));
-        if (last.y == 0u) continue;  // a sentinel on the way: the later levels stay invalid
-        const uint32_t *src = jump + static_cast<uint64_t>(last.x) * words;
-        for (uint32_t j = 0; j < count; j++) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(src + 2u * j);
-            if (v.y == 0u) break;
-            *reinterpret_cast<uint2 *>(e + 2u * (from + j)) = v;
+        const uint32_t valid = e[3] >> 16;
+        if (pass == 2) {
+            if (!(valid & 1u)) continue;
+            const uint32_t *s = jump + static_cast<uint64_t>(e[0]) * words;
+            if (!(jump_valid(s, words) & 1u)) continue;
+            e[1] = s[0];
+            e[2] = (e[2] & 0xffffu) | (jump_code1(s, words) << 16);
+            e[3] = (e[3] & 0xffffu) | ((valid | 2u) << 16);
+        } else if (pass == 3) {
+            if (!(valid & 2u)) continue;
+            const uint32_t *s = jump + static_cast<uint64_t>(e[1]) * words;
+            const uint32_t sv = jump_valid(s, words);
+            if (!(sv & 1u)) continue;
+            uint32_t v = valid | 4u;
+            const uint32_t c3 = jump_code1(s, words);
+            if (words == 8) {
+                e[4] = s[0];
+                if (sv & 2u) {
+                    e[5] = s[1];
+                    e[7] = s[2] >> 16;  // level 4 codes; level 5 comes in pass 4
+                    v |= 8u;
+                }
+            }
+            e[3] = c3 | (v << 16);
+        } else {
+            if (!(valid & 8u)) continue;
+            const uint32_t *s = jump + static_cast<uint64_t>(e[5]) * words;
+            if (!(jump_valid(s, words) & 1u)) continue;
+            e[6] = s[0];
+            e[7] = (e[7] & 0xffffu) | (jump_code1(s, words) << 16);
+            e[3] = (e[3] & 0xffffu) | ((valid | 16u) << 16);
         }
     }
 }
@@ -841,12 +884,9 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             jump_.alloc(div_ceil(static_cast<uint64_t>(n_) * words, 4) * 4);
             const unsigned grid = grid_for_items(n_);
             hipLaunchKernelGGL(derive_jump_level1_kernel, dim3(grid), dim3(kBlock), 0, stream, view_, jump_.get(), words);
-            if (jump_bytes >= 16)
+            for (uint32_t pass = 2; jump_bytes >= 16 && pass <= (jump_bytes == 32 ? 4u : 3u); pass++)
                 hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
-                                   1u, 1u);
-            if (jump_bytes == 32)
-                hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
-                                   2u, 2u);
+                                   pass);
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             view_.jump = jump_.get();
@@ -1176,10 +1216,22 @@ int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff,
     make_current();
     hipStream_t stream = hipStreamPerThread;
     DeviceQueries dq(qbuf, qoff, nq, stream);
-    DeviceBuffer<uint32_t> d_start(nq), d_end(nq), d_count(out_count ? nq : 0);
+    const bool intervals = out_start != nullptr || out_end != nullptr;
+    DeviceBuffer<uint32_t> d_start(intervals ? nq : 0), d_end(intervals ? nq : 0), d_count(out_count ? nq : 0);
     DeviceBuffer<uint8_t> d_status(nq);
-    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), d_count.get(), d_status.get(),
-                  stream, nullptr, nullptr, query_options());
+    {
+        SearchCall c;
+        c.d_qbuf = dq.qbuf.get();
+        c.d_qbeg = dq.qoff.get();
+        c.d_qend = dq.qoff.get() + 1;
+        c.nq = nq;
+        c.d_start = d_start.get();
+        c.d_end = d_end.get();
+        c.d_count = d_count.get();
+        c.d_status = d_status.get();
+        c.mode = intervals ? 0 : 1;  // counts alone do not need the exact interval (lazy tail)
+        launch_search_call(view_, c, stream, query_options());
+    }
     GDX_HIP(hipGetLastError());
     download_widened(d_start.get(), out_start, nq, stream);
     download_widened(d_end.get(), out_end, nq, stream);
@@ -1193,11 +1245,16 @@ int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff,
 
 void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                             gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
-                            const uint2 *d_hint) const
+                            const uint4 *d_rec) const
 {
     hipStream_t stream = hipStreamPerThread;
     DeviceBuffer<uint64_t> d_off(m + 1);
-    {
+    if (d_rec) {
+        const size_t tb = hit_offsets_rec_temp_bytes(m);
+        DeviceBuffer<uint8_t> temp(tb ? tb : 1);
+        launch_hit_offsets_rec(d_rec, m, d_off.get(), temp.get(), tb, stream);
+        GDX_HIP(hipStreamSynchronize(stream));
+    } else {
         const size_t tb = hit_offsets_temp_bytes(m);
         DeviceBuffer<uint8_t> temp(tb ? tb : 1);
         launch_hit_offsets(d_start, d_end, m, d_off.get(), temp.get(), tb, stream);
@@ -1215,8 +1272,8 @@ void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint
     }
     DeviceBuffer<gdx_hit_t> d_hits(total);
     DeviceBuffer<uint8_t> ws(locate_workspace_bytes(total));
-    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream, nullptr, d_hint,
-                  query_options());
+    launch_locate(view_, d_start, d_end, m, d_off.get(), total, d_hits.get(), true, ws.get(), stream, nullptr, nullptr,
+                  query_options(), d_rec);
     GDX_HIP(hipGetLastError());
     GDX_HIP(hipMemcpyAsync(hits, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
@@ -1234,11 +1291,19 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
     make_current();
     hipStream_t stream = hipStreamPerThread;
     DeviceQueries dq(qbuf, qoff, nq, stream);
-    DeviceBuffer<uint32_t> d_start(nq), d_end(nq);
     DeviceBuffer<uint8_t> d_status(nq);
-    DeviceBuffer<uint2> d_hint(nq);  // sampled rows the search passed through: no walk for those hits
-    launch_search(view_, dq.qbuf.get(), dq.qoff.get(), nq, d_start.get(), d_end.get(), nullptr, d_status.get(), stream,
-                  nullptr, d_hint.get(), query_options());
+    DeviceBuffer<uint4> d_rec(nq);  // count, status and locate hint of every query (search mode 1)
+    {
+        SearchCall c;
+        c.d_qbuf = dq.qbuf.get();
+        c.d_qbeg = dq.qoff.get();
+        c.d_qend = dq.qoff.get() + 1;
+        c.nq = nq;
+        c.d_rec = d_rec.get();
+        c.d_status = d_status.get();
+        c.mode = 1;
+        launch_search_call(view_, c, stream, query_options());
+    }
     GDX_HIP(hipGetLastError());
     std::vector<uint8_t> status(nq);
     GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
@@ -1246,7 +1311,7 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
     if (out_status) std::memcpy(out_status, status.data(), nq);
     int rc = any_status(status.data(), nq);
     int lrc = GDX_OK;
-    locate_device(d_start.get(), d_end.get(), nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc, d_hint.get());
+    locate_device(nullptr, nullptr, nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc, d_rec.get());
     return lrc != GDX_OK ? lrc : rc;
 }
 
@@ -1289,6 +1354,40 @@ int FmIndex::cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint
     GDX_HIP(hipMemcpy(status.data(), d_status.get(), m, hipMemcpyDeviceToHost));
     if (out_status) std::memcpy(out_status, status.data(), m);
     return any_status(status.data(), m);
+}
+
+int FmIndex::cursor_extend_front_strings(uint64_t *start, uint64_t *end, const uint8_t *qbuf, const uint64_t *qoff,
+                                         uint64_t m, uint8_t *status) const
+{
+    check_queries(qbuf, qoff, m);
+    if (m == 0) return GDX_OK;
+    if (!start || !end) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    make_current();
+    hipStream_t stream = hipStreamPerThread;
+    DeviceQueries dq(qbuf, qoff, m, stream);
+    DeviceBuffer<uint32_t> d_start(m), d_end(m);
+    DeviceBuffer<uint8_t> d_status(m);
+    upload_narrowed(start, d_start.get(), m, n_, "cursor start", stream);
+    upload_narrowed(end, d_end.get(), m, n_, "cursor end", stream);
+    if (status) GDX_HIP(hipMemcpyAsync(d_status.get(), status, m, hipMemcpyHostToDevice, stream));
+    else GDX_HIP(hipMemsetAsync(d_status.get(), 0, m, stream));
+    SearchCall c;
+    c.d_qbuf = dq.qbuf.get();
+    c.d_qbeg = dq.qoff.get();
+    c.d_qend = dq.qoff.get() + 1;
+    c.nq = m;
+    c.d_start = d_start.get();
+    c.d_end = d_end.get();
+    c.d_status = d_status.get();
+    c.mode = 2;
+    launch_search_call(view_, c, stream, query_options());
+    GDX_HIP(hipGetLastError());
+    download_widened(d_start.get(), start, m, stream);
+    download_widened(d_end.get(), end, m, stream);
+    std::vector<uint8_t> st(m);
+    GDX_HIP(hipMemcpy(st.data(), d_status.get(), m, hipMemcpyDeviceToHost));
+    if (status) std::memcpy(status, st.data(), m);
+    return any_status(st.data(), m);
 }
 
 int FmIndex::cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets,

@@ -86,6 +86,8 @@ public:
                     gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
     int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
                                  uint8_t *out_status) const;
+    int cursor_extend_front_strings(uint64_t *start, uint64_t *end, const uint8_t *qbuf, const uint64_t *qoff, uint64_t m,
+                                    uint8_t *status) const;
     int cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets,
                            gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total) const;
     int rank_many(const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out) const;
@@ -106,7 +108,7 @@ private:
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                        gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
-                       const uint2 *d_hint = nullptr) const;
+                       const uint4 *d_rec = nullptr) const;
 
     IndexConfig cfg_;
     BuildStats stats_;

@@ -20,6 +20,36 @@ struct QueryOptions {
     int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
 };
 
+// Active lists of the cursor-extension mode (search mode 2): the cursors to extend are those listed in active_in
+// (*n_active_in of them, a device value; null = all), the ones still non-empty afterwards are appended to active_out
+// (*n_active_out must be zeroed by the caller beforehand).
+struct CursorArgs {
+    const uint32_t *active_in = nullptr;
+    const uint32_t *n_active_in = nullptr;
+    uint32_t *active_out = nullptr;
+    uint32_t *n_active_out = nullptr;
+};
+
+// One search launch.  Query i = d_qbuf[d_qbeg[i] .. d_qend[i]) (d_qend = d_qbeg + 1 for the usual offsets array).
+// mode 0: exact intervals (cursors_for_many_queries); mode 1: count / locate (end - start is the count, start / end
+// are only meaningful through the hint or record; see search_pair_body); mode 2: cursor extension, start / end are
+// in / out.  Any output may be null.  rec: one 16-byte record per query {start, end, hint row, hint symbols |
+// status << 24} for launch_hit_offsets_rec / launch_locate.
+struct SearchCall {
+    const uint8_t *d_qbuf = nullptr;
+    const uint64_t *d_qbeg = nullptr, *d_qend = nullptr;
+    uint64_t nq = 0;
+    uint32_t *d_start = nullptr, *d_end = nullptr, *d_count = nullptr;
+    uint8_t *d_status = nullptr;
+    uint2 *d_hint = nullptr;
+    uint4 *d_rec = nullptr;
+    unsigned long long *d_step_stats = nullptr;
+    int mode = 0;
+    CursorArgs cursors;
+};
+void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream,
+                        const QueryOptions &qo = QueryOptions());
+
 // ---- search.hip ---------------------------------------------------------------------------
 // Backward search of nq queries (lookup jump + LF loop), one lane per query.
 // Any of out_start/out_end/out_count/out_status may be null.  d_hint (optional, uint2[nq]): locate hints for
@@ -45,11 +75,17 @@ void launch_fill_top(const IndexView &ix, uint2 *d_top, uint32_t depth, hipStrea
 size_t hit_offsets_temp_bytes(uint64_t m);
 void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *d_hit_offsets,
                         void *d_temp, size_t temp_bytes, hipStream_t stream);
+// the same scan over 16-byte search records (SearchCall::d_rec)
+size_t hit_offsets_rec_temp_bytes(uint64_t m);
+void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
+                            hipStream_t stream);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
-                   const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions());
+                   const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
+                   const uint4 *d_rec = nullptr);
+// d_rec != null: start / hint come from the search records instead of d_start / d_hint (d_start, d_end unused)
 
 }  // namespace gdx

@@ -40,9 +40,15 @@ struct IndexView {
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
-    // --- jump table: 8 / 16 / 32 LF steps of a narrow interval per fetch -------------------------------
-    const void *jump;             // [n] entries of jump_bytes: level j = {row after 8j LF steps, nibble codes of the
-                                  // symbols those 8 steps need}, j = 1 .. jump_bytes / 8; null when absent
+    // --- jump table: 8 .. 40 LF steps of a narrow interval per fetch -----------------------------------
+    // [n] entries of jump_bytes.  Level j of entry i = {t_j = row after 8j LF steps from row i, c_j = 2-bit codes
+    // (dense symbol - 1, bits 15:14 = the first of them) of the symbols of steps 8j-7 .. 8j, valid bit j-1 = these
+    // and all earlier symbols are in 1..4}; a code without its target is a lookahead: it tells whether a row
+    // survives further steps without saying where it goes.  As 32-bit words:
+    //    8 bytes: {t1, c1 | valid << 16}                                   1 level
+    //   16 bytes: {t1, t2, c1 | c2 << 16, c3 | valid << 16}                 2 levels + lookahead c3
+    //   32 bytes: the same + {t3, t4, t5, c4 | c5 << 16}                    5 levels (c_{j+1} is the lookahead of j)
+    const void *jump;             // null when absent
     uint32_t jump_bytes;          // 0, 8, 16 or 32
     // --- top table: interval after the first top_depth symbols of a DNA query, one cache-resident fetch ----
     const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); the entry of
@@ -266,63 +272,85 @@ __device__ __forceinline__ uint32_t group_max(uint32_t v)
     return v;
 }
 
-// Line loads with an explicit cache policy: 0 = plain, 1 = sc1 (served by L2, no allocation in the CU's
-// L1), 2 = nt, 3 = sc0 sc1.  The asm loads are waited for by hand; the compiler's counters do not see them.
-// kChunks 16-byte chunks per lane and line, `step` chunks apart (a group of 8 / kChunks lanes covers a line).
+// One round of line / entry loads as ONE asm statement: every load, the exec masking of the optional ones and the
+// single wait sit between the same pair of braces, so no compiler-generated instruction (a register copy, a scratch
+// spill of a destination that is still in flight) can land between issue and wait -- the compiler's own waitcnt
+// bookkeeping does not see loads issued from inline asm.  The destinations are early-clobber outputs: they are
+// defined by the statement and complete when it ends; lanes outside a mask get undefined values.
+// kPolicy: 0 = plain loads, 1 = sc1 (served by L2, no allocation in the CU's L1).
+// two lines of one chunk per lane (8 lanes per line): a always, b only in the lanes of m_b
 template <int kPolicy>
-__device__ __forceinline__ void issue_chunk_load(const u32x4 *p, u32x4 &v)
-{
-    if (kPolicy == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
-    else if (kPolicy == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
-    else if (kPolicy == 2) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
-}
-
-// The same load executed only by the lanes of `mask` (a subset of the active lanes); v is undefined in the other
-// lanes.  Done with the exec mask inside one asm statement, so the compiler sees a straight-line definition of v
-// and has no branch join at which it could place a copy of the still-pending register before the hand-written
-// wait.
-template <int kPolicy>
-__device__ __forceinline__ void issue_chunk_load_masked(const u32x4 *p, u32x4 &v, unsigned long long mask)
+__device__ __forceinline__ void load_round2(const u32x4 *pa, const u32x4 *pb, unsigned long long m_b, u32x4 &a, u32x4 &b)
 {
     unsigned long long saved;
-    if (kPolicy == 0)
-        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off\n\ts_mov_b64 exec, %1"
-                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
-    else if (kPolicy == 1)
-        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off sc1\n\ts_mov_b64 exec, %1"
-                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
-    else if (kPolicy == 2)
-        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off nt\n\ts_mov_b64 exec, %1"
-                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
+    if (kPolicy == 1)
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                     "s_and_saveexec_b64 %2, %5\n\t"
+                     "global_load_dwordx4 %1, %4, off sc1\n\t"
+                     "s_mov_b64 exec, %2\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&s"(saved)
+                     : "v"(pa), "v"(pb), "s"(m_b)
+                     : "memory", "scc");
     else
-        asm volatile("s_and_saveexec_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, off sc0 sc1\n\ts_mov_b64 exec, %1"
-                     : "=&v"(v), "=&s"(saved) : "v"(p), "s"(mask) : "memory", "scc");
+        asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                     "s_and_saveexec_b64 %2, %5\n\t"
+                     "global_load_dwordx4 %1, %4, off\n\t"
+                     "s_mov_b64 exec, %2\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&s"(saved)
+                     : "v"(pa), "v"(pb), "s"(m_b)
+                     : "memory", "scc");
 }
 
+// two lines of two chunks per lane (4 lanes per line), or a jump entry in a0 (+ a1): a0 always, a1 in the lanes of
+// m_a1, b0 and b1 in the lanes of m_b
+template <int kPolicy>
+__device__ __forceinline__ void load_round4(const u32x4 *pa0, const u32x4 *pa1, const u32x4 *pb0, const u32x4 *pb1,
+                                            unsigned long long m_a1, unsigned long long m_b, u32x4 &a0, u32x4 &a1,
+                                            u32x4 &b0, u32x4 &b1)
+{
+    unsigned long long saved;
+    if (kPolicy == 1)
+        asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
+                     "s_mov_b64 %4, exec\n\t"
+                     "s_and_b64 exec, %4, %9\n\t"
+                     "global_load_dwordx4 %1, %6, off sc1\n\t"
+                     "s_and_b64 exec, %4, %10\n\t"
+                     "global_load_dwordx4 %2, %7, off sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off sc1\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&s"(saved)
+                     : "v"(pa0), "v"(pa1), "v"(pb0), "v"(pb1), "s"(m_a1), "s"(m_b)
+                     : "memory", "scc");
+    else
+        asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                     "s_mov_b64 %4, exec\n\t"
+                     "s_and_b64 exec, %4, %9\n\t"
+                     "global_load_dwordx4 %1, %6, off\n\t"
+                     "s_and_b64 exec, %4, %10\n\t"
+                     "global_load_dwordx4 %2, %7, off\n\t"
+                     "global_load_dwordx4 %3, %8, off\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&s"(saved)
+                     : "v"(pa0), "v"(pa1), "v"(pb0), "v"(pb1), "s"(m_a1), "s"(m_b)
+                     : "memory", "scc");
+}
+
+// both border lines of an interval for a group of 8 / kChunks lanes; b = a when the borders share a line
 template <int kPolicy, int kChunks>
 __device__ __forceinline__ void load_two_lines(const u32x4 *pa, const u32x4 *pb, bool second, int step,
                                                u32x4 (&a)[kChunks], u32x4 (&b)[kChunks])
 {
-    if (kPolicy == 0) {
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) a[k] = pa[k * step];
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) b[k] = a[k];
-        if (second) {
-#pragma unroll
-            for (int k = 0; k < kChunks; k++) b[k] = pb[k * step];
-        }
-        return;
+    const unsigned long long m_b = __ballot(second);
+    if (kChunks == 1) {
+        load_round2<kPolicy>(pa, pb, m_b, a[0], b[0]);
+    } else {
+        const unsigned long long all = __ballot(true);
+        load_round4<kPolicy>(pa, pa + step, pb, pb + step, all, m_b, a[0], a[kChunks - 1], b[0], b[kChunks - 1]);
     }
-#pragma unroll
-    for (int k = 0; k < kChunks; k++) issue_chunk_load<kPolicy>(pa + k * step, a[k]);
-    if (second) {
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) issue_chunk_load<kPolicy>(pb + k * step, b[k]);
-    }
-    if (kChunks == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[kChunks - 1]), "+v"(b[kChunks - 1])::"memory");
     if (!second) {
 #pragma unroll
         for (int k = 0; k < kChunks; k++) b[k] = a[k];

@@ -32,6 +32,21 @@ struct IntervalSize {
 using SizeIterator =
     rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, IntervalSize, uint64_t>;
 
+// the same from the 16-byte search records {start, end, hint row, hint symbols | status << 24}
+struct RecordSize {
+    const uint4 *rec;
+    uint64_t m;
+    __host__ __device__ uint64_t operator()(uint64_t q) const
+    {
+        if (q >= m) return 0ull;
+        const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
+        return static_cast<uint64_t>(v.y - v.x);
+    }
+};
+
+using RecordSizeIterator =
+    rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, RecordSize, uint64_t>;
+
 __global__ __launch_bounds__(kBlock) void mark_heads_kernel(const uint32_t *__restrict__ start,
                                                             const uint32_t *__restrict__ end, uint64_t m,
                                                             const uint64_t *__restrict__ hit_offsets,
@@ -144,13 +159,14 @@ template <class Table, bool kWide>
 __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
-                                                              const uint2 *__restrict__ hint, uint64_t total,
+                                                              const uint2 *__restrict__ hint,
+                                                              const uint4 *__restrict__ rec, uint64_t total,
                                                               void *__restrict__ hits_out,
                                                               unsigned long long *__restrict__ step_stats)
 {
     __shared__ uint32_t s_count[257];
     __shared__ uint32_t s_row[kLocateChunk];
-    __shared__ uint16_t s_idx[kLocateChunk];
+    __shared__ uint32_t s_idx[kLocateChunk];  // slot in the chunk (low 11 bits) | symbols to subtract << 11
     __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first
     __shared__ uint32_t s_n, s_head;
     // the text-id search of every hit is a chain of dependent loads: from LDS when the sentinel array is small
@@ -185,13 +201,23 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
             const uint64_t h = base + i;
             const uint32_t q = qa + s_query[i];
             const uint64_t first = hit_offsets[q];
-            uint32_t row = start[q] + static_cast<uint32_t>(h - first);  // SA index of this hit
-            uint32_t back = 0;                                            // SA[hit row] = SA[row] - back
-            if (hint != nullptr && hit_offsets[q + 1] - first == 1u) {
-                const uint2 hv = hint[q];
-                if (hv.x != 0xffffffffu) {
-                    row = hv.x;
-                    back = hv.y;
+            uint32_t row;       // SA index of this hit, or the hinted row
+            uint32_t back = 0;  // SA[hit row] = SA[row] - back
+            if (rec != nullptr) {
+                const uint4 r = rec[q];
+                row = r.x + static_cast<uint32_t>(h - first);
+                if (r.z != 0xffffffffu && r.y - r.x == 1u) {
+                    row = r.z;
+                    back = r.w & 0xffffffu;
+                }
+            } else {
+                row = start[q] + static_cast<uint32_t>(h - first);
+                if (hint != nullptr && hit_offsets[q + 1] - first == 1u) {
+                    const uint2 hv = hint[q];
+                    if (hv.x != 0xffffffffu && hv.y < (1u << 21)) {
+                        row = hv.x;
+                        back = hv.y;
+                    }
                 }
             }
             const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
@@ -199,21 +225,23 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
                 store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
             } else {
+                // (a hinted row that is not sampled comes from the search's lazy tail: the walk starts there)
                 const uint32_t k = atomicAdd(&s_n, 1u);
                 s_row[k] = row;
-                s_idx[k] = static_cast<uint16_t>(i);
+                s_idx[k] = i | (back << 11);
             }
         }
         __syncthreads();
         const uint32_t queued = s_n;
         bool have = false;
-        uint32_t row = 0, steps = 0, idx = 0;
+        uint32_t row = 0, steps = 0, idx = 0, back = 0;
         for (;;) {
             if (!have) {
                 const uint32_t k = atomicAdd(&s_head, 1u);
                 if (k < queued) {
                     row = s_row[k];
-                    idx = s_idx[k];
+                    idx = s_idx[k] & 2047u;
+                    back = s_idx[k] >> 11;
                     steps = 0;
                     have = true;
                 }
@@ -224,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 const uint32_t c = Table::symbol_and_rank(ix, row, r);
                 if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
                     const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, row);
-                    store_hit<kWide>(ix, ix.border_vals[b] + steps, hits_out, base + idx, sentinels);
+                    store_hit<kWide>(ix, ix.border_vals[b] + steps - back, hits_out, base + idx, sentinels);
                     walk_steps += steps;
                     have = false;
                 } else {
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                     const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
                     if (sampled) {
                         const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
-                        store_hit<kWide>(ix, ix.sa_samples[slot] + steps, hits_out, base + idx, sentinels);
+                        store_hit<kWide>(ix, ix.sa_samples[slot] + steps - back, hits_out, base + idx, sentinels);
                         walk_steps += steps;
                         have = false;
                     }
@@ -372,6 +400,24 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
 }
 
+size_t hit_offsets_rec_temp_bytes(uint64_t m)
+{
+    size_t bytes = 0;
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{nullptr, m});
+    uint64_t *out = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1),
+                                  rocprim::plus<uint64_t>());
+    return bytes;
+}
+
+void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
+                            hipStream_t stream)
+{
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, m});
+    GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
+                                    static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
+}
+
 size_t locate_workspace_bytes(uint64_t total_hits)
 {
     return align_up(total_hits * sizeof(uint32_t), 256) + align_up(max_scan_temp_bytes(total_hits), 256) + 256;
@@ -380,7 +426,7 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo)
+                   const QueryOptions &qo, const uint4 *d_rec)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -391,7 +437,8 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         const char *e = getenv("GDX_LOCATE_VARIANT");
         return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
     }();
-    const int variant = (qo.locate_variant >= 0 && qo.locate_variant <= 2) ? qo.locate_variant : env_variant;
+    int variant = (qo.locate_variant >= 0 && qo.locate_variant <= 2) ? qo.locate_variant : env_variant;
+    if (d_rec != nullptr) variant = 0;  // only the queue kernel reads search records
     if (variant != 0) {  // the lock-step variants map hit slots to queries with head marks + a max-scan over all hits
         GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,
@@ -418,7 +465,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE)                                                                                  \
     hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,      \
-                       d_hit_offsets, m, first, d_hint, total_hits, d_hits, d_step_stats)
+                       d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats)
         if (ix.layout == 0) {
             if (wide) GDX_LOCATE_Q(LineTable, true);
             else GDX_LOCATE_Q(LineTable, false);

@@ -87,6 +87,15 @@ struct CodeWindow {
         const uint64_t w1 = w >= 1u ? b[w - 1u] : 0ull;
         set(qbuf, begin, rem, w0, w1, s_dense);
     }
+    // the same query, positioned at another rem (after a jump of more than one window word)
+    __device__ __forceinline__ void reinit(uint32_t rem, const uint8_t *s_dense)
+    {
+        const uint32_t w = rem ? ((off0 + rem - 1u) >> 3) : 0u;
+        cur_w = w;
+        raw = w >= 2u ? base[w - 2u] : 0ull;
+        cur = translate(rem ? base[w] : 0ull, s_dense);
+        next = translate(w >= 1u ? base[w - 1u] : 0ull, s_dense);
+    }
     // codes of the 8 symbols that end with symbol rem-1 (nibble 7 = symbol rem-1, the next one to consume);
     // moves the window one word down when the position has left it.  rem >= 1.  Nibbles of symbols before
     // the start of the query are garbage and must not be used (callers check rem).
@@ -141,16 +150,32 @@ __device__ __forceinline__ bool top_lookup(const IndexView &ix, uint32_t a, uint
     return true;
 }
 
+// appends the cursors of this wavefront's `alive` lanes to ca.active_out: one atomic per wavefront
+__device__ __forceinline__ void compact_alive(bool alive, uint32_t q, const CursorArgs &ca)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    uint32_t first = 0;
+    if (static_cast<int>(lane) == leader) first = atomicAdd(ca.n_active_out, static_cast<uint32_t>(__popcll(mask)));
+    first = __shfl(first, leader);
+    if (alive) ca.active_out[first + __popcll(mask & ((1ull << lane) - 1ull))] = q;
+}
+
 // kGroup lanes cooperate on one query (1: LineTable / GenericTable, 4: QuadLineTable); control flow is
-// uniform inside a group, lane 0 of the group writes the results.
-template <class Table, int kGroup>
+// uniform inside a group, lane 0 of the group writes the results.  kResume: cursor extension (see search_pair_body,
+// kMode 2): start from the interval in out_start / out_end, no lookup table, active lists.
+template <class Table, int kGroup, bool kResume>
 __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
-                                                        const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                        const uint64_t *__restrict__ qbeg,
+                                                        const uint64_t *__restrict__ qend, uint64_t nq,
                                                         uint32_t *__restrict__ out_start,
                                                         uint32_t *__restrict__ out_end,
                                                         uint32_t *__restrict__ out_count,
                                                         uint8_t *__restrict__ out_status,
-                                                        unsigned long long *__restrict__ step_stats)
+                                                        unsigned long long *__restrict__ step_stats,
+                                                        uint4 *__restrict__ out_rec, CursorArgs ca)
 {
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -161,15 +186,28 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
     const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint32_t *active = kResume ? ca.active_in : nullptr;
+    if (kResume && ca.n_active_in != nullptr) nq = *ca.n_active_in;
     uint32_t lf_steps = 0;  // only reported through step_stats (bench accounting, null in normal calls)
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; q < nq;
-         q += stride) {
-        const uint64_t begin = qoff[q], end = qoff[q + 1];
+    for (uint64_t at = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; at < nq;
+         at += stride) {
+        const uint64_t q = active ? active[at] : at;
+        const uint64_t begin = qbeg[q], end = qend[q];
         const uint64_t len = end - begin;
         // lib.rs:277-281 split_query_for_lookup
-        const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
-                                                                 : static_cast<uint32_t>(ix.depth);
+        const uint32_t t = kResume ? 0u
+                                   : (len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                            : static_cast<uint32_t>(ix.depth));
         uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
+        bool stopped = false;
+        if (kResume) {
+            lo = out_start[q];
+            hi = out_end[q];
+            if (out_status != nullptr) {
+                status = out_status[q];
+                stopped = status != GDX_Q_OK;
+            }
+        }
         if (t > 0) {
             // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
             uint32_t idx = 0, factor = 1;
@@ -194,11 +232,11 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
         QueryWindow win;
         win.init(qbuf, begin, pos);
         // lib.rs:226-232 / batch_computed_cursors.rs:62-70: stop at the empty interval
-        while (pos > begin && lo != hi) {
+        while (pos > begin && lo != hi && !stopped) {
             const uint32_t c = s_dense[win.get(pos - 1)];
             if (c == 0) {  // alphabet.rs:195-198
                 status = GDX_Q_INVALID_SYMBOL;
-                lo = hi = 0;
+                if (!kResume) lo = hi = 0;
                 break;
             }
             uint32_t rlo, rhi;
@@ -210,11 +248,14 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
             lf_steps++;
         }
         if (writer) {
+            if (out_rec) out_rec[q] = make_uint4(lo, hi, 0xffffffffu, (status & 0xffu) << 24);
             if (out_start) out_start[q] = lo;
             if (out_end) out_end[q] = hi;
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
         }
+        if (kResume && ca.active_out != nullptr)
+            compact_alive(writer && lo != hi && status == GDX_Q_OK, static_cast<uint32_t>(q), ca);
     }
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
@@ -238,7 +279,9 @@ __device__ __forceinline__ uint32_t length_bucket(uint64_t len)
 
 // Orders queries [base, base + cnt) of the batch by length bucket into s_perm (indices relative to base); returns
 // false (s_perm untouched) when the lengths are uniform enough: max - min <= min / 4.  Block-wide, all threads.
-__device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict__ qoff, uint64_t base, uint32_t cnt,
+__device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict__ qbeg,
+                                                      const uint64_t *__restrict__ qend,
+                                                      const uint32_t *__restrict__ active, uint64_t base, uint32_t cnt,
                                                       uint16_t *s_perm, uint32_t *s_cnt, uint32_t *s_minmax)
 {
     if (threadIdx.x < kLenBuckets) s_cnt[threadIdx.x] = 0;
@@ -249,7 +292,8 @@ __device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict
     __syncthreads();
     uint32_t mn = 0xffffffffu, mx = 0;
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const uint64_t len = qoff[base + i + 1] - qoff[base + i];
+        const uint64_t qi = active ? active[base + i] : base + i;
+        const uint64_t len = qend[qi] - qbeg[qi];
         const uint32_t l = len > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(len);
         mn = l < mn ? l : mn;
         mx = l > mx ? l : mx;
@@ -279,26 +323,62 @@ __device__ __forceinline__ bool order_range_by_length(const uint64_t *__restrict
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const uint32_t r = atomicAdd(&s_cnt[length_bucket(qoff[base + i + 1] - qoff[base + i])], 1u);
+        const uint64_t qi = active ? active[base + i] : base + i;
+        const uint32_t r = atomicAdd(&s_cnt[length_bucket(qend[qi] - qbeg[qi])], 1u);
         s_perm[r] = static_cast<uint16_t>(i);
     }
     __syncthreads();
     return true;
 }
 
-// Backward search on pair lines: eight lanes per query, two LF steps per line fetch while both next
-// symbols are searchable and the interval stays non-empty; everything else (odd tail, N, the step at
-// which the interval empties -- whose frozen (start, end) must be the reference's) goes through the
-// one-step rank lines, so the result is identical to search_kernel's.
-template <int kPolicy, int kGroup, bool kStats, int kJump>
+// all eight nibbles are dense codes 1..4 (searchable DNA symbols)
+__device__ __forceinline__ bool all_dna(uint32_t x)
+{
+    const uint32_t y = x - 0x11111111u;  // per nibble c - 1 when there is no zero nibble (no borrow)
+    return ((y & ~x & 0x88888888u) | (y & 0xccccccccu)) == 0u;
+}
+
+// eight nibble codes 1..4 -> eight 2-bit codes (c - 1), nibble 7 (the symbol consumed first) in bits 15:14: the form
+// the jump entries store (layout.hpp).  Only meaningful when all_dna(x).
+__device__ __forceinline__ uint32_t to_2bit(uint32_t x)
+{
+    uint32_t y = x - 0x11111111u;
+    y = (y & 0x03030303u) | ((y & 0x30303030u) >> 2);
+    y = (y & 0x000f000fu) | ((y & 0x0f000f00u) >> 4);
+    return (y & 0xffu) | ((y >> 8) & 0xff00u);
+}
+
+constexpr uint32_t kNoCode = 0x10000u;  // compares unequal to every 16-bit entry code
+
+// Backward search on pair lines, the jump table and the top table: kGroup = 4 or 8 lanes per
+// query, every loop iteration is one round of loads for the whole wavefront.
+// kMode 0 (intervals): out_start / out_end are the reference's half-open SA interval, bit for bit, also for empty
+//   results (cursors_for_many_queries).
+// kMode 1 (count / locate): only the number of occurrences and the locate hint matter.  A query whose interval is one
+//   row wide and that has fewer than eight symbols left after a jump is finished from the jump entry already in
+//   registers -- its next level holds the symbols preceding that row's suffix, so comparing them with the query's
+//   remaining symbols tells whether the occurrence survives, without fetching the row's pair line (the "lazy tail").
+//   The interval then reported is [row, row + 1) or [row, row) of the row BEFORE those steps together with a hint
+//   {row', rem'}: "SA[hit] = SA[row'] - rem'".  end - start is the reference's count; start / end themselves are only
+//   meaningful to launch_locate through the hint.  Results go to out_rec (one 16-byte record per query:
+//   {start, end, hint row, hint symbols | status << 24}) when it is given.
+// kMode 2 (cursor extension, Cursor::extend_query_front cursor.rs:34-51 applied to every symbol of a string, right to
+//   left): the search resumes from the interval in out_start / out_end (in / out) instead of [0, n); the top table
+//   is used for a cursor that is still the empty cursor [0, n).  The queries are those listed in ca.active_in
+//   (*ca.n_active_in of them; null = all nq), and the cursors that are still non-empty afterwards are appended to
+//   ca.active_out (device-side compaction: one atomic per wavefront), so that a caller feeding long queries in
+//   chunks touches only live cursors.  An invalid symbol stops its cursor where it stands (status set).
+template <int kPolicy, int kGroup, bool kStats, int kJump, int kMode>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
-                                                             const uint64_t *__restrict__ qoff, uint64_t nq,
+                                                             const uint64_t *__restrict__ qbeg,
+                                                             const uint64_t *__restrict__ qend, uint64_t nq,
                                                              uint32_t *__restrict__ out_start,
                                                              uint32_t *__restrict__ out_end,
                                                              uint32_t *__restrict__ out_count,
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
-                                                             uint32_t range, int schedule, uint2 *__restrict__ out_hint)
+                                                             uint32_t range, int schedule, uint2 *__restrict__ out_hint,
+                                                             uint4 *__restrict__ out_rec, CursorArgs ca)
 {
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -312,21 +392,37 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
     const bool writer = (threadIdx.x % kGroup) == 0;
+    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
+    const bool hinting = out_hint != nullptr || out_rec != nullptr;
     uint32_t lf_steps = 0;
     unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
+    const uint32_t *active = kMode == 2 ? ca.active_in : nullptr;
+    if (kMode == 2 && ca.n_active_in != nullptr) nq = *ca.n_active_in;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
     const uint64_t base = rg * range;
     const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
     if (rg != blockIdx.x) __syncthreads();  // the previous range's order is no longer read
-    const bool ordered = schedule != 0 && order_range_by_length(qoff, base, cnt, s_perm, s_cnt, s_minmax);
+    const bool ordered = schedule != 0 && order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
     for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
-        const uint64_t q = base + (ordered ? s_perm[slot] : slot);
-        const uint64_t begin = qoff[q], end = qoff[q + 1];
+        const uint64_t at = base + (ordered ? s_perm[slot] : slot);
+        const uint64_t q = active ? active[at] : at;
+        const uint64_t begin = qbeg[q], end = qend[q];
         const uint64_t len = end - begin;
-        const uint32_t t = len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
-                                                                 : static_cast<uint32_t>(ix.depth);
+        const uint32_t t = kMode == 2 ? 0u
+                                      : (len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                               : static_cast<uint32_t>(ix.depth));
         uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
+        bool stopped = false;  // kMode 2: a cursor that met an invalid symbol earlier stays where it stopped
+        if (kMode == 2) {
+            lo = out_start[q];
+            hi = out_end[q];
+            if (out_status != nullptr) {
+                status = out_status[q];
+                stopped = status != GDX_Q_OK;
+            }
+        }
+        const bool fresh = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210)
         uint32_t rem = 0;  // symbols still to consume, right to left
         CodeWindow win;
         // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
@@ -334,7 +430,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         // which is everything the reference checks for its t-symbol suffix (lookup_table.rs:99-113); the interval
         // is the one the configured table plus the LF steps in between would give.
         bool topped = false;
-        if (ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull) {
+        if (ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull &&
+            (kMode != 2 || (fresh && !stopped))) {
+            const uint32_t lo0 = lo, hi0 = hi;
             rem = static_cast<uint32_t>(len);
             win.init(qbuf, begin, rem, s_dense);
             const uint32_t a = win.code8(rem, s_dense);
@@ -343,11 +441,12 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (topped) {
                 rem -= ix.top_depth;
                 if (kStats) lf_steps += ix.top_depth;
+            } else {
+                lo = lo0;
+                hi = hi0;
             }
         }
         if (!topped) {
-            lo = 0;
-            hi = ix.n;
             if (t > 0) {
                 // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
                 uint32_t idx = 0, factor = 1;
@@ -368,16 +467,22 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     lo = hi = 0;
                 }
             }
-            rem = static_cast<uint32_t>(len - t);
+            rem = stopped ? 0u : static_cast<uint32_t>(len - t);
             win.init(qbuf, begin, rem, s_dense);
         }
-        bool jump_ok = ix.jump != nullptr && ix.jump_bytes == static_cast<uint32_t>(kJump);
+        // hints carry symbol counts of 21 bits (locate.hip packs them beside a slot number); longer queries
+        // (2 M symbols and more) simply do not jump
+        bool jump_ok = ix.jump != nullptr && ix.jump_bytes == static_cast<uint32_t>(kJump) && len < (1ull << 21);
         uint32_t iters = 0;  // fetch rounds of this query (divergence accounting, kStats only)
         // Every iteration is one round of loads for the whole wavefront, whatever its queries are doing: a group
         // either reads its jump entry or the pair line(s) of its interval borders, all loads are issued, then
         // waited for once, then each group interprets what it got (a wavefront whose groups took different
         // branches, each with its own load and wait, would pay one DRAM latency per branch).
         constexpr int kChunks = 8 / kGroup;
+        // levels of an entry the group can use, and codes it sees (one more than levels = a lookahead, except in
+        // full 32-byte entries whose fifth code belongs to the fifth level)
+        constexpr int kLevels = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 2 : 5);
+        constexpr int kCodes = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 3 : 5);
         const uint32_t sub = threadIdx.x & (kGroup - 1u);
         while (rem > 0 && lo != hi) {
             if (kStats) iters++;
@@ -385,7 +490,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             const uint32_t c1 = code >> 28;
             if (c1 == 0) {  // alphabet.rs:195-198
                 status = GDX_Q_INVALID_SYMBOL;
-                lo = hi = 0;
+                if (kMode != 2) lo = hi = 0;
                 break;
             }
             if (c1 > 4u) {  // a valid symbol outside 1..4 (N): rank lines, rare
@@ -400,18 +505,39 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             }
             const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
             // Intervals of at most one row per lane of the group jump: lane j reads the entry of row lo + j.  The
-            // rows whose stored symbols equal the query's next 8 / 16 are exactly those that survive these LF steps,
-            // and LF keeps their order, so they map onto [min target, max target + 1).
-            const bool jumping = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols &&
-                                 !has_zero_nibble(code);
-            // entries of 16 / 32 bytes: the codes of the next 8-symbol groups after `code`, read straight from the
-            // query (the window stays; it is re-initialised after a jump of more than 8 symbols)
-            constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : (kChunks >= 2 ? 4 : 2));
-            uint32_t codes[4] = {code, 0u, 0u, 0u};
+            // rows whose stored symbols equal the query's next 8, 16, ... are exactly those that survive these LF
+            // steps, and LF keeps their order, so they map onto [min target, max target + 1).
+            const bool jumping = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols && all_dna(code);
+            // 2-bit codes of the query's next 8-symbol groups (level j + 1 <-> symbols rem - 8j - 1 .. rem - 8j - 8),
+            // read straight from the query (the window stays; it is re-initialised after a jump of more than 8
+            // symbols), packed like the entries store them: qa = level 1 | level 2 << 16, qb = level 3,
+            // qc = level 4 | level 5 << 16; qok bit j = level j + 1 lies inside the query and is all symbols 1..4
+            uint32_t qa = 0, qb = 0, qc = 0, qok = 0;
+            uint32_t tail16 = kNoCode;  // kMode 1: codes of the last rem % 8 symbols, in the top bits
             if (jumping) {
+                qa = to_2bit(code);
+                qok = 1u;
 #pragma unroll
-                for (int j = 1; j < kLevels; j++)
-                    if (rem >= (j + 1u) * kJumpSymbols) codes[j] = win.peek8(rem - j * kJumpSymbols, s_dense);
+                for (int j = 1; j < kLevels; j++) {
+                    if (rem >= (j + 1u) * kJumpSymbols) {
+                        const uint32_t cj = win.peek8(rem - j * kJumpSymbols, s_dense);
+                        if (all_dna(cj)) {
+                            const uint32_t v = to_2bit(cj);
+                            if (j == 1) qa |= v << 16;
+                            if (j == 2) qb = v;
+                            if (j == 3) qc = v;
+                            if (j == 4) qc |= v << 16;
+                            qok |= 1u << j;
+                        }
+                    }
+                }
+                if (kMode == 1 && (rem & 7u) != 0u && (rem >> 3) < static_cast<uint32_t>(kCodes)) {
+                    // the query's first rem % 8 symbols as the top nibbles (the lower ones set to a valid code)
+                    const uint32_t tl = rem & 7u;
+                    const uint32_t m = 0xffffffffu << (4u * (8u - tl));
+                    const uint32_t cj = ((win.peek8(8u, s_dense) << (4u * (8u - tl))) & m) | (0x11111111u & ~m);
+                    if (all_dna(cj)) tail16 = to_2bit(cj);
+                }
             }
             const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
             const bool second = !jumping && line_hi != line_lo;
@@ -425,64 +551,65 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 else pa = tab + static_cast<uint64_t>(row) * (kJump / 16);
                 pa1 = pa + 1;  // second half of a 32-byte entry
             }
-            const bool need_a1 = !jumping || kLevels == 4;
+            const bool need_a1 = !jumping || kLevels == 5;
             const unsigned long long m_a1 = __ballot(need_a1), m_second = __ballot(second);
             u32x4 a[kChunks], b[kChunks];
-            issue_chunk_load<kPolicy>(pa, a[0]);
-            if (kChunks == 2) issue_chunk_load_masked<kPolicy>(pa1, a[kChunks - 1], m_a1);
-#pragma unroll
-            for (int k = 0; k < kChunks; k++) {
-                issue_chunk_load_masked<kPolicy>(pb + k * kGroup, b[k], m_second);
-            }
-            if (kChunks == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[kChunks - 1]), "+v"(b[kChunks - 1])::"memory");
+            // all loads of the round, their exec masks and the one wait: a single asm statement (layout.hpp)
+            if (kChunks == 2) load_round4<kPolicy>(pa, pa1, pb, pb + kGroup, m_a1, m_second, a[0], a[kChunks - 1], b[0], b[kChunks - 1]);
+            else load_round2<kPolicy>(pa, pb, m_second, a[0], b[0]);
             if (jumping) {
-                // level j (1-based) of an entry: {row after 8j steps, codes of steps 8j-7 .. 8j}
-                uint32_t tgt[4] = {0u, 0u, 0u, 0u}, cod[4] = {0u, 0u, 0u, 0u};
+                // entry layout (layout.hpp): a[0] = {t1, t2, c1 | c2 << 16, c3 | valid << 16},
+                // a[1] = {t3, t4, t5, c4 | c5 << 16}; 8-byte entries: {t1, c1 | valid << 16}
+                uint32_t valid, da, db = 0, dc = 0;  // d*: stored codes XOR query codes, packed as above
+                const u32x4 e0 = a[0], e1 = a[kChunks - 1];
                 if (kJump == 8) {
-                    tgt[0] = (row & 1u) ? a[0].z : a[0].x;
-                    cod[0] = (row & 1u) ? a[0].w : a[0].y;
+                    const uint32_t w = (row & 1u) ? e0.w : e0.y;
+                    da = (w ^ qa) & 0xffffu;
+                    valid = w >> 16;
                 } else {
-                    tgt[0] = a[0].x;
-                    cod[0] = a[0].y;
-                    tgt[1] = a[0].z;
-                    cod[1] = a[0].w;
-                    if (kLevels == 4) {
-                        tgt[2] = a[kChunks - 1].x;
-                        cod[2] = a[kChunks - 1].y;
-                        tgt[3] = a[kChunks - 1].z;
-                        cod[3] = a[kChunks - 1].w;
-                    }
+                    da = e0.z ^ qa;
+                    db = (e0.w ^ qb) & 0xffffu;
+                    valid = e0.w >> 16;
+                    if (kLevels == 5) dc = e1.w ^ qc;
                 }
-                // how many levels this lane's row matches; a level needs all the levels before it
-                uint32_t lvl = cod[0] == code ? 1u : 0u;
-#pragma unroll
-                for (int j = 1; j < kLevels; j++)
-                    if (lvl == static_cast<uint32_t>(j) && rem >= (j + 1u) * kJumpSymbols && cod[j] == codes[j] &&
-                        !has_zero_nibble(codes[j]))
-                        lvl = j + 1u;
+                // how many levels this lane's row matches: a level needs a valid stored level (the valid bits are
+                // cumulative), a usable query level and equal codes, and all the levels before it
+                uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
+                if (kLevels >= 2) good |= (da >> 16) == 0u ? 2u : 0u;
+                if (kLevels == 5) {
+                    good |= db == 0u ? 4u : 0u;
+                    good |= (dc & 0xffffu) == 0u ? 8u : 0u;
+                    good |= (dc >> 16) == 0u ? 16u : 0u;
+                }
+                good &= valid & qok;
+                const uint32_t lvl = static_cast<uint32_t>(__builtin_ctz(~good | (1u << kLevels)));  // trailing ones
                 const uint32_t best = group_max<kGroup>(lvl);
                 if (best != 0u) {
                     const bool mine = lvl == best;
-                    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
                     // locate hint, candidate 1: the one-row interval this jump starts from (see below)
                     uint32_t hr = 0xffffffffu, ho = 0;
-                    const bool want_hint = out_hint != nullptr && !(status >> 31);  // one hint per query is enough
-                    if (want_hint && hi - lo == 1u &&
-                        (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u))) {
+                    const bool want_hint = hinting && !(status >> 31);  // one hint per query is enough
+                    if (want_hint && hi - lo == 1u && (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u))) {
                         hr = lo;
                         ho = rem;
                     }
-                    const uint32_t target = best == 4u ? tgt[3] : (best == 3u ? tgt[2] : (best == 2u ? tgt[1] : tgt[0]));
+                    uint32_t target = kJump == 8 ? ((row & 1u) ? e0.z : e0.x) : e0.x;
+                    if (kLevels >= 2) target = best == 2u ? e0.y : target;
+                    if (kLevels == 5) {
+                        target = best == 3u ? e1.x : target;
+                        target = best == 4u ? e1.y : target;
+                        target = best == 5u ? e1.z : target;
+                    }
                     lo = group_min<kGroup>(mine ? target : 0xffffffffu);
                     hi = group_max<kGroup>(mine ? target : 0u) + 1u;
                     const uint32_t done = best * kJumpSymbols;
                     rem -= done;
                     if (kStats) lf_steps += done;
-                    if (want_hint && hi - lo == 1u && hr == 0xffffffffu) {
+                    const bool one_row = hi - lo == 1u;
+                    if (want_hint && one_row && hr == 0xffffffffu) {
                         // Locate hint: the interval is one row, i.e. one occurrence at text position p, and the
                         // suffix of row lo starts rem symbols after p (rem are still to be matched to its left), so
-                        // p = SA[lo] - rem; the rows this jump passed through after 8, 16, 24 steps qualify too,
+                        // p = SA[lo] - rem; the rows this jump passed through after 8, 16, ... steps qualify too,
                         // that many symbols earlier.  If one of them is a sampled row, locate needs no walk.
                         if (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u)) {
                             hr = lo;
@@ -491,12 +618,40 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #pragma unroll
                         for (int j = kLevels - 1; j >= 1; j--) {
                             if (hr == 0xffffffffu && best > static_cast<uint32_t>(j)) {
-                                const uint32_t mid = group_min<kGroup>(mine ? tgt[j - 1] : 0xffffffffu);
+                                const uint32_t tj = j == 1 ? e0.x : (j == 2 ? e0.y : (j == 3 ? e1.x : e1.y));  // t_j
+                                const uint32_t mid = group_min<kGroup>(mine ? tj : 0xffffffffu);
                                 if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
                                     hr = mid;
                                     ho = rem + (best - j) * kJumpSymbols;
                                 }
                             }
+                        }
+                    }
+                    if (kMode == 1 && one_row && rem > 0u && rem < kJumpSymbols && best < static_cast<uint32_t>(kCodes)) {
+                        // Lazy tail: the next level of the matching row's entry holds the eight symbols that precede
+                        // the suffix of row lo; the occurrence survives iff the query's last rem symbols equal the
+                        // first rem of them.  2 = survives, 1 = does not, 0 = cannot tell (that level is invalid, or
+                        // a symbol outside 1..4 among the query's last rem): then the pair lines decide.
+                        uint32_t nxt = e0.z >> 16;  // codes of level best + 1
+                        nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
+                        if (kLevels == 5) {
+                            nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
+                            nxt = best == 4u ? (e1.w >> 16) : nxt;
+                        }
+                        const bool can = mine && ((valid >> best) & 1u) && tail16 != kNoCode;
+                        const uint32_t tmask = (0xffffu << (16u - 2u * rem)) & 0xffffu;
+                        const uint32_t verdict = group_max<kGroup>(can ? (((nxt ^ tail16) & tmask) == 0u ? 2u : 1u) : 0u);
+                        if (verdict != 0u) {
+                            if (kStats) lf_steps += rem;  // (an upper bound when the occurrence does not survive)
+                            if (verdict == 2u) {
+                                if (hinting && hr == 0xffffffffu) {  // no sampled row on the way: locate walks from lo
+                                    hr = lo;
+                                    ho = rem;
+                                }
+                            } else {
+                                hi = lo;
+                            }
+                            rem = 0;
                         }
                     }
                     if (hr != 0xffffffffu) {
@@ -505,10 +660,11 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(hr, ho);
                         status |= 0x80000000u;  // hinted (kept out of the status byte below)
                     }
-                    if (done > kJumpSymbols) win.init(qbuf, begin, rem, s_dense);
+                    if (done > kJumpSymbols && rem > 0u) win.reinit(rem, s_dense);
                 } else {
-                    // the interval empties within the next 8 steps: the pair lines find where, which yields the
-                    // reference's frozen interval (rare: a read that occurs in the text always matches)
+                    // the interval empties within the next 8 steps (or a stored symbol is outside 1..4): the pair
+                    // lines find where, which yields the reference's frozen interval (rare: a read that occurs in
+                    // the text always matches)
                     jump_ok = false;
                 }
                 continue;
@@ -531,7 +687,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 }
                 const uint32_t nlo = group_sum<kGroup>(plo), nhi = group_sum<kGroup>(phi);
                 if (nlo != nhi) {
-                    if (out_hint != nullptr && !(status >> 31) && hi - lo == 1u && nhi - nlo == 1u) {
+                    if (hinting && !(status >> 31) && hi - lo == 1u && nhi - nlo == 1u && rem < (1u << 21)) {
                         // locate hint from a pair step of a one-row interval: the row in between, LF(c1, lo), comes
                         // out of the same line; rem - 1 symbols are still unmatched there (see the jump above)
                         const uint32_t bx1 = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
@@ -540,7 +696,6 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #pragma unroll
                         for (int k = 0; k < kChunks; k++) pm += PairTable::single_partial(a[k], sub + k * kGroup, c1, nx1, lo);
                         const uint32_t mid = group_sum<kGroup>(pm);
-                        const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
                         if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
                             if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(mid, rem - 1u);
                             status |= 0x80000000u;
@@ -571,12 +726,25 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             }
         }
         if (writer) {
+            // a hint describes the one row of a non-empty result; drop it when the search went on and emptied it
+            const bool hinted = (status >> 31) && hi - lo == 1u;
+            const uint2 hv = hinted ? s_hint[threadIdx.x / kGroup] : make_uint2(0xffffffffu, 0u);
+            if (out_rec) {
+                uint4 rec;
+                rec.x = lo;
+                rec.y = hi;
+                rec.z = hv.x;
+                rec.w = (hv.y & 0xffffffu) | ((status & 0xffu) << 24);
+                out_rec[q] = rec;
+            }
             if (out_start) out_start[q] = lo;
             if (out_end) out_end[q] = hi;
             if (out_count) out_count[q] = hi - lo;
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
-            if (out_hint) out_hint[q] = (status >> 31) ? s_hint[threadIdx.x / kGroup] : make_uint2(0xffffffffu, 0u);
+            if (out_hint) out_hint[q] = hv;
         }
+        if (kMode == 2 && ca.active_out != nullptr)  // compaction: the cursors that can still be extended
+            compact_alive(writer && lo != hi && (status & 0xffu) == 0u, static_cast<uint32_t>(q), ca);
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;
             for (int off = 32; off > 0; off >>= 1) {
@@ -596,39 +764,40 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 }
 
 #define GDX_SEARCH_ARGS                                                                                      \
-    IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qoff, uint64_t nq,         \
-        uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, \
-        uint8_t *__restrict__ out_status, unsigned long long *__restrict__ step_stats, uint32_t range, int schedule, \
-        uint2 *__restrict__ out_hint
+    IndexView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg,                       \
+        const uint64_t *__restrict__ qend, uint64_t nq, uint32_t *__restrict__ out_start,                    \
+        uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status,  \
+        unsigned long long *__restrict__ step_stats, uint32_t range, int schedule, uint2 *__restrict__ out_hint, \
+        uint4 *__restrict__ out_rec, CursorArgs ca
 #define GDX_SEARCH_FWD \
-    ix, qbuf, qoff, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule, out_hint
+    ix, qbuf, qbeg, qend, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule, out_hint, out_rec, ca
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
 // The 4-lane kernel holds two chunks per lane and line.  With the jump levels, hints and ranges it no longer fits
 // 64 VGPRs without spilling 19 of them (whose scratch traffic showed up as a million DRAM writes per 10 M reads),
 // so it runs at 7 waves per SIMD (72 VGPRs, 5 spilled): 11.1 ms against 11.6 ms at 8 waves and 11.7 ms at 6.
-template <int kPolicy, int kJump>
+template <int kPolicy, int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, false, kJump>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, false, kJump, kMode>(GDX_SEARCH_FWD);
 }
-template <int kPolicy, int kJump>
+template <int kPolicy, int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, false, kJump>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, false, kJump, kMode>(GDX_SEARCH_FWD);
 }
 // accounting variants (gdx_search_step_stats_dev): the counters cost registers, so they are kept out of the
-// timed kernels
-template <int kPolicy, int kJump>
+// timed kernels; always the exact mode, whose LF steps are the reference's
+template <int kPolicy, int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel8(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 8, true, kJump>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 8, true, kJump, kMode>(GDX_SEARCH_FWD);
 }
-template <int kPolicy, int kJump>
+template <int kPolicy, int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) void search_pair_stats_kernel4(GDX_SEARCH_ARGS)
 {
-    search_pair_body<kPolicy, 4, true, kJump>(GDX_SEARCH_FWD);
+    search_pair_body<kPolicy, 4, true, kJump, kMode>(GDX_SEARCH_FWD);
 }
 
 // Cursor::extend_query_front for m independent cursors (cursor.rs:34-51).  kGroup lanes per cursor as in
@@ -786,7 +955,25 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                    uint32_t *d_out_start, uint32_t *d_out_end, uint32_t *d_out_count, uint8_t *d_out_status,
                    hipStream_t stream, unsigned long long *d_step_stats, uint2 *d_hint, const QueryOptions &qo)
 {
+    SearchCall c;
+    c.d_qbuf = d_qbuf;
+    c.d_qbeg = d_qoff;
+    c.d_qend = d_qoff + 1;
+    c.nq = nq;
+    c.d_start = d_out_start;
+    c.d_end = d_out_end;
+    c.d_count = d_out_count;
+    c.d_status = d_out_status;
+    c.d_hint = d_hint;
+    c.d_step_stats = d_step_stats;
+    launch_search_call(ix, c, stream, qo);
+}
+
+void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t stream, const QueryOptions &qo)
+{
+    const uint64_t nq = c.nq;
     if (nq == 0) return;
+    if (c.mode < 0 || c.mode > 2) fail(GDX_ERR_INVALID_ARGUMENT, "internal: search mode %d", c.mode);
     const int variant = qo.search_variant >= 0 ? qo.search_variant : search_variant();
     // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
     // profiles/r01/search_variants.md): many short-lived blocks beat a resident grid -- 65536 blocks: 78 ms,
@@ -805,6 +992,7 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
         if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
         return static_cast<unsigned>(blocks);
     };
+    const CursorArgs ca = c.cursors;
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
         // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
         // QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
@@ -823,56 +1011,66 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                                                   : static_cast<unsigned>(n_ranges < (1u << 20) ? n_ranges : (1u << 20));
         // Cache policy of the line / entry loads: plain by default.  sc1 (no allocation in the CU's L1) was worth
         // +5 % while the first levels of the search were cache-resident pair lines; with the top table every load
-        // is a DRAM miss and plain loads measure 3 % faster.  GDX_LOAD_POLICY=0|1 = plain, sc1 (nt and sc0 sc1 were
-        // tried on the pair lines too: plain 101.5, sc1 95.7, nt 98.7, sc0 sc1 96.5 ms at the time; search_variants.md).
+        // is a DRAM miss and plain loads measure 3 % faster.  QueryOptions::load_policy / GDX_LOAD_POLICY=0|1.
         static const int env_policy = [] {
             const char *e = getenv("GDX_LOAD_POLICY");
             return e ? atoi(e) : 0;
         }();
-        const int policy = qo.load_policy >= 0 ? qo.load_policy : env_policy;
+        const int policy = (qo.load_policy >= 0 ? qo.load_policy : env_policy) == 1 ? 1 : 0;
         // Ranges whose query lengths are spread out are searched in length order (order_range_by_length);
-        // GDX_SEARCH_SCHEDULE=0 keeps the query order.
+        // QueryOptions::length_schedule / GDX_SEARCH_SCHEDULE=0 keeps the query order.
         static const int env_schedule = [] {
             const char *e = getenv("GDX_SEARCH_SCHEDULE");
             return (e && e[0] == '0') ? 0 : 1;
         }();
         const int schedule = qo.length_schedule >= 0 ? (qo.length_schedule != 0) : env_schedule;
-#define GDX_PAIR_LAUNCH(KERNEL)                                                                                   \
-    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, d_qbuf, d_qoff, nq, d_out_start, \
-                       d_out_end, d_out_count, d_out_status, d_step_stats, range, schedule, d_hint)
-#define GDX_PAIR_LAUNCH_W(KERNEL, P)                                \
-    do {                                                            \
-        if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32>));  \
-        else if (ix.jump_bytes == 16) GDX_PAIR_LAUNCH((KERNEL<P, 16>)); \
-        else GDX_PAIR_LAUNCH((KERNEL<P, 8>));                       \
+#define GDX_PAIR_LAUNCH(KERNEL)                                                                                     \
+    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, c.d_qbuf, c.d_qbeg, c.d_qend, nq,   \
+                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, ca)
+#define GDX_PAIR_LAUNCH_W(KERNEL, P, M)                                    \
+    do {                                                                   \
+        if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32, M>));      \
+        else if (ix.jump_bytes == 16) GDX_PAIR_LAUNCH((KERNEL<P, 16, M>)); \
+        else GDX_PAIR_LAUNCH((KERNEL<P, 8, M>));                           \
     } while (0)
-        if (d_step_stats != nullptr) {
-            if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 0);
-            else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0);
+#define GDX_PAIR_LAUNCH_M(KERNEL, P)                      \
+    do {                                                  \
+        if (c.mode == 0) GDX_PAIR_LAUNCH_W(KERNEL, P, 0); \
+        else if (c.mode == 1) GDX_PAIR_LAUNCH_W(KERNEL, P, 1); \
+        else GDX_PAIR_LAUNCH_W(KERNEL, P, 2);             \
+    } while (0)
+        if (c.d_step_stats != nullptr) {  // accounting: always the exact mode (the reference's LF steps)
+            if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 0, 0);
+            else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0, 0);
         } else if (lanes == 8) {
-            if (policy == 1) GDX_PAIR_LAUNCH_W(search_pair_kernel8, 1);
-            else GDX_PAIR_LAUNCH_W(search_pair_kernel8, 0);
+            if (policy == 1) GDX_PAIR_LAUNCH_M(search_pair_kernel8, 1);
+            else GDX_PAIR_LAUNCH_M(search_pair_kernel8, 0);
         } else {
-            if (policy == 0) GDX_PAIR_LAUNCH_W(search_pair_kernel4, 0);
-            else GDX_PAIR_LAUNCH_W(search_pair_kernel4, 1);
+            if (policy == 0) GDX_PAIR_LAUNCH_M(search_pair_kernel4, 0);
+            else GDX_PAIR_LAUNCH_M(search_pair_kernel4, 1);
         }
+#undef GDX_PAIR_LAUNCH_M
 #undef GDX_PAIR_LAUNCH_W
 #undef GDX_PAIR_LAUNCH
-    } else if (ix.layout == 0 && variant != 1) {
-        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));  // only the pair kernels hint
-        const unsigned blocks = group_grid(kBlock / 4);
-        hipLaunchKernelGGL((search_kernel<QuadLineTable, 4>), dim3(blocks), dim3(kBlock), lds_pad,
-                           stream, ix, d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status,
-                           d_step_stats);
-    } else if (ix.layout == 0) {
-        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));
-        hipLaunchKernelGGL((search_kernel<LineTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix, d_qbuf,
-                           d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
-    } else {
-        if (d_hint) GDX_HIP(hipMemsetAsync(d_hint, 0xff, nq * sizeof(uint2), stream));
-        hipLaunchKernelGGL((search_kernel<GenericTable, 1>), dim3(grid_for_items(nq)), dim3(kBlock), 0, stream, ix,
-                           d_qbuf, d_qoff, nq, d_out_start, d_out_end, d_out_count, d_out_status, d_step_stats);
+        return;
     }
+    // rank-line and generic kernels: no hints (locate then walks from the interval itself)
+    if (c.d_hint) GDX_HIP(hipMemsetAsync(c.d_hint, 0xff, nq * sizeof(uint2), stream));
+#define GDX_PLAIN_LAUNCH(TABLE, GROUP, GRID)                                                                        \
+    do {                                                                                                            \
+        if (c.mode == 2)                                                                                            \
+            hipLaunchKernelGGL((search_kernel<TABLE, GROUP, true>), dim3(GRID), dim3(kBlock), lds_pad, stream, ix,  \
+                               c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status,         \
+                               c.d_step_stats, c.d_rec, ca);                                                        \
+        else                                                                                                        \
+            hipLaunchKernelGGL((search_kernel<TABLE, GROUP, false>), dim3(GRID), dim3(kBlock), lds_pad, stream, ix, \
+                               c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status,         \
+                               c.d_step_stats, c.d_rec, ca);                                                        \
+    } while (0)
+    if (ix.layout == 0 && variant != 1) GDX_PLAIN_LAUNCH(QuadLineTable, 4, group_grid(kBlock / 4));
+    else if (ix.layout == 0) GDX_PLAIN_LAUNCH(LineTable, 1, grid_for_items(nq));
+    else GDX_PLAIN_LAUNCH(GenericTable, 1, grid_for_items(nq));
+#undef GDX_PLAIN_LAUNCH
 }
 
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,

@@ -151,6 +151,35 @@ class DeviceEngine:
                                                      _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
                                                      _stream()))
 
+    # ---- fused count + locate over 16-byte search records (gdx_locate_many_*_dev) -------------------------
+    def alloc_records(self, nq: int) -> torch.Tensor:
+        return torch.empty((max(nq, 1), 4), dtype=torch.int32, device=self.dev)
+
+    def locate_search(self, q: DeviceQueries, rec: torch.Tensor) -> None:
+        _lib.check(self.lib.gdx_locate_many_search_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec), _stream()))
+
+    def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor) -> None:
+        _lib.check(self.lib.gdx_locate_many_offsets_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), _stream()))
+
+    def locate_hits(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, total: int, hits: torch.Tensor,
+                    workspace: torch.Tensor) -> None:
+        _lib.check(self.lib.gdx_locate_many_hits_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
+                                                     _ptr(workspace), _stream()))
+
+    def unpack_records(self, rec: torch.Tensor, nq: int, counts=None, status=None) -> None:
+        _lib.check(self.lib.gdx_locate_many_unpack_dev(self.h, _ptr(rec), nq,
+                                                       _ptr(counts) if counts is not None else None,
+                                                       _ptr(status) if status is not None else None, _stream()))
+
+    # ---- batched cursor extension by strings (gdx_cursor_extend_front_strings_dev) ------------------------
+    def cursor_extend_strings(self, start, end, qbuf, qbeg, qend, m, status=None, active_in=None, n_active_in=None,
+                              active_out=None, n_active_out=None) -> None:
+        opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
+        _lib.check(self.lib.gdx_cursor_extend_front_strings_dev(self.h, _ptr(start), _ptr(end), _ptr(qbuf), _ptr(qbeg),
+                                                                _ptr(qend), m, opt(status), opt(active_in),
+                                                                opt(n_active_in), opt(active_out), opt(n_active_out),
+                                                                _stream()))
+
     def search_step_stats(self, q: DeviceQueries):
         """(LF steps, line fetches of all queries, fetch slots their wavefronts spent)"""
         steps = torch.zeros(3, dtype=torch.int64, device=self.dev)

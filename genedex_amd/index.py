@@ -276,6 +276,18 @@ class FmIndex:
         _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
         return s, e, status
 
+    def extend_front_strings_raw(self, starts, ends, qbuf, qoff, status=None, strict=True):
+        """gdx_cursor_extend_front_strings: cursor i is extended by the whole string i (right to left)."""
+        s = np.array(starts, dtype=np.uint64)
+        e = np.array(ends, dtype=np.uint64)
+        qbuf = np.ascontiguousarray(qbuf, dtype=np.uint8)
+        qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+        st_arr = np.zeros(s.size, dtype=np.uint8) if status is None else np.array(status, dtype=np.uint8)
+        st = self._lib.gdx_cursor_extend_front_strings(self._h, _p(s, u64p), _p(e, u64p), _p(qbuf, u8p),
+                                                       _p(qoff, u64p), s.size, _p(st_arr, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return s, e, st_arr
+
     def rank_many(self, symbols, idx):
         """TextWithRankSupport::rank (text_with_rank_support/mod.rs:106-110), batched."""
         sym = np.ascontiguousarray(symbols, dtype=np.uint8)
@@ -383,6 +395,12 @@ class Cursor:
         """cursor.rs:34-38; raises where the reference panics (symbol not in the alphabet)."""
         sym = symbol if isinstance(symbol, int) else bytes(symbol)[0]
         s, e, _ = self.index.extend_front_raw([self.start], [self.end], [sym])
+        self.start, self.end = int(s[0]), int(e[0])
+
+    def extend_query_front_by(self, symbols) -> None:
+        """extend_query_front for every symbol of `symbols`, last symbol first, in one launch"""
+        qbuf, qoff = pack_queries([bytes(symbols)])
+        s, e, _ = self.index.extend_front_strings_raw([self.start], [self.end], qbuf, qoff)
         self.start, self.end = int(s[0]), int(e[0])
 
     def count(self) -> int:

@@ -283,6 +283,51 @@ int gdx_cursors_for_many_queries_hint_dev(const gdx_index_t *ix, const void *d_q
 int gdx_locate_intervals_hint_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
                                   const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
                                   const void *d_hint, void *stream);
+/* ---- fused count + locate on the device (the device form of FmIndex::locate_many, lib.rs:179-185) -----------------
+ * The search writes one opaque 16-byte record per query (d_records: 16-byte aligned, 16 * nq bytes) that carries the
+ * query's number of occurrences, its status and what locate needs.  Because only the hits matter here -- not the
+ * suffix-array interval itself -- the search may finish a query from a jump-table entry it already holds instead of
+ * fetching one more line ("lazy tail"); counts and hits are the reference's, bit for bit and in
+ * the same order.
+ *   1. gdx_locate_many_search_dev     qbuf, qoff -> records
+ *   2. gdx_locate_many_offsets_dev    records -> d_hit_offsets (u64[nq+1], exclusive scan of the counts);
+ *                                     d_hit_offsets[nq] is the number of hits (read it back to size d_hits)
+ *   3. gdx_locate_many_hits_dev       records + offsets -> d_hits (gdx_hit32_t[total]), hits of query i at
+ *                                     [off[i], off[i+1]) in suffix-array order (lib.rs:187-197);
+ *                                     d_workspace: gdx_locate_workspace_bytes(total) bytes
+ * gdx_locate_many_unpack_dev extracts counts (u32) and / or status bytes from the records (either may be NULL). */
+int gdx_locate_many_search_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff /*u64*/, uint64_t nq,
+                               void *d_records, void *stream);
+int gdx_locate_many_offsets_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_hit_offsets,
+                                void *stream);
+int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                             uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
+int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
+                               void *d_out_status, void *stream);
+
+/* ---- batched cursor extension by strings (Cursor::extend_query_front, cursor.rs:34-51, applied to every symbol of
+ * a string from its last to its first; ROADMAP.md:33 "API to use batched search with cursors") --------------------
+ * Cursor i is extended by string i = d_qbuf[d_qbeg[i] .. d_qend[i]) (for a plain offsets array pass d_qoff and
+ * d_qoff + 1; two arrays allow chunk views into longer queries without copying bytes).  d_start / d_end are
+ * in / out.  A cursor whose interval is (or becomes) empty is left as it is and the rest of its string is not
+ * looked at (the reference would still translate those symbols and panic on an invalid one, cursor.rs:35-38).
+ * An invalid symbol stops the cursor where it stands and sets d_status[i] = GDX_Q_INVALID_SYMBOL; a stopped cursor
+ * ignores later calls (d_status is in / out when given: zero it together with gdx_cursor_empty).
+ * Active lists (optional, device-side compaction so that a caller feeding long queries in chunks only touches live
+ * cursors): d_active_in = indices (u32) of the cursors to extend, *d_n_active_in (u32 in device memory) of them,
+ * NULL = all m; the cursors that are still non-empty and not stopped afterwards are appended to d_active_out
+ * (u32[m], any order) and counted in *d_n_active_out (u32 in device memory, zeroed by this call).  m remains the
+ * upper bound the launch is sized for.  One launch advances a cursor by its whole string through the pair lines
+ * and the jump table (up to 40 LF steps per fetch), not one LF step per launch. */
+int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start /*u32*/, void *d_end /*u32*/,
+                                        const void *d_qbuf, const void *d_qbeg /*u64*/, const void *d_qend /*u64*/,
+                                        uint64_t m, void *d_status /*u8 or NULL*/, const void *d_active_in,
+                                        const void *d_n_active_in, void *d_active_out, void *d_n_active_out,
+                                        void *stream);
+/* host form: strings = qbuf + qoff[m+1]; start / end in / out; status (in / out, may be NULL) */
+int gdx_cursor_extend_front_strings(const gdx_index_t *ix, uint64_t *start, uint64_t *end, const uint8_t *qbuf,
+                                    const uint64_t *qoff, uint64_t m, uint8_t *status);
+
 /* Unlike gdx_rank_many, which returns GDX_ERR_INVALID_ARGUMENT, the device form cannot report an argument
  * error without synchronising: an entry with symbol >= sigma or idx > n yields d_out[i] = 0 and, if d_error
  * (u32, may be NULL) is given, *d_error is set to 1 (the caller zeroes it beforehand). */

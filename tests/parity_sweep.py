@@ -2,13 +2,12 @@
 """Randomised parity sweep of the HIP path against the CPU oracle, wider than the pytest suite.
 
 Every round draws a configuration (alphabet, number and size of texts, repeat structure, sampling rate, lookup
-depth, jump entry size, forced top-table depth, lanes per query, index storage), builds the index with both
-implementations and compares intervals, statuses, hits (host API = fused search + hinted locate; device API with and
-without hints) bit for bit.  Test infrastructure: it uses oracle/ as the checker.
+depth, jump entry size, forced top-table depth, lanes per query, load policy, index storage: gdx_build_options_t /
+gdx_query_options_t), builds the index with both implementations and compares intervals, statuses, hits (host API;
+device API with and without hints; the fused record path with its lazy tails; cursors extended chunk by chunk with
+device-side active lists) bit for bit.  Test infrastructure: it uses oracle/ as the checker.
 
 usage: python tests/parity_sweep.py [rounds, default 60] [seed, default 1]  -> one JSON line
-Kernel variants chosen by environment variables read once per process (lanes) are swept by running the tool in
-several processes: GDX_SEARCH_LANES=8 python tests/parity_sweep.py ...
 """
 import json
 import os
@@ -84,27 +83,18 @@ def one_round(rng, stats):
     rate = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 33]))
     k = a.num_searchable_dense_symbols()
     depth = int(rng.integers(0, 6 if k <= 4 else 3))
-    env = {"GDX_JUMP_BYTES": str(rng.choice(["32", "32", "16", "8", "0"])),
-           "GDX_TOP_DEPTH": str(rng.choice(["", "", "0", "3", "6", "8", "10"])),
-           "GDX_NO_PAIR_LINES": str(rng.choice(["", "", "", "1"]))}
+    build = {"jump_entry_bytes": [32, 32, 16, 8, 0][int(rng.integers(0, 5))],
+             "top_table_depth": [None, None, 0, 3, 6, 8, 10][int(rng.integers(0, 7))],
+             "pair_lines": [None, None, None, False][int(rng.integers(0, 4))]}
+    query = {"search_lanes": [4, 4, 8][int(rng.integers(0, 3))], "load_policy": int(rng.integers(0, 2)),
+             "length_schedule": int(rng.integers(0, 2))}
     storage = str(rng.choice(["i32", "u32"]))
     cfg = {"alphabet": name, "total": total, "n_texts": n_texts, "mode": mode, "sa_rate": rate, "depth": depth,
-           "storage": storage, **env}
-    saved = {key: os.environ.get(key) for key in env}
-    for key, v in env.items():
-        if v:
-            os.environ[key] = v
-        else:
-            os.environ.pop(key, None)
-    try:
-        texts = draw_texts(rng, symbols, total, n_texts, mode)
-        g = FmIndexConfig(storage).suffix_array_sampling_rate(rate).lookup_table_depth(depth).construct_index(texts, a)
-    finally:
-        for key, v in saved.items():
-            if v is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = v
+           "storage": storage, **build, **query}
+    texts = draw_texts(rng, symbols, total, n_texts, mode)
+    g = (FmIndexConfig(storage).suffix_array_sampling_rate(rate).lookup_table_depth(depth)
+         .acceleration_structures(**build).construct_index(texts, a))
+    g.set_query_options(**query)
     c = OracleIndex.build(texts, a.io_to_dense_table, a.num_dense_symbols(), k, sa_rate=rate, lookup_depth=depth,
                           width=-32 if storage == "i32" else 32)
     qs = draw_queries(rng, texts, symbols, int(rng.integers(200, 3000)), int(rng.choice([8, 40, 70, 150, 400])))
@@ -144,6 +134,57 @@ def one_round(rng, stats):
                 ("dev hits", hint, cfg)
             if hint:
                 stats["hinted_queries"] += int(((out["hint"] & 0xffffffff) != 0xffffffff).sum().item())
+        # fused count + locate over search records (lazy tails): counts, offsets and hits are the reference's
+        rec = eng.alloc_records(dq.nq)
+        off_t = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+        eng.locate_search(dq, rec)
+        eng.locate_offsets(rec, dq.nq, off_t)
+        torch.cuda.synchronize()
+        tot = int(off_t[dq.nq].item())
+        exp_off = np.concatenate([[0], np.cumsum((ce[keep] - cs[keep]).astype(np.uint64))]).astype(np.uint64)
+        assert off_t.cpu().numpy().astype(np.uint64).tolist() == exp_off.tolist(), ("rec offsets", cfg)
+        hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+        if tot:
+            eng.locate_hits(rec, dq.nq, off_t, tot, hits, ws)
+        counts = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+        stat = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+        eng.unpack_records(rec, dq.nq, counts, stat)
+        torch.cuda.synchronize()
+        h = hits[:tot].cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), \
+            ("rec hits", cfg)
+        assert counts.cpu().numpy().astype(np.uint32).tolist() == (ce[keep] - cs[keep]).astype(np.uint32).tolist(), ("rec counts", cfg)
+        assert not stat.any().item(), ("rec status", cfg)
+        stats["lazy_or_hinted_records"] = stats.get("lazy_or_hinted_records", 0) + int((rec[:dq.nq, 2] != -1).sum().item())
+        # the same queries through the batched cursor API, fed in chunks of `chunk` symbols from the right, with
+        # device-side active lists: identical intervals (cursor.rs:34-51 applied symbol by symbol)
+        chunk = int(rng.choice([1, 5, 8, 16, 32, 50]))
+        m = dq.nq
+        qoff_t = dq.qoff
+        beg, endq = qoff_t[:-1].clone(), qoff_t[1:].clone()
+        cur_s = torch.zeros(m, dtype=torch.int32, device="cuda")
+        cur_e = torch.full((m,), g.total_text_len(), dtype=torch.int64, device="cuda").to(torch.int32)
+        cur_st = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        act = [torch.arange(m, dtype=torch.int32, device="cuda"), torch.empty(m, dtype=torch.int32, device="cuda")]
+        n_act = [torch.tensor([m], dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")]
+        hi_edge = endq.clone()
+        rounds = 0
+        while True:
+            lo_edge = torch.maximum(beg, hi_edge - chunk)
+            eng.cursor_extend_strings(cur_s, cur_e, dq.qbuf, lo_edge, hi_edge, m, cur_st, act[0], n_act[0], act[1], n_act[1])
+            hi_edge = lo_edge
+            act.reverse()
+            n_act.reverse()
+            rounds += 1
+            if int(n_act[0].item()) == 0 or bool((hi_edge <= beg).all().item()):
+                break
+        torch.cuda.synchronize()
+        # a cursor whose query still had symbols left when it emptied is frozen exactly like the fused search
+        assert cur_s.cpu().numpy().astype(np.uint32).tolist() == cs[keep].astype(np.uint32).tolist(), ("cursor start", chunk, cfg)
+        assert cur_e.cpu().numpy().astype(np.uint32).tolist() == ce[keep].astype(np.uint32).tolist(), ("cursor end", chunk, cfg)
+        assert not cur_st.any().item()
+        stats["cursor_rounds"] = stats.get("cursor_rounds", 0) + rounds
     stats["queries"] += len(qs)
     stats["hits"] += int(co[-1])
     stats["status_nonzero"] += int((st != 0).sum())
@@ -159,10 +200,11 @@ def main():
     seen = {}
     for _ in range(rounds):
         cfg = one_round(rng, stats)
-        for key in ("alphabet", "mode", "GDX_JUMP_BYTES", "GDX_TOP_DEPTH", "GDX_NO_PAIR_LINES", "sa_rate", "depth"):
+        for key in ("alphabet", "mode", "jump_entry_bytes", "top_table_depth", "pair_lines", "search_lanes", "load_policy",
+                    "length_schedule", "sa_rate", "depth"):
             seen.setdefault(key, {}).setdefault(str(cfg[key]), 0)
             seen[key][str(cfg[key])] += 1
-    print(json.dumps({"rounds": rounds, "seed": seed, "lanes": os.environ.get("GDX_SEARCH_LANES", "4"), "all_equal": True,
+    print(json.dumps({"rounds": rounds, "seed": seed, "all_equal": True,
                       "seconds": round(time.time() - t0, 1), **stats, "configurations_seen": seen}))
 
 

@@ -637,3 +637,125 @@ def test_randomised_configurations_sample():
     for _ in range(25):
         mod.one_round(rng, stats)
     assert stats["queries"] > 10_000 and stats["hits"] > 0
+
+
+def _device_queries(qs):
+    from genedex_amd.device import DeviceQueries
+
+    qbuf, qoff = pack_queries(qs)
+    return DeviceQueries.from_host(qbuf, qoff), qbuf, qoff
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_record_path_equals_oracle(seed, search_variant):
+    """gdx_locate_many_{search,offsets,hits}_dev: the search may finish a query from the jump entry it holds (lazy
+    tail) and reports counts + locate hints in 16-byte records; counts, hit offsets and hits (order included) are the
+    oracle's for every query length modulo 8, every sampling rate and every index configuration."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine
+
+    rng = np.random.default_rng(7000 + seed)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=60000, symbols=b"ACGTN" if seed % 3 == 0 else b"ACGT")
+    rate = [1, 2, 3, 4, 7, 16][seed]
+    g, c = both(texts, a, sa_rate=rate, depth=[0, 2][seed % 2])
+    qs = mixed_queries(rng, texts, 1500, 300, 75) + [b"", b"A", b"ACGTACGTAC"]
+    dq, qbuf, qoff = _device_queries(qs)
+    eng = DeviceEngine(g)
+    rec = eng.alloc_records(dq.nq)
+    off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+    eng.locate_search(dq, rec)
+    eng.locate_offsets(rec, dq.nq, off)
+    torch.cuda.synchronize()
+    total = int(off[dq.nq].item())
+    hits = torch.empty((max(total, 1), 2), dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(eng.locate_workspace_bytes(total), 16), dtype=torch.uint8, device="cuda")
+    eng.locate_hits(rec, dq.nq, off, total, hits, ws)
+    counts = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+    status = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+    eng.unpack_records(rec, dq.nq, counts, status)
+    torch.cuda.synchronize()
+    co, ct, cp = c.locate_many(qs)
+    assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+    h = hits[:total].cpu().numpy().astype(np.uint32)
+    assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
+    assert counts.cpu().numpy().astype(np.uint32).tolist() == np.diff(co).tolist()
+    assert not status.any().item()
+    # gdx_count_many_dev takes the same shortcut
+    counts2 = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+    eng.count(dq, counts2, status)
+    torch.cuda.synchronize()
+    assert torch.equal(counts, counts2)
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 8, 16, 32, 40, 1000])
+def test_cursor_strings_in_chunks_equal_fused_search(chunk, search_variant):
+    """gdx_cursor_extend_front_strings_dev: queries fed to cursor_empty cursors `chunk` symbols at a time from the
+    right, with device-side active lists, end in exactly the intervals of cursors_for_many_queries (and hence of
+    cursor.rs:34-51 applied symbol by symbol), frozen empty intervals included."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine
+
+    rng = np.random.default_rng(7100 + chunk)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=50000, symbols=b"ACGTN" if chunk % 2 else b"ACGT")
+    g, c = both(texts, a)
+    qs = mixed_queries(rng, texts, 1200, 500, 160) + [b""]
+    dq, qbuf, qoff = _device_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    eng = DeviceEngine(g)
+    m = dq.nq
+    n = g.total_text_len()
+    beg, end = dq.qoff[:-1].clone(), dq.qoff[1:].clone()
+    cur_s = torch.zeros(m, dtype=torch.int32, device="cuda")
+    cur_e = torch.full((m,), n, dtype=torch.int32, device="cuda")
+    cur_st = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    act = [torch.arange(m, dtype=torch.int32, device="cuda"), torch.empty(m, dtype=torch.int32, device="cuda")]
+    n_act = [torch.tensor([m], dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")]
+    edge = end.clone()
+    seen_counts = []
+    while True:
+        lo = torch.maximum(beg, edge - chunk)
+        eng.cursor_extend_strings(cur_s, cur_e, dq.qbuf, lo, edge, m, cur_st, act[0], n_act[0], act[1], n_act[1])
+        edge = lo
+        act.reverse()
+        n_act.reverse()
+        live = int(n_act[0].item())
+        seen_counts.append(live)
+        # the active list holds exactly the cursors that are non-empty
+        listed = sorted(act[0][:live].cpu().tolist())
+        assert listed == torch.nonzero(cur_s != cur_e).flatten().cpu().tolist()
+        if live == 0 or bool((edge <= beg).all().item()):
+            break
+    assert cur_s.cpu().numpy().astype(np.uint32).tolist() == cs.astype(np.uint32).tolist()
+    assert cur_e.cpu().numpy().astype(np.uint32).tolist() == ce.astype(np.uint32).tolist()
+    assert not cur_st.any().item()
+    assert seen_counts == sorted(seen_counts, reverse=True)  # cursors only ever leave the list
+    # host form, whole strings at once, and the Python mirror of Cursor
+    s0 = np.zeros(m, dtype=np.uint64)
+    e0 = np.full(m, n, dtype=np.uint64)
+    hs, he, hst = g.extend_front_strings_raw(s0, e0, qbuf, qoff)
+    assert hs.tolist() == cs.tolist() and he.tolist() == ce.tolist() and not hst.any()
+    cur = g.cursor_empty()
+    cur.extend_query_front_by(qs[0])
+    assert cur.interval() == (int(cs[0]), int(ce[0]))
+
+
+def test_cursor_strings_stop_at_an_invalid_symbol():
+    """alphabet.rs:195-198 panics on a symbol outside the alphabet; here the cursor stops where it stands, its
+    status is set, it leaves the active list and ignores later calls."""
+    a = alph.ascii_dna()
+    texts = [b"ACGTACGTTTGACA"]
+    g, c = both(texts, a)
+    qs = [b"ACGT", b"AC!T", b"TTGA"]
+    qbuf, qoff = pack_queries(qs)
+    n = g.total_text_len()
+    s, e, st = g.extend_front_strings_raw(np.zeros(3, np.uint64), np.full(3, n, np.uint64), qbuf, qoff, strict=False)
+    want = g.cursors_for_many_queries([b"ACGT", b"T", b"TTGA"])  # query 1 stops after its last symbol
+    assert [(int(a_), int(b_)) for a_, b_ in zip(s, e)] == [w.interval() for w in want]
+    assert st.tolist() == [0, 1, 0]
+    s2, e2, st2 = g.extend_front_strings_raw(s, e, *pack_queries([b"T", b"A", b""]), status=st, strict=False)
+    assert (int(s2[1]), int(e2[1])) == (int(s[1]), int(e[1])) and st2.tolist() == [0, 1, 0]
+    assert (int(s2[0]), int(e2[0])) == g.cursor_for_query(b"TACGT").interval()
