@@ -2,22 +2,34 @@
 """bench.py -- headline benchmark: queries/sec (count+locate) on an hg38-scale synthetic DNA text.
 
 One "step" = one pass of the query hot path over one batch of synthetic reads that already sit in HBM:
-backward search of every query (lookup jump + LF loop) -> exclusive scan of the interval sizes ->
-locate walk of every hit (+ the result gather to rank 0 when N > 1).  The index (3.1 G symbols incl.
-24 sentinels, u32, sampling rate 4) is built on the GPU before the timed region and is not timed.
+backward search of every query -> exclusive scan of the counts -> locate of every hit (+ the result gather to
+rank 0 when N > 1).  The index (3.1 G symbols incl. 24 sentinels, u32, sampling rate 4 = BASELINE.json configs[2])
+is built on the GPU before the timed region and is not timed.
 
-    python bench.py --gpus N --steps K --warmup W [--workload hg38|cfg2|small] [--op count+locate|count]
+    python bench.py --gpus N --steps K --warmup W [--workload hg38|mixed|cfg2|small] [--op count+locate|count]
 
-For N > 1 launch one rank per GPU with torch.distributed.run; the index is replicated, every rank
-searches its own shard of N x nq queries (weak scaling), results are gathered to rank 0 over RCCL.
-Rank 0 prints ONE JSON line.  Everything else goes to stderr.
+For N > 1 launch one rank per GPU with torch.distributed.run; the index is replicated, every rank searches its own
+batch of nq queries (weak scaling: `value`), results are gathered to rank 0 over RCCL; the same run then shards ONE
+batch of nq queries over the ranks (BASELINE.json configs[3]: `strong_scaling`).  Rank 0 prints ONE JSON line.
+Everything else goes to stderr.
+
+Roofline (N = 1): `roofline.traffic` = HBM bytes of the dominant kernel per launch, measured by rocprofv3 PMC passes
+of this very workload that bench.py itself starts as child processes BEFORE it touches the GPU (FETCH_SIZE and
+WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); `roofline.frac` =
+traffic / live HIP-event duration / 8 TB/s, at most 1 by construction.  The ratio of the reference algorithm's
+logical bytes to the time is reported separately as `algorithmic_ratio`.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +57,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -59,26 +71,327 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true")
-    ap.add_argument("--no-hint", action="store_true", help="locate without the hints of the search (A/B)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run the locate of batch k on a second stream beside the search of batch k + 1 (measured: "
-                         "20.8 instead of 21.2 ms per step, both kernels contend for DRAM requests; off by default so "
-                         "that the per-kernel durations stay those of the kernels alone)")
-    ap.add_argument("--verify-hits", type=int, default=1_000_000)
+    ap.add_argument("--no-hint", action="store_true", help="arrays path: locate without the hints of the search (A/B)")
     ap.add_argument("--path", default="records", choices=["records", "arrays"],
                     help="records: fused count + locate over 16-byte search records (gdx_locate_many_*_dev, lazy "
                          "tails); arrays: exact intervals + hints (gdx_cursors_for_many_queries_hint_dev + "
                          "gdx_locate_intervals_hint_dev), the round-1 path")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the locate of batch k on a second stream beside the search of batch k + 1 (measured in "
+                         "round 1: 2 %%, both kernels contend for DRAM requests; off by default so that the per-kernel "
+                         "durations stay those of the kernels alone)")
+    ap.add_argument("--verify-hits", type=int, default=1_000_000)
     ap.add_argument("--secondary-depth", type=int, default=10,
-                    help="N=1 only: after the headline run (reference-default lookup depth), rebuild the index with "
-                         "this lookup-table depth, time the same step and check the counts are identical; 0 = skip")
-    args = ap.parse_args()
+                    help="N=1 only: lookup-table depth of the `lookup_depth_D` secondary design point; 0 = no secondaries")
+    ap.add_argument("--jump-bytes", type=int, default=None, help="gdx_build_options_t.jump_entry_bytes")
+    ap.add_argument("--top-depth", type=int, default=None, help="gdx_build_options_t.top_table_depth")
+    ap.add_argument("--no-pair-lines", action="store_true", help="gdx_build_options_t.pair_lines = 0")
+    ap.add_argument("--lanes", type=int, default=None, help="gdx_query_options_t.search_lanes")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the rocprofv3 PMC child passes (roofline.traffic then falls back to the committed "
+                         "summary under profiles/ and says so)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+# ======================================================================================================
+# live PMC: rocprofv3 child processes of this same script (--pmc-child), one counter group per pass
+
+PMC_PASSES = [
+    ("requests", ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_REQ_sum", "TCC_HIT_sum"]),
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+]
+
+
+def pmc_child(args):
+    """The workload of the parent, once, without any of its measurements: what rocprofv3 observes."""
+    import torch
+
+    from genedex_amd import alphabet
+    from genedex_amd.device import DeviceEngine, DeviceQueries, build_index_from_device_text, hg38_text_lengths, synth_text
+
+    wl = workload_of(args)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    io_text = synth_text(wl["total"], seed=42, n_per_million=10_000, device=dev)
+    lengths = hg38_text_lengths(wl["total"], wl["n_texts"])
+    index = build_index_from_device_text(io_text, lengths, alphabet.ascii_dna_with_n(), sa_rate=args.sa_rate,
+                                         lookup_depth=args.lookup_depth, index_storage=wl["storage"],
+                                         options=build_options_of(args))
+    apply_query_options(index, args)
+    nq = wl["nq"]
+    queries = DeviceQueries.synth(io_text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
+    eng = DeviceEngine(index)
+    runner = StepRunner(torch, eng, queries, nq, args.op == "count+locate", args.path, hint=not args.no_hint)
+    runner.size()
+    for _ in range(2):
+        runner.step(0, False)
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_child": True, "nq": nq, "hits": runner.total_hits}), flush=True)
+
+
+def run_live_pmc(args):
+    """-> ({kernel short name: {counter: per-launch value}}, None) or (None, reason).  Runs before the parent touches
+    the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process."""
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
+                  "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate)]
+    for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", args.jump_bytes),
+                    ("--top-depth", args.top_depth), ("--lanes", args.lanes)):
+        if v is not None:
+            child_args += [flag, str(v)]
+    if args.no_pair_lines:
+        child_args.append("--no-pair-lines")
+    if args.no_hint:
+        child_args.append("--no-hint")
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    for name, counters in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
+               "search_pair_kernel|locate_queue_kernel|search_kernel", "--output-format", "csv", "-d", d, "--",
+               "python3", os.path.join(ROOT, "bench.py"), *child_args]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                tail = r.stderr.decode(errors="replace")[-400:]
+                return None, f"PMC pass '{name}' failed (rc {r.returncode}): {tail}"
+            agg = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = (short_kernel_name(row["Kernel_Name"]), row["Counter_Name"])
+                    a = agg.setdefault(k, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+            for (kern, counter), (n, s) in agg.items():
+                out.setdefault(kern, {})[counter] = {"per_launch": s / n, "launches": n}
+        except subprocess.TimeoutExpired:
+            return None, f"PMC pass '{name}' timed out"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    log(f"[bench] live PMC passes took {time.time() - t0:.0f}s: {sorted(out)}")
+    return out, None
+
+
+def short_kernel_name(name: str) -> str:
+    import re
+
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    m = re.search(r"(gdx::[A-Za-z0-9_]+(?:<[^>(]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0][-60:]
+
+
+def traffic_of(pmc, pattern):
+    """HBM bytes per launch of the kernel whose name contains `pattern`: 2 * FETCH_SIZE[KB] * 1024 (every DRAM request
+    of gfx950 is 128 B and FETCH_SIZE tallies 64 B each: MI355X_MICROARCH.md section HBM, re-checked on this kernel's
+    own access pattern by tools/calibrate_fetch_size.sh) + WRITE_SIZE[KB] * 1024."""
+    if not pmc:
+        return None
+    names = [k for k in pmc if pattern in k and "stats" not in k]
+    if len(names) != 1:
+        return None
+    c = pmc[names[0]]
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    res = {"kernel": names[0], "read_bytes": 2.0 * c["FETCH_SIZE"]["per_launch"] * 1024.0,
+           "write_bytes": c["WRITE_SIZE"]["per_launch"] * 1024.0}
+    res["bytes"] = res["read_bytes"] + res["write_bytes"]
+    if "TCC_EA0_RDREQ_sum" in c:
+        res["read_requests"] = c["TCC_EA0_RDREQ_sum"]["per_launch"]
+        res["write_requests"] = c["TCC_EA0_WRREQ_sum"]["per_launch"]
+        res["l2_requests"] = c["TCC_REQ_sum"]["per_launch"]
+        res["l2_hits"] = c["TCC_HIT_sum"]["per_launch"]
+    return res
+
+
+# ======================================================================================================
+
+def workload_of(args):
+    wl = dict(WORKLOADS[args.workload])
+    if args.nq:
+        wl["nq"] = args.nq
+    if args.total:
+        wl["total"] = args.total
+    return wl
+
+
+def build_options_of(args, **override):
+    from genedex_amd.index import build_options
+
+    kw = dict(jump_entry_bytes=args.jump_bytes, top_table_depth=args.top_depth,
+              pair_lines=False if args.no_pair_lines else None)
+    kw.update(override)
+    return build_options(**kw)
+
+
+def apply_query_options(index, args):
+    if args.lanes is not None:
+        index.set_query_options(search_lanes=args.lanes)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class StepRunner:
+    """One timed step of the hot path on resident inputs: search -> offsets scan -> locate, on `n_slots` result sets."""
+
+    def __init__(self, torch, eng, queries, nq, do_locate, path, hint=True, n_slots=1):
+        self.torch, self.eng, self.q, self.nq = torch, eng, queries, nq
+        self.do_locate = do_locate
+        self.use_rec = path == "records" and do_locate
+        self.hint = hint and do_locate
+        self.n_slots = n_slots
+        self.outs = [self._alloc() for _ in range(n_slots)]
+        self.total_hits = 0
+        self.hits, self.ws = [], []
+        self.ev_search, self.ev_locate = [], []
+
+    def _alloc(self):
+        o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
+        if self.use_rec:
+            o["rec"] = self.eng.alloc_records(self.nq)
+        return o
+
+    def search(self, o):
+        if self.use_rec:
+            self.eng.locate_search(self.q, o["rec"])
+        else:
+            self.eng.search(self.q, o)
+
+    def offsets(self, o):
+        if self.use_rec:
+            self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"])
+        else:
+            self.eng.hit_offsets(o, self.nq)
+
+    def locate(self, o, h, ws):
+        if self.use_rec:
+            self.eng.locate_hits(o["rec"], self.nq, o["hit_offsets"], self.total_hits, h, ws)
+        else:
+            self.eng.locate(o, self.nq, self.total_hits, h, ws)
+
+    def counts(self, o):
+        """per-query number of occurrences (int32 tensor)"""
+        if self.use_rec:
+            return self.torch.sub(o["rec"][:self.nq, 1], o["rec"][:self.nq, 0])
+        return self.torch.sub(o["end"], o["start"])
+
+    def status(self, o):
+        if self.use_rec:
+            return (o["rec"][:self.nq, 3] >> 24) & 0xff
+        return o["status"]
+
+    def size(self):
+        """sizing pass (also the first warm-up of the kernels): total hits, result buffers"""
+        torch = self.torch
+        o = self.outs[0]
+        self.search(o)
+        self.offsets(o)
+        torch.cuda.synchronize()
+        self.total_hits = int(o["hit_offsets"][self.nq].item()) if self.nq else 0
+        dev = o["hit_offsets"].device
+        self.hits = [torch.zeros((max(self.total_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(self.n_slots)]
+        nbytes = max(self.eng.locate_workspace_bytes(self.total_hits), 16)
+        self.ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+        return self.total_hits
+
+    def step(self, slot, record, side_stream=None, after=None):
+        torch = self.torch
+        o, h, ws = self.outs[slot], self.hits[slot], self.ws[slot]
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.search(o)
+        b.record()
+        if record:
+            self.ev_search.append((a, b))
+        with (torch.cuda.stream(side_stream) if side_stream is not None else _null()):
+            if side_stream is not None:
+                side_stream.wait_event(b)
+            if self.do_locate:
+                self.offsets(o)
+                c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c.record()
+                self.locate(o, h, ws)
+                d.record()
+                if record:
+                    self.ev_locate.append((c, d))
+            if after is not None:
+                after(slot)
+
+    @staticmethod
+    def mean_ms(events):
+        return float(sum(a.elapsed_time(b) for a, b in events) / len(events)) if events else None
+
+
+def timed_steps(torch, gdist, runner, steps, warmup, dev, gather=None, count_of=None, overlap=False):
+    """W untimed + K timed steps bracketed by barrier + synchronize; -> max-over-ranks seconds"""
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream() if overlap else None
+    slot_free = [None] * runner.n_slots
+    no = [0]
+
+    def after(slot):
+        if gather:
+            count_of(slot)
+            gather.submit(slot)
+        if overlap:
+            slot_free[slot] = torch.cuda.Event()
+            slot_free[slot].record()
+
+    def one(record):
+        slot = no[0] % runner.n_slots
+        no[0] += 1
+        if gather:
+            gather.acquire(slot)
+        if slot_free[slot] is not None:
+            main_stream.wait_event(slot_free[slot])
+        runner.step(slot, record, side_stream, after)
+
+    for _ in range(warmup):
+        one(False)
+    if gather:
+        gather.drain()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(True)
+    if gather:
+        gather.drain()
+    torch.cuda.synchronize()
+    gdist.barrier()
+    return gdist.max_over_ranks(time.perf_counter() - t0, dev), (no[0] - 1) % runner.n_slots
+
+
+def main():
+    args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+
+    # PMC passes first: they are separate processes that each need the GPU's memory for their own index, and starting
+    # them before this process initialises the GPU keeps every exec clear of a process that holds the device
+    pmc, pmc_note = None, "live PMC passes run at N = 1 only"
+    if world == 1 and not args.no_live_pmc:
+        pmc, pmc_note = run_live_pmc(args)
+        if pmc is None:
+            log(f"[bench] live PMC unavailable: {pmc_note}")
 
     import numpy as np
     import torch  # before libgdx.so: both must share torch's HIP runtime
@@ -105,13 +418,10 @@ def main():
     from genedex_amd.device import (DeviceEngine, DeviceQueries, build_index_from_device_text, hg38_text_lengths,
                                     measure_bandwidth, synth_text)
 
-    wl = dict(WORKLOADS[args.workload])
-    if args.nq:
-        wl["nq"] = args.nq
-    if args.total:
-        wl["total"] = args.total
+    wl = workload_of(args)
     nq = wl["nq"]
     alpha = alphabet.ascii_dna_with_n()
+    do_locate = args.op == "count+locate"
 
     # ---- inputs into HBM, index build (untimed) ----------------------------------------------------
     t0 = time.time()
@@ -121,194 +431,111 @@ def main():
     t_text = time.time() - t0
     t0 = time.time()
     index = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate,
-                                         lookup_depth=args.lookup_depth, index_storage=wl["storage"])
+                                         lookup_depth=args.lookup_depth, index_storage=wl["storage"],
+                                         options=build_options_of(args))
+    apply_query_options(index, args)
     t_build = time.time() - t0
     stats = index.build_stats()
     log(f"[bench r{rank}] text {t_text:.1f}s, index build {t_build:.1f}s {stats}, "
         f"index {index.info.device_bytes / 1e9:.2f} GB in HBM, n = {index.total_text_len()}")
     t0 = time.time()
+    # weak scaling: every rank has its own batch (rank 0's is the N = 1 batch)
     queries = DeviceQueries.synth(io_text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"],
                                   seed=43 + 1000 * rank)
     log(f"[bench r{rank}] {nq} queries ({queries.total_bytes / 1e9:.2f} GB) generated in {time.time() - t0:.1f}s")
 
     eng = DeviceEngine(index)
-    do_locate = args.op == "count+locate"
-    use_rec = args.path == "records" and do_locate
-    out = eng.alloc_outputs(nq, hint=do_locate and not args.no_hint)
-    if use_rec:
-        out["rec"] = eng.alloc_records(nq)
-
-    def run_search(o):
-        if use_rec:
-            eng.locate_search(queries, o["rec"])
-        else:
-            eng.search(queries, o)
-
-    def run_offsets(o):
-        if use_rec:
-            eng.locate_offsets(o["rec"], nq, o["hit_offsets"])
-        else:
-            eng.hit_offsets(o, nq)
-
-    def run_locate(o, h, ws):
-        if use_rec:
-            eng.locate_hits(o["rec"], nq, o["hit_offsets"], total_hits, h, ws)
-        else:
-            eng.locate(o, nq, total_hits, h, ws)
-
-    # sizing pass (also the first warm-up of the kernels)
-    run_search(out)
-    run_offsets(out)
-    torch.cuda.synchronize()
-    total_hits = int(out["hit_offsets"][nq].item())
-    if use_rec:
-        cnt32 = torch.empty(nq, dtype=torch.int32, device=dev)
-        eng.unpack_records(out["rec"], nq, cnt32, out["status"])
-        out["start"].zero_()
-        out["end"].copy_(cnt32)  # end - start = count for the checks below (the exact intervals are not computed)
-        del cnt32
-    n_status = int((out["status"] != 0).sum().item())
-    hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
-    workspace = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
-    # Per-query counts travel to rank 0 in the narrowest integer type that holds the largest count of any rank
-    # (known from the sizing pass; lossless): 1 instead of 4 bytes per query on this workload, which keeps the
-    # gather of a batch (counts + 8 bytes per hit, over one xGMI link per peer) shorter than the step it hides behind.
-    max_count = int((out["end"] - out["start"]).max().item()) if nq else 0
-    if world > 1:
-        max_count = gdist.max_int_over_ranks(max_count, dev)
-    count_dtype = torch.uint8 if max_count <= 0xff else (torch.int16 if max_count <= 0x7fff else torch.int32)
-    counts = torch.empty(nq, dtype=count_dtype, device=dev)
+    aux = eng.aux_info()
+    n_slots = 2 if (world > 1 or (do_locate and args.overlap)) else 1
+    runner = StepRunner(torch, eng, queries, nq, do_locate, args.path, hint=not args.no_hint, n_slots=n_slots)
+    total_hits = runner.size()
+    out = runner.outs[0]
+    n_status = int((runner.status(out) != 0).sum().item())
     log(f"[bench r{rank}] {total_hits} hits, {n_status} queries with non-zero status")
 
-    ev_search, ev_locate = [], []
-
-    # N > 1: results are gathered to rank 0 over RCCL asynchronously, double-buffered, so that the gather of
-    # batch k overlaps the kernels of batch k+1 (payloads padded to the largest shard up front).
-    # Result slots: one, or two when the gather of batch k (N > 1) or its locate (--overlap) runs beside the search
-    # of batch k + 1.
-    overlap = do_locate and args.overlap
-    slots = [(out, hits, counts, workspace)]
-    gather = None
+    # N > 1: results are gathered to rank 0 over RCCL asynchronously, double-buffered, so that the gather of batch k
+    # overlaps the kernels of batch k+1 (payloads padded to the largest shard up front).  Per-query counts travel in
+    # the narrowest integer type that holds the largest count of any rank (known from the sizing pass; lossless).
+    gather, count_of, gathered_bytes = None, None, 0
     if world > 1:
-        max_hits = gdist.max_int_over_ranks(total_hits, dev)
-        hits = torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev)
-        slots = [(out, hits, counts, workspace)]
-    if world > 1 or overlap:
-        o2 = eng.alloc_outputs(nq, hint="hint" in out)
-        if use_rec:
-            o2["rec"] = eng.alloc_records(nq)
-        slots.append((o2, torch.zeros_like(hits), torch.empty_like(counts), torch.empty_like(workspace)))
-    if world > 1:
-        gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for (_, h, c, _w) in slots], dst=0)
-    main_stream = torch.cuda.current_stream()
-    side_stream = torch.cuda.Stream() if overlap else main_stream
-    slot_free = [None] * len(slots)  # event: the side stream is done with the slot's buffers
-    step_no = [0]
-
-    def step(record):
-        slot = step_no[0] % len(slots)
-        step_no[0] += 1
-        o, h, cnt, ws = slots[slot]
-        if gather:
-            gather.acquire(slot)
-        if slot_free[slot] is not None:
-            main_stream.wait_event(slot_free[slot])
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        run_search(o)
-        b.record()
-        if record:
-            ev_search.append((a, b))
-        with torch.cuda.stream(side_stream):
-            if overlap:
-                side_stream.wait_event(b)
-            if do_locate:
-                run_offsets(o)
-                c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                c.record()
-                run_locate(o, h, ws)
-                d.record()
-                if record:
-                    ev_locate.append((c, d))
-            if gather:
-                if use_rec:
-                    cnt.copy_(torch.sub(o["rec"][:nq, 1], o["rec"][:nq, 0]))
-                else:
-                    cnt.copy_(torch.sub(o["end"], o["start"]))  # copy_ narrows to the gather's count type
-                gather.submit(slot)
-            if overlap:
-                slot_free[slot] = torch.cuda.Event()
-                slot_free[slot].record()
-
-    for _ in range(args.warmup):
-        step(False)
-    if gather:
-        gather.drain()
-    gdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    if gather:
-        gather.drain()
-    torch.cuda.synchronize()
-    gdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = gdist.max_over_ranks(elapsed, dev)
+        gather, count_of, gathered_bytes = make_gather(torch, gdist, runner, dev, do_locate)
+    elapsed, _ = timed_steps(torch, gdist, runner, args.steps, args.warmup, dev, gather, count_of,
+                             overlap=do_locate and args.overlap)
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * world / (ms_per_step / 1e3)
+    search_ms = runner.mean_ms(runner.ev_search)
+    locate_ms = runner.mean_ms(runner.ev_locate)
+    hits = runner.hits[0]
 
-    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_search]))
-    locate_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_locate])) if ev_locate else None
-
-    # ---- algorithmic bytes, counted by an extra, untimed pass ------------------
+    # ---- algorithmic bytes, counted by an extra, untimed pass in the exact mode -----------
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
-    variant = os.environ.get("GDX_SEARCH_VARIANT", "pair")
-    uniform = wl["len_max"] - wl["len_min"] <= wl["len_min"] // 4
-    lanes = os.environ.get("GDX_SEARCH_LANES", "4")
-    aux = eng.aux_info()
-    policy = os.environ.get("GDX_LOAD_POLICY", "0")
-    kernel_name = {"pair": f"search_pair_kernel{lanes}<{policy}, {aux['jump_entry_bytes'] or 8}>",
-                   "quad": "search_kernel<QuadLineTable,4>", "lane": "search_kernel<LineTable,1>"}[variant]
-    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": search_bytes / (search_ms / 1e3) / 1e9,
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
-                "traffic": None, "algorithmic_bytes_per_launch": search_bytes, "lf_steps_per_launch": lf_steps,
-                "avg_launch_ms": search_ms,
-                "note": "achieved = algorithmic bytes of the reference's algorithm (60 B per LF step it would execute, "
-                        "BASELINE.md section 4) / kernel time; frac > 1 means the jump / top tables deliver those LF "
-                        "steps with fewer bytes than the reference layout needs, not that HBM exceeds its peak: see "
-                        "traffic (measured DRAM bytes per launch) and random_request_model for the bound of the kernel "
-                        "as built",
-                "line_fetches_per_query": fetches / nq if fetches else None,
-                "active_lane_fraction": fetches / fetch_slots if fetch_slots else None}
-    roofline.update(pmc_traffic(kernel_name, args, wl, nq))
+    kernel_pattern = "search_pair_kernel" if aux["pair_lines"] else "search_kernel"
+    search_traffic = traffic_of(pmc, kernel_pattern)
+    traffic_source = "live: rocprofv3 --pmc child passes of this run (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+    if search_traffic is None:
+        search_traffic, traffic_source = committed_traffic(args, nq, aux, pmc_note)
+    roofline = {"bound": "hbm", "kernel": (search_traffic or {}).get("kernel", kernel_pattern), "unit": "GB/s",
+                "peak": HBM_PEAK_GBPS, "avg_launch_ms": search_ms}
+    if search_traffic:
+        roofline["traffic"] = search_traffic["bytes"]
+        roofline["achieved"] = search_traffic["bytes"] / (search_ms / 1e3) / 1e9
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBPS
+        roofline["traffic_read_bytes"] = search_traffic["read_bytes"]
+        roofline["traffic_write_bytes"] = search_traffic["write_bytes"]
+        if "read_requests" in search_traffic:
+            roofline["dram_read_requests_per_query"] = search_traffic["read_requests"] / nq
+            roofline["dram_write_requests_per_query"] = search_traffic["write_requests"] / nq
+            roofline["l2_hit_rate"] = search_traffic["l2_hits"] / max(search_traffic["l2_requests"], 1)
+    else:
+        roofline.update({"traffic": None, "achieved": None, "frac": None})
+    roofline["traffic_source"] = traffic_source
+    roofline["algorithmic_bytes_per_launch"] = search_bytes
+    roofline["lf_steps_per_launch"] = lf_steps
+    roofline["algorithmic_ratio"] = search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
+    roofline["note"] = ("frac = measured HBM traffic of the kernel / its live HIP-event duration / 8 TB/s. "
+                        "algorithmic_ratio = the reference algorithm's logical bytes (60 B per LF step it would execute "
+                        "+ query bytes + 8 B result, SURVEY.md 8d) / the same time / 8 TB/s: it exceeds 1 because the top "
+                        "table, the jump table and the lazy tail deliver those LF steps with far fewer fetches, not "
+                        "because HBM exceeds its peak. The kernel is a chain of dependent random 128-byte requests; see "
+                        "random_request_model for that bound.")
+    roofline["line_fetches_per_query_exact_mode"] = fetches / nq if fetches else None
+    roofline["active_lane_fraction_exact_mode"] = fetches / fetch_slots if fetch_slots else None
     locate_roofline = None
     if do_locate and total_hits:
         acct = out
-        if use_rec:  # the accounting pass counts the reference's walk steps from the exact intervals, without hints
+        if runner.use_rec:  # the accounting pass counts the reference's walk steps from the exact intervals, without hints
             acct = eng.alloc_outputs(nq, hint=False)
             eng.search(queries, acct)
             eng.hit_offsets(acct, nq)
-        walk_steps = eng.locate_walk_steps(acct, nq, total_hits, hits, workspace)
-        if use_rec:
+        walk_steps = eng.locate_walk_steps(acct, nq, total_hits, hits, runner.ws[0])
+        if runner.use_rec:
             del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
-        locate_roofline = {"bound": "hbm", "kernel": "locate_queue_kernel<LineTable> (+ slot -> query map)",
-                           "achieved": locate_bytes / (locate_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": locate_bytes / (locate_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+        lt = traffic_of(pmc, "locate_queue_kernel")
+        locate_roofline = {"bound": "hbm", "kernel": "locate_queue_kernel (+ slot -> query map)", "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "avg_launch_ms": locate_ms,
+                           "traffic": lt["bytes"] if lt else None,
+                           "achieved": lt["bytes"] / (locate_ms / 1e3) / 1e9 if lt else None,
+                           "frac": lt["bytes"] / (locate_ms / 1e3) / 1e9 / HBM_PEAK_GBPS if lt else None,
+                           "dram_read_requests_per_hit": lt["read_requests"] / total_hits if lt and "read_requests" in lt else None,
                            "algorithmic_bytes_per_launch": locate_bytes, "walk_steps_per_launch": walk_steps,
-                           "hits_per_launch": total_hits, "avg_launch_ms": locate_ms}
+                           "algorithmic_ratio": locate_bytes / (locate_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                           "hits_per_launch": total_hits}
 
     # ---- size-independent parity properties at full size ---------------------------------------------------
+    counts = runner.counts(out)
     parity = {"queries_with_status": n_status}
-    found = int(((out["end"] - out["start"]) > 0).sum().item())
+    found = int((counts > 0).sum().item())
     parity["queries_found"] = found
     parity["found_fraction"] = found / nq
+    parity["sum_of_counts_equals_hits"] = int(counts.to(torch.int64).sum().item()) == total_hits
     if do_locate and total_hits and args.verify_hits:
         parity.update(verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, args.verify_hits))
         if parity["hits_checked"] != parity["hits_matching_text"]:
             raise SystemExit(f"PARITY FAILURE: {parity}")
+    if do_locate and not parity["sum_of_counts_equals_hits"]:
+        raise SystemExit(f"PARITY FAILURE: {parity}")
 
     result = {
         "metric": "queries/sec (count+locate), hg38-scale text, 100M len-50 reads" if do_locate
@@ -316,56 +543,59 @@ def main():
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": wl["label"], "name": args.workload, "op": args.op, "queries_per_gpu": nq,
+        "config": {"workload": f"{wl['label']}; index = reference arrays + pair lines + {aux['jump_entry_bytes']}-byte jump "
+                               f"entries + depth-{aux['top_table_depth']} top table ({index.info.device_bytes / 1e9:.1f} GB "
+                               f"per replica)",
+                   "name": args.workload, "op": args.op, "path": args.path, "queries_per_gpu": nq,
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
-                   "aux_structures": eng.aux_info(),
+                   "aux_structures": aux,
                    "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0",
-                   "gathered_bytes_per_rank_and_step": (nq * counts.element_size() + (hits.numel() * 4 if do_locate else 0))
-                   if world > 1 else 0},
+                   "gathered_bytes_per_rank_and_step": gathered_bytes},
         "roofline": roofline,
         "locate_roofline": locate_roofline,
+        "kernel_ms": {"search": search_ms, "locate": locate_ms},
         "parity": parity,
         "index_build_seconds": t_build,
         "index_bytes": int(index.info.device_bytes),
     }
 
+    # ---- BASELINE.json configs[3]: ONE batch of nq queries sharded over the ranks (strong scaling) ---------
+    if world > 1 and not args.no_strong:
+        del gather, count_of
+        runner.outs, runner.hits, runner.ws = [], [], []
+        del out, hits, counts
+        torch.cuda.empty_cache()
+        result["strong_scaling"] = strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq, do_locate, args, rank,
+                                                  world, dev)
+
     if rank == 0 and not args.no_bandwidth:
         result["measured_bandwidth"] = measure_bandwidth(dev)
-        result["roofline"]["frac_of_measured_stream"] = (result["roofline"]["achieved"]
-                                                          / result["measured_bandwidth"]["stream_copy_GBps"])
-        log(f"[bench] measured bandwidth: {result['measured_bandwidth']}")
-        # The kernel's own bound: it is made of dependent random 128-byte requests, whose measured ceiling on this
-        # GPU (gather128_group of measure_bandwidth) is well below the streaming peak.
-        rq = result["roofline"].get("dram_read_requests_per_query")
+        bw = result["measured_bandwidth"]
+        log(f"[bench] measured bandwidth: {bw}")
+        if roofline.get("achieved"):
+            roofline["frac_of_measured_stream_read"] = roofline["achieved"] / bw["stream_read_GBps"]
+        # The kernel's own bound: dependent random 128-byte requests, whose measured ceiling on this GPU
+        # (gather128_group of measure_bandwidth) is well below the streaming peak.
+        rq = roofline.get("dram_read_requests_per_query")
         if rq:
             rate = rq * nq / (search_ms / 1e3) / 1e9
-            ceiling = result["measured_bandwidth"]["gather128_group_Glines_per_s"]
-            result["roofline"]["random_request_model"] = {
-                "dram_requests_per_launch": rq * nq, "achieved_Greq_per_s": rate, "measured_ceiling_Greq_per_s": ceiling,
-                "frac_of_ceiling": rate / ceiling, "traffic_frac_of_hbm_peak": result["roofline"]["traffic"]
-                / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS}
+            ceiling = bw["gather128_group_Glines_per_s"]
+            roofline["random_request_model"] = {"dram_requests_per_launch": rq * nq, "achieved_Greq_per_s": rate,
+                                                "measured_ceiling_Greq_per_s": ceiling, "frac_of_ceiling": rate / ceiling}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl)
+        result["cpu_baseline"] = cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl)
     else:
         result["cpu_baseline"] = None
 
     if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
-        # Secondary design points, never `value`: (1) the reference's lookup-table knob at the depth BASELINE.md names;
-        # (2) pair lines but no jump / top table; (3) every acceleration structure of this build switched off (rank
-        # lines with the reference's information content only).  The HBM each rung spends is in `index_bytes`.
-        base_counts = (out["end"] - out["start"]).clone()
-        del eng, index
+        base_counts = counts.clone()
+        runner.outs, runner.hits, runner.ws = [], [], []
+        del out, hits, counts
         torch.cuda.empty_cache()
-        common = (torch, io_text, lengths, alpha, queries, out, hits, workspace, base_counts, nq, total_hits,
-                  do_locate, args, wl)
-        result["secondary"] = [
-            secondary_run(f"lookup_depth_{args.secondary_depth}", args.secondary_depth, {}, *common),
-            secondary_run("pair_lines_only", args.lookup_depth, {"GDX_TOP_DEPTH": "0", "GDX_NO_JUMP_TABLE": "1"}, *common),
-            secondary_run("no_acceleration_structures", args.lookup_depth,
-                          {"GDX_TOP_DEPTH": "0", "GDX_NO_JUMP_TABLE": "1", "GDX_NO_PAIR_LINES": "1"}, *common),
-        ]
+        result["secondary"] = secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
+                                          args, wl)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -373,88 +603,233 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_run(name, lookup_depth, env, torch, io_text, lengths, alpha, queries, out, hits, workspace, base_counts,
-                  nq, total_hits, do_locate, args, wl):
-    """Rebuild the index with another configuration, time the same step and require identical interval sizes.
-    `lookup_depth` is the reference's knob (config.rs:36-47; README.md:101-115 recommends a deeper table for large
-    texts); `env` switches build-time structures of this implementation (fm_index.hip)."""
-    from genedex_amd.device import DeviceEngine, build_index_from_device_text
+def make_gather(torch, gdist, runner, dev, do_locate):
+    """Pads the hit buffers to the largest shard, picks the count type, returns (PipelinedGather, count_of, bytes)."""
+    nq = runner.nq
+    o = runner.outs[0]
+    max_count = int(runner.counts(o).max().item()) if nq else 0
+    max_count = gdist.max_int_over_ranks(max_count, dev)
+    count_dtype = torch.uint8 if max_count <= 0xff else (torch.int16 if max_count <= 0x7fff else torch.int32)
+    max_hits = gdist.max_int_over_ranks(runner.total_hits, dev)
+    max_nq = gdist.max_int_over_ranks(nq, dev)
+    runner.hits = [torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
+    cnts = [torch.zeros(max(max_nq, 1), dtype=count_dtype, device=dev) for _ in range(runner.n_slots)]
+    gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for c, h in zip(cnts, runner.hits)], dst=0)
 
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        t0 = time.time()
-        index = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=lookup_depth,
-                                             index_storage=wl["storage"])
-        t_build = time.time() - t0
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    eng = DeviceEngine(index)
-    ev_s, ev_l = [], []
+    def count_of(slot):
+        cnts[slot][:nq].copy_(runner.counts(runner.outs[slot]))  # copy_ narrows to the gather's count type
 
-    def step(record):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        eng.search(queries, out)
-        b.record()
-        if do_locate:
-            eng.hit_offsets(out, nq)
-            c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c.record()
-            eng.locate(out, nq, total_hits, hits, workspace)
-            d.record()
-            if record:
-                ev_l.append((c, d))
-        if record:
-            ev_s.append((a, b))
+    nbytes = cnts[0].numel() * cnts[0].element_size() + (runner.hits[0].numel() * 4 if do_locate else 0)
+    return gather, count_of, nbytes
 
-    step(False)
-    torch.cuda.synchronize()
-    steps = min(args.steps, 3)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(True)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    same = bool(torch.equal(out["end"] - out["start"], base_counts))
-    if not same:
-        raise SystemExit(f"PARITY FAILURE: secondary configuration {name} changed interval sizes")
-    res = {"name": name, "lookup_depth": lookup_depth, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3),
-           "unit": "queries/s", "ms_per_step": ms, "search_ms": sum(a.elapsed_time(b) for a, b in ev_s) / len(ev_s),
-           "locate_ms": sum(a.elapsed_time(b) for a, b in ev_l) / len(ev_l) if ev_l else None,
-           "counts_identical_to_headline": same, "index_build_seconds": t_build,
-           "index_bytes": int(index.info.device_bytes)}
-    log(f"[bench] secondary {name}: {res}")
-    del eng, index
-    torch.cuda.empty_cache()
+
+def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate, args, rank, world, dev):
+    """BASELINE.json configs[3]: the N = 1 batch (seed 43) split into `world` contiguous shards (dist.shard_range), one
+    per rank, results gathered to rank 0; value = nq_total / max-over-ranks step time.  Rank 0 also runs the whole
+    batch alone once and requires the concatenated shard results to equal it bit for bit."""
+    from genedex_amd.device import DeviceQueries
+
+    full = DeviceQueries.synth(io_text, lengths, nq_total, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
+    lo, hi = gdist.shard_range(nq_total, rank, world)
+    shard = full.slice(lo, hi)
+    runner = StepRunner(torch, eng, shard, hi - lo, do_locate, args.path, hint=not args.no_hint, n_slots=2)
+    runner.size()
+    gather, count_of, nbytes = make_gather(torch, gdist, runner, dev, do_locate)
+    steps = max(args.steps, 1)
+    elapsed, last = timed_steps(torch, gdist, runner, steps, args.warmup, dev, gather, count_of)
+    ms = elapsed / steps * 1e3
+    res = {"scaling": "strong", "value": nq_total / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
+           "queries_total": nq_total, "queries_this_rank": hi - lo, "steps": steps,
+           "kernel_ms_rank0": {"search": runner.mean_ms(runner.ev_search), "locate": runner.mean_ms(runner.ev_locate)},
+           "gathered_bytes_per_rank_and_step": nbytes}
+    # bit-exactness: concatenated shards == the one-rank output (SURVEY.md section 8e)
+    sizes = gdist.gather_ints(runner.total_hits, dev)
+    if rank == 0:
+        parts = gather.gathered(last)
+        shard_len = [gdist.shard_range(nq_total, r, world) for r in range(world)]
+        cnt_cat = torch.cat([parts[0][r][: b - a] for r, (a, b) in enumerate(shard_len)])
+        hit_cat = torch.cat([parts[1][r][: sizes[r]] for r in range(world)]) if do_locate else None
+        del gather, runner
+        torch.cuda.empty_cache()
+        single = StepRunner(torch, eng, full, nq_total, do_locate, args.path, hint=not args.no_hint)
+        single.size()
+        single.step(0, False)
+        torch.cuda.synchronize()
+        same_counts = bool(torch.equal(cnt_cat.to(torch.int64), single.counts(single.outs[0]).to(torch.int64)))
+        same_hits = bool(torch.equal(hit_cat, single.hits[0][: single.total_hits])) if do_locate else None
+        res["shards_equal_single_rank_output"] = {"counts": same_counts, "hits": same_hits}
+        if not same_counts or same_hits is False:
+            raise SystemExit(f"PARITY FAILURE: sharded results differ from the one-rank output: {res}")
     return res
 
 
-def pmc_traffic(kernel_name, args, wl, nq):
-    """HBM traffic of the search kernel per launch from the committed rocprofv3 PMC summary of this very
-    configuration (FETCH_SIZE cannot be read from inside the process).  Correction per
-    MI355X_MICROARCH.md section HBM and tools/calibrate_fetch_size.sh: every DRAM request of this GPU is
-    128 bytes (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ also for 64-byte gathers) and FETCH_SIZE tallies 64 bytes
-    per request, so read bytes = 2 * FETCH_SIZE[KB] * 1024.  The PMC pass runs fewer queries; traffic per
-    query is scaled to this launch."""
-    path = os.path.join(ROOT, "profiles", "r01", "search_pmc_final.json")
+def committed_traffic(args, nq, aux, why):
+    """Fallback when the live PMC passes are unavailable: the committed summary of the same configuration."""
+    path = os.path.join(ROOT, "profiles", "r02", "search_pmc_final.json")
     try:
         with open(path) as f:
-            pmc = json.load(f)
-        if (pmc["workload"], pmc["lookup_depth"], pmc["kernel"]) != (args.workload, args.lookup_depth, kernel_name):
-            return {"traffic": None}
-        per_query = (2 * pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024 / pmc["queries_per_launch"]
-        res = {"traffic": per_query * nq, "traffic_source": "profiles/r01/search_pmc_final.json (rocprofv3 --pmc FETCH_SIZE / "
-               "WRITE_SIZE, separate passes, FETCH_SIZE doubled: all requests are 128 B)"}
-        if "TCC_EA0_RDREQ_per_launch" in pmc:
-            res["dram_read_requests_per_query"] = pmc["TCC_EA0_RDREQ_per_launch"] / pmc["queries_per_launch"]
-        return res
+            p = json.load(f)
+        if ((p["workload"], p["lookup_depth"], p["path"], p["jump_entry_bytes"], p["top_table_depth"])
+                != (args.workload, args.lookup_depth, args.path, aux["jump_entry_bytes"], aux["top_table_depth"])):
+            return None, f"unavailable ({why}; the committed summary is of another configuration)"
+        scale = nq / p["queries_per_launch"]
+        t = {"kernel": p["kernel"], "read_bytes": p["read_bytes_per_launch"] * scale,
+             "write_bytes": p["write_bytes_per_launch"] * scale, "read_requests": p["read_requests_per_launch"] * scale,
+             "write_requests": p["write_requests_per_launch"] * scale, "l2_requests": p["l2_requests_per_launch"] * scale,
+             "l2_hits": p["l2_hits_per_launch"] * scale}
+        t["bytes"] = t["read_bytes"] + t["write_bytes"]
+        return t, (f"NOT measured in this run ({why}); committed summary {os.path.relpath(path, ROOT)} of the same "
+                   f"configuration")
     except (OSError, KeyError, ValueError):
-        return {"traffic": None}
+        return None, f"unavailable ({why})"
+
+
+def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
+    """(ms per step, search ms, locate ms, counts) of the resident index in its current configuration"""
+    runner = StepRunner(torch, eng, queries, nq, do_locate, args.path, hint=not args.no_hint)
+    runner.size()
+    runner.step(0, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step(0, True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    counts = runner.counts(runner.outs[0]).clone()
+    return ms, runner.mean_ms(runner.ev_search), runner.mean_ms(runner.ev_locate), counts
+
+
+def secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl):
+    """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
+    rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
+    information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
+    50 M reads of mixed length through the fused call and through the batched cursor API.  (3) The reference's
+    lookup-table knob at the depth BASELINE.md names."""
+    from genedex_amd.device import DeviceEngine, build_index_from_device_text
+
+    res = []
+    ladder = [("top14_jump32", dict(top_table_depth=14)),
+              ("top16_jump16", dict(jump_entry_bytes=16)),
+              ("top14_jump16", dict(top_table_depth=14, jump_entry_bytes=16)),
+              ("top12_jump8", dict(top_table_depth=12, jump_entry_bytes=8)),
+              ("pair_lines_only", dict(top_table_depth=0, jump_entry_bytes=0)),
+              ("reference_arrays_only", dict(top_table_depth=0, jump_entry_bytes=0, pair_lines=False))]
+    if args.no_extras:
+        ladder = ladder[-2:]
+    for name, opts in ladder:
+        t0 = time.time()
+        index.rebuild_aux(**opts)
+        t_aux = time.time() - t0
+        ms, s_ms, l_ms, counts = time_config(torch, eng, queries, nq, do_locate, args)
+        same = bool(torch.equal(counts, base_counts))
+        if not same:
+            raise SystemExit(f"PARITY FAILURE: secondary configuration {name} changed the counts")
+        r = {"name": name, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s",
+             "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
+             "aux_rebuild_seconds": t_aux, "index_bytes": int(index.info.device_bytes)}
+        if name == "reference_arrays_only":
+            # like-for-like roofline: the reference's information content, its algorithmic bytes per LF step
+            lf_steps, _, _ = eng.search_step_stats(queries)
+            b = queries.total_bytes + 60 * lf_steps + 8 * nq
+            r["roofline_reference_layout"] = {
+                "bound": "hbm", "kernel": "search_kernel<QuadLineTable, 4>", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": b, "achieved": b / (s_ms / 1e3) / 1e9,
+                "frac": b / (s_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                "note": "algorithmic bytes of SURVEY.md 8d / kernel time / 8 TB/s on the 4.65 GB index without any "
+                        "acceleration structure (every 30-byte rank costs one 128-byte DRAM request there)"}
+        log(f"[bench] secondary {name}: {r}")
+        res.append(r)
+        del counts
+    index.rebuild_aux()  # back to the headline configuration
+    if not args.no_extras:
+        res.append(mixed_length_secondary(torch, eng, io_text, lengths))
+    # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays)
+    del eng, index
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    index2 = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=args.secondary_depth,
+                                          index_storage=wl["storage"], options=build_options_of(args))
+    apply_query_options(index2, args)
+    t_build = time.time() - t0
+    eng2 = DeviceEngine(index2)
+    ms, s_ms, l_ms, counts = time_config(torch, eng2, queries, nq, do_locate, args)
+    same = bool(torch.equal(counts, base_counts))
+    if not same:
+        raise SystemExit("PARITY FAILURE: the lookup-depth secondary changed the counts")
+    res.append({"name": f"lookup_depth_{args.secondary_depth}", "lookup_depth": args.secondary_depth,
+                "aux_structures": eng2.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
+                "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
+                "index_build_seconds": t_build, "index_bytes": int(index2.info.device_bytes)})
+    log(f"[bench] secondary {res[-1]}")
+    return res
+
+
+def mixed_length_secondary(torch, eng, io_text, lengths):
+    """BASELINE.json configs[4]: 50 M reads of length 20..150, 70 % sampled / 30 % random (early termination), through
+    (a) the fused cursors_for_many_queries call and (b) the batched cursor API: cursor_empty, then
+    gdx_cursor_extend_front_strings_dev with 32 symbols per call and device-side active lists.  Identical intervals."""
+    from genedex_amd.device import DeviceQueries
+
+    w = WORKLOADS["mixed"]
+    nq = w["nq"]
+    dev = io_text.device
+    q = DeviceQueries.synth(io_text, lengths, nq, w["len_min"], w["len_max"], w["sampled_ppm"], seed=47)
+    out = eng.alloc_outputs(nq)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    fused_ms = timed(lambda: eng.search(q, out))
+    lf_steps, fetches, slots = eng.search_step_stats(q)
+    chunk = 32
+    n = eng.index.total_text_len()
+    beg, end = q.qoff[:-1], q.qoff[1:]
+    cur_s = torch.empty(nq, dtype=torch.int32, device=dev)
+    cur_e = torch.empty(nq, dtype=torch.int32, device=dev)
+    cur_st = torch.empty(nq, dtype=torch.uint8, device=dev)
+    act = [torch.empty(nq, dtype=torch.int32, device=dev) for _ in range(2)]
+    n_act = [torch.empty(1, dtype=torch.int32, device=dev) for _ in range(2)]
+    edges = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)]
+    rounds = -(-w["len_max"] // chunk)
+    live = []
+
+    def cursor_api(record_live=False):
+        cur_s.zero_()
+        cur_e.fill_(n if n < (1 << 31) else n - (1 << 32))  # cursor_empty for every read
+        cur_st.zero_()
+        hi = end
+        a, na = None, None  # first call: all cursors
+        for r in range(rounds):
+            lo = edges[r % 2]
+            torch.sub(hi, chunk, out=lo)
+            torch.maximum(lo, beg, out=lo)
+            eng.cursor_extend_strings(cur_s, cur_e, q.qbuf, lo, hi, nq, cur_st, a, na, act[r % 2], n_act[r % 2])
+            a, na = act[r % 2], n_act[r % 2]
+            hi = lo
+            if record_live:
+                live.append(int(na.item()))
+
+    cursor_ms = timed(cursor_api)
+    cursor_api(record_live=True)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]) and not bool(cur_st.any().item()))
+    if not same:
+        raise SystemExit("PARITY FAILURE: the batched cursor API and the fused search disagree on workload 5")
+    res = {"name": "mixed_lengths_20_150 (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
+           "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms,
+           "cursor_api_value": nq / (cursor_ms / 1e3), "cursor_api_ms": cursor_ms, "unit": "queries/s",
+           "cursor_api": f"cursor_empty + {rounds} x gdx_cursor_extend_front_strings_dev ({chunk} symbols per call, "
+                         f"device-side active lists, no host round trip inside a pass)",
+           "live_cursors_after_each_call": live, "intervals_identical": same,
+           "lf_steps": lf_steps, "active_lane_fraction_fused": fetches / slots if slots else None}
+    log(f"[bench] secondary {res}")
+    return res
 
 
 def verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, n_check):
@@ -485,7 +860,7 @@ def verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, n_c
     return {"hits_checked": int(h.numel()), "hits_matching_text": int(ok.sum().item())}
 
 
-def cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl):
+def cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl):
     """The CPU restatement of genedex's batched path (oracle/), timed on all host cores on a bounded sample
     of the same queries against the same index, and compared bit for bit with the GPU results."""
     from oracle import oracle as orc
@@ -528,20 +903,30 @@ def cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl):
     n_sample = int(min(queries.nq, max(calib, rate * args.cpu_seconds)))
     s, e, loc, tc, tl = run(0, n_sample)
     value = n_sample / (tc + tl)
-    # bit-exactness at full index size: same intervals, same hits in the same order
-    gs = out["start"][:n_sample].cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
-    ge = out["end"][:n_sample].cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    # bit-exactness at full index size: the timed path's counts and hits (same order), and the exact intervals of
+    # the interval call (cursors_for_many_queries) on the same prefix
+    out = runner.outs[0]
+    g_counts = runner.counts(out)[:n_sample].cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    same_counts = bool(np.array_equal(g_counts, e - s))
+    exact = runner.eng.alloc_outputs(n_sample)
+    runner.eng.search(queries.slice(0, n_sample), exact)
+    torch.cuda.synchronize()
+    gs = exact["start"].cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    ge = exact["end"].cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
     same_intervals = bool(np.array_equal(gs, s) and np.array_equal(ge, e))
+    del exact
     same_hits = None
     if do_locate:
+        runner.step(0, False)  # the accounting pass rewrote the hit buffer (same values); make it the timed path's again
+        torch.cuda.synchronize()
         off, t, p = loc
         n_h = int(off[-1])
-        gh = hits[:n_h].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        gh = runner.hits[0][:n_h].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         goff = out["hit_offsets"][:n_sample + 1].cpu().numpy().astype(np.uint64)
         same_hits = bool(np.array_equal(goff, off) and np.array_equal(gh[:, 0], t.astype(np.int64))
                          and np.array_equal(gh[:, 1], p.astype(np.int64)))
-    if not same_intervals or same_hits is False:
-        raise SystemExit(f"PARITY FAILURE vs CPU oracle: intervals {same_intervals}, hits {same_hits}")
+    if not same_intervals or not same_counts or same_hits is False:
+        raise SystemExit(f"PARITY FAILURE vs CPU oracle: intervals {same_intervals}, counts {same_counts}, hits {same_hits}")
     # the author's "batching gives about 2x" (src/lib.rs:37-40): batched vs single-query path on ONE thread
     m1 = min(queries.nq, 100_000)
     qbuf1, qoff1 = queries.host_slice(0, m1)
@@ -552,11 +937,13 @@ def cpu_baseline(np, index, alpha, queries, out, hits, do_locate, args, wl):
     cpu.cursors_single(qbuf1, qoff1, n_threads=1)
     t_single1 = time.perf_counter() - t0
     log(f"[bench] CPU baseline: {n_sample} queries, count {tc:.2f}s + locate {tl:.2f}s on {cores} threads "
-        f"-> {value:.3e} q/s; GPU results identical: intervals {same_intervals}, hits {same_hits}")
+        f"-> {value:.3e} q/s; GPU results identical: intervals {same_intervals}, counts {same_counts}, hits {same_hits}")
     return {"value": value, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"first {n_sample} queries of the GPU batch, same index (BWT + samples exported from the GPU "
-                      f"build, occurrence table rebuilt in the reference layout), count {tc:.2f}s + locate {tl:.2f}s",
-            "count_only_value": n_sample / tc, "bit_exact_vs_gpu": {"intervals": same_intervals, "hits": same_hits},
+                      f"build, occurrence table rebuilt in the reference layout, lookup depth {args.lookup_depth}, no "
+                      f"acceleration structures), count {tc:.2f}s + locate {tl:.2f}s",
+            "count_only_value": n_sample / tc,
+            "bit_exact_vs_gpu": {"intervals": same_intervals, "counts": same_counts, "hits": same_hits},
             "one_thread": {"batched_path_count_qps": m1 / t_batched1, "single_query_path_count_qps": m1 / t_single1,
                            "batching_speedup": t_single1 / t_batched1, "queries": m1}}
 

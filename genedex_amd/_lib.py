@@ -55,7 +55,8 @@ class BuildOptions(C.Structure):
 
 class QueryOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
-                ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32)]
+                ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32),
+                ("locate_jump_walk", C.c_int32)]
 
 
 class IndexAux(C.Structure):
@@ -145,6 +146,7 @@ SIGNATURES = {
     "gdx_fastx_next_batch": [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)],
     "gdx_fastx_close": [vp],
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
              "gdx_build_options_init": None, "gdx_query_options_init": None,

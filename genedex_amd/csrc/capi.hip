@@ -198,6 +198,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->load_policy = -1;
     opts->length_schedule = -1;
     opts->locate_kernel = -1;
+    opts->locate_jump_walk = -1;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -358,6 +359,9 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
             q.load_policy = opts->load_policy;
             q.length_schedule = opts->length_schedule;
             q.locate_variant = opts->locate_kernel;
+            if (opts->locate_jump_walk < -1 || opts->locate_jump_walk > 1)
+                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            q.locate_jump_walk = opts->locate_jump_walk;
         }
         ix->impl->set_query_options(q);
         return (int)GDX_OK;
@@ -376,6 +380,7 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->load_policy = q.load_policy;
         out->length_schedule = q.length_schedule;
         out->locate_kernel = q.locate_variant;
+        out->locate_jump_walk = q.locate_jump_walk;
         return (int)GDX_OK;
     });
 }
@@ -860,7 +865,22 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
         gdx::launch_locate(deref(ix).view(), static_cast<const uint32_t *>(d_start),
                            static_cast<const uint32_t *>(d_end), m, static_cast<const uint64_t *>(d_hit_offsets),
                            total_hits, d_hits, false, d_workspace, as_stream(stream),
-                           static_cast<unsigned long long *>(d_steps), nullptr, deref(ix).query_options());
+                           static_cast<unsigned long long *>(d_steps), nullptr, deref(ix).query_options(), nullptr,
+                           true);
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_hits_stats_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                                   uint64_t total_hits, void *d_hits, void *d_workspace, void *d_steps, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits,
+                           d_hits, false, d_workspace, as_stream(stream), static_cast<unsigned long long *>(d_steps),
+                           nullptr, f.query_options(), static_cast<const uint4 *>(d_records));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

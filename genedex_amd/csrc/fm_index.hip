@@ -935,6 +935,7 @@ void FmIndex::set_query_options(const QueryOptions &q)
     q_load_policy_.store(q.load_policy);
     q_schedule_.store(q.length_schedule);
     q_locate_variant_.store(q.locate_variant);
+    q_locate_jump_walk_.store(q.locate_jump_walk);
 }
 
 QueryOptions FmIndex::query_options() const
@@ -945,6 +946,7 @@ QueryOptions FmIndex::query_options() const
     q.load_policy = q_load_policy_.load();
     q.length_schedule = q_schedule_.load();
     q.locate_variant = q_locate_variant_.load();
+    q.locate_jump_walk = q_locate_jump_walk_.load();
     return q;
 }
 

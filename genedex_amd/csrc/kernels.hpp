@@ -18,6 +18,7 @@ struct QueryOptions {
     int load_policy = -1;      // -1 default (0 plain), 1 sc1
     int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
     int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
+    int locate_jump_walk = -1; // -1 default (1: the queue kernel walks through the jump table), 0 rank lines only
 };
 
 // Active lists of the cursor-extension mode (search mode 2): the cursors to extend are those listed in active_in
@@ -85,7 +86,9 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
-                   const uint4 *d_rec = nullptr);
+                   const uint4 *d_rec = nullptr, bool reference_walk = false);
+// reference_walk: walk one LF step at a time (sampled_suffix_array.rs:118-131) so that the steps counted through
+// d_step_stats are the reference's
 // d_rec != null: start / hint come from the search records instead of d_start / d_hint (d_start, d_end unused)
 
 }  // namespace gdx

@@ -155,7 +155,12 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(const uint64_
 // (mean 3 steps at rate 4, maximum over a wavefront ~15) does not idle the other lanes.
 constexpr uint32_t kLocateChunk = 2048;
 
-template <class Table, bool kWide>
+// Phase 1 walks through the JUMP TABLE when the index has one with at least two levels (kJumpWalk): the entry of
+// row r names the rows after 8, 16, ... LF steps, so one 32-byte fetch offers up to five candidates for a sampled row
+// (SA[r] = SA[t_j] + 8 j; 76 % per fetch at rate 4) where a rank-line step offers one (25 %): 1.3 fetches per walking
+// hit instead of 4.  PMC (profiles/r02): the rank-line walk was 54 % of the kernel's DRAM requests.  A level that is
+// invalid (a sentinel or a symbol outside 1..4 within its eight steps) is crossed with rank-line steps.
+template <class Table, bool kWide, bool kJumpWalk>
 __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
         }
         __syncthreads();
         const uint32_t queued = s_n;
+        if (step_stats && threadIdx.x == 0) atomicAdd(step_stats + 1, static_cast<unsigned long long>(queued));
         bool have = false;
         uint32_t row = 0, steps = 0, idx = 0, back = 0;
         for (;;) {
@@ -247,7 +253,42 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 }
             }
             if (!__any(have)) break;
-            if (have) {  // one step of sampled_suffix_array.rs:118-131 (the row is known not to be sampled)
+            bool jumped = false;
+            if (kJumpWalk && have) {
+                // levels of the entry of `row` (layout.hpp): first the sampled target nearest to row, else as far
+                // as the valid levels reach
+                const uint32_t words = ix.jump_bytes >> 2;
+                const u32x4 *e = reinterpret_cast<const u32x4 *>(static_cast<const uint32_t *>(ix.jump) +
+                                                                 static_cast<uint64_t>(row) * words);
+                const u32x4 e0 = e[0];
+                u32x4 e1 = e0;
+                if (ix.jump_bytes == 32) e1 = e[1];
+                const uint32_t valid = e0.w >> 16;
+                const uint32_t n_lv = ix.jump_bytes == 32 ? 5u : 2u;
+                uint32_t t[5] = {e0.x, e0.y, e1.x, e1.y, e1.z};
+                uint32_t reach = 0;  // valid levels (cumulative bits)
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++)
+                    if (j < n_lv && ((valid >> j) & 1u)) reach = j + 1u;
+                uint32_t got = 0;  // first level whose target is a sampled row
+#pragma unroll
+                for (uint32_t j = 5; j >= 1; j--)
+                    if (j <= reach && (pow2 ? ((t[j - 1] & ix.sa_rate_pow2_mask) == 0) : (t[j - 1] % ix.sa_rate == 0))) got = j;
+                if (got != 0u) {
+                    const uint32_t tr = t[got - 1u];
+                    const uint32_t slot = pow2 ? (tr >> ix.sa_rate_shift) : (tr / ix.sa_rate);
+                    steps += got * kJumpSymbols;
+                    store_hit<kWide>(ix, ix.sa_samples[slot] + steps - back, hits_out, base + idx, sentinels);
+                    walk_steps += steps;
+                    have = false;
+                    jumped = true;
+                } else if (reach != 0u) {
+                    row = t[reach - 1u];
+                    steps += reach * kJumpSymbols;
+                    jumped = true;
+                }
+            }
+            if (have && !jumped) {  // one step of sampled_suffix_array.rs:118-131 (the row is known not to be sampled)
                 uint32_t r;
                 const uint32_t c = Table::symbol_and_rank(ix, row, r);
                 if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
@@ -426,7 +467,7 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo, const uint4 *d_rec)
+                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -463,15 +504,21 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                            dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, first);
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
-#define GDX_LOCATE_Q(TABLE, WIDE)                                                                                  \
-    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,      \
+#define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                              \
+    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,  \
                        d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats)
+        // the walk goes through the jump table when there is one with at least two levels, unless the caller
+        // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
+        const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
+                               qo.locate_jump_walk != 0;
         if (ix.layout == 0) {
-            if (wide) GDX_LOCATE_Q(LineTable, true);
-            else GDX_LOCATE_Q(LineTable, false);
+            if (wide && jump_walk) GDX_LOCATE_Q(LineTable, true, true);
+            else if (wide) GDX_LOCATE_Q(LineTable, true, false);
+            else if (jump_walk) GDX_LOCATE_Q(LineTable, false, true);
+            else GDX_LOCATE_Q(LineTable, false, false);
         } else {
-            if (wide) GDX_LOCATE_Q(GenericTable, true);
-            else GDX_LOCATE_Q(GenericTable, false);
+            if (wide) GDX_LOCATE_Q(GenericTable, true, false);
+            else GDX_LOCATE_Q(GenericTable, false, false);
         }
 #undef GDX_LOCATE_Q
     } else if (ix.layout == 0 && ix.pair_lines != nullptr && variant == 2) {

@@ -50,16 +50,20 @@ struct QueryWindow {
     }
 };
 
-// The query as the pair kernels see it: dense codes, one nibble per symbol, eight symbols per 32-bit word,
-// read right-to-left.  A window word is fetched two words ahead (raw) and translated through the alphabet
-// table in LDS once, when it becomes the lower word of the window, so a symbol costs one LDS read however
-// often it is looked at, and all position arithmetic is 32-bit and relative to the query.
-struct CodeWindow {
-    const uint64_t *base;  // words of the query buffer; base[0] holds the first byte of the query
+// The query as the pair kernels see it: dense codes, one nibble per symbol, eight symbols per 32-bit word, read
+// right-to-left.  The kGroup lanes of a query translate the query COOPERATIVELY: a span of eight 8-byte words (64
+// bytes: a whole 50-mer) is loaded and translated through the alphabet table in LDS by the group at once, each lane
+// its own one (8 lanes) or two (4 lanes) words, and any lane fetches any translated word of the span from its
+// owner with one ds_bpermute (the LDS crossbar, no LDS memory).  Translating every word in every lane -- which is
+// what a plain per-lane window does -- made the kernel VALU-bound: PMC showed 880 VALU instructions per wavefront
+// and 16 queries, 85 % VALU issue utilisation, and no gain from a quarter fewer DRAM requests.
+template <int kGroup>
+struct SpanWindow {
+    static constexpr int kWordsPerLane = 8 / kGroup;
+    const uint64_t *base;  // base[0] holds the first byte of the query
     uint32_t off0;         // byte offset of the query inside base[0]
-    uint32_t cur_w;        // index of the word translated in `cur`
-    uint32_t cur, next;    // translated words cur_w and cur_w - 1 (nibble k = dense code of byte k, 0 = invalid)
-    uint64_t raw;          // word cur_w - 2, requested ahead
+    uint32_t top_w;        // span word k = query word top_w - k, k = 0 .. 7 (words below 0 read as 0)
+    uint32_t w0, w1;       // this lane's translated span words: k = sub * kWordsPerLane (and + 1)
 
     static __device__ __forceinline__ uint32_t translate(uint64_t w, const uint8_t *s_dense)
     {
@@ -68,56 +72,61 @@ struct CodeWindow {
         for (uint32_t k = 0; k < 8; k++) t |= static_cast<uint32_t>(s_dense[(w >> (8u * k)) & 0xffu]) << (4u * k);
         return t;
     }
-    __device__ __forceinline__ void set(const uint8_t *qbuf, uint64_t begin, uint32_t rem, uint64_t w0, uint64_t w1,
-                                        const uint8_t *s_dense)
+    __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin)
     {
         base = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
         off0 = static_cast<uint32_t>(begin & 7u);
-        cur_w = rem ? ((off0 + rem - 1u) >> 3) : 0u;
-        raw = cur_w >= 2u ? base[cur_w - 2u] : 0ull;
-        cur = translate(w0, s_dense);
-        next = translate(w1, s_dense);
+        top_w = 0;
+        w0 = w1 = 0;
     }
-    // rem = symbols of the query not consumed yet
-    __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin, uint32_t rem, const uint8_t *s_dense)
+    // positions the span so that its first word holds symbol rem - 1 (rem >= 1); group-uniform
+    __device__ __forceinline__ void load(uint32_t rem, const uint8_t *s_dense)
     {
-        const uint64_t *b = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
-        const uint32_t w = rem ? ((static_cast<uint32_t>(begin & 7u) + rem - 1u) >> 3) : 0u;
-        const uint64_t w0 = rem ? b[w] : 0ull;
-        const uint64_t w1 = w >= 1u ? b[w - 1u] : 0ull;
-        set(qbuf, begin, rem, w0, w1, s_dense);
-    }
-    // the same query, positioned at another rem (after a jump of more than one window word)
-    __device__ __forceinline__ void reinit(uint32_t rem, const uint8_t *s_dense)
-    {
-        const uint32_t w = rem ? ((off0 + rem - 1u) >> 3) : 0u;
-        cur_w = w;
-        raw = w >= 2u ? base[w - 2u] : 0ull;
-        cur = translate(rem ? base[w] : 0ull, s_dense);
-        next = translate(w >= 1u ? base[w - 1u] : 0ull, s_dense);
-    }
-    // codes of the 8 symbols that end with symbol rem-1 (nibble 7 = symbol rem-1, the next one to consume);
-    // moves the window one word down when the position has left it.  rem >= 1.  Nibbles of symbols before
-    // the start of the query are garbage and must not be used (callers check rem).
-    __device__ __forceinline__ uint32_t code8(uint32_t rem, const uint8_t *s_dense)
-    {
-        const uint32_t b = off0 + rem - 1u, w = b >> 3;
-        if (w != cur_w) {
-            cur_w = w;
-            cur = next;
-            next = translate(raw, s_dense);
-            raw = w >= 2u ? base[w - 2u] : 0ull;
+        const uint32_t sub = threadIdx.x & (kGroup - 1u);
+        top_w = (off0 + rem - 1u) >> 3;
+        const int32_t first = static_cast<int32_t>(top_w) - static_cast<int32_t>(sub) * kWordsPerLane;
+        uint64_t r0 = 0, r1 = 0;
+        if (kWordsPerLane == 2) {
+            if (first >= 1) {  // both words with one 16-byte load (8-byte aligned)
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(base + (first - 1));
+                r1 = static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32);
+                r0 = static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32);
+            } else if (first == 0) {
+                r0 = base[0];
+            }
+        } else if (first >= 0) {
+            r0 = base[first];
         }
-        const uint32_t s = (b & 7u) + 1u;  // nibbles taken from `cur`
+        w0 = translate(r0, s_dense);
+        if (kWordsPerLane == 2) w1 = translate(r1, s_dense);
+    }
+    // translated span word k (0 .. 7), k uniform in the group
+    __device__ __forceinline__ uint32_t word(uint32_t k) const
+    {
+        const uint32_t owner = (threadIdx.x & 63u & ~(kGroup - 1u)) + k / kWordsPerLane;
+        const uint32_t mine = (kWordsPerLane == 2 && (k & 1u)) ? w1 : w0;
+        return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(owner << 2), static_cast<int>(mine)));
+    }
+    // true when the symbols r - 1 .. r - 8 (those of them that exist) lie inside the span
+    __device__ __forceinline__ bool covers(uint32_t r) const
+    {
+        const uint32_t hi_w = (off0 + r - 1u) >> 3, lo_w = (off0 + (r >= 8u ? r - 8u : 0u)) >> 3;
+        return hi_w <= top_w && top_w - lo_w <= 7u;
+    }
+    // codes of the 8 symbols that end with symbol r - 1 (nibble 7 = symbol r - 1); the span must cover them.
+    // Nibbles of symbols before the start of the query are garbage and must not be used (callers check r).
+    __device__ __forceinline__ uint32_t at(uint32_t r) const
+    {
+        const uint32_t b = off0 + r - 1u, k = top_w - (b >> 3);
+        const uint32_t s = (b & 7u) + 1u;  // nibbles taken from span word k, the rest from word k + 1
+        const uint32_t cur = word(k), next = word(k + 1u > 7u ? 7u : k + 1u);
         return s == 8u ? cur : __builtin_amdgcn_alignbit(cur, next, 4u * s);
     }
-    // the same codes for any r <= rem (r >= 8) read straight from the query bytes; the window does not move
-    __device__ __forceinline__ uint32_t peek8(uint32_t r, const uint8_t *s_dense) const
+    // the same for the symbols the search consumes next (rem >= 1): moves the span down when they have left it
+    __device__ __forceinline__ uint32_t code8(uint32_t rem, const uint8_t *s_dense)
     {
-        const uint32_t p = off0 + r - 8u, w = p >> 3, sh = (p & 7u) * 8u;
-        uint64_t v = base[w];
-        if (sh) v = (v >> sh) | (base[w + 1u] << (64u - sh));
-        return translate(v, s_dense);
+        if (!covers(rem)) load(rem, s_dense);
+        return at(rem);
     }
 };
 
@@ -129,21 +138,17 @@ __device__ __forceinline__ bool has_zero_nibble(uint32_t x) { return ((x - 0x111
 // they stood at the step that emptied it, like the reference's lookup tables, lookup_table.rs:225-258), so such a
 // query is finished by the lookup.  Returns false when a symbol is outside 1..4: the caller then runs the ordinary
 // steps from the start, which validate symbols as lazily as the reference does.
+__device__ __forceinline__ bool all_dna(uint32_t x);
+__device__ __forceinline__ uint32_t to_2bit(uint32_t x);
+
 __device__ __forceinline__ bool top_lookup(const IndexView &ix, uint32_t a, uint32_t b, uint32_t &lo, uint32_t &hi)
 {
-    const uint32_t d = ix.top_depth;
-    const uint64_t all = (static_cast<uint64_t>(a) << 32) | b;
-    const uint64_t used = ~0ull << (4u * (16u - d));                  // the top d nibbles
-    const uint64_t v = (all & used) | (0x1111111111111111ull & ~used);  // unused nibbles := 1 (valid)
-    const uint64_t y = v - 0x1111111111111111ull;                     // per nibble c - 1 (no borrow if no zero nibble)
-    const bool zero = (y & ~v & 0x8888888888888888ull) != 0ull;
-    if (zero || (y & 0xccccccccccccccccull) != 0ull) return false;
-    uint64_t x = y;                                                   // 2 significant bits per nibble
-    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
-    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
-    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
-    x = (x | (x >> 16)) & 0x00000000ffffffffull;
-    const uint32_t idx = static_cast<uint32_t>(x) >> (32u - 2u * d);
+    const uint32_t d = ix.top_depth;  // 1 .. 16: the top min(d, 8) nibbles of a and the top d - 8 of b
+    const uint32_t ma = d >= 8u ? 0xffffffffu : 0xffffffffu << (4u * (8u - d));
+    const uint32_t mb = d > 8u ? 0xffffffffu << (4u * (16u - d)) : 0u;
+    const uint32_t va = (a & ma) | (0x11111111u & ~ma), vb = (b & mb) | (0x11111111u & ~mb);  // unused := valid
+    if (!all_dna(va) || !all_dna(vb)) return false;
+    const uint32_t idx = ((to_2bit(va) << 16) | to_2bit(vb)) >> (32u - 2u * d);
     const uint2 e = ix.top[idx];
     lo = e.x;
     hi = e.y;
@@ -424,7 +429,8 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         }
         const bool fresh = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210)
         uint32_t rem = 0;  // symbols still to consume, right to left
-        CodeWindow win;
+        SpanWindow<kGroup> win;
+        win.init(qbuf, begin);
         // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
         // top_depth symbols are all in 1..4, hence (with at least four searchable symbols) valid and searchable,
         // which is everything the reference checks for its t-symbol suffix (lookup_table.rs:99-113); the interval
@@ -434,7 +440,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             (kMode != 2 || (fresh && !stopped))) {
             const uint32_t lo0 = lo, hi0 = hi;
             rem = static_cast<uint32_t>(len);
-            win.init(qbuf, begin, rem, s_dense);
+            win.load(rem, s_dense);
             const uint32_t a = win.code8(rem, s_dense);
             const uint32_t b = ix.top_depth > 8u ? win.code8(rem - 8u, s_dense) : 0u;
             topped = top_lookup(ix, a, b, lo, hi);
@@ -468,7 +474,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 }
             }
             rem = stopped ? 0u : static_cast<uint32_t>(len - t);
-            win.init(qbuf, begin, rem, s_dense);
+            if (rem > 0u) win.load(rem, s_dense);
         }
         // hints carry symbol counts of 21 bits (locate.hip packs them beside a slot number); longer queries
         // (2 M symbols and more) simply do not jump
@@ -515,12 +521,18 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             uint32_t qa = 0, qb = 0, qc = 0, qok = 0;
             uint32_t tail16 = kNoCode;  // kMode 1: codes of the last rem % 8 symbols, in the top bits
             if (jumping) {
+                // every symbol the levels (and the lazy tail) look at must be inside the span: after a span load
+                // at rem they are (40 symbols and their alignment are at most seven words)
+                const uint32_t n_lv = rem >> 3 < static_cast<uint32_t>(kLevels) ? rem >> 3 : static_cast<uint32_t>(kLevels);
+                const uint32_t r_low = (kMode == 1 && (rem >> 3) < static_cast<uint32_t>(kCodes)) ? 8u
+                                                                                                 : rem - (n_lv - 1u) * kJumpSymbols;
+                if (!win.covers(r_low)) win.load(rem, s_dense);
                 qa = to_2bit(code);
                 qok = 1u;
 #pragma unroll
                 for (int j = 1; j < kLevels; j++) {
                     if (rem >= (j + 1u) * kJumpSymbols) {
-                        const uint32_t cj = win.peek8(rem - j * kJumpSymbols, s_dense);
+                        const uint32_t cj = win.at(rem - j * kJumpSymbols);
                         if (all_dna(cj)) {
                             const uint32_t v = to_2bit(cj);
                             if (j == 1) qa |= v << 16;
@@ -535,7 +547,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     // the query's first rem % 8 symbols as the top nibbles (the lower ones set to a valid code)
                     const uint32_t tl = rem & 7u;
                     const uint32_t m = 0xffffffffu << (4u * (8u - tl));
-                    const uint32_t cj = ((win.peek8(8u, s_dense) << (4u * (8u - tl))) & m) | (0x11111111u & ~m);
+                    const uint32_t cj = ((win.at(8u) << (4u * (8u - tl))) & m) | (0x11111111u & ~m);
                     if (all_dna(cj)) tail16 = to_2bit(cj);
                 }
             }
@@ -660,7 +672,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(hr, ho);
                         status |= 0x80000000u;  // hinted (kept out of the status byte below)
                     }
-                    if (done > kJumpSymbols && rem > 0u) win.reinit(rem, s_dense);
+
                 } else {
                     // the interval empties within the next 8 steps (or a stored symbol is outside 1..4): the pair
                     // lines find where, which yields the reference's frozen interval (rare: a read that occurs in

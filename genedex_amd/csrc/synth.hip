@@ -153,6 +153,37 @@ __global__ __launch_bounds__(kBlock) void gather_lane_kernel(const u32x4 *__rest
     if (acc == 0x12345u) *sink = acc;  // keeps the loads alive
 }
 
+// mode 3: every lane reads one random entry of kBytes (8, 16 or 32: a top-table entry, a jump entry) with one or two
+// loads, two independent entries in flight: the access shape of a one-lane-per-query search
+template <int kBytes>
+__global__ __launch_bounds__(kBlock) void gather_small_kernel(const uint2 *__restrict__ src, uint64_t n_entries,
+                                                              uint64_t per_thread, uint64_t seed,
+                                                              uint32_t *__restrict__ sink)
+{
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    uint32_t state = static_cast<uint32_t>(mix64(seed + tid));
+    uint32_t acc = 0;
+    for (uint64_t k = 0; k < per_thread; k += 2) {
+        const uint64_t e0 = pick_line(pcg_next(state), n_entries), e1 = pick_line(pcg_next(state), n_entries);
+        if (kBytes == 8) {
+            const uint2 a = src[e0], b = src[e1];
+            acc ^= a.x ^ a.y ^ b.x ^ b.y;
+        } else {
+            const u32x4 *s16 = reinterpret_cast<const u32x4 *>(src);
+            constexpr int kVec = kBytes >= 16 ? kBytes / 16 : 1;
+            u32x4 v0[kVec], v1[kVec];
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                v0[j] = s16[e0 * kVec + j];
+                v1[j] = s16[e1 * kVec + j];
+            }
+#pragma unroll
+            for (int j = 0; j < kVec; j++) acc ^= v0[j].x ^ v0[j].w ^ v1[j].y ^ v1[j].z;
+        }
+    }
+    if (acc == 0x12345u) *sink = acc;
+}
+
 // mode 1: kVecPerLine adjacent lanes read one line, 16 bytes each, two independent lines in flight
 template <int kVecPerLine>
 __global__ __launch_bounds__(kBlock) void gather_group_kernel(const u32x4 *__restrict__ src, uint64_t n_lines,
@@ -241,11 +272,25 @@ void launch_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hip
 void launch_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
                           uint64_t seed, uint32_t mode, uint32_t *d_sink, hipStream_t stream)
 {
-    if (line_bytes != 64 && line_bytes != 128) fail(GDX_ERR_INVALID_ARGUMENT, "line_bytes must be 64 or 128");
     if (n_lines >= (1ull << 32)) fail(GDX_ERR_INVALID_ARGUMENT, "n_lines must be < 2^32");
     if (n_lines == 0 || n_accesses == 0) return;
     const unsigned grid = 256u * 8u;
     const uint64_t threads = static_cast<uint64_t>(grid) * kBlock;
+    if (mode == 3) {
+        uint64_t per_thread = div_ceil(n_accesses, threads);
+        per_thread += per_thread & 1u;
+        const uint2 *s8 = static_cast<const uint2 *>(d_src);
+        if (line_bytes == 8)
+            hipLaunchKernelGGL(gather_small_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, s8, n_lines, per_thread, seed, d_sink);
+        else if (line_bytes == 16)
+            hipLaunchKernelGGL(gather_small_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, s8, n_lines, per_thread, seed, d_sink);
+        else if (line_bytes == 32)
+            hipLaunchKernelGGL(gather_small_kernel<32>, dim3(grid), dim3(kBlock), 0, stream, s8, n_lines, per_thread, seed, d_sink);
+        else
+            fail(GDX_ERR_INVALID_ARGUMENT, "mode 3: line_bytes must be 8, 16 or 32");
+        return;
+    }
+    if (line_bytes != 64 && line_bytes != 128) fail(GDX_ERR_INVALID_ARGUMENT, "line_bytes must be 64 or 128");
     const u32x4 *src = static_cast<const u32x4 *>(d_src);
     if (mode == 0 || mode == 2) {
         uint64_t per_thread = div_ceil(n_accesses, threads);

@@ -86,6 +86,12 @@ class DeviceQueries:
         pad[:total] = qbuf[:total]
         return cls(torch.from_numpy(pad).to(device), torch.from_numpy(qoff.astype(np.int64)).to(device), nq, total)
 
+    def slice(self, lo: int, hi: int) -> "DeviceQueries":
+        """queries [lo, hi) as a view: the same byte buffer, a window of the offsets (no copy)"""
+        off = self.qoff[lo:hi + 1]
+        nbytes = int((off[-1] - off[0]).item()) if hi > lo else 0
+        return DeviceQueries(self.qbuf, off, hi - lo, nbytes)
+
     def host_slice(self, first: int, count: int):
         """(qbuf, qoff) of queries [first, first+count) as numpy arrays (for the CPU baseline / checks)."""
         off = self.qoff[first:first + count + 1].cpu().numpy().astype(np.uint64)
@@ -202,12 +208,19 @@ class DeviceEngine:
     def search_lf_steps(self, q: DeviceQueries) -> int:
         return self.search_step_stats(q)[0]
 
+    def locate_record_walks(self, rec, nq: int, hit_offsets, total: int, hits, workspace):
+        """(walk steps executed with the records' hints, hits that walked)"""
+        steps = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        _lib.check(self.lib.gdx_locate_many_hits_stats_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
+                                                           _ptr(workspace), _ptr(steps), _stream()))
+        return [int(x) for x in steps.tolist()]
+
     def locate_walk_steps(self, out, m: int, total: int, hits: torch.Tensor, workspace: torch.Tensor) -> int:
-        steps = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        steps = torch.zeros(2, dtype=torch.int64, device=self.dev)
         _lib.check(self.lib.gdx_locate_step_stats_dev(self.h, _ptr(out["start"]), _ptr(out["end"]), m,
                                                       _ptr(out["hit_offsets"]), total, _ptr(hits), _ptr(workspace),
                                                       _ptr(steps), _stream()))
-        return int(steps.item())
+        return int(steps[0].item())
 
 
 def measure_bandwidth(device="cuda", gib: float = 4.0, reps: int = 3):

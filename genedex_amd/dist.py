@@ -119,3 +119,14 @@ def max_int_over_ranks(value: int, device) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(t.item())
+
+
+def gather_ints(value: int, device):
+    """one integer per rank -> list of world integers on every rank"""
+    rank, n = world()
+    if n == 1:
+        return [int(value)]
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(t) for _ in range(n)]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]

@@ -161,7 +161,7 @@ class FmIndex:
         return {f: int(getattr(a, f)) for f, _ in a._fields_ if f != "reserved"}
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
-                          locate_kernel=None) -> None:
+                          locate_kernel=None, locate_jump_walk=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -176,6 +176,8 @@ class FmIndex:
             o.length_schedule = int(length_schedule)
         if locate_kernel is not None:
             o.locate_kernel = {"queue": 0, "lane": 1, "pair": 2}.get(locate_kernel, locate_kernel)
+        if locate_jump_walk is not None:
+            o.locate_jump_walk = int(bool(locate_jump_walk))
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

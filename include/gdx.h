@@ -178,6 +178,7 @@ typedef struct {
     int32_t load_policy;     /* -1 default (0 plain loads), 1 = sc1 (no L1 allocation)                        */
     int32_t length_schedule; /* -1 default (1: a block orders its queries by length when they differ), 0 off  */
     int32_t locate_kernel;   /* -1 default (0 queue kernel), 1 one lane per hit, 2 eight lanes per hit        */
+    int32_t locate_jump_walk; /* -1 default (1: the locate walk goes through the jump table), 0 rank lines only */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);

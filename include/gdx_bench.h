@@ -51,7 +51,9 @@ int gdx_bench_stream_read(const void *d_src, uint64_t bytes, void *d_sink, void 
  * mode 0: one lane reads a whole line (the access shape of the lane-per-query rank);
  * mode 1: line_bytes/16 adjacent lanes read one line, 16 bytes each;
  * mode 2: as mode 0 but every next line depends on the data just loaded (a dependent chain per lane,
- *         the shape of an LF loop).  n_accesses should be a multiple of 2^20.  d_sink: u32[1]. */
+ *         the shape of an LF loop);
+ * mode 3: every lane reads one entry of line_bytes = 8, 16 or 32 (the shape of a one-lane-per-query search reading
+ *         top-table and jump-table entries).  n_accesses should be a multiple of 2^20.  d_sink: u32[1]. */
 int gdx_bench_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
                             uint64_t seed, uint32_t mode, void *d_sink, void *stream);
 
@@ -61,10 +63,16 @@ int gdx_bench_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_b
  * longest query of the wave ends), so [1] / [2] is the active-lane fraction of the search. */
 int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                               void *d_steps, void *stream);
-/* same call as gdx_locate_intervals_dev; d_steps (u64[1], pre-zeroed) += locate walk steps executed */
+/* same call as gdx_locate_intervals_dev; d_steps (u64[2], pre-zeroed): [0] += locate walk steps executed,
+ * [1] += hits that had to walk at all */
 int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const void *d_end, uint64_t m,
                               const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace,
                               void *d_steps, void *stream);
+
+/* the same call as gdx_locate_many_hits_dev; d_steps (u64[2], pre-zeroed): [0] += walk steps actually executed
+ * (with the records' hints), [1] += hits that had to walk at all */
+int gdx_locate_many_hits_stats_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                                   uint64_t total_hits, void *d_hits, void *d_workspace, void *d_steps, void *stream);
 
 /* Query acceleration structures the index carries beside the reference's arrays (DESIGN.md "HBM layout"):
  * out[0] = 1 if pair lines are present, out[1] = bytes per jump-table entry (0 = none, 8 or 16),

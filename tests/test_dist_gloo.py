@@ -75,6 +75,7 @@ def _worker(rank, world, port, result_path):
             pipelined_ok &= torch.equal(got[2][0][: counts.numel()].to(torch.int64), torch.clamp(counts, max=255))
     fixed = gdist.gather_fixed(torch.tensor([rank, hi - lo]), dst=0)
     tmax = gdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    ints_ok = gdist.gather_ints(10 + rank, torch.device("cpu")) == [10, 11]
     gdist.barrier()
     if rank == 0:
         all_counts = torch.cat(got_counts).numpy()
@@ -83,7 +84,7 @@ def _worker(rank, world, port, result_path):
         foff, ft, fp = replica.locate_intervals(fs, fe)
         ok = (np.array_equal(all_counts, (fe - fs).astype(np.int64))
               and np.array_equal(all_hits[:, 0], ft.astype(np.int64)) and np.array_equal(all_hits[:, 1], fp.astype(np.int64))
-              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok)
+              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok and ints_ok)
         open(result_path, "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
 

@@ -99,8 +99,8 @@ def test_rank_kats(kat):
         if sent[-1] != text.size - 1:
             continue
         samples = np.zeros(-(-text.size // 4), dtype=np.uint32)
-        ix = FmIndex.from_parts(count, o.blocks, text.size, samples, 4, np.arange(n_texts), np.zeros(n_texts), sent,
-                                a)
+        # the planes ARE the BWT here, so the rows that hold the sentinel are the positions of symbol 0
+        ix = FmIndex.from_parts(count, o.blocks, text.size, samples, 4, sent, np.zeros(n_texts), sent, a)
         cols = naive_occurrence_columns(text, sigma)
         step = 1 if text.size < 3000 else 53
         idx = np.array(sorted(set(range(0, text.size + 1, step)) | {text.size}), dtype=np.uint64)
@@ -211,7 +211,7 @@ _VARIANTS = {
     "pair-narrow": (dict(search_kernel="pair"), dict(jump_entry_bytes=8, top_table_depth=0)),
     # forced top depths: on these small texts most deep entries are empty, so the fall-back to the ordinary
     # path runs constantly
-    "pair-top4": (dict(search_kernel="pair"), dict(top_table_depth=4)),
+    "pair-top4": (dict(search_kernel="pair", locate_jump_walk=False), dict(top_table_depth=4)),
     "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
     "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
