@@ -589,12 +589,17 @@ def main():
     else:
         result["cpu_baseline"] = None
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["end_to_end"] = end_to_end(np, torch, index, queries, nq, counts, total_hits, ms_per_step, search_ms)
+
     if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
         base_counts = counts.clone()
         runner.outs, runner.hits, runner.ws = [], [], []
-        del out, hits, counts
+        del out, hits, counts, runner
         torch.cuda.empty_cache()
-        result["secondary"] = secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
+        owned = {"eng": eng, "index": index}  # handed over: the last rung frees the index before building another
+        del eng, index
+        result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
                                           args, wl)
 
     if rank == 0:
@@ -699,7 +704,7 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
     return ms, runner.mean_ms(runner.ev_search), runner.mean_ms(runner.ev_locate), counts
 
 
-def secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl):
+def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -707,6 +712,7 @@ def secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts
     lookup-table knob at the depth BASELINE.md names."""
     from genedex_amd.device import DeviceEngine, build_index_from_device_text
 
+    eng, index = owned["eng"], owned["index"]
     res = []
     ladder = [("top14_jump32", dict(top_table_depth=14)),
               ("top16_jump16", dict(jump_entry_bytes=16)),
@@ -744,6 +750,7 @@ def secondaries(torch, eng, index, io_text, lengths, alpha, queries, base_counts
     if not args.no_extras:
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
     # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays)
+    owned.clear()
     del eng, index
     torch.cuda.empty_cache()
     t0 = time.time()
@@ -829,6 +836,91 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
            "live_cursors_after_each_call": live, "intervals_identical": same,
            "lf_steps": lf_steps, "active_lane_fraction_fused": fetches / slots if slots else None}
     log(f"[bench] secondary {res}")
+    return res
+
+
+def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, search_ms):
+    """SURVEY.md 8d "wall-clock incl. H2D/D2H": the host-pointer calls a genedex caller would make (queries as &[u8] in
+    host memory, lib.rs:155-185; results into host arrays), which run as a chunked H2D || kernels || D2H pipeline
+    (host_api.hip).  Never `value`.  The PCIe rates are measured here with pinned 1 GiB copies."""
+    import ctypes as C
+
+    from genedex_amd import _lib
+
+    lib = _lib.load()
+    dev = queries.qbuf.device
+    nbytes = queries.total_bytes
+    qbuf = queries.qbuf[:nbytes].cpu().numpy()
+    qoff = queries.qoff.cpu().numpy().astype(np.uint64)
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+
+    def copy_rate(dst, src):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return (1 << 30) / best / 1e9
+
+    h2d, d2h = copy_rate(dbuf, pin), copy_rate(pin, dbuf)
+    del pin, dbuf
+    counts = np.empty(nq, dtype=np.uint64)
+    status = np.empty(nq, dtype=np.uint8)
+    u8p, u64p = _lib.u8p, _lib.u64p
+
+    def count_call():
+        _lib.check(lib.gdx_count_many(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                      counts.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+    def best_of(fn, reps=2):
+        fn()  # the first call also sizes the pinned staging buffers
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
+    t_count = best_of(count_call)
+    same_counts = bool(np.array_equal(counts, dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)))
+    offs = np.empty(nq + 1, dtype=np.uint64)
+    total = C.c_uint64(0)
+    last = {}
+
+    def locate_call():
+        ptr = C.POINTER(_lib.HitStruct)()
+        _lib.check(lib.gdx_locate_many_alloc(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                             offs.ctypes.data_as(u64p), C.byref(ptr), C.byref(total),
+                                             status.ctypes.data_as(u8p)))
+        if last.get("ptr"):
+            lib.gdx_free_hits(last["ptr"])
+        last["ptr"] = ptr
+
+    t_locate = best_of(locate_call)
+    same_total = total.value == total_hits and int(offs[-1]) == total_hits
+    if last.get("ptr"):
+        lib.gdx_free_hits(last["ptr"])
+    if not same_counts or not same_total:
+        raise SystemExit("PARITY FAILURE: the host-pointer calls disagree with the device-resident path")
+    in_bytes = nbytes + 8 * (nq + 1)
+    out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
+    out_locate_bytes = 5 * nq + 8 * total_hits
+    bound_count = max(in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3)
+    bound_locate = max(in_bytes / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3)
+    res = {"count_qps": nq / t_count, "count_seconds": t_count, "locate_qps": nq / t_locate, "locate_seconds": t_locate,
+           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "h2d_bytes": in_bytes, "d2h_bytes_count": out_count_bytes,
+           "d2h_bytes_locate": out_locate_bytes,
+           "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
+           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, kernel time)",
+           "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
+                    "identical to the device-resident path", "query_packing": "none (ASCII)",
+           "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
+    log(f"[bench] end to end: {res}")
     return res
 
 

@@ -113,6 +113,8 @@ SIGNATURES = {
     "gdx_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
     "gdx_cursors_for_many_queries": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],
     "gdx_locate_many": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p, u8p],
+    "gdx_locate_many_alloc": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(C.POINTER(HitStruct)), u64p, u8p],
+    "gdx_free_hits": [C.POINTER(HitStruct)],
     "gdx_cursor_empty": [vp, u64p, u64p],
     "gdx_cursor_extend_front_many": [vp, u64p, u64p, u8p, C.c_uint64, u8p],
     "gdx_cursor_locate_many": [vp, u64p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p],
@@ -137,6 +139,7 @@ SIGNATURES = {
     "gdx_synth_queries_dev": [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp,
                               C.c_uint64, u64p, vp],
     "gdx_debug_set_search_variant": [C.c_int],
+    "gdx_debug_set_host_chunking": [C.c_uint64, C.c_uint64],
     "gdx_bench_stream_copy": [vp, vp, C.c_uint64, vp],
     "gdx_bench_stream_read": [vp, C.c_uint64, vp, vp],
     "gdx_bench_random_gather": [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp],
@@ -149,7 +152,7 @@ SIGNATURES = {
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
-             "gdx_build_options_init": None, "gdx_query_options_init": None,
+             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None,
              "gdx_locate_workspace_bytes": C.c_uint64}
 
 _lib = None

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary declared in include/gdx.h (and the bench / synthetic-data
 // helpers of include/gdx_bench.h).  Exceptions never cross it: they become a gdx_status plus a
 // thread-local message.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -490,6 +491,16 @@ int gdx_locate_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *
     });
 }
 
+int gdx_locate_many_alloc(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                          uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
+{
+    return guarded([&] {
+        return deref(ix).locate_many_alloc(qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
+    });
+}
+
+void gdx_free_hits(gdx_hit_t *hits) { std::free(hits); }
+
 int gdx_cursor_empty(const gdx_index_t *ix, uint64_t *start, uint64_t *end)
 {
     return guarded([&] {
@@ -791,6 +802,12 @@ int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uin
                            static_cast<uint8_t *>(d_qbuf), qbuf_capacity, out_total_bytes, as_stream(stream));
         return (int)GDX_OK;
     });
+}
+
+int gdx_debug_set_host_chunking(uint64_t queries, uint64_t bytes)
+{
+    gdx::set_host_chunking(queries, bytes);
+    return GDX_OK;
 }
 
 int gdx_debug_set_search_variant(int variant)

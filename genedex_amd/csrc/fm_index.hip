@@ -737,10 +737,18 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     view_.n = static_cast<uint32_t>(n_);
     view_.n_texts = static_cast<uint32_t>(n_texts_);
     view_.sa_rate = static_cast<uint32_t>(cfg_.sa_rate);
-    const bool pow2 = (cfg_.sa_rate & (cfg_.sa_rate - 1)) == 0;
-    view_.sa_rate_pow2_mask = pow2 ? static_cast<uint32_t>(cfg_.sa_rate - 1) : 0xffffffffu;
-    view_.sa_rate_shift = 0;
-    while (pow2 && (1ull << view_.sa_rate_shift) < cfg_.sa_rate) view_.sa_rate_shift++;
+    {
+        uint32_t d = static_cast<uint32_t>(cfg_.sa_rate), rot = 0;
+        while ((d & 1u) == 0u) {
+            d >>= 1;
+            rot++;
+        }
+        uint32_t inv = d;  // Newton iteration for the inverse of an odd number modulo 2^32 (3 correct bits to start)
+        for (int it = 0; it < 5; it++) inv *= 2u - d * inv;
+        view_.sa_inv = inv;
+        view_.sa_rot = rot;
+        view_.sa_limit = static_cast<uint32_t>(0xffffffffull / cfg_.sa_rate);
+    }
     view_.sigma = sigma;
     view_.nbits = nbits;
     view_.n_searchable = cfg_.n_searchable;
@@ -1210,41 +1218,6 @@ void download_widened(const uint32_t *d_in, uint64_t *h_out, uint64_t m, hipStre
 
 }  // namespace
 
-int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
-                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const
-{
-    check_queries(qbuf, qoff, nq);
-    if (nq == 0) return GDX_OK;
-    make_current();
-    hipStream_t stream = hipStreamPerThread;
-    DeviceQueries dq(qbuf, qoff, nq, stream);
-    const bool intervals = out_start != nullptr || out_end != nullptr;
-    DeviceBuffer<uint32_t> d_start(intervals ? nq : 0), d_end(intervals ? nq : 0), d_count(out_count ? nq : 0);
-    DeviceBuffer<uint8_t> d_status(nq);
-    {
-        SearchCall c;
-        c.d_qbuf = dq.qbuf.get();
-        c.d_qbeg = dq.qoff.get();
-        c.d_qend = dq.qoff.get() + 1;
-        c.nq = nq;
-        c.d_start = d_start.get();
-        c.d_end = d_end.get();
-        c.d_count = d_count.get();
-        c.d_status = d_status.get();
-        c.mode = intervals ? 0 : 1;  // counts alone do not need the exact interval (lazy tail)
-        launch_search_call(view_, c, stream, query_options());
-    }
-    GDX_HIP(hipGetLastError());
-    download_widened(d_start.get(), out_start, nq, stream);
-    download_widened(d_end.get(), out_end, nq, stream);
-    download_widened(d_count.get(), out_count, nq, stream);
-    std::vector<uint8_t> status(nq);
-    GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
-    GDX_HIP(hipStreamSynchronize(stream));
-    if (out_status) std::memcpy(out_status, status.data(), nq);
-    return any_status(status.data(), nq);
-}
-
 void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                             gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
                             const uint4 *d_rec) const
@@ -1279,42 +1252,6 @@ void FmIndex::locate_device(const uint32_t *d_start, const uint32_t *d_end, uint
     GDX_HIP(hipGetLastError());
     GDX_HIP(hipMemcpyAsync(hits, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
-}
-
-int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
-                         gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const
-{
-    check_queries(qbuf, qoff, nq);
-    if (out_total) *out_total = 0;
-    if (nq == 0) {
-        if (out_hit_offsets) out_hit_offsets[0] = 0;
-        return GDX_OK;
-    }
-    make_current();
-    hipStream_t stream = hipStreamPerThread;
-    DeviceQueries dq(qbuf, qoff, nq, stream);
-    DeviceBuffer<uint8_t> d_status(nq);
-    DeviceBuffer<uint4> d_rec(nq);  // count, status and locate hint of every query (search mode 1)
-    {
-        SearchCall c;
-        c.d_qbuf = dq.qbuf.get();
-        c.d_qbeg = dq.qoff.get();
-        c.d_qend = dq.qoff.get() + 1;
-        c.nq = nq;
-        c.d_rec = d_rec.get();
-        c.d_status = d_status.get();
-        c.mode = 1;
-        launch_search_call(view_, c, stream, query_options());
-    }
-    GDX_HIP(hipGetLastError());
-    std::vector<uint8_t> status(nq);
-    GDX_HIP(hipMemcpyAsync(status.data(), d_status.get(), nq, hipMemcpyDeviceToHost, stream));
-    GDX_HIP(hipStreamSynchronize(stream));
-    if (out_status) std::memcpy(out_status, status.data(), nq);
-    int rc = any_status(status.data(), nq);
-    int lrc = GDX_OK;
-    locate_device(nullptr, nullptr, nq, out_hit_offsets, hits, hits_capacity, out_total, &lrc, d_rec.get());
-    return lrc != GDX_OK ? lrc : rc;
 }
 
 namespace {

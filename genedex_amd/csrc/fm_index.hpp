@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -84,6 +85,9 @@ public:
                                  uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const;
     int locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                     gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
+    // the same as locate_many with a hit buffer the library allocates (malloc; the caller frees it): one pass
+    int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                          gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
     int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
                                  uint8_t *out_status) const;
     int cursor_extend_front_strings(uint64_t *start, uint64_t *end, const uint8_t *qbuf, const uint64_t *qoff, uint64_t m,
@@ -104,6 +108,10 @@ public:
 
 private:
     FmIndex() = default;
+    // chunked, three-deep pipeline behind the host-pointer query calls (host_api.hip)
+    int host_pipeline(int kind, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a, uint64_t *out_b,
+                      uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total,
+                      const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
@@ -134,5 +142,8 @@ private:
     DeviceBuffer<uint2> lookup_;
     IndexView view_{};
 };
+
+// chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
+void set_host_chunking(uint64_t queries, uint64_t bytes);
 
 }  // namespace gdx

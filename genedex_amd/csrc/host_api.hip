@@ -1,0 +1,513 @@
+// host_api.hip -- the host-pointer query calls (gdx_count_many, gdx_cursors_for_many_queries, gdx_locate_many):
+// FmIndex::count_many / cursors_for_many_queries / locate_many of the reference (lib.rs:155-185) for callers whose
+// queries and results live in host memory.
+//
+// A call is a pipeline over chunks of the batch, three chunks in flight:
+//
+//     host threads: user memory -> pinned staging   |  H2D (copy-in stream)  |  kernels (compute stream)
+//                                                   |  D2H (copy-out stream) |  host threads: pinned -> user arrays
+//
+// so that the PCIe transfers of chunk k + 1 / k - 1 run beside the kernels of chunk k and a call costs about
+// max(H2D time, D2H time, kernel time) instead of their sum.  Device results travel narrow (u32 counts and rows,
+// 8-byte hits, one status byte) and are widened to the ABI's u64 by the host threads while they copy.  Results are
+// order preserving: chunk boundaries are invisible to the caller.
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "fm_index.hpp"
+#include "kernels.hpp"
+
+namespace gdx {
+
+namespace {
+
+constexpr int kSlots = 3;
+std::atomic<uint64_t> g_chunk_bytes{32ull << 20};   // query bytes per chunk
+std::atomic<uint64_t> g_chunk_queries{1ull << 20};  // and at most this many queries
+
+// ---- a small persistent worker pool for the staging copies ------------------------------------------------
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n) : n_(n < 1 ? 1 : n)
+    {
+        for (unsigned i = 1; i < n_; i++) threads_.emplace_back([this, i] { loop(i); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    unsigned size() const { return n_; }
+    // fn(worker, n_workers) on every worker (the caller is worker 0); returns when all are done
+    void run(const std::function<void(unsigned, unsigned)> &fn)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            pending_ = n_ - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        fn(0, n_);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    // [0, n) split into contiguous parts of whole `align` units
+    template <class F>
+    void parallel_range(uint64_t n, uint64_t align, F f)
+    {
+        if (n < (1u << 16) || n_ == 1) {
+            f(0, n);
+            return;
+        }
+        run([&](unsigned w, unsigned nw) {
+            const uint64_t per = (n / nw + align) / align * align;
+            const uint64_t lo = std::min<uint64_t>(n, per * w), hi = std::min<uint64_t>(n, lo + per);
+            if (hi > lo) f(lo, hi);
+        });
+    }
+
+private:
+    void loop(unsigned idx)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned, unsigned)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            if (fn) (*fn)(idx, n_);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    unsigned n_;
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned, unsigned)> *fn_ = nullptr;
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+unsigned host_threads()
+{
+    static const unsigned n = [] {
+        if (const char *e = getenv("GDX_HOST_THREADS")) return static_cast<unsigned>(std::max(1, atoi(e)));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::min(16u, std::max(2u, hw / 4u));
+    }();
+    return n;
+}
+
+// ---- grow-only pinned host memory and device memory per (thread, device, slot) -----------------------------
+struct Buf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+struct BufCache {
+    std::vector<std::pair<uint64_t, Buf>> pinned, device;  // key = device << 8 | id
+    ~BufCache()
+    {
+        for (auto &kv : pinned)
+            if (kv.second.ptr) (void)hipHostFree(kv.second.ptr);
+        for (auto &kv : device)
+            if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    }
+};
+BufCache &cache()
+{
+    thread_local BufCache c;
+    return c;
+}
+void *cached(std::vector<std::pair<uint64_t, Buf>> &v, uint64_t key, size_t bytes, bool pinned)
+{
+    Buf *b = nullptr;
+    for (auto &kv : v)
+        if (kv.first == key) b = &kv.second;
+    if (!b) {
+        v.emplace_back(key, Buf{});
+        b = &v.back().second;
+    }
+    if (b->bytes < bytes) {
+        if (b->ptr) {
+            GDX_HIP(hipDeviceSynchronize());
+            if (pinned) GDX_HIP(hipHostFree(b->ptr));
+            else GDX_HIP(hipFree(b->ptr));
+            b->ptr = nullptr;
+            b->bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (pinned) GDX_HIP(hipHostMalloc(&b->ptr, want, hipHostMallocDefault));
+        else GDX_HIP(hipMalloc(&b->ptr, want));
+        b->bytes = want;
+    }
+    return b->ptr;
+}
+template <class T>
+T *pinned_buf(int device, int id, size_t count)
+{
+    return static_cast<T *>(cached(cache().pinned, (static_cast<uint64_t>(device) << 8) | id, count * sizeof(T) + 16, true));
+}
+template <class T>
+T *device_buf(int device, int id, size_t count)
+{
+    return static_cast<T *>(cached(cache().device, (static_cast<uint64_t>(device) << 8) | id, count * sizeof(T) + 16, false));
+}
+
+struct Streams {
+    hipStream_t in = nullptr, k = nullptr, out = nullptr;
+    hipEvent_t ev_in[kSlots] = {}, ev_k[kSlots] = {}, ev_out[kSlots] = {}, ev_total[kSlots] = {};
+    Streams()
+    {
+        GDX_HIP(hipStreamCreateWithFlags(&in, hipStreamNonBlocking));
+        GDX_HIP(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
+        GDX_HIP(hipStreamCreateWithFlags(&out, hipStreamNonBlocking));
+        for (int s = 0; s < kSlots; s++) {
+            GDX_HIP(hipEventCreateWithFlags(&ev_in[s], hipEventDisableTiming));
+            GDX_HIP(hipEventCreateWithFlags(&ev_k[s], hipEventDisableTiming));
+            GDX_HIP(hipEventCreateWithFlags(&ev_out[s], hipEventDisableTiming));
+            GDX_HIP(hipEventCreateWithFlags(&ev_total[s], hipEventDisableTiming));
+        }
+    }
+    ~Streams()
+    {
+        for (int s = 0; s < kSlots; s++) {
+            if (ev_in[s]) (void)hipEventDestroy(ev_in[s]);
+            if (ev_k[s]) (void)hipEventDestroy(ev_k[s]);
+            if (ev_out[s]) (void)hipEventDestroy(ev_out[s]);
+            if (ev_total[s]) (void)hipEventDestroy(ev_total[s]);
+        }
+        if (in) (void)hipStreamDestroy(in);
+        if (k) (void)hipStreamDestroy(k);
+        if (out) (void)hipStreamDestroy(out);
+    }
+};
+
+__global__ __launch_bounds__(256) void unpack_counts_kernel(const uint4 *__restrict__ rec, uint64_t nq,
+                                                            uint32_t *__restrict__ counts, uint8_t *__restrict__ status)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; q < nq; q += stride) {
+        const uint4 r = rec[q];
+        counts[q] = r.y - r.x;
+        status[q] = static_cast<uint8_t>(r.w >> 24);
+    }
+}
+
+void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, WorkerPool &pool)
+{
+    if (!qoff) fail(GDX_ERR_INVALID_ARGUMENT, "qoff is null");
+    if (nq >= 0xffffffffull) fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 queries in one call");
+    std::atomic<bool> bad{false};
+    pool.parallel_range(nq, 1, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++)
+            if (qoff[i + 1] < qoff[i]) bad.store(true);
+    });
+    if (bad.load()) fail(GDX_ERR_INVALID_ARGUMENT, "qoff must be non-decreasing");
+    if (qoff[nq] > qoff[0] && !qbuf) fail(GDX_ERR_INVALID_ARGUMENT, "qbuf is null");
+}
+
+enum class Kind { kIntervals, kCounts, kLocate };
+
+struct Chunk {
+    uint64_t q0 = 0, nq = 0, bytes = 0, total = 0, hit_base = 0;
+};
+
+}  // namespace
+
+// The pipeline behind all three calls.  Intervals: out_a = start, out_b = end.  Counts: out_a = counts.  Locate:
+// out_a = hit offsets (nq + 1), hits / hits_capacity / out_total as in gdx_locate_many; grow_hits (optional) is asked
+// for room when the caller's buffer is managed by the library (gdx_locate_many_alloc).
+int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a,
+                           uint64_t *out_b, uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity,
+                           uint64_t *out_total, const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits) const
+{
+    const Kind kind = static_cast<Kind>(kind_i);
+    WorkerPool pool(host_threads());
+    check_queries(qbuf, qoff, nq, pool);
+    if (out_total) *out_total = 0;
+    if (kind == Kind::kLocate && out_a) out_a[0] = 0;
+    if (nq == 0) return GDX_OK;
+    make_current();
+    const int dev = cfg_.device_id;
+    const QueryOptions qo = query_options();
+    Streams st;
+
+    // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
+    const uint64_t kChunkBytes = g_chunk_bytes.load(), kChunkQueries = g_chunk_queries.load();
+    std::vector<Chunk> chunks;
+    for (uint64_t q0 = 0; q0 < nq;) {
+        uint64_t hi = std::min(nq, q0 + kChunkQueries);
+        if (qoff[hi] - qoff[q0] > kChunkBytes) {
+            const uint64_t *p = std::upper_bound(qoff + q0 + 1, qoff + hi + 1, qoff[q0] + kChunkBytes);
+            hi = static_cast<uint64_t>(p - qoff) - 1;
+            if (hi <= q0) hi = q0 + 1;  // a single query longer than a chunk
+        }
+        Chunk c;
+        c.q0 = q0;
+        c.nq = hi - q0;
+        c.bytes = qoff[hi] - qoff[q0];
+        chunks.push_back(c);
+        q0 = hi;
+    }
+    const size_t n_chunks = chunks.size();
+    uint64_t max_nq = 0, max_bytes = 0;
+    for (const Chunk &c : chunks) {
+        max_nq = std::max(max_nq, c.nq);
+        max_bytes = std::max(max_bytes, c.bytes);
+    }
+    const uint64_t qbuf_cap = div_ceil(max_bytes + 1, 8) * 8 + 8;
+
+    // per-slot buffers (ids: slot * 16 + n)
+    uint8_t *h_in[kSlots], *d_qbuf[kSlots], *h_status[kSlots], *d_status[kSlots];
+    uint64_t *h_qoff[kSlots], *d_qoff[kSlots], *d_off[kSlots];
+    uint32_t *h_a[kSlots], *h_b[kSlots], *d_a[kSlots], *d_b[kSlots];
+    uint4 *d_rec[kSlots];
+    uint64_t *h_total[kSlots];
+    void *d_scan[kSlots];
+    size_t scan_bytes = 0;
+    if (kind == Kind::kLocate) scan_bytes = hit_offsets_rec_temp_bytes(max_nq);
+    for (int s = 0; s < kSlots; s++) {
+        h_in[s] = pinned_buf<uint8_t>(dev, s * 16 + 0, qbuf_cap);
+        h_qoff[s] = pinned_buf<uint64_t>(dev, s * 16 + 1, max_nq + 1);
+        h_a[s] = pinned_buf<uint32_t>(dev, s * 16 + 2, max_nq);
+        h_b[s] = kind == Kind::kIntervals ? pinned_buf<uint32_t>(dev, s * 16 + 3, max_nq) : nullptr;
+        h_status[s] = pinned_buf<uint8_t>(dev, s * 16 + 4, max_nq);
+        h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 1);
+        d_qbuf[s] = device_buf<uint8_t>(dev, s * 16 + 0, qbuf_cap);
+        d_qoff[s] = device_buf<uint64_t>(dev, s * 16 + 1, max_nq + 1);
+        d_a[s] = device_buf<uint32_t>(dev, s * 16 + 2, max_nq);
+        d_b[s] = kind == Kind::kIntervals ? device_buf<uint32_t>(dev, s * 16 + 3, max_nq) : nullptr;
+        d_status[s] = device_buf<uint8_t>(dev, s * 16 + 4, max_nq);
+        d_rec[s] = kind == Kind::kLocate ? device_buf<uint4>(dev, s * 16 + 5, max_nq) : nullptr;
+        d_off[s] = kind == Kind::kLocate ? device_buf<uint64_t>(dev, s * 16 + 6, max_nq + 1) : nullptr;
+        d_scan[s] = kind == Kind::kLocate ? device_buf<uint8_t>(dev, s * 16 + 7, scan_bytes ? scan_bytes : 1) : nullptr;
+    }
+    gdx_hit32_t *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
+    void *d_ws[kSlots] = {};
+
+    std::atomic<bool> any_status{false};
+    uint64_t hit_base = 0;    // hits of the chunks drained so far
+    bool capacity_ok = true;  // locate: the caller's buffer holds everything so far
+
+    auto stage_in = [&](size_t k) {  // user memory -> pinned staging -> device, search (+ scan, total) enqueued
+        const int s = static_cast<int>(k % kSlots);
+        Chunk &c = chunks[k];
+        const uint64_t base = qoff[c.q0];
+        pool.parallel_range(c.bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + base + lo, hi - lo); });
+        pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
+        });
+        const uint64_t padded = div_ceil(c.bytes + 1, 8) * 8;
+        std::memset(h_in[s] + c.bytes, 0, padded - c.bytes);  // 8-byte windows may read past the last query
+        GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
+        GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
+        GDX_HIP(hipEventRecord(st.ev_in[s], st.in));
+        GDX_HIP(hipStreamWaitEvent(st.k, st.ev_in[s], 0));
+        SearchCall call;
+        call.d_qbuf = d_qbuf[s];
+        call.d_qbeg = d_qoff[s];
+        call.d_qend = d_qoff[s] + 1;
+        call.nq = c.nq;
+        if (kind == Kind::kIntervals) {
+            call.d_start = d_a[s];
+            call.d_end = d_b[s];
+            call.d_status = d_status[s];
+            call.mode = 0;
+        } else if (kind == Kind::kCounts) {
+            call.d_count = d_a[s];
+            call.d_status = d_status[s];
+            call.mode = 1;
+        } else {
+            call.d_rec = d_rec[s];
+            call.mode = 1;
+        }
+        launch_search_call(view_, call, st.k, qo);
+        GDX_HIP(hipGetLastError());
+        if (kind == Kind::kLocate) {
+            const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((c.nq + 255) / 256, 4096));
+            hipLaunchKernelGGL(unpack_counts_kernel, dim3(blocks), dim3(256), 0, st.k, d_rec[s], c.nq, d_a[s], d_status[s]);
+            launch_hit_offsets_rec(d_rec[s], c.nq, d_off[s], d_scan[s], scan_bytes, st.k);
+            GDX_HIP(hipMemcpyAsync(h_total[s], d_off[s] + c.nq, sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
+            GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
+        } else {
+            GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
+        }
+    };
+
+    auto stage_mid = [&](size_t k) {  // locate: the chunk's total is known -> locate, then all D2H; else just D2H
+        const int s = static_cast<int>(k % kSlots);
+        Chunk &c = chunks[k];
+        if (kind == Kind::kLocate) {
+            GDX_HIP(hipEventSynchronize(st.ev_total[s]));
+            c.total = *h_total[s];
+            if (c.total) {
+                d_hits[s] = device_buf<gdx_hit32_t>(dev, s * 16 + 8, c.total);
+                h_hits[s] = pinned_buf<gdx_hit32_t>(dev, s * 16 + 6, c.total);
+                d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
+                launch_locate(view_, nullptr, nullptr, c.nq, d_off[s], c.total, d_hits[s], false, d_ws[s], st.k, nullptr,
+                              nullptr, qo, d_rec[s]);
+                GDX_HIP(hipGetLastError());
+            }
+            GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
+        }
+        GDX_HIP(hipStreamWaitEvent(st.out, st.ev_k[s], 0));
+        GDX_HIP(hipMemcpyAsync(h_a[s], d_a[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
+        if (kind == Kind::kIntervals)
+            GDX_HIP(hipMemcpyAsync(h_b[s], d_b[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
+        GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
+        if (kind == Kind::kLocate && c.total)
+            GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * sizeof(gdx_hit32_t), hipMemcpyDeviceToHost, st.out));
+        GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
+    };
+
+    auto stage_out = [&](size_t k) {  // pinned staging -> the caller's arrays, widened
+        const int s = static_cast<int>(k % kSlots);
+        Chunk &c = chunks[k];
+        GDX_HIP(hipEventSynchronize(st.ev_out[s]));
+        const uint32_t *a = h_a[s], *b = h_b[s];
+        const uint8_t *stt = h_status[s];
+        if (kind == Kind::kLocate) {
+            c.hit_base = hit_base;
+            if (out_a) {  // offsets: running sum of the counts (a serial dependency: done per worker in two passes)
+                const unsigned nw = pool.size();
+                std::vector<uint64_t> part(nw + 1, 0);
+                pool.run([&](unsigned w, unsigned n) {
+                    const uint64_t lo = c.nq * w / n, hi = c.nq * (w + 1) / n;
+                    uint64_t sum = 0;
+                    for (uint64_t i = lo; i < hi; i++) sum += a[i];
+                    part[w + 1] = sum;
+                });
+                for (unsigned w = 0; w < nw; w++) part[w + 1] += part[w];
+                pool.run([&](unsigned w, unsigned n) {
+                    const uint64_t lo = c.nq * w / n, hi = c.nq * (w + 1) / n;
+                    uint64_t sum = hit_base + part[w];
+                    for (uint64_t i = lo; i < hi; i++) {
+                        sum += a[i];
+                        out_a[c.q0 + i + 1] = sum;
+                    }
+                });
+            }
+            const uint64_t need = hit_base + c.total;
+            if (grow_hits && need > hits_capacity) hits = (*grow_hits)(need, &hits_capacity);  // at least `need`
+            if (hits && need <= hits_capacity && capacity_ok) {
+                const gdx_hit32_t *src = h_hits[s];
+                gdx_hit_t *dst = hits + hit_base;
+                pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t i = lo; i < hi; i++) {
+                        dst[i].text_id = src[i].text_id;
+                        dst[i].position = src[i].position;
+                    }
+                });
+            } else {
+                capacity_ok = false;
+            }
+            hit_base = need;
+        } else {
+            pool.parallel_range(c.nq, 8, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) {
+                    if (out_a) out_a[c.q0 + i] = a[i];
+                    if (out_b) out_b[c.q0 + i] = b[i];
+                }
+            });
+        }
+        pool.parallel_range(c.nq, 64, [&](uint64_t lo, uint64_t hi) {
+            bool any = false;
+            for (uint64_t i = lo; i < hi; i++) any |= stt[i] != 0;
+            if (out_status) std::memcpy(out_status + c.q0 + lo, stt + lo, hi - lo);
+            if (any) any_status.store(true);
+        });
+    };
+
+    // software pipeline: while the GPU works on chunk k, the host stages chunk k + 1 in and drains chunk k - 1
+    for (size_t step = 0; step < n_chunks + 2; step++) {
+        if (step < n_chunks) stage_in(step);
+        if (step >= 1 && step - 1 < n_chunks) stage_mid(step - 1);
+        if (step >= 2) stage_out(step - 2);
+    }
+    GDX_HIP(hipStreamSynchronize(st.out));
+    if (out_total) *out_total = hit_base;
+    if (kind == Kind::kLocate && hit_base > 0 && !capacity_ok) return GDX_ERR_CAPACITY;
+    return any_status.load() ? GDX_ERR_QUERY_STATUS : GDX_OK;
+}
+
+void set_host_chunking(uint64_t queries, uint64_t bytes)
+{
+    g_chunk_queries.store(queries ? queries : (1ull << 20));
+    g_chunk_bytes.store(bytes ? bytes : (32ull << 20));
+}
+
+int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const
+{
+    if (out_start || out_end) {
+        const int rc = host_pipeline(static_cast<int>(Kind::kIntervals), qbuf, qoff, nq, out_start, out_end, out_status,
+                                     nullptr, 0, nullptr, nullptr);
+        if (out_count && out_start && out_end)
+            for (uint64_t i = 0; i < nq; i++) out_count[i] = out_end[i] - out_start[i];
+        return rc;
+    }
+    return host_pipeline(static_cast<int>(Kind::kCounts), qbuf, qoff, nq, out_count, nullptr, out_status, nullptr, 0,
+                         nullptr, nullptr);
+}
+
+int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                         gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const
+{
+    return host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, hits,
+                         hits ? hits_capacity : 0, out_total, nullptr);
+}
+
+int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                               gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const
+{
+    if (!out_hits) fail(GDX_ERR_INVALID_ARGUMENT, "out_hits is null");
+    *out_hits = nullptr;
+    gdx_hit_t *buf = nullptr;
+    uint64_t cap = 0;
+    const std::function<gdx_hit_t *(uint64_t, uint64_t *)> grow = [&](uint64_t need, uint64_t *new_cap) {
+        const uint64_t want = std::max<uint64_t>(need, cap + cap / 2 + 4096);
+        void *p = std::realloc(buf, want * sizeof(gdx_hit_t));
+        if (!p) {
+            std::free(buf);
+            buf = nullptr;
+            fail(GDX_ERR_DEVICE, "out of host memory for %llu hits", static_cast<unsigned long long>(want));
+        }
+        buf = static_cast<gdx_hit_t *>(p);
+        cap = want;
+        if (new_cap) *new_cap = cap;
+        return buf;
+    };
+    int rc;
+    try {
+        // a first guess from the batch size spares most reallocations (one hit per query is the common shape)
+        grow(nq + nq / 8, nullptr);
+        rc = host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, buf, cap,
+                           out_total, &grow);
+    } catch (...) {
+        std::free(buf);
+        throw;
+    }
+    *out_hits = buf;
+    return rc;
+}
+
+}  // namespace gdx

@@ -69,8 +69,9 @@ struct IndexView {
     uint32_t n;                   // total text length incl. sentinels
     uint32_t n_texts;
     uint32_t sa_rate;
-    uint32_t sa_rate_pow2_mask;   // sa_rate-1 if sa_rate is a power of two, else 0xffffffff
-    uint32_t sa_rate_shift;
+    // division-free "is row i sampled, and which sample": sa_rate = 2^sa_rot * d with d odd, sa_inv = d^-1 mod 2^32,
+    // sa_limit = (2^32 - 1) / sa_rate; see sampled_slot()
+    uint32_t sa_inv, sa_rot, sa_limit;
     int32_t sigma;
     int32_t nbits;
     int32_t n_searchable;
@@ -454,6 +455,21 @@ struct GenericTable {
         return c;
     }
 };
+
+// sampled_suffix_array.rs:118 `i % sampling_rate == 0` and :133 `i / sampling_rate` in three instructions for any
+// rate: q = rotr(i * sa_inv, sa_rot) equals i / sa_rate when sa_rate divides i and exceeds sa_limit otherwise (the
+// divisibility test by multiplication with the modular inverse of the odd part; the rotation checks the power of two)
+__device__ __forceinline__ bool sampled_slot(const IndexView &ix, uint32_t i, uint32_t &slot)
+{
+    const uint32_t m = i * ix.sa_inv;
+    slot = __builtin_amdgcn_alignbit(m, m, ix.sa_rot);
+    return slot <= ix.sa_limit;
+}
+__device__ __forceinline__ bool is_sampled(const IndexView &ix, uint32_t i)
+{
+    uint32_t slot;
+    return sampled_slot(ix, i, slot);
+}
 
 // lower_bound over a small sorted u32 array (text ids, border keys)
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key)

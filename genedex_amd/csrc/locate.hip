@@ -66,12 +66,8 @@ __device__ __forceinline__ uint32_t walk_to_sample(const IndexView &ix, const ui
     steps = 0;
     for (;;) {
         // :118 while i % sampling_rate != 0
-        const bool sampled =
-            ix.sa_rate_pow2_mask != 0xffffffffu ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
-        if (sampled) {
-            const uint32_t slot = ix.sa_rate_pow2_mask != 0xffffffffu ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate);
-            return ix.sa_samples[slot] + steps;  // :133-136
-        }
+        uint32_t slot;
+        if (sampled_slot(ix, i, slot)) return ix.sa_samples[slot] + steps;  // :133-136
         uint32_t r;
         const uint32_t c = Table::symbol_and_rank(ix, i, r);
         if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
@@ -181,7 +177,6 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
     if (ix.n_texts <= kLdsTexts)
         for (uint32_t i = threadIdx.x; i < ix.n_texts; i += kBlock) s_sentinels[i] = ix.sentinels[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
     uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
     const uint64_t n_chunks = (total + kLocateChunk - 1) / kLocateChunk;
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -225,9 +220,8 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                     }
                 }
             }
-            const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
-            if (sampled) {  // sampled_suffix_array.rs:133-136 with zero steps
-                const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
+            uint32_t slot;
+            if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
                 store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
             } else {
                 // (a hinted row that is not sampled comes from the search's lazy tail: the walk starts there)
@@ -273,10 +267,10 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 uint32_t got = 0;  // first level whose target is a sampled row
 #pragma unroll
                 for (uint32_t j = 5; j >= 1; j--)
-                    if (j <= reach && (pow2 ? ((t[j - 1] & ix.sa_rate_pow2_mask) == 0) : (t[j - 1] % ix.sa_rate == 0))) got = j;
+                    if (j <= reach && is_sampled(ix, t[j - 1])) got = j;
                 if (got != 0u) {
-                    const uint32_t tr = t[got - 1u];
-                    const uint32_t slot = pow2 ? (tr >> ix.sa_rate_shift) : (tr / ix.sa_rate);
+                    uint32_t slot;
+                    (void)sampled_slot(ix, t[got - 1u], slot);
                     steps += got * kJumpSymbols;
                     store_hit<kWide>(ix, ix.sa_samples[slot] + steps - back, hits_out, base + idx, sentinels);
                     walk_steps += steps;
@@ -299,9 +293,8 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                 } else {
                     row = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
                     steps++;
-                    const bool sampled = pow2 ? ((row & ix.sa_rate_pow2_mask) == 0) : (row % ix.sa_rate == 0);
-                    if (sampled) {
-                        const uint32_t slot = pow2 ? (row >> ix.sa_rate_shift) : (row / ix.sa_rate);
+                    uint32_t slot;
+                    if (sampled_slot(ix, row, slot)) {
                         store_hit<kWide>(ix, ix.sa_samples[slot] + steps - back, hits_out, base + idx, sentinels);
                         walk_steps += steps;
                         have = false;
@@ -328,7 +321,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __syncthreads();
     const uint32_t sub = threadIdx.x & 7u;
     const bool writer = sub == 0;
-    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
     uint32_t walk_steps = 0;
     for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; h < total;
@@ -337,9 +329,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);
         uint32_t steps = 0, pos;
         for (;;) {
-            const bool sampled = pow2 ? ((i & ix.sa_rate_pow2_mask) == 0) : (i % ix.sa_rate == 0);
-            if (sampled) {  // sampled_suffix_array.rs:133-136
-                pos = ix.sa_samples[pow2 ? (i >> ix.sa_rate_shift) : (i / ix.sa_rate)] + steps;
+            uint32_t slot;
+            if (sampled_slot(ix, i, slot)) {  // sampled_suffix_array.rs:133-136
+                pos = ix.sa_samples[slot] + steps;
                 break;
             }
             const u32x4 c = ix.pair_lines[(static_cast<uint64_t>(i >> kPairLineShift) << 3) + sub];
@@ -369,7 +361,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t mask = PairTable::low_mask(i, sub);  // chunk index == lane for 8 lanes
             const bool own1 = (sub >> 1) == (c1 - 1u);
             const uint32_t i1 = oct_sum(__popc(m1 & mask) + (own1 ? ((c.y >> 16) << ((sub & 1u) * 16u)) : 0u));
-            const bool sampled1 = pow2 ? ((i1 & ix.sa_rate_pow2_mask) == 0) : (i1 % ix.sa_rate == 0);
+            const bool sampled1 = is_sampled(ix, i1);
             if (sampled1 || c0 - 1u >= 4u) {
                 i = i1;
                 steps++;

@@ -57,6 +57,10 @@ struct QueryWindow {
 // owner with one ds_bpermute (the LDS crossbar, no LDS memory).  Translating every word in every lane -- which is
 // what a plain per-lane window does -- made the kernel VALU-bound: PMC showed 880 VALU instructions per wavefront
 // and 16 queries, 85 % VALU issue utilisation, and no gain from a quarter fewer DRAM requests.
+__device__ __forceinline__ bool all_dna(uint32_t x);
+__device__ __forceinline__ uint32_t to_2bit(uint32_t x);
+constexpr uint32_t kNoCode = 0x10000u;  // compares unequal to every 16-bit entry code
+
 template <int kGroup>
 struct SpanWindow {
     static constexpr int kWordsPerLane = 8 / kGroup;
@@ -64,6 +68,8 @@ struct SpanWindow {
     uint32_t off0;         // byte offset of the query inside base[0]
     uint32_t top_w;        // span word k = query word top_w - k, k = 0 .. 7 (words below 0 read as 0)
     uint32_t w0, w1;       // this lane's translated span words: k = sub * kWordsPerLane (and + 1)
+    uint32_t p;            // the same words as 2-bit codes (dense - 1), 16 bits each: w0 in the low half, w1 above
+    uint32_t valid8;       // bit k: all eight symbols of span word k are dense codes 1..4 (the same in the group)
 
     static __device__ __forceinline__ uint32_t translate(uint64_t w, const uint8_t *s_dense)
     {
@@ -77,7 +83,7 @@ struct SpanWindow {
         base = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
         off0 = static_cast<uint32_t>(begin & 7u);
         top_w = 0;
-        w0 = w1 = 0;
+        w0 = w1 = p = valid8 = 0;
     }
     // positions the span so that its first word holds symbol rem - 1 (rem >= 1); group-uniform
     __device__ __forceinline__ void load(uint32_t rem, const uint8_t *s_dense)
@@ -99,6 +105,37 @@ struct SpanWindow {
         }
         w0 = translate(r0, s_dense);
         if (kWordsPerLane == 2) w1 = translate(r1, s_dense);
+        // 2-bit form and the group's validity mask (an OR over the group's lanes by DPP)
+        p = to_2bit(w0);
+        uint32_t m = all_dna(w0) ? 1u : 0u;
+        if (kWordsPerLane == 2) {
+            p |= to_2bit(w1) << 16;
+            m |= all_dna(w1) ? 2u : 0u;
+        }
+        m <<= sub * kWordsPerLane;
+        m |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0xB1, 0xF, 0xF, true));
+        m |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x4E, 0xF, 0xF, true));
+        if (kGroup == 8) m |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x141, 0xF, 0xF, true));
+        valid8 = m;
+    }
+    // 2-bit codes of span word k (16 bits)
+    __device__ __forceinline__ uint32_t word2(uint32_t k) const
+    {
+        const uint32_t owner = (threadIdx.x & 63u & ~(kGroup - 1u)) + k / kWordsPerLane;
+        const uint32_t v = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(owner << 2), static_cast<int>(p)));
+        return (kWordsPerLane == 2 && (k & 1u)) ? v >> 16 : v & 0xffffu;
+    }
+    // 2-bit codes of the symbols r - 1 .. r - 8 (r >= 8, covered by the span), bits 15:14 = symbol r - 1: the form the
+    // jump entries store; kNoCode when a word they touch holds a symbol outside 1..4 (conservative: the caller then
+    // looks at the nibbles)
+    __device__ __forceinline__ uint32_t level(uint32_t r) const
+    {
+        const uint32_t b = off0 + r - 1u, k = top_w - (b >> 3);
+        const uint32_t s = (b & 7u) + 1u;
+        const uint32_t k1 = k + 1u > 7u ? 7u : k + 1u;
+        const uint32_t need = (1u << k) | (s < 8u ? (1u << k1) : 0u);
+        const uint32_t x = (word2(k) << 16) | word2(k1);
+        return (valid8 & need) == need ? ((x >> (2u * s)) & 0xffffu) : kNoCode;
     }
     // translated span word k (0 .. 7), k uniform in the group
     __device__ __forceinline__ uint32_t word(uint32_t k) const
@@ -353,8 +390,6 @@ __device__ __forceinline__ uint32_t to_2bit(uint32_t x)
     return (y & 0xffu) | ((y >> 8) & 0xff00u);
 }
 
-constexpr uint32_t kNoCode = 0x10000u;  // compares unequal to every 16-bit entry code
-
 // Backward search on pair lines, the jump table and the top table: kGroup = 4 or 8 lanes per
 // query, every loop iteration is one round of loads for the whole wavefront.
 // kMode 0 (intervals): out_start / out_end are the reference's half-open SA interval, bit for bit, also for empty
@@ -391,13 +426,18 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     __shared__ uint2 s_hint[kBlock / kGroup];  // locate hint of the query each group is searching
     __shared__ uint32_t s_cnt[kLenBuckets];
     __shared__ uint32_t s_minmax[2];
+    // kMode 2: the cursors of the block's current range that stay alive, appended to ca.active_out with ONE global
+    // atomic per range (an atomic per wavefront serialised the whole chip on one address: 27 ms per call at 34 M
+    // live cursors)
+    __shared__ uint32_t s_alive[kMode == 2 ? kMaxRange : 1];
+    __shared__ uint32_t s_nalive, s_alive_base;
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
+    if (threadIdx.x == 0) s_nalive = 0;
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
     const bool writer = (threadIdx.x % kGroup) == 0;
-    const bool pow2 = ix.sa_rate_pow2_mask != 0xffffffffu;
     const bool hinting = out_hint != nullptr || out_rec != nullptr;
     uint32_t lf_steps = 0;
     unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
@@ -441,9 +481,22 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             const uint32_t lo0 = lo, hi0 = hi;
             rem = static_cast<uint32_t>(len);
             win.load(rem, s_dense);
-            const uint32_t a = win.code8(rem, s_dense);
-            const uint32_t b = ix.top_depth > 8u ? win.code8(rem - 8u, s_dense) : 0u;
-            topped = top_lookup(ix, a, b, lo, hi);
+            // the index straight from the span's 2-bit codes when 16 symbols are there and clean, else from nibbles
+            uint32_t l1 = kNoCode, l2 = kNoCode;
+            if (rem >= 16u) {
+                l1 = win.level(rem);
+                l2 = win.level(rem - 8u);
+            }
+            if (l1 != kNoCode && l2 != kNoCode) {
+                const uint2 e = ix.top[((l1 << 16) | l2) >> (32u - 2u * ix.top_depth)];
+                lo = e.x;
+                hi = e.y;
+                topped = true;
+            } else {
+                const uint32_t a = win.code8(rem, s_dense);
+                const uint32_t b = ix.top_depth > 8u ? win.code8(rem - 8u, s_dense) : 0u;
+                topped = top_lookup(ix, a, b, lo, hi);
+            }
             if (topped) {
                 rem -= ix.top_depth;
                 if (kStats) lf_steps += ix.top_depth;
@@ -492,49 +545,55 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         const uint32_t sub = threadIdx.x & (kGroup - 1u);
         while (rem > 0 && lo != hi) {
             if (kStats) iters++;
-            const uint32_t code = win.code8(rem, s_dense);
-            const uint32_t c1 = code >> 28;
-            if (c1 == 0) {  // alphabet.rs:195-198
-                status = GDX_Q_INVALID_SYMBOL;
-                if (kMode != 2) lo = hi = 0;
-                break;
-            }
-            if (c1 > 4u) {  // a valid symbol outside 1..4 (N): rank lines, rare
-                uint32_t rlo, rhi;
-                QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
-                const uint32_t cc = s_count[c1];
-                lo = cc + rlo;
-                hi = cc + rhi;
-                rem--;
-                if (kStats) lf_steps++;
-                continue;
-            }
-            const uint32_t c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
+            if (!win.covers(rem)) win.load(rem, s_dense);
             // Intervals of at most one row per lane of the group jump: lane j reads the entry of row lo + j.  The
             // rows whose stored symbols equal the query's next 8, 16, ... are exactly those that survive these LF
             // steps, and LF keeps their order, so they map onto [min target, max target + 1).
-            const bool jumping = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols && all_dna(code);
-            // 2-bit codes of the query's next 8-symbol groups (level j + 1 <-> symbols rem - 8j - 1 .. rem - 8j - 8),
-            // read straight from the query (the window stays; it is re-initialised after a jump of more than 8
-            // symbols), packed like the entries store them: qa = level 1 | level 2 << 16, qb = level 3,
-            // qc = level 4 | level 5 << 16; qok bit j = level j + 1 lies inside the query and is all symbols 1..4
-            uint32_t qa = 0, qb = 0, qc = 0, qok = 0;
+            const bool narrow = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols;
+            // level codes of the query, packed like the entries store them: qa = level 1 | level 2 << 16, qb = level 3,
+            // qc = level 4 | level 5 << 16 (level j + 1 <-> symbols rem - 8j - 1 .. rem - 8j - 8); qok bit j = level
+            // j + 1 lies inside the query and is all symbols 1..4.  They come from the span's 2-bit words; only when
+            // those cannot vouch for level 1 (a symbol outside 1..4 somewhere in its words) are the nibbles looked at.
+            uint32_t qa = narrow ? win.level(rem) : kNoCode;
+            bool jumping = qa != kNoCode;
+            uint32_t c1 = 1u, c2 = 0u;
+            if (!jumping) {
+                const uint32_t code = win.at(rem);
+                c1 = code >> 28;
+                if (c1 == 0) {  // alphabet.rs:195-198
+                    status = GDX_Q_INVALID_SYMBOL;
+                    if (kMode != 2) lo = hi = 0;
+                    break;
+                }
+                if (c1 > 4u) {  // a valid symbol outside 1..4 (N): rank lines, rare
+                    uint32_t rlo, rhi;
+                    QuadLineTable::rank2(ix, c1, lo, hi, rlo, rhi);
+                    const uint32_t cc = s_count[c1];
+                    lo = cc + rlo;
+                    hi = cc + rhi;
+                    rem--;
+                    if (kStats) lf_steps++;
+                    continue;
+                }
+                c2 = rem >= 2u ? ((code >> 24) & 15u) : 0u;
+                jumping = narrow && all_dna(code);
+                if (jumping) qa = to_2bit(code);
+            }
+            uint32_t qb = 0, qc = 0, qok = 0;
             uint32_t tail16 = kNoCode;  // kMode 1: codes of the last rem % 8 symbols, in the top bits
             if (jumping) {
                 // every symbol the levels (and the lazy tail) look at must be inside the span: after a span load
                 // at rem they are (40 symbols and their alignment are at most seven words)
                 const uint32_t n_lv = rem >> 3 < static_cast<uint32_t>(kLevels) ? rem >> 3 : static_cast<uint32_t>(kLevels);
-                const uint32_t r_low = (kMode == 1 && (rem >> 3) < static_cast<uint32_t>(kCodes)) ? 8u
-                                                                                                 : rem - (n_lv - 1u) * kJumpSymbols;
+                const bool tail = kMode == 1 && (rem & 7u) != 0u && (rem >> 3) < static_cast<uint32_t>(kCodes);
+                const uint32_t r_low = tail ? 8u : rem - (n_lv - 1u) * kJumpSymbols;
                 if (!win.covers(r_low)) win.load(rem, s_dense);
-                qa = to_2bit(code);
                 qok = 1u;
 #pragma unroll
                 for (int j = 1; j < kLevels; j++) {
                     if (rem >= (j + 1u) * kJumpSymbols) {
-                        const uint32_t cj = win.at(rem - j * kJumpSymbols);
-                        if (all_dna(cj)) {
-                            const uint32_t v = to_2bit(cj);
+                        const uint32_t v = win.level(rem - j * kJumpSymbols);
+                        if (v != kNoCode) {
                             if (j == 1) qa |= v << 16;
                             if (j == 2) qb = v;
                             if (j == 3) qc = v;
@@ -543,12 +602,10 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         }
                     }
                 }
-                if (kMode == 1 && (rem & 7u) != 0u && (rem >> 3) < static_cast<uint32_t>(kCodes)) {
-                    // the query's first rem % 8 symbols as the top nibbles (the lower ones set to a valid code)
-                    const uint32_t tl = rem & 7u;
-                    const uint32_t m = 0xffffffffu << (4u * (8u - tl));
-                    const uint32_t cj = ((win.at(8u) << (4u * (8u - tl))) & m) | (0x11111111u & ~m);
-                    if (all_dna(cj)) tail16 = to_2bit(cj);
+                if (tail) {
+                    // the query's first rem % 8 symbols in the top bits; level(8) = symbols 7 .. 0
+                    const uint32_t v = win.level(8u);
+                    if (v != kNoCode) tail16 = (v << (2u * (8u - (rem & 7u)))) & 0xffffu;
                 }
             }
             const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
@@ -601,7 +658,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     // locate hint, candidate 1: the one-row interval this jump starts from (see below)
                     uint32_t hr = 0xffffffffu, ho = 0;
                     const bool want_hint = hinting && !(status >> 31);  // one hint per query is enough
-                    if (want_hint && hi - lo == 1u && (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u))) {
+                    if (want_hint && hi - lo == 1u && is_sampled(ix, lo)) {
                         hr = lo;
                         ho = rem;
                     }
@@ -623,7 +680,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         // suffix of row lo starts rem symbols after p (rem are still to be matched to its left), so
                         // p = SA[lo] - rem; the rows this jump passed through after 8, 16, ... steps qualify too,
                         // that many symbols earlier.  If one of them is a sampled row, locate needs no walk.
-                        if (pow2 ? ((lo & ix.sa_rate_pow2_mask) == 0u) : (lo % ix.sa_rate == 0u)) {
+                        if (is_sampled(ix, lo)) {
                             hr = lo;
                             ho = rem;
                         }
@@ -632,7 +689,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                             if (hr == 0xffffffffu && best > static_cast<uint32_t>(j)) {
                                 const uint32_t tj = j == 1 ? e0.x : (j == 2 ? e0.y : (j == 3 ? e1.x : e1.y));  // t_j
                                 const uint32_t mid = group_min<kGroup>(mine ? tj : 0xffffffffu);
-                                if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
+                                if (is_sampled(ix, mid)) {
                                     hr = mid;
                                     ho = rem + (best - j) * kJumpSymbols;
                                 }
@@ -708,7 +765,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
 #pragma unroll
                         for (int k = 0; k < kChunks; k++) pm += PairTable::single_partial(a[k], sub + k * kGroup, c1, nx1, lo);
                         const uint32_t mid = group_sum<kGroup>(pm);
-                        if (pow2 ? ((mid & ix.sa_rate_pow2_mask) == 0u) : (mid % ix.sa_rate == 0u)) {
+                        if (is_sampled(ix, mid)) {
                             if (writer) s_hint[threadIdx.x / kGroup] = make_uint2(mid, rem - 1u);
                             status |= 0x80000000u;
                         }
@@ -755,8 +812,8 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
             if (out_hint) out_hint[q] = hv;
         }
-        if (kMode == 2 && ca.active_out != nullptr)  // compaction: the cursors that can still be extended
-            compact_alive(writer && lo != hi && (status & 0xffu) == 0u, static_cast<uint32_t>(q), ca);
+        if (kMode == 2 && ca.active_out != nullptr && writer && lo != hi && (status & 0xffu) == 0u)
+            s_alive[atomicAdd(&s_nalive, 1u)] = static_cast<uint32_t>(q);  // the cursors that can still be extended
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;
             for (int off = 32; off > 0; off >>= 1) {
@@ -766,6 +823,15 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             group_iters += iters;
             wave_slots += wave_max;
         }
+    }
+    if (kMode == 2 && ca.active_out != nullptr) {  // flush the range's live cursors: one atomic, coalesced stores
+        __syncthreads();
+        const uint32_t n_alive = s_nalive;
+        if (threadIdx.x == 0 && n_alive != 0u) s_alive_base = atomicAdd(ca.n_active_out, n_alive);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_alive; i += kBlock) ca.active_out[s_alive_base + i] = s_alive[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nalive = 0;
     }
     }  // ranges
     if (kStats && step_stats && writer) {

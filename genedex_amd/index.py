@@ -250,6 +250,25 @@ class FmIndex:
         hits = hits[: total.value]
         return off, hits[:, 0].copy(), hits[:, 1].copy(), status
 
+    def locate_alloc_raw(self, qbuf, qoff, strict=True):
+        """gdx_locate_many_alloc (one pass) -> (hit_offsets, text_ids, positions, status)"""
+        nq = qoff.size - 1
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        total = C.c_uint64(0)
+        ptr = C.POINTER(_lib.HitStruct)()
+        st = self._lib.gdx_locate_many_alloc(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(off, u64p), C.byref(ptr),
+                                             C.byref(total), _p(status, u8p))
+        try:
+            _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+            n = total.value
+            hits = np.ctypeslib.as_array(C.cast(ptr, u64p), shape=(max(n, 1) * 2,))[: 2 * n].reshape(n, 2).copy() \
+                if n else np.zeros((0, 2), dtype=np.uint64)
+        finally:
+            if ptr:
+                self._lib.gdx_free_hits(ptr)
+        return off, hits[:, 0].copy(), hits[:, 1].copy(), status
+
     def locate_intervals_raw(self, starts, ends):
         starts = np.ascontiguousarray(starts, dtype=np.uint64)
         ends = np.ascontiguousarray(ends, dtype=np.uint64)

@@ -234,6 +234,16 @@ int gdx_locate_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *
                     uint64_t *out_hit_offsets /*nq+1*/, gdx_hit_t *hits, uint64_t hits_capacity,
                     uint64_t *out_total, uint8_t *out_status);
 
+/* The same in ONE pass: the library allocates the hit array (*out_hits, `*out_total` entries; release it with
+ * gdx_free_hits).  gdx_locate_many with a caller-owned buffer needs a sizing call first, i.e. searches twice. */
+int gdx_locate_many_alloc(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                          uint64_t *out_hit_offsets /*nq+1*/, gdx_hit_t **out_hits, uint64_t *out_total,
+                          uint8_t *out_status);
+void gdx_free_hits(gdx_hit_t *hits);
+/* All three host-pointer query calls above run as a pipeline over chunks of the batch (copy-in, kernels and copy-out
+ * of neighbouring chunks overlap, pinned staging filled by a few host threads; GDX_HOST_THREADS overrides their
+ * number), so a call costs about max(PCIe in, PCIe out, kernels) rather than their sum. */
+
 /* ---------------------------------------------------------------------------------------
  * batched cursor API   (Cursor, cursor.rs:16-73; the reference has only the scalar form,
  * ROADMAP.md:33 lists the batched one as future work)                                     */

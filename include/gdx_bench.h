@@ -43,6 +43,10 @@ int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uin
  * All variants return identical results; the switch exists for A/B measurements and parity tests. */
 int gdx_debug_set_search_variant(int variant);
 
+/* chunk size of the pipeline behind the host-pointer query calls (queries and query bytes per chunk; 0 = default
+ * 2^20 queries / 32 MB): tests force many small chunks through it */
+int gdx_debug_set_host_chunking(uint64_t queries, uint64_t bytes);
+
 /* streaming copy of `bytes` (multiple of 16): the "measured HBM bandwidth" denominator */
 int gdx_bench_stream_copy(void *d_dst, const void *d_src, uint64_t bytes, void *stream);
 /* streaming read of `bytes` (multiple of 16) */

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from genedex_amd import alphabet as alph
+from helpers import random_texts
 from oracle.oracle import OracleIndex, pack_queries
 
 pytestmark = pytest.mark.gpu
@@ -165,3 +166,58 @@ def test_save_and_load_round_trip(setup, tmp_path):
     for name in ("short.gdx", "junk.gdx", "missing.gdx"):
         with pytest.raises(GdxError):
             FmIndex.load_from_file(tmp_path / name, alph.ascii_dna_with_n())
+
+
+@pytest.mark.parametrize("chunk_queries,chunk_bytes", [(777, 0), (0, 4096), (1, 0)])
+def test_host_calls_are_chunk_invariant(chunk_queries, chunk_bytes):
+    """The host-pointer calls run as a pipeline over chunks (host_api.hip); chunk boundaries must be invisible:
+    same counts, intervals, hit offsets and hits as the oracle whatever the chunk size, including a query longer
+    than a chunk, empty queries, the sizing call, a too-small buffer and the allocating variant."""
+    from genedex_amd import GdxError, _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=30000, symbols=b"ACGT")
+    from genedex_amd import FmIndexConfig
+
+    g = FmIndexConfig("u32").suffix_array_sampling_rate(3).lookup_table_depth(2).construct_index(texts, a)
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=3, lookup_depth=2, width=32)
+    qs = [texts[0][10:10 + int(n)] for n in rng.integers(0, 90, 5000)] + [b"", texts[0][5:9000], b"ACGTTTGAC", b""]
+    qs += [bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(n))) for n in rng.integers(0, 40, 3000)]
+    if chunk_queries == 1:
+        qs = qs[:300] + qs[-300:]
+    qbuf, qoff = pack_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    co, ct, cp = c.locate_many(qs)
+    lib.gdx_debug_set_host_chunking(chunk_queries, chunk_bytes)
+    try:
+        s, e, st = g.cursors_raw(qbuf, qoff)
+        assert s.tolist() == cs.tolist() and e.tolist() == ce.tolist() and not st.any()
+        counts, _ = g.count_raw(qbuf, qoff)
+        assert counts.tolist() == (ce - cs).tolist()
+        off, t, p, _ = g.locate_raw(qbuf, qoff)  # sizing call + fill
+        assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+        off2, t2, p2, _ = g.locate_alloc_raw(qbuf, qoff)  # one pass, library-owned buffer
+        assert off2.tolist() == co.tolist() and t2.tolist() == ct.tolist() and p2.tolist() == cp.tolist()
+        # a buffer that is too small: GDX_ERR_CAPACITY, the required size and the offsets are still reported
+        nq = qoff.size - 1
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        small = np.zeros((int(co[-1]) // 2, 2), dtype=np.uint64)
+        total = C.c_uint64(0)
+        rc = lib.gdx_locate_many(g._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                 offs.ctypes.data_as(_lib.u64p), small.ctypes.data_as(C.POINTER(_lib.HitStruct)),
+                                 small.shape[0], C.byref(total), None)
+        assert rc == _lib.GDX_ERR_CAPACITY and total.value == int(co[-1]) and offs.tolist() == co.tolist()
+        # a bad symbol somewhere in the middle: its status alone is set, everything else stays valid
+        bad = list(qs)
+        bad[len(bad) // 2] = b"AC?T"
+        bb, bo = pack_queries(bad)
+        with pytest.raises(GdxError):
+            g.count_raw(bb, bo)
+        counts_b, st_b = g.count_raw(bb, bo, strict=False)
+        assert st_b[len(bad) // 2] == _lib.GDX_Q_INVALID_SYMBOL and int(st_b.sum()) == _lib.GDX_Q_INVALID_SYMBOL
+        keep = np.arange(nq) != len(bad) // 2
+        assert counts_b[keep].tolist() == (ce - cs)[keep].tolist()
+    finally:
+        lib.gdx_debug_set_host_chunking(0, 0)
