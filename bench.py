@@ -897,11 +897,16 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
         _lib.check(lib.gdx_locate_many_alloc(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
                                              offs.ctypes.data_as(u64p), C.byref(ptr), C.byref(total),
                                              status.ctypes.data_as(u8p)))
-        if last.get("ptr"):
-            lib.gdx_free_hits(last["ptr"])
         last["ptr"] = ptr
 
-    t_locate = best_of(locate_call)
+    t_locate = None
+    for _ in range(3):  # (the first call also sizes the pinned staging buffers)
+        if last.get("ptr"):
+            lib.gdx_free_hits(last.pop("ptr"))
+        t0 = time.perf_counter()
+        locate_call()
+        dt = time.perf_counter() - t0
+        t_locate = dt if t_locate is None or dt < t_locate else t_locate
     same_total = total.value == total_hits and int(offs[-1]) == total_hits
     if last.get("ptr"):
         lib.gdx_free_hits(last["ptr"])

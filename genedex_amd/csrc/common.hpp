@@ -3,31 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
-#include <cstdarg>
 #include <cstdint>
-#include <cstdio>
-#include <stdexcept>
 #include <string>
 
 #include "../../include/gdx.h"
+#include "errors.hpp"
 
 namespace gdx {
-
-// error carried through the host code and turned into a gdx_status at the C ABI
-struct Error : std::runtime_error {
-    int status;
-    Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
-};
-
-[[noreturn]] inline void fail(int status, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    throw Error(status, buf);
-}
 
 #define GDX_HIP(expr)                                                                          \
     do {                                                                                       \

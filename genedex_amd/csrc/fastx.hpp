@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "common.hpp"
+#include "errors.hpp"
 
 namespace gdx {
 

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "index_file.hpp"
 #include "kernels.hpp"
 
 namespace gdx {
@@ -1391,46 +1392,13 @@ int FmIndex::symbol_at_many(const uint64_t *idx, uint64_t m, uint8_t *out) const
 // =============================================================================================
 // persistence: header + the reference's logical arrays
 
-namespace {
-
-constexpr char kMagic[8] = {'G', 'D', 'X', 'I', 'D', 'X', '0', '1'};
-
-struct FileHeader {
-    char magic[8];
-    uint64_t n, n_texts, sa_rate, n_plane_words, n_samples;
-    int32_t sigma, n_searchable, lookup_depth, index_width;
-    uint8_t io_to_dense[256];
-};
-
-struct File {
-    FILE *f;
-    explicit File(const char *path, const char *mode) : f(std::fopen(path, mode))
-    {
-        if (!f) fail(GDX_ERR_INVALID_ARGUMENT, "cannot open %s", path);
-    }
-    ~File()
-    {
-        if (f) std::fclose(f);
-    }
-    void write(const void *p, size_t bytes)
-    {
-        if (bytes && std::fwrite(p, 1, bytes, f) != bytes) fail(GDX_ERR_DEVICE, "short write");
-    }
-    void read(void *p, size_t bytes)
-    {
-        if (bytes && std::fread(p, 1, bytes, f) != bytes) fail(GDX_ERR_INVALID_ARGUMENT, "index file is truncated");
-    }
-};
-
-}  // namespace
-
 void FmIndex::save(const char *path) const
 {
     if (!path) fail(GDX_ERR_INVALID_ARGUMENT, "path is null");
     const int nbits = view_.nbits;
     const uint64_t len = n_ + 1, n_blocks = div_ceil(len, 64);
     FileHeader h{};
-    std::memcpy(h.magic, kMagic, 8);
+    std::memcpy(h.magic, kIndexFileMagic, 8);
     h.n = n_;
     h.n_texts = n_texts_;
     h.sa_rate = cfg_.sa_rate;
@@ -1446,7 +1414,7 @@ void FmIndex::save(const char *path) const
     std::vector<uint32_t> sbo(div_ceil(len, 65536) * cfg_.sigma), samples(h.n_samples);
     export_condensed_table(planes.data(), bo.data(), sbo.data());
     export_sa_samples(samples.data());
-    File out(path, "wb");
+    IndexFile out(path, "wb");
     out.write(&h, sizeof(h));
     out.write(count_host_.data(), count_host_.size() * sizeof(uint64_t));
     out.write(sentinels_host_.data(), n_texts_ * sizeof(uint64_t));
@@ -1459,26 +1427,8 @@ void FmIndex::save(const char *path) const
 std::unique_ptr<FmIndex> FmIndex::load(const char *path, int device_id, const BuildOptions &build)
 {
     if (!path) fail(GDX_ERR_INVALID_ARGUMENT, "path is null");
-    File in(path, "rb");
-    FileHeader h;
-    in.read(&h, sizeof(h));
-    if (std::memcmp(h.magic, kMagic, 8) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "%s is not a gdx index file", path);
-    if (h.sigma < 2 || h.sigma > 256 || h.n_texts == 0 || h.n_texts > h.n || h.n > 0xffffffffull || h.sa_rate == 0 ||
-        h.sa_rate > 0xffffffffull || h.n_samples != div_ceil(h.n, h.sa_rate) ||
-        h.n_plane_words != div_ceil(h.n + 1, 64) * static_cast<uint64_t>(ilog2_ceil(static_cast<uint64_t>(h.sigma))))
-        fail(GDX_ERR_INVALID_ARGUMENT, "index file header is inconsistent");
-    {
-        // the payload sizes follow from the header: compare with the file before allocating anything
-        const uint64_t payload = (static_cast<uint64_t>(h.sigma) + 1 + 3 * h.n_texts + h.n_plane_words) * sizeof(uint64_t) +
-                                 h.n_samples * sizeof(uint32_t);
-        const long at = std::ftell(in.f);
-        if (at < 0 || std::fseek(in.f, 0, SEEK_END) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "cannot seek in %s", path);
-        const long size = std::ftell(in.f);
-        if (size < 0 || std::fseek(in.f, at, SEEK_SET) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "cannot seek in %s", path);
-        if (static_cast<uint64_t>(size - at) != payload)
-            fail(GDX_ERR_INVALID_ARGUMENT, "index file is truncated or has trailing bytes (%lld payload bytes, header says %llu)",
-                 static_cast<long long>(size - at), static_cast<unsigned long long>(payload));
-    }
+    IndexFile in(path, "rb");
+    const FileHeader h = read_index_header(in, path);
     IndexConfig cfg;
     std::memcpy(cfg.io_to_dense, h.io_to_dense, 256);
     cfg.sigma = h.sigma;

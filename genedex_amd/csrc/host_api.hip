@@ -18,6 +18,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sys/mman.h>
+
 #include "fm_index.hpp"
 #include "kernels.hpp"
 
@@ -483,16 +485,24 @@ int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64
     *out_hits = nullptr;
     gdx_hit_t *buf = nullptr;
     uint64_t cap = 0;
+    // The hit array is large (16 bytes per hit) and written exactly once: 2 MB alignment + MADV_HUGEPAGE keeps the
+    // first-touch page faults (one per 4 KB otherwise, ~100 ms per GB single-threaded) out of the pipeline.
     const std::function<gdx_hit_t *(uint64_t, uint64_t *)> grow = [&](uint64_t need, uint64_t *new_cap) {
         const uint64_t want = std::max<uint64_t>(need, cap + cap / 2 + 4096);
-        void *p = std::realloc(buf, want * sizeof(gdx_hit_t));
-        if (!p) {
+        const size_t bytes = (want * sizeof(gdx_hit_t) + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+        void *p = nullptr;
+        if (posix_memalign(&p, 2u << 20, bytes) != 0 || !p) {
             std::free(buf);
             buf = nullptr;
             fail(GDX_ERR_DEVICE, "out of host memory for %llu hits", static_cast<unsigned long long>(want));
         }
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        if (buf) {  // rare: the first guess (one hit per query and a bit) was too small
+            std::memcpy(p, buf, cap * sizeof(gdx_hit_t));
+            std::free(buf);
+        }
         buf = static_cast<gdx_hit_t *>(p);
-        cap = want;
+        cap = bytes / sizeof(gdx_hit_t);
         if (new_cap) *new_cap = cap;
         return buf;
     };

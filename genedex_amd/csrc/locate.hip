@@ -127,12 +127,14 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
 // first[c] = the query that owns hit slot c * chunk (the largest q with hit_offsets[q] <= c * chunk; empty
 // queries in between share the offset and are skipped by taking the largest).  One lane per chunk.
 __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(const uint64_t *__restrict__ hit_offsets, uint64_t m,
-                                                                   uint64_t n_chunks, uint32_t chunk,
+                                                                   uint64_t n_chunks, uint32_t chunk, uint64_t total,
                                                                    uint32_t *__restrict__ first)
 {
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t h0 = c * chunk;
+    if (c > n_chunks) return;
+    // entry n_chunks = the query that owns the LAST hit slot, so that the last chunk's block stops there instead of
+    // scanning every trailing query without hits
+    const uint64_t h0 = c < n_chunks ? c * chunk : total - 1;
     uint64_t lo = 0, hi = m;  // upper_bound over hit_offsets[0 .. m): first q with hit_offsets[q] > h0
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
     __shared__ uint32_t s_count[257];
     __shared__ uint32_t s_row[kLocateChunk];
     __shared__ uint32_t s_idx[kLocateChunk];  // slot in the chunk (low 11 bits) | symbols to subtract << 11
-    __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first
+    __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first (+ 1)
+    __shared__ uint32_t s_part[kBlock];
     __shared__ uint32_t s_n, s_head;
     // the text-id search of every hit is a chain of dependent loads: from LDS when the sentinel array is small
     constexpr uint32_t kLdsTexts = 256;
@@ -187,19 +190,49 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
             s_n = 0;
             s_head = 0;
         }
-        // hit slot -> query: the chunk's slots belong to the queries qa .. qb (chunk_first_query_kernel); every
-        // query marks its own slots, so no batch-wide pass over the hits is needed for this
+        // hit slot -> query: the chunk's slots belong to the queries qa .. qb (chunk_first_query_kernel).  Every
+        // query with hits marks its FIRST slot inside the chunk with its number (+ 1), then an inclusive max-scan over
+        // the chunk's slots (8 per thread, partial maxima through LDS) carries the numbers to the other slots: the cost
+        // per slot does not depend on how the hits are distributed over the queries (one query with all 2048 slots of
+        // the chunk costs what 2048 queries with one hit each cost), and no batch-wide pass over the hits is needed.
         const uint32_t qa = first_query[chunk];
-        const uint32_t qb = chunk + 1 < n_chunks ? first_query[chunk + 1] : static_cast<uint32_t>(m - 1);
+        const uint32_t qb = first_query[chunk + 1];
+        for (uint32_t i = threadIdx.x; i < kLocateChunk; i += kBlock) s_query[i] = 0;
+        __syncthreads();
         for (uint64_t q = static_cast<uint64_t>(qa) + threadIdx.x; q <= qb; q += kBlock) {
             const uint64_t a = hit_offsets[q], b = hit_offsets[q + 1];
-            const uint64_t from = a > base ? a : base, to = b < base + cnt ? b : base + cnt;
-            for (uint64_t h = from; h < to; h++) s_query[h - base] = static_cast<uint32_t>(q - qa);
+            const uint64_t from = a > base ? a : base;
+            if (b > from && from < base + cnt) s_query[from - base] = static_cast<uint32_t>(q - qa) + 1u;
+        }
+        __syncthreads();
+        {
+            constexpr uint32_t kPer = kLocateChunk / kBlock;  // consecutive slots per thread
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) {
+                const uint32_t v = s_query[threadIdx.x * kPer + j];
+                run = v > run ? v : run;
+            }
+            s_part[threadIdx.x] = run;
+            __syncthreads();
+            for (int off = 1; off < kBlock; off <<= 1) {  // inclusive max-scan of the partial maxima
+                const uint32_t o = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0u;
+                __syncthreads();
+                if (o > s_part[threadIdx.x]) s_part[threadIdx.x] = o;
+                __syncthreads();
+            }
+            run = threadIdx.x > 0 ? s_part[threadIdx.x - 1] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) {
+                const uint32_t v = s_query[threadIdx.x * kPer + j];
+                run = v > run ? v : run;
+                s_query[threadIdx.x * kPer + j] = run;
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
             const uint64_t h = base + i;
-            const uint32_t q = qa + s_query[i];
+            const uint32_t q = qa + s_query[i] - 1u;
             const uint64_t first = hit_offsets[q];
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
@@ -492,8 +525,8 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     if (variant == 0) {
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
         uint32_t *first = heads;  // n_chunks entries of the workspace
-        hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, first);
+        hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock) / kBlock)),
+                           dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, total_hits, first);
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                              \

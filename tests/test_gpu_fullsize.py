@@ -115,7 +115,9 @@ def test_full_size_properties_workload5(hg38_scale):
     torch.cuda.synchronize()
     assert not bool(out["status"].any().item())
     found = int((out["end"] != out["start"]).sum().item())
-    assert 0.699 * nq < found < 0.705 * nq
+    # 70 % of the reads are drawn from the text, but a window with an N is redrawn at most 8 times and then replaced
+    # by a random read: long reads (P(no N in 150 symbols) = 0.22) are found a little less often than 70 %
+    assert 0.66 * nq < found < 0.70 * nq
     n = h["index"].total_text_len()
     beg, end = q.qoff[:-1], q.qoff[1:]
     lens = end - beg
@@ -134,7 +136,7 @@ def test_full_size_properties_workload5(hg38_scale):
     assert bool((hi == beg).all().item())  # every symbol was offered
     assert torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]) and not bool(cur_st.any().item())
     # random reads die in the first call (top table), found reads stay alive to the end
-    assert live == sorted(live, reverse=True) and live[0] < 0.72 * nq and live[-1] == found
+    assert live == sorted(live, reverse=True) and live[0] < 0.70 * nq and live[-1] == found
     # the same cursors, one symbol per launch (Cursor::extend_query_front as the reference has it), on a prefix
     m = 200_000
     s1 = torch.zeros(m, dtype=torch.int32, device=dev)

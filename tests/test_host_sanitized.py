@@ -1,0 +1,112 @@
+"""The host-side code of libgdx.so that parses untrusted bytes (FASTA / FASTQ reader, index-file header), compiled for
+the CPU with AddressSanitizer + UndefinedBehaviorSanitizer and fed malformed inputs: every one must end in a clean
+error, none in a sanitizer report.  (GPU sanitizers are not available on the pool; the kernels are covered by the
+parity tests.)  The same sources are compiled into libgdx.so."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_checks", "host_checks.cpp")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host_checks") / "host_checks")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", SRC, "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+
+    def run(*args):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+        r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=120, env=env)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr[-2000:])
+        return r.returncode, r.stdout.strip()
+
+    return run
+
+
+def test_fastx_reader_on_wellformed_and_malformed_files(checker, tmp_path):
+    rng = np.random.default_rng(11)
+    seqs = ["".join(rng.choice(list("ACGTN"), int(rng.integers(0, 300)))) for _ in range(200)]
+    fa = tmp_path / "ok.fa"
+    fa.write_text("".join(f">s{i}\n{s[:70]}\n{s[70:]}\n" for i, s in enumerate(seqs)))
+    rc, out = checker("fastx", fa, 7, 700)
+    assert rc == 0 and out.split()[:3] == ["ok", "200", str(sum(map(len, seqs)))]
+    fq = tmp_path / "ok.fq"
+    fq.write_text("".join(f"@r{i}\n{s}\n+\n{'@' * len(s)}\n" for i, s in enumerate(seqs) if s))
+    rc, out = checker("fastx", fq, 1000, 1 << 20)
+    assert rc == 0 and out.split()[1] == str(sum(1 for s in seqs if s))
+    cases = {
+        "truncated_quality.fq": "@r\nACGTACGT\n+\n@@@",                     # fewer quality characters than symbols
+        "no_plus.fq": "@r\nACGTACGT\nACGT",                                 # the file ends inside the sequence
+        "wrong_first_byte.fa": "ACGT\n>x\nAC\n",                           # a record must start with '>' or '@'
+        "quality_overrun.fq": "@r\nAC\n+\n@@@@@@@@\n@s\nAC\n+\n@@\n",       # more quality than symbols
+        "huge_record.fa": ">x\n" + "A" * 5000 + "\n",                       # a record larger than the whole buffer
+        "only_header.fq": "@r",
+        "binary_junk.fa": ">" + "".join(map(chr, rng.integers(1, 255, 4000))),
+        "nul_bytes.fq": "@r\n\0\0\0\n+\n\0\0\0\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_bytes(text.encode("latin-1"))
+        rc, out = checker("fastx", p, 3, 64)
+        assert rc in (0, 3), (name, out)
+        if name in ("truncated_quality.fq", "no_plus.fq", "wrong_first_byte.fa", "huge_record.fa", "only_header.fq"):
+            assert rc == 3 and out.startswith("error:"), (name, out)
+    (tmp_path / "empty.fa").write_bytes(b"")
+    rc, out = checker("fastx", tmp_path / "empty.fa", 3, 64)
+    assert (rc, out.split()[:3]) == (0, ["ok", "0", "0"])
+    rc, out = checker("fastx", tmp_path / "missing.fa", 3, 64)
+    assert rc == 3 and "cannot open" in out
+
+
+def header_bytes(n=1000, n_texts=2, sa_rate=4, sigma=6, n_searchable=4, depth=0, width=32, plane_words=None,
+                 n_samples=None, magic=b"GDXIDX01"):
+    bits = max(1, (sigma - 1).bit_length()) if sigma > 1 else 0
+    if plane_words is None:
+        plane_words = -(-(n + 1) // 64) * bits
+    if n_samples is None:
+        n_samples = -(-n // sa_rate) if sa_rate else 0
+    return (magic + struct.pack("<5Q4i", n, n_texts, sa_rate, plane_words, n_samples, sigma, n_searchable, depth, width)
+            + bytes(256)), plane_words, n_samples
+
+
+def test_index_file_header_validation(checker, tmp_path):
+    def write(name, header, payload_bytes):
+        p = tmp_path / name
+        p.write_bytes(header + bytes(payload_bytes))
+        return p
+
+    h, pw, ns = header_bytes()
+    payload = (6 + 1 + 3 * 2 + pw) * 8 + ns * 4
+    rc, out = checker("header", write("good.gdx", h, payload))
+    assert rc == 0 and out == "ok n=1000 texts=2 sigma=6"
+    bad = {
+        "short_payload": (h, payload - 1),
+        "long_payload": (h, payload + 8),
+        "no_payload": (h, 0),
+        "half_header": (h[:100], 0),
+        "wrong_magic": (header_bytes(magic=b"NOTANIDX")[0], payload),
+        "plane_words_small": (header_bytes(plane_words=1)[0], (6 + 1 + 6 + 1) * 8 + ns * 4),   # the ADVICE case
+        "plane_words_huge": (header_bytes(plane_words=1 << 60)[0], payload),
+        "n_texts_overflow": (header_bytes(n_texts=(1 << 64) - 1)[0], payload),
+        "n_texts_gt_n": (header_bytes(n=5, n_texts=6)[0], payload),
+        "n_too_large": (header_bytes(n=1 << 40)[0], payload),
+        "zero_rate": (header_bytes(sa_rate=0)[0], payload),
+        "samples_mismatch": (header_bytes(n_samples=3)[0], payload),
+        "sigma_1": (header_bytes(sigma=1)[0], payload),
+        "sigma_1000": (header_bytes(sigma=1000)[0], payload),
+        "searchable_ge_sigma": (header_bytes(n_searchable=6)[0], payload),
+        "negative_depth": (header_bytes(depth=-1)[0], payload),
+        "odd_width": (header_bytes(width=48)[0], payload),
+        "empty_file": (b"", 0),
+    }
+    for name, (hdr, pay) in bad.items():
+        rc, out = checker("header", write(name + ".gdx", hdr, pay))
+        assert rc == 3 and out.startswith("error:"), (name, out)
