@@ -115,6 +115,14 @@ SIGNATURES = {
     "gdx_locate_many": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p, u8p],
     "gdx_locate_many_alloc": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(C.POINTER(HitStruct)), u64p, u8p],
     "gdx_free_hits": [C.POINTER(HitStruct)],
+    "gdx_multi_build": [u8p, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                        C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
+    "gdx_multi_free": [vp],
+    "gdx_multi_replicas": [vp],
+    "gdx_multi_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
+    "gdx_multi_cursors_for_many_queries": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],
+    "gdx_multi_locate_many_alloc": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(C.POINTER(HitStruct)), u64p, u8p],
     "gdx_cursor_empty": [vp, u64p, u64p],
     "gdx_cursor_extend_front_many": [vp, u64p, u64p, u8p, C.c_uint64, u8p],
     "gdx_cursor_locate_many": [vp, u64p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p],
@@ -152,7 +160,7 @@ SIGNATURES = {
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
-             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None,
+             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None,
              "gdx_locate_workspace_bytes": C.c_uint64}
 
 _lib = None

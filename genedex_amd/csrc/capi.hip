@@ -6,6 +6,8 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/gdx.h"
 #include "../../include/gdx_bench.h"
@@ -67,6 +69,10 @@ void *stream_scratch(hipStream_t stream, int slot, size_t bytes)
 
 struct gdx_index {
     std::unique_ptr<gdx::FmIndex> impl;
+};
+
+struct gdx_multi {
+    std::unique_ptr<gdx::Multi> impl;
 };
 
 struct gdx_fastx {
@@ -900,6 +906,112 @@ int gdx_locate_many_hits_stats_dev(const gdx_index_t *ix, const void *d_records,
                            nullptr, f.query_options(), static_cast<const uint4 *>(d_records));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
+    });
+}
+
+// ---- replicas on several GPUs behind one handle -----------------------------------------------------------
+
+int gdx_multi_from_indexes(gdx_index_t **replicas, int n_replicas, gdx_multi_t **out)
+{
+    return guarded([&] {
+        if (!out || !replicas || n_replicas < 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_multi_from_indexes: bad argument");
+        *out = nullptr;
+        for (int r = 0; r < n_replicas; r++) {
+            if (!replicas[r] || !replicas[r]->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "replica %d is null", r);
+            const gdx::FmIndex &a = *replicas[0]->impl, &b = *replicas[r]->impl;
+            if (a.total_text_len() != b.total_text_len() || a.num_texts() != b.num_texts() ||
+                a.config().sa_rate != b.config().sa_rate || a.config().sigma != b.config().sigma ||
+                std::memcmp(a.config().io_to_dense, b.config().io_to_dense, 256) != 0)
+                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "replica %d was not built from the same texts / configuration", r);
+        }
+        auto m = std::make_unique<gdx::Multi>();
+        for (int r = 0; r < n_replicas; r++) {
+            m->replicas.push_back(std::move(replicas[r]->impl));
+            delete replicas[r];  // the handle is consumed
+            replicas[r] = nullptr;
+        }
+        *out = new gdx_multi{std::move(m)};
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_multi_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts, const uint8_t *io_to_dense,
+                    int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth, int index_width,
+                    const int *device_ids, int n_devices, const gdx_build_options_t *opts, gdx_multi_t **out)
+{
+    return guarded([&] {
+        if (!out || !device_ids || n_devices < 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_multi_build: bad argument");
+        *out = nullptr;
+        auto m = std::make_unique<gdx::Multi>();
+        m->replicas.resize(n_devices);
+        std::vector<std::string> errors(n_devices);
+        std::vector<int> status(n_devices, GDX_OK);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < n_devices; r++) {  // every device builds its own replica (the builder is deterministic)
+            threads.emplace_back([&, r] {
+                try {
+                    auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_ids[r], opts);
+                    m->replicas[r] = gdx::FmIndex::construct_index(texts_buf, false, text_offsets, n_texts, cfg);
+                } catch (const gdx::Error &e) {
+                    status[r] = e.status;
+                    errors[r] = e.what();
+                } catch (const std::exception &e) {
+                    status[r] = GDX_ERR_DEVICE;
+                    errors[r] = e.what();
+                }
+            });
+        }
+        for (auto &t : threads) t.join();
+        for (int r = 0; r < n_devices; r++)
+            if (status[r] != GDX_OK) gdx::fail(status[r], "device %d: %s", device_ids[r], errors[r].c_str());
+        *out = new gdx_multi{std::move(m)};
+        return (int)GDX_OK;
+    });
+}
+
+void gdx_multi_free(gdx_multi_t *m)
+{
+    if (!m) return;
+    (void)guarded([&] {
+        if (m->impl)
+            for (auto &rep : m->impl->replicas)
+                if (rep) {
+                    DeviceGuard guard(rep->config().device_id);
+                    rep.reset();
+                }
+        delete m;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_multi_replicas(const gdx_multi_t *m) { return (m && m->impl) ? static_cast<int>(m->impl->replicas.size()) : 0; }
+
+int gdx_multi_count_many(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_counts,
+                         uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
+        if (!out_counts && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_counts is null");
+        return gdx::multi_cursors(*m->impl, qbuf, qoff, nq, nullptr, nullptr, out_counts, out_status);
+    });
+}
+
+int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                       uint64_t *out_start, uint64_t *out_end, uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
+        if ((!out_start || !out_end) && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_start / out_end is null");
+        return gdx::multi_cursors(*m->impl, qbuf, qoff, nq, out_start, out_end, nullptr, out_status);
+    });
+}
+
+int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
+        return gdx::multi_locate_alloc(*m->impl, qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
     });
 }
 

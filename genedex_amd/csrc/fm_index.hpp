@@ -143,6 +143,15 @@ private:
     IndexView view_{};
 };
 
+// ---- multi.hip: replicas on several devices behind one handle (gdx_multi_*) ---------------------------------
+struct Multi {
+    std::vector<std::unique_ptr<FmIndex>> replicas;
+};
+int multi_cursors(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+                  uint64_t *out_end, uint64_t *out_count, uint8_t *out_status);
+int multi_locate_alloc(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                       gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
+
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
 void set_host_chunking(uint64_t queries, uint64_t bytes);
 

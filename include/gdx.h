@@ -345,6 +345,29 @@ int gdx_cursor_extend_front_strings(const gdx_index_t *ix, uint64_t *start, uint
 int gdx_rank_many_dev(const gdx_index_t *ix, const void *d_symbols, const void *d_idx /*u32*/, uint64_t m,
                       void *d_out /*u32*/, void *d_error /*u32 or NULL*/, void *stream);
 
+/* ---- several GPUs of one node behind one handle ------------------------------------------
+ * For a host that is one process (the Rust caller), not a set of torch.distributed ranks: the index is replicated,
+ * one replica per device; a query call cuts the batch into contiguous shards (shard r = queries [nq r / g,
+ * nq (r + 1) / g)), every replica runs the host-pointer pipeline on its shard over its own PCIe link from its own
+ * thread and writes into the caller's arrays at the shard's offset.  The devices exchange nothing (the results live
+ * in host memory), and the output is bit for bit the one-GPU output.  gdx_multi_from_indexes CONSUMES the replica
+ * handles it is given (they are set to NULL); all must come from the same texts and configuration. */
+typedef struct gdx_multi gdx_multi_t;
+int gdx_multi_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
+                    const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                    int index_width, const int *device_ids, int n_devices, const gdx_build_options_t *opts,
+                    gdx_multi_t **out);
+int gdx_multi_from_indexes(gdx_index_t **replicas, int n_replicas, gdx_multi_t **out);
+void gdx_multi_free(gdx_multi_t *m);
+int gdx_multi_replicas(const gdx_multi_t *m);
+int gdx_multi_count_many(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                         uint64_t *out_counts, uint8_t *out_status);
+int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                       uint64_t *out_start, uint64_t *out_end, uint8_t *out_status);
+int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total,
+                                uint8_t *out_status);
+
 /* ---- query / text ingestion (host only) ---------------------------------------------------------------------
  * Streaming FASTA / FASTQ reader that fills the layout the calls above take: sequences appended to qbuf, offsets
  * to qoff[0 .. n] (qoff[0] = 0).  The reference leaves reading to its callers (ROADMAP.md:35-37 notes it can cost

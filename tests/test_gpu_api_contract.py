@@ -221,3 +221,46 @@ def test_host_calls_are_chunk_invariant(chunk_queries, chunk_bytes):
         assert counts_b[keep].tolist() == (ce - cs)[keep].tolist()
     finally:
         lib.gdx_debug_set_host_chunking(0, 0)
+
+
+def test_multi_handle_shards_equal_single_gpu(setup):
+    """gdx_multi_*: replicas behind one handle (here: three replicas on the one GPU of the box), the batch cut into
+    contiguous shards, one host thread and pipeline per replica; the output is bit for bit the one-handle output."""
+    _lib, lib, g, c, texts, rng = setup
+    a = alph.ascii_dna_with_n()
+    tbuf, toff = pack_queries(texts)
+    tab = np.ascontiguousarray(a.io_to_dense_table, dtype=np.uint8)
+    devs = (C.c_int * 3)(0, 0, 0)
+    m = C.c_void_p()
+    _lib.check(lib.gdx_multi_build(tbuf.ctypes.data_as(_lib.u8p), toff.ctypes.data_as(_lib.u64p), len(texts),
+                                   tab.ctypes.data_as(_lib.u8p), 6, 4, 4, 3, 32, devs, 3, None, C.byref(m)))
+    try:
+        assert lib.gdx_multi_replicas(m) == 3
+        qs = [texts[int(rng.integers(0, 3))][s:s + int(rng.integers(0, 70))] for s in rng.integers(0, 19000, 4001)]
+        qs = [q for q in qs if b"N" not in q[-3:]] + [b"", b"ACGT"]
+        qbuf, qoff = pack_queries(qs)
+        nq = qoff.size - 1
+        cs, ce = c.cursors_for_many(qbuf, qoff)
+        co, ct, cp = c.locate_many(qs)
+        s_ = np.zeros(nq, dtype=np.uint64)
+        e_ = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros(nq, dtype=np.uint8)
+        _lib.check(lib.gdx_multi_cursors_for_many_queries(m, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p),
+                                                          nq, s_.ctypes.data_as(_lib.u64p), e_.ctypes.data_as(_lib.u64p),
+                                                          st.ctypes.data_as(_lib.u8p)))
+        assert s_.tolist() == cs.tolist() and e_.tolist() == ce.tolist() and not st.any()
+        cnt = np.zeros(nq, dtype=np.uint64)
+        _lib.check(lib.gdx_multi_count_many(m, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                            cnt.ctypes.data_as(_lib.u64p), None))
+        assert cnt.tolist() == (ce - cs).tolist()
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        ptr = C.POINTER(_lib.HitStruct)()
+        _lib.check(lib.gdx_multi_locate_many_alloc(m, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                                   off.ctypes.data_as(_lib.u64p), C.byref(ptr), C.byref(total), None))
+        n = total.value
+        hits = np.ctypeslib.as_array(C.cast(ptr, _lib.u64p), shape=(2 * n,)).reshape(n, 2).copy()
+        lib.gdx_free_hits(ptr)
+        assert off.tolist() == co.tolist() and hits[:, 0].tolist() == ct.tolist() and hits[:, 1].tolist() == cp.tolist()
+    finally:
+        lib.gdx_multi_free(m)
