@@ -768,6 +768,82 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
                 "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
                 "index_build_seconds": t_build, "index_bytes": int(index2.info.device_bytes)})
     log(f"[bench] secondary {res[-1]}")
+    if not args.no_extras and wl["total"] >= 1 << 24:
+        del eng2, index2, counts
+        torch.cuda.empty_cache()
+        res.append(genome_like_secondary(torch, alpha, wl, args))
+    return res
+
+
+def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
+    """The hard case for the jump tables: a text of the same size with the repeat structure of a genome (30 %
+    segmental duplications with 0.5 % divergence, tandem repeats, poly-A, long N gaps; genome_like_text) instead of
+    i.i.d. symbols, the same 100 M len-50 reads (90 % drawn from the text).  Reads from repeats have intervals that
+    stay wider than four rows after the top table and fall back to pair-line steps; reads with more than `max_hits`
+    occurrences (poly-A, tandem repeats: up to tens of millions each) are counted but not located, as a read mapper
+    would do.  Hits are verified against the text."""
+    from genedex_amd.device import (DeviceEngine, DeviceQueries, build_index_from_device_text, genome_like_text,
+                                    hg38_text_lengths)
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    total, nq = wl["total"], wl["nq"]
+    t0 = time.time()
+    text = genome_like_text(total, dev)
+    lengths = hg38_text_lengths(total, wl["n_texts"])
+    torch.cuda.synchronize()
+    t_text = time.time() - t0
+    t0 = time.time()
+    index = build_index_from_device_text(text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=args.lookup_depth,
+                                         index_storage=wl["storage"], options=build_options_of(args))
+    apply_query_options(index, args)
+    t_build = time.time() - t0
+    eng = DeviceEngine(index)
+    q = DeviceQueries.synth(text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
+    rec = eng.alloc_records(nq)
+    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    eng.locate_search(q, rec)
+    eng.locate_offsets(rec, nq, off, max_hits)
+    torch.cuda.synchronize()
+    total_hits = int(off[nq].item())
+    counts = (rec[:nq, 1] - rec[:nq, 0]).to(torch.int64) & 0xFFFFFFFF
+    hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
+    ws = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
+    ev = []
+
+    def step(record):
+        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record()
+        eng.locate_search(q, rec)
+        b.record()
+        eng.locate_offsets(rec, nq, off, max_hits)
+        eng.locate_hits(rec, nq, off, total_hits, hits, ws)
+        c.record()
+        if record:
+            ev.append((a, b, c))
+
+    step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step(True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    chk = verify_hits(torch, text, lengths, q, {"hit_offsets": off}, hits, total_hits, nq, 1_000_000) if total_hits else {}
+    if chk and chk["hits_checked"] != chk["hits_matching_text"]:
+        raise SystemExit(f"PARITY FAILURE on the genome-like text: {chk}")
+    lf_steps, fetches, slots = eng.search_step_stats(q)
+    res = {"name": "genome_like_text (repeats, tandem repeats, poly-A, N gaps)", "text_len": total, "queries": nq,
+           "max_hits_located_per_query": max_hits, "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
+           "search_ms": sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev),
+           "scan_and_locate_ms": sum(b.elapsed_time(c) for _, b, c in ev) / len(ev),
+           "queries_found": int((counts > 0).sum().item()), "occurrences_of_all_queries": int(counts.sum().item()),
+           "queries_over_the_limit": int((counts > max_hits).sum().item()), "hits_located": total_hits,
+           "mean_hits_per_located_query": total_hits / max(int(((counts > 0) & (counts <= max_hits)).sum().item()), 1),
+           "lf_steps": lf_steps, "line_fetches_per_query_exact_mode": fetches / nq,
+           "active_lane_fraction_exact_mode": fetches / slots if slots else None,
+           "index_build_seconds": t_build, "text_seconds": t_text, "build_stats": index.build_stats(),
+           "aux_structures": eng.aux_info(), **chk}
+    log(f"[bench] secondary {res}")
     return res
 
 

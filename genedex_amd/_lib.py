@@ -137,6 +137,7 @@ SIGNATURES = {
     "gdx_rank_many_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_search_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_locate_many_offsets_dev": [vp, vp, C.c_uint64, vp, vp],
+    "gdx_locate_many_offsets_capped_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_locate_many_hits_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_unpack_dev": [vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],

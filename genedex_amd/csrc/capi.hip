@@ -689,6 +689,12 @@ int gdx_locate_many_search_dev(const gdx_index_t *ix, const void *d_qbuf, const 
 int gdx_locate_many_offsets_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_hit_offsets,
                                 void *stream)
 {
+    return gdx_locate_many_offsets_capped_dev(ix, d_records, nq, 0, d_hit_offsets, stream);
+}
+
+int gdx_locate_many_offsets_capped_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
+                                       void *d_hit_offsets, void *stream)
+{
     return guarded([&] {
         const gdx::FmIndex &f = deref(ix);
         check_records(d_records);
@@ -696,7 +702,7 @@ int gdx_locate_many_offsets_dev(const gdx_index_t *ix, const void *d_records, ui
         const size_t tb = gdx::hit_offsets_rec_temp_bytes(nq);
         void *temp = gdx::stream_scratch(as_stream(stream), 10, tb ? tb : 1);
         gdx::launch_hit_offsets_rec(static_cast<const uint4 *>(d_records), nq, static_cast<uint64_t *>(d_hit_offsets),
-                                    temp, tb, as_stream(stream));
+                                    temp, tb, as_stream(stream), max_hits);
         return (int)GDX_OK;
     });
 }

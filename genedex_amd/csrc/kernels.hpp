@@ -78,8 +78,9 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
                         void *d_temp, size_t temp_bytes, hipStream_t stream);
 // the same scan over 16-byte search records (SearchCall::d_rec)
 size_t hit_offsets_rec_temp_bytes(uint64_t m);
+// max_hits != 0: queries with more occurrences get no hit slots (counted, not located)
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
-                            hipStream_t stream);
+                            hipStream_t stream, uint32_t max_hits = 0);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,

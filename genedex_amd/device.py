@@ -164,8 +164,10 @@ class DeviceEngine:
     def locate_search(self, q: DeviceQueries, rec: torch.Tensor) -> None:
         _lib.check(self.lib.gdx_locate_many_search_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec), _stream()))
 
-    def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor) -> None:
-        _lib.check(self.lib.gdx_locate_many_offsets_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), _stream()))
+    def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, max_hits: int = 0) -> None:
+        """max_hits != 0: queries with more occurrences are counted but get no hit slots"""
+        _lib.check(self.lib.gdx_locate_many_offsets_capped_dev(self.h, _ptr(rec), nq, max_hits, _ptr(hit_offsets),
+                                                               _stream()))
 
     def locate_hits(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, total: int, hits: torch.Tensor,
                     workspace: torch.Tensor) -> None:
@@ -260,6 +262,58 @@ def measure_bandwidth(device="cuda", gib: float = 4.0, reps: int = 3):
             res[f"gather{line}_{names[mode]}_GBps"] = n_acc * line / t / 1e9
             res[f"gather{line}_{names[mode]}_Glines_per_s"] = n_acc / t / 1e9
     return res
+
+
+def genome_like_text(total: int, dev, seed: int = 7) -> torch.Tensor:
+    """A text with the repeat structure of a genome instead of i.i.d. symbols: random base sequence, then copies --
+    30 % of the text is made of duplicated segments (1 k .. 2 M symbols, 0.5 % substitutions), 3 % tandem repeats
+    (unit 2..60), 1 % poly-A, 2 % runs of N (assembly gaps, up to total / 100)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    text = synth_text(total, seed=seed, n_per_million=100, device=dev)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+
+    def place(n_symbols, make):
+        done = 0
+        while done < n_symbols:
+            done += make()
+
+    def duplication():
+        ln = int(min(rng.integers(1_000, 2_000_000), total // 8))
+        src, dst = int(rng.integers(0, total - ln)), int(rng.integers(0, total - ln))
+        seg = text[src:src + ln].clone()
+        n_mut = max(1, ln // 200)
+        at = torch.randint(0, ln, (n_mut,), device=dev, generator=g)
+        seg[at] = acgt[torch.randint(0, 4, (n_mut,), device=dev, generator=g)]
+        text[dst:dst + ln] = seg
+        return ln
+
+    def tandem():
+        unit = int(rng.integers(2, 61))
+        ln = int(rng.integers(unit * 5, unit * 2000))
+        dst = int(rng.integers(0, total - ln))
+        u = acgt[torch.randint(0, 4, (unit,), device=dev, generator=g)]
+        text[dst:dst + ln] = u.repeat(ln // unit + 1)[:ln]
+        return ln
+
+    def poly_a():
+        ln = int(rng.integers(20, 5000))
+        dst = int(rng.integers(0, total - ln))
+        text[dst:dst + ln] = ord("A")
+        return ln
+
+    def gap():
+        ln = int(rng.integers(1000, max(2000, total // 100)))
+        dst = int(rng.integers(0, total - ln))
+        text[dst:dst + ln] = ord("N")
+        return ln
+
+    place(int(0.30 * total), duplication)
+    place(int(0.03 * total), tandem)
+    place(int(0.01 * total), poly_a)
+    place(int(0.02 * total), gap)
+    return text
 
 
 def hg38_text_lengths(total: int, n_texts: int = 24):

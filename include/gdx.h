@@ -311,6 +311,11 @@ int gdx_locate_many_search_dev(const gdx_index_t *ix, const void *d_qbuf, const 
                                void *d_records, void *stream);
 int gdx_locate_many_offsets_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_hit_offsets,
                                 void *stream);
+/* the same scan with a per-query limit: a query with more than max_hits occurrences gets no hit slots (it is still
+ * counted -- gdx_locate_many_unpack_dev reports its count -- but not located: what read mappers do with reads that
+ * fall into repeats); max_hits = 0 means no limit */
+int gdx_locate_many_offsets_capped_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
+                                       void *d_hit_offsets, void *stream);
 int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
                              uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,

@@ -16,58 +16,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from genedex_amd import alphabet  # noqa: E402
-from genedex_amd.device import DeviceEngine, DeviceQueries, build_index_from_device_text, synth_text  # noqa: E402
-
-
-def genome_like_text(total: int, dev, seed: int = 7) -> torch.Tensor:
-    """Random base sequence, then copies: 30 % of the text is made of duplicated segments (1 k .. 2 M symbols,
-    0.5 % substitutions), 3 % tandem repeats (unit 2..60), 1 % poly-A, 2 % runs of N (up to total / 100)."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    rng = np.random.default_rng(seed)
-    text = synth_text(total, seed=seed, n_per_million=100, device=dev)
-    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-
-    def place(n_symbols, make):
-        done = 0
-        while done < n_symbols:
-            done += make()
-
-    def duplication():
-        ln = int(min(rng.integers(1_000, 2_000_000), total // 8))
-        src, dst = int(rng.integers(0, total - ln)), int(rng.integers(0, total - ln))
-        seg = text[src:src + ln].clone()
-        n_mut = max(1, ln // 200)
-        at = torch.randint(0, ln, (n_mut,), device=dev, generator=g)
-        seg[at] = acgt[torch.randint(0, 4, (n_mut,), device=dev, generator=g)]
-        text[dst:dst + ln] = seg
-        return ln
-
-    def tandem():
-        unit = int(rng.integers(2, 61))
-        ln = int(rng.integers(unit * 5, unit * 2000))
-        dst = int(rng.integers(0, total - ln))
-        u = acgt[torch.randint(0, 4, (unit,), device=dev, generator=g)]
-        text[dst:dst + ln] = u.repeat(ln // unit + 1)[:ln]
-        return ln
-
-    def poly_a():
-        ln = int(rng.integers(20, 5000))
-        dst = int(rng.integers(0, total - ln))
-        text[dst:dst + ln] = ord("A")
-        return ln
-
-    def gap():
-        ln = int(rng.integers(1000, max(2000, total // 100)))
-        dst = int(rng.integers(0, total - ln))
-        text[dst:dst + ln] = ord("N")
-        return ln
-
-    place(int(0.30 * total), duplication)
-    place(int(0.03 * total), tandem)
-    place(int(0.01 * total), poly_a)
-    place(int(0.02 * total), gap)
-    return text
+from genedex_amd.device import DeviceEngine, DeviceQueries, build_index_from_device_text, genome_like_text  # noqa: E402
 
 
 def count_by_scan(text: torch.Tensor, lengths, q: torch.Tensor) -> int:
