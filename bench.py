@@ -988,7 +988,57 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
         lib.gdx_free_hits(last["ptr"])
     if not same_counts or not same_total:
         raise SystemExit("PARITY FAILURE: the host-pointer calls disagree with the device-resident path")
+    # the same count call on 2-bit packed queries (include/gdx.h "packed queries"): a quarter of the query bytes over
+    # PCIe; packing is done once by gdx_pack_queries (host threads) and timed separately -- a caller that stores its
+    # reads packed never pays it
+    packed = np.empty(int(lib.gdx_packed_bytes(nbytes)), dtype=np.uint8)
+    exc = np.empty(1 << 20, dtype=np.uint64)
+    n_exc = C.c_uint64(0)
+    t0 = time.perf_counter()
+    _lib.check(lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                    packed.ctypes.data_as(u8p), exc.ctypes.data_as(u64p), exc.size, C.byref(n_exc)))
+    t_pack = time.perf_counter() - t0
+    counts_p = np.empty(nq, dtype=np.uint64)
+
+    def count_packed_call():
+        _lib.check(lib.gdx_count_many_packed(index._h, packed.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                             counts_p.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+    t_count_packed = best_of(count_packed_call)
+    keep = np.ones(nq, dtype=bool)
+    keep[exc[: n_exc.value].astype(np.int64)] = False
+    same_packed = bool(np.array_equal(counts_p[keep], counts[keep]))
+    if not same_packed:
+        raise SystemExit("PARITY FAILURE: packed queries give other counts than ASCII queries")
+    # device-resident: the search kernel on packed input (records mode), packed on the device from the ASCII batch
+    d_packed = torch.zeros(packed.size, dtype=torch.uint8, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.gdx_pack_queries_dev(index._h, C.c_void_p(queries.qbuf.data_ptr()), nbytes, C.c_void_p(d_packed.data_ptr()),
+                                        None, C.c_void_p(d_bad.data_ptr()), stream))
+    rec = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+
+    def packed_search():
+        _lib.check(lib.gdx_locate_many_search_packed_dev(index._h, C.c_void_p(d_packed.data_ptr()),
+                                                         C.c_void_p(queries.qoff.data_ptr()), nq, C.c_void_p(rec.data_ptr()),
+                                                         stream))
+
+    packed_search()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(3):
+        packed_search()
+    ev[1].record()
+    torch.cuda.synchronize()
+    packed_search_ms = ev[0].elapsed_time(ev[1]) / 3
+    same_dev = bool(torch.equal((rec[:, 1] - rec[:, 0])[torch.from_numpy(keep).to(dev)],
+                                dev_counts[torch.from_numpy(keep).to(dev)]))
+    if not same_dev:
+        raise SystemExit("PARITY FAILURE: the packed device search gives other counts")
+    del d_packed, rec
     in_bytes = nbytes + 8 * (nq + 1)
+    packed_in_bytes = nbytes // 4 + 8 * (nq + 1)
     out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
     out_locate_bytes = 5 * nq + 8 * total_hits
     bound_count = max(in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3)
@@ -999,7 +1049,14 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
            "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
            "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, kernel time)",
            "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
-                    "identical to the device-resident path", "query_packing": "none (ASCII)",
+                    "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
+           "packed_queries": {"count_qps": nq / t_count_packed, "count_seconds": t_count_packed, "h2d_bytes": packed_in_bytes,
+                              "count_over_bound": t_count_packed / max(packed_in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9),
+                                                                       search_ms / 1e3),
+                              "host_packing_seconds_not_included": t_pack, "exception_queries": int(n_exc.value),
+                              "device_search_ms_on_packed_input": packed_search_ms,
+                              "device_search_ms_on_ascii_input": search_ms,
+                              "counts_identical_outside_the_exceptions": same_packed and same_dev},
            "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
     log(f"[bench] end to end: {res}")
     return res

@@ -2,7 +2,13 @@
 //!
 //! NOT compiled in this repository's image (no rustc/cargo); kept as the reference-side stub a
 //! genedex maintainer would add, e.g. as `src/gpu.rs` behind a `gpu` cargo feature, linking with
-//! `cargo:rustc-link-lib=dylib=gdx`.
+//! `cargo:rustc-link-lib=dylib=gdx`.  It is a parallel type (`GpuFmIndex`), not `FmIndex<I, R>` itself:
+//! the reference's `FmIndex` is generic over a sealed operator trait whose methods are called one
+//! rank at a time (text_with_rank_support/mod.rs:88-133); a GPU cannot be driven at that granularity,
+//! so the drop-in point is the batched public API (`count_many`, `locate_many`,
+//! `cursors_for_many_queries`, lib.rs:155-246), whose signatures are mirrored here: any
+//! `IntoIterator<Item: AsRef<[u8]>>` in, lazy iterators out (the results are computed by one call and
+//! then handed out lazily).
 #![allow(non_camel_case_types)]
 
 use std::ffi::CStr;
@@ -16,6 +22,10 @@ pub struct gdx_fastx_t {
 pub struct gdx_index_t {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct gdx_multi_t {
+    _private: [u8; 0],
+}
 
 /// lib.rs:331-335
 #[repr(C)]
@@ -25,33 +35,66 @@ pub struct Hit {
     pub position: u64,
 }
 
+/// gdx_build_options_t: which derived acceleration structures an index carries (include/gdx.h).
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct BuildOptions {
+    pub struct_size: u32,
+    pub pair_lines: i32,       // -1 default, 0 off, 1 on
+    pub jump_entry_bytes: i32, // -1 default (32), 0, 8, 16, 32
+    pub top_table_depth: i32,  // -1 default, 0 none, 1..=16
+    pub aux_budget_bytes: u64, // 0 = default
+}
+impl Default for BuildOptions {
+    fn default() -> Self {
+        let mut o = std::mem::MaybeUninit::<BuildOptions>::uninit();
+        unsafe {
+            gdx_build_options_init(o.as_mut_ptr());
+            o.assume_init()
+        }
+    }
+}
+
+/// gdx_query_options_t: kernel variants of the query calls on a handle (results never depend on them).
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct QueryOptions {
+    pub struct_size: u32,
+    pub search_kernel: i32,
+    pub search_lanes: i32,
+    pub load_policy: i32,
+    pub length_schedule: i32,
+    pub locate_kernel: i32,
+    pub locate_jump_walk: i32,
+}
+
 pub const GDX_OK: c_int = 0;
 pub const GDX_ERR_CAPACITY: c_int = 5;
 pub const GDX_ERR_QUERY_STATUS: c_int = 6;
 
 extern "C" {
     pub fn gdx_last_error() -> *const c_char;
-    pub fn gdx_index_build(
+    pub fn gdx_build_options_init(opts: *mut BuildOptions);
+    pub fn gdx_query_options_init(opts: *mut QueryOptions);
+    pub fn gdx_index_build_ex(
         texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8,
         sigma: c_int, n_searchable: c_int, sa_rate: u64, lookup_depth: c_int, index_width: c_int,
-        device_id: c_int, out: *mut *mut gdx_index_t,
-    ) -> c_int;
-    pub fn gdx_index_from_parts(
-        count: *const u64, interleaved_blocks: *const u64, n: u64, sa_samples: *const u32, sa_rate: u64,
-        border_keys: *const u64, border_vals: *const u64, sentinel_indices: *const u64, n_texts: u64,
-        io_to_dense: *const u8, sigma: c_int, n_searchable: c_int, lookup_depth: c_int,
-        index_width: c_int, device_id: c_int, out: *mut *mut gdx_index_t,
+        device_id: c_int, opts: *const BuildOptions, out: *mut *mut gdx_index_t,
     ) -> c_int;
     /// table_kind 0 = condensed, 1 = flat; block_bits 64 | 512 (FmIndexCondensed64/512, FmIndexFlat64/512)
-    pub fn gdx_index_from_parts_ex(
+    pub fn gdx_index_from_parts_ex2(
         table_kind: c_int, block_bits: c_int, count: *const u64, interleaved_blocks: *const u64, n: u64,
         sa_samples: *const u32, sa_rate: u64, border_keys: *const u64, border_vals: *const u64,
         sentinel_indices: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int, n_searchable: c_int,
-        lookup_depth: c_int, index_width: c_int, device_id: c_int, out: *mut *mut gdx_index_t,
+        lookup_depth: c_int, index_width: c_int, device_id: c_int, opts: *const BuildOptions,
+        out: *mut *mut gdx_index_t,
     ) -> c_int;
     pub fn gdx_index_save(ix: *const gdx_index_t, path: *const c_char) -> c_int;
-    pub fn gdx_index_load(path: *const c_char, device_id: c_int, out: *mut *mut gdx_index_t) -> c_int;
+    pub fn gdx_index_load_ex(
+        path: *const c_char, device_id: c_int, opts: *const BuildOptions, out: *mut *mut gdx_index_t,
+    ) -> c_int;
     pub fn gdx_index_free(ix: *mut gdx_index_t);
+    pub fn gdx_index_set_query_options(ix: *mut gdx_index_t, opts: *const QueryOptions) -> c_int;
     pub fn gdx_count_many(
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64,
         out_status: *mut u8,
@@ -60,14 +103,21 @@ extern "C" {
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_start: *mut u64,
         out_end: *mut u64, out_status: *mut u8,
     ) -> c_int;
-    pub fn gdx_locate_many(
+    /// one pass, library-allocated hit array (release with gdx_free_hits)
+    pub fn gdx_locate_many_alloc(
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_hit_offsets: *mut u64,
-        hits: *mut Hit, hits_capacity: u64, out_total: *mut u64, out_status: *mut u8,
+        out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
     ) -> c_int;
+    pub fn gdx_free_hits(hits: *mut Hit);
     pub fn gdx_cursor_empty(ix: *const gdx_index_t, start: *mut u64, end: *mut u64) -> c_int;
     pub fn gdx_cursor_extend_front_many(
         ix: *const gdx_index_t, start: *mut u64, end: *mut u64, io_symbols: *const u8, m: u64,
         out_status: *mut u8,
+    ) -> c_int;
+    /// every cursor extended by a whole string (right to left) in one launch
+    pub fn gdx_cursor_extend_front_strings(
+        ix: *const gdx_index_t, start: *mut u64, end: *mut u64, qbuf: *const u8, qoff: *const u64, m: u64,
+        status: *mut u8,
     ) -> c_int;
     pub fn gdx_cursor_locate_many(
         ix: *const gdx_index_t, start: *const u64, end: *const u64, m: u64, out_hit_offsets: *mut u64,
@@ -76,32 +126,39 @@ extern "C" {
     pub fn gdx_rank_many(
         ix: *const gdx_index_t, symbols: *const u8, idx: *const u64, m: u64, out: *mut u64,
     ) -> c_int;
-    // device-resident variants take *const c_void device pointers and a hipStream_t
-    pub fn gdx_count_many_dev(
-        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64,
-        d_out_counts: *mut c_void, d_out_status: *mut c_void, stream: *mut c_void,
-    ) -> c_int;
-    // search + locate on device buffers: the search leaves an opaque 8-byte hint per query for the locate of the
-    // same intervals (a sampled suffix-array row the query passed through), which then needs no walk
-    pub fn gdx_cursors_for_many_queries_hint_dev(
-        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, d_out_start: *mut c_void,
-        d_out_end: *mut c_void, d_out_status: *mut c_void, d_hint: *mut c_void, stream: *mut c_void,
-    ) -> c_int;
-    pub fn gdx_hit_offsets_dev(
-        ix: *const gdx_index_t, d_start: *const c_void, d_end: *const c_void, m: u64, d_hit_offsets: *mut c_void,
+    // device-resident variants take *const c_void device pointers and a hipStream_t; the fused count + locate:
+    pub fn gdx_locate_many_search_dev(
+        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, d_records: *mut c_void,
         stream: *mut c_void,
     ) -> c_int;
+    pub fn gdx_locate_many_offsets_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, nq: u64, d_hit_offsets: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
     pub fn gdx_locate_workspace_bytes(total_hits: u64) -> u64;
+    pub fn gdx_locate_many_hits_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, nq: u64, d_hit_offsets: *const c_void, total_hits: u64,
+        d_hits: *mut c_void, d_workspace: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    // several GPUs of one node behind one handle
+    pub fn gdx_multi_build(
+        texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int,
+        n_searchable: c_int, sa_rate: u64, lookup_depth: c_int, index_width: c_int, device_ids: *const c_int,
+        n_devices: c_int, opts: *const BuildOptions, out: *mut *mut gdx_multi_t,
+    ) -> c_int;
+    pub fn gdx_multi_free(m: *mut gdx_multi_t);
+    pub fn gdx_multi_count_many(
+        m: *const gdx_multi_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64, out_status: *mut u8,
+    ) -> c_int;
+    pub fn gdx_multi_locate_many_alloc(
+        m: *const gdx_multi_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_hit_offsets: *mut u64,
+        out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
+    ) -> c_int;
     // FASTA / FASTQ ingestion into (qbuf, qoff) batches (host only)
     pub fn gdx_fastx_open(path: *const c_char, out: *mut *mut gdx_fastx_t) -> c_int;
     pub fn gdx_fastx_next_batch(
         reader: *mut gdx_fastx_t, qbuf: *mut u8, qbuf_capacity: u64, qoff: *mut u64, max_records: u64, n_out: *mut u64,
     ) -> c_int;
     pub fn gdx_fastx_close(reader: *mut gdx_fastx_t);
-    pub fn gdx_locate_intervals_hint_dev(
-        ix: *const gdx_index_t, d_start: *const c_void, d_end: *const c_void, m: u64, d_hit_offsets: *const c_void,
-        total_hits: u64, d_hits: *mut c_void, d_workspace: *mut c_void, d_hint: *const c_void, stream: *mut c_void,
-    ) -> c_int;
 }
 
 fn check(rc: c_int) {
@@ -118,6 +175,29 @@ fn pack<Q: AsRef<[u8]>>(queries: impl IntoIterator<Item = Q>) -> (Vec<u8>, Vec<u
         off.push(buf.len() as u64);
     }
     (buf, off)
+}
+
+/// Hits of one call, owned by the library's allocation; handed out per query without copying.
+pub struct Hits {
+    ptr: *mut Hit,
+    total: usize,
+    offsets: Vec<u64>,
+}
+impl Drop for Hits {
+    fn drop(&mut self) {
+        unsafe { gdx_free_hits(self.ptr) }
+    }
+}
+impl Hits {
+    /// hits of query i, in suffix-array order (lib.rs:187-197)
+    pub fn of(&self, i: usize) -> &[Hit] {
+        let (a, b) = (self.offsets[i] as usize, self.offsets[i + 1] as usize);
+        if self.total == 0 { &[] } else { unsafe { std::slice::from_raw_parts(self.ptr.add(a), b - a) } }
+    }
+    /// the shape of `FmIndex::locate_many`: an iterator over queries of iterators over hits
+    pub fn iter(&self) -> impl Iterator<Item = impl Iterator<Item = Hit> + '_> + '_ {
+        (0..self.offsets.len() - 1).map(move |i| self.of(i).iter().copied())
+    }
 }
 
 /// Owns an index replica in HBM.  Send + Sync like `FmIndex` (handles are immutable).
@@ -145,54 +225,54 @@ impl GpuFmIndex {
     /// `Alphabet::io_to_dense_representation_table` (alphabet.rs:25).
     pub fn construct<T: AsRef<[u8]>>(
         texts: impl IntoIterator<Item = T>, io_to_dense: &[u8; 256], sigma: usize, n_searchable: usize,
-        sa_rate: usize, lookup_depth: usize, index_width: i32, device: i32,
+        sa_rate: usize, lookup_depth: usize, index_width: i32, device: i32, options: &BuildOptions,
     ) -> Self {
         let (buf, off) = pack(texts);
         let mut raw = std::ptr::null_mut();
         check(unsafe {
-            gdx_index_build(buf.as_ptr(), off.as_ptr(), off.len() as u64 - 1, io_to_dense.as_ptr(), sigma as c_int,
-                            n_searchable as c_int, sa_rate as u64, lookup_depth as c_int, index_width, device, &mut raw)
+            gdx_index_build_ex(buf.as_ptr(), off.as_ptr(), off.len() as u64 - 1, io_to_dense.as_ptr(), sigma as c_int,
+                               n_searchable as c_int, sa_rate as u64, lookup_depth as c_int, index_width, device,
+                               options, &mut raw)
         });
         Self { raw }
     }
 
     /// lib.rs:155-161
-    pub fn count_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> Vec<usize> {
+    pub fn count_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> impl Iterator<Item = usize> {
         let (buf, off) = pack(queries);
         let nq = off.len() - 1;
         let mut counts = vec![0u64; nq];
         check(unsafe { gdx_count_many(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, counts.as_mut_ptr(), std::ptr::null_mut()) });
-        counts.into_iter().map(|c| c as usize).collect()
+        counts.into_iter().map(|c| c as usize)
     }
 
     /// lib.rs:147-149
     pub fn count(&self, query: &[u8]) -> usize {
-        self.count_many([query])[0]
+        self.count_many([query]).next().unwrap()
     }
 
-    /// lib.rs:179-185; hits of query i are `hits[offsets[i]..offsets[i+1]]`
-    pub fn locate_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> (Vec<u64>, Vec<Hit>) {
+    /// lib.rs:179-185, one pass (search, scan, locate pipelined over chunks of the batch)
+    pub fn locate_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> Hits {
         let (buf, off) = pack(queries);
         let nq = off.len() - 1;
         let mut offsets = vec![0u64; nq + 1];
-        let mut total = 0u64;
-        let rc = unsafe {
-            gdx_locate_many(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, offsets.as_mut_ptr(), std::ptr::null_mut(), 0,
-                            &mut total, std::ptr::null_mut())
-        };
-        if rc != GDX_ERR_CAPACITY { check(rc); }
-        let mut hits = vec![Hit { text_id: 0, position: 0 }; total as usize];
-        if total > 0 {
-            check(unsafe {
-                gdx_locate_many(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, offsets.as_mut_ptr(), hits.as_mut_ptr(),
-                                total, &mut total, std::ptr::null_mut())
-            });
-        }
-        (offsets, hits)
+        let (mut total, mut ptr) = (0u64, std::ptr::null_mut());
+        check(unsafe {
+            gdx_locate_many_alloc(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, offsets.as_mut_ptr(), &mut ptr,
+                                  &mut total, std::ptr::null_mut())
+        });
+        Hits { ptr, total: total as usize, offsets }
+    }
+
+    /// lib.rs:169-177
+    pub fn locate(&self, query: &[u8]) -> impl Iterator<Item = Hit> {
+        self.locate_many([query]).of(0).to_vec().into_iter()
     }
 
     /// lib.rs:241-246
-    pub fn cursors_for_many_queries<'a, Q: AsRef<[u8]>>(&'a self, queries: impl IntoIterator<Item = Q>) -> Vec<GpuCursor<'a>> {
+    pub fn cursors_for_many_queries<'a, Q: AsRef<[u8]>>(
+        &'a self, queries: impl IntoIterator<Item = Q>,
+    ) -> impl Iterator<Item = GpuCursor<'a>> {
         let (buf, off) = pack(queries);
         let nq = off.len() - 1;
         let (mut s, mut e) = (vec![0u64; nq], vec![0u64; nq]);
@@ -200,7 +280,12 @@ impl GpuFmIndex {
             gdx_cursors_for_many_queries(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, s.as_mut_ptr(), e.as_mut_ptr(),
                                          std::ptr::null_mut())
         });
-        s.into_iter().zip(e).map(|(start, end)| GpuCursor { index: self, start, end }).collect()
+        s.into_iter().zip(e).map(move |(start, end)| GpuCursor { index: self, start, end })
+    }
+
+    /// lib.rs:217-235
+    pub fn cursor_for_query(&self, query: &[u8]) -> GpuCursor<'_> {
+        self.cursors_for_many_queries([query]).next().unwrap()
     }
 
     /// lib.rs:202-210
@@ -208,6 +293,25 @@ impl GpuFmIndex {
         let (mut start, mut end) = (0u64, 0u64);
         check(unsafe { gdx_cursor_empty(self.raw, &mut start, &mut end) });
         GpuCursor { index: self, start, end }
+    }
+
+    /// Batched form of the cursor API (ROADMAP.md:33): every cursor extended by its own string, last symbol first,
+    /// in ONE launch (up to 40 LF steps per memory fetch), instead of one launch per symbol.
+    pub fn extend_cursors_front<'a, Q: AsRef<[u8]>>(
+        &'a self, cursors: &mut [GpuCursor<'a>], strings: impl IntoIterator<Item = Q>,
+    ) {
+        let (buf, off) = pack(strings);
+        assert_eq!(off.len() - 1, cursors.len());
+        let mut s: Vec<u64> = cursors.iter().map(|c| c.start).collect();
+        let mut e: Vec<u64> = cursors.iter().map(|c| c.end).collect();
+        check(unsafe {
+            gdx_cursor_extend_front_strings(self.raw, s.as_mut_ptr(), e.as_mut_ptr(), buf.as_ptr(), off.as_ptr(),
+                                            cursors.len() as u64, std::ptr::null_mut())
+        });
+        for (c, (start, end)) in cursors.iter_mut().zip(s.into_iter().zip(e)) {
+            c.start = start;
+            c.end = end;
+        }
     }
 }
 
@@ -223,7 +327,7 @@ impl<'a> GpuCursor<'a> {
         (self.end - self.start) as usize
     }
     /// cursor.rs:71-73
-    pub fn locate(&self) -> Vec<Hit> {
+    pub fn locate(&self) -> impl Iterator<Item = Hit> {
         let mut offsets = [0u64; 2];
         let mut total = 0u64;
         let mut hits = vec![Hit { text_id: 0, position: 0 }; self.count()];
@@ -231,6 +335,52 @@ impl<'a> GpuCursor<'a> {
             gdx_cursor_locate_many(self.index.raw, &self.start, &self.end, 1, offsets.as_mut_ptr(), hits.as_mut_ptr(),
                                    hits.len() as u64, &mut total)
         });
-        hits
+        hits.into_iter()
+    }
+}
+
+/// Index replicas on several GPUs of one node behind one handle: the batch is cut into contiguous shards, one
+/// pipeline thread per device; results equal the one-GPU results bit for bit.
+pub struct MultiGpuFmIndex {
+    raw: *mut gdx_multi_t,
+}
+unsafe impl Send for MultiGpuFmIndex {}
+unsafe impl Sync for MultiGpuFmIndex {}
+impl Drop for MultiGpuFmIndex {
+    fn drop(&mut self) {
+        unsafe { gdx_multi_free(self.raw) }
+    }
+}
+impl MultiGpuFmIndex {
+    pub fn construct<T: AsRef<[u8]>>(
+        texts: impl IntoIterator<Item = T>, io_to_dense: &[u8; 256], sigma: usize, n_searchable: usize,
+        sa_rate: usize, lookup_depth: usize, index_width: i32, devices: &[i32], options: &BuildOptions,
+    ) -> Self {
+        let (buf, off) = pack(texts);
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            gdx_multi_build(buf.as_ptr(), off.as_ptr(), off.len() as u64 - 1, io_to_dense.as_ptr(), sigma as c_int,
+                            n_searchable as c_int, sa_rate as u64, lookup_depth as c_int, index_width,
+                            devices.as_ptr(), devices.len() as c_int, options, &mut raw)
+        });
+        Self { raw }
+    }
+    pub fn count_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> impl Iterator<Item = usize> {
+        let (buf, off) = pack(queries);
+        let nq = off.len() - 1;
+        let mut counts = vec![0u64; nq];
+        check(unsafe { gdx_multi_count_many(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, counts.as_mut_ptr(), std::ptr::null_mut()) });
+        counts.into_iter().map(|c| c as usize)
+    }
+    pub fn locate_many<Q: AsRef<[u8]>>(&self, queries: impl IntoIterator<Item = Q>) -> Hits {
+        let (buf, off) = pack(queries);
+        let nq = off.len() - 1;
+        let mut offsets = vec![0u64; nq + 1];
+        let (mut total, mut ptr) = (0u64, std::ptr::null_mut());
+        check(unsafe {
+            gdx_multi_locate_many_alloc(self.raw, buf.as_ptr(), off.as_ptr(), nq as u64, offsets.as_mut_ptr(), &mut ptr,
+                                        &mut total, std::ptr::null_mut())
+        });
+        Hits { ptr, total: total as usize, offsets }
     }
 }

@@ -140,6 +140,14 @@ SIGNATURES = {
     "gdx_locate_many_offsets_capped_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_locate_many_hits_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_unpack_dev": [vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_packed_bytes": [C.c_uint64],
+    "gdx_pack_queries": [vp, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
+    "gdx_pack_queries_dev": [vp, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_count_many_packed": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
+    "gdx_cursors_for_many_queries_packed": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],
+    "gdx_cursors_for_many_queries_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_count_many_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_search_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings": [vp, u64p, u64p, u8p, u64p, C.c_uint64, u8p],
     # gdx_bench.h
@@ -162,7 +170,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
              "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None,
-             "gdx_locate_workspace_bytes": C.c_uint64}
+             "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64}
 
 _lib = None
 

@@ -739,6 +739,105 @@ int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uin
     });
 }
 
+// ---- packed queries ------------------------------------------------------------------------------------
+
+uint64_t gdx_packed_bytes(uint64_t n_symbols) { return (n_symbols + 3) / 4 / 8 * 8 + 16; }
+
+int gdx_pack_queries(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
+                     uint64_t *out_exceptions, uint64_t exceptions_capacity, uint64_t *out_n_exceptions)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (exceptions_capacity && !out_exceptions) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_exceptions is null");
+        const uint64_t n = f.pack_queries_host(qbuf, qoff, nq, out_packed, out_exceptions, exceptions_capacity);
+        if (out_n_exceptions) *out_n_exceptions = n;
+        return n > exceptions_capacity ? (int)GDX_ERR_CAPACITY : (int)GDX_OK;
+    });
+}
+
+int gdx_pack_queries_dev(const gdx_index_t *ix, const void *d_qbuf, uint64_t n_symbols, void *d_packed, void *d_bad_flags,
+                         void *d_bad_symbols, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_pack_queries(f.view(), static_cast<const uint8_t *>(d_qbuf), n_symbols, static_cast<uint8_t *>(d_packed),
+                                 static_cast<uint8_t *>(d_bad_flags), static_cast<unsigned long long *>(d_bad_symbols),
+                                 as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_count_many_packed(const gdx_index_t *ix, const uint8_t *packed, const uint64_t *qoff, uint64_t nq,
+                          uint64_t *out_counts, uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!out_counts && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_counts is null");
+        return deref(ix).cursors_for_many_queries(packed, qoff, nq, nullptr, nullptr, out_counts, out_status, true);
+    });
+}
+
+int gdx_cursors_for_many_queries_packed(const gdx_index_t *ix, const uint8_t *packed, const uint64_t *qoff, uint64_t nq,
+                                        uint64_t *out_start, uint64_t *out_end, uint8_t *out_status)
+{
+    return guarded([&] {
+        if ((!out_start || !out_end) && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_start / out_end is null");
+        return deref(ix).cursors_for_many_queries(packed, qoff, nq, out_start, out_end, nullptr, out_status, true);
+    });
+}
+
+// mode 0 = intervals (start, end), 1 = counts, 2 = records
+static int packed_search_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq, int what,
+                             void *d_a, void *d_b, void *d_status, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_packed) & 1u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_packed must be 2-byte aligned");
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        c.d_qbuf = static_cast<const uint8_t *>(d_packed);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = c.d_qbeg + 1;
+        c.nq = nq;
+        c.packed = true;
+        c.d_status = static_cast<uint8_t *>(d_status);
+        if (what == 0) {
+            c.d_start = static_cast<uint32_t *>(d_a);
+            c.d_end = static_cast<uint32_t *>(d_b);
+            c.mode = 0;
+        } else if (what == 1) {
+            c.d_count = static_cast<uint32_t *>(d_a);
+            c.mode = 1;
+        } else {
+            check_records(d_a);
+            c.d_rec = static_cast<uint4 *>(d_a);
+            c.mode = 1;
+        }
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_cursors_for_many_queries_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
+                                            void *d_out_start, void *d_out_end, void *d_out_status, void *stream)
+{
+    return packed_search_dev(ix, d_packed, d_qoff, nq, 0, d_out_start, d_out_end, d_out_status, stream);
+}
+
+int gdx_count_many_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
+                              void *d_out_counts, void *d_out_status, void *stream)
+{
+    return packed_search_dev(ix, d_packed, d_qoff, nq, 1, d_out_counts, nullptr, d_out_status, stream);
+}
+
+int gdx_locate_many_search_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
+                                      void *d_records, void *stream)
+{
+    return packed_search_dev(ix, d_packed, d_qoff, nq, 2, d_records, nullptr, nullptr, stream);
+}
+
 int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start, void *d_end, const void *d_qbuf,
                                         const void *d_qbeg, const void *d_qend, uint64_t m, void *d_status,
                                         const void *d_active_in, const void *d_n_active_in, void *d_active_out,

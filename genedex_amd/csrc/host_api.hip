@@ -240,8 +240,10 @@ struct Chunk {
 // for room when the caller's buffer is managed by the library (gdx_locate_many_alloc).
 int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a,
                            uint64_t *out_b, uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity,
-                           uint64_t *out_total, const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits) const
+                           uint64_t *out_total, const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits,
+                           bool packed) const
 {
+    // packed: qbuf holds 2-bit codes (symbol j in bits 2 (j & 3) of byte j >> 2) and qoff counts symbols
     const Kind kind = static_cast<Kind>(kind_i);
     WorkerPool pool(host_threads());
     check_queries(qbuf, qoff, nq, pool);
@@ -276,7 +278,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         max_nq = std::max(max_nq, c.nq);
         max_bytes = std::max(max_bytes, c.bytes);
     }
-    const uint64_t qbuf_cap = div_ceil(max_bytes + 1, 8) * 8 + 8;
+    const uint64_t qbuf_cap = div_ceil(max_bytes + 1, 8) * 8 + 16;  // (packed: max_bytes counts symbols, 4 per byte)
 
     // per-slot buffers (ids: slot * 16 + n)
     uint8_t *h_in[kSlots], *d_qbuf[kSlots], *h_status[kSlots], *d_status[kSlots];
@@ -313,13 +315,16 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     auto stage_in = [&](size_t k) {  // user memory -> pinned staging -> device, search (+ scan, total) enqueued
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
-        const uint64_t base = qoff[c.q0];
-        pool.parallel_range(c.bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + base + lo, hi - lo); });
+        // packed: the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
+        const uint64_t base = packed ? (qoff[c.q0] & ~7ull) : qoff[c.q0];
+        const uint64_t src_byte = packed ? base / 4 : base;
+        const uint64_t n_bytes = packed ? div_ceil(qoff[c.q0 + c.nq] - base, 4) : c.bytes;
+        pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
         pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
         });
-        const uint64_t padded = div_ceil(c.bytes + 1, 8) * 8;
-        std::memset(h_in[s] + c.bytes, 0, padded - c.bytes);  // 8-byte windows may read past the last query
+        const uint64_t padded = div_ceil(n_bytes + 2, 8) * 8;
+        std::memset(h_in[s] + n_bytes, 0, padded - n_bytes);  // windows may read past the last query
         GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
         GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
         GDX_HIP(hipEventRecord(st.ev_in[s], st.in));
@@ -329,6 +334,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         call.d_qbeg = d_qoff[s];
         call.d_qend = d_qoff[s] + 1;
         call.nq = c.nq;
+        call.packed = packed;
         if (kind == Kind::kIntervals) {
             call.d_start = d_a[s];
             call.d_end = d_b[s];
@@ -451,6 +457,47 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     return any_status.load() ? GDX_ERR_QUERY_STATUS : GDX_OK;
 }
 
+// ASCII -> 2-bit on the host, by all pool threads; exceptions = the queries that hold a symbol which is not one of
+// the dense codes 1..4 (sorted, unique); returns how many there are (the first `capacity` of them are stored)
+uint64_t FmIndex::pack_queries_host(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
+                                    uint64_t *out_exc, uint64_t capacity) const
+{
+    WorkerPool pool(host_threads());
+    check_queries(qbuf, qoff, nq, pool);
+    if (!out_packed && nq && qoff[nq]) fail(GDX_ERR_INVALID_ARGUMENT, "out_packed is null");
+    const uint64_t n_sym = nq ? qoff[nq] : 0;
+    const uint64_t n_bytes = div_ceil(n_sym, 4);
+    const uint8_t *tab = cfg_.io_to_dense;
+    const uint64_t first = nq ? qoff[0] : 0;  // symbols before the first query are not looked at (code 0)
+    std::vector<std::vector<uint64_t>> bad(pool.size());
+    pool.run([&](unsigned w, unsigned nw) {
+        const uint64_t per = (n_bytes / nw + 64) / 64 * 64;
+        const uint64_t lo = std::min(n_bytes, per * w), hi = std::min(n_bytes, lo + per);
+        std::vector<uint64_t> &mine = bad[w];
+        for (uint64_t b = lo; b < hi; b++) {
+            uint32_t out = 0;
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t j = 4 * b + k;
+                if (j < first || j >= n_sym) continue;
+                const uint32_t d = tab[qbuf[j]];
+                if (d - 1u < 4u) {
+                    out |= (d - 1u) << (2u * k);
+                } else {
+                    const uint64_t q = static_cast<uint64_t>(std::upper_bound(qoff, qoff + nq + 1, j) - qoff) - 1;
+                    if (mine.empty() || mine.back() != q) mine.push_back(q);
+                }
+            }
+            out_packed[b] = static_cast<uint8_t>(out);
+        }
+    });
+    std::vector<uint64_t> all;
+    for (auto &v : bad) all.insert(all.end(), v.begin(), v.end());
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (uint64_t i = 0; i < all.size() && i < capacity; i++) out_exc[i] = all[i];
+    return all.size();
+}
+
 void set_host_chunking(uint64_t queries, uint64_t bytes)
 {
     g_chunk_queries.store(queries ? queries : (1ull << 20));
@@ -458,17 +505,19 @@ void set_host_chunking(uint64_t queries, uint64_t bytes)
 }
 
 int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
-                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status) const
+                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed) const
 {
+    if (packed && (view_.layout != 0 || view_.pair_lines == nullptr))
+        fail(GDX_ERR_UNSUPPORTED, "packed queries need an index with pair lines (sigma <= 8, pair_lines on)");
     if (out_start || out_end) {
         const int rc = host_pipeline(static_cast<int>(Kind::kIntervals), qbuf, qoff, nq, out_start, out_end, out_status,
-                                     nullptr, 0, nullptr, nullptr);
+                                     nullptr, 0, nullptr, nullptr, packed);
         if (out_count && out_start && out_end)
             for (uint64_t i = 0; i < nq; i++) out_count[i] = out_end[i] - out_start[i];
         return rc;
     }
     return host_pipeline(static_cast<int>(Kind::kCounts), qbuf, qoff, nq, out_count, nullptr, out_status, nullptr, 0,
-                         nullptr, nullptr);
+                         nullptr, nullptr, packed);
 }
 
 int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,

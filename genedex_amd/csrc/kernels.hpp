@@ -46,6 +46,7 @@ struct SearchCall {
     uint4 *d_rec = nullptr;
     unsigned long long *d_step_stats = nullptr;
     int mode = 0;
+    bool packed = false;  // d_qbuf holds 2-bit codes, d_qbeg / d_qend count symbols (pair-line indexes only)
     CursorArgs cursors;
 };
 void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream,
@@ -60,6 +61,9 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
                    hipStream_t stream, unsigned long long *d_step_stats = nullptr, uint2 *d_hint = nullptr,
                    const QueryOptions &qo = QueryOptions());
 void set_search_variant(int v);  // 0 quad, 1 lane, 2 pair (default), -1 re-read the environment
+// ASCII -> 2-bit packed queries on the device (include/gdx.h "packed queries")
+void launch_pack_queries(const IndexView &ix, const uint8_t *d_qbuf, uint64_t n_symbols, uint8_t *d_packed,
+                         uint8_t *d_bad_flags, unsigned long long *d_bad_symbols, hipStream_t stream);
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,
                          uint64_t m, uint8_t *d_out_status, hipStream_t stream);
 // d_error (u32, pre-zeroed) is set to 1 when an argument is out of range

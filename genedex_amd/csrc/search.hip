@@ -61,11 +61,14 @@ __device__ __forceinline__ bool all_dna(uint32_t x);
 __device__ __forceinline__ uint32_t to_2bit(uint32_t x);
 constexpr uint32_t kNoCode = 0x10000u;  // compares unequal to every 16-bit entry code
 
-template <int kGroup>
+// kPacked: the query buffer holds 2-bit codes (dense symbol - 1 of the four searchable symbols, symbol j of the
+// buffer in bits 2 (j & 3) of byte j >> 2; include/gdx.h "packed queries") and offsets count SYMBOLS: a span word is
+// then a 16-bit unit of the buffer that needs no translation at all.
+template <int kGroup, bool kPacked>
 struct SpanWindow {
     static constexpr int kWordsPerLane = 8 / kGroup;
-    const uint64_t *base;  // base[0] holds the first byte of the query
-    uint32_t off0;         // byte offset of the query inside base[0]
+    const uint64_t *base;  // base[0] holds the first byte of the query (packed: the 16-bit unit of its first symbol)
+    uint32_t off0;         // byte (packed: symbol) offset of the query inside base[0] (inside its first unit)
     uint32_t top_w;        // span word k = query word top_w - k, k = 0 .. 7 (words below 0 read as 0)
     uint32_t w0, w1;       // this lane's translated span words: k = sub * kWordsPerLane (and + 1)
     uint32_t p;            // the same words as 2-bit codes (dense - 1), 16 bits each: w0 in the low half, w1 above
@@ -80,10 +83,20 @@ struct SpanWindow {
     }
     __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin)
     {
-        base = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+        if (kPacked) base = reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3));
+        else base = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
         off0 = static_cast<uint32_t>(begin & 7u);
         top_w = 0;
         w0 = w1 = p = valid8 = 0;
+    }
+    // eight 2-bit codes -> eight nibble codes 1..4
+    static __device__ __forceinline__ uint32_t spread(uint32_t u)
+    {
+        uint32_t x = u & 0xffffu;
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        return x + 0x11111111u;
     }
     // positions the span so that its first word holds symbol rem - 1 (rem >= 1); group-uniform
     __device__ __forceinline__ void load(uint32_t rem, const uint8_t *s_dense)
@@ -91,6 +104,16 @@ struct SpanWindow {
         const uint32_t sub = threadIdx.x & (kGroup - 1u);
         top_w = (off0 + rem - 1u) >> 3;
         const int32_t first = static_cast<int32_t>(top_w) - static_cast<int32_t>(sub) * kWordsPerLane;
+        if (kPacked) {  // the units ARE the 2-bit span words; every symbol is one of the four searchable ones
+            const uint16_t *units = reinterpret_cast<const uint16_t *>(base);
+            const uint32_t u0 = first >= 0 ? units[first] : 0u;
+            const uint32_t u1 = (kWordsPerLane == 2 && first >= 1) ? units[first - 1] : 0u;
+            p = u0 | (u1 << 16);
+            w0 = spread(u0);
+            w1 = spread(u1);
+            valid8 = 0xffu;
+            return;
+        }
         uint64_t r0 = 0, r1 = 0;
         if (kWordsPerLane == 2) {
             if (first >= 1) {  // both words with one 16-byte load (8-byte aligned)
@@ -408,7 +431,7 @@ __device__ __forceinline__ uint32_t to_2bit(uint32_t x)
 //   (*ca.n_active_in of them; null = all nq), and the cursors that are still non-empty afterwards are appended to
 //   ca.active_out (device-side compaction: one atomic per wavefront), so that a caller feeding long queries in
 //   chunks touches only live cursors.  An invalid symbol stops its cursor where it stands (status set).
-template <int kPolicy, int kGroup, bool kStats, int kJump, int kMode>
+template <int kPolicy, int kGroup, bool kStats, int kJump, int kMode, bool kPacked = false>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qbeg,
                                                              const uint64_t *__restrict__ qend, uint64_t nq,
@@ -454,9 +477,10 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         const uint64_t q = active ? active[at] : at;
         const uint64_t begin = qbeg[q], end = qend[q];
         const uint64_t len = end - begin;
-        const uint32_t t = kMode == 2 ? 0u
-                                      : (len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
-                                                                               : static_cast<uint32_t>(ix.depth));
+        // (packed queries skip the configured lookup table: the steps it replaces give the same interval)
+        const uint32_t t = (kMode == 2 || kPacked) ? 0u
+                                                   : (len < static_cast<uint64_t>(ix.depth) ? static_cast<uint32_t>(len)
+                                                                                            : static_cast<uint32_t>(ix.depth));
         uint32_t lo = 0, hi = ix.n, status = GDX_Q_OK;
         bool stopped = false;  // kMode 2: a cursor that met an invalid symbol earlier stays where it stopped
         if (kMode == 2) {
@@ -469,7 +493,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         }
         const bool fresh = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210)
         uint32_t rem = 0;  // symbols still to consume, right to left
-        SpanWindow<kGroup> win;
+        SpanWindow<kGroup, kPacked> win;
         win.init(qbuf, begin);
         // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
         // top_depth symbols are all in 1..4, hence (with at least four searchable symbols) valid and searchable,
@@ -865,6 +889,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 {
     search_pair_body<kPolicy, 4, false, kJump, kMode>(GDX_SEARCH_FWD);
 }
+// packed queries (2 bits per symbol): 4 lanes per query, plain loads
+template <int kJump, int kMode>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_packed_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_body<0, 4, false, kJump, kMode, true>(GDX_SEARCH_FWD);
+}
 // accounting variants (gdx_search_step_stats_dev): the counters cost registers, so they are kept out of the
 // timed kernels; always the exact mode, whose LF steps are the reference's
 template <int kPolicy, int kJump, int kMode>
@@ -1117,7 +1147,18 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         else if (c.mode == 1) GDX_PAIR_LAUNCH_W(KERNEL, P, 1); \
         else GDX_PAIR_LAUNCH_W(KERNEL, P, 2);             \
     } while (0)
-        if (c.d_step_stats != nullptr) {  // accounting: always the exact mode (the reference's LF steps)
+        if (c.packed) {
+            if (c.mode == 2 || c.d_step_stats != nullptr) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");
+#define GDX_PACKED_W(M)                                                                    \
+    do {                                                                                   \
+        if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((search_pair_packed_kernel4<32, M>));     \
+        else if (ix.jump_bytes == 16) GDX_PAIR_LAUNCH((search_pair_packed_kernel4<16, M>)); \
+        else GDX_PAIR_LAUNCH((search_pair_packed_kernel4<8, M>));                          \
+    } while (0)
+            if (c.mode == 0) GDX_PACKED_W(0);
+            else GDX_PACKED_W(1);
+#undef GDX_PACKED_W
+        } else if (c.d_step_stats != nullptr) {  // accounting: always the exact mode (the reference's LF steps)
             if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 0, 0);
             else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0, 0);
         } else if (lanes == 8) {
@@ -1133,6 +1174,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         return;
     }
     // rank-line and generic kernels: no hints (locate then walks from the interval itself)
+    if (c.packed) fail(GDX_ERR_UNSUPPORTED, "packed queries need an index with pair lines (sigma <= 8, pair_lines on)");
     if (c.d_hint) GDX_HIP(hipMemsetAsync(c.d_hint, 0xff, nq * sizeof(uint2), stream));
 #define GDX_PLAIN_LAUNCH(TABLE, GROUP, GRID)                                                                        \
     do {                                                                                                            \
@@ -1149,6 +1191,48 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
     else if (ix.layout == 0) GDX_PLAIN_LAUNCH(LineTable, 1, grid_for_items(nq));
     else GDX_PLAIN_LAUNCH(GenericTable, 1, grid_for_items(nq));
 #undef GDX_PLAIN_LAUNCH
+}
+
+// ASCII -> 2-bit: packed byte b holds the codes of bytes 4 b .. 4 b + 3 of the query buffer; *bad_symbols counts the
+// symbols that are not one of the dense codes 1..4 (their code is written as 0), bad_flags (optional, one byte per
+// 64 symbols) marks where they are so that the caller can find the queries they belong to
+__global__ __launch_bounds__(kBlock) void pack_queries_kernel(const uint8_t *__restrict__ io_to_dense,
+                                                              const uint8_t *__restrict__ qbuf, uint64_t n_symbols,
+                                                              uint8_t *__restrict__ packed, uint8_t *__restrict__ bad_flags,
+                                                              unsigned long long *__restrict__ bad_symbols)
+{
+    __shared__ uint8_t s_dense[256];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = io_to_dense[i];
+    __syncthreads();
+    const uint64_t n_bytes = (n_symbols + 3) / 4;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    uint32_t bad = 0;
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; b < n_bytes; b += stride) {
+        uint32_t out = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t j = 4 * b + k;
+            if (j < n_symbols) {
+                const uint32_t d = s_dense[qbuf[j]];
+                if (d - 1u < 4u) {
+                    out |= (d - 1u) << (2u * k);
+                } else {
+                    bad++;
+                    if (bad_flags) bad_flags[j >> 6] = 1;
+                }
+            }
+        }
+        packed[b] = static_cast<uint8_t>(out);
+    }
+    if (bad && bad_symbols) atomicAdd(bad_symbols, static_cast<unsigned long long>(bad));
+}
+
+void launch_pack_queries(const IndexView &ix, const uint8_t *d_qbuf, uint64_t n_symbols, uint8_t *d_packed,
+                         uint8_t *d_bad_flags, unsigned long long *d_bad_symbols, hipStream_t stream)
+{
+    if (n_symbols == 0) return;
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(grid_for_items((n_symbols + 3) / 4)), dim3(kBlock), 0, stream,
+                       ix.io_to_dense, d_qbuf, n_symbols, d_packed, d_bad_flags, d_bad_symbols);
 }
 
 void launch_extend_front(const IndexView &ix, uint32_t *d_start, uint32_t *d_end, const uint8_t *d_io_symbols,

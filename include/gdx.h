@@ -321,6 +321,41 @@ int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint6
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream);
 
+/* ---- packed queries ("allow 2-bit host packing as an optional input format") ------------------------
+ * Four symbols per byte instead of one: symbol j of the buffer sits in bits 2 (j & 3) .. 2 (j & 3) + 1 of byte j >> 2
+ * and holds (dense code - 1) of one of the dense symbols 1..4 (A, C, G, T of the DNA alphabets); offsets count SYMBOLS
+ * (the very qoff array of the ASCII form when the packed buffer was made from the whole ASCII buffer).  A query with
+ * any other symbol (N, IUPAC codes, bytes outside the alphabet) cannot be expressed: it is an EXCEPTION, its packed
+ * symbols are 0 and its results from the packed calls are meaningless -- run the exceptions through the ASCII calls.
+ * Packed input quarters the PCIe traffic of the host calls and the query-byte DRAM traffic of the search and needs
+ * no alphabet translation; results are identical.  Needs an index with pair lines (sigma <= 8).
+ * A packed buffer for n symbols takes gdx_packed_bytes(n) bytes (padded: the kernels read whole 16-bit units), must
+ * be 2-byte aligned (device) and is made by
+ *   gdx_pack_queries      on the host, by a few threads; out_exceptions receives the sorted indices of the exception
+ *                         queries (GDX_ERR_CAPACITY and the needed count in *out_n_exceptions if there are more)
+ *   gdx_pack_queries_dev  on the device from a device-resident ASCII buffer; *d_bad_symbols (u64, zeroed by the
+ *                         caller, may be NULL) counts symbols outside 1..4, d_bad_flags (u8 per 64 symbols, zeroed by
+ *                         the caller, may be NULL) marks where they are */
+uint64_t gdx_packed_bytes(uint64_t n_symbols);
+int gdx_pack_queries(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
+                     uint64_t *out_exceptions, uint64_t exceptions_capacity, uint64_t *out_n_exceptions);
+int gdx_pack_queries_dev(const gdx_index_t *ix, const void *d_qbuf, uint64_t n_symbols, void *d_packed,
+                         void *d_bad_flags, void *d_bad_symbols, void *stream);
+/* gdx_count_many / gdx_cursors_for_many_queries on packed host buffers (the same chunked pipeline) */
+int gdx_count_many_packed(const gdx_index_t *ix, const uint8_t *packed, const uint64_t *qoff, uint64_t nq,
+                          uint64_t *out_counts, uint8_t *out_status);
+int gdx_cursors_for_many_queries_packed(const gdx_index_t *ix, const uint8_t *packed, const uint64_t *qoff,
+                                        uint64_t nq, uint64_t *out_start, uint64_t *out_end, uint8_t *out_status);
+/* the device-resident search calls on packed buffers; the rest of a locate (gdx_locate_many_offsets_dev,
+ * gdx_locate_many_hits_dev) is unchanged */
+int gdx_cursors_for_many_queries_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff,
+                                            uint64_t nq, void *d_out_start, void *d_out_end, void *d_out_status,
+                                            void *stream);
+int gdx_count_many_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
+                              void *d_out_counts, void *d_out_status, void *stream);
+int gdx_locate_many_search_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
+                                      void *d_records, void *stream);
+
 /* ---- batched cursor extension by strings (Cursor::extend_query_front, cursor.rs:34-51, applied to every symbol of
  * a string from its last to its first; ROADMAP.md:33 "API to use batched search with cursors") --------------------
  * Cursor i is extended by string i = d_qbuf[d_qbeg[i] .. d_qend[i]) (for a plain offsets array pass d_qoff and

@@ -759,3 +759,94 @@ def test_cursor_strings_stop_at_an_invalid_symbol():
     s2, e2, st2 = g.extend_front_strings_raw(s, e, *pack_queries([b"T", b"A", b""]), status=st, strict=False)
     assert (int(s2[1]), int(e2[1])) == (int(s[1]), int(e[1])) and st2.tolist() == [0, 1, 0]
     assert (int(s2[0]), int(e2[0])) == g.cursor_for_query(b"TACGT").interval()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_packed_queries_equal_ascii_queries(seed, search_variant):
+    """Packed queries (2 bits per symbol, include/gdx.h): host and device packing agree, the exception list names
+    exactly the queries with a symbol outside A, C, G, T, and every other query gets the oracle's intervals, counts
+    and hits from the packed host calls (through many small chunks) and the packed device calls."""
+    import ctypes as C
+
+    import torch
+
+    from genedex_amd import _lib
+    from genedex_amd.device import DeviceEngine, _ptr, _stream
+
+    if search_variant in ("quad", "lane"):
+        pytest.skip("packed queries run on the pair-line kernels")
+    lib = _lib.load()
+    rng = np.random.default_rng(7300 + seed)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=40000, symbols=b"ACGTN" if seed % 2 else b"ACGT")
+    g, c = both(texts, a, sa_rate=[4, 1, 5, 16][seed], depth=[0, 3][seed % 2])
+    qs = mixed_queries(rng, texts, 1200, 400, 90) + [b"", b"ACGT", b"NNNN", b"ACGNT" * 5, b"acgtACGT"]
+    qbuf, qoff = pack_queries(qs)
+    nq = qoff.size - 1
+    n_sym = int(qoff[-1])
+    packed = np.zeros(int(lib.gdx_packed_bytes(n_sym)), dtype=np.uint8)
+    exc = np.zeros(nq, dtype=np.uint64)
+    n_exc = C.c_uint64(0)
+    _lib.check(lib.gdx_pack_queries(g._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                    packed.ctypes.data_as(_lib.u8p), exc.ctypes.data_as(_lib.u64p), nq, C.byref(n_exc)))
+    dense = a.io_to_dense_table
+    want_exc = [i for i, q in enumerate(qs) if any(not 1 <= dense[b] <= 4 for b in q)]
+    assert exc[: n_exc.value].tolist() == want_exc
+    # too small an exception buffer: the needed size is reported
+    if want_exc:
+        rc = lib.gdx_pack_queries(g._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                  packed.ctypes.data_as(_lib.u8p), exc.ctypes.data_as(_lib.u64p), 0, C.byref(n_exc))
+        assert rc == _lib.GDX_ERR_CAPACITY and n_exc.value == len(want_exc)
+    # device packing gives the same bytes and counts the bad symbols
+    d_q = torch.from_numpy(np.concatenate([qbuf[:n_sym], np.zeros(8, np.uint8)])).cuda()
+    d_packed = torch.zeros(packed.size, dtype=torch.uint8, device="cuda")
+    d_bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(lib.gdx_pack_queries_dev(g._h, _ptr(d_q), n_sym, _ptr(d_packed), None, _ptr(d_bad), _stream()))
+    torch.cuda.synchronize()
+    assert d_packed.cpu().numpy()[: (n_sym + 3) // 4].tolist() == packed[: (n_sym + 3) // 4].tolist()
+    assert int(d_bad.item()) == sum(1 for q in qs for b in q if not 1 <= dense[b] <= 4)
+    ok = np.ones(nq, dtype=bool)
+    ok[want_exc] = False
+    cs, ce = c.cursors_for_many(*pack_queries([q if k else b"" for q, k in zip(qs, ok)]))  # exceptions -> empty query
+    # host calls on the packed buffer, through many chunks
+    lib.gdx_debug_set_host_chunking(97, 0)
+    try:
+        s = np.zeros(nq, dtype=np.uint64)
+        e = np.zeros(nq, dtype=np.uint64)
+        st = np.zeros(nq, dtype=np.uint8)
+        _lib.check(lib.gdx_cursors_for_many_queries_packed(g._h, packed.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p),
+                                                           nq, s.ctypes.data_as(_lib.u64p), e.ctypes.data_as(_lib.u64p),
+                                                           st.ctypes.data_as(_lib.u8p)))
+        assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist() and not st.any()
+        cnt = np.zeros(nq, dtype=np.uint64)
+        _lib.check(lib.gdx_count_many_packed(g._h, packed.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                             cnt.ctypes.data_as(_lib.u64p), None))
+        assert cnt[ok].tolist() == (ce - cs)[ok].tolist()
+    finally:
+        lib.gdx_debug_set_host_chunking(0, 0)
+    # device calls: intervals, and the fused count + locate over records
+    eng = DeviceEngine(g)
+    d_off = torch.from_numpy(qoff.astype(np.int64)).cuda()
+    d_s = torch.empty(nq, dtype=torch.int32, device="cuda")
+    d_e = torch.empty(nq, dtype=torch.int32, device="cuda")
+    d_st = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.gdx_cursors_for_many_queries_packed_dev(g._h, _ptr(d_packed), _ptr(d_off), nq, _ptr(d_s), _ptr(d_e),
+                                                           _ptr(d_st), _stream()))
+    torch.cuda.synchronize()
+    assert d_s.cpu().numpy().astype(np.uint32)[ok].tolist() == cs.astype(np.uint32)[ok].tolist()
+    assert d_e.cpu().numpy().astype(np.uint32)[ok].tolist() == ce.astype(np.uint32)[ok].tolist()
+    rec = eng.alloc_records(nq)
+    _lib.check(lib.gdx_locate_many_search_packed_dev(g._h, _ptr(d_packed), _ptr(d_off), nq, _ptr(rec), _stream()))
+    rec[torch.from_numpy(~ok).cuda(), 1] = rec[torch.from_numpy(~ok).cuda(), 0]  # the exceptions count as absent here
+    off = torch.empty(nq + 1, dtype=torch.int64, device="cuda")
+    eng.locate_offsets(rec, nq, off)
+    torch.cuda.synchronize()
+    total = int(off[nq].item())
+    hits = torch.empty((max(total, 1), 2), dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(eng.locate_workspace_bytes(total), 16), dtype=torch.uint8, device="cuda")
+    eng.locate_hits(rec, nq, off, total, hits, ws)
+    torch.cuda.synchronize()
+    co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+    assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+    h = hits[:total].cpu().numpy().astype(np.uint32)
+    assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
