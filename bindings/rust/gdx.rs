@@ -66,6 +66,7 @@ pub struct QueryOptions {
     pub length_schedule: i32,
     pub locate_kernel: i32,
     pub locate_jump_walk: i32,
+    pub search_defer_after: i32,
 }
 
 pub const GDX_OK: c_int = 0;

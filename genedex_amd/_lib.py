@@ -56,13 +56,13 @@ class BuildOptions(C.Structure):
 class QueryOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
                 ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32),
-                ("locate_jump_walk", C.c_int32)]
+                ("locate_jump_walk", C.c_int32), ("search_defer_after", C.c_int32)]
 
 
 class IndexAux(C.Structure):
     _fields_ = [("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32), ("top_table_depth", C.c_int32),
                 ("wanted_jump_entry_bytes", C.c_int32), ("wanted_top_table_depth", C.c_int32),
-                ("reserved", C.c_int32), ("aux_bytes", C.c_uint64), ("aux_budget_bytes", C.c_uint64)]
+                ("wide_permille", C.c_int32), ("aux_bytes", C.c_uint64), ("aux_budget_bytes", C.c_uint64)]
 
 
 class BuildStats(C.Structure):

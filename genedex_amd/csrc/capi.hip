@@ -206,6 +206,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->length_schedule = -1;
     opts->locate_kernel = -1;
     opts->locate_jump_walk = -1;
+    opts->search_defer_after = -1;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -341,7 +342,7 @@ int gdx_index_aux(const gdx_index_t *ix, gdx_index_aux_t *out)
         out->top_table_depth = v.top ? static_cast<int32_t>(v.top_depth) : 0;
         out->wanted_jump_entry_bytes = static_cast<int32_t>(r.wanted_jump_bytes);
         out->wanted_top_table_depth = static_cast<int32_t>(r.wanted_top_depth);
-        out->reserved = 0;
+        out->wide_permille = static_cast<int32_t>(r.wide_fraction * 1000.0 + 0.5);
         out->aux_bytes = r.aux_bytes;
         out->aux_budget_bytes = r.budget_bytes;
         return (int)GDX_OK;
@@ -369,6 +370,9 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
             if (opts->locate_jump_walk < -1 || opts->locate_jump_walk > 1)
                 gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
             q.locate_jump_walk = opts->locate_jump_walk;
+            if (opts->search_defer_after < -1 || opts->search_defer_after > 1000)
+                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            q.search_defer_after = opts->search_defer_after;
         }
         ix->impl->set_query_options(q);
         return (int)GDX_OK;
@@ -388,6 +392,7 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->length_schedule = q.length_schedule;
         out->locate_kernel = q.locate_variant;
         out->locate_jump_walk = q.locate_jump_walk;
+        out->search_defer_after = q.search_defer_after;
         return (int)GDX_OK;
     });
 }

@@ -909,6 +909,15 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             GDX_HIP(hipGetLastError());
             view_.top = top_.get();
             view_.top_depth = top_depth;
+            // how repetitive the text is, as the search sees it: the share of text positions whose D-mer interval
+            // stays wider than a 4-lane jump can take (reads from there fall back to pair-line steps)
+            DeviceBuffer<unsigned long long> d_sum(1);
+            GDX_HIP(hipMemsetAsync(d_sum.get(), 0, sizeof(unsigned long long), stream));
+            launch_top_wide(top_.get(), top_depth, 4u, d_sum.get(), stream);
+            unsigned long long wide = 0;
+            GDX_HIP(hipMemcpyAsync(&wide, d_sum.get(), sizeof(wide), hipMemcpyDeviceToHost, stream));
+            GDX_HIP(hipStreamSynchronize(stream));
+            aux_report_.wide_fraction = n_ ? static_cast<double>(wide) / static_cast<double>(n_) : 0.0;
         }
         aux_report_.aux_bytes = jump_.bytes() + top_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
@@ -945,6 +954,7 @@ void FmIndex::set_query_options(const QueryOptions &q)
     q_schedule_.store(q.length_schedule);
     q_locate_variant_.store(q.locate_variant);
     q_locate_jump_walk_.store(q.locate_jump_walk);
+    q_defer_after_.store(q.search_defer_after);
 }
 
 QueryOptions FmIndex::query_options() const
@@ -956,6 +966,9 @@ QueryOptions FmIndex::query_options() const
     q.length_schedule = q_schedule_.load();
     q.locate_variant = q_locate_variant_.load();
     q.locate_jump_walk = q_locate_jump_walk_.load();
+    q.search_defer_after = q_defer_after_.load();
+    // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
+    if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;
     return q;
 }
 

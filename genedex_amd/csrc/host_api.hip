@@ -4,8 +4,9 @@
 //
 // A call is a pipeline over chunks of the batch, three chunks in flight:
 //
-//     host threads: user memory -> pinned staging   |  H2D (copy-in stream)  |  kernels (compute stream)
-//                                                   |  D2H (copy-out stream) |  host threads: pinned -> user arrays
+//     feeder thread + workers: user memory -> pinned staging  |  H2D (copy-in stream)  |  kernels (compute stream)
+//                                                             |  D2H (copy-out stream) |  calling thread + workers:
+//                                                                                         pinned -> the user's arrays
 //
 // so that the PCIe transfers of chunk k + 1 / k - 1 run beside the kernels of chunk k and a call costs about
 // max(H2D time, D2H time, kernel time) instead of their sum.  Device results travel narrow (u32 counts and rows,
@@ -14,6 +15,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -312,7 +314,8 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     uint64_t hit_base = 0;    // hits of the chunks drained so far
     bool capacity_ok = true;  // locate: the caller's buffer holds everything so far
 
-    auto stage_in = [&](size_t k) {  // user memory -> pinned staging -> device, search (+ scan, total) enqueued
+    // user memory -> pinned staging -> device, search (+ scan, total) enqueued; runs on the feeder thread
+    auto stage_in_with = [&](size_t k, WorkerPool &pool) {
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
         // packed: the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
@@ -445,11 +448,71 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         });
     };
 
-    // software pipeline: while the GPU works on chunk k, the host stages chunk k + 1 in and drains chunk k - 1
-    for (size_t step = 0; step < n_chunks + 2; step++) {
-        if (step < n_chunks) stage_in(step);
-        if (step >= 1 && step - 1 < n_chunks) stage_mid(step - 1);
-        if (step >= 2) stage_out(step - 2);
+    // Software pipeline with two host threads: the feeder stages chunks in (its own worker pool) as soon as a slot is
+    // free, this thread enqueues the locate / copy-out of chunk k and drains chunk k - 1 (its own pool), so that the
+    // copy-in of chunk k + 1 overlaps the widening of chunk k - 1 on the host as well as on the PCIe links.
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t staged = 0, drained = 0;  // chunks staged in / fully drained
+    bool abort = false;
+    std::exception_ptr feeder_error;
+    WorkerPool in_pool(host_threads());
+    std::thread feeder([&] {
+        try {
+            GDX_HIP(hipSetDevice(dev));
+            for (size_t k = 0; k < n_chunks; k++) {
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return abort || k < drained + kSlots; });
+                    if (abort) return;
+                }
+                stage_in_with(k, in_pool);
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    staged = k + 1;
+                }
+                cv.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu);
+            feeder_error = std::current_exception();
+            abort = true;
+            cv.notify_all();
+        }
+    });
+    try {
+        for (size_t step = 0; step < n_chunks + 1; step++) {
+            if (step < n_chunks) {
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return abort || staged > step; });
+                    if (abort) break;
+                }
+                stage_mid(step);
+            }
+            if (step >= 1) {
+                stage_out(step - 1);
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    drained = step;
+                }
+                cv.notify_all();
+            }
+        }
+    } catch (...) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            abort = true;
+        }
+        cv.notify_all();
+        feeder.join();
+        (void)hipDeviceSynchronize();
+        throw;
+    }
+    feeder.join();
+    if (feeder_error) {
+        (void)hipDeviceSynchronize();
+        std::rethrow_exception(feeder_error);
     }
     GDX_HIP(hipStreamSynchronize(st.out));
     if (out_total) *out_total = hit_base;

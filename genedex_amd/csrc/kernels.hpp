@@ -19,6 +19,8 @@ struct QueryOptions {
     int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
     int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
     int locate_jump_walk = -1; // -1 default (1: the queue kernel walks through the jump table), 0 rank lines only
+    int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
+                                  // finished in the block's straggler pass; 0 = never
 };
 
 // Active lists of the cursor-extension mode (search mode 2): the cursors to extend are those listed in active_in
@@ -75,6 +77,8 @@ void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t 
 void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream);
 // Top table of the pair kernels (IndexView::top): 4^depth entries, dense symbols 1..4 only, rank-line layout.
 void launch_fill_top(const IndexView &ix, uint2 *d_top, uint32_t depth, hipStream_t stream);
+// *d_sum (pre-zeroed) += widths of the top-table entries wider than `rows` rows
+void launch_top_wide(const uint2 *d_top, uint32_t depth, uint32_t rows, unsigned long long *d_sum, hipStream_t stream);
 
 // ---- locate.hip ---------------------------------------------------------------------------
 size_t hit_offsets_temp_bytes(uint64_t m);

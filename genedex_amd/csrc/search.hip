@@ -335,6 +335,8 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
 // lanes it saved), and there is no pre-pass and no host round trip.  Ranges of (nearly) equal lengths skip it.
 constexpr uint32_t kLenBuckets = 64;
 constexpr uint32_t kMaxRange = 3072;  // queries per block and range: u16 permutation, 6 KB of LDS
+constexpr uint32_t kMaxDefer = 512;   // stragglers a block can park per range (8 KB of LDS); more are finished in place
+constexpr uint32_t kCursorRange = 1024;  // cursor extension: queries per range (their live list is 4 KB of LDS)
 
 __device__ __forceinline__ uint32_t length_bucket(uint64_t len)
 {
@@ -431,7 +433,7 @@ __device__ __forceinline__ uint32_t to_2bit(uint32_t x)
 //   (*ca.n_active_in of them; null = all nq), and the cursors that are still non-empty afterwards are appended to
 //   ca.active_out (device-side compaction: one atomic per wavefront), so that a caller feeding long queries in
 //   chunks touches only live cursors.  An invalid symbol stops its cursor where it stands (status set).
-template <int kPolicy, int kGroup, bool kStats, int kJump, int kMode, bool kPacked = false>
+template <int kPolicy, int kGroup, bool kStats, int kJump, int kMode, bool kPacked = false, bool kDefer = false>
 __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                              const uint64_t *__restrict__ qbeg,
                                                              const uint64_t *__restrict__ qend, uint64_t nq,
@@ -441,7 +443,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                                                              uint8_t *__restrict__ out_status,
                                                              unsigned long long *__restrict__ step_stats,
                                                              uint32_t range, int schedule, uint2 *__restrict__ out_hint,
-                                                             uint4 *__restrict__ out_rec, CursorArgs ca)
+                                                             uint4 *__restrict__ out_rec, CursorArgs ca, uint32_t defer_after)
 {
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -452,11 +454,21 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     // kMode 2: the cursors of the block's current range that stay alive, appended to ca.active_out with ONE global
     // atomic per range (an atomic per wavefront serialised the whole chip on one address: 27 ms per call at 34 M
     // live cursors)
-    __shared__ uint32_t s_alive[kMode == 2 ? kMaxRange : 1];
+    __shared__ uint32_t s_alive[kMode == 2 ? kCursorRange : 1];
     __shared__ uint32_t s_nalive, s_alive_base;
+    // Stragglers: a query that is not done after its allowance of load rounds (a read from a repeat, whose interval
+    // stays wide and is narrowed two symbols per round) is parked here {query, lo, hi, rem} and finished in a second
+    // pass over the block's range in which EVERY group works on such a query, instead of holding the fifteen finished
+    // queries of its wavefront for dozens of rounds (genome-like text: active lanes 0.27 without this).
+    // (kDefer is a template parameter: the bookkeeping costs the plain kernel 1.6 ms per 100 M reads in registers)
+    __shared__ uint4 s_defer[kDefer ? kMaxDefer : 1];
+    __shared__ uint32_t s_ndefer;
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    if (threadIdx.x == 0) s_nalive = 0;
+    if (threadIdx.x == 0) {
+        s_nalive = 0;
+        s_ndefer = 0;
+    }
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
@@ -472,9 +484,19 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
     if (rg != blockIdx.x) __syncthreads();  // the previous range's order is no longer read
     const bool ordered = schedule != 0 && order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
-    for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
-        const uint64_t at = base + (ordered ? s_perm[slot] : slot);
-        const uint64_t q = active ? active[at] : at;
+    for (int phase = 0; phase < (kDefer ? 2 : 1); phase++) {  // 0: the range's queries; 1: the stragglers parked in phase 0
+    uint32_t n_items = cnt;
+    if (kDefer && phase == 1) {
+        if (defer_after == 0u) break;
+        __syncthreads();
+        n_items = s_ndefer < kMaxDefer ? s_ndefer : kMaxDefer;
+        if (n_items == 0u) break;
+    }
+    for (uint32_t slot = threadIdx.x / kGroup; slot < n_items; slot += kBlock / kGroup) {
+        uint4 parked = make_uint4(0u, 0u, 0u, 0u);
+        if (kDefer && phase == 1) parked = s_defer[slot];
+        const uint64_t at = base + (ordered ? s_perm[phase == 0 ? slot : 0u] : slot);
+        const uint64_t q = (kDefer && phase == 1) ? static_cast<uint64_t>(parked.x) : (active ? active[at] : at);
         const uint64_t begin = qbeg[q], end = qend[q];
         const uint64_t len = end - begin;
         // (packed queries skip the configured lookup table: the steps it replaces give the same interval)
@@ -495,12 +517,20 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         uint32_t rem = 0;  // symbols still to consume, right to left
         SpanWindow<kGroup, kPacked> win;
         win.init(qbuf, begin);
+        if (kDefer && phase == 1) {  // a parked query resumes where it stood (it had no status and no hint)
+            lo = parked.y;
+            hi = parked.z;
+            rem = parked.w;
+            status = GDX_Q_OK;
+            stopped = false;
+            win.load(rem, s_dense);
+        }
         // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
         // top_depth symbols are all in 1..4, hence (with at least four searchable symbols) valid and searchable,
         // which is everything the reference checks for its t-symbol suffix (lookup_table.rs:99-113); the interval
         // is the one the configured table plus the LF steps in between would give.
-        bool topped = false;
-        if (ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull &&
+        bool topped = kDefer && phase == 1;
+        if (!topped && ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull &&
             (kMode != 2 || (fresh && !stopped))) {
             const uint32_t lo0 = lo, hi0 = hi;
             rem = static_cast<uint32_t>(len);
@@ -557,6 +587,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         // (2 M symbols and more) simply do not jump
         bool jump_ok = ix.jump != nullptr && ix.jump_bytes == static_cast<uint32_t>(kJump) && len < (1ull << 21);
         uint32_t iters = 0;  // fetch rounds of this query (divergence accounting, kStats only)
+        // allowance of load rounds before the query is parked: what a query that jumps needs, plus defer_after
+        uint32_t rounds = 0, allowance = 0xffffffffu;
+        bool deferred = false;
         // Every iteration is one round of loads for the whole wavefront, whatever its queries are doing: a group
         // either reads its jump entry or the pair line(s) of its interval borders, all loads are issued, then
         // waited for once, then each group interprets what it got (a wavefront whose groups took different
@@ -567,7 +600,20 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         constexpr int kLevels = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 2 : 5);
         constexpr int kCodes = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 3 : 5);
         const uint32_t sub = threadIdx.x & (kGroup - 1u);
+        if (kDefer && phase == 0 && defer_after != 0u) allowance = defer_after + rem / (kJumpSymbols * kLevels);
         while (rem > 0 && lo != hi) {
+            if (kDefer && rounds >= allowance) {  // park it (group-uniform); a full list means it is finished in place
+                uint32_t slot_d = 0;
+                if (writer) slot_d = atomicAdd(&s_ndefer, 1u);
+                slot_d = static_cast<uint32_t>(__shfl(static_cast<int>(slot_d), static_cast<int>(threadIdx.x & 63u & ~(kGroup - 1u))));
+                if (slot_d < kMaxDefer) {
+                    if (writer) s_defer[slot_d] = make_uint4(static_cast<uint32_t>(q), lo, hi, rem);
+                    deferred = true;
+                    break;
+                }
+                allowance = 0xffffffffu;
+            }
+            if (kDefer) rounds++;
             if (kStats) iters++;
             if (!win.covers(rem)) win.load(rem, s_dense);
             // Intervals of at most one row per lane of the group jump: lane j reads the entry of row lo + j.  The
@@ -818,7 +864,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 if (kStats) lf_steps++;
             }
         }
-        if (writer) {
+        if (writer && !deferred) {
             // a hint describes the one row of a non-empty result; drop it when the search went on and emptied it
             const bool hinted = (status >> 31) && hi - lo == 1u;
             const uint2 hv = hinted ? s_hint[threadIdx.x / kGroup] : make_uint2(0xffffffffu, 0u);
@@ -836,7 +882,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
             if (out_hint) out_hint[q] = hv;
         }
-        if (kMode == 2 && ca.active_out != nullptr && writer && lo != hi && (status & 0xffu) == 0u)
+        if (kMode == 2 && ca.active_out != nullptr && writer && !deferred && lo != hi && (status & 0xffu) == 0u)
             s_alive[atomicAdd(&s_nalive, 1u)] = static_cast<uint32_t>(q);  // the cursors that can still be extended
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;
@@ -847,6 +893,11 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             group_iters += iters;
             wave_slots += wave_max;
         }
+    }
+    }  // phases
+    if (kDefer && defer_after != 0u) {  // the parked queries of this range are done
+        __syncthreads();
+        if (threadIdx.x == 0) s_ndefer = 0;
     }
     if (kMode == 2 && ca.active_out != nullptr) {  // flush the range's live cursors: one atomic, coalesced stores
         __syncthreads();
@@ -870,9 +921,10 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         const uint64_t *__restrict__ qend, uint64_t nq, uint32_t *__restrict__ out_start,                    \
         uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status,  \
         unsigned long long *__restrict__ step_stats, uint32_t range, int schedule, uint2 *__restrict__ out_hint, \
-        uint4 *__restrict__ out_rec, CursorArgs ca
+        uint4 *__restrict__ out_rec, CursorArgs ca, uint32_t defer_after
 #define GDX_SEARCH_FWD \
-    ix, qbuf, qbeg, qend, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule, out_hint, out_rec, ca
+    ix, qbuf, qbeg, qend, nq, out_start, out_end, out_count, out_status, step_stats, range, schedule, out_hint, out_rec, ca, \
+        defer_after
 
 // Register budgets: with the default budget the 8-lane kernel needs 99 SGPRs and the hardware admits only 6-7
 // blocks per CU (MI355X_MICROARCH.md residency).  waves_per_eu(8, 8) -> 64 VGPRs / 78 SGPRs, 8 blocks per CU.
@@ -888,6 +940,18 @@ template <int kPolicy, int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_kernel4(GDX_SEARCH_ARGS)
 {
     search_pair_body<kPolicy, 4, false, kJump, kMode>(GDX_SEARCH_FWD);
+}
+// the same with the straggler pass (plain loads; modes 0 and 1): for texts whose reads often stay wide after the top
+// table (launch_search_call decides)
+template <int kPolicy, int kJump, int kMode>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_pair_defer_kernel8(GDX_SEARCH_ARGS)
+{
+    search_pair_body<0, 8, false, kJump, kMode, false, true>(GDX_SEARCH_FWD);
+}
+template <int kPolicy, int kJump, int kMode>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_defer_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_body<0, 4, false, kJump, kMode, false, true>(GDX_SEARCH_FWD);
 }
 // packed queries (2 bits per symbol): 4 lanes per query, plain loads
 template <int kJump, int kMode>
@@ -1113,7 +1177,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         // 48 rounds per group at large batches, 1792+ blocks at small ones; GDX_SEARCH_GRID = number of blocks.
         uint64_t per_block = (nq + 1791) / 1792;
         per_block = (per_block + 63) / 64 * 64;
-        const uint32_t range = static_cast<uint32_t>(per_block > kMaxRange ? kMaxRange : per_block);
+        const uint32_t range_cap = c.mode == 2 ? kCursorRange : kMaxRange;
+        const uint32_t range = static_cast<uint32_t>(per_block > range_cap ? range_cap : per_block);
         const uint64_t n_ranges = (nq + range - 1) / range;
         const unsigned blocks = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                   : static_cast<unsigned>(n_ranges < (1u << 20) ? n_ranges : (1u << 20));
@@ -1132,9 +1197,20 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             return (e && e[0] == '0') ? 0 : 1;
         }();
         const int schedule = qo.length_schedule >= 0 ? (qo.length_schedule != 0) : env_schedule;
+        // Stragglers are parked after their allowance + defer_after load rounds and finished together
+        // (search_pair_body); QueryOptions::search_defer_after (resolved per index by FmIndex::query_options: on when
+        // the text is repetitive) / GDX_SEARCH_DEFER; 0 = never.  The accounting kernels never park (their per-query
+        // round counts describe the plain lock-step schedule).
+        static const int env_defer = [] {
+            const char *e = getenv("GDX_SEARCH_DEFER");
+            return e ? atoi(e) : 0;
+        }();
+        const uint32_t defer_after = c.d_step_stats != nullptr ? 0u
+                                     : static_cast<uint32_t>(qo.search_defer_after >= 0 ? qo.search_defer_after : env_defer);
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                     \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, c.d_qbuf, c.d_qbeg, c.d_qend, nq,   \
-                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, ca)
+                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, ca, \
+                       defer_after)
 #define GDX_PAIR_LAUNCH_W(KERNEL, P, M)                                    \
     do {                                                                   \
         if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32, M>));      \
@@ -1161,6 +1237,15 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         } else if (c.d_step_stats != nullptr) {  // accounting: always the exact mode (the reference's LF steps)
             if (lanes == 8) GDX_PAIR_LAUNCH_W(search_pair_stats_kernel8, 0, 0);
             else GDX_PAIR_LAUNCH_W(search_pair_stats_kernel4, 0, 0);
+        } else if (defer_after != 0u && c.mode != 2) {
+#define GDX_PAIR_LAUNCH_D(KERNEL)                          \
+    do {                                                  \
+        if (c.mode == 0) GDX_PAIR_LAUNCH_W(KERNEL, 0, 0); \
+        else GDX_PAIR_LAUNCH_W(KERNEL, 0, 1);             \
+    } while (0)
+            if (lanes == 8) GDX_PAIR_LAUNCH_D(search_pair_defer_kernel8);
+            else GDX_PAIR_LAUNCH_D(search_pair_defer_kernel4);
+#undef GDX_PAIR_LAUNCH_D
         } else if (lanes == 8) {
             if (policy == 1) GDX_PAIR_LAUNCH_M(search_pair_kernel8, 1);
             else GDX_PAIR_LAUNCH_M(search_pair_kernel8, 0);
@@ -1271,6 +1356,28 @@ void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStre
     for (int j = 0; j < depth; j++) entries *= static_cast<uint64_t>(ix.n_searchable);
     GDX_DISPATCH_TABLE(ix, fill_lookup_kernel, grid_for_items(entries), stream, ix, d_lookup, depth,
                        static_cast<uint32_t>(entries));
+}
+
+// sum of the interval widths of the top-table entries wider than `rows` rows = the number of text positions whose
+// D-mer stays wider than a jump can take after the top table (a measure of how repetitive the text is)
+__global__ __launch_bounds__(kBlock) void top_wide_kernel(const uint2 *__restrict__ top, uint64_t entries, uint32_t rows,
+                                                          unsigned long long *__restrict__ sum)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    unsigned long long mine = 0;
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) {
+        const uint2 v = top[e];
+        const uint32_t w = v.y - v.x;
+        if (w > rows) mine += w;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(sum, mine);
+}
+
+void launch_top_wide(const uint2 *d_top, uint32_t depth, uint32_t rows, unsigned long long *d_sum, hipStream_t stream)
+{
+    const uint64_t entries = 1ull << (2u * depth);
+    hipLaunchKernelGGL(top_wide_kernel, dim3(grid_for_items(entries)), dim3(kBlock), 0, stream, d_top, entries, rows, d_sum);
 }
 
 void launch_fill_top(const IndexView &ix, uint2 *d_top, uint32_t depth, hipStream_t stream)

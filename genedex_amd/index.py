@@ -158,10 +158,10 @@ class FmIndex:
     def aux(self) -> dict:
         a = _lib.IndexAux()
         _lib.check(self._lib.gdx_index_aux(self._h, C.byref(a)))
-        return {f: int(getattr(a, f)) for f, _ in a._fields_ if f != "reserved"}
+        return {f: int(getattr(a, f)) for f, _ in a._fields_}
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
-                          locate_kernel=None, locate_jump_walk=None) -> None:
+                          locate_kernel=None, locate_jump_walk=None, search_defer_after=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -178,6 +178,8 @@ class FmIndex:
             o.locate_kernel = {"queue": 0, "lane": 1, "pair": 2}.get(locate_kernel, locate_kernel)
         if locate_jump_walk is not None:
             o.locate_jump_walk = int(bool(locate_jump_walk))
+        if search_defer_after is not None:
+            o.search_defer_after = int(search_defer_after)
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

@@ -161,7 +161,10 @@ typedef struct {
     int32_t top_table_depth;         /* 0 = no top table                              */
     int32_t wanted_jump_entry_bytes; /* != jump_entry_bytes: the budget shrank it     */
     int32_t wanted_top_table_depth;
-    int32_t reserved;
+    int32_t wide_permille;           /* thousandths of the text positions whose top-table interval is wider than
+                                        4 rows: how repetitive the text is as the search sees it (i.i.d. 3.1 G
+                                        symbols: 13; genome-like: ~350); above 50 the search parks stragglers
+                                        by default (gdx_query_options_t.search_defer_after)                */
     uint64_t aux_bytes;              /* jump + top table                              */
     uint64_t aux_budget_bytes;       /* the budget that applied                       */
 } gdx_index_aux_t;
@@ -179,6 +182,10 @@ typedef struct {
     int32_t length_schedule; /* -1 default (1: a block orders its queries by length when they differ), 0 off  */
     int32_t locate_kernel;   /* -1 default (0 queue kernel), 1 one lane per hit, 2 eight lanes per hit        */
     int32_t locate_jump_walk; /* -1 default (1: the locate walk goes through the jump table), 0 rank lines only */
+    int32_t search_defer_after; /* a query still unfinished this many load rounds after the allowance of a query
+                                that jumps is parked and finished in its block's straggler pass, where all lanes work
+                                on such queries (reads from repeats); 0 = never park; -1 default: 3 on repetitive
+                                texts (gdx_index_aux_t.wide_permille > 50), else 0 (the bookkeeping is not free)    */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);

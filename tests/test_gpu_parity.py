@@ -206,8 +206,9 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
 _VARIANTS = {
     # name: (query options, build options)
     "pair": (dict(search_kernel="pair"), {}),  # defaults: 32-byte jump entries, top table sized from the text
-    "pair-8lanes": (dict(search_kernel="pair", search_lanes=8), {}),
-    "pair-jump16": (dict(search_kernel="pair"), dict(jump_entry_bytes=16)),
+    "pair-8lanes": (dict(search_kernel="pair", search_lanes=8, search_defer_after=1), {}),
+    "pair-park-all": (dict(search_kernel="pair", search_defer_after=1), dict(jump_entry_bytes=0, top_table_depth=6)),
+    "pair-jump16": (dict(search_kernel="pair", search_defer_after=0), dict(jump_entry_bytes=16)),
     "pair-narrow": (dict(search_kernel="pair"), dict(jump_entry_bytes=8, top_table_depth=0)),
     # forced top depths: on these small texts most deep entries are empty, so the fall-back to the ordinary
     # path runs constantly
