@@ -487,6 +487,10 @@ def main():
             roofline["dram_read_requests_per_query"] = search_traffic["read_requests"] / nq
             roofline["dram_write_requests_per_query"] = search_traffic["write_requests"] / nq
             roofline["l2_hit_rate"] = search_traffic["l2_hits"] / max(search_traffic["l2_requests"], 1)
+            roofline["dram_read_requests_per_launch"] = search_traffic["read_requests"]
+            roofline["dram_write_requests_per_launch"] = search_traffic["write_requests"]
+            roofline["l2_requests_per_launch"] = search_traffic["l2_requests"]
+            roofline["l2_hits_per_launch"] = search_traffic["l2_hits"]
     else:
         roofline.update({"traffic": None, "achieved": None, "frac": None})
     roofline["traffic_source"] = traffic_source

@@ -163,7 +163,7 @@ typedef struct {
     int32_t wanted_top_table_depth;
     int32_t wide_permille;           /* thousandths of the text positions whose top-table interval is wider than
                                         4 rows: how repetitive the text is as the search sees it (i.i.d. 3.1 G
-                                        symbols: 13; genome-like: ~350); above 50 the search parks stragglers
+                                        symbols: 3; genome-like: 95); above 50 the search parks stragglers
                                         by default (gdx_query_options_t.search_defer_after)                */
     uint64_t aux_bytes;              /* jump + top table                              */
     uint64_t aux_budget_bytes;       /* the budget that applied                       */
