@@ -1083,6 +1083,7 @@ void gdx_multi_free(gdx_multi_t *m)
 {
     if (!m) return;
     (void)guarded([&] {
+        if (m->impl) m->impl->workers.clear();  // joins the worker threads (their buffer caches go with them)
         if (m->impl)
             for (auto &rep : m->impl->replicas)
                 if (rep) {

@@ -148,12 +148,30 @@ private:
 };
 
 // ---- multi.hip: replicas on several devices behind one handle (gdx_multi_*) ---------------------------------
+// One long-lived worker thread per replica: the host-pointer pipeline keeps its pinned staging and device buffers in
+// per-thread caches (host_api.hip), so the threads have to outlive the calls.
+class ReplicaWorker {
+public:
+    ReplicaWorker();
+    ~ReplicaWorker();
+    ReplicaWorker(const ReplicaWorker &) = delete;
+    ReplicaWorker &operator=(const ReplicaWorker &) = delete;
+    void submit(std::function<void()> job);  // runs on the worker thread
+    void wait();                             // until every submitted job is done
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
 struct Multi {
     std::vector<std::unique_ptr<FmIndex>> replicas;
+    std::vector<std::unique_ptr<ReplicaWorker>> workers;  // one per replica, created on first use
+    ReplicaWorker &worker(size_t r);
 };
-int multi_cursors(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+int multi_cursors(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
                   uint64_t *out_end, uint64_t *out_count, uint8_t *out_status);
-int multi_locate_alloc(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                        gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
 
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.

@@ -5,7 +5,10 @@
 // link and writes its results straight into the caller's arrays at the shard's offset; there is no exchange between
 // the devices at all (results live in host memory).  Order preserving: the output equals the one-GPU output.
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include <sys/mman.h>
@@ -13,6 +16,71 @@
 #include "fm_index.hpp"
 
 namespace gdx {
+
+struct ReplicaWorker::Impl {
+    std::mutex m;
+    std::condition_variable cv, idle;
+    std::deque<std::function<void()>> jobs;
+    size_t running = 0;
+    bool stop = false;
+    std::thread thread;
+};
+
+ReplicaWorker::ReplicaWorker() : impl_(new Impl)
+{
+    Impl *p = impl_.get();
+    p->thread = std::thread([p] {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(p->m);
+                p->cv.wait(g, [p] { return p->stop || !p->jobs.empty(); });
+                if (p->jobs.empty()) return;  // stop requested and nothing left
+                job = std::move(p->jobs.front());
+                p->jobs.pop_front();
+                p->running++;
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> g(p->m);
+                p->running--;
+            }
+            p->idle.notify_all();
+        }
+    });
+}
+
+ReplicaWorker::~ReplicaWorker()
+{
+    {
+        std::lock_guard<std::mutex> g(impl_->m);
+        impl_->stop = true;
+    }
+    impl_->cv.notify_all();
+    if (impl_->thread.joinable()) impl_->thread.join();
+}
+
+void ReplicaWorker::submit(std::function<void()> job)
+{
+    {
+        std::lock_guard<std::mutex> g(impl_->m);
+        impl_->jobs.push_back(std::move(job));
+    }
+    impl_->cv.notify_one();
+}
+
+void ReplicaWorker::wait()
+{
+    std::unique_lock<std::mutex> g(impl_->m);
+    impl_->idle.wait(g, [this] { return impl_->jobs.empty() && impl_->running == 0; });
+}
+
+ReplicaWorker &Multi::worker(size_t r)
+{
+    if (workers.size() < replicas.size()) workers.resize(replicas.size());
+    if (!workers[r]) workers[r] = std::make_unique<ReplicaWorker>();
+    return *workers[r];
+}
 
 namespace {
 
@@ -23,14 +91,15 @@ struct ShardResult {
     uint64_t total = 0;
 };
 
+// per_shard(r, lo, hi) on the worker thread of every replica (calls on one handle are serialised by the caller's
+// use of the workers: a second concurrent call queues behind the first)
 template <class F>
-int run_shards(const Multi &m, uint64_t nq, F per_shard)
+int run_shards(Multi &m, uint64_t nq, F per_shard)
 {
     const size_t g = m.replicas.size();
     std::vector<ShardResult> res(g);
-    std::vector<std::thread> threads;
     for (size_t r = 0; r < g; r++) {
-        threads.emplace_back([&, r] {
+        m.worker(r).submit([&, r] {
             const uint64_t lo = nq * r / g, hi = nq * (r + 1) / g;
             try {
                 res[r].rc = per_shard(r, lo, hi, res[r]);
@@ -43,7 +112,7 @@ int run_shards(const Multi &m, uint64_t nq, F per_shard)
             }
         });
     }
-    for (auto &t : threads) t.join();
+    for (size_t r = 0; r < g; r++) m.worker(r).wait();
     int rc = GDX_OK;
     for (size_t r = 0; r < g; r++) {
         if (res[r].rc != GDX_OK && res[r].rc != GDX_ERR_QUERY_STATUS) fail(res[r].rc, "replica %zu: %s", r, res[r].error.c_str());
@@ -54,7 +123,7 @@ int run_shards(const Multi &m, uint64_t nq, F per_shard)
 
 }  // namespace
 
-int multi_cursors(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
+int multi_cursors(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
                   uint64_t *out_end, uint64_t *out_count, uint8_t *out_status)
 {
     if (!qoff) fail(GDX_ERR_INVALID_ARGUMENT, "qoff is null");
@@ -66,7 +135,7 @@ int multi_cursors(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uin
     });
 }
 
-int multi_locate_alloc(const Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                        gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
 {
     if (!qoff || !out_hits || !out_hit_offsets) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");

@@ -953,6 +953,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 {
     search_pair_body<0, 4, false, kJump, kMode, false, true>(GDX_SEARCH_FWD);
 }
+// (experiment: the same at 6 waves per SIMD, 80 VGPRs; GDX_DEFER_WAVES=6)
+template <int kPolicy, int kJump, int kMode>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void search_pair_defer6_kernel4(GDX_SEARCH_ARGS)
+{
+    search_pair_body<0, 4, false, kJump, kMode, false, true>(GDX_SEARCH_FWD);
+}
 // packed queries (2 bits per symbol): 4 lanes per query, plain loads
 template <int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_packed_kernel4(GDX_SEARCH_ARGS)
@@ -1243,7 +1249,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         if (c.mode == 0) GDX_PAIR_LAUNCH_W(KERNEL, 0, 0); \
         else GDX_PAIR_LAUNCH_W(KERNEL, 0, 1);             \
     } while (0)
+            static const int defer_waves = [] { const char *e = getenv("GDX_DEFER_WAVES"); return e ? atoi(e) : 7; }();
             if (lanes == 8) GDX_PAIR_LAUNCH_D(search_pair_defer_kernel8);
+            else if (defer_waves == 6) GDX_PAIR_LAUNCH_D(search_pair_defer6_kernel4);
             else GDX_PAIR_LAUNCH_D(search_pair_defer_kernel4);
 #undef GDX_PAIR_LAUNCH_D
         } else if (lanes == 8) {

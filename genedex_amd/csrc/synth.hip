@@ -6,6 +6,8 @@
 
 #include "common.hpp"
 #include "layout.hpp"
+#include <cstdlib>
+
 #include "synth.hpp"
 
 namespace gdx {
@@ -203,16 +205,20 @@ __global__ __launch_bounds__(kBlock) void gather_group_kernel(const u32x4 *__res
     if (acc == 0x12345u) *sink = acc;
 }
 
-// streaming read: sums 16-byte words, 4 loads in flight per lane
+// streaming read: sums 16-byte words, kUnroll loads in flight per lane, optionally non-temporal (no cache allocation)
+template <int kUnroll, bool kNt>
 __global__ __launch_bounds__(kBlock) void stream_read_kernel(const u32x4 *__restrict__ src, uint64_t n16,
                                                              uint32_t *__restrict__ sink)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     uint32_t acc = 0;
     uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) v[k] = kNt ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) acc ^= v[k].x ^ v[k].w;
     }
     for (; i < n16; i += stride) acc ^= src[i].x;
     if (acc == 0x12345u) *sink = acc;
@@ -265,8 +271,12 @@ void launch_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hip
 {
     const uint64_t n16 = bytes / 16;
     if (n16 == 0) return;
-    hipLaunchKernelGGL(stream_read_kernel, dim3(256u * 8u), dim3(kBlock), 0, stream,
-                       static_cast<const u32x4 *>(d_src), n16, d_sink);
+    // GDX_STREAM_VARIANT (experiments): 0 = 4 loads in flight, 1 = 8 non-temporal, 2 = 8 plain on twice the blocks
+    static const int variant = [] { const char *e = getenv("GDX_STREAM_VARIANT"); return e ? atoi(e) : 1; }();
+    const u32x4 *src = static_cast<const u32x4 *>(d_src);
+    if (variant == 0) hipLaunchKernelGGL((stream_read_kernel<4, false>), dim3(256u * 8u), dim3(kBlock), 0, stream, src, n16, d_sink);
+    else if (variant == 2) hipLaunchKernelGGL((stream_read_kernel<8, false>), dim3(256u * 16u), dim3(kBlock), 0, stream, src, n16, d_sink);
+    else hipLaunchKernelGGL((stream_read_kernel<8, true>), dim3(256u * 8u), dim3(kBlock), 0, stream, src, n16, d_sink);
 }
 
 void launch_random_gather(const void *d_src, uint64_t n_lines, uint32_t line_bytes, uint64_t n_accesses,
