@@ -87,6 +87,7 @@ def parse_args():
     ap.add_argument("--top-depth", type=int, default=None, help="gdx_build_options_t.top_table_depth")
     ap.add_argument("--no-pair-lines", action="store_true", help="gdx_build_options_t.pair_lines = 0")
     ap.add_argument("--lanes", type=int, default=None, help="gdx_query_options_t.search_lanes")
+    ap.add_argument("--load-policy", type=int, default=None, help="gdx_query_options_t.load_policy")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the rocprofv3 PMC child passes (roofline.traffic then falls back to the committed "
                          "summary under profiles/ and says so)")
@@ -133,18 +134,22 @@ def pmc_child(args):
     print(json.dumps({"pmc_child": True, "nq": nq, "hits": runner.total_hits}), flush=True)
 
 
-def run_live_pmc(args):
+def run_live_pmc(args, reference_layout=False):
     """-> ({kernel short name: {counter: per-launch value}}, None) or (None, reason).  Runs before the parent touches
-    the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process."""
+    the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process.
+    reference_layout: the same workload on an index without any acceleration structure (the ladder's last rung)."""
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
                   "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate)]
-    for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", args.jump_bytes),
-                    ("--top-depth", args.top_depth), ("--lanes", args.lanes)):
+    jump_bytes, top_depth, no_pairs = args.jump_bytes, args.top_depth, args.no_pair_lines
+    if reference_layout:
+        jump_bytes, top_depth, no_pairs = 0, 0, True
+    for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", jump_bytes),
+                    ("--top-depth", top_depth), ("--lanes", args.lanes), ("--load-policy", args.load_policy)):
         if v is not None:
             child_args += [flag, str(v)]
-    if args.no_pair_lines:
+    if no_pairs:
         child_args.append("--no-pair-lines")
     if args.no_hint:
         child_args.append("--no-hint")
@@ -231,8 +236,8 @@ def build_options_of(args, **override):
 
 
 def apply_query_options(index, args):
-    if args.lanes is not None:
-        index.set_query_options(search_lanes=args.lanes)
+    if args.lanes is not None or getattr(args, "load_policy", None) is not None:
+        index.set_query_options(search_lanes=args.lanes, load_policy=getattr(args, "load_policy", None))
 
 
 class _null:
@@ -387,11 +392,13 @@ def main():
 
     # PMC passes first: they are separate processes that each need the GPU's memory for their own index, and starting
     # them before this process initialises the GPU keeps every exec clear of a process that holds the device
-    pmc, pmc_note = None, "live PMC passes run at N = 1 only"
+    pmc, pmc_note, pmc_ref = None, "live PMC passes run at N = 1 only", None
     if world == 1 and not args.no_live_pmc:
         pmc, pmc_note = run_live_pmc(args)
         if pmc is None:
             log(f"[bench] live PMC unavailable: {pmc_note}")
+        elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
+            pmc_ref, _ = run_live_pmc(args, reference_layout=True)
 
     import numpy as np
     import torch  # before libgdx.so: both must share torch's HIP runtime
@@ -604,7 +611,7 @@ def main():
         owned = {"eng": eng, "index": index}  # handed over: the last rung frees the index before building another
         del eng, index
         result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
-                                          args, wl)
+                                          args, wl, pmc_ref)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -708,7 +715,7 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
     return ms, runner.mean_ms(runner.ev_search), runner.mean_ms(runner.ev_locate), counts
 
 
-def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl):
+def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -747,6 +754,17 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
                 "frac": b / (s_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
                 "note": "algorithmic bytes of SURVEY.md 8d / kernel time / 8 TB/s on the 4.65 GB index without any "
                         "acceleration structure (every 30-byte rank costs one 128-byte DRAM request there)"}
+            t_ref = traffic_of(pmc_ref, "search_kernel")
+            if t_ref:  # the same kernel's measured HBM traffic (PMC child passes of this run on the same configuration)
+                rl = r["roofline_reference_layout"]
+                rl["algorithmic_ratio"] = rl.pop("frac")
+                rl["traffic"] = t_ref["bytes"]
+                rl["achieved"] = t_ref["bytes"] / (s_ms / 1e3) / 1e9
+                rl["frac"] = rl["achieved"] / HBM_PEAK_GBPS
+                rl["dram_read_requests_per_query"] = t_ref.get("read_requests", 0) / nq
+                rl["note"] = ("frac = measured HBM traffic / kernel time / 8 TB/s on the 4.65 GB index without any acceleration "
+                              "structure; algorithmic_ratio = the logical bytes of SURVEY.md 8d over the same time (every "
+                              "30-byte rank costs one 128-byte request)")
         log(f"[bench] secondary {name}: {r}")
         res.append(r)
         del counts

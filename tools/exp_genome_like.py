@@ -12,7 +12,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from genedex_amd import alphabet  # noqa: E402
 
-args = argparse.Namespace(sa_rate=4, lookup_depth=0, jump_bytes=None, top_depth=None, no_pair_lines=False, lanes=None)
+args = argparse.Namespace(sa_rate=4, lookup_depth=0, jump_bytes=None, top_depth=None, no_pair_lines=False, lanes=None, load_policy=None)
 wl = dict(bench.WORKLOADS["hg38"])
 torch.cuda.set_device(0)
 res = bench.genome_like_secondary(torch, alphabet.ascii_dna_with_n(), wl, args)
