@@ -67,6 +67,7 @@ pub struct QueryOptions {
     pub locate_kernel: i32,
     pub locate_jump_walk: i32,
     pub search_defer_after: i32,
+    pub search_fast: i32,
 }
 
 pub const GDX_OK: c_int = 0;

@@ -207,6 +207,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->locate_kernel = -1;
     opts->locate_jump_walk = -1;
     opts->search_defer_after = -1;
+    opts->search_fast = -1;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -373,6 +374,8 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
             if (opts->search_defer_after < -1 || opts->search_defer_after > 1000)
                 gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
             q.search_defer_after = opts->search_defer_after;
+            if (opts->search_fast < -1 || opts->search_fast > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            q.search_fast = opts->search_fast;
         }
         ix->impl->set_query_options(q);
         return (int)GDX_OK;
@@ -393,6 +396,7 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->locate_kernel = q.locate_variant;
         out->locate_jump_walk = q.locate_jump_walk;
         out->search_defer_after = q.search_defer_after;
+        out->search_fast = q.search_fast;
         return (int)GDX_OK;
     });
 }

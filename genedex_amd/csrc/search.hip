@@ -476,8 +476,8 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     const bool hinting = out_hint != nullptr || out_rec != nullptr;
     uint32_t lf_steps = 0;
     unsigned long long group_iters = 0, wave_slots = 0;  // step_stats[1], [2]
-    const uint32_t *active = kMode == 2 ? ca.active_in : nullptr;
-    if (kMode == 2 && ca.n_active_in != nullptr) nq = *ca.n_active_in;
+    const uint32_t *active = ca.active_in;  // cursor lists (mode 2) or the leftover list of the fast path
+    if (ca.n_active_in != nullptr) nq = *ca.n_active_in;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
     const uint64_t base = rg * range;
@@ -961,6 +961,217 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 {
     search_pair_body<0, 4, false, kJump, kMode, false, true>(GDX_SEARCH_FWD);
 }
+// ---- fast path of the count / locate search ----------------------------------------------------------------------
+// What almost every read of a non-repetitive text does is: top table, then jumps, then the lazy tail -- no pair line
+// is ever touched.  This kernel does only that, which leaves out the second line of registers, the pair-step
+// arithmetic, the N path, hints through LDS and the length order, and therefore runs at more waves per SIMD (the
+// occupancy curve of profiles/r02/experiments.md section 3 extrapolates to 4.5 ms at unlimited parallelism).  A query
+// it cannot finish that way (no top-table hit, an interval wider than four rows, a symbol outside A C G T, a tail the
+// lookahead cannot decide, fewer than eight symbols left on a multi-row interval) is appended to `leftover` untouched
+// and searched by the general kernel afterwards (launch_search_call).  Results for the queries it finishes are the
+// general kernel's, bit for bit.
+// (the few fields of the IndexView it needs, so that the kernel arguments do not eat the SGPR budget of 8+ waves)
+struct FastView {
+    const uint2 *top;
+    const void *jump;
+    const uint8_t *io_to_dense;
+    uint32_t top_depth, sa_inv, sa_rot, sa_limit;
+};
+__device__ __forceinline__ bool is_sampled(const FastView &ix, uint32_t i)
+{
+    const uint32_t m = i * ix.sa_inv;
+    return __builtin_amdgcn_alignbit(m, m, ix.sa_rot) <= ix.sa_limit;
+}
+
+template <int kJump>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
+    FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
+    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+{
+    constexpr int kGroup = 4;
+    constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : 5);
+    constexpr int kCodes = kJump == 8 ? 1 : (kJump == 16 ? 3 : 5);
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_left[kMaxRange];
+    __shared__ uint32_t s_nleft, s_left_base;
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    if (threadIdx.x == 0) s_nleft = 0;
+    __syncthreads();
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint32_t sub = threadIdx.x & (kGroup - 1u);
+    const bool hinting = out_rec != nullptr;
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        const uint64_t base = rg * range;
+        const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+        for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
+            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const uint64_t begin = qbeg[q];
+            const uint64_t len = qend[q] - begin;
+            bool bail = !(len >= 16u && len >= ix.top_depth && len < (1ull << 21));
+            uint32_t lo = 0, hi = 0, rem = 0, hr = 0xffffffffu, ho = 0;
+            SpanWindow<kGroup, false> win;
+            win.init(qbuf, begin);
+            if (!bail) {
+                rem = static_cast<uint32_t>(len);
+                win.load(rem, s_dense);
+                const uint32_t l1 = win.level(rem), l2 = win.level(rem - 8u);
+                if (l1 == kNoCode || l2 == kNoCode) {
+                    bail = true;
+                } else {
+                    const uint2 e = ix.top[((l1 << 16) | l2) >> (32u - 2u * ix.top_depth)];
+                    lo = e.x;
+                    hi = e.y;
+                    rem -= ix.top_depth;
+                }
+            }
+            while (!bail && rem > 0u && lo != hi) {
+                if (hi - lo > static_cast<uint32_t>(kGroup) || rem < kJumpSymbols) {
+                    bail = true;
+                    break;
+                }
+                if (!win.covers(rem)) win.load(rem, s_dense);
+                uint32_t qa = win.level(rem);
+                if (qa == kNoCode) {
+                    bail = true;
+                    break;
+                }
+                const uint32_t n_lv = rem >> 3 < static_cast<uint32_t>(kLevels) ? rem >> 3 : static_cast<uint32_t>(kLevels);
+                const bool tail = (rem & 7u) != 0u && (rem >> 3) < static_cast<uint32_t>(kCodes);
+                if (!win.covers(tail ? 8u : rem - (n_lv - 1u) * kJumpSymbols)) win.load(rem, s_dense);
+                uint32_t qb = 0, qc = 0, qok = 1u, tail16 = kNoCode;
+#pragma unroll
+                for (int j = 1; j < kLevels; j++) {
+                    if (rem >= (j + 1u) * kJumpSymbols) {
+                        const uint32_t v = win.level(rem - j * kJumpSymbols);
+                        if (v != kNoCode) {
+                            if (j == 1) qa |= v << 16;
+                            if (j == 2) qb = v;
+                            if (j == 3) qc = v;
+                            if (j == 4) qc |= v << 16;
+                            qok |= 1u << j;
+                        }
+                    }
+                }
+                if (tail) {
+                    const uint32_t v = win.level(8u);
+                    if (v != kNoCode) tail16 = (v << (2u * (8u - (rem & 7u)))) & 0xffffu;
+                }
+                const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
+                const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
+                const u32x4 *pa = kJump == 8 ? tab + (row >> 1) : tab + static_cast<uint64_t>(row) * (kJump / 16);
+                u32x4 e0, e1;
+                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(true) : 0ull, e0, e1);
+                uint32_t valid, da, db = 0, dc = 0;
+                if (kJump == 8) {
+                    const uint32_t w = (row & 1u) ? e0.w : e0.y;
+                    da = (w ^ qa) & 0xffffu;
+                    valid = w >> 16;
+                } else {
+                    da = e0.z ^ qa;
+                    db = (e0.w ^ qb) & 0xffffu;
+                    valid = e0.w >> 16;
+                    if (kLevels == 5) dc = e1.w ^ qc;
+                }
+                uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
+                if (kLevels >= 2) good |= (da >> 16) == 0u ? 2u : 0u;
+                if (kLevels == 5) {
+                    good |= db == 0u ? 4u : 0u;
+                    good |= (dc & 0xffffu) == 0u ? 8u : 0u;
+                    good |= (dc >> 16) == 0u ? 16u : 0u;
+                }
+                good &= valid & qok;
+                const uint32_t lvl = static_cast<uint32_t>(__builtin_ctz(~good | (1u << kLevels)));
+                const uint32_t best = group_max<kGroup>(lvl);
+                if (best == 0u) {  // no row survives the next eight symbols: the count is 0 (mode 1 needs no interval)
+                    hi = lo;
+                    break;
+                }
+                const bool mine = lvl == best;
+                if (hinting && hr == 0xffffffffu && hi - lo == 1u && is_sampled(ix, lo)) {
+                    hr = lo;
+                    ho = rem;
+                }
+                uint32_t target = kJump == 8 ? ((row & 1u) ? e0.z : e0.x) : e0.x;
+                if (kLevels >= 2) target = best == 2u ? e0.y : target;
+                if (kLevels == 5) {
+                    target = best == 3u ? e1.x : target;
+                    target = best == 4u ? e1.y : target;
+                    target = best == 5u ? e1.z : target;
+                }
+                lo = group_min<kGroup>(mine ? target : 0xffffffffu);
+                hi = group_max<kGroup>(mine ? target : 0u) + 1u;
+                rem -= best * kJumpSymbols;
+                const bool one_row = hi - lo == 1u;
+                if (hinting && one_row && hr == 0xffffffffu) {
+                    if (is_sampled(ix, lo)) {
+                        hr = lo;
+                        ho = rem;
+                    }
+#pragma unroll
+                    for (int j = kLevels - 1; j >= 1; j--) {
+                        if (hr == 0xffffffffu && best > static_cast<uint32_t>(j)) {
+                            const uint32_t tj = j == 1 ? e0.x : (j == 2 ? e0.y : (j == 3 ? e1.x : e1.y));
+                            const uint32_t mid = group_min<kGroup>(mine ? tj : 0xffffffffu);
+                            if (is_sampled(ix, mid)) {
+                                hr = mid;
+                                ho = rem + (best - j) * kJumpSymbols;
+                            }
+                        }
+                    }
+                }
+                if (one_row && rem > 0u && rem < kJumpSymbols) {
+                    if (best >= static_cast<uint32_t>(kCodes)) {  // no lookahead left in this entry
+                        bail = true;
+                        break;
+                    }
+                    uint32_t nxt = e0.z >> 16;
+                    nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
+                    if (kLevels == 5) {
+                        nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
+                        nxt = best == 4u ? (e1.w >> 16) : nxt;
+                    }
+                    const bool can = mine && ((valid >> best) & 1u) && tail16 != kNoCode;
+                    const uint32_t tmask = (0xffffu << (16u - 2u * rem)) & 0xffffu;
+                    const uint32_t verdict = group_max<kGroup>(can ? (((nxt ^ tail16) & tmask) == 0u ? 2u : 1u) : 0u);
+                    if (verdict == 0u) {
+                        bail = true;
+                        break;
+                    }
+                    if (verdict == 2u) {
+                        if (hinting && hr == 0xffffffffu) {
+                            hr = lo;
+                            ho = rem;
+                        }
+                    } else {
+                        hi = lo;
+                    }
+                    rem = 0;
+                }
+            }
+            if (writer) {
+                if (bail) {
+                    s_left[atomicAdd(&s_nleft, 1u)] = q;
+                } else {
+                    const bool hinted = hr != 0xffffffffu && hi - lo == 1u;
+                    if (out_rec) out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? (ho & 0xffffffu) : 0u);
+                    if (out_count) out_count[q] = hi - lo;
+                    if (out_status) out_status[q] = 0;
+                }
+            }
+        }
+        // flush the range's leftover queries: one atomic, coalesced stores
+        __syncthreads();
+        const uint32_t n_left = s_nleft;
+        if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nleft = 0;
+    }
+}
+
 // packed queries (2 bits per symbol): 4 lanes per query, plain loads
 template <int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_packed_kernel4(GDX_SEARCH_ARGS)
@@ -1217,8 +1428,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                                      : static_cast<uint32_t>(qo.search_defer_after >= 0 ? qo.search_defer_after : env_defer);
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                     \
     hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, c.d_qbuf, c.d_qbeg, c.d_qend, nq,   \
-                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, ca, \
-                       defer_after)
+                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, \
+                       ca_general, defer_after)
 #define GDX_PAIR_LAUNCH_W(KERNEL, P, M)                                    \
     do {                                                                   \
         if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32, M>));      \
@@ -1231,6 +1442,29 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         else if (c.mode == 1) GDX_PAIR_LAUNCH_W(KERNEL, P, 1); \
         else GDX_PAIR_LAUNCH_W(KERNEL, P, 2);             \
     } while (0)
+        // Fast path (search_fast_kernel4): count / locate mode on an index with top and jump tables whose text is not
+        // repetitive.  It finishes what needs no pair line and lists the rest, which the general kernel then searches
+        // from the list.  QueryOptions::search_fast / GDX_SEARCH_FAST=0 switch it off.
+        static const int env_fast = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : 1; }();
+        const bool fast = c.mode == 1 && !c.packed && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
+                          defer_after == 0u && ix.top != nullptr && ix.top_depth >= 1u && ix.jump != nullptr &&
+                          ca.active_in == nullptr && c.d_hint == nullptr && c.d_start == nullptr && c.d_end == nullptr &&
+                          (qo.search_fast >= 0 ? qo.search_fast != 0 : env_fast != 0) && nq < 0xffffffffull;
+        CursorArgs ca_general = ca;
+        if (fast) {
+            uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit};
+#define GDX_FAST_LAUNCH(J)                                                                                              \
+    hipLaunchKernelGGL((search_fast_kernel4<J>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, c.d_qend, \
+                       nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left)
+            if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32);
+            else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16);
+            else GDX_FAST_LAUNCH(8);
+#undef GDX_FAST_LAUNCH
+            ca_general.active_in = d_left + 4;  // the general kernel below searches the leftover list
+            ca_general.n_active_in = d_left;
+        }
         if (c.packed) {
             if (c.mode == 2 || c.d_step_stats != nullptr) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");
 #define GDX_PACKED_W(M)                                                                    \

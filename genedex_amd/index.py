@@ -161,7 +161,7 @@ class FmIndex:
         return {f: int(getattr(a, f)) for f, _ in a._fields_}
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
-                          locate_kernel=None, locate_jump_walk=None, search_defer_after=None) -> None:
+                          locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -180,6 +180,8 @@ class FmIndex:
             o.locate_jump_walk = int(bool(locate_jump_walk))
         if search_defer_after is not None:
             o.search_defer_after = int(search_defer_after)
+        if search_fast is not None:
+            o.search_fast = int(bool(search_fast))
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

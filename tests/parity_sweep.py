@@ -88,7 +88,8 @@ def one_round(rng, stats):
              "pair_lines": [None, None, None, False][int(rng.integers(0, 4))]}
     query = {"search_lanes": [4, 4, 8][int(rng.integers(0, 3))], "load_policy": int(rng.integers(0, 2)),
              "length_schedule": int(rng.integers(0, 2)), "locate_jump_walk": int(rng.integers(0, 4)) != 0,
-             "search_defer_after": [None, 0, 1, 2, 5][int(rng.integers(0, 5))]}
+             "search_defer_after": [None, 0, 1, 2, 5][int(rng.integers(0, 5))],
+             "search_fast": int(rng.integers(0, 3)) != 0}
     storage = str(rng.choice(["i32", "u32"]))
     cfg = {"alphabet": name, "total": total, "n_texts": n_texts, "mode": mode, "sa_rate": rate, "depth": depth,
            "storage": storage, **build, **query}
@@ -202,7 +203,7 @@ def main():
     for _ in range(rounds):
         cfg = one_round(rng, stats)
         for key in ("alphabet", "mode", "jump_entry_bytes", "top_table_depth", "pair_lines", "search_lanes", "load_policy",
-                    "length_schedule", "locate_jump_walk", "search_defer_after", "sa_rate", "depth"):
+                    "length_schedule", "locate_jump_walk", "search_defer_after", "search_fast", "sa_rate", "depth"):
             seen.setdefault(key, {}).setdefault(str(cfg[key]), 0)
             seen[key][str(cfg[key])] += 1
     print(json.dumps({"rounds": rounds, "seed": seed, "all_equal": True,

@@ -214,6 +214,7 @@ _VARIANTS = {
     # path runs constantly
     "pair-top4": (dict(search_kernel="pair", locate_jump_walk=False), dict(top_table_depth=4)),
     "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
+    "pair-no-fast": (dict(search_kernel="pair", search_fast=False), {}),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
     "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
