@@ -159,7 +159,7 @@ def run_live_pmc(args, reference_layout=False):
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_pair_kernel|locate_queue_kernel|search_kernel", "--output-format", "csv", "-d", d, "--",
+               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|search_kernel", "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
@@ -198,21 +198,36 @@ def traffic_of(pmc, pattern):
     own access pattern by tools/calibrate_fetch_size.sh) + WRITE_SIZE[KB] * 1024."""
     if not pmc:
         return None
-    names = [k for k in pmc if pattern in k and "stats" not in k]
-    if len(names) != 1:
-        return None
-    c = pmc[names[0]]
-    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-        return None
-    res = {"kernel": names[0], "read_bytes": 2.0 * c["FETCH_SIZE"]["per_launch"] * 1024.0,
-           "write_bytes": c["WRITE_SIZE"]["per_launch"] * 1024.0}
-    res["bytes"] = res["read_bytes"] + res["write_bytes"]
-    if "TCC_EA0_RDREQ_sum" in c:
-        res["read_requests"] = c["TCC_EA0_RDREQ_sum"]["per_launch"]
-        res["write_requests"] = c["TCC_EA0_WRREQ_sum"]["per_launch"]
-        res["l2_requests"] = c["TCC_REQ_sum"]["per_launch"]
-        res["l2_hits"] = c["TCC_HIT_sum"]["per_launch"]
-    return res
+    # a search step may be two launches (the fast-path kernel, then the general kernel on the queries it left over):
+    # `pattern` may name several kernels separated by '|'; their per-launch counters are added
+    total = None
+    for pat in pattern.split("|"):
+        names = [k for k in pmc if pat in k and "stats" not in k]
+        if len(names) > 1:
+            return None
+        if not names:
+            continue
+        c = pmc[names[0]]
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            return None
+        res = {"kernel": names[0], "read_bytes": 2.0 * c["FETCH_SIZE"]["per_launch"] * 1024.0,
+               "write_bytes": c["WRITE_SIZE"]["per_launch"] * 1024.0}
+        res["bytes"] = res["read_bytes"] + res["write_bytes"]
+        if "TCC_EA0_RDREQ_sum" in c:
+            res["read_requests"] = c["TCC_EA0_RDREQ_sum"]["per_launch"]
+            res["write_requests"] = c["TCC_EA0_WRREQ_sum"]["per_launch"]
+            res["l2_requests"] = c["TCC_REQ_sum"]["per_launch"]
+            res["l2_hits"] = c["TCC_HIT_sum"]["per_launch"]
+        if total is None:
+            total = res
+            total["by_kernel"] = {res["kernel"]: res["bytes"]}
+        else:
+            total["by_kernel"][res["kernel"]] = res["bytes"]
+            total["kernel"] += " + " + res["kernel"]
+            for key in ("read_bytes", "write_bytes", "bytes", "read_requests", "write_requests", "l2_requests", "l2_hits"):
+                if key in total and key in res:
+                    total[key] += res[key]
+    return total
 
 
 # ======================================================================================================
@@ -477,7 +492,7 @@ def main():
     # ---- algorithmic bytes, counted by an extra, untimed pass in the exact mode -----------
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
-    kernel_pattern = "search_pair_kernel" if aux["pair_lines"] else "search_kernel"
+    kernel_pattern = "search_fast_kernel|search_pair_kernel" if aux["pair_lines"] else "search_kernel"
     search_traffic = traffic_of(pmc, kernel_pattern)
     traffic_source = "live: rocprofv3 --pmc child passes of this run (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
     if search_traffic is None:
@@ -488,6 +503,7 @@ def main():
         roofline["traffic"] = search_traffic["bytes"]
         roofline["achieved"] = search_traffic["bytes"] / (search_ms / 1e3) / 1e9
         roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBPS
+        roofline["traffic_by_kernel"] = search_traffic.get("by_kernel")
         roofline["traffic_read_bytes"] = search_traffic["read_bytes"]
         roofline["traffic_write_bytes"] = search_traffic["write_bytes"]
         if "read_requests" in search_traffic:
@@ -504,7 +520,10 @@ def main():
     roofline["algorithmic_bytes_per_launch"] = search_bytes
     roofline["lf_steps_per_launch"] = lf_steps
     roofline["algorithmic_ratio"] = search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
-    roofline["note"] = ("frac = measured HBM traffic of the kernel / its live HIP-event duration / 8 TB/s. "
+    roofline["note"] = ("The search step is the fast-path kernel (top table + jumps + lazy tail) followed by the general "
+                        "kernel on the few queries it left over; traffic, requests and avg_launch_ms are those of both "
+                        "launches together (rocprofv3's kernel stats list them separately). "
+                        "frac = measured HBM traffic of the kernel / its live HIP-event duration / 8 TB/s. "
                         "algorithmic_ratio = the reference algorithm's logical bytes (60 B per LF step it would execute "
                         "+ query bytes + 8 B result, SURVEY.md 8d) / the same time / 8 TB/s: it exceeds 1 because the top "
                         "table, the jump table and the lazy tail deliver those LF steps with far fewer fetches, not "

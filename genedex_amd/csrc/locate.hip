@@ -161,8 +161,21 @@ constexpr uint32_t kLocateChunk = 2048;
 // (SA[r] = SA[t_j] + 8 j; 76 % per fetch at rate 4) where a rank-line step offers one (25 %): 1.3 fetches per walking
 // hit instead of 4.  PMC (profiles/r02): the rank-line walk was 54 % of the kernel's DRAM requests.  A level that is
 // invalid (a sentinel or a symbol outside 1..4 within its eight steps) is crossed with rank-line steps.
+// (the kernel gets the few fields of the IndexView it reads -- the whole view costs SGPRs -- and its queue shares LDS
+// with the slot -> query map, so that eight blocks fit a CU: it ran at 5 waves per SIMD before)
+struct LocateView {
+    const u32x4 *lines;
+    const uint32_t *sb_offsets;
+    const uint64_t *g_planes;
+    const uint16_t *g_block_off;
+    const void *jump;
+    const uint32_t *count, *sa_samples, *border_keys, *border_vals, *sentinels;
+    uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
+    int32_t sigma, nbits;
+};
+
 template <class Table, bool kWide, bool kJumpWalk>
-__global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, const uint32_t *__restrict__ start,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_queue_kernel(LocateView lv, const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
                                                               const uint2 *__restrict__ hint,
@@ -170,10 +183,31 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
                                                               void *__restrict__ hits_out,
                                                               unsigned long long *__restrict__ step_stats)
 {
+    IndexView ix{};
+    ix.lines = lv.lines;
+    ix.sb_offsets = lv.sb_offsets;
+    ix.g_planes = lv.g_planes;
+    ix.g_block_off = lv.g_block_off;
+    ix.jump = lv.jump;
+    ix.count = lv.count;
+    ix.sa_samples = lv.sa_samples;
+    ix.border_keys = lv.border_keys;
+    ix.border_vals = lv.border_vals;
+    ix.sentinels = lv.sentinels;
+    ix.sb_stride = lv.sb_stride;
+    ix.jump_bytes = lv.jump_bytes;
+    ix.n_texts = lv.n_texts;
+    ix.sa_inv = lv.sa_inv;
+    ix.sa_rot = lv.sa_rot;
+    ix.sa_limit = lv.sa_limit;
+    ix.sigma = lv.sigma;
+    ix.nbits = lv.nbits;
     __shared__ uint32_t s_count[257];
-    __shared__ uint32_t s_row[kLocateChunk];
     __shared__ uint32_t s_idx[kLocateChunk];  // slot in the chunk (low 11 bits) | symbols to subtract << 11
-    __shared__ uint32_t s_query[kLocateChunk];  // query of every hit slot of the chunk, relative to the chunk's first (+ 1)
+    // query of every hit slot of the chunk, relative to the chunk's first (+ 1); once every thread holds its slots'
+    // queries in registers the same memory is the queue's row array
+    __shared__ uint32_t s_query[kLocateChunk];
+    uint32_t *const s_row = s_query;
     __shared__ uint32_t s_part[kBlock];
     __shared__ uint32_t s_n, s_head;
     // the text-id search of every hit is a chain of dependent loads: from LDS when the sentinel array is small
@@ -233,9 +267,17 @@ __global__ __launch_bounds__(kBlock) void locate_queue_kernel(IndexView ix, cons
             }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
+        constexpr uint32_t kSlotsPerThread = kLocateChunk / kBlock;
+        uint32_t qrel[kSlotsPerThread];
+#pragma unroll
+        for (uint32_t j = 0; j < kSlotsPerThread; j++) qrel[j] = s_query[threadIdx.x + j * kBlock];
+        __syncthreads();  // s_query may be overwritten by the queue (s_row) from here on
+#pragma unroll
+        for (uint32_t j = 0; j < kSlotsPerThread; j++) {
+            const uint32_t i = threadIdx.x + j * kBlock;
+            if (i >= cnt) break;
             const uint64_t h = base + i;
-            const uint32_t q = qa + s_query[i] - 1u;
+            const uint32_t q = qa + qrel[j] - 1u;
             const uint64_t first = hit_offsets[q];
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
@@ -533,10 +575,13 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                              \
-    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW>), dim3(qgrid), dim3(kBlock), 0, stream, ix, d_start,  \
+    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW>), dim3(qgrid), dim3(kBlock), 0, stream, lv, d_start,  \
                        d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
+        const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.count, ix.sa_samples,
+                            ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
+                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
         if (ix.layout == 0) {

@@ -25,6 +25,11 @@ def test_traffic_from_pmc_counters():
     assert t["read_bytes"] == 2 * 1000.0 * 1024 and t["write_bytes"] == 100.0 * 1024
     assert t["bytes"] == t["read_bytes"] + t["write_bytes"] and t["read_requests"] == 16000.0
     assert bench.traffic_of(pmc, "locate_queue_kernel") is None  # no WRITE_SIZE pass for it: not half a number
+    # two launches that make one step: counters add up
+    pmc["gdx::search_fast_kernel4<32>"] = {"FETCH_SIZE": {"per_launch": 500.0, "launches": 3},
+                                           "WRITE_SIZE": {"per_launch": 50.0, "launches": 3}}
+    both = bench.traffic_of(pmc, "search_fast_kernel|search_pair_kernel")
+    assert both["bytes"] == t["bytes"] + 2 * 500.0 * 1024 + 50.0 * 1024 and len(both["by_kernel"]) == 2
     assert bench.traffic_of(None, "x") is None and bench.traffic_of(pmc, "no_such_kernel") is None
     name = ("void gdx::(anonymous namespace)::search_pair_kernel4<0, 32, 1>(gdx::IndexView, unsigned char const*, "
             "unsigned long const*)")
