@@ -16,6 +16,56 @@
 
 namespace gdx {
 
+// IndexView::perm_*: the alphabet table restricted to the dense symbols 1..4 as two 8-entry byte tables indexed by the
+// low three bits of the IO byte.  Exists when the searchable bytes that share their low three bits are one symbol in
+// at most two spellings that differ in bit 5 only (A / a), which holds for every DNA alphabet of the reference
+// (alphabet.rs:264-345); tried with the exact mask first, then case-insensitively.
+static void make_perm_translation(const uint8_t *io_to_dense, IndexView &view)
+{
+    view.perm_ok = 0;
+    view.perm_code_lo = view.perm_code_hi = view.perm_exp_lo = view.perm_exp_hi = view.perm_mask = 0;
+    for (uint32_t mask : {0xffu, 0xdfu}) {
+        uint8_t code[8], expect[8];
+        bool ok = true;
+        for (uint32_t k = 0; k < 8 && ok; k++) {
+            int e = -1, d = -1;
+            for (uint32_t c = k; c < 256 && ok; c += 8) {
+                const uint32_t dense = io_to_dense[c];
+                if (dense < 1 || dense > 4) continue;
+                if (e < 0) {
+                    e = static_cast<int>(c & mask);
+                    d = static_cast<int>(dense);
+                } else if (e != static_cast<int>(c & mask) || d != static_cast<int>(dense)) {
+                    ok = false;
+                }
+            }
+            if (e < 0) {  // no searchable byte ends in these bits: an entry no byte with these low bits can equal
+                expect[k] = static_cast<uint8_t>(k ^ 1u);
+                code[k] = 0;
+                continue;
+            }
+            for (uint32_t c = k; c < 256 && ok; c += 8) {  // no other byte may pass the test
+                const uint32_t dense = io_to_dense[c];
+                if ((dense < 1 || dense > 4) && static_cast<int>(c & mask) == e) ok = false;
+            }
+            expect[k] = static_cast<uint8_t>(e);
+            code[k] = static_cast<uint8_t>(d - 1);
+        }
+        if (!ok) continue;
+        auto word = [](const uint8_t *b) {
+            return static_cast<uint32_t>(b[0]) | (static_cast<uint32_t>(b[1]) << 8) | (static_cast<uint32_t>(b[2]) << 16) |
+                   (static_cast<uint32_t>(b[3]) << 24);
+        };
+        view.perm_code_lo = word(code);
+        view.perm_code_hi = word(code + 4);
+        view.perm_exp_lo = word(expect);
+        view.perm_exp_hi = word(expect + 4);
+        view.perm_mask = mask * 0x01010101u;
+        view.perm_ok = 1;
+        return;
+    }
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -278,27 +328,25 @@ __global__ __launch_bounds__(kBlock) void derive_jump_level1_kernel(IndexView ix
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
-        uint32_t row = static_cast<uint32_t>(p), code = 0;
-        bool ok = true;
-        for (uint32_t k = 0; k < kJumpSymbols; k++) {
+        uint32_t row = static_cast<uint32_t>(p), code = 0, steps = 0;
+        for (; steps < kJumpSymbols; steps++) {
             uint32_t r;
             const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
-            if (c - 1u >= 4u) {  // sentinel or a symbol outside 1..4
-                ok = false;
-                break;
-            }
-            code |= (c - 1u) << (2u * (kJumpSymbols - 1u - k));
+            if (c - 1u >= 4u) break;  // sentinel or a symbol outside 1..4
+            code |= (c - 1u) << (2u * (kJumpSymbols - 1u - steps));
             row = ix.count[c] + r;
         }
+        // a level-1 code that stops short keeps its leading symbols and their number (bits 8..11 of the valid field):
+        // enough to decide a query with fewer symbols left than that (search_fast_kernel4)
+        const bool ok = steps == kJumpSymbols;
+        const uint32_t flags = ((ok ? 1u : 0u) | (steps << 8)) << 16;
         uint32_t *e = jump + p * words;
         for (uint32_t w = 0; w < words; w++) e[w] = 0u;
-        if (ok) {
-            e[0] = row;
-            if (words == 2) e[1] = code | (1u << 16);
-            else {
-                e[2] = code;
-                e[3] = 1u << 16;
-            }
+        if (ok) e[0] = row;
+        if (words == 2) e[1] = code | flags;
+        else {
+            e[2] = code;
+            e[3] = flags;
         }
     }
 }
@@ -750,6 +798,7 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
         view_.sa_rot = rot;
         view_.sa_limit = static_cast<uint32_t>(0xffffffffull / cfg_.sa_rate);
     }
+    make_perm_translation(cfg_.io_to_dense, view_);
     view_.sigma = sigma;
     view_.nbits = nbits;
     view_.n_searchable = cfg_.n_searchable;

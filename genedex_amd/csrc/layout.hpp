@@ -48,6 +48,8 @@ struct IndexView {
     //    8 bytes: {t1, c1 | valid << 16}                                   1 level
     //   16 bytes: {t1, t2, c1 | c2 << 16, c3 | valid << 16}                 2 levels + lookahead c3
     //   32 bytes: the same + {t3, t4, t5, c4 | c5 << 16}                    5 levels (c_{j+1} is the lookahead of j)
+    // Bits 8..11 of the valid field: how many leading symbols of c1 are real (8 when valid bit 0 is set); an entry
+    // whose first level is cut short by a sentinel or an N still tells whether its row survives that many steps.
     const void *jump;             // null when absent
     uint32_t jump_bytes;          // 0, 8, 16 or 32
     // --- top table: interval after the first top_depth symbols of a DNA query, one cache-resident fetch ----
@@ -57,6 +59,12 @@ struct IndexView {
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
+    // the same table for the four searchable symbols 1..4 in a form v_perm_b32 can apply to four bytes at once
+    // (make_perm_translation, fm_index.hip): byte c is one of them exactly when (c & perm_mask) == exp[c & 7], and its
+    // dense code is then code[c & 7] + 1; exp / code are 8-byte tables held in two registers each.  perm_ok = 0: the
+    // alphabet has no such table (two searchable symbols share their low three bits) and kernels use io_to_dense.
+    uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;
+    int32_t perm_ok;
     // --- sampled suffix array ------------------------------------------------------------
     const uint32_t *sa_samples;   // SA[i] for i % sa_rate == 0
     const uint32_t *border_keys;  // sorted SA indices whose BWT symbol is the sentinel

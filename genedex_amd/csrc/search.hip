@@ -126,6 +126,12 @@ struct SpanWindow {
         } else if (first >= 0) {
             r0 = base[first];
         }
+        finish(r0, r1, s_dense);
+    }
+    // the second half of load(): this lane's raw span words -> translated words, 2-bit form, validity mask
+    __device__ __forceinline__ void finish(uint64_t r0, uint64_t r1, const uint8_t *s_dense)
+    {
+        const uint32_t sub = threadIdx.x & (kGroup - 1u);
         w0 = translate(r0, s_dense);
         if (kWordsPerLane == 2) w1 = translate(r1, s_dense);
         // 2-bit form and the group's validity mask (an OR over the group's lanes by DPP)
@@ -964,18 +970,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 // ---- fast path of the count / locate search ----------------------------------------------------------------------
 // What almost every read of a non-repetitive text does is: top table, then jumps, then the lazy tail -- no pair line
 // is ever touched.  This kernel does only that, which leaves out the second line of registers, the pair-step
-// arithmetic, the N path, hints through LDS and the length order, and therefore runs at more waves per SIMD (the
-// occupancy curve of profiles/r02/experiments.md section 3 extrapolates to 4.5 ms at unlimited parallelism).  A query
-// it cannot finish that way (no top-table hit, an interval wider than four rows, a symbol outside A C G T, a tail the
-// lookahead cannot decide, fewer than eight symbols left on a multi-row interval) is appended to `leftover` untouched
-// and searched by the general kernel afterwards (launch_search_call).  Results for the queries it finishes are the
-// general kernel's, bit for bit.
+// arithmetic, the N path, hints through LDS and the length order: fewer instructions and eight waves per SIMD.  A
+// query it cannot finish that way (no top-table hit, an interval wider than four rows, a symbol outside A C G T among
+// the symbols it looks at, fewer than eight symbols left on a multi-row interval, a tail that runs into a sentinel or
+// an N of the text) is appended to `leftover` untouched and searched by the general kernel afterwards
+// (launch_search_call).  Counts and hits of the queries it finishes are the general kernel's, bit for bit.
 // (the few fields of the IndexView it needs, so that the kernel arguments do not eat the SGPR budget of 8+ waves)
 struct FastView {
     const uint2 *top;
     const void *jump;
     const uint8_t *io_to_dense;
     uint32_t top_depth, sa_inv, sa_rot, sa_limit;
+    uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
 };
 __device__ __forceinline__ bool is_sampled(const FastView &ix, uint32_t i)
 {
@@ -983,7 +989,89 @@ __device__ __forceinline__ bool is_sampled(const FastView &ix, uint32_t i)
     return __builtin_amdgcn_alignbit(m, m, ix.sa_rot) <= ix.sa_limit;
 }
 
-template <int kJump>
+// Instruction count is what bounds this kernel (profiles/r02/experiments.md section 9: its first version, built from
+// SpanWindow, issued 479 VALU instructions per wavefront and round of 16 queries at 100 % VALU utilisation, and a
+// software pipeline with four queries in flight per lane group changed nothing), hence:
+//  * query bytes -> 2-bit codes with v_perm_b32 table lookups on four bytes at once (IndexView::perm_*: an 8-entry
+//    table indexed by the low three bits of the byte, and the byte the entry expects, which makes the test exact)
+//    instead of sixteen LDS reads and nibble arithmetic per lane; alphabets without such a table use LDS as before;
+//  * all eight 16-bit level codes of the window (top-table index, jump levels, lazy tail) come from ONE funnel shift
+//    per lane and four DPP broadcasts instead of two ds_bpermute and ~15 VALU per level;
+//  * a one-row interval with fewer than eight symbols left and no lookahead code (lengths 16 + 40 k + 1..7 with
+//    32-byte entries) is decided by the first level code of its row's entry instead of going to the general kernel.
+struct FastWindow {
+    uint32_t l0, l1, l2, l3;  // level 2 t | level 2 t + 1 << 16 held by lane t of the group (level j = the 2-bit codes
+                              // of the symbols rem - 1 - 8 j .. rem - 8 - 8 j, bits 15:14 = the first of them)
+    uint32_t valid8;          // bit k: every symbol of span word k is one of the four searchable ones
+    uint32_t s0;              // symbols of a level that lie in its first span word (1 .. 8)
+};
+// four query bytes -> their 2-bit codes in 8 bits (byte 0 in bits 1:0); `bad` becomes non-zero on any other byte
+__device__ __forceinline__ uint32_t fast_pack4(const FastView &ix, uint32_t c, uint32_t &bad)
+{
+    const uint32_t sel = c & 0x07070707u;
+    const uint32_t code = __builtin_amdgcn_perm(ix.perm_code_hi, ix.perm_code_lo, sel);
+    const uint32_t expect = __builtin_amdgcn_perm(ix.perm_exp_hi, ix.perm_exp_lo, sel);
+    bad |= (c & ix.perm_mask) ^ expect;
+    uint32_t t = (code << 6) | code;
+    t = (t << 12) | t;
+    return (t >> 18) & 0xffu;
+}
+__device__ __forceinline__ uint32_t fast_pack4_lds(const uint8_t *s_dense, uint32_t c, uint32_t &bad)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t d = static_cast<uint32_t>(s_dense[(c >> (8u * k)) & 0xffu]) - 1u;
+        bad |= d & ~3u;
+        out |= (d & 3u) << (2u * k);
+    }
+    return out;
+}
+// positions the window so that level 0 starts at symbol rem - 1 (rem >= 1): each lane loads and translates two of
+// the eight span words (as SpanWindow::load), then the levels are cut out of the group's 128-bit code string
+template <bool kPerm>
+__device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint8_t *s_dense, const uint64_t *wbase,
+                                                  uint32_t off0, uint32_t rem, uint32_t sub)
+{
+    const uint32_t b = off0 + rem - 1u;
+    const int32_t first = static_cast<int32_t>(b >> 3) - static_cast<int32_t>(sub) * 2;
+    u32x4 raw = {0u, 0u, 0u, 0u};  // x, y = word first - 1 (span word 2 sub + 1); z, w = word first (span word 2 sub)
+    if (first >= 1) {
+        raw = *reinterpret_cast<const u32x4 *>(wbase + (first - 1));
+    } else if (first == 0) {
+        const uint64_t r0 = wbase[0];
+        raw.z = static_cast<uint32_t>(r0);
+        raw.w = static_cast<uint32_t>(r0 >> 32);
+    }
+    uint32_t bad0 = 0, bad1 = 0, p;
+    if (kPerm) {
+        p = fast_pack4(ix, raw.z, bad0) | (fast_pack4(ix, raw.w, bad0) << 8) | (fast_pack4(ix, raw.x, bad1) << 16) |
+            (fast_pack4(ix, raw.y, bad1) << 24);
+    } else {
+        p = fast_pack4_lds(s_dense, raw.z, bad0) | (fast_pack4_lds(s_dense, raw.w, bad0) << 8) |
+            (fast_pack4_lds(s_dense, raw.x, bad1) << 16) | (fast_pack4_lds(s_dense, raw.y, bad1) << 24);
+    }
+    uint32_t m = ((bad0 == 0u && first >= 0) ? 1u : 0u) | ((bad1 == 0u && first >= 1) ? 2u : 0u);
+    m <<= 2u * sub;
+    m |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0xB1, 0xF, 0xF, true));
+    m |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x4E, 0xF, 0xF, true));
+    FastWindow w;
+    w.valid8 = m;
+    w.s0 = (b & 7u) + 1u;
+    // lane t: words 2 t (low half of p), 2 t + 1 (high half) and, from lane t + 1, word 2 t + 2
+    const uint32_t nxt = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(p), 0xF9, 0xF, 0xF, true));  // quad_perm [1,2,3,3]
+    const uint32_t even = __builtin_amdgcn_alignbit(p, p, 16);       // word 2 t << 16 | word 2 t + 1
+    const uint32_t odd = (p & 0xffff0000u) | (nxt & 0xffffu);         // word 2 t + 1 << 16 | word 2 t + 2
+    const uint32_t sh = 2u * w.s0;                                    // 2 .. 16
+    const uint32_t lv = ((even >> sh) & 0xffffu) | ((odd >> sh) << 16);
+    w.l0 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0x00, 0xF, 0xF, true));
+    w.l1 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0x55, 0xF, 0xF, true));
+    w.l2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0xAA, 0xF, 0xF, true));
+    w.l3 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0xFF, 0xF, 0xF, true));
+    return w;
+}
+
+template <int kJump, bool kPerm>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
     FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
@@ -995,12 +1083,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_left[kMaxRange];
     __shared__ uint32_t s_nleft, s_left_base;
-    for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    if (!kPerm)
+        for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     if (threadIdx.x == 0) s_nleft = 0;
     __syncthreads();
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
     const bool hinting = out_rec != nullptr;
+    const uint32_t depth = ix.top_depth;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
         const uint64_t base = rg * range;
@@ -1009,69 +1099,106 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t q = static_cast<uint32_t>(base + slot);
             const uint64_t begin = qbeg[q];
             const uint64_t len = qend[q] - begin;
-            bool bail = !(len >= 16u && len >= ix.top_depth && len < (1ull << 21));
+            bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0, hr = 0xffffffffu, ho = 0;
-            SpanWindow<kGroup, false> win;
-            win.init(qbuf, begin);
+            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
+            FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
+            uint32_t shift = 0;  // levels of the window already used up: level i of the round is window level shift + i
+            bool fresh = false;  // the window is positioned for the round to come
             if (!bail) {
                 rem = static_cast<uint32_t>(len);
-                win.load(rem, s_dense);
-                const uint32_t l1 = win.level(rem), l2 = win.level(rem - 8u);
-                if (l1 == kNoCode || l2 == kNoCode) {
+                w = fast_window<kPerm>(ix, s_dense, wbase, off0, rem, sub);
+                const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
+                if ((w.valid8 & need) != need) {
                     bail = true;
                 } else {
-                    const uint2 e = ix.top[((l1 << 16) | l2) >> (32u - 2u * ix.top_depth)];
+                    const uint2 e = ix.top[__builtin_amdgcn_alignbit(w.l0, w.l0, 16) >> (32u - 2u * depth)];
                     lo = e.x;
                     hi = e.y;
-                    rem -= ix.top_depth;
+                    rem -= depth;
+                    shift = depth >> 3;
+                    fresh = (depth & 7u) == 0u;  // depth 8 or 16: the jump levels are levels 1.. or 2.. of this window
                 }
             }
             while (!bail && rem > 0u && lo != hi) {
-                if (hi - lo > static_cast<uint32_t>(kGroup) || rem < kJumpSymbols) {
+                const uint32_t rows = hi - lo;
+                if (rows > static_cast<uint32_t>(kGroup) || (rem < kJumpSymbols && rows != 1u)) {
                     bail = true;
                     break;
                 }
-                if (!win.covers(rem)) win.load(rem, s_dense);
-                uint32_t qa = win.level(rem);
-                if (qa == kNoCode) {
-                    bail = true;
-                    break;
+                if (!fresh) {
+                    w = fast_window<kPerm>(ix, s_dense, wbase, off0, rem, sub);
+                    shift = 0;
                 }
+                fresh = false;
+                // the level string from level `shift` on: a0 = levels 0 | 1 << 16 of the round, a1 = 2 | 3, a2 = 4 | 5
+                uint32_t a0, a1, a2;
+                if (shift == 2u) {
+                    a0 = w.l1;
+                    a1 = w.l2;
+                    a2 = w.l3;
+                } else if (shift == 1u) {
+                    a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
+                    a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                    a2 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                } else {
+                    a0 = w.l0;
+                    a1 = w.l1;
+                    a2 = w.l2;
+                }
+                const uint32_t v8 = w.valid8 >> shift;                            // bit i: first word of level i valid
+                const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));        // bit i: level i valid
                 const uint32_t n_lv = rem >> 3 < static_cast<uint32_t>(kLevels) ? rem >> 3 : static_cast<uint32_t>(kLevels);
-                const bool tail = (rem & 7u) != 0u && (rem >> 3) < static_cast<uint32_t>(kCodes);
-                if (!win.covers(tail ? 8u : rem - (n_lv - 1u) * kJumpSymbols)) win.load(rem, s_dense);
-                uint32_t qb = 0, qc = 0, qok = 1u, tail16 = kNoCode;
-#pragma unroll
-                for (int j = 1; j < kLevels; j++) {
-                    if (rem >= (j + 1u) * kJumpSymbols) {
-                        const uint32_t v = win.level(rem - j * kJumpSymbols);
-                        if (v != kNoCode) {
-                            if (j == 1) qa |= v << 16;
-                            if (j == 2) qb = v;
-                            if (j == 3) qc = v;
-                            if (j == 4) qc |= v << 16;
-                            qok |= 1u << j;
-                        }
-                    }
+                if (n_lv != 0u && (vl & 1u) == 0u) {  // a symbol outside A C G T among the next eight
+                    bail = true;
+                    break;
                 }
-                if (tail) {
-                    const uint32_t v = win.level(8u);
-                    if (v != kNoCode) tail16 = (v << (2u * (8u - (rem & 7u)))) & 0xffffu;
-                }
+                const uint32_t qa = a0, qb = a1 & 0xffffu, qc = __builtin_amdgcn_alignbit(a2, a1, 16);
+                const uint32_t qok = vl & ((1u << n_lv) - 1u);
+                // the symbols after the n_lv full levels (fewer than eight), in the top bits of the level that follows
+                const uint32_t n_tail = rem - n_lv * kJumpSymbols;  // only used when < 8
+                const uint32_t tw = (n_lv >> 1) == 0u ? a0 : ((n_lv >> 1) == 1u ? a1 : a2);
+                const uint32_t tail16 = (n_lv & 1u) ? tw >> 16 : tw & 0xffffu;
+                const bool tail_ok = ((v8 >> n_lv) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_lv + 1u)) & 1u) != 0u);
+
                 const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
                 const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
                 const u32x4 *pa = kJump == 8 ? tab + (row >> 1) : tab + static_cast<uint64_t>(row) * (kJump / 16);
                 u32x4 e0, e1;
-                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(true) : 0ull, e0, e1);
-                uint32_t valid, da, db = 0, dc = 0;
+                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(n_lv != 0u) : 0ull, e0, e1);
+                uint32_t valid, c1;
                 if (kJump == 8) {
-                    const uint32_t w = (row & 1u) ? e0.w : e0.y;
-                    da = (w ^ qa) & 0xffffu;
-                    valid = w >> 16;
+                    const uint32_t ew = (row & 1u) ? e0.w : e0.y;
+                    c1 = ew & 0xffffu;
+                    valid = ew >> 16;
+                } else {
+                    c1 = e0.z & 0xffffu;
+                    valid = e0.w >> 16;
+                }
+                const uint32_t tmask = (0xffffu << (16u - 2u * (n_tail & 7u))) & 0xffffu;
+                if (n_lv == 0u) {  // one row, fewer than eight symbols: the row's first level code decides
+                    if (!tail_ok || n_tail > ((valid >> 8) & 0xfu)) {  // (the entry says how many symbols of c1 are real)
+                        bail = true;
+                        break;
+                    }
+                    if (((c1 ^ tail16) & tmask) == 0u) {
+                        if (hinting && hr == 0xffffffffu) {
+                            hr = lo;
+                            ho = rem;
+                        }
+                    } else {
+                        hi = lo;
+                    }
+                    rem = 0;
+                    break;
+                }
+                uint32_t da, db = 0, dc = 0;
+                if (kJump == 8) {
+                    da = (c1 ^ qa) & 0xffffu;
                 } else {
                     da = e0.z ^ qa;
                     db = (e0.w ^ qb) & 0xffffu;
-                    valid = e0.w >> 16;
                     if (kLevels == 5) dc = e1.w ^ qc;
                 }
                 uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
@@ -1089,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     break;
                 }
                 const bool mine = lvl == best;
-                if (hinting && hr == 0xffffffffu && hi - lo == 1u && is_sampled(ix, lo)) {
+                if (hinting && hr == 0xffffffffu && rows == 1u && is_sampled(ix, lo)) {
                     hr = lo;
                     ho = rem;
                 }
@@ -1121,33 +1248,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         }
                     }
                 }
-                if (one_row && rem > 0u && rem < kJumpSymbols) {
-                    if (best >= static_cast<uint32_t>(kCodes)) {  // no lookahead left in this entry
-                        bail = true;
-                        break;
-                    }
+                // lazy tail: the code that follows the levels just taken holds the next eight symbols of this row's path
+                if (one_row && rem > 0u && rem < kJumpSymbols && best < static_cast<uint32_t>(kCodes)) {
                     uint32_t nxt = e0.z >> 16;
                     nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
                     if (kLevels == 5) {
                         nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
                         nxt = best == 4u ? (e1.w >> 16) : nxt;
                     }
-                    const bool can = mine && ((valid >> best) & 1u) && tail16 != kNoCode;
-                    const uint32_t tmask = (0xffffu << (16u - 2u * rem)) & 0xffffu;
+                    const bool can = mine && ((valid >> best) & 1u) && tail_ok;
                     const uint32_t verdict = group_max<kGroup>(can ? (((nxt ^ tail16) & tmask) == 0u ? 2u : 1u) : 0u);
                     if (verdict == 0u) {
-                        bail = true;
-                        break;
-                    }
-                    if (verdict == 2u) {
-                        if (hinting && hr == 0xffffffffu) {
-                            hr = lo;
-                            ho = rem;
+                        if (!tail_ok) {
+                            bail = true;
+                            break;
                         }
+                        // the lookahead code is cut short: the next round asks the row's own entry
                     } else {
-                        hi = lo;
+                        if (verdict == 2u) {
+                            if (hinting && hr == 0xffffffffu) {
+                                hr = lo;
+                                ho = rem;
+                            }
+                        } else {
+                            hi = lo;
+                        }
+                        rem = 0;
                     }
-                    rem = 0;
                 }
             }
             if (writer) {
@@ -1454,14 +1581,30 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         if (fast) {
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
-            const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit};
-#define GDX_FAST_LAUNCH(J)                                                                                              \
-    hipLaunchKernelGGL((search_fast_kernel4<J>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, c.d_qend, \
-                       nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left)
-            if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32);
-            else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16);
-            else GDX_FAST_LAUNCH(8);
+            const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit,
+                              ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+            static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
+#define GDX_FAST_LAUNCH(J, PERM)                                                                                      \
+    hipLaunchKernelGGL((search_fast_kernel4<J, PERM>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, \
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left)
+#define GDX_FAST_LAUNCH_P(PERM)                                  \
+    do {                                                         \
+        if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32, PERM);      \
+        else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16, PERM); \
+        else GDX_FAST_LAUNCH(8, PERM);                           \
+    } while (0)
+            if (ix.perm_ok && !env_no_perm) GDX_FAST_LAUNCH_P(true);
+            else GDX_FAST_LAUNCH_P(false);
+#undef GDX_FAST_LAUNCH_P
 #undef GDX_FAST_LAUNCH
+            static const bool env_stats = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list
+            if (env_stats) {
+                uint32_t n_left = 0;
+                GDX_HIP(hipMemcpyAsync(&n_left, d_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                GDX_HIP(hipStreamSynchronize(stream));
+                fprintf(stderr, "gdx: fast path left %u of %llu queries to the general kernel\n", n_left,
+                        static_cast<unsigned long long>(nq));
+            }
             ca_general.active_in = d_left + 4;  // the general kernel below searches the leftover list
             ca_general.n_active_in = d_left;
         }

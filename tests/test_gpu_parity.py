@@ -691,6 +691,49 @@ def test_fused_record_path_equals_oracle(seed, search_variant):
     assert torch.equal(counts, counts2)
 
 
+_TRANSLATIONS = {
+    # how the fast-path kernel turns query bytes into 2-bit codes (IndexView::perm_*): name -> (alphabet, symbols of
+    # the texts, symbols of random queries -- some of them outside the alphabet or not searchable)
+    "case_insensitive": (alph.ascii_dna_with_n, b"ACGTacgtNn", b"ACGTacgtN!"),       # v_perm tables, mask 0xdf
+    "case_sensitive": (lambda: alph.Alphabet.from_io_symbols(b"ACGTN", 1), b"ACGTN", b"ACGTacgtN"),  # mask 0xff
+    # A, I, Q, Y share their low three bits: no v_perm table, the kernel translates through the table in LDS
+    "clashing_low_bits": (lambda: alph.Alphabet.from_io_symbols(b"AIQYN", 1), b"AIQYN", b"AIQYNC"),
+    "bytes_0_to_4": (lambda: alph.u8_until(4), bytes(range(5)), bytes(range(7))),
+}
+
+
+@pytest.mark.parametrize("name", list(_TRANSLATIONS))
+def test_fast_path_query_translation(name):
+    """The fast-path search kernel translates query bytes with v_perm_b32 tables when the alphabet allows it and
+    through the 256-byte table otherwise; counts, statuses and hits are the oracle's either way, also for queries
+    with symbols that are not searchable or not in the alphabet (alphabet.rs:195-198: status, no result)."""
+    make, text_symbols, query_symbols = _TRANSLATIONS[name]
+    a = make()
+    rng = np.random.default_rng(sum(name.encode()))
+    texts = [bytes(text_symbols[i] for i in rng.integers(0, len(text_symbols), int(rng.integers(1000, 30000))))
+             for _ in range(4)]
+    g, c = both(texts, a, sa_rate=3)
+    assert g.aux()["jump_entry_bytes"] == 32 and g.aux()["top_table_depth"] >= 1
+    qs = []
+    for _ in range(3000):
+        t = texts[int(rng.integers(0, len(texts)))]
+        pos = int(rng.integers(0, len(t)))
+        qs.append(t[pos:pos + int(rng.integers(0, 90))])
+    for _ in range(600):
+        qs.append(bytes(query_symbols[i] for i in rng.integers(0, len(query_symbols), int(rng.integers(0, 40)))))
+    qbuf, qoff = pack_queries(qs)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    ok = cst == 0
+    assert ok.sum() > len(qs) // 2 and (~ok).sum() > 10
+    counts, st = g.count_raw(qbuf, qoff, strict=False)
+    assert st.tolist() == cst.tolist()
+    assert counts[ok].tolist() == (ce - cs)[ok].tolist()
+    off, t_, p_, st2 = g.locate_raw(qbuf, qoff, strict=False)
+    assert st2.tolist() == cst.tolist()
+    co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+    assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+
+
 @pytest.mark.parametrize("chunk", [1, 7, 8, 16, 32, 40, 1000])
 def test_cursor_strings_in_chunks_equal_fused_search(chunk, search_variant):
     """gdx_cursor_extend_front_strings_dev: queries fed to cursor_empty cursors `chunk` symbols at a time from the
