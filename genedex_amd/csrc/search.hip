@@ -1029,27 +1029,36 @@ __device__ __forceinline__ uint32_t fast_pack4_lds(const uint8_t *s_dense, uint3
 }
 // positions the window so that level 0 starts at symbol rem - 1 (rem >= 1): each lane loads and translates two of
 // the eight span words (as SpanWindow::load), then the levels are cut out of the group's 128-bit code string
-template <bool kPerm>
+// kXlate: 0 = bytes through the table in LDS, 1 = bytes through the v_perm tables, 2 = packed queries (the span words
+// are 16-bit units of the buffer, wbase points at the unit of the query's first symbol and off0 counts symbols)
+template <int kXlate>
 __device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint8_t *s_dense, const uint64_t *wbase,
                                                   uint32_t off0, uint32_t rem, uint32_t sub)
 {
     const uint32_t b = off0 + rem - 1u;
     const int32_t first = static_cast<int32_t>(b >> 3) - static_cast<int32_t>(sub) * 2;
-    u32x4 raw = {0u, 0u, 0u, 0u};  // x, y = word first - 1 (span word 2 sub + 1); z, w = word first (span word 2 sub)
-    if (first >= 1) {
-        raw = *reinterpret_cast<const u32x4 *>(wbase + (first - 1));
-    } else if (first == 0) {
-        const uint64_t r0 = wbase[0];
-        raw.z = static_cast<uint32_t>(r0);
-        raw.w = static_cast<uint32_t>(r0 >> 32);
-    }
     uint32_t bad0 = 0, bad1 = 0, p;
-    if (kPerm) {
-        p = fast_pack4(ix, raw.z, bad0) | (fast_pack4(ix, raw.w, bad0) << 8) | (fast_pack4(ix, raw.x, bad1) << 16) |
-            (fast_pack4(ix, raw.y, bad1) << 24);
+    if (kXlate == 2) {
+        const uint16_t *units = reinterpret_cast<const uint16_t *>(wbase);
+        const uint32_t u0 = first >= 0 ? units[first] : 0u;
+        const uint32_t u1 = first >= 1 ? units[first - 1] : 0u;
+        p = u0 | (u1 << 16);
     } else {
-        p = fast_pack4_lds(s_dense, raw.z, bad0) | (fast_pack4_lds(s_dense, raw.w, bad0) << 8) |
-            (fast_pack4_lds(s_dense, raw.x, bad1) << 16) | (fast_pack4_lds(s_dense, raw.y, bad1) << 24);
+        u32x4 raw = {0u, 0u, 0u, 0u};  // x, y = word first - 1 (span word 2 sub + 1); z, w = word first (span word 2 sub)
+        if (first >= 1) {
+            raw = *reinterpret_cast<const u32x4 *>(wbase + (first - 1));
+        } else if (first == 0) {
+            const uint64_t r0 = wbase[0];
+            raw.z = static_cast<uint32_t>(r0);
+            raw.w = static_cast<uint32_t>(r0 >> 32);
+        }
+        if (kXlate == 1) {
+            p = fast_pack4(ix, raw.z, bad0) | (fast_pack4(ix, raw.w, bad0) << 8) | (fast_pack4(ix, raw.x, bad1) << 16) |
+                (fast_pack4(ix, raw.y, bad1) << 24);
+        } else {
+            p = fast_pack4_lds(s_dense, raw.z, bad0) | (fast_pack4_lds(s_dense, raw.w, bad0) << 8) |
+                (fast_pack4_lds(s_dense, raw.x, bad1) << 16) | (fast_pack4_lds(s_dense, raw.y, bad1) << 24);
+        }
     }
     uint32_t m = ((bad0 == 0u && first >= 0) ? 1u : 0u) | ((bad1 == 0u && first >= 1) ? 2u : 0u);
     m <<= 2u * sub;
@@ -1071,7 +1080,7 @@ __device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint
     return w;
 }
 
-template <int kJump, bool kPerm>
+template <int kJump, int kXlate>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
     FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
@@ -1083,7 +1092,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_left[kMaxRange];
     __shared__ uint32_t s_nleft, s_left_base;
-    if (!kPerm)
+    if (kXlate == 0)
         for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     if (threadIdx.x == 0) s_nleft = 0;
     __syncthreads();
@@ -1101,14 +1110,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint64_t len = qend[q] - begin;
             bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0, hr = 0xffffffffu, ho = 0;
-            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint64_t *wbase = kXlate == 2 ? reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3))
+                                                : reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0;  // levels of the window already used up: level i of the round is window level shift + i
             bool fresh = false;  // the window is positioned for the round to come
             if (!bail) {
                 rem = static_cast<uint32_t>(len);
-                w = fast_window<kPerm>(ix, s_dense, wbase, off0, rem, sub);
+                w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                 const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
                 if ((w.valid8 & need) != need) {
                     bail = true;
@@ -1128,7 +1138,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     break;
                 }
                 if (!fresh) {
-                    w = fast_window<kPerm>(ix, s_dense, wbase, off0, rem, sub);
+                    w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                     shift = 0;
                 }
                 fresh = false;
@@ -1554,9 +1564,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         const uint32_t defer_after = c.d_step_stats != nullptr ? 0u
                                      : static_cast<uint32_t>(qo.search_defer_after >= 0 ? qo.search_defer_after : env_defer);
 #define GDX_PAIR_LAUNCH(KERNEL)                                                                                     \
-    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(kBlock), lds_pad, stream, ix, c.d_qbuf, c.d_qbeg, c.d_qend, nq,   \
-                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, range, schedule, c.d_hint, c.d_rec, \
-                       ca_general, defer_after)
+    hipLaunchKernelGGL(KERNEL, dim3(g_blocks), dim3(kBlock), lds_pad, stream, ix, c.d_qbuf, c.d_qbeg, c.d_qend, nq, \
+                       c.d_start, c.d_end, c.d_count, c.d_status, c.d_step_stats, g_range, schedule, c.d_hint,      \
+                       c.d_rec, ca_general, defer_after)
 #define GDX_PAIR_LAUNCH_W(KERNEL, P, M)                                    \
     do {                                                                   \
         if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((KERNEL<P, 32, M>));      \
@@ -1573,28 +1583,36 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         // repetitive.  It finishes what needs no pair line and lists the rest, which the general kernel then searches
         // from the list.  QueryOptions::search_fast / GDX_SEARCH_FAST=0 switch it off.
         static const int env_fast = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : 1; }();
-        const bool fast = c.mode == 1 && !c.packed && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
+        const bool fast = c.mode == 1 && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
                           defer_after == 0u && ix.top != nullptr && ix.top_depth >= 1u && ix.jump != nullptr &&
                           ca.active_in == nullptr && c.d_hint == nullptr && c.d_start == nullptr && c.d_end == nullptr &&
                           (qo.search_fast >= 0 ? qo.search_fast != 0 : env_fast != 0) && nq < 0xffffffffull;
         CursorArgs ca_general = ca;
+        unsigned g_blocks = blocks;  // grid and range size of the general kernel
+        uint32_t g_range = range;
         if (fast) {
+            // the leftover list is short (0.3 % of the reads of a non-repetitive text) and its length is only known on
+            // the device: small ranges spread it over the chip, a capped grid strides over whatever there is
+            g_range = 256;
+            const uint64_t g_ranges = (nq + g_range - 1) / g_range;
+            g_blocks = static_cast<unsigned>(g_ranges < 8192 ? g_ranges : 8192);
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
             const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit,
                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
-#define GDX_FAST_LAUNCH(J, PERM)                                                                                      \
-    hipLaunchKernelGGL((search_fast_kernel4<J, PERM>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, \
+#define GDX_FAST_LAUNCH(J, XLATE)                                                                                      \
+    hipLaunchKernelGGL((search_fast_kernel4<J, XLATE>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, \
                        c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left)
-#define GDX_FAST_LAUNCH_P(PERM)                                  \
-    do {                                                         \
-        if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32, PERM);      \
-        else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16, PERM); \
-        else GDX_FAST_LAUNCH(8, PERM);                           \
+#define GDX_FAST_LAUNCH_P(XLATE)                                  \
+    do {                                                          \
+        if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32, XLATE);      \
+        else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16, XLATE); \
+        else GDX_FAST_LAUNCH(8, XLATE);                           \
     } while (0)
-            if (ix.perm_ok && !env_no_perm) GDX_FAST_LAUNCH_P(true);
-            else GDX_FAST_LAUNCH_P(false);
+            if (c.packed) GDX_FAST_LAUNCH_P(2);
+            else if (ix.perm_ok && !env_no_perm) GDX_FAST_LAUNCH_P(1);
+            else GDX_FAST_LAUNCH_P(0);
 #undef GDX_FAST_LAUNCH_P
 #undef GDX_FAST_LAUNCH
             static const bool env_stats = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list
