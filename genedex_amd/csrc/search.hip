@@ -1031,27 +1031,37 @@ __device__ __forceinline__ uint32_t fast_pack4_lds(const uint8_t *s_dense, uint3
 // the eight span words (as SpanWindow::load), then the levels are cut out of the group's 128-bit code string
 // kXlate: 0 = bytes through the table in LDS, 1 = bytes through the v_perm tables, 2 = packed queries (the span words
 // are 16-bit units of the buffer, wbase points at the unit of the query's first symbol and off0 counts symbols)
+// the loads of fast_window: this lane's two span words, untranslated (packed queries: both units in .x)
 template <int kXlate>
-__device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint8_t *s_dense, const uint64_t *wbase,
-                                                  uint32_t off0, uint32_t rem, uint32_t sub)
+__device__ __forceinline__ u32x4 fast_window_load(const uint64_t *wbase, uint32_t off0, uint32_t rem, uint32_t sub)
+{
+    const uint32_t b = off0 + rem - 1u;
+    const int32_t first = static_cast<int32_t>(b >> 3) - static_cast<int32_t>(sub) * 2;
+    u32x4 raw = {0u, 0u, 0u, 0u};  // x, y = word first - 1 (span word 2 sub + 1); z, w = word first (span word 2 sub)
+    if (kXlate == 2) {
+        const uint16_t *units = reinterpret_cast<const uint16_t *>(wbase);
+        const uint32_t u0 = first >= 0 ? units[first] : 0u;
+        const uint32_t u1 = first >= 1 ? units[first - 1] : 0u;
+        raw.x = u0 | (u1 << 16);
+    } else if (first >= 1) {
+        raw = *reinterpret_cast<const u32x4 *>(wbase + (first - 1));
+    } else if (first == 0) {
+        const uint64_t r0 = wbase[0];
+        raw.z = static_cast<uint32_t>(r0);
+        raw.w = static_cast<uint32_t>(r0 >> 32);
+    }
+    return raw;
+}
+template <int kXlate>
+__device__ __forceinline__ FastWindow fast_window_finish(const FastView &ix, const uint8_t *s_dense, u32x4 raw,
+                                                         uint32_t off0, uint32_t rem, uint32_t sub)
 {
     const uint32_t b = off0 + rem - 1u;
     const int32_t first = static_cast<int32_t>(b >> 3) - static_cast<int32_t>(sub) * 2;
     uint32_t bad0 = 0, bad1 = 0, p;
     if (kXlate == 2) {
-        const uint16_t *units = reinterpret_cast<const uint16_t *>(wbase);
-        const uint32_t u0 = first >= 0 ? units[first] : 0u;
-        const uint32_t u1 = first >= 1 ? units[first - 1] : 0u;
-        p = u0 | (u1 << 16);
+        p = raw.x;
     } else {
-        u32x4 raw = {0u, 0u, 0u, 0u};  // x, y = word first - 1 (span word 2 sub + 1); z, w = word first (span word 2 sub)
-        if (first >= 1) {
-            raw = *reinterpret_cast<const u32x4 *>(wbase + (first - 1));
-        } else if (first == 0) {
-            const uint64_t r0 = wbase[0];
-            raw.z = static_cast<uint32_t>(r0);
-            raw.w = static_cast<uint32_t>(r0 >> 32);
-        }
         if (kXlate == 1) {
             p = fast_pack4(ix, raw.z, bad0) | (fast_pack4(ix, raw.w, bad0) << 8) | (fast_pack4(ix, raw.x, bad1) << 16) |
                 (fast_pack4(ix, raw.y, bad1) << 24);
@@ -1078,6 +1088,12 @@ __device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint
     w.l2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0xAA, 0xF, 0xF, true));
     w.l3 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0xFF, 0xF, 0xF, true));
     return w;
+}
+template <int kXlate>
+__device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint8_t *s_dense, const uint64_t *wbase,
+                                                  uint32_t off0, uint32_t rem, uint32_t sub)
+{
+    return fast_window_finish<kXlate>(ix, s_dense, fast_window_load<kXlate>(wbase, off0, rem, sub), off0, rem, sub);
 }
 
 template <int kJump, int kXlate>
