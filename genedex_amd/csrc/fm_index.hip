@@ -1020,6 +1020,10 @@ QueryOptions FmIndex::query_options() const
     q.search_fast = q_fast_.load();
     // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
     if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;
+    // default: the fast-path kernel first, unless the top table is so shallow for this text that most reads leave it
+    // on more rows than a jump takes -- their intervals narrow fastest on pair lines (top 12 / 8-byte jumps at hg38
+    // scale: 21.8 ms without, 26.5 ms with the fast path in front)
+    if (q.search_fast < 0) q.search_fast = aux_report_.wide_fraction > 0.5 ? 0 : 1;
     return q;
 }
 

@@ -19,7 +19,7 @@ struct QueryOptions {
     int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
     int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
     int locate_jump_walk = -1; // -1 default (1: the queue kernel walks through the jump table), 0 rank lines only
-    int search_fast = -1;         // -1 default (1): count / locate searches run the fast-path kernel first, 0 = never
+    int search_fast = -1;         // count / locate searches run the fast-path kernel first (1) or not (0); -1 = per index
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
                                   // finished in the block's straggler pass; 0 = never
 };
@@ -32,7 +32,17 @@ struct CursorArgs {
     const uint32_t *n_active_in = nullptr;
     uint32_t *active_out = nullptr;
     uint32_t *n_active_out = nullptr;
+    // where the fast-path kernel left the listed queries: {lo, hi, symbols left, 1} to go on from there, {.., 0} to
+    // start from the beginning; indexed by query, null = all start from the beginning
+    const uint4 *resume_state = nullptr;
 };
+
+// Search records (16 bytes per query, mode 1): {start, end, hint row, hint symbols | status << 24} -- end - start is
+// the count; with a hint (row != 0xffffffff, count 1) the hit is SA[hint row] - hint symbols.  A MASKED record
+// (kRecMasked set in the fourth word; search_fast_kernel4 on reads that end on several rows) is {first row, first row
+// + count, mask, symbols | kRecMasked}: the hits are SA[first row + j] - symbols for the set bits j of the mask, in
+// that order, which is the reference's.
+constexpr uint32_t kRecMasked = 1u << 23;
 
 // One search launch.  Query i = d_qbuf[d_qbeg[i] .. d_qend[i]) (d_qend = d_qbeg + 1 for the usual offsets array).
 // mode 0: exact intervals (cursors_for_many_queries); mode 1: count / locate (end - start is the count, start / end

@@ -284,7 +284,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (rec != nullptr) {
                 const uint4 r = rec[q];
                 row = r.x + static_cast<uint32_t>(h - first);
-                if (r.z != 0xffffffffu && r.y - r.x == 1u) {
+                if (r.w & kRecMasked) {  // the (h - first)-th surviving row of the mask, `symbols` steps before the hit
+                    uint32_t m = r.z;
+                    for (uint32_t t = static_cast<uint32_t>(h - first); t > 0u; t--) m &= m - 1u;
+                    row = r.x + static_cast<uint32_t>(__builtin_ctz(m | 0x80000000u));
+                    back = r.w & 0x1fffffu;
+                } else if (r.z != 0xffffffffu && r.y - r.x == 1u) {
                     row = r.z;
                     back = r.w & 0xffffffu;
                 }

@@ -503,6 +503,14 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         if (kDefer && phase == 1) parked = s_defer[slot];
         const uint64_t at = base + (ordered ? s_perm[phase == 0 ? slot : 0u] : slot);
         const uint64_t q = (kDefer && phase == 1) ? static_cast<uint64_t>(parked.x) : (active ? active[at] : at);
+        bool resumed = kDefer && phase == 1;
+        if (kMode != 2 && ca.resume_state != nullptr && !resumed) {  // a leftover of the fast path, taken up where it stood
+            const uint4 st = ca.resume_state[q];
+            if (st.w == 1u) {
+                parked = make_uint4(static_cast<uint32_t>(q), st.x, st.y, st.z);
+                resumed = true;
+            }
+        }
         const uint64_t begin = qbeg[q], end = qend[q];
         const uint64_t len = end - begin;
         // (packed queries skip the configured lookup table: the steps it replaces give the same interval)
@@ -523,19 +531,19 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         uint32_t rem = 0;  // symbols still to consume, right to left
         SpanWindow<kGroup, kPacked> win;
         win.init(qbuf, begin);
-        if (kDefer && phase == 1) {  // a parked query resumes where it stood (it had no status and no hint)
+        if (resumed) {  // a parked query resumes where it stood (it had no status and no hint)
             lo = parked.y;
             hi = parked.z;
             rem = parked.w;
             status = GDX_Q_OK;
             stopped = false;
-            win.load(rem, s_dense);
+            if (rem > 0u) win.load(rem, s_dense);
         }
         // The top table is tried first when it is deeper than the configured lookup table: a hit means the last
         // top_depth symbols are all in 1..4, hence (with at least four searchable symbols) valid and searchable,
         // which is everything the reference checks for its t-symbol suffix (lookup_table.rs:99-113); the interval
         // is the one the configured table plus the LF steps in between would give.
-        bool topped = kDefer && phase == 1;
+        bool topped = resumed;
         if (!topped && ix.top != nullptr && ix.top_depth > t && k >= 4u && len >= ix.top_depth && len <= 0xffffffffull &&
             (kMode != 2 || (fresh && !stopped))) {
             const uint32_t lo0 = lo, hi0 = hi;
@@ -1100,9 +1108,10 @@ template <int kJump, int kXlate>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
     FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
-    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state)
 {
     constexpr int kGroup = 4;
+    constexpr uint32_t kWideRows = 16;  // widest interval a round takes: four rows per lane
     constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : 5);
     constexpr int kCodes = kJump == 8 ? 1 : (kJump == 16 ? 3 : 5);
     __shared__ uint8_t s_dense[256];
@@ -1132,6 +1141,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0;  // levels of the window already used up: level i of the round is window level shift + i
             bool fresh = false;  // the window is positioned for the round to come
+            bool progressed = false;  // lo, hi, rem describe the search after the top table and whole rounds
+            bool masked = false;      // the result is a masked record: hr = mask of surviving rows, ho = symbols left
             if (!bail) {
                 rem = static_cast<uint32_t>(len);
                 w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
@@ -1145,11 +1156,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     rem -= depth;
                     shift = depth >> 3;
                     fresh = (depth & 7u) == 0u;  // depth 8 or 16: the jump levels are levels 1.. or 2.. of this window
+                    progressed = true;
                 }
             }
             while (!bail && rem > 0u && lo != hi) {
                 const uint32_t rows = hi - lo;
-                if (rows > static_cast<uint32_t>(kGroup) || (rem < kJumpSymbols && rows != 1u)) {
+                if (rows > kWideRows) {
                     bail = true;
                     break;
                 }
@@ -1188,11 +1200,124 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint32_t tail16 = (n_lv & 1u) ? tw >> 16 : tw & 0xffffu;
                 const bool tail_ok = ((v8 >> n_lv) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_lv + 1u)) & 1u) != 0u);
 
+                const uint32_t tmask = (0xffffu << (16u - 2u * (n_tail & 7u))) & 0xffffu;
+                if (n_lv == 0u) {
+                    // Fewer than eight symbols left: the first code of every row's own entry says whether the row
+                    // survives them (the entry tells how many leading symbols of a code that was cut short are real).
+                    // The survivors keep their order under the remaining LF steps, so the hits are
+                    // SA[row] - rem of the surviving rows in row order: one row is a hint like any other, several are
+                    // a masked record {first row, first row + survivors, mask, rem | 1 << 23} (kernels.hpp).
+                    if (!tail_ok) {
+                        bail = true;
+                        break;
+                    }
+                    uint32_t alive = 0, undecided = 0;
+                    const u32x4 *ttab = static_cast<const u32x4 *>(ix.jump);
+                    for (uint32_t r0 = lo; r0 < hi; r0 += kGroup) {  // group-uniform trip count
+                        const bool real = r0 + sub < hi;
+                        const uint32_t trow = real ? r0 + sub : hi - 1u;
+                        const u32x4 *tp = kJump == 8 ? ttab + (trow >> 1) : ttab + static_cast<uint64_t>(trow) * (kJump / 16);
+                        u32x4 t0, t1;
+                        load_round2<0>(tp, tp + 1, 0ull, t0, t1);
+                        const uint32_t tw = kJump == 8 ? ((trow & 1u) ? t0.w : t0.y) : t0.z;
+                        const uint32_t tvalid = kJump == 8 ? tw >> 16 : t0.w >> 16;
+                        if (real) {
+                            if (n_tail > ((tvalid >> 8) & 0xfu)) undecided = 1u;
+                            else if (((tw ^ tail16) & tmask) == 0u) alive |= 1u << (trow - lo);
+                        }
+                    }
+                    if (group_max<kGroup>(undecided) != 0u) {
+                        bail = true;
+                        break;
+                    }
+                    alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0xB1, 0xF, 0xF, true));
+                    alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0x4E, 0xF, 0xF, true));
+                    if (rows == 1u) {
+                        if (alive != 0u) {
+                            if (hinting && hr == 0xffffffffu) {
+                                hr = lo;
+                                ho = rem;
+                            }
+                        } else {
+                            hi = lo;
+                        }
+                    } else {
+                        masked = true;
+                        hr = alive;
+                        ho = rem;
+                        hi = lo + static_cast<uint32_t>(__popc(alive));
+                    }
+                    rem = 0;
+                    break;
+                }
+                if (rows > static_cast<uint32_t>(kGroup)) {
+                    // A wide interval (a read from a repeat family, or a shallow top table): every lane takes up to four
+                    // rows, one load round each.  The rows that match `best` levels map onto [min, max + 1) of their
+                    // level-`best` targets as in the narrow case; per level the lane keeps min and max over its rows that
+                    // reach it.  No hint and no lazy tail here: they describe one row.
+                    uint32_t mn[kLevels], mx[kLevels], reach = 0;
+#pragma unroll
+                    for (int j = 0; j < kLevels; j++) {
+                        mn[j] = 0xffffffffu;
+                        mx[j] = 0u;
+                    }
+                    const u32x4 *wtab = static_cast<const u32x4 *>(ix.jump);
+                    for (uint32_t r0 = lo; r0 < hi; r0 += kGroup) {  // group-uniform trip count
+                        const bool real = r0 + sub < hi;
+                        const uint32_t wrow = real ? r0 + sub : hi - 1u;
+                        const u32x4 *wp = kJump == 8 ? wtab + (wrow >> 1) : wtab + static_cast<uint64_t>(wrow) * (kJump / 16);
+                        u32x4 w0, w1;
+                        load_round2<0>(wp, wp + 1, kJump == 32 ? __ballot(true) : 0ull, w0, w1);
+                        uint32_t wvalid, wgood;
+                        if (kJump == 8) {
+                            const uint32_t ew = (wrow & 1u) ? w0.w : w0.y;
+                            wvalid = ew >> 16;
+                            wgood = ((ew ^ qa) & 0xffffu) == 0u ? 1u : 0u;
+                        } else {
+                            const uint32_t da = w0.z ^ qa;
+                            wvalid = w0.w >> 16;
+                            wgood = ((da & 0xffffu) == 0u ? 1u : 0u) | ((da >> 16) == 0u ? 2u : 0u);
+                            if (kLevels == 5) {
+                                const uint32_t dc = w1.w ^ qc;
+                                wgood |= ((w0.w ^ qb) & 0xffffu) == 0u ? 4u : 0u;
+                                wgood |= (dc & 0xffffu) == 0u ? 8u : 0u;
+                                wgood |= (dc >> 16) == 0u ? 16u : 0u;
+                            }
+                        }
+                        wgood &= wvalid & qok;
+                        const uint32_t wl = real ? static_cast<uint32_t>(__builtin_ctz(~wgood | (1u << kLevels))) : 0u;
+                        reach = wl > reach ? wl : reach;
+#pragma unroll
+                        for (int j = 0; j < kLevels; j++) {
+                            const uint32_t tj = kJump == 8 ? ((wrow & 1u) ? w0.z : w0.x)
+                                                           : (j == 0 ? w0.x : (j == 1 ? w0.y : (j == 2 ? w1.x : (j == 3 ? w1.y : w1.z))));
+                            if (wl > static_cast<uint32_t>(j)) {
+                                mn[j] = tj < mn[j] ? tj : mn[j];
+                                mx[j] = tj > mx[j] ? tj : mx[j];
+                            }
+                        }
+                    }
+                    const uint32_t wbest = group_max<kGroup>(reach);
+                    if (wbest == 0u) {  // no row survives the next eight symbols
+                        hi = lo;
+                        break;
+                    }
+                    uint32_t bmn = mn[0], bmx = mx[0];
+#pragma unroll
+                    for (int j = 1; j < kLevels; j++) {
+                        bmn = wbest == static_cast<uint32_t>(j + 1) ? mn[j] : bmn;
+                        bmx = wbest == static_cast<uint32_t>(j + 1) ? mx[j] : bmx;
+                    }
+                    lo = group_min<kGroup>(bmn);
+                    hi = group_max<kGroup>(bmx) + 1u;
+                    rem -= wbest * kJumpSymbols;
+                    continue;
+                }
                 const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
                 const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
                 const u32x4 *pa = kJump == 8 ? tab + (row >> 1) : tab + static_cast<uint64_t>(row) * (kJump / 16);
                 u32x4 e0, e1;
-                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(n_lv != 0u) : 0ull, e0, e1);
+                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(true) : 0ull, e0, e1);
                 uint32_t valid, c1;
                 if (kJump == 8) {
                     const uint32_t ew = (row & 1u) ? e0.w : e0.y;
@@ -1201,23 +1326,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 } else {
                     c1 = e0.z & 0xffffu;
                     valid = e0.w >> 16;
-                }
-                const uint32_t tmask = (0xffffu << (16u - 2u * (n_tail & 7u))) & 0xffffu;
-                if (n_lv == 0u) {  // one row, fewer than eight symbols: the row's first level code decides
-                    if (!tail_ok || n_tail > ((valid >> 8) & 0xfu)) {  // (the entry says how many symbols of c1 are real)
-                        bail = true;
-                        break;
-                    }
-                    if (((c1 ^ tail16) & tmask) == 0u) {
-                        if (hinting && hr == 0xffffffffu) {
-                            hr = lo;
-                            ho = rem;
-                        }
-                    } else {
-                        hi = lo;
-                    }
-                    rem = 0;
-                    break;
                 }
                 uint32_t da, db = 0, dc = 0;
                 if (kJump == 8) {
@@ -1306,9 +1414,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (writer) {
                 if (bail) {
                     s_left[atomicAdd(&s_nleft, 1u)] = q;
+                    // where the general kernel goes on: after the top table and whole rounds, or from the start
+                    state[q] = make_uint4(lo, hi, rem, progressed ? 1u : 0u);
                 } else {
                     const bool hinted = hr != 0xffffffffu && hi - lo == 1u;
-                    if (out_rec) out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? (ho & 0xffffffu) : 0u);
+                    if (out_rec) {
+                        if (masked) out_rec[q] = make_uint4(lo, hi, hr, (ho & 0x1fffffu) | kRecMasked);
+                        else out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? (ho & 0xffffffu) : 0u);
+                    }
                     if (out_count) out_count[q] = hi - lo;
                     if (out_status) out_status[q] = 0;
                 }
@@ -1595,14 +1708,16 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         else if (c.mode == 1) GDX_PAIR_LAUNCH_W(KERNEL, P, 1); \
         else GDX_PAIR_LAUNCH_W(KERNEL, P, 2);             \
     } while (0)
-        // Fast path (search_fast_kernel4): count / locate mode on an index with top and jump tables whose text is not
-        // repetitive.  It finishes what needs no pair line and lists the rest, which the general kernel then searches
-        // from the list.  QueryOptions::search_fast / GDX_SEARCH_FAST=0 switch it off.
-        static const int env_fast = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : 1; }();
+        // Fast path (search_fast_kernel4): count / locate mode on an index with top and jump tables.  It finishes
+        // what needs no pair line (intervals of up to sixteen rows) and lists the rest, which the general kernel --
+        // with the straggler pass when the index asks for it -- takes up from the list where the fast path stopped.
+        // QueryOptions::search_fast / GDX_SEARCH_FAST=0 switch it off.
+        // (qo.search_fast arrives resolved by FmIndex::query_options; the environment variable is a debug override)
+        static const int env_fast = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : -1; }();
         const bool fast = c.mode == 1 && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
-                          defer_after == 0u && ix.top != nullptr && ix.top_depth >= 1u && ix.jump != nullptr &&
+                          ix.top != nullptr && ix.top_depth >= 1u && ix.jump != nullptr &&
                           ca.active_in == nullptr && c.d_hint == nullptr && c.d_start == nullptr && c.d_end == nullptr &&
-                          (qo.search_fast >= 0 ? qo.search_fast != 0 : env_fast != 0) && nq < 0xffffffffull;
+                          (env_fast >= 0 ? env_fast != 0 : qo.search_fast != 0) && nq < 0xffffffffull;
         CursorArgs ca_general = ca;
         unsigned g_blocks = blocks;  // grid and range size of the general kernel
         uint32_t g_range = range;
@@ -1614,12 +1729,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             g_blocks = static_cast<unsigned>(g_ranges < 8192 ? g_ranges : 8192);
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            // where a leftover query stands is kept in its record slot (a scratch array when the call has no records)
+            uint4 *d_state = c.d_rec != nullptr ? c.d_rec : static_cast<uint4 *>(stream_scratch(stream, 12, nq * sizeof(uint4)));
             const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit,
                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
 #define GDX_FAST_LAUNCH(J, XLATE)                                                                                      \
     hipLaunchKernelGGL((search_fast_kernel4<J, XLATE>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, \
-                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left)
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state)
 #define GDX_FAST_LAUNCH_P(XLATE)                                  \
     do {                                                          \
         if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32, XLATE);      \
@@ -1641,6 +1758,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             }
             ca_general.active_in = d_left + 4;  // the general kernel below searches the leftover list
             ca_general.n_active_in = d_left;
+            ca_general.resume_state = d_state;
         }
         if (c.packed) {
             if (c.mode == 2 || c.d_step_stats != nullptr) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");

@@ -691,6 +691,63 @@ def test_fused_record_path_equals_oracle(seed, search_variant):
     assert torch.equal(counts, counts2)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fused_records_on_repeat_families(seed, search_variant):
+    """Reads from repeat families end on several rows: the fast-path search takes intervals of up to sixteen rows
+    through the jump table and decides the last few symbols of every row from the row's own entry (masked records);
+    wider families and reads next to N or a text border go on in the general kernel from where the fast path
+    stopped.  Counts, hit offsets and hits in the reference's order for family sizes 1..40, every read length
+    16..90 and several sampling rates."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine
+
+    rng = np.random.default_rng(9100 + seed)
+    a = alph.ascii_dna_with_n()
+    texts = []
+    for _ in range(6):
+        parts = []
+        for _ in range(int(rng.integers(3, 9))):
+            unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(40, 400))))
+            for _ in range(int(rng.choice([1, 2, 3, 5, 8, 15, 17, 40]))):
+                copy = bytearray(unit)
+                if rng.random() < 0.7:  # a diverged copy
+                    copy[int(rng.integers(0, len(copy)))] = b"ACGT"[int(rng.integers(0, 4))]
+                parts.append(bytes(copy))
+                if rng.random() < 0.3:
+                    parts.append(b"N" * int(rng.integers(1, 4)) if seed % 2 else b"")
+        order = rng.permutation(len(parts))
+        texts.append(b"".join(parts[i] for i in order))
+    g, c = both(texts, a, sa_rate=[4, 1, 3, 16][seed])
+    qs = []
+    for _ in range(4000):
+        t = texts[int(rng.integers(0, len(texts)))]
+        ln = int(rng.integers(16, 91))
+        pos = int(rng.integers(0, max(1, len(t) - ln)))
+        q = t[pos:pos + ln]
+        if b"N" not in q:
+            qs.append(q)
+    dq, qbuf, qoff = _device_queries(qs)
+    eng = DeviceEngine(g)
+    rec = eng.alloc_records(dq.nq)
+    off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+    eng.locate_search(dq, rec)
+    eng.locate_offsets(rec, dq.nq, off)
+    torch.cuda.synchronize()
+    total = int(off[dq.nq].item())
+    hits = torch.empty((max(total, 1), 2), dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(eng.locate_workspace_bytes(total), 16), dtype=torch.uint8, device="cuda")
+    eng.locate_hits(rec, dq.nq, off, total, hits, ws)
+    torch.cuda.synchronize()
+    co, ct, cp = c.locate_many(qs)
+    assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+    h = hits[:total].cpu().numpy().astype(np.uint32)
+    assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
+    assert int((np.diff(co) > 1).sum()) > len(qs) // 4  # many multi-hit reads
+    counts, st = g.count_raw(qbuf, qoff)
+    assert counts.tolist() == np.diff(co).tolist() and not st.any()
+
+
 _TRANSLATIONS = {
     # how the fast-path kernel turns query bytes into 2-bit codes (IndexView::perm_*): name -> (alphabet, symbols of
     # the texts, symbols of random queries -- some of them outside the alphabet or not searchable)
