@@ -374,7 +374,7 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
             if (opts->search_defer_after < -1 || opts->search_defer_after > 1000)
                 gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
             q.search_defer_after = opts->search_defer_after;
-            if (opts->search_fast < -1 || opts->search_fast > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            if (opts->search_fast < -1 || opts->search_fast > 2) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
             q.search_fast = opts->search_fast;
         }
         ix->impl->set_query_options(q);

@@ -1023,7 +1023,8 @@ QueryOptions FmIndex::query_options() const
     // default: the fast-path kernel first, unless the top table is so shallow for this text that most reads leave it
     // on more rows than a jump takes -- their intervals narrow fastest on pair lines (top 12 / 8-byte jumps at hg38
     // scale: 21.8 ms without, 26.5 ms with the fast path in front)
-    if (q.search_fast < 0) q.search_fast = aux_report_.wide_fraction > 0.5 ? 0 : 1;
+    // -- and with jumps over up to sixteen rows when reads from repeats are common (they cost every other read 3 %)
+    if (q.search_fast < 0) q.search_fast = aux_report_.wide_fraction > 0.5 ? 0 : (aux_report_.wide_fraction > 0.02 ? 2 : 1);
     return q;
 }
 

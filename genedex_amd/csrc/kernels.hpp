@@ -19,7 +19,7 @@ struct QueryOptions {
     int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
     int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
     int locate_jump_walk = -1; // -1 default (1: the queue kernel walks through the jump table), 0 rank lines only
-    int search_fast = -1;         // count / locate searches run the fast-path kernel first (1) or not (0); -1 = per index
+    int search_fast = -1;         // count / locate searches run the fast-path kernel first (1; 2 = with 16-row jumps) or not (0); -1 = per index
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
                                   // finished in the block's straggler pass; 0 = never
 };

@@ -1104,14 +1104,16 @@ __device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint
     return fast_window_finish<kXlate>(ix, s_dense, fast_window_load<kXlate>(wbase, off0, rem, sub), off0, rem, sub);
 }
 
-template <int kJump, int kXlate>
+// kWide: intervals of up to sixteen rows (four per lane, one load round each) instead of four -- chosen per index
+// (launch_search_call): on a text without repeats almost no read needs it and the loops cost the others 3 %
+template <int kJump, int kXlate, bool kWide>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
     FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state)
 {
     constexpr int kGroup = 4;
-    constexpr uint32_t kWideRows = 16;  // widest interval a round takes: four rows per lane
+    constexpr uint32_t kWideRows = kWide ? 16 : kGroup;  // widest interval a round takes
     constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : 5);
     constexpr int kCodes = kJump == 8 ? 1 : (kJump == 16 ? 3 : 5);
     __shared__ uint8_t s_dense[256];
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     }
                     uint32_t alive = 0, undecided = 0;
                     const u32x4 *ttab = static_cast<const u32x4 *>(ix.jump);
-                    for (uint32_t r0 = lo; r0 < hi; r0 += kGroup) {  // group-uniform trip count
+                    for (uint32_t r0 = lo; r0 < (kWide ? hi : lo + 1u); r0 += kGroup) {  // group-uniform trip count
                         const bool real = r0 + sub < hi;
                         const uint32_t trow = real ? r0 + sub : hi - 1u;
                         const u32x4 *tp = kJump == 8 ? ttab + (trow >> 1) : ttab + static_cast<uint64_t>(trow) * (kJump / 16);
@@ -1250,7 +1252,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     rem = 0;
                     break;
                 }
-                if (rows > static_cast<uint32_t>(kGroup)) {
+                if (kWide && rows > static_cast<uint32_t>(kGroup)) {
                     // A wide interval (a read from a repeat family, or a shallow top table): every lane takes up to four
                     // rows, one load round each.  The rows that match `best` levels map onto [min, max + 1) of their
                     // level-`best` targets as in the narrow case; per level the lane keeps min and max over its rows that
@@ -1734,9 +1736,17 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit,
                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
-#define GDX_FAST_LAUNCH(J, XLATE)                                                                                      \
-    hipLaunchKernelGGL((search_fast_kernel4<J, XLATE>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, c.d_qbeg, \
-                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state)
+            // sixteen-row rounds where reads from repeats are common (QueryOptions::search_fast == 2)
+            const bool wide_rounds = (env_fast >= 0 ? env_fast : qo.search_fast) == 2;
+#define GDX_FAST_LAUNCH(J, XLATE)                                                                                           \
+    do {                                                                                                                    \
+        if (wide_rounds)                                                                                                    \
+            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, true>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf,  \
+                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, false>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, \
+                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state); \
+    } while (0)
 #define GDX_FAST_LAUNCH_P(XLATE)                                  \
     do {                                                          \
         if (ix.jump_bytes == 32) GDX_FAST_LAUNCH(32, XLATE);      \

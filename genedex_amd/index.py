@@ -181,7 +181,7 @@ class FmIndex:
         if search_defer_after is not None:
             o.search_defer_after = int(search_defer_after)
         if search_fast is not None:
-            o.search_fast = int(bool(search_fast))
+            o.search_fast = int(search_fast)  # False / True / 2 (jumps over up to 16 rows)
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

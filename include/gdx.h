@@ -187,10 +187,11 @@ typedef struct {
                                 on such queries (reads from repeats); 0 = never park; -1 default: 3 on repetitive
                                 texts (gdx_index_aux_t.wide_permille > 50), else 0 (the bookkeeping is not free)    */
     int32_t search_fast;     /* 1: count / locate searches first run a slim kernel that only knows the top table,
-                                jumps over intervals of up to 16 rows and tails decided from jump entries, and hand
-                                what it cannot finish to the general kernel; 0 = general kernel only; -1 default: 1
-                                unless most reads leave the top table on more than four rows
-                                (gdx_index_aux_t.wide_permille > 500: a top table that is shallow for the text)   */
+                                jumps and tails decided from jump entries, and hand what it cannot finish to the
+                                general kernel; 2: the same with jumps over intervals of up to 16 rows (reads from
+                                repeat families) instead of 4; 0 = general kernel only; -1 default, by
+                                gdx_index_aux_t.wide_permille: > 500 (a top table that is shallow for the text) 0,
+                                > 20 (a repetitive text) 2, else 1                                              */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);

@@ -89,7 +89,7 @@ def one_round(rng, stats):
     query = {"search_lanes": [4, 4, 8][int(rng.integers(0, 3))], "load_policy": int(rng.integers(0, 2)),
              "length_schedule": int(rng.integers(0, 2)), "locate_jump_walk": int(rng.integers(0, 4)) != 0,
              "search_defer_after": [None, 0, 1, 2, 5][int(rng.integers(0, 5))],
-             "search_fast": int(rng.integers(0, 3)) != 0}
+             "search_fast": int(rng.integers(0, 3))}
     storage = str(rng.choice(["i32", "u32"]))
     cfg = {"alphabet": name, "total": total, "n_texts": n_texts, "mode": mode, "sa_rate": rate, "depth": depth,
            "storage": storage, **build, **query}

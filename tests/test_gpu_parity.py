@@ -215,6 +215,8 @@ _VARIANTS = {
     "pair-top4": (dict(search_kernel="pair", locate_jump_walk=False), dict(top_table_depth=4)),
     "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
     "pair-no-fast": (dict(search_kernel="pair", search_fast=False), {}),
+    "pair-fast": (dict(search_kernel="pair", search_fast=1), {}),  # (the default asks the index: wide_permille)
+    "pair-fast-wide": (dict(search_kernel="pair", search_fast=2), {}),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
     "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
@@ -719,6 +721,8 @@ def test_fused_records_on_repeat_families(seed, search_variant):
         order = rng.permutation(len(parts))
         texts.append(b"".join(parts[i] for i in order))
     g, c = both(texts, a, sa_rate=[4, 1, 3, 16][seed])
+    if "search_fast" not in _QUERY_OPTIONS:  # (off by default on a text this repetitive: wide_permille > 500)
+        g.set_query_options(**{**_QUERY_OPTIONS, "search_fast": 2})
     qs = []
     for _ in range(4000):
         t = texts[int(rng.integers(0, len(texts)))]
@@ -770,6 +774,7 @@ def test_fast_path_query_translation(name):
     texts = [bytes(text_symbols[i] for i in rng.integers(0, len(text_symbols), int(rng.integers(1000, 30000))))
              for _ in range(4)]
     g, c = both(texts, a, sa_rate=3)
+    g.set_query_options(search_fast=1 + sum(name.encode()) % 2)
     assert g.aux()["jump_entry_bytes"] == 32 and g.aux()["top_table_depth"] >= 1
     qs = []
     for _ in range(3000):
