@@ -2,10 +2,11 @@
 // FmIndex::count_many / cursors_for_many_queries / locate_many of the reference (lib.rs:155-185) for callers whose
 // queries and results live in host memory.
 //
-// A call is a pipeline over chunks of the batch, three chunks in flight:
+// A call is a pipeline over chunks of the batch, four chunks in flight, three host threads:
 //
 //     feeder thread + workers: user memory -> pinned staging  |  H2D (copy-in stream)  |  kernels (compute stream)
-//                                                             |  D2H (copy-out stream) |  calling thread + workers:
+//     calling thread: waits for a chunk's search (locate: its number of hits), enqueues locate and the copies out
+//                                                             |  D2H (copy-out stream) |  drainer thread + workers:
 //                                                                                         pinned -> the user's arrays
 //
 // so that the PCIe transfers of chunk k + 1 / k - 1 run beside the kernels of chunk k and a call costs about
@@ -13,6 +14,7 @@
 // 8-byte hits, one status byte) and are widened to the ABI's u64 by the host threads while they copy.  Results are
 // order preserving: chunk boundaries are invisible to the caller.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <exception>
@@ -28,8 +30,12 @@
 namespace gdx {
 
 namespace {
+double now_seconds()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
 std::atomic<uint64_t> g_chunk_bytes{32ull << 20};   // query bytes per chunk
 std::atomic<uint64_t> g_chunk_queries{1ull << 20};  // and at most this many queries
 
@@ -448,25 +454,43 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         });
     };
 
-    // Software pipeline with two host threads: the feeder stages chunks in (its own worker pool) as soon as a slot is
-    // free, this thread enqueues the locate / copy-out of chunk k and drains chunk k - 1 (its own pool), so that the
-    // copy-in of chunk k + 1 overlaps the widening of chunk k - 1 on the host as well as on the PCIe links.
+    // Software pipeline with three host threads: the feeder stages chunks in (its own worker pool) as soon as a slot is
+    // free; this thread waits for the search of chunk k (locate: for its number of hits), enqueues locate and the
+    // copies out; the drainer widens chunk k - 1 into the caller's arrays (its own pool).  Copy-in, kernels, copy-out
+    // and both host-side copies of different chunks overlap; with the middle and the drain stage on one thread the
+    // locate call took 1.6-1.8 x the PCIe time of its input, the thread being busy widening hits while a finished
+    // search waited for its locate launch.
+    // GDX_HOST_TIMING=1 (debug): where the three threads spend the call, in seconds
+    static const bool timing = getenv("GDX_HOST_TIMING") != nullptr;
+    double t_in_wait = 0, t_in_work = 0, t_mid_wait = 0, t_mid_work = 0, t_out_wait = 0, t_out_work = 0;
     std::mutex mu;
     std::condition_variable cv;
-    size_t staged = 0, drained = 0;  // chunks staged in / fully drained
+    size_t staged = 0, launched = 0, drained = 0;  // chunks staged in / with their copy-out enqueued / fully drained
     bool abort = false;
-    std::exception_ptr feeder_error;
+    std::exception_ptr worker_error;
     WorkerPool in_pool(host_threads());
+    auto fail_all = [&](std::exception_ptr e) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!worker_error) worker_error = e;
+        abort = true;
+        cv.notify_all();
+    };
     std::thread feeder([&] {
         try {
             GDX_HIP(hipSetDevice(dev));
             for (size_t k = 0; k < n_chunks; k++) {
+                const double t0 = timing ? now_seconds() : 0.0;
                 {
                     std::unique_lock<std::mutex> g(mu);
                     cv.wait(g, [&] { return abort || k < drained + kSlots; });
                     if (abort) return;
                 }
+                const double t1 = timing ? now_seconds() : 0.0;
                 stage_in_with(k, in_pool);
+                if (timing) {
+                    t_in_wait += t1 - t0;
+                    t_in_work += now_seconds() - t1;
+                }
                 {
                     std::lock_guard<std::mutex> g(mu);
                     staged = k + 1;
@@ -474,45 +498,66 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
                 cv.notify_all();
             }
         } catch (...) {
-            std::lock_guard<std::mutex> g(mu);
-            feeder_error = std::current_exception();
-            abort = true;
-            cv.notify_all();
+            fail_all(std::current_exception());
         }
     });
-    try {
-        for (size_t step = 0; step < n_chunks + 1; step++) {
-            if (step < n_chunks) {
+    std::thread drainer([&] {
+        try {
+            GDX_HIP(hipSetDevice(dev));
+            for (size_t k = 0; k < n_chunks; k++) {
+                const double t0 = timing ? now_seconds() : 0.0;
                 {
                     std::unique_lock<std::mutex> g(mu);
-                    cv.wait(g, [&] { return abort || staged > step; });
-                    if (abort) break;
+                    cv.wait(g, [&] { return abort || launched > k; });
+                    if (abort) return;
                 }
-                stage_mid(step);
-            }
-            if (step >= 1) {
-                stage_out(step - 1);
+                const double t1 = timing ? now_seconds() : 0.0;
+                stage_out(k);
+                if (timing) {
+                    t_out_wait += t1 - t0;
+                    t_out_work += now_seconds() - t1;
+                }
                 {
                     std::lock_guard<std::mutex> g(mu);
-                    drained = step;
+                    drained = k + 1;
                 }
                 cv.notify_all();
             }
+        } catch (...) {
+            fail_all(std::current_exception());
+        }
+    });
+    try {
+        for (size_t k = 0; k < n_chunks; k++) {
+            const double t0 = timing ? now_seconds() : 0.0;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return abort || staged > k; });
+                if (abort) break;
+            }
+            const double t1 = timing ? now_seconds() : 0.0;
+            stage_mid(k);
+            if (timing) {
+                t_mid_wait += t1 - t0;
+                t_mid_work += now_seconds() - t1;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                launched = k + 1;
+            }
+            cv.notify_all();
         }
     } catch (...) {
-        {
-            std::lock_guard<std::mutex> g(mu);
-            abort = true;
-        }
-        cv.notify_all();
-        feeder.join();
-        (void)hipDeviceSynchronize();
-        throw;
+        fail_all(std::current_exception());
     }
     feeder.join();
-    if (feeder_error) {
+    drainer.join();
+    if (timing)
+        fprintf(stderr, "gdx host pipeline: %zu chunks; feeder wait %.3f work %.3f; launcher wait %.3f work %.3f; drainer wait %.3f work %.3f\n",
+                n_chunks, t_in_wait, t_in_work, t_mid_wait, t_mid_work, t_out_wait, t_out_work);
+    if (worker_error) {
         (void)hipDeviceSynchronize();
-        std::rethrow_exception(feeder_error);
+        std::rethrow_exception(worker_error);
     }
     GDX_HIP(hipStreamSynchronize(st.out));
     if (out_total) *out_total = hit_base;
