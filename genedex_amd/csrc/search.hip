@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (bail) {
                     s_left[atomicAdd(&s_nleft, 1u)] = q;
                     // where the general kernel goes on: after the top table and whole rounds, or from the start
-                    state[q] = make_uint4(lo, hi, rem, progressed ? 1u : 0u);
+                    if (state) state[q] = make_uint4(lo, hi, rem, progressed ? 1u : 0u);
                 } else {
                     const bool hinted = hr != 0xffffffffu && hi - lo == 1u;
                     if (out_rec) {
@@ -1731,8 +1731,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             g_blocks = static_cast<unsigned>(g_ranges < 8192 ? g_ranges : 8192);
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
-            // where a leftover query stands is kept in its record slot (a scratch array when the call has no records)
-            uint4 *d_state = c.d_rec != nullptr ? c.d_rec : static_cast<uint4 *>(stream_scratch(stream, 12, nq * sizeof(uint4)));
+            // where a leftover query stands is kept in its record slot; a call without records (counts only) lets the
+            // general kernel start its few leftovers over rather than allocate 16 bytes per query for them
+            uint4 *d_state = c.d_rec;
             const FastView fv{ix.top, ix.jump, ix.io_to_dense, ix.top_depth, ix.sa_inv, ix.sa_rot, ix.sa_limit,
                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS

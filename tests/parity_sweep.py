@@ -159,6 +159,7 @@ def one_round(rng, stats):
         assert counts.cpu().numpy().astype(np.uint32).tolist() == (ce[keep] - cs[keep]).astype(np.uint32).tolist(), ("rec counts", cfg)
         assert not stat.any().item(), ("rec status", cfg)
         stats["lazy_or_hinted_records"] = stats.get("lazy_or_hinted_records", 0) + int((rec[:dq.nq, 2] != -1).sum().item())
+        stats["masked_records"] = stats.get("masked_records", 0) + int((((rec[:dq.nq, 3] >> 23) & 1) == 1).sum().item())
         # the same queries through the batched cursor API, fed in chunks of `chunk` symbols from the right, with
         # device-side active lists: identical intervals (cursor.rs:34-51 applied symbol by symbol)
         chunk = int(rng.choice([1, 5, 8, 16, 32, 50]))
