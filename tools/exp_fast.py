@@ -42,6 +42,26 @@ for name, lo, hi, n in (("len50", 50, 50, nq), ("len20_150", 20, 150, nq // 2)):
         else:
             res[f"kind{kind}_counts_equal"] = bool(torch.equal(counts, ref[0]))
         del rec
+    # exact intervals (cursors_for_many_queries): general kernel against the exact instantiation of the fast path
+    ref_iv = None
+    for kind in (0, 1):
+        index.set_query_options(search_fast=kind)
+        o = eng.alloc_outputs(n)
+        eng.search(q, o)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            eng.search(q, o)
+        ev[1].record()
+        torch.cuda.synchronize()
+        res[f"intervals_kind{kind}_ms"] = ev[0].elapsed_time(ev[1]) / 5
+        if ref_iv is None:
+            ref_iv = (o["start"].clone(), o["end"].clone(), o["status"].clone())
+        else:
+            res["intervals_equal"] = bool(torch.equal(o["start"], ref_iv[0]) and torch.equal(o["end"], ref_iv[1])
+                                          and torch.equal(o["status"], ref_iv[2]))
+        del o
     out[name] = res
     del q
 print(json.dumps(out))
