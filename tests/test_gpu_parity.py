@@ -752,6 +752,55 @@ def test_fused_records_on_repeat_families(seed, search_variant):
     assert counts.tolist() == np.diff(co).tolist() and not st.any()
 
 
+@pytest.mark.parametrize("fast", [None, 0, 1, 2])
+def test_genome_like_text_against_oracle(fast):
+    """4 Mi symbols with the repeat structure of bench.py's genome-like text (segmental duplications with 0.5 %
+    divergence, tandem repeats, poly-A, N gaps), 60 k reads of length 50 and of lengths 20..150: counts, hit offsets
+    and hits of the record path equal the oracle's whichever way the search kernels split the work (general kernel
+    only, fast path with 4-row or 16-row jumps, the index's own choice)."""
+    import torch
+
+    from genedex_amd import synth
+    from genedex_amd.device import DeviceEngine, genome_like_text
+
+    a = alph.ascii_dna_with_n()
+    total = 1 << 22
+    buf = genome_like_text(total, torch.device("cuda"), seed=11).cpu().numpy().tobytes()
+    texts, at = [], 0
+    for ln in synth.split_lengths(total, 3):
+        texts.append(buf[at:at + ln])
+        at += ln
+    g, c = both(texts, a, sa_rate=4)
+    if fast is not None:
+        g.set_query_options(search_fast=fast)
+    eng = DeviceEngine(g)
+    masked = 0
+    for len_min, len_max, seed in ((50, 50, 5), (20, 150, 6)):
+        qbuf, qoff = synth.host_queries(texts, nq=30_000, len_min=len_min, len_max=len_max, sampled_fraction=0.9, seed=seed)
+        from genedex_amd.device import DeviceQueries
+
+        dq = DeviceQueries.from_host(qbuf, qoff)
+        rec = eng.alloc_records(dq.nq)
+        off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+        eng.locate_search(dq, rec)
+        eng.locate_offsets(rec, dq.nq, off)
+        torch.cuda.synchronize()
+        tot = int(off[dq.nq].item())
+        hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_hits(rec, dq.nq, off, tot, hits, ws)
+        torch.cuda.synchronize()
+        cs, ce = c.cursors_for_many(qbuf, qoff, n_threads=4)
+        co, ct, cp = c.locate_intervals(cs, ce, n_threads=4)
+        assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+        h = hits[:tot].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(h[:, 0], ct.astype(np.uint32)) and np.array_equal(h[:, 1], cp.astype(np.uint32))
+        masked += int((((rec[:dq.nq, 3] >> 23) & 1) == 1).sum().item())
+        assert int((np.diff(co.astype(np.int64)) > 1).sum()) > 1000  # reads from repeats
+    if fast in (1, 2):
+        assert masked > 1000  # reads that end on several rows were finished by the fast path
+
+
 _TRANSLATIONS = {
     # how the fast-path kernel turns query bytes into 2-bit codes (IndexView::perm_*): name -> (alphabet, symbols of
     # the texts, symbols of random queries -- some of them outside the alphabet or not searchable)
