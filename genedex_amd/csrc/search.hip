@@ -421,6 +421,43 @@ __device__ __forceinline__ uint32_t to_2bit(uint32_t x)
     return (y & 0xffu) | ((y >> 8) & 0xff00u);
 }
 
+// Live cursors of a block's range (cursor extension, mode 2) are appended to the global list IN THE ORDER OF THEIR
+// POSITIONS in the range: s_live[p] = the cursor at position p, or kDeadCursor.  A list that starts sorted then stays
+// sorted chunk by chunk, and the next call's gathers of start / end / status / string offsets by cursor number touch
+// neighbouring lines; appending in the order of LDS atomics scattered them over sixteen lines per load instruction,
+// which made a call over 34 M live cursors with empty strings cost 3.3 ms.
+constexpr uint32_t kDeadCursor = 0xffffffffu;
+__device__ __forceinline__ void flush_live_ordered(uint32_t *s_live, uint32_t cnt, uint32_t *s_part, uint32_t *s_base,
+                                                   uint32_t *active_out, uint32_t *n_active_out)
+{
+    constexpr uint32_t kPer = kCursorRange / kBlock;
+    uint32_t v[kPer], mine = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) {
+        const uint32_t p = threadIdx.x * kPer + j;
+        v[j] = p < cnt ? s_live[p] : kDeadCursor;
+        s_live[p] = kDeadCursor;  // for the next range
+        mine += v[j] != kDeadCursor ? 1u : 0u;
+    }
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {  // inclusive scan
+        const uint32_t o = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += o;
+        __syncthreads();
+    }
+    const uint32_t total = s_part[kBlock - 1];
+    if (threadIdx.x == 0 && total != 0u) *s_base = atomicAdd(n_active_out, total);
+    __syncthreads();
+    uint32_t pos = *s_base + s_part[threadIdx.x] - mine;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++)
+        if (v[j] != kDeadCursor) active_out[pos++] = v[j];
+    __syncthreads();
+}
+
 // Backward search on pair lines, the jump table and the top table: kGroup = 4 or 8 lanes per
 // query, every loop iteration is one round of loads for the whole wavefront.
 // kMode 0 (intervals): out_start / out_end are the reference's half-open SA interval, bit for bit, also for empty
@@ -460,8 +497,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     // kMode 2: the cursors of the block's current range that stay alive, appended to ca.active_out with ONE global
     // atomic per range (an atomic per wavefront serialised the whole chip on one address: 27 ms per call at 34 M
     // live cursors)
-    __shared__ uint32_t s_alive[kMode == 2 ? kCursorRange : 1];
-    __shared__ uint32_t s_nalive, s_alive_base;
+    __shared__ uint32_t s_alive[kMode == 2 ? kCursorRange : 1];  // flush_live_ordered
+    __shared__ uint32_t s_alive_part[kMode == 2 ? kBlock : 1];
+    __shared__ uint32_t s_alive_base;
     // Stragglers: a query that is not done after its allowance of load rounds (a read from a repeat, whose interval
     // stays wide and is narrowed two symbols per round) is parked here {query, lo, hi, rem} and finished in a second
     // pass over the block's range in which EVERY group works on such a query, instead of holding the fifteen finished
@@ -471,10 +509,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     __shared__ uint32_t s_ndefer;
     for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
     for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    if (threadIdx.x == 0) {
-        s_nalive = 0;
-        s_ndefer = 0;
-    }
+    if (kMode == 2)
+        for (uint32_t i = threadIdx.x; i < kCursorRange; i += kBlock) s_alive[i] = kDeadCursor;
+    if (threadIdx.x == 0) s_ndefer = 0;
     __syncthreads();
 
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
@@ -898,14 +935,17 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 rec.w = (hv.y & 0xffffffu) | ((status & 0xffu) << 24);
                 out_rec[q] = rec;
             }
-            if (out_start) out_start[q] = lo;
-            if (out_end) out_end[q] = hi;
+            // (a cursor that got an empty string, or was stopped earlier, is as it was: nothing to store -- calls over
+            // live lists whose reads have mostly ended are made of such cursors)
+            const bool unchanged = kMode == 2 && (len == 0u || stopped);
+            if (out_start && !unchanged) out_start[q] = lo;
+            if (out_end && !unchanged) out_end[q] = hi;
             if (out_count) out_count[q] = hi - lo;
-            if (out_status) out_status[q] = static_cast<uint8_t>(status);
+            if (out_status && !unchanged) out_status[q] = static_cast<uint8_t>(status);
             if (out_hint) out_hint[q] = hv;
         }
         if (kMode == 2 && ca.active_out != nullptr && writer && !deferred && lo != hi && (status & 0xffu) == 0u)
-            s_alive[atomicAdd(&s_nalive, 1u)] = static_cast<uint32_t>(q);  // the cursors that can still be extended
+            s_alive[at - base] = static_cast<uint32_t>(q);  // the cursors that can still be extended
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;
             for (int off = 32; off > 0; off >>= 1) {
@@ -921,15 +961,8 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         __syncthreads();
         if (threadIdx.x == 0) s_ndefer = 0;
     }
-    if (kMode == 2 && ca.active_out != nullptr) {  // flush the range's live cursors: one atomic, coalesced stores
-        __syncthreads();
-        const uint32_t n_alive = s_nalive;
-        if (threadIdx.x == 0 && n_alive != 0u) s_alive_base = atomicAdd(ca.n_active_out, n_alive);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_alive; i += kBlock) ca.active_out[s_alive_base + i] = s_alive[i];
-        __syncthreads();
-        if (threadIdx.x == 0) s_nalive = 0;
-    }
+    if (kMode == 2 && ca.active_out != nullptr)  // the range's live cursors: one atomic, in order
+        flush_live_ordered(s_alive, cnt, s_alive_part, &s_alive_base, ca.active_out, ca.n_active_out);
     }  // ranges
     if (kStats && step_stats && writer) {
         atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
