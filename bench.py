@@ -921,12 +921,17 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
     n_act = [torch.empty(1, dtype=torch.int32, device=dev) for _ in range(2)]
     edges = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)]
     rounds = -(-w["len_max"] // chunk)
-    live = []
+    live = {"strings": [], "chunks": []}
 
-    def cursor_api(record_live=False):
+    def reset():
         cur_s.zero_()
         cur_e.fill_(n if n < (1 << 31) else n - (1 << 32))  # cursor_empty for every read
         cur_st.zero_()
+
+    def cursor_api_strings(record_live=False):
+        """gdx_cursor_extend_front_strings_dev: the caller computes the chunk edges; a read stays in the live list as
+        long as its interval is non-empty (it gets empty strings once it has ended)"""
+        reset()
         hi = end
         a, na = None, None  # first call: all cursors
         for r in range(rounds):
@@ -937,20 +942,40 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
             a, na = act[r % 2], n_act[r % 2]
             hi = lo
             if record_live:
-                live.append(int(na.item()))
+                live["strings"].append(int(na.item()))
 
-    cursor_ms = timed(cursor_api)
-    cursor_api(record_live=True)
-    torch.cuda.synchronize()
-    same = bool(torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]) and not bool(cur_st.any().item()))
-    if not same:
-        raise SystemExit("PARITY FAILURE: the batched cursor API and the fused search disagree on workload 5")
+    def cursor_api_chunks(record_live=False):
+        """gdx_cursor_extend_front_chunk_dev: chunk k of every read, the live list drops reads that have ended"""
+        reset()
+        a, na = None, None
+        for r in range(rounds):
+            eng.cursor_extend_chunk(cur_s, cur_e, q.qbuf, q.qoff, nq, chunk, r, cur_st, a, na, act[r % 2], n_act[r % 2])
+            a, na = act[r % 2], n_act[r % 2]
+            if record_live:
+                live["chunks"].append(int(na.item()))
+
+    def check(what):
+        torch.cuda.synchronize()
+        if not (torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]) and not bool(cur_st.any().item())):
+            raise SystemExit(f"PARITY FAILURE: the batched cursor API ({what}) and the fused search disagree on workload 5")
+
+    strings_ms = timed(cursor_api_strings)
+    cursor_api_strings(record_live=True)
+    check("strings")
+    cursor_ms = timed(cursor_api_chunks)
+    cursor_api_chunks(record_live=True)
+    check("chunks")
+    same = True
     res = {"name": "mixed_lengths_20_150 (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
            "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms,
            "cursor_api_value": nq / (cursor_ms / 1e3), "cursor_api_ms": cursor_ms, "unit": "queries/s",
-           "cursor_api": f"cursor_empty + {rounds} x gdx_cursor_extend_front_strings_dev ({chunk} symbols per call, "
-                         f"device-side active lists, no host round trip inside a pass)",
-           "live_cursors_after_each_call": live, "intervals_identical": same,
+           "cursor_api": f"cursor_empty + {rounds} x gdx_cursor_extend_front_chunk_dev ({chunk} symbols per call, "
+                         f"device-side live lists, no host round trip inside a pass)",
+           "cursor_api_strings_ms": strings_ms,
+           "cursor_api_strings": "the same through gdx_cursor_extend_front_strings_dev (chunk edges computed by the "
+                                 "caller, reads that have ended stay in the live list)",
+           "live_cursors_after_each_call": live["chunks"], "live_cursors_after_each_call_strings": live["strings"],
+           "intervals_identical": same,
            "lf_steps": lf_steps, "active_lane_fraction_fused": fetches / slots if slots else None}
     log(f"[bench] secondary {res}")
     return res

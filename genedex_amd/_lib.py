@@ -149,6 +149,7 @@ SIGNATURES = {
     "gdx_count_many_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_search_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],
+    "gdx_cursor_extend_front_chunk_dev": [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings": [vp, u64p, u64p, u8p, u64p, C.c_uint64, u8p],
     # gdx_bench.h
     "gdx_index_build_stats": [vp, C.POINTER(BuildStats)],

@@ -880,6 +880,42 @@ int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start, vo
     });
 }
 
+int gdx_cursor_extend_front_chunk_dev(const gdx_index_t *ix, void *d_start, void *d_end, const void *d_qbuf,
+                                      const void *d_qoff, uint64_t m, uint32_t chunk_symbols, uint32_t chunk_index,
+                                      void *d_status, const void *d_active_in, const void *d_n_active_in,
+                                      void *d_active_out, void *d_n_active_out, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        if (m && (!d_start || !d_end || !d_qoff)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+        if (chunk_symbols == 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "chunk_symbols must be positive");
+        if ((d_active_out == nullptr) != (d_n_active_out == nullptr) || (d_active_in != nullptr && d_n_active_in == nullptr))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "active lists need their counters");
+        if (m >= 0xffffffffull) gdx::fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 cursors in one call");
+        DeviceGuard guard(f.config().device_id);
+        if (d_n_active_out) GDX_HIP(hipMemsetAsync(d_n_active_out, 0, sizeof(uint32_t), as_stream(stream)));
+        gdx::SearchCall c;
+        c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = static_cast<const uint64_t *>(d_qoff) + 1;
+        c.nq = m;
+        c.d_start = static_cast<uint32_t *>(d_start);
+        c.d_end = static_cast<uint32_t *>(d_end);
+        c.d_status = static_cast<uint8_t *>(d_status);
+        c.mode = 2;
+        c.cursors.active_in = static_cast<const uint32_t *>(d_active_in);
+        c.cursors.n_active_in = static_cast<const uint32_t *>(d_n_active_in);
+        c.cursors.active_out = static_cast<uint32_t *>(d_active_out);
+        c.cursors.n_active_out = static_cast<uint32_t *>(d_n_active_out);
+        c.cursors.chunk_symbols = chunk_symbols;
+        c.cursors.chunk_index = chunk_index;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_cursor_extend_front_strings(const gdx_index_t *ix, uint64_t *start, uint64_t *end, const uint8_t *qbuf,
                                     const uint64_t *qoff, uint64_t m, uint8_t *status)
 {

@@ -32,6 +32,10 @@ struct CursorArgs {
     const uint32_t *n_active_in = nullptr;
     uint32_t *active_out = nullptr;
     uint32_t *n_active_out = nullptr;
+    // chunk view (gdx_cursor_extend_front_chunk_dev): when chunk_symbols != 0, cursor i is extended by chunk
+    // chunk_index (counted from the end) of query [qbeg[i], qend[i]) and stays in the live list only while symbols
+    // are left of that chunk
+    uint32_t chunk_symbols = 0, chunk_index = 0;
     // where the fast-path kernel left the listed queries: {lo, hi, symbols left, 1} to go on from there, {.., 0} to
     // start from the beginning; indexed by query, null = all start from the beginning
     const uint4 *resume_state = nullptr;

@@ -263,7 +263,14 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     for (uint64_t at = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; at < nq;
          at += stride) {
         const uint64_t q = active ? active[at] : at;
-        const uint64_t begin = qbeg[q], end = qend[q];
+        uint64_t begin = qbeg[q], end = qend[q];
+        bool more_left = true;  // chunk view (CursorArgs::chunk_symbols): the query has symbols left of this chunk
+        if (kResume && ca.chunk_symbols != 0u) {
+            const uint64_t first = begin, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
+            end = end - first > skip ? end - skip : first;
+            begin = end - first > ca.chunk_symbols ? end - ca.chunk_symbols : first;
+            more_left = begin > first;
+        }
         const uint64_t len = end - begin;
         // lib.rs:277-281 split_query_for_lookup
         const uint32_t t = kResume ? 0u
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
             if (out_status) out_status[q] = static_cast<uint8_t>(status);
         }
         if (kResume && ca.active_out != nullptr)
-            compact_alive(writer && lo != hi && status == GDX_Q_OK, static_cast<uint32_t>(q), ca);
+            compact_alive(writer && lo != hi && status == GDX_Q_OK && more_left, static_cast<uint32_t>(q), ca);
     }
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(lf_steps));
 }
@@ -526,7 +533,9 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
     const uint64_t base = rg * range;
     const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
     if (rg != blockIdx.x) __syncthreads();  // the previous range's order is no longer read
-    const bool ordered = schedule != 0 && order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
+    // (chunk view: the strings of a call are chunks of one size, whatever the lengths of the queries)
+    const bool ordered = schedule != 0 && !(kMode == 2 && ca.chunk_symbols != 0u) &&
+                         order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
     for (int phase = 0; phase < (kDefer ? 2 : 1); phase++) {  // 0: the range's queries; 1: the stragglers parked in phase 0
     uint32_t n_items = cnt;
     if (kDefer && phase == 1) {
@@ -548,7 +557,14 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 resumed = true;
             }
         }
-        const uint64_t begin = qbeg[q], end = qend[q];
+        uint64_t begin = qbeg[q], end = qend[q];
+        bool more_left = true;  // kMode 2, chunk view: the query has symbols left of this chunk
+        if (kMode == 2 && ca.chunk_symbols != 0u) {
+            const uint64_t first = begin, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
+            end = end - first > skip ? end - skip : first;
+            begin = end - first > ca.chunk_symbols ? end - ca.chunk_symbols : first;
+            more_left = begin > first;
+        }
         const uint64_t len = end - begin;
         // (packed queries skip the configured lookup table: the steps it replaces give the same interval)
         const uint32_t t = (kMode == 2 || kPacked) ? 0u
@@ -944,7 +960,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             if (out_status && !unchanged) out_status[q] = static_cast<uint8_t>(status);
             if (out_hint) out_hint[q] = hv;
         }
-        if (kMode == 2 && ca.active_out != nullptr && writer && !deferred && lo != hi && (status & 0xffu) == 0u)
+        if (kMode == 2 && ca.active_out != nullptr && writer && !deferred && lo != hi && (status & 0xffu) == 0u && more_left)
             s_alive[at - base] = static_cast<uint32_t>(q);  // the cursors that can still be extended
         if (kStats && step_stats) {  // the wavefront ran max(iters) iterations for this batch of queries
             uint32_t wave_max = iters;

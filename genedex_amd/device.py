@@ -188,6 +188,15 @@ class DeviceEngine:
                                                                 opt(n_active_in), opt(active_out), opt(n_active_out),
                                                                 _stream()))
 
+    def cursor_extend_chunk(self, start, end, qbuf, qoff, m, chunk_symbols, chunk_index, status=None, active_in=None,
+                            n_active_in=None, active_out=None, n_active_out=None) -> None:
+        """gdx_cursor_extend_front_chunk_dev: chunk `chunk_index` (from the right) of every query, no edge arrays."""
+        opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
+        _lib.check(self.lib.gdx_cursor_extend_front_chunk_dev(self.h, _ptr(start), _ptr(end), _ptr(qbuf), _ptr(qoff), m,
+                                                              int(chunk_symbols), int(chunk_index), opt(status),
+                                                              opt(active_in), opt(n_active_in), opt(active_out),
+                                                              opt(n_active_out), _stream()))
+
     def search_step_stats(self, q: DeviceQueries):
         """(LF steps, line fetches of all queries, fetch slots their wavefronts spent)"""
         steps = torch.zeros(3, dtype=torch.int64, device=self.dev)

@@ -388,6 +388,16 @@ int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start /*u
                                         uint64_t m, void *d_status /*u8 or NULL*/, const void *d_active_in,
                                         const void *d_n_active_in, void *d_active_out, void *d_n_active_out,
                                         void *stream);
+/* The same for callers that feed whole queries a chunk at a time (what a read mapper does): call k = 0, 1, 2, ...
+ * extends cursor i by chunk k of query i, counted from the query's END in chunks of chunk_symbols symbols -- the
+ * symbols [max(qoff[i], qoff[i+1] - (k + 1) c), qoff[i+1] - k c), nothing when the query is shorter than k c.  No
+ * per-call offset arrays, and the live list is sharper: a cursor is appended to d_active_out only if it is
+ * non-empty, not stopped AND its query has symbols left of this chunk, so a call never visits a finished query. */
+int gdx_cursor_extend_front_chunk_dev(const gdx_index_t *ix, void *d_start /*u32*/, void *d_end /*u32*/,
+                                      const void *d_qbuf, const void *d_qoff /*u64[m+1]*/, uint64_t m,
+                                      uint32_t chunk_symbols, uint32_t chunk_index, void *d_status,
+                                      const void *d_active_in, const void *d_n_active_in, void *d_active_out,
+                                      void *d_n_active_out, void *stream);
 /* host form: strings = qbuf + qoff[m+1]; start / end in / out; status (in / out, may be NULL) */
 int gdx_cursor_extend_front_strings(const gdx_index_t *ix, uint64_t *start, uint64_t *end, const uint8_t *qbuf,
                                     const uint64_t *qoff, uint64_t m, uint8_t *status);

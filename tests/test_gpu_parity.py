@@ -889,6 +889,25 @@ def test_cursor_strings_in_chunks_equal_fused_search(chunk, search_variant):
     assert cur_e.cpu().numpy().astype(np.uint32).tolist() == ce.astype(np.uint32).tolist()
     assert not cur_st.any().item()
     assert seen_counts == sorted(seen_counts, reverse=True)  # cursors only ever leave the list
+    # gdx_cursor_extend_front_chunk_dev: the same feeding without edge arrays; its live list holds the cursors that
+    # are non-empty AND have symbols left of the chunk just taken
+    ck_s = torch.zeros(m, dtype=torch.int32, device="cuda")
+    ck_e = torch.full((m,), n, dtype=torch.int32, device="cuda")
+    ck_st = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    lens = (end - beg)
+    a_in, na_in = None, None
+    k = 0
+    while True:
+        eng.cursor_extend_chunk(ck_s, ck_e, dq.qbuf, dq.qoff, m, chunk, k, ck_st, a_in, na_in, act[1], n_act[1])
+        live = int(n_act[1].item())
+        want = torch.nonzero((ck_s != ck_e) & (lens > (k + 1) * chunk)).flatten().cpu().tolist()
+        got = act[1][:live].cpu().tolist()
+        assert sorted(got) == want
+        if live == 0:
+            break
+        a_in, na_in = act[1].clone(), n_act[1].clone()
+        k += 1
+    assert torch.equal(ck_s, cur_s) and torch.equal(ck_e, cur_e) and not ck_st.any().item()
     # host form, whole strings at once, and the Python mirror of Cursor
     s0 = np.zeros(m, dtype=np.uint64)
     e0 = np.full(m, n, dtype=np.uint64)
