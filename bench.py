@@ -408,7 +408,11 @@ def main():
     # PMC passes first: they are separate processes that each need the GPU's memory for their own index, and starting
     # them before this process initialises the GPU keeps every exec clear of a process that holds the device
     pmc, pmc_note, pmc_ref = None, "live PMC passes run at N = 1 only", None
-    if world == 1 and not args.no_live_pmc:
+    profiled = any(k in os.environ for k in ("ROCPROFILER_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled:  # under rocprofv3 already (its preload initialised the GPU): no nested profiler children
+        pmc_note = "bench.py itself runs under a profiler"
+    elif world == 1 and not args.no_live_pmc:
         pmc, pmc_note = run_live_pmc(args)
         if pmc is None:
             log(f"[bench] live PMC unavailable: {pmc_note}")
@@ -644,7 +648,8 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     o = runner.outs[0]
     max_count = int(runner.counts(o).max().item()) if nq else 0
     max_count = gdist.max_int_over_ranks(max_count, dev)
-    count_dtype = torch.uint8 if max_count <= 0xff else (torch.int16 if max_count <= 0x7fff else torch.int32)
+    # (torch's RCCL process group maps int8 / uint8 / int32 / int64 and the float types only: no 16-bit integers)
+    count_dtype = torch.uint8 if max_count <= 0xff else torch.int32
     max_hits = gdist.max_int_over_ranks(runner.total_hits, dev)
     max_nq = gdist.max_int_over_ranks(nq, dev)
     runner.hits = [torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]

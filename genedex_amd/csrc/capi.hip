@@ -157,9 +157,14 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
 {
     gdx::BuildOptions b;
     if (!o) return b;
-    if (o->struct_size < sizeof(gdx_build_options_t))
-        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_build_options_t.struct_size is %u, expected %zu (use gdx_build_options_init)",
-                  o->struct_size, sizeof(gdx_build_options_t));
+    // struct_size lets the struct grow: a caller compiled against an older header passes a shorter struct, whose
+    // missing tail takes the defaults; a longer one (newer caller) is read up to what this library knows
+    gdx_build_options_t full;
+    gdx_build_options_init(&full);
+    if (o->struct_size < 2 * sizeof(uint32_t))
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_build_options_t.struct_size is %u (use gdx_build_options_init)", o->struct_size);
+    std::memcpy(&full, o, o->struct_size < sizeof(full) ? o->struct_size : sizeof(full));
+    o = &full;
     if (o->pair_lines < -1 || o->pair_lines > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "pair_lines must be -1, 0 or 1");
     if (o->jump_entry_bytes != -1 && o->jump_entry_bytes != 0 && o->jump_entry_bytes != 8 && o->jump_entry_bytes != 16 &&
         o->jump_entry_bytes != 32)
@@ -355,9 +360,14 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
     return guarded([&] {
         if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
         gdx::QueryOptions q;
+        gdx_query_options_t full;
         if (opts) {
-            if (opts->struct_size < sizeof(gdx_query_options_t))
+            // (struct_size: as in make_build_options -- a shorter struct of an older caller keeps defaults for the rest)
+            gdx_query_options_init(&full);
+            if (opts->struct_size < 2 * sizeof(uint32_t))
                 gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t.struct_size is too small (use gdx_query_options_init)");
+            std::memcpy(&full, opts, opts->struct_size < sizeof(full) ? opts->struct_size : sizeof(full));
+            opts = &full;
             if (opts->search_kernel < -1 || opts->search_kernel > 2 ||
                 (opts->search_lanes != 0 && opts->search_lanes != 4 && opts->search_lanes != 8) || opts->load_policy < -1 ||
                 opts->load_policy > 3 || opts->length_schedule < -1 || opts->length_schedule > 1 ||
@@ -405,6 +415,7 @@ int gdx_index_rebuild_aux(gdx_index_t *ix, const gdx_build_options_t *opts)
 {
     return guarded([&] {
         if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
+        DeviceGuard guard(ix->impl->config().device_id);
         ix->impl->rebuild_aux(make_build_options(opts));
         return (int)GDX_OK;
     });
@@ -1068,9 +1079,12 @@ int gdx_multi_from_indexes(gdx_index_t **replicas, int n_replicas, gdx_multi_t *
         *out = nullptr;
         for (int r = 0; r < n_replicas; r++) {
             if (!replicas[r] || !replicas[r]->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "replica %d is null", r);
+            for (int k = 0; k < r; k++)
+                if (replicas[k] == replicas[r]) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "replica %d is the same handle as replica %d", r, k);
             const gdx::FmIndex &a = *replicas[0]->impl, &b = *replicas[r]->impl;
             if (a.total_text_len() != b.total_text_len() || a.num_texts() != b.num_texts() ||
                 a.config().sa_rate != b.config().sa_rate || a.config().sigma != b.config().sigma ||
+                a.config().n_searchable != b.config().n_searchable || a.config().lookup_depth != b.config().lookup_depth ||
                 std::memcmp(a.config().io_to_dense, b.config().io_to_dense, 256) != 0)
                 gdx::fail(GDX_ERR_INVALID_ARGUMENT, "replica %d was not built from the same texts / configuration", r);
         }
@@ -1080,6 +1094,7 @@ int gdx_multi_from_indexes(gdx_index_t **replicas, int n_replicas, gdx_multi_t *
             delete replicas[r];  // the handle is consumed
             replicas[r] = nullptr;
         }
+        m->start_workers();
         *out = new gdx_multi{std::move(m)};
         return (int)GDX_OK;
     });
@@ -1114,6 +1129,7 @@ int gdx_multi_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint
         for (auto &t : threads) t.join();
         for (int r = 0; r < n_devices; r++)
             if (status[r] != GDX_OK) gdx::fail(status[r], "device %d: %s", device_ids[r], errors[r].c_str());
+        m->start_workers();
         *out = new gdx_multi{std::move(m)};
         return (int)GDX_OK;
     });

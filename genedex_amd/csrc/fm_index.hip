@@ -681,6 +681,12 @@ void validate_config(const IndexConfig &cfg)
         pw *= cfg.n_searchable;
     }
     if (total >= 2147483648.0) fail(GDX_ERR_INVALID_ARGUMENT, "lookup tables would need %.3g entries", total);
+    // every entry point (build, import, load of an untrusted file): a dense code indexes count[] and the superblock
+    // offsets at query time
+    for (int b = 0; b < 256; b++)
+        if (cfg.io_to_dense[b] >= cfg.sigma)
+            fail(GDX_ERR_INVALID_ARGUMENT, "io_to_dense[%d] = %d is not a dense symbol (sigma = %d)", b,
+                 static_cast<int>(cfg.io_to_dense[b]), cfg.sigma);
     int dc = 0;
     if (hipGetDeviceCount(&dc) != hipSuccess || dc <= 0) fail(GDX_ERR_DEVICE, "no HIP device available");
     if (cfg.device_id < 0 || cfg.device_id >= dc) fail(GDX_ERR_INVALID_ARGUMENT, "device_id %d out of range", cfg.device_id);
@@ -982,8 +988,14 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
     DeviceBuffer<uint8_t> d_bwt;
     if (view_.layout == 0 && n_ > 0) {
         const uint64_t padded = div_ceil(n_ + 1, 128) * 128;
-        // the rank lines stay; the pair lines are rebuilt from the BWT they encode
+        // the rank lines stay; the pair lines are rebuilt from the BWT they encode.  The view forgets every table
+        // before its buffer goes: if an allocation below throws, the handle stays usable on the rank lines
         view_.pair_lines = nullptr;
+        view_.jump = nullptr;
+        view_.jump_bytes = 0;
+        view_.top = nullptr;
+        view_.top_depth = 0;
+        aux_report_ = AuxReport{};
         pair_lines_.release();
         jump_.release();
         top_.release();

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "build.hpp"
@@ -166,8 +167,10 @@ private:
 
 struct Multi {
     std::vector<std::unique_ptr<FmIndex>> replicas;
-    std::vector<std::unique_ptr<ReplicaWorker>> workers;  // one per replica, created on first use
-    ReplicaWorker &worker(size_t r);
+    std::vector<std::unique_ptr<ReplicaWorker>> workers;  // one per replica (start_workers)
+    std::mutex call_mutex;  // calls on one handle run one after the other: a second concurrent call queues here
+    void start_workers();   // once, when the replicas are in place
+    ReplicaWorker &worker(size_t r) { return *workers[r]; }
 };
 int multi_cursors(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
                   uint64_t *out_end, uint64_t *out_count, uint8_t *out_status);

@@ -66,6 +66,8 @@ inline FileHeader read_index_header(IndexFile &in, const char *path)
         h.n_samples != div_ceil_u64(h.n, h.sa_rate) ||
         h.n_plane_words != div_ceil_u64(h.n + 1, 64) * static_cast<uint64_t>(plane_bits(static_cast<uint64_t>(h.sigma))))
         fail(GDX_ERR_INVALID_ARGUMENT, "index file header is inconsistent");
+    for (int b = 0; b < 256; b++)  // a dense code indexes count[] and the superblock offsets at query time
+        if (h.io_to_dense[b] >= h.sigma) fail(GDX_ERR_INVALID_ARGUMENT, "index file header: io_to_dense[%d] is not a dense symbol", b);
     const uint64_t payload = (static_cast<uint64_t>(h.sigma) + 1 + 3 * h.n_texts + h.n_plane_words) * sizeof(uint64_t) +
                              h.n_samples * sizeof(uint32_t);
     const long at = std::ftell(in.f);

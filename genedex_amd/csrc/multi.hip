@@ -75,11 +75,10 @@ void ReplicaWorker::wait()
     impl_->idle.wait(g, [this] { return impl_->jobs.empty() && impl_->running == 0; });
 }
 
-ReplicaWorker &Multi::worker(size_t r)
+void Multi::start_workers()
 {
-    if (workers.size() < replicas.size()) workers.resize(replicas.size());
-    if (!workers[r]) workers[r] = std::make_unique<ReplicaWorker>();
-    return *workers[r];
+    workers.clear();
+    for (size_t r = 0; r < replicas.size(); r++) workers.push_back(std::make_unique<ReplicaWorker>());
 }
 
 namespace {
@@ -97,20 +96,30 @@ template <class F>
 int run_shards(Multi &m, uint64_t nq, F per_shard)
 {
     const size_t g = m.replicas.size();
+    // one call at a time per handle: the workers' queues then hold this call's jobs only, so waiting for them to go
+    // idle is waiting for this call
+    std::lock_guard<std::mutex> serial(m.call_mutex);
     std::vector<ShardResult> res(g);
-    for (size_t r = 0; r < g; r++) {
-        m.worker(r).submit([&, r] {
-            const uint64_t lo = nq * r / g, hi = nq * (r + 1) / g;
-            try {
-                res[r].rc = per_shard(r, lo, hi, res[r]);
-            } catch (const Error &e) {
-                res[r].rc = e.status;
-                res[r].error = e.what();
-            } catch (const std::exception &e) {
-                res[r].rc = GDX_ERR_DEVICE;
-                res[r].error = e.what();
-            }
-        });
+    size_t submitted = 0;
+    try {
+        for (size_t r = 0; r < g; r++) {
+            m.worker(r).submit([&, r] {
+                const uint64_t lo = nq * r / g, hi = nq * (r + 1) / g;
+                try {
+                    res[r].rc = per_shard(r, lo, hi, res[r]);
+                } catch (const Error &e) {
+                    res[r].rc = e.status;
+                    res[r].error = e.what();
+                } catch (const std::exception &e) {
+                    res[r].rc = GDX_ERR_DEVICE;
+                    res[r].error = e.what();
+                }
+            });
+            submitted++;
+        }
+    } catch (...) {  // (a submit that ran out of memory) the jobs already queued still reference res: let them finish
+        for (size_t r = 0; r < submitted; r++) m.worker(r).wait();
+        throw;
     }
     for (size_t r = 0; r < g; r++) m.worker(r).wait();
     int rc = GDX_OK;

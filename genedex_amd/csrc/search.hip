@@ -1767,6 +1767,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         static const int env_fast = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : -1; }();
         const bool fast = c.mode == 1 && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
                           ix.top != nullptr && ix.top_depth >= 1u && ix.jump != nullptr &&
+                          // the guards of the general kernel's top-table step (search_pair_body): dense 1..4 must all be
+                          // searchable, and a configured lookup table deeper than the top table keeps its own check of
+                          // the symbols between the two depths (a valid but unsearchable symbol there is an error, not a
+                          // step) -- a leftover resumed after the top table would skip it
+                          ix.n_searchable >= 4 && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
                           ca.active_in == nullptr && c.d_hint == nullptr && c.d_start == nullptr && c.d_end == nullptr &&
                           (env_fast >= 0 ? env_fast != 0 : qo.search_fast != 0) && nq < 0xffffffffull;
         CursorArgs ca_general = ca;

@@ -293,8 +293,10 @@ def genome_like_text(total: int, dev, seed: int = 7) -> torch.Tensor:
         src, dst = int(rng.integers(0, total - ln)), int(rng.integers(0, total - ln))
         seg = text[src:src + ln].clone()
         n_mut = max(1, ln // 200)
-        at = torch.randint(0, ln, (n_mut,), device=dev, generator=g)
-        seg[at] = acgt[torch.randint(0, 4, (n_mut,), device=dev, generator=g)]
+        # distinct positions: a scatter with duplicate indices has no defined winner, and the text must be the same
+        # text in every run
+        at = torch.unique(torch.randint(0, ln, (n_mut,), device=dev, generator=g))
+        seg[at] = acgt[torch.randint(0, 4, (at.numel(),), device=dev, generator=g)]
         text[dst:dst + ln] = seg
         return ln
 

@@ -299,6 +299,39 @@ def test_status_codes_match_the_reference_panics(search_variant):
             g.cursors_raw(qbuf, qoff)  # strict: a reference panic is an error of the call
 
 
+@pytest.mark.parametrize("fast", [0, 1, 2])
+def test_lookup_deeper_than_top_table_with_unsearchable_symbol(fast):
+    """The fast path must not take a query whose N sits between the top table's depth and the configured lookup
+    depth: the reference rejects it (lookup_table.rs:154-158 -> GDX_Q_UNSEARCHABLE_IN_LOOKUP), whatever
+    search_fast says, for the count, the record (locate) and the interval entry points alike."""
+    rng = np.random.default_rng(1234)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=20000, symbols=b"ACGT")
+    g, c = both(texts, a, depth=6, top_table_depth=4)
+    g.set_query_options(search_kernel="pair", search_fast=fast)
+    qs = []
+    for q in mixed_queries(rng, texts, 300, 50, 40):
+        if len(q) >= 24:
+            k = int(rng.integers(0, 3))
+            if k == 0:  # an N right above the top table's four symbols, inside the six of the lookup table
+                q = q[:-5] + b"N" + q[-4:]
+            elif k == 1:  # an N outside both: consumed by an LF step, count 0, status OK
+                q = q[:-9] + b"N" + q[-8:]
+        qs.append(q)
+    qbuf, qoff = pack_queries(qs)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    assert (cst == 2).sum() > 20 and (cst == 0).sum() > 100
+    s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+    counts, st_count = g.count_raw(qbuf, qoff, strict=False)
+    off, t, p, st_loc = g.locate_raw(qbuf, qoff, strict=False)
+    assert st.tolist() == cst.tolist() and st_count.tolist() == cst.tolist() and st_loc.tolist() == cst.tolist()
+    ok = cst == 0
+    assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+    assert counts[ok].tolist() == (ce - cs)[ok].tolist() and not counts[~ok].any()
+    co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+
+
 def test_cursor_api():
     rng = np.random.default_rng(9)
     a = alph.ascii_dna_with_n()

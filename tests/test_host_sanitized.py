@@ -67,14 +67,14 @@ def test_fastx_reader_on_wellformed_and_malformed_files(checker, tmp_path):
 
 
 def header_bytes(n=1000, n_texts=2, sa_rate=4, sigma=6, n_searchable=4, depth=0, width=32, plane_words=None,
-                 n_samples=None, magic=b"GDXIDX01"):
+                 n_samples=None, magic=b"GDXIDX01", table=bytes(256)):
     bits = max(1, (sigma - 1).bit_length()) if sigma > 1 else 0
     if plane_words is None:
         plane_words = -(-(n + 1) // 64) * bits
     if n_samples is None:
         n_samples = -(-n // sa_rate) if sa_rate else 0
     return (magic + struct.pack("<5Q4i", n, n_texts, sa_rate, plane_words, n_samples, sigma, n_searchable, depth, width)
-            + bytes(256)), plane_words, n_samples
+            + table), plane_words, n_samples
 
 
 def test_index_file_header_validation(checker, tmp_path):
@@ -106,7 +106,14 @@ def test_index_file_header_validation(checker, tmp_path):
         "negative_depth": (header_bytes(depth=-1)[0], payload),
         "odd_width": (header_bytes(width=48)[0], payload),
         "empty_file": (b"", 0),
+        # a byte that maps to a dense code >= sigma would index count[] / the superblock offsets out of bounds at query time
+        "dense_code_ge_sigma": (header_bytes(table=bytes(65) + bytes([6]) + bytes(190))[0], payload),
+        "dense_code_255": (header_bytes(table=bytes(255) + bytes([255]))[0], payload),
     }
+    ok_table = bytearray(256)
+    ok_table[65], ok_table[67] = 1, 5  # the largest dense code, sigma - 1, is fine
+    rc, out = checker("header", write("good_table.gdx", header_bytes(table=bytes(ok_table))[0], payload))
+    assert rc == 0, out
     for name, (hdr, pay) in bad.items():
         rc, out = checker("header", write(name + ".gdx", hdr, pay))
         assert rc == 3 and out.startswith("error:"), (name, out)

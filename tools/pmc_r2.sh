@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-bandwidth --secondary-depth 0 --verify-hits 0 $*"
+ARGS="--no-live-pmc --no-strong --no-extras --steps 1 --warmup 0 --no-cpu-baseline --no-bandwidth --secondary-depth 0 --verify-hits 0 $*"
 i=0
 for grp in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_HIT_sum" \
            "FETCH_SIZE" "WRITE_SIZE" \
