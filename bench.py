@@ -39,15 +39,18 @@ if ROOT not in sys.path:
 WORKLOADS = {
     # BASELINE.md section 3, workload 3/4: 24 texts proportional to hg38, 100 M reads of length 50
     "hg38": dict(total=3_100_000_000, n_texts=24, nq=100_000_000, len_min=50, len_max=50, sampled_ppm=900_000,
-                 storage="u32", label="hg38-scale 3.1G DNA-N text (24 texts), 100M len-50 reads 90% sampled / 10% random"),
+                 storage="u32", short="hg38-scale 3.1G text, 100M len-50 reads",
+                 label="hg38-scale 3.1G DNA-N text (24 texts), 100M len-50 reads 90% sampled / 10% random"),
     # workload 5: mixed lengths, early termination
     "mixed": dict(total=3_100_000_000, n_texts=24, nq=50_000_000, len_min=20, len_max=150, sampled_ppm=700_000,
-                  storage="u32", label="hg38-scale text, 50M reads of length 20..150, 70% sampled / 30% random"),
+                  storage="u32", short="hg38-scale text, 50M reads len 20..150",
+                  label="hg38-scale text, 50M reads of length 20..150, 70% sampled / 30% random"),
     # workload 2
     "cfg2": dict(total=1 << 28, n_texts=1, nq=10_000_000, len_min=50, len_max=50, sampled_ppm=900_000,
-                 storage="i32", label="256 MB DNA-N text, 10M len-50 reads"),
+                 storage="i32", short="256 MB text, 10M len-50 reads", label="256 MB DNA-N text, 10M len-50 reads"),
     "small": dict(total=1 << 24, n_texts=3, nq=1_000_000, len_min=50, len_max=50, sampled_ppm=900_000,
-                  storage="i32", label="16 MB DNA-N text, 1M len-50 reads (plumbing check)"),
+                  storage="i32", short="16 MB text, 1M len-50 reads",
+                  label="16 MB DNA-N text, 1M len-50 reads (plumbing check)"),
 }
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -276,6 +279,7 @@ class StepRunner:
         self.total_hits = 0
         self.hits, self.ws = [], []
         self.ev_search, self.ev_locate = [], []
+        self.sized_in_step = True  # the timed step reads the number of hits back and sizes the hit buffer itself
 
     def _alloc(self):
         o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
@@ -340,6 +344,17 @@ class StepRunner:
                 side_stream.wait_event(b)
             if self.do_locate:
                 self.offsets(o)
+                if self.sized_in_step:
+                    # what a caller cannot skip: the number of hits comes back to the host (one 8-byte copy + a stream
+                    # sync) and sizes the hit buffer; the buffers only grow, so a steady state allocates nothing
+                    self.total_hits = int(o["hit_offsets"][self.nq].item()) if self.nq else 0
+                    if self.total_hits > self.hits[slot].shape[0]:
+                        self.hits[slot] = torch.empty((self.total_hits, 2), dtype=torch.int32, device=h.device)
+                        h = self.hits[slot]
+                    need = self.eng.locate_workspace_bytes(self.total_hits)
+                    if need > self.ws[slot].numel():
+                        self.ws[slot] = torch.empty(need, dtype=torch.uint8, device=h.device)
+                        ws = self.ws[slot]
                 c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 c.record()
                 self.locate(o, h, ws)
@@ -524,15 +539,34 @@ def main():
     roofline["algorithmic_bytes_per_launch"] = search_bytes
     roofline["lf_steps_per_launch"] = lf_steps
     roofline["algorithmic_ratio"] = search_bytes / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
-    roofline["note"] = ("The search step is the fast-path kernel (top table + jumps + lazy tail) followed by the general "
-                        "kernel on the few queries it left over; traffic, requests and avg_launch_ms are those of both "
-                        "launches together (rocprofv3's kernel stats list them separately). "
-                        "frac = measured HBM traffic of the kernel / its live HIP-event duration / 8 TB/s. "
-                        "algorithmic_ratio = the reference algorithm's logical bytes (60 B per LF step it would execute "
-                        "+ query bytes + 8 B result, SURVEY.md 8d) / the same time / 8 TB/s: it exceeds 1 because the top "
-                        "table, the jump table and the lazy tail deliver those LF steps with far fewer fetches, not "
-                        "because HBM exceeds its peak. The kernel is a chain of dependent random 128-byte requests; see "
-                        "random_request_model for that bound.")
+    # SURVEY 8(d) literally: algorithmic bytes / kernel time (/ peak).  Above 1 on this index, because the top and jump
+    # tables deliver the reference's LF steps with far fewer fetches; the fraction that IS a roofline fraction of the
+    # reference's own work is `reference_layout.frac_algorithmic` below (the same kernel family on the reference's arrays)
+    roofline["achieved_algorithmic"] = search_bytes / (search_ms / 1e3) / 1e9
+    roofline["frac_algorithmic"] = roofline["algorithmic_ratio"]
+    # bytes the kernels actually consume per launch: query bytes + one 8-byte offset + one 8-byte top entry + 32 bytes per
+    # jump entry (ceil((len - D) / 40) per read: 32 steps + an 8-symbol lookahead each) + the 16-byte record written
+    mean_len = queries.total_bytes / max(nq, 1)
+    entries = max(0.0, -(-(mean_len - aux["top_table_depth"]) // 40)) if aux["jump_entry_bytes"] == 32 else None
+    if entries is not None and aux["top_table_depth"]:
+        useful = queries.total_bytes + nq * (8 + 8 + 32 * entries + 16)
+        roofline["useful_bytes_per_launch"] = useful
+        roofline["useful_bytes_per_query"] = useful / nq
+        if search_traffic:
+            roofline["wasted_traffic_ratio"] = search_traffic["bytes"] / useful
+            roofline["frac_useful"] = useful / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
+    roofline["note"] = "frac=PMC traffic/time/peak; frac_algorithmic=SURVEY 8d bytes/time/peak (>1: tables replace LF steps)"
+    roofline["note_long"] = ("The search step is the fast-path kernel (top table + jumps + lazy tail) followed by the general "
+                             "kernel on the few queries it left over; traffic, requests and avg_launch_ms are those of both "
+                             "launches together (rocprofv3's kernel stats list them separately). "
+                             "frac = measured HBM traffic of the kernel / its live HIP-event duration / 8 TB/s. "
+                             "frac_algorithmic = the reference algorithm's logical bytes (60 B per LF step it would execute "
+                             "+ query bytes + 8 B result, SURVEY.md 8d) / the same time / 8 TB/s: it exceeds 1 because the "
+                             "top table, the jump table and the lazy tail deliver those LF steps with far fewer fetches. "
+                             "wasted_traffic_ratio = traffic / the bytes the kernels consume (every 8-byte top entry and "
+                             "32-byte jump entry costs a 128-byte DRAM request). The kernel is a chain of dependent random "
+                             "128-byte requests; see random_request_model for that bound; reference_layout = the same "
+                             "measurement on the reference's arrays alone (frac_algorithmic there is a true 8d fraction).")
     roofline["line_fetches_per_query_exact_mode"] = fetches / nq if fetches else None
     roofline["active_lane_fraction_exact_mode"] = fetches / fetch_slots if fetch_slots else None
     locate_roofline = None
@@ -577,9 +611,10 @@ def main():
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"{wl['label']}; index = reference arrays + pair lines + {aux['jump_entry_bytes']}-byte jump "
-                               f"entries + depth-{aux['top_table_depth']} top table ({index.info.device_bytes / 1e9:.1f} GB "
-                               f"per replica)",
+        "config": {"workload": f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + pair "
+                               f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
+                               f"top table; {wl['label']}",
+                   "index_gb_per_replica": index.info.device_bytes / 1e9,
                    "name": args.workload, "op": args.op, "path": args.path, "queries_per_gpu": nq,
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
@@ -635,6 +670,15 @@ def main():
         del eng, index
         result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
                                           args, wl, pmc_ref)
+        for r in result["secondary"]:  # the like-for-like rung, in the keys the driver keeps
+            rl = r.get("roofline_reference_layout")
+            if rl:
+                roofline["reference_layout"] = {
+                    "index_bytes": r["index_bytes"], "search_ms": r["search_ms"], "value": r["value"],
+                    "frac_traffic": rl.get("frac") if "traffic" in rl else None,
+                    "frac_algorithmic": rl.get("algorithmic_ratio", rl.get("frac")),
+                    "traffic": rl.get("traffic"), "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
+                    "dram_read_requests_per_query": rl.get("dram_read_requests_per_query")}
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -877,8 +921,33 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     chk = verify_hits(torch, text, lengths, q, {"hit_offsets": off}, hits, total_hits, nq, 1_000_000) if total_hits else {}
     if chk and chk["hits_checked"] != chk["hits_matching_text"]:
         raise SystemExit(f"PARITY FAILURE on the genome-like text: {chk}")
+    # oracle gate at bench size, like the headline's: a >= 1 M-query prefix against the CPU restatement on the same index
+    # (counts of every query; hits, in order, of the queries under the limit)
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    n_gate = min(nq, 1_000_000)
+    avail, _ = host_threads()
+    cpu = oracle_from_index(np, index, alpha, args, wl, avail)
+    qb, qo = q.host_slice(0, n_gate)
+    cs, ce = cpu.cursors_for_many(qb, qo, n_threads=avail)
+    g_counts = counts[:n_gate].cpu().numpy().astype(np.uint64)
+    gate_counts = bool(np.array_equal(g_counts, ce - cs))
+    keep = (ce - cs) <= max_hits
+    co, ct, cp = cpu.locate_intervals(np.where(keep, cs, 0), np.where(keep, ce, 0), n_threads=avail)
+    n_h = int(co[-1])
+    gh = hits[:n_h].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    goff = off[:n_gate + 1].cpu().numpy().astype(np.uint64)
+    gate_hits = bool(np.array_equal(goff, co) and np.array_equal(gh[:, 0], ct.astype(np.int64))
+                     and np.array_equal(gh[:, 1], cp.astype(np.int64)))
+    del cpu
+    if not gate_counts or not gate_hits:
+        raise SystemExit(f"PARITY FAILURE on the genome-like text vs the CPU oracle: counts {gate_counts}, hits {gate_hits}")
     lf_steps, fetches, slots = eng.search_step_stats(q)
     res = {"name": "genome_like_text (repeats, tandem repeats, poly-A, N gaps)", "text_len": total, "queries": nq,
+           "oracle_gate": {"queries": n_gate, "hits": n_h, "counts_identical": gate_counts, "hits_identical": gate_hits},
+           "text_checksum": int(text[: total // 8 * 8].view(torch.int64).sum().item()),  # the same text in every run
            "max_hits_located_per_query": max_hits, "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
            "search_ms": sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev),
            "scan_and_locate_ms": sum(b.elapsed_time(c) for _, b, c in ev) / len(ev),
@@ -1161,12 +1230,47 @@ def verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, n_c
     return {"hits_checked": int(h.numel()), "hits_matching_text": int(ok.sum().item())}
 
 
-def cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl):
-    """The CPU restatement of genedex's batched path (oracle/), timed on all host cores on a bounded sample
-    of the same queries against the same index, and compared bit for bit with the GPU results."""
+def host_threads():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup CPU quota if there is one
+    (os.cpu_count() reports the machine, not the container)."""
+    n = len(os.sched_getaffinity(0))
+    note = f"affinity {n} of {os.cpu_count()} CPUs"
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            q = parse(open(path).read())
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+        if q is not None:
+            note += f", cgroup quota {q:.1f} CPUs"
+            n = max(1, min(n, int(q)))
+        break
+    return n, note
+
+
+def oracle_from_index(np, index, alpha, args, wl, n_threads, lib=None):
+    """The CPU restatement's index (reference layout) from the arrays the GPU build exports."""
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    bwt = index.export_bwt()
+    samples = index.export_sa_samples()
+    bk, bv = index.export_borders()
+    sent = index.export_sentinel_indices()
+    width = {"u32": 32, "i32": -32, "i64": 64}[wl["storage"]]
+    return orc.OracleIndex.from_bwt(bwt, samples, args.sa_rate, bk, bv, sent, alpha.io_to_dense_table, 6, 4,
+                                    lookup_depth=args.lookup_depth, width=width, n_threads=n_threads, lib=lib)
+
+
+def cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl):
+    """The CPU restatement of genedex's batched path (oracle/), timed on the host cores of this box on a bounded sample
+    of the same queries against the same index, and compared bit for bit with the GPU results.  The thread count is
+    swept (1, 8, 32, 64, 128, all usable CPUs) and the best is reported, with the sweep."""
+    from oracle import oracle as orc
+
+    avail, avail_note = host_threads()
+    # (libgomp reads these when it is loaded: threads spread over the cores and stay there)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "threads")
     lib = None
     try:  # rebuild for this host's CPU; fall back to the shipped generic build
         path = orc.build_oracle(out=f"/tmp/libgdx_oracle_native_{os.getpid()}.so",
@@ -1176,33 +1280,35 @@ def cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl):
         log(f"[bench] native oracle build failed ({e}); using the shipped build")
         lib = orc.load()
     t0 = time.time()
-    bwt = index.export_bwt()
-    samples = index.export_sa_samples()
-    bk, bv = index.export_borders()
-    sent = index.export_sentinel_indices()
-    width = {"u32": 32, "i32": -32, "i64": 64}[wl["storage"]]
-    cpu = orc.OracleIndex.from_bwt(bwt, samples, args.sa_rate, bk, bv, sent, alpha.io_to_dense_table, 6, 4,
-                                   lookup_depth=args.lookup_depth, width=width, n_threads=cores, lib=lib)
-    del bwt, samples
-    log(f"[bench] CPU index (reference layout) ready in {time.time() - t0:.1f}s on {cores} threads")
+    cpu = oracle_from_index(np, index, alpha, args, wl, avail, lib)
+    log(f"[bench] CPU index (reference layout, huge pages, parallel first touch) ready in {time.time() - t0:.1f}s; {avail_note}")
 
-    def run(first, count):
+    def run(first, count, threads):
         qbuf, qoff = queries.host_slice(first, count)
         t0 = time.perf_counter()
-        s, e = cpu.cursors_for_many(qbuf, qoff, n_threads=cores)
+        s, e = cpu.cursors_for_many(qbuf, qoff, n_threads=threads)
         t_count = time.perf_counter() - t0
         t_loc, loc = 0.0, None
         if do_locate:
             t0 = time.perf_counter()
-            loc = cpu.locate_intervals(s, e, n_threads=cores)
+            loc = cpu.locate_intervals(s, e, n_threads=threads)
             t_loc = time.perf_counter() - t0
         return s, e, loc, t_count, t_loc
 
-    calib = min(queries.nq, 200_000)
-    _, _, _, tc, tl = run(0, calib)
-    rate = calib / max(tc + tl, 1e-6)
-    n_sample = int(min(queries.nq, max(calib, rate * args.cpu_seconds)))
-    s, e, loc, tc, tl = run(0, n_sample)
+    # thread sweep, ~1.5 s of CPU work each (sized from a one-thread calibration)
+    calib = min(queries.nq, 50_000)
+    _, _, _, tc, tl = run(0, calib, 1)
+    rate1 = calib / max(tc + tl, 1e-6)
+    sweep = {}
+    for th in sorted({t for t in (1, 8, 32, 64, 128, avail) if t <= avail}):
+        m = int(min(queries.nq, max(calib, rate1 * min(th, 48) * 1.5)))
+        run(0, min(m, 20_000 * th), th)  # threads started, pages of the outputs touched
+        _, _, _, tc, tl = run(0, m, th)
+        sweep[th] = {"queries": m, "count_s": tc, "locate_s": tl, "qps": m / (tc + tl), "count_only_qps": m / tc}
+        log(f"[bench] CPU baseline sweep: {th} threads -> {sweep[th]['qps']:.3e} q/s (count only {sweep[th]['count_only_qps']:.3e})")
+    best = max(sweep, key=lambda t: sweep[t]["qps"])
+    n_sample = int(min(queries.nq, max(calib, sweep[best]["qps"] * args.cpu_seconds)))
+    s, e, loc, tc, tl = run(0, n_sample, best)
     value = n_sample / (tc + tl)
     # bit-exactness at full index size: the timed path's counts and hits (same order), and the exact intervals of
     # the interval call (cursors_for_many_queries) on the same prefix
@@ -1237,12 +1343,18 @@ def cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl):
     t0 = time.perf_counter()
     cpu.cursors_single(qbuf1, qoff1, n_threads=1)
     t_single1 = time.perf_counter() - t0
-    log(f"[bench] CPU baseline: {n_sample} queries, count {tc:.2f}s + locate {tl:.2f}s on {cores} threads "
+    log(f"[bench] CPU baseline: {n_sample} queries, count {tc:.2f}s + locate {tl:.2f}s on {best} threads "
         f"-> {value:.3e} q/s; GPU results identical: intervals {same_intervals}, counts {same_counts}, hits {same_hits}")
-    return {"value": value, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sample} queries of the GPU batch, same index (BWT + samples exported from the GPU "
-                      f"build, occurrence table rebuilt in the reference layout, lookup depth {args.lookup_depth}, no "
-                      f"acceleration structures), count {tc:.2f}s + locate {tl:.2f}s",
+    one = sweep[min(sweep)]["qps"]
+    return {"value": value, "unit": "queries/s", "cores": best, "kind": "port",
+            "sample": f"first {n_sample} queries, count {tc:.2f}s + locate {tl:.2f}s, {best} of {avail} usable threads",
+            "sample_long": f"first {n_sample} queries of the GPU batch, same index (BWT + samples exported from the GPU "
+                           f"build, occurrence table rebuilt in the reference layout on huge pages, lookup depth "
+                           f"{args.lookup_depth}, no acceleration structures), count {tc:.2f}s + locate {tl:.2f}s",
+            "usable_threads": avail, "usable_threads_note": avail_note,
+            "speedup_over_one_thread": value / one if one else None,
+            "thread_sweep_qps": {str(t): round(v["qps"]) for t, v in sweep.items()},
+            "thread_sweep_count_only_qps": {str(t): round(v["count_only_qps"]) for t, v in sweep.items()},
             "count_only_value": n_sample / tc,
             "bit_exact_vs_gpu": {"intervals": same_intervals, "counts": same_counts, "hits": same_hits},
             "one_thread": {"batched_path_count_qps": m1 / t_batched1, "single_query_path_count_qps": m1 / t_single1,

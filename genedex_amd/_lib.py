@@ -163,6 +163,7 @@ SIGNATURES = {
     "gdx_bench_random_gather": [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_search_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_index_aux_info": [vp, C.POINTER(C.c_uint32)],
+    "gdx_bench_lf_walk_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     "gdx_fastx_open": [C.c_char_p, C.POINTER(vp)],
     "gdx_fastx_next_batch": [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)],
     "gdx_fastx_close": [vp],

@@ -1027,6 +1027,19 @@ int gdx_search_step_stats_dev(const gdx_index_t *ix, const void *d_qbuf, const v
     });
 }
 
+int gdx_bench_lf_walk_dev(const gdx_index_t *ix, const void *d_rows, uint64_t m, uint32_t steps, void *d_symbols,
+                          void *d_end_rows, void *stream)
+{
+    return guarded([&] {
+        DeviceGuard guard(deref(ix).config().device_id);
+        if (m != 0 && (!d_rows || !d_symbols)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_bench_lf_walk_dev: null argument");
+        gdx::launch_lf_walk(deref(ix).view(), static_cast<const uint32_t *>(d_rows), m, steps,
+                            static_cast<uint8_t *>(d_symbols), static_cast<uint32_t *>(d_end_rows), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
 {
     return guarded([&] {

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void derive_bwt0_kernel(IndexView ix, uint8
 // comes from eight LF steps on the rank lines; later levels are copied from the entries of earlier targets:
 //   pass 2: level 2 of i = level 1 of entry t1(i)
 //   pass 3: levels 3, 4 of i = levels 1, 2 of entry t2(i)   (16-byte entries keep only the codes of level 3)
-//   pass 4: level 5 of i = level 1 of entry t4(i)
+//   pass 4: codes of level 5 of i = codes of level 1 of entry t4(i)   (a lookahead: the fifth target gave way to SA[i])
+//   pass 5 (32-byte entries): SA[i] by the locate walk from row i (sampled_suffix_array.rs:110-138)
 // Every pass reads only fields that earlier passes completed and writes only its own entry, whole words at a
 // time, so the passes run in place.
 __device__ __forceinline__ uint32_t jump_valid(const uint32_t *e, uint32_t words)
@@ -386,10 +387,34 @@ __global__ __launch_bounds__(kBlock) void derive_jump_levels_kernel(uint64_t n, 
             if (!(valid & 8u)) continue;
             const uint32_t *s = jump + static_cast<uint64_t>(e[5]) * words;
             if (!(jump_valid(s, words) & 1u)) continue;
-            e[6] = s[0];
             e[7] = (e[7] & 0xffffu) | (jump_code1(s, words) << 16);
             e[3] = (e[3] & 0xffffu) | ((valid | 16u) << 16);
         }
+    }
+}
+
+// word 6 of every 32-byte entry: SA[row], recovered exactly as locate would (walk to a sampled row or to a text start)
+__global__ __launch_bounds__(kBlock) void fill_jump_sa_kernel(IndexView ix, uint32_t *__restrict__ jump)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
+        uint32_t row = static_cast<uint32_t>(p), steps = 0, sa;
+        for (;;) {
+            uint32_t slot;
+            if (sampled_slot(ix, row, slot)) {
+                sa = ix.sa_samples[slot] + steps;
+                break;
+            }
+            uint32_t r;
+            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
+            if (c == 0) {
+                sa = ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, row)] + steps;
+                break;
+            }
+            row = ix.count[c] + r;
+            steps++;
+        }
+        jump[p * 8 + 6] = sa;
     }
 }
 
@@ -951,6 +976,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             for (uint32_t pass = 2; jump_bytes >= 16 && pass <= (jump_bytes == 32 ? 4u : 3u); pass++)
                 hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
                                    pass);
+            if (jump_bytes == 32)
+                hipLaunchKernelGGL(fill_jump_sa_kernel, dim3(grid), dim3(kBlock), 0, stream, view_, jump_.get());
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             view_.jump = jump_.get();

@@ -47,6 +47,9 @@ struct CursorArgs {
 // + count, mask, symbols | kRecMasked}: the hits are SA[first row + j] - symbols for the set bits j of the mask, in
 // that order, which is the reference's.
 constexpr uint32_t kRecMasked = 1u << 23;
+// A RESOLVED record (32-byte jump entries carry SA[row]): {start, end, text position of the one hit, kRecResolved |
+// status << 24}, end - start == 1 -- locate only turns the position into (text id, offset).
+constexpr uint32_t kRecResolved = 1u << 22;
 
 // One search launch.  Query i = d_qbuf[d_qbeg[i] .. d_qend[i]) (d_qend = d_qbeg + 1 for the usual offsets array).
 // mode 0: exact intervals (cursors_for_many_queries); mode 1: count / locate (end - start is the count, start / end
@@ -88,6 +91,9 @@ void launch_rank_many(const IndexView &ix, const uint8_t *d_symbols, const uint3
                       uint32_t *d_out, uint32_t *d_error, hipStream_t stream);
 void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t m, uint8_t *d_out,
                            uint32_t *d_error, hipStream_t stream);
+// gdx_bench_lf_walk_dev (gdx_bench.h): `steps` LF steps from every start row, the BWT symbols met on the way
+void launch_lf_walk(const IndexView &ix, const uint32_t *d_rows, uint64_t m, uint32_t steps, uint8_t *d_symbols,
+                    uint32_t *d_end_rows, hipStream_t stream);
 // fills lookup table `depth` (entries k^depth) of ix.lookup; d_lookup is the writable alias of ix.lookup
 void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream);
 // Top table of the pair kernels (IndexView::top): 4^depth entries, dense symbols 1..4 only, rank-line layout.

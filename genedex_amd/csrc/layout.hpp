@@ -47,7 +47,12 @@ struct IndexView {
     // survives further steps without saying where it goes.  As 32-bit words:
     //    8 bytes: {t1, c1 | valid << 16}                                   1 level
     //   16 bytes: {t1, t2, c1 | c2 << 16, c3 | valid << 16}                 2 levels + lookahead c3
-    //   32 bytes: the same + {t3, t4, t5, c4 | c5 << 16}                    5 levels (c_{j+1} is the lookahead of j)
+    //   32 bytes: the same + {t3, t4, SA[i], c4 | c5 << 16}                 4 levels + lookahead c5 (valid bit 4 = c5
+    //             is usable) and the suffix-array value of the row itself: a search that narrows to one row while
+    //             it holds that row's entry knows the hit's text position (SA[i] - symbols still to match) without
+    //             any locate walk, and locate resolves any other row with one fetch instead of a walk to a sample
+    //             (round 2 stored a fifth target there; the sample read was then one DRAM request per hit and two
+    //             thirds of locate's traffic)
     // Bits 8..11 of the valid field: how many leading symbols of c1 are real (8 when valid bit 0 is set); an entry
     // whose first level is cut short by a sentinel or an N still tells whether its row survives that many steps.
     const void *jump;             // null when absent

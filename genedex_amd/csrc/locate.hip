@@ -156,11 +156,11 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(const uint64_
 // (mean 3 steps at rate 4, maximum over a wavefront ~15) does not idle the other lanes.
 constexpr uint32_t kLocateChunk = 2048;
 
-// Phase 1 walks through the JUMP TABLE when the index has one with at least two levels (kJumpWalk): the entry of
-// row r names the rows after 8, 16, ... LF steps, so one 32-byte fetch offers up to five candidates for a sampled row
-// (SA[r] = SA[t_j] + 8 j; 76 % per fetch at rate 4) where a rank-line step offers one (25 %): 1.3 fetches per walking
-// hit instead of 4.  PMC (profiles/r02): the rank-line walk was 54 % of the kernel's DRAM requests.  A level that is
-// invalid (a sentinel or a symbol outside 1..4 within its eight steps) is crossed with rank-line steps.
+// Phase 1 walks through the JUMP TABLE when the index has 16-byte entries (kJumpWalk): the entry of row r names the
+// rows after 8 and 16 LF steps, so one fetch offers two candidates for a sampled row (SA[r] = SA[t_j] + 8 j) where a
+// rank-line step offers one.  A level that is invalid (a sentinel or a symbol outside 1..4 within its eight steps) is
+// crossed with rank-line steps.  (Round 2 walked 32-byte entries the same way over five targets; they now carry SA[r]
+// itself: kEntrySA.)
 // (the kernel gets the few fields of the IndexView it reads -- the whole view costs SGPRs -- and its queue shares LDS
 // with the slot -> query map, so that eight blocks fit a CU: it ran at 5 waves per SIMD before)
 struct LocateView {
@@ -174,7 +174,9 @@ struct LocateView {
     int32_t sigma, nbits;
 };
 
-template <class Table, bool kWide, bool kJumpWalk>
+// kEntrySA: the index has 32-byte jump entries, which carry SA[row] (layout.hpp): every hit is finished in phase 0 with
+// one fetch of its row's entry -- or with none when the search resolved it (kRecResolved) -- and nothing ever walks.
+template <class Table, bool kWide, bool kJumpWalk, bool kEntrySA>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_queue_kernel(LocateView lv, const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
@@ -284,6 +286,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (rec != nullptr) {
                 const uint4 r = rec[q];
                 row = r.x + static_cast<uint32_t>(h - first);
+                if (r.w & kRecResolved) {  // the search already knows the text position
+                    store_hit<kWide>(ix, r.z, hits_out, h, sentinels);
+                    continue;
+                }
                 if (r.w & kRecMasked) {  // the (h - first)-th surviving row of the mask, `symbols` steps before the hit
                     uint32_t m = r.z;
                     for (uint32_t t = static_cast<uint32_t>(h - first); t > 0u; t--) m &= m - 1u;
@@ -304,7 +310,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 }
             }
             uint32_t slot;
-            if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
+            if (kEntrySA) {
+                const uint32_t sa = static_cast<const uint32_t *>(ix.jump)[static_cast<uint64_t>(row) * 8u + 6u];
+                store_hit<kWide>(ix, sa - back, hits_out, h, sentinels);
+            } else if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
                 store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
             } else {
                 // (a hinted row that is not sampled comes from the search's lazy tail: the walk starts there)
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 s_idx[k] = i | (back << 11);
             }
         }
+        if (kEntrySA) continue;  // nothing was queued (the loop's first barrier orders the next chunk's LDS writes)
         __syncthreads();
         const uint32_t queued = s_n;
         if (step_stats && threadIdx.x == 0) atomicAdd(step_stats + 1, static_cast<unsigned long long>(queued));
@@ -332,24 +342,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!__any(have)) break;
             bool jumped = false;
             if (kJumpWalk && have) {
-                // levels of the entry of `row` (layout.hpp): first the sampled target nearest to row, else as far
-                // as the valid levels reach
-                const uint32_t words = ix.jump_bytes >> 2;
-                const u32x4 *e = reinterpret_cast<const u32x4 *>(static_cast<const uint32_t *>(ix.jump) +
-                                                                 static_cast<uint64_t>(row) * words);
-                const u32x4 e0 = e[0];
-                u32x4 e1 = e0;
-                if (ix.jump_bytes == 32) e1 = e[1];
+                // levels of the entry of `row` (layout.hpp; 16-byte entries here, 32-byte ones take the kEntrySA path):
+                // first the sampled target nearest to row, else as far as the valid levels reach
+                const u32x4 e0 = *reinterpret_cast<const u32x4 *>(static_cast<const uint32_t *>(ix.jump) +
+                                                                 static_cast<uint64_t>(row) * 4u);
                 const uint32_t valid = e0.w >> 16;
-                const uint32_t n_lv = ix.jump_bytes == 32 ? 5u : 2u;
-                uint32_t t[5] = {e0.x, e0.y, e1.x, e1.y, e1.z};
-                uint32_t reach = 0;  // valid levels (cumulative bits)
-#pragma unroll
-                for (uint32_t j = 0; j < 5; j++)
-                    if (j < n_lv && ((valid >> j) & 1u)) reach = j + 1u;
+                const uint32_t t[2] = {e0.x, e0.y};
+                const uint32_t reach = (valid & 2u) ? 2u : (valid & 1u);  // valid levels (cumulative bits)
                 uint32_t got = 0;  // first level whose target is a sampled row
 #pragma unroll
-                for (uint32_t j = 5; j >= 1; j--)
+                for (uint32_t j = 2; j >= 1; j--)
                     if (j <= reach && is_sampled(ix, t[j - 1])) got = j;
                 if (got != 0u) {
                     uint32_t slot;
@@ -579,9 +581,15 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                            dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, total_hits, first);
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
-#define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                              \
-    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW>), dim3(qgrid), dim3(kBlock), 0, stream, lv, d_start,  \
-                       d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats)
+#define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                     \
+    do {                                                                                                                  \
+        if (JW && entry_sa)                                                                                               \
+            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, JW>), dim3(qgrid), dim3(kBlock), 0, stream, lv,      \
+                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats);        \
+        else                                                                                                              \
+            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
+                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats);        \
+    } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.count, ix.sa_samples,
@@ -589,6 +597,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                             ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
+        const bool entry_sa = jump_walk && ix.jump_bytes == 32;  // SA[row] inside the entries: no walk at all
         if (ix.layout == 0) {
             if (wide && jump_walk) GDX_LOCATE_Q(LineTable, true, true);
             else if (wide) GDX_LOCATE_Q(LineTable, true, false);

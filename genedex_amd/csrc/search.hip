@@ -672,8 +672,11 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         constexpr int kChunks = 8 / kGroup;
         // levels of an entry the group can use, and codes it sees (one more than levels = a lookahead, except in
         // full 32-byte entries whose fifth code belongs to the fifth level)
-        constexpr int kLevels = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 2 : 5);
+        constexpr int kLevels = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 2 : 4);
         constexpr int kCodes = kJump == 8 ? 1 : ((kJump == 16 || kChunks == 1) ? 3 : 5);
+        constexpr bool kHalf2 = kLevels == 4;     // the group also reads the entry's second half {t3, t4, SA, c4 | c5 << 16}
+        constexpr bool kEntrySA = kJump == 32;    // entries carry SA[row]: locate resolves ANY row with one fetch, so a
+                                                  // hint only has to say how many symbols a lazy tail left unmatched
         const uint32_t sub = threadIdx.x & (kGroup - 1u);
         if (kDefer && phase == 0 && defer_after != 0u) allowance = defer_after + rem / (kJumpSymbols * kLevels);
         while (rem > 0 && lo != hi) {
@@ -696,7 +699,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             // steps, and LF keeps their order, so they map onto [min target, max target + 1).
             const bool narrow = jump_ok && hi - lo <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols;
             // level codes of the query, packed like the entries store them: qa = level 1 | level 2 << 16, qb = level 3,
-            // qc = level 4 | level 5 << 16 (level j + 1 <-> symbols rem - 8j - 1 .. rem - 8j - 8); qok bit j = level
+            // qc = level 4 (level j + 1 <-> symbols rem - 8j - 1 .. rem - 8j - 8); qok bit j = level
             // j + 1 lies inside the query and is all symbols 1..4.  They come from the span's 2-bit words; only when
             // those cannot vouch for level 1 (a symbol outside 1..4 somewhere in its words) are the nibbles looked at.
             uint32_t qa = narrow ? win.level(rem) : kNoCode;
@@ -765,7 +768,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 else pa = tab + static_cast<uint64_t>(row) * (kJump / 16);
                 pa1 = pa + 1;  // second half of a 32-byte entry
             }
-            const bool need_a1 = !jumping || kLevels == 5;
+            const bool need_a1 = !jumping || kHalf2;
             const unsigned long long m_a1 = __ballot(need_a1), m_second = __ballot(second);
             u32x4 a[kChunks], b[kChunks];
             // all loads of the round, their exec masks and the one wait: a single asm statement (layout.hpp)
@@ -773,7 +776,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
             else load_round2<kPolicy>(pa, pb, m_second, a[0], b[0]);
             if (jumping) {
                 // entry layout (layout.hpp): a[0] = {t1, t2, c1 | c2 << 16, c3 | valid << 16},
-                // a[1] = {t3, t4, t5, c4 | c5 << 16}; 8-byte entries: {t1, c1 | valid << 16}
+                // a[1] = {t3, t4, SA, c4 | c5 << 16}; 8-byte entries: {t1, c1 | valid << 16}
                 uint32_t valid, da, db = 0, dc = 0;  // d*: stored codes XOR query codes, packed as above
                 const u32x4 e0 = a[0], e1 = a[kChunks - 1];
                 if (kJump == 8) {
@@ -784,16 +787,15 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     da = e0.z ^ qa;
                     db = (e0.w ^ qb) & 0xffffu;
                     valid = e0.w >> 16;
-                    if (kLevels == 5) dc = e1.w ^ qc;
+                    if (kHalf2) dc = e1.w ^ qc;
                 }
                 // how many levels this lane's row matches: a level needs a valid stored level (the valid bits are
                 // cumulative), a usable query level and equal codes, and all the levels before it
                 uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
                 if (kLevels >= 2) good |= (da >> 16) == 0u ? 2u : 0u;
-                if (kLevels == 5) {
+                if (kHalf2) {
                     good |= db == 0u ? 4u : 0u;
                     good |= (dc & 0xffffu) == 0u ? 8u : 0u;
-                    good |= (dc >> 16) == 0u ? 16u : 0u;
                 }
                 good &= valid & qok;
                 const uint32_t lvl = static_cast<uint32_t>(__builtin_ctz(~good | (1u << kLevels)));  // trailing ones
@@ -802,17 +804,16 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                     const bool mine = lvl == best;
                     // locate hint, candidate 1: the one-row interval this jump starts from (see below)
                     uint32_t hr = 0xffffffffu, ho = 0;
-                    const bool want_hint = hinting && !(status >> 31);  // one hint per query is enough
+                    const bool want_hint = !kEntrySA && hinting && !(status >> 31);  // one hint per query is enough
                     if (want_hint && hi - lo == 1u && is_sampled(ix, lo)) {
                         hr = lo;
                         ho = rem;
                     }
                     uint32_t target = kJump == 8 ? ((row & 1u) ? e0.z : e0.x) : e0.x;
                     if (kLevels >= 2) target = best == 2u ? e0.y : target;
-                    if (kLevels == 5) {
+                    if (kHalf2) {
                         target = best == 3u ? e1.x : target;
                         target = best == 4u ? e1.y : target;
-                        target = best == 5u ? e1.z : target;
                     }
                     lo = group_min<kGroup>(mine ? target : 0xffffffffu);
                     hi = group_max<kGroup>(mine ? target : 0u) + 1u;
@@ -848,7 +849,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                         // a symbol outside 1..4 among the query's last rem): then the pair lines decide.
                         uint32_t nxt = e0.z >> 16;  // codes of level best + 1
                         nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
-                        if (kLevels == 5) {
+                        if (kHalf2) {
                             nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
                             nxt = best == 4u ? (e1.w >> 16) : nxt;
                         }
@@ -901,7 +902,7 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
                 }
                 const uint32_t nlo = group_sum<kGroup>(plo), nhi = group_sum<kGroup>(phi);
                 if (nlo != nhi) {
-                    if (hinting && !(status >> 31) && hi - lo == 1u && nhi - nlo == 1u && rem < (1u << 21)) {
+                    if (!kEntrySA && hinting && !(status >> 31) && hi - lo == 1u && nhi - nlo == 1u && rem < (1u << 21)) {
                         // locate hint from a pair step of a one-row interval: the row in between, LF(c1, lo), comes
                         // out of the same line; rem - 1 symbols are still unmatched there (see the jump above)
                         const uint32_t bx1 = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
@@ -1163,8 +1164,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 {
     constexpr int kGroup = 4;
     constexpr uint32_t kWideRows = kWide ? 16 : kGroup;  // widest interval a round takes
-    constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : 5);
+    constexpr int kLevels = kJump == 8 ? 1 : (kJump == 16 ? 2 : 4);
     constexpr int kCodes = kJump == 8 ? 1 : (kJump == 16 ? 3 : 5);
+    constexpr bool kHalf2 = kJump == 32;    // entries have a second half {t3, t4, SA[row], c4 | c5 << 16}
+    // 32-byte entries carry SA[row] (layout.hpp): the round in which the interval becomes (or is) one row knows the hit's
+    // text position, SA[that row] - symbols still to match, and the record is RESOLVED (kernels.hpp) -- no sampled-row
+    // candidates to test (64 of the 420 VALU instructions per round in round 2) and no sample read in locate
+    constexpr bool kEntrySA = kJump == 32;
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_left[kMaxRange];
     __shared__ uint32_t s_nleft, s_left_base;
@@ -1194,6 +1200,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool fresh = false;  // the window is positioned for the round to come
             bool progressed = false;  // lo, hi, rem describe the search after the top table and whole rounds
             bool masked = false;      // the result is a masked record: hr = mask of surviving rows, ho = symbols left
+            bool resolved = false;    // kEntrySA: hr = text position of the hit of the one-row interval
             if (!bail) {
                 rem = static_cast<uint32_t>(len);
                 w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
@@ -1262,14 +1269,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         bail = true;
                         break;
                     }
-                    uint32_t alive = 0, undecided = 0;
+                    uint32_t alive = 0, undecided = 0, own_sa = 0;
                     const u32x4 *ttab = static_cast<const u32x4 *>(ix.jump);
+                    // (the second half of the entry -- the same 128-byte line -- only for the SA value of a single row)
+                    const unsigned long long m_sa = kEntrySA ? __ballot(hinting && rows == 1u && !resolved) : 0ull;
                     for (uint32_t r0 = lo; r0 < (kWide ? hi : lo + 1u); r0 += kGroup) {  // group-uniform trip count
                         const bool real = r0 + sub < hi;
                         const uint32_t trow = real ? r0 + sub : hi - 1u;
                         const u32x4 *tp = kJump == 8 ? ttab + (trow >> 1) : ttab + static_cast<uint64_t>(trow) * (kJump / 16);
                         u32x4 t0, t1;
-                        load_round2<0>(tp, tp + 1, 0ull, t0, t1);
+                        load_round2<0>(tp, tp + 1, m_sa, t0, t1);
+                        if (kEntrySA) own_sa = t1.z;
                         const uint32_t tw = kJump == 8 ? ((trow & 1u) ? t0.w : t0.y) : t0.z;
                         const uint32_t tvalid = kJump == 8 ? tw >> 16 : t0.w >> 16;
                         if (real) {
@@ -1285,7 +1295,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0x4E, 0xF, 0xF, true));
                     if (rows == 1u) {
                         if (alive != 0u) {
-                            if (hinting && hr == 0xffffffffu) {
+                            if (kEntrySA) {
+                                if (hinting && !resolved) {
+                                    hr = own_sa - rem;
+                                    resolved = true;
+                                }
+                            } else if (hinting && hr == 0xffffffffu) {
                                 hr = lo;
                                 ho = rem;
                             }
@@ -1318,7 +1333,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         const uint32_t wrow = real ? r0 + sub : hi - 1u;
                         const u32x4 *wp = kJump == 8 ? wtab + (wrow >> 1) : wtab + static_cast<uint64_t>(wrow) * (kJump / 16);
                         u32x4 w0, w1;
-                        load_round2<0>(wp, wp + 1, kJump == 32 ? __ballot(true) : 0ull, w0, w1);
+                        load_round2<0>(wp, wp + 1, kHalf2 ? __ballot(true) : 0ull, w0, w1);
                         uint32_t wvalid, wgood;
                         if (kJump == 8) {
                             const uint32_t ew = (wrow & 1u) ? w0.w : w0.y;
@@ -1328,11 +1343,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             const uint32_t da = w0.z ^ qa;
                             wvalid = w0.w >> 16;
                             wgood = ((da & 0xffffu) == 0u ? 1u : 0u) | ((da >> 16) == 0u ? 2u : 0u);
-                            if (kLevels == 5) {
+                            if (kHalf2) {
                                 const uint32_t dc = w1.w ^ qc;
                                 wgood |= ((w0.w ^ qb) & 0xffffu) == 0u ? 4u : 0u;
                                 wgood |= (dc & 0xffffu) == 0u ? 8u : 0u;
-                                wgood |= (dc >> 16) == 0u ? 16u : 0u;
                             }
                         }
                         wgood &= wvalid & qok;
@@ -1341,7 +1355,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
                         for (int j = 0; j < kLevels; j++) {
                             const uint32_t tj = kJump == 8 ? ((wrow & 1u) ? w0.z : w0.x)
-                                                           : (j == 0 ? w0.x : (j == 1 ? w0.y : (j == 2 ? w1.x : (j == 3 ? w1.y : w1.z))));
+                                                           : (j == 0 ? w0.x : (j == 1 ? w0.y : (j == 2 ? w1.x : w1.y)));
                             if (wl > static_cast<uint32_t>(j)) {
                                 mn[j] = tj < mn[j] ? tj : mn[j];
                                 mx[j] = tj > mx[j] ? tj : mx[j];
@@ -1368,7 +1382,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
                 const u32x4 *pa = kJump == 8 ? tab + (row >> 1) : tab + static_cast<uint64_t>(row) * (kJump / 16);
                 u32x4 e0, e1;
-                load_round2<0>(pa, pa + 1, kJump == 32 ? __ballot(true) : 0ull, e0, e1);
+                load_round2<0>(pa, pa + 1, kHalf2 ? __ballot(true) : 0ull, e0, e1);
                 uint32_t valid, c1;
                 if (kJump == 8) {
                     const uint32_t ew = (row & 1u) ? e0.w : e0.y;
@@ -1384,14 +1398,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 } else {
                     da = e0.z ^ qa;
                     db = (e0.w ^ qb) & 0xffffu;
-                    if (kLevels == 5) dc = e1.w ^ qc;
+                    if (kHalf2) dc = e1.w ^ qc;
                 }
                 uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
                 if (kLevels >= 2) good |= (da >> 16) == 0u ? 2u : 0u;
-                if (kLevels == 5) {
+                if (kHalf2) {
                     good |= db == 0u ? 4u : 0u;
                     good |= (dc & 0xffffu) == 0u ? 8u : 0u;
-                    good |= (dc >> 16) == 0u ? 16u : 0u;
                 }
                 good &= valid & qok;
                 const uint32_t lvl = static_cast<uint32_t>(__builtin_ctz(~good | (1u << kLevels)));
@@ -1401,22 +1414,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     break;
                 }
                 const bool mine = lvl == best;
-                if (hinting && hr == 0xffffffffu && rows == 1u && is_sampled(ix, lo)) {
+                if (!kEntrySA && hinting && hr == 0xffffffffu && rows == 1u && is_sampled(ix, lo)) {
                     hr = lo;
                     ho = rem;
                 }
                 uint32_t target = kJump == 8 ? ((row & 1u) ? e0.z : e0.x) : e0.x;
                 if (kLevels >= 2) target = best == 2u ? e0.y : target;
-                if (kLevels == 5) {
+                if (kHalf2) {
                     target = best == 3u ? e1.x : target;
                     target = best == 4u ? e1.y : target;
-                    target = best == 5u ? e1.z : target;
                 }
+                const uint32_t rem_before = rem;
                 lo = group_min<kGroup>(mine ? target : 0xffffffffu);
                 hi = group_max<kGroup>(mine ? target : 0u) + 1u;
                 rem -= best * kJumpSymbols;
                 const bool one_row = hi - lo == 1u;
-                if (hinting && one_row && hr == 0xffffffffu) {
+                if (kEntrySA) {
+                    // the one surviving row's own SA value sits in the lane that read its entry: the occurrence starts
+                    // rem_before symbols before that row's suffix (and stays there whatever rows the path visits next)
+                    if (hinting && one_row && !resolved) {
+                        hr = group_max<kGroup>(mine ? e1.z : 0u) - rem_before;
+                        resolved = true;
+                    }
+                } else if (hinting && one_row && hr == 0xffffffffu) {
                     if (is_sampled(ix, lo)) {
                         hr = lo;
                         ho = rem;
@@ -1437,7 +1457,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (one_row && rem > 0u && rem < kJumpSymbols && best < static_cast<uint32_t>(kCodes)) {
                     uint32_t nxt = e0.z >> 16;
                     nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
-                    if (kLevels == 5) {
+                    if (kHalf2) {
                         nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
                         nxt = best == 4u ? (e1.w >> 16) : nxt;
                     }
@@ -1451,7 +1471,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         // the lookahead code is cut short: the next round asks the row's own entry
                     } else {
                         if (verdict == 2u) {
-                            if (hinting && hr == 0xffffffffu) {
+                            if (!kEntrySA && hinting && hr == 0xffffffffu) {  // (kEntrySA: resolved by this round)
                                 hr = lo;
                                 ho = rem;
                             }
@@ -1468,9 +1488,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // where the general kernel goes on: after the top table and whole rounds, or from the start
                     if (state) state[q] = make_uint4(lo, hi, rem, progressed ? 1u : 0u);
                 } else {
-                    const bool hinted = hr != 0xffffffffu && hi - lo == 1u;
+                    const bool hinted = (kEntrySA ? resolved : hr != 0xffffffffu) && hi - lo == 1u;
                     if (out_rec) {
                         if (masked) out_rec[q] = make_uint4(lo, hi, hr, (ho & 0x1fffffu) | kRecMasked);
+                        else if (kEntrySA) out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? kRecResolved : 0u);
                         else out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? (ho & 0xffffffu) : 0u);
                     }
                     if (out_count) out_count[q] = hi - lo;
@@ -1573,6 +1594,33 @@ __global__ __launch_bounds__(kBlock) void symbol_at_kernel(IndexView ix, const u
             continue;
         }
         out[i] = static_cast<uint8_t>(Table::symbol_at(ix, p));
+    }
+}
+
+// gdx_bench_lf_walk_dev: the text read backwards through the occurrence table alone (symbol_at + rank + count, i.e.
+// sampled_suffix_array.rs:118-131 without the samples)
+template <class Table>
+__global__ __launch_bounds__(kBlock) void lf_walk_kernel(IndexView ix, const uint32_t *__restrict__ rows, uint64_t m,
+                                                         uint32_t steps, uint8_t *__restrict__ symbols,
+                                                         uint32_t *__restrict__ end_rows)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        uint32_t row = rows[i];
+        uint8_t *out = symbols + i * steps;
+        uint32_t j = 0;
+        for (; j < steps && row < ix.n; j++) {
+            uint32_t r;
+            const uint32_t c = Table::symbol_and_rank(ix, row, r);
+            out[j] = static_cast<uint8_t>(c);
+            if (c == 0) {
+                j++;
+                break;
+            }
+            row = ix.count[c] + r;
+        }
+        for (; j < steps; j++) out[j] = 0xffu;
+        if (end_rows) end_rows[i] = row;
     }
 }
 
@@ -1951,6 +1999,13 @@ void launch_symbol_at_many(const IndexView &ix, const uint32_t *d_idx, uint64_t 
 {
     if (m == 0) return;
     GDX_DISPATCH_TABLE(ix, symbol_at_kernel, grid_for_items(m), stream, ix, d_idx, m, d_out, d_error);
+}
+
+void launch_lf_walk(const IndexView &ix, const uint32_t *d_rows, uint64_t m, uint32_t steps, uint8_t *d_symbols,
+                    uint32_t *d_end_rows, hipStream_t stream)
+{
+    if (m == 0 || steps == 0) return;
+    GDX_DISPATCH_TABLE(ix, lf_walk_kernel, grid_for_items(m), stream, ix, d_rows, m, steps, d_symbols, d_end_rows);
 }
 
 void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStream_t stream)

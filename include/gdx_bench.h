@@ -78,6 +78,13 @@ int gdx_locate_step_stats_dev(const gdx_index_t *ix, const void *d_start, const 
 int gdx_locate_many_hits_stats_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
                                    uint64_t total_hits, void *d_hits, void *d_workspace, void *d_steps, void *stream);
 
+/* Independent check of a built index (tests/test_gpu_fullsize.py): from each of the m start rows d_rows[i] (u32) walk
+ * `steps` LF steps on the occurrence table and write the BWT symbol met at every step (dense code) to
+ * d_symbols[i * steps + j] -- the text read backwards from position SA[row] - 1.  A chain that meets the sentinel stops:
+ * that entry is 0, the rest of the chain 0xff.  d_end_rows (u32[m], may be null): the row each chain stopped at. */
+int gdx_bench_lf_walk_dev(const gdx_index_t *ix, const void *d_rows, uint64_t m, uint32_t steps, void *d_symbols,
+                          void *d_end_rows, void *stream);
+
 /* Query acceleration structures the index carries beside the reference's arrays (DESIGN.md "HBM layout"):
  * out[0] = 1 if pair lines are present, out[1] = bytes per jump-table entry (0 = none, 8 or 16),
  * out[2] = depth of the top table (0 = none), out[3] = reserved (0). */

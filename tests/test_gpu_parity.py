@@ -572,7 +572,12 @@ def test_full_size_properties_workload2():
     total_hits = int(out["hit_offsets"][nq].item())
     assert int((out["status"] != 0).sum().item()) == 0
     hinted = int(((out["hint"] & 0xffffffff) != 0xffffffff).sum().item())
-    assert hinted > nq // 3  # most one-occurrence reads pass through a sampled row while they jump
+    if eng.aux_info()["jump_entry_bytes"] == 32:
+        # 32-byte jump entries carry SA[row]: locate resolves any row with one fetch, so the exact-interval search
+        # leaves no sampled-row hints (they would save nothing)
+        assert hinted == 0
+    else:
+        assert hinted > nq // 3  # most one-occurrence reads pass through a sampled row while they jump
     counts = (out["end"] - out["start"]).to(torch.int64)
     assert int(counts.sum().item()) == total_hits
     found = int((counts > 0).sum().item())

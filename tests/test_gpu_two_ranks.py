@@ -31,3 +31,38 @@ def test_bench_two_ranks_on_one_gpu():
     st = d["strong_scaling"]
     assert st["scaling"] == "strong" and st["queries_total"] == 1_000_000 and st["queries_this_rank"] == 500_000
     assert st["shards_equal_single_rank_output"] == {"counts": True, "hits": True} and st["value"] > 0
+
+
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """The same run on the real backend -- torch's "nccl" process group IS RCCL on ROCm -- one rank per GPU: weak and
+    strong scaling, the shard == single-rank check included.  Needs two GPUs; the single-GPU boxes skip it."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GDX_BENCH_ONE_GPU", None)
+    env.pop("GDX_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small",
+           "--steps", "3", "--no-bandwidth", "--nq", "1000000"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["strong_scaling"]["shards_equal_single_rank_output"] == {"counts": True, "hits": True}
+
+
+def test_gather_count_dtype_is_one_rccl_maps():
+    """torch's NCCL/RCCL process group has no 16-bit integer type (ProcessGroupNCCL: int8, uint8, int32, int64, floats):
+    the gathered per-query counts must travel as uint8 or int32 whatever the largest count is."""
+    import re
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r"count_dtype = (.*)", src)
+    assert m and "int16" not in m.group(1) and "uint8" in m.group(1) and "int32" in m.group(1)
