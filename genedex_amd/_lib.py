@@ -56,7 +56,8 @@ class BuildOptions(C.Structure):
 class QueryOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
                 ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32),
-                ("locate_jump_walk", C.c_int32), ("search_defer_after", C.c_int32), ("search_fast", C.c_int32)]
+                ("locate_jump_walk", C.c_int32), ("search_defer_after", C.c_int32), ("search_fast", C.c_int32),
+                ("search_exact", C.c_int32)]
 
 
 class IndexAux(C.Structure):

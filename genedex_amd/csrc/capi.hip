@@ -213,6 +213,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->locate_jump_walk = -1;
     opts->search_defer_after = -1;
     opts->search_fast = -1;
+    opts->search_exact = -1;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -386,6 +387,8 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
             q.search_defer_after = opts->search_defer_after;
             if (opts->search_fast < -1 || opts->search_fast > 2) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
             q.search_fast = opts->search_fast;
+            if (opts->search_exact < -1 || opts->search_exact > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+            q.search_exact = opts->search_exact;
         }
         ix->impl->set_query_options(q);
         return (int)GDX_OK;
@@ -407,6 +410,7 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->locate_jump_walk = q.locate_jump_walk;
         out->search_defer_after = q.search_defer_after;
         out->search_fast = q.search_fast;
+        out->search_exact = q.search_exact;
         return (int)GDX_OK;
     });
 }

@@ -1044,6 +1044,7 @@ void FmIndex::set_query_options(const QueryOptions &q)
     q_locate_jump_walk_.store(q.locate_jump_walk);
     q_defer_after_.store(q.search_defer_after);
     q_fast_.store(q.search_fast);
+    q_exact_.store(q.search_exact);
 }
 
 QueryOptions FmIndex::query_options() const
@@ -1057,6 +1058,7 @@ QueryOptions FmIndex::query_options() const
     q.locate_jump_walk = q_locate_jump_walk_.load();
     q.search_defer_after = q_defer_after_.load();
     q.search_fast = q_fast_.load();
+    q.search_exact = q_exact_.load();
     // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
     if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;
     // default: the fast-path kernel first, unless the top table is so shallow for this text that most reads leave it

@@ -22,6 +22,7 @@ struct QueryOptions {
     int search_fast = -1;         // count / locate searches run the fast-path kernel first (1; 2 = with 16-row jumps) or not (0); -1 = per index
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
                                   // finished in the block's straggler pass; 0 = never
+    int search_exact = -1;        // exact-interval and cursor searches run search_exact_kernel4 first (default) or not (0)
 };
 
 // Active lists of the cursor-extension mode (search mode 2): the cursors to extend are those listed in active_in

@@ -1064,7 +1064,8 @@ struct FastWindow {
     uint32_t s0;              // symbols of a level that lie in its first span word (1 .. 8)
 };
 // four query bytes -> their 2-bit codes in 8 bits (byte 0 in bits 1:0); `bad` becomes non-zero on any other byte
-__device__ __forceinline__ uint32_t fast_pack4(const FastView &ix, uint32_t c, uint32_t &bad)
+template <class View>
+__device__ __forceinline__ uint32_t fast_pack4(const View &ix, uint32_t c, uint32_t &bad)
 {
     const uint32_t sel = c & 0x07070707u;
     const uint32_t code = __builtin_amdgcn_perm(ix.perm_code_hi, ix.perm_code_lo, sel);
@@ -1110,8 +1111,8 @@ __device__ __forceinline__ u32x4 fast_window_load(const uint64_t *wbase, uint32_
     }
     return raw;
 }
-template <int kXlate>
-__device__ __forceinline__ FastWindow fast_window_finish(const FastView &ix, const uint8_t *s_dense, u32x4 raw,
+template <int kXlate, class View>
+__device__ __forceinline__ FastWindow fast_window_finish(const View &ix, const uint8_t *s_dense, u32x4 raw,
                                                          uint32_t off0, uint32_t rem, uint32_t sub)
 {
     const uint32_t b = off0 + rem - 1u;
@@ -1147,8 +1148,8 @@ __device__ __forceinline__ FastWindow fast_window_finish(const FastView &ix, con
     w.l3 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(lv), 0xFF, 0xF, 0xF, true));
     return w;
 }
-template <int kXlate>
-__device__ __forceinline__ FastWindow fast_window(const FastView &ix, const uint8_t *s_dense, const uint64_t *wbase,
+template <int kXlate, class View>
+__device__ __forceinline__ FastWindow fast_window(const View &ix, const uint8_t *s_dense, const uint64_t *wbase,
                                                   uint32_t off0, uint32_t rem, uint32_t sub)
 {
     return fast_window_finish<kXlate>(ix, s_dense, fast_window_load<kXlate>(wbase, off0, rem, sub), off0, rem, sub);
@@ -1510,6 +1511,295 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
 }
 
+// ---- exact intervals and cursor chunks with the fast kernel's instruction diet --------------------------------------
+// cursors_for_many_queries (mode 0) and the cursor extension calls (mode 2) need the reference's interval bit for bit,
+// so no lazy tail: what is left after the whole jump levels is stepped on the pair lines, and the eight symbols within
+// which an interval empties likewise (the frozen interval is the reference's).  PMC on round 2's general kernel
+// (profiles/r03/pmc_general_r2_kernel.md): 730 VALU instructions per round of 16 queries at 89 % VALU busy for the
+// fused exact search, ~1000 per round and cursor for a 32-symbol chunk call -- instruction issue, not requests, was
+// what the cursor API ran into.  This kernel does what those calls do on clean input with the fast kernel's window
+// (v_perm_b32 translation, level codes by one funnel shift) and leaves everything else -- a symbol outside A C G T
+// anywhere near what it reads (status codes, N steps on the rank lines), a cursor stopped earlier, queries of 2 M
+// symbols -- untouched on a list for the general kernel (launch_search_call), which is the statement of the semantics.
+struct ExactView {
+    const uint2 *top;
+    const void *jump;
+    const u32x4 *pair_lines;
+    const uint8_t *io_to_dense;
+    uint32_t top_depth, n;
+    uint32_t lookup_depth;  // the configured lookup table is never read, but its eager symbol check must not be skipped
+    uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+};
+
+__device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint32_t v = a;
+    v = i == 1u ? b : v;
+    v = i == 2u ? c : v;
+    v = i == 3u ? d : v;
+    return v;
+}
+
+template <int kJump, int kXlate, bool kCursor>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_exact_kernel4(
+    ExactView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
+    uint64_t nq, uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count,
+    uint8_t *__restrict__ out_status, uint32_t range, int schedule, uint32_t *__restrict__ leftover,
+    uint32_t *__restrict__ n_leftover, CursorArgs ca)
+{
+    constexpr int kGroup = 4;
+    constexpr int kLevels = kJump == 0 ? 0 : (kJump == 8 ? 1 : (kJump == 16 ? 2 : 4));
+    constexpr bool kHalf2 = kJump == 32;
+    constexpr uint32_t kRangeCap = kCursor ? kCursorRange : kMaxRange;
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_left[kRangeCap];
+    __shared__ uint32_t s_nleft, s_left_base;
+    __shared__ uint32_t s_alive[kCursor ? kCursorRange : 1];  // flush_live_ordered
+    __shared__ uint32_t s_alive_part[kCursor ? kBlock : 1];
+    __shared__ uint32_t s_alive_base;
+    __shared__ uint16_t s_perm[kCursor ? 1 : kMaxRange];  // order_range_by_length (fused searches of mixed lengths)
+    __shared__ uint32_t s_cnt[kLenBuckets];
+    __shared__ uint32_t s_minmax[2];
+    if (kXlate == 0)
+        for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = ix.io_to_dense[i];
+    if (kCursor)
+        for (uint32_t i = threadIdx.x; i < kCursorRange; i += kBlock) s_alive[i] = kDeadCursor;
+    if (threadIdx.x == 0) s_nleft = 0;
+    __syncthreads();
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint32_t sub = threadIdx.x & (kGroup - 1u);
+    const uint32_t depth = ix.top_depth;
+    const uint32_t *active = ca.active_in;
+    if (ca.n_active_in != nullptr) nq = *ca.n_active_in;
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        const uint64_t base = rg * range;
+        const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+        // (a call's cursor strings have one size; fused searches of spread-out lengths run in length order)
+        const bool ordered = !kCursor && schedule != 0 &&
+                             order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
+        for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
+            const uint64_t at = base + (ordered ? s_perm[slot] : slot);
+            const uint32_t q = active ? active[at] : static_cast<uint32_t>(at);
+            uint64_t begin = qbeg[q], end = qend[q];
+            bool more_left = true;  // chunk view: the query has symbols left of this chunk
+            if (kCursor && ca.chunk_symbols != 0u) {
+                const uint64_t first = begin, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
+                end = end - first > skip ? end - skip : first;
+                begin = end - first > ca.chunk_symbols ? end - ca.chunk_symbols : first;
+                more_left = begin > first;
+            }
+            const uint64_t len = end - begin;
+            uint32_t lo = 0, hi = ix.n;
+            bool bail = len >= (1ull << 21);
+            if (kCursor) {
+                lo = out_start[q];
+                hi = out_end[q];
+                if (out_status != nullptr && out_status[q] != 0) bail = true;  // stopped earlier: the general kernel knows
+            }
+            const bool empty_cursor = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210): the top table applies
+            uint32_t rem = bail ? 0u : static_cast<uint32_t>(len);
+            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
+            FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
+            uint32_t shift = 0;   // whole levels of the window used up
+            uint32_t part = 0;    // symbols of level `shift` used up by pair steps
+            bool fresh = false;   // the window is positioned: symbol rem - 1 is symbol `part` of its level `shift`
+            bool jump_ok = kJump != 0 && ix.jump != nullptr;
+            if (!bail && empty_cursor && ix.top != nullptr && rem >= 16u && rem >= depth) {
+                w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
+                const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
+                if ((w.valid8 & need) != need) {
+                    bail = true;
+                } else {
+                    const uint2 e = ix.top[__builtin_amdgcn_alignbit(w.l0, w.l0, 16) >> (32u - 2u * depth)];
+                    lo = e.x;  // (the entry of an absent D-mer is its frozen interval, as the reference's lookup tables)
+                    hi = e.y;
+                    rem -= depth;
+                    shift = depth >> 3;
+                    part = depth & 7u;
+                    fresh = true;
+                }
+            } else if (!kCursor && ix.lookup_depth != 0u) {
+                // the reference checks every symbol of its lookup suffix before anything else (lookup_table.rs:99-113);
+                // the steps below are lazy, so a query that does not pass the top table's check goes to the general kernel
+                bail = true;
+            }
+            while (!bail && rem > 0u && lo != hi) {
+                const uint32_t rows = hi - lo;
+                const bool jumping = jump_ok && rows <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols;
+                // the window must hold what this round reads: whole levels from an aligned position for a jump (levels
+                // 0 .. 6 of a window are always inside its eight words), one or two symbols for a pair step
+                if (!fresh || (jumping ? (part != 0u || shift > 2u) : shift > 6u)) {
+                    w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
+                    shift = 0;
+                    part = 0;
+                }
+                fresh = true;
+                const uint32_t v8 = w.valid8 >> shift;                      // bit i: first word of level shift + i valid
+                const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));  // bit i: level shift + i valid
+                if (jumping) {
+                    if ((vl & 1u) == 0u) {  // a symbol outside A C G T among the next eight
+                        bail = true;
+                        break;
+                    }
+                    uint32_t a0, a1, a2;
+                    if (shift == 2u) {
+                        a0 = w.l1;
+                        a1 = w.l2;
+                        a2 = w.l3;
+                    } else if (shift == 1u) {
+                        a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
+                        a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                        a2 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                    } else {
+                        a0 = w.l0;
+                        a1 = w.l1;
+                        a2 = w.l2;
+                    }
+                    const uint32_t n_lv = rem >> 3 < static_cast<uint32_t>(kLevels) ? rem >> 3 : static_cast<uint32_t>(kLevels);
+                    const uint32_t qa = a0, qb = a1 & 0xffffu, qc = __builtin_amdgcn_alignbit(a2, a1, 16);
+                    const uint32_t qok = vl & ((1u << n_lv) - 1u);
+                    const uint32_t row = lo + sub < hi ? lo + sub : hi - 1u;  // spare lanes repeat the last row
+                    const u32x4 *tab = static_cast<const u32x4 *>(ix.jump);
+                    const u32x4 *pa = kJump == 8 ? tab + (row >> 1) : tab + static_cast<uint64_t>(row) * (kJump / 16);
+                    u32x4 e0, e1;
+                    load_round2<0>(pa, pa + 1, kHalf2 ? __ballot(true) : 0ull, e0, e1);
+                    uint32_t valid, da, db = 0, dc = 0;
+                    if (kJump == 8) {
+                        const uint32_t ew = (row & 1u) ? e0.w : e0.y;
+                        da = (ew ^ qa) & 0xffffu;
+                        valid = ew >> 16;
+                    } else {
+                        da = e0.z ^ qa;
+                        db = (e0.w ^ qb) & 0xffffu;
+                        valid = e0.w >> 16;
+                        if (kHalf2) dc = e1.w ^ qc;
+                    }
+                    uint32_t good = (da & 0xffffu) == 0u ? 1u : 0u;
+                    if (kLevels >= 2) good |= (da >> 16) == 0u ? 2u : 0u;
+                    if (kHalf2) {
+                        good |= db == 0u ? 4u : 0u;
+                        good |= (dc & 0xffffu) == 0u ? 8u : 0u;
+                    }
+                    good &= valid & qok;
+                    const uint32_t lvl = static_cast<uint32_t>(__builtin_ctz(~good | (1u << kLevels)));
+                    const uint32_t best = group_max<kGroup>(lvl);
+                    if (best == 0u) {
+                        // the interval empties within the next eight steps, or a stored / query symbol there is outside
+                        // A C G T: the pair lines find where (the frozen interval must be the reference's)
+                        jump_ok = false;
+                        continue;
+                    }
+                    const bool mine = lvl == best;
+                    uint32_t target = kJump == 8 ? ((row & 1u) ? e0.z : e0.x) : e0.x;
+                    if (kLevels >= 2) target = best == 2u ? e0.y : target;
+                    if (kHalf2) {
+                        target = best == 3u ? e1.x : target;
+                        target = best == 4u ? e1.y : target;
+                    }
+                    // the rows that match `best` levels are the ones that survive these LF steps, and LF keeps their order
+                    lo = group_min<kGroup>(mine ? target : 0xffffffffu);
+                    hi = group_max<kGroup>(mine ? target : 0u) + 1u;
+                    rem -= best * kJumpSymbols;
+                    shift += best;
+                    continue;
+                }
+                // one pair-line round: two LF steps, or one (odd tail, or the step at which the interval empties)
+                const uint32_t e = sel4(shift >> 1, w.l0, w.l1, w.l2, w.l3);
+                const uint32_t f = sel4((shift >> 1) + 1u, w.l0, w.l1, w.l2, w.l3);
+                const uint32_t lv2 = (shift & 1u) ? ((e & 0xffff0000u) | (f & 0xffffu)) : __builtin_amdgcn_alignbit(e, e, 16);
+                const uint32_t x = lv2 << (2u * part);  // bits 31:30 = symbol rem - 1, 29:28 = symbol rem - 2
+                const bool two = rem >= 2u;
+                {
+                    // symbol t of the level string from level `shift` on lies in span word shift + (t >= s0): only the
+                    // words the one or two symbols of this round come from have to be clean (a tail near the query's
+                    // first byte reaches into the word before it, which may hold anything)
+                    const uint32_t t_last = part + (two ? 1u : 0u);
+                    const uint32_t need = (part < w.s0 ? 1u : 2u) | (t_last < w.s0 ? 1u : 2u);
+                    if ((v8 & need) != need) {
+                        bail = true;
+                        break;
+                    }
+                }
+                const uint32_t c1 = (x >> 30) + 1u, c2 = two ? ((x >> 28) & 3u) + 1u : 0u;
+                const uint32_t line_lo = lo >> kPairLineShift, line_hi = hi >> kPairLineShift;
+                const bool second = line_hi != line_lo;
+                const u32x4 *pa = ix.pair_lines + (static_cast<uint64_t>(line_lo) << 3) + sub;
+                const u32x4 *pb = ix.pair_lines + (static_cast<uint64_t>(line_hi) << 3) + sub;
+                u32x4 a[2], b[2];
+                load_round4<0>(pa, pa + kGroup, pb, pb + kGroup, __ballot(true), __ballot(second), a[0], a[1], b[0], b[1]);
+                if (!second) {
+                    b[0] = a[0];
+                    b[1] = a[1];
+                }
+                bool stepped = false;
+                if (two) {  // c1 is consumed first (it precedes the current suffix), then c2
+                    const uint32_t pair = (c2 - 1u) * 4u + (c1 - 1u);
+                    const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14) | ((c2 & 1u) << 24);
+                    const uint32_t bits_y = ((c2 >> 1) & 1u) | ((c2 & 4u) << 6);
+                    const uint32_t nx = ~(bits_x * 0xffu);
+                    const uint32_t ny = ~(bits_y * 0xffu) & 0xffffu;
+                    uint32_t plo = 0, phi = 0;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        plo += PairTable::pair_partial(a[k], sub + k * kGroup, pair, nx, ny, lo);
+                        phi += PairTable::pair_partial(b[k], sub + k * kGroup, pair, nx, ny, hi);
+                    }
+                    const uint32_t nlo = quad_sum(plo), nhi = quad_sum(phi);
+                    if (nlo != nhi) {
+                        lo = nlo;
+                        hi = nhi;
+                        rem -= 2u;
+                        part += 2u;
+                        stepped = true;
+                    }
+                    // else: the interval empties within these two steps -- one step on the same lines, so that the
+                    // frozen interval is the one the reference reports
+                }
+                if (!stepped) {
+                    const uint32_t bits_x = (c1 & 1u) | ((c1 & 2u) << 7) | ((c1 & 4u) << 14);
+                    const uint32_t nx = ~(bits_x * 0xffu) & 0xffffffu;
+                    uint32_t plo = 0, phi = 0;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        plo += PairTable::single_partial(a[k], sub + k * kGroup, c1, nx, lo);
+                        phi += PairTable::single_partial(b[k], sub + k * kGroup, c1, nx, hi);
+                    }
+                    lo = quad_sum(plo);
+                    hi = quad_sum(phi);
+                    rem -= 1u;
+                    part += 1u;
+                }
+                shift += part >> 3;
+                part &= 7u;
+            }
+            if (writer) {
+                if (bail) {
+                    s_left[atomicAdd(&s_nleft, 1u)] = q;
+                } else {
+                    const bool unchanged = kCursor && len == 0u;  // a cursor that got an empty string is as it was
+                    if (out_start && !unchanged) out_start[q] = lo;
+                    if (out_end && !unchanged) out_end[q] = hi;
+                    if (out_count) out_count[q] = hi - lo;
+                    if (!kCursor && out_status) out_status[q] = 0;
+                    if (kCursor && ca.active_out != nullptr && lo != hi && more_left) s_alive[slot] = q;
+                }
+            }
+        }
+        // the range's leftover queries: one atomic, coalesced stores; its live cursors: one atomic, in position order
+        __syncthreads();
+        const uint32_t n_left = s_nleft;
+        if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nleft = 0;
+        if (kCursor && ca.active_out != nullptr)
+            flush_live_ordered(s_alive, cnt, s_alive_part, &s_alive_base, ca.active_out, ca.n_active_out);
+    }
+}
+
 // packed queries (2 bits per symbol): 4 lanes per query, plain loads
 template <int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_packed_kernel4(GDX_SEARCH_ARGS)
@@ -1825,6 +2115,48 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         CursorArgs ca_general = ca;
         unsigned g_blocks = blocks;  // grid and range size of the general kernel
         uint32_t g_range = range;
+        // Exact intervals and cursor extension on clean input (search_exact_kernel4): what it cannot finish is listed for
+        // the general kernel below.  QueryOptions::search_exact / GDX_SEARCH_EXACT=0 switch it off.
+        static const int env_exact = [] { const char *e = getenv("GDX_SEARCH_EXACT"); return e ? atoi(e) : -1; }();
+        const bool exact = (c.mode == 0 || c.mode == 2) && c.d_step_stats == nullptr && lanes == 4 && policy == 0 && !c.packed &&
+                           c.d_hint == nullptr && c.d_rec == nullptr && c.d_start != nullptr && c.d_end != nullptr &&
+                           ix.n_searchable >= 4 && ix.sigma >= 5 && ca.resume_state == nullptr &&
+                           (ix.top == nullptr || ix.top_depth >= static_cast<uint32_t>(ix.depth)) &&
+                           (env_exact >= 0 ? env_exact != 0 : qo.search_exact != 0) && (defer_after == 0u || c.mode == 2) &&
+                           nq < 0xffffffffull;
+        if (exact) {
+            uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            const ExactView ev{ix.top, ix.jump, ix.pair_lines, ix.io_to_dense, ix.top_depth, ix.n, static_cast<uint32_t>(ix.depth),
+                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+            static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
+            const bool perm = ix.perm_ok && !env_no_perm;
+#define GDX_EXACT_LAUNCH(J, XLATE, CURSOR)                                                                                  \
+    hipLaunchKernelGGL((search_exact_kernel4<J, XLATE, CURSOR>), dim3(blocks), dim3(kBlock), 0, stream, ev, c.d_qbuf,       \
+                       c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status, range, schedule, d_left + 4, d_left, ca)
+#define GDX_EXACT_LAUNCH_X(J, CURSOR)                    \
+    do {                                                 \
+        if (perm) GDX_EXACT_LAUNCH(J, 1, CURSOR);        \
+        else GDX_EXACT_LAUNCH(J, 0, CURSOR);             \
+    } while (0)
+#define GDX_EXACT_LAUNCH_J(CURSOR)                                                 \
+    do {                                                                           \
+        if (ix.jump == nullptr) GDX_EXACT_LAUNCH_X(0, CURSOR);                     \
+        else if (ix.jump_bytes == 32) GDX_EXACT_LAUNCH_X(32, CURSOR);              \
+        else if (ix.jump_bytes == 16) GDX_EXACT_LAUNCH_X(16, CURSOR);              \
+        else GDX_EXACT_LAUNCH_X(8, CURSOR);                                        \
+    } while (0)
+            if (c.mode == 2) GDX_EXACT_LAUNCH_J(true);
+            else GDX_EXACT_LAUNCH_J(false);
+#undef GDX_EXACT_LAUNCH_J
+#undef GDX_EXACT_LAUNCH_X
+#undef GDX_EXACT_LAUNCH
+            g_range = 256;
+            const uint64_t g_ranges = (nq + g_range - 1) / g_range;
+            g_blocks = static_cast<unsigned>(g_ranges < 8192 ? g_ranges : 8192);
+            ca_general.active_in = d_left + 4;  // the general kernel below goes over the leftover list
+            ca_general.n_active_in = d_left;
+        }
         if (fast) {
             // the leftover list is short (0.3 % of the reads of a non-repetitive text) and its length is only known on
             // the device: small ranges spread it over the chip, a capped grid strides over whatever there is

@@ -161,7 +161,8 @@ class FmIndex:
         return {f: int(getattr(a, f)) for f, _ in a._fields_}
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
-                          locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None) -> None:
+                          locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None,
+                          search_exact=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -182,6 +183,8 @@ class FmIndex:
             o.search_defer_after = int(search_defer_after)
         if search_fast is not None:
             o.search_fast = int(search_fast)  # False / True / 2 (jumps over up to 16 rows)
+        if search_exact is not None:
+            o.search_exact = int(bool(search_exact))
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

@@ -192,6 +192,9 @@ typedef struct {
                                 repeat families) instead of 4; 0 = general kernel only; -1 default, by
                                 gdx_index_aux_t.wide_permille: > 500 (a top table that is shallow for the text) 0,
                                 > 20 (a repetitive text) 2, else 1                                              */
+    int32_t search_exact;    /* -1 default (1): cursors_for_many_queries and the cursor extension calls first run a slim
+                                kernel for clean input (symbols A C G T only: top table, whole jump levels, exact pair-line
+                                steps) and hand what it cannot finish to the general kernel; 0 = general kernel only    */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);

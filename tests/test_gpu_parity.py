@@ -215,6 +215,8 @@ _VARIANTS = {
     "pair-top4": (dict(search_kernel="pair", locate_jump_walk=False), dict(top_table_depth=4)),
     "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
     "pair-no-fast": (dict(search_kernel="pair", search_fast=False), {}),
+    # the general kernel alone (no slim kernel in front of it) for exact intervals and cursors too
+    "pair-general-only": (dict(search_kernel="pair", search_fast=False, search_exact=False), {}),
     "pair-fast": (dict(search_kernel="pair", search_fast=1), {}),  # (the default asks the index: wide_permille)
     "pair-fast-wide": (dict(search_kernel="pair", search_fast=2), {}),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
