@@ -57,7 +57,7 @@ class QueryOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
                 ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32),
                 ("locate_jump_walk", C.c_int32), ("search_defer_after", C.c_int32), ("search_fast", C.c_int32),
-                ("search_exact", C.c_int32)]
+                ("search_exact", C.c_int32), ("max_hits_per_query", C.c_uint32)]
 
 
 class IndexAux(C.Structure):
@@ -120,6 +120,7 @@ SIGNATURES = {
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
+    "gdx_multi_set_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_multi_replicas": [vp],
     "gdx_multi_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
     "gdx_multi_cursors_for_many_queries": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],

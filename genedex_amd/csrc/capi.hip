@@ -178,6 +178,42 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
     return b;
 }
 
+gdx::QueryOptions parse_query_options(const gdx_query_options_t *opts)
+{
+    gdx::QueryOptions q;
+    gdx_query_options_t full;
+    if (opts) {
+        // (struct_size: as in make_build_options -- a shorter struct of an older caller keeps defaults for the rest)
+        gdx_query_options_init(&full);
+        if (opts->struct_size < 2 * sizeof(uint32_t))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t.struct_size is too small (use gdx_query_options_init)");
+        std::memcpy(&full, opts, opts->struct_size < sizeof(full) ? opts->struct_size : sizeof(full));
+        opts = &full;
+        if (opts->search_kernel < -1 || opts->search_kernel > 2 ||
+            (opts->search_lanes != 0 && opts->search_lanes != 4 && opts->search_lanes != 8) || opts->load_policy < -1 ||
+            opts->load_policy > 3 || opts->length_schedule < -1 || opts->length_schedule > 1 ||
+            opts->locate_kernel < -1 || opts->locate_kernel > 2)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.search_variant = opts->search_kernel;
+        q.search_lanes = opts->search_lanes;
+        q.load_policy = opts->load_policy;
+        q.length_schedule = opts->length_schedule;
+        q.locate_variant = opts->locate_kernel;
+        if (opts->locate_jump_walk < -1 || opts->locate_jump_walk > 1)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.locate_jump_walk = opts->locate_jump_walk;
+        if (opts->search_defer_after < -1 || opts->search_defer_after > 1000)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.search_defer_after = opts->search_defer_after;
+        if (opts->search_fast < -1 || opts->search_fast > 2) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.search_fast = opts->search_fast;
+        if (opts->search_exact < -1 || opts->search_exact > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.search_exact = opts->search_exact;
+        q.max_hits_per_query = opts->max_hits_per_query;
+    }
+    return q;
+}
+
 }  // namespace
 
 extern "C" {
@@ -214,6 +250,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->search_defer_after = -1;
     opts->search_fast = -1;
     opts->search_exact = -1;
+    opts->max_hits_per_query = 0;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -360,37 +397,17 @@ int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts
 {
     return guarded([&] {
         if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
-        gdx::QueryOptions q;
-        gdx_query_options_t full;
-        if (opts) {
-            // (struct_size: as in make_build_options -- a shorter struct of an older caller keeps defaults for the rest)
-            gdx_query_options_init(&full);
-            if (opts->struct_size < 2 * sizeof(uint32_t))
-                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t.struct_size is too small (use gdx_query_options_init)");
-            std::memcpy(&full, opts, opts->struct_size < sizeof(full) ? opts->struct_size : sizeof(full));
-            opts = &full;
-            if (opts->search_kernel < -1 || opts->search_kernel > 2 ||
-                (opts->search_lanes != 0 && opts->search_lanes != 4 && opts->search_lanes != 8) || opts->load_policy < -1 ||
-                opts->load_policy > 3 || opts->length_schedule < -1 || opts->length_schedule > 1 ||
-                opts->locate_kernel < -1 || opts->locate_kernel > 2)
-                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
-            q.search_variant = opts->search_kernel;
-            q.search_lanes = opts->search_lanes;
-            q.load_policy = opts->load_policy;
-            q.length_schedule = opts->length_schedule;
-            q.locate_variant = opts->locate_kernel;
-            if (opts->locate_jump_walk < -1 || opts->locate_jump_walk > 1)
-                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
-            q.locate_jump_walk = opts->locate_jump_walk;
-            if (opts->search_defer_after < -1 || opts->search_defer_after > 1000)
-                gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
-            q.search_defer_after = opts->search_defer_after;
-            if (opts->search_fast < -1 || opts->search_fast > 2) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
-            q.search_fast = opts->search_fast;
-            if (opts->search_exact < -1 || opts->search_exact > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
-            q.search_exact = opts->search_exact;
-        }
-        ix->impl->set_query_options(q);
+        ix->impl->set_query_options(parse_query_options(opts));
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_multi_set_query_options(gdx_multi_t *m, const gdx_query_options_t *opts)
+{
+    return guarded([&] {
+        if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
+        const gdx::QueryOptions q = parse_query_options(opts);
+        for (auto &rep : m->impl->replicas) rep->set_query_options(q);
         return (int)GDX_OK;
     });
 }
@@ -411,6 +428,7 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->search_defer_after = q.search_defer_after;
         out->search_fast = q.search_fast;
         out->search_exact = q.search_exact;
+        out->max_hits_per_query = q.max_hits_per_query;
         return (int)GDX_OK;
     });
 }

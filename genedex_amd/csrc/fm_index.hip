@@ -1045,6 +1045,7 @@ void FmIndex::set_query_options(const QueryOptions &q)
     q_defer_after_.store(q.search_defer_after);
     q_fast_.store(q.search_fast);
     q_exact_.store(q.search_exact);
+    q_max_hits_.store(q.max_hits_per_query);
 }
 
 QueryOptions FmIndex::query_options() const
@@ -1059,6 +1060,7 @@ QueryOptions FmIndex::query_options() const
     q.search_defer_after = q_defer_after_.load();
     q.search_fast = q_fast_.load();
     q.search_exact = q_exact_.load();
+    q.max_hits_per_query = q_max_hits_.load();
     // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
     if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;
     // default: the fast-path kernel first, unless the top table is so shallow for this text that most reads leave it

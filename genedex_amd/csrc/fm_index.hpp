@@ -127,6 +127,7 @@ private:
     BuildStats stats_;
     AuxReport aux_report_;
     std::atomic<int> q_search_variant_{-1}, q_search_lanes_{0}, q_load_policy_{-1}, q_schedule_{-1}, q_locate_variant_{-1}, q_locate_jump_walk_{-1}, q_defer_after_{-1}, q_fast_{-1}, q_exact_{-1};
+    std::atomic<uint32_t> q_max_hits_{0};
     uint64_t n_ = 0, n_texts_ = 0;
     std::vector<uint64_t> count_host_;      // sigma+1
     std::vector<uint64_t> sentinels_host_;  // n_texts

@@ -10,9 +10,11 @@
 //                                                                                         pinned -> the user's arrays
 //
 // so that the PCIe transfers of chunk k + 1 / k - 1 run beside the kernels of chunk k and a call costs about
-// max(H2D time, D2H time, kernel time) instead of their sum.  Device results travel narrow (u32 counts and rows,
-// 8-byte hits, one status byte) and are widened to the ABI's u64 by the host threads while they copy.  Results are
-// order preserving: chunk boundaries are invisible to the caller.
+// max(H2D time, D2H time, kernel time) instead of their sum.  Counts and interval borders travel narrow (u32) and are
+// widened by the host threads while they copy; locate results leave the device in the ABI's own form -- 16-byte
+// gdx_hit_t and u64 hit offsets of the chunk -- so that the drainer only copies (and adds the chunk's base to the
+// offsets): the D2H link has room (a hit is 16 of the ~23 bytes per query going out, against 58 coming in), the
+// host cores of a container often do not.  Results are order preserving: chunk boundaries are invisible to the caller.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -22,6 +24,7 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
 #include <sys/mman.h>
 
 #include "fm_index.hpp"
@@ -117,12 +120,36 @@ private:
     bool stop_ = false;
 };
 
+// CPUs this process may use: the affinity mask cut by the cgroup quota (a container on a 256-thread host may own 16)
+unsigned usable_cpus()
+{
+    static const unsigned n = [] {
+        unsigned cpus = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = static_cast<unsigned>(CPU_COUNT(&set));
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+            char quota[32] = {0};
+            unsigned long period = 0;
+            if (std::fscanf(f, "%31s %lu", quota, &period) == 2 && period != 0 && std::strcmp(quota, "max") != 0)
+                cpus = std::min<unsigned>(cpus, std::max(1ul, std::strtoul(quota, nullptr, 10) / period));
+            std::fclose(f);
+        } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1 (period 100 ms default)
+            long q = -1;
+            if (std::fscanf(g, "%ld", &q) == 1 && q > 0) cpus = std::min<unsigned>(cpus, std::max(1l, q / 100000));
+            std::fclose(g);
+        }
+        return std::max(1u, cpus);
+    }();
+    return n;
+}
+
+// workers of ONE pool; a call runs two pools (staging in, draining out) beside its three pipeline threads
 unsigned host_threads()
 {
     static const unsigned n = [] {
         if (const char *e = getenv("GDX_HOST_THREADS")) return static_cast<unsigned>(std::max(1, atoi(e)));
-        const unsigned hw = std::thread::hardware_concurrency();
-        return std::min(16u, std::max(2u, hw / 4u));
+        const unsigned cpus = usable_cpus();
+        return std::min(16u, std::max(2u, cpus > 6u ? (cpus - 2u) / 2u : 2u));
     }();
     return n;
 }
@@ -211,15 +238,12 @@ struct Streams {
     }
 };
 
-__global__ __launch_bounds__(256) void unpack_counts_kernel(const uint4 *__restrict__ rec, uint64_t nq,
-                                                            uint32_t *__restrict__ counts, uint8_t *__restrict__ status)
+__global__ __launch_bounds__(256) void unpack_status_kernel(const uint4 *__restrict__ rec, uint64_t nq,
+                                                            uint8_t *__restrict__ status)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; q < nq; q += stride) {
-        const uint4 r = rec[q];
-        counts[q] = r.y - r.x;
-        status[q] = static_cast<uint8_t>(r.w >> 24);
-    }
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; q < nq; q += stride)
+        status[q] = static_cast<uint8_t>(rec[q].w >> 24);
 }
 
 void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, WorkerPool &pool)
@@ -313,7 +337,10 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         d_off[s] = kind == Kind::kLocate ? device_buf<uint64_t>(dev, s * 16 + 6, max_nq + 1) : nullptr;
         d_scan[s] = kind == Kind::kLocate ? device_buf<uint8_t>(dev, s * 16 + 7, scan_bytes ? scan_bytes : 1) : nullptr;
     }
-    gdx_hit32_t *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
+    uint64_t *h_off[kSlots] = {};  // locate: the chunk's hit offsets (h_off[i] = hits of its queries before query i)
+    if (kind == Kind::kLocate)
+        for (int s = 0; s < kSlots; s++) h_off[s] = pinned_buf<uint64_t>(dev, s * 16 + 10, max_nq + 1);
+    gdx_hit_t *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
     void *d_ws[kSlots] = {};
 
     std::atomic<bool> any_status{false};
@@ -361,8 +388,9 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         GDX_HIP(hipGetLastError());
         if (kind == Kind::kLocate) {
             const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((c.nq + 255) / 256, 4096));
-            hipLaunchKernelGGL(unpack_counts_kernel, dim3(blocks), dim3(256), 0, st.k, d_rec[s], c.nq, d_a[s], d_status[s]);
-            launch_hit_offsets_rec(d_rec[s], c.nq, d_off[s], d_scan[s], scan_bytes, st.k);
+            hipLaunchKernelGGL(unpack_status_kernel, dim3(blocks), dim3(256), 0, st.k, d_rec[s], c.nq, d_status[s]);
+            // (max_hits_per_query: a query gets slots for its first k rows only -- locate(q).take(k))
+            launch_hit_offsets_rec(d_rec[s], c.nq, d_off[s], d_scan[s], scan_bytes, st.k, qo.max_hits_per_query, true);
             GDX_HIP(hipMemcpyAsync(h_total[s], d_off[s] + c.nq, sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
             GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
         } else {
@@ -377,22 +405,25 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = *h_total[s];
             if (c.total) {
-                d_hits[s] = device_buf<gdx_hit32_t>(dev, s * 16 + 8, c.total);
-                h_hits[s] = pinned_buf<gdx_hit32_t>(dev, s * 16 + 6, c.total);
+                d_hits[s] = device_buf<gdx_hit_t>(dev, s * 16 + 8, c.total);
+                h_hits[s] = pinned_buf<gdx_hit_t>(dev, s * 16 + 6, c.total);
                 d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
-                launch_locate(view_, nullptr, nullptr, c.nq, d_off[s], c.total, d_hits[s], false, d_ws[s], st.k, nullptr,
+                launch_locate(view_, nullptr, nullptr, c.nq, d_off[s], c.total, d_hits[s], true, d_ws[s], st.k, nullptr,
                               nullptr, qo, d_rec[s]);
                 GDX_HIP(hipGetLastError());
             }
             GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
         }
         GDX_HIP(hipStreamWaitEvent(st.out, st.ev_k[s], 0));
-        GDX_HIP(hipMemcpyAsync(h_a[s], d_a[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
+        if (kind == Kind::kLocate)
+            GDX_HIP(hipMemcpyAsync(h_off[s], d_off[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st.out));
+        else
+            GDX_HIP(hipMemcpyAsync(h_a[s], d_a[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
         if (kind == Kind::kIntervals)
             GDX_HIP(hipMemcpyAsync(h_b[s], d_b[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
         if (kind == Kind::kLocate && c.total)
-            GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * sizeof(gdx_hit32_t), hipMemcpyDeviceToHost, st.out));
+            GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
     };
 
@@ -404,36 +435,19 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         const uint8_t *stt = h_status[s];
         if (kind == Kind::kLocate) {
             c.hit_base = hit_base;
-            if (out_a) {  // offsets: running sum of the counts (a serial dependency: done per worker in two passes)
-                const unsigned nw = pool.size();
-                std::vector<uint64_t> part(nw + 1, 0);
-                pool.run([&](unsigned w, unsigned n) {
-                    const uint64_t lo = c.nq * w / n, hi = c.nq * (w + 1) / n;
-                    uint64_t sum = 0;
-                    for (uint64_t i = lo; i < hi; i++) sum += a[i];
-                    part[w + 1] = sum;
-                });
-                for (unsigned w = 0; w < nw; w++) part[w + 1] += part[w];
-                pool.run([&](unsigned w, unsigned n) {
-                    const uint64_t lo = c.nq * w / n, hi = c.nq * (w + 1) / n;
-                    uint64_t sum = hit_base + part[w];
-                    for (uint64_t i = lo; i < hi; i++) {
-                        sum += a[i];
-                        out_a[c.q0 + i + 1] = sum;
-                    }
+            if (out_a) {  // the chunk's offsets (scanned on the device) shifted by the hits of the chunks before it
+                const uint64_t *off = h_off[s];
+                const uint64_t shift_by = hit_base;
+                pool.parallel_range(c.nq, 8, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t i = lo; i < hi; i++) out_a[c.q0 + i + 1] = off[i + 1] + shift_by;
                 });
             }
             const uint64_t need = hit_base + c.total;
             if (grow_hits && need > hits_capacity) hits = (*grow_hits)(need, &hits_capacity);  // at least `need`
             if (hits && need <= hits_capacity && capacity_ok) {
-                const gdx_hit32_t *src = h_hits[s];
+                const gdx_hit_t *src = h_hits[s];
                 gdx_hit_t *dst = hits + hit_base;
-                pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) {
-                    for (uint64_t i = lo; i < hi; i++) {
-                        dst[i].text_id = src[i].text_id;
-                        dst[i].position = src[i].position;
-                    }
-                });
+                pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(gdx_hit_t)); });
             } else {
                 capacity_ok = false;
             }

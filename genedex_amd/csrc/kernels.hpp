@@ -23,6 +23,8 @@ struct QueryOptions {
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
                                   // finished in the block's straggler pass; 0 = never
     int search_exact = -1;        // exact-interval and cursor searches run search_exact_kernel4 first (default) or not (0)
+    uint32_t max_hits_per_query = 0;  // host-pointer locate calls: at most this many hits per query, the first ones in
+                                      // suffix-array order (locate(q).take(k) of the reference's lazy iterator); 0 = all
 };
 
 // Active lists of the cursor-extension mode (search mode 2): the cursors to extend are those listed in active_in
@@ -108,9 +110,10 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
                         void *d_temp, size_t temp_bytes, hipStream_t stream);
 // the same scan over 16-byte search records (SearchCall::d_rec)
 size_t hit_offsets_rec_temp_bytes(uint64_t m);
-// max_hits != 0: queries with more occurrences get no hit slots (counted, not located)
+// max_hits != 0: queries with more occurrences get no hit slots (counted, not located) -- or, with `take`, slots for
+// their first max_hits rows
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
-                            hipStream_t stream, uint32_t max_hits = 0);
+                            hipStream_t stream, uint32_t max_hits = 0, bool take = false);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,

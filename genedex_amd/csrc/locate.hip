@@ -37,13 +37,15 @@ struct RecordSize {
     const uint4 *rec;
     uint64_t m;
     uint32_t max_hits;  // 0 = no limit; a query with more occurrences than this gets no hit slots (it is counted,
-                        // not located: what read mappers do with reads from repeats)
+                        // not located: what read mappers do with reads from repeats) -- or, with `take`, slots for its
+                        // first max_hits rows (lib.rs:187-197: the reference's locate is lazy, callers take(k))
+    bool take;
     __host__ __device__ uint64_t operator()(uint64_t q) const
     {
         if (q >= m) return 0ull;
         const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
         const uint32_t c = v.y - v.x;
-        return (max_hits != 0u && c > max_hits) ? 0ull : static_cast<uint64_t>(c);
+        return (max_hits != 0u && c > max_hits) ? (take ? static_cast<uint64_t>(max_hits) : 0ull) : static_cast<uint64_t>(c);
     }
 };
 
@@ -521,7 +523,7 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
 size_t hit_offsets_rec_temp_bytes(uint64_t m)
 {
     size_t bytes = 0;
-    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{nullptr, m, 0u});
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{nullptr, m, 0u, false});
     uint64_t *out = nullptr;
     (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1),
                                   rocprim::plus<uint64_t>());
@@ -529,9 +531,9 @@ size_t hit_offsets_rec_temp_bytes(uint64_t m)
 }
 
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
-                            hipStream_t stream, uint32_t max_hits)
+                            hipStream_t stream, uint32_t max_hits, bool take)
 {
-    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, m, max_hits});
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, m, max_hits, take});
     GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
 }

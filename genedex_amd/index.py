@@ -162,7 +162,7 @@ class FmIndex:
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
                           locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None,
-                          search_exact=None) -> None:
+                          search_exact=None, max_hits_per_query=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -185,6 +185,8 @@ class FmIndex:
             o.search_fast = int(search_fast)  # False / True / 2 (jumps over up to 16 rows)
         if search_exact is not None:
             o.search_exact = int(bool(search_exact))
+        if max_hits_per_query is not None:
+            o.max_hits_per_query = int(max_hits_per_query)  # host-pointer locate calls: locate(q).take(k)
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

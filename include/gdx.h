@@ -195,6 +195,10 @@ typedef struct {
     int32_t search_exact;    /* -1 default (1): cursors_for_many_queries and the cursor extension calls first run a slim
                                 kernel for clean input (symbols A C G T only: top table, whole jump levels, exact pair-line
                                 steps) and hand what it cannot finish to the general kernel; 0 = general kernel only    */
+    uint32_t max_hits_per_query; /* gdx_locate_many / gdx_locate_many_alloc / gdx_multi_locate_many_alloc: at most this many
+                                hits per query, the first ones in suffix-array order -- locate(q).take(k) of the reference's
+                                lazy iterator (lib.rs:187-197): one poly-A read on a genome would otherwise materialise
+                                gigabytes of hits.  hit_offsets then counts the hits RETURNED.  0 = all (default)        */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);
@@ -426,6 +430,8 @@ int gdx_multi_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint
 int gdx_multi_from_indexes(gdx_index_t **replicas, int n_replicas, gdx_multi_t **out);
 void gdx_multi_free(gdx_multi_t *m);
 int gdx_multi_replicas(const gdx_multi_t *m);
+/* gdx_index_set_query_options on every replica (e.g. max_hits_per_query for gdx_multi_locate_many_alloc) */
+int gdx_multi_set_query_options(gdx_multi_t *m, const gdx_query_options_t *opts);
 int gdx_multi_count_many(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                          uint64_t *out_counts, uint8_t *out_status);
 int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,

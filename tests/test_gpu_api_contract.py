@@ -264,3 +264,80 @@ def test_multi_handle_shards_equal_single_gpu(setup):
         assert off.tolist() == co.tolist() and hits[:, 0].tolist() == ct.tolist() and hits[:, 1].tolist() == cp.tolist()
     finally:
         lib.gdx_multi_free(m)
+
+
+def test_locate_takes_at_most_max_hits_per_query():
+    """gdx_query_options_t.max_hits_per_query: the host-pointer locate calls return the first k hits of a query in
+    suffix-array order -- locate(q).take(k) on the reference's lazy iterator (lib.rs:187-197) -- so one poly-A read does
+    not materialise every occurrence.  Counts stay the reference's; hit_offsets count the hits returned."""
+    from genedex_amd import FmIndexConfig, _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+    a = alph.ascii_dna_with_n()
+    body = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 30000))
+    texts = [body[:15000] + b"A" * 60000 + body[15000:], b"A" * 5000 + body[:2000], body[100:9000]]
+    g = FmIndexConfig("u32").construct_index(texts, a)
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=0, width=32)
+    qs = [b"A" * 20, body[200:260], b"A" * 50, body[5000:5030], b"AAAAAAAAAAAAAAAAAAAC", b"A" * 16, b""]
+    qs += [body[s:s + 40] for s in rng.integers(0, 29000, 300)]
+    qbuf, qoff = pack_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    assert int((ce - cs)[0]) > 60000
+    for k in (1, 7, 100, 100000):
+        g.set_query_options(max_hits_per_query=k)
+        take = np.minimum(ce - cs, k)
+        co, ct, cp = c.locate_intervals(cs, cs + take)
+        for call in (g.locate_raw, g.locate_alloc_raw):
+            off, t, p, st = call(qbuf, qoff)
+            assert not st.any()
+            assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist(), (k, call.__name__)
+        counts, _ = g.count_raw(qbuf, qoff)  # counting is not limited
+        assert counts.tolist() == (ce - cs).tolist()
+    g.set_query_options()
+    off, t, p, _ = g.locate_alloc_raw(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce)
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    # the same limit through the multi handle (every replica takes the option)
+    tbuf, toff = pack_queries(texts)
+    tab = np.ascontiguousarray(a.io_to_dense_table, dtype=np.uint8)
+    devs = (C.c_int * 2)(0, 0)
+    m = C.c_void_p()
+    _lib.check(lib.gdx_multi_build(tbuf.ctypes.data_as(_lib.u8p), toff.ctypes.data_as(_lib.u64p), len(texts),
+                                   tab.ctypes.data_as(_lib.u8p), 6, 4, 4, 0, 32, devs, 2, None, C.byref(m)))
+    try:
+        o = _lib.QueryOptions()
+        lib.gdx_query_options_init(C.byref(o))
+        o.max_hits_per_query = 9
+        _lib.check(lib.gdx_multi_set_query_options(m, C.byref(o)))
+        nq = qoff.size - 1
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        ptr = C.POINTER(_lib.HitStruct)()
+        _lib.check(lib.gdx_multi_locate_many_alloc(m, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                                   off.ctypes.data_as(_lib.u64p), C.byref(ptr), C.byref(total), None))
+        n = total.value
+        hits = np.ctypeslib.as_array(C.cast(ptr, _lib.u64p), shape=(2 * n,)).reshape(n, 2).copy()
+        lib.gdx_free_hits(ptr)
+        co, ct, cp = c.locate_intervals(cs, cs + np.minimum(ce - cs, 9))
+        assert off.tolist() == co.tolist() and hits[:, 0].tolist() == ct.tolist() and hits[:, 1].tolist() == cp.tolist()
+    finally:
+        lib.gdx_multi_free(m)
+
+
+def test_query_options_struct_may_be_shorter_than_the_library_knows():
+    """struct_size lets gdx_query_options_t grow: a caller built against an older header passes a shorter struct and the
+    fields it does not know keep their defaults."""
+    from genedex_amd import FmIndexConfig, _lib
+
+    lib = _lib.load()
+    g = FmIndexConfig("u32").construct_index([b"ACGTACGTTTGA"], alph.ascii_dna())
+    o = _lib.QueryOptions()
+    lib.gdx_query_options_init(C.byref(o))
+    o.search_fast = 0
+    o.max_hits_per_query = 5          # beyond the size the caller declares: must be ignored
+    o.struct_size = 9 * 4             # the round-2 struct: struct_size + eight int32 fields
+    _lib.check(lib.gdx_index_set_query_options(g._h, C.byref(o)))
+    back = _lib.QueryOptions()
+    _lib.check(lib.gdx_index_get_query_options(g._h, C.byref(back)))
+    assert back.search_fast == 0 and back.max_hits_per_query == 0
