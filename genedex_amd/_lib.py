@@ -60,6 +60,15 @@ class QueryOptions(C.Structure):
                 ("search_exact", C.c_int32), ("max_hits_per_query", C.c_uint32)]
 
 
+class DeviceShard(C.Structure):
+    _fields_ = [("d_qbuf", C.c_void_p), ("d_qoff", C.c_void_p), ("nq", C.c_uint64)]
+
+
+class Gathered(C.Structure):
+    _fields_ = [("d_counts", C.c_void_p), ("d_hit_offsets", C.c_void_p), ("d_hits", C.c_void_p), ("d_status", C.c_void_p),
+                ("nq", C.c_uint64), ("total_hits", C.c_uint64), ("device_id", C.c_int32), ("used_rccl", C.c_int32)]
+
+
 class IndexAux(C.Structure):
     _fields_ = [("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32), ("top_table_depth", C.c_int32),
                 ("wanted_jump_entry_bytes", C.c_int32), ("wanted_top_table_depth", C.c_int32),
@@ -120,6 +129,7 @@ SIGNATURES = {
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
+    "gdx_multi_locate_many_gather_dev": [vp, vp, C.c_int, C.c_int, vp],
     "gdx_multi_set_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_multi_replicas": [vp],
     "gdx_multi_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],

@@ -1208,6 +1208,37 @@ int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf
     });
 }
 
+int gdx_multi_locate_many_gather_dev(gdx_multi_t *m, const gdx_device_shard_t *shards, int n_shards, int root,
+                                     gdx_gathered_t *out)
+{
+    return guarded([&] {
+        if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
+        if (!shards || !out || n_shards < 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_multi_locate_many_gather_dev: bad argument");
+        int prev = 0;
+        GDX_HIP(hipGetDevice(&prev));
+        std::vector<gdx::DeviceShard> sh(n_shards);
+        for (int r = 0; r < n_shards; r++)
+            sh[r] = gdx::DeviceShard{static_cast<const uint8_t *>(shards[r].d_qbuf), static_cast<const uint64_t *>(shards[r].d_qoff), shards[r].nq};
+        gdx::Gathered g{};
+        try {
+            gdx::multi_locate_gather_dev(*m->impl, sh.data(), n_shards, root, &g);
+        } catch (...) {
+            (void)hipSetDevice(prev);
+            throw;
+        }
+        (void)hipSetDevice(prev);
+        out->d_counts = g.d_counts;
+        out->d_hit_offsets = g.d_hit_offsets;
+        out->d_hits = g.d_hits;
+        out->d_status = g.d_status;
+        out->nq = g.nq;
+        out->total_hits = g.total_hits;
+        out->device_id = g.device_id;
+        out->used_rccl = g.used_rccl;
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                                 uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
 {

@@ -81,6 +81,10 @@ public:
     // drops the pair lines / jump table / top table and builds them again with other options (bench ladder;
     // not safe against concurrent queries)
     void rebuild_aux(const BuildOptions &opts);
+    // search -> scan -> locate of a device-resident batch on this replica's device, results left in the given buffers
+    // (grown as needed): counts u32[nq], status u8[nq], hits gdx_hit32_t[total]; returns the number of hits
+    uint64_t locate_shard_dev(const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq, DeviceBuffer<uint32_t> &counts,
+                              DeviceBuffer<uint8_t> &status, DeviceBuffer<gdx_hit32_t> &hits, hipStream_t stream) const;
 
     // ---- host-pointer query API (each call uploads, runs, downloads, synchronises) -------------
     // packed: qbuf holds 2-bit codes and qoff counts symbols (include/gdx.h "packed queries")
@@ -169,12 +173,33 @@ private:
 struct Multi {
     std::vector<std::unique_ptr<FmIndex>> replicas;
     std::vector<std::unique_ptr<ReplicaWorker>> workers;  // one per replica (start_workers)
-    std::mutex call_mutex;  // calls on one handle run one after the other: a second concurrent call queues here
+    std::recursive_mutex call_mutex;  // calls on one handle run one after the other: a second concurrent call queues here
+    // gdx_multi_locate_many_gather_dev: RCCL communicators (one per replica, created on first use) and the root's
+    // result buffers
+    std::vector<void *> comms;
+    DeviceBuffer<uint32_t> g_counts;
+    DeviceBuffer<uint64_t> g_offsets;
+    DeviceBuffer<gdx_hit32_t> g_hits;
+    DeviceBuffer<uint8_t> g_status, g_scan;
+    int g_device = -1;
+    ~Multi();
     void start_workers();   // once, when the replicas are in place
     ReplicaWorker &worker(size_t r) { return *workers[r]; }
 };
 int multi_cursors(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
                   uint64_t *out_end, uint64_t *out_count, uint8_t *out_status);
+struct DeviceShard {
+    const uint8_t *d_qbuf;
+    const uint64_t *d_qoff;
+    uint64_t nq;
+};
+struct Gathered {
+    void *d_counts, *d_hit_offsets, *d_hits, *d_status;
+    uint64_t nq, total_hits;
+    int device_id, used_rccl;
+};
+void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, int root, Gathered *out);
+// FmIndex half of it: search -> scan -> locate of a device-resident shard on this replica's device (multi.hip)
 int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                        gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
 

@@ -114,6 +114,12 @@ size_t hit_offsets_rec_temp_bytes(uint64_t m);
 // their first max_hits rows
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
                             hipStream_t stream, uint32_t max_hits = 0, bool take = false);
+// exclusive scan of m u32 counts into m + 1 u64 offsets (the root of gdx_multi_locate_many_gather_dev)
+size_t count_offsets_temp_bytes(uint64_t m);
+void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offsets, void *d_temp, size_t temp_bytes,
+                          hipStream_t stream);
+// counts (end - start) and status bytes out of search records
+void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,

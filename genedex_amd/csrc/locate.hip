@@ -538,6 +538,49 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
 }
 
+namespace {
+struct CountAt {
+    const uint32_t *counts;
+    uint64_t m;
+    __host__ __device__ uint64_t operator()(uint64_t q) const { return q < m ? static_cast<uint64_t>(counts[q]) : 0ull; }
+};
+using CountIterator = rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, CountAt, uint64_t>;
+
+__global__ __launch_bounds__(kBlock) void unpack_records_kernel(const uint4 *__restrict__ rec, uint64_t m,
+                                                                uint32_t *__restrict__ counts, uint8_t *__restrict__ status)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < m; q += stride) {
+        const uint4 r = rec[q];
+        if (counts) counts[q] = r.y - r.x;
+        if (status) status[q] = static_cast<uint8_t>(r.w >> 24);
+    }
+}
+}  // namespace
+
+size_t count_offsets_temp_bytes(uint64_t m)
+{
+    size_t bytes = 0;
+    CountIterator in(rocprim::counting_iterator<uint64_t>(0), CountAt{nullptr, m});
+    uint64_t *out = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1), rocprim::plus<uint64_t>());
+    return bytes;
+}
+
+void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offsets, void *d_temp, size_t temp_bytes,
+                          hipStream_t stream)
+{
+    CountIterator in(rocprim::counting_iterator<uint64_t>(0), CountAt{d_counts, m});
+    GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_offsets, uint64_t(0), static_cast<size_t>(m + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+}
+
+void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream)
+{
+    if (m == 0) return;
+    hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_rec, m, d_counts, d_status);
+}
+
 size_t locate_workspace_bytes(uint64_t total_hits)
 {
     return align_up(total_hits * sizeof(uint32_t), 256) + align_up(max_scan_temp_bytes(total_hits), 256) + 256;

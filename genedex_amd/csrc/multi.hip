@@ -98,7 +98,7 @@ int run_shards(Multi &m, uint64_t nq, F per_shard)
     const size_t g = m.replicas.size();
     // one call at a time per handle: the workers' queues then hold this call's jobs only, so waiting for them to go
     // idle is waiting for this call
-    std::lock_guard<std::mutex> serial(m.call_mutex);
+    std::lock_guard<std::recursive_mutex> serial(m.call_mutex);
     std::vector<ShardResult> res(g);
     size_t submitted = 0;
     try {
@@ -201,6 +201,224 @@ int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint
     }
     for (gdx_hit_t *h : shard_hits) std::free(h);
     return rc;
+}
+
+}  // namespace gdx
+
+// =====================================================================================================================
+// Device-resident shards, results gathered to one GPU with RCCL point-to-point transfers (gdx_multi_locate_many_gather_dev)
+
+#include <dlfcn.h>
+
+namespace gdx {
+
+uint64_t FmIndex::locate_shard_dev(const uint8_t *d_qbuf, const uint64_t *d_qoff, uint64_t nq, DeviceBuffer<uint32_t> &counts,
+                                   DeviceBuffer<uint8_t> &status, DeviceBuffer<gdx_hit32_t> &hits, hipStream_t stream) const
+{
+    if (nq == 0) return 0;
+    if (nq >= 0xffffffffull) fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 queries in one shard");
+    const QueryOptions qo = query_options();
+    DeviceBuffer<uint4> rec(nq);
+    DeviceBuffer<uint64_t> off(nq + 1);
+    const size_t scan_bytes = hit_offsets_rec_temp_bytes(nq);
+    DeviceBuffer<uint8_t> scan(scan_bytes ? scan_bytes : 1);
+    if (counts.count < nq) counts.alloc(nq);
+    if (status.count < nq) status.alloc(nq);
+    SearchCall call;
+    call.d_qbuf = d_qbuf;
+    call.d_qbeg = d_qoff;
+    call.d_qend = d_qoff + 1;
+    call.nq = nq;
+    call.d_rec = rec.get();
+    call.mode = 1;
+    launch_search_call(view_, call, stream, qo);
+    GDX_HIP(hipGetLastError());
+    launch_unpack_records(rec.get(), nq, counts.get(), status.get(), stream);
+    launch_hit_offsets_rec(rec.get(), nq, off.get(), scan.get(), scan_bytes, stream);
+    uint64_t total = 0;
+    GDX_HIP(hipMemcpyAsync(&total, off.get() + nq, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (total) {
+        if (hits.count < total) hits.alloc(total);
+        DeviceBuffer<uint8_t> ws(locate_workspace_bytes(total));
+        launch_locate(view_, nullptr, nullptr, nq, off.get(), total, hits.get(), false, ws.get(), stream, nullptr, nullptr, qo,
+                      rec.get());
+        GDX_HIP(hipGetLastError());
+        GDX_HIP(hipStreamSynchronize(stream));
+    }
+    return total;
+}
+
+namespace {
+
+// the few entry points of RCCL this needs, resolved at first use: libgdx.so has no link-time dependency on it (a box
+// without RCCL, or a single-GPU one, never loads it)
+struct Rccl {
+    using comm_t = void *;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl()
+    {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(h, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(h, "ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    return r;
+}
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3;  // ncclDataType_t (rccl.h)
+
+void nccl_check(int rc, const char *what)
+{
+    if (rc != 0) fail(GDX_ERR_DEVICE, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+}
+
+}  // namespace
+
+Multi::~Multi()
+{
+    if (!comms.empty() && rccl().ok)
+        for (void *c : comms)
+            if (c) (void)rccl().CommDestroy(c);
+    if (g_device >= 0 && hipSetDevice(g_device) == hipSuccess) {
+        g_counts.release();
+        g_offsets.release();
+        g_hits.release();
+        g_status.release();
+        g_scan.release();
+    }
+}
+
+void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, int root, Gathered *out)
+{
+    const size_t g = m.replicas.size();
+    if (!shards || !out || n_shards != static_cast<int>(g)) fail(GDX_ERR_INVALID_ARGUMENT, "one shard per replica is expected");
+    if (root < 0 || root >= n_shards) fail(GDX_ERR_INVALID_ARGUMENT, "root replica out of range");
+    std::vector<int> dev(g);
+    bool all_same = true, all_distinct = true;
+    for (size_t r = 0; r < g; r++) {
+        dev[r] = m.replicas[r]->config().device_id;
+        all_same &= dev[r] == dev[0];
+        for (size_t k = 0; k < r; k++) all_distinct &= dev[k] != dev[r];
+        if (shards[r].nq != 0 && (!shards[r].d_qoff || !shards[r].d_qbuf)) fail(GDX_ERR_INVALID_ARGUMENT, "shard %zu: null pointer", r);
+    }
+    std::lock_guard<std::recursive_mutex> serial(m.call_mutex);  // the handle's result buffers are this call's until it returns
+    const bool use_rccl = g > 1 && !all_same;
+    if (use_rccl && !all_distinct) fail(GDX_ERR_UNSUPPORTED, "replicas must sit on distinct devices, or all on one");
+    if (use_rccl && !rccl().ok) fail(GDX_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded");
+
+    // every replica: search -> scan -> locate of its shard on its own device and stream (the replica's worker thread)
+    struct Local {
+        DeviceBuffer<uint32_t> counts;
+        DeviceBuffer<uint8_t> status;
+        DeviceBuffer<gdx_hit32_t> hits;
+        hipStream_t stream = nullptr;
+        uint64_t total = 0;
+    };
+    std::vector<Local> loc(g);
+    const int rc = run_shards(m, 0, [&](size_t r, uint64_t, uint64_t, ShardResult &) {
+        GDX_HIP(hipSetDevice(dev[r]));
+        GDX_HIP(hipStreamCreateWithFlags(&loc[r].stream, hipStreamNonBlocking));
+        loc[r].total = m.replicas[r]->locate_shard_dev(shards[r].d_qbuf, shards[r].d_qoff, shards[r].nq, loc[r].counts,
+                                                       loc[r].status, loc[r].hits, loc[r].stream);
+        return static_cast<int>(GDX_OK);
+    });
+    (void)rc;
+    // where every shard lands on the root
+    std::vector<uint64_t> qbase(g + 1, 0), hbase(g + 1, 0);
+    for (size_t r = 0; r < g; r++) {
+        qbase[r + 1] = qbase[r] + shards[r].nq;
+        hbase[r + 1] = hbase[r] + loc[r].total;
+    }
+    const uint64_t nq = qbase[g], total = hbase[g];
+    GDX_HIP(hipSetDevice(dev[root]));
+    if (m.g_device != dev[root]) {
+        m.g_counts.release();
+        m.g_offsets.release();
+        m.g_hits.release();
+        m.g_status.release();
+        m.g_scan.release();
+        m.g_device = dev[root];
+    }
+    if (m.g_counts.count < nq + 1) m.g_counts.alloc(nq + 1);
+    if (m.g_status.count < nq + 1) m.g_status.alloc(nq + 1);
+    if (m.g_offsets.count < nq + 1) m.g_offsets.alloc(nq + 1);
+    if (m.g_hits.count < total + 1) m.g_hits.alloc(total + 1);
+    hipStream_t root_stream = loc[root].stream;
+    if (use_rccl) {
+        if (m.comms.empty()) {
+            m.comms.assign(g, nullptr);
+            nccl_check(rccl().CommInitAll(m.comms.data(), static_cast<int>(g), dev.data()), "ncclCommInitAll");
+        }
+        // one group: the root posts a receive per shard and array, every other replica the matching sends -- the
+        // transfers of all shards run at once over their own xGMI links
+        nccl_check(rccl().GroupStart(), "ncclGroupStart");
+        for (size_t r = 0; r < g; r++) {
+            if (static_cast<int>(r) == root) continue;
+            const int rr = static_cast<int>(r);
+            if (shards[r].nq) {
+                nccl_check(rccl().Send(loc[r].counts.get(), shards[r].nq, kNcclUint32, root, m.comms[r], loc[r].stream), "ncclSend");
+                nccl_check(rccl().Recv(m.g_counts.get() + qbase[r], shards[r].nq, kNcclUint32, rr, m.comms[root], root_stream), "ncclRecv");
+                nccl_check(rccl().Send(loc[r].status.get(), shards[r].nq, kNcclUint8, root, m.comms[r], loc[r].stream), "ncclSend");
+                nccl_check(rccl().Recv(m.g_status.get() + qbase[r], shards[r].nq, kNcclUint8, rr, m.comms[root], root_stream), "ncclRecv");
+            }
+            if (loc[r].total) {
+                nccl_check(rccl().Send(loc[r].hits.get(), loc[r].total * 2, kNcclUint32, root, m.comms[r], loc[r].stream), "ncclSend");
+                nccl_check(rccl().Recv(m.g_hits.get() + hbase[r], loc[r].total * 2, kNcclUint32, rr, m.comms[root], root_stream), "ncclRecv");
+            }
+        }
+        nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+    for (size_t r = 0; r < g; r++) {  // the root's own shard, and every shard when all replicas share the device
+        if (use_rccl && static_cast<int>(r) != root) continue;
+        if (shards[r].nq) {
+            GDX_HIP(hipMemcpyAsync(m.g_counts.get() + qbase[r], loc[r].counts.get(), shards[r].nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, root_stream));
+            GDX_HIP(hipMemcpyAsync(m.g_status.get() + qbase[r], loc[r].status.get(), shards[r].nq, hipMemcpyDeviceToDevice, root_stream));
+        }
+        if (loc[r].total)
+            GDX_HIP(hipMemcpyAsync(m.g_hits.get() + hbase[r], loc[r].hits.get(), loc[r].total * sizeof(gdx_hit32_t), hipMemcpyDeviceToDevice, root_stream));
+    }
+    const size_t scan_bytes = count_offsets_temp_bytes(nq);
+    if (m.g_scan.count < scan_bytes + 1) m.g_scan.alloc(scan_bytes + 1);
+    launch_count_offsets(m.g_counts.get(), nq, m.g_offsets.get(), m.g_scan.get(), scan_bytes, root_stream);
+    GDX_HIP(hipGetLastError());
+    for (size_t r = 0; r < g; r++) {  // every sender's buffers must outlive its transfers
+        GDX_HIP(hipSetDevice(dev[r]));
+        GDX_HIP(hipStreamSynchronize(loc[r].stream));
+    }
+    for (size_t r = 0; r < g; r++) {
+        GDX_HIP(hipSetDevice(dev[r]));
+        loc[r].counts.release();
+        loc[r].status.release();
+        loc[r].hits.release();
+        (void)hipStreamDestroy(loc[r].stream);
+    }
+    out->d_counts = m.g_counts.get();
+    out->d_hit_offsets = m.g_offsets.get();
+    out->d_hits = m.g_hits.get();
+    out->d_status = m.g_status.get();
+    out->nq = nq;
+    out->total_hits = total;
+    out->device_id = dev[root];
+    out->used_rccl = use_rccl ? 1 : 0;
 }
 
 }  // namespace gdx

@@ -436,6 +436,30 @@ int gdx_multi_count_many(const gdx_multi_t *m, const uint8_t *qbuf, const uint64
                          uint64_t *out_counts, uint8_t *out_status);
 int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                                        uint64_t *out_start, uint64_t *out_end, uint8_t *out_status);
+/* Device-resident form: the queries of shard r already sit in the HBM of replica r's device; every
+ * replica runs search -> scan -> locate on its shard, then the per-query counts (u32) and the hits (gdx_hit32_t) of all
+ * shards are gathered into buffers on the ROOT replica's device by RCCL point-to-point transfers over xGMI (ncclSend /
+ * ncclRecv of every shard inside one group: one exchange step, no collective, no reduction), and the root scans the
+ * counts into global hit offsets.  Order preserving: shard r's queries and hits follow shard r - 1's, so the output is
+ * the one-GPU output of the concatenated batch.  The result buffers belong to the handle and stay valid until the next
+ * gather call on it or gdx_multi_free.  Replicas must sit on distinct devices (RCCL, loaded on first use), or all on
+ * one device (plain device copies; what a single-GPU box can test). */
+typedef struct {
+    const void *d_qbuf; /* query bytes, on the device of replica r            */
+    const void *d_qoff; /* u64[nq + 1] offsets into d_qbuf, on the same device */
+    uint64_t nq;
+} gdx_device_shard_t;
+typedef struct {
+    void *d_counts;      /* u32[nq]         occurrences of every query, shard after shard */
+    void *d_hit_offsets; /* u64[nq + 1]     hits of query i at [off[i], off[i + 1])       */
+    void *d_hits;        /* gdx_hit32_t[total_hits], suffix-array order within a query    */
+    void *d_status;      /* u8[nq]                                                        */
+    uint64_t nq, total_hits;
+    int32_t device_id;   /* the root replica's device, where all of the above live        */
+    int32_t used_rccl;   /* 1: the transfers went through ncclSend / ncclRecv             */
+} gdx_gathered_t;
+int gdx_multi_locate_many_gather_dev(gdx_multi_t *m, const gdx_device_shard_t *shards, int n_shards, int root,
+                                     gdx_gathered_t *out);
 int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                                 uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total,
                                 uint8_t *out_status);

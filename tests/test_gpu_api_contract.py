@@ -341,3 +341,78 @@ def test_query_options_struct_may_be_shorter_than_the_library_knows():
     back = _lib.QueryOptions()
     _lib.check(lib.gdx_index_get_query_options(g._h, C.byref(back)))
     assert back.search_fast == 0 and back.max_hits_per_query == 0
+
+
+def _gather_dev_case(n_replicas, devices):
+    """gdx_multi_locate_many_gather_dev: every replica locates the shard that sits in its own HBM, counts and hits are
+    gathered on the root's device; the result must be the one-handle output of the concatenated batch."""
+    import torch
+
+    from genedex_amd import FmIndexConfig, _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(314)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, 30000, p=[.2475, .2475, .2475, .2475, .01])) for _ in range(3)]
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=0, width=32)
+    tbuf, toff = pack_queries(texts)
+    tab = np.ascontiguousarray(a.io_to_dense_table, dtype=np.uint8)
+    devs = (C.c_int * n_replicas)(*devices)
+    m = C.c_void_p()
+    _lib.check(lib.gdx_multi_build(tbuf.ctypes.data_as(_lib.u8p), toff.ctypes.data_as(_lib.u64p), len(texts),
+                                   tab.ctypes.data_as(_lib.u8p), 6, 4, 4, 0, 32, devs, n_replicas, None, C.byref(m)))
+    try:
+        qs = [texts[int(rng.integers(0, 3))][s:s + int(rng.integers(1, 70))] for s in rng.integers(0, 29000, 5000)]
+        qs = [q for q in qs if b"N" not in q] + [b"", b"ACGT", b"A"]
+        co, ct, cp = c.locate_many(qs)
+        cs, ce = c.cursors_for_many(*pack_queries(qs))
+        bounds = [len(qs) * r // n_replicas for r in range(n_replicas + 1)]
+        shards = (_lib.DeviceShard * n_replicas)()
+        keep = []
+        for r in range(n_replicas):
+            qb, qo = pack_queries(qs[bounds[r]:bounds[r + 1]])
+            pad = np.zeros((qb.size + 16) // 8 * 8 + 8, dtype=np.uint8)
+            pad[:qb.size] = qb
+            d = torch.device("cuda", devices[r])
+            tq, to = torch.from_numpy(pad).to(d), torch.from_numpy(qo.astype(np.int64)).to(d)
+            keep += [tq, to]
+            shards[r] = _lib.DeviceShard(tq.data_ptr(), to.data_ptr(), qo.size - 1)
+        for root in sorted({0, n_replicas - 1}):
+            out = _lib.Gathered()
+            _lib.check(lib.gdx_multi_locate_many_gather_dev(m, shards, n_replicas, root, C.byref(out)))
+            assert out.nq == len(qs) and out.total_hits == int(co[-1]) and out.device_id == devices[root]
+            assert out.used_rccl == (1 if len(set(devices)) > 1 else 0)
+            d = torch.device("cuda", out.device_id)
+
+            class _Dev:  # a library-owned device buffer as a zero-copy torch tensor (__cuda_array_interface__)
+                def __init__(self, ptr, shape, typestr):
+                    self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": shape, "typestr": typestr, "version": 2}
+
+            with torch.cuda.device(d):
+                torch.cuda.synchronize()
+                counts = torch.as_tensor(_Dev(out.d_counts, (out.nq,), "<i4"), device=d).clone()
+                offs = torch.as_tensor(_Dev(out.d_hit_offsets, (out.nq + 1,), "<i8"), device=d).clone()
+                hits = torch.as_tensor(_Dev(out.d_hits, (max(out.total_hits, 1), 2), "<i4"), device=d).clone()
+                stat = torch.as_tensor(_Dev(out.d_status, (out.nq,), "|u1"), device=d).clone()
+                torch.cuda.synchronize()
+            assert (counts.cpu().numpy().astype(np.uint64) & 0xFFFFFFFF).tolist() == (ce - cs).tolist()
+            assert offs.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+            h = hits[: out.total_hits].cpu().numpy().astype(np.uint32)
+            assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
+            assert not stat.any().item()
+    finally:
+        lib.gdx_multi_free(m)
+
+
+def test_multi_gather_dev_three_replicas_on_one_device():
+    _gather_dev_case(3, [0, 0, 0])
+
+
+def test_multi_gather_dev_over_rccl():
+    """The same with one replica per GPU: the transfers are ncclSend / ncclRecv over xGMI.  Needs two GPUs."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL point-to-point between devices)")
+    n = min(torch.cuda.device_count(), 4)
+    _gather_dev_case(n, list(range(n)))
