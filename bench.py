@@ -793,14 +793,19 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
 
     eng, index = owned["eng"], owned["index"]
     res = []
-    ladder = [("top14_jump32", dict(top_table_depth=14)),
+    text = dict(jump_entry_bytes=0, pair_lines=False, text_units=True)  # the rest of a read against the text at SA[row]
+    ladder = [("top16_sa_text", dict(top_table_depth=16, full_suffix_array=True, **text)),
+              ("top15_sa_text", dict(top_table_depth=15, full_suffix_array=True, **text)),
+              ("top14_text", dict(top_table_depth=14, **text)),
+              ("top13_text", dict(top_table_depth=13, **text)),
+              ("top14_jump32", dict(top_table_depth=14)),
               ("top16_jump16", dict(jump_entry_bytes=16)),
               ("top14_jump16", dict(top_table_depth=14, jump_entry_bytes=16)),
               ("top12_jump8", dict(top_table_depth=12, jump_entry_bytes=8)),
               ("pair_lines_only", dict(top_table_depth=0, jump_entry_bytes=0)),
               ("reference_arrays_only", dict(top_table_depth=0, jump_entry_bytes=0, pair_lines=False))]
     if args.no_extras:
-        ladder = ladder[-2:]
+        ladder = [r for r in ladder if r[0] in ("top16_sa_text", "top14_text", "pair_lines_only", "reference_arrays_only")]
     for name, opts in ladder:
         t0 = time.time()
         index.rebuild_aux(**opts)

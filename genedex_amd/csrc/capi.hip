@@ -175,6 +175,10 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
     b.jump_bytes = o->jump_entry_bytes;
     b.top_depth = o->top_table_depth;
     b.aux_budget_bytes = o->aux_budget_bytes;
+    if (o->full_suffix_array < -1 || o->full_suffix_array > 1 || o->text_units < -1 || o->text_units > 1)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "full_suffix_array / text_units must be -1, 0 or 1");
+    b.full_sa = o->full_suffix_array;
+    b.text_units = o->text_units;
     return b;
 }
 
@@ -235,6 +239,8 @@ void gdx_build_options_init(gdx_build_options_t *opts)
     opts->jump_entry_bytes = -1;
     opts->top_table_depth = -1;
     opts->aux_budget_bytes = 0;
+    opts->full_suffix_array = -1;
+    opts->text_units = -1;
 }
 
 void gdx_query_options_init(gdx_query_options_t *opts)
@@ -1070,7 +1076,7 @@ int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
         out[0] = v.pair_lines != nullptr;
         out[1] = v.jump ? v.jump_bytes : 0u;
         out[2] = v.top ? v.top_depth : 0u;
-        out[3] = 0;
+        out[3] = (v.sa_full ? 1u : 0u) | (v.text_units ? 2u : 0u);
         return (int)GDX_OK;
     });
 }

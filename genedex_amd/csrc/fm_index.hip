@@ -393,6 +393,67 @@ __global__ __launch_bounds__(kBlock) void derive_jump_levels_kernel(uint64_t n, 
     }
 }
 
+// SA[row] of one row, recovered exactly as locate would (walk to a sampled row or to a text start); the 32-byte jump
+// entries hold it already when they exist
+__device__ __forceinline__ uint32_t sa_of_row(const IndexView &ix, uint32_t row)
+{
+    if (ix.jump != nullptr && ix.jump_bytes == 32) return static_cast<const uint32_t *>(ix.jump)[static_cast<uint64_t>(row) * 8u + 6u];
+    uint32_t steps = 0;
+    for (;;) {
+        uint32_t slot;
+        if (sampled_slot(ix, row, slot)) return ix.sa_samples[slot] + steps;
+        uint32_t r;
+        const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
+        if (c == 0) return ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, row)] + steps;
+        row = ix.count[c] + r;
+        steps++;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_sa_full_kernel(IndexView ix, uint32_t *__restrict__ sa)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride)
+        sa[p] = sa_of_row(ix, static_cast<uint32_t>(p));
+}
+
+// Text units (layout.hpp): all mask bits set and codes zero to begin with -- the pad units in front, the tail behind the
+// text -- then every row r puts its BWT symbol where it stands in the text: text[SA[r] - 1] = bwt[r] (bwt.rs:93-116 read
+// backwards; the row with SA = 0 holds the last sentinel).  Works for built, imported and loaded indexes alike.
+__global__ __launch_bounds__(kBlock) void init_text_units_kernel(u32x4 *__restrict__ units, uint64_t n_units, uint64_t n)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t u = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; u < n_units; u += stride) {
+        // positions of the text proper start clean (mask 0): the scatter sets the mask of every non-A C G T symbol
+        uint32_t mask = 0xffffffffu;
+        if (u >= kTextPadUnits) {
+            const uint64_t first = (u - kTextPadUnits) * 32u;
+            if (first + 32u <= n) mask = 0u;
+            else if (first < n) mask = 0xffffffffu << static_cast<uint32_t>(n - first);
+        }
+        u32x4 v = {0u, 0u, mask, 0u};
+        units[u] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_text_units_kernel(IndexView ix, const uint32_t *__restrict__ sa,
+                                                                    uint32_t *__restrict__ words)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < ix.n; r += stride) {
+        const uint32_t c = LineTable::symbol_at(ix, static_cast<uint32_t>(r));
+        const uint32_t p = sa[r];
+        const uint64_t pos = p == 0u ? static_cast<uint64_t>(ix.n) - 1u : static_cast<uint64_t>(p) - 1u;
+        uint32_t *unit = words + ((pos >> 5) + kTextPadUnits) * 4u;
+        const uint32_t i = static_cast<uint32_t>(pos & 31u);
+        if (c - 1u < 4u) {
+            if (c != 1u) atomicOr(unit + (i >> 4), (c - 1u) << (2u * (i & 15u)));
+        } else {
+            atomicOr(unit + 2, 1u << i);
+        }
+    }
+}
+
 // word 6 of every 32-byte entry: SA[row], recovered exactly as locate would (walk to a sampled row or to a text start)
 __global__ __launch_bounds__(kBlock) void fill_jump_sa_kernel(IndexView ix, uint32_t *__restrict__ jump)
 {
@@ -734,7 +795,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return top_.bytes() + jump_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return top_.bytes() + jump_.bytes() + sa_full_.bytes() + text_units_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -861,9 +922,13 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     view_.jump_bytes = 0;
     view_.top = nullptr;
     view_.top_depth = 0;
+    view_.sa_full = nullptr;
+    view_.text_units = nullptr;
     pair_lines_.release();
     jump_.release();
     top_.release();
+    sa_full_.release();
+    text_units_.release();
     // environment variables are debug overrides of fields left at their default
     auto env_int = [](const char *name, int fallback) {
         const char *e = getenv(name);
@@ -871,8 +936,10 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     };
     int want_pairs = bo.pair_lines;
     if (want_pairs < 0) want_pairs = env_int("GDX_NO_PAIR_LINES", 0) == 1 ? 0 : 1;
-    if (view_.layout == 0 && n_ > 0 && want_pairs) {
+    const bool want_text = bo.text_units == 1, want_sa_full = bo.full_sa == 1;
+    if (view_.layout == 0 && n_ > 0 && (want_pairs || want_text || want_sa_full)) {
         double t0 = now_seconds();
+        if (want_pairs) {
         const uint64_t n_lines = div_ceil(len, 128);
         const uint64_t padded = n_lines * 128;
         DeviceBuffer<uint8_t> d_bwt0(padded);
@@ -910,6 +977,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         GDX_HIP(hipStreamSynchronize(stream));
         GDX_HIP(hipGetLastError());
         view_.pair_lines = pair_lines_.get();
+        }  // pair lines
         // jump table: 32-byte entries by default (BuildOptions::jump_bytes; GDX_JUMP_BYTES / GDX_NO_JUMP_TABLE
         // override the default only)
         uint32_t jump_bytes = 32;
@@ -921,6 +989,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         }
         if (jump_bytes != 0 && jump_bytes != 8 && jump_bytes != 16 && jump_bytes != 32)
             fail(GDX_ERR_INVALID_ARGUMENT, "jump entry bytes must be 0, 8, 16 or 32");
+        if (!want_pairs) jump_bytes = 0;  // the jump table belongs to the pair-line kernels
         // top table depth wanted: even (the pair steps that follow consume two symbols each) and as deep as leaves
         // about one row per entry (4^D <= 2 n), so that most reads can jump right after it; at most 16 (34 GB).
         // Measured (search_variants.md section 25): 3.1 G symbols: 16 beats 14 by 23 %; 2^28: 14 beats 12; 2^24: 12
@@ -931,6 +1000,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         else top_depth = static_cast<uint32_t>(env_int("GDX_TOP_DEPTH", static_cast<int>(top_depth)));
         if (top_depth > 16u) top_depth = 16u;
         if (view_.sigma < 5) top_depth = 0;
+        if (!want_pairs && !want_text) top_depth = 0;  // nothing would read it
         aux_report_.wanted_jump_bytes = jump_bytes;
         aux_report_.wanted_top_depth = top_depth;
         // Both tables are optional and have to fit into a budget: BuildOptions::aux_budget_bytes, by default what
@@ -953,8 +1023,10 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
                 }
             }
             aux_report_.budget_bytes = static_cast<uint64_t>(budget);
+            // (the full suffix array and the text units are asked for explicitly: they count, but do not shrink)
+            const double fixed = (want_sa_full ? 4.0 : 0.0) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_);
             auto need = [&] {
-                return static_cast<double>(jump_bytes) * static_cast<double>(n_) +
+                return fixed + static_cast<double>(jump_bytes) * static_cast<double>(n_) +
                        (top_depth ? 8.0 * static_cast<double>(1ull << (2u * top_depth)) : 0.0);
             };
             while (need() > budget) {
@@ -1001,7 +1073,32 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             GDX_HIP(hipStreamSynchronize(stream));
             aux_report_.wide_fraction = n_ ? static_cast<double>(wide) / static_cast<double>(n_) : 0.0;
         }
-        aux_report_.aux_bytes = jump_.bytes() + top_.bytes();
+        // full suffix array: SA[row] by the locate walk (or out of the 32-byte jump entries, which hold it already)
+        if (want_sa_full || want_text) {
+            DeviceBuffer<uint32_t> sa_tmp;
+            uint32_t *d_sa = nullptr;
+            if (want_sa_full) {
+                sa_full_.alloc(n_);
+                d_sa = sa_full_.get();
+            } else {
+                sa_tmp.alloc(n_);
+                d_sa = sa_tmp.get();
+            }
+            hipLaunchKernelGGL(fill_sa_full_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_sa);
+            if (want_text) {
+                const uint64_t n_units = div_ceil(n_, 32) + kTextPadUnits + 2;
+                text_units_.alloc(n_units);
+                hipLaunchKernelGGL(init_text_units_kernel, dim3(grid_for_items(n_units)), dim3(kBlock), 0, stream,
+                                   text_units_.get(), n_units, n_);
+                hipLaunchKernelGGL(scatter_text_units_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_sa,
+                                   reinterpret_cast<uint32_t *>(text_units_.get()));
+            }
+            GDX_HIP(hipStreamSynchronize(stream));
+            GDX_HIP(hipGetLastError());
+            if (want_sa_full) view_.sa_full = sa_full_.get();
+            if (want_text) view_.text_units = text_units_.get();
+        }
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }
@@ -1022,7 +1119,11 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         view_.jump_bytes = 0;
         view_.top = nullptr;
         view_.top_depth = 0;
+        view_.sa_full = nullptr;
+        view_.text_units = nullptr;
         aux_report_ = AuxReport{};
+        sa_full_.release();
+        text_units_.release();
         pair_lines_.release();
         jump_.release();
         top_.release();

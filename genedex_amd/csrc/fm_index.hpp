@@ -28,6 +28,8 @@ struct BuildOptions {
     int jump_bytes = -1;            // -1 default (32), 0 none, 8, 16, 32
     int top_depth = -1;             // -1 default (largest even D <= 16 with 4^D <= 2n), 0 none, 1..16
     uint64_t aux_budget_bytes = 0;  // cap for jump + top table; 0 = min(free HBM - reserve, half of the HBM)
+    int full_sa = -1;               // 1: SA[row] of every row as its own array
+    int text_units = -1;            // 1: the text itself, 16 bytes per 32 symbols (layout.hpp)
 };
 
 // What the aux build decided (gdx_index_aux_t)
@@ -143,6 +145,8 @@ private:
     DeviceBuffer<u32x4> pair_lines_;
     DeviceBuffer<uint32_t> jump_;
     DeviceBuffer<uint2> top_;
+    DeviceBuffer<uint32_t> sa_full_;
+    DeviceBuffer<u32x4> text_units_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;
     DeviceBuffer<uint32_t> count_;

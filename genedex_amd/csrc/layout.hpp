@@ -61,6 +61,15 @@ struct IndexView {
     const uint2 *top;             // [4^top_depth], index = 2-bit codes (first consumed symbol highest); the entry of
                                   // an absent D-mer is its frozen empty interval; null when absent
     uint32_t top_depth;           // 1..16
+    // --- full suffix array and the text itself (optional; the low-memory alternative to the jump table) ----------------
+    const uint32_t *sa_full;      // [n] SA[row], null when absent (32-byte jump entries carry the same value in word 6)
+    // Text units: the concatenated text (sentinels included), 32 symbols per 16-byte unit {codes lo, codes hi, mask, 0}:
+    // 2-bit code (dense - 1) of symbol 32 u + i in bits 2 i + 1 : 2 i of the 64-bit code string, mask bit i set when that
+    // symbol is not one of the dense codes 1..4 (sentinel, N, ...; its code is 0).  kTextPadUnits zero units (mask bits
+    // set) precede unit 0, so that a window that starts before the text reads as "no match".  A search that is down to a
+    // few rows compares the rest of the query with the text at SA[row] -- 32 symbols per 64-bit compare, one or two
+    // fetches per row whatever the length -- instead of walking LF steps (search_verify_kernel4).
+    const u32x4 *text_units;      // null when absent
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -247,6 +256,7 @@ struct QuadLineTable {
 //   y = b0p1 | b0p2 << 8 | (16 bits of single[1 + j/2], low half if j is even) << 16
 //   z = pair[2j], w = pair[2j+1]                          (pair index = (c2-1)*4 + (c1-1))
 
+constexpr uint32_t kTextPadUnits = 2;   // zero units in front of the text units (IndexView::text_units)
 constexpr uint32_t kPairLineShift = 6;  // 64 positions per pair line
 constexpr uint32_t kJumpSymbols = 8;    // LF steps folded into one jump-table entry
 

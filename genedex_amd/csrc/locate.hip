@@ -171,6 +171,7 @@ struct LocateView {
     const uint64_t *g_planes;
     const uint16_t *g_block_off;
     const void *jump;
+    const uint32_t *sa_full;  // SA[row] of every row, or null (then kEntrySA reads it out of the 32-byte jump entries)
     const uint32_t *count, *sa_samples, *border_keys, *border_vals, *sentinels;
     uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
     int32_t sigma, nbits;
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             uint32_t slot;
             if (kEntrySA) {
-                const uint32_t sa = static_cast<const uint32_t *>(ix.jump)[static_cast<uint64_t>(row) * 8u + 6u];
+                const uint32_t sa = lv.sa_full != nullptr ? lv.sa_full[row]
+                                                          : static_cast<const uint32_t *>(ix.jump)[static_cast<uint64_t>(row) * 8u + 6u];
                 store_hit<kWide>(ix, sa - back, hits_out, h, sentinels);
             } else if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
                 store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
@@ -628,8 +630,8 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                     \
     do {                                                                                                                  \
-        if (JW && entry_sa)                                                                                               \
-            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, JW>), dim3(qgrid), dim3(kBlock), 0, stream, lv,      \
+        if (entry_sa)                                                                                                     \
+            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
                                d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats);        \
         else                                                                                                              \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
@@ -637,12 +639,14 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
-        const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.count, ix.sa_samples,
+        const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
                             ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
                             ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
-        const bool entry_sa = jump_walk && ix.jump_bytes == 32;  // SA[row] inside the entries: no walk at all
+        // SA[row] inside the entries, or as an array of its own: no walk at all
+        const bool entry_sa = (jump_walk && ix.jump_bytes == 32) ||
+                              (ix.layout == 0 && ix.sa_full != nullptr && !reference_walk && qo.locate_jump_walk != 0);
         if (ix.layout == 0) {
             if (wide && jump_walk) GDX_LOCATE_Q(LineTable, true, true);
             else if (wide) GDX_LOCATE_Q(LineTable, true, false);

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
     const bool writer = (threadIdx.x % kGroup) == 0;
-    const uint32_t *active = kResume ? ca.active_in : nullptr;
-    if (kResume && ca.n_active_in != nullptr) nq = *ca.n_active_in;
+    const uint32_t *active = ca.active_in;  // cursor lists, or the queries another kernel left over
+    if (ca.n_active_in != nullptr) nq = *ca.n_active_in;
     uint32_t lf_steps = 0;  // only reported through step_stats (bench accounting, null in normal calls)
     for (uint64_t at = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; at < nq;
          at += stride) {
@@ -1800,6 +1800,220 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     }
 }
 
+// ---- count / locate searches by comparing with the text (the low-memory alternative to the jump table) ---------------
+// On an index with text units (IndexView::text_units) a search that is down to a few rows does not walk the rest of the
+// query through LF steps: every lane of the group takes one row, fetches SA[row] -- from the full suffix array, from the
+// 32-byte jump entry, or by the locate walk to a sampled row -- and compares the query's remaining symbols with the text
+// in front of that position, 32 symbols per 64-bit compare.  The rows that match are exactly the rows that survive the
+// remaining LF steps, LF keeps their order, and the hit of a surviving row is SA[row] - symbols left: one row becomes a
+// RESOLVED record, several a masked one (kernels.hpp), precisely what search_fast_kernel4 writes.  Requests per read:
+// top entry + SA + one text line per row, whatever the read length -- against one jump entry per 32 symbols, at a
+// fraction of the memory (4 bits per symbol instead of 32 bytes per row).  Intervals wider than `max_rows` are first
+// narrowed by LF steps on the rank lines (no pair lines needed).  What it cannot finish -- a symbol outside A C G T,
+// a query shorter than the top table is deep -- is listed for the general kernel.
+struct VerifyView {
+    const uint2 *top;
+    const u32x4 *text_units;
+    const uint32_t *sa_full;
+    const void *jump;  // 32-byte entries (SA in word 6) or null
+    const u32x4 *lines;
+    const uint32_t *sb_offsets, *count, *sa_samples, *border_keys, *border_vals;
+    const uint8_t *io_to_dense;
+    uint32_t top_depth, n, n_texts, sa_inv, sa_rot, sa_limit, max_rows;
+    uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+};
+
+template <int kXlate>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_verify_kernel4(
+    VerifyView vv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
+    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+{
+    constexpr int kGroup = 4;
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_count[8];
+    __shared__ uint32_t s_left[kMaxRange];
+    __shared__ uint32_t s_nleft, s_left_base;
+    if (kXlate == 0)
+        for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = vv.io_to_dense[i];
+    if (threadIdx.x < 8) s_count[threadIdx.x] = threadIdx.x < 6 ? vv.count[threadIdx.x] : 0u;
+    if (threadIdx.x == 0) s_nleft = 0;
+    __syncthreads();
+    IndexView ix{};  // what QuadLineTable / LineTable / sampled_slot read
+    ix.lines = vv.lines;
+    ix.sb_offsets = vv.sb_offsets;
+    ix.sa_inv = vv.sa_inv;
+    ix.sa_rot = vv.sa_rot;
+    ix.sa_limit = vv.sa_limit;
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint32_t sub = threadIdx.x & (kGroup - 1u);
+    const uint32_t depth = vv.top_depth;
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        const uint64_t base = rg * range;
+        const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+        for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
+            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const uint64_t begin = qbeg[q];
+            const uint64_t len = qend[q] - begin;
+            bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
+            uint32_t lo = 0, hi = 0, rem = 0;
+            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
+            FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
+            uint32_t shift = 0, part = 0;  // levels / symbols of level `shift` of the window already used up
+            if (!bail) {
+                rem = static_cast<uint32_t>(len);
+                w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
+                const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
+                if ((w.valid8 & need) != need) {
+                    bail = true;
+                } else {
+                    const uint2 e = vv.top[__builtin_amdgcn_alignbit(w.l0, w.l0, 16) >> (32u - 2u * depth)];
+                    lo = e.x;
+                    hi = e.y;
+                    rem -= depth;
+                    shift = depth >> 3;
+                    part = depth & 7u;
+                }
+            }
+            // narrow with LF steps on the rank lines while the interval is wider than the rows a verify round takes
+            while (!bail && rem > 0u && hi - lo > vv.max_rows) {
+                if (shift > 6u) {
+                    w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
+                    shift = 0;
+                    part = 0;
+                }
+                const uint32_t v8 = w.valid8 >> shift;
+                if ((v8 & (part < w.s0 ? 1u : 2u)) == 0u) {  // the word this symbol comes from is not clean
+                    bail = true;
+                    break;
+                }
+                const uint32_t e = sel4(shift >> 1, w.l0, w.l1, w.l2, w.l3);
+                const uint32_t lv = (shift & 1u) ? e >> 16 : e & 0xffffu;
+                const uint32_t c = ((lv >> (14u - 2u * part)) & 3u) + 1u;
+                uint32_t rlo, rhi;
+                QuadLineTable::rank2(ix, c, lo, hi, rlo, rhi);
+                lo = s_count[c] + rlo;  // lib.rs:273-275
+                hi = s_count[c] + rhi;
+                rem--;
+                part++;
+                shift += part >> 3;
+                part &= 7u;
+            }
+            const uint32_t rows = hi - lo;
+            uint32_t alive = 0, pos = 0;  // alive: bit j = row lo + j matches; pos: SA of this lane's row
+            if (!bail && rem > 0u && rows != 0u) {
+                const bool real = sub < rows;
+                const uint32_t row = real ? lo + sub : lo;
+                // SA[row]: the full suffix array, the row's jump entry, or the locate walk (sampled_suffix_array.rs:110-138)
+                if (vv.sa_full != nullptr) {
+                    pos = vv.sa_full[row];
+                } else if (vv.jump != nullptr) {
+                    pos = static_cast<const uint32_t *>(vv.jump)[static_cast<uint64_t>(row) * 8u + 6u];
+                } else {
+                    uint32_t r_ = row, steps = 0;
+                    for (;;) {
+                        uint32_t slot_;
+                        if (sampled_slot(ix, r_, slot_)) {
+                            pos = vv.sa_samples[slot_] + steps;
+                            break;
+                        }
+                        uint32_t rk;
+                        const uint32_t c = LineTable::symbol_and_rank(ix, r_, rk);
+                        if (c == 0) {
+                            pos = vv.border_vals[lower_bound_u32(vv.border_keys, vv.n_texts, r_)] + steps;
+                            break;
+                        }
+                        r_ = vv.count[c] + rk;
+                        steps++;
+                    }
+                }
+                bool ok = real && pos >= rem;  // the occurrence would start at pos - rem
+                // compare the query's first `rem` symbols with the text in front of pos, 32 symbols per pass from the right
+                uint32_t rem_v = rem;
+                bool first = part == 0u && shift <= 3u;  // the window still serves the first pass
+                while (rem_v > 0u) {
+                    if (!first) {
+                        w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem_v, sub);
+                        shift = 0;
+                    }
+                    first = false;
+                    const uint32_t n_v = rem_v < 32u ? rem_v : 32u;
+                    // validity of the query words these symbols come from (group-uniform)
+                    const uint32_t v8 = w.valid8 >> shift;
+                    const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));
+                    const uint32_t n_full = n_v >> 3, n_tail = n_v & 7u;
+                    bool clean = (vl & ((1u << n_full) - 1u)) == ((1u << n_full) - 1u);
+                    if (n_tail != 0u) clean = clean && ((v8 >> n_full) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_full + 1u)) & 1u) != 0u);
+                    if (!clean) {
+                        bail = true;
+                        break;
+                    }
+                    uint32_t a0, a1;  // levels shift, shift + 1 | shift + 2, shift + 3 of the window
+                    if (shift == 0u) {
+                        a0 = w.l0;
+                        a1 = w.l1;
+                    } else if (shift == 1u) {
+                        a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
+                        a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                    } else if (shift == 2u) {
+                        a0 = w.l1;
+                        a1 = w.l2;
+                    } else {
+                        a0 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                        a1 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                    }
+                    // the 32 symbols [rem_v - 32, rem_v) in text order: level shift + 3 lowest, level shift highest
+                    const uint64_t qcode = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a0, a0, 16)) << 32) |
+                                           static_cast<uint64_t>(__builtin_amdgcn_alignbit(a1, a1, 16));
+                    const uint64_t s0 = static_cast<uint64_t>(pos) - rem + rem_v + 32u * kTextPadUnits - 32u;  // (ok: pos >= rem)
+                    const uint32_t b = static_cast<uint32_t>(s0 & 31u);
+                    const u32x4 *tu = vv.text_units + (s0 >> 5);
+                    const u32x4 u0 = ok ? tu[0] : u32x4{0u, 0u, 0u, 0u};
+                    const u32x4 u1 = (ok && b != 0u) ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                    const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
+                    const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
+                    const uint64_t tcode = b ? (c0 >> (2u * b)) | (c1 << (64u - 2u * b)) : c0;
+                    const uint32_t tmask = b ? (u0.z >> b) | (u1.z << (32u - b)) : u0.z;
+                    const uint64_t vm64 = n_v == 32u ? ~0ull : ~0ull << (2u * (32u - n_v));
+                    const uint32_t vm32 = n_v == 32u ? ~0u : ~0u << (32u - n_v);
+                    ok = ok && ((qcode ^ tcode) & vm64) == 0ull && (tmask & vm32) == 0u;
+                    rem_v -= n_v;
+                }
+                alive = (ok && !bail) ? 1u << sub : 0u;
+                alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0xB1, 0xF, 0xF, true));
+                alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0x4E, 0xF, 0xF, true));
+            }
+            if (writer) {
+                if (bail) {
+                    s_left[atomicAdd(&s_nleft, 1u)] = q;
+                } else {
+                    uint4 rec;
+                    if (rem == 0u || rows == 0u) {
+                        rec = make_uint4(lo, hi, 0xffffffffu, 0u);  // the interval itself (count = rows)
+                    } else if (rows == 1u) {
+                        // (lane 0 holds row lo: its SA value is this record's position)
+                        rec = alive ? make_uint4(lo, lo + 1u, pos - rem, kRecResolved) : make_uint4(lo, lo, 0xffffffffu, 0u);
+                    } else {
+                        rec = make_uint4(lo, lo + static_cast<uint32_t>(__popc(alive)), alive, (rem & 0x1fffffu) | kRecMasked);
+                    }
+                    if (out_rec) out_rec[q] = rec;
+                    if (out_count) out_count[q] = rec.y - rec.x;
+                    if (out_status) out_status[q] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_left = s_nleft;
+        if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nleft = 0;
+    }
+}
+
 // packed queries (2 bits per symbol): 4 lanes per query, plain loads
 template <int kJump, int kMode>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_pair_packed_kernel4(GDX_SEARCH_ARGS)
@@ -2038,7 +2252,44 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
         return static_cast<unsigned>(blocks);
     };
-    const CursorArgs ca = c.cursors;
+    CursorArgs ca = c.cursors;
+    bool leftover_list = false;  // ca.active_in is the (short) list another kernel of this call left over
+    // Count / locate searches on an index with text units and no jump table: top table, then the rest of the query against
+    // the text at SA[row] (search_verify_kernel4); what it cannot finish is listed for the general kernel of the index
+    // (pair lines or rank lines) below.  QueryOptions::search_fast = 0 switches it off like the other fast path.
+    {
+        static const int env_fast_v = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : -1; }();
+        const bool verify = c.mode == 1 && ix.layout == 0 && ix.text_units != nullptr && ix.top != nullptr && ix.top_depth >= 1u &&
+                            ix.jump == nullptr && ix.n_searchable >= 4 && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
+                            c.d_step_stats == nullptr && !c.packed && c.d_hint == nullptr && c.d_start == nullptr &&
+                            c.d_end == nullptr && ca.active_in == nullptr && nq < 0xffffffffull &&
+                            (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
+        if (verify) {
+            uint64_t per_block = (nq + 1791) / 1792;
+            per_block = (per_block + 63) / 64 * 64;
+            const uint32_t v_range = static_cast<uint32_t>(per_block > kMaxRange ? kMaxRange : per_block);
+            const uint64_t v_ranges = (nq + v_range - 1) / v_range;
+            const unsigned v_blocks = static_cast<unsigned>(v_ranges < (1u << 20) ? v_ranges : (1u << 20));
+            uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            // rows a verify round takes: four when SA[row] is one fetch away, one when it costs a locate walk
+            const uint32_t max_rows = ix.sa_full != nullptr ? 4u : 1u;
+            const VerifyView vv{ix.top, ix.text_units, ix.sa_full, nullptr, ix.lines, ix.sb_offsets, ix.count, ix.sa_samples,
+                                ix.border_keys, ix.border_vals, ix.io_to_dense, ix.top_depth, ix.n, ix.n_texts, ix.sa_inv,
+                                ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
+                                ix.perm_exp_hi, ix.perm_mask};
+            static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
+            if (ix.perm_ok && !env_no_perm_v)
+                hipLaunchKernelGGL((search_verify_kernel4<1>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left);
+            else
+                hipLaunchKernelGGL((search_verify_kernel4<0>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left);
+            ca.active_in = d_left + 4;
+            ca.n_active_in = d_left;
+            leftover_list = true;
+        }
+    }
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
         // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
         // QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
@@ -2115,6 +2366,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         CursorArgs ca_general = ca;
         unsigned g_blocks = blocks;  // grid and range size of the general kernel
         uint32_t g_range = range;
+        if (leftover_list) {  // short, and its length is only known on the device: small ranges, a capped grid
+            g_range = 256;
+            const uint64_t g_ranges = (nq + g_range - 1) / g_range;
+            g_blocks = static_cast<unsigned>(g_ranges < 8192 ? g_ranges : 8192);
+        }
         // Exact intervals and cursor extension on clean input (search_exact_kernel4): what it cannot finish is listed for
         // the general kernel below.  QueryOptions::search_exact / GDX_SEARCH_EXACT=0 switch it off.
         static const int env_exact = [] { const char *e = getenv("GDX_SEARCH_EXACT"); return e ? atoi(e) : -1; }();

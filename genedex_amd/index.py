@@ -41,7 +41,8 @@ def pack_queries(queries):
 _WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
 
 
-def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None):
+def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None,
+                  full_suffix_array=None, text_units=None):
     """gdx_build_options_t (include/gdx.h); None = the library's default for that field."""
     o = _lib.BuildOptions()
     _lib.load().gdx_build_options_init(C.byref(o))
@@ -53,6 +54,10 @@ def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, 
         o.top_table_depth = int(top_table_depth)
     if aux_budget_bytes is not None:
         o.aux_budget_bytes = int(aux_budget_bytes)
+    if full_suffix_array is not None:
+        o.full_suffix_array = int(bool(full_suffix_array))
+    if text_units is not None:
+        o.text_units = int(bool(text_units))
     return o
 
 
@@ -87,11 +92,11 @@ class FmIndexConfig:
         return self
 
     def acceleration_structures(self, pair_lines=None, jump_entry_bytes=None, top_table_depth=None,
-                                aux_budget_bytes=None) -> "FmIndexConfig":
+                                aux_budget_bytes=None, full_suffix_array=None, text_units=None) -> "FmIndexConfig":
         """gdx_build_options_t: which derived structures the index carries beside the reference's arrays
         (results are identical with any combination); None keeps the default."""
         self._build = dict(pair_lines=pair_lines, jump_entry_bytes=jump_entry_bytes, top_table_depth=top_table_depth,
-                           aux_budget_bytes=aux_budget_bytes)
+                           aux_budget_bytes=aux_budget_bytes, full_suffix_array=full_suffix_array, text_units=text_units)
         return self
 
     def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":

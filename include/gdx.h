@@ -134,6 +134,12 @@ typedef struct {
     uint64_t aux_budget_bytes; /* cap for jump + top table together; 0 = default: free device memory
                                   minus a reserve for query batches, at most half of the device memory.
                                   Tables that do not fit shrink (gdx_index_aux reports what was built). */
+    int32_t full_suffix_array; /* -1 / 0 default off, 1: SA[row] of EVERY row as its own array (4 bytes per symbol); with
+                                  32-byte jump entries the same values already sit inside the entries                 */
+    int32_t text_units;        /* -1 / 0 default off, 1: the concatenated text itself, 4 bits per symbol (2-bit code + a
+                                  "not A C G T" bit, 16 bytes per 32 symbols): once a search is down to a few rows, the rest
+                                  of the query is compared with the text at SA[row] in one fetch per row instead of LF
+                                  steps -- the low-memory alternative to the jump table (count / locate searches)      */
 } gdx_build_options_t;
 void gdx_build_options_init(gdx_build_options_t *opts);
 

@@ -87,7 +87,7 @@ int gdx_bench_lf_walk_dev(const gdx_index_t *ix, const void *d_rows, uint64_t m,
 
 /* Query acceleration structures the index carries beside the reference's arrays (DESIGN.md "HBM layout"):
  * out[0] = 1 if pair lines are present, out[1] = bytes per jump-table entry (0 = none, 8 or 16),
- * out[2] = depth of the top table (0 = none), out[3] = reserved (0). */
+ * out[2] = depth of the top table (0 = none), out[3] = bit 0: full suffix array present, bit 1: text units present. */
 int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4]);
 
 /* Drops the pair lines / jump table / top table of an index and builds them again with other options, without

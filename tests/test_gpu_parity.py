@@ -221,6 +221,12 @@ _VARIANTS = {
     "pair-fast-wide": (dict(search_kernel="pair", search_fast=2), {}),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
     "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
+    # text units instead of a jump table: count / locate searches compare the rest of the query with the text at SA[row]
+    "verify-sa": (dict(search_kernel="pair"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=7,
+                                                   full_suffix_array=True, text_units=True)),
+    "verify-walk": (dict(search_kernel="pair"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=5, text_units=True)),
+    "verify-pairs": (dict(search_kernel="pair"), dict(jump_entry_bytes=0, top_table_depth=8, full_suffix_array=True,
+                                                      text_units=True)),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 
