@@ -1168,6 +1168,9 @@ QueryOptions FmIndex::query_options() const
     // on more rows than a jump takes -- their intervals narrow fastest on pair lines (top 12 / 8-byte jumps at hg38
     // scale: 21.8 ms without, 26.5 ms with the fast path in front)
     // -- and with jumps over up to sixteen rows when reads from repeats are common (they cost every other read 3 %)
+    // (an index with text units and no jump table narrows wide intervals on the rank lines and then compares with the
+    // text: search_verify_kernel4 is worth running whatever the top table leaves)
+    if (q.search_fast < 0 && view_.text_units != nullptr && view_.jump == nullptr) q.search_fast = 1;
     if (q.search_fast < 0) q.search_fast = aux_report_.wide_fraction > 0.5 ? 0 : (aux_report_.wide_fraction > 0.02 ? 2 : 1);
     return q;
 }
