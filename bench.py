@@ -89,6 +89,8 @@ def parse_args():
     ap.add_argument("--jump-bytes", type=int, default=None, help="gdx_build_options_t.jump_entry_bytes")
     ap.add_argument("--top-depth", type=int, default=None, help="gdx_build_options_t.top_table_depth")
     ap.add_argument("--no-pair-lines", action="store_true", help="gdx_build_options_t.pair_lines = 0")
+    ap.add_argument("--full-sa", action="store_true", help="gdx_build_options_t.full_suffix_array = 1")
+    ap.add_argument("--text-units", action="store_true", help="gdx_build_options_t.text_units = 1")
     ap.add_argument("--lanes", type=int, default=None, help="gdx_query_options_t.search_lanes")
     ap.add_argument("--load-policy", type=int, default=None, help="gdx_query_options_t.load_policy")
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -137,10 +139,11 @@ def pmc_child(args):
     print(json.dumps({"pmc_child": True, "nq": nq, "hits": runner.total_hits}), flush=True)
 
 
-def run_live_pmc(args, reference_layout=False):
+def run_live_pmc(args, reference_layout=False, rung=None):
     """-> ({kernel short name: {counter: per-launch value}}, None) or (None, reason).  Runs before the parent touches
     the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process.
-    reference_layout: the same workload on an index without any acceleration structure (the ladder's last rung)."""
+    reference_layout: the same workload on an index without any acceleration structure (the ladder's last rung);
+    rung = "top16_sa_text": on the 53 GB rung (top table + full suffix array + text units, no jump table, no pair lines)."""
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
@@ -148,6 +151,9 @@ def run_live_pmc(args, reference_layout=False):
     jump_bytes, top_depth, no_pairs = args.jump_bytes, args.top_depth, args.no_pair_lines
     if reference_layout:
         jump_bytes, top_depth, no_pairs = 0, 0, True
+    if rung == "top16_sa_text":
+        jump_bytes, top_depth, no_pairs = 0, 16, True
+        child_args += ["--full-sa", "--text-units"]
     for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", jump_bytes),
                     ("--top-depth", top_depth), ("--lanes", args.lanes), ("--load-policy", args.load_policy)):
         if v is not None:
@@ -162,7 +168,8 @@ def run_live_pmc(args, reference_layout=False):
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|search_kernel", "--output-format", "csv", "-d", d, "--",
+               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
+               "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
@@ -248,7 +255,9 @@ def build_options_of(args, **override):
     from genedex_amd.index import build_options
 
     kw = dict(jump_entry_bytes=args.jump_bytes, top_table_depth=args.top_depth,
-              pair_lines=False if args.no_pair_lines else None)
+              pair_lines=False if args.no_pair_lines else None,
+              full_suffix_array=True if getattr(args, "full_sa", False) else None,
+              text_units=True if getattr(args, "text_units", False) else None)
     kw.update(override)
     return build_options(**kw)
 
@@ -422,7 +431,7 @@ def main():
 
     # PMC passes first: they are separate processes that each need the GPU's memory for their own index, and starting
     # them before this process initialises the GPU keeps every exec clear of a process that holds the device
-    pmc, pmc_note, pmc_ref = None, "live PMC passes run at N = 1 only", None
+    pmc, pmc_note, pmc_ref, pmc_text = None, "live PMC passes run at N = 1 only", None, None
     profiled = any(k in os.environ for k in ("ROCPROFILER_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
     if profiled:  # under rocprofv3 already (its preload initialised the GPU): no nested profiler children
@@ -433,6 +442,7 @@ def main():
             log(f"[bench] live PMC unavailable: {pmc_note}")
         elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
             pmc_ref, _ = run_live_pmc(args, reference_layout=True)
+            pmc_text, _ = run_live_pmc(args, rung="top16_sa_text")
 
     import numpy as np
     import torch  # before libgdx.so: both must share torch's HIP runtime
@@ -669,7 +679,7 @@ def main():
         owned = {"eng": eng, "index": index}  # handed over: the last rung frees the index before building another
         del eng, index
         result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
-                                          args, wl, pmc_ref)
+                                          args, wl, pmc_ref, pmc_text)
         for r in result["secondary"]:  # the like-for-like rung, in the keys the driver keeps
             rl = r.get("roofline_reference_layout")
             if rl:
@@ -783,7 +793,8 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
     return ms, runner.mean_ms(runner.ev_search), runner.mean_ms(runner.ev_locate), counts
 
 
-def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None):
+def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None,
+                pmc_text=None):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -796,8 +807,9 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
     text = dict(jump_entry_bytes=0, pair_lines=False, text_units=True)  # the rest of a read against the text at SA[row]
     ladder = [("top16_sa_text", dict(top_table_depth=16, full_suffix_array=True, **text)),
               ("top15_sa_text", dict(top_table_depth=15, full_suffix_array=True, **text)),
+              ("top14_sa_text", dict(top_table_depth=14, full_suffix_array=True, **text)),
               ("top14_text", dict(top_table_depth=14, **text)),
-              ("top13_text", dict(top_table_depth=13, **text)),
+              ("top12_text", dict(top_table_depth=12, **text)),
               ("top14_jump32", dict(top_table_depth=14)),
               ("top16_jump16", dict(jump_entry_bytes=16)),
               ("top14_jump16", dict(top_table_depth=14, jump_entry_bytes=16)),
@@ -817,6 +829,13 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         r = {"name": name, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s",
              "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
              "aux_rebuild_seconds": t_aux, "index_bytes": int(index.info.device_bytes)}
+        if name == "top16_sa_text":
+            t_txt = traffic_of(pmc_text, "search_verify_kernel|search_kernel")
+            if t_txt:  # measured HBM traffic of this rung's search (PMC child passes of this run on the same configuration)
+                r["roofline"] = {"bound": "hbm", "kernel": t_txt["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                 "traffic": t_txt["bytes"], "achieved": t_txt["bytes"] / (s_ms / 1e3) / 1e9,
+                                 "frac": t_txt["bytes"] / (s_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                 "dram_read_requests_per_query": t_txt.get("read_requests", 0) / nq, "avg_launch_ms": s_ms}
         if name == "reference_arrays_only":
             # like-for-like roofline: the reference's information content, its algorithmic bytes per LF step
             lf_steps, _, _ = eng.search_step_stats(queries)

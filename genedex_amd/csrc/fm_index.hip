@@ -410,11 +410,94 @@ __device__ __forceinline__ uint32_t sa_of_row(const IndexView &ix, uint32_t row)
     }
 }
 
-__global__ __launch_bounds__(kBlock) void fill_sa_full_kernel(IndexView ix, uint32_t *__restrict__ sa)
+__global__ __launch_bounds__(kBlock) void fill_sa_full_kernel(IndexView ix, uint32_t *__restrict__ sa, uint32_t stride_words,
+                                                              uint32_t offset)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride)
-        sa[p] = sa_of_row(ix, static_cast<uint32_t>(p));
+        sa[p * stride_words + offset] = sa_of_row(ix, static_cast<uint32_t>(p));
+}
+
+// SA[row] of EVERY row by pointer jumping instead of one walk per row: link[r] = {row after d LF steps, d}, or {SA[r], 0}
+// once known (sampled rows and rows whose BWT symbol is the sentinel know it from the start).  A round replaces
+// {x, d} by {link[x].row, d + link[x].d} -- or resolves r when x is resolved -- so a chain of length L is done after
+// log2(L) rounds.  The plain walk is quadratic on long runs of one symbol (an assembly gap of 30 M N: the rows of
+// N^j X lie a constant number of rows apart, and where that number is a multiple of the sampling rate a walk only ends
+// when the run does: 93 s for the genome-like text of the bench); this is ~25 rounds over the table whatever the text.
+// Updates race, harmlessly: every 8-byte value a round can read is a valid {row, distance} pair of its row.
+__global__ __launch_bounds__(kBlock) void sa_links_init_kernel(IndexView ix, unsigned long long *__restrict__ link)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
+        const uint32_t row = static_cast<uint32_t>(p);
+        uint32_t slot, r;
+        unsigned long long v;
+        if (sampled_slot(ix, row, slot)) {
+            v = ix.sa_samples[slot];
+        } else {
+            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
+            if (c == 0) v = ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, row)];
+            else v = static_cast<unsigned long long>(ix.count[c] + r) | (1ull << 32);
+        }
+        link[p] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sa_links_round_kernel(uint64_t n, unsigned long long *__restrict__ link,
+                                                                unsigned long long *__restrict__ n_open)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    unsigned long long open = 0;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride) {
+        const unsigned long long v = link[p];
+        const uint32_t d = static_cast<uint32_t>(v >> 32);
+        if (d == 0u) continue;
+        const unsigned long long m = __atomic_load_n(link + static_cast<uint32_t>(v), __ATOMIC_RELAXED);
+        const uint32_t md = static_cast<uint32_t>(m >> 32);
+        const unsigned long long nv = md == 0u ? static_cast<unsigned long long>(static_cast<uint32_t>(m) + d)
+                                               : (m & 0xffffffffull) | (static_cast<unsigned long long>(d + md) << 32);
+        __atomic_store_n(link + p, nv, __ATOMIC_RELAXED);
+        open += md != 0u ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) open += __shfl_xor(open, off);
+    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(n_open, open);
+}
+
+__global__ __launch_bounds__(kBlock) void sa_links_store_kernel(uint64_t n, const unsigned long long *__restrict__ link,
+                                                                uint32_t *__restrict__ sa, uint32_t stride_words, uint32_t offset)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < n; p += stride)
+        sa[p * stride_words + offset] = static_cast<uint32_t>(link[p]);
+}
+
+// out[row * stride_words + offset] = SA[row] for every row
+void compute_full_sa(const IndexView &ix, uint64_t n, uint32_t *d_out, uint32_t stride_words, uint32_t offset, hipStream_t stream)
+{
+    const unsigned grid = grid_for_items(n);
+    unsigned long long *d_link = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_link), n * sizeof(unsigned long long) + 8) != hipSuccess) {
+        (void)hipGetLastError();  // not enough room for the links: one walk per row
+        hipLaunchKernelGGL(fill_sa_full_kernel, dim3(grid), dim3(kBlock), 0, stream, ix, d_out, stride_words, offset);
+        return;
+    }
+    unsigned long long *d_open = d_link + n;
+    hipLaunchKernelGGL(sa_links_init_kernel, dim3(grid), dim3(kBlock), 0, stream, ix, d_link);
+    unsigned long long open = 1;
+    for (int round = 0; round < 64 && open != 0; round++) {
+        open = 0;
+        GDX_HIP(hipMemsetAsync(d_open, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(sa_links_round_kernel, dim3(grid), dim3(kBlock), 0, stream, n, d_link, d_open);
+        GDX_HIP(hipMemcpyAsync(&open, d_open, sizeof(open), hipMemcpyDeviceToHost, stream));
+        GDX_HIP(hipStreamSynchronize(stream));
+    }
+    if (open != 0) {
+        (void)hipFree(d_link);
+        fail(GDX_ERR_INVALID_ARGUMENT, "the suffix-array samples and the BWT are inconsistent (an LF chain never reaches a sample)");
+    }
+    hipLaunchKernelGGL(sa_links_store_kernel, dim3(grid), dim3(kBlock), 0, stream, n, d_link, d_out, stride_words, offset);
+    GDX_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d_link);
 }
 
 // Text units (layout.hpp): all mask bits set and codes zero to begin with -- the pad units in front, the tail behind the
@@ -451,31 +534,6 @@ __global__ __launch_bounds__(kBlock) void scatter_text_units_kernel(IndexView ix
         } else {
             atomicOr(unit + 2, 1u << i);
         }
-    }
-}
-
-// word 6 of every 32-byte entry: SA[row], recovered exactly as locate would (walk to a sampled row or to a text start)
-__global__ __launch_bounds__(kBlock) void fill_jump_sa_kernel(IndexView ix, uint32_t *__restrict__ jump)
-{
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; p < ix.n; p += stride) {
-        uint32_t row = static_cast<uint32_t>(p), steps = 0, sa;
-        for (;;) {
-            uint32_t slot;
-            if (sampled_slot(ix, row, slot)) {
-                sa = ix.sa_samples[slot] + steps;
-                break;
-            }
-            uint32_t r;
-            const uint32_t c = LineTable::symbol_and_rank(ix, row, r);
-            if (c == 0) {
-                sa = ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, row)] + steps;
-                break;
-            }
-            row = ix.count[c] + r;
-            steps++;
-        }
-        jump[p * 8 + 6] = sa;
     }
 }
 
@@ -1048,8 +1106,10 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             for (uint32_t pass = 2; jump_bytes >= 16 && pass <= (jump_bytes == 32 ? 4u : 3u); pass++)
                 hipLaunchKernelGGL(derive_jump_levels_kernel, dim3(grid), dim3(kBlock), 0, stream, n_, jump_.get(), words,
                                    pass);
-            if (jump_bytes == 32)
-                hipLaunchKernelGGL(fill_jump_sa_kernel, dim3(grid), dim3(kBlock), 0, stream, view_, jump_.get());
+            if (jump_bytes == 32) {
+                GDX_HIP(hipStreamSynchronize(stream));
+                compute_full_sa(view_, n_, jump_.get(), 8u, 6u, stream);
+            }
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             view_.jump = jump_.get();
@@ -1084,7 +1144,10 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
                 sa_tmp.alloc(n_);
                 d_sa = sa_tmp.get();
             }
-            hipLaunchKernelGGL(fill_sa_full_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_sa);
+            if (view_.jump != nullptr && view_.jump_bytes == 32)  // (the entries hold it already)
+                hipLaunchKernelGGL(fill_sa_full_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_sa, 1u, 0u);
+            else
+                compute_full_sa(view_, n_, d_sa, 1u, 0u, stream);
             if (want_text) {
                 const uint64_t n_units = div_ceil(n_, 32) + kTextPadUnits + 2;
                 text_units_.alloc(n_units);
