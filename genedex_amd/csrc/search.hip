@@ -1481,6 +1481,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         }
                         rem = 0;
                     }
+                } else if (!one_row && rem > 0u && rem < kJumpSymbols && best < static_cast<uint32_t>(kCodes) && tail_ok) {
+                    // The same for SEVERAL surviving rows (a read from a repeat family): every lane whose row matched all
+                    // `best` levels holds the lookahead of its own path.  The rows after this jump are [lo, hi) = the
+                    // images of those rows in their order, so the ones whose lookahead agrees with the query's last
+                    // symbols are the hits: a masked record over [lo, hi) -- without the extra round of entry reads the
+                    // tail round above would cost -- or a resolved one when a single row is left.
+                    uint32_t nxt = e0.z >> 16;
+                    nxt = best == 2u ? (e0.w & 0xffffu) : nxt;
+                    if (kHalf2) {
+                        nxt = best == 3u ? (e1.w & 0xffffu) : nxt;
+                        nxt = best == 4u ? (e1.w >> 16) : nxt;
+                    }
+                    const bool can = ((valid >> best) & 1u) != 0u;
+                    if (group_max<kGroup>(mine && !can ? 1u : 0u) == 0u) {  // every surviving row has a usable lookahead
+                        const bool match = mine && ((nxt ^ tail16) & tmask) == 0u;
+                        uint32_t alive = match ? 1u << (target - lo) : 0u;
+                        alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0xB1, 0xF, 0xF, true));
+                        alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0x4E, 0xF, 0xF, true));
+                        const uint32_t n_alive = static_cast<uint32_t>(__popc(alive));
+                        if (kEntrySA && hinting && n_alive == 1u) {
+                            hr = group_max<kGroup>(match ? e1.z : 0u) - rem_before;
+                            resolved = true;
+                            lo += static_cast<uint32_t>(__builtin_ctz(alive));
+                            hi = lo + 1u;
+                        } else if (n_alive == 0u) {
+                            hi = lo;
+                        } else {
+                            masked = true;
+                            hr = alive;
+                            ho = rem;
+                            hi = lo + n_alive;
+                        }
+                        rem = 0;
+                    }
                 }
             }
             if (writer) {
