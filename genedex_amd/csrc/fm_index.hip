@@ -818,13 +818,21 @@ void validate_config(const IndexConfig &cfg)
         fail(GDX_ERR_INVALID_ARGUMENT, "index_width must be 32 (u32), -32 (i32) or 64 (i64)");
     if (cfg.lookup_depth < 0 || cfg.lookup_depth > kMaxLookupDepth)
         fail(GDX_ERR_INVALID_ARGUMENT, "lookup_table_depth must be in 0..=%d", kMaxLookupDepth);
-    // all tables 0..=depth must fit comfortably: sum k^t < 2^31 entries
+    // all tables 0..=depth (8 bytes per entry) must fit the device beside the index itself: at most a third of its
+    // memory (DNA: depth 16 = 46 GB, depth 17 = 183 GB is refused on a 288 GB GPU)
     double total = 0, pw = 1;
     for (int t = 0; t <= cfg.lookup_depth; t++) {
         total += pw;
         pw *= cfg.n_searchable;
     }
-    if (total >= 2147483648.0) fail(GDX_ERR_INVALID_ARGUMENT, "lookup tables would need %.3g entries", total);
+    {
+        size_t free_b = 0, total_b = 0;
+        double limit = 2147483648.0 * 8.0;  // (no device yet: the old bound)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b != 0) limit = static_cast<double>(total_b) / 3.0;
+        else (void)hipGetLastError();
+        if (total * 8.0 > limit || total >= 1.8e19)
+            fail(GDX_ERR_INVALID_ARGUMENT, "lookup tables of depth %d would need %.3g bytes", cfg.lookup_depth, total * 8.0);
+    }
     // every entry point (build, import, load of an untrusted file): a dense code indexes count[] and the superblock
     // offsets at query time
     for (int b = 0; b < 256; b++)
@@ -932,7 +940,6 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     view_.border_vals = border_vals_.get();
     view_.sentinels = sentinels_.get();
     view_.lookup = lookup_.get();
-    for (int t = 0; t < kMaxLookupDepth + 2; t++) view_.lookup_off[t] = static_cast<uint32_t>(lookup_off_host_[t]);
     view_.n = static_cast<uint32_t>(n_);
     view_.n_texts = static_cast<uint32_t>(n_texts_);
     view_.sa_rate = static_cast<uint32_t>(cfg_.sa_rate);

@@ -62,7 +62,7 @@ inline FileHeader read_index_header(IndexFile &in, const char *path)
     if (std::memcmp(h.magic, kIndexFileMagic, 8) != 0) fail(GDX_ERR_INVALID_ARGUMENT, "%s is not a gdx index file", path);
     if (h.sigma < 2 || h.sigma > 256 || h.n_searchable < 1 || h.n_searchable >= h.sigma || h.n_texts == 0 ||
         h.n_texts > h.n || h.n > 0xffffffffull || h.sa_rate == 0 || h.sa_rate > 0xffffffffull || h.lookup_depth < 0 ||
-        h.lookup_depth > 15 || (h.index_width != 32 && h.index_width != -32 && h.index_width != 64) ||
+        h.lookup_depth > 24 || (h.index_width != 32 && h.index_width != -32 && h.index_width != 64) ||
         h.n_samples != div_ceil_u64(h.n, h.sa_rate) ||
         h.n_plane_words != div_ceil_u64(h.n + 1, 64) * static_cast<uint64_t>(plane_bits(static_cast<uint64_t>(h.sigma))))
         fail(GDX_ERR_INVALID_ARGUMENT, "index file header is inconsistent");

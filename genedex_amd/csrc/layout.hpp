@@ -26,7 +26,10 @@ namespace gdx {
 // 64-byte line to scratch / LDS
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxLookupDepth = 15;
+// lookup tables of all depths 0..=d are built (lookup_table.rs:163-181); the reference computes indices with
+// const-curried code up to depth 15 and a dynamic loop beyond (lookup_table.rs:68-113) -- here every depth is the loop.
+// The limit is memory: the deepest table alone has n_searchable^d entries of 8 bytes (4^16 = 34 GB for DNA).
+constexpr int kMaxLookupDepth = 24;
 constexpr uint32_t kSuperblockShift = 16;  // 65536 positions (condensed.rs:34)
 constexpr uint32_t kLineShift = 7;         // 128 positions per rank line
 constexpr uint32_t kLinesPerSuperblock = 1u << (kSuperblockShift - kLineShift);
@@ -85,8 +88,7 @@ struct IndexView {
     const uint32_t *border_vals;  // SA value there (= start of a text)
     const uint32_t *sentinels;    // sentinel_indices (text_id_search_tree.rs:8)
     // --- lookup tables -------------------------------------------------------------------
-    const uint2 *lookup;          // all depths 0..depth concatenated; table t starts at lookup_off[t]
-    uint32_t lookup_off[kMaxLookupDepth + 2];
+    const uint2 *lookup;          // all depths 0..depth concatenated; table t starts at lookup_offset(k, t)
     // --- scalars ---------------------------------------------------------------------------
     uint32_t n;                   // total text length incl. sentinels
     uint32_t n_texts;
@@ -100,6 +102,17 @@ struct IndexView {
     int32_t depth;
     int32_t layout;
 };
+
+// first entry of lookup table t among the concatenated tables: sum of k^j for j < t (k = number of searchable symbols)
+__host__ __device__ __forceinline__ uint64_t lookup_offset(uint32_t k, uint32_t t)
+{
+    uint64_t off = 0, pw = 1;
+    for (uint32_t j = 0; j < t; j++) {
+        off += pw;
+        pw *= k;
+    }
+    return off;
+}
 
 // ---------------------------------------------------------------------------------------
 // rank lines (layout 0)

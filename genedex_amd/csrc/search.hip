@@ -288,18 +288,18 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
         }
         if (t > 0) {
             // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
-            uint32_t idx = 0, factor = 1;
+            uint64_t idx = 0, factor = 1;
             bool unsearchable = false;
             for (uint32_t j = 0; j < t; j++) {
                 const uint32_t d = s_dense[qbuf[end - t + j]];
                 if (d == 0) status = GDX_Q_INVALID_SYMBOL;
                 unsearchable |= (d - 1u >= k);
-                idx += (d - 1u) * factor;
+                idx += static_cast<uint64_t>(d - 1u) * factor;
                 factor *= k;
             }
             if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
             if (status == GDX_Q_OK) {
-                const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                const uint2 v = ix.lookup[lookup_offset(k, t) + idx];
                 lo = v.x;
                 hi = v.y;
             } else {
@@ -637,18 +637,18 @@ __device__ __forceinline__ void search_pair_body(IndexView ix, const uint8_t *__
         if (!topped) {
             if (t > 0) {
                 // lookup_table.rs:99-113: idx = sum (dense-1) * k^j, j = 0 is the leftmost suffix symbol
-                uint32_t idx = 0, factor = 1;
+                uint64_t idx = 0, factor = 1;
                 bool unsearchable = false;
                 for (uint32_t j = 0; j < t; j++) {
                     const uint32_t d = s_dense[qbuf[end - t + j]];
                     if (d == 0) status = GDX_Q_INVALID_SYMBOL;
                     unsearchable |= (d - 1u >= k);
-                    idx += (d - 1u) * factor;
+                    idx += static_cast<uint64_t>(d - 1u) * factor;
                     factor *= k;
                 }
                 if (status == GDX_Q_OK && unsearchable) status = GDX_Q_UNSEARCHABLE_IN_LOOKUP;
                 if (status == GDX_Q_OK) {
-                    const uint2 v = ix.lookup[ix.lookup_off[t] + idx];
+                    const uint2 v = ix.lookup[lookup_offset(k, t) + idx];
                     lo = v.x;
                     hi = v.y;
                 } else {
@@ -1591,6 +1591,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     __shared__ uint32_t s_alive[kCursor ? kCursorRange : 1];  // flush_live_ordered
     __shared__ uint32_t s_alive_part[kCursor ? kBlock : 1];
     __shared__ uint32_t s_alive_base;
+    __shared__ uint32_t s_stage_q[kCursor ? kBlock : 1], s_stage_lo[kCursor ? kBlock : 1], s_stage_hi[kCursor ? kBlock : 1],
+        s_stage_len[kCursor ? kBlock : 1];
+    __shared__ uint64_t s_stage_begin[kCursor ? kBlock : 1];
     __shared__ uint16_t s_perm[kCursor ? 1 : kMaxRange];  // order_range_by_length (fused searches of mixed lengths)
     __shared__ uint32_t s_cnt[kLenBuckets];
     __shared__ uint32_t s_minmax[2];
@@ -1612,24 +1615,59 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
         // (a call's cursor strings have one size; fused searches of spread-out lengths run in length order)
         const bool ordered = !kCursor && schedule != 0 &&
                              order_range_by_length(qbeg, qend, active, base, cnt, s_perm, s_cnt, s_minmax);
-        for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
-            const uint64_t at = base + (ordered ? s_perm[slot] : slot);
-            const uint32_t q = active ? active[at] : static_cast<uint32_t>(at);
-            uint64_t begin = qbeg[q], end = qend[q];
-            bool more_left = true;  // chunk view: the query has symbols left of this chunk
-            if (kCursor && ca.chunk_symbols != 0u) {
-                const uint64_t first = begin, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
-                end = end - first > skip ? end - skip : first;
-                begin = end - first > ca.chunk_symbols ? end - ca.chunk_symbols : first;
-                more_left = begin > first;
+        // Cursor calls stage 256 cursors at a time: every thread fetches ONE cursor's number, string offsets and state (five
+        // gathers that depend on the list entry) into LDS, then the lane groups work from there.  A call was bound by
+        // the per-cursor chain of dependent loads -- list -> state and offsets -> bytes -> top / jump entry, with only
+        // 16 cursors in flight per wavefront (PMC: neither VALU, 74 % busy, nor requests, 63 % of the ceiling) -- and
+        // this takes its first two links out of the chain, 256 at once.
+        for (uint32_t s0 = 0; s0 < cnt; s0 += (kCursor ? static_cast<uint32_t>(kBlock) : cnt)) {
+        const uint32_t s1 = kCursor ? (cnt - s0 < static_cast<uint32_t>(kBlock) ? cnt : s0 + kBlock) : cnt;
+        if (kCursor) {
+            __syncthreads();  // the previous stage has been read
+            const uint32_t i = s0 + threadIdx.x;
+            if (i < s1) {
+                const uint32_t cq = active ? active[base + i] : static_cast<uint32_t>(base + i);
+                uint64_t cb = qbeg[cq], ce = qend[cq];
+                const uint32_t clo = out_start[cq], chi = out_end[cq];
+                const uint32_t cst = out_status != nullptr ? out_status[cq] : 0u;
+                bool more = true;  // chunk view: the query has symbols left of this chunk
+                if (ca.chunk_symbols != 0u) {
+                    const uint64_t first = cb, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
+                    ce = ce - first > skip ? ce - skip : first;
+                    cb = ce - first > ca.chunk_symbols ? ce - ca.chunk_symbols : first;
+                    more = cb > first;
+                }
+                const uint64_t clen = ce - cb;
+                // stopped earlier (the general kernel knows what to do), or too long for the jump levels: bail
+                const bool cbail = cst != 0u || clen >= (1ull << 21);
+                s_stage_q[threadIdx.x] = cq;
+                s_stage_lo[threadIdx.x] = clo;
+                s_stage_hi[threadIdx.x] = chi;
+                s_stage_begin[threadIdx.x] = cb;
+                s_stage_len[threadIdx.x] = (cbail ? 0u : static_cast<uint32_t>(clen)) | (more ? 1u << 30 : 0u) | (cbail ? 1u << 31 : 0u);
             }
-            const uint64_t len = end - begin;
-            uint32_t lo = 0, hi = ix.n;
-            bool bail = len >= (1ull << 21);
+            __syncthreads();
+        }
+        for (uint32_t slot = s0 + threadIdx.x / kGroup; slot < s1; slot += kBlock / kGroup) {
+            uint32_t q, lo = 0, hi = ix.n;
+            uint64_t begin, len;
+            bool more_left = true, bail;
             if (kCursor) {
-                lo = out_start[q];
-                hi = out_end[q];
-                if (out_status != nullptr && out_status[q] != 0) bail = true;  // stopped earlier: the general kernel knows
+                const uint32_t k = slot - s0;
+                const uint32_t packed = s_stage_len[k];
+                q = s_stage_q[k];
+                lo = s_stage_lo[k];
+                hi = s_stage_hi[k];
+                begin = s_stage_begin[k];
+                len = packed & 0x3fffffffu;
+                more_left = ((packed >> 30) & 1u) != 0u;
+                bail = (packed >> 31) != 0u;
+            } else {
+                const uint64_t at = base + (ordered ? s_perm[slot] : slot);
+                q = active ? active[at] : static_cast<uint32_t>(at);
+                begin = qbeg[q];
+                len = qend[q] - begin;
+                bail = len >= (1ull << 21);
             }
             const bool empty_cursor = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210): the top table applies
             uint32_t rem = bail ? 0u : static_cast<uint32_t>(len);
@@ -1821,6 +1859,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 }
             }
         }
+        }  // stages
         // the range's leftover queries: one atomic, coalesced stores; its live cursors: one atomic, in position order
         __syncthreads();
         const uint32_t n_left = s_nleft;
@@ -2167,16 +2206,17 @@ __global__ __launch_bounds__(kBlock) void lf_walk_kernel(IndexView ix, const uin
 // same (start, end) as the reference's recursive fill through the smaller tables.
 template <class Table>
 __global__ __launch_bounds__(kBlock) void fill_lookup_kernel(IndexView ix, uint2 *__restrict__ lookup, int depth,
-                                                             uint32_t entries)
+                                                             uint64_t entries)
 {
     const uint32_t k = static_cast<uint32_t>(ix.n_searchable);
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint64_t first = lookup_offset(k, static_cast<uint32_t>(depth));
     for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) {
-        uint32_t pw = 1;
+        uint64_t pw = 1;
         for (int j = 1; j < depth; j++) pw *= k;  // k^(depth-1)
         uint32_t lo = 0, hi = ix.n;
         for (int j = depth - 1; j >= 0 && lo != hi; j--) {
-            const uint32_t c = (static_cast<uint32_t>(e) / pw) % k + 1u;
+            const uint32_t c = static_cast<uint32_t>((e / pw) % k) + 1u;
             uint32_t rlo, rhi;
             Table::rank2(ix, c, lo, hi, rlo, rhi);
             const uint32_t cc = ix.count[c];
@@ -2184,7 +2224,7 @@ __global__ __launch_bounds__(kBlock) void fill_lookup_kernel(IndexView ix, uint2
             hi = cc + rhi;
             pw /= k;
         }
-        lookup[ix.lookup_off[depth] + e] = make_uint2(lo, hi);
+        lookup[first + e] = make_uint2(lo, hi);
     }
 }
 
@@ -2634,8 +2674,7 @@ void launch_fill_lookup(const IndexView &ix, uint2 *d_lookup, int depth, hipStre
 {
     uint64_t entries = 1;
     for (int j = 0; j < depth; j++) entries *= static_cast<uint64_t>(ix.n_searchable);
-    GDX_DISPATCH_TABLE(ix, fill_lookup_kernel, grid_for_items(entries), stream, ix, d_lookup, depth,
-                       static_cast<uint32_t>(entries));
+    GDX_DISPATCH_TABLE(ix, fill_lookup_kernel, grid_for_items(entries), stream, ix, d_lookup, depth, entries);
 }
 
 // sum of the interval widths of the top-table entries wider than `rows` rows = the number of text positions whose

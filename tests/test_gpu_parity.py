@@ -1071,3 +1071,30 @@ def test_packed_queries_equal_ascii_queries(seed, search_variant):
     assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
     h = hits[:total].cpu().numpy().astype(np.uint32)
     assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
+
+
+@pytest.mark.parametrize("depth", [16, 19])
+def test_lookup_tables_deeper_than_fifteen(depth):
+    """The reference indexes its lookup tables with const-curried code up to depth 15 and a dynamic loop beyond
+    (lookup_table.rs:68-113); here every depth is the loop, with 64-bit table offsets.  A two-symbol alphabet keeps the
+    deep tables small (2^depth entries); an unsearchable symbol inside the suffix is still reported."""
+    rng = np.random.default_rng(1600 + depth)
+    a = alph.Alphabet.from_io_symbols(b"ACN", 1)  # A, C searchable; N valid but not searchable
+    texts = [bytes(b"ACN"[i] for i in rng.choice(3, int(rng.integers(3000, 9000)), p=[.49, .49, .02])) for _ in range(3)]
+    g, c = both(texts, a, depth=depth)
+    assert g.export_lookup_table(depth).tolist() == c.lookup_table(depth).tolist()
+    qs = []
+    for _ in range(1500):
+        t = texts[int(rng.integers(0, 3))]
+        pos = int(rng.integers(0, len(t)))
+        qs.append(t[pos:pos + int(rng.integers(0, 60))])
+        qs.append(bytes(b"AC"[i] for i in rng.integers(0, 2, int(rng.integers(0, 40)))))
+    qbuf, qoff = pack_queries(qs)
+    s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    assert st.tolist() == cst.tolist() and (cst == 2).sum() > 10
+    ok = st == 0
+    assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+    off, t_, p_, _ = g.locate_raw(qbuf, qoff, strict=False)
+    co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+    assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
