@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything profiles/r03/*final* is made of, on the GPU box (via gpurun, from the repo root): tools/final_profiles_r3.sh <tag>
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+cd $R
+python3 -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/gpu_tests_final.log
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_hg38_final.json 2> $OUT/bench.err; echo bench rc=$?
+python3 tools/make_pmc_final_r2.py $OUT/bench_hg38_final.json $OUT/search_pmc_final.json > /dev/null
+export TMPDIR=/tmp
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 \
+  --no-live-pmc --no-cpu-baseline --no-bandwidth --no-extras --secondary-depth 0 > $OUT/trace_bench.json 2> $OUT/trace.err
+python3 $R/tools/summarize_rocprof.py stats $OUT/trace > $OUT/bench_hg38_final_kernel_stats.md
+find $OUT/trace -name '*.csv' -delete
+cd $R
+python3 tools/exp_general.py 3 > $OUT/exp_general_final.json 2> /dev/null
+python3 tests/parity_sweep.py 250 1 > $OUT/parity_sweep_seed1.json 2> $OUT/parity1.err
+tail -3 $OUT/gpu_tests_final.log; tail -c 400 $OUT/parity_sweep_seed1.json; echo; cat $OUT/bench_hg38_final_kernel_stats.md | head -12
