@@ -759,7 +759,7 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
 
 def committed_traffic(args, nq, aux, why):
     """Fallback when the live PMC passes are unavailable: the committed summary of the same configuration."""
-    path = os.path.join(ROOT, "profiles", "r02", "search_pmc_final.json")
+    path = os.path.join(ROOT, "profiles", "r03", "search_pmc_final.json")
     try:
         with open(path) as f:
             p = json.load(f)
