@@ -44,6 +44,8 @@ pub struct BuildOptions {
     pub jump_entry_bytes: i32, // -1 default (32), 0, 8, 16, 32
     pub top_table_depth: i32,  // -1 default, 0 none, 1..=16
     pub aux_budget_bytes: u64, // 0 = default
+    pub full_suffix_array: i32, // -1 / 0 off, 1: SA[row] of every row as its own array
+    pub text_units: i32,        // -1 / 0 off, 1: the text at 4 bits per symbol (count / locate compare with it)
 }
 impl Default for BuildOptions {
     fn default() -> Self {
@@ -68,6 +70,32 @@ pub struct QueryOptions {
     pub locate_jump_walk: i32,
     pub search_defer_after: i32,
     pub search_fast: i32,
+    pub search_exact: i32,
+    /// host-pointer locate calls return at most this many hits per query, the first ones in suffix-array order:
+    /// `locate(q).take(k)` on the reference's lazy iterator (lib.rs:187-197); 0 = all
+    pub max_hits_per_query: u32,
+}
+
+/// gdx_device_shard_t / gdx_gathered_t: gdx_multi_locate_many_gather_dev (device-resident shards, results gathered on the
+/// root replica's GPU with ncclSend / ncclRecv)
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct DeviceShard {
+    pub d_qbuf: *const c_void,
+    pub d_qoff: *const c_void,
+    pub nq: u64,
+}
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct Gathered {
+    pub d_counts: *mut c_void,
+    pub d_hit_offsets: *mut c_void,
+    pub d_hits: *mut c_void,
+    pub d_status: *mut c_void,
+    pub nq: u64,
+    pub total_hits: u64,
+    pub device_id: i32,
+    pub used_rccl: i32,
 }
 
 pub const GDX_OK: c_int = 0;
@@ -148,6 +176,10 @@ extern "C" {
         n_devices: c_int, opts: *const BuildOptions, out: *mut *mut gdx_multi_t,
     ) -> c_int;
     pub fn gdx_multi_free(m: *mut gdx_multi_t);
+    pub fn gdx_multi_set_query_options(m: *mut gdx_multi_t, opts: *const QueryOptions) -> c_int;
+    pub fn gdx_multi_locate_many_gather_dev(
+        m: *mut gdx_multi_t, shards: *const DeviceShard, n_shards: c_int, root: c_int, out: *mut Gathered,
+    ) -> c_int;
     pub fn gdx_multi_count_many(
         m: *const gdx_multi_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64, out_status: *mut u8,
     ) -> c_int;
