@@ -7,12 +7,12 @@ include/gdx.h, built into libgdx.so), and the host-side mirror of the reference'
 from . import alphabet
 from .alphabet import Alphabet
 
-__all__ = ["alphabet", "Alphabet", "FmIndexConfig", "FmIndex", "Cursor", "Hit", "GdxError"]
+__all__ = ["alphabet", "Alphabet", "FmIndexConfig", "FmIndex", "PartitionedFmIndex", "Cursor", "Hit", "GdxError"]
 
 
 def __getattr__(name):
     # the query API needs libgdx.so; importing the alphabet tables alone does not
-    if name in ("FmIndexConfig", "FmIndex", "Cursor", "Hit", "pack_queries"):
+    if name in ("FmIndexConfig", "FmIndex", "PartitionedFmIndex", "Cursor", "Hit", "pack_queries"):
         from . import index
 
         return getattr(index, name)

@@ -130,6 +130,13 @@ SIGNATURES = {
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
+    "gdx_parts_build": [vp, C.c_int, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint64,
+                        C.POINTER(BuildOptions), C.POINTER(vp)],
+    "gdx_parts_free": [vp],
+    "gdx_parts_info": [vp, u64p],
+    "gdx_parts_set_query_options": [vp, C.POINTER(QueryOptions)],
+    "gdx_parts_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
+    "gdx_parts_locate_many_alloc": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(C.POINTER(HitStruct)), u64p, u8p],
     "gdx_multi_locate_many_gather_dev": [vp, vp, C.c_int, C.c_int, vp],
     "gdx_multi_set_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_multi_replicas": [vp],
@@ -184,7 +191,7 @@ SIGNATURES = {
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
-             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None,
+             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
              "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64}
 
 _lib = None

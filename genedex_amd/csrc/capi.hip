@@ -75,6 +75,10 @@ struct gdx_multi {
     std::unique_ptr<gdx::Multi> impl;
 };
 
+struct gdx_parts {
+    std::unique_ptr<gdx::Parts> impl;
+};
+
 struct gdx_fastx {
     std::unique_ptr<gdx::FastxReader> impl;
 };
@@ -1251,6 +1255,80 @@ int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const
     return guarded([&] {
         if (!m || !m->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "multi handle is null");
         return gdx::multi_locate_alloc(*m->impl, qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
+    });
+}
+
+// ---- partitioned index (parts.hip) ---------------------------------------------------------------------------------
+
+int gdx_parts_build(const void *texts_buf, int texts_on_device, const uint64_t *text_offsets, uint64_t n_texts,
+                    const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                    int device_id, uint64_t max_part_symbols, const gdx_build_options_t *opts, gdx_parts_t **out)
+{
+    return guarded([&] {
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        *out = nullptr;
+        auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, 32, device_id, opts);
+        DeviceGuard guard(device_id);
+        auto impl = gdx::Parts::build(static_cast<const uint8_t *>(texts_buf), texts_on_device != 0, text_offsets, n_texts, cfg,
+                                      max_part_symbols);
+        *out = new gdx_parts{std::move(impl)};
+        return (int)GDX_OK;
+    });
+}
+
+void gdx_parts_free(gdx_parts_t *p)
+{
+    if (!p) return;
+    (void)guarded([&] {
+        if (p->impl && !p->impl->parts.empty()) {
+            DeviceGuard guard(p->impl->cfg.device_id);
+            p->impl->parts.clear();
+        }
+        delete p;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_parts_info(const gdx_parts_t *p, uint64_t out[4])
+{
+    return guarded([&] {
+        if (!p || !p->impl || !out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+        out[0] = p->impl->parts.size();
+        out[1] = p->impl->total_len;
+        out[2] = p->impl->first_text.back();
+        out[3] = 0;
+        for (auto &ix : p->impl->parts) out[3] += ix->device_bytes();
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_parts_set_query_options(gdx_parts_t *p, const gdx_query_options_t *opts)
+{
+    return guarded([&] {
+        if (!p || !p->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "parts handle is null");
+        const gdx::QueryOptions q = parse_query_options(opts);
+        for (auto &ix : p->impl->parts) ix->set_query_options(q);
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_parts_count_many(const gdx_parts_t *p, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                         uint64_t *out_counts, uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!p || !p->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "parts handle is null");
+        DeviceGuard guard(p->impl->cfg.device_id);
+        return p->impl->count_many(qbuf, qoff, nq, out_counts, out_status);
+    });
+}
+
+int gdx_parts_locate_many_alloc(const gdx_parts_t *p, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
+{
+    return guarded([&] {
+        if (!p || !p->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "parts handle is null");
+        DeviceGuard guard(p->impl->cfg.device_id);
+        return p->impl->locate_many_alloc(qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
     });
 }
 

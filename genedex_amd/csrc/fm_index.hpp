@@ -207,6 +207,20 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
 int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                        gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
 
+// A collection beyond 2^32 - 1 symbols as several 32-bit indexes cut at text borders (parts.hip, gdx_parts_*)
+struct Parts {
+    std::vector<std::unique_ptr<FmIndex>> parts;
+    std::vector<uint64_t> first_text;  // [parts + 1]: number of texts before every part
+    uint64_t total_len = 0;            // symbols incl. sentinels
+    IndexConfig cfg;
+    ~Parts();
+    static std::unique_ptr<Parts> build(const uint8_t *texts_buf, bool texts_on_device, const uint64_t *text_offsets,
+                                        uint64_t n_texts, const IndexConfig &cfg, uint64_t max_part_symbols);
+    int count_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_counts, uint8_t *out_status) const;
+    int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                          gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
+};
+
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
 void set_host_chunking(uint64_t queries, uint64_t bytes);
 

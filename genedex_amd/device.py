@@ -330,3 +330,16 @@ def genome_like_text(total: int, dev, seed: int = 7) -> torch.Tensor:
 
 def hg38_text_lengths(total: int, n_texts: int = 24):
     return split_lengths(total, n_texts)
+
+
+def build_parts_from_device_text(io_text: torch.Tensor, text_lengths, alphabet: Alphabet, sa_rate=4, lookup_depth=0,
+                                 max_part_symbols=0, options=None):
+    """gdx_parts_build on a text that already sits in HBM: a collection beyond 2^32 - 1 symbols as several 32-bit
+    indexes cut at text borders (index.PartitionedFmIndex)."""
+    from .index import PartitionedFmIndex
+
+    toff = np.zeros(len(text_lengths) + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(text_lengths, dtype=np.uint64), out=toff[1:])
+    torch.cuda.synchronize()
+    return PartitionedFmIndex._build(_ptr(io_text), 1, toff, len(text_lengths), alphabet, sa_rate, lookup_depth,
+                                     io_text.device.index or 0, max_part_symbols, options)

@@ -450,3 +450,100 @@ class Cursor:
 
     def __copy__(self):
         return Cursor(self.index, self.start, self.end)  # cursor.rs:22-28 Cursor is Copy
+
+
+class PartitionedFmIndex:
+    """gdx_parts_* (include/gdx.h): a collection of texts beyond 2^32 - 1 symbols -- the reference's `IndexStorage = i64`
+    case (construction/mod.rs:225-252) -- as several 32-bit indexes cut at text borders.  count / locate only: counts
+    and hit sets are the reference's; there is no single suffix-array interval of the whole collection, and a query's
+    hits come part after part."""
+
+    def __init__(self, handle, alphabet: Alphabet):
+        self._h = handle
+        self._lib = _lib.load()
+        self._alphabet = alphabet
+        out = (C.c_uint64 * 4)()
+        _lib.check(self._lib.gdx_parts_info(self._h, out))
+        self.num_parts, self._total_len, self._num_texts, self.device_bytes = (int(x) for x in out)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.gdx_parts_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def construct(cls, texts, alphabet: Alphabet, sa_rate=4, lookup_depth=0, device=0, max_part_symbols=0, options=None):
+        texts = [bytes(t) for t in texts]
+        tbuf, toff = pack_queries(texts)
+        return cls._build(tbuf.ctypes.data_as(C.c_void_p), 0, toff, len(texts), alphabet, sa_rate, lookup_depth, device,
+                          max_part_symbols, options)
+
+    @classmethod
+    def _build(cls, texts_ptr, on_device, toff, n_texts, alphabet, sa_rate, lookup_depth, device, max_part_symbols, options):
+        lib = _lib.load()
+        handle = C.c_void_p()
+        tab = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
+        opts = options if options is not None else build_options()
+        toff = np.ascontiguousarray(toff, dtype=np.uint64)
+        _lib.check(lib.gdx_parts_build(texts_ptr, int(on_device), _p(toff, u64p), int(n_texts), _p(tab, u8p),
+                                       alphabet.num_dense_symbols(), alphabet.num_searchable_dense_symbols(), int(sa_rate),
+                                       int(lookup_depth), int(device), int(max_part_symbols), C.byref(opts), C.byref(handle)))
+        return cls(handle, alphabet)
+
+    def num_texts(self) -> int:
+        return self._num_texts
+
+    def total_text_len(self) -> int:
+        return self._total_len
+
+    def set_query_options(self, **kw) -> None:
+        o = _lib.QueryOptions()
+        self._lib.gdx_query_options_init(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, int(v))
+        _lib.check(self._lib.gdx_parts_set_query_options(self._h, C.byref(o)))
+
+    def count_raw(self, qbuf, qoff, strict=True):
+        nq = qoff.size - 1
+        counts = np.zeros(nq, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        st = self._lib.gdx_parts_count_many(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(counts, u64p), _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return counts, status
+
+    def locate_raw(self, qbuf, qoff, strict=True):
+        """-> (hit_offsets u64[nq+1], text_ids u64[total], positions u64[total], status)"""
+        nq = qoff.size - 1
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        total = C.c_uint64(0)
+        ptr = C.POINTER(_lib.HitStruct)()
+        st = self._lib.gdx_parts_locate_many_alloc(self._h, _p(qbuf, u8p), _p(qoff, u64p), nq, _p(off, u64p), C.byref(ptr),
+                                                   C.byref(total), _p(status, u8p))
+        try:
+            _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+            n = total.value
+            hits = np.ctypeslib.as_array(C.cast(ptr, u64p), shape=(max(n, 1) * 2,))[: 2 * n].reshape(n, 2).copy() \
+                if n else np.zeros((0, 2), dtype=np.uint64)
+        finally:
+            if ptr:
+                self._lib.gdx_free_hits(ptr)
+        return off, hits[:, 0].copy(), hits[:, 1].copy(), status
+
+    def count_many(self, queries):
+        return self.count_raw(*pack_queries(queries))[0]
+
+    def count(self, query) -> int:
+        return int(self.count_many([query])[0])
+
+    def locate_many(self, queries):
+        qbuf, qoff = pack_queries(queries)
+        off, t, p, _ = self.locate_raw(qbuf, qoff)
+        t, p = t.tolist(), p.tolist()
+        return [[Hit(t[h], p[h]) for h in range(int(off[q]), int(off[q + 1]))] for q in range(qoff.size - 1)]
+
+    def locate(self, query):
+        return self.locate_many([query])[0]

@@ -442,6 +442,28 @@ int gdx_multi_count_many(const gdx_multi_t *m, const uint8_t *qbuf, const uint64
                          uint64_t *out_counts, uint8_t *out_status);
 int gdx_multi_cursors_for_many_queries(const gdx_multi_t *m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                                        uint64_t *out_start, uint64_t *out_end, uint8_t *out_status);
+/* ---- collections beyond 2^32 - 1 symbols (the reference: IndexStorage = i64, construction/mod.rs:225-252): a
+ * PARTITIONED index.  Rows and text positions are 32-bit in every table and kernel of this library, so a collection that
+ * does not fit one index is cut at text borders into parts of at most max_part_symbols (0 = 2^32 - 1; sentinels count),
+ * every part gets its own index on the device, and a query runs against each: count = the sum of the parts' counts,
+ * locate = the parts' hits part after part with global text ids.  Counts and hit sets are the reference's (an occurrence
+ * lies inside one text); the single suffix-array interval of the whole collection (cursors) is not available, and a
+ * query's hits come in suffix-array order per part (the reference leaves the order of locate() open, lib.rs:163).  A
+ * single text that does not fit a part is refused (GDX_ERR_TEXT_TOO_LONG).  texts_on_device != 0: texts_buf is a device
+ * pointer (text_offsets stays on the host). */
+typedef struct gdx_parts gdx_parts_t;
+int gdx_parts_build(const void *texts_buf, int texts_on_device, const uint64_t *text_offsets, uint64_t n_texts,
+                    const uint8_t *io_to_dense, int sigma, int n_searchable, uint64_t sa_rate, int lookup_depth,
+                    int device_id, uint64_t max_part_symbols, const gdx_build_options_t *opts, gdx_parts_t **out);
+void gdx_parts_free(gdx_parts_t *p);
+/* out[0] = number of parts, out[1] = total symbols incl. sentinels, out[2] = number of texts, out[3] = device bytes */
+int gdx_parts_info(const gdx_parts_t *p, uint64_t out[4]);
+int gdx_parts_set_query_options(gdx_parts_t *p, const gdx_query_options_t *opts);
+int gdx_parts_count_many(const gdx_parts_t *p, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                         uint64_t *out_counts, uint8_t *out_status);
+int gdx_parts_locate_many_alloc(const gdx_parts_t *p, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
+
 /* Device-resident form: the queries of shard r already sit in the HBM of replica r's device; every
  * replica runs search -> scan -> locate on its shard, then the per-query counts (u32) and the hits (gdx_hit32_t) of all
  * shards are gathered into buffers on the ROOT replica's device by RCCL point-to-point transfers over xGMI (ncclSend /

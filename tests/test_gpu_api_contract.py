@@ -416,3 +416,48 @@ def test_multi_gather_dev_over_rccl():
         pytest.skip("needs two GPUs (RCCL point-to-point between devices)")
     n = min(torch.cuda.device_count(), 4)
     _gather_dev_case(n, list(range(n)))
+
+
+@pytest.mark.parametrize("depth", [0, 3])
+def test_partitioned_index_equals_one_index_on_counts_and_hit_sets(depth):
+    """gdx_parts_*: a collection cut at text borders into several 32-bit indexes (what stands in for the reference's
+    IndexStorage = i64 beyond 2^32 - 1 symbols).  Counts, statuses and hit SETS equal the oracle's single index over the
+    whole collection; hits come part after part, suffix-array order inside a part."""
+    from genedex_amd import GdxError, PartitionedFmIndex, _lib
+
+    rng = np.random.default_rng(4242 + depth)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, int(rng.integers(0, 4000)), p=[.2475, .2475, .2475, .2475, .01]))
+             for _ in range(23)]
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=depth, width=64)
+    g = PartitionedFmIndex.construct(texts, a, sa_rate=4, lookup_depth=depth, max_part_symbols=9000)
+    assert g.num_parts >= 4 and g.num_texts() == len(texts) and g.total_text_len() == c.n
+    qs = [texts[int(rng.integers(0, 23))] for _ in range(3)]  # whole texts as queries
+    for _ in range(2500):
+        t = texts[int(rng.integers(0, 23))]
+        if len(t):
+            pos = int(rng.integers(0, len(t)))
+            qs.append(t[pos:pos + int(rng.integers(0, 40))])
+        qs.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 12)))))
+    qs += [b"ACXGT", b"", b"NNN", b"GATTACA" * 3]
+    qbuf, qoff = pack_queries(qs)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    counts, st = g.count_raw(qbuf, qoff, strict=False)
+    assert st.tolist() == cst.tolist()
+    ok = cst == 0
+    assert counts[ok].tolist() == (ce - cs)[ok].tolist() and not counts[~ok].any()
+    off, t, p, st2 = g.locate_raw(qbuf, qoff, strict=False)
+    assert st2.tolist() == cst.tolist()
+    co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
+    assert off.tolist() == co.tolist()
+    for k in range(len(qs)):
+        got = sorted(zip(t[off[k]:off[k + 1]].tolist(), p[off[k]:off[k + 1]].tolist()))
+        want = sorted(zip(ct[co[k]:co[k + 1]].tolist(), cp[co[k]:co[k + 1]].tolist()))
+        assert got == want, qs[k]
+    with pytest.raises(GdxError) as e:  # a single text must fit one part
+        PartitionedFmIndex.construct([b"ACGT" * 5000, b"ACGT"], a, max_part_symbols=9000)
+    assert e.value.status == _lib.GDX_ERR_TEXT_TOO_LONG
+    one = PartitionedFmIndex.construct(texts, a, sa_rate=4, lookup_depth=depth)  # everything fits one part
+    assert one.num_parts == 1
+    off1, t1, p1, _ = one.locate_raw(qbuf, qoff, strict=False)
+    assert off1.tolist() == co.tolist() and t1.tolist() == ct.tolist() and p1.tolist() == cp.tolist()
