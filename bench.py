@@ -168,7 +168,7 @@ def run_live_pmc(args, reference_layout=False, rung=None):
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
+               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
                "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
@@ -289,6 +289,10 @@ class StepRunner:
         self.hits, self.ws = [], []
         self.ev_search, self.ev_locate = [], []
         self.sized_in_step = True  # the timed step reads the number of hits back and sizes the hit buffer itself
+        # records path: offsets and single-hit locate in ONE pass over the records (gdx_locate_many_scan_hits_dev)
+        self.fused_scan = self.use_rec and os.environ.get("GDX_BENCH_NO_FUSED_SCAN") != "1"
+        self.scan_ws, self.totals = [], []
+        self.ev_scan = []
 
     def _alloc(self):
         o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
@@ -337,6 +341,10 @@ class StepRunner:
         self.hits = [torch.zeros((max(self.total_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(self.n_slots)]
         nbytes = max(self.eng.locate_workspace_bytes(self.total_hits), 16)
         self.ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+        if self.fused_scan:
+            sb = max(self.eng.scan_workspace_bytes(self.nq), 16)
+            self.scan_ws = [torch.empty(sb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+            self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
         return self.total_hits
 
     def step(self, slot, record, side_stream=None, after=None):
@@ -351,7 +359,32 @@ class StepRunner:
         with (torch.cuda.stream(side_stream) if side_stream is not None else _null()):
             if side_stream is not None:
                 side_stream.wait_event(b)
-            if self.do_locate:
+            if self.do_locate and self.fused_scan:
+                # one pass: offsets + the hit of every single-hit query, into the buffer the previous step sized; then the
+                # one host round trip (both totals); then only what that pass left open
+                c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c.record()
+                self.eng.locate_scan_hits(o["rec"], self.nq, o["hit_offsets"], h, h.shape[0], self.scan_ws[slot],
+                                          self.totals[slot])
+                tot, rest = (int(x) for x in self.totals[slot].tolist())
+                self.total_hits = tot
+                if tot > h.shape[0]:  # the buffer offered was too small: grow it, locate everything (offsets are valid)
+                    self.hits[slot] = torch.empty((tot, 2), dtype=torch.int32, device=h.device)
+                    h = self.hits[slot]
+                    rest = -1
+                if rest != 0:
+                    need = self.eng.locate_workspace_bytes(tot)
+                    if need > self.ws[slot].numel():
+                        self.ws[slot] = torch.empty(need, dtype=torch.uint8, device=h.device)
+                        ws = self.ws[slot]
+                    if rest < 0:
+                        self.locate(o, h, ws)
+                    else:
+                        self.eng.locate_hits_rest(o["rec"], self.nq, o["hit_offsets"], tot, h, ws)
+                d.record()
+                if record:
+                    self.ev_locate.append((c, d))
+            elif self.do_locate:
                 self.offsets(o)
                 if self.sized_in_step:
                     # what a caller cannot skip: the number of hits comes back to the host (one 8-byte copy + a stream
@@ -590,8 +623,11 @@ def main():
         if runner.use_rec:
             del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
-        lt = traffic_of(pmc, "locate_queue_kernel")
-        locate_roofline = {"bound": "hbm", "kernel": "locate_queue_kernel (+ slot -> query map)", "peak": HBM_PEAK_GBPS,
+        lt = traffic_of(pmc, "scan_locate_kernel|locate_queue_kernel")
+        locate_roofline = {"bound": "hbm", "kernel": (lt or {}).get("kernel", "scan_locate_kernel"), "peak": HBM_PEAK_GBPS,
+                           "what": "hit offsets + hits in one pass over the records (scan_locate_kernel) + the host read-back of "
+                                   "the totals + the queue kernel on what that pass left open" if runner.fused_scan else
+                                   "locate_queue_kernel after the separate scan",
                            "unit": "GB/s", "avg_launch_ms": locate_ms,
                            "traffic": lt["bytes"] if lt else None,
                            "achieved": lt["bytes"] / (locate_ms / 1e3) / 1e9 if lt else None,

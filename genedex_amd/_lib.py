@@ -130,6 +130,9 @@ SIGNATURES = {
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
+    "gdx_locate_many_scan_workspace_bytes": [C.c_uint64],
+    "gdx_locate_many_scan_hits_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_hits_rest_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_parts_build": [vp, C.c_int, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                         C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_parts_free": [vp],
@@ -192,7 +195,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
              "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
-             "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64}
+             "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64,
+             "gdx_locate_many_scan_workspace_bytes": C.c_uint64}
 
 _lib = None
 

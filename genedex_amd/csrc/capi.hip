@@ -774,6 +774,45 @@ int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint6
     });
 }
 
+uint64_t gdx_locate_many_scan_workspace_bytes(uint64_t nq) { return gdx::scan_locate_workspace_bytes(nq); }
+
+int gdx_locate_many_scan_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
+                                  void *d_hit_offsets, void *d_hits, uint64_t hits_capacity, void *d_scan_workspace,
+                                  void *d_totals, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_hit_offsets || !d_totals || !d_scan_workspace || (hits_capacity != 0 && !d_hits))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_scan_hits_dev: null argument");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_scan_locate(f.view(), static_cast<const uint4 *>(d_records), nq, max_hits, false,
+                                static_cast<uint64_t *>(d_hit_offsets), d_hits, hits_capacity, false, d_scan_workspace,
+                                static_cast<unsigned long long *>(d_totals), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_hits_rest_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                                  uint64_t total_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        // the scan pass stored every single hit when the index has SA[row] at hand; otherwise the walk fills in all slots
+        // (resolved ones are written again, with the same values)
+        const gdx::IndexView &v = f.view();
+        const bool have_sa = v.layout == 0 && (v.sa_full != nullptr || (v.jump != nullptr && v.jump_bytes == 32));
+        gdx::launch_locate(v, nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits, false,
+                           d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
+                           static_cast<const uint4 *>(d_records), false, have_sa);
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream)
 {

@@ -126,7 +126,16 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
-                   const uint4 *d_rec = nullptr, bool reference_walk = false);
+                   const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false);
+// One pass over the search records (locate.hip scan_locate_kernel): the hit offsets (what launch_hit_offsets_rec
+// computes) and, in the same pass, the hit of every query with exactly one hit slot -- resolved records need nothing,
+// others one fetch of SA[row] when the index has it.  d_totals (u64[2]): [0] = all hit slots, [1] = the slots left to
+// launch_locate(..., skip_single = true): queries with several hits, and single hits that need a walk.  Hits at or beyond
+// hits_capacity are not stored.
+size_t scan_locate_workspace_bytes(uint64_t m);
+void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uint32_t max_hits, bool take,
+                        uint64_t *d_hit_offsets, void *d_hits, uint64_t hits_capacity, bool wide, void *d_workspace,
+                        unsigned long long *d_totals, hipStream_t stream);
 // reference_walk: walk one LF step at a time (sampled_suffix_array.rs:118-131) so that the steps counted through
 // d_step_stats are the reference's
 // d_rec != null: start / hint come from the search records instead of d_start / d_hint (d_start, d_end unused)

@@ -175,6 +175,7 @@ struct LocateView {
     const uint32_t *count, *sa_samples, *border_keys, *border_vals, *sentinels;
     uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
     int32_t sigma, nbits;
+    uint32_t skip_single;  // 1: the hits of queries with exactly one hit slot are in place already (scan_locate_kernel)
 };
 
 // kEntrySA: the index has 32-byte jump entries, which carry SA[row] (layout.hpp): every hit is finished in phase 0 with
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint64_t h = base + i;
             const uint32_t q = qa + qrel[j] - 1u;
             const uint64_t first = hit_offsets[q];
+            if (lv.skip_single != 0u && hit_offsets[q + 1] - first == 1u) continue;
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
             if (rec != nullptr) {
@@ -485,6 +487,141 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
+// ---- one pass over the search records: hit offsets AND the hit of every query that has exactly one -------------------
+// The count + locate step of a read batch is search -> scan of the counts -> locate.  With resolved records (32-byte jump
+// entries carry SA[row]) the last two are streaming passes over the same records: an exclusive scan that reads them
+// and writes the offsets, then a kernel that reads records and offsets again and writes the hits.  This kernel does both
+// at once -- a single-pass scan with decoupled look-back (tiles of 2048 queries take tickets, publish {aggregate |
+// inclusive prefix} in one 64-bit word, and look back over their predecessors) whose tiles then store the hit of every
+// query with exactly one hit slot: resolved -> the position is in the record; otherwise one fetch of SA[row] when the
+// index has it (jump entry / full suffix array).  Queries with several hits (and single hits that would need a walk) are
+// only counted (totals[1]); the queue kernel fills them in afterwards with LocateView::skip_single.  Hits beyond
+// hits_capacity are not stored: the caller compares totals[0] with the capacity it offered.
+constexpr uint32_t kScanTile = 2048;
+constexpr unsigned long long kTileAggregate = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
+
+template <bool kWide>
+__global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, const uint4 *__restrict__ rec, uint64_t m,
+                                                             uint32_t max_hits, uint32_t take,
+                                                             uint64_t *__restrict__ hit_offsets, void *__restrict__ hits_out,
+                                                             uint64_t hits_capacity, unsigned long long *__restrict__ tile_state,
+                                                             uint32_t *__restrict__ ticket,
+                                                             unsigned long long *__restrict__ totals)
+{
+    constexpr uint32_t kPer = kScanTile / kBlock;  // consecutive queries per thread (one 128-byte line of records)
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_warp[kBlock / 64];
+    __shared__ unsigned long long s_prefix;
+    constexpr uint32_t kLdsTexts = 256;
+    __shared__ uint32_t s_sentinels[kLdsTexts];
+    IndexView ix{};
+    ix.sentinels = lv.sentinels;
+    ix.n_texts = lv.n_texts;
+    const uint32_t *sentinels = lv.n_texts <= kLdsTexts ? s_sentinels : lv.sentinels;
+    if (lv.n_texts <= kLdsTexts)
+        for (uint32_t i = threadIdx.x; i < lv.n_texts; i += kBlock) s_sentinels[i] = lv.sentinels[i];
+    const bool have_sa = lv.sa_full != nullptr || (lv.jump != nullptr && lv.jump_bytes == 32u);
+    const uint64_t n_tiles = (m + kScanTile - 1) / kScanTile;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tiles are handed out in order: a tile only waits for earlier ones
+        __syncthreads();
+        const uint64_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        const uint64_t q0 = tile * kScanTile + static_cast<uint64_t>(threadIdx.x) * kPer;
+        uint4 r[kPer];
+        uint32_t c[kPer];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint64_t q = q0 + j;
+            r[j] = q < m ? rec[q] : make_uint4(0u, 0u, 0u, 0u);
+            uint32_t cnt = r[j].y - r[j].x;
+            if (max_hits != 0u && cnt > max_hits) cnt = take ? max_hits : 0u;  // RecordSize
+            c[j] = cnt;
+            mine += cnt;
+        }
+        // block-wide exclusive scan of the per-thread sums
+        unsigned long long incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off);
+            if (static_cast<int>(threadIdx.x & 63u) >= off) incl += o;
+        }
+        if ((threadIdx.x & 63u) == 63u) s_warp[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = incl - mine, tile_total = 0;
+        for (uint32_t wv = 0; wv < kBlock / 64; wv++) {
+            const unsigned long long v = s_warp[wv];
+            if (wv < (threadIdx.x >> 6)) before += v;
+            tile_total += v;
+        }
+        if (threadIdx.x == 0) {
+            unsigned long long prefix = 0;
+            if (tile == 0) {
+                __atomic_store_n(tile_state, kTilePrefix | tile_total, __ATOMIC_RELEASE);
+            } else {
+                __atomic_store_n(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELEASE);
+                for (uint64_t p = tile; p-- > 0;) {  // look back: sum aggregates until a tile that knows its inclusive prefix
+                    unsigned long long v;
+                    do {
+                        v = __atomic_load_n(tile_state + p, __ATOMIC_ACQUIRE);
+                    } while ((v >> 62) == 0ull);
+                    prefix += v & kTileValue;
+                    if ((v >> 62) == 2ull) break;
+                }
+                __atomic_store_n(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELEASE);
+            }
+            s_prefix = prefix;
+            if (tile == n_tiles - 1) {
+                hit_offsets[m] = prefix + tile_total;
+                totals[0] = prefix + tile_total;
+            }
+        }
+        __syncthreads();
+        unsigned long long off = s_prefix + before;
+        unsigned long long rest = 0;  // hit slots this kernel leaves to the queue kernel
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint64_t q = q0 + j;
+            if (q < m) {
+                hit_offsets[q] = off;
+                if (c[j] == 1u) {
+                    const uint4 rr = r[j];
+                    bool done = false;
+                    uint32_t pos = 0;
+                    if (rr.w & kRecResolved) {
+                        pos = rr.z;
+                        done = true;
+                    } else if (have_sa) {
+                        uint32_t row = rr.x, back = 0;
+                        if (rr.w & kRecMasked) {
+                            row = rr.x + static_cast<uint32_t>(__builtin_ctz(rr.z | 0x80000000u));
+                            back = rr.w & 0x1fffffu;
+                        } else if (rr.z != 0xffffffffu && rr.y - rr.x == 1u) {
+                            row = rr.z;
+                            back = rr.w & 0xffffffu;
+                        }
+                        const uint32_t sa = lv.sa_full != nullptr ? lv.sa_full[row]
+                                                                  : static_cast<const uint32_t *>(lv.jump)[static_cast<uint64_t>(row) * 8u + 6u];
+                        pos = sa - back;
+                        done = true;
+                    }
+                    if (done) {
+                        if (off < hits_capacity) store_hit<kWide>(ix, pos, hits_out, off, sentinels);
+                    } else {
+                        rest += 1u;
+                    }
+                } else {
+                    rest += c[j];
+                }
+            }
+            off += c[j];
+        }
+        for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o);
+        if ((threadIdx.x & 63u) == 0 && rest != 0ull) atomicAdd(totals + 1, rest);
+    }
+}
+
 unsigned grid_for_items(uint64_t items)
 {
     const uint64_t blocks = (items + kBlock - 1) / kBlock;
@@ -583,6 +720,38 @@ void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, u
     hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_rec, m, d_counts, d_status);
 }
 
+size_t scan_locate_workspace_bytes(uint64_t m)
+{
+    return align_up(((m + kScanTile - 1) / kScanTile + 1) * sizeof(unsigned long long), 256) + 256;
+}
+
+void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uint32_t max_hits, bool take,
+                        uint64_t *d_hit_offsets, void *d_hits, uint64_t hits_capacity, bool wide, void *d_workspace,
+                        unsigned long long *d_totals, hipStream_t stream)
+{
+    GDX_HIP(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), stream));
+    if (m == 0) {
+        GDX_HIP(hipMemsetAsync(d_hit_offsets, 0, sizeof(uint64_t), stream));
+        return;
+    }
+    const uint64_t n_tiles = (m + kScanTile - 1) / kScanTile;
+    const size_t state_bytes = align_up((n_tiles + 1) * sizeof(unsigned long long), 256);
+    unsigned long long *state = static_cast<unsigned long long *>(d_workspace);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(static_cast<char *>(d_workspace) + state_bytes);
+    GDX_HIP(hipMemsetAsync(d_workspace, 0, state_bytes + 256, stream));
+    const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.layout == 0 ? ix.sa_full : nullptr,
+                        ix.count, ix.sa_samples, ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride,
+                        ix.layout == 0 ? ix.jump_bytes : 0u, ix.n_texts, ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, 0u};
+    // a resident grid: every block takes tiles by ticket until they run out
+    const unsigned grid = static_cast<unsigned>(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
+    if (wide)
+        hipLaunchKernelGGL(scan_locate_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, lv, d_rec, m, max_hits, take ? 1u : 0u,
+                           d_hit_offsets, d_hits, hits_capacity, state, ticket, d_totals);
+    else
+        hipLaunchKernelGGL(scan_locate_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, lv, d_rec, m, max_hits, take ? 1u : 0u,
+                           d_hit_offsets, d_hits, hits_capacity, state, ticket, d_totals);
+}
+
 size_t locate_workspace_bytes(uint64_t total_hits)
 {
     return align_up(total_hits * sizeof(uint32_t), 256) + align_up(max_scan_temp_bytes(total_hits), 256) + 256;
@@ -591,7 +760,7 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk)
+                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -641,7 +810,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
                             ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
-                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits};
+                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, skip_single ? 1u : 0u};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
         // SA[row] inside the entries, or as an array of its own: no walk at all

@@ -344,6 +344,22 @@ int gdx_locate_many_offsets_capped_dev(const gdx_index_t *ix, const void *d_reco
                                        void *d_hit_offsets, void *stream);
 int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
                              uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
+/* gdx_locate_many_offsets_capped_dev AND the hits of every query with exactly one hit slot in ONE pass over the records
+ * (a single-pass scan with decoupled look-back whose tiles store those hits: a resolved record holds the position, any
+ * other single hit is one fetch of SA[row] on an index that has it).  d_hits must be offered before the total is known:
+ * hits at or beyond hits_capacity are not stored.  d_totals (u64[2], device): [0] = all hit slots (= d_hit_offsets[nq]),
+ * [1] = slots this pass left open (queries with several hits; single hits that need a locate walk).  The caller reads
+ * d_totals back (the one host round trip of a count + locate step) and then
+ *   totals[0] > hits_capacity: grows its buffer and calls gdx_locate_many_hits_dev (the offsets are valid);
+ *   totals[1] != 0:            calls gdx_locate_many_hits_rest_dev, which fills in exactly the open slots;
+ *   else:                      is done.
+ * d_scan_workspace: gdx_locate_many_scan_workspace_bytes(nq) bytes. */
+uint64_t gdx_locate_many_scan_workspace_bytes(uint64_t nq);
+int gdx_locate_many_scan_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
+                                  void *d_hit_offsets, void *d_hits, uint64_t hits_capacity, void *d_scan_workspace,
+                                  void *d_totals, void *stream);
+int gdx_locate_many_hits_rest_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
+                                  uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream);
 

@@ -461,3 +461,53 @@ def test_partitioned_index_equals_one_index_on_counts_and_hit_sets(depth):
     assert one.num_parts == 1
     off1, t1, p1, _ = one.locate_raw(qbuf, qoff, strict=False)
     assert off1.tolist() == co.tolist() and t1.tolist() == ct.tolist() and p1.tolist() == cp.tolist()
+
+
+@pytest.mark.parametrize("build", [dict(), dict(jump_entry_bytes=16), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=7,
+                                                                           full_suffix_array=True, text_units=True),
+                                   dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=5, text_units=True)])
+def test_scan_and_single_hits_in_one_pass(build):
+    """gdx_locate_many_scan_hits_dev (+ gdx_locate_many_hits_rest_dev): offsets and the hits of single-hit queries in one
+    pass over the records, the rest by the queue kernel -- the same offsets and hits as the three-call protocol and the
+    oracle, for indexes with SA[row] at hand (32-byte entries, full suffix array) and without, with a hit buffer that is
+    large enough and one that is too small."""
+    import torch
+
+    from genedex_amd import FmIndexConfig
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(808)
+    a = alph.ascii_dna_with_n()
+    body = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 40000))
+    texts = [body[:30000], body[5000:9000] + b"NNNN" + body[100:3000], b"A" * 300 + body[200:6000]]
+    g = FmIndexConfig("u32").acceleration_structures(**build).construct_index(texts, a)
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=0, width=32)
+    qs = [body[s:s + int(rng.integers(16, 70))] for s in rng.integers(0, 39000, 5000)]
+    qs += [bytes(b"ACGT"[i] for i in rng.integers(0, 4, 20)) for _ in range(500)] + [b"A" * 20, b"", b"ACGTNACG"]
+    qbuf, qoff = pack_queries(qs)
+    co, ct, cp = c.locate_many(qs)
+    dq = DeviceQueries.from_host(qbuf, qoff)
+    eng = DeviceEngine(g)
+    nq = dq.nq
+    rec = eng.alloc_records(nq)
+    eng.locate_search(dq, rec)
+    total = int(co[-1])
+    for capacity in (total + 7, total // 2):
+        off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
+        hits = torch.full((max(capacity, 1), 2), -1, dtype=torch.int32, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        sws = torch.empty(max(eng.scan_workspace_bytes(nq), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_scan_hits(rec, nq, off, hits, capacity, sws, totals)
+        tot, rest = (int(x) for x in totals.tolist())
+        assert tot == total and off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+        if tot > capacity:  # the caller grows its buffer and locates everything with the offsets it has
+            hits = torch.empty((tot, 2), dtype=torch.int32, device="cuda")
+            ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+            eng.locate_hits(rec, nq, off, tot, hits, ws)
+        elif rest:
+            ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+            eng.locate_hits_rest(rec, nq, off, tot, hits, ws)
+        torch.cuda.synchronize()
+        h = hits[:tot].cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), (build, capacity)
+        assert rest > 0  # the poly-A query alone has hundreds of hits
