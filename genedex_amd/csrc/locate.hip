@@ -555,26 +555,36 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
             if (wv < (threadIdx.x >> 6)) before += v;
             tile_total += v;
         }
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64u) {
+            // the tile's first wavefront looks back 64 predecessors at a time: the tiles in flight all start with an
+            // aggregate only, so a tile sums up to a few thousand of them before it meets one that knows its prefix (one
+            // lane walking them one by one made the pass 20 ms instead of 1)
+            const uint32_t lane = threadIdx.x;
             unsigned long long prefix = 0;
-            if (tile == 0) {
-                __atomic_store_n(tile_state, kTilePrefix | tile_total, __ATOMIC_RELEASE);
-            } else {
-                __atomic_store_n(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELEASE);
-                for (uint64_t p = tile; p-- > 0;) {  // look back: sum aggregates until a tile that knows its inclusive prefix
-                    unsigned long long v;
+            if (tile != 0 && lane == 0) __atomic_store_n(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELEASE);
+            long long p = static_cast<long long>(tile) - 1 - static_cast<long long>(lane);
+            for (;;) {
+                unsigned long long v = kTilePrefix;  // before tile 0: an inclusive prefix of 0
+                if (p >= 0) {
                     do {
                         v = __atomic_load_n(tile_state + p, __ATOMIC_ACQUIRE);
                     } while ((v >> 62) == 0ull);
-                    prefix += v & kTileValue;
-                    if ((v >> 62) == 2ull) break;
                 }
-                __atomic_store_n(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELEASE);
+                const unsigned long long is_prefix = __ballot((v >> 62) == 2ull);
+                const int first = is_prefix ? __ffsll(static_cast<long long>(is_prefix)) - 1 : 64;
+                unsigned long long part = static_cast<int>(lane) <= first ? v & kTileValue : 0ull;
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                prefix += part;
+                if (is_prefix) break;
+                p -= 64;
             }
-            s_prefix = prefix;
-            if (tile == n_tiles - 1) {
-                hit_offsets[m] = prefix + tile_total;
-                totals[0] = prefix + tile_total;
+            if (lane == 0) {
+                __atomic_store_n(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELEASE);
+                s_prefix = prefix;
+                if (tile == n_tiles - 1) {
+                    hit_offsets[m] = prefix + tile_total;
+                    totals[0] = prefix + tile_total;
+                }
             }
         }
         __syncthreads();
