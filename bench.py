@@ -289,8 +289,10 @@ class StepRunner:
         self.hits, self.ws = [], []
         self.ev_search, self.ev_locate = [], []
         self.sized_in_step = True  # the timed step reads the number of hits back and sizes the hit buffer itself
-        # records path: offsets and single-hit locate in ONE pass over the records (gdx_locate_many_scan_hits_dev)
-        self.fused_scan = self.use_rec and os.environ.get("GDX_BENCH_NO_FUSED_SCAN") != "1"
+        # records path, optional (GDX_BENCH_FUSED_SCAN=1): offsets and single-hit locate in ONE pass over the records
+        # (gdx_locate_many_scan_hits_dev).  Measured 1.7 ms against 1.33 ms for the two streaming passes it replaces (the
+        # look-back of a single-pass scan crosses XCDs; profiles/r03/experiments.md section 8), so it is not the default.
+        self.fused_scan = self.use_rec and os.environ.get("GDX_BENCH_FUSED_SCAN") == "1"
         self.scan_ws, self.totals = [], []
         self.ev_scan = []
 

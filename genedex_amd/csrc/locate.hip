@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
 {
     constexpr uint32_t kPer = kScanTile / kBlock;  // consecutive queries per thread (one 128-byte line of records)
     __shared__ uint32_t s_tile;
-    __shared__ unsigned long long s_warp[kBlock / 64];
+    __shared__ unsigned long long s_warp[(kScanTile / kBlock) * (kBlock / 64)];
     __shared__ unsigned long long s_prefix;
     constexpr uint32_t kLdsTexts = 256;
     __shared__ uint32_t s_sentinels[kLdsTexts];
@@ -528,46 +528,55 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
         __syncthreads();
         const uint64_t tile = s_tile;
         if (tile >= n_tiles) break;
-        const uint64_t q0 = tile * kScanTile + static_cast<uint64_t>(threadIdx.x) * kPer;
+        // striped arrangement: thread t holds queries j * 256 + t of the tile (j = 0 .. 7), so that record loads, offset
+        // stores and hit stores of a wavefront touch consecutive memory; the scan is done row by row
+        const uint64_t q0 = tile * kScanTile + threadIdx.x;
         uint4 r[kPer];
         uint32_t c[kPer];
-        unsigned long long mine = 0;
+        unsigned long long incl[kPer];
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j++) {
-            const uint64_t q = q0 + j;
+            const uint64_t q = q0 + static_cast<uint64_t>(j) * kBlock;
             r[j] = q < m ? rec[q] : make_uint4(0u, 0u, 0u, 0u);
             uint32_t cnt = r[j].y - r[j].x;
             if (max_hits != 0u && cnt > max_hits) cnt = take ? max_hits : 0u;  // RecordSize
             c[j] = cnt;
-            mine += cnt;
+            unsigned long long x = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long o = __shfl_up(x, off);
+                if (static_cast<int>(threadIdx.x & 63u) >= off) x += o;
+            }
+            incl[j] = x;
+            if ((threadIdx.x & 63u) == 63u) s_warp[j * (kBlock / 64) + (threadIdx.x >> 6)] = x;
         }
-        // block-wide exclusive scan of the per-thread sums
-        unsigned long long incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long o = __shfl_up(incl, off);
-            if (static_cast<int>(threadIdx.x & 63u) >= off) incl += o;
-        }
-        if ((threadIdx.x & 63u) == 63u) s_warp[threadIdx.x >> 6] = incl;
         __syncthreads();
-        unsigned long long before = incl - mine, tile_total = 0;
-        for (uint32_t wv = 0; wv < kBlock / 64; wv++) {
-            const unsigned long long v = s_warp[wv];
-            if (wv < (threadIdx.x >> 6)) before += v;
-            tile_total += v;
+        unsigned long long before[kPer], tile_total = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            unsigned long long row_before = 0, row_total = 0;
+            for (uint32_t wv = 0; wv < kBlock / 64; wv++) {
+                const unsigned long long v = s_warp[j * (kBlock / 64) + wv];
+                if (wv < (threadIdx.x >> 6)) row_before += v;
+                row_total += v;
+            }
+            before[j] = tile_total + row_before + incl[j] - c[j];
+            tile_total += row_total;
         }
         if (threadIdx.x < 64u) {
+            // (the flag travels in the same 64-bit word as the value, so relaxed device-scope atomics are all the protocol
+            // needs: acquire / release at system scope made every poll an L2 invalidation on this multi-XCD chip)
             // the tile's first wavefront looks back 64 predecessors at a time: the tiles in flight all start with an
             // aggregate only, so a tile sums up to a few thousand of them before it meets one that knows its prefix (one
             // lane walking them one by one made the pass 20 ms instead of 1)
             const uint32_t lane = threadIdx.x;
             unsigned long long prefix = 0;
-            if (tile != 0 && lane == 0) __atomic_store_n(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELEASE);
+            if (tile != 0 && lane == 0) __hip_atomic_store(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long p = static_cast<long long>(tile) - 1 - static_cast<long long>(lane);
             for (;;) {
                 unsigned long long v = kTilePrefix;  // before tile 0: an inclusive prefix of 0
                 if (p >= 0) {
                     do {
-                        v = __atomic_load_n(tile_state + p, __ATOMIC_ACQUIRE);
+                        v = __hip_atomic_load(tile_state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } while ((v >> 62) == 0ull);
                 }
                 const unsigned long long is_prefix = __ballot((v >> 62) == 2ull);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
                 p -= 64;
             }
             if (lane == 0) {
-                __atomic_store_n(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELEASE);
+                __hip_atomic_store(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_prefix = prefix;
                 if (tile == n_tiles - 1) {
                     hit_offsets[m] = prefix + tile_total;
@@ -588,11 +597,12 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
             }
         }
         __syncthreads();
-        unsigned long long off = s_prefix + before;
+        const unsigned long long tile_base = s_prefix;
         unsigned long long rest = 0;  // hit slots this kernel leaves to the queue kernel
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j++) {
-            const uint64_t q = q0 + j;
+            const uint64_t q = q0 + static_cast<uint64_t>(j) * kBlock;
+            const unsigned long long off = tile_base + before[j];
             if (q < m) {
                 hit_offsets[q] = off;
                 if (c[j] == 1u) {
@@ -625,7 +635,6 @@ __global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, cons
                     rest += c[j];
                 }
             }
-            off += c[j];
         }
         for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o);
         if ((threadIdx.x & 63u) == 0 && rest != 0ull) atomicAdd(totals + 1, rest);
@@ -753,7 +762,9 @@ void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uin
                         ix.count, ix.sa_samples, ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride,
                         ix.layout == 0 ? ix.jump_bytes : 0u, ix.n_texts, ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, 0u};
     // a resident grid: every block takes tiles by ticket until they run out
-    const unsigned grid = static_cast<unsigned>(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
+    static const long grid_env = [] { const char *e = getenv("GDX_SCAN_GRID"); return e ? atol(e) : 0L; }();  // experiments
+    const uint64_t grid_cap = grid_env > 0 ? static_cast<uint64_t>(grid_env) : 256u * 8u;
+    const unsigned grid = static_cast<unsigned>(n_tiles < grid_cap ? n_tiles : grid_cap);
     if (wide)
         hipLaunchKernelGGL(scan_locate_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, lv, d_rec, m, max_hits, take ? 1u : 0u,
                            d_hit_offsets, d_hits, hits_capacity, state, ticket, d_totals);
