@@ -1155,29 +1155,6 @@ __device__ __forceinline__ FastWindow fast_window(const View &ix, const uint8_t 
     return fast_window_finish<kXlate>(ix, s_dense, fast_window_load<kXlate>(wbase, off0, rem, sub), off0, rem, sub);
 }
 
-// the same from query words staged in LDS (search_exact_kernel4, cursor calls): `words` = the kStageWords aligned 8-byte
-// words from the one that holds the string's first byte
-constexpr uint32_t kStageWords = 5;  // a 32-symbol chunk at any alignment: at most five words (7 + 32 bytes)
-template <int kXlate, class View>
-__device__ __forceinline__ FastWindow fast_window_staged(const View &ix, const uint8_t *s_dense, const uint64_t *words,
-                                                         uint32_t off0, uint32_t rem, uint32_t sub)
-{
-    const uint32_t b = off0 + rem - 1u;
-    const int32_t first = static_cast<int32_t>(b >> 3) - static_cast<int32_t>(sub) * 2;
-    u32x4 raw = {0u, 0u, 0u, 0u};
-    if (first >= 0 && first < static_cast<int32_t>(kStageWords)) {
-        const uint64_t r0 = words[first];
-        raw.z = static_cast<uint32_t>(r0);
-        raw.w = static_cast<uint32_t>(r0 >> 32);
-    }
-    if (first >= 1 && first <= static_cast<int32_t>(kStageWords)) {
-        const uint64_t r1 = words[first - 1];
-        raw.x = static_cast<uint32_t>(r1);
-        raw.y = static_cast<uint32_t>(r1 >> 32);
-    }
-    return fast_window_finish<kXlate>(ix, s_dense, raw, off0, rem, sub);
-}
-
 // kWide: intervals of up to sixteen rows (four per lane, one load round each) instead of four -- chosen per index
 // (launch_search_call): on a text without repeats almost no read needs it and the loops cost the others 3 %
 template <int kJump, int kXlate, bool kWide>
@@ -1609,8 +1586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     constexpr bool kHalf2 = kJump == 32;
     constexpr uint32_t kRangeCap = kCursor ? kCursorRange : kMaxRange;
     __shared__ uint8_t s_dense[256];
-    // (cursor calls flush their leftovers stage by stage: 7 blocks per CU need the LDS)
-    __shared__ uint32_t s_left[kCursor ? kBlock : kRangeCap];
+    __shared__ uint32_t s_left[kRangeCap];
     __shared__ uint32_t s_nleft, s_left_base;
     __shared__ uint32_t s_alive[kCursor ? kCursorRange : 1];  // flush_live_ordered
     __shared__ uint32_t s_alive_part[kCursor ? kBlock : 1];
@@ -1618,7 +1594,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     __shared__ uint32_t s_stage_q[kCursor ? kBlock : 1], s_stage_lo[kCursor ? kBlock : 1], s_stage_hi[kCursor ? kBlock : 1],
         s_stage_len[kCursor ? kBlock : 1];
     __shared__ uint64_t s_stage_begin[kCursor ? kBlock : 1];
-    __shared__ uint64_t s_stage_words[kCursor ? kBlock * kStageWords : 1];  // the string's bytes when they fit (bit 29 of len)
     __shared__ uint16_t s_perm[kCursor ? 1 : kMaxRange];  // order_range_by_length (fused searches of mixed lengths)
     __shared__ uint32_t s_cnt[kLenBuckets];
     __shared__ uint32_t s_minmax[2];
@@ -1669,17 +1644,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 s_stage_lo[threadIdx.x] = clo;
                 s_stage_hi[threadIdx.x] = chi;
                 s_stage_begin[threadIdx.x] = cb;
-                // the string's bytes too when it fits kStageWords words (a chunk of up to 32 symbols always does): the third
-                // link of the chain
-                const bool fits = !cbail && clen != 0u && ((cb & 7u) + clen + 7u) / 8u <= kStageWords;
-                if (fits) {
-                    const uint64_t *src = reinterpret_cast<const uint64_t *>(qbuf) + (cb >> 3);
-                    const uint32_t n_words = static_cast<uint32_t>(((cb & 7u) + clen + 7u) / 8u);
-#pragma unroll
-                    for (uint32_t k = 0; k < kStageWords; k++) s_stage_words[threadIdx.x * kStageWords + k] = k < n_words ? src[k] : 0ull;
-                }
-                s_stage_len[threadIdx.x] = (cbail ? 0u : static_cast<uint32_t>(clen)) | (fits ? 1u << 29 : 0u) | (more ? 1u << 30 : 0u) |
-                                           (cbail ? 1u << 31 : 0u);
+                s_stage_len[threadIdx.x] = (cbail ? 0u : static_cast<uint32_t>(clen)) | (more ? 1u << 30 : 0u) | (cbail ? 1u << 31 : 0u);
             }
             __syncthreads();
         }
@@ -1687,7 +1652,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             uint32_t q, lo = 0, hi = ix.n;
             uint64_t begin, len;
             bool more_left = true, bail;
-            const uint64_t *staged_words = nullptr;  // cursor calls: the string's words in LDS
             if (kCursor) {
                 const uint32_t k = slot - s0;
                 const uint32_t packed = s_stage_len[k];
@@ -1695,8 +1659,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 lo = s_stage_lo[k];
                 hi = s_stage_hi[k];
                 begin = s_stage_begin[k];
-                len = packed & 0x1fffffffu;
-                staged_words = ((packed >> 29) & 1u) != 0u ? s_stage_words + k * kStageWords : nullptr;
+                len = packed & 0x3fffffffu;
                 more_left = ((packed >> 30) & 1u) != 0u;
                 bail = (packed >> 31) != 0u;
             } else {
@@ -1716,8 +1679,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             bool fresh = false;   // the window is positioned: symbol rem - 1 is symbol `part` of its level `shift`
             bool jump_ok = kJump != 0 && ix.jump != nullptr;
             if (!bail && empty_cursor && ix.top != nullptr && rem >= 16u && rem >= depth) {
-                w = (kCursor && staged_words != nullptr) ? fast_window_staged<kXlate>(ix, s_dense, staged_words, off0, rem, sub)
-                                                          : fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
+                w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                 const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
                 if ((w.valid8 & need) != need) {
                     bail = true;
@@ -1741,8 +1703,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 // the window must hold what this round reads: whole levels from an aligned position for a jump (levels
                 // 0 .. 6 of a window are always inside its eight words), one or two symbols for a pair step
                 if (!fresh || (jumping ? (part != 0u || shift > 2u) : shift > 6u)) {
-                    w = (kCursor && staged_words != nullptr) ? fast_window_staged<kXlate>(ix, s_dense, staged_words, off0, rem, sub)
-                                                          : fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
+                    w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                     shift = 0;
                     part = 0;
                 }
@@ -1898,7 +1859,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 }
             }
         }
-        // the leftover queries of the stage (cursor calls) / the range: one atomic, coalesced stores
+        }  // stages
+        // the range's leftover queries: one atomic, coalesced stores; its live cursors: one atomic, in position order
         __syncthreads();
         const uint32_t n_left = s_nleft;
         if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
@@ -1906,8 +1868,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
         for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
         __syncthreads();
         if (threadIdx.x == 0) s_nleft = 0;
-        }  // stages
-        // the range's live cursors: one atomic, in position order
         if (kCursor && ca.active_out != nullptr)
             flush_live_ordered(s_alive, cnt, s_alive_part, &s_alive_base, ca.active_out, ca.n_active_out);
     }
