@@ -130,6 +130,7 @@ SIGNATURES = {
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
+    "gdx_debug_force_wide": [C.c_int],
     "gdx_locate_many_scan_workspace_bytes": [C.c_uint64],
     "gdx_locate_many_scan_hits_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_hits_rest_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],

@@ -69,6 +69,7 @@ void *stream_scratch(hipStream_t stream, int slot, size_t bytes)
 
 struct gdx_index {
     std::unique_ptr<gdx::FmIndex> impl;
+    std::unique_ptr<gdx::WideIndex> wide;  // index storage beyond 32 bits (wide.hip): exactly one of the two is set
 };
 
 struct gdx_multi {
@@ -131,8 +132,20 @@ gdx::IndexConfig make_config(const uint8_t *io_to_dense, int sigma, int n_search
 
 const gdx::FmIndex &deref(const gdx_index_t *ix)
 {
+    if (ix && ix->wide)
+        gdx::fail(GDX_ERR_UNSUPPORTED, "this call is not available on an index with 64-bit storage (count, cursors_for_many_queries "
+                                       "and locate on host pointers are)");
     if (!ix || !ix->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "index handle is null");
     return *ix->impl;
+}
+
+// index_width 64 and a collection that does not fit 32-bit rows (or gdx_debug_force_wide): the 64-bit engine of wide.hip
+std::atomic<int> g_force_wide{0};
+bool wants_wide(const uint64_t *text_offsets, uint64_t n_texts, int index_width)
+{
+    if (index_width != 64 || !text_offsets || n_texts == 0) return false;
+    const uint64_t n = text_offsets[n_texts] - text_offsets[0] + n_texts;
+    return n > 0xffffffffull || g_force_wide.load() != 0;
 }
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
@@ -279,8 +292,13 @@ int gdx_index_build_ex(const uint8_t *texts_buf, const uint64_t *text_offsets, u
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
         auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
+        if (wants_wide(text_offsets, n_texts, index_width)) {
+            DeviceGuard guard(device_id);
+            *out = new gdx_index{nullptr, gdx::WideIndex::construct_index(texts_buf, false, text_offsets, n_texts, cfg)};
+            return (int)GDX_OK;
+        }
         auto impl = gdx::FmIndex::construct_index(texts_buf, false, text_offsets, n_texts, cfg);
-        *out = new gdx_index{std::move(impl)};
+        *out = new gdx_index{std::move(impl), nullptr};
         return (int)GDX_OK;
     });
 }
@@ -301,9 +319,15 @@ int gdx_index_build_dev_ex(const void *d_texts_buf, const uint64_t *text_offsets
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
         auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
+        if (wants_wide(text_offsets, n_texts, index_width)) {
+            DeviceGuard guard(device_id);
+            *out = new gdx_index{nullptr, gdx::WideIndex::construct_index(static_cast<const uint8_t *>(d_texts_buf), true,
+                                                                          text_offsets, n_texts, cfg)};
+            return (int)GDX_OK;
+        }
         auto impl = gdx::FmIndex::construct_index(static_cast<const uint8_t *>(d_texts_buf), true, text_offsets,
                                                   n_texts, cfg);
-        *out = new gdx_index{std::move(impl)};
+        *out = new gdx_index{std::move(impl), nullptr};
         return (int)GDX_OK;
     });
 }
@@ -331,7 +355,7 @@ int gdx_index_from_parts_ex2(int table_kind, int block_bits, const uint64_t *cou
         auto cfg = make_config(io_to_dense, sigma, n_searchable, sa_rate, lookup_depth, index_width, device_id, opts);
         auto impl = gdx::FmIndex::from_parts(table_kind, block_bits, count, interleaved_blocks, n, sa_samples,
                                              border_keys, border_vals, sentinel_indices, n_texts, cfg);
-        *out = new gdx_index{std::move(impl)};
+        *out = new gdx_index{std::move(impl), nullptr};
         return (int)GDX_OK;
     });
 }
@@ -366,7 +390,7 @@ int gdx_index_load_ex(const char *path, int device_id, const gdx_build_options_t
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
         auto impl = gdx::FmIndex::load(path, device_id, make_build_options(opts));
-        *out = new gdx_index{std::move(impl)};
+        *out = new gdx_index{std::move(impl), nullptr};
         return (int)GDX_OK;
     });
 }
@@ -378,6 +402,10 @@ void gdx_index_free(gdx_index_t *ix)
         if (ix->impl) {
             DeviceGuard guard(ix->impl->config().device_id);  // the caller's current device is left as it was
             ix->impl.reset();
+        }
+        if (ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            ix->wide.reset();
         }
         delete ix;
         return (int)GDX_OK;
@@ -456,6 +484,21 @@ int gdx_index_rebuild_aux(gdx_index_t *ix, const gdx_build_options_t *opts)
 int gdx_index_info(const gdx_index_t *ix, gdx_index_info_t *out)
 {
     return guarded([&] {
+        if (ix && ix->wide) {
+            if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+            const gdx::WideIndex &w = *ix->wide;
+            out->total_text_len = w.total_text_len();
+            out->num_texts = w.num_texts();
+            out->sigma = w.config().sigma;
+            out->n_searchable = w.config().n_searchable;
+            out->lookup_depth = w.config().lookup_depth;
+            out->index_width = 64;
+            out->sa_rate = w.config().sa_rate;
+            out->device_bytes = w.device_bytes();
+            out->device_id = w.config().device_id;
+            out->table_layout = 0;
+            return (int)GDX_OK;
+        }
         const gdx::FmIndex &f = deref(ix);
         if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
         out->total_text_len = f.total_text_len();
@@ -498,7 +541,17 @@ int gdx_index_build_stats(const gdx_index_t *ix, gdx_build_stats_t *out)
     })
 
 int gdx_index_export_count(const gdx_index_t *ix, uint64_t *count) { GDX_EXPORT(count, f.export_count(count)); }
-int gdx_index_export_bwt(const gdx_index_t *ix, uint8_t *bwt) { GDX_EXPORT(bwt, f.export_bwt(bwt)); }
+int gdx_index_export_bwt(const gdx_index_t *ix, uint8_t *bwt)
+{
+    if (ix && ix->wide)
+        return guarded([&] {
+            if (!bwt) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "bwt is null");
+            DeviceGuard guard(ix->wide->config().device_id);
+            ix->wide->export_bwt(bwt);
+            return (int)GDX_OK;
+        });
+    GDX_EXPORT(bwt, f.export_bwt(bwt));
+}
 int gdx_index_export_sa_samples(const gdx_index_t *ix, uint32_t *s) { GDX_EXPORT(sa, f.export_sa_samples(s)); }
 int gdx_index_export_borders(const gdx_index_t *ix, uint64_t *k, uint64_t *v) { GDX_EXPORT(b, f.export_borders(k, v)); }
 int gdx_index_export_sentinel_indices(const gdx_index_t *ix, uint64_t *o) { GDX_EXPORT(s, f.export_sentinel_indices(o)); }
@@ -527,6 +580,10 @@ int gdx_count_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *q
 {
     return guarded([&] {
         if (!out_counts && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_counts is null");
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->cursors_for_many_queries(qbuf, qoff, nq, nullptr, nullptr, out_counts, out_status);
+        }
         return deref(ix).cursors_for_many_queries(qbuf, qoff, nq, nullptr, nullptr, out_counts, out_status);
     });
 }
@@ -536,6 +593,10 @@ int gdx_cursors_for_many_queries(const gdx_index_t *ix, const uint8_t *qbuf, con
 {
     return guarded([&] {
         if ((!out_start || !out_end) && nq) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_start / out_end is null");
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->cursors_for_many_queries(qbuf, qoff, nq, out_start, out_end, nullptr, out_status);
+        }
         return deref(ix).cursors_for_many_queries(qbuf, qoff, nq, out_start, out_end, nullptr, out_status);
     });
 }
@@ -545,6 +606,10 @@ int gdx_locate_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *
                     uint8_t *out_status)
 {
     return guarded([&] {
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->locate_many(qbuf, qoff, nq, out_hit_offsets, hits, hits ? hits_capacity : 0, out_total, out_status);
+        }
         return deref(ix).locate_many(qbuf, qoff, nq, out_hit_offsets, hits, hits_capacity, out_total, out_status);
     });
 }
@@ -553,6 +618,10 @@ int gdx_locate_many_alloc(const gdx_index_t *ix, const uint8_t *qbuf, const uint
                           uint64_t *out_hit_offsets, gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status)
 {
     return guarded([&] {
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->locate_many_alloc(qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
+        }
         return deref(ix).locate_many_alloc(qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status);
     });
 }
@@ -562,8 +631,13 @@ void gdx_free_hits(gdx_hit_t *hits) { std::free(hits); }
 int gdx_cursor_empty(const gdx_index_t *ix, uint64_t *start, uint64_t *end)
 {
     return guarded([&] {
-        const gdx::FmIndex &f = deref(ix);
         if (!start || !end) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+        if (ix && ix->wide) {
+            *start = 0;
+            *end = ix->wide->total_text_len();
+            return (int)GDX_OK;
+        }
+        const gdx::FmIndex &f = deref(ix);
         *start = 0;  // lib.rs:202-210
         *end = f.total_text_len();
         return (int)GDX_OK;
@@ -1109,6 +1183,12 @@ int gdx_bench_lf_walk_dev(const gdx_index_t *ix, const void *d_rows, uint64_t m,
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
+}
+
+int gdx_debug_force_wide(int on)
+{
+    g_force_wide.store(on != 0 ? 1 : 0);
+    return GDX_OK;
 }
 
 int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])

@@ -800,6 +800,18 @@ __global__ __launch_bounds__(kBlock) void check_parts_kernel(const uint32_t *__r
         if (bwt[border_keys[i]] != 0) atomicOr(flag, 2u);
 }
 
+}  // namespace
+
+// rank lines + per-superblock symbol totals of a zero padded BWT (used by the wide index too, wide.hip)
+void launch_build_lines(const uint8_t *d_bwt_padded, uint64_t n, uint64_t n_lines, u32x4 *d_lines, uint32_t *d_sb_totals,
+                        uint64_t n_sb, hipStream_t stream)
+{
+    hipLaunchKernelGGL(build_lines_kernel, dim3(static_cast<unsigned>(n_sb)), dim3(kBlock), 0, stream, d_bwt_padded, n, n_lines,
+                       d_lines, d_sb_totals);
+}
+
+namespace {
+
 int ilog2_ceil(uint64_t v)  // condensed.rs:417-419
 {
     int bits = 0;

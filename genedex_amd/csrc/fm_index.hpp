@@ -207,6 +207,35 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
 int multi_locate_alloc(Multi &m, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                        gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status);
 
+void launch_build_lines(const uint8_t *d_bwt_padded, uint64_t n, uint64_t n_lines, u32x4 *d_lines, uint32_t *d_sb_totals,
+                        uint64_t n_sb, hipStream_t stream);
+
+// Index storage beyond 32 bits (wide.hip): rows and text positions are 64-bit; the reference's own arrays only (rank lines,
+// u64 superblock offsets, sampled suffix array, borders) and one-lane-per-query kernels -- the functional equivalent
+// of `IndexStorage for i64` (construction/mod.rs:225-252), not a fast path.
+class WideIndex {
+public:
+    static std::unique_ptr<WideIndex> construct_index(const uint8_t *texts_buf, bool texts_on_device,
+                                                      const uint64_t *text_offsets, uint64_t n_texts, const IndexConfig &cfg);
+    ~WideIndex();
+    const IndexConfig &config() const;
+    uint64_t total_text_len() const;
+    uint64_t num_texts() const;
+    uint64_t device_bytes() const;
+    int cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start, uint64_t *out_end,
+                                 uint64_t *out_count, uint8_t *out_status) const;
+    int locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets, gdx_hit_t *hits,
+                    uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
+    int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
+                          gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
+    void export_bwt(uint8_t *bwt) const;
+
+private:
+    WideIndex();
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+};
+
 // A collection beyond 2^32 - 1 symbols as several 32-bit indexes cut at text borders (parts.hip, gdx_parts_*)
 struct Parts {
     std::vector<std::unique_ptr<FmIndex>> parts;

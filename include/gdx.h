@@ -15,8 +15,15 @@
  *    `_dev` entry points take DEVICE pointers plus a hipStream_t (passed as void*) and
  *    enqueue work without synchronising.
  *  - counts, positions and SA indices are uint64_t at the host ABI (usize in the reference).
- *    Inside, and in the `_dev` entry points, they are uint32_t: this build supports
- *    index storage types i32 and u32 (n <= 2^32-1); i64 is accepted when n fits.
+ *    Inside, and in the `_dev` entry points, they are uint32_t for index storage types i32 and
+ *    u32 (n <= 2^32-1) and for i64 when n fits.  index_width 64 with a collection that does NOT
+ *    fit (the reference: IndexStorage for i64, construction/mod.rs:225-252) builds an index with
+ *    64-bit rows on the reference's own arrays (wide.hip): gdx_index_build[_dev][_ex],
+ *    gdx_index_info, gdx_count_many, gdx_cursors_for_many_queries, gdx_locate_many[_alloc],
+ *    gdx_cursor_empty and gdx_index_export_bwt serve it (same intervals, counts, hits and hit order
+ *    as the reference's algorithm; lookup depth 0, alphabets of up to 7 symbols + sentinel; a plain
+ *    engine, ~25x slower than the 32-bit one); every other call returns GDX_ERR_UNSUPPORTED on it.
+ *    Collections that split at text borders are served faster by the partitioned index (gdx_parts_*).
  *  - a set of queries is one byte buffer `qbuf` plus `qoff[nq+1]` byte offsets
  *    (query i = qbuf[qoff[i] .. qoff[i+1])), IO symbols (ASCII), any mix of lengths.
  */

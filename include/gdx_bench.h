@@ -43,6 +43,9 @@ int gdx_synth_queries_dev(const void *d_io_text, const void *d_text_offsets, uin
  * All variants return identical results; the switch exists for A/B measurements and parity tests. */
 int gdx_debug_set_search_variant(int variant);
 
+/* tests: index_width 64 takes the 64-bit engine (wide.hip) even when the collection would fit 32-bit rows */
+int gdx_debug_force_wide(int on);
+
 /* chunk size of the pipeline behind the host-pointer query calls (queries and query bytes per chunk; 0 = default
  * 2^20 queries / 32 MB): tests force many small chunks through it */
 int gdx_debug_set_host_chunking(uint64_t queries, uint64_t bytes);

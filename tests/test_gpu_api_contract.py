@@ -511,3 +511,59 @@ def test_scan_and_single_hits_in_one_pass(build):
         h = hits[:tot].cpu().numpy().astype(np.uint32)
         assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), (build, capacity)
         assert rest > 0  # the poly-A query alone has hundreds of hits
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wide_index_equals_oracle_i64(seed):
+    """Index storage beyond 32 bits (wide.hip; the reference's IndexStorage for i64): the 64-bit engine forced onto small
+    inputs -- suffix sorter by plain prefix doubling on 64-bit ranks, u64 superblock offsets and samples -- must give the
+    oracle's BWT, intervals (also frozen empty ones), statuses, counts and hits in the oracle's order."""
+    from genedex_amd import FmIndexConfig, GdxError, _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(9100 + seed)
+    a = alph.ascii_dna_with_n()
+    if seed == 0:
+        texts = random_texts(rng, len_max=30000, symbols=b"ACGTN")
+    elif seed == 1:  # repeats: many doubling rounds
+        unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 301))
+        texts = [unit * 40, b"A" * 3000, unit[:100] * 7, b""]
+    elif seed == 2:  # more than one superblock, sentinels inside
+        texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, 70000, p=[.2475, .2475, .2475, .2475, .01])) for _ in range(3)]
+    else:
+        texts = [b"", b"A", b"ACGT", b"", b"NNNN", bytes(b"ACGT"[i] for i in rng.integers(0, 4, 5000))]
+    rate = [4, 1, 7, 3][seed]
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=rate, lookup_depth=0, width=64)
+    lib.gdx_debug_force_wide(1)
+    try:
+        g = FmIndexConfig("i64").suffix_array_sampling_rate(rate).construct_index(texts, a)
+    finally:
+        lib.gdx_debug_force_wide(0)
+    assert g.info.index_width == 64 and g.total_text_len() == c.n and g.num_texts() == len(texts)
+    assert g.export_bwt().tobytes() == c.bwt.tobytes()
+    qs = [b"", b"A", b"ACXGT", b"NN", b"TNA"]
+    for _ in range(1500):
+        t = texts[int(rng.integers(0, len(texts)))]
+        if len(t):
+            pos = int(rng.integers(0, len(t)))
+            qs.append(t[pos:pos + int(rng.integers(0, 60))])
+        qs.append(bytes(b"ACGTN"[i] for i in rng.integers(0, 5, int(rng.integers(0, 12)))))
+    qbuf, qoff = pack_queries(qs)
+    s, e, st = g.cursors_raw(qbuf, qoff, strict=False)
+    cs, ce, cst = c.cursors_single(qbuf, qoff)
+    assert st.tolist() == cst.tolist()
+    ok = st == 0
+    assert s[ok].tolist() == cs[ok].tolist() and e[ok].tolist() == ce[ok].tolist()
+    counts, _ = g.count_raw(qbuf, qoff, strict=False)
+    assert counts[ok].tolist() == (ce - cs)[ok].tolist()
+    small = ok & ((ce - cs) < 5000)
+    keep = [q for q, k in zip(qs, small) if k]
+    kb, ko = pack_queries(keep)
+    co, ct, cp = c.locate_intervals(cs[small], ce[small])
+    for call in (g.locate_raw, g.locate_alloc_raw):
+        off, t_, p_, _ = call(kb, ko)
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+    assert g.cursor_empty().interval() == (0, c.n)
+    with pytest.raises(GdxError) as err:  # the rest of the ABI says so instead of misbehaving
+        g.rank_many([1], [0])
+    assert err.value.status == _lib.GDX_ERR_UNSUPPORTED

