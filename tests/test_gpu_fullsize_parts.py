@@ -79,7 +79,12 @@ def test_single_index_beyond_two_to_the_32():
     found = int((counts > 0).sum())
     assert 0.899 * nq < found < 0.9005 * nq
     s, e, st = g.cursors_raw(qbuf, qoff)
-    assert np.array_equal(e - s, counts) and int(e.max()) > (1 << 32)  # rows beyond 32 bits are in use
+    assert np.array_equal(e - s, counts)
+    # rows beyond 32 bits are in use: N is the largest symbol, so the suffixes that start with N are the last rows
+    ns, ne, _ = g.cursors_raw(*__import__("genedex_amd").pack_queries([b"N", b"NA"]))
+    assert int(ne[0]) == (1 << 32) + (1 << 20) and int(ns[0]) < (1 << 32) and int(ns[1]) > (1 << 32) - (1 << 26)
+    n_count = int((io_text == ord("N")).sum().item())
+    assert int(ne[0] - ns[0]) == n_count
     off, t, p, st = g.locate_alloc_raw(qbuf, qoff)
     assert not st.any() and int(off[-1]) == int(counts.sum()) == t.size
     assert int(p.max()) > (1 << 32) - (1 << 22)  # positions near the end of the 4 G text
