@@ -567,12 +567,29 @@ int gdx_index_export_condensed_table(const gdx_index_t *ix, uint64_t *blocks, ui
 
 int gdx_rank_many(const gdx_index_t *ix, const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out)
 {
-    return guarded([&] { return deref(ix).rank_many(symbols, idx, m, out); });
+    return guarded([&] {
+        if (ix && ix->wide) {
+            if (m != 0 && !symbols) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->rank_or_symbol_many(symbols, idx, m, out);
+        }
+        return deref(ix).rank_many(symbols, idx, m, out);
+    });
 }
 
 int gdx_symbol_at_many(const gdx_index_t *ix, const uint64_t *idx, uint64_t m, uint8_t *out)
 {
-    return guarded([&] { return deref(ix).symbol_at_many(idx, m, out); });
+    return guarded([&] {
+        if (ix && ix->wide) {
+            if (m != 0 && !out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+            DeviceGuard guard(ix->wide->config().device_id);
+            std::vector<uint64_t> wide_out(m);
+            const int rc = ix->wide->rank_or_symbol_many(nullptr, idx, m, wide_out.data());
+            for (uint64_t i = 0; i < m; i++) out[i] = static_cast<uint8_t>(wide_out[i]);
+            return rc;
+        }
+        return deref(ix).symbol_at_many(idx, m, out);
+    });
 }
 
 int gdx_count_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
@@ -647,14 +664,25 @@ int gdx_cursor_empty(const gdx_index_t *ix, uint64_t *start, uint64_t *end)
 int gdx_cursor_extend_front_many(const gdx_index_t *ix, uint64_t *start, uint64_t *end, const uint8_t *io_symbols,
                                  uint64_t m, uint8_t *out_status)
 {
-    return guarded([&] { return deref(ix).cursor_extend_front_many(start, end, io_symbols, m, out_status); });
+    return guarded([&] {
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->cursor_extend_front_many(start, end, io_symbols, m, out_status);
+        }
+        return deref(ix).cursor_extend_front_many(start, end, io_symbols, m, out_status);
+    });
 }
 
 int gdx_cursor_locate_many(const gdx_index_t *ix, const uint64_t *start, const uint64_t *end, uint64_t m,
                            uint64_t *out_hit_offsets, gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total)
 {
-    return guarded(
-        [&] { return deref(ix).cursor_locate_many(start, end, m, out_hit_offsets, hits, hits_capacity, out_total); });
+    return guarded([&] {
+        if (ix && ix->wide) {
+            DeviceGuard guard(ix->wide->config().device_id);
+            return ix->wide->cursor_locate_many(start, end, m, out_hit_offsets, hits, hits_capacity, out_total);
+        }
+        return deref(ix).cursor_locate_many(start, end, m, out_hit_offsets, hits, hits_capacity, out_total);
+    });
 }
 
 // ---- device-resident entry points ---------------------------------------------------------------------

@@ -228,6 +228,11 @@ public:
                     uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
     int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                           gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
+    int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m, uint8_t *out_status) const;
+    int cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets, gdx_hit_t *hits,
+                           uint64_t hits_capacity, uint64_t *out_total) const;
+    // rank(symbols[i], idx[i]) (symbols != null) or symbol_at(idx[i]) as u64 (symbols == null)
+    int rank_or_symbol_many(const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out) const;
     void export_bwt(uint8_t *bwt) const;
 
 private:

@@ -152,6 +152,51 @@ __global__ __launch_bounds__(kBlock) void wide_locate_kernel(WideView v, const u
     }
 }
 
+// Cursor::extend_query_front for m independent cursors (cursor.rs:34-51), one lane each
+__global__ __launch_bounds__(kBlock) void wide_extend_front_kernel(WideView v, uint64_t *__restrict__ start, uint64_t *__restrict__ end,
+                                                                   const uint8_t *__restrict__ io_symbols, uint64_t m,
+                                                                   uint8_t *__restrict__ out_status)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        const uint64_t lo = start[i], hi = end[i];
+        const uint32_t c = v.io_to_dense[io_symbols[i]];  // cursor.rs:34-38: translated before anything else
+        uint32_t status = GDX_Q_OK;
+        if (c == 0) {
+            status = GDX_Q_INVALID_SYMBOL;
+        } else if (lo != hi) {  // cursor.rs:41-48
+            const uint64_t cc = v.count[c];
+            start[i] = cc + wide_rank(v, c, lo);
+            end[i] = cc + wide_rank(v, c, hi);
+        }
+        out_status[i] = static_cast<uint8_t>(status);
+    }
+}
+
+// TextWithRankSupport::rank / symbol_at (text_with_rank_support/mod.rs:106-110, condensed.rs:343-362)
+__global__ __launch_bounds__(kBlock) void wide_rank_kernel(WideView v, const uint8_t *__restrict__ symbols, const uint64_t *__restrict__ idx,
+                                                           uint64_t m, uint64_t *__restrict__ out, uint32_t *__restrict__ error)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < m; i += stride) {
+        const uint32_t c = symbols ? symbols[i] : 0u;
+        const uint64_t p = idx[i];
+        if (symbols) {
+            if (c >= static_cast<uint32_t>(v.sigma) || p > v.n) {  // mod.rs:107-108
+                *error = 1;
+                out[i] = 0;
+            } else {
+                out[i] = wide_rank(v, c, p);
+            }
+        } else if (p >= v.n) {  // condensed.rs:344
+            *error = 1;
+            out[i] = 0;
+        } else {
+            out[i] = line_symbol_at(wide_line(v, p), static_cast<uint32_t>(p & 127u));
+        }
+    }
+}
+
 struct WideSize {
     const uint64_t *start, *end;
     uint64_t m;
@@ -558,6 +603,120 @@ int WideIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qof
     return any ? GDX_ERR_QUERY_STATUS : GDX_OK;
 }
 
+// d_s / d_e (m intervals on the device) -> hit offsets (host, shifted by hit_base) and hits; returns the number of hits
+static uint64_t wide_locate_intervals(const WideView &view, const uint64_t *d_s, const uint64_t *d_e, uint64_t m, uint64_t hit_base,
+                                      uint64_t *out_hit_offsets /* [m + 1] slots from the chunk's first, or null */, gdx_hit_t *hits,
+                                      uint64_t hits_capacity, bool &fits, hipStream_t stream)
+{
+    DeviceBuffer<uint64_t> d_hoff(m + 1);
+    WideSizeIterator sizes(rocprim::counting_iterator<uint64_t>(0), WideSize{d_s, d_e, m});
+    size_t scan_bytes = 0;
+    GDX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, sizes, d_hoff.get(), uint64_t(0), static_cast<size_t>(m + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    DeviceBuffer<uint8_t> scan_tmp(scan_bytes ? scan_bytes : 1);
+    GDX_HIP(rocprim::exclusive_scan(scan_tmp.get(), scan_bytes, sizes, d_hoff.get(), uint64_t(0), static_cast<size_t>(m + 1),
+                                    rocprim::plus<uint64_t>(), stream));
+    std::vector<uint64_t> hoff(m + 1);
+    GDX_HIP(hipMemcpyAsync(hoff.data(), d_hoff.get(), (m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    const uint64_t total = hoff[m];
+    if (out_hit_offsets)
+        for (uint64_t i = 0; i < m; i++) out_hit_offsets[i + 1] = hit_base + hoff[i + 1];
+    if (total != 0 && hits != nullptr && hit_base + total <= hits_capacity && fits) {
+        DeviceBuffer<uint32_t> heads(total);
+        DeviceBuffer<gdx_hit_t> d_hits(total);
+        GDX_HIP(hipMemsetAsync(heads.get(), 0, total * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(wide_mark_heads_kernel, dim3(wgrid(m)), dim3(kBlock), 0, stream, d_s, d_e, m, d_hoff.get(), heads.get());
+        size_t max_bytes = 0;
+        GDX_HIP(rocprim::inclusive_scan(nullptr, max_bytes, heads.get(), heads.get(), static_cast<size_t>(total), rocprim::maximum<uint32_t>(), stream));
+        DeviceBuffer<uint8_t> max_tmp(max_bytes ? max_bytes : 1);
+        GDX_HIP(rocprim::inclusive_scan(max_tmp.get(), max_bytes, heads.get(), heads.get(), static_cast<size_t>(total), rocprim::maximum<uint32_t>(), stream));
+        hipLaunchKernelGGL(wide_locate_kernel, dim3(wgrid(total)), dim3(kBlock), 0, stream, view, d_s, d_hoff.get(), heads.get(), total, d_hits.get());
+        GDX_HIP(hipGetLastError());
+        GDX_HIP(hipMemcpyAsync(hits + hit_base, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
+        GDX_HIP(hipStreamSynchronize(stream));
+    } else if (total != 0) {
+        fits = false;
+    }
+    return total;
+}
+
+int WideIndex::cursor_locate_many(const uint64_t *start, const uint64_t *end, uint64_t m, uint64_t *out_hit_offsets, gdx_hit_t *hits,
+                                  uint64_t hits_capacity, uint64_t *out_total) const
+{
+    if (out_total) *out_total = 0;
+    if (out_hit_offsets) out_hit_offsets[0] = 0;
+    if (m == 0) return GDX_OK;
+    if (!start || !end) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint64_t i = 0; i < m; i++)
+        if (start[i] > end[i] || end[i] > p_->n) fail(GDX_ERR_INVALID_ARGUMENT, "cursor %llu is not an interval of this index", static_cast<unsigned long long>(i));
+    GDX_HIP(hipSetDevice(p_->cfg.device_id));
+    hipStream_t stream = hipStreamPerThread;
+    bool fits = true;
+    uint64_t hit_base = 0;
+    for (uint64_t q0 = 0; q0 < m; q0 += kWideChunkQueries) {
+        const uint64_t c = std::min(kWideChunkQueries, m - q0);
+        DeviceBuffer<uint64_t> d_s(c), d_e(c);
+        GDX_HIP(hipMemcpyAsync(d_s.get(), start + q0, c * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        GDX_HIP(hipMemcpyAsync(d_e.get(), end + q0, c * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        hit_base += wide_locate_intervals(p_->view, d_s.get(), d_e.get(), c, hit_base, out_hit_offsets ? out_hit_offsets + q0 : nullptr, hits,
+                                          hits ? hits_capacity : 0, fits, stream);
+    }
+    if (out_total) *out_total = hit_base;
+    return hit_base > 0 && !fits ? GDX_ERR_CAPACITY : GDX_OK;
+}
+
+int WideIndex::cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m, uint8_t *out_status) const
+{
+    if (m == 0) return GDX_OK;
+    if (!start || !end || !io_symbols) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    GDX_HIP(hipSetDevice(p_->cfg.device_id));
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint64_t> d_s(m), d_e(m);
+    DeviceBuffer<uint8_t> d_sym(m), d_st(m);
+    GDX_HIP(hipMemcpyAsync(d_s.get(), start, m * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    GDX_HIP(hipMemcpyAsync(d_e.get(), end, m * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    GDX_HIP(hipMemcpyAsync(d_sym.get(), io_symbols, m, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(wide_extend_front_kernel, dim3(wgrid(m)), dim3(kBlock), 0, stream, p_->view, d_s.get(), d_e.get(), d_sym.get(), m,
+                       d_st.get());
+    GDX_HIP(hipGetLastError());
+    std::vector<uint8_t> st(m);
+    GDX_HIP(hipMemcpyAsync(start, d_s.get(), m * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(end, d_e.get(), m * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(st.data(), d_st.get(), m, hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    bool any = false;
+    for (uint64_t i = 0; i < m; i++) {
+        if (out_status) out_status[i] = st[i];
+        any |= st[i] != 0;
+    }
+    return any ? GDX_ERR_QUERY_STATUS : GDX_OK;
+}
+
+int WideIndex::rank_or_symbol_many(const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out) const
+{
+    if (m == 0) return GDX_OK;
+    if (!idx || !out) fail(GDX_ERR_INVALID_ARGUMENT, "null argument");
+    GDX_HIP(hipSetDevice(p_->cfg.device_id));
+    hipStream_t stream = hipStreamPerThread;
+    DeviceBuffer<uint8_t> d_sym(symbols ? m : 1);
+    DeviceBuffer<uint64_t> d_idx(m), d_out(m);
+    DeviceBuffer<uint32_t> d_err(1);
+    if (symbols) GDX_HIP(hipMemcpyAsync(d_sym.get(), symbols, m, hipMemcpyHostToDevice, stream));
+    GDX_HIP(hipMemcpyAsync(d_idx.get(), idx, m * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    GDX_HIP(hipMemsetAsync(d_err.get(), 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(wide_rank_kernel, dim3(wgrid(m)), dim3(kBlock), 0, stream, p_->view, symbols ? d_sym.get() : nullptr, d_idx.get(), m,
+                       d_out.get(), d_err.get());
+    GDX_HIP(hipGetLastError());
+    uint32_t err = 0;
+    GDX_HIP(hipMemcpyAsync(&err, d_err.get(), sizeof(err), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipMemcpyAsync(out, d_out.get(), m * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    if (err) fail(GDX_ERR_INVALID_ARGUMENT, symbols ? "rank: symbol >= alphabet size or idx > text_len (mod.rs:107-108)"
+                                                     : "symbol_at: idx >= text_len (condensed.rs:344)");
+    return GDX_OK;
+}
+
 int WideIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets, gdx_hit_t *hits,
                            uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const
 {
@@ -574,45 +733,20 @@ int WideIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t n
         std::vector<uint64_t> off(m + 1);
         for (uint64_t i = 0; i <= m; i++) off[i] = qoff[q0 + i] - base;
         DeviceBuffer<uint8_t> d_q(bytes + 16), d_st(m);
-        DeviceBuffer<uint64_t> d_off(m + 1), d_s(m), d_e(m), d_hoff(m + 1);
+        DeviceBuffer<uint64_t> d_off(m + 1), d_s(m), d_e(m);
         if (bytes) GDX_HIP(hipMemcpyAsync(d_q.get(), qbuf + base, bytes, hipMemcpyHostToDevice, stream));
         GDX_HIP(hipMemcpyAsync(d_off.get(), off.data(), (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(wide_search_kernel, dim3(wgrid(m)), dim3(kBlock), 0, stream, p_->view, d_q.get(), d_off.get(), m, d_s.get(),
                            d_e.get(), d_st.get());
-        WideSizeIterator sizes(rocprim::counting_iterator<uint64_t>(0), WideSize{d_s.get(), d_e.get(), m});
-        size_t scan_bytes = 0;
-        GDX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, sizes, d_hoff.get(), uint64_t(0), static_cast<size_t>(m + 1),
-                                        rocprim::plus<uint64_t>(), stream));
-        DeviceBuffer<uint8_t> scan_tmp(scan_bytes ? scan_bytes : 1);
-        GDX_HIP(rocprim::exclusive_scan(scan_tmp.get(), scan_bytes, sizes, d_hoff.get(), uint64_t(0), static_cast<size_t>(m + 1),
-                                        rocprim::plus<uint64_t>(), stream));
-        std::vector<uint64_t> hoff(m + 1);
         std::vector<uint8_t> st(m);
-        GDX_HIP(hipMemcpyAsync(hoff.data(), d_hoff.get(), (m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         GDX_HIP(hipMemcpyAsync(st.data(), d_st.get(), m, hipMemcpyDeviceToHost, stream));
         GDX_HIP(hipStreamSynchronize(stream));
-        const uint64_t total = hoff[m];
         for (uint64_t i = 0; i < m; i++) {
-            if (out_hit_offsets) out_hit_offsets[q0 + i + 1] = hit_base + hoff[i + 1];
             if (out_status) out_status[q0 + i] = st[i];
             any |= st[i] != 0;
         }
-        if (total != 0 && hits != nullptr && hit_base + total <= hits_capacity && fits) {
-            DeviceBuffer<uint32_t> heads(total);
-            DeviceBuffer<gdx_hit_t> d_hits(total);
-            GDX_HIP(hipMemsetAsync(heads.get(), 0, total * sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(wide_mark_heads_kernel, dim3(wgrid(m)), dim3(kBlock), 0, stream, d_s.get(), d_e.get(), m, d_hoff.get(), heads.get());
-            size_t max_bytes = 0;
-            GDX_HIP(rocprim::inclusive_scan(nullptr, max_bytes, heads.get(), heads.get(), static_cast<size_t>(total), rocprim::maximum<uint32_t>(), stream));
-            DeviceBuffer<uint8_t> max_tmp(max_bytes ? max_bytes : 1);
-            GDX_HIP(rocprim::inclusive_scan(max_tmp.get(), max_bytes, heads.get(), heads.get(), static_cast<size_t>(total), rocprim::maximum<uint32_t>(), stream));
-            hipLaunchKernelGGL(wide_locate_kernel, dim3(wgrid(total)), dim3(kBlock), 0, stream, p_->view, d_s.get(), d_hoff.get(), heads.get(), total, d_hits.get());
-            GDX_HIP(hipGetLastError());
-            GDX_HIP(hipMemcpyAsync(hits + hit_base, d_hits.get(), total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, stream));
-            GDX_HIP(hipStreamSynchronize(stream));
-        } else if (total != 0) {
-            fits = false;
-        }
+        const uint64_t total = wide_locate_intervals(p_->view, d_s.get(), d_e.get(), m, hit_base,
+                                                     out_hit_offsets ? out_hit_offsets + q0 : nullptr, hits, hits_capacity, fits, stream);
         hit_base += total;
     });
     if (out_total) *out_total = hit_base;

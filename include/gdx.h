@@ -20,7 +20,8 @@
  *    fit (the reference: IndexStorage for i64, construction/mod.rs:225-252) builds an index with
  *    64-bit rows on the reference's own arrays (wide.hip): gdx_index_build[_dev][_ex],
  *    gdx_index_info, gdx_count_many, gdx_cursors_for_many_queries, gdx_locate_many[_alloc],
- *    gdx_cursor_empty and gdx_index_export_bwt serve it (same intervals, counts, hits and hit order
+ *    gdx_cursor_empty, gdx_cursor_extend_front_many, gdx_cursor_locate_many, gdx_rank_many,
+ *    gdx_symbol_at_many and gdx_index_export_bwt serve it (same intervals, counts, hits and hit order
  *    as the reference's algorithm; lookup depth 0, alphabets of up to 7 symbols + sentinel; a plain
  *    engine, ~25x slower than the 32-bit one); every other call returns GDX_ERR_UNSUPPORTED on it.
  *    Collections that split at text borders are served faster by the partitioned index (gdx_parts_*).

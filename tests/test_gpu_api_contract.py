@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from genedex_amd import alphabet as alph
-from helpers import random_texts
+from helpers import naive_occurrence_columns, random_texts
 from oracle.oracle import OracleIndex, pack_queries
 
 pytestmark = pytest.mark.gpu
@@ -564,6 +564,25 @@ def test_wide_index_equals_oracle_i64(seed):
         off, t_, p_, _ = call(kb, ko)
         assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
     assert g.cursor_empty().interval() == (0, c.n)
+    # Cursor::extend_query_front one symbol at a time, Cursor::locate, and the operator level (rank / symbol_at)
+    m = 300
+    starts, ends = np.zeros(m, dtype=np.uint64), np.full(m, c.n, dtype=np.uint64)
+    want = [(0, c.n)] * m
+    for step in range(8):
+        syms = np.frombuffer(bytes(b"ACGTNacgt"[i] for i in rng.integers(0, 9, m)), dtype=np.uint8)
+        starts, ends, st2 = g.extend_front_raw(starts, ends, syms)
+        want = [c.extend_front(s_, e_, int(sym))[:2] for (s_, e_), sym in zip(want, syms)]
+        assert not st2.any() and list(zip(starts.tolist(), ends.tolist())) == want
+    few = (ends - starts) < 3000
+    off, t_, p_ = g.locate_intervals_raw(starts[few], ends[few])
+    co, ct, cp = c.locate_intervals(starts[few], ends[few])
+    assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+    idx = np.unique(rng.integers(0, c.n + 1, 400)).astype(np.uint64)
+    cols = naive_occurrence_columns(c.bwt, c.sigma)
+    for sym in range(c.sigma):
+        assert g.rank_many(np.full(idx.size, sym, dtype=np.uint8), idx).tolist() == cols[sym, idx.astype(np.int64)].tolist()
+    pos = idx[idx < c.n]
+    assert g.symbol_at_many(pos).tolist() == c.bwt[pos.astype(np.int64)].tolist()
     with pytest.raises(GdxError) as err:  # the rest of the ABI says so instead of misbehaving
-        g.rank_many([1], [0])
+        g.save_to_file("/tmp/should_not_exist.gdx")
     assert err.value.status == _lib.GDX_ERR_UNSUPPORTED
