@@ -26,6 +26,10 @@ pub struct gdx_index_t {
 pub struct gdx_multi_t {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct gdx_parts_t {
+    _private: [u8; 0],
+}
 
 /// lib.rs:331-335
 #[repr(C)]
@@ -176,6 +180,23 @@ extern "C" {
         n_devices: c_int, opts: *const BuildOptions, out: *mut *mut gdx_multi_t,
     ) -> c_int;
     pub fn gdx_multi_free(m: *mut gdx_multi_t);
+    // collections beyond 2^32 - 1 symbols as several 32-bit indexes cut at text borders (count / locate); a single text
+    // beyond that, or cursors over the whole collection: build with index_width 64 (the 64-bit engine) instead
+    pub fn gdx_parts_build(
+        texts_buf: *const c_void, texts_on_device: c_int, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8,
+        sigma: c_int, n_searchable: c_int, sa_rate: u64, lookup_depth: c_int, device_id: c_int, max_part_symbols: u64,
+        opts: *const BuildOptions, out: *mut *mut gdx_parts_t,
+    ) -> c_int;
+    pub fn gdx_parts_free(p: *mut gdx_parts_t);
+    pub fn gdx_parts_info(p: *const gdx_parts_t, out: *mut u64) -> c_int;
+    pub fn gdx_parts_set_query_options(p: *mut gdx_parts_t, opts: *const QueryOptions) -> c_int;
+    pub fn gdx_parts_count_many(
+        p: *const gdx_parts_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_counts: *mut u64, out_status: *mut u8,
+    ) -> c_int;
+    pub fn gdx_parts_locate_many_alloc(
+        p: *const gdx_parts_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_hit_offsets: *mut u64,
+        out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
+    ) -> c_int;
     pub fn gdx_multi_set_query_options(m: *mut gdx_multi_t, opts: *const QueryOptions) -> c_int;
     pub fn gdx_multi_locate_many_gather_dev(
         m: *mut gdx_multi_t, shards: *const DeviceShard, n_shards: c_int, root: c_int, out: *mut Gathered,
@@ -330,7 +351,7 @@ impl GpuFmIndex {
     }
 
     /// Batched form of the cursor API (ROADMAP.md:33): every cursor extended by its own string, last symbol first,
-    /// in ONE launch (up to 40 LF steps per memory fetch), instead of one launch per symbol.
+    /// in ONE launch (up to 32 LF steps per memory fetch), instead of one launch per symbol.
     pub fn extend_cursors_front<'a, Q: AsRef<[u8]>>(
         &'a self, cursors: &mut [GpuCursor<'a>], strings: impl IntoIterator<Item = Q>,
     ) {

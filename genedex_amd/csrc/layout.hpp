@@ -43,7 +43,7 @@ struct IndexView {
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
-    // --- jump table: 8 .. 40 LF steps of a narrow interval per fetch -----------------------------------
+    // --- jump table: 8 .. 32 LF steps of a narrow interval per fetch -----------------------------------
     // [n] entries of jump_bytes.  Level j of entry i = {t_j = row after 8j LF steps from row i, c_j = 2-bit codes
     // (dense symbol - 1, bits 15:14 = the first of them) of the symbols of steps 8j-7 .. 8j, valid bit j-1 = these
     // and all earlier symbols are in 1..4}; a code without its target is a lookahead: it tells whether a row

@@ -419,7 +419,7 @@ int gdx_locate_many_search_packed_dev(const gdx_index_t *ix, const void *d_packe
  * NULL = all m; the cursors that are still non-empty and not stopped afterwards are appended to d_active_out
  * (u32[m], any order) and counted in *d_n_active_out (u32 in device memory, zeroed by this call).  m remains the
  * upper bound the launch is sized for.  One launch advances a cursor by its whole string through the pair lines
- * and the jump table (up to 40 LF steps per fetch), not one LF step per launch. */
+ * and the jump table (up to 32 LF steps per fetch), not one LF step per launch. */
 int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start /*u32*/, void *d_end /*u32*/,
                                         const void *d_qbuf, const void *d_qbeg /*u64*/, const void *d_qend /*u64*/,
                                         uint64_t m, void *d_status /*u8 or NULL*/, const void *d_active_in,
