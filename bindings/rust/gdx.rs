@@ -50,6 +50,8 @@ pub struct BuildOptions {
     pub aux_budget_bytes: u64, // 0 = default
     pub full_suffix_array: i32, // -1 / 0 off, 1: SA[row] of every row as its own array
     pub text_units: i32,        // -1 / 0 off, 1: the text at 4 bits per symbol (count / locate compare with it)
+    pub seed_symbols: i32,      // -1 / 0 off, 1: seed table with k from the text length, 8..=24: that k
+    pub seed_load_percent: i32, // 0 = default (70)
 }
 impl Default for BuildOptions {
     fn default() -> Self {
@@ -78,6 +80,7 @@ pub struct QueryOptions {
     /// host-pointer locate calls return at most this many hits per query, the first ones in suffix-array order:
     /// `locate(q).take(k)` on the reference's lazy iterator (lib.rs:187-197); 0 = all
     pub max_hits_per_query: u32,
+    pub search_seed: i32, // -1 default (on when the index has a seed table), 0 off
 }
 
 /// gdx_device_shard_t / gdx_gathered_t: gdx_multi_locate_many_gather_dev (device-resident shards, results gathered on the

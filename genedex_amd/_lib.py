@@ -51,14 +51,14 @@ class IndexInfo(C.Structure):
 class BuildOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32),
                 ("top_table_depth", C.c_int32), ("aux_budget_bytes", C.c_uint64), ("full_suffix_array", C.c_int32),
-                ("text_units", C.c_int32)]
+                ("text_units", C.c_int32), ("seed_symbols", C.c_int32), ("seed_load_percent", C.c_int32)]
 
 
 class QueryOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("search_kernel", C.c_int32), ("search_lanes", C.c_int32),
                 ("load_policy", C.c_int32), ("length_schedule", C.c_int32), ("locate_kernel", C.c_int32),
                 ("locate_jump_walk", C.c_int32), ("search_defer_after", C.c_int32), ("search_fast", C.c_int32),
-                ("search_exact", C.c_int32), ("max_hits_per_query", C.c_uint32)]
+                ("search_exact", C.c_int32), ("max_hits_per_query", C.c_uint32), ("search_seed", C.c_int32)]
 
 
 class DeviceShard(C.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
                                  C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_index_load_ex": [C.c_char_p, C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_index_aux": [vp, C.POINTER(IndexAux)],
+    "gdx_index_seed_info": [vp, C.POINTER(C.c_uint64)],
     "gdx_index_set_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_index_get_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_index_rebuild_aux": [vp, C.POINTER(BuildOptions)],

@@ -196,6 +196,12 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
         gdx::fail(GDX_ERR_INVALID_ARGUMENT, "full_suffix_array / text_units must be -1, 0 or 1");
     b.full_sa = o->full_suffix_array;
     b.text_units = o->text_units;
+    if (o->seed_symbols < -1 || o->seed_symbols > 24 || (o->seed_symbols > 1 && o->seed_symbols < 8))
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "seed_symbols must be -1, 0, 1 (automatic) or 8..24");
+    if (o->seed_load_percent != 0 && (o->seed_load_percent < 20 || o->seed_load_percent > 100))
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
+    b.seed_symbols = o->seed_symbols;
+    b.seed_load_percent = o->seed_load_percent;
     return b;
 }
 
@@ -231,6 +237,8 @@ gdx::QueryOptions parse_query_options(const gdx_query_options_t *opts)
         if (opts->search_exact < -1 || opts->search_exact > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
         q.search_exact = opts->search_exact;
         q.max_hits_per_query = opts->max_hits_per_query;
+        if (opts->search_seed < -1 || opts->search_seed > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_options_t: field out of range");
+        q.search_seed = opts->search_seed;
     }
     return q;
 }
@@ -258,6 +266,8 @@ void gdx_build_options_init(gdx_build_options_t *opts)
     opts->aux_budget_bytes = 0;
     opts->full_suffix_array = -1;
     opts->text_units = -1;
+    opts->seed_symbols = -1;
+    opts->seed_load_percent = 0;
 }
 
 void gdx_query_options_init(gdx_query_options_t *opts)
@@ -274,6 +284,7 @@ void gdx_query_options_init(gdx_query_options_t *opts)
     opts->search_fast = -1;
     opts->search_exact = -1;
     opts->max_hits_per_query = 0;
+    opts->search_seed = -1;
 }
 
 int gdx_index_build(const uint8_t *texts_buf, const uint64_t *text_offsets, uint64_t n_texts,
@@ -467,6 +478,25 @@ int gdx_index_get_query_options(const gdx_index_t *ix, gdx_query_options_t *out)
         out->search_fast = q.search_fast;
         out->search_exact = q.search_exact;
         out->max_hits_per_query = q.max_hits_per_query;
+        out->search_seed = q.search_seed;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_seed_info(const gdx_index_t *ix, uint64_t out[8])
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        const gdx::AuxReport &r = f.aux_report();
+        out[0] = f.view().seed ? r.seed_k : 0;
+        out[1] = r.seed_buckets;
+        out[2] = r.seed_single;
+        out[3] = r.seed_multi;
+        out[4] = r.seed_overflowed;
+        out[5] = r.seed_max_disp;
+        out[6] = r.seed_bytes;
+        out[7] = f.view().seed_tag_bits;
         return (int)GDX_OK;
     });
 }

@@ -537,6 +537,149 @@ __global__ __launch_bounds__(kBlock) void scatter_text_units_kernel(IndexView ix
     }
 }
 
+// ---- seed table (IndexView::seed) -------------------------------------------------------------------------------------
+// The rows of the suffix array whose suffix starts with the same k-mer are one interval, so the distinct k-mers of the
+// text are the rows whose k-mer differs from the row before ("heads"), and everything about them -- interval, position,
+// the symbols in front -- is read off the full suffix array and the text units.
+
+// 32 text symbols from position s (a unit-array position: text position + 32 * kTextPadUnits): codes and "not A C G T" mask
+__device__ __forceinline__ void text_window32(const u32x4 *__restrict__ units, uint64_t s, uint64_t &code, uint32_t &mask)
+{
+    const uint32_t b = static_cast<uint32_t>(s & 31u);
+    const u32x4 u0 = units[s >> 5];
+    const u32x4 u1 = units[(s >> 5) + 1];  // (two spare units follow the text)
+    const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
+    const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
+    code = b ? (c0 >> (2u * b)) | (c1 << (64u - 2u * b)) : c0;
+    mask = b ? (u0.z >> b) | (u1.z << (32u - b)) : u0.z;
+}
+
+// the k-mer (k <= 24) at text position p as a key, false when it holds a sentinel / N or runs off the text
+__device__ __forceinline__ bool seed_key_at(const u32x4 *__restrict__ units, uint32_t p, uint32_t k, uint64_t &key)
+{
+    uint64_t code;
+    uint32_t mask;
+    text_window32(units, static_cast<uint64_t>(p) + 32u * kTextPadUnits, code, mask);
+    key = code & ((1ull << (2u * k)) - 1ull);
+    return (mask & ((1u << k) - 1u)) == 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void seed_count_heads_kernel(const u32x4 *__restrict__ units, const uint32_t *__restrict__ sa,
+                                                                  uint64_t n, uint32_t k, unsigned long long *__restrict__ n_heads)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    unsigned long long mine = 0;
+    for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < n; r += stride) {
+        uint64_t key, prev = 0;
+        if (!seed_key_at(units, sa[r], k, key)) continue;
+        const bool same = r > 0 && seed_key_at(units, sa[r - 1], k, prev) && prev == key;
+        mine += same ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(n_heads, mine);
+}
+
+__global__ __launch_bounds__(kBlock) void seed_clear_kernel(u32x4 *__restrict__ table, uint64_t entries)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const u32x4 empty = {kSeedEmpty, 0u, 0u, 0u};
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) table[e] = empty;
+}
+
+// stats: [0] entries of kind 0, [1] entries of kind 1, [2] entries that found no slot within kSeedMaxDisp buckets (the
+// build then starts over with more buckets), [3] largest displacement
+__global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__restrict__ units, const uint32_t *__restrict__ sa,
+                                                             uint64_t n, uint32_t k, uint32_t tag_bits, uint32_t buckets,
+                                                             u32x4 *__restrict__ table, uint32_t *__restrict__ fill,
+                                                             unsigned long long *__restrict__ stats)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    unsigned long long n_kind[2] = {0, 0}, n_failed = 0, max_d = 0;
+    for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < n; r += stride) {
+        uint64_t key, other = 0;
+        const uint32_t p = sa[r];
+        if (!seed_key_at(units, p, k, key)) continue;
+        if (r > 0 && seed_key_at(units, sa[r - 1], k, other) && other == key) continue;  // not the first row of its k-mer
+        // end of the interval: rows r .. hi - 1 start with the k-mer (galloping, then bisection)
+        auto same = [&](uint64_t x) { return seed_key_at(units, sa[x], k, other) && other == key; };
+        uint64_t hi = r + 1;
+        if (hi < n && same(hi)) {
+            uint64_t step = 2;
+            while (r + step < n && same(r + step)) step *= 2;
+            uint64_t good = r + step / 2, bad = r + step < n ? r + step : n;  // same(good), !same(bad) (or bad == n)
+            while (bad - good > 1) {
+                const uint64_t mid = good + (bad - good) / 2;
+                if (same(mid)) good = mid;
+                else bad = mid;
+            }
+            hi = bad;
+        }
+        u32x4 e = {kSeedKind, static_cast<uint32_t>(r), static_cast<uint32_t>(hi), 0u};
+        if (hi - r == 1) {
+            uint64_t code;
+            uint32_t mask;
+            text_window32(units, static_cast<uint64_t>(p) + 32u * kTextPadUnits - 32u, code, mask);
+            // symbols A C G T right in front of p (bit 31 of the mask is the symbol at p - 1)
+            const uint32_t v = mask == 0u ? 32u : static_cast<uint32_t>(__builtin_clz(mask));
+            if (v == 32u || v <= 29u) {
+                if (v != 32u) code = (code & ~63ull) | v;  // (the low three symbols are not among the v)
+                e.x = v == 32u ? 0u : kSeedPartial;
+                e.y = p;
+                e.z = static_cast<uint32_t>(code);
+                e.w = static_cast<uint32_t>(code >> 32);
+            }
+        }
+        uint32_t tag;
+        uint32_t b = seed_home(key, tag_bits, buckets, tag);
+        uint32_t d = 0;
+        for (;;) {
+            const uint32_t slot = atomicAdd(fill + b, 1u);
+            if (slot < 8u) {
+                e.x |= tag | (d << kSeedDispShift);
+                table[(static_cast<uint64_t>(b) << 3) + slot] = e;
+                n_kind[(e.x & kSeedKind) ? 1 : 0]++;
+                max_d = d > max_d ? d : max_d;
+                break;
+            }
+            if (++d > kSeedMaxDisp) {
+                n_failed++;
+                break;
+            }
+            b = b + 1u == buckets ? 0u : b + 1u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_kind[0] += __shfl_xor(n_kind[0], off);
+        n_kind[1] += __shfl_xor(n_kind[1], off);
+        n_failed += __shfl_xor(n_failed, off);
+        const unsigned long long o = __shfl_xor(max_d, off);
+        max_d = o > max_d ? o : max_d;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_kind[0]) atomicAdd(stats + 0, n_kind[0]);
+        if (n_kind[1]) atomicAdd(stats + 1, n_kind[1]);
+        if (n_failed) atomicAdd(stats + 2, n_failed);
+        if (max_d) atomicMax(stats + 3, max_d);
+    }
+}
+
+// every entry of a bucket that turned an entry away says so (the search then looks into the next bucket as well);
+// *n_flagged counts those buckets
+__global__ __launch_bounds__(kBlock) void seed_flag_kernel(u32x4 *__restrict__ table, const uint32_t *__restrict__ fill,
+                                                           uint64_t entries, unsigned long long *__restrict__ n_flagged)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    unsigned long long mine = 0;
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; e < entries; e += stride) {
+        if (fill[e >> 3] > 8u) {
+            reinterpret_cast<uint32_t *>(table + e)[0] |= kSeedOverflow;
+            mine += (e & 7u) == 0u ? 1u : 0u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(n_flagged, mine);
+}
+
 // Bit planes of one 64-position block of bwt1 / bwt0 (zero padded input) and its 16 pair + 4 single counts.
 struct PairBlock {
     uint64_t p1[3], p0[3];
@@ -873,7 +1016,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return top_.bytes() + jump_.bytes() + sa_full_.bytes() + text_units_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return top_.bytes() + jump_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -1001,11 +1144,14 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     view_.top_depth = 0;
     view_.sa_full = nullptr;
     view_.text_units = nullptr;
+    view_.seed = nullptr;
+    view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
     pair_lines_.release();
     jump_.release();
     top_.release();
     sa_full_.release();
     text_units_.release();
+    seed_.release();
     // environment variables are debug overrides of fields left at their default
     auto env_int = [](const char *name, int fallback) {
         const char *e = getenv(name);
@@ -1013,7 +1159,20 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     };
     int want_pairs = bo.pair_lines;
     if (want_pairs < 0) want_pairs = env_int("GDX_NO_PAIR_LINES", 0) == 1 ? 0 : 1;
-    const bool want_text = bo.text_units == 1, want_sa_full = bo.full_sa == 1;
+    // seed table (layout.hpp): wanted explicitly; k from the text length unless given: ceil(log4 n) + 8, so that a k-mer
+    // that occurs at all almost always occurs once (3.1 G symbols: 24), at most 24 (k + 32 symbols fit the search window)
+    uint32_t seed_k = 0;
+    if (bo.seed_symbols >= 1 && view_.sigma >= 5) {
+        if (bo.seed_symbols == 1) {
+            seed_k = 8;
+            while (seed_k < 24 && (1ull << (2u * (seed_k - 8u))) < n_) seed_k++;
+        } else {
+            seed_k = static_cast<uint32_t>(bo.seed_symbols);
+        }
+        if (seed_k < 8u || seed_k > 24u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_symbols must be 1 (automatic) or 8..24");
+    }
+    const bool want_seed = seed_k != 0;
+    const bool want_text = bo.text_units == 1 || want_seed, want_sa_full = bo.full_sa == 1;
     if (view_.layout == 0 && n_ > 0 && (want_pairs || want_text || want_sa_full)) {
         double t0 = now_seconds();
         if (want_pairs) {
@@ -1101,7 +1260,10 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             }
             aux_report_.budget_bytes = static_cast<uint64_t>(budget);
             // (the full suffix array and the text units are asked for explicitly: they count, but do not shrink)
-            const double fixed = (want_sa_full ? 4.0 : 0.0) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_);
+            // (the seed table: 16 bytes per distinct k-mer over the load factor -- about n k-mers)
+            const double seed_load = (bo.seed_load_percent > 0 ? bo.seed_load_percent : 70) / 100.0;
+            const double fixed = (want_sa_full ? 4.0 : 0.0) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_) +
+                                 (want_seed ? 16.0 / seed_load : 0.0) * static_cast<double>(n_);
             auto need = [&] {
                 return fixed + static_cast<double>(jump_bytes) * static_cast<double>(n_) +
                        (top_depth ? 8.0 * static_cast<double>(1ull << (2u * top_depth)) : 0.0);
@@ -1177,11 +1339,70 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             }
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
+            if (want_seed) build_seed_table(d_sa, seed_k, stream);
             if (want_sa_full) view_.sa_full = sa_full_.get();
             if (want_text) view_.text_units = text_units_.get();
         }
-        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes();
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
+    }
+}
+
+// Seed table out of the full suffix array and the text units (both on the device; layout.hpp describes the entries).
+void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream)
+{
+    const BuildOptions &bo = cfg_.build;
+    const uint32_t load = bo.seed_load_percent > 0 ? static_cast<uint32_t>(bo.seed_load_percent) : 70u;
+    if (load < 20u || load > 100u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
+    const unsigned grid = grid_for_items(n_);
+    DeviceBuffer<unsigned long long> d_stats(8);
+    GDX_HIP(hipMemsetAsync(d_stats.get(), 0, 8 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(seed_count_heads_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, d_stats.get());
+    unsigned long long heads = 0;
+    GDX_HIP(hipMemcpyAsync(&heads, d_stats.get(), sizeof(heads), hipMemcpyDeviceToHost, stream));
+    GDX_HIP(hipStreamSynchronize(stream));
+    GDX_HIP(hipGetLastError());
+    // buckets: the load factor decides, but (bucket, tag) must name a k-mer exactly: 2^(2k - tag bits) <= buckets with
+    // at most kSeedTagBitsMax tag bits
+    uint64_t buckets = (heads * 100ull + 8ull * load - 1) / (8ull * load);
+    if (buckets < 1) buckets = 1;
+    if (2u * k > kSeedTagBitsMax && buckets < (1ull << (2u * k - kSeedTagBitsMax))) buckets = 1ull << (2u * k - kSeedTagBitsMax);
+    for (int attempt = 0;; attempt++) {
+        if (buckets > (1ull << 31)) fail(GDX_ERR_UNSUPPORTED, "seed table: too many buckets");
+        uint32_t log2b = 0;
+        while ((2ull << log2b) <= buckets) log2b++;
+        const uint32_t tag_bits = 2u * k > log2b ? 2u * k - log2b : 0u;
+        seed_.alloc(buckets * 8);
+        DeviceBuffer<uint32_t> d_fill(buckets);
+        GDX_HIP(hipMemsetAsync(d_fill.get(), 0, buckets * sizeof(uint32_t), stream));
+        GDX_HIP(hipMemsetAsync(d_stats.get(), 0, 8 * sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(seed_clear_kernel, dim3(grid_for_items(buckets * 8)), dim3(kBlock), 0, stream, seed_.get(), buckets * 8);
+        hipLaunchKernelGGL(seed_insert_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, tag_bits,
+                           static_cast<uint32_t>(buckets), seed_.get(), d_fill.get(), d_stats.get());
+        hipLaunchKernelGGL(seed_flag_kernel, dim3(grid_for_items(buckets * 8)), dim3(kBlock), 0, stream, seed_.get(), d_fill.get(),
+                           buckets * 8, d_stats.get() + 4);
+        unsigned long long st[5];
+        GDX_HIP(hipMemcpyAsync(st, d_stats.get(), sizeof(st), hipMemcpyDeviceToHost, stream));
+        GDX_HIP(hipStreamSynchronize(stream));
+        GDX_HIP(hipGetLastError());
+        if (st[2] != 0) {  // an entry found no slot within kSeedMaxDisp buckets of its home: more buckets
+            seed_.release();
+            if (attempt >= 6) fail(GDX_ERR_UNSUPPORTED, "seed table: no placement found");
+            buckets = buckets + buckets / 4 + 1;
+            continue;
+        }
+        view_.seed = seed_.get();
+        view_.seed_buckets = static_cast<uint32_t>(buckets);
+        view_.seed_k = k;
+        view_.seed_tag_bits = tag_bits;
+        aux_report_.seed_k = k;
+        aux_report_.seed_buckets = buckets;
+        aux_report_.seed_single = st[0];
+        aux_report_.seed_multi = st[1];
+        aux_report_.seed_max_disp = st[3];
+        aux_report_.seed_overflowed = st[4];
+        aux_report_.seed_bytes = seed_.bytes();
+        return;
     }
 }
 
@@ -1203,9 +1424,12 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         view_.top_depth = 0;
         view_.sa_full = nullptr;
         view_.text_units = nullptr;
+        view_.seed = nullptr;
+        view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
         aux_report_ = AuxReport{};
         sa_full_.release();
         text_units_.release();
+        seed_.release();
         pair_lines_.release();
         jump_.release();
         top_.release();
@@ -1228,6 +1452,7 @@ void FmIndex::set_query_options(const QueryOptions &q)
     q_defer_after_.store(q.search_defer_after);
     q_fast_.store(q.search_fast);
     q_exact_.store(q.search_exact);
+    q_seed_.store(q.search_seed);
     q_max_hits_.store(q.max_hits_per_query);
 }
 
@@ -1243,6 +1468,7 @@ QueryOptions FmIndex::query_options() const
     q.search_defer_after = q_defer_after_.load();
     q.search_fast = q_fast_.load();
     q.search_exact = q_exact_.load();
+    q.search_seed = q_seed_.load();
     q.max_hits_per_query = q_max_hits_.load();
     // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
     if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;

@@ -30,6 +30,9 @@ struct BuildOptions {
     uint64_t aux_budget_bytes = 0;  // cap for jump + top table; 0 = min(free HBM - reserve, half of the HBM)
     int full_sa = -1;               // 1: SA[row] of every row as its own array
     int text_units = -1;            // 1: the text itself, 16 bytes per 32 symbols (layout.hpp)
+    int seed_symbols = -1;          // -1 / 0 none, 1 = seed table with k chosen from the text length, 8..24 = that k
+                                    // (implies text_units)
+    int seed_load_percent = 0;      // slots filled on average, 0 = default (70), 20..100
 };
 
 // What the aux build decided (gdx_index_aux_t)
@@ -37,6 +40,8 @@ struct AuxReport {
     uint32_t wanted_jump_bytes = 0, wanted_top_depth = 0;  // before the budget was applied
     uint64_t budget_bytes = 0, aux_bytes = 0;
     double wide_fraction = 0.0;  // share of text positions whose top-table interval is wider than 4 rows
+    // seed table: k, buckets, entries of kind 0 / kind 1, buckets that turned an entry away, largest displacement
+    uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0;
 };
 
 struct IndexConfig {
@@ -125,6 +130,7 @@ private:
                       const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits, bool packed = false) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
+    void build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream);
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                        gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
                        const uint4 *d_rec = nullptr) const;
@@ -132,7 +138,7 @@ private:
     IndexConfig cfg_;
     BuildStats stats_;
     AuxReport aux_report_;
-    std::atomic<int> q_search_variant_{-1}, q_search_lanes_{0}, q_load_policy_{-1}, q_schedule_{-1}, q_locate_variant_{-1}, q_locate_jump_walk_{-1}, q_defer_after_{-1}, q_fast_{-1}, q_exact_{-1};
+    std::atomic<int> q_search_variant_{-1}, q_search_lanes_{0}, q_load_policy_{-1}, q_schedule_{-1}, q_locate_variant_{-1}, q_locate_jump_walk_{-1}, q_defer_after_{-1}, q_fast_{-1}, q_exact_{-1}, q_seed_{-1};
     std::atomic<uint32_t> q_max_hits_{0};
     uint64_t n_ = 0, n_texts_ = 0;
     std::vector<uint64_t> count_host_;      // sigma+1
@@ -147,6 +153,7 @@ private:
     DeviceBuffer<uint2> top_;
     DeviceBuffer<uint32_t> sa_full_;
     DeviceBuffer<u32x4> text_units_;
+    DeviceBuffer<u32x4> seed_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;
     DeviceBuffer<uint32_t> count_;

@@ -23,6 +23,7 @@ struct QueryOptions {
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
                                   // finished in the block's straggler pass; 0 = never
     int search_exact = -1;        // exact-interval and cursor searches run search_exact_kernel4 first (default) or not (0)
+    int search_seed = -1;         // count / locate searches start from the seed table when the index has one (default) or not (0)
     uint32_t max_hits_per_query = 0;  // host-pointer locate calls: at most this many hits per query, the first ones in
                                       // suffix-array order (locate(q).take(k) of the reference's lazy iterator); 0 = all
 };

@@ -73,6 +73,27 @@ struct IndexView {
     // few rows compares the rest of the query with the text at SA[row] -- 32 symbols per 64-bit compare, one or two
     // fetches per row whatever the length -- instead of walking LF steps (search_verify_kernel4).
     const u32x4 *text_units;      // null when absent
+    // --- seed table: the LAST seed_k symbols of a count / locate query in one 128-byte fetch, and for most reads the
+    // whole answer (optional, needs the text units) -------------------------------------------------------------------------
+    // A bucketed hash table over the distinct seed_k-mers (A C G T only) of the text: seed_buckets buckets of eight 16-byte
+    // entries.  key = the k-mer in text order, 2 bits per symbol, first symbol lowest; tag = its low seed_tag_bits bits,
+    // a = key >> seed_tag_bits (< seed_buckets by construction), home bucket = (a + umulhi(tag * 0x9E3779B1, buckets))
+    // mod buckets -- for a fixed tag the map a -> bucket is one to one, so (bucket, tag) names the k-mer exactly and
+    // an absent k-mer is known to be absent.  An entry that found its home bucket full sits `disp` buckets further
+    // (linear probing over buckets); bit 31 of every entry of a bucket says that some entry was turned away there.
+    //   word 0: tag [20:0] | disp [25:21] (31 = empty slot) | kind [26] | partial [27] | overflow [31]
+    //   kind 0 (the k-mer occurs once):
+    //           {w0, SA of its row, codes of the 32 symbols in front of that position (as a text unit: first lowest)}
+    //           -- a read of up to seed_k + 32 symbols is decided by this entry alone, position included; a longer one
+    //           goes on comparing with the text units.  `partial`: only the v <= 29 symbols right in front are A C G T
+    //           of the same text (then comes a sentinel, an N, ...); v sits in the low six bits of the codes, and a read
+    //           that reaches further back than v symbols does not occur
+    //   kind 1 (several rows; or one row with 30 or 31 such symbols in front):
+    //           {w0, lo, hi, 0} = the k-mer's suffix-array interval; the search goes on from there as after a top table
+    const u32x4 *seed;            // null when absent
+    uint32_t seed_buckets;
+    uint32_t seed_k;              // 8..32
+    uint32_t seed_tag_bits;       // 0..21
     // --- C array, alphabet -------------------------------------------------------------
     const uint32_t *count;        // [sigma+1]  (lib.rs:95)
     const uint8_t *io_to_dense;   // [256]      (alphabet.rs:24-28)
@@ -102,6 +123,26 @@ struct IndexView {
     int32_t depth;
     int32_t layout;
 };
+
+// seed table entries (IndexView::seed)
+constexpr uint32_t kSeedTagBitsMax = 21;
+constexpr uint32_t kSeedDispShift = 21;
+constexpr uint32_t kSeedMaxDisp = 30;                       // 31 marks an empty slot
+constexpr uint32_t kSeedEmpty = 31u << kSeedDispShift;
+constexpr uint32_t kSeedMatchMask = 0x03ffffffu;            // tag and disp
+constexpr uint32_t kSeedKind = 1u << 26;
+constexpr uint32_t kSeedPartial = 1u << 27;
+constexpr uint32_t kSeedFound = 1u << 28;                   // never set in the table: marks a matched entry in registers
+constexpr uint32_t kSeedOverflow = 1u << 31;
+
+__device__ __forceinline__ uint32_t seed_home(uint64_t key, uint32_t tag_bits, uint32_t buckets, uint32_t &tag)
+{
+    tag = static_cast<uint32_t>(key) & ((1u << tag_bits) - 1u);
+    const uint32_t a = static_cast<uint32_t>(key >> tag_bits);
+    uint32_t b = a + __umulhi(tag * 0x9E3779B1u, buckets);  // both < buckets
+    if (b >= buckets) b -= buckets;
+    return b;
+}
 
 // first entry of lookup table t among the concatenated tables: sum of k^j for j < t (k = number of searchable symbols)
 __host__ __device__ __forceinline__ uint64_t lookup_offset(uint32_t k, uint32_t t)

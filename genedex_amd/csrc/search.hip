@@ -1894,9 +1894,17 @@ struct VerifyView {
     const uint8_t *io_to_dense;
     uint32_t top_depth, n, n_texts, sa_inv, sa_rot, sa_limit, max_rows;
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+    const u32x4 *seed;  // kSeed: IndexView::seed*
+    uint32_t seed_buckets, seed_k, seed_tag_bits;
 };
 
-template <int kXlate>
+// kSeed: the seed table instead of the top table (layout.hpp): ONE 128-byte bucket per read answers the last seed_k
+// symbols, and when that k-mer occurs once in the text -- nearly every read of a text without repeats -- the entry also
+// holds the position and the 32 symbols in front of it: a read of up to seed_k + 32 symbols is counted and located with
+// that single fetch (1.5 DRAM requests per len-50 read with its query bytes, against 2.7 through top and jump table),
+// a longer one goes on against the text units.  A k-mer on several rows hands over its interval and the search
+// continues as after a top table; an absent one is known to be absent.
+template <int kXlate, bool kSeed>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_verify_kernel4(
     VerifyView vv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
@@ -1929,13 +1937,93 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             const uint32_t q = static_cast<uint32_t>(base + slot);
             const uint64_t begin = qbeg[q];
             const uint64_t len = qend[q] - begin;
-            bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
+            bool bail = kSeed ? !(len >= vv.seed_k && len < (1ull << 21)) : !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0;
             const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0, part = 0;  // levels / symbols of level `shift` of the window already used up
-            if (!bail) {
+            bool single = false;           // kSeed: the k-mer occurs once, `pos` is where (no row is known)
+            bool single_ok = false;        // ... and the (up to) 32 symbols in front of it are the query's
+            uint32_t pos = 0;              // SA of this lane's row
+            if (kSeed && !bail) {
+                rem = static_cast<uint32_t>(len);
+                w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
+                const uint32_t k = vv.seed_k;
+                // the symbols this step decides on: the k of the seed and up to 32 in front of them
+                const uint32_t n_look = rem < k + 32u ? rem : k + 32u;
+                const uint32_t n_words = n_look <= w.s0 ? 1u : 1u + ((n_look - w.s0 + 7u) >> 3);
+                if ((w.valid8 & ((1u << n_words) - 1u)) != (1u << n_words) - 1u) {
+                    bail = true;
+                } else {
+                    // the window as one string, the query's last symbol in the top bits of w0
+                    const uint32_t w0 = __builtin_amdgcn_alignbit(w.l0, w.l0, 16), w1 = __builtin_amdgcn_alignbit(w.l1, w.l1, 16);
+                    const uint32_t w2 = __builtin_amdgcn_alignbit(w.l2, w.l2, 16), w3 = __builtin_amdgcn_alignbit(w.l3, w.l3, 16);
+                    const uint64_t key = ((static_cast<uint64_t>(w0) << 32) | w1) >> (64u - 2u * k);
+                    uint32_t tag;
+                    uint32_t b = seed_home(key, vv.seed_tag_bits, vv.seed_buckets, tag);
+                    uint32_t ex, ey, ez, ew;
+                    for (uint32_t d = 0;; d++) {
+                        const u32x4 *bp = vv.seed + (static_cast<uint64_t>(b) << 3) + 2u * sub;
+                        const u32x4 e0 = bp[0], e1 = bp[1];
+                        const uint32_t want = tag | (d << kSeedDispShift);
+                        const bool m0 = (e0.x & kSeedMatchMask) == want, m1 = (e1.x & kSeedMatchMask) == want;
+                        const u32x4 es = m0 ? e0 : e1;
+                        const bool m = m0 || m1;
+                        ex = m ? (es.x | kSeedFound) : (e0.x & kSeedOverflow);
+                        ey = m ? es.y : 0u;
+                        ez = m ? es.z : 0u;
+                        ew = m ? es.w : 0u;
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0xB1, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0xB1, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0xB1, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0xB1, 0xF, 0xF, true));
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0x4E, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0x4E, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0x4E, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0x4E, 0xF, 0xF, true));
+                        // found, or the bucket never turned an entry away: the k-mer is not in the text
+                        if ((ex & kSeedFound) != 0u || (ex & kSeedOverflow) == 0u || d >= kSeedMaxDisp) break;
+                        b = b + 1u == vv.seed_buckets ? 0u : b + 1u;
+                    }
+                    rem -= k;
+                    shift = k >> 3;
+                    part = k & 7u;
+                    if ((ex & kSeedFound) == 0u) {
+                        lo = hi = 0u;  // count 0
+                    } else if ((ex & kSeedKind) != 0u) {
+                        lo = ey;
+                        hi = ez;
+                    } else {
+                        single = true;
+                        lo = 0u;
+                        hi = 1u;
+                        pos = ey;
+                        // the 32 symbols that follow the seed in the window (in front of it in the query), in text order
+                        uint32_t qh, ql;
+                        const uint32_t sh = 32u - 2u * (k & 15u);
+                        if (k == 16u) {
+                            qh = w1;
+                            ql = w2;
+                        } else if (k < 16u) {
+                            qh = __builtin_amdgcn_alignbit(w0, w1, sh);
+                            ql = __builtin_amdgcn_alignbit(w1, w2, sh);
+                        } else {
+                            qh = __builtin_amdgcn_alignbit(w1, w2, sh);
+                            ql = __builtin_amdgcn_alignbit(w2, w3, sh);
+                        }
+                        const uint32_t n_v = rem < 32u ? rem : 32u;
+                        const uint64_t vm64 = n_v == 32u ? ~0ull : ~(~0ull >> (2u * n_v));
+                        const uint64_t qcode = (static_cast<uint64_t>(qh) << 32) | ql;
+                        const uint64_t tcode = (static_cast<uint64_t>(ew) << 32) | ez;
+                        // (partial entry: only ez & 63 <= 29 symbols in front are text A C G T -- a read that needs more
+                        // runs into a sentinel or an N there; one that needs fewer never looks at those six bits)
+                        const uint32_t n_text = (ex & kSeedPartial) != 0u ? (ez & 63u) : 0xffffffffu;
+                        single_ok = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
+                    }
+                }
+            }
+            if (!kSeed && !bail) {
                 rem = static_cast<uint32_t>(len);
                 w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
                 const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
@@ -1975,12 +2063,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 part &= 7u;
             }
             const uint32_t rows = hi - lo;
-            uint32_t alive = 0, pos = 0;  // alive: bit j = row lo + j matches; pos: SA of this lane's row
-            if (!bail && rem > 0u && rows != 0u) {
+            uint32_t alive = 0;  // bit j = row lo + j matches
+            if (kSeed && single && !bail && (rem <= 32u || !single_ok)) {
+                alive = single_ok ? 1u : 0u;  // decided by the entry alone
+            } else if (!bail && rem > 0u && rows != 0u) {
                 const bool real = sub < rows;
                 const uint32_t row = real ? lo + sub : lo;
                 // SA[row]: the full suffix array, the row's jump entry, or the locate walk (sampled_suffix_array.rs:110-138)
-                if (vv.sa_full != nullptr) {
+                if (kSeed && single) {
+                    // (known from the entry, as are the 32 symbols in front of it: the text compare starts beyond them)
+                } else if (vv.sa_full != nullptr) {
                     pos = vv.sa_full[row];
                 } else if (vv.jump != nullptr) {
                     pos = static_cast<const uint32_t *>(vv.jump)[static_cast<uint64_t>(row) * 8u + 6u];
@@ -2006,6 +2098,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 // compare the query's first `rem` symbols with the text in front of pos, 32 symbols per pass from the right
                 uint32_t rem_v = rem;
                 bool first = part == 0u && shift <= 3u;  // the window still serves the first pass
+                if (kSeed && single) {
+                    rem_v = rem - 32u;
+                    first = false;
+                }
                 while (rem_v > 0u) {
                     if (!first) {
                         w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem_v, sub);
@@ -2063,7 +2159,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                     s_left[atomicAdd(&s_nleft, 1u)] = q;
                 } else {
                     uint4 rec;
-                    if (rem == 0u || rows == 0u) {
+                    if (kSeed && single) {
+                        // (no row is known, and none is needed: a resolved record is its position)
+                        rec = alive ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
+                    } else if (rem == 0u || rows == 0u) {
                         rec = make_uint4(lo, hi, 0xffffffffu, 0u);  // the interval itself (count = rows)
                     } else if (rows == 1u) {
                         // (lane 0 holds row lo: its SA value is this record's position)
@@ -2333,12 +2432,18 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
     // (pair lines or rank lines) below.  QueryOptions::search_fast = 0 switches it off like the other fast path.
     {
         static const int env_fast_v = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : -1; }();
-        const bool verify = c.mode == 1 && ix.layout == 0 && ix.text_units != nullptr && ix.top != nullptr && ix.top_depth >= 1u &&
-                            ix.jump == nullptr && ix.n_searchable >= 4 && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
-                            c.d_step_stats == nullptr && !c.packed && c.d_hint == nullptr && c.d_start == nullptr &&
-                            c.d_end == nullptr && ca.active_in == nullptr && nq < 0xffffffffull &&
+        static const int env_seed = [] { const char *e = getenv("GDX_SEARCH_SEED"); return e ? atoi(e) : -1; }();
+        const bool clean_call = c.mode == 1 && ix.layout == 0 && ix.text_units != nullptr && ix.n_searchable >= 4 &&
+                                c.d_step_stats == nullptr && !c.packed && c.d_hint == nullptr && c.d_start == nullptr &&
+                                c.d_end == nullptr && ca.active_in == nullptr && nq < 0xffffffffull;
+        // (a configured lookup table deeper than the seed keeps its own check of the symbols between the two depths, as
+        // with the top table below)
+        const bool seed = clean_call && ix.seed != nullptr && ix.seed_k >= static_cast<uint32_t>(ix.depth) &&
+                          (env_seed >= 0 ? env_seed != 0 : qo.search_seed != 0);
+        const bool verify = !seed && clean_call && ix.top != nullptr && ix.top_depth >= 1u && ix.jump == nullptr &&
+                            ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
                             (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
-        if (verify) {
+        if (seed || verify) {
             uint64_t per_block = (nq + 1791) / 1792;
             per_block = (per_block + 63) / 64 * 64;
             const uint32_t v_range = static_cast<uint32_t>(per_block > kMaxRange ? kMaxRange : per_block);
@@ -2347,18 +2452,33 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
             // rows a verify round takes: four when SA[row] is one fetch away, one when it costs a locate walk
-            const uint32_t max_rows = ix.sa_full != nullptr ? 4u : 1u;
-            const VerifyView vv{ix.top, ix.text_units, ix.sa_full, nullptr, ix.lines, ix.sb_offsets, ix.count, ix.sa_samples,
-                                ix.border_keys, ix.border_vals, ix.io_to_dense, ix.top_depth, ix.n, ix.n_texts, ix.sa_inv,
-                                ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
-                                ix.perm_exp_hi, ix.perm_mask};
+            const bool entry_sa = ix.jump != nullptr && ix.jump_bytes == 32;
+            const uint32_t max_rows = (ix.sa_full != nullptr || entry_sa) ? 4u : 1u;
+            const VerifyView vv{ix.top, ix.text_units, ix.sa_full, entry_sa ? ix.jump : nullptr, ix.lines, ix.sb_offsets, ix.count,
+                                ix.sa_samples, ix.border_keys, ix.border_vals, ix.io_to_dense, ix.top_depth, ix.n, ix.n_texts,
+                                ix.sa_inv, ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
+                                ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits};
             static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
-            if (ix.perm_ok && !env_no_perm_v)
-                hipLaunchKernelGGL((search_verify_kernel4<1>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,
-                                   c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left);
-            else
-                hipLaunchKernelGGL((search_verify_kernel4<0>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,
-                                   c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left);
+            const bool perm = ix.perm_ok && !env_no_perm_v;
+#define GDX_VERIFY_LAUNCH(XLATE, SEED)                                                                                        \
+    hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg, \
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left)
+            if (seed) {
+                if (perm) GDX_VERIFY_LAUNCH(1, true);
+                else GDX_VERIFY_LAUNCH(0, true);
+            } else {
+                if (perm) GDX_VERIFY_LAUNCH(1, false);
+                else GDX_VERIFY_LAUNCH(0, false);
+            }
+#undef GDX_VERIFY_LAUNCH
+            static const bool env_stats_v = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list
+            if (env_stats_v) {
+                uint32_t n_left = 0;
+                GDX_HIP(hipMemcpyAsync(&n_left, d_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                GDX_HIP(hipStreamSynchronize(stream));
+                fprintf(stderr, "gdx: %s path left %u of %llu queries to the general kernel\n", seed ? "seed" : "verify", n_left,
+                        static_cast<unsigned long long>(nq));
+            }
             ca.active_in = d_left + 4;
             ca.n_active_in = d_left;
             leftover_list = true;

@@ -230,7 +230,8 @@ class DeviceEngine:
                 "full_suffix_array": bool(out[3] & 1), "text_units": bool(out[3] & 2),
                 "aux_bytes": a["aux_bytes"], "aux_budget_bytes": a["aux_budget_bytes"], "wide_permille": a["wide_permille"],
                 "shrunk_by_budget": (a["wanted_jump_entry_bytes"], a["wanted_top_table_depth"])
-                != (a["jump_entry_bytes"], a["top_table_depth"])}
+                != (a["jump_entry_bytes"], a["top_table_depth"]),
+                "seed": self.index.seed_info()}
 
     def search_lf_steps(self, q: DeviceQueries) -> int:
         return self.search_step_stats(q)[0]

@@ -42,7 +42,7 @@ _WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
 
 
 def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None,
-                  full_suffix_array=None, text_units=None):
+                  full_suffix_array=None, text_units=None, seed_symbols=None, seed_load_percent=None):
     """gdx_build_options_t (include/gdx.h); None = the library's default for that field."""
     o = _lib.BuildOptions()
     _lib.load().gdx_build_options_init(C.byref(o))
@@ -58,6 +58,10 @@ def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, 
         o.full_suffix_array = int(bool(full_suffix_array))
     if text_units is not None:
         o.text_units = int(bool(text_units))
+    if seed_symbols is not None:
+        o.seed_symbols = 1 if seed_symbols is True else int(seed_symbols)  # True = k chosen from the text length
+    if seed_load_percent is not None:
+        o.seed_load_percent = int(seed_load_percent)
     return o
 
 
@@ -92,11 +96,13 @@ class FmIndexConfig:
         return self
 
     def acceleration_structures(self, pair_lines=None, jump_entry_bytes=None, top_table_depth=None,
-                                aux_budget_bytes=None, full_suffix_array=None, text_units=None) -> "FmIndexConfig":
+                                aux_budget_bytes=None, full_suffix_array=None, text_units=None, seed_symbols=None,
+                                seed_load_percent=None) -> "FmIndexConfig":
         """gdx_build_options_t: which derived structures the index carries beside the reference's arrays
         (results are identical with any combination); None keeps the default."""
         self._build = dict(pair_lines=pair_lines, jump_entry_bytes=jump_entry_bytes, top_table_depth=top_table_depth,
-                           aux_budget_bytes=aux_budget_bytes, full_suffix_array=full_suffix_array, text_units=text_units)
+                           aux_budget_bytes=aux_budget_bytes, full_suffix_array=full_suffix_array, text_units=text_units,
+                           seed_symbols=seed_symbols, seed_load_percent=seed_load_percent)
         return self
 
     def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":
@@ -165,9 +171,17 @@ class FmIndex:
         _lib.check(self._lib.gdx_index_aux(self._h, C.byref(a)))
         return {f: int(getattr(a, f)) for f, _ in a._fields_}
 
+    def seed_info(self) -> dict:
+        """The seed table of the index (gdx_index_seed_info); k == 0: none."""
+        out = (C.c_uint64 * 8)()
+        _lib.check(self._lib.gdx_index_seed_info(self._h, out))
+        names = ("k", "buckets", "single_entries", "interval_entries", "overflowed_buckets", "max_displacement", "bytes",
+                 "tag_bits")
+        return {n: int(v) for n, v in zip(names, out)}
+
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
                           locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None,
-                          search_exact=None, max_hits_per_query=None) -> None:
+                          search_exact=None, max_hits_per_query=None, search_seed=None) -> None:
         """Kernel variant of the query calls on this handle; None = default.  Results never depend on it."""
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
@@ -192,6 +206,8 @@ class FmIndex:
             o.search_exact = int(bool(search_exact))
         if max_hits_per_query is not None:
             o.max_hits_per_query = int(max_hits_per_query)  # host-pointer locate calls: locate(q).take(k)
+        if search_seed is not None:
+            o.search_seed = int(bool(search_seed))
         _lib.check(self._lib.gdx_index_set_query_options(self._h, C.byref(o)))
 
     def rebuild_aux(self, **kw) -> None:

@@ -148,6 +148,16 @@ typedef struct {
                                   "not A C G T" bit, 16 bytes per 32 symbols): once a search is down to a few rows, the rest
                                   of the query is compared with the text at SA[row] in one fetch per row instead of LF
                                   steps -- the low-memory alternative to the jump table (count / locate searches)      */
+    int32_t seed_symbols;      /* -1 / 0 default off; 1 = a SEED TABLE with k chosen from the text length (ceil(log4 n) + 8, at
+                                  most 24), 8..24 = that k; implies text_units.  A bucketed hash table over the distinct k-mers of
+                                  the text (16 bytes each over the load factor: 71 GB for 3.1 G symbols): count / locate searches
+                                  fetch ONE 128-byte bucket for the last k symbols of a read, and when that k-mer occurs once in
+                                  the text -- nearly every read of a text without repeats -- the entry also holds its position and
+                                  the 32 symbols in front of it, so a read of up to k + 32 symbols is counted AND located with that
+                                  single fetch; longer reads go on against the text units, k-mers on several rows hand over their
+                                  suffix-array interval (results are the reference's either way).  gdx_index_seed_info reports   */
+    int32_t seed_load_percent; /* 0 default (70): slots of the seed table filled on average, 20..100 (fewer: more memory, fewer
+                                  reads that need a second bucket)                                                                */
 } gdx_build_options_t;
 void gdx_build_options_init(gdx_build_options_t *opts);
 
@@ -183,6 +193,11 @@ typedef struct {
     uint64_t aux_budget_bytes;       /* the budget that applied                       */
 } gdx_index_aux_t;
 int gdx_index_aux(const gdx_index_t *ix, gdx_index_aux_t *out);
+/* the seed table of an index: out[0] = k (0 = none), [1] = buckets of 128 bytes, [2] = k-mers that occur once with 32 symbols
+ * A C G T in front (answered by their entry alone), [3] = other k-mers (entries that hold a suffix-array interval), [4] = buckets
+ * that turned an entry away (a miss there looks into the next bucket as well), [5] = largest displacement in buckets,
+ * [6] = bytes, [7] = tag bits */
+int gdx_index_seed_info(const gdx_index_t *ix, uint64_t out[8]);
 
 /* ---- query options: which kernel variant the query calls on this handle use.  Every combination returns
  * identical results (the parity tests run them all); the defaults are the measured fastest.  The setting is
@@ -213,6 +228,8 @@ typedef struct {
                                 hits per query, the first ones in suffix-array order -- locate(q).take(k) of the reference's
                                 lazy iterator (lib.rs:187-197): one poly-A read on a genome would otherwise materialise
                                 gigabytes of hits.  hit_offsets then counts the hits RETURNED.  0 = all (default)        */
+    int32_t search_seed;     /* -1 default (1): count / locate searches start from the seed table when the index has one
+                                (gdx_build_options_t.seed_symbols); 0 = as if it had none                                    */
 } gdx_query_options_t;
 void gdx_query_options_init(gdx_query_options_t *opts);
 int gdx_index_set_query_options(gdx_index_t *ix, const gdx_query_options_t *opts);

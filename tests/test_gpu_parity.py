@@ -227,6 +227,14 @@ _VARIANTS = {
     "verify-walk": (dict(search_kernel="pair"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=5, text_units=True)),
     "verify-pairs": (dict(search_kernel="pair"), dict(jump_entry_bytes=0, top_table_depth=8, full_suffix_array=True,
                                                       text_units=True)),
+    # seed table in front (count / locate searches): a bucket fetch answers the last k symbols, and reads whose k-mer
+    # occurs once are answered by its entry alone
+    "seed-sa": (dict(search_kernel="pair"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0,
+                                                 full_suffix_array=True, seed_symbols=12)),
+    "seed-walk": (dict(search_kernel="quad"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, seed_symbols=True)),
+    # with everything else present too; a full table (every bucket overflows into its neighbours)
+    "seed-all": (dict(search_kernel="pair"), dict(seed_symbols=9, seed_load_percent=100)),
+    "seed-8": (dict(search_kernel="pair"), dict(jump_entry_bytes=16, seed_symbols=8, seed_load_percent=100)),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 
@@ -994,7 +1002,7 @@ def test_packed_queries_equal_ascii_queries(seed, search_variant):
     from genedex_amd import _lib
     from genedex_amd.device import DeviceEngine, _ptr, _stream
 
-    if search_variant in ("quad", "lane", "verify-sa", "verify-walk"):
+    if search_variant in ("quad", "lane", "verify-sa", "verify-walk", "seed-sa", "seed-walk"):
         pytest.skip("packed queries run on the pair-line kernels")
     lib = _lib.load()
     rng = np.random.default_rng(7300 + seed)

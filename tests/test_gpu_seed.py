@@ -1,0 +1,175 @@
+"""Seed table (gdx_build_options_t.seed_symbols): a bucketed hash table over the distinct k-mers of the text in front of
+the count / locate searches.  Whatever it holds, counts, hits and hit order are the reference's (the oracle's), and the
+same index answers identically with the table switched off."""
+import numpy as np
+import pytest
+
+from genedex_amd import alphabet as alph
+
+from helpers import naive_search, random_texts
+from test_gpu_parity import cpu_index, gpu_index, mixed_queries, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+LEAN = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0)
+
+
+def repetitive_texts(rng, n_texts=3, unit_len=300, copies=5, tail=800, symbols=b"ACGT"):
+    """texts that share segments (k-mers on several rows) next to unique stretches"""
+    unit = bytes(symbols[i] for i in rng.integers(0, len(symbols), unit_len))
+    out = []
+    for _ in range(n_texts):
+        parts = []
+        for _ in range(copies):
+            parts.append(unit[: int(rng.integers(40, unit_len))])
+            parts.append(bytes(symbols[i] for i in rng.integers(0, len(symbols), int(rng.integers(0, tail)))))
+        out.append(b"".join(parts))
+    return out
+
+
+def check_against_oracle(g, c, qs, texts=None, fold=None):
+    qbuf, qoff = pack_queries(qs)
+    off, t, p, st = g.locate_raw(qbuf, qoff)
+    co, ct, cp = c.locate_many(qs)
+    assert not st.any()
+    assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist()
+    counts, st = g.count_raw(qbuf, qoff)
+    assert not st.any()
+    assert counts.tolist() == np.diff(co).tolist()
+    if texts is not None:
+        for k, q in list(enumerate(qs))[:150]:
+            got = set(zip(t[off[k]:off[k + 1]].tolist(), p[off[k]:off[k + 1]].tolist()))
+            assert got == naive_search(texts, q, fold=fold), q
+    return off, t, p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seed_index_equals_oracle(seed):
+    rng = np.random.default_rng(9100 + seed)
+    a = [alph.ascii_dna(), alph.ascii_dna_with_n(), alph.ascii_dna_iupac_as_dna_with_n()][seed % 3]
+    symbols = b"ACGTN" if seed % 3 else b"ACGT"
+    texts = (repetitive_texts(rng, symbols=symbols) if seed % 2 else random_texts(rng, len_max=6000, symbols=symbols))
+    k = [8, 9, 12, 13, 16, True][seed % 6]
+    load = [None, 100, 40, 85][seed % 4]
+    extra = [LEAN, dict(LEAN, full_suffix_array=True), {}, dict(jump_entry_bytes=16, top_table_depth=5)][(seed // 2) % 4]
+    depth = [0, 3, 0, 6][seed % 4]
+    rate = int(rng.integers(1, 20))
+    g = gpu_index(texts, a, sa_rate=rate, depth=depth, seed_symbols=k, seed_load_percent=load, **extra)
+    c = cpu_index(texts, a, sa_rate=rate, depth=depth)
+    info = g.seed_info()
+    assert info["k"] == (k if k is not True else info["k"]) and info["k"] >= 8
+    assert info["single_entries"] + info["interval_entries"] > 0 or sum(len(t) for t in texts) < 8
+    qs = mixed_queries(rng, texts, 500, 150, 140) + [b"", b"A", b"ACGTACGT", b"ACGTACGTA"]
+    # reads that agree with the text on the seed and disagree further front (within and beyond the entry's 32 symbols)
+    for q in list(qs[:200]):
+        if len(q) > 12:
+            at = int(rng.integers(0, len(q) - 9))
+            qs.append(q[:at] + bytes([b"ACGT"[(b"ACGT".find(q[at:at + 1]) + 1) % 4]]) + q[at + 1:])
+    qs = [q for q in qs if b"N" not in q or depth == 0]
+    want = check_against_oracle(g, c, qs, texts, fold=a.io_to_dense_table)
+    g.set_query_options(search_seed=False)
+    off, t, p, _ = g.locate_raw(*pack_queries(qs))
+    assert off.tolist() == want[0].tolist() and t.tolist() == want[1].tolist() and p.tolist() == want[2].tolist()
+
+
+def test_seed_entries_are_the_distinct_kmers():
+    rng = np.random.default_rng(77)
+    a = alph.ascii_dna_with_n()
+    texts = repetitive_texts(rng, symbols=b"ACGTN")
+    k = 10
+    g = gpu_index(texts, a, seed_symbols=k, **LEAN)
+    kmers = {}
+    for t in texts:
+        for i in range(len(t) - k + 1):
+            w = t[i:i + k]
+            if b"N" not in w:
+                kmers.setdefault(w, []).append((t, i))
+    single = 0
+    for w, occ in kmers.items():
+        if len(occ) == 1:
+            t, i = occ[0]
+            v = 0  # symbols A C G T of the same text right in front
+            while v < 32 and i - v - 1 >= 0 and t[i - v - 1:i - v] != b"N":
+                v += 1
+            if v == 32 or v <= 29:  # (30 and 31 do not fit the entry's six bits: interval entries)
+                single += 1
+    info = g.seed_info()
+    assert info["single_entries"] == single
+    assert info["interval_entries"] == len(kmers) - single
+    assert info["bytes"] == info["buckets"] * 128
+    assert info["max_displacement"] <= 30
+
+
+def test_reads_longer_than_the_entry_covers_and_text_starts():
+    """k + 32 symbols are decided by the entry; the rest is compared with the text units.  Occurrences within 32
+    symbols of a text start (or behind an N) have interval entries and take the general route."""
+    rng = np.random.default_rng(5)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, 3000)) for _ in range(3)]
+    texts[1] = texts[1][:500] + b"N" + texts[1][501:]
+    g = gpu_index(texts, a, seed_symbols=12, full_suffix_array=True, **LEAN)
+    c = cpu_index(texts, a)
+    qs = []
+    for t in texts:
+        for start in (0, 1, 5, 20, 31, 32, 33, 100, 470, 489, 501, 502, 533, 534):
+            for ln in (12, 13, 40, 43, 44, 45, 76, 77, 108, 109, 300):
+                if start + ln <= len(t):
+                    q = t[start:start + ln]
+                    if b"N" not in q:
+                        qs.append(q)
+                        if ln > 50:  # one symbol off, far in front of the seed
+                            qs.append(bytes([b"ACGT"[(b"ACGT".find(q[:1]) + 1) % 4]]) + q[1:])
+    check_against_oracle(g, c, qs, texts)
+
+
+def test_queries_with_other_symbols_and_short_ones_go_the_general_way():
+    a = alph.ascii_dna_with_n()
+    rng = np.random.default_rng(8)
+    texts = [bytes(b"ACGTN"[i] for i in rng.integers(0, 5, 4000)), bytes(b"ACGT"[i] for i in rng.integers(0, 4, 2000))]
+    g = gpu_index(texts, a, seed_symbols=9)
+    c = cpu_index(texts, a)
+    qs = mixed_queries(rng, texts, 400, 50, 60, allow_n=True)
+    qs += [q[:3] for q in qs[:50]] + [b"N" * 12, b"ACGTNACGTACGT"]
+    check_against_oracle(g, c, qs, texts)
+    # status codes: a byte outside the alphabet is the reference's panic whatever the seed table says
+    # (the search reaches the X: what follows it occurs in the text)
+    qbuf, qoff = pack_queries([texts[1][100:105] + b"X" + texts[1][106:140], texts[1][100:140]])
+    _, st = g.count_raw(qbuf, qoff, strict=False)
+    _, _, cst = c.cursors_single(qbuf, qoff)
+    assert st.tolist() == cst.tolist() and st[0] != 0 and st[1] == 0
+
+
+def test_lookup_depth_beyond_the_seed_switches_it_off():
+    a = alph.ascii_dna_with_n()
+    rng = np.random.default_rng(9)
+    texts = random_texts(rng, len_max=5000, symbols=b"ACGT")
+    g = gpu_index(texts, a, depth=9, seed_symbols=8)
+    c = cpu_index(texts, a, depth=9)
+    qs = [q for q in mixed_queries(rng, texts, 300, 50, 50)]
+    check_against_oracle(g, c, qs, texts)
+
+
+def test_seed_k24_on_a_small_text():
+    """the full-size k on a small text: 2^27 buckets (17 GB), nearly all empty"""
+    import torch
+
+    if torch.cuda.mem_get_info()[0] < 40e9:
+        pytest.skip("needs 40 GB of free device memory")
+    a = alph.ascii_dna()
+    rng = np.random.default_rng(24)
+    texts = repetitive_texts(rng, n_texts=4, unit_len=600, tail=3000)
+    g = gpu_index(texts, a, seed_symbols=24, **LEAN)
+    c = cpu_index(texts, a)
+    info = g.seed_info()
+    assert info["k"] == 24 and info["buckets"] == 1 << 27 and info["tag_bits"] == 21
+    qs = mixed_queries(rng, texts, 800, 100, 160)
+    check_against_oracle(g, c, qs, texts)
+
+
+def test_bad_seed_options_are_rejected():
+    from genedex_amd import GdxError
+
+    a = alph.ascii_dna()
+    for kw in (dict(seed_symbols=5), dict(seed_symbols=25), dict(seed_symbols=12, seed_load_percent=10)):
+        with pytest.raises(GdxError):
+            gpu_index([b"ACGTACGTACGTAAAC"], a, **kw)

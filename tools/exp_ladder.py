@@ -27,6 +27,13 @@ RUNGS = {
     "top12_text": dict(top_table_depth=12, **text),
     "top16_sa_text_pairs": dict(top_table_depth=16, full_suffix_array=True, jump_entry_bytes=0, text_units=True),
     "pair_lines_only": dict(top_table_depth=0, jump_entry_bytes=0),
+    # seed table in front (one bucket fetch per read; reads whose k-mer occurs once are answered by the entry)
+    "seed_sa_text": dict(top_table_depth=0, full_suffix_array=True, seed_symbols=True, **text),
+    "seed_text": dict(top_table_depth=0, seed_symbols=True, **text),
+    "seed60_sa_text": dict(top_table_depth=0, full_suffix_array=True, seed_symbols=True, seed_load_percent=60, **text),
+    "seed80_sa_text": dict(top_table_depth=0, full_suffix_array=True, seed_symbols=True, seed_load_percent=80, **text),
+    "seed20_sa_text": dict(top_table_depth=0, full_suffix_array=True, seed_symbols=20, **text),
+    "seed_all": dict(seed_symbols=True, aux_budget_bytes=240_000_000_000),
 }
 names = sys.argv[1:] or list(RUNGS)
 total = 3_100_000_000
