@@ -86,6 +86,10 @@ def parse_args():
     ap.add_argument("--verify-hits", type=int, default=1_000_000)
     ap.add_argument("--secondary-depth", type=int, default=10,
                     help="N=1 only: lookup-table depth of the `lookup_depth_D` secondary design point; 0 = no secondaries")
+    ap.add_argument("--index", default="seed", choices=["seed", "tables"],
+                    help="headline index: seed = the reference's arrays + seed table + text units + full suffix array (74 GB "
+                         "at hg38 scale); tables = the library's default structures (pair lines + 32-byte jump entries + "
+                         "depth-16 top table, 144 GB: the headline of rounds 1..3a, a ladder rung now)")
     ap.add_argument("--jump-bytes", type=int, default=None, help="gdx_build_options_t.jump_entry_bytes")
     ap.add_argument("--top-depth", type=int, default=None, help="gdx_build_options_t.top_table_depth")
     ap.add_argument("--no-pair-lines", action="store_true", help="gdx_build_options_t.pair_lines = 0")
@@ -99,7 +103,14 @@ def parse_args():
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    args = ap.parse_args()
+    explicit = (args.jump_bytes is not None or args.top_depth is not None or args.no_pair_lines or args.full_sa or args.text_units)
+    if explicit:  # hand-picked structures (ladder rungs of the PMC children, experiments)
+        args.index = "tables"
+    return args
+
+
+SEED_INDEX = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, full_suffix_array=True, seed_symbols=True)
 
 
 # ======================================================================================================
@@ -147,13 +158,15 @@ def run_live_pmc(args, reference_layout=False, rung=None):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
-                  "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate)]
+                  "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate),
+                  "--index", "tables" if (reference_layout or rung) else args.index]
     jump_bytes, top_depth, no_pairs = args.jump_bytes, args.top_depth, args.no_pair_lines
     if reference_layout:
         jump_bytes, top_depth, no_pairs = 0, 0, True
     if rung == "top16_sa_text":
         jump_bytes, top_depth, no_pairs = 0, 16, True
         child_args += ["--full-sa", "--text-units"]
+    # rung == "tables": the library's default structures (--index tables, nothing else)
     for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", jump_bytes),
                     ("--top-depth", top_depth), ("--lanes", args.lanes), ("--load-policy", args.load_policy)):
         if v is not None:
@@ -168,7 +181,7 @@ def run_live_pmc(args, reference_layout=False, rung=None):
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
+               "search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
                "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
@@ -254,10 +267,14 @@ def workload_of(args):
 def build_options_of(args, **override):
     from genedex_amd.index import build_options
 
+    if getattr(args, "index", "tables") == "seed" and not override:
+        return build_options(**SEED_INDEX)
     kw = dict(jump_entry_bytes=args.jump_bytes, top_table_depth=args.top_depth,
               pair_lines=False if args.no_pair_lines else None,
               full_suffix_array=True if getattr(args, "full_sa", False) else None,
-              text_units=True if getattr(args, "text_units", False) else None)
+              text_units=True if getattr(args, "text_units", False) else None,
+              seed_symbols=getattr(args, "seed_symbols", None), seed_load_percent=getattr(args, "seed_load_percent", None),
+              aux_budget_bytes=getattr(args, "aux_budget_bytes", None))
     kw.update(override)
     return build_options(**kw)
 
@@ -477,7 +494,7 @@ def main():
             log(f"[bench] live PMC unavailable: {pmc_note}")
         elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
             pmc_ref, _ = run_live_pmc(args, reference_layout=True)
-            pmc_text, _ = run_live_pmc(args, rung="top16_sa_text")
+            pmc_text, _ = run_live_pmc(args, rung="tables" if args.index == "seed" else "top16_sa_text")
 
     import numpy as np
     import torch  # before libgdx.so: both must share torch's HIP runtime
@@ -556,7 +573,10 @@ def main():
     # ---- algorithmic bytes, counted by an extra, untimed pass in the exact mode -----------
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
-    kernel_pattern = "search_fast_kernel|search_pair_kernel" if aux["pair_lines"] else "search_kernel"
+    if aux["seed"]["k"]:  # the seed kernel, the seed-aware verify kernel on what it listed, the general kernel on the rest
+        kernel_pattern = "search_seed_kernel|search_verify_kernel|" + ("search_pair_kernel" if aux["pair_lines"] else "search_kernel")
+    else:
+        kernel_pattern = "search_fast_kernel|search_pair_kernel" if aux["pair_lines"] else "search_kernel"
     search_traffic = traffic_of(pmc, kernel_pattern)
     traffic_source = "live: rocprofv3 --pmc child passes of this run (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
     if search_traffic is None:
@@ -593,7 +613,16 @@ def main():
     # jump entry (ceil((len - D) / 40) per read: 32 steps + an 8-symbol lookahead each) + the 16-byte record written
     mean_len = queries.total_bytes / max(nq, 1)
     entries = max(0.0, -(-(mean_len - aux["top_table_depth"]) // 40)) if aux["jump_entry_bytes"] == 32 else None
-    if entries is not None and aux["top_table_depth"]:
+    if aux["seed"]["k"]:
+        # query bytes + one 8-byte offset + one 16-byte seed entry + the 16-byte record written (reads longer than k + 32
+        # symbols also compare with text units: not counted)
+        useful = queries.total_bytes + nq * (8 + 16 + 16)
+        roofline["useful_bytes_per_launch"] = useful
+        roofline["useful_bytes_per_query"] = useful / nq
+        if search_traffic:
+            roofline["wasted_traffic_ratio"] = search_traffic["bytes"] / useful
+            roofline["frac_useful"] = useful / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
+    elif entries is not None and aux["top_table_depth"]:
         useful = queries.total_bytes + nq * (8 + 8 + 32 * entries + 16)
         roofline["useful_bytes_per_launch"] = useful
         roofline["useful_bytes_per_query"] = useful / nq
@@ -601,6 +630,14 @@ def main():
             roofline["wasted_traffic_ratio"] = search_traffic["bytes"] / useful
             roofline["frac_useful"] = useful / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
     roofline["note"] = "frac=PMC traffic/time/peak; frac_algorithmic=SURVEY 8d bytes/time/peak (>1: tables replace LF steps)"
+    if aux["seed"]["k"]:
+        roofline["note_long_seed"] = (
+            "The search step is the seed kernel (one 128-byte bucket of the seed table per read: the last k symbols, and for a "
+            "k-mer that occurs once its position and the 32 symbols in front), the seed-aware verify kernel on the reads it "
+            "listed (k-mers on several rows) and the general kernel on what is left (symbols outside A C G T); traffic and "
+            "avg_launch_ms are those of all three launches.  Per read the step moves ~202 bytes of HBM traffic (128 bucket + 58 "
+            "query bytes and offset + 16 record): it is bound by HBM bytes -- every random access costs a whole 128-byte line "
+            "-- not by instructions or requests in flight.")
     roofline["note_long"] = ("The search step is the fast-path kernel (top table + jumps + lazy tail) followed by the general "
                              "kernel on the few queries it left over; traffic, requests and avg_launch_ms are those of both "
                              "launches together (rocprofv3's kernel stats list them separately). "
@@ -659,9 +696,11 @@ def main():
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + pair "
-                               f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
-                               f"top table; {wl['label']}",
+        "config": {"workload": (f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + "
+                                f"seed table (k={aux['seed']['k']}) + text units + full SA; {wl['label']}") if aux["seed"]["k"] else
+                               (f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + pair "
+                                f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
+                                f"top table; {wl['label']}"),
                    "index_gb_per_replica": index.info.device_bytes / 1e9,
                    "name": args.workload, "op": args.op, "path": args.path, "queries_per_gpu": nq,
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
@@ -707,7 +746,8 @@ def main():
         result["cpu_baseline"] = None
 
     if rank == 0 and world == 1 and not args.no_extras:
-        result["end_to_end"] = end_to_end(np, torch, index, queries, nq, counts, total_hits, ms_per_step, search_ms)
+        result["end_to_end"] = end_to_end(np, torch, index, queries, nq, counts, total_hits, ms_per_step, search_ms,
+                                           has_pair_lines=aux["pair_lines"])
 
     if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
         base_counts = counts.clone()
@@ -717,7 +757,7 @@ def main():
         owned = {"eng": eng, "index": index}  # handed over: the last rung frees the index before building another
         del eng, index
         result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
-                                          args, wl, pmc_ref, pmc_text)
+                                          args, wl, pmc_ref, pmc_text, result.get("end_to_end"))
         for r in result["secondary"]:  # the like-for-like rung, in the keys the driver keeps
             rl = r.get("roofline_reference_layout")
             if rl:
@@ -832,7 +872,7 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
 
 
 def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None,
-                pmc_text=None):
+                pmc_text=None, e2e=None):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -854,8 +894,14 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
               ("top12_jump8", dict(top_table_depth=12, jump_entry_bytes=8)),
               ("pair_lines_only", dict(top_table_depth=0, jump_entry_bytes=0)),
               ("reference_arrays_only", dict(top_table_depth=0, jump_entry_bytes=0, pair_lines=False))]
+    if args.index == "seed":
+        # the headline is the seed rung; the library's default structures (the headline of earlier rounds) and the seed
+        # table without the full suffix array come first
+        ladder = [("tables_top16_jump32_pairs", {}),
+                  ("seed_text_no_sa", {k: v for k, v in SEED_INDEX.items() if k != "full_suffix_array"})] + ladder
     if args.no_extras:
-        ladder = [r for r in ladder if r[0] in ("top16_sa_text", "top14_text", "pair_lines_only", "reference_arrays_only")]
+        ladder = [r for r in ladder if r[0] in ("tables_top16_jump32_pairs", "top16_sa_text", "top14_text", "pair_lines_only",
+                                                "reference_arrays_only")]
     for name, opts in ladder:
         t0 = time.time()
         index.rebuild_aux(**opts)
@@ -867,8 +913,9 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         r = {"name": name, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s",
              "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
              "aux_rebuild_seconds": t_aux, "index_bytes": int(index.info.device_bytes)}
-        if name == "top16_sa_text":
-            t_txt = traffic_of(pmc_text, "search_verify_kernel|search_kernel")
+        if name == ("tables_top16_jump32_pairs" if args.index == "seed" else "top16_sa_text"):
+            t_txt = traffic_of(pmc_text, "search_fast_kernel|search_pair_kernel" if args.index == "seed"
+                               else "search_verify_kernel|search_kernel")
             if t_txt:  # measured HBM traffic of this rung's search (PMC child passes of this run on the same configuration)
                 r["roofline"] = {"bound": "hbm", "kernel": t_txt["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                                  "traffic": t_txt["bytes"], "achieved": t_txt["bytes"] / (s_ms / 1e3) / 1e9,
@@ -898,8 +945,14 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         log(f"[bench] secondary {name}: {r}")
         res.append(r)
         del counts
-    index.rebuild_aux()  # back to the headline configuration
+    index.rebuild_aux()  # the library's default structures (what the exact-interval and cursor calls below run on)
     if not args.no_extras:
+        if args.index == "seed" and e2e:  # the packed-query calls run on the pair-line kernels
+            import numpy as np
+            ms_t, s_ms_t, _, _ = time_config(torch, eng, queries, nq, do_locate, args)
+            res.append({"name": "packed_queries_end_to_end (default structures)",
+                        **packed_end_to_end(np, torch, index, queries, nq, base_counts, e2e["pcie_h2d_GBps"], e2e["pcie_d2h_GBps"],
+                                            s_ms_t), "device_search_ms_on_ascii_input": s_ms_t})
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
     # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays)
     owned.clear()
@@ -923,7 +976,8 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
     if not args.no_extras and wl["total"] >= 1 << 24:
         del eng2, index2, counts
         torch.cuda.empty_cache()
-        res.append(genome_like_secondary(torch, alpha, wl, args))
+        # (on the library's default structures: reads from repeats are where the jump table beats the seed table)
+        res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), "index": "tables"})))
     return res
 
 
@@ -1117,7 +1171,7 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
     return res
 
 
-def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, search_ms):
+def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, search_ms, has_pair_lines=True):
     """SURVEY.md 8d "wall-clock incl. H2D/D2H": the host-pointer calls a genedex caller would make (queries as &[u8] in
     host memory, lib.rs:155-185; results into host arrays), which run as a chunked H2D || kernels || D2H pipeline
     (host_api.hip).  Never `value`.  The PCIe rates are measured here with pinned 1 GiB copies."""
@@ -1190,9 +1244,54 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
         lib.gdx_free_hits(last["ptr"])
     if not same_counts or not same_total:
         raise SystemExit("PARITY FAILURE: the host-pointer calls disagree with the device-resident path")
-    # the same count call on 2-bit packed queries (include/gdx.h "packed queries"): a quarter of the query bytes over
-    # PCIe; packing is done once by gdx_pack_queries (host threads) and timed separately -- a caller that stores its
-    # reads packed never pays it
+    in_bytes = nbytes + 8 * (nq + 1)
+    out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
+    out_locate_bytes = 5 * nq + 8 * total_hits
+    bound_count = max(in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3)
+    bound_locate = max(in_bytes / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3)
+    res = {"count_qps": nq / t_count, "count_seconds": t_count, "locate_qps": nq / t_locate, "locate_seconds": t_locate,
+           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "h2d_bytes": in_bytes, "d2h_bytes_count": out_count_bytes,
+           "d2h_bytes_locate": out_locate_bytes,
+           "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
+           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, kernel time)",
+           "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
+                    "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
+           "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
+    if has_pair_lines:
+        res["packed_queries"] = packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms)
+    else:
+        res["packed_queries"] = "measured on the default structures (packed queries run on the pair-line kernels): see secondary"
+    log(f"[bench] end to end: {res}")
+    return res
+
+
+def packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms):
+    """The count call on 2-bit packed queries (include/gdx.h "packed queries"; pair-line kernels): a quarter of the query
+    bytes over PCIe; packing is done once by gdx_pack_queries (host threads) and timed separately -- a caller that stores
+    its reads packed never pays it."""
+    import ctypes as C
+
+    from genedex_amd import _lib
+
+    lib = _lib.load()
+    dev = queries.qbuf.device
+    nbytes = queries.total_bytes
+    qbuf = queries.qbuf[:nbytes].cpu().numpy()
+    qoff = queries.qoff.cpu().numpy().astype(np.uint64)
+    counts = dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    status = np.empty(nq, dtype=np.uint8)
+    u8p, u64p = _lib.u8p, _lib.u64p
+
+    def best_of(fn, reps=2):
+        fn()
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
     packed = np.empty(int(lib.gdx_packed_bytes(nbytes)), dtype=np.uint8)
     exc = np.empty(1 << 20, dtype=np.uint64)
     n_exc = C.c_uint64(0)
@@ -1239,29 +1338,14 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
     if not same_dev:
         raise SystemExit("PARITY FAILURE: the packed device search gives other counts")
     del d_packed, rec
-    in_bytes = nbytes + 8 * (nq + 1)
     packed_in_bytes = nbytes // 4 + 8 * (nq + 1)
-    out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
-    out_locate_bytes = 5 * nq + 8 * total_hits
-    bound_count = max(in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3)
-    bound_locate = max(in_bytes / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3)
-    res = {"count_qps": nq / t_count, "count_seconds": t_count, "locate_qps": nq / t_locate, "locate_seconds": t_locate,
-           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "h2d_bytes": in_bytes, "d2h_bytes_count": out_count_bytes,
-           "d2h_bytes_locate": out_locate_bytes,
-           "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
-           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, kernel time)",
-           "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
-                    "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
-           "packed_queries": {"count_qps": nq / t_count_packed, "count_seconds": t_count_packed, "h2d_bytes": packed_in_bytes,
-                              "count_over_bound": t_count_packed / max(packed_in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9),
-                                                                       search_ms / 1e3),
-                              "host_packing_seconds_not_included": t_pack, "exception_queries": int(n_exc.value),
-                              "device_search_ms_on_packed_input": packed_search_ms,
-                              "device_search_ms_on_ascii_input": search_ms,
-                              "counts_identical_outside_the_exceptions": same_packed and same_dev},
-           "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
-    log(f"[bench] end to end: {res}")
-    return res
+    out_count_bytes = 5 * nq
+    return {"count_qps": nq / t_count_packed, "count_seconds": t_count_packed, "h2d_bytes": packed_in_bytes,
+            "count_over_bound": t_count_packed / max(packed_in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
+            "host_packing_seconds_not_included": t_pack, "exception_queries": int(n_exc.value),
+            "device_search_ms_on_packed_input": packed_search_ms,
+            "counts_identical_outside_the_exceptions": same_packed and same_dev,
+            "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h}
 
 
 def verify_hits(torch, io_text, lengths, queries, out, hits, total_hits, nq, n_check):

@@ -621,9 +621,9 @@ __global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__rest
             text_window32(units, static_cast<uint64_t>(p) + 32u * kTextPadUnits - 32u, code, mask);
             // symbols A C G T right in front of p (bit 31 of the mask is the symbol at p - 1)
             const uint32_t v = mask == 0u ? 32u : static_cast<uint32_t>(__builtin_clz(mask));
-            if (v == 32u || v <= 29u) {
-                if (v != 32u) code = (code & ~63ull) | v;  // (the low three symbols are not among the v)
-                e.x = v == 32u ? 0u : kSeedPartial;
+            {
+                if (v <= 29u) code = (code & ~63ull) | v;  // (the low three symbols are not among the v)
+                e.x = v == 32u ? 0u : (kSeedPartial | (v >= 30u ? (v - 29u) << kSeedPartialShift : 0u));
                 e.y = p;
                 e.z = static_cast<uint32_t>(code);
                 e.w = static_cast<uint32_t>(code >> 32);

@@ -81,14 +81,15 @@ struct IndexView {
     // mod buckets -- for a fixed tag the map a -> bucket is one to one, so (bucket, tag) names the k-mer exactly and
     // an absent k-mer is known to be absent.  An entry that found its home bucket full sits `disp` buckets further
     // (linear probing over buckets); bit 31 of every entry of a bucket says that some entry was turned away there.
-    //   word 0: tag [20:0] | disp [25:21] (31 = empty slot) | kind [26] | partial [27] | overflow [31]
+    //   word 0: tag [20:0] | disp [25:21] (31 = empty slot) | kind [26] | partial [27] | v code [30:29] | overflow [31]
     //   kind 0 (the k-mer occurs once):
     //           {w0, SA of its row, codes of the 32 symbols in front of that position (as a text unit: first lowest)}
     //           -- a read of up to seed_k + 32 symbols is decided by this entry alone, position included; a longer one
-    //           goes on comparing with the text units.  `partial`: only the v <= 29 symbols right in front are A C G T
-    //           of the same text (then comes a sentinel, an N, ...); v sits in the low six bits of the codes, and a read
-    //           that reaches further back than v symbols does not occur
-    //   kind 1 (several rows; or one row with 30 or 31 such symbols in front):
+    //           goes on comparing with the text units.  `partial`: only the v < 32 symbols right in front are A C G T
+    //           of the same text (then comes a sentinel, an N, ...); v sits in the low six bits of the codes (bits 30:29
+    //           of word 0: 1 = v is 30, 2 = 31, which leave no room there), and a read that reaches further back than v
+    //           symbols does not occur
+    //   kind 1 (several rows):
     //           {w0, lo, hi, 0} = the k-mer's suffix-array interval; the search goes on from there as after a top table
     const u32x4 *seed;            // null when absent
     uint32_t seed_buckets;
@@ -132,6 +133,7 @@ constexpr uint32_t kSeedEmpty = 31u << kSeedDispShift;
 constexpr uint32_t kSeedMatchMask = 0x03ffffffu;            // tag and disp
 constexpr uint32_t kSeedKind = 1u << 26;
 constexpr uint32_t kSeedPartial = 1u << 27;
+constexpr uint32_t kSeedPartialShift = 29;                  // bits 30:29 of a partial entry: 0 = v in the codes, 1 = 30, 2 = 31
 constexpr uint32_t kSeedFound = 1u << 28;                   // never set in the table: marks a matched entry in registers
 constexpr uint32_t kSeedOverflow = 1u << 31;
 

@@ -1908,7 +1908,8 @@ template <int kXlate, bool kSeed>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_verify_kernel4(
     VerifyView vv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
-    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list)  // list != null: only the *n_list queries listed
 {
     constexpr int kGroup = 4;
     __shared__ uint8_t s_dense[256];
@@ -1929,12 +1930,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
     const uint32_t depth = vv.top_depth;
+    if (list != nullptr) nq = *n_list;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
         const uint64_t base = rg * range;
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
-            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const uint32_t q = list != nullptr ? list[base + slot] : static_cast<uint32_t>(base + slot);
             const uint64_t begin = qbeg[q];
             const uint64_t len = qend[q] - begin;
             bool bail = kSeed ? !(len >= vv.seed_k && len < (1ull << 21)) : !(len >= 16u && len >= depth && len < (1ull << 21));
@@ -2016,9 +2018,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                         const uint64_t vm64 = n_v == 32u ? ~0ull : ~(~0ull >> (2u * n_v));
                         const uint64_t qcode = (static_cast<uint64_t>(qh) << 32) | ql;
                         const uint64_t tcode = (static_cast<uint64_t>(ew) << 32) | ez;
-                        // (partial entry: only ez & 63 <= 29 symbols in front are text A C G T -- a read that needs more
-                        // runs into a sentinel or an N there; one that needs fewer never looks at those six bits)
-                        const uint32_t n_text = (ex & kSeedPartial) != 0u ? (ez & 63u) : 0xffffffffu;
+                        // (partial entry: only n_text < 32 symbols in front are text A C G T -- a read that needs more runs
+                        // into a sentinel or an N there; one that needs fewer never looks at the bits that hold the number)
+                        const uint32_t v_code = (ex >> kSeedPartialShift) & 3u;
+                        const uint32_t n_text = (ex & kSeedPartial) == 0u ? 0xffffffffu : (v_code == 0u ? (ez & 63u) : 29u + v_code);
                         single_ok = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
                     }
                 }
@@ -2176,6 +2179,222 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 }
             }
         }
+        __syncthreads();
+        const uint32_t n_left = s_nleft;
+        if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nleft = 0;
+    }
+}
+
+// ---- the seed table's own kernel ---------------------------------------------------------------------------------------
+// What search_verify_kernel4<., true> does for the two cases that need nothing but the seed table and the text units --
+// the k-mer is absent, or it occurs once -- as a software pipeline: PMC on that kernel (profiles/r03/experiments.md
+// section 9) showed 404 VALU instructions per round of 16 reads (a third of them moving spilled scalars: the view has
+// twenty pointers) at 33 G requests/s, below the gather ceiling, because a read is a chain of three dependent loads
+// (offsets -> query bytes -> bucket) and a wavefront waited for each in turn.  Here the offsets of round i + 3 and the
+// query bytes of round i + 2 are in flight while round i + 1 computes its key and round i looks at its bucket, the view
+// is eleven words, and everything else -- a k-mer on several rows, a symbol outside A C G T, a read shorter than the
+// seed -- is listed for search_verify_kernel4<., true> (which takes such a list), whose own leftovers go to the general
+// kernel as before.
+struct SeedView {
+    const u32x4 *seed;
+    const u32x4 *text_units;
+    const uint8_t *io_to_dense;
+    uint32_t buckets, k, tag_bits;
+    uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+};
+
+template <int kXlate>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_seed_kernel4(
+    SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
+    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+{
+    constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
+    constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
+    __shared__ uint8_t s_dense[256];
+    __shared__ uint32_t s_left[kMaxRange];
+    __shared__ uint32_t s_nleft, s_left_base;
+    if (kXlate == 0)
+        for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = sv.io_to_dense[i];
+    if (threadIdx.x == 0) s_nleft = 0;
+    __syncthreads();
+    const bool writer = (threadIdx.x % kGroup) == 0;
+    const uint32_t sub = threadIdx.x & (kGroup - 1u);
+    const uint32_t slot0 = threadIdx.x / kGroup;
+    const uint32_t k = sv.k;
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        const uint64_t base = rg * range;
+        const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+        const int n_it = static_cast<int>((cnt + kGroups - 1u) / kGroups);
+        // pipeline state: stage C = offsets loaded, B = query bytes loaded, A = bucket loaded
+        uint64_t c_beg = 0, c_end = 0;
+        bool c_on = false;
+        u32x4 b_raw = {0u, 0u, 0u, 0u};
+        uint64_t b_beg = 0;
+        uint32_t b_len = kNoQuery;  // kNoQuery: nothing in this stage
+        u32x4 a_e0 = {0u, 0u, 0u, 0u}, a_e1 = {0u, 0u, 0u, 0u};
+        uint32_t a_tag = 0, a_bucket = 0, a_qh = 0, a_ql = 0, a_rem = kNoQuery;  // a_rem: symbols in front of the seed
+        bool a_left = false;  // the read of stage A goes to the leftover list
+        for (int it = -3; it < n_it; it++) {
+            // ---- stage A -> result: round `it` looks at its bucket -------------------------------------------------
+            if (it >= 0) {
+                const uint32_t slot = slot0 + static_cast<uint32_t>(it) * kGroups;
+                const uint32_t q = static_cast<uint32_t>(base + slot);
+                if (a_left) {
+                    if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;
+                } else if (a_rem != kNoQuery) {
+                    uint32_t ex, ey, ez, ew;
+                    u32x4 e0 = a_e0, e1 = a_e1;
+                    uint32_t b = a_bucket;
+                    for (uint32_t d = 0;; d++) {
+                        const uint32_t want = a_tag | (d << kSeedDispShift);
+                        const bool m0 = (e0.x & kSeedMatchMask) == want, m1 = (e1.x & kSeedMatchMask) == want;
+                        const u32x4 es = m0 ? e0 : e1;
+                        const bool m = m0 || m1;
+                        ex = m ? (es.x | kSeedFound) : (e0.x & kSeedOverflow);
+                        ey = m ? es.y : 0u;
+                        ez = m ? es.z : 0u;
+                        ew = m ? es.w : 0u;
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0xB1, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0xB1, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0xB1, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0xB1, 0xF, 0xF, true));
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0x4E, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0x4E, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0x4E, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0x4E, 0xF, 0xF, true));
+                        if ((ex & kSeedFound) != 0u || (ex & kSeedOverflow) == 0u || d >= kSeedMaxDisp) break;
+                        b = b + 1u == sv.buckets ? 0u : b + 1u;  // the bucket turned an entry away: look into the next one
+                        const u32x4 *bp = sv.seed + (static_cast<uint64_t>(b) << 3) + 2u * sub;
+                        e0 = bp[0];
+                        e1 = bp[1];
+                    }
+                    if ((ex & kSeedFound) != 0u && (ex & kSeedKind) != 0u) {
+                        if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;  // several rows: search_verify_kernel4 takes it
+                    } else {
+                        bool hit = false, left = false;
+                        const uint32_t rem = a_rem, pos = ey;
+                        if ((ex & kSeedFound) != 0u) {
+                            const uint32_t n_v = rem < 32u ? rem : 32u;
+                            const uint64_t vm64 = n_v == 32u ? ~0ull : ~(~0ull >> (2u * n_v));
+                            const uint64_t qcode = (static_cast<uint64_t>(a_qh) << 32) | a_ql;
+                            const uint64_t tcode = (static_cast<uint64_t>(ew) << 32) | ez;
+                            const uint32_t v_code = (ex >> kSeedPartialShift) & 3u;
+                            const uint32_t n_text = (ex & kSeedPartial) == 0u ? 0xffffffffu : (v_code == 0u ? (ez & 63u) : 29u + v_code);
+                            hit = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
+                            if (hit && rem > 32u) {
+                                // the rest against the text units, 32 symbols per pass from the right (as search_verify_kernel4)
+                                const uint64_t begin = qbeg[q];
+                                const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+                                const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
+                                uint32_t rem_v = rem - 32u;
+                                while (rem_v > 0u) {
+                                    const FastWindow w = fast_window<kXlate>(sv, s_dense, wbase, off0, rem_v, sub);
+                                    const uint32_t n_w = rem_v < 32u ? rem_v : 32u;
+                                    const uint32_t n_words = n_w <= w.s0 ? 1u : 1u + ((n_w - w.s0 + 7u) >> 3);
+                                    if ((w.valid8 & ((1u << n_words) - 1u)) != (1u << n_words) - 1u) {
+                                        left = true;  // a symbol outside A C G T further front: the general route
+                                        break;
+                                    }
+                                    const uint64_t qc = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(w.l0, w.l0, 16)) << 32) |
+                                                        static_cast<uint64_t>(__builtin_amdgcn_alignbit(w.l1, w.l1, 16));
+                                    const uint64_t s0 = static_cast<uint64_t>(pos) - rem + rem_v + 32u * kTextPadUnits - 32u;
+                                    const uint32_t tb = static_cast<uint32_t>(s0 & 31u);
+                                    const u32x4 *tu = sv.text_units + (s0 >> 5);
+                                    const u32x4 u0 = tu[0];
+                                    const u32x4 u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                                    const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
+                                    const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
+                                    const uint64_t tc = tb ? (c0 >> (2u * tb)) | (c1 << (64u - 2u * tb)) : c0;
+                                    const uint32_t tm = tb ? (u0.z >> tb) | (u1.z << (32u - tb)) : u0.z;
+                                    const uint64_t m64 = n_w == 32u ? ~0ull : ~0ull << (2u * (32u - n_w));
+                                    const uint32_t m32 = n_w == 32u ? ~0u : ~0u << (32u - n_w);
+                                    if (((qc ^ tc) & m64) != 0ull || (tm & m32) != 0u) {
+                                        hit = false;
+                                        break;
+                                    }
+                                    rem_v -= n_w;
+                                }
+                            }
+                        }
+                        if (writer) {
+                            if (left) {
+                                s_left[atomicAdd(&s_nleft, 1u)] = q;
+                            } else {
+                                // (no row is known, and none is needed: a resolved record is its position)
+                                if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
+                                if (out_count) out_count[q] = hit ? 1u : 0u;
+                                if (out_status) out_status[q] = 0;
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- stage B -> A: round `it + 1` turns its query bytes into key, bucket address and the 32 symbols in front
+            a_left = false;
+            a_rem = kNoQuery;
+            if (b_len != kNoQuery) {
+                if (b_len < k || b_len >= (1u << 21)) {
+                    a_left = true;
+                } else {
+                    const uint32_t off0 = static_cast<uint32_t>(b_beg & 7u);
+                    const FastWindow w = fast_window_finish<kXlate>(sv, s_dense, b_raw, off0, b_len, sub);
+                    const uint32_t n_look = b_len < k + 32u ? b_len : k + 32u;
+                    const uint32_t n_words = n_look <= w.s0 ? 1u : 1u + ((n_look - w.s0 + 7u) >> 3);
+                    if ((w.valid8 & ((1u << n_words) - 1u)) != (1u << n_words) - 1u) {
+                        a_left = true;
+                    } else {
+                        const uint32_t w0 = __builtin_amdgcn_alignbit(w.l0, w.l0, 16), w1 = __builtin_amdgcn_alignbit(w.l1, w.l1, 16);
+                        const uint32_t w2 = __builtin_amdgcn_alignbit(w.l2, w.l2, 16), w3 = __builtin_amdgcn_alignbit(w.l3, w.l3, 16);
+                        const uint64_t key = ((static_cast<uint64_t>(w0) << 32) | w1) >> (64u - 2u * k);
+                        a_bucket = seed_home(key, sv.tag_bits, sv.buckets, a_tag);
+                        const u32x4 *bp = sv.seed + (static_cast<uint64_t>(a_bucket) << 3) + 2u * sub;
+                        a_e0 = bp[0];
+                        a_e1 = bp[1];
+                        const uint32_t sh = 32u - 2u * (k & 15u);
+                        if (k == 16u) {
+                            a_qh = w1;
+                            a_ql = w2;
+                        } else if (k < 16u) {
+                            a_qh = __builtin_amdgcn_alignbit(w0, w1, sh);
+                            a_ql = __builtin_amdgcn_alignbit(w1, w2, sh);
+                        } else {
+                            a_qh = __builtin_amdgcn_alignbit(w1, w2, sh);
+                            a_ql = __builtin_amdgcn_alignbit(w2, w3, sh);
+                        }
+                        a_rem = b_len - k;
+                    }
+                }
+            }
+            // ---- stage C -> B: round `it + 2` knows where its query is and asks for its last 64 bytes ----------------
+            b_len = kNoQuery;
+            if (c_on) {
+                const uint64_t len = c_end - c_beg;
+                b_beg = c_beg;
+                b_len = len < (1ull << 21) ? static_cast<uint32_t>(len) : (1u << 21);
+                if (b_len >= k && b_len < (1u << 21)) {
+                    const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (c_beg >> 3);
+                    b_raw = fast_window_load<kXlate>(wbase, static_cast<uint32_t>(c_beg & 7u), b_len, sub);
+                }
+            }
+            // ---- -> stage C: the offsets of round `it + 3` -------------------------------------------------------------
+            c_on = false;
+            if (it + 3 < n_it) {
+                const uint32_t slot = slot0 + static_cast<uint32_t>(it + 3) * kGroups;
+                if (slot < cnt) {
+                    const uint32_t q = static_cast<uint32_t>(base + slot);
+                    c_beg = qbeg[q];
+                    c_end = qend[q];
+                    c_on = true;
+                }
+            }
+        }
+        // flush the range's leftover queries: one atomic, coalesced stores
         __syncthreads();
         const uint32_t n_left = s_nleft;
         if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
@@ -2460,15 +2679,39 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                                 ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits};
             static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
             const bool perm = ix.perm_ok && !env_no_perm_v;
-#define GDX_VERIFY_LAUNCH(XLATE, SEED)                                                                                        \
-    hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(v_blocks), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg, \
-                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_left + 4, d_left)
+#define GDX_VERIFY_LAUNCH(XLATE, SEED, BLOCKS, RANGE, LEFT, LIST)                                                             \
+    hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(BLOCKS), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,    \
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST)
+            uint32_t *const no_list = nullptr;
             if (seed) {
-                if (perm) GDX_VERIFY_LAUNCH(1, true);
-                else GDX_VERIFY_LAUNCH(0, true);
+                // the seed table's own kernel first (absent k-mers and k-mers that occur once); what it lists -- k-mers on
+                // several rows, reads shorter than the seed, other symbols -- goes through the seed-aware verify kernel,
+                // whose own leftovers the general kernel takes.  The lists' lengths are only known on the device: small
+                // ranges, a capped grid that strides over whatever there is.
+                static const int env_lean = [] { const char *e = getenv("GDX_SEARCH_SEED_LEAN"); return e ? atoi(e) : 1; }();
+                if (env_lean != 0) {
+                    uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
+                    GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
+                    const SeedView sv{ix.seed, ix.text_units, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
+                                      ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+                    if (perm)
+                        hipLaunchKernelGGL((search_seed_kernel4<1>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first);
+                    else
+                        hipLaunchKernelGGL((search_seed_kernel4<0>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first);
+                    const uint32_t l_range = 256;
+                    const uint64_t l_ranges = (nq + l_range - 1) / l_range;
+                    const unsigned l_blocks = static_cast<unsigned>(l_ranges < 8192 ? l_ranges : 8192);
+                    if (perm) GDX_VERIFY_LAUNCH(1, true, l_blocks, l_range, d_left, d_first);
+                    else GDX_VERIFY_LAUNCH(0, true, l_blocks, l_range, d_left, d_first);
+                } else {
+                    if (perm) GDX_VERIFY_LAUNCH(1, true, v_blocks, v_range, d_left, no_list);
+                    else GDX_VERIFY_LAUNCH(0, true, v_blocks, v_range, d_left, no_list);
+                }
             } else {
-                if (perm) GDX_VERIFY_LAUNCH(1, false);
-                else GDX_VERIFY_LAUNCH(0, false);
+                if (perm) GDX_VERIFY_LAUNCH(1, false, v_blocks, v_range, d_left, no_list);
+                else GDX_VERIFY_LAUNCH(0, false, v_blocks, v_range, d_left, no_list);
             }
 #undef GDX_VERIFY_LAUNCH
             static const bool env_stats_v = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list

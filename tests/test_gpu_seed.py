@@ -87,12 +87,7 @@ def test_seed_entries_are_the_distinct_kmers():
     single = 0
     for w, occ in kmers.items():
         if len(occ) == 1:
-            t, i = occ[0]
-            v = 0  # symbols A C G T of the same text right in front
-            while v < 32 and i - v - 1 >= 0 and t[i - v - 1:i - v] != b"N":
-                v += 1
-            if v == 32 or v <= 29:  # (30 and 31 do not fit the entry's six bits: interval entries)
-                single += 1
+            single += 1
     info = g.seed_info()
     assert info["single_entries"] == single
     assert info["interval_entries"] == len(kmers) - single
