@@ -976,8 +976,10 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
     if not args.no_extras and wl["total"] >= 1 << 24:
         del eng2, index2, counts
         torch.cuda.empty_cache()
-        # (on the library's default structures: reads from repeats are where the jump table beats the seed table)
-        res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), "index": "tables"})))
+        # (seed table AND the library's default structures: a read from a repeat goes on from its seed entry's interval with
+        # one jump round -- search_seed_kernel4 -> search_fast_kernel4 over its list -> the general kernel)
+        both = {"index": "tables", "seed_symbols": 1, "aux_budget_bytes": 240_000_000_000} if args.index == "seed" else {}
+        res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), **both})))
     return res
 
 

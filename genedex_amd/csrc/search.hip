@@ -1161,7 +1161,10 @@ template <int kJump, int kXlate, bool kWide>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_fast_kernel4(
     FastView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
-    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state)
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state,
+    // list != null: only the *n_list queries listed (what the seed kernel left over), each from where its state says:
+    // {lo, hi, symbols left, 1} = the interval of its last symbols (a seed-table entry), {.., 0} = from the beginning
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list)
 {
     constexpr int kGroup = 4;
     constexpr uint32_t kWideRows = kWide ? 16 : kGroup;  // widest interval a round takes
@@ -1183,14 +1186,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
     const bool hinting = out_rec != nullptr;
     const uint32_t depth = ix.top_depth;
+    if (list != nullptr) nq = *n_list;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
         const uint64_t base = rg * range;
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
-            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const uint32_t q = list != nullptr ? list[base + slot] : static_cast<uint32_t>(base + slot);
             const uint64_t begin = qbeg[q];
             const uint64_t len = qend[q] - begin;
+            uint4 resume = make_uint4(0u, 0u, 0u, 0u);
+            if (list != nullptr && state != nullptr) resume = state[q];
             bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0, hr = 0xffffffffu, ho = 0;
             const uint64_t *wbase = kXlate == 2 ? reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3))
@@ -1202,7 +1208,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             bool progressed = false;  // lo, hi, rem describe the search after the top table and whole rounds
             bool masked = false;      // the result is a masked record: hr = mask of surviving rows, ho = symbols left
             bool resolved = false;    // kEntrySA: hr = text position of the hit of the one-row interval
-            if (!bail) {
+            if (resume.w == 1u && len < (1ull << 21)) {
+                bail = false;  // (a read shorter than the top table is deep may still have a seed)
+                lo = resume.x;
+                hi = resume.y;
+                rem = resume.z;
+                progressed = true;
+            } else if (!bail) {
                 rem = static_cast<uint32_t>(len);
                 w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                 const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
@@ -2211,7 +2223,9 @@ template <int kXlate>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_seed_kernel4(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
-    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
+    uint4 *__restrict__ state)  // != null: where a listed read stands, {lo, hi, symbols left, 1} after a seed entry that holds
+                                // an interval, {0, 0, 0, 0} = from the beginning (search_fast_kernel4 goes on from there)
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
@@ -2246,7 +2260,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint32_t slot = slot0 + static_cast<uint32_t>(it) * kGroups;
                 const uint32_t q = static_cast<uint32_t>(base + slot);
                 if (a_left) {
-                    if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;
+                    if (writer) {
+                        s_left[atomicAdd(&s_nleft, 1u)] = q;
+                        if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
+                    }
                 } else if (a_rem != kNoQuery) {
                     uint32_t ex, ey, ez, ew;
                     u32x4 e0 = a_e0, e1 = a_e1;
@@ -2275,7 +2292,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         e1 = bp[1];
                     }
                     if ((ex & kSeedFound) != 0u && (ex & kSeedKind) != 0u) {
-                        if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;  // several rows: search_verify_kernel4 takes it
+                        if (writer) {  // several rows: the next kernel takes it from this interval
+                            s_left[atomicAdd(&s_nleft, 1u)] = q;
+                            if (state) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                        }
                     } else {
                         bool hit = false, left = false;
                         const uint32_t rem = a_rem, pos = ey;
@@ -2325,6 +2345,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         if (writer) {
                             if (left) {
                                 s_left[atomicAdd(&s_nleft, 1u)] = q;
+                                if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
                             } else {
                                 // (no row is known, and none is needed: a resolved record is its position)
                                 if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
@@ -2646,6 +2667,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
     };
     CursorArgs ca = c.cursors;
     bool leftover_list = false;  // ca.active_in is the (short) list another kernel of this call left over
+    uint32_t *seed_list = nullptr;  // ... the seed kernel's, with each read's state in its record slot: search_fast_kernel4 next
     // Count / locate searches on an index with text units and no jump table: top table, then the rest of the query against
     // the text at SA[row] (search_verify_kernel4); what it cannot finish is listed for the general kernel of the index
     // (pair lines or rank lines) below.  QueryOptions::search_fast = 0 switches it off like the other fast path.
@@ -2685,26 +2707,36 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             uint32_t *const no_list = nullptr;
             if (seed) {
                 // the seed table's own kernel first (absent k-mers and k-mers that occur once); what it lists -- k-mers on
-                // several rows, reads shorter than the seed, other symbols -- goes through the seed-aware verify kernel,
-                // whose own leftovers the general kernel takes.  The lists' lengths are only known on the device: small
-                // ranges, a capped grid that strides over whatever there is.
+                // several rows, reads shorter than the seed, other symbols -- goes on in search_fast_kernel4 from the entry's
+                // interval when the index has top and jump tables (one jump round for the rest of a read from a repeat),
+                // else through the seed-aware verify kernel; their leftovers go to the general kernel.  The lists' lengths
+                // are only known on the device: small ranges, a capped grid that strides over whatever there is.
                 static const int env_lean = [] { const char *e = getenv("GDX_SEARCH_SEED_LEAN"); return e ? atoi(e) : 1; }();
+                static const int env_chain = [] { const char *e = getenv("GDX_SEARCH_SEED_CHAIN"); return e ? atoi(e) : 1; }();
+                const bool to_fast = env_lean != 0 && env_chain != 0 && variant == 2 && ix.pair_lines != nullptr && ix.top != nullptr &&
+                                     ix.top_depth >= 1u && ix.jump != nullptr && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
+                                     (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
                     GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
                     const SeedView sv{ix.seed, ix.text_units, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
                                       ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+                    uint4 *d_seed_state = to_fast ? c.d_rec : nullptr;
                     if (perm)
                         hipLaunchKernelGGL((search_seed_kernel4<1>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first);
+                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first, d_seed_state);
                     else
                         hipLaunchKernelGGL((search_seed_kernel4<0>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first);
-                    const uint32_t l_range = 256;
-                    const uint64_t l_ranges = (nq + l_range - 1) / l_range;
-                    const unsigned l_blocks = static_cast<unsigned>(l_ranges < 8192 ? l_ranges : 8192);
-                    if (perm) GDX_VERIFY_LAUNCH(1, true, l_blocks, l_range, d_left, d_first);
-                    else GDX_VERIFY_LAUNCH(0, true, l_blocks, l_range, d_left, d_first);
+                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first, d_seed_state);
+                    if (to_fast) {
+                        seed_list = d_first;
+                    } else {
+                        const uint32_t l_range = 256;
+                        const uint64_t l_ranges = (nq + l_range - 1) / l_range;
+                        const unsigned l_blocks = static_cast<unsigned>(l_ranges < 8192 ? l_ranges : 8192);
+                        if (perm) GDX_VERIFY_LAUNCH(1, true, l_blocks, l_range, d_left, d_first);
+                        else GDX_VERIFY_LAUNCH(0, true, l_blocks, l_range, d_left, d_first);
+                    }
                 } else {
                     if (perm) GDX_VERIFY_LAUNCH(1, true, v_blocks, v_range, d_left, no_list);
                     else GDX_VERIFY_LAUNCH(0, true, v_blocks, v_range, d_left, no_list);
@@ -2717,13 +2749,13 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             static const bool env_stats_v = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list
             if (env_stats_v) {
                 uint32_t n_left = 0;
-                GDX_HIP(hipMemcpyAsync(&n_left, d_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                GDX_HIP(hipMemcpyAsync(&n_left, seed_list ? seed_list : d_left, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 GDX_HIP(hipStreamSynchronize(stream));
-                fprintf(stderr, "gdx: %s path left %u of %llu queries to the general kernel\n", seed ? "seed" : "verify", n_left,
+                fprintf(stderr, "gdx: %s path left %u of %llu queries to the next kernel\n", seed ? "seed" : "verify", n_left,
                         static_cast<unsigned long long>(nq));
             }
-            ca.active_in = d_left + 4;
-            ca.n_active_in = d_left;
+            ca.active_in = (seed_list ? seed_list : d_left) + 4;
+            ca.n_active_in = seed_list ? seed_list : d_left;
             leftover_list = true;
         }
     }
@@ -2798,9 +2830,10 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                           // the symbols between the two depths (a valid but unsearchable symbol there is an error, not a
                           // step) -- a leftover resumed after the top table would skip it
                           ix.n_searchable >= 4 && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
-                          ca.active_in == nullptr && c.d_hint == nullptr && c.d_start == nullptr && c.d_end == nullptr &&
-                          (env_fast >= 0 ? env_fast != 0 : qo.search_fast != 0) && nq < 0xffffffffull;
+                          (ca.active_in == nullptr || seed_list != nullptr) && c.d_hint == nullptr && c.d_start == nullptr &&
+                          c.d_end == nullptr && (env_fast >= 0 ? env_fast != 0 : qo.search_fast != 0) && nq < 0xffffffffull;
         CursorArgs ca_general = ca;
+        if (seed_list != nullptr) ca_general.resume_state = c.d_rec;  // (should the fast kernel not run: lanes, load policy)
         unsigned g_blocks = blocks;  // grid and range size of the general kernel
         uint32_t g_range = range;
         if (leftover_list) {  // short, and its length is only known on the device: small ranges, a capped grid
@@ -2866,14 +2899,20 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
             // sixteen-row rounds where reads from repeats are common (QueryOptions::search_fast == 2)
             const bool wide_rounds = (env_fast >= 0 ? env_fast : qo.search_fast) == 2;
-#define GDX_FAST_LAUNCH(J, XLATE)                                                                                           \
-    do {                                                                                                                    \
-        if (wide_rounds)                                                                                                    \
-            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, true>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf,  \
-                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state); \
-        else                                                                                                                \
-            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, false>), dim3(blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, \
-                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, range, d_left + 4, d_left, d_state); \
+            // (after the seed kernel: over its list -- small ranges, a capped grid, as for the general kernel's lists)
+            const unsigned f_blocks = seed_list ? g_blocks : blocks;
+            const uint32_t f_range = seed_list ? g_range : range;
+            const uint32_t *f_list = seed_list ? seed_list + 4 : nullptr;
+#define GDX_FAST_LAUNCH(J, XLATE)                                                                                             \
+    do {                                                                                                                      \
+        if (wide_rounds)                                                                                                      \
+            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, true>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf,  \
+                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
+                               f_list, seed_list);                                                                            \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, false>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, \
+                               c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
+                               f_list, seed_list);                                                                            \
     } while (0)
 #define GDX_FAST_LAUNCH_P(XLATE)                                  \
     do {                                                          \
