@@ -111,6 +111,7 @@ def parse_args():
 
 
 SEED_INDEX = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, full_suffix_array=True, seed_symbols=True)
+FULL_INDEX = dict(seed_symbols=True, inverse_suffix_array=True, aux_budget_bytes=250_000_000_000)
 
 
 # ======================================================================================================
@@ -945,15 +946,42 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         log(f"[bench] secondary {name}: {r}")
         res.append(r)
         del counts
-    index.rebuild_aux()  # the library's default structures (what the exact-interval and cursor calls below run on)
+    if args.index == "seed":
+        # every structure at once (214 GB): the library's defaults for the exact-interval and cursor calls below, plus seed
+        # table and inverse suffix array (exact intervals of reads that occur once: seed entry + one ISA fetch)
+        index.rebuild_aux(**FULL_INDEX)
+    else:
+        index.rebuild_aux()  # the library's default structures
     if not args.no_extras:
         if args.index == "seed" and e2e:  # the packed-query calls run on the pair-line kernels
             import numpy as np
             ms_t, s_ms_t, _, _ = time_config(torch, eng, queries, nq, do_locate, args)
-            res.append({"name": "packed_queries_end_to_end (default structures)",
+            res.append({"name": "packed_queries_end_to_end (index with every structure)", "aux_structures": eng.aux_info(),
+                        "index_bytes": int(index.info.device_bytes),
                         **packed_end_to_end(np, torch, index, queries, nq, base_counts, e2e["pcie_h2d_GBps"], e2e["pcie_d2h_GBps"],
                                             s_ms_t), "device_search_ms_on_ascii_input": s_ms_t})
+        # exact intervals of the headline's reads (cursors_for_many_queries): bit-identical to the reference's, frozen empty
+        # ones included (tests); here their widths must be the headline's counts
+        xo = eng.alloc_outputs(nq)
+        eng.search(queries, xo)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(3):
+            eng.search(queries, xo)
+        ev[1].record()
+        torch.cuda.synchronize()
+        x_ms = ev[0].elapsed_time(ev[1]) / 3
+        x_same = bool(torch.equal(torch.sub(xo["end"], xo["start"]), base_counts))
+        if not x_same:
+            raise SystemExit("PARITY FAILURE: exact interval widths differ from the headline's counts")
+        res.append({"name": "exact_intervals_len50 (cursors_for_many_queries on the headline's reads)", "queries": nq,
+                    "ms": x_ms, "value": nq / (x_ms / 1e3), "unit": "queries/s", "widths_identical_to_headline_counts": x_same,
+                    "aux_structures": eng.aux_info(), "index_bytes": int(index.info.device_bytes)})
+        log(f"[bench] secondary {res[-1]}")
+        del xo
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
+        res[-1]["aux_structures"] = eng.aux_info()
     # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays)
     owned.clear()
     del eng, index

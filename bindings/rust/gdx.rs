@@ -52,6 +52,7 @@ pub struct BuildOptions {
     pub text_units: i32,        // -1 / 0 off, 1: the text at 4 bits per symbol (count / locate compare with it)
     pub seed_symbols: i32,      // -1 / 0 off, 1: seed table with k from the text length, 8..=24: that k
     pub seed_load_percent: i32, // 0 = default (70)
+    pub inverse_suffix_array: i32, // -1 / 0 off, 1: ISA as its own array (exact intervals through the seed table)
 }
 impl Default for BuildOptions {
     fn default() -> Self {

@@ -51,7 +51,8 @@ class IndexInfo(C.Structure):
 class BuildOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32),
                 ("top_table_depth", C.c_int32), ("aux_budget_bytes", C.c_uint64), ("full_suffix_array", C.c_int32),
-                ("text_units", C.c_int32), ("seed_symbols", C.c_int32), ("seed_load_percent", C.c_int32)]
+                ("text_units", C.c_int32), ("seed_symbols", C.c_int32), ("seed_load_percent", C.c_int32),
+                ("inverse_suffix_array", C.c_int32)]
 
 
 class QueryOptions(C.Structure):

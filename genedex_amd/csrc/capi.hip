@@ -202,6 +202,8 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
         gdx::fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
     b.seed_symbols = o->seed_symbols;
     b.seed_load_percent = o->seed_load_percent;
+    if (o->inverse_suffix_array < -1 || o->inverse_suffix_array > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "inverse_suffix_array must be -1, 0 or 1");
+    b.inverse_sa = o->inverse_suffix_array;
     return b;
 }
 
@@ -268,6 +270,7 @@ void gdx_build_options_init(gdx_build_options_t *opts)
     opts->text_units = -1;
     opts->seed_symbols = -1;
     opts->seed_load_percent = 0;
+    opts->inverse_suffix_array = -1;
 }
 
 void gdx_query_options_init(gdx_query_options_t *opts)
@@ -1257,7 +1260,7 @@ int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
         out[0] = v.pair_lines != nullptr;
         out[1] = v.jump ? v.jump_bytes : 0u;
         out[2] = v.top ? v.top_depth : 0u;
-        out[3] = (v.sa_full ? 1u : 0u) | (v.text_units ? 2u : 0u);
+        out[3] = (v.sa_full ? 1u : 0u) | (v.text_units ? 2u : 0u) | (v.isa ? 4u : 0u);
         return (int)GDX_OK;
     });
 }

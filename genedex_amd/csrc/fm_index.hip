@@ -537,6 +537,13 @@ __global__ __launch_bounds__(kBlock) void scatter_text_units_kernel(IndexView ix
     }
 }
 
+// inverse suffix array: isa[SA[r]] = r
+__global__ __launch_bounds__(kBlock) void scatter_isa_kernel(const uint32_t *__restrict__ sa, uint64_t n, uint32_t *__restrict__ isa)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < n; r += stride) isa[sa[r]] = static_cast<uint32_t>(r);
+}
+
 // ---- seed table (IndexView::seed) -------------------------------------------------------------------------------------
 // The rows of the suffix array whose suffix starts with the same k-mer are one interval, so the distinct k-mers of the
 // text are the rows whose k-mer differs from the row before ("heads"), and everything about them -- interval, position,
@@ -1016,7 +1023,7 @@ void FmIndex::make_current() const { GDX_HIP(hipSetDevice(cfg_.device_id)); }
 
 uint64_t FmIndex::device_bytes() const
 {
-    return top_.bytes() + jump_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
+    return top_.bytes() + jump_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + isa_.bytes() + pair_lines_.bytes() + lines_.bytes() + sb_offsets_.bytes() + g_planes_.bytes() + g_block_off_.bytes() + count_.bytes() +
            io_to_dense_.bytes() + sa_samples_.bytes() + border_keys_.bytes() + border_vals_.bytes() +
            sentinels_.bytes() + lookup_.bytes();
 }
@@ -1146,6 +1153,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     view_.text_units = nullptr;
     view_.seed = nullptr;
     view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
+    view_.isa = nullptr;
+    isa_.release();
     pair_lines_.release();
     jump_.release();
     top_.release();
@@ -1172,8 +1181,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         if (seed_k < 8u || seed_k > 24u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_symbols must be 1 (automatic) or 8..24");
     }
     const bool want_seed = seed_k != 0;
-    const bool want_text = bo.text_units == 1 || want_seed, want_sa_full = bo.full_sa == 1;
-    if (view_.layout == 0 && n_ > 0 && (want_pairs || want_text || want_sa_full)) {
+    const bool want_text = bo.text_units == 1 || want_seed, want_sa_full = bo.full_sa == 1, want_isa = bo.inverse_sa == 1;
+    if (view_.layout == 0 && n_ > 0 && (want_pairs || want_text || want_sa_full || want_isa)) {
         double t0 = now_seconds();
         if (want_pairs) {
         const uint64_t n_lines = div_ceil(len, 128);
@@ -1262,7 +1271,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             // (the full suffix array and the text units are asked for explicitly: they count, but do not shrink)
             // (the seed table: 16 bytes per distinct k-mer over the load factor -- about n k-mers)
             const double seed_load = (bo.seed_load_percent > 0 ? bo.seed_load_percent : 70) / 100.0;
-            const double fixed = (want_sa_full ? 4.0 : 0.0) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_) +
+            const double fixed = ((want_sa_full ? 4.0 : 0.0) + (want_isa ? 4.0 : 0.0)) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_) +
                                  (want_seed ? 16.0 / seed_load : 0.0) * static_cast<double>(n_);
             auto need = [&] {
                 return fixed + static_cast<double>(jump_bytes) * static_cast<double>(n_) +
@@ -1315,7 +1324,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             aux_report_.wide_fraction = n_ ? static_cast<double>(wide) / static_cast<double>(n_) : 0.0;
         }
         // full suffix array: SA[row] by the locate walk (or out of the 32-byte jump entries, which hold it already)
-        if (want_sa_full || want_text) {
+        if (want_sa_full || want_text || want_isa) {
             DeviceBuffer<uint32_t> sa_tmp;
             uint32_t *d_sa = nullptr;
             if (want_sa_full) {
@@ -1340,10 +1349,17 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
             if (want_seed) build_seed_table(d_sa, seed_k, stream);
+            if (want_isa) {
+                isa_.alloc(n_);
+                hipLaunchKernelGGL(scatter_isa_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, d_sa, n_, isa_.get());
+                GDX_HIP(hipStreamSynchronize(stream));
+                GDX_HIP(hipGetLastError());
+                view_.isa = isa_.get();
+            }
             if (want_sa_full) view_.sa_full = sa_full_.get();
             if (want_text) view_.text_units = text_units_.get();
         }
-        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes();
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + isa_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }
@@ -1426,6 +1442,8 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         view_.text_units = nullptr;
         view_.seed = nullptr;
         view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
+        view_.isa = nullptr;
+        isa_.release();
         aux_report_ = AuxReport{};
         sa_full_.release();
         text_units_.release();

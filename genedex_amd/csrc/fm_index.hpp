@@ -33,6 +33,8 @@ struct BuildOptions {
     int seed_symbols = -1;          // -1 / 0 none, 1 = seed table with k chosen from the text length, 8..24 = that k
                                     // (implies text_units)
     int seed_load_percent = 0;      // slots filled on average, 0 = default (70), 20..100
+    int inverse_sa = -1;            // 1: ISA[position] = row as its own array (4 bytes per symbol): exact intervals through the
+                                    // seed table
 };
 
 // What the aux build decided (gdx_index_aux_t)
@@ -154,6 +156,7 @@ private:
     DeviceBuffer<uint32_t> sa_full_;
     DeviceBuffer<u32x4> text_units_;
     DeviceBuffer<u32x4> seed_;
+    DeviceBuffer<uint32_t> isa_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;
     DeviceBuffer<uint32_t> count_;

@@ -92,6 +92,9 @@ struct IndexView {
     //   kind 1 (several rows):
     //           {w0, lo, hi, 0} = the k-mer's suffix-array interval; the search goes on from there as after a top table
     const u32x4 *seed;            // null when absent
+    // inverse suffix array (optional): isa[p] = the row whose suffix starts at text position p.  With it the seed table
+    // also answers EXACT intervals: a read that occurs once, at position p, has the interval [isa[p], isa[p] + 1)
+    const uint32_t *isa;          // [n], null when absent
     uint32_t seed_buckets;
     uint32_t seed_k;              // 8..32
     uint32_t seed_tag_bits;       // 0..21

@@ -2214,15 +2214,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 struct SeedView {
     const u32x4 *seed;
     const u32x4 *text_units;
+    const uint32_t *isa;  // kExact: IndexView::isa
     const uint8_t *io_to_dense;
     uint32_t buckets, k, tag_bits;
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
 };
 
-template <int kXlate>
+// kExact: exact intervals (cursors_for_many_queries) instead of records: a read whose seed occurs once and whose other
+// symbols agree with the text occurs once itself, and the row of its only suffix is ISA[its position] -- one more fetch
+// (IndexView::isa), issued in one round and stored in the next.  Everything else needs the reference's frozen empty
+// interval (or an interval wider than a row) and is listed for search_exact_kernel4.
+template <int kXlate, bool kExact>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_seed_kernel4(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
     uint4 *__restrict__ state)  // != null: where a listed read stands, {lo, hi, symbols left, 1} after a seed entry that holds
                                 // an interval, {0, 0, 0, 0} = from the beginning (search_fast_kernel4 goes on from there)
@@ -2254,7 +2260,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         u32x4 a_e0 = {0u, 0u, 0u, 0u}, a_e1 = {0u, 0u, 0u, 0u};
         uint32_t a_tag = 0, a_bucket = 0, a_qh = 0, a_ql = 0, a_rem = kNoQuery;  // a_rem: symbols in front of the seed
         bool a_left = false;  // the read of stage A goes to the leftover list
-        for (int it = -3; it < n_it; it++) {
+        uint32_t z_row = 0, z_q = 0;  // kExact: the row of read z_q is on its way
+        bool z_on = false;
+        for (int it = -3; it <= n_it; it++) {
+            if (kExact) {
+                if (z_on && writer) {
+                    out_start[z_q] = z_row;
+                    out_end[z_q] = z_row + 1u;
+                    if (out_count) out_count[z_q] = 1u;
+                    if (out_status) out_status[z_q] = 0;
+                }
+                z_on = false;
+            }
+            if (it == n_it) break;
             // ---- stage A -> result: round `it` looks at its bucket -------------------------------------------------
             if (it >= 0) {
                 const uint32_t slot = slot0 + static_cast<uint32_t>(it) * kGroups;
@@ -2292,9 +2310,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         e1 = bp[1];
                     }
                     if ((ex & kSeedFound) != 0u && (ex & kSeedKind) != 0u) {
-                        if (writer) {  // several rows: the next kernel takes it from this interval
+                        if (kExact && a_rem == 0u) {  // the read IS the k-mer: the entry holds its interval
+                            if (writer) {
+                                out_start[q] = ey;
+                                out_end[q] = ez;
+                                if (out_count) out_count[q] = ez - ey;
+                                if (out_status) out_status[q] = 0;
+                            }
+                        } else if (writer) {  // several rows: the next kernel takes it from this interval
                             s_left[atomicAdd(&s_nleft, 1u)] = q;
-                            if (state) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                            if (!kExact && state) state[q] = make_uint4(ey, ez, a_rem, 1u);
                         }
                     } else {
                         bool hit = false, left = false;
@@ -2342,7 +2367,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 }
                             }
                         }
-                        if (writer) {
+                        if (kExact) {
+                            if (left || !hit) {  // no occurrence: the reference's frozen empty interval is the exact kernel's to find
+                                if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;
+                            } else {
+                                z_row = sv.isa[pos - rem];
+                                z_q = q;
+                                z_on = true;
+                            }
+                        } else if (writer) {
                             if (left) {
                                 s_left[atomicAdd(&s_nleft, 1u)] = q;
                                 if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -2719,15 +2752,18 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
                     GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
-                    const SeedView sv{ix.seed, ix.text_units, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
+                    const SeedView sv{ix.seed, ix.text_units, nullptr, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
                                       ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
                     uint4 *d_seed_state = to_fast ? c.d_rec : nullptr;
+                    uint32_t *const none = nullptr;
                     if (perm)
-                        hipLaunchKernelGGL((search_seed_kernel4<1>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first, d_seed_state);
+                        hipLaunchKernelGGL((search_seed_kernel4<1, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
+                                           c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
+                                           d_first, d_seed_state);
                     else
-                        hipLaunchKernelGGL((search_seed_kernel4<0>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first, d_seed_state);
+                        hipLaunchKernelGGL((search_seed_kernel4<0, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
+                                           c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
+                                           d_first, d_seed_state);
                     if (to_fast) {
                         seed_list = d_first;
                     } else {
@@ -2850,6 +2886,34 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                            (ix.top == nullptr || ix.top_depth >= static_cast<uint32_t>(ix.depth)) &&
                            (env_exact >= 0 ? env_exact != 0 : qo.search_exact != 0) && (defer_after == 0u || c.mode == 2) &&
                            nq < 0xffffffffull;
+        // Exact intervals on an index with seed table and inverse suffix array: the seed kernel answers the reads that occur
+        // exactly once through their seed (interval = the row ISA[position]); the exact kernel then goes over its list.
+        static const int env_seed_x = [] { const char *e = getenv("GDX_SEARCH_SEED"); return e ? atoi(e) : -1; }();
+        const bool seed_exact = exact && c.mode == 0 && ix.seed != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
+                                ix.seed_k >= static_cast<uint32_t>(ix.depth) && ca.active_in == nullptr &&
+                                (env_seed_x >= 0 ? env_seed_x != 0 : qo.search_seed != 0);
+        CursorArgs ca_exact = ca;
+        unsigned x_blocks = blocks;
+        uint32_t x_range = range;
+        if (seed_exact) {
+            uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
+            const SeedView sv{ix.seed, ix.text_units, ix.isa, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
+                              ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+            static const bool env_no_perm_s = getenv("GDX_SEARCH_NO_PERM") != nullptr;
+            uint4 *const no_rec = nullptr;
+            if (ix.perm_ok && !env_no_perm_s)
+                hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec);
+            else
+                hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec);
+            ca_exact.active_in = d_first + 4;
+            ca_exact.n_active_in = d_first;
+            x_range = 256;
+            const uint64_t x_ranges = (nq + x_range - 1) / x_range;
+            x_blocks = static_cast<unsigned>(x_ranges < 8192 ? x_ranges : 8192);
+        }
         if (exact) {
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
@@ -2858,8 +2922,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
             const bool perm = ix.perm_ok && !env_no_perm;
 #define GDX_EXACT_LAUNCH(J, XLATE, CURSOR)                                                                                  \
-    hipLaunchKernelGGL((search_exact_kernel4<J, XLATE, CURSOR>), dim3(blocks), dim3(kBlock), 0, stream, ev, c.d_qbuf,       \
-                       c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status, range, schedule, d_left + 4, d_left, ca)
+    hipLaunchKernelGGL((search_exact_kernel4<J, XLATE, CURSOR>), dim3(x_blocks), dim3(kBlock), 0, stream, ev, c.d_qbuf,     \
+                       c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status, x_range, schedule, d_left + 4, d_left, ca_exact)
 #define GDX_EXACT_LAUNCH_X(J, CURSOR)                    \
     do {                                                 \
         if (perm) GDX_EXACT_LAUNCH(J, 1, CURSOR);        \

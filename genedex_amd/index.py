@@ -42,7 +42,8 @@ _WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
 
 
 def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None,
-                  full_suffix_array=None, text_units=None, seed_symbols=None, seed_load_percent=None):
+                  full_suffix_array=None, text_units=None, seed_symbols=None, seed_load_percent=None,
+                  inverse_suffix_array=None):
     """gdx_build_options_t (include/gdx.h); None = the library's default for that field."""
     o = _lib.BuildOptions()
     _lib.load().gdx_build_options_init(C.byref(o))
@@ -62,6 +63,8 @@ def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, 
         o.seed_symbols = 1 if seed_symbols is True else int(seed_symbols)  # True = k chosen from the text length
     if seed_load_percent is not None:
         o.seed_load_percent = int(seed_load_percent)
+    if inverse_suffix_array is not None:
+        o.inverse_suffix_array = int(bool(inverse_suffix_array))
     return o
 
 
@@ -97,12 +100,13 @@ class FmIndexConfig:
 
     def acceleration_structures(self, pair_lines=None, jump_entry_bytes=None, top_table_depth=None,
                                 aux_budget_bytes=None, full_suffix_array=None, text_units=None, seed_symbols=None,
-                                seed_load_percent=None) -> "FmIndexConfig":
+                                seed_load_percent=None, inverse_suffix_array=None) -> "FmIndexConfig":
         """gdx_build_options_t: which derived structures the index carries beside the reference's arrays
         (results are identical with any combination); None keeps the default."""
         self._build = dict(pair_lines=pair_lines, jump_entry_bytes=jump_entry_bytes, top_table_depth=top_table_depth,
                            aux_budget_bytes=aux_budget_bytes, full_suffix_array=full_suffix_array, text_units=text_units,
-                           seed_symbols=seed_symbols, seed_load_percent=seed_load_percent)
+                           seed_symbols=seed_symbols, seed_load_percent=seed_load_percent,
+                           inverse_suffix_array=inverse_suffix_array)
         return self
 
     def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":

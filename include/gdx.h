@@ -158,6 +158,10 @@ typedef struct {
                                   suffix-array interval (results are the reference's either way).  gdx_index_seed_info reports   */
     int32_t seed_load_percent; /* 0 default (70): slots of the seed table filled on average, 20..100 (fewer: more memory, fewer
                                   reads that need a second bucket)                                                                */
+    int32_t inverse_suffix_array; /* -1 / 0 default off, 1: ISA[position] = row as its own array (4 bytes per symbol).  With it and a
+                                  seed table, cursors_for_many_queries answers every read that occurs exactly once (its seed's
+                                  entry, the text in front, then ONE fetch of the row) without LF steps; other reads take the usual
+                                  route, so the intervals -- frozen empty ones included -- stay the reference's               */
 } gdx_build_options_t;
 void gdx_build_options_init(gdx_build_options_t *opts);
 

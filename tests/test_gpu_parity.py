@@ -233,8 +233,11 @@ _VARIANTS = {
                                                  full_suffix_array=True, seed_symbols=12)),
     "seed-walk": (dict(search_kernel="quad"), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, seed_symbols=True)),
     # with everything else present too; a full table (every bucket overflows into its neighbours)
-    "seed-all": (dict(search_kernel="pair"), dict(seed_symbols=9, seed_load_percent=100)),
-    "seed-8": (dict(search_kernel="pair"), dict(jump_entry_bytes=16, seed_symbols=8, seed_load_percent=100)),
+    "seed-all": (dict(search_kernel="pair"), dict(jump_entry_bytes=16, seed_symbols=9, seed_load_percent=100)),
+    # + inverse suffix array: exact intervals of reads that occur once come from the seed entry and one ISA fetch
+    "seed-isa": (dict(search_kernel="pair"), dict(seed_symbols=10, inverse_suffix_array=True)),
+    "seed-isa-nojump": (dict(search_kernel="pair"), dict(jump_entry_bytes=0, top_table_depth=0, seed_symbols=True,
+                                                         inverse_suffix_array=True)),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 

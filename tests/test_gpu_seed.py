@@ -72,6 +72,40 @@ def test_seed_index_equals_oracle(seed):
     assert off.tolist() == want[0].tolist() and t.tolist() == want[1].tolist() and p.tolist() == want[2].tolist()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_exact_intervals_through_seed_table_and_inverse_suffix_array(seed):
+    """cursors_for_many_queries: a read that occurs exactly once gets [ISA[position], + 1) from its seed entry; every
+    other read -- absent (the reference's frozen empty interval), on several rows, with other symbols -- takes the usual
+    kernels.  All intervals equal the oracle's, and the switch changes nothing."""
+    rng = np.random.default_rng(9300 + seed)
+    a = [alph.ascii_dna(), alph.ascii_dna_with_n()][seed % 2]
+    symbols = b"ACGTN" if seed % 2 else b"ACGT"
+    texts = repetitive_texts(rng, symbols=symbols) if seed % 4 < 2 else random_texts(rng, len_max=8000, symbols=symbols)
+    k = [8, 11, 16, True][seed % 4]
+    extra = [{}, dict(jump_entry_bytes=16, top_table_depth=6), dict(jump_entry_bytes=0, top_table_depth=0), {}][(seed // 2) % 4]
+    depth = [0, 4][seed % 2]
+    g = gpu_index(texts, a, depth=depth, seed_symbols=k, inverse_suffix_array=True, seed_load_percent=[None, 100][seed % 2], **extra)
+    c = cpu_index(texts, a, depth=depth)
+    qs = mixed_queries(rng, texts, 600, 200, 150) + [b"", b"A", b"ACGTACGT"]
+    for q in list(qs[:200]):  # one symbol off
+        if len(q) > 12:
+            at = int(rng.integers(0, len(q)))
+            qs.append(q[:at] + bytes([b"ACGT"[(b"ACGT".find(q[at:at + 1]) + 1) % 4]]) + q[at + 1:])
+    qs = [q for q in qs if b"N" not in q or depth == 0]
+    qbuf, qoff = pack_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    s, e, st = g.cursors_raw(qbuf, qoff)
+    assert not st.any()
+    assert s.tolist() == cs.tolist() and e.tolist() == ce.tolist()
+    g.set_query_options(search_seed=False)
+    s2, e2, _ = g.cursors_raw(qbuf, qoff)
+    assert s2.tolist() == cs.tolist() and e2.tolist() == ce.tolist()
+    # the cursor API on the same index (cursor_for_query -> count / locate)
+    for q in qs[:20]:
+        cur = g.cursor_for_query(q)
+        assert cur.count() == len(naive_search(texts, q, fold=a.io_to_dense_table))
+
+
 def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()

@@ -15,13 +15,20 @@ from genedex_amd.device import (DeviceEngine, DeviceQueries, build_index_from_de
                                 synth_text)
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+opts = {}  # build options, e.g. seed_symbols=1 inverse_suffix_array=1 aux_budget_bytes=250000000000
+for kv in sys.argv[2:]:
+    k, v = kv.split("=")
+    opts[k] = int(v)
 total = 3_100_000_000
 dev = torch.device("cuda", 0)
 io_text = synth_text(total, seed=42, n_per_million=10_000, device=dev)
 lengths = hg38_text_lengths(total, 24)
-index = build_index_from_device_text(io_text, lengths, alphabet.ascii_dna_with_n(), index_storage="u32")
+from genedex_amd.index import build_options  # noqa: E402
+
+index = build_index_from_device_text(io_text, lengths, alphabet.ascii_dna_with_n(), index_storage="u32",
+                                     options=build_options(**opts))
 eng = DeviceEngine(index)
-res = {"reps": reps}
+res = {"reps": reps, "index_gb": index.info.device_bytes / 1e9, "aux": eng.aux_info()}
 
 
 def timed(fn):
