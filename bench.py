@@ -842,8 +842,8 @@ def committed_traffic(args, nq, aux, why):
     try:
         with open(path) as f:
             p = json.load(f)
-        if ((p["workload"], p["lookup_depth"], p["path"], p["jump_entry_bytes"], p["top_table_depth"])
-                != (args.workload, args.lookup_depth, args.path, aux["jump_entry_bytes"], aux["top_table_depth"])):
+        if ((p["workload"], p["lookup_depth"], p["path"], p["jump_entry_bytes"], p["top_table_depth"], p.get("seed_k", 0))
+                != (args.workload, args.lookup_depth, args.path, aux["jump_entry_bytes"], aux["top_table_depth"], aux["seed"]["k"])):
             return None, f"unavailable ({why}; the committed summary is of another configuration)"
         scale = nq / p["queries_per_launch"]
         t = {"kernel": p["kernel"], "read_bytes": p["read_bytes_per_launch"] * scale,

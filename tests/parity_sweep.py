@@ -89,11 +89,17 @@ def one_round(rng, stats):
              # the text itself and the full suffix array (count / locate searches compare with the text when there is no jump
              # table) in a third of the rounds
              "text_units": [None, None, True][int(rng.integers(0, 3))],
-             "full_suffix_array": [None, True][int(rng.integers(0, 2))]}
+             "full_suffix_array": [None, True][int(rng.integers(0, 2))],
+             # seed table (its own kernel, then the fast / verify / general kernels on what it lists) and inverse suffix array
+             # (exact intervals through the seed table) in two fifths of the rounds
+             "seed_symbols": [None, None, None, True, 8, 12][int(rng.integers(0, 6))],
+             "seed_load_percent": [None, 100, 45][int(rng.integers(0, 3))],
+             "inverse_suffix_array": [None, True][int(rng.integers(0, 2))]}
     query = {"search_lanes": [4, 4, 8][int(rng.integers(0, 3))], "load_policy": int(rng.integers(0, 2)),
              "length_schedule": int(rng.integers(0, 2)), "locate_jump_walk": int(rng.integers(0, 4)) != 0,
              "search_defer_after": [None, 0, 1, 2, 5][int(rng.integers(0, 5))],
-             "search_fast": int(rng.integers(0, 3)), "search_exact": int(rng.integers(0, 3)) != 0}
+             "search_fast": int(rng.integers(0, 3)), "search_exact": int(rng.integers(0, 3)) != 0,
+             "search_seed": int(rng.integers(0, 4)) != 0}
     storage = str(rng.choice(["i32", "u32"]))
     cfg = {"alphabet": name, "total": total, "n_texts": n_texts, "mode": mode, "sa_rate": rate, "depth": depth,
            "storage": storage, **build, **query}
@@ -209,7 +215,8 @@ def main():
         cfg = one_round(rng, stats)
         for key in ("alphabet", "mode", "jump_entry_bytes", "top_table_depth", "pair_lines", "search_lanes", "load_policy",
                     "length_schedule", "locate_jump_walk", "search_defer_after", "search_fast", "search_exact", "text_units",
-                    "full_suffix_array", "sa_rate", "depth"):
+                    "full_suffix_array", "seed_symbols", "seed_load_percent", "inverse_suffix_array", "search_seed", "sa_rate",
+                    "depth"):
             seen.setdefault(key, {}).setdefault(str(cfg[key]), 0)
             seen[key][str(cfg[key])] += 1
     print(json.dumps({"rounds": rounds, "seed": seed, "all_equal": True,

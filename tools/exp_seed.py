@@ -41,6 +41,9 @@ ms, s_ms, l_ms, counts = bench.time_config(torch, eng, q, nq, True, A, steps=rep
 res["len50"] = {"ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "Gq_per_s": nq / ms / 1e6,
                 "found": int((counts > 0).sum().item())}
 del q, counts
+if os.environ.get("GDX_EXP_SKIP_MIXED") == "1":  # (PMC passes: one kind of launch only)
+    print(json.dumps(res))
+    sys.exit(0)
 nq2 = nq // 2
 q = DeviceQueries.synth(io_text, lengths, nq2, 20, 150, 700_000, seed=47)
 ms, s_ms, l_ms, counts = bench.time_config(torch, eng, q, nq2, True, A, steps=reps)

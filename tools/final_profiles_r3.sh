@@ -15,6 +15,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 python3 $R/tools/summarize_rocprof.py stats $OUT/trace > $OUT/bench_hg38_final_kernel_stats.md
 find $OUT/trace -name '*.csv' -delete
 cd $R
-python3 tools/exp_general.py 3 > $OUT/exp_general_final.json 2> /dev/null
-python3 tests/parity_sweep.py 250 1 > $OUT/parity_sweep_seed1.json 2> $OUT/parity1.err
-tail -3 $OUT/gpu_tests_final.log; tail -c 400 $OUT/parity_sweep_seed1.json; echo; cat $OUT/bench_hg38_final_kernel_stats.md | head -12
+# exact intervals and the cursor API on the index with every structure (seed table + inverse suffix array + tables)
+python3 tools/exp_general.py 3 seed_symbols=1 inverse_suffix_array=1 aux_budget_bytes=250000000000 > $OUT/exp_general_final.json 2> /dev/null
+python3 tools/exp_seed.py 3 > $OUT/exp_seed_final.json 2> /dev/null
+python3 tests/parity_sweep.py 300 21 > $OUT/parity_sweep_seed21.json 2> $OUT/parity21.err
+bash tools/pmc_seed.sh $1/pmc_seed_kernel > /dev/null 2>&1
+tail -3 $OUT/gpu_tests_final.log; tail -c 400 $OUT/parity_sweep_seed21.json; echo; cat $OUT/bench_hg38_final_kernel_stats.md | head -12

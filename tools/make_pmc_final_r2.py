@@ -11,6 +11,7 @@ r, c = d["roofline"], d["config"]
 assert r["traffic_source"].startswith("live"), "the bench line has no live PMC traffic"
 out = {"workload": c["name"], "lookup_depth": c["lookup_depth"], "path": c["path"],
        "jump_entry_bytes": c["aux_structures"]["jump_entry_bytes"], "top_table_depth": c["aux_structures"]["top_table_depth"],
+       "seed_k": c["aux_structures"].get("seed", {}).get("k", 0),
        "kernel": r["kernel"], "queries_per_launch": c["queries_per_gpu"],
        "read_bytes_per_launch": r["traffic_read_bytes"], "write_bytes_per_launch": r["traffic_write_bytes"],
        "read_requests_per_launch": r["dram_read_requests_per_launch"],

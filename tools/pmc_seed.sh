@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
+export GDX_EXP_SKIP_MIXED=1
 cd /tmp
 i=0
 for grp in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_HIT_sum" \
