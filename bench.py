@@ -75,10 +75,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true")
     ap.add_argument("--no-hint", action="store_true", help="arrays path: locate without the hints of the search (A/B)")
-    ap.add_argument("--path", default="records", choices=["records", "arrays"],
-                    help="records: fused count + locate over 16-byte search records (gdx_locate_many_*_dev, lazy "
-                         "tails); arrays: exact intervals + hints (gdx_cursors_for_many_queries_hint_dev + "
-                         "gdx_locate_intervals_hint_dev), the round-1 path")
+    ap.add_argument("--path", default="records", choices=["records", "records16", "arrays"],
+                    help="records: fused count + locate over search records with the compact results beside them "
+                         "(gdx_locate_many_*_compact_dev: 4 bytes per read the seed kernel answers, 16-byte records for the "
+                         "rest); records16: 16-byte records only (gdx_locate_many_*_dev, rounds 2..3a); arrays: exact "
+                         "intervals + hints (gdx_cursors_for_many_queries_hint_dev + gdx_locate_intervals_hint_dev), the "
+                         "round-1 path")
     ap.add_argument("--overlap", action="store_true",
                     help="run the locate of batch k on a second stream beside the search of batch k + 1 (measured in "
                          "round 1: 2 %%, both kernels contend for DRAM requests; off by default so that the per-kernel "
@@ -299,7 +301,8 @@ class StepRunner:
     def __init__(self, torch, eng, queries, nq, do_locate, path, hint=True, n_slots=1):
         self.torch, self.eng, self.q, self.nq = torch, eng, queries, nq
         self.do_locate = do_locate
-        self.use_rec = path == "records" and do_locate
+        self.use_rec = path in ("records", "records16") and do_locate
+        self.use_compact = path == "records" and do_locate
         self.hint = hint and do_locate
         self.n_slots = n_slots
         self.outs = [self._alloc() for _ in range(n_slots)]
@@ -310,7 +313,7 @@ class StepRunner:
         # records path, optional (GDX_BENCH_FUSED_SCAN=1): offsets and single-hit locate in ONE pass over the records
         # (gdx_locate_many_scan_hits_dev).  Measured 1.7 ms against 1.33 ms for the two streaming passes it replaces (the
         # look-back of a single-pass scan crosses XCDs; profiles/r03/experiments.md section 8), so it is not the default.
-        self.fused_scan = self.use_rec and os.environ.get("GDX_BENCH_FUSED_SCAN") == "1"
+        self.fused_scan = self.use_rec and not self.use_compact and os.environ.get("GDX_BENCH_FUSED_SCAN") == "1"
         self.scan_ws, self.totals = [], []
         self.ev_scan = []
 
@@ -318,35 +321,43 @@ class StepRunner:
         o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
         if self.use_rec:
             o["rec"] = self.eng.alloc_records(self.nq)
+            o["compact"] = self.eng.alloc_compact(self.nq) if self.use_compact else None
         return o
 
     def search(self, o):
         if self.use_rec:
-            self.eng.locate_search(self.q, o["rec"])
+            self.eng.locate_search(self.q, o["rec"], compact=o["compact"])
         else:
             self.eng.search(self.q, o)
 
     def offsets(self, o):
         if self.use_rec:
-            self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"])
+            self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"], compact=o["compact"])
         else:
             self.eng.hit_offsets(o, self.nq)
 
     def locate(self, o, h, ws):
         if self.use_rec:
-            self.eng.locate_hits(o["rec"], self.nq, o["hit_offsets"], self.total_hits, h, ws)
+            self.eng.locate_hits(o["rec"], self.nq, o["hit_offsets"], self.total_hits, h, ws, compact=o["compact"])
         else:
             self.eng.locate(o, self.nq, self.total_hits, h, ws)
 
     def counts(self, o):
         """per-query number of occurrences (int32 tensor)"""
         if self.use_rec:
-            return self.torch.sub(o["rec"][:self.nq, 1], o["rec"][:self.nq, 0])
+            d = self.torch.sub(o["rec"][:self.nq, 1], o["rec"][:self.nq, 0])
+            if o["compact"] is not None:  # -2: see the record; -1: no occurrence; else the position of the only hit
+                c = o["compact"][:self.nq]
+                d = self.torch.where(c == -2, d, (c != -1).to(self.torch.int32))
+            return d
         return self.torch.sub(o["end"], o["start"])
 
     def status(self, o):
         if self.use_rec:
-            return (o["rec"][:self.nq, 3] >> 24) & 0xff
+            s = (o["rec"][:self.nq, 3] >> 24) & 0xff
+            if o["compact"] is not None:
+                s = self.torch.where(o["compact"][:self.nq] == -2, s, self.torch.zeros_like(s))
+            return s
         return o["status"]
 
     def size(self):
@@ -615,9 +626,9 @@ def main():
     mean_len = queries.total_bytes / max(nq, 1)
     entries = max(0.0, -(-(mean_len - aux["top_table_depth"]) // 40)) if aux["jump_entry_bytes"] == 32 else None
     if aux["seed"]["k"]:
-        # query bytes + one 8-byte offset + one 16-byte seed entry + the 16-byte record written (reads longer than k + 32
-        # symbols also compare with text units: not counted)
-        useful = queries.total_bytes + nq * (8 + 16 + 16)
+        # query bytes + one 8-byte offset + one 16-byte seed entry + the result written (4 bytes compact, else a 16-byte
+        # record; reads longer than k + 32 symbols also compare with text units: not counted)
+        useful = queries.total_bytes + nq * (8 + 16 + (4 if runner.use_compact else 16))
         roofline["useful_bytes_per_launch"] = useful
         roofline["useful_bytes_per_query"] = useful / nq
         if search_traffic:

@@ -177,6 +177,20 @@ extern "C" {
         ix: *const gdx_index_t, d_records: *const c_void, nq: u64, d_hit_offsets: *const c_void, total_hits: u64,
         d_hits: *mut c_void, d_workspace: *mut c_void, stream: *mut c_void,
     ) -> c_int;
+    // the same with compact results beside the records (u32 per query: position of the only hit, !0 = none, !1 = see the
+    // record): on an index with a seed table scan and locate stream 4 bytes per query instead of 16
+    pub fn gdx_locate_many_search_compact_dev(
+        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, d_records: *mut c_void,
+        d_compact: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_locate_many_offsets_compact_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, max_hits: u32,
+        d_hit_offsets: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_locate_many_hits_compact_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, d_hit_offsets: *const c_void,
+        total_hits: u64, d_hits: *mut c_void, d_workspace: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
     // several GPUs of one node behind one handle
     pub fn gdx_multi_build(
         texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int,

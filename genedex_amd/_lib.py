@@ -166,6 +166,10 @@ SIGNATURES = {
     "gdx_locate_many_offsets_capped_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_locate_many_hits_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_unpack_dev": [vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_search_compact_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_offsets_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp],
+    "gdx_locate_many_hits_compact_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_unpack_compact_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_packed_bytes": [C.c_uint64],
     "gdx_pack_queries": [vp, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
     "gdx_pack_queries_dev": [vp, vp, C.c_uint64, vp, vp, vp, vp],

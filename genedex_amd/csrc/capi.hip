@@ -965,6 +965,75 @@ int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uin
     });
 }
 
+// ---- the same with compact results beside the records (gdx.h) -------------------------------------------------
+
+int gdx_locate_many_search_compact_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                       void *d_records, void *d_compact, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if ((reinterpret_cast<uintptr_t>(d_qbuf) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qbuf must be 8-byte aligned");
+        check_records(d_records);
+        if (!d_compact && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_compact is null");
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = c.d_qbeg + 1;
+        c.nq = nq;
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.d_compact = static_cast<uint32_t *>(d_compact);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_offsets_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                        uint32_t max_hits, void *d_hit_offsets, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        const size_t tb = gdx::hit_offsets_rec_temp_bytes(nq);
+        void *temp = gdx::stream_scratch(as_stream(stream), 10, tb ? tb : 1);
+        gdx::launch_hit_offsets_rec(static_cast<const uint4 *>(d_records), nq, static_cast<uint64_t *>(d_hit_offsets),
+                                    temp, tb, as_stream(stream), max_hits, false, static_cast<const uint32_t *>(d_compact));
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                     const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits,
+                           d_hits, false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
+                           static_cast<const uint4 *>(d_records), false, false, static_cast<const uint32_t *>(d_compact));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                       void *d_out_counts, void *d_out_status, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_unpack_records(static_cast<const uint4 *>(d_records), nq, static_cast<uint32_t *>(d_out_counts),
+                                   static_cast<uint8_t *>(d_out_status), as_stream(stream), static_cast<const uint32_t *>(d_compact));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 // ---- packed queries ------------------------------------------------------------------------------------
 
 uint64_t gdx_packed_bytes(uint64_t n_symbols) { return (n_symbols + 3) / 4 / 8 * 8 + 16; }

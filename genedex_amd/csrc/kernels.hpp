@@ -55,6 +55,13 @@ constexpr uint32_t kRecMasked = 1u << 23;
 // status << 24}, end - start == 1 -- locate only turns the position into (text id, offset).
 constexpr uint32_t kRecResolved = 1u << 22;
 
+// COMPACT results (optional, beside the records): one u32 per query = the text position of its only hit, kCompactNone = no
+// occurrence, kCompactSee = look at the query's 16-byte record (several hits, an unresolved row, a status).  The seed
+// kernel answers nearly every read of a text without repeats this way, and scan and locate then stream 4 bytes per
+// query instead of 16 (the record slots of such queries are not written at all).
+constexpr uint32_t kCompactNone = 0xffffffffu;
+constexpr uint32_t kCompactSee = 0xfffffffeu;
+
 // One search launch.  Query i = d_qbuf[d_qbeg[i] .. d_qend[i]) (d_qend = d_qbeg + 1 for the usual offsets array).
 // mode 0: exact intervals (cursors_for_many_queries); mode 1: count / locate (end - start is the count, start / end
 // are only meaningful through the hint or record; see search_pair_body); mode 2: cursor extension, start / end are
@@ -68,6 +75,7 @@ struct SearchCall {
     uint8_t *d_status = nullptr;
     uint2 *d_hint = nullptr;
     uint4 *d_rec = nullptr;
+    uint32_t *d_compact = nullptr;  // mode 1 with d_rec: compact results (above)
     unsigned long long *d_step_stats = nullptr;
     int mode = 0;
     bool packed = false;  // d_qbuf holds 2-bit codes, d_qbeg / d_qend count symbols (pair-line indexes only)
@@ -114,20 +122,22 @@ size_t hit_offsets_rec_temp_bytes(uint64_t m);
 // max_hits != 0: queries with more occurrences get no hit slots (counted, not located) -- or, with `take`, slots for
 // their first max_hits rows
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
-                            hipStream_t stream, uint32_t max_hits = 0, bool take = false);
+                            hipStream_t stream, uint32_t max_hits = 0, bool take = false, const uint32_t *d_compact = nullptr);
 // exclusive scan of m u32 counts into m + 1 u64 offsets (the root of gdx_multi_locate_many_gather_dev)
 size_t count_offsets_temp_bytes(uint64_t m);
 void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offsets, void *d_temp, size_t temp_bytes,
                           hipStream_t stream);
 // counts (end - start) and status bytes out of search records
-void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream);
+void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream,
+                           const uint32_t *d_compact = nullptr);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
-                   const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false);
+                   const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false,
+                   const uint32_t *d_compact = nullptr);
 // One pass over the search records (locate.hip scan_locate_kernel): the hit offsets (what launch_hit_offsets_rec
 // computes) and, in the same pass, the hit of every query with exactly one hit slot -- resolved records need nothing,
 // others one fetch of SA[row] when the index has it.  d_totals (u64[2]): [0] = all hit slots, [1] = the slots left to

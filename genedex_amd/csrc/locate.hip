@@ -35,6 +35,7 @@ using SizeIterator =
 // the same from the 16-byte search records {start, end, hint row, hint symbols | status << 24}
 struct RecordSize {
     const uint4 *rec;
+    const uint32_t *compact;  // null, or the compact results beside the records (kernels.hpp)
     uint64_t m;
     uint32_t max_hits;  // 0 = no limit; a query with more occurrences than this gets no hit slots (it is counted,
                         // not located: what read mappers do with reads from repeats) -- or, with `take`, slots for its
@@ -43,6 +44,10 @@ struct RecordSize {
     __host__ __device__ uint64_t operator()(uint64_t q) const
     {
         if (q >= m) return 0ull;
+        if (compact != nullptr) {
+            const uint32_t c4 = compact[q];
+            if (c4 != kCompactSee) return c4 == kCompactNone ? 0ull : 1ull;
+        }
         const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
         const uint32_t c = v.y - v.x;
         return (max_hits != 0u && c > max_hits) ? (take ? static_cast<uint64_t>(max_hits) : 0ull) : static_cast<uint64_t>(c);
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                               const uint2 *__restrict__ hint,
                                                               const uint4 *__restrict__ rec, uint64_t total,
                                                               void *__restrict__ hits_out,
-                                                              unsigned long long *__restrict__ step_stats)
+                                                              unsigned long long *__restrict__ step_stats,
+                                                              const uint32_t *__restrict__ compact)
 {
     IndexView ix{};
     ix.lines = lv.lines;
@@ -289,6 +295,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
             if (rec != nullptr) {
+                if (compact != nullptr) {  // (kernels.hpp: the position itself, or "see the record")
+                    const uint32_t c4 = compact[q];
+                    if (c4 < kCompactSee) {
+                        store_hit<kWide>(ix, c4, hits_out, h, sentinels);
+                        continue;
+                    }
+                }
                 const uint4 r = rec[q];
                 row = r.x + static_cast<uint32_t>(h - first);
                 if (r.w & kRecResolved) {  // the search already knows the text position
@@ -681,7 +694,7 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
 size_t hit_offsets_rec_temp_bytes(uint64_t m)
 {
     size_t bytes = 0;
-    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{nullptr, m, 0u, false});
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{nullptr, nullptr, m, 0u, false});
     uint64_t *out = nullptr;
     (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1),
                                   rocprim::plus<uint64_t>());
@@ -689,9 +702,9 @@ size_t hit_offsets_rec_temp_bytes(uint64_t m)
 }
 
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
-                            hipStream_t stream, uint32_t max_hits, bool take)
+                            hipStream_t stream, uint32_t max_hits, bool take, const uint32_t *d_compact)
 {
-    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, m, max_hits, take});
+    RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
     GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
 }
@@ -705,10 +718,19 @@ struct CountAt {
 using CountIterator = rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, CountAt, uint64_t>;
 
 __global__ __launch_bounds__(kBlock) void unpack_records_kernel(const uint4 *__restrict__ rec, uint64_t m,
-                                                                uint32_t *__restrict__ counts, uint8_t *__restrict__ status)
+                                                                uint32_t *__restrict__ counts, uint8_t *__restrict__ status,
+                                                                const uint32_t *__restrict__ compact)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < m; q += stride) {
+        if (compact != nullptr) {
+            const uint32_t c4 = compact[q];
+            if (c4 != kCompactSee) {
+                if (counts) counts[q] = c4 == kCompactNone ? 0u : 1u;
+                if (status) status[q] = 0;
+                continue;
+            }
+        }
         const uint4 r = rec[q];
         if (counts) counts[q] = r.y - r.x;
         if (status) status[q] = static_cast<uint8_t>(r.w >> 24);
@@ -733,10 +755,12 @@ void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offs
                                     rocprim::plus<uint64_t>(), stream));
 }
 
-void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream)
+void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream,
+                           const uint32_t *d_compact)
 {
     if (m == 0) return;
-    hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_rec, m, d_counts, d_status);
+    hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_rec, m, d_counts, d_status,
+                       d_compact);
 }
 
 size_t scan_locate_workspace_bytes(uint64_t m)
@@ -781,7 +805,7 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single)
+                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -822,10 +846,12 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     do {                                                                                                                  \
         if (entry_sa)                                                                                                     \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
-                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats);        \
+                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
+                               d_compact);                                                                                \
         else                                                                                                              \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
-                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats);        \
+                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
+                               d_compact);                                                                                \
     } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)

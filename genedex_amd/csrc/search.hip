@@ -2230,8 +2230,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
-    uint4 *__restrict__ state)  // != null: where a listed read stands, {lo, hi, symbols left, 1} after a seed entry that holds
+    uint4 *__restrict__ state,  // != null: where a listed read stands, {lo, hi, symbols left, 1} after a seed entry that holds
                                 // an interval, {0, 0, 0, 0} = from the beginning (search_fast_kernel4 goes on from there)
+    uint32_t *__restrict__ out_compact)  // != null: compact results instead of records (kernels.hpp)
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
@@ -2281,6 +2282,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     if (writer) {
                         s_left[atomicAdd(&s_nleft, 1u)] = q;
                         if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
+                        if (!kExact && out_compact) out_compact[q] = kCompactSee;
                     }
                 } else if (a_rem != kNoQuery) {
                     uint32_t ex, ey, ez, ew;
@@ -2320,6 +2322,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         } else if (writer) {  // several rows: the next kernel takes it from this interval
                             s_left[atomicAdd(&s_nleft, 1u)] = q;
                             if (!kExact && state) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                            if (!kExact && out_compact) out_compact[q] = kCompactSee;
                         }
                     } else {
                         bool hit = false, left = false;
@@ -2379,9 +2382,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             if (left) {
                                 s_left[atomicAdd(&s_nleft, 1u)] = q;
                                 if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
+                                if (out_compact) out_compact[q] = kCompactSee;
                             } else {
                                 // (no row is known, and none is needed: a resolved record is its position)
-                                if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
+                                if (out_compact) out_compact[q] = hit ? pos - rem : kCompactNone;
+                                else if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
                                 if (out_count) out_count[q] = hit ? 1u : 0u;
                                 if (out_status) out_status[q] = 0;
                             }
@@ -2701,6 +2706,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
     CursorArgs ca = c.cursors;
     bool leftover_list = false;  // ca.active_in is the (short) list another kernel of this call left over
     uint32_t *seed_list = nullptr;  // ... the seed kernel's, with each read's state in its record slot: search_fast_kernel4 next
+    bool compact_by_seed = false;   // c.d_compact has been filled by the seed kernel
+    if (c.d_compact != nullptr && (c.mode != 1 || c.d_rec == nullptr))
+        fail(GDX_ERR_INVALID_ARGUMENT, "internal: compact results go with the records of a count / locate search");
     // Count / locate searches on an index with text units and no jump table: top table, then the rest of the query against
     // the text at SA[row] (search_verify_kernel4); what it cannot finish is listed for the general kernel of the index
     // (pair lines or rank lines) below.  QueryOptions::search_fast = 0 switches it off like the other fast path.
@@ -2759,11 +2767,12 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                     if (perm)
                         hipLaunchKernelGGL((search_seed_kernel4<1, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state);
+                                           d_first, d_seed_state, c.d_compact);
                     else
                         hipLaunchKernelGGL((search_seed_kernel4<0, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state);
+                                           d_first, d_seed_state, c.d_compact);
+                    compact_by_seed = true;
                     if (to_fast) {
                         seed_list = d_first;
                     } else {
@@ -2795,6 +2804,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             leftover_list = true;
         }
     }
+    // compact results without the seed kernel: every query says "see the record"
+    if (c.d_compact != nullptr && !compact_by_seed) GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.d_compact), static_cast<int>(kCompactSee), nq, stream));
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
         // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
         // QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
@@ -2902,12 +2913,15 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
             static const bool env_no_perm_s = getenv("GDX_SEARCH_NO_PERM") != nullptr;
             uint4 *const no_rec = nullptr;
+            uint32_t *const none_u32 = nullptr;
             if (ix.perm_ok && !env_no_perm_s)
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec);
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
+                                   none_u32);
             else
                 hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec);
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
+                                   none_u32);
             ca_exact.active_in = d_first + 4;
             ca_exact.n_active_in = d_first;
             x_range = 256;

@@ -161,16 +161,33 @@ class DeviceEngine:
     def alloc_records(self, nq: int) -> torch.Tensor:
         return torch.empty((max(nq, 1), 4), dtype=torch.int32, device=self.dev)
 
-    def locate_search(self, q: DeviceQueries, rec: torch.Tensor) -> None:
+    def alloc_compact(self, nq: int) -> torch.Tensor:
+        """compact results beside the records (gdx.h): int32[nq], the position of the only hit / -1 none / -2 see the record"""
+        return torch.empty(max(nq, 1), dtype=torch.int32, device=self.dev)
+
+    def locate_search(self, q: DeviceQueries, rec: torch.Tensor, compact: torch.Tensor = None) -> None:
+        if compact is not None:
+            _lib.check(self.lib.gdx_locate_many_search_compact_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec),
+                                                                   _ptr(compact), _stream()))
+            return
         _lib.check(self.lib.gdx_locate_many_search_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec), _stream()))
 
-    def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, max_hits: int = 0) -> None:
+    def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, max_hits: int = 0,
+                       compact: torch.Tensor = None) -> None:
         """max_hits != 0: queries with more occurrences are counted but get no hit slots"""
+        if compact is not None:
+            _lib.check(self.lib.gdx_locate_many_offsets_compact_dev(self.h, _ptr(rec), _ptr(compact), nq, max_hits,
+                                                                    _ptr(hit_offsets), _stream()))
+            return
         _lib.check(self.lib.gdx_locate_many_offsets_capped_dev(self.h, _ptr(rec), nq, max_hits, _ptr(hit_offsets),
                                                                _stream()))
 
     def locate_hits(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, total: int, hits: torch.Tensor,
-                    workspace: torch.Tensor) -> None:
+                    workspace: torch.Tensor, compact: torch.Tensor = None) -> None:
+        if compact is not None:
+            _lib.check(self.lib.gdx_locate_many_hits_compact_dev(self.h, _ptr(rec), _ptr(compact), nq, _ptr(hit_offsets), total,
+                                                                 _ptr(hits), _ptr(workspace), _stream()))
+            return
         _lib.check(self.lib.gdx_locate_many_hits_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
                                                      _ptr(workspace), _stream()))
 
@@ -189,7 +206,12 @@ class DeviceEngine:
         _lib.check(self.lib.gdx_locate_many_hits_rest_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
                                                           _ptr(workspace), _stream()))
 
-    def unpack_records(self, rec: torch.Tensor, nq: int, counts=None, status=None) -> None:
+    def unpack_records(self, rec: torch.Tensor, nq: int, counts=None, status=None, compact=None) -> None:
+        if compact is not None:
+            _lib.check(self.lib.gdx_locate_many_unpack_compact_dev(self.h, _ptr(rec), _ptr(compact), nq,
+                                                                   _ptr(counts) if counts is not None else None,
+                                                                   _ptr(status) if status is not None else None, _stream()))
+            return
         _lib.check(self.lib.gdx_locate_many_unpack_dev(self.h, _ptr(rec), nq,
                                                        _ptr(counts) if counts is not None else None,
                                                        _ptr(status) if status is not None else None, _stream()))

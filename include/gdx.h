@@ -391,6 +391,21 @@ int gdx_locate_many_hits_rest_dev(const gdx_index_t *ix, const void *d_records, 
                                   uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream);
+/* COMPACT results beside the records: d_compact (u32[nq], device) holds per query the text position of its ONLY hit
+ * (concatenated texts incl. sentinels, as the resolved records), 0xffffffff = no occurrence, or 0xfffffffe = "see
+ * d_records[q]" (several hits, a row that still has to be located, a status).  On an index with a seed table
+ * (gdx_build_options_t.seed_symbols) the search answers nearly every read of a text without repeats this way and leaves
+ * their 16-byte records untouched; offsets and hits then stream 4 bytes per query instead of 16.  On any other index every
+ * entry says "see the record" (same results, no gain).  The four calls mirror gdx_locate_many_search_dev /
+ * _offsets_capped_dev / _hits_dev / _unpack_dev; results are identical to theirs (lib.rs:155-185). */
+int gdx_locate_many_search_compact_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                       void *d_records, void *d_compact, void *stream);
+int gdx_locate_many_offsets_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                        uint32_t max_hits, void *d_hit_offsets, void *stream);
+int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                     const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
+int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                       void *d_out_counts, void *d_out_status, void *stream);
 
 /* ---- packed queries ("allow 2-bit host packing as an optional input format") ------------------------
  * Four symbols per byte instead of one: symbol j of the buffer sits in bits 2 (j & 3) .. 2 (j & 3) + 1 of byte j >> 2

@@ -106,6 +106,67 @@ def test_exact_intervals_through_seed_table_and_inverse_suffix_array(seed):
         assert cur.count() == len(naive_search(texts, q, fold=a.io_to_dense_table))
 
 
+def device_locate(g, qs, compact, max_hits=0):
+    """search -> offsets -> hits on the device through the records calls, with or without the compact results"""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    eng = DeviceEngine(g)
+    dq = DeviceQueries.from_host(*pack_queries(qs))
+    rec = eng.alloc_records(dq.nq)
+    rec.fill_(0x5a5a5a5a)  # (stale bytes: the compact path leaves the records of answered reads untouched)
+    cmp_ = eng.alloc_compact(dq.nq) if compact else None
+    off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+    eng.locate_search(dq, rec, compact=cmp_)
+    eng.locate_offsets(rec, dq.nq, off, max_hits, compact=cmp_)
+    torch.cuda.synchronize()
+    tot = int(off[dq.nq].item())
+    hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+    if tot:
+        eng.locate_hits(rec, dq.nq, off, tot, hits, ws, compact=cmp_)
+    counts = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+    stat = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+    eng.unpack_records(rec, dq.nq, counts, stat, compact=cmp_)
+    torch.cuda.synchronize()
+    answered = int((cmp_[:dq.nq] != -2).sum().item()) if compact else 0
+    return (off.cpu().numpy().astype(np.uint64), hits[:tot].cpu().numpy().astype(np.uint32), counts.cpu().numpy().astype(np.uint32),
+            stat.cpu().numpy(), answered)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_compact_results_equal_records_and_oracle(seed):
+    """gdx_locate_many_*_compact_dev: 4 bytes per query wherever the seed kernel answers a read, "see the record" elsewhere
+    (every query on an index without a seed table) -- offsets, hits, counts and statuses are those of the records path and
+    of the oracle."""
+    rng = np.random.default_rng(9500 + seed)
+    a = [alph.ascii_dna(), alph.ascii_dna_with_n()][seed % 2]
+    symbols = b"ACGTN" if seed % 2 else b"ACGT"
+    texts = repetitive_texts(rng, symbols=symbols) if seed % 4 < 2 else random_texts(rng, len_max=8000, symbols=symbols)
+    build = [dict(LEAN, seed_symbols=True, full_suffix_array=True), dict(seed_symbols=11), {},
+             dict(LEAN, seed_symbols=9, seed_load_percent=100)][(seed // 2) % 4]
+    g = gpu_index(texts, a, **build)
+    c = cpu_index(texts, a)
+    qs = [q for q in mixed_queries(rng, texts, 600, 200, 120) + [b"", b"ACGTACGTACGT"] if b"N" not in q]
+    co, ct, cp = c.locate_many(qs)
+    got = {}
+    for compact in (False, True):
+        off, hits, counts, stat, answered = device_locate(g, qs, compact)
+        assert off.tolist() == co.tolist()
+        assert hits[:, 0].tolist() == ct.astype(np.uint32).tolist() and hits[:, 1].tolist() == cp.astype(np.uint32).tolist()
+        assert counts.tolist() == np.diff(co).astype(np.uint32).tolist() and not stat.any()
+        got[compact] = answered
+    if build.get("seed_symbols"):
+        assert got[True] > len(qs) // 4  # the seed kernel answered reads compactly
+    else:
+        assert got[True] == 0
+    # a cap on the hits per query applies to the records behind "see the record" alike
+    off_a, hits_a, _, _, _ = device_locate(g, qs, False, max_hits=2)
+    off_b, hits_b, _, _, _ = device_locate(g, qs, True, max_hits=2)
+    assert off_a.tolist() == off_b.tolist() and hits_a.tolist() == hits_b.tolist()
+
+
 def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()
