@@ -38,7 +38,7 @@ def test_traffic_from_pmc_counters():
 
 def test_committed_fallback_summary_is_readable():
     args = argparse.Namespace(workload="hg38", lookup_depth=0, path="records")
-    aux = {"jump_entry_bytes": 32, "top_table_depth": 16}
+    aux = {"jump_entry_bytes": 0, "top_table_depth": 0, "seed": {"k": 24}}  # the headline index (bench.py --index seed)
     t, source = bench.committed_traffic(args, 100_000_000, aux, "test")
     assert t is not None and "NOT measured in this run" in source
     assert 2.0e10 < t["bytes"] < 6.0e10 and 2.0 < t["read_requests"] / 1e8 < 4.0
