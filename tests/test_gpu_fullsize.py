@@ -269,3 +269,69 @@ def test_full_size_index_against_the_text(hg38_scale):
         assert border.get(int(end_h[c])) == int(st[t]), "the chain did not stop on this text's border row"
         texts_hit.add(t)
     assert texts_hit == set(range(N_TEXTS))
+
+
+def test_full_size_seed_table_and_inverse_suffix_array(hg38_scale):
+    """The same index with every structure at once (seed table k = 24, text units, inverse suffix array beside the default
+    tables; 214 GB): the seed kernel's count + locate -- through 16-byte records and through the compact results -- and
+    its exact intervals equal what the tables alone give for all 100 M reads of workload 3 and all 50 M of workload 5,
+    and a prefix equals the oracle's.  (Last test of the module: it rebuilds the shared index's structures.)"""
+    from genedex_amd.device import DeviceQueries
+
+    h = hg38_scale
+    torch, eng, dev, index = h["torch"], h["eng"], h["dev"], h["index"]
+    index.rebuild_aux(seed_symbols=True, inverse_suffix_array=True, aux_budget_bytes=250_000_000_000)
+    aux = eng.aux_info()
+    assert aux["seed"]["k"] == 24 and aux["inverse_suffix_array"] and aux["text_units"] and aux["jump_entry_bytes"] == 32
+    info = index.seed_info()
+    assert info["single_entries"] > 2_000_000_000 and info["max_displacement"] <= 30
+
+    def located(q, nq, compact, seed):
+        index.set_query_options(search_seed=seed)
+        rec = eng.alloc_records(nq)
+        cmp_ = eng.alloc_compact(nq) if compact else None
+        off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        eng.locate_search(q, rec, compact=cmp_)
+        eng.locate_offsets(rec, nq, off, compact=cmp_)
+        torch.cuda.synchronize()
+        total = int(off[nq].item())
+        hits = torch.empty((total, 2), dtype=torch.int32, device=dev)
+        ws = torch.empty(eng.locate_workspace_bytes(total), dtype=torch.uint8, device=dev)
+        eng.locate_hits(rec, nq, off, total, hits, ws, compact=cmp_)
+        torch.cuda.synchronize()
+        answered = int((cmp_[:nq] != -2).sum().item()) if compact else 0
+        return off, hits, answered
+
+    for nq, lmin, lmax, ppm, sd in ((100_000_000, 50, 50, 900_000, 43), (50_000_000, 20, 150, 700_000, 47)):
+        q = DeviceQueries.synth(h["io_text"], h["lengths"], nq, lmin, lmax, ppm, seed=sd)
+        off0, hits0, _ = located(q, nq, False, False)          # the tables alone
+        off1, hits1, _ = located(q, nq, False, True)           # seed kernel, 16-byte records
+        assert torch.equal(off0, off1) and torch.equal(hits0, hits1)
+        del off1, hits1
+        off2, hits2, answered = located(q, nq, True, True)      # seed kernel, compact results
+        assert torch.equal(off0, off2) and torch.equal(hits0, hits2)
+        assert answered > 0.99 * nq if lmin == 50 else answered > 0.9 * nq
+        del off2, hits2
+        # exact intervals: seed entry + one ISA fetch for the reads that occur once, the exact kernel for the rest
+        outs = []
+        for seed in (False, True):
+            index.set_query_options(search_seed=seed)
+            out = eng.alloc_outputs(nq)
+            eng.search(q, out)
+            torch.cuda.synchronize()
+            assert not bool(out["status"].any().item())
+            outs.append(out)
+        assert torch.equal(outs[0]["start"], outs[1]["start"]) and torch.equal(outs[0]["end"], outs[1]["end"])
+        # a prefix against the oracle on the same index
+        m = 1_000_000
+        qbuf, qoff = q.host_slice(0, m)
+        cs, ce = h["cpu"].cursors_for_many(qbuf, qoff, n_threads=h["threads"])
+        assert np.array_equal(outs[1]["start"][:m].cpu().numpy().astype(np.uint32), cs.astype(np.uint32))
+        assert np.array_equal(outs[1]["end"][:m].cpu().numpy().astype(np.uint32), ce.astype(np.uint32))
+        co, ct, cp = h["cpu"].locate_intervals(cs, ce, n_threads=h["threads"])
+        assert np.array_equal(off0[:m + 1].cpu().numpy().astype(np.uint64), co)
+        gh = hits0[: int(co[-1])].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(gh[:, 0], ct.astype(np.uint32)) and np.array_equal(gh[:, 1], cp.astype(np.uint32))
+        del outs, off0, hits0, q
+        torch.cuda.empty_cache()
+    index.set_query_options()
