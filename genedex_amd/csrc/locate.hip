@@ -691,6 +691,128 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
 }
 
+// Offsets scan in two passes over the counts: tile sums, a scan of the sums by one block, then every tile scans itself
+// from its base.  rocPRIM's single-pass scan reads the counts once but its look-back crosses the XCDs (as in
+// scan_locate_kernel, profiles/r03/experiments.md section 8): 0.63-0.66 ms for 100 M counts, 2.5 times what the bytes
+// take.  Here every wavefront owns 512 consecutive queries and reads / writes them as eight coalesced rows of 64.
+constexpr uint32_t kScan2Rows = 8;
+constexpr uint32_t kScan2Wave = 64 * kScan2Rows;              // queries per wavefront
+constexpr uint32_t kScan2Tile = (kBlock / 64) * kScan2Wave;   // queries per block and tile (2048)
+
+__global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, uint64_t m, unsigned long long *__restrict__ sums)
+{
+    __shared__ unsigned long long s_part[kBlock / 64];
+    const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) mine += f(q0 + j * 64u);
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) s_part[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < kBlock / 64; w++) t += s_part[w];
+            sums[tile] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// exclusive scan of the tile sums in place, by one block; sums[n_tiles] = the total
+__global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_tiles)
+{
+    __shared__ unsigned long long s_part[1024];
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    constexpr uint32_t kPer = 16;
+    for (uint64_t base = 0; base < n_tiles; base += 1024ull * kPer) {
+        unsigned long long v[kPer], run = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint64_t i = base + threadIdx.x * kPer + j;
+            v[j] = i < n_tiles ? sums[i] : 0ull;
+            run += v[j];
+        }
+        s_part[threadIdx.x] = run;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long o = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s_part[threadIdx.x] += o;
+            __syncthreads();
+        }
+        unsigned long long before = s_carry + (threadIdx.x > 0 ? s_part[threadIdx.x - 1] : 0ull);
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint64_t i = base + threadIdx.x * kPer + j;
+            if (i < n_tiles) sums[i] = before;
+            before += v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[n_tiles] = s_carry;
+}
+
+__global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, uint64_t m, const unsigned long long *__restrict__ sums,
+                                                                 uint64_t *__restrict__ offsets)
+{
+    __shared__ unsigned long long s_part[kBlock / 64];
+    const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
+        unsigned long long c[kScan2Rows], incl[kScan2Rows], carry = 0;
+        bool big = false;
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            c[j] = f(q0 + j * 64u);
+            big = big || c[j] >= (1ull << 25);
+        }
+        // row j = queries q0 - lane + 64 j ..: an inclusive scan across the lanes, rows chained by their totals -- in 32
+        // bits when no count of the wavefront could make a row's sum overflow (64 x 2^25), which is practically always
+        if (__ballot(big) == 0ull) {
+#pragma unroll
+            for (uint32_t j = 0; j < kScan2Rows; j++) {
+                uint32_t x = static_cast<uint32_t>(c[j]);
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(x, off);
+                    if (static_cast<int>(lane) >= off) x += o;
+                }
+                incl[j] = x + carry;
+                carry += __shfl(x, 63);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kScan2Rows; j++) {
+                unsigned long long x = c[j];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned long long o = __shfl_up(x, off);
+                    if (static_cast<int>(lane) >= off) x += o;
+                }
+                incl[j] = x + carry;
+                carry += __shfl(x, 63);
+            }
+        }
+        if (lane == 0) s_part[wave] = carry;  // the wavefront's total
+        __syncthreads();
+        unsigned long long before = sums[tile];
+        for (uint32_t w = 0; w < wave; w++) before += s_part[w];
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            const uint64_t q = q0 + j * 64u;
+            if (q < m) offsets[q] = before + incl[j] - c[j];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[m] = sums[n_tiles];
+}
+
 size_t hit_offsets_rec_temp_bytes(uint64_t m)
 {
     size_t bytes = 0;
@@ -698,12 +820,24 @@ size_t hit_offsets_rec_temp_bytes(uint64_t m)
     uint64_t *out = nullptr;
     (void)rocprim::exclusive_scan(nullptr, bytes, in, out, uint64_t(0), static_cast<size_t>(m + 1),
                                   rocprim::plus<uint64_t>());
-    return bytes;
+    const size_t two_pass = ((m + kScan2Tile - 1) / kScan2Tile + 2) * sizeof(unsigned long long);
+    return bytes > two_pass ? bytes : two_pass;
 }
 
 void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offsets, void *d_temp, size_t temp_bytes,
                             hipStream_t stream, uint32_t max_hits, bool take, const uint32_t *d_compact)
 {
+    static const int env_scan = [] { const char *e = getenv("GDX_SCAN_TWO_PASS"); return e ? atoi(e) : 1; }();  // 0: rocPRIM
+    if (env_scan != 0 && m >= 1) {
+        const RecordSize f{d_rec, d_compact, m, max_hits, take};
+        const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+        unsigned long long *sums = static_cast<unsigned long long *>(d_temp);
+        const unsigned grid = static_cast<unsigned>(n_tiles < 65536 ? n_tiles : 65536);
+        hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums);
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
+        hipLaunchKernelGGL(scan2_tile_scan_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets);
+        return;
+    }
     RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
     GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
