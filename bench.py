@@ -415,6 +415,31 @@ class StepRunner:
                 d.record()
                 if record:
                     self.ev_locate.append((c, d))
+            elif self.do_locate and self.use_compact:
+                # totals -> the one host round trip (sizes the hit buffer) -> offsets and the hits of the compactly answered
+                # reads in ONE pass, the rest from the records (gdx_locate_many_totals_compact_dev / _offsets_hits_compact_dev)
+                if slot >= len(self.scan_ws):
+                    dev = h.device
+                    self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev)
+                                    for _ in range(self.n_slots)]
+                    self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
+                self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], compact=o["compact"])
+                tot, rest = (int(x) for x in self.totals[slot].tolist())
+                self.total_hits = tot
+                if tot > self.hits[slot].shape[0]:
+                    self.hits[slot] = torch.empty((tot, 2), dtype=torch.int32, device=h.device)
+                    h = self.hits[slot]
+                need = self.eng.locate_workspace_bytes(tot) if rest else 0
+                if need > self.ws[slot].numel():
+                    self.ws[slot] = torch.empty(need, dtype=torch.uint8, device=h.device)
+                    ws = self.ws[slot]
+                c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c.record()
+                self.eng.locate_offsets_hits(o["rec"], self.nq, self.scan_ws[slot], o["hit_offsets"], tot, rest, h, ws,
+                                             compact=o["compact"])
+                d.record()
+                if record:
+                    self.ev_locate.append((c, d))
             elif self.do_locate:
                 self.offsets(o)
                 if self.sized_in_step:

@@ -170,6 +170,9 @@ SIGNATURES = {
     "gdx_locate_many_offsets_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_locate_many_hits_compact_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_unpack_compact_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_totals_workspace_bytes": [C.c_uint64],
+    "gdx_locate_many_totals_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
+    "gdx_locate_many_offsets_hits_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp],
     "gdx_packed_bytes": [C.c_uint64],
     "gdx_pack_queries": [vp, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
     "gdx_pack_queries_dev": [vp, vp, C.c_uint64, vp, vp, vp, vp],
@@ -200,7 +203,7 @@ SIGNATURES = {
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
-_RESTYPES = {"gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
+_RESTYPES = {"gdx_locate_many_totals_workspace_bytes": C.c_uint64, "gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
              "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
              "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64,
              "gdx_locate_many_scan_workspace_bytes": C.c_uint64}

@@ -1020,6 +1020,53 @@ int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_record
     });
 }
 
+uint64_t gdx_locate_many_totals_workspace_bytes(uint64_t nq) { return gdx::scan_totals_workspace_bytes(nq); }
+
+int gdx_locate_many_totals_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                       uint32_t max_hits, void *d_scan_workspace, void *d_totals, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_scan_workspace || !d_totals) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_totals_compact_dev: null argument");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_scan_totals(static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
+                                false, d_scan_workspace, static_cast<unsigned long long *>(d_totals), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                             uint32_t max_hits, const void *d_scan_workspace, void *d_hit_offsets,
+                                             uint64_t total_hits, uint64_t rest_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_scan_workspace || !d_hit_offsets || (total_hits != 0 && !d_hits))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_offsets_hits_compact_dev: null argument");
+        DeviceGuard guard(f.config().device_id);
+        // few open slots: the scan pass stores the compactly answered hits and flags the locate chunks with open slots, locate
+        // visits only those; many (reads from repeats, short reads): the scan writes offsets only and locate streams over all slots
+        const bool sparse = d_compact != nullptr && rest_hits * 16 <= total_hits;
+        if ((rest_hits != 0 || d_compact == nullptr) && total_hits != 0 && !d_workspace)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_offsets_hits_compact_dev: d_workspace is null");
+        uint8_t *flags = (sparse && rest_hits != 0)
+                             ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(total_hits) : nullptr;
+        gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
+                                       max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits, total_hits,
+                                       false, as_stream(stream), sparse, flags);
+        if (rest_hits != 0 || !sparse)
+            gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits,
+                               false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
+                               static_cast<const uint4 *>(d_records), false, false, static_cast<const uint32_t *>(d_compact),
+                               sparse, flags);
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
                                        void *d_out_counts, void *d_out_status, void *stream)
 {

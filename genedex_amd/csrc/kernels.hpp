@@ -137,7 +137,21 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
                    const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false,
-                   const uint32_t *d_compact = nullptr);
+                   const uint32_t *d_compact = nullptr, bool compact_stored = false, const uint8_t *d_chunk_flags = nullptr);
+// Offsets scan in two steps with the one host round trip between them: launch_scan_totals leaves d_totals (u64[2]) = {all
+// hit slots, the slots of queries whose compact result says "see the record"} and the tile bases in d_scan_workspace
+// (scan_totals_workspace_bytes); launch_scan_offsets_store then writes the offsets and, in the same pass, the hit of every
+// query whose compact result is its position.  launch_locate(..., compact_stored = true) fills what is left (totals[1]).
+size_t scan_totals_workspace_bytes(uint64_t m);
+void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits, bool take,
+                        void *d_scan_workspace, unsigned long long *d_totals, hipStream_t stream);
+void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
+                               bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
+                               uint64_t hits_capacity, bool wide, hipStream_t stream, bool store = true,
+                               uint8_t *d_chunk_flags = nullptr);
+// store == false: offsets only.  d_chunk_flags (inside the locate workspace at locate_chunk_flags_offset(total_hits), filled by
+// the store pass): launch_locate then only visits the chunks of hit slots in which that pass left something open
+size_t locate_chunk_flags_offset(uint64_t total_hits);
 // One pass over the search records (locate.hip scan_locate_kernel): the hit offsets (what launch_hit_offsets_rec
 // computes) and, in the same pass, the hit of every query with exactly one hit slot -- resolved records need nothing,
 // others one fetch of SA[row] when the index has it.  d_totals (u64[2]): [0] = all hit slots, [1] = the slots left to

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                               const uint4 *__restrict__ rec, uint64_t total,
                                                               void *__restrict__ hits_out,
                                                               unsigned long long *__restrict__ step_stats,
-                                                              const uint32_t *__restrict__ compact)
+                                                              const uint32_t *__restrict__ compact,
+                                                              const uint8_t *__restrict__ chunk_flags)  // != null: only the chunks flagged
 {
     IndexView ix{};
     ix.lines = lv.lines;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
     const uint64_t n_chunks = (total + kLocateChunk - 1) / kLocateChunk;
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (chunk_flags != nullptr && chunk_flags[chunk] == 0) continue;  // (block-uniform) nothing left to do in this chunk
         const uint64_t base = chunk * kLocateChunk;
         const uint32_t cnt = total - base < kLocateChunk ? static_cast<uint32_t>(total - base) : kLocateChunk;
         __syncthreads();  // the previous chunk's queue is drained, s_count is loaded
@@ -291,14 +293,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint64_t h = base + i;
             const uint32_t q = qa + qrel[j] - 1u;
             const uint64_t first = hit_offsets[q];
-            if (lv.skip_single != 0u && hit_offsets[q + 1] - first == 1u) continue;
+            if (lv.skip_single == 1u && hit_offsets[q + 1] - first == 1u) continue;
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
             if (rec != nullptr) {
                 if (compact != nullptr) {  // (kernels.hpp: the position itself, or "see the record")
                     const uint32_t c4 = compact[q];
                     if (c4 < kCompactSee) {
-                        store_hit<kWide>(ix, c4, hits_out, h, sentinels);
+                        // (skip_single 2: launch_scan_offsets_store has stored these hits already)
+                        if (lv.skip_single != 2u) store_hit<kWide>(ix, c4, hits_out, h, sentinels);
                         continue;
                     }
                 }
@@ -699,16 +702,57 @@ constexpr uint32_t kScan2Rows = 8;
 constexpr uint32_t kScan2Wave = 64 * kScan2Rows;              // queries per wavefront
 constexpr uint32_t kScan2Tile = (kBlock / 64) * kScan2Wave;   // queries per block and tile (2048)
 
-__global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, uint64_t m, unsigned long long *__restrict__ sums)
+// the counts of queries q0, q0 + 64, ..: all loads issued before any is looked at (RecordSize::operator() asks for the record
+// only after it has seen the compact result -- eight dependent round trips per thread when called in a loop)
+__device__ __forceinline__ void scan2_load_counts(const RecordSize &f, uint64_t q0, uint64_t m, unsigned long long (&c)[kScan2Rows],
+                                                  uint32_t (&c4)[kScan2Rows])
+{
+    if (f.compact != nullptr) {
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            const uint64_t q = q0 + j * 64u;
+            c4[j] = q < m ? f.compact[q] : kCompactNone;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++)
+            c[j] = c4[j] == kCompactSee ? f(q0 + j * 64u) : (c4[j] == kCompactNone ? 0ull : 1ull);
+    } else {
+        uint2 v[kScan2Rows];
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            const uint64_t q = q0 + j * 64u;
+            v[j] = q < m ? *reinterpret_cast<const uint2 *>(f.rec + q) : make_uint2(0u, 0u);
+            c4[j] = kCompactSee;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            const uint32_t n = v[j].y - v[j].x;
+            c[j] = (f.max_hits != 0u && n > f.max_hits) ? (f.take ? static_cast<unsigned long long>(f.max_hits) : 0ull)
+                                                        : static_cast<unsigned long long>(n);
+        }
+    }
+}
+
+// rest (optional, pre-zeroed): += the hit slots of the queries whose compact result says "see the record" (all of them
+// when there are no compact results) -- what a locate pass still has to fill after scan2_tile_scan_kernel stored the hits
+// of the others
+__global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, uint64_t m, unsigned long long *__restrict__ sums,
+                                                                 unsigned long long *__restrict__ rest)
 {
     __shared__ unsigned long long s_part[kBlock / 64];
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    unsigned long long open_slots = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
-        unsigned long long mine = 0;
+        unsigned long long mine = 0, c[kScan2Rows];
+        uint32_t c4[kScan2Rows];
+        scan2_load_counts(f, q0, m, c, c4);
 #pragma unroll
-        for (uint32_t j = 0; j < kScan2Rows; j++) mine += f(q0 + j * 64u);
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            mine += c[j];
+            if (rest != nullptr && c4[j] == kCompactSee) open_slots += c[j];
+        }
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if (lane == 0) s_part[wave] = mine;
         __syncthreads();
@@ -718,6 +762,17 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, u
             sums[tile] = t;
         }
         __syncthreads();
+    }
+    if (rest != nullptr) {  // one atomic per block (a resident grid: launch_scan_totals)
+        for (int off = 32; off > 0; off >>= 1) open_slots += __shfl_xor(open_slots, off);
+        __syncthreads();
+        if (lane == 0) s_part[wave] = open_slots;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < kBlock / 64; w++) t += s_part[w];
+            if (t != 0) atomicAdd(rest, t);
+        }
     }
 }
 
@@ -759,33 +814,56 @@ __global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__
     if (threadIdx.x == 0) sums[n_tiles] = s_carry;
 }
 
+// kStore: the pass also stores the hit of every query whose compact result IS its position (text id by the search tree of
+// text_id_search_tree.rs:35-64 over the sentinel positions, from LDS when they are few) -- offsets and most hits in one
+// pass over 4 bytes per query; hits at or beyond hits_capacity are not stored
+template <bool kStore, bool kWide>
 __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, uint64_t m, const unsigned long long *__restrict__ sums,
-                                                                 uint64_t *__restrict__ offsets)
+                                                                 uint64_t *__restrict__ offsets, const uint32_t *__restrict__ sentinels_g,
+                                                                 uint32_t n_texts, void *__restrict__ hits_out, uint64_t hits_capacity,
+                                                                 uint8_t *__restrict__ chunk_flags)  // kStore, != null (pre-zeroed): marks the
+                                                                 // locate chunks that hold slots this pass leaves open
 {
     __shared__ unsigned long long s_part[kBlock / 64];
+    constexpr uint32_t kLdsTexts = 256;
+    __shared__ uint32_t s_sentinels[kStore ? kLdsTexts : 1];
+    const uint32_t *sentinels = sentinels_g;
+    IndexView ix{};
+    if (kStore) {
+        ix.sentinels = sentinels_g;
+        ix.n_texts = n_texts;
+        if (n_texts <= kLdsTexts) {
+            for (uint32_t i = threadIdx.x; i < n_texts; i += kBlock) s_sentinels[i] = sentinels_g[i];
+            sentinels = s_sentinels;
+            __syncthreads();
+        }
+    }
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
         unsigned long long c[kScan2Rows], incl[kScan2Rows], carry = 0;
+        uint32_t c4[kScan2Rows];
+        scan2_load_counts(f, q0, m, c, c4);
         bool big = false;
 #pragma unroll
-        for (uint32_t j = 0; j < kScan2Rows; j++) {
-            c[j] = f(q0 + j * 64u);
-            big = big || c[j] >= (1ull << 25);
-        }
+        for (uint32_t j = 0; j < kScan2Rows; j++) big = big || c[j] >= (1ull << 25);
         // row j = queries q0 - lane + 64 j ..: an inclusive scan across the lanes, rows chained by their totals -- in 32
         // bits when no count of the wavefront could make a row's sum overflow (64 x 2^25), which is practically always
         if (__ballot(big) == 0ull) {
 #pragma unroll
             for (uint32_t j = 0; j < kScan2Rows; j++) {
-                uint32_t x = static_cast<uint32_t>(c[j]);
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t o = __shfl_up(x, off);
-                    if (static_cast<int>(lane) >= off) x += o;
-                }
-                incl[j] = x + carry;
-                carry += __shfl(x, 63);
+                // inclusive scan over the 64 lanes by DPP: inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of row 0 / 2
+                // onto row 1 / 3 (row_bcast15) and lane 31 onto rows 2 and 3 (row_bcast31)
+                int x = static_cast<int>(static_cast<uint32_t>(c[j]));
+                x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+                incl[j] = static_cast<uint32_t>(x) + carry;
+                carry += static_cast<uint32_t>(__builtin_amdgcn_readlane(x, 63));
             }
         } else {
 #pragma unroll
@@ -806,7 +884,17 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
 #pragma unroll
         for (uint32_t j = 0; j < kScan2Rows; j++) {
             const uint64_t q = q0 + j * 64u;
-            if (q < m) offsets[q] = before + incl[j] - c[j];
+            if (q < m) {
+                const uint64_t at = before + incl[j] - c[j];
+                offsets[q] = at;
+                if (kStore && c[j] != 0ull) {
+                    if (c4[j] < kCompactSee) {
+                        if (at < hits_capacity) store_hit<kWide>(ix, c4[j], hits_out, at, sentinels);
+                    } else if (chunk_flags != nullptr) {
+                        for (uint64_t ch = at / kLocateChunk; ch <= (at + c[j] - 1u) / kLocateChunk; ch++) chunk_flags[ch] = 1;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -833,14 +921,66 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
         const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
         unsigned long long *sums = static_cast<unsigned long long *>(d_temp);
         const unsigned grid = static_cast<unsigned>(n_tiles < 65536 ? n_tiles : 65536);
-        hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums);
+        unsigned long long *const no_rest = nullptr;
+        const uint32_t *const no_sent = nullptr;
+        void *const no_hits = nullptr;
+        hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, no_rest);
         hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
-        hipLaunchKernelGGL(scan2_tile_scan_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets);
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
+                           no_sent, 0u, no_hits, uint64_t(0), static_cast<uint8_t *>(nullptr));
         return;
     }
     RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
     GDX_HIP(rocprim::exclusive_scan(d_temp, temp_bytes, in, d_hit_offsets, uint64_t(0),
                                     static_cast<size_t>(m + 1), rocprim::plus<uint64_t>(), stream));
+}
+
+// where launch_scan_offsets_store / launch_locate keep the chunk flags inside a locate workspace of locate_workspace_bytes(total)
+// (behind the first-query table of the chunks, which takes n_chunks + 1 of the workspace's total x 4 bytes)
+size_t locate_chunk_flags_offset(uint64_t total_hits)
+{
+    const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
+    return align_up((n_chunks + 2) * sizeof(uint32_t), 256);
+}
+
+size_t scan_totals_workspace_bytes(uint64_t m) { return ((m + kScan2Tile - 1) / kScan2Tile + 2) * sizeof(unsigned long long); }
+
+void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits, bool take,
+                        void *d_scan_workspace, unsigned long long *d_totals, hipStream_t stream)
+{
+    GDX_HIP(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), stream));
+    if (m == 0) return;
+    const RecordSize f{d_rec, d_compact, m, max_hits, take};
+    const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+    unsigned long long *sums = static_cast<unsigned long long *>(d_scan_workspace);
+    const unsigned grid = static_cast<unsigned>(n_tiles < 4096 ? n_tiles : 4096);
+    hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_totals + 1);
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
+    GDX_HIP(hipMemcpyAsync(d_totals, sums + n_tiles, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+}
+
+void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
+                               bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
+                               uint64_t hits_capacity, bool wide, hipStream_t stream, bool store, uint8_t *d_chunk_flags)
+{
+    if (m == 0) {
+        GDX_HIP(hipMemsetAsync(d_hit_offsets, 0, sizeof(uint64_t), stream));
+        return;
+    }
+    const RecordSize f{d_rec, d_compact, m, max_hits, take};
+    const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+    const unsigned long long *sums = static_cast<const unsigned long long *>(d_scan_workspace);
+    const unsigned grid = static_cast<unsigned>(n_tiles < 65536 ? n_tiles : 65536);
+    if (d_chunk_flags != nullptr) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, (hits_capacity + kLocateChunk - 1) / kLocateChunk + 1, stream));
+    if (!store || d_compact == nullptr || d_hits == nullptr)
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, static_cast<uint8_t *>(nullptr));
+    else if (wide)
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags);
+    else
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags);
 }
 
 namespace {
@@ -939,7 +1079,8 @@ size_t locate_workspace_bytes(uint64_t total_hits)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact)
+                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact,
+                   bool compact_stored, const uint8_t *d_chunk_flags)
 {
     if (total_hits == 0 || m == 0) return;
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -981,17 +1122,17 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         if (entry_sa)                                                                                                     \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
                                d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
-                               d_compact);                                                                                \
+                               d_compact, d_chunk_flags);                                                                 \
         else                                                                                                              \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
                                d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
-                               d_compact);                                                                                \
+                               d_compact, d_chunk_flags);                                                                 \
     } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
                             ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
-                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, skip_single ? 1u : 0u};
+                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, compact_stored ? 2u : (skip_single ? 1u : 0u)};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
         // SA[row] inside the entries, or as an array of its own: no walk at all

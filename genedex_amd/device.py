@@ -191,6 +191,23 @@ class DeviceEngine:
         _lib.check(self.lib.gdx_locate_many_hits_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
                                                      _ptr(workspace), _stream()))
 
+    def totals_workspace_bytes(self, nq: int) -> int:
+        return int(self.lib.gdx_locate_many_totals_workspace_bytes(nq))
+
+    def locate_totals(self, rec: torch.Tensor, nq: int, scan_ws: torch.Tensor, totals: torch.Tensor, max_hits: int = 0,
+                      compact: torch.Tensor = None) -> None:
+        """gdx_locate_many_totals_compact_dev: totals = int64[2] (all hit slots, slots behind "see the record")"""
+        _lib.check(self.lib.gdx_locate_many_totals_compact_dev(self.h, _ptr(rec), _ptr(compact) if compact is not None else None,
+                                                               nq, max_hits, _ptr(scan_ws), _ptr(totals), _stream()))
+
+    def locate_offsets_hits(self, rec: torch.Tensor, nq: int, scan_ws: torch.Tensor, hit_offsets: torch.Tensor, total: int,
+                            rest: int, hits: torch.Tensor, workspace: torch.Tensor, max_hits: int = 0,
+                            compact: torch.Tensor = None) -> None:
+        """gdx_locate_many_offsets_hits_compact_dev: offsets + the hits the compact results answer in one pass, then the rest"""
+        _lib.check(self.lib.gdx_locate_many_offsets_hits_compact_dev(
+            self.h, _ptr(rec), _ptr(compact) if compact is not None else None, nq, max_hits, _ptr(scan_ws), _ptr(hit_offsets),
+            total, rest, _ptr(hits), _ptr(workspace) if workspace is not None else None, _stream()))
+
     def scan_workspace_bytes(self, nq: int) -> int:
         return int(self.lib.gdx_locate_many_scan_workspace_bytes(nq))
 

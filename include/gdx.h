@@ -406,6 +406,21 @@ int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_record
                                      const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
                                        void *d_out_counts, void *d_out_status, void *stream);
+/* Offsets and hits in two calls around the ONE host round trip of a count + locate step (instead of offsets, round trip,
+ * hits): gdx_locate_many_totals_compact_dev sums the counts -- d_totals (u64[2], device) = {all hit slots, the slots of the
+ * queries whose compact result says "see the record"} -- and leaves the bases of its tiles in d_scan_workspace
+ * (gdx_locate_many_totals_workspace_bytes(nq) bytes); the caller reads d_totals back, sizes d_hits (total_hits entries of
+ * gdx_hit32_t) and d_workspace (gdx_locate_workspace_bytes(total_hits), only needed when rest_hits != 0) and calls
+ * gdx_locate_many_offsets_hits_compact_dev, which writes d_hit_offsets (u64[nq + 1]) and in the SAME pass over the compact
+ * results stores the hit of every query they answer, then locates the remaining rest_hits slots from the records.
+ * d_compact may be NULL (records only: the second call is then the plain offsets + hits).  Same results as the other
+ * record calls. */
+uint64_t gdx_locate_many_totals_workspace_bytes(uint64_t nq);
+int gdx_locate_many_totals_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                       uint32_t max_hits, void *d_scan_workspace, void *d_totals, void *stream);
+int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                             uint32_t max_hits, const void *d_scan_workspace, void *d_hit_offsets,
+                                             uint64_t total_hits, uint64_t rest_hits, void *d_hits, void *d_workspace, void *stream);
 
 /* ---- packed queries ("allow 2-bit host packing as an optional input format") ------------------------
  * Four symbols per byte instead of one: symbol j of the buffer sits in bits 2 (j & 3) .. 2 (j & 3) + 1 of byte j >> 2

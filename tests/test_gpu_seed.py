@@ -106,7 +106,7 @@ def test_exact_intervals_through_seed_table_and_inverse_suffix_array(seed):
         assert cur.count() == len(naive_search(texts, q, fold=a.io_to_dense_table))
 
 
-def device_locate(g, qs, compact, max_hits=0):
+def device_locate(g, qs, compact, max_hits=0, fused=False):
     """search -> offsets -> hits on the device through the records calls, with or without the compact results"""
     import torch
 
@@ -119,13 +119,24 @@ def device_locate(g, qs, compact, max_hits=0):
     cmp_ = eng.alloc_compact(dq.nq) if compact else None
     off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
     eng.locate_search(dq, rec, compact=cmp_)
-    eng.locate_offsets(rec, dq.nq, off, max_hits, compact=cmp_)
-    torch.cuda.synchronize()
-    tot = int(off[dq.nq].item())
-    hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
-    ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
-    if tot:
-        eng.locate_hits(rec, dq.nq, off, tot, hits, ws, compact=cmp_)
+    if fused:  # totals -> (host) -> offsets + the compactly answered hits in one pass, then the rest
+        sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        eng.locate_totals(rec, dq.nq, sws, totals, max_hits, compact=cmp_)
+        tot, rest = (int(x) for x in totals.tolist())
+        hits = torch.full((max(tot, 1), 2), -7, dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_offsets_hits(rec, dq.nq, sws, off, tot, rest, hits, ws, max_hits, compact=cmp_)
+        torch.cuda.synchronize()
+        assert int(off[dq.nq].item()) == tot and rest <= tot
+    else:
+        eng.locate_offsets(rec, dq.nq, off, max_hits, compact=cmp_)
+        torch.cuda.synchronize()
+        tot = int(off[dq.nq].item())
+        hits = torch.empty((max(tot, 1), 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+        if tot:
+            eng.locate_hits(rec, dq.nq, off, tot, hits, ws, compact=cmp_)
     counts = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
     stat = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
     eng.unpack_records(rec, dq.nq, counts, stat, compact=cmp_)
@@ -151,8 +162,8 @@ def test_compact_results_equal_records_and_oracle(seed):
     qs = [q for q in mixed_queries(rng, texts, 600, 200, 120) + [b"", b"ACGTACGTACGT"] if b"N" not in q]
     co, ct, cp = c.locate_many(qs)
     got = {}
-    for compact in (False, True):
-        off, hits, counts, stat, answered = device_locate(g, qs, compact)
+    for compact, fused in ((False, False), (True, False), (True, True), (False, True)):
+        off, hits, counts, stat, answered = device_locate(g, qs, compact, fused=fused)
         assert off.tolist() == co.tolist()
         assert hits[:, 0].tolist() == ct.astype(np.uint32).tolist() and hits[:, 1].tolist() == cp.astype(np.uint32).tolist()
         assert counts.tolist() == np.diff(co).astype(np.uint32).tolist() and not stat.any()
@@ -165,6 +176,8 @@ def test_compact_results_equal_records_and_oracle(seed):
     off_a, hits_a, _, _, _ = device_locate(g, qs, False, max_hits=2)
     off_b, hits_b, _, _, _ = device_locate(g, qs, True, max_hits=2)
     assert off_a.tolist() == off_b.tolist() and hits_a.tolist() == hits_b.tolist()
+    off_c, hits_c, _, _, _ = device_locate(g, qs, True, max_hits=2, fused=True)
+    assert off_a.tolist() == off_c.tolist() and hits_a.tolist() == hits_c.tolist()
 
 
 def test_seed_entries_are_the_distinct_kmers():
