@@ -302,7 +302,9 @@ class StepRunner:
         self.torch, self.eng, self.q, self.nq = torch, eng, queries, nq
         self.do_locate = do_locate
         self.use_rec = path in ("records", "records16") and do_locate
-        self.use_compact = path == "records" and do_locate
+        # (compact results only where something fills them: on an index without seed table every entry would say "see the
+        # record" and the extra array would only cost its fill and its reads)
+        self.use_compact = path == "records" and do_locate and eng.index.seed_info()["k"] != 0
         self.hint = hint and do_locate
         self.n_slots = n_slots
         self.outs = [self._alloc() for _ in range(n_slots)]

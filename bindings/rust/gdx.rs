@@ -191,6 +191,19 @@ extern "C" {
         ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, d_hit_offsets: *const c_void,
         total_hits: u64, d_hits: *mut c_void, d_workspace: *mut c_void, stream: *mut c_void,
     ) -> c_int;
+    // offsets and hits around the one host round trip: totals (u64[2] on the device: all hit slots, slots behind "see the
+    // record") -> read back, size d_hits -> offsets + the compactly answered hits in one pass, then the rest
+    pub fn gdx_locate_many_totals_workspace_bytes(nq: u64) -> u64;
+    pub fn gdx_locate_many_totals_compact_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, max_hits: u32,
+        d_scan_workspace: *mut c_void, d_totals: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_locate_many_offsets_hits_compact_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, max_hits: u32,
+        d_scan_workspace: *const c_void, d_hit_offsets: *mut c_void, total_hits: u64, rest_hits: u64, d_hits: *mut c_void,
+        d_workspace: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_index_seed_info(ix: *const gdx_index_t, out: *mut u64) -> c_int;
     // several GPUs of one node behind one handle
     pub fn gdx_multi_build(
         texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int,
