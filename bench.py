@@ -184,7 +184,7 @@ def run_live_pmc(args, reference_layout=False, rung=None):
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|search_kernel|search_verify_kernel|search_exact_kernel",
+               "search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|search_kernel|search_verify_kernel|search_exact_kernel",
                "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
@@ -425,7 +425,12 @@ class StepRunner:
                     self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev)
                                     for _ in range(self.n_slots)]
                     self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
+                ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ta.record()
                 self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], compact=o["compact"])
+                tb.record()
+                if record:
+                    self.ev_scan.append((ta, tb))
                 tot, rest = (int(x) for x in self.totals[slot].tolist())
                 self.total_hits = tot
                 if tot > self.hits[slot].shape[0]:
@@ -701,9 +706,16 @@ def main():
         if runner.use_rec:
             del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
-        lt = traffic_of(pmc, "scan_locate_kernel|locate_queue_kernel")
+        if runner.use_compact:  # offsets and the compactly answered hits in one pass, the queue kernel on flagged chunks only
+            lt = traffic_of(pmc, "scan2_tile_scan_kernel|locate_queue_kernel")
+        else:
+            lt = traffic_of(pmc, "scan_locate_kernel|locate_queue_kernel")
         locate_roofline = {"bound": "hbm", "kernel": (lt or {}).get("kernel", "scan_locate_kernel"), "peak": HBM_PEAK_GBPS,
-                           "what": "hit offsets + hits in one pass over the records (scan_locate_kernel) + the host read-back of "
+                           "what": "gdx_locate_many_offsets_hits_compact_dev: hit offsets + the hits of the compactly answered reads "
+                                   "in one pass over 4 bytes per query (scan2_tile_scan_kernel<true, false>), then the queue kernel "
+                                   "on the chunks with slots left open; the totals pass before the host round trip "
+                                   "(scan2_tile_sums_kernel) is kernel_ms.totals" if runner.use_compact else
+                                   "hit offsets + hits in one pass over the records (scan_locate_kernel) + the host read-back of "
                                    "the totals + the queue kernel on what that pass left open" if runner.fused_scan else
                                    "locate_queue_kernel after the separate scan",
                            "unit": "GB/s", "avg_launch_ms": locate_ms,
@@ -749,7 +761,7 @@ def main():
                    "gathered_bytes_per_rank_and_step": gathered_bytes},
         "roofline": roofline,
         "locate_roofline": locate_roofline,
-        "kernel_ms": {"search": search_ms, "locate": locate_ms},
+        "kernel_ms": {"search": search_ms, "locate": locate_ms, "totals": runner.mean_ms(runner.ev_scan)},
         "parity": parity,
         "index_build_seconds": t_build,
         "index_bytes": int(index.info.device_bytes),
