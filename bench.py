@@ -707,7 +707,7 @@ def main():
             del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
         if runner.use_compact:  # offsets and the compactly answered hits in one pass, the queue kernel on flagged chunks only
-            lt = traffic_of(pmc, "scan2_tile_scan_kernel|locate_queue_kernel")
+            lt = traffic_of(pmc, "scan2_tile_scan_kernel<true, false>|locate_queue_kernel")
         else:
             lt = traffic_of(pmc, "scan_locate_kernel|locate_queue_kernel")
         locate_roofline = {"bound": "hbm", "kernel": (lt or {}).get("kernel", "scan_locate_kernel"), "peak": HBM_PEAK_GBPS,
