@@ -1384,7 +1384,11 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t str
     if (buckets < 1) buckets = 1;
     if (2u * k > kSeedTagBitsMax && buckets < (1ull << (2u * k - kSeedTagBitsMax))) buckets = 1ull << (2u * k - kSeedTagBitsMax);
     for (int attempt = 0;; attempt++) {
-        if (buckets > (1ull << 31)) fail(GDX_ERR_UNSUPPORTED, "seed table: too many buckets");
+        // (bucket numbers and their sums are 32-bit: a fuller table instead of a failure when a low load factor asks for more)
+        if (buckets > (1ull << 31)) {
+            if (heads > 8ull * (1ull << 31) || attempt > 0) fail(GDX_ERR_UNSUPPORTED, "seed table: too many buckets");
+            buckets = 1ull << 31;
+        }
         uint32_t log2b = 0;
         while ((2ull << log2b) <= buckets) log2b++;
         const uint32_t tag_bits = 2u * k > log2b ? 2u * k - log2b : 0u;
