@@ -168,6 +168,28 @@ def one_round(rng, stats):
             ("rec hits", cfg)
         assert counts.cpu().numpy().astype(np.uint32).tolist() == (ce[keep] - cs[keep]).astype(np.uint32).tolist(), ("rec counts", cfg)
         assert not stat.any().item(), ("rec status", cfg)
+        # the same through the compact results and the fused totals -> offsets + hits calls (gdx_locate_many_*_compact_dev)
+        rec2 = eng.alloc_records(dq.nq)
+        rec2.fill_(0x5a5a5a5a)
+        cmp2 = eng.alloc_compact(dq.nq)
+        off2 = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+        eng.locate_search(dq, rec2, compact=cmp2)
+        sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        eng.locate_totals(rec2, dq.nq, sws, totals, compact=cmp2)
+        tot2, rest2 = (int(x) for x in totals.tolist())
+        assert tot2 == tot, ("compact total", cfg)
+        hits2 = torch.full((max(tot2, 1), 2), -7, dtype=torch.int32, device="cuda")
+        ws2 = torch.empty(max(eng.locate_workspace_bytes(tot2), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_offsets_hits(rec2, dq.nq, sws, off2, tot2, rest2, hits2, ws2, compact=cmp2)
+        counts2 = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+        stat2 = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+        eng.unpack_records(rec2, dq.nq, counts2, stat2, compact=cmp2)
+        torch.cuda.synchronize()
+        assert torch.equal(off2, off_t), ("compact offsets", cfg)
+        assert torch.equal(hits2[:tot2], hits[:tot]), ("compact hits", cfg)
+        assert torch.equal(counts2, counts) and not stat2.any().item(), ("compact counts", cfg)
+        stats["compact_answers"] = stats.get("compact_answers", 0) + int((cmp2[:dq.nq] != -2).sum().item())
         stats["lazy_or_hinted_records"] = stats.get("lazy_or_hinted_records", 0) + int((rec[:dq.nq, 2] != -1).sum().item())
         stats["masked_records"] = stats.get("masked_records", 0) + int((((rec[:dq.nq, 3] >> 23) & 1) == 1).sum().item())
         # the same queries through the batched cursor API, fed in chunks of `chunk` symbols from the right, with
