@@ -1056,7 +1056,10 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         torch.cuda.empty_cache()
         # (seed table AND the library's default structures: a read from a repeat goes on from its seed entry's interval with
         # one jump round -- search_seed_kernel4 -> search_fast_kernel4 over its list -> the general kernel)
-        both = {"index": "tables", "seed_symbols": 1, "aux_budget_bytes": 240_000_000_000} if args.index == "seed" else {}
+        # + the full suffix array: the hits of a read from a repeat are consecutive rows -- 32 of their SA values per 128-byte
+        # line there, 4 per line inside the 32-byte jump entries (scan + locate of 573 M hits 5.35 -> 4.0 ms)
+        both = ({"index": "tables", "seed_symbols": 1, "full_sa": True, "aux_budget_bytes": 250_000_000_000}
+                if args.index == "seed" else {})
         res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), **both})))
     return res
 
