@@ -276,3 +276,27 @@ def test_bad_seed_options_are_rejected():
     for kw in (dict(seed_symbols=5), dict(seed_symbols=25), dict(seed_symbols=12, seed_load_percent=10)):
         with pytest.raises(GdxError):
             gpu_index([b"ACGTACGTACGTAAAC"], a, **kw)
+
+
+def test_seed_table_on_a_loaded_index(tmp_path):
+    """The seed table is derived from the index's own BWT and suffix array, so an index loaded from a file gets it like a
+    built one (gdx_index_load_ex with build options)."""
+    from genedex_amd import FmIndex
+    from genedex_amd.index import build_options
+
+    rng = np.random.default_rng(77)
+    a = alph.ascii_dna_with_n()
+    texts = repetitive_texts(rng, symbols=b"ACGTN")
+    plain = gpu_index(texts, a, sa_rate=3)
+    c = cpu_index(texts, a, sa_rate=3)
+    path = tmp_path / "index.gdx"
+    plain.save_to_file(path)
+    opts = build_options(seed_symbols=11, inverse_suffix_array=True, full_suffix_array=True)
+    loaded = FmIndex.load_from_file(path, a, options=opts)
+    assert loaded.seed_info()["k"] == 11 and plain.seed_info()["k"] == 0
+    qs = [q for q in mixed_queries(rng, texts, 500, 100, 90) if b"N" not in q]
+    check_against_oracle(loaded, c, qs, texts, fold=a.io_to_dense_table)
+    qbuf, qoff = pack_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    s, e, st = loaded.cursors_raw(qbuf, qoff)
+    assert not st.any() and s.tolist() == cs.tolist() and e.tolist() == ce.tolist()
