@@ -53,6 +53,7 @@ pub struct BuildOptions {
     pub seed_symbols: i32,      // -1 / 0 off, 1: seed table with k from the text length, 8..=24: that k
     pub seed_load_percent: i32, // 0 = default (70)
     pub inverse_suffix_array: i32, // -1 / 0 off, 1: ISA as its own array (exact intervals through the seed table)
+    pub reference_table_layout: i32, // -1 / 0 this library's table, 1..=4: Condensed64 / Condensed512 / Flat64 / Flat512 as genedex builds them
 }
 impl Default for BuildOptions {
     fn default() -> Self {

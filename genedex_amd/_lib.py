@@ -52,7 +52,7 @@ class BuildOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("pair_lines", C.c_int32), ("jump_entry_bytes", C.c_int32),
                 ("top_table_depth", C.c_int32), ("aux_budget_bytes", C.c_uint64), ("full_suffix_array", C.c_int32),
                 ("text_units", C.c_int32), ("seed_symbols", C.c_int32), ("seed_load_percent", C.c_int32),
-                ("inverse_suffix_array", C.c_int32)]
+                ("inverse_suffix_array", C.c_int32), ("reference_table_layout", C.c_int32)]
 
 
 class QueryOptions(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "gdx_index_export_sentinel_indices": [vp, u64p],
     "gdx_index_export_lookup_table": [vp, C.c_int, u32p],
     "gdx_index_export_condensed_table": [vp, u64p, u16p, u32p],
+    "gdx_index_export_reference_table": [vp, u64p, C.c_uint64, u64p, u32p, C.c_uint64, u64p],
     "gdx_rank_many": [vp, u8p, u64p, C.c_uint64, u64p],
     "gdx_symbol_at_many": [vp, u64p, C.c_uint64, u8p],
     "gdx_count_many": [vp, u8p, u64p, C.c_uint64, u64p, u8p],

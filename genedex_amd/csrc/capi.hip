@@ -202,6 +202,9 @@ gdx::BuildOptions make_build_options(const gdx_build_options_t *o)
         gdx::fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
     b.seed_symbols = o->seed_symbols;
     b.seed_load_percent = o->seed_load_percent;
+    if (o->reference_table_layout < -1 || o->reference_table_layout > 4)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, "reference_table_layout must be -1, 0 or 1..4");
+    b.table_layout = o->reference_table_layout;
     if (o->inverse_suffix_array < -1 || o->inverse_suffix_array > 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "inverse_suffix_array must be -1, 0 or 1");
     b.inverse_sa = o->inverse_suffix_array;
     return b;
@@ -271,6 +274,7 @@ void gdx_build_options_init(gdx_build_options_t *opts)
     opts->seed_symbols = -1;
     opts->seed_load_percent = 0;
     opts->inverse_suffix_array = -1;
+    opts->reference_table_layout = -1;
 }
 
 void gdx_query_options_init(gdx_query_options_t *opts)
@@ -596,6 +600,19 @@ int gdx_index_export_condensed_table(const gdx_index_t *ix, uint64_t *blocks, ui
                                      uint32_t *superblock_offsets)
 {
     GDX_EXPORT(t, f.export_condensed_table(blocks, block_offsets, superblock_offsets));
+}
+
+int gdx_index_export_reference_table(const gdx_index_t *ix, uint64_t *interleaved_blocks, uint64_t capacity_words,
+                                     uint64_t *out_n_words, uint32_t *interleaved_superblock_offsets, uint64_t capacity_offsets,
+                                     uint64_t *out_n_offsets)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!out_n_words || !out_n_offsets) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_index_export_reference_table: null argument");
+        f.export_reference_table(interleaved_blocks, capacity_words, out_n_words, interleaved_superblock_offsets, capacity_offsets,
+                                 out_n_offsets);
+        return (int)GDX_OK;
+    });
 }
 
 int gdx_rank_many(const gdx_index_t *ix, const uint8_t *symbols, const uint64_t *idx, uint64_t m, uint64_t *out)

@@ -879,6 +879,58 @@ __global__ __launch_bounds__(kBlock) void build_generic_offsets_kernel(const uin
     }
 }
 
+// The reference's occurrence table in any of its four variants (IndexView::g_kind ...), from the BWT: one thread per block
+// and unit (condensed: bit plane, flat: symbol) packs the block's words ...
+__global__ __launch_bounds__(kBlock) void build_ref_blocks_kernel(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t n_blocks,
+                                                                  uint32_t kind, uint32_t wpb, uint32_t used, uint32_t units,
+                                                                  uint64_t *__restrict__ blocks)
+{
+    const uint64_t total = n_blocks * units;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; w < total; w += stride) {
+        const uint64_t k = w / units;
+        const uint32_t u = static_cast<uint32_t>(w % units);
+        uint64_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint64_t p0 = k * used;
+        for (uint32_t j = 0; j < used && p0 + j < n; j++) {
+            const uint32_t s = bwt[p0 + j];
+            const uint32_t bit = kind == 0u ? (s >> u) & 1u : (s == u ? 1u : 0u);
+            const uint32_t pos = kind == 0u ? j : j + 16u;  // (flat: the first 16 bits of a block are its offset)
+#pragma unroll
+            for (uint32_t t = 0; t < 8; t++)
+                if (t == (pos >> 6)) words[t] |= static_cast<uint64_t>(bit) << (pos & 63u);
+        }
+        for (uint32_t t = 0; t < wpb; t++) blocks[w * wpb + t] = words[t];
+    }
+}
+
+// ... and one thread per (superblock, symbol) walks the superblock once: the symbol's offset at every block start (u16, into
+// block_off or -- flat -- into the first 16 bits of the block itself; blocks behind the text's last position included:
+// idx == n must be addressable) and the superblock total.  O(n * sigma) work, as build_generic_offsets_kernel.
+__global__ __launch_bounds__(kBlock) void build_ref_offsets_kernel(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t n_blocks,
+                                                                   uint64_t n_sb, uint32_t kind, uint32_t wpb, uint32_t used,
+                                                                   uint32_t sb_size, int sigma, uint64_t *__restrict__ blocks,
+                                                                   uint16_t *__restrict__ block_off, uint32_t *__restrict__ sb_totals)
+{
+    const uint64_t total = n_sb * static_cast<uint64_t>(sigma);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint64_t per_sb = sb_size / used;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; w < total; w += stride) {
+        const uint64_t sb = w / sigma;
+        const uint32_t c = static_cast<uint32_t>(w % sigma);
+        uint32_t sum = 0;
+        const uint64_t b0 = sb * per_sb, b1 = b0 + per_sb < n_blocks ? b0 + per_sb : n_blocks;
+        const uint64_t sb_end = (sb + 1) * sb_size < n ? (sb + 1) * sb_size : n;
+        for (uint64_t b = b0; b < b1; b++) {
+            if (kind == 0u) block_off[b * sigma + c] = static_cast<uint16_t>(sum);
+            else blocks[(b * sigma + c) * wpb] |= static_cast<uint64_t>(sum & 0xffffu);
+            const uint64_t p0 = b * used, p1 = p0 + used < sb_end ? p0 + used : sb_end;
+            for (uint64_t p = p0; p < p1; p++) sum += (bwt[p] == c);
+        }
+        sb_totals[sb * sigma + c] = sum;
+    }
+}
+
 template <class Table>
 __global__ __launch_bounds__(kBlock) void decode_bwt_kernel(IndexView ix, uint8_t *__restrict__ bwt)
 {
@@ -1039,8 +1091,36 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     double t0 = now_seconds();
 
     view_ = IndexView{};
-    view_.layout = sigma <= 8 ? 0 : 1;
-    if (view_.layout == 0) {
+    const int ref_layout = cfg_.build.table_layout >= 1 ? cfg_.build.table_layout : 0;  // 1..4: Condensed64/512, Flat64/512
+    view_.layout = (sigma <= 8 && ref_layout == 0) ? 0 : 1;
+    view_.g_kind = 0;
+    view_.g_wpb = 1;
+    view_.g_used = 64;
+    view_.g_sb = 65536;
+    if (ref_layout != 0) {
+        // the reference's own table, whichever variant was asked for (block.rs, condensed.rs:59-124, flat.rs:59-126)
+        const uint32_t kind = ref_layout >= 3 ? 1u : 0u, wpb = (ref_layout == 2 || ref_layout == 4) ? 8u : 1u;
+        const uint32_t used = kind == 0u ? 64u * wpb : 64u * wpb - 16u;
+        const uint32_t sb_size = kind == 0u ? 65536u : (65536u / used) * used;
+        const uint32_t units = kind == 0u ? static_cast<uint32_t>(nbits) : static_cast<uint32_t>(sigma);
+        const uint64_t n_blocks = div_ceil(len, used);
+        const uint64_t n_sbr = div_ceil(len, sb_size);
+        g_planes_.alloc(n_blocks * units * wpb);
+        if (kind == 0u) g_block_off_.alloc(n_blocks * sigma);
+        sb_offsets_.alloc(n_sbr * sigma);
+        hipLaunchKernelGGL(build_ref_blocks_kernel, dim3(grid_for_items(n_blocks * units)), dim3(kBlock), 0, stream, d_bwt_padded,
+                           n_, n_blocks, kind, wpb, used, units, g_planes_.get());
+        hipLaunchKernelGGL(build_ref_offsets_kernel, dim3(grid_for_items(n_sbr * sigma)), dim3(kBlock), 0, stream, d_bwt_padded,
+                           n_, n_blocks, n_sbr, kind, wpb, used, sb_size, sigma, g_planes_.get(), g_block_off_.get(),
+                           sb_offsets_.get());
+        hipLaunchKernelGGL(superblock_prefix_kernel, dim3(1), dim3(256), 0, stream, sb_offsets_.get(), n_sbr,
+                           static_cast<uint32_t>(sigma));
+        view_.sb_stride = static_cast<uint32_t>(sigma);
+        view_.g_kind = kind;
+        view_.g_wpb = wpb;
+        view_.g_used = used;
+        view_.g_sb = sb_size;
+    } else if (view_.layout == 0) {
         const uint64_t n_lines = div_ceil(len, 128);
         lines_.alloc(n_lines * 4);
         sb_offsets_.alloc(n_sb * 8);
@@ -2043,14 +2123,17 @@ void FmIndex::export_condensed_table(uint64_t *blocks, uint16_t *block_offsets, 
     hipStream_t stream = hipStreamPerThread;
     const int sigma = cfg_.sigma, nbits = view_.nbits;
     const uint64_t len = n_ + 1, n_blocks = div_ceil(len, 64), n_sb = div_ceil(len, 65536);
-    if (view_.layout == 1) {
+    if (view_.layout == 1 && view_.g_kind == 0u && view_.g_wpb == 1u) {  // Condensed / Block64 as it is
         GDX_HIP(hipMemcpy(blocks, g_planes_.get(), g_planes_.bytes(), hipMemcpyDeviceToHost));
         GDX_HIP(hipMemcpy(block_offsets, g_block_off_.get(), g_block_off_.bytes(), hipMemcpyDeviceToHost));
         GDX_HIP(hipMemcpy(superblock_offsets, sb_offsets_.get(), sb_offsets_.bytes(), hipMemcpyDeviceToHost));
         return;
     }
     DeviceBuffer<uint8_t> d_bwt(n_ ? n_ : 1);
-    hipLaunchKernelGGL(decode_bwt_kernel<LineTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt.get());
+    if (view_.layout == 1)  // (another of the reference's variants: through the BWT)
+        hipLaunchKernelGGL(decode_bwt_kernel<GenericTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt.get());
+    else
+        hipLaunchKernelGGL(decode_bwt_kernel<LineTable>, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, view_, d_bwt.get());
     DeviceBuffer<uint64_t> d_planes(n_blocks * nbits);
     DeviceBuffer<uint16_t> d_bo(n_blocks * sigma);
     DeviceBuffer<uint32_t> d_sb(n_sb * sigma);
@@ -2065,6 +2148,25 @@ void FmIndex::export_condensed_table(uint64_t *blocks, uint16_t *block_offsets, 
     GDX_HIP(hipMemcpyAsync(superblock_offsets, d_sb.get(), d_sb.bytes(), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
     GDX_HIP(hipGetLastError());
+}
+
+// the occurrence table of a reference_table_layout index as it sits in HBM: interleaved blocks (the flat variants carry their
+// block offsets inside), u32 superblock offsets; returns the number of 64-bit words / offsets through n_words / n_sb
+void FmIndex::export_reference_table(uint64_t *blocks, uint64_t capacity_words, uint64_t *n_words, uint32_t *superblock_offsets,
+                                     uint64_t capacity_sb, uint64_t *n_sb) const
+{
+    make_current();
+    if (view_.layout != 1) fail(GDX_ERR_UNSUPPORTED, "the index was not built with reference_table_layout");
+    *n_words = g_planes_.bytes() / sizeof(uint64_t);
+    *n_sb = sb_offsets_.bytes() / sizeof(uint32_t);
+    if (blocks != nullptr) {
+        if (capacity_words < *n_words) fail(GDX_ERR_CAPACITY, "export_reference_table: block buffer too small");
+        GDX_HIP(hipMemcpy(blocks, g_planes_.get(), g_planes_.bytes(), hipMemcpyDeviceToHost));
+    }
+    if (superblock_offsets != nullptr) {
+        if (capacity_sb < *n_sb) fail(GDX_ERR_CAPACITY, "export_reference_table: superblock buffer too small");
+        GDX_HIP(hipMemcpy(superblock_offsets, sb_offsets_.get(), sb_offsets_.bytes(), hipMemcpyDeviceToHost));
+    }
 }
 
 }  // namespace gdx

@@ -33,6 +33,8 @@ struct BuildOptions {
     int seed_symbols = -1;          // -1 / 0 none, 1 = seed table with k chosen from the text length, 8..24 = that k
                                     // (implies text_units)
     int seed_load_percent = 0;      // slots filled on average, 0 = default (70), 20..100
+    int table_layout = -1;          // -1 / 0: this implementation's own occurrence table (rank lines for sigma <= 8); 1..4: the
+                                    // reference's Condensed64 / Condensed512 / Flat64 / Flat512 layout, queried as it is
     int inverse_sa = -1;            // 1: ISA[position] = row as its own array (4 bytes per symbol): exact intervals through the
                                     // seed table
 };
@@ -123,6 +125,8 @@ public:
     void export_sentinel_indices(uint64_t *out) const;
     void export_lookup_table(int depth, uint32_t *pairs) const;
     void export_condensed_table(uint64_t *blocks, uint16_t *block_offsets, uint32_t *superblock_offsets) const;
+    void export_reference_table(uint64_t *blocks, uint64_t capacity_words, uint64_t *n_words, uint32_t *superblock_offsets,
+                                uint64_t capacity_sb, uint64_t *n_sb) const;
 
 private:
     FmIndex() = default;

@@ -41,6 +41,14 @@ struct IndexView {
     const uint64_t *g_planes;     // generic: [n_blocks64][nbits]       (layout 1)
     const uint16_t *g_block_off;  // generic: [n_blocks64][sigma]
     uint32_t sb_stride;           // 8 for layout 0, sigma for layout 1
+    // layout 1 is the reference's own occurrence table, any of its four variants (gdx_build_options_t.reference_table_layout;
+    // the default for sigma > 8 is Condensed / Block64):
+    //   g_kind 0 = condensed (condensed.rs:24-47): plane b of block k = words [(k * nbits + b) * g_wpb, + g_wpb) of g_planes,
+    //              u16 block offsets g_block_off[k * sigma + c], u32 superblock offsets every 65536 positions
+    //   g_kind 1 = flat (flat.rs:30-52): block of symbol c = words [(k * sigma + c) * g_wpb, + g_wpb): 16 bits of block offset,
+    //              then g_used = 64 g_wpb - 16 indicator bits; superblocks of g_sb = (65536 / g_used) * g_used positions
+    uint32_t g_kind, g_wpb;       // g_wpb: 64-bit words per block, 1 (Block64) or 8 (Block512)
+    uint32_t g_used, g_sb;        // positions per block / per superblock
     // --- pair lines: one or two LF steps per 128-byte fetch (rank-line layout only) -------------
     const u32x4 *pair_lines;      // [ceil((n+1)/64)][8], null when absent
     // --- jump table: 8 .. 32 LF steps of a narrow interval per fetch -----------------------------------
@@ -499,22 +507,54 @@ struct PairTable {
 // generic planes (layout 1): the reference's own three arrays
 
 struct GenericTable {
+    // rank(symbol, idx) over the reference's own arrays (condensed.rs:291-341, flat.rs:221-246); Condensed / Block64 -- what
+    // alphabets beyond eight symbols get by default -- keeps its own short path
     static __device__ __forceinline__ uint32_t rank(const IndexView &ix, uint32_t symbol, uint32_t idx)
     {
-        const uint32_t blk = idx >> 6;
-        const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * ix.sb_stride + symbol];
-        const uint32_t bo = ix.g_block_off[static_cast<uint64_t>(blk) * ix.sigma + symbol];
-        const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(blk) * ix.nbits;
-        uint64_t acc = ~0ull;
-        uint32_t s = symbol;
-        for (int b = 0; b < ix.nbits; b++) {
-            uint64_t p = planes[b];
-            acc &= (s & 1u) ? p : ~p;
-            s >>= 1;
+        if (ix.g_kind == 0u && ix.g_wpb == 1u) {
+            const uint32_t blk = idx >> 6;
+            const uint32_t sb = ix.sb_offsets[(idx >> kSuperblockShift) * ix.sb_stride + symbol];
+            const uint32_t bo = ix.g_block_off[static_cast<uint64_t>(blk) * ix.sigma + symbol];
+            const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(blk) * ix.nbits;
+            uint64_t acc = ~0ull;
+            uint32_t s = symbol;
+            for (int b = 0; b < ix.nbits; b++) {
+                uint64_t p = planes[b];
+                acc &= (s & 1u) ? p : ~p;
+                s >>= 1;
+            }
+            const uint32_t t = idx & 63u;
+            const uint64_t mask = t ? (~0ull >> (64u - t)) : 0ull;
+            return sb + bo + __popcll(acc & mask);
         }
-        const uint32_t t = idx & 63u;
-        const uint64_t mask = t ? (~0ull >> (64u - t)) : 0ull;
-        return sb + bo + __popcll(acc & mask);
+        const uint32_t blk = idx / ix.g_used, t = idx - blk * ix.g_used;  // t positions of the block count
+        uint32_t r = ix.sb_offsets[(idx / ix.g_sb) * ix.sb_stride + symbol];
+        if (ix.g_kind == 0u) {
+            r += ix.g_block_off[static_cast<uint64_t>(blk) * ix.sigma + symbol];
+            const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(blk) * ix.nbits * ix.g_wpb;
+            for (uint32_t w = 0; w * 64u < t; w++) {
+                uint64_t acc = ~0ull;
+                uint32_t s = symbol;
+                for (int b = 0; b < ix.nbits; b++) {
+                    const uint64_t p = planes[static_cast<uint32_t>(b) * ix.g_wpb + w];
+                    acc &= (s & 1u) ? p : ~p;
+                    s >>= 1;
+                }
+                const uint32_t left = t - w * 64u;
+                r += __popcll(left >= 64u ? acc : acc & (~0ull >> (64u - left)));
+            }
+        } else {
+            const uint64_t *blkw = ix.g_planes + (static_cast<uint64_t>(blk) * ix.sigma + symbol) * ix.g_wpb;
+            r += static_cast<uint32_t>(blkw[0] & 0xffffull);  // the block offset lives in the block's first 16 bits
+            const uint32_t end = t + 16u;                      // indicator bits 16 .. end - 1 count
+            for (uint32_t w = 0; w * 64u < end; w++) {
+                uint64_t v = blkw[w];
+                if (w == 0u) v &= ~0xffffull;
+                const uint32_t left = end - w * 64u;
+                r += __popcll(left >= 64u ? v : v & (~0ull >> (64u - left)));
+            }
+        }
+        return r;
     }
     static __device__ __forceinline__ void rank2(const IndexView &ix, uint32_t symbol, uint32_t lo, uint32_t hi,
                                                  uint32_t &rlo, uint32_t &rhi)
@@ -524,10 +564,19 @@ struct GenericTable {
     }
     static __device__ __forceinline__ uint32_t symbol_at(const IndexView &ix, uint32_t idx)
     {
-        const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(idx >> 6) * ix.nbits;
-        const uint32_t t = idx & 63u;
+        if (ix.g_kind == 0u) {
+            const uint32_t blk = idx / ix.g_used, t = idx - blk * ix.g_used;
+            const uint64_t *planes = ix.g_planes + static_cast<uint64_t>(blk) * ix.nbits * ix.g_wpb + (t >> 6);
+            uint32_t c = 0;
+            for (int b = 0; b < ix.nbits; b++)
+                c |= static_cast<uint32_t>((planes[static_cast<uint32_t>(b) * ix.g_wpb] >> (t & 63u)) & 1ull) << b;
+            return c;
+        }
+        const uint32_t blk = idx / ix.g_used, t = idx - blk * ix.g_used + 16u;
+        const uint64_t *blkw = ix.g_planes + static_cast<uint64_t>(blk) * ix.sigma * ix.g_wpb + (t >> 6);
         uint32_t c = 0;
-        for (int b = 0; b < ix.nbits; b++) c |= static_cast<uint32_t>((planes[b] >> t) & 1ull) << b;
+        for (int s = 0; s < ix.sigma; s++)  // flat.rs:248-266: exactly one indicator bit is set
+            c = ((blkw[static_cast<uint32_t>(s) * ix.g_wpb] >> (t & 63u)) & 1ull) ? static_cast<uint32_t>(s) : c;
         return c;
     }
     static __device__ __forceinline__ uint32_t symbol_and_rank(const IndexView &ix, uint32_t idx, uint32_t &rank_out)

@@ -181,6 +181,7 @@ struct LocateView {
     uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
     int32_t sigma, nbits;
     uint32_t skip_single;  // 1: the hits of queries with exactly one hit slot are in place already (scan_locate_kernel)
+    uint32_t g_kind, g_wpb, g_used, g_sb;  // IndexView: which of the reference's table variants layout 1 is
 };
 
 // kEntrySA: the index has 32-byte jump entries, which carry SA[row] (layout.hpp): every hit is finished in phase 0 with
@@ -208,6 +209,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     ix.border_vals = lv.border_vals;
     ix.sentinels = lv.sentinels;
     ix.sb_stride = lv.sb_stride;
+    ix.g_kind = lv.g_kind;
+    ix.g_wpb = lv.g_wpb;
+    ix.g_used = lv.g_used;
+    ix.g_sb = lv.g_sb;
     ix.jump_bytes = lv.jump_bytes;
     ix.n_texts = lv.n_texts;
     ix.sa_inv = lv.sa_inv;
@@ -1058,7 +1063,8 @@ void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uin
     GDX_HIP(hipMemsetAsync(d_workspace, 0, state_bytes + 256, stream));
     const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.layout == 0 ? ix.sa_full : nullptr,
                         ix.count, ix.sa_samples, ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride,
-                        ix.layout == 0 ? ix.jump_bytes : 0u, ix.n_texts, ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, 0u};
+                        ix.layout == 0 ? ix.jump_bytes : 0u, ix.n_texts, ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, 0u,
+                        ix.g_kind, ix.g_wpb, ix.g_used, ix.g_sb};
     // a resident grid: every block takes tiles by ticket until they run out
     static const long grid_env = [] { const char *e = getenv("GDX_SCAN_GRID"); return e ? atol(e) : 0L; }();  // experiments
     const uint64_t grid_cap = grid_env > 0 ? static_cast<uint64_t>(grid_env) : 256u * 8u;
@@ -1132,7 +1138,8 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
                             ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
-                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, compact_stored ? 2u : (skip_single ? 1u : 0u)};
+                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, compact_stored ? 2u : (skip_single ? 1u : 0u),
+                            ix.g_kind, ix.g_wpb, ix.g_used, ix.g_sb};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
         // SA[row] inside the entries, or as an array of its own: no walk at all

@@ -43,7 +43,7 @@ _WIDTHS = {"u32": 32, "i32": -32, "i64": 64}
 
 def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, aux_budget_bytes=None,
                   full_suffix_array=None, text_units=None, seed_symbols=None, seed_load_percent=None,
-                  inverse_suffix_array=None):
+                  inverse_suffix_array=None, reference_table_layout=None):
     """gdx_build_options_t (include/gdx.h); None = the library's default for that field."""
     o = _lib.BuildOptions()
     _lib.load().gdx_build_options_init(C.byref(o))
@@ -65,6 +65,9 @@ def build_options(pair_lines=None, jump_entry_bytes=None, top_table_depth=None, 
         o.seed_load_percent = int(seed_load_percent)
     if inverse_suffix_array is not None:
         o.inverse_suffix_array = int(bool(inverse_suffix_array))
+    if reference_table_layout is not None:
+        names = {"condensed64": 1, "condensed512": 2, "flat64": 3, "flat512": 4}
+        o.reference_table_layout = names.get(reference_table_layout, reference_table_layout)
     return o
 
 
@@ -100,13 +103,13 @@ class FmIndexConfig:
 
     def acceleration_structures(self, pair_lines=None, jump_entry_bytes=None, top_table_depth=None,
                                 aux_budget_bytes=None, full_suffix_array=None, text_units=None, seed_symbols=None,
-                                seed_load_percent=None, inverse_suffix_array=None) -> "FmIndexConfig":
+                                seed_load_percent=None, inverse_suffix_array=None, reference_table_layout=None) -> "FmIndexConfig":
         """gdx_build_options_t: which derived structures the index carries beside the reference's arrays
         (results are identical with any combination); None keeps the default."""
         self._build = dict(pair_lines=pair_lines, jump_entry_bytes=jump_entry_bytes, top_table_depth=top_table_depth,
                            aux_budget_bytes=aux_budget_bytes, full_suffix_array=full_suffix_array, text_units=text_units,
                            seed_symbols=seed_symbols, seed_load_percent=seed_load_percent,
-                           inverse_suffix_array=inverse_suffix_array)
+                           inverse_suffix_array=inverse_suffix_array, reference_table_layout=reference_table_layout)
         return self
 
     def construct_index(self, texts, alphabet: Alphabet) -> "FmIndex":
@@ -431,6 +434,16 @@ class FmIndex:
         sbo = np.zeros(-(-n1 // 65536) * sigma, dtype=np.uint32)
         _lib.check(self._lib.gdx_index_export_condensed_table(self._h, _p(blocks, u64p), _p(bo, u16p), _p(sbo, u32p)))
         return blocks, bo, sbo
+
+    def export_reference_table(self):
+        """(interleaved blocks u64, superblock offsets u32) of an index built with reference_table_layout"""
+        nw, ns = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.gdx_index_export_reference_table(self._h, None, 0, C.byref(nw), None, 0, C.byref(ns)))
+        blocks = np.zeros(max(nw.value, 1), dtype=np.uint64)
+        sbo = np.zeros(max(ns.value, 1), dtype=np.uint32)
+        _lib.check(self._lib.gdx_index_export_reference_table(self._h, _p(blocks, u64p), blocks.size, C.byref(nw), _p(sbo, u32p),
+                                                              sbo.size, C.byref(ns)))
+        return blocks[: nw.value], sbo[: ns.value]
 
     def build_stats(self):
         st = _lib.BuildStats()

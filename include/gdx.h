@@ -162,6 +162,14 @@ typedef struct {
                                   seed table, cursors_for_many_queries answers every read that occurs exactly once (its seed's
                                   entry, the text in front, then ONE fetch of the row) without LF steps; other reads take the usual
                                   route, so the intervals -- frozen empty ones included -- stay the reference's               */
+    int32_t reference_table_layout; /* -1 / 0 default: this library's own occurrence table (rank lines for sigma <= 8, the
+                                  reference's Condensed / Block64 arrays beyond); 1..4: the REFERENCE's table in the variant named
+                                  -- 1 CondensedTextWithRankSupport<Block64>, 2 <Block512>, 3 FlatTextWithRankSupport<Block64>,
+                                  4 <Block512> (lib.rs:102-113; bit for bit the arrays genedex builds: interleaved blocks, block
+                                  offsets -- inside the blocks for the flat variants --, superblock offsets) and kernels that
+                                  query it as it is, one lane per query: the reference's own speed / memory points
+                                  (condensed.rs:291-341, flat.rs:221-266) instead of this library's.  No pair lines, jump, top
+                                  or seed table on such an index (they belong to the rank-line layout).                  */
 } gdx_build_options_t;
 void gdx_build_options_init(gdx_build_options_t *opts);
 
@@ -261,6 +269,12 @@ int gdx_index_export_lookup_table(const gdx_index_t *ix, int depth, uint32_t *pa
 int gdx_index_export_condensed_table(const gdx_index_t *ix, uint64_t *interleaved_blocks,
                                      uint16_t *interleaved_block_offsets,
                                      uint32_t *interleaved_superblock_offsets);
+/* an index built with gdx_build_options_t.reference_table_layout: its occurrence table as it sits in HBM -- the
+ * reference's interleaved blocks of that variant (flat: block offsets inside the blocks, flat.rs:30-52) and u32 superblock
+ * offsets.  NULL buffers: only the sizes (64-bit words / offsets) are returned. */
+int gdx_index_export_reference_table(const gdx_index_t *ix, uint64_t *interleaved_blocks, uint64_t capacity_words,
+                                     uint64_t *out_n_words, uint32_t *interleaved_superblock_offsets, uint64_t capacity_offsets,
+                                     uint64_t *out_n_offsets);
 
 /* ---------------------------------------------------------------------------------------
  * operator level   (TextWithRankSupport, text_with_rank_support/mod.rs:88-133)           */

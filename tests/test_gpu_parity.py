@@ -238,6 +238,11 @@ _VARIANTS = {
     "seed-isa": (dict(search_kernel="pair"), dict(seed_symbols=10, inverse_suffix_array=True)),
     "seed-isa-nojump": (dict(search_kernel="pair"), dict(jump_entry_bytes=0, top_table_depth=0, seed_symbols=True,
                                                          inverse_suffix_array=True)),
+    # the reference's own occurrence table in its four variants, queried as it is (one lane per query)
+    "ref-condensed64": (dict(search_kernel="lane"), dict(reference_table_layout="condensed64")),
+    "ref-condensed512": (dict(search_kernel="lane"), dict(reference_table_layout="condensed512")),
+    "ref-flat64": (dict(search_kernel="lane", locate_kernel="lane"), dict(reference_table_layout="flat64")),
+    "ref-flat512": (dict(search_kernel="lane"), dict(reference_table_layout="flat512")),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 
@@ -1005,7 +1010,7 @@ def test_packed_queries_equal_ascii_queries(seed, search_variant):
     from genedex_amd import _lib
     from genedex_amd.device import DeviceEngine, _ptr, _stream
 
-    if search_variant in ("quad", "lane", "verify-sa", "verify-walk", "seed-sa", "seed-walk"):
+    if search_variant in ("quad", "lane", "verify-sa", "verify-walk", "seed-sa", "seed-walk") or search_variant.startswith("ref-"):
         pytest.skip("packed queries run on the pair-line kernels")
     lib = _lib.load()
     rng = np.random.default_rng(7300 + seed)

@@ -300,3 +300,50 @@ def test_seed_table_on_a_loaded_index(tmp_path):
     cs, ce = c.cursors_for_many(qbuf, qoff)
     s, e, st = loaded.cursors_raw(qbuf, qoff)
     assert not st.any() and s.tolist() == cs.tolist() and e.tolist() == ce.tolist()
+
+
+# ---- the reference's own occurrence tables as selectable layouts (gdx_build_options_t.reference_table_layout) ----------
+
+@pytest.mark.parametrize("layout", ["condensed64", "condensed512", "flat64", "flat512"])
+def test_reference_table_layouts_bit_for_bit_and_queried_as_they_are(layout):
+    """An index built with reference_table_layout holds the reference's table of that variant -- interleaved blocks (the flat
+    ones with their block offsets inside) and superblock offsets equal the oracle's restatement of condensed.rs:59-124 /
+    flat.rs:59-126 word for word -- and rank / symbol_at / search / locate run on it (GenericTable) with the oracle's results."""
+    from helpers import naive_occurrence_columns
+    from oracle.oracle import OracleTable
+
+    rng = np.random.default_rng(sum(layout.encode()))
+    a = alph.ascii_dna_with_n()
+    for total in (0, 47, 48, 49, 495, 496, 497, 512, 65471, 65472, 65473, 65520, 65536, 70001, 200000):
+        texts = [bytes(b"ACGTN"[i] for i in rng.integers(0, 5, max(total - 1, 0)))]
+        g = gpu_index(texts, a, reference_table_layout=layout)
+        c = cpu_index(texts, a)
+        kind = layout.rstrip("0123456789")
+        bits = int(layout[len(kind):])
+        want = OracleTable(c.bwt, 6, kind, bits)
+        blocks, sbo = g.export_reference_table()
+        assert np.array_equal(blocks, want.blocks), (layout, total)
+        assert np.array_equal(sbo, want.superblock_offsets), (layout, total)
+        n = c.n
+        step = 1 if n < 3000 else 37
+        idx = np.array(sorted(set(range(0, n + 1, step)) | {n} | {i for i in (47, 48, 49, 495, 496, 497, 511, 512, 513, 65471, 65472,
+                                                                             65519, 65520, 65535, 65536) if i <= n}), dtype=np.uint64)
+        cols = naive_occurrence_columns(c.bwt, 6)
+        for s in range(6):
+            got = g.rank_many(np.full(idx.size, s, dtype=np.uint8), idx)
+            assert np.array_equal(got, cols[s][idx.astype(np.int64)]), (layout, total, s)
+        if n:
+            at = np.arange(0, n, step, dtype=np.uint64)
+            assert np.array_equal(g.symbol_at_many(at), c.bwt[at.astype(np.int64)])
+        assert np.array_equal(g.export_bwt(), c.bwt)
+        if total >= 495:
+            qs = mixed_queries(rng, texts, 200, 60, 40, allow_n=True)
+            check_against_oracle(g, c, qs, texts, fold=a.io_to_dense_table)
+            qbuf, qoff = pack_queries(qs)
+            cs, ce = c.cursors_for_many(qbuf, qoff)
+            s_, e_, st = g.cursors_raw(qbuf, qoff)
+            assert not st.any() and s_.tolist() == cs.tolist() and e_.tolist() == ce.tolist()
+            # the Condensed / Block64 export (what gdx_index_save writes) of any layout is the same table
+            b64 = OracleTable(c.bwt, 6, "condensed", 64)
+            eb, ebo, esb = g.export_condensed_table()
+            assert np.array_equal(eb, b64.blocks) and np.array_equal(ebo, b64.block_offsets) and np.array_equal(esb, b64.superblock_offsets)
