@@ -239,10 +239,9 @@ _VARIANTS = {
     "seed-isa-nojump": (dict(search_kernel="pair"), dict(jump_entry_bytes=0, top_table_depth=0, seed_symbols=True,
                                                          inverse_suffix_array=True)),
     # the reference's own occurrence table in its four variants, queried as it is (one lane per query)
-    "ref-condensed64": (dict(search_kernel="lane"), dict(reference_table_layout="condensed64")),
+    # (all four, bit for bit and at the block boundaries: tests/test_gpu_seed.py::test_reference_table_layouts_...)
     "ref-condensed512": (dict(search_kernel="lane"), dict(reference_table_layout="condensed512")),
     "ref-flat64": (dict(search_kernel="lane", locate_kernel="lane"), dict(reference_table_layout="flat64")),
-    "ref-flat512": (dict(search_kernel="lane"), dict(reference_table_layout="flat512")),
     "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
 }
 
