@@ -1054,6 +1054,28 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
     if not args.no_extras and wl["total"] >= 1 << 24:
         del eng2, index2, counts
         torch.cuda.empty_cache()
+        # the reference's own occurrence tables, exactly as genedex lays them out and queried in place (one lane per query,
+        # gdx_build_options_t.reference_table_layout): its speed / memory points on this GPU, on a fifth of the batch
+        from genedex_amd.index import build_options as _bo
+        n_sub = min(nq, 20_000_000)
+        q_sub = queries.slice(0, n_sub)
+        for layout in ("condensed64", "flat64"):
+            t0 = time.time()
+            ix_r = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=args.lookup_depth,
+                                                index_storage=wl["storage"], options=_bo(reference_table_layout=layout))
+            t_build = time.time() - t0
+            eng_r = DeviceEngine(ix_r)
+            ms, s_ms, l_ms, counts_r = time_config(torch, eng_r, q_sub, n_sub, do_locate, args, steps=2)
+            same = bool(torch.equal(counts_r, base_counts[:n_sub]))
+            if not same:
+                raise SystemExit(f"PARITY FAILURE: the {layout} table changed the counts")
+            res.append({"name": f"reference_table_{layout} (genedex's own layout, queried in place)", "queries": n_sub,
+                        "value": n_sub / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms,
+                        "counts_identical_to_headline": same, "index_build_seconds": t_build,
+                        "index_bytes": int(ix_r.info.device_bytes)})
+            log(f"[bench] secondary {res[-1]}")
+            del eng_r, ix_r, counts_r
+            torch.cuda.empty_cache()
         # (seed table AND the library's default structures: a read from a repeat goes on from its seed entry's interval with
         # one jump round -- search_seed_kernel4 -> search_fast_kernel4 over its list -> the general kernel)
         # + the full suffix array: the hits of a read from a repeat are consecutive rows -- 32 of their SA values per 128-byte
