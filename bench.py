@@ -791,14 +791,25 @@ def main():
             roofline["random_request_model"] = {"dram_requests_per_launch": rq * nq, "achieved_Greq_per_s": rate,
                                                 "measured_ceiling_Greq_per_s": ceiling, "frac_of_ceiling": rate / ceiling}
 
+    # The measurements beside the headline must not take the line with them when the box runs out of something (memory for
+    # the 214 GB index of the secondaries, a host allocation): an ordinary exception is reported in the line; a PARITY FAILURE
+    # (SystemExit) still ends the run without a number.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl)
+        try:
+            result["cpu_baseline"] = cpu_baseline(np, torch, index, alpha, queries, runner, do_locate, args, wl)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cpu_baseline failed: {e!r}")
+            result["cpu_baseline"] = {"error": repr(e)}
     else:
         result["cpu_baseline"] = None
 
     if rank == 0 and world == 1 and not args.no_extras:
-        result["end_to_end"] = end_to_end(np, torch, index, queries, nq, counts, total_hits, ms_per_step, search_ms,
-                                           has_pair_lines=aux["pair_lines"])
+        try:
+            result["end_to_end"] = end_to_end(np, torch, index, queries, nq, counts, total_hits, ms_per_step, search_ms,
+                                               has_pair_lines=aux["pair_lines"])
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] end_to_end failed: {e!r}")
+            result["end_to_end"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and args.secondary_depth > 0 and wl["len_min"] >= 16:
         base_counts = counts.clone()
@@ -807,8 +818,14 @@ def main():
         torch.cuda.empty_cache()
         owned = {"eng": eng, "index": index}  # handed over: the last rung frees the index before building another
         del eng, index
-        result["secondary"] = secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate,
-                                          args, wl, pmc_ref, pmc_text, result.get("end_to_end"))
+        result["secondary"] = []
+        try:
+            secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref, pmc_text,
+                        result.get("end_to_end") if "error" not in (result.get("end_to_end") or {}) else None,
+                        res=result["secondary"])
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] secondaries stopped: {e!r}")
+            result["secondary_error"] = repr(e)
         for r in result["secondary"]:  # the like-for-like rung, in the keys the driver keeps
             rl = r.get("roofline_reference_layout")
             if rl:
@@ -923,7 +940,7 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
 
 
 def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None,
-                pmc_text=None, e2e=None):
+                pmc_text=None, e2e=None, res=None):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -932,7 +949,7 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
     from genedex_amd.device import DeviceEngine, build_index_from_device_text
 
     eng, index = owned["eng"], owned["index"]
-    res = []
+    res = res if res is not None else []
     text = dict(jump_entry_bytes=0, pair_lines=False, text_units=True)  # the rest of a read against the text at SA[row]
     ladder = [("top16_sa_text", dict(top_table_depth=16, full_suffix_array=True, **text)),
               ("top15_sa_text", dict(top_table_depth=15, full_suffix_array=True, **text)),
