@@ -205,6 +205,15 @@ extern "C" {
         d_workspace: *mut c_void, stream: *mut c_void,
     ) -> c_int;
     pub fn gdx_index_seed_info(ix: *const gdx_index_t, out: *mut u64) -> c_int;
+    /// an index built with `reference_table_layout`: genedex's own interleaved blocks and superblock offsets as they sit in HBM
+    pub fn gdx_index_export_reference_table(
+        ix: *const gdx_index_t, interleaved_blocks: *mut u64, capacity_words: u64, out_n_words: *mut u64,
+        interleaved_superblock_offsets: *mut u32, capacity_offsets: u64, out_n_offsets: *mut u64,
+    ) -> c_int;
+    pub fn gdx_locate_many_unpack_compact_dev(
+        ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, d_out_counts: *mut c_void,
+        d_out_status: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
     // several GPUs of one node behind one handle
     pub fn gdx_multi_build(
         texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int,
