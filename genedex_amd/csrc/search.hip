@@ -2232,16 +2232,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
     uint4 *__restrict__ state,  // != null: where a listed read stands, {lo, hi, symbols left, 1} after a seed entry that holds
                                 // an interval, {0, 0, 0, 0} = from the beginning (search_fast_kernel4 goes on from there)
-    uint32_t *__restrict__ out_compact)  // != null: compact results instead of records (kernels.hpp)
+    uint32_t *__restrict__ out_compact,  // != null: compact results instead of records (kernels.hpp)
+    // reads longer than the entry covers whose seed and 32 symbols in front agree with the text: listed for
+    // seed_text_kernel4 with {position of the seed, symbols in front of it} in long_state[q * long_stride] (the first half
+    // of their record slot, or an array of its own when the call has no records; exact mode: in out_start / out_end)
+    uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long, uint2 *__restrict__ long_state, uint32_t long_stride)
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
     __shared__ uint8_t s_dense[256];
-    __shared__ uint32_t s_left[kMaxRange];
-    __shared__ uint32_t s_nleft, s_left_base;
+    __shared__ uint16_t s_left[kMaxRange], s_long[kMaxRange];  // slots of the range (its base is added when they are flushed)
+    __shared__ uint32_t s_nleft, s_left_base, s_nlong, s_long_base;
     if (kXlate == 0)
         for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = sv.io_to_dense[i];
-    if (threadIdx.x == 0) s_nleft = 0;
+    if (threadIdx.x == 0) s_nleft = s_nlong = 0;
     __syncthreads();
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
@@ -2280,7 +2284,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint32_t q = static_cast<uint32_t>(base + slot);
                 if (a_left) {
                     if (writer) {
-                        s_left[atomicAdd(&s_nleft, 1u)] = q;
+                        s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                         if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
                         if (!kExact && out_compact) out_compact[q] = kCompactSee;
                     }
@@ -2320,12 +2324,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 if (out_status) out_status[q] = 0;
                             }
                         } else if (writer) {  // several rows: the next kernel takes it from this interval
-                            s_left[atomicAdd(&s_nleft, 1u)] = q;
+                            s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                             if (!kExact && state) state[q] = make_uint4(ey, ez, a_rem, 1u);
                             if (!kExact && out_compact) out_compact[q] = kCompactSee;
                         }
                     } else {
-                        bool hit = false, left = false;
+                        bool hit = false, left = false, is_long = false;
                         const uint32_t rem = a_rem, pos = ey;
                         if ((ex & kSeedFound) != 0u) {
                             const uint32_t n_v = rem < 32u ? rem : 32u;
@@ -2335,44 +2339,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             const uint32_t v_code = (ex >> kSeedPartialShift) & 3u;
                             const uint32_t n_text = (ex & kSeedPartial) == 0u ? 0xffffffffu : (v_code == 0u ? (ez & 63u) : 29u + v_code);
                             hit = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
-                            if (hit && rem > 32u) {
-                                // the rest against the text units, 32 symbols per pass from the right (as search_verify_kernel4)
-                                const uint64_t begin = qbeg[q];
-                                const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
-                                const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
-                                uint32_t rem_v = rem - 32u;
-                                while (rem_v > 0u) {
-                                    const FastWindow w = fast_window<kXlate>(sv, s_dense, wbase, off0, rem_v, sub);
-                                    const uint32_t n_w = rem_v < 32u ? rem_v : 32u;
-                                    const uint32_t n_words = n_w <= w.s0 ? 1u : 1u + ((n_w - w.s0 + 7u) >> 3);
-                                    if ((w.valid8 & ((1u << n_words) - 1u)) != (1u << n_words) - 1u) {
-                                        left = true;  // a symbol outside A C G T further front: the general route
-                                        break;
-                                    }
-                                    const uint64_t qc = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(w.l0, w.l0, 16)) << 32) |
-                                                        static_cast<uint64_t>(__builtin_amdgcn_alignbit(w.l1, w.l1, 16));
-                                    const uint64_t s0 = static_cast<uint64_t>(pos) - rem + rem_v + 32u * kTextPadUnits - 32u;
-                                    const uint32_t tb = static_cast<uint32_t>(s0 & 31u);
-                                    const u32x4 *tu = sv.text_units + (s0 >> 5);
-                                    const u32x4 u0 = tu[0];
-                                    const u32x4 u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
-                                    const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
-                                    const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
-                                    const uint64_t tc = tb ? (c0 >> (2u * tb)) | (c1 << (64u - 2u * tb)) : c0;
-                                    const uint32_t tm = tb ? (u0.z >> tb) | (u1.z << (32u - tb)) : u0.z;
-                                    const uint64_t m64 = n_w == 32u ? ~0ull : ~0ull << (2u * (32u - n_w));
-                                    const uint32_t m32 = n_w == 32u ? ~0u : ~0u << (32u - n_w);
-                                    if (((qc ^ tc) & m64) != 0ull || (tm & m32) != 0u) {
-                                        hit = false;
-                                        break;
-                                    }
-                                    rem_v -= n_w;
+                            is_long = hit && rem > 32u;  // the rest against the text units: seed_text_kernel4
+                        }
+                        if (is_long) {
+                            if (writer) {
+                                s_long[atomicAdd(&s_nlong, 1u)] = static_cast<uint16_t>(slot);
+                                if (kExact) {
+                                    out_start[q] = pos;
+                                    out_end[q] = rem;
+                                } else {
+                                    long_state[static_cast<uint64_t>(q) * long_stride] = make_uint2(pos, rem);
+                                    if (out_compact) out_compact[q] = kCompactSee;  // (seed_text_kernel4 writes the result)
                                 }
                             }
-                        }
-                        if (kExact) {
+                        } else if (kExact) {
                             if (left || !hit) {  // no occurrence: the reference's frozen empty interval is the exact kernel's to find
-                                if (writer) s_left[atomicAdd(&s_nleft, 1u)] = q;
+                                if (writer) s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                             } else {
                                 z_row = sv.isa[pos - rem];
                                 z_q = q;
@@ -2380,7 +2362,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             }
                         } else if (writer) {
                             if (left) {
-                                s_left[atomicAdd(&s_nleft, 1u)] = q;
+                                s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                                 if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
                                 if (out_compact) out_compact[q] = kCompactSee;
                             } else {
@@ -2458,9 +2440,139 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t n_left = s_nleft;
         if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = s_left[i];
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = static_cast<uint32_t>(base) + s_left[i];
+        const uint32_t n_lng = s_nlong;
+        if (threadIdx.x == 0 && n_lng != 0u) s_long_base = atomicAdd(n_long, n_lng);
         __syncthreads();
-        if (threadIdx.x == 0) s_nleft = 0;
+        for (uint32_t i = threadIdx.x; i < n_lng; i += kBlock) long_list[s_long_base + i] = static_cast<uint32_t>(base) + s_long[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nleft = s_nlong = 0;
+    }
+}
+
+// The reads search_seed_kernel4 listed as "long": seed and the 32 symbols in front agree with the text at `pos`, `rem` symbols
+// are in front of the seed in all.  The rest against the text units, every lane of the group its own 32 symbols: lane `sub`
+// of round r takes the symbols [e - 32, e) of the query with e = rem - 32 - 32 (4 r + sub) (clipped at the query's start),
+// reads them as bytes and compares their 2-bit codes with the text in front of the occurrence -- four independent (query,
+// text) fetches in flight per read.  (Inside the seed kernel this was a loop of dependent fetches, one 32-symbol pass after
+// the other, and most of its time on reads of 20..150 symbols; done there lane-parallel it cost the pipeline 32 spilled
+// registers.)  Results as search_seed_kernel4 writes them; a symbol outside A C G T goes on the leftover list.
+template <int kXlate, bool kExact>
+__global__ __launch_bounds__(kBlock) void seed_text_kernel4(
+    SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint32_t *__restrict__ list,
+    const uint32_t *__restrict__ n_list, const uint2 *__restrict__ long_state, uint32_t long_stride,
+    uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_compact,
+    uint4 *__restrict__ state, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+{
+    constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
+    __shared__ uint8_t s_dense[256];
+    if (kXlate == 0) {
+        for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = sv.io_to_dense[i];
+        __syncthreads();
+    }
+    const uint32_t sub = threadIdx.x & (kGroup - 1u);
+    const bool writer = sub == 0u;
+    const uint64_t n = *n_list;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kGroups + threadIdx.x / kGroup; i < n;
+         i += static_cast<uint64_t>(gridDim.x) * kGroups) {
+        const uint32_t q = list[i];
+        uint32_t pos, rem;
+        if (kExact) {
+            pos = out_start[q];
+            rem = out_end[q];
+        } else {
+            const uint2 st = long_state[static_cast<uint64_t>(q) * long_stride];
+            pos = st.x;
+            rem = st.y;
+        }
+        const uint64_t begin = qbeg[q];
+        const uint32_t rest = rem - 32u;  // (rem > 32: why the read is here)
+        uint32_t bad_q = 0, bad_t = 0;    // a query symbol outside A C G T / a mismatch, in any lane
+        for (uint32_t done = 0; done < rest; done += 128u) {
+            const uint32_t skip = done + 32u * sub;
+            if (skip < rest) {
+                const uint32_t e = rest - skip, n_c = e < 32u ? e : 32u, qs = e - n_c;
+                // query bytes [qs, qs + n_c) as aligned 8-byte words (only the words that hold one of them)
+                const uint64_t at = begin + qs;
+                const uint64_t *wp = reinterpret_cast<const uint64_t *>(qbuf) + (at >> 3);
+                const uint32_t sh = static_cast<uint32_t>(at & 7u) * 8u;
+                const uint32_t n_need = (static_cast<uint32_t>(at & 7u) + n_c + 7u) >> 3;  // 1 .. 5
+                uint64_t w0 = wp[0], w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+                if (n_need > 1u) w1 = wp[1];
+                if (n_need > 2u) w2 = wp[2];
+                if (n_need > 3u) w3 = wp[3];
+                if (n_need > 4u) w4 = wp[4];
+                // the text [tp, tp + n_c) in front of the occurrence, tp = pos - rem + qs
+                const uint64_t s0 = static_cast<uint64_t>(pos) - rem + qs + 32u * kTextPadUnits;
+                const uint32_t tb = static_cast<uint32_t>(s0 & 31u);
+                const u32x4 *tu = sv.text_units + (s0 >> 5);
+                const u32x4 u0 = tu[0];
+                const u32x4 u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                if (sh != 0u) {
+                    w0 = (w0 >> sh) | (w1 << (64u - sh));
+                    w1 = (w1 >> sh) | (w2 << (64u - sh));
+                    w2 = (w2 >> sh) | (w3 << (64u - sh));
+                    w3 = (w3 >> sh) | (w4 << (64u - sh));
+                }
+                // 32 bytes -> 64 bits of codes (byte i in bits 2 i + 1 : 2 i); b[g] != 0: group g (bytes 4 g .. 4 g + 3) holds a byte
+                // that is not A C G T (the v_perm translation says which byte, the LDS table only that there is one)
+                uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                const uint32_t wd[8] = {static_cast<uint32_t>(w0), static_cast<uint32_t>(w0 >> 32), static_cast<uint32_t>(w1),
+                                        static_cast<uint32_t>(w1 >> 32), static_cast<uint32_t>(w2), static_cast<uint32_t>(w2 >> 32),
+                                        static_cast<uint32_t>(w3), static_cast<uint32_t>(w3 >> 32)};
+                uint64_t qc = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < 8; g++) {
+                    const uint32_t code = kXlate == 1 ? fast_pack4(sv, wd[g], b[g]) : fast_pack4_lds(s_dense, wd[g], b[g]);
+                    qc |= static_cast<uint64_t>(code) << (8u * g);
+                }
+                const uint32_t full = n_c >> 2, part = n_c & 3u;
+                uint32_t inv = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < 8; g++) {
+                    // (LDS path: a group is flagged as a whole; the bytes behind n_c are later symbols of the same read, whose
+                    // own chunk flags them too, so nothing is sent the slow way that would not go there anyway)
+                    const uint32_t bg = kXlate == 1 ? b[g] : (b[g] != 0u ? 0xffffffffu : 0u);
+                    if (g < full) inv |= bg;
+                    else if (g == full && part != 0u) inv |= bg & ((1u << (8u * part)) - 1u);
+                }
+                const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
+                const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
+                const uint64_t tc = tb ? (c0 >> (2u * tb)) | (c1 << (64u - 2u * tb)) : c0;
+                const uint32_t tm = tb ? (u0.z >> tb) | (u1.z << (32u - tb)) : u0.z;
+                const uint64_t m64 = n_c == 32u ? ~0ull : (1ull << (2u * n_c)) - 1ull;
+                const uint32_t m32 = n_c == 32u ? ~0u : (1u << n_c) - 1u;
+                if (inv != 0u) bad_q = 1u;
+                if (((qc ^ tc) & m64) != 0ull || (tm & m32) != 0u) bad_t = 1u;
+            }
+        }
+        const bool left = group_max<kGroup>(bad_q) != 0u;  // a symbol outside A C G T further front: the general route
+        const bool hit = group_max<kGroup>(bad_t) == 0u;
+        if (kExact) {
+            if (left || !hit) {  // (no occurrence: the reference's frozen empty interval is the exact kernel's to find)
+                if (writer) leftover[atomicAdd(n_leftover, 1u)] = q;
+            } else {
+                const uint32_t row = sv.isa[pos - rem];
+                if (writer) {
+                    out_start[q] = row;
+                    out_end[q] = row + 1u;
+                    if (out_count) out_count[q] = 1u;
+                    if (out_status) out_status[q] = 0;
+                }
+            }
+        } else if (writer) {
+            if (left) {
+                leftover[atomicAdd(n_leftover, 1u)] = q;
+                if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
+                if (out_compact) out_compact[q] = kCompactSee;
+            } else {
+                if (out_compact) out_compact[q] = hit ? pos - rem : kCompactNone;
+                else if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
+                if (out_count) out_count[q] = hit ? 1u : 0u;
+                if (out_status) out_status[q] = 0;
+            }
+        }
     }
 }
 
@@ -2764,14 +2876,31 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                                       ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
                     uint4 *d_seed_state = to_fast ? c.d_rec : nullptr;
                     uint32_t *const none = nullptr;
-                    if (perm)
+                    // reads longer than a seed entry covers: listed with {position, symbols in front} in the first half of their
+                    // record slot (an array of its own when the call has no records) for seed_text_kernel4, whose own
+                    // leftovers (a symbol outside A C G T further front) join the seed kernel's list
+                    uint32_t *d_long = static_cast<uint32_t *>(stream_scratch(stream, 13, (nq + 4) * sizeof(uint32_t)));
+                    GDX_HIP(hipMemsetAsync(d_long, 0, sizeof(uint32_t), stream));
+                    uint2 *d_long_state = c.d_rec != nullptr ? reinterpret_cast<uint2 *>(c.d_rec)
+                                                             : static_cast<uint2 *>(stream_scratch(stream, 14, nq * sizeof(uint2)));
+                    const uint32_t long_stride = c.d_rec != nullptr ? 2u : 1u;
+                    const uint64_t t_groups = (nq + kBlock / 4 - 1) / (kBlock / 4);
+                    const unsigned t_blocks = static_cast<unsigned>(t_groups < 8192 ? t_groups : 8192);
+                    if (perm) {
                         hipLaunchKernelGGL((search_seed_kernel4<1, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact);
-                    else
+                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride);
+                        hipLaunchKernelGGL((seed_text_kernel4<1, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
+                                           c.d_compact, d_seed_state, d_first + 4, d_first);
+                    } else {
                         hipLaunchKernelGGL((search_seed_kernel4<0, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact);
+                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride);
+                        hipLaunchKernelGGL((seed_text_kernel4<0, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
+                                           c.d_compact, d_seed_state, d_first + 4, d_first);
+                    }
                     compact_by_seed = true;
                     if (to_fast) {
                         seed_list = d_first;
@@ -2914,14 +3043,26 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             static const bool env_no_perm_s = getenv("GDX_SEARCH_NO_PERM") != nullptr;
             uint4 *const no_rec = nullptr;
             uint32_t *const none_u32 = nullptr;
-            if (ix.perm_ok && !env_no_perm_s)
+            uint32_t *d_long = static_cast<uint32_t *>(stream_scratch(stream, 13, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_long, 0, sizeof(uint32_t), stream));
+            uint2 *const no_state = nullptr;
+            const uint64_t t_groups = (nq + kBlock / 4 - 1) / (kBlock / 4);
+            const unsigned t_blocks = static_cast<unsigned>(t_groups < 8192 ? t_groups : 8192);
+            if (ix.perm_ok && !env_no_perm_s) {
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32);
-            else
+                                   none_u32, d_long + 4, d_long, no_state, 0u);
+                hipLaunchKernelGGL((seed_text_kernel4<1, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
+                                   d_first + 4, d_first);
+            } else {
                 hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32);
+                                   none_u32, d_long + 4, d_long, no_state, 0u);
+                hipLaunchKernelGGL((seed_text_kernel4<0, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
+                                   d_first + 4, d_first);
+            }
             ca_exact.active_in = d_first + 4;
             ca_exact.n_active_in = d_first;
             x_range = 256;
