@@ -1277,12 +1277,21 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
     cursor_ms = timed(cursor_api_chunks)
     cursor_api_chunks(record_live=True)
     check("chunks")
+    # the same API with more symbols per call: a cursor extension costs its own fixed lines (list entry, state, offsets, the
+    # line of query bytes) beside one jump entry per 32 symbols, so fewer, longer calls move fewer bytes
+    by_chunk = {str(chunk): cursor_ms}
+    for c2 in (64, 80):
+        chunk, rounds = c2, -(-w["len_max"] // c2)
+        by_chunk[str(c2)] = timed(cursor_api_chunks)
+        check(f"chunks of {c2}")
+    chunk, rounds = 32, -(-w["len_max"] // 32)
     same = True
     res = {"name": "mixed_lengths_20_150 (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
            "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms,
            "cursor_api_value": nq / (cursor_ms / 1e3), "cursor_api_ms": cursor_ms, "unit": "queries/s",
            "cursor_api": f"cursor_empty + {rounds} x gdx_cursor_extend_front_chunk_dev ({chunk} symbols per call, "
                          f"device-side live lists, no host round trip inside a pass)",
+           "cursor_api_ms_by_symbols_per_call": by_chunk,
            "cursor_api_strings_ms": strings_ms,
            "cursor_api_strings": "the same through gdx_cursor_extend_front_strings_dev (chunk edges computed by the "
                                  "caller, reads that have ended stay in the live list)",

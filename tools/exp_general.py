@@ -62,15 +62,18 @@ n_act = [torch.empty(1, dtype=torch.int32, device=dev) for _ in range(2)]
 call_ms = []
 
 
+chunk = int(os.environ.get("GDX_EXP_CHUNK", 32))
+
+
 def cursor_pass(record=False):
     cur_s.zero_()
     cur_e.fill_(n if n < (1 << 31) else n - (1 << 32))
     cur_st.zero_()
     a, na = None, None
-    for r in range(5):
+    for r in range((150 + chunk - 1) // chunk):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
-        eng.cursor_extend_chunk(cur_s, cur_e, q.qbuf, q.qoff, nq, 32, r, cur_st, a, na, act[r % 2], n_act[r % 2])
+        eng.cursor_extend_chunk(cur_s, cur_e, q.qbuf, q.qoff, nq, chunk, r, cur_st, a, na, act[r % 2], n_act[r % 2])
         ev[1].record()
         a, na = act[r % 2], n_act[r % 2]
         if record:
@@ -81,5 +84,6 @@ def cursor_pass(record=False):
 res["cursor_chunks_ms"] = timed(cursor_pass)
 cursor_pass(record=True)
 res["cursor_call_ms"] = call_ms
+res["cursor_chunk_symbols"] = chunk
 res["cursor_equals_fused"] = bool(torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]))
 print(json.dumps(res))
