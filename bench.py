@@ -856,8 +856,18 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     cnts = [torch.zeros(max(max_nq, 1), dtype=count_dtype, device=dev) for _ in range(runner.n_slots)]
     gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for c, h in zip(cnts, runner.hits)], dst=0)
 
+    counts32 = [torch.empty(max(nq, 1), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)] if runner.use_rec else None
+
     def count_of(slot):
-        cnts[slot][:nq].copy_(runner.counts(runner.outs[slot]))  # copy_ narrows to the gather's count type
+        # per-query counts out of the step's results in the gather's count type (copy_ narrows); with records one pass of
+        # gdx_locate_many_unpack[_compact]_dev instead of torch arithmetic over the strided 16-byte records -- this runs
+        # inside every timed step of an N > 1 run, which an N = 1 run does not have
+        if runner.use_rec:
+            o_ = runner.outs[slot]
+            runner.eng.unpack_records(o_["rec"], nq, counts32[slot], None, compact=o_["compact"])
+            cnts[slot][:nq].copy_(counts32[slot][:nq])
+        else:
+            cnts[slot][:nq].copy_(runner.counts(runner.outs[slot]))
 
     nbytes = cnts[0].numel() * cnts[0].element_size() + (runner.hits[0].numel() * 4 if do_locate else 0)
     return gather, count_of, nbytes
