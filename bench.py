@@ -854,7 +854,18 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     max_nq = gdist.max_int_over_ranks(nq, dev)
     runner.hits = [torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
     cnts = [torch.zeros(max(max_nq, 1), dtype=count_dtype, device=dev) for _ in range(runner.n_slots)]
-    gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for c, h in zip(cnts, runner.hits)], dst=0)
+    # Hits travel as two arrays -- text ids as bytes when the collection has at most 256 texts, positions as int32 -- instead
+    # of (int32, int32) pairs: 5 instead of 8 bytes per hit over the one xGMI link every rank has to rank 0.  With the seed
+    # index a rank produces ~21 G results/s; as pairs that would be 172 GB/s per link, more than a link carries (DESIGN.md
+    # section 6), and the gather rather than the kernels would bound the step.  Lossless: rank 0 holds the same hits.
+    n_texts = int(runner.eng.index.num_texts())
+    split = do_locate and n_texts <= 256
+    if split:
+        ids = [torch.zeros(max(max_hits, 1), dtype=torch.uint8, device=dev) for _ in range(runner.n_slots)]
+        pos = [torch.zeros(max(max_hits, 1), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
+        gather = gdist.PipelinedGather([[c, i, p] for c, i, p in zip(cnts, ids, pos)], dst=0)
+    else:
+        gather = gdist.PipelinedGather([[c, h] if do_locate else [c] for c, h in zip(cnts, runner.hits)], dst=0)
 
     counts32 = [torch.empty(max(nq, 1), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)] if runner.use_rec else None
 
@@ -868,8 +879,17 @@ def make_gather(torch, gdist, runner, dev, do_locate):
             cnts[slot][:nq].copy_(counts32[slot][:nq])
         else:
             cnts[slot][:nq].copy_(runner.counts(runner.outs[slot]))
+        if split:
+            th = min(runner.total_hits, ids[slot].numel())
+            h_ = runner.hits[slot]
+            ids[slot][:th].copy_(h_[:th, 0])  # (text ids < 256: copy_ narrows)
+            pos[slot][:th].copy_(h_[:th, 1])
 
-    nbytes = cnts[0].numel() * cnts[0].element_size() + (runner.hits[0].numel() * 4 if do_locate else 0)
+    if split:
+        nbytes = cnts[0].numel() * cnts[0].element_size() + 5 * ids[0].numel()
+    else:
+        nbytes = cnts[0].numel() * cnts[0].element_size() + (runner.hits[0].numel() * 4 if do_locate else 0)
+    gather.hits_are_split = split
     return gather, count_of, nbytes
 
 
@@ -898,7 +918,11 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
         parts = gather.gathered(last)
         shard_len = [gdist.shard_range(nq_total, r, world) for r in range(world)]
         cnt_cat = torch.cat([parts[0][r][: b - a] for r, (a, b) in enumerate(shard_len)])
-        hit_cat = torch.cat([parts[1][r][: sizes[r]] for r in range(world)]) if do_locate else None
+        if do_locate and getattr(gather, "hits_are_split", False):  # (text ids as bytes, positions as int32: back to pairs)
+            hit_cat = torch.cat([torch.stack([parts[1][r][: sizes[r]].to(torch.int32), parts[2][r][: sizes[r]]], dim=1)
+                                 for r in range(world)])
+        else:
+            hit_cat = torch.cat([parts[1][r][: sizes[r]] for r in range(world)]) if do_locate else None
         del gather, runner
         torch.cuda.empty_cache()
         single = StepRunner(torch, eng, full, nq_total, do_locate, args.path, hint=not args.no_hint)

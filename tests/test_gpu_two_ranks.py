@@ -24,7 +24,7 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["config"]["queries_per_gpu"] == 1_000_000 and d["value"] > 0
-    assert d["config"]["gathered_bytes_per_rank_and_step"] > 1_000_000  # 1-byte counts + 8 bytes per hit
+    assert d["config"]["gathered_bytes_per_rank_and_step"] > 1_000_000  # 1-byte counts + 5 bytes per hit (text id byte + int32 position)
     assert d["parity"]["hits_checked"] == d["parity"]["hits_matching_text"] > 0
     assert d["cpu_baseline"] is None  # N = 1 only
     # BASELINE configs[3]: ONE batch sharded over the ranks; rank 0 reran it alone and compared bit for bit
