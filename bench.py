@@ -480,11 +480,19 @@ def timed_steps(torch, gdist, runner, steps, warmup, dev, gather=None, count_of=
     side_stream = torch.cuda.Stream() if overlap else None
     slot_free = [None] * runner.n_slots
     no = [0]
+    # what an N > 1 step does beyond an N = 1 step -- the counts in the gather's type, the hit pairs split into the two
+    # arrays that travel -- runs on a stream of its own behind the step's kernels, beside the next step's search, and the
+    # gather is enqueued from there (it waits for that stream); acquire(slot) two steps later waits for the gather
+    post_stream = torch.cuda.Stream() if gather else None
 
     def after(slot):
         if gather:
-            count_of(slot)
-            gather.submit(slot)
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(post_stream):
+                post_stream.wait_event(done)
+                count_of(slot)
+                gather.submit(slot)
         if overlap:
             slot_free[slot] = torch.cuda.Event()
             slot_free[slot].record()
