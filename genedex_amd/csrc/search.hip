@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 // an N of the text) is appended to `leftover` untouched and searched by the general kernel afterwards
 // (launch_search_call).  Counts and hits of the queries it finishes are the general kernel's, bit for bit.
 // (the few fields of the IndexView it needs, so that the kernel arguments do not eat the SGPR budget of 8+ waves)
+// resume states of the seed kernel's list in their packed form (search_seed_kernel4 -> search_fast_kernel4, state_packed):
+// {lo, rows << 24 | kStatePacked | symbols left, codes hi, codes lo} carries the 32 symbols in front of the seed as 2-bit
+// codes (the one to be consumed next in the top bits of `codes hi`); {lo, kStatePlain | symbols left, hi, 0} an interval
+// of 256+ rows; all zero = from the beginning
+constexpr uint32_t kStatePacked = 1u << 23, kStatePlain = 1u << 22;
+
 struct FastView {
     const uint2 *top;
     const void *jump;
@@ -1164,7 +1170,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state,
     // list != null: only the *n_list queries listed (what the seed kernel left over), each from where its state says:
     // {lo, hi, symbols left, 1} = the interval of its last symbols (a seed-table entry), {.., 0} = from the beginning
-    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list)
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
+    // state_packed != 0 (with list): the states are packed ones (kStatePacked) -- a read with at most 32 symbols left is
+    // finished from its state and the jump entries alone, neither its offsets nor its bytes are fetched
+    uint32_t state_packed)
 {
     constexpr int kGroup = 4;
     constexpr uint32_t kWideRows = kWide ? 16 : kGroup;  // widest interval a round takes
@@ -1193,22 +1202,55 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
             const uint32_t q = list != nullptr ? list[base + slot] : static_cast<uint32_t>(base + slot);
-            const uint64_t begin = qbeg[q];
-            const uint64_t len = qend[q] - begin;
             uint4 resume = make_uint4(0u, 0u, 0u, 0u);
             if (list != nullptr && state != nullptr) resume = state[q];
-            bool bail = !(len >= 16u && len >= depth && len < (1ull << 21));
+            // (a read that is finished from its packed state never asks where its bytes are)
+            const bool from_state = state_packed != 0u && (resume.y & kStatePacked) != 0u && (resume.y & 0x1fffffu) <= 32u;
+            uint64_t begin = 0, len = 0;
+            const uint64_t *wbase = nullptr;
+            uint32_t off0 = 0;
+            bool located = false;
+            auto locate_query = [&]() {
+                begin = qbeg[q];
+                len = qend[q] - begin;
+                wbase = kXlate == 2 ? reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3))
+                                    : reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+                off0 = static_cast<uint32_t>(begin & 7u);
+                located = true;
+            };
+            if (!from_state) locate_query();
+            bool bail = !from_state && !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0, hr = 0xffffffffu, ho = 0;
-            const uint64_t *wbase = kXlate == 2 ? reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3))
-                                                : reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
-            const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0;  // levels of the window already used up: level i of the round is window level shift + i
             bool fresh = false;  // the window is positioned for the round to come
             bool progressed = false;  // lo, hi, rem describe the search after the top table and whole rounds
             bool masked = false;      // the result is a masked record: hr = mask of surviving rows, ho = symbols left
             bool resolved = false;    // kEntrySA: hr = text position of the hit of the one-row interval
-            if (resume.w == 1u && len < (1ull << 21)) {
+            if (state_packed != 0u && (resume.y & kStatePlain) != 0u) {
+                bail = false;
+                lo = resume.x;
+                hi = resume.z;
+                rem = resume.y & 0x1fffffu;
+                progressed = true;
+            } else if (state_packed != 0u && (resume.y & kStatePacked) != 0u) {
+                bail = false;
+                lo = resume.x;
+                hi = lo + (resume.y >> 24);
+                rem = resume.y & 0x1fffffu;
+                progressed = true;
+                if (from_state) {
+                    // the window from the state: levels 0 | 1 and 2 | 3 (eight symbols each, the first of a level in its top
+                    // bits), every level inside one clean word
+                    w.l0 = __builtin_amdgcn_alignbit(resume.z, resume.z, 16);
+                    w.l1 = __builtin_amdgcn_alignbit(resume.w, resume.w, 16);
+                    w.l2 = w.l3 = 0u;
+                    w.valid8 = 0x0fu;
+                    w.s0 = 8u;
+                    shift = 0;
+                    fresh = true;
+                }
+            } else if (state_packed == 0u && resume.w == 1u && len < (1ull << 21)) {
                 bail = false;  // (a read shorter than the top table is deep may still have a seed)
                 lo = resume.x;
                 hi = resume.y;
@@ -1237,6 +1279,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     break;
                 }
                 if (!fresh) {
+                    if (!located) locate_query();
                     w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                     shift = 0;
                 }
@@ -2236,7 +2279,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // reads longer than the entry covers whose seed and 32 symbols in front agree with the text: listed for
     // seed_text_kernel4 with {position of the seed, symbols in front of it} in long_state[q * long_stride] (the first half
     // of their record slot, or an array of its own when the call has no records; exact mode: in out_start / out_end)
-    uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long, uint2 *__restrict__ long_state, uint32_t long_stride)
+    uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long, uint2 *__restrict__ long_state, uint32_t long_stride,
+    // state_packed != 0: a read listed with its seed entry's interval also carries the 32 symbols in front of the seed, as the
+    // 2-bit codes this kernel holds anyway: {lo, rows << 24 | kStatePacked | symbols left, codes hi, codes lo} -- the fast
+    // kernel then needs neither the read's offsets nor its bytes for up to 32 symbols (kStatePacked, search_fast_kernel4)
+    uint32_t state_packed)
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
@@ -2325,7 +2372,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             }
                         } else if (writer) {  // several rows: the next kernel takes it from this interval
                             s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
-                            if (!kExact && state) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                            if (!kExact && state) {
+                                if (state_packed == 0u) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                                else if (ez - ey < 256u) state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | a_rem, a_qh, a_ql);
+                                else state[q] = make_uint4(ey, kStatePlain | a_rem, ez, 0u);
+                            }
                             if (!kExact && out_compact) out_compact[q] = kCompactSee;
                         }
                     } else {
@@ -2815,9 +2866,23 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
         return static_cast<unsigned>(blocks);
     };
+    // lanes per query of the pair-line kernels: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries
+    // in flight); QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
+    static const int env_lanes = [] {
+        const char *e = getenv("GDX_SEARCH_LANES");
+        return (e && atoi(e) == 8) ? 8 : 4;
+    }();
+    const int lanes = (qo.search_lanes == 4 || qo.search_lanes == 8) ? qo.search_lanes : env_lanes;
+    // cache policy of their line / entry loads (see below): QueryOptions::load_policy / GDX_LOAD_POLICY=0|1
+    static const int env_policy = [] {
+        const char *e = getenv("GDX_LOAD_POLICY");
+        return e ? atoi(e) : 0;
+    }();
+    const int policy = (qo.load_policy >= 0 ? qo.load_policy : env_policy) == 1 ? 1 : 0;
     CursorArgs ca = c.cursors;
     bool leftover_list = false;  // ca.active_in is the (short) list another kernel of this call left over
     uint32_t *seed_list = nullptr;  // ... the seed kernel's, with each read's state in its record slot: search_fast_kernel4 next
+    uint32_t seed_state_packed = 0;  // ... in the packed form (kStatePacked)
     bool compact_by_seed = false;   // c.d_compact has been filled by the seed kernel
     if (c.d_compact != nullptr && (c.mode != 1 || c.d_rec == nullptr))
         fail(GDX_ERR_INVALID_ARGUMENT, "internal: compact results go with the records of a count / locate search");
@@ -2866,9 +2931,12 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                 // are only known on the device: small ranges, a capped grid that strides over whatever there is.
                 static const int env_lean = [] { const char *e = getenv("GDX_SEARCH_SEED_LEAN"); return e ? atoi(e) : 1; }();
                 static const int env_chain = [] { const char *e = getenv("GDX_SEARCH_SEED_CHAIN"); return e ? atoi(e) : 1; }();
+                // (to_fast implies every condition of `fast` below: the packed states are only search_fast_kernel4's to read)
                 const bool to_fast = env_lean != 0 && env_chain != 0 && variant == 2 && ix.pair_lines != nullptr && ix.top != nullptr &&
                                      ix.top_depth >= 1u && ix.jump != nullptr && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
-                                     (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
+                                     lanes == 4 && policy == 0 && (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
+                static const int env_packed = [] { const char *e = getenv("GDX_SEARCH_SEED_PACKED"); return e ? atoi(e) : 1; }();
+                seed_state_packed = to_fast && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
                     GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
@@ -2889,14 +2957,16 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                     if (perm) {
                         hipLaunchKernelGGL((search_seed_kernel4<1, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride);
+                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,
+                                           seed_state_packed);
                         hipLaunchKernelGGL((seed_text_kernel4<1, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
                                            c.d_compact, d_seed_state, d_first + 4, d_first);
                     } else {
                         hipLaunchKernelGGL((search_seed_kernel4<0, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
                                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride);
+                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,
+                                           seed_state_packed);
                         hipLaunchKernelGGL((seed_text_kernel4<0, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
                                            c.d_compact, d_seed_state, d_first + 4, d_first);
@@ -2936,13 +3006,6 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
     // compact results without the seed kernel: every query says "see the record"
     if (c.d_compact != nullptr && !compact_by_seed) GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.d_compact), static_cast<int>(kCompactSee), nq, stream));
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
-        // lanes per query: 8 (one 16-byte chunk per lane) or 4 (two chunks per lane, twice the queries in flight);
-        // QueryOptions::search_lanes, else GDX_SEARCH_LANES, else 4
-        static const int env_lanes = [] {
-            const char *e = getenv("GDX_SEARCH_LANES");
-            return (e && atoi(e) == 8) ? 8 : 4;
-        }();
-        const int lanes = (qo.search_lanes == 4 || qo.search_lanes == 8) ? qo.search_lanes : env_lanes;
         // Every block searches contiguous ranges of `range` queries (a multiple of 64, at most kMaxRange): about
         // 48 rounds per group at large batches, 1792+ blocks at small ones; GDX_SEARCH_GRID = number of blocks.
         uint64_t per_block = (nq + 1791) / 1792;
@@ -2955,11 +3018,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         // Cache policy of the line / entry loads: plain by default.  sc1 (no allocation in the CU's L1) was worth
         // +5 % while the first levels of the search were cache-resident pair lines; with the top table every load
         // is a DRAM miss and plain loads measure 3 % faster.  QueryOptions::load_policy / GDX_LOAD_POLICY=0|1.
-        static const int env_policy = [] {
-            const char *e = getenv("GDX_LOAD_POLICY");
-            return e ? atoi(e) : 0;
-        }();
-        const int policy = (qo.load_policy >= 0 ? qo.load_policy : env_policy) == 1 ? 1 : 0;
+        // (resolved above the seed block)
         // Ranges whose query lengths are spread out are searched in length order (order_range_by_length);
         // QueryOptions::length_schedule / GDX_SEARCH_SCHEDULE=0 keeps the query order.
         static const int env_schedule = [] {
@@ -3009,7 +3068,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                           (ca.active_in == nullptr || seed_list != nullptr) && c.d_hint == nullptr && c.d_start == nullptr &&
                           c.d_end == nullptr && (env_fast >= 0 ? env_fast != 0 : qo.search_fast != 0) && nq < 0xffffffffull;
         CursorArgs ca_general = ca;
-        if (seed_list != nullptr) ca_general.resume_state = c.d_rec;  // (should the fast kernel not run: lanes, load policy)
+        if (seed_list != nullptr && !fast) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the seed kernel's list without the fast kernel");
         unsigned g_blocks = blocks;  // grid and range size of the general kernel
         uint32_t g_range = range;
         if (leftover_list) {  // short, and its length is only known on the device: small ranges, a capped grid
@@ -3051,14 +3110,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             if (ix.perm_ok && !env_no_perm_s) {
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u);
                 hipLaunchKernelGGL((seed_text_kernel4<1, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
                                    d_first + 4, d_first);
             } else {
                 hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u);
                 hipLaunchKernelGGL((seed_text_kernel4<0, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
                                    d_first + 4, d_first);
@@ -3127,11 +3186,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         if (wide_rounds)                                                                                                      \
             hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, true>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf,  \
                                c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
-                               f_list, seed_list);                                                                            \
+                               f_list, seed_list, seed_state_packed); \
         else                                                                                                                  \
             hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, false>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, \
                                c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
-                               f_list, seed_list);                                                                            \
+                               f_list, seed_list, seed_state_packed); \
     } while (0)
 #define GDX_FAST_LAUNCH_P(XLATE)                                  \
     do {                                                          \

@@ -180,6 +180,42 @@ def test_compact_results_equal_records_and_oracle(seed):
     assert off_a.tolist() == off_c.tolist() and hits_a.tolist() == hits_c.tolist()
 
 
+@pytest.mark.parametrize("copies", [3, 40, 300])
+@pytest.mark.parametrize("wide", [False, True])
+def test_seed_intervals_hand_the_fast_kernel_their_state(copies, wide):
+    """A k-mer on several rows: the seed kernel lists the read with the entry's interval and the 32 symbols in front of
+    the seed packed into its state, the fast kernel finishes it from there (reads of up to k + 32 symbols without a
+    look at their bytes; 256+ rows travel as a plain interval and end in the general kernel).  Records and the compact
+    / fused results alike."""
+    rng = np.random.default_rng(9700 + copies)
+    unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 60))
+    parts = []
+    for _ in range(copies):
+        parts.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(20, 90)))))
+        parts.append(unit)
+    texts = [b"".join(parts), bytes(b"ACGT"[i] for i in rng.integers(0, 4, 3000)) + unit[20:]]
+    a = alph.ascii_dna()
+    g = gpu_index(texts, a, sa_rate=3, seed_symbols=12)
+    g.set_query_options(search_fast=2 if wide else 1)
+    c = cpu_index(texts, a, sa_rate=3)
+    assert g.seed_info()["interval_entries"] > 0
+    qs = [unit, unit[20:], unit[-12:], unit[-13:], unit[-44:], unit[-45:]]
+    joined = texts[0]
+    for _ in range(400):  # reads that end inside or at the end of a copy and start in the unique flank in front of it
+        end = int(rng.integers(13, len(joined) + 1))
+        qs.append(joined[max(0, end - int(rng.integers(12, 120))):end])
+    for q in list(qs[6:206]):  # ... and with one symbol changed somewhere in front of the seed
+        if len(q) > 13:
+            at = int(rng.integers(0, len(q) - 12))
+            qs.append(q[:at] + bytes([b"ACGT"[(b"ACGT".find(q[at:at + 1]) + 1) % 4]]) + q[at + 1:])
+    want = check_against_oracle(g, c, qs, texts)
+    for compact, fused in ((False, False), (True, False), (True, True)):
+        off, hits, counts, stat, _ = device_locate(g, qs, compact, fused=fused)
+        assert off.tolist() == want[0].tolist() and not stat.any()
+        assert hits[:, 0].tolist() == want[1].astype(np.uint32).tolist() and hits[:, 1].tolist() == want[2].astype(np.uint32).tolist()
+        assert counts.tolist() == np.diff(want[0]).astype(np.uint32).tolist()
+
+
 def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()

@@ -34,7 +34,8 @@ def stats(d):
     total = sum(v[1] for v in agg.values())
     print("| kernel | calls | total ms | avg ms | % |")
     print("|---|---|---|---|---|")
-    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 25  # rows shown (by total time)
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"| {k} | {c} | {t / 1e6:.3f} | {t / c / 1e6:.4f} | {100 * t / total:.2f} |")
 
 

@@ -8,6 +8,6 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/$SCRIPT "$@" > $OUT/trace_out.json 2> $OUT/trace.err
-python3 $R/tools/summarize_rocprof.py stats $OUT/trace > $OUT/kernel_stats.md
+python3 $R/tools/summarize_rocprof.py stats $OUT/trace 80 > $OUT/kernel_stats.md
 find $OUT/trace -name '*.csv' -delete
 head -14 $OUT/kernel_stats.md
