@@ -606,6 +606,9 @@ def main():
     total_hits = runner.size()
     out = runner.outs[0]
     n_status = int((runner.status(out) != 0).sum().item())
+    # (queries whose compact result says "see the record" and their hits: what travels beside the 4 bytes per query at N > 1)
+    exceptions = dict(zip(("queries", "hits"), gdist.exception_sizes(out["compact"], out["hit_offsets"], nq))) \
+        if runner.use_compact else None
     log(f"[bench r{rank}] {total_hits} hits, {n_status} queries with non-zero status")
 
     # N > 1: results are gathered to rank 0 over RCCL asynchronously, double-buffered, so that the gather of batch k
@@ -766,7 +769,10 @@ def main():
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
                    "aux_structures": aux,
                    "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0",
-                   "gathered_bytes_per_rank_and_step": gathered_bytes},
+                   "gathered_bytes_per_rank_and_step": gathered_bytes,
+                   "compact_exceptions": exceptions,
+                   "gather_wire": (("compact results + exceptions" if getattr(gather, "compact_wire", False) else "arrays")
+                                   if gather is not None else None)},
         "roofline": roofline,
         "locate_roofline": locate_roofline,
         "kernel_ms": {"search": search_ms, "locate": locate_ms, "totals": runner.mean_ms(runner.ev_scan)},
@@ -860,6 +866,16 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     count_dtype = torch.uint8 if max_count <= 0xff else torch.int32
     max_hits = gdist.max_int_over_ranks(runner.total_hits, dev)
     max_nq = gdist.max_int_over_ranks(nq, dev)
+    # On an index with a seed table the search's compact results travel as they are, with the few queries that have more to
+    # say beside them (make_compact_gather) -- whenever that is fewer bytes than the arrays below (it is not on a text of repeats)
+    wire = os.environ.get("GDX_BENCH_GATHER", "auto")
+    if do_locate and runner.use_compact and int(runner.eng.index.num_texts()) <= 256 and wire in ("auto", "compact"):
+        n_exc, n_exc_hits = gdist.exception_sizes(o["compact"], o["hit_offsets"], nq)
+        cap_q = max(gdist.max_int_over_ranks(n_exc, dev), 1)
+        cap_h = max(gdist.max_int_over_ranks(n_exc_hits, dev), 1)
+        arrays_bytes = max(max_nq, 1) * (1 if max_count <= 0xff else 4) + 5 * max(max_hits, 1)
+        if wire == "compact" or 4 * max(max_nq, 1) + 4 * cap_q + 5 * cap_h + 8 < arrays_bytes:
+            return make_compact_gather(torch, gdist, runner, dev, max_nq, cap_q, cap_h, {"queries": n_exc, "hits": n_exc_hits})
     runner.hits = [torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
     cnts = [torch.zeros(max(max_nq, 1), dtype=count_dtype, device=dev) for _ in range(runner.n_slots)]
     # Hits travel as two arrays -- text ids as bytes when the collection has at most 256 texts, positions as int32 -- instead
@@ -901,6 +917,78 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     return gather, count_of, nbytes
 
 
+def make_compact_gather(torch, gdist, runner, dev, max_nq, cap_q, cap_h, exceptions):
+    """The gather of a count + locate step on an index with a seed table: the search's compact results travel as they are
+    -- 4 bytes per query: the text position of its only hit, "none" or "see the exceptions" -- beside the counts and hits
+    of the exceptions (dist.pack_exceptions, sized by the sizing pass: the steps repeat the same batch).  A link into rank 0
+    carries one direction of one xGMI link's 153.6 GB/s, so at ~21 G results/s per rank the bytes per result decide the
+    step: 4.0x instead of 5.5.  Rank 0 turns every arrived shard into text id + position per query
+    (gdx_compact_split_hits_dev, one kernel per shard, enqueued when the gather is acquired) -- inside the timed region."""
+    nq = runner.nq
+    o = runner.outs[0]
+    n = max(max_nq, 1)
+    slots = [[torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(cap_q, dtype=torch.int32, device=dev),
+              torch.zeros(cap_h, dtype=torch.uint8, device=dev), torch.zeros(cap_h, dtype=torch.int32, device=dev),
+              torch.zeros(2, dtype=torch.int32, device=dev)] for _ in range(runner.n_slots)]
+    rank, world = gdist.world()
+    root_ids = root_pos = None
+    if rank == 0:
+        root_ids = [[torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(runner.n_slots)]
+        root_pos = [[torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(runner.n_slots)]
+
+    def on_gathered(slot, own=False):
+        # (rank 0's own shard is on its device in every form already: only a check asks for it in this one)
+        for r, words in enumerate(gather.gathered(slot)[0]):
+            if (r == 0) == own:
+                runner.eng.compact_split_hits(words, n, root_ids[slot][r], root_pos[slot][r])
+
+    gather = gdist.PipelinedGather(slots, dst=0, on_gathered=on_gathered)
+
+    # the search writes its compact results straight into the buffer that travels
+    for s_, o_ in zip(slots, runner.outs):
+        s_[0][:nq].copy_(o_["compact"][:nq])
+        o_["compact"] = s_[0]
+    listed = [(torch.zeros(cap_q, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+              for _ in range(runner.n_slots)]
+
+    def pack(slot):
+        o_ = runner.outs[slot]
+        words, exc_cnt, exc_ids, exc_pos, meta = slots[slot]
+        runner.eng.compact_exceptions(words, nq, *listed[slot])
+        gdist.pack_exceptions(words, o_["hit_offsets"], runner.hits[slot], nq, exc_cnt, exc_ids, exc_pos, meta, listed[slot])
+
+    gather.hits_are_split = True
+    gather.compact_wire = True
+    gather.root_ids, gather.root_pos = root_ids, root_pos
+    gather.split_own = lambda slot: on_gathered(slot, own=True)
+    gather.exceptions = exceptions
+    return gather, pack, 4 * n + 4 * cap_q + 5 * cap_h + 8
+
+
+def gathered_shards(torch, gdist, gather, slot, shard_len, sizes, do_locate):
+    """rank 0: (counts, hits or None) of the gathered shards of `slot`, concatenated, as a one-rank run would hold them"""
+    parts = gather.gathered(slot)
+    world = len(shard_len)
+    if getattr(gather, "compact_wire", False):
+        gather.split_own(slot)
+        cnts, hits = [], []
+        for r, (a, b) in enumerate(shard_len):
+            c, h = gdist.expand_split_results(gather.root_ids[slot][r], gather.root_pos[slot][r], parts[1][r], parts[2][r],
+                                              parts[3][r], parts[4][r], b - a)
+            if h.shape[0] != sizes[r]:
+                raise SystemExit(f"PARITY FAILURE: shard {r} arrived with {h.shape[0]} hits, its rank located {sizes[r]}")
+            cnts.append(c)
+            hits.append(h)
+        return torch.cat(cnts), torch.cat(hits)
+    cnt_cat = torch.cat([parts[0][r][: b - a] for r, (a, b) in enumerate(shard_len)])
+    if do_locate and getattr(gather, "hits_are_split", False):  # (text ids as bytes, positions as int32: back to pairs)
+        hit_cat = torch.cat([torch.stack([parts[1][r][: sizes[r]].to(torch.int32), parts[2][r][: sizes[r]]], dim=1)
+                             for r in range(world)])
+    else:
+        hit_cat = torch.cat([parts[1][r][: sizes[r]] for r in range(world)]) if do_locate else None
+    return cnt_cat, hit_cat
+
+
 def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate, args, rank, world, dev):
     """BASELINE.json configs[3]: the N = 1 batch (seed 43) split into `world` contiguous shards (dist.shard_range), one
     per rank, results gathered to rank 0; value = nq_total / max-over-ranks step time.  Rank 0 also runs the whole
@@ -923,14 +1011,9 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
     # bit-exactness: concatenated shards == the one-rank output
     sizes = gdist.gather_ints(runner.total_hits, dev)
     if rank == 0:
-        parts = gather.gathered(last)
         shard_len = [gdist.shard_range(nq_total, r, world) for r in range(world)]
-        cnt_cat = torch.cat([parts[0][r][: b - a] for r, (a, b) in enumerate(shard_len)])
-        if do_locate and getattr(gather, "hits_are_split", False):  # (text ids as bytes, positions as int32: back to pairs)
-            hit_cat = torch.cat([torch.stack([parts[1][r][: sizes[r]].to(torch.int32), parts[2][r][: sizes[r]]], dim=1)
-                                 for r in range(world)])
-        else:
-            hit_cat = torch.cat([parts[1][r][: sizes[r]] for r in range(world)]) if do_locate else None
+        cnt_cat, hit_cat = gathered_shards(torch, gdist, gather, last, shard_len, sizes, do_locate)
+        res["gather_wire"] = "compact" if getattr(gather, "compact_wire", False) else "arrays"
         del gather, runner
         torch.cuda.empty_cache()
         single = StepRunner(torch, eng, full, nq_total, do_locate, args.path, hint=not args.no_hint)

@@ -214,6 +214,16 @@ extern "C" {
         ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, d_out_counts: *mut c_void,
         d_out_status: *mut c_void, stream: *mut c_void,
     ) -> c_int;
+    /// compact results as text id bytes + positions in the text (-1 none, -2 see the record): the multi-GPU gather's form
+    pub fn gdx_compact_split_hits_dev(
+        ix: *const gdx_index_t, d_compact: *const c_void, nq: u64, d_out_text_ids: *mut c_void, d_out_positions: *mut c_void,
+        stream: *mut c_void,
+    ) -> c_int;
+    /// the queries whose compact result says "see the record" (unordered, up to `capacity`); *d_out_n (u64) = all of them
+    pub fn gdx_compact_exceptions_dev(
+        ix: *const gdx_index_t, d_compact: *const c_void, nq: u64, d_out_queries: *mut c_void, capacity: u64,
+        d_out_n: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
     // several GPUs of one node behind one handle
     pub fn gdx_multi_build(
         texts_buf: *const u8, text_offsets: *const u64, n_texts: u64, io_to_dense: *const u8, sigma: c_int,

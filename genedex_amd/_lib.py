@@ -171,6 +171,8 @@ SIGNATURES = {
     "gdx_locate_many_offsets_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp],
     "gdx_locate_many_hits_compact_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_unpack_compact_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_compact_split_hits_dev": [vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_compact_exceptions_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp],
     "gdx_locate_many_totals_workspace_bytes": [C.c_uint64],
     "gdx_locate_many_totals_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     "gdx_locate_many_offsets_hits_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp],

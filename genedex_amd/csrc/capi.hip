@@ -1098,6 +1098,44 @@ int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_reco
     });
 }
 
+int gdx_compact_split_hits_dev(const gdx_index_t *ix, const void *d_compact, uint64_t nq, void *d_out_text_ids,
+                               void *d_out_positions, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (d_compact == nullptr || d_out_text_ids == nullptr || d_out_positions == nullptr)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_compact_split_hits_dev: null buffer");
+        if ((reinterpret_cast<uintptr_t>(d_compact) | reinterpret_cast<uintptr_t>(d_out_positions)) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(d_out_text_ids) % 4 != 0)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_compact_split_hits_dev: buffers must be 16-byte (text ids: 4-byte) aligned");
+        if (f.view().n_texts > 256u)
+            gdx::fail(GDX_ERR_UNSUPPORTED, "gdx_compact_split_hits_dev: text ids as bytes need a collection of at most 256 texts");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_compact_split(f.view(), static_cast<const uint32_t *>(d_compact), nq, static_cast<uint8_t *>(d_out_text_ids),
+                                  static_cast<int32_t *>(d_out_positions), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_compact_exceptions_dev(const gdx_index_t *ix, const void *d_compact, uint64_t nq, void *d_out_queries,
+                               uint64_t capacity, void *d_out_n, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (d_compact == nullptr || d_out_n == nullptr || (d_out_queries == nullptr && capacity != 0))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_compact_exceptions_dev: null buffer");
+        if (reinterpret_cast<uintptr_t>(d_compact) % 16 != 0 || reinterpret_cast<uintptr_t>(d_out_n) % 8 != 0)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_compact_exceptions_dev: d_compact must be 16-byte, d_out_n 8-byte aligned");
+        if (nq > 0xffffffffull) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_compact_exceptions_dev: more than 2^32 - 1 queries");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_compact_exceptions(static_cast<const uint32_t *>(d_compact), nq, static_cast<uint32_t *>(d_out_queries),
+                                       capacity, static_cast<unsigned long long *>(d_out_n), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 // ---- packed queries ------------------------------------------------------------------------------------
 
 uint64_t gdx_packed_bytes(uint64_t n_symbols) { return (n_symbols + 3) / 4 / 8 * 8 + 16; }

@@ -130,6 +130,12 @@ void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offs
 // counts (end - start) and status bytes out of search records
 void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream,
                            const uint32_t *d_compact = nullptr);
+// compact results -> text id bytes and positions in the text (-1 none, -2 see the exceptions); at most 256 texts
+void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64_t m, uint8_t *d_ids, int32_t *d_pos,
+                          hipStream_t stream);
+// the queries whose compact result says "see the record": unordered list (up to `capacity`), *d_n = how many there are
+void launch_compact_exceptions(const uint32_t *d_compact, uint64_t m, uint32_t *d_list, uint64_t capacity,
+                               unsigned long long *d_n, hipStream_t stream);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,

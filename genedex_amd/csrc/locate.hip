@@ -1015,7 +1015,104 @@ __global__ __launch_bounds__(kBlock) void unpack_records_kernel(const uint4 *__r
         if (status) status[q] = static_cast<uint8_t>(r.w >> 24);
     }
 }
+
+// compact results as they travel between devices (one u32 per query, gdx_compact_split_hits_dev): text id byte and
+// position in that text of the only hit, position -1 = no occurrence, -2 = "see the exceptions".  Four queries per thread:
+// one 16-byte load, one 4-byte and one 16-byte store.
+__global__ __launch_bounds__(kBlock) void compact_split_kernel(const uint32_t *__restrict__ compact, uint64_t m,
+                                                               const uint32_t *__restrict__ sentinels, uint32_t n_texts,
+                                                               uint8_t *__restrict__ ids, int32_t *__restrict__ pos)
+{
+    __shared__ uint32_t s_sent[256];
+    for (uint32_t i = threadIdx.x; i < n_texts; i += kBlock) s_sent[i] = sentinels[i];
+    __syncthreads();
+    auto split = [&](uint32_t c4, uint32_t &id, int32_t &p) {
+        id = 0u;
+        p = c4 == kCompactNone ? -1 : -2;
+        if (c4 < kCompactSee) {
+            id = lower_bound_u32(s_sent, n_texts, c4);
+            p = static_cast<int32_t>(id == 0u ? c4 : c4 - s_sent[id - 1u] - 1u);
+        }
+    };
+    const uint64_t quads = m / 4u;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < quads; i += stride) {
+        const u32x4 c = reinterpret_cast<const u32x4 *>(compact)[i];
+        uint32_t i0, i1, i2, i3;
+        int32_t p0, p1, p2, p3;
+        split(c.x, i0, p0);
+        split(c.y, i1, p1);
+        split(c.z, i2, p2);
+        split(c.w, i3, p3);
+        reinterpret_cast<uint32_t *>(ids)[i] = i0 | (i1 << 8) | (i2 << 16) | (i3 << 24);
+        reinterpret_cast<int4 *>(pos)[i] = make_int4(p0, p1, p2, p3);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < m - quads * 4u) {
+        const uint64_t q = quads * 4u + threadIdx.x;
+        uint32_t id;
+        int32_t p;
+        split(compact[q], id, p);
+        ids[q] = static_cast<uint8_t>(id);
+        pos[q] = p;
+    }
+}
+
+// the queries whose compact result says "see the record", listed in no particular order (the caller sorts the few there
+// are); *n counts all of them, whatever the list holds.  Four queries per thread, one atomic per wavefront that has any.
+__global__ __launch_bounds__(kBlock) void compact_exceptions_kernel(const uint32_t *__restrict__ compact, uint64_t m,
+                                                                    uint32_t *__restrict__ list, uint64_t capacity,
+                                                                    unsigned long long *__restrict__ n)
+{
+    const uint64_t quads = (m + 3u) / 4u;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t i0 = static_cast<uint64_t>(blockIdx.x) * kBlock; i0 < quads; i0 += stride) {  // (block-uniform trip count)
+        const uint64_t i = i0 + threadIdx.x;
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (i < quads) {
+            if (i * 4u + 4u <= m) {
+                const u32x4 v = reinterpret_cast<const u32x4 *>(compact)[i];
+                c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w;
+            } else {
+                for (uint32_t k = 0; i * 4u + k < m; k++) c[k] = compact[i * 4u + k];
+            }
+        }
+        const uint32_t mine = (c[0] == kCompactSee) + (c[1] == kCompactSee) + (c[2] == kCompactSee) + (c[3] == kCompactSee);
+        if (__ballot(mine != 0u) == 0ull) continue;
+        uint32_t incl = mine;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        unsigned long long base = 0;
+        if (lane == 63u) base = atomicAdd(n, static_cast<unsigned long long>(incl));
+        base = __shfl(base, 63);
+        uint64_t at = base + incl - mine;
+        for (uint32_t k = 0; k < 4u; k++)
+            if (c[k] == kCompactSee) {
+                if (at < capacity) list[at] = static_cast<uint32_t>(i * 4u + k);
+                at++;
+            }
+    }
+}
 }  // namespace
+
+void launch_compact_exceptions(const uint32_t *d_compact, uint64_t m, uint32_t *d_list, uint64_t capacity,
+                               unsigned long long *d_n, hipStream_t stream)
+{
+    GDX_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), stream));
+    if (m == 0) return;
+    hipLaunchKernelGGL(compact_exceptions_kernel, dim3(grid_for_items((m + 3) / 4)), dim3(kBlock), 0, stream, d_compact, m,
+                       d_list, capacity, d_n);
+}
+
+void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64_t m, uint8_t *d_ids, int32_t *d_pos,
+                          hipStream_t stream)
+{
+    if (m == 0) return;
+    hipLaunchKernelGGL(compact_split_kernel, dim3(grid_for_items((m + 3) / 4)), dim3(kBlock), 0, stream, d_compact, m,
+                       ix.sentinels, ix.n_texts, d_ids, d_pos);
+}
 
 size_t count_offsets_temp_bytes(uint64_t m)
 {

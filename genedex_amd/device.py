@@ -233,6 +233,17 @@ class DeviceEngine:
                                                        _ptr(counts) if counts is not None else None,
                                                        _ptr(status) if status is not None else None, _stream()))
 
+    def compact_split_hits(self, compact: torch.Tensor, nq: int, text_ids: torch.Tensor, positions: torch.Tensor) -> None:
+        """gdx_compact_split_hits_dev: compact results -> uint8 text ids + int32 positions in the text (-1 none, -2 see the
+        record); what the root of a multi-GPU gather turns a received shard into"""
+        _lib.check(self.lib.gdx_compact_split_hits_dev(self.h, _ptr(compact), nq, _ptr(text_ids), _ptr(positions), _stream()))
+
+    def compact_exceptions(self, compact: torch.Tensor, nq: int, queries: torch.Tensor, n: torch.Tensor) -> None:
+        """gdx_compact_exceptions_dev: the queries that say "see the record" into `queries` (int32 / uint32 view, unordered, as
+        many as it holds); n (int64[1]) = how many there are"""
+        _lib.check(self.lib.gdx_compact_exceptions_dev(self.h, _ptr(compact), nq, _ptr(queries), queries.numel(), _ptr(n),
+                                                       _stream()))
+
     # ---- batched cursor extension by strings (gdx_cursor_extend_front_strings_dev) ------------------------
     def cursor_extend_strings(self, start, end, qbuf, qbeg, qend, m, status=None, active_in=None, n_active_in=None,
                               active_out=None, n_active_out=None) -> None:

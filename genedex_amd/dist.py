@@ -81,10 +81,13 @@ class PipelinedGather:
     (`max_rows`), so no size exchange happens inside the timed loop.
     """
 
-    def __init__(self, slots, dst: int = 0):
+    def __init__(self, slots, dst: int = 0, on_gathered=None):
         # slots: list (one per slot) of lists of tensors; same shapes/dtypes on every rank
+        # on_gathered(slot): called on dst, from acquire(), once the slot's gather has arrived and before its receive
+        # buffers can be written again (what dst does with a received batch, e.g. GPU kernels enqueued behind the gather)
         self.slots = slots
         self.dst = dst
+        self.on_gathered = on_gathered
         self.rank, self.world = world()
         self.pending = [[] for _ in slots]
         self.recv = None
@@ -92,9 +95,12 @@ class PipelinedGather:
             self.recv = [[[torch.empty_like(t) for _ in range(self.world)] for t in slot] for slot in slots]
 
     def acquire(self, slot: int) -> None:
+        arrived = bool(self.pending[slot])
         for w in self.pending[slot]:
             w.wait()
         self.pending[slot] = []
+        if arrived and self.on_gathered is not None and self.rank == self.dst:
+            self.on_gathered(slot)
 
     def submit(self, slot: int) -> None:
         if self.world == 1:
@@ -110,6 +116,94 @@ class PipelinedGather:
     def gathered(self, slot: int):
         """On dst: per tensor of the slot the list of world tensors (after acquire/drain)."""
         return self.recv[slot] if self.recv is not None else [[t] for t in self.slots[slot]]
+
+
+# ---- compact results on the wire --------------------------------------------------------------------------------------
+# A count + locate shard travels to the root as the search's compact results -- one 32-bit word per query: the text position
+# of its only hit, COMPACT_NONE, or COMPACT_SEE (gdx.h, gdx_locate_many_search_compact_dev) -- plus, for the queries that
+# say COMPACT_SEE, their counts and hits ("exceptions", in query order).  4 bytes per query on a text without repeats
+# instead of a count byte and 5 bytes per hit; the root turns the words into text id + position with one kernel
+# (gdx_compact_split_hits_dev).  The functions below are the tensor plumbing around that; they run on any device.
+COMPACT_NONE = -1  # (the int32 views of 0xffffffff / 0xfffffffe)
+COMPACT_SEE = -2
+
+
+def exception_sizes(compact: torch.Tensor, hit_offsets: torch.Tensor, nq: int):
+    """(number of queries that say COMPACT_SEE, number of their hits); synchronises -- for sizing the buffers"""
+    if nq == 0:
+        return 0, 0
+    see = compact[:nq] == COMPACT_SEE
+    cnt = hit_offsets[1:nq + 1] - hit_offsets[:nq]
+    return int(see.sum().item()), int((cnt * see).sum().item())
+
+
+def pack_exceptions(compact: torch.Tensor, hit_offsets: torch.Tensor, hits: torch.Tensor, nq: int, exc_cnt: torch.Tensor,
+                    exc_ids: torch.Tensor, exc_pos: torch.Tensor, meta: torch.Tensor, listed=None) -> None:
+    """Counts (exc_cnt, int32[cap_q]) and hits (exc_ids uint8[cap_h], exc_pos int32[cap_h]) of the queries whose compact
+    result says COMPACT_SEE, in query order; meta (int32[2]) = their true numbers (what exceeds a capacity is dropped and
+    shows there).  Fixed shapes, no host synchronisation.
+    listed = (queries int32[cap_q] in any order, n int64[1]): the list gdx_compact_exceptions_dev made (DeviceEngine.
+    compact_exceptions) -- one streaming pass instead of the mask / select passes of the tensor library."""
+    cap_q, cap_h = exc_cnt.numel(), exc_ids.numel()
+    dev = compact.device
+    if listed is not None:
+        queries, n_listed = listed
+        valid = torch.arange(cap_q, device=dev) < n_listed
+        eq = torch.sort(torch.where(valid, queries.to(torch.int64) & 0xffffffff, nq))[0]
+        n_see = n_listed[0]
+    else:
+        see = compact[:nq] == COMPACT_SEE
+        eq = torch.nonzero_static(see, size=cap_q, fill_value=nq)[:, 0]  # (padding: query nq, whose count comes out as 0)
+        n_see = see.sum()
+    lo = hit_offsets[eq.clamp(max=nq)]
+    cnt = hit_offsets[(eq + 1).clamp(max=nq)] - lo
+    exc_cnt.copy_(cnt)
+    fits = torch.cumsum(cnt, 0) <= cap_h
+    kept = cnt * fits
+    csum = torch.cumsum(kept, 0)
+    n_kept = csum[-1:]
+    rep = torch.cat([kept, cap_h - n_kept])  # (one more bucket takes the unused tail of the buffers)
+    which = torch.repeat_interleave(torch.arange(cap_q + 1, device=dev), rep, output_size=cap_h)
+    lo_ext = torch.cat([lo, lo.new_zeros(1)])
+    first = torch.cat([csum - kept, n_kept])
+    src = lo_ext[which] + (torch.arange(cap_h, device=dev) - first[which])
+    src = src.clamp_(min=0, max=hits.shape[0] - 1)
+    exc_ids.copy_(hits[src, 0])
+    exc_pos.copy_(hits[src, 1])
+    meta[0] = n_see
+    meta[1] = cnt.sum()
+
+
+def expand_split_results(ids: torch.Tensor, pos: torch.Tensor, exc_cnt: torch.Tensor, exc_ids: torch.Tensor,
+                         exc_pos: torch.Tensor, meta: torch.Tensor, nq: int):
+    """One gathered shard -- per-query text id / position (-1 none, -2 exception) and its exceptions -- in the form a
+    one-rank run produces: (counts int64[nq], hits int32[total, 2]).  For checks; synchronises."""
+    n_exc, n_exc_hits = int(meta[0].item()), int(meta[1].item())
+    if n_exc > exc_cnt.numel() or n_exc_hits > exc_ids.numel():
+        raise ValueError(f"exceptions ({n_exc} queries, {n_exc_hits} hits) exceed the buffers they travel in "
+                         f"({exc_cnt.numel()}, {exc_ids.numel()})")
+    dev = pos.device
+    p = pos[:nq].to(torch.int64)
+    see = p == COMPACT_SEE
+    if int(see.sum().item()) != n_exc:
+        raise ValueError("the number of exceptions differs from the number of queries that point to them")
+    cnt = (p >= 0).to(torch.int64)
+    e_cnt = exc_cnt[:n_exc].to(torch.int64)
+    cnt[see] = e_cnt
+    total = int(cnt.sum().item())
+    off = torch.cumsum(cnt, 0) - cnt
+    hq = torch.repeat_interleave(torch.arange(nq, device=dev), cnt, output_size=total)  # the query of every hit
+    h_id = ids[:nq][hq].to(torch.int32)
+    h_pos = pos[:nq][hq].to(torch.int32)
+    if n_exc:
+        is_exc = see[hq]
+        e_rank = torch.cumsum(see.to(torch.int64), 0) - 1
+        e_off = torch.cumsum(e_cnt, 0) - e_cnt
+        within = torch.arange(total, device=dev) - off[hq]
+        src = (e_off[e_rank[hq].clamp(min=0)] + within).clamp(min=0, max=max(n_exc_hits - 1, 0))
+        h_id = torch.where(is_exc, exc_ids[src].to(torch.int32), h_id)
+        h_pos = torch.where(is_exc, exc_pos[src].to(torch.int32), h_pos)
+    return cnt, torch.stack([h_id, h_pos], dim=1)
 
 
 def max_int_over_ranks(value: int, device) -> int:

@@ -420,6 +420,19 @@ int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_record
                                      const void *d_hit_offsets, uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
                                        void *d_out_counts, void *d_out_status, void *stream);
+/* Compact results in the form they travel in between devices (the multi-GPU gather): per query one
+ * text id byte and one int32 -- the position in that text of the query's only hit (lib.rs:155-185 Hit { text_id, position }),
+ * -1 = no occurrence, -2 = "see the record" (the sender ships those queries' counts and hits beside).  5 bytes per query on
+ * the receiving side from 4 on the wire.  Collections of at most 256 texts (else GDX_ERR_UNSUPPORTED); d_compact and
+ * d_out_positions 16-byte aligned, d_out_text_ids 4-byte aligned. */
+int gdx_compact_split_hits_dev(const gdx_index_t *ix, const void *d_compact, uint64_t nq, void *d_out_text_ids,
+                               void *d_out_positions, void *stream);
+/* The queries whose compact result says "see the record": their numbers (u32) into d_out_queries in NO particular order, as
+ * many as `capacity` holds; *d_out_n (u64, device) = how many there are in all.  One streaming pass over d_compact (16-byte
+ * aligned).  The sender of the multi-GPU gather lists its exceptions with this (on a text without repeats a few in a
+ * million queries) and sorts them. */
+int gdx_compact_exceptions_dev(const gdx_index_t *ix, const void *d_compact, uint64_t nq, void *d_out_queries,
+                               uint64_t capacity, void *d_out_n, void *stream);
 /* Offsets and hits in two calls around the ONE host round trip of a count + locate step (instead of offsets, round trip,
  * hits): gdx_locate_many_totals_compact_dev sums the counts -- d_totals (u64[2], device) = {all hit slots, the slots of the
  * queries whose compact result says "see the record"} -- and leaves the bases of its tiles in d_scan_workspace

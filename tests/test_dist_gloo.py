@@ -73,6 +73,56 @@ def _worker(rank, world, port, result_path):
                 pipelined_ok &= bool((got[0][r][: rhi - rlo] >= step).all())
             pipelined_ok &= torch.equal(got[1][0][: hits.shape[0]], hits)
             pipelined_ok &= torch.equal(got[2][0][: counts.numel()].to(torch.int64), torch.clamp(counts, max=255))
+    # the compact wire (bench.py make_compact_gather): one word per query -- the position of its only hit in the concatenated
+    # texts, none, or "see the exceptions" -- plus counts and hits of the exceptions; the root splits the words into text id +
+    # position (gdx_compact_split_hits_dev on the GPU; restated with numpy here) when the gather is acquired
+    starts = np.concatenate([[0], np.cumsum([len(x) + 1 for x in texts])]).astype(np.int64)
+    n_shard = hi - lo
+    cnt_np = (e - s).astype(np.int64)
+    words = np.full(n_shard, gdist.COMPACT_SEE, dtype=np.int32)
+    words[cnt_np == 0] = gdist.COMPACT_NONE
+    single = np.flatnonzero((cnt_np == 1) & (np.arange(n_shard) % 7 != 0))  # (some single hits travel as exceptions too)
+    words[single] = (starts[t[off[single]].astype(np.int64)] + p[off[single]].astype(np.int64)).astype(np.int32)
+    hits32 = torch.from_numpy(np.stack([t.astype(np.int32), p.astype(np.int32)], axis=1))
+    n_exc, n_exc_hits = gdist.exception_sizes(torch.from_numpy(words), torch.from_numpy(off.astype(np.int64)), n_shard)
+    cpu = torch.device("cpu")
+    cap_q, cap_h = gdist.max_int_over_ranks(n_exc, cpu), gdist.max_int_over_ranks(n_exc_hits, cpu)
+    n_max = nq // world + 1
+    cslots = [[torch.full((n_max,), -1, dtype=torch.int32), torch.zeros(cap_q, dtype=torch.int32),
+               torch.zeros(cap_h, dtype=torch.uint8), torch.zeros(cap_h, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)]
+              for _ in range(2)]
+    split = [[None] * world for _ in range(2)]
+    arrivals = []
+
+    def on_gathered(slot):
+        arrivals.append(slot)
+        for r, w in enumerate(cg.gathered(slot)[0]):
+            w = w.numpy().astype(np.int64)
+            tid = np.searchsorted(starts[1:] - 1, np.maximum(w, 0), side="left")  # the sentinel at or after the position
+            inside = np.where(w >= 0, w - starts[np.minimum(tid, len(texts) - 1)], w)
+            split[slot][r] = (torch.from_numpy(np.where(w >= 0, tid, 0).astype(np.uint8)), torch.from_numpy(inside.astype(np.int32)))
+
+    cg = gdist.PipelinedGather(cslots, dst=0, on_gathered=on_gathered)
+    for step in range(3):
+        slot = step % 2
+        cg.acquire(slot)
+        cslots[slot][0][:n_shard] = torch.from_numpy(words)
+        gdist.pack_exceptions(cslots[slot][0], torch.from_numpy(off.astype(np.int64)), hits32, n_shard, *cslots[slot][1:])
+        cg.submit(slot)
+    cg.drain()
+    compact_ok = True
+    if rank == 0:
+        compact_ok = sorted(arrivals) == [0, 0, 1]
+        c_cnt, c_hits = [], []
+        for r in range(world):
+            rlo, rhi = gdist.shard_range(nq, r, world)
+            got = cg.gathered(0)
+            cc, hh = gdist.expand_split_results(split[0][r][0], split[0][r][1], got[1][r], got[2][r], got[3][r], got[4][r], rhi - rlo)
+            c_cnt.append(cc)
+            c_hits.append(hh)
+        c_cnt, c_hits = torch.cat(c_cnt).numpy(), torch.cat(c_hits).numpy()
+    else:
+        compact_ok = arrivals == []
     fixed = gdist.gather_fixed(torch.tensor([rank, hi - lo]), dst=0)
     tmax = gdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     ints_ok = gdist.gather_ints(10 + rank, torch.device("cpu")) == [10, 11]
@@ -84,7 +134,9 @@ def _worker(rank, world, port, result_path):
         foff, ft, fp = replica.locate_intervals(fs, fe)
         ok = (np.array_equal(all_counts, (fe - fs).astype(np.int64))
               and np.array_equal(all_hits[:, 0], ft.astype(np.int64)) and np.array_equal(all_hits[:, 1], fp.astype(np.int64))
-              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok and ints_ok)
+              and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok and ints_ok
+              and compact_ok and np.array_equal(c_cnt, (fe - fs).astype(np.int64))
+              and np.array_equal(c_hits[:, 0], ft.astype(np.int32)) and np.array_equal(c_hits[:, 1], fp.astype(np.int32)))
         open(result_path, "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
 
@@ -105,3 +157,34 @@ def test_shard_ranges_partition_the_batch():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_exceptions_beyond_their_buffers_are_noticed():
+    """pack_exceptions never writes past a capacity; the true numbers travel in `meta` and the receiving side refuses"""
+    import pytest
+
+    from genedex_amd import dist as gdist
+
+    words = torch.tensor([5, -2, -1, -2, -2], dtype=torch.int32)
+    off = torch.tensor([0, 1, 3, 3, 6, 7], dtype=torch.int64)
+    hits = torch.arange(14, dtype=torch.int32).reshape(7, 2)
+    exc_cnt, exc_ids, exc_pos = torch.zeros(3, dtype=torch.int32), torch.zeros(4, dtype=torch.uint8), torch.zeros(4, dtype=torch.int32)
+    meta = torch.zeros(2, dtype=torch.int32)
+    gdist.pack_exceptions(words, off, hits, 5, exc_cnt, exc_ids, exc_pos, meta)
+    assert meta.tolist() == [3, 6] and exc_cnt.tolist() == [2, 3, 1]
+    assert exc_ids[:2].tolist() == [2, 4] and exc_pos[:2].tolist() == [3, 5]  # what fits whole is there
+    ids, pos = torch.zeros(5, dtype=torch.uint8), torch.tensor([1, -2, -1, -2, -2], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        gdist.expand_split_results(ids, pos, exc_cnt, exc_ids, exc_pos, meta, 5)
+    big_ids, big_pos = torch.zeros(6, dtype=torch.uint8), torch.zeros(6, dtype=torch.int32)
+    gdist.pack_exceptions(words, off, hits, 5, exc_cnt, big_ids, big_pos, meta)
+    cnt, hh = gdist.expand_split_results(ids, pos, exc_cnt, big_ids, big_pos, meta, 5)
+    assert cnt.tolist() == [1, 2, 0, 3, 1]
+    assert hh.tolist() == [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10, 11], [12, 13]]
+    # the same from a list of the exceptions in any order (what gdx_compact_exceptions_dev hands over), longer than needed
+    exc_cnt4 = torch.zeros(4, dtype=torch.int32)
+    listed = (torch.tensor([4, 1, 3, 99], dtype=torch.int32), torch.tensor([3], dtype=torch.int64))
+    gdist.pack_exceptions(words, off, hits, 5, exc_cnt4, big_ids, big_pos, meta, listed)
+    assert meta.tolist() == [3, 6] and exc_cnt4.tolist() == [2, 3, 1, 0]
+    cnt, hh2 = gdist.expand_split_results(ids, pos, exc_cnt4, big_ids, big_pos, meta, 5)
+    assert cnt.tolist() == [1, 2, 0, 3, 1] and hh2.tolist() == hh.tolist()

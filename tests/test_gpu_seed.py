@@ -216,6 +216,64 @@ def test_seed_intervals_hand_the_fast_kernel_their_state(copies, wide):
         assert counts.tolist() == np.diff(want[0]).astype(np.uint32).tolist()
 
 
+@pytest.mark.parametrize("n_texts", [1, 5, 200])
+def test_compact_results_split_into_text_id_and_position(n_texts):
+    """gdx_compact_split_hits_dev (the receiving side of the multi-GPU gather): every compactly answered query's word becomes
+    the text id and position of its only hit -- the oracle's -- "none" becomes -1, "see the record" -2."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(9800 + n_texts)
+    texts = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(30, 4000 // max(n_texts // 20, 1))))) for _ in range(n_texts)]
+    texts[0] = texts[0] + texts[0][-40:]  # (a repeat: reads from it say "see the record")
+    a = alph.ascii_dna()
+    g = gpu_index(texts, a, seed_symbols=10)
+    c = cpu_index(texts, a)
+    qs = mixed_queries(rng, texts, 801, 200, 60) + [texts[0][-30:], b"ACGTTGCATTTAGGACCA"]
+    co, ct, cp = c.locate_many(qs)
+    eng = DeviceEngine(g)
+    dq = DeviceQueries.from_host(*pack_queries(qs))
+    rec, cmp_ = eng.alloc_records(dq.nq), eng.alloc_compact(dq.nq)
+    eng.locate_search(dq, rec, compact=cmp_)
+    ids = torch.full((dq.nq,), 77, dtype=torch.uint8, device="cuda")
+    pos = torch.full((dq.nq,), 77, dtype=torch.int32, device="cuda")
+    eng.compact_split_hits(cmp_, dq.nq, ids, pos)
+    torch.cuda.synchronize()
+    words, ids, pos = cmp_[:dq.nq].cpu().numpy(), ids.cpu().numpy(), pos.cpu().numpy()
+    counts = np.diff(co)
+    answered = 0
+    for q in range(dq.nq):
+        if words[q] == -2:
+            assert pos[q] == -2 and ids[q] == 0
+        elif words[q] == -1:
+            assert counts[q] == 0 and pos[q] == -1 and ids[q] == 0
+        else:
+            assert counts[q] == 1 and (int(ids[q]), int(pos[q])) == (int(ct[co[q]]), int(cp[co[q]])), q
+            answered += 1
+    assert answered > dq.nq // 4 and (words == -2).any()
+    # gdx_compact_exceptions_dev: the queries that say "see the record", in any order; a list too short still counts them all
+    want = np.flatnonzero(words == -2)
+    for cap in (len(want) + 3, max(len(want) // 2, 1)):
+        listed = torch.full((cap,), -5, dtype=torch.int32, device="cuda")
+        n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        eng.compact_exceptions(cmp_, dq.nq, listed, n)
+        torch.cuda.synchronize()
+        assert int(n.item()) == len(want)
+        got = listed.cpu().numpy()[: min(cap, len(want))]
+        assert len(set(got.tolist())) == len(got) and set(got.tolist()) <= set(want.tolist())
+        if cap >= len(want):
+            assert sorted(got.tolist()) == want.tolist() and (listed.cpu().numpy()[len(want):] == -5).all()
+    if n_texts <= 5:
+        return
+    # more than 256 texts: text ids do not fit a byte
+    many = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, 20)) for _ in range(257)]
+    g2 = gpu_index(many, a, seed_symbols=8)
+    eng2 = DeviceEngine(g2)
+    with pytest.raises(Exception, match="256 texts"):
+        eng2.compact_split_hits(cmp_, 4, torch.zeros(4, dtype=torch.uint8, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
+
+
 def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()
