@@ -23,4 +23,6 @@ python3 tools/exp_general.py 3 seed_symbols=1 inverse_suffix_array=1 aux_budget_
 python3 tools/exp_seed.py 3 > $OUT/exp_seed_final.json 2> /dev/null
 python3 tests/parity_sweep.py 300 21 > $OUT/parity_sweep_seed21.json 2> $OUT/parity21.err
 bash tools/pmc_seed.sh $1/pmc_seed_kernel > /dev/null 2>&1
+python3 tools/exp_gather_pack.py 5 > $OUT/exp_gather_pack.json 2> /dev/null
+bash tools/trace_exp.sh $1/genome_like_trace tools/exp_genome_like.py seed_symbols=1 aux_budget_bytes=250000000000 full_sa=1 > /dev/null 2>&1
 tail -3 $OUT/gpu_tests_final.log; tail -c 400 $OUT/parity_sweep_seed21.json; echo; cat $OUT/bench_hg38_final_kernel_stats.md | head -12
