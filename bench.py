@@ -8,15 +8,19 @@ is built on the GPU before the timed region and is not timed.
 
     python bench.py --gpus N --steps K --warmup W [--workload hg38|mixed|cfg2|small] [--op count+locate|count]
 
-For N > 1 launch one rank per GPU with torch.distributed.run; the index is replicated, every rank searches its own
-batch of nq queries (weak scaling: `value`), results are gathered to rank 0 over RCCL; the same run then shards ONE
-batch of nq queries over the ranks (BASELINE.json configs[3]: `strong_scaling`).  Rank 0 prints ONE JSON line.
-Everything else goes to stderr.
+For N > 1 launch one rank per GPU with torch.distributed.run; the index is replicated and results are gathered to rank 0
+over RCCL.  The run first gives every rank its own batch of nq queries (`weak_scaling`), then shards ONE batch of nq
+queries over the ranks -- BASELINE.json configs[3], which is what `value`, `ms_per_step` and `config.workload` report at
+N > 1 (`scaling: "strong"`).  Rank 0 prints ONE JSON line of less than 4 KB (the contract's keys, `roofline`,
+`cpu_baseline`); every other measurement (ladder, secondaries, end to end, bandwidths) goes to --side-file
+(gpurun_out/bench_secondary.json) and to stderr.
 
 Roofline (N = 1): `roofline.traffic` = HBM bytes of the dominant kernel per launch, measured by rocprofv3 PMC passes
 of this very workload that bench.py itself starts as child processes BEFORE it touches the GPU (FETCH_SIZE and
 WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); `roofline.frac` =
-traffic / live HIP-event duration / 8 TB/s, at most 1 by construction.  The ratio of the reference algorithm's
+traffic / live HIP-event duration / 8 TB/s, at most 1 by construction; `roofline.frac_rocprof` = the same traffic over
+rocprofv3's own average duration of the kernels in a `--kernel-trace --stats` child pass of the same workload (its
+kernel_stats.csv is kept beside the side file: the summary under profiles/ is that file).  The ratio of the reference algorithm's
 logical bytes to the time is reported separately as `algorithmic_ratio`.
 """
 from __future__ import annotations
@@ -105,6 +109,10 @@ def parse_args():
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child-steps", type=int, default=2, help=argparse.SUPPRESS)
+    ap.add_argument("--side-file", default=os.environ.get("GDX_BENCH_SIDE_FILE", os.path.join("gpurun_out", "bench_secondary.json")),
+                    help="where everything beside the contract line goes (secondaries, ladder, end-to-end, bandwidths, notes): "
+                         "the one stdout line stays below 4 KB")
     args = ap.parse_args()
     explicit = (args.jump_bytes is not None or args.top_depth is not None or args.no_pair_lines or args.full_sa or args.text_units)
     if explicit:  # hand-picked structures (ladder rungs of the PMC children, experiments)
@@ -123,7 +131,12 @@ PMC_PASSES = [
     ("requests", ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_REQ_sum", "TCC_HIT_sum"]),
     ("fetch", ["FETCH_SIZE"]),
     ("write", ["WRITE_SIZE"]),
+    # no counters: rocprofv3's own kernel durations of the same child workload (`--kernel-trace --stats`), so that the time
+    # under the traffic can be the profiler's as well as this process's HIP events (roofline.avg_launch_ms_rocprof)
+    ("kernel_trace", None),
 ]
+KERNEL_REGEX = ("search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
+                "search_kernel|search_verify_kernel|search_exact_kernel")
 
 
 def pmc_child(args):
@@ -147,13 +160,53 @@ def pmc_child(args):
     eng = DeviceEngine(index)
     runner = StepRunner(torch, eng, queries, nq, args.op == "count+locate", args.path, hint=not args.no_hint)
     runner.size()
-    for _ in range(2):
+    for _ in range(args.pmc_child_steps):
         runner.step(0, False)
     torch.cuda.synchronize()
     print(json.dumps({"pmc_child": True, "nq": nq, "hits": runner.total_hits}), flush=True)
 
 
-def run_live_pmc(args, reference_layout=False, rung=None):
+def read_kernel_stats(path, out, keep=None):
+    """rocprofv3's kernel_stats.csv -> out[kernel short name]["rocprof_avg_ms"] (+ launches); `keep`: copy the file there"""
+    import re
+
+    agg = {}
+    for row in csv.DictReader(open(path)):
+        name = row.get("Name") or row.get("Kernel_Name") or ""
+        if not re.search(KERNEL_REGEX, name):
+            continue
+        a = agg.setdefault(short_kernel_name(name), [0, 0.0])
+        a[0] += int(float(row["Calls"]))
+        a[1] += float(row["TotalDurationNs"])
+    for kern, (calls, total_ns) in agg.items():
+        if calls:
+            out.setdefault(kern, {})["rocprof"] = {"avg_ms": total_ns / calls / 1e6, "launches": calls}
+    if keep:
+        try:
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            shutil.copyfile(path, keep)
+        except OSError:
+            pass
+
+
+def rocprof_ms_of(pmc, pattern):
+    """sum of rocprofv3's average durations (ms) of the kernels `pattern` names ('|'-separated), or None"""
+    if not pmc:
+        return None
+    total = 0.0
+    for pat in pattern.split("|"):
+        names = [k for k in pmc if pat in k and "stats" not in k]
+        if len(names) > 1:
+            return None
+        if names:
+            r = pmc[names[0]].get("rocprof")
+            if not r:
+                return None
+            total += r["avg_ms"]
+    return total or None
+
+
+def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False):
     """-> ({kernel short name: {counter: per-launch value}}, None) or (None, reason).  Runs before the parent touches
     the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process.
     reference_layout: the same workload on an index without any acceleration structure (the ladder's last rung);
@@ -183,12 +236,25 @@ def run_live_pmc(args, reference_layout=False, rung=None):
     t0 = time.time()
     for name, counters in PMC_PASSES:
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex",
-               "search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|search_kernel|search_verify_kernel|search_exact_kernel",
-               "--output-format", "csv", "-d", d, "--",
-               "python3", os.path.join(ROOT, "bench.py"), *child_args]
+        if counters is None:
+            if not kernel_trace:
+                continue
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
+                   "python3", os.path.join(ROOT, "bench.py"), *child_args, "--pmc-child-steps", "12"]
+        else:
+            cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", KERNEL_REGEX,
+                   "--output-format", "csv", "-d", d, "--",
+                   "python3", os.path.join(ROOT, "bench.py"), *child_args]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            if counters is None:
+                # a failed timing pass does not take the traffic with it
+                stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+                if r.returncode == 0 and stats:
+                    read_kernel_stats(stats[0], out, keep=kernel_trace if isinstance(kernel_trace, str) else None)
+                else:
+                    log(f"[bench] kernel-trace child pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}")
+                continue
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 tail = r.stderr.decode(errors="replace")[-400:]
@@ -541,7 +607,8 @@ def main():
     if profiled:  # under rocprofv3 already (its preload initialised the GPU): no nested profiler children
         pmc_note = "bench.py itself runs under a profiler"
     elif world == 1 and not args.no_live_pmc:
-        pmc, pmc_note = run_live_pmc(args)
+        pmc, pmc_note = run_live_pmc(args, kernel_trace=os.path.join(os.path.dirname(os.path.abspath(args.side_file)),
+                                                                     "bench_kernel_stats.csv"))
         if pmc is None:
             log(f"[bench] live PMC unavailable: {pmc_note}")
         elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
@@ -642,6 +709,12 @@ def main():
         roofline["traffic"] = search_traffic["bytes"]
         roofline["achieved"] = search_traffic["bytes"] / (search_ms / 1e3) / 1e9
         roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBPS
+        # the same traffic over rocprofv3's own average durations of these kernels (the kernel-trace child pass of this run):
+        # what profiles/ reproduces; the spread between the two is process to process (where the structures land in HBM)
+        rp_ms = rocprof_ms_of(pmc, kernel_pattern)
+        if rp_ms:
+            roofline["avg_launch_ms_rocprof"] = rp_ms
+            roofline["frac_rocprof"] = search_traffic["bytes"] / (rp_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
         roofline["traffic_by_kernel"] = search_traffic.get("by_kernel")
         roofline["traffic_read_bytes"] = search_traffic["read_bytes"]
         roofline["traffic_write_bytes"] = search_traffic["write_bytes"]
@@ -851,9 +924,122 @@ def main():
                     "dram_read_requests_per_query": rl.get("dram_read_requests_per_query")}
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        if world > 1 and "strong_scaling" in result:
+            report_strong_scaling(result, wl)
+        side = write_side_file(args.side_file, result)
+        print(json.dumps(compact_line(result, side)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout; round 3's 25 KB line was cut and went unparsed
+
+
+def report_strong_scaling(result, wl):
+    """N > 1: BASELINE.json configs[3] is ONE batch of nq reads sharded over the ranks, so `value`, `ms_per_step`,
+    `scaling` and `config.workload` become those of the strong-scaling measurement; the every-rank-its-own-batch number
+    that was timed first moves to `weak_scaling`."""
+    st = result["strong_scaling"]
+    result["weak_scaling"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "unit": "queries/s",
+                              "queries_per_gpu": result["config"]["queries_per_gpu"],
+                              "gathered_bytes_per_rank_and_step": result["config"]["gathered_bytes_per_rank_and_step"]}
+    n = result["n_gpus"]
+    result["value"], result["ms_per_step"], result["scaling"] = st["value"], st["ms_per_step"], "strong"
+    result["steps"] = st["steps"]
+    c = result["config"]
+    c["workload"] = (f"{wl['short']}: ONE batch of {st['queries_total']} reads sharded over {n} GPUs (BASELINE configs[3]), index "
+                     f"{c['index_gb_per_replica']:.0f} GB replicated, results gathered to rank 0 over RCCL")
+    c["queries_per_gpu"] = st["queries_this_rank"]
+    c["queries_total"] = st["queries_total"]
+    c["gathered_bytes_per_rank_and_step"] = st["gathered_bytes_per_rank_and_step"]
+    c["gather_wire"] = st.get("gather_wire", c.get("gather_wire"))
+    result["parity"]["shards_equal_single_rank_output"] = st.get("shards_equal_single_rank_output")
+
+
+def write_side_file(path, result):
+    """Everything measured, in full, beside the contract line (and on stderr); -> the path written or None."""
+    log("[bench] full result: " + json.dumps(result))
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(result, f, indent=1)
+        return path
+    except OSError as e:
+        log(f"[bench] side file {path} not written: {e!r}")
+        return None
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d and k in d and d[k] is not None}
+
+
+def _num(x):
+    """numbers at 6 significant digits: the line is for reading and for ratios, the side file keeps every digit"""
+    if isinstance(x, float):
+        return float(f"{x:.6g}")
+    if isinstance(x, dict):
+        return {k: _num(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_num(v) for v in x]
+    return x
+
+
+def compact_line(result, side_file=None):
+    """The ONE stdout line: the contract's keys, `roofline` and `cpu_baseline` in their short forms, nothing else.
+    Guaranteed below LINE_LIMIT bytes (strings are cut, optional parts dropped in a fixed order if it ever grows)."""
+    r = result.get("roofline") or {}
+    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "avg_launch_ms_rocprof",
+                     "frac_rocprof", "frac_algorithmic", "algorithmic_bytes_per_launch", "wasted_traffic_ratio",
+                     "useful_bytes_per_query", "dram_read_requests_per_query", "l2_hit_rate", "frac_of_measured_stream_read"))
+    for k in ("traffic", "achieved", "frac"):  # the contract's keys are there even when nothing was measured (null)
+        roof.setdefault(k, r.get(k))
+    roof["traffic_source"] = (r.get("traffic_source") or "")[:160]
+    if r.get("reference_layout"):
+        roof["reference_layout"] = _pick(r["reference_layout"], ("index_bytes", "value", "search_ms", "frac_traffic",
+                                                                 "frac_algorithmic", "dram_read_requests_per_query"))
+        t, a = r["reference_layout"].get("traffic"), r["reference_layout"].get("algorithmic_bytes_per_launch")
+        if t and a:
+            roof["reference_layout"]["wasted_traffic_ratio"] = t / a
+    c = result.get("cpu_baseline")
+    cpu = c if (c is None or "error" in c) else _pick(c, ("value", "unit", "cores", "kind", "sample", "usable_threads",
+                                                             "count_only_value", "bit_exact_vs_gpu"))
+    if cpu and isinstance(cpu.get("sample"), str):
+        cpu["sample"] = cpu["sample"][:200]
+    cfg = result.get("config") or {}
+    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "queries_per_gpu", "queries_total", "text_len",
+                         "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism",
+                         "gathered_bytes_per_rank_and_step", "gather_wire", "compact_exceptions"))
+    if isinstance(config.get("workload"), str):
+        config["workload"] = config["workload"][:300]
+    line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = config
+    line["roofline"] = roof
+    line["cpu_baseline"] = cpu
+    line["kernel_ms"] = result.get("kernel_ms")
+    lr = result.get("locate_roofline")
+    if lr:
+        line["locate_roofline"] = _pick(lr, ("kernel", "avg_launch_ms", "traffic", "frac", "hits_per_launch"))
+    line["parity"] = _pick(result.get("parity") or {}, ("queries_with_status", "queries_found", "sum_of_counts_equals_hits",
+                                                        "hits_checked", "hits_matching_text", "shards_equal_single_rank_output"))
+    if result.get("weak_scaling"):
+        line["weak_scaling"] = result["weak_scaling"]
+    elif result.get("strong_scaling"):
+        line["strong_scaling"] = _pick(result["strong_scaling"], ("value", "ms_per_step", "queries_total"))
+    e = result.get("end_to_end")
+    if e and "error" not in e:
+        line["end_to_end"] = _pick(e, ("count_qps", "locate_qps", "pcie_h2d_GBps", "pcie_d2h_GBps", "count_over_bound",
+                                            "locate_over_bound"))
+    line["index_build_seconds"] = result.get("index_build_seconds")
+    line["side_file"] = side_file
+    line = _num(line)
+    for drop in ("end_to_end", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:  # (cannot happen with the keys above: every string is cut, every list is gone)
+        line["config"] = {"workload": config.get("workload", "")[:200]}
+    return line
 
 
 def make_gather(torch, gdist, runner, dev, do_locate):

@@ -180,3 +180,85 @@ def test_compact_gather_plumbing_with_a_restated_engine():
     r2.use_rec = False
     g2, count_of, _ = bench.make_gather(torch, gdist, r2, torch.device("cpu"), True)
     assert not getattr(g2, "compact_wire", False) and g2.hits_are_split
+
+
+def _round3_result(n_gpus=1):
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03", "bench_hg38_final.json")).read().strip().splitlines()[-1])
+    d["n_gpus"] = n_gpus
+    return d
+
+
+def test_the_stdout_line_stays_below_4_kb_whatever_was_measured(tmp_path):
+    """Round 3's line carried every secondary (25 KB) and the driver could not read it back: the line bench.py prints now
+    holds the contract's keys, roofline and cpu_baseline only; everything else goes to the side file."""
+    full = _round3_result()
+    assert len(json.dumps(full)) > 20_000  # the round-3 line as it was
+    side = bench.write_side_file(str(tmp_path / "side" / "bench_secondary.json"), full)
+    assert side and json.load(open(side))["secondary"]  # nothing is lost: the side file has it all
+    text = json.dumps(bench.compact_line(full, side))
+    assert len(text.encode()) < bench.LINE_LIMIT == 4096 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert "secondary" not in line and "measured_bandwidth" not in line and line["side_file"] == side
+    assert "workload" in line["config"] and "model" not in line["config"] and "aux_structures" not in line["config"]
+    assert abs(line["value"] - full["value"]) < 1e-5 * full["value"]
+    r = line["roofline"]
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frac_algorithmic",
+                "wasted_traffic_ratio"):
+        assert key in r, key
+    assert abs(r["frac"] - r["traffic"] / (r["avg_launch_ms"] / 1e3) / 1e9 / r["peak"]) < 1e-4
+    assert set(r["reference_layout"]) >= {"frac_traffic", "frac_algorithmic", "value"}
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and "thread_sweep_qps" not in c
+    # a line that nothing could shorten enough still fits: strings are cut, optional parts go
+    bloated = _round3_result()
+    bloated["config"]["workload"] = "w" * 50_000
+    bloated["roofline"]["traffic_source"] = "t" * 50_000
+    bloated["roofline"]["kernel"] = "k" * 300
+    bloated["cpu_baseline"]["sample"] = "s" * 50_000
+    bloated["parity"] = {k: 1 for k in ("queries_with_status", "queries_found", "sum_of_counts_equals_hits", "hits_checked")}
+    assert len(json.dumps(bench.compact_line(bloated, "x" * 100)).encode()) < bench.LINE_LIMIT
+    # nothing measured (no PMC, no CPU baseline): the contract's keys are still there, as nulls
+    bare = _round3_result()
+    bare["roofline"] = {"bound": "hbm", "kernel": "k", "unit": "GB/s", "peak": 8000.0, "avg_launch_ms": 3.0, "traffic": None,
+                        "achieved": None, "frac": None}
+    bare["cpu_baseline"] = None
+    line = bench.compact_line(bare, None)
+    assert line["roofline"]["traffic"] is None and line["roofline"]["frac"] is None and line["cpu_baseline"] is None
+
+
+def test_at_n_gpus_above_one_the_line_reports_the_sharded_batch():
+    """BASELINE.json configs[3] is ONE 100 M batch sharded over the ranks: at N > 1 `value` is that measurement, the
+    every-rank-its-own-batch number moves to `weak_scaling`."""
+    full = _round3_result(n_gpus=8)
+    weak_value, weak_ms = full["value"], full["ms_per_step"]
+    full["config"]["gathered_bytes_per_rank_and_step"] = 400_000_000
+    full["strong_scaling"] = {"scaling": "strong", "value": 1.2e11, "unit": "queries/s", "ms_per_step": 0.83, "queries_total": 100_000_000,
+                              "queries_this_rank": 12_500_000, "steps": 20, "gathered_bytes_per_rank_and_step": 50_000_008,
+                              "gather_wire": "compact", "shards_equal_single_rank_output": {"counts": True, "hits": True}}
+    bench.report_strong_scaling(full, bench.WORKLOADS["hg38"])
+    line = json.loads(json.dumps(bench.compact_line(full, None)))
+    assert len(json.dumps(line).encode()) < bench.LINE_LIMIT
+    assert line["scaling"] == "strong" and line["value"] == 1.2e11 and line["ms_per_step"] == 0.83 and line["n_gpus"] == 8
+    assert "ONE batch of 100000000 reads sharded over 8 GPUs" in line["config"]["workload"]
+    assert line["config"]["queries_total"] == 100_000_000 and line["config"]["queries_per_gpu"] == 12_500_000
+    assert line["config"]["gather_wire"] == "compact" and line["config"]["gathered_bytes_per_rank_and_step"] == 50_000_008
+    assert abs(line["weak_scaling"]["value"] - weak_value) < 1e-5 * weak_value and line["weak_scaling"]["ms_per_step"] == float(f"{weak_ms:.6g}")
+    assert line["parity"]["shards_equal_single_rank_output"] == {"counts": True, "hits": True}
+
+
+def test_kernel_stats_of_the_trace_child_pass(tmp_path):
+    p = tmp_path / "k_kernel_stats.csv"
+    p.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                 '"void gdx::(anonymous namespace)::search_seed_kernel4<1, false>(gdx::IndexView)",13,52000000,4000000,50,1,2,3\n'
+                 '"void gdx::(anonymous namespace)::search_verify_kernel4<1, true>(gdx::IndexView)",13,1300000,100000,5,1,2,3\n'
+                 '"void rocprim::detail::something()",5,100,20,0,1,2,3\n')
+    out = {"gdx::search_seed_kernel4<1, false>": {"FETCH_SIZE": {"per_launch": 1.0, "launches": 3}}}
+    bench.read_kernel_stats(str(p), out, keep=str(tmp_path / "kept" / "stats.csv"))
+    assert out["gdx::search_seed_kernel4<1, false>"]["rocprof"] == {"avg_ms": 4.0, "launches": 13}
+    assert "FETCH_SIZE" in out["gdx::search_seed_kernel4<1, false>"] and len(out) == 2
+    assert (tmp_path / "kept" / "stats.csv").exists()
+    assert abs(bench.rocprof_ms_of(out, "search_seed_kernel|search_verify_kernel|search_kernel") - 4.1) < 1e-9
+    assert bench.rocprof_ms_of(out, "locate_queue_kernel") is None and bench.rocprof_ms_of(None, "x") is None
