@@ -3,7 +3,7 @@
 # that brings torch's runtime up first -- three times, every test named with its duration, a traceback dump of every thread
 # after 150 s in one test, a hard stop after 900 s per run.  Output: gpurun_out/stall/run{1,2,3}.log
 mkdir -p gpurun_out/stall
-export GDX_TEST_NO_RUNTIME_FIRST=1
+# (until round 4 a session fixture brought torch up first; the probe ran with it disabled: GDX_TEST_NO_RUNTIME_FIRST=1)
 for i in 1 2 3; do
   timeout 900 python -X faulthandler -m pytest tests/test_gpu_seed.py -m gpu -v --durations=0 \
       -o faulthandler_timeout=150 -p no:cacheprovider > gpurun_out/stall/run$i.log 2>&1
@@ -11,7 +11,7 @@ for i in 1 2 3; do
   tail -3 gpurun_out/stall/run$i.log | tee -a gpurun_out/stall/summary.txt
 done
 # the same with the fixture, once
-unset GDX_TEST_NO_RUNTIME_FIRST
+
 timeout 900 python -X faulthandler -m pytest tests/test_gpu_seed.py -m gpu -v --durations=0 -o faulthandler_timeout=150 \
     -p no:cacheprovider > gpurun_out/stall/run_fixture.log 2>&1
 echo "with fixture rc=$?" | tee -a gpurun_out/stall/summary.txt
