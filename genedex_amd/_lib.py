@@ -62,6 +62,11 @@ class QueryOptions(C.Structure):
                 ("search_exact", C.c_int32), ("max_hits_per_query", C.c_uint32), ("search_seed", C.c_int32)]
 
 
+class QueryLayout(C.Structure):
+    """gdx_query_layout_t"""
+    _fields_ = [("struct_size", C.c_uint32), ("packed", C.c_int32), ("uniform_len", C.c_uint64)]
+
+
 class DeviceShard(C.Structure):
     _fields_ = [("d_qbuf", C.c_void_p), ("d_qoff", C.c_void_p), ("nq", C.c_uint64)]
 
@@ -184,6 +189,11 @@ SIGNATURES = {
     "gdx_cursors_for_many_queries_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_count_many_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_search_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp],
+    "gdx_query_layout_init": [C.POINTER(QueryLayout)],
+    "gdx_locate_many_search_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
+    "gdx_locate_many_search_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp],
+    "gdx_count_many_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
+    "gdx_cursors_for_many_queries_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],
     "gdx_cursor_extend_front_chunk_dev": [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings": [vp, u64p, u64p, u8p, u64p, C.c_uint64, u8p],
@@ -207,7 +217,7 @@ SIGNATURES = {
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
 _RESTYPES = {"gdx_locate_many_totals_workspace_bytes": C.c_uint64, "gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
-             "gdx_build_options_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
+             "gdx_build_options_init": None, "gdx_query_layout_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
              "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64,
              "gdx_locate_many_scan_workspace_bytes": C.c_uint64}
 

@@ -1235,6 +1235,114 @@ int gdx_locate_many_search_packed_dev(const gdx_index_t *ix, const void *d_packe
     return packed_search_dev(ix, d_packed, d_qoff, nq, 2, d_records, nullptr, nullptr, stream);
 }
 
+// ---- query layouts: packed and / or uniform batches through one description (gdx.h) ------------------------------
+
+void gdx_query_layout_init(gdx_query_layout_t *layout)
+{
+    if (!layout) return;
+    std::memset(layout, 0, sizeof(*layout));
+    layout->struct_size = sizeof(*layout);
+}
+
+namespace {
+// fills the query side of a SearchCall from a layout (null = ASCII with offsets: the plain calls)
+void apply_layout(gdx::SearchCall &c, const void *d_qbuf, const void *d_qoff, uint64_t nq, const gdx_query_layout_t *layout)
+{
+    gdx_query_layout_t l;
+    gdx_query_layout_init(&l);
+    if (layout) {
+        if (layout->struct_size < 16 || layout->struct_size > sizeof(l)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.struct_size");
+        std::memcpy(&l, layout, layout->struct_size);
+    }
+    if (l.packed != 0 && l.packed != 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.packed must be 0 or 1");
+    if (l.uniform_len >= (1ull << 21)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.uniform_len must be below 2^21");
+    const uintptr_t align = l.packed ? 1u : 7u;
+    if ((reinterpret_cast<uintptr_t>(d_qbuf) & align) != 0)
+        gdx::fail(GDX_ERR_INVALID_ARGUMENT, l.packed ? "d_qbuf (packed) must be 2-byte aligned" : "d_qbuf must be 8-byte aligned");
+    if (l.uniform_len == 0 && !d_qoff && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_qoff is null and the layout is not uniform");
+    c.d_qbuf = static_cast<const uint8_t *>(d_qbuf);
+    c.nq = nq;
+    c.packed = l.packed != 0;
+    c.uniform_len = static_cast<uint32_t>(l.uniform_len);
+    if (l.uniform_len == 0) {
+        c.d_qbeg = static_cast<const uint64_t *>(d_qoff);
+        c.d_qend = c.d_qbeg + 1;
+    }
+}
+}  // namespace
+
+int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                              const gdx_query_layout_t *layout, void *d_records, void *d_compact, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_compact && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_compact is null");
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.d_compact = static_cast<uint32_t *>(d_compact);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_search_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                      const gdx_query_layout_t *layout, void *d_records, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_count_many_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                              const gdx_query_layout_t *layout, void *d_out_counts, void *d_out_status, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_count = static_cast<uint32_t *>(d_out_counts);
+        c.d_status = static_cast<uint8_t *>(d_out_status);
+        c.mode = 1;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                            const gdx_query_layout_t *layout, void *d_out_start, void *d_out_end,
+                                            void *d_out_status, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        DeviceGuard guard(f.config().device_id);
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_start = static_cast<uint32_t *>(d_out_start);
+        c.d_end = static_cast<uint32_t *>(d_out_end);
+        c.d_status = static_cast<uint8_t *>(d_out_status);
+        c.mode = 0;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_cursor_extend_front_strings_dev(const gdx_index_t *ix, void *d_start, void *d_end, const void *d_qbuf,
                                         const void *d_qbeg, const void *d_qend, uint64_t m, void *d_status,
                                         const void *d_active_in, const void *d_n_active_in, void *d_active_out,

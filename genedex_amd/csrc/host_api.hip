@@ -629,8 +629,8 @@ void set_host_chunking(uint64_t queries, uint64_t bytes)
 int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
                                       uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed) const
 {
-    if (packed && (view_.layout != 0 || view_.pair_lines == nullptr))
-        fail(GDX_ERR_UNSUPPORTED, "packed queries need an index with pair lines (sigma <= 8, pair_lines on)");
+    if (packed && (view_.layout != 0 || view_.n_searchable < 4))
+        fail(GDX_ERR_UNSUPPORTED, "packed queries need the rank-line layout (sigma <= 8) with dense symbols 1..4 searchable");
     if (out_start || out_end) {
         const int rc = host_pipeline(static_cast<int>(Kind::kIntervals), qbuf, qoff, nq, out_start, out_end, out_status,
                                      nullptr, 0, nullptr, nullptr, packed);

@@ -78,7 +78,9 @@ struct SearchCall {
     uint32_t *d_compact = nullptr;  // mode 1 with d_rec: compact results (above)
     unsigned long long *d_step_stats = nullptr;
     int mode = 0;
-    bool packed = false;  // d_qbuf holds 2-bit codes, d_qbeg / d_qend count symbols (pair-line indexes only)
+    bool packed = false;  // d_qbuf holds 2-bit codes, d_qbeg / d_qend count symbols (rank-line layout, sigma <= 8)
+    uint32_t uniform_len = 0;  // != 0: a uniform batch -- every query has this many symbols, query i starts at symbol
+                               // i * uniform_len; d_qbeg / d_qend may be null (gdx_query_layout_t)
     CursorArgs cursors;
 };
 void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream,

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -49,6 +50,53 @@ struct QueryWindow {
         return static_cast<uint32_t>(cur >> ((at & 7u) * 8u)) & 0xffu;
     }
 };
+
+// The same over packed queries (include/gdx.h "packed queries": symbol j of the buffer in bits 2 (j & 7) of 16-bit unit
+// j >> 3, offsets count symbols): one 2-byte load per 8 LF steps; get() returns the 2-bit code (dense symbol - 1).
+struct PackedQueryWindow {
+    const uint16_t *units;
+    uint32_t cur, next;
+    uint64_t cur_unit, first_unit;
+
+    __device__ __forceinline__ void init(const uint8_t *qbuf, uint64_t begin, uint64_t pos)
+    {
+        units = reinterpret_cast<const uint16_t *>(qbuf);
+        first_unit = begin >> 3;
+        const bool any = pos > begin;
+        cur_unit = any ? ((pos - 1) >> 3) : first_unit;
+        cur = any ? units[cur_unit] : 0u;
+        next = (any && cur_unit > first_unit) ? units[cur_unit - 1] : 0u;
+    }
+    __device__ __forceinline__ uint32_t get(uint64_t at)
+    {
+        const uint64_t u = at >> 3;
+        if (u != cur_unit) {
+            cur_unit = u;
+            cur = next;
+            next = (u > first_unit) ? units[u - 1] : 0u;
+        }
+        return (cur >> ((at & 7u) * 2u)) & 3u;
+    }
+};
+
+// Where query q lies in the buffer: [qbeg[q], qend[q]) from the offsets arrays, or -- a UNIFORM batch, ulen != 0: every
+// query has ulen symbols and query q starts at q * ulen (gdx_query_layout_t) -- computed, which saves the kernels the
+// 8 bytes of offsets per query (the arrays may then be null).
+__device__ __forceinline__ uint64_t query_begin(const uint64_t *__restrict__ qbeg, uint32_t ulen, uint64_t q)
+{
+    return ulen != 0u ? q * ulen : qbeg[q];
+}
+__device__ __forceinline__ uint64_t query_end(const uint64_t *__restrict__ qend, uint32_t ulen, uint64_t q)
+{
+    return ulen != 0u ? (q + 1u) * ulen : qend[q];
+}
+// the aligned word (packed, kXlate == 2: the 16-bit unit) that holds the first symbol of a query: fast_window's `wbase`
+template <int kXlate>
+__device__ __forceinline__ const uint64_t *query_words(const uint8_t *__restrict__ qbuf, uint64_t begin)
+{
+    if (kXlate == 2) return reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(qbuf) + (begin >> 3));
+    return reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+}
 
 // The query as the pair kernels see it: dense codes, one nibble per symbol, eight symbols per 32-bit word, read
 // right-to-left.  The kGroup lanes of a query translate the query COOPERATIVELY: a span of eight 8-byte words (64
@@ -237,7 +285,8 @@ __device__ __forceinline__ void compact_alive(bool alive, uint32_t q, const Curs
 // kGroup lanes cooperate on one query (1: LineTable / GenericTable, 4: QuadLineTable); control flow is
 // uniform inside a group, lane 0 of the group writes the results.  kResume: cursor extension (see search_pair_body,
 // kMode 2): start from the interval in out_start / out_end, no lookup table, active lists.
-template <class Table, int kGroup, bool kResume>
+// kPacked: 2-bit queries (never with kResume); ulen: uniform batch (query_begin).
+template <class Table, int kGroup, bool kResume, bool kPacked = false>
 __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint8_t *__restrict__ qbuf,
                                                         const uint64_t *__restrict__ qbeg,
                                                         const uint64_t *__restrict__ qend, uint64_t nq,
@@ -246,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
                                                         uint32_t *__restrict__ out_count,
                                                         uint8_t *__restrict__ out_status,
                                                         unsigned long long *__restrict__ step_stats,
-                                                        uint4 *__restrict__ out_rec, CursorArgs ca)
+                                                        uint4 *__restrict__ out_rec, CursorArgs ca, uint32_t ulen)
 {
     __shared__ uint8_t s_dense[256];
     __shared__ uint32_t s_count[257];
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
     for (uint64_t at = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; at < nq;
          at += stride) {
         const uint64_t q = active ? active[at] : at;
-        uint64_t begin = qbeg[q], end = qend[q];
+        uint64_t begin = query_begin(qbeg, ulen, q), end = query_end(qend, ulen, q);
         bool more_left = true;  // chunk view (CursorArgs::chunk_symbols): the query has symbols left of this chunk
         if (kResume && ca.chunk_symbols != 0u) {
             const uint64_t first = begin, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
@@ -291,7 +340,8 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
             uint64_t idx = 0, factor = 1;
             bool unsearchable = false;
             for (uint32_t j = 0; j < t; j++) {
-                const uint32_t d = s_dense[qbuf[end - t + j]];
+                const uint64_t sj = end - t + j;
+                const uint32_t d = kPacked ? ((static_cast<uint32_t>(qbuf[sj >> 2]) >> (2u * (sj & 3u))) & 3u) + 1u : s_dense[qbuf[sj]];
                 if (d == 0) status = GDX_Q_INVALID_SYMBOL;
                 unsearchable |= (d - 1u >= k);
                 idx += static_cast<uint64_t>(d - 1u) * factor;
@@ -307,11 +357,11 @@ __global__ __launch_bounds__(kBlock) void search_kernel(IndexView ix, const uint
             }
         }
         uint64_t pos = end - t;  // symbols [begin, pos) are still to be consumed, right to left
-        QueryWindow win;
+        typename std::conditional<kPacked, PackedQueryWindow, QueryWindow>::type win;
         win.init(qbuf, begin, pos);
         // lib.rs:226-232 / batch_computed_cursors.rs:62-70: stop at the empty interval
         while (pos > begin && lo != hi && !stopped) {
-            const uint32_t c = s_dense[win.get(pos - 1)];
+            const uint32_t c = kPacked ? win.get(pos - 1) + 1u : s_dense[win.get(pos - 1)];
             if (c == 0) {  // alphabet.rs:195-198
                 status = GDX_Q_INVALID_SYMBOL;
                 if (!kResume) lo = hi = 0;
@@ -1964,7 +2014,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     VerifyView vv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
-    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list)  // list != null: only the *n_list queries listed
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,  // list != null: only the *n_list queries listed
+    uint32_t ulen)  // uniform batch (query_begin)
 {
     constexpr int kGroup = 4;
     __shared__ uint8_t s_dense[256];
@@ -1992,11 +2043,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
             const uint32_t q = list != nullptr ? list[base + slot] : static_cast<uint32_t>(base + slot);
-            const uint64_t begin = qbeg[q];
-            const uint64_t len = qend[q] - begin;
+            const uint64_t begin = query_begin(qbeg, ulen, q);
+            const uint64_t len = query_end(qend, ulen, q) - begin;
             bool bail = kSeed ? !(len >= vv.seed_k && len < (1ull << 21)) : !(len >= 16u && len >= depth && len < (1ull << 21));
             uint32_t lo = 0, hi = 0, rem = 0;
-            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint64_t *wbase = query_words<kXlate>(qbuf, begin);
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0, part = 0;  // levels / symbols of level `shift` of the window already used up
@@ -2283,7 +2334,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // state_packed != 0: a read listed with its seed entry's interval also carries the 32 symbols in front of the seed, as the
     // 2-bit codes this kernel holds anyway: {lo, rows << 24 | kStatePacked | symbols left, codes hi, codes lo} -- the fast
     // kernel then needs neither the read's offsets nor its bytes for up to 32 symbols (kStatePacked, search_fast_kernel4)
-    uint32_t state_packed)
+    uint32_t state_packed,
+    uint32_t ulen)  // uniform batch (query_begin): the offsets stage of the pipeline computes instead of loading
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
@@ -2469,10 +2521,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint64_t len = c_end - c_beg;
                 b_beg = c_beg;
                 b_len = len < (1ull << 21) ? static_cast<uint32_t>(len) : (1u << 21);
-                if (b_len >= k && b_len < (1u << 21)) {
-                    const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (c_beg >> 3);
-                    b_raw = fast_window_load<kXlate>(wbase, static_cast<uint32_t>(c_beg & 7u), b_len, sub);
-                }
+                if (b_len >= k && b_len < (1u << 21))
+                    b_raw = fast_window_load<kXlate>(query_words<kXlate>(qbuf, c_beg), static_cast<uint32_t>(c_beg & 7u), b_len, sub);
             }
             // ---- -> stage C: the offsets of round `it + 3` -------------------------------------------------------------
             c_on = false;
@@ -2480,8 +2530,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint32_t slot = slot0 + static_cast<uint32_t>(it + 3) * kGroups;
                 if (slot < cnt) {
                     const uint32_t q = static_cast<uint32_t>(base + slot);
-                    c_beg = qbeg[q];
-                    c_end = qend[q];
+                    c_beg = query_begin(qbeg, ulen, q);
+                    c_end = query_end(qend, ulen, q);
                     c_on = true;
                 }
             }
@@ -2514,7 +2564,7 @@ __global__ __launch_bounds__(kBlock) void seed_text_kernel4(
     const uint32_t *__restrict__ n_list, const uint2 *__restrict__ long_state, uint32_t long_stride,
     uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_compact,
-    uint4 *__restrict__ state, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover)
+    uint4 *__restrict__ state, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint32_t ulen)
 {
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     __shared__ uint8_t s_dense[256];
@@ -2537,15 +2587,37 @@ __global__ __launch_bounds__(kBlock) void seed_text_kernel4(
             pos = st.x;
             rem = st.y;
         }
-        const uint64_t begin = qbeg[q];
+        const uint64_t begin = query_begin(qbeg, ulen, q);
         const uint32_t rest = rem - 32u;  // (rem > 32: why the read is here)
         uint32_t bad_q = 0, bad_t = 0;    // a query symbol outside A C G T / a mismatch, in any lane
         for (uint32_t done = 0; done < rest; done += 128u) {
             const uint32_t skip = done + 32u * sub;
             if (skip < rest) {
                 const uint32_t e = rest - skip, n_c = e < 32u ? e : 32u, qs = e - n_c;
-                // query bytes [qs, qs + n_c) as aligned 8-byte words (only the words that hold one of them)
                 const uint64_t at = begin + qs;
+                // the text [tp, tp + n_c) in front of the occurrence, tp = pos - rem + qs
+                const uint64_t s0 = static_cast<uint64_t>(pos) - rem + qs + 32u * kTextPadUnits;
+                const uint32_t tb = static_cast<uint32_t>(s0 & 31u);
+                const u32x4 *tu = sv.text_units + (s0 >> 5);
+                uint64_t qc = 0;  // the 2-bit codes of the symbols [qs, qs + n_c): symbol qs + i in bits 2 i + 1 : 2 i
+                uint32_t inv = 0;
+                u32x4 u0, u1;
+                if (kXlate == 2) {
+                    // packed: the codes are the buffer's bits from 2 * at on -- the 16-bit units that hold them (1 .. 5)
+                    const uint16_t *up = reinterpret_cast<const uint16_t *>(qbuf) + (at >> 3);
+                    const uint32_t sh = static_cast<uint32_t>(at & 7u) * 2u;
+                    const uint32_t n_need = (static_cast<uint32_t>(at & 7u) + n_c + 7u) >> 3;
+                    uint64_t lo64 = up[0];
+                    uint32_t hi16 = 0;
+                    if (n_need > 1u) lo64 |= static_cast<uint64_t>(up[1]) << 16;
+                    if (n_need > 2u) lo64 |= static_cast<uint64_t>(up[2]) << 32;
+                    if (n_need > 3u) lo64 |= static_cast<uint64_t>(up[3]) << 48;
+                    if (n_need > 4u) hi16 = up[4];
+                    u0 = tu[0];
+                    u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                    qc = sh != 0u ? (lo64 >> sh) | (static_cast<uint64_t>(hi16) << (64u - sh)) : lo64;
+                } else {
+                // query bytes [qs, qs + n_c) as aligned 8-byte words (only the words that hold one of them)
                 const uint64_t *wp = reinterpret_cast<const uint64_t *>(qbuf) + (at >> 3);
                 const uint32_t sh = static_cast<uint32_t>(at & 7u) * 8u;
                 const uint32_t n_need = (static_cast<uint32_t>(at & 7u) + n_c + 7u) >> 3;  // 1 .. 5
@@ -2554,12 +2626,8 @@ __global__ __launch_bounds__(kBlock) void seed_text_kernel4(
                 if (n_need > 2u) w2 = wp[2];
                 if (n_need > 3u) w3 = wp[3];
                 if (n_need > 4u) w4 = wp[4];
-                // the text [tp, tp + n_c) in front of the occurrence, tp = pos - rem + qs
-                const uint64_t s0 = static_cast<uint64_t>(pos) - rem + qs + 32u * kTextPadUnits;
-                const uint32_t tb = static_cast<uint32_t>(s0 & 31u);
-                const u32x4 *tu = sv.text_units + (s0 >> 5);
-                const u32x4 u0 = tu[0];
-                const u32x4 u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                u0 = tu[0];
+                u1 = tb != 0u ? tu[1] : u32x4{0u, 0u, 0u, 0u};
                 if (sh != 0u) {
                     w0 = (w0 >> sh) | (w1 << (64u - sh));
                     w1 = (w1 >> sh) | (w2 << (64u - sh));
@@ -2572,14 +2640,12 @@ __global__ __launch_bounds__(kBlock) void seed_text_kernel4(
                 const uint32_t wd[8] = {static_cast<uint32_t>(w0), static_cast<uint32_t>(w0 >> 32), static_cast<uint32_t>(w1),
                                         static_cast<uint32_t>(w1 >> 32), static_cast<uint32_t>(w2), static_cast<uint32_t>(w2 >> 32),
                                         static_cast<uint32_t>(w3), static_cast<uint32_t>(w3 >> 32)};
-                uint64_t qc = 0;
 #pragma unroll
                 for (uint32_t g = 0; g < 8; g++) {
                     const uint32_t code = kXlate == 1 ? fast_pack4(sv, wd[g], b[g]) : fast_pack4_lds(s_dense, wd[g], b[g]);
                     qc |= static_cast<uint64_t>(code) << (8u * g);
                 }
                 const uint32_t full = n_c >> 2, part = n_c & 3u;
-                uint32_t inv = 0;
 #pragma unroll
                 for (uint32_t g = 0; g < 8; g++) {
                     // (LDS path: a group is flagged as a whole; the bytes behind n_c are later symbols of the same read, whose
@@ -2587,6 +2653,7 @@ __global__ __launch_bounds__(kBlock) void seed_text_kernel4(
                     const uint32_t bg = kXlate == 1 ? b[g] : (b[g] != 0u ? 0xffffffffu : 0u);
                     if (g < full) inv |= bg;
                     else if (g == full && part != 0u) inv |= bg & ((1u << (8u * part)) - 1u);
+                }
                 }
                 const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
                 const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
@@ -2843,12 +2910,34 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
     launch_search_call(ix, c, stream, qo);
 }
 
-void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t stream, const QueryOptions &qo)
+// offsets of a uniform batch, for the kernels that read them from memory (fill_uniform_offsets_kernel)
+__global__ __launch_bounds__(kBlock) void fill_uniform_offsets_kernel(uint64_t *__restrict__ off, uint64_t n, uint32_t ulen)
 {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) off[i] = i * ulen;
+}
+
+void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream, const QueryOptions &qo)
+{
+    SearchCall c = call;
     const uint64_t nq = c.nq;
     if (nq == 0) return;
     if (c.mode < 0 || c.mode > 2) fail(GDX_ERR_INVALID_ARGUMENT, "internal: search mode %d", c.mode);
     const int variant = qo.search_variant >= 0 ? qo.search_variant : search_variant();
+    if (c.packed && (ix.layout != 0 || ix.n_searchable < 4))
+        fail(GDX_ERR_UNSUPPORTED, "packed queries need the rank-line layout (sigma <= 8) with dense symbols 1..4 searchable");
+    if (c.packed && (c.mode == 2 || c.d_step_stats != nullptr)) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");
+    // Uniform batches (SearchCall::uniform_len): the seed chain and the rank-line kernels compute where a query lies; the
+    // pair-line kernels read offsets, which are then written once into scratch (8 bytes per query, one streaming pass)
+    if (c.uniform_len != 0u && ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
+        uint64_t *d_off = static_cast<uint64_t *>(stream_scratch(stream, 15, (nq + 1) * sizeof(uint64_t)));
+        hipLaunchKernelGGL(fill_uniform_offsets_kernel, dim3(grid_for_items(nq + 1)), dim3(kBlock), 0, stream, d_off, nq + 1,
+                           c.uniform_len);
+        c.d_qbeg = d_off;
+        c.d_qend = d_off + 1;
+        c.uniform_len = 0;
+    }
+    const uint32_t ulen = c.uniform_len;
     // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
     // profiles/r01/search_variants.md): many short-lived blocks beat a resident grid -- 65536 blocks: 78 ms,
     // 1792 (7 per CU): 89 ms, 2048 (8 per CU, all resident, lock-step): 112 ms.  So: about 48 queries per
@@ -2893,7 +2982,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         static const int env_fast_v = [] { const char *e = getenv("GDX_SEARCH_FAST"); return e ? atoi(e) : -1; }();
         static const int env_seed = [] { const char *e = getenv("GDX_SEARCH_SEED"); return e ? atoi(e) : -1; }();
         const bool clean_call = c.mode == 1 && ix.layout == 0 && ix.text_units != nullptr && ix.n_searchable >= 4 &&
-                                c.d_step_stats == nullptr && !c.packed && c.d_hint == nullptr && c.d_start == nullptr &&
+                                c.d_step_stats == nullptr && c.d_hint == nullptr && c.d_start == nullptr &&
                                 c.d_end == nullptr && ca.active_in == nullptr && nq < 0xffffffffull;
         // (a configured lookup table deeper than the seed keeps its own check of the symbols between the two depths, as
         // with the top table below)
@@ -2918,10 +3007,17 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                                 ix.sa_inv, ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
                                 ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits};
             static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
-            const bool perm = ix.perm_ok && !env_no_perm_v;
-#define GDX_VERIFY_LAUNCH(XLATE, SEED, BLOCKS, RANGE, LEFT, LIST)                                                             \
+            // how the kernels get 2-bit codes: 2 = the buffer holds them (packed queries), 1 = v_perm tables, 0 = the table in LDS
+            const int xlate = c.packed ? 2 : ((ix.perm_ok && !env_no_perm_v) ? 1 : 0);
+#define GDX_VERIFY_LAUNCH_X(XLATE, SEED, BLOCKS, RANGE, LEFT, LIST)                                                           \
     hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(BLOCKS), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,    \
-                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST)
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST, ulen)
+#define GDX_VERIFY_LAUNCH(SEED, BLOCKS, RANGE, LEFT, LIST)                             \
+    do {                                                                               \
+        if (xlate == 2) GDX_VERIFY_LAUNCH_X(2, SEED, BLOCKS, RANGE, LEFT, LIST);       \
+        else if (xlate == 1) GDX_VERIFY_LAUNCH_X(1, SEED, BLOCKS, RANGE, LEFT, LIST);  \
+        else GDX_VERIFY_LAUNCH_X(0, SEED, BLOCKS, RANGE, LEFT, LIST);                  \
+    } while (0)
             uint32_t *const no_list = nullptr;
             if (seed) {
                 // the seed table's own kernel first (absent k-mers and k-mers that occur once); what it lists -- k-mers on
@@ -2954,23 +3050,20 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                     const uint32_t long_stride = c.d_rec != nullptr ? 2u : 1u;
                     const uint64_t t_groups = (nq + kBlock / 4 - 1) / (kBlock / 4);
                     const unsigned t_blocks = static_cast<unsigned>(t_groups < 8192 ? t_groups : 8192);
-                    if (perm) {
-                        hipLaunchKernelGGL((search_seed_kernel4<1, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
-                                           c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,
-                                           seed_state_packed);
-                        hipLaunchKernelGGL((seed_text_kernel4<1, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
-                                           c.d_compact, d_seed_state, d_first + 4, d_first);
-                    } else {
-                        hipLaunchKernelGGL((search_seed_kernel4<0, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,
-                                           c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,
-                                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,
-                                           seed_state_packed);
-                        hipLaunchKernelGGL((seed_text_kernel4<0, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
-                                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,
-                                           c.d_compact, d_seed_state, d_first + 4, d_first);
-                    }
+#define GDX_SEED_LAUNCH(XLATE)                                                                                                  \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((search_seed_kernel4<XLATE, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,         \
+                           c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,          \
+                           d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,                 \
+                           seed_state_packed, ulen);                                                                           \
+        hipLaunchKernelGGL((seed_text_kernel4<XLATE, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg, \
+                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
+                           c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
+    } while (0)
+                    if (xlate == 2) GDX_SEED_LAUNCH(2);
+                    else if (xlate == 1) GDX_SEED_LAUNCH(1);
+                    else GDX_SEED_LAUNCH(0);
+#undef GDX_SEED_LAUNCH
                     compact_by_seed = true;
                     if (to_fast) {
                         seed_list = d_first;
@@ -2978,18 +3071,16 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
                         const uint32_t l_range = 256;
                         const uint64_t l_ranges = (nq + l_range - 1) / l_range;
                         const unsigned l_blocks = static_cast<unsigned>(l_ranges < 8192 ? l_ranges : 8192);
-                        if (perm) GDX_VERIFY_LAUNCH(1, true, l_blocks, l_range, d_left, d_first);
-                        else GDX_VERIFY_LAUNCH(0, true, l_blocks, l_range, d_left, d_first);
+                        GDX_VERIFY_LAUNCH(true, l_blocks, l_range, d_left, d_first);
                     }
                 } else {
-                    if (perm) GDX_VERIFY_LAUNCH(1, true, v_blocks, v_range, d_left, no_list);
-                    else GDX_VERIFY_LAUNCH(0, true, v_blocks, v_range, d_left, no_list);
+                    GDX_VERIFY_LAUNCH(true, v_blocks, v_range, d_left, no_list);
                 }
             } else {
-                if (perm) GDX_VERIFY_LAUNCH(1, false, v_blocks, v_range, d_left, no_list);
-                else GDX_VERIFY_LAUNCH(0, false, v_blocks, v_range, d_left, no_list);
+                GDX_VERIFY_LAUNCH(false, v_blocks, v_range, d_left, no_list);
             }
 #undef GDX_VERIFY_LAUNCH
+#undef GDX_VERIFY_LAUNCH_X
             static const bool env_stats_v = getenv("GDX_SEARCH_FAST_STATS") != nullptr;  // debug: size of the leftover list
             if (env_stats_v) {
                 uint32_t n_left = 0;
@@ -3110,17 +3201,17 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             if (ix.perm_ok && !env_no_perm_s) {
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen);
                 hipLaunchKernelGGL((seed_text_kernel4<1, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
-                                   d_first + 4, d_first);
+                                   d_first + 4, d_first, ulen);
             } else {
                 hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen);
                 hipLaunchKernelGGL((seed_text_kernel4<0, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
-                                   d_first + 4, d_first);
+                                   d_first + 4, d_first, ulen);
             }
             ca_exact.active_in = d_first + 4;
             ca_exact.n_active_in = d_first;
@@ -3216,7 +3307,6 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
             ca_general.resume_state = d_state;
         }
         if (c.packed) {
-            if (c.mode == 2 || c.d_step_stats != nullptr) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");
 #define GDX_PACKED_W(M)                                                                    \
     do {                                                                                   \
         if (ix.jump_bytes == 32) GDX_PAIR_LAUNCH((search_pair_packed_kernel4<32, M>));     \
@@ -3252,18 +3342,21 @@ void launch_search_call(const IndexView &ix, const SearchCall &c, hipStream_t st
         return;
     }
     // rank-line and generic kernels: no hints (locate then walks from the interval itself)
-    if (c.packed) fail(GDX_ERR_UNSUPPORTED, "packed queries need an index with pair lines (sigma <= 8, pair_lines on)");
     if (c.d_hint) GDX_HIP(hipMemsetAsync(c.d_hint, 0xff, nq * sizeof(uint2), stream));
 #define GDX_PLAIN_LAUNCH(TABLE, GROUP, GRID)                                                                        \
     do {                                                                                                            \
         if (c.mode == 2)                                                                                            \
             hipLaunchKernelGGL((search_kernel<TABLE, GROUP, true>), dim3(GRID), dim3(kBlock), lds_pad, stream, ix,  \
                                c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status,         \
-                               c.d_step_stats, c.d_rec, ca);                                                        \
+                               c.d_step_stats, c.d_rec, ca, ulen);                                                  \
+        else if (c.packed)                                                                                          \
+            hipLaunchKernelGGL((search_kernel<TABLE, GROUP, false, true>), dim3(GRID), dim3(kBlock), lds_pad, stream, ix, \
+                               c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status,         \
+                               c.d_step_stats, c.d_rec, ca, ulen);                                                  \
         else                                                                                                        \
             hipLaunchKernelGGL((search_kernel<TABLE, GROUP, false>), dim3(GRID), dim3(kBlock), lds_pad, stream, ix, \
                                c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status,         \
-                               c.d_step_stats, c.d_rec, ca);                                                        \
+                               c.d_step_stats, c.d_rec, ca, ulen);                                                  \
     } while (0)
     if (ix.layout == 0 && variant != 1) GDX_PLAIN_LAUNCH(QuadLineTable, 4, group_grid(kBlock / 4));
     else if (ix.layout == 0) GDX_PLAIN_LAUNCH(LineTable, 1, grid_for_items(nq));

@@ -56,10 +56,50 @@ def build_index_from_device_text(io_text: torch.Tensor, text_lengths, alphabet: 
 
 
 class DeviceQueries:
-    """A query set resident in HBM: qbuf (u8, padded to 8 bytes) + qoff (u64[nq+1])."""
+    """A query set resident in HBM: qbuf (u8, padded to 8 bytes) + qoff (u64[nq+1]).
+    packed: qbuf holds 2-bit codes, four symbols per byte (gdx.h "packed queries"; qoff still counts symbols);
+    uniform_len != 0: every query has that many symbols and query i starts at symbol i * uniform_len (the search calls then
+    pass no offsets: gdx_query_layout_t).  total_bytes = the bytes of qbuf the queries occupy in this form."""
 
-    def __init__(self, qbuf: torch.Tensor, qoff: torch.Tensor, nq: int, total_bytes: int):
+    def __init__(self, qbuf: torch.Tensor, qoff: torch.Tensor, nq: int, total_bytes: int, packed: bool = False,
+                 uniform_len: int = 0):
         self.qbuf, self.qoff, self.nq, self.total_bytes = qbuf, qoff, nq, total_bytes
+        self.packed, self.uniform_len = packed, uniform_len
+
+    def layout(self):
+        """(gdx_query_layout_t or None, offsets pointer) for the *_layout_dev calls"""
+        if not self.packed and not self.uniform_len:
+            return None, _ptr(self.qoff)
+        lay = _lib.QueryLayout()
+        _lib.load().gdx_query_layout_init(C.byref(lay))
+        lay.packed = 1 if self.packed else 0
+        lay.uniform_len = int(self.uniform_len)
+        return lay, (C.c_void_p(0) if self.uniform_len else _ptr(self.qoff))
+
+    def total_symbols(self) -> int:
+        return self.total_bytes * 4 if self.packed else self.total_bytes  # (packed: rounded up to whole bytes)
+
+    def as_uniform(self, length: int) -> "DeviceQueries":
+        """the same batch declared uniform (every query `length` symbols, back to back from symbol 0): checked on the device"""
+        n = self.nq
+        if n:
+            want = torch.arange(0, n + 1, device=self.qoff.device, dtype=torch.int64) * length
+            if not torch.equal(self.qoff[: n + 1], want):
+                raise ValueError("the batch is not uniform: query i must span [i * length, (i + 1) * length)")
+        return DeviceQueries(self.qbuf, self.qoff, n, self.total_bytes, self.packed, length)
+
+    def as_packed(self, index: FmIndex) -> "DeviceQueries":
+        """2-bit form of the batch made on the device (gdx_pack_queries_dev); raises if a query has a symbol outside the
+        four searchable ones (such queries are the packed form's exceptions and go through the ASCII calls)"""
+        lib = _lib.load()
+        n_sym = int(self.qoff[self.nq].item()) if self.nq else 0
+        nbytes = int(lib.gdx_packed_bytes(n_sym))
+        packed = torch.zeros(nbytes, dtype=torch.uint8, device=self.qbuf.device)
+        bad = torch.zeros(1, dtype=torch.int64, device=self.qbuf.device)
+        _lib.check(lib.gdx_pack_queries_dev(index._h, _ptr(self.qbuf), n_sym, _ptr(packed), C.c_void_p(0), _ptr(bad), _stream()))
+        if int(bad.item()):
+            raise ValueError(f"{int(bad.item())} symbols outside the four searchable ones: not expressible in 2 bits")
+        return DeviceQueries(packed, self.qoff, self.nq, (n_sym + 3) // 4, True, self.uniform_len)
 
     @classmethod
     def synth(cls, io_text: torch.Tensor, text_lengths, nq: int, len_min: int, len_max: int,
@@ -88,6 +128,8 @@ class DeviceQueries:
 
     def slice(self, lo: int, hi: int) -> "DeviceQueries":
         """queries [lo, hi) as a view: the same byte buffer, a window of the offsets (no copy)"""
+        if self.packed or self.uniform_len:
+            raise ValueError("slice(): plain batches only (a packed / uniform shard is packed from the sliced plain batch)")
         off = self.qoff[lo:hi + 1]
         nbytes = int((off[-1] - off[0]).item()) if hi > lo else 0
         return DeviceQueries(self.qbuf, off, hi - lo, nbytes)
@@ -125,6 +167,14 @@ class DeviceEngine:
 
     def search(self, q: DeviceQueries, out) -> None:
         """cursors_for_many_queries: intervals + status (the dominant kernel)."""
+        lay, qoff = q.layout()
+        if lay is not None:
+            if "hint" in out:
+                raise ValueError("hints go with plain batches")
+            _lib.check(self.lib.gdx_cursors_for_many_queries_layout_dev(self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay),
+                                                                        _ptr(out["start"]), _ptr(out["end"]),
+                                                                        _ptr(out["status"]), _stream()))
+            return
         if "hint" in out:
             _lib.check(self.lib.gdx_cursors_for_many_queries_hint_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq,
                                                                       _ptr(out["start"]), _ptr(out["end"]),
@@ -136,6 +186,11 @@ class DeviceEngine:
                                                              _ptr(out["status"]), _stream()))
 
     def count(self, q: DeviceQueries, counts: torch.Tensor, status: torch.Tensor) -> None:
+        lay, qoff = q.layout()
+        if lay is not None:
+            _lib.check(self.lib.gdx_count_many_layout_dev(self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay), _ptr(counts),
+                                                          _ptr(status), _stream()))
+            return
         _lib.check(self.lib.gdx_count_many_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(counts),
                                                _ptr(status), _stream()))
 
@@ -166,6 +221,15 @@ class DeviceEngine:
         return torch.empty(max(nq, 1), dtype=torch.int32, device=self.dev)
 
     def locate_search(self, q: DeviceQueries, rec: torch.Tensor, compact: torch.Tensor = None) -> None:
+        lay, qoff = q.layout()
+        if lay is not None:
+            if compact is not None:
+                _lib.check(self.lib.gdx_locate_many_search_compact_layout_dev(self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay),
+                                                                              _ptr(rec), _ptr(compact), _stream()))
+            else:
+                _lib.check(self.lib.gdx_locate_many_search_layout_dev(self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay), _ptr(rec),
+                                                                      _stream()))
+            return
         if compact is not None:
             _lib.check(self.lib.gdx_locate_many_search_compact_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec),
                                                                    _ptr(compact), _stream()))

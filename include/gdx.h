@@ -456,7 +456,8 @@ int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *
  * any other symbol (N, IUPAC codes, bytes outside the alphabet) cannot be expressed: it is an EXCEPTION, its packed
  * symbols are 0 and its results from the packed calls are meaningless -- run the exceptions through the ASCII calls.
  * Packed input quarters the PCIe traffic of the host calls and the query-byte DRAM traffic of the search and needs
- * no alphabet translation; results are identical.  Needs an index with pair lines (sigma <= 8).
+ * no alphabet translation; results are identical.  Needs the rank-line layout (sigma <= 8, dense symbols 1..4 searchable:
+ * the DNA alphabets) -- with or without pair lines, seed table, text units.
  * A packed buffer for n symbols takes gdx_packed_bytes(n) bytes (padded: the kernels read whole 16-bit units), must
  * be 2-byte aligned (device) and is made by
  *   gdx_pack_queries      on the host, by a few threads; out_exceptions receives the sorted indices of the exception
@@ -483,6 +484,37 @@ int gdx_count_many_packed_dev(const gdx_index_t *ix, const void *d_packed, const
                               void *d_out_counts, void *d_out_status, void *stream);
 int gdx_locate_many_search_packed_dev(const gdx_index_t *ix, const void *d_packed, const void *d_qoff, uint64_t nq,
                                       void *d_records, void *stream);
+
+/* ---- query layouts: how a batch of queries lies in its buffer ---------------------------------------------------------
+ * The reference's batch calls take any iterator of byte slices (lib.rs:155-161, 179-185, 241-246); a device has one buffer.
+ * Beside the plain form -- IO symbols, one byte each, with an offsets array -- a batch may be
+ *   packed   2-bit codes, four symbols per byte ("packed queries" above; ROADMAP.md:35-37), and / or
+ *   uniform  every query has the same number of symbols and query i starts at symbol i * uniform_len: no offsets array at
+ *            all (d_qoff may be NULL) -- a batch of sequencer reads.  The kernels then compute where a read lies instead of
+ *            loading 8 bytes of offsets per read.
+ * A len-50 read costs the search 58 bytes of query traffic in the plain form, 20.5 packed, 12.5 packed + uniform, next to
+ * the one 128-byte bucket of the seed table it looks at.  Results are identical in every form (exceptions of the packed
+ * form as above).  On every index of the rank-line layout (sigma <= 8); the seed-table kernels, the text-unit kernels and
+ * the rank-line kernel read all forms natively, the pair-line kernels read offsets (a uniform batch gets them written into
+ * scratch, once per call).  Initialise with gdx_query_layout_init(); layout == NULL means the plain form. */
+typedef struct {
+    uint32_t struct_size;  /* sizeof(gdx_query_layout_t) */
+    int32_t packed;        /* 0: IO symbols (d_qbuf 8-byte aligned); 1: 2-bit codes (d_qbuf 2-byte aligned) */
+    uint64_t uniform_len;  /* 0: offsets in d_qoff (u64[nq + 1], counting symbols); 1 .. 2^21 - 1: uniform batch */
+} gdx_query_layout_t;
+void gdx_query_layout_init(gdx_query_layout_t *layout);
+/* gdx_locate_many_search_compact_dev / gdx_locate_many_search_dev / gdx_count_many_dev / gdx_cursors_for_many_queries_dev
+ * on a batch in the given layout (FmIndex::locate_many / count_many / cursors_for_many_queries, lib.rs:155-246); the rest
+ * of a locate (gdx_locate_many_totals_compact_dev, ..._offsets_hits_compact_dev, ..._hits_dev) never looks at the queries */
+int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                              const gdx_query_layout_t *layout, void *d_records, void *d_compact, void *stream);
+int gdx_locate_many_search_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                      const gdx_query_layout_t *layout, void *d_records, void *stream);
+int gdx_count_many_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                              const gdx_query_layout_t *layout, void *d_out_counts, void *d_out_status, void *stream);
+int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                            const gdx_query_layout_t *layout, void *d_out_start, void *d_out_end,
+                                            void *d_out_status, void *stream);
 
 /* ---- batched cursor extension by strings (Cursor::extend_query_front, cursor.rs:34-51, applied to every symbol of
  * a string from its last to its first; ROADMAP.md:33 "API to use batched search with cursors") --------------------

@@ -1009,8 +1009,8 @@ def test_packed_queries_equal_ascii_queries(seed, search_variant):
     from genedex_amd import _lib
     from genedex_amd.device import DeviceEngine, _ptr, _stream
 
-    if search_variant in ("quad", "lane", "verify-sa", "verify-walk", "seed-sa", "seed-walk") or search_variant.startswith("ref-"):
-        pytest.skip("packed queries run on the pair-line kernels")
+    if search_variant.startswith("ref-"):
+        pytest.skip("packed queries go with the rank-line layout (the reference's own tables are queried as ASCII)")
     lib = _lib.load()
     rng = np.random.default_rng(7300 + seed)
     a = alph.ascii_dna_with_n()
@@ -1086,6 +1086,96 @@ def test_packed_queries_equal_ascii_queries(seed, search_variant):
     assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
     h = hits[:total].cpu().numpy().astype(np.uint32)
     assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_query_layouts_equal_plain_queries(seed, search_variant):
+    """gdx_query_layout_t: a batch as IO symbols with offsets (the plain form), uniform (no offsets), packed (2 bits per
+    symbol), packed + uniform -- intervals, counts and located hits of every form are the oracle's, on every kernel variant
+    and index structure (the seed-table chain, the text-unit kernels and the rank-line kernel read all forms natively; the
+    pair-line kernels get a uniform batch's offsets written into scratch).  Uniform batches of reads shorter than the seed,
+    of exactly the seed's length, of the entry's reach (k + 32) and longer (text units) are included."""
+    import ctypes as C
+
+    import torch
+
+    from genedex_amd import _lib
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    if search_variant.startswith("ref-"):
+        pytest.skip("layouts go with the rank-line layout")
+    rng = np.random.default_rng(8100 + seed)
+    a = alph.ascii_dna_with_n()
+    texts = random_texts(rng, len_max=30000, symbols=b"ACGTN" if seed % 2 else b"ACGT")
+    g, c = both(texts, a, sa_rate=[4, 1, 3, 8][seed], depth=[0, 2][seed % 2])
+    eng = DeviceEngine(g)
+    k = int(g.seed_info()["k"])
+    lengths = sorted({1, 7, 20, 50, 101, max(k - 1, 1), max(k, 1), k + 32, k + 33, k + 70})
+    for length in lengths:
+        # reads of this length: substrings (without N: expressible in 2 bits), random ones, and substrings with one change
+        qs = []
+        for _ in range(400):
+            t = texts[int(rng.integers(0, len(texts)))]
+            if len(t) >= length:
+                pos = int(rng.integers(0, len(t) - length + 1))
+                q = bytearray(t[pos:pos + length])
+                if b"N" in q:
+                    continue
+                if rng.random() < 0.3:
+                    q[int(rng.integers(0, length))] = b"ACGT"[int(rng.integers(0, 4))]
+                qs.append(bytes(q))
+        qs += [bytes(b"ACGT"[i] for i in rng.integers(0, 4, length)) for _ in range(100)]
+        qbuf, qoff = pack_queries(qs)
+        nq = len(qs)
+        cs, ce = c.cursors_for_many(qbuf, qoff)
+        co, ct, cp = c.locate_intervals(cs, ce)
+        plain = DeviceQueries.from_host(qbuf, qoff)
+        forms = {"uniform": plain.as_uniform(length), "packed": plain.as_packed(g),
+                 "packed+uniform": plain.as_packed(g).as_uniform(length)}
+        for name, dq in forms.items():
+            what = f"{name}, length {length}"
+            out = eng.alloc_outputs(nq)
+            eng.search(dq, out)
+            assert out["start"].cpu().numpy().astype(np.uint32).tolist() == cs.astype(np.uint32).tolist(), what
+            assert out["end"].cpu().numpy().astype(np.uint32).tolist() == ce.astype(np.uint32).tolist(), what
+            assert not out["status"].any().item(), what
+            cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+            st = torch.empty(nq, dtype=torch.uint8, device="cuda")
+            eng.count(dq, cnt, st)
+            assert cnt.cpu().numpy().astype(np.uint64).tolist() == (ce - cs).tolist() and not st.any().item(), what
+            for compact in (True, False):
+                rec = eng.alloc_records(nq)
+                cw = eng.alloc_compact(nq) if compact else None
+                eng.locate_search(dq, rec, compact=cw)
+                off = torch.empty(nq + 1, dtype=torch.int64, device="cuda")
+                eng.locate_offsets(rec, nq, off, compact=cw)
+                torch.cuda.synchronize()
+                total = int(off[nq].item())
+                hits = torch.empty((max(total, 1), 2), dtype=torch.int32, device="cuda")
+                ws = torch.empty(max(eng.locate_workspace_bytes(total), 16), dtype=torch.uint8, device="cuda")
+                eng.locate_hits(rec, nq, off, total, hits, ws, compact=cw)
+                torch.cuda.synchronize()
+                assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist(), what
+                h = hits[:total].cpu().numpy().astype(np.uint32)
+                assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist(), what
+    # what a layout must refuse
+    lib = _lib.load()
+    lay = _lib.QueryLayout()
+    lib.gdx_query_layout_init(C.byref(lay))
+    assert lay.struct_size == C.sizeof(_lib.QueryLayout) and lay.packed == 0 and lay.uniform_len == 0
+    dq = DeviceQueries.from_host(*pack_queries([b"ACGT", b"ACGT"]))
+    cnt = torch.empty(2, dtype=torch.int32, device="cuda")
+    st = torch.empty(2, dtype=torch.uint8, device="cuda")
+    from genedex_amd.device import _ptr, _stream
+    assert lib.gdx_count_many_layout_dev(g._h, _ptr(dq.qbuf), None, 2, C.byref(lay), _ptr(cnt), _ptr(st), _stream()) == _lib.GDX_ERR_INVALID_ARGUMENT
+    lay.packed = 2
+    assert lib.gdx_count_many_layout_dev(g._h, _ptr(dq.qbuf), _ptr(dq.qoff), 2, C.byref(lay), _ptr(cnt), _ptr(st), _stream()) == _lib.GDX_ERR_INVALID_ARGUMENT
+    lay.packed, lay.uniform_len = 0, 1 << 21
+    assert lib.gdx_count_many_layout_dev(g._h, _ptr(dq.qbuf), None, 2, C.byref(lay), _ptr(cnt), _ptr(st), _stream()) == _lib.GDX_ERR_INVALID_ARGUMENT
+    with pytest.raises(ValueError):
+        DeviceQueries.from_host(*pack_queries([b"ACGT", b"ACG"])).as_uniform(4)
+    with pytest.raises(ValueError):
+        DeviceQueries.from_host(*pack_queries([b"ACGT", b"ACNT"])).as_packed(g)
 
 
 @pytest.mark.parametrize("depth", [16, 19])
