@@ -108,6 +108,11 @@ def parse_args():
                          "summary under profiles/ and says so)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
+    ap.add_argument("--input", default="ascii", choices=["ascii", "uniform", "packed", "packed+uniform"],
+                    help="how the batch lies in HBM when the timed region starts (gdx_query_layout_t): ascii = IO symbols + "
+                         "u64 offsets (the reference's byte slices); uniform = the same bytes declared uniform (every read "
+                         "len symbols, no offsets read); packed = 2-bit codes + offsets; packed+uniform = 2-bit codes, no "
+                         "offsets.  uniform forms need len_min == len_max")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-steps", type=int, default=2, help=argparse.SUPPRESS)
     ap.add_argument("--side-file", default=os.environ.get("GDX_BENCH_SIDE_FILE", os.path.join("gpurun_out", "bench_secondary.json")),
@@ -135,7 +140,7 @@ PMC_PASSES = [
     # under the traffic can be the profiler's as well as this process's HIP events (roofline.avg_launch_ms_rocprof)
     ("kernel_trace", None),
 ]
-KERNEL_REGEX = ("search_seed_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
+KERNEL_REGEX = ("search_seed_kernel|search_seed_lane_kernel|seed_text_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
                 "search_kernel|search_verify_kernel|search_exact_kernel")
 
 
@@ -158,7 +163,8 @@ def pmc_child(args):
     nq = wl["nq"]
     queries = DeviceQueries.synth(io_text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
     eng = DeviceEngine(index)
-    runner = StepRunner(torch, eng, queries, nq, args.op == "count+locate", args.path, hint=not args.no_hint)
+    runner = StepRunner(torch, eng, input_form(queries, index, args, wl), nq, args.op == "count+locate", args.path,
+                        hint=not args.no_hint)
     runner.size()
     for _ in range(args.pmc_child_steps):
         runner.step(0, False)
@@ -214,6 +220,7 @@ def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
+                  "--input", args.input if not (reference_layout or rung) else "ascii",
                   "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate),
                   "--index", "tables" if (reference_layout or rung) else args.index]
     jump_bytes, top_depth, no_pairs = args.jump_bytes, args.top_depth, args.no_pair_lines
@@ -331,6 +338,19 @@ def workload_of(args):
     if args.total:
         wl["total"] = args.total
     return wl
+
+
+def input_form(queries, index, args, wl):
+    """the batch in the form --input names (made before the timed region; `queries` stays the plain form)"""
+    form = getattr(args, "input", "ascii")
+    q = queries
+    if "uniform" in form and wl["len_min"] != wl["len_max"]:
+        raise SystemExit(f"--input {form}: workload {args.workload} has reads of {wl['len_min']}..{wl['len_max']} symbols")
+    if "packed" in form:
+        q = q.as_packed(index)
+    if "uniform" in form:
+        q = q.as_uniform(wl["len_min"])
+    return q
 
 
 def build_options_of(args, **override):
@@ -669,7 +689,8 @@ def main():
     eng = DeviceEngine(index)
     aux = eng.aux_info()
     n_slots = 2 if (world > 1 or (do_locate and args.overlap)) else 1
-    runner = StepRunner(torch, eng, queries, nq, do_locate, args.path, hint=not args.no_hint, n_slots=n_slots)
+    run_queries = input_form(queries, index, args, wl)
+    runner = StepRunner(torch, eng, run_queries, nq, do_locate, args.path, hint=not args.no_hint, n_slots=n_slots)
     total_hits = runner.size()
     out = runner.outs[0]
     n_status = int((runner.status(out) != 0).sum().item())
@@ -696,7 +717,8 @@ def main():
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
     if aux["seed"]["k"]:  # the seed kernel, the seed-aware verify kernel on what it listed, the general kernel on the rest
-        kernel_pattern = "search_seed_kernel|search_verify_kernel|" + ("search_pair_kernel" if aux["pair_lines"] else "search_kernel")
+        kernel_pattern = ("search_seed_lane_kernel|search_seed_kernel|seed_text_kernel|search_verify_kernel|" +
+                          ("search_pair_kernel" if aux["pair_lines"] else "search_kernel"))
     else:
         kernel_pattern = "search_fast_kernel|search_pair_kernel" if aux["pair_lines"] else "search_kernel"
     search_traffic = traffic_of(pmc, kernel_pattern)
@@ -744,7 +766,7 @@ def main():
     if aux["seed"]["k"]:
         # query bytes + one 8-byte offset + one 16-byte seed entry + the result written (4 bytes compact, else a 16-byte
         # record; reads longer than k + 32 symbols also compare with text units: not counted)
-        useful = queries.total_bytes + nq * (8 + 16 + (4 if runner.use_compact else 16))
+        useful = run_queries.total_bytes + nq * ((0 if run_queries.uniform_len else 8) + 16 + (4 if runner.use_compact else 16))
         roofline["useful_bytes_per_launch"] = useful
         roofline["useful_bytes_per_query"] = useful / nq
         if search_traffic:
@@ -837,7 +859,8 @@ def main():
                                 f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
                                 f"top table; {wl['label']}"),
                    "index_gb_per_replica": index.info.device_bytes / 1e9,
-                   "name": args.workload, "op": args.op, "path": args.path, "queries_per_gpu": nq,
+                   "name": args.workload, "op": args.op, "path": args.path, "input": args.input, "queries_per_gpu": nq,
+                   "query_bytes_per_gpu": run_queries.total_bytes + (0 if run_queries.uniform_len else 8 * (nq + 1)),
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
                    "aux_structures": aux,
@@ -1006,7 +1029,7 @@ def compact_line(result, side_file=None):
     if cpu and isinstance(cpu.get("sample"), str):
         cpu["sample"] = cpu["sample"][:200]
     cfg = result.get("config") or {}
-    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "queries_per_gpu", "queries_total", "text_len",
+    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "input", "queries_per_gpu", "queries_total", "text_len",
                          "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism",
                          "gathered_bytes_per_rank_and_step", "gather_wire", "compact_exceptions"))
     if isinstance(config.get("workload"), str):
@@ -1183,7 +1206,8 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
 
     full = DeviceQueries.synth(io_text, lengths, nq_total, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
     lo, hi = gdist.shard_range(nq_total, rank, world)
-    shard = full.slice(lo, hi)
+    # (a rank holds its shard as a batch of its own: the form --input names is made from that)
+    shard = input_form(full.copy_slice(lo, hi) if args.input != "ascii" else full.slice(lo, hi), eng.index, args, wl)
     runner = StepRunner(torch, eng, shard, hi - lo, do_locate, args.path, hint=not args.no_hint, n_slots=2)
     runner.size()
     gather, count_of, nbytes = make_gather(torch, gdist, runner, dev, do_locate)
@@ -1202,7 +1226,7 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
         res["gather_wire"] = "compact" if getattr(gather, "compact_wire", False) else "arrays"
         del gather, runner
         torch.cuda.empty_cache()
-        single = StepRunner(torch, eng, full, nq_total, do_locate, args.path, hint=not args.no_hint)
+        single = StepRunner(torch, eng, input_form(full, eng.index, args, wl), nq_total, do_locate, args.path, hint=not args.no_hint)
         single.size()
         single.step(0, False)
         torch.cuda.synchronize()

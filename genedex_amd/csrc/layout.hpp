@@ -25,6 +25,7 @@ namespace gdx {
 // native clang vector: HIP's uint4 is a struct-with-union that defeats SROA and sends the
 // 64-byte line to scratch / LDS
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // four dwords at a dword-aligned address
 
 // lookup tables of all depths 0..=d are built (lookup_table.rs:163-181); the reference computes indices with
 // const-curried code up to depth 15 and a dynamic loop beyond (lookup_table.rs:68-113) -- here every depth is the loop.

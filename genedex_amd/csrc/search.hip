@@ -2551,6 +2551,279 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
 }
 
+// ---- the seed table, one LANE per read ---------------------------------------------------------------------------------
+// search_seed_kernel4 gives every read four lanes, and everything that is the same for the four -- offsets, translation,
+// key, hash, the compare with the entry, the result -- is computed four times over: 250 VALU instructions per round of 16
+// reads, 65 % of the SIMDs' issue slots at 3.5-4.1 ms per 100 M reads, and occupancy beyond seven waves bought nothing
+// (profiles/r04/README.md): the kernel had become instruction-bound at two thirds of the gather ceiling.  Here a wavefront
+// takes 64 reads at a time and splits the work by what it is:
+//   S1  lane = read: its last 56 symbols (packed: a 112-bit field of the buffer, five dwords; ASCII: 64 bytes through the
+//       v_perm tables) -> key, bucket, tag, the 32 symbols in front of the seed; {bucket, tag} goes to LDS;
+//   G   four rounds, lane group g of round r fetches the bucket of read 16 r + g (4 lanes x 32 bytes = the 128-byte line, the
+//       access shape the DRAM likes: all 64 lines of the wavefront in flight at once) and the lane that holds the matching
+//       entry puts it into the read's LDS slot;
+//   S2  lane = read: the entry against the read's own symbols -> count, position, compact result; coalesced stores.
+// The scalar work is done once per read, the 128-byte fetches keep their four-lane shape.
+// A read whose k-mer is not in its home bucket while that bucket has turned entries away (5.6 % of the reads at 70 % load)
+// must look into the next bucket: such reads are parked in a queue of the wavefront (LDS: bucket, tag | displacement and
+// what S2 needs) and, whenever 64 of them have gathered, take a G pass of their own -- dense like the others, instead of
+// a dependent second fetch that the other 63 lanes wait for.  The queue lives across the ranges of a block and is drained
+// when the wavefront runs out of reads.  Results, lists and states are those of search_seed_kernel4 (a k-mer on several
+// rows, a read shorter than the seed, a symbol outside A C G T: listed for the next kernel).  Count / locate searches only.
+template <int kXlate, bool kUniform>
+__global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
+    SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
+    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state,
+    uint32_t *__restrict__ out_compact, uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long,
+    uint2 *__restrict__ long_state, uint32_t long_stride, uint32_t state_packed, uint32_t ulen)
+{
+    static_assert(kXlate == 1 || kXlate == 2, "v_perm tables or packed queries");
+    constexpr uint32_t kWaves = kBlock / 64;
+    constexpr uint32_t kNoTag = 0xffffffffu;  // matches no entry (kSeedMatchMask leaves 26 bits)
+    constexpr int kRaw = kXlate == 2 ? 5 : 16;  // dwords a lane loads for its read
+    constexpr uint32_t kQueue = 128;            // parked reads per wavefront: < 64 before a chunk adds up to 64
+    __shared__ uint2 s_bt[kWaves][64];
+    __shared__ u32x4 s_e[kWaves][64];
+    __shared__ uint16_t s_long[kMaxRange];
+    __shared__ uint32_t s_nlong, s_long_base;
+    __shared__ uint32_t s_pq[kWaves][kQueue], s_pb[kWaves][kQueue], s_pt[kWaves][kQueue], s_pr[kWaves][kQueue];
+    __shared__ uint2 s_pc[kWaves][kQueue];
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, sub = lane & 3u, grp = lane >> 2;
+    constexpr uint32_t kWin = 56;  // the window a lane loads: the last 56 symbols of its read (k <= 24: k + 32 <= 56)
+    const uint32_t k = sv.k, span = k + 32u;  // symbols of a read this kernel looks at: the last `span` of the window
+    const uint32_t drop2 = 2u * (kWin - span);  // bits of the window's code string in front of them (0 .. 32)
+    const uint32_t *qw = reinterpret_cast<const uint32_t *>(qbuf);
+    uint32_t n_parked = 0;  // wave-uniform
+
+    // G: every lane has put {bucket, tag | displacement} (or kNoTag) of its read into s_bt; returns the read's entry with
+    // kSeedFound set, or {overflow bit of the bucket, 0, 0, 0}
+    auto gather = [&]() -> u32x4 {
+        __builtin_amdgcn_wave_barrier();
+        u32x4 e0[4], e1[4];
+        uint32_t want[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint2 bt = s_bt[wave][16u * r + grp];
+            want[r] = bt.y;
+            const u32x4 *bp = sv.seed + (static_cast<uint64_t>(bt.x) << 3) + 2u * sub;
+            e0[r] = bp[0];
+            e1[r] = bp[1];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const bool m0 = (e0[r].x & kSeedMatchMask) == want[r], m1 = (e1[r].x & kSeedMatchMask) == want[r];
+            // no entry matches: the slot says whether the bucket ever turned one away (bit 31 of every entry)
+            if (sub == 0u) s_e[wave][16u * r + grp] = u32x4{e0[r].x & kSeedOverflow, 0u, 0u, 0u};
+            if (m0 || m1) {
+                u32x4 es = m0 ? e0[r] : e1[r];
+                es.x |= kSeedFound;
+                s_e[wave][16u * r + grp] = es;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        return s_e[wave][lane];
+    };
+    // S2 of a read whose entry (or absence) is known; slot = its place in the range (0xffffffff: not known any more)
+    auto finish = [&](uint32_t q, uint32_t slot, uint32_t rem, uint64_t qcode, const u32x4 &en) {
+        const uint32_t ex = en.x, ey = en.y, ez = en.z, ew = en.w;
+        const bool found = (ex & kSeedFound) != 0u;
+        if (found && (ex & kSeedKind) != 0u) {
+            // several rows: the next kernel takes it from this interval
+            leftover[atomicAdd(n_leftover, 1u)] = q;
+            if (state) {
+                if (state_packed == 0u) state[q] = make_uint4(ey, ez, rem, 1u);
+                else if (ez - ey < 256u)
+                    state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | rem, static_cast<uint32_t>(qcode >> 32),
+                                          static_cast<uint32_t>(qcode));
+                else state[q] = make_uint4(ey, kStatePlain | rem, ez, 0u);
+            }
+            if (out_compact) out_compact[q] = kCompactSee;
+            return;
+        }
+        bool hit = false;
+        const uint32_t pos = ey;
+        if (found) {
+            const uint32_t n_v = rem < 32u ? rem : 32u;
+            const uint64_t vm64 = n_v == 32u ? ~0ull : ~(~0ull >> (2u * n_v));
+            const uint64_t tcode = (static_cast<uint64_t>(ew) << 32) | ez;
+            const uint32_t v_code = (ex >> kSeedPartialShift) & 3u;
+            const uint32_t n_text = (ex & kSeedPartial) == 0u ? 0xffffffffu : (v_code == 0u ? (ez & 63u) : 29u + v_code);
+            hit = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
+        }
+        if (hit && rem > 32u) {  // the rest against the text units: seed_text_kernel4
+            if (slot != 0xffffffffu) s_long[atomicAdd(&s_nlong, 1u)] = static_cast<uint16_t>(slot);
+            else long_list[atomicAdd(n_long, 1u)] = q;
+            long_state[static_cast<uint64_t>(q) * long_stride] = make_uint2(pos, rem);
+            if (out_compact) out_compact[q] = kCompactSee;  // (seed_text_kernel4 writes the result)
+            return;
+        }
+        // (no row is known, and none is needed: a resolved record is its position)
+        if (out_compact) out_compact[q] = hit ? pos - rem : kCompactNone;
+        else if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
+        if (out_count) out_count[q] = hit ? 1u : 0u;
+        if (out_status) out_status[q] = 0;
+    };
+    // parks the reads of the lanes with `again` set: the next bucket, one more displacement
+    auto park = [&](bool again, uint32_t q, uint32_t bucket, uint32_t tagd, uint32_t rem, uint64_t qcode) {
+        const unsigned long long mask = __ballot(again);
+        if (mask == 0ull) return;
+        if (again) {
+            const uint32_t at = n_parked + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+            s_pq[wave][at] = q;
+            s_pb[wave][at] = bucket + 1u == sv.buckets ? 0u : bucket + 1u;
+            s_pt[wave][at] = tagd + (1u << kSeedDispShift);
+            s_pr[wave][at] = rem;
+            s_pc[wave][at] = make_uint2(static_cast<uint32_t>(qcode), static_cast<uint32_t>(qcode >> 32));
+        }
+        n_parked += static_cast<uint32_t>(__popcll(mask));
+    };
+    // true: the k-mer is not in this bucket, but may sit further on (the bucket turned entries away)
+    auto goes_on = [&](const u32x4 &en, uint32_t tagd) {
+        return (en.x & kSeedFound) == 0u && (en.x & kSeedOverflow) != 0u && (tagd >> kSeedDispShift) < kSeedMaxDisp;
+    };
+    // one G pass over (up to) 64 parked reads
+    auto parked_pass = [&]() {
+        const uint32_t take = n_parked < 64u ? n_parked : 64u;
+        const uint32_t first = n_parked - take;
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = lane < take;
+        uint32_t q = 0, bucket = 0, tagd = kNoTag, rem = 0;
+        uint64_t qcode = 0;
+        if (mine) {
+            q = s_pq[wave][first + lane];
+            bucket = s_pb[wave][first + lane];
+            tagd = s_pt[wave][first + lane];
+            rem = s_pr[wave][first + lane];
+            const uint2 c = s_pc[wave][first + lane];
+            qcode = (static_cast<uint64_t>(c.y) << 32) | c.x;
+        }
+        __builtin_amdgcn_wave_barrier();
+        n_parked = first;
+        s_bt[wave][lane] = make_uint2(bucket, tagd);
+        const u32x4 en = gather();
+        const bool again = mine && goes_on(en, tagd);
+        if (mine && !again) finish(q, 0xffffffffu, rem, qcode, en);
+        park(again, q, bucket, tagd, rem, qcode);
+    };
+
+    const uint64_t n_ranges = (nq + range - 1) / range;
+    for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
+        const uint64_t base = rg * range;
+        const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
+        const uint32_t n_chunks = (cnt + 63u) >> 6;
+        // ---- where read `slot` of the range ends and how long it is; its raw dwords (prefetched one chunk ahead) ----
+        uint64_t r_end = 0;
+        uint32_t r_len = 0;
+        bool r_on = false, r_load = false;
+        uint32_t raw[kRaw];
+#pragma unroll
+        for (int i = 0; i < kRaw; i++) raw[i] = 0u;
+        auto fetch = [&](uint32_t ch) {
+            const uint32_t slot = ch * 64u + lane;
+            r_on = ch < n_chunks && slot < cnt;
+            r_load = false;
+            if (!r_on) return;
+            const uint64_t q = base + slot;
+            uint64_t beg;
+            if (kUniform) {
+                beg = q * ulen;
+                r_end = beg + ulen;
+            } else {
+                beg = qbeg[q];
+                r_end = qend[q];
+            }
+            const uint64_t len = r_end - beg;
+            r_len = len < (1ull << 21) ? static_cast<uint32_t>(len) : (1u << 21);
+            // (a read that ends inside the first 56 symbols of the buffer would make the window start before the buffer)
+            r_load = r_len >= k && r_len < (1u << 21) && r_end >= kWin;
+            if (!r_load) return;
+            if (kXlate == 2) {
+                const uint64_t bit = 2ull * (r_end - kWin);
+                const uint32_t *p = qw + (bit >> 5);
+                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p);
+                raw[0] = v.x, raw[1] = v.y, raw[2] = v.z, raw[3] = v.w;
+                raw[4] = p[4];
+            } else {
+                const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(qw + ((r_end - kWin) >> 2));
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const u32x4_a4 v = p[i];
+                    raw[4 * i] = v.x, raw[4 * i + 1] = v.y, raw[4 * i + 2] = v.z, raw[4 * i + 3] = v.w;
+                }
+            }
+        };
+        fetch(wave);
+        for (uint32_t ch = wave; ch < n_chunks; ch += kWaves) {
+            const uint32_t slot = ch * 64u + lane;
+            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const bool on = r_on;
+            // ---- S1: the raw dwords -> the 2-bit codes of the window, f0 (its first 16 symbols, the first lowest) .. f3; the
+            // last `span` of them are the 32 symbols in front of the seed (qcode, as a text unit) and the k-mer (key)
+            bool left = on && !r_load;  // shorter than the seed, too long, at the very start of the buffer: the next kernel
+            const uint32_t rem = r_len - k;
+            uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+            if (kXlate == 2) {
+                const uint32_t sh = static_cast<uint32_t>(2ull * (r_end - kWin)) & 31u;
+                f0 = __builtin_amdgcn_alignbit(raw[1], raw[0], sh);
+                f1 = __builtin_amdgcn_alignbit(raw[2], raw[1], sh);
+                f2 = __builtin_amdgcn_alignbit(raw[3], raw[2], sh);
+                f3 = __builtin_amdgcn_alignbit(raw[4], raw[3], sh);
+            } else {
+                const uint32_t o = static_cast<uint32_t>(r_end - kWin) & 3u;
+                // symbols that count: [lo, 56) of the window (the ones before are not looked at, or belong to the read in front)
+                const uint32_t lo = kWin - (r_len < span ? r_len : span);
+                uint32_t bad = 0, c[14];
+#pragma unroll
+                for (uint32_t i = 0; i < 14; i++) {
+                    const uint32_t bytes = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], o);
+                    uint32_t b = 0;
+                    c[i] = fast_pack4(sv, bytes, b);
+                    const uint32_t m = 4u * i + 4u <= lo ? 0u : (4u * i >= lo ? 0xffffffffu : 0xffffffffu << (8u * (lo - 4u * i)));
+                    bad |= b & m;
+                }
+                f0 = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+                f1 = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+                f2 = c[8] | (c[9] << 8) | (c[10] << 16) | (c[11] << 24);
+                f3 = c[12] | (c[13] << 8);
+                if (bad != 0u) left = on;  // a symbol outside A C G T among those looked at
+            }
+            const uint64_t wq = (static_cast<uint64_t>(f1) << 32) | f0, wk = (static_cast<uint64_t>(f3) << 32) | f2;
+            const uint64_t qcode = drop2 == 0u ? wq : (wq >> drop2) | (wk << (64u - drop2));
+            const uint64_t key = (wk >> drop2) & ((1ull << (2u * k)) - 1ull);
+            uint32_t tag = 0;
+            const uint32_t bucket = seed_home(key, sv.tag_bits, sv.buckets, tag);
+            const bool look = on && !left;
+            s_bt[wave][lane] = look ? make_uint2(bucket, tag) : make_uint2(0u, kNoTag);
+            // ---- the next chunk's offsets and raw dwords are on their way while this one looks at its buckets ----
+            fetch(ch + kWaves);
+            const u32x4 en = gather();
+            // ---- S2: lane = read again
+            if (left) {  // from the beginning, by the next kernel
+                leftover[atomicAdd(n_leftover, 1u)] = q;
+                if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
+                if (out_compact) out_compact[q] = kCompactSee;
+            }
+            const bool again = look && goes_on(en, tag);
+            if (look && !again) finish(q, slot, rem, qcode, en);
+            park(again, q, bucket, tag, rem, qcode);
+            if (n_parked >= 64u) parked_pass();
+        }
+        // flush the range's list of long reads: one atomic, coalesced stores
+        __syncthreads();
+        const uint32_t n_lng = s_nlong;
+        if (threadIdx.x == 0 && n_lng != 0u) s_long_base = atomicAdd(n_long, n_lng);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_lng; i += kBlock) long_list[s_long_base + i] = static_cast<uint32_t>(base) + s_long[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_nlong = 0;
+        __syncthreads();
+    }
+    while (n_parked != 0u) parked_pass();  // (the chains are short: the largest displacement of a table is in gdx_index_seed_info)
+}
+
 // The reads search_seed_kernel4 listed as "long": seed and the 32 symbols in front agree with the text at `pos`, `rem` symbols
 // are in front of the seed in all.  The rest against the text units, every lane of the group its own 32 symbols: lane `sub`
 // of round r takes the symbols [e - 32, e) of the query with e = rem - 32 - 32 (4 r + sub) (clipped at the query's start),
@@ -3050,9 +3323,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     const uint32_t long_stride = c.d_rec != nullptr ? 2u : 1u;
                     const uint64_t t_groups = (nq + kBlock / 4 - 1) / (kBlock / 4);
                     const unsigned t_blocks = static_cast<unsigned>(t_groups < 8192 ? t_groups : 8192);
+                    // (experiments: GDX_SEED_PAD = dynamic LDS bytes per block, which caps the resident blocks per CU)
+                    static const unsigned seed_pad = [] { const char *e = getenv("GDX_SEED_PAD"); return e ? static_cast<unsigned>(atol(e)) : 0u; }();
 #define GDX_SEED_LAUNCH(XLATE)                                                                                                  \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((search_seed_kernel4<XLATE, false>), dim3(v_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf,         \
+        hipLaunchKernelGGL((search_seed_kernel4<XLATE, false>), dim3(v_blocks), dim3(kBlock), seed_pad, stream, sv, c.d_qbuf,  \
                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,          \
                            d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,                 \
                            seed_state_packed, ulen);                                                                           \
@@ -3060,9 +3335,28 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
                            c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
     } while (0)
-                    if (xlate == 2) GDX_SEED_LAUNCH(2);
+                    // one lane per read (search_seed_lane_kernel) where its loads apply: 2-bit codes or v_perm tables, k <= 24, a
+                    // dword-aligned buffer; GDX_SEED_LANE=0: the four-lane kernel
+                    static const int env_lane = [] { const char *e = getenv("GDX_SEED_LANE"); return e ? atoi(e) : 1; }();
+                    const bool lane_kernel = env_lane != 0 && xlate != 0 && ix.seed_k <= 24u && ix.seed_k >= 8u &&
+                                             (reinterpret_cast<uintptr_t>(c.d_qbuf) & 3u) == 0;
+#define GDX_SEED_LANE_LAUNCH(XLATE, UNIFORM)                                                                                    \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((search_seed_lane_kernel<XLATE, UNIFORM>), dim3(v_blocks), dim3(kBlock), seed_pad, stream, sv,      \
+                           c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first,    \
+                           d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride, seed_state_packed, ulen);  \
+        hipLaunchKernelGGL((seed_text_kernel4<XLATE, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg, \
+                           d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
+                           c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
+    } while (0)
+                    if (lane_kernel && xlate == 2 && ulen != 0u) GDX_SEED_LANE_LAUNCH(2, true);
+                    else if (lane_kernel && xlate == 2) GDX_SEED_LANE_LAUNCH(2, false);
+                    else if (lane_kernel && ulen != 0u) GDX_SEED_LANE_LAUNCH(1, true);
+                    else if (lane_kernel) GDX_SEED_LANE_LAUNCH(1, false);
+                    else if (xlate == 2) GDX_SEED_LAUNCH(2);
                     else if (xlate == 1) GDX_SEED_LAUNCH(1);
                     else GDX_SEED_LAUNCH(0);
+#undef GDX_SEED_LANE_LAUNCH
 #undef GDX_SEED_LAUNCH
                     compact_by_seed = true;
                     if (to_fast) {

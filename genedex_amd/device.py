@@ -134,6 +134,16 @@ class DeviceQueries:
         nbytes = int((off[-1] - off[0]).item()) if hi > lo else 0
         return DeviceQueries(self.qbuf, off, hi - lo, nbytes)
 
+    def copy_slice(self, lo: int, hi: int) -> "DeviceQueries":
+        """queries [lo, hi) as a batch of their own (bytes copied, offsets from 0): what a rank holds of a sharded batch"""
+        if self.packed or self.uniform_len:
+            raise ValueError("copy_slice(): plain batches only")
+        off = self.qoff[lo:hi + 1]
+        b0, b1 = (int(off[0].item()), int(off[-1].item())) if hi > lo else (0, 0)
+        buf = torch.zeros((b1 - b0 + 8 + 7) // 8 * 8, dtype=torch.uint8, device=self.qbuf.device)
+        buf[: b1 - b0] = self.qbuf[b0:b1]
+        return DeviceQueries(buf, off - off[0] if hi > lo else off.clone(), hi - lo, b1 - b0)
+
     def host_slice(self, first: int, count: int):
         """(qbuf, qoff) of queries [first, first+count) as numpy arrays (for the CPU baseline / checks)."""
         off = self.qoff[first:first + count + 1].cpu().numpy().astype(np.uint64)

@@ -335,3 +335,86 @@ def test_full_size_seed_table_and_inverse_suffix_array(hg38_scale):
         del outs, off0, hits0, q
         torch.cuda.empty_cache()
     index.set_query_options()
+
+
+def test_full_size_headline_configuration(hg38_scale):
+    """bench.py's headline configuration itself, at full size: the index `--index seed` builds (the reference's arrays + seed
+    table k = 24 + text units + full suffix array; no pair lines, jump or top table) and the timed path -- compact search ->
+    totals -> offsets + hits (bench.StepRunner) -- on the 100 M len-50 batch in every input form (ASCII + offsets, uniform,
+    packed, packed + uniform) and on the 50 M mixed batch (lengths 20..150: reads shorter than the seed go from the seed
+    kernel to the verify kernel to the rank-line kernel) with an N poked into every 64th read (the same chain): a prefix
+    of 1.5 M reads equals the oracle on the same index (counts, hit offsets, hits, order), every form gives the same
+    offsets and hits for all reads, and hits across the batch spell their reads.  (Rebuilds the shared index's
+    structures: keep it last.)"""
+    import bench
+    from genedex_amd.device import DeviceQueries
+
+    h = hg38_scale
+    torch, eng, dev, index = h["torch"], h["eng"], h["dev"], h["index"]
+    index.set_query_options()
+    index.rebuild_aux(**bench.SEED_INDEX)
+    aux = eng.aux_info()
+    assert aux["seed"]["k"] == 24 and aux["text_units"] and aux["full_suffix_array"]
+    assert not aux["pair_lines"] and aux["jump_entry_bytes"] == 0 and aux["top_table_depth"] == 0
+    assert 70e9 < index.info.device_bytes < 80e9
+
+    def step(q, nq):
+        runner = bench.StepRunner(torch, eng, q, nq, True, "records")
+        assert runner.use_compact
+        runner.size()
+        runner.step(0, False)
+        torch.cuda.synchronize()
+        o = runner.outs[0]
+        return o["hit_offsets"], runner.hits[0][: runner.total_hits], runner.counts(o).to(torch.int64), runner.status(o), o["compact"]
+
+    def against_oracle(q_plain, off, hits, counts, m):
+        qbuf, qoff = q_plain.host_slice(0, m)
+        cs, ce = h["cpu"].cursors_for_many(qbuf, qoff, n_threads=h["threads"])
+        assert np.array_equal(counts[:m].cpu().numpy().astype(np.uint64), ce - cs)
+        co, ct, cp = h["cpu"].locate_intervals(cs, ce, n_threads=h["threads"])
+        assert np.array_equal(off[: m + 1].cpu().numpy().astype(np.uint64), co)
+        gh = hits[: int(co[-1])].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(gh[:, 0], ct.astype(np.uint32)) and np.array_equal(gh[:, 1], cp.astype(np.uint32))
+
+    # ---- workload 3: 100 M reads of 50 symbols, every input form
+    nq = 100_000_000
+    plain = DeviceQueries.synth(h["io_text"], h["lengths"], nq, 50, 50, 900_000, seed=43)
+    off0, hits0, counts0, status0, compact0 = step(plain, nq)
+    assert not bool(status0.any().item()) and int(counts0.sum().item()) == hits0.shape[0] == int(off0[nq].item())
+    assert int((compact0[:nq] != -2).sum().item()) > 0.9999 * nq  # answered by the seed kernel: 4 bytes per read
+    against_oracle(plain, off0, hits0, counts0, 1_500_000)
+    chk = bench.verify_hits(torch, h["io_text"], h["lengths"], plain, {"hit_offsets": off0}, hits0, hits0.shape[0], nq, 2_000_000)
+    assert chk["hits_checked"] == chk["hits_matching_text"] == 2_000_000
+    off0, hits0 = off0.clone(), hits0.clone()
+    for form in ("uniform", "packed", "packed+uniform"):
+        q = plain
+        if "packed" in form:
+            q = q.as_packed(index)
+        if "uniform" in form:
+            q = q.as_uniform(50)
+        off, hits, counts, status, _ = step(q, nq)
+        assert torch.equal(off, off0) and torch.equal(hits, hits0) and not bool(status.any().item()), form
+        del off, hits, counts, q
+    del plain, off0, hits0, counts0, compact0
+    torch.cuda.empty_cache()
+
+    # ---- workload 5's batch (lengths 20..150, 70 % sampled) with an N poked into every 64th read
+    nq = 50_000_000
+    mixed = DeviceQueries.synth(h["io_text"], h["lengths"], nq, 20, 150, 700_000, seed=47)
+    lens = (mixed.qoff[1: nq + 1] - mixed.qoff[:nq])
+    assert int((lens < 24).sum().item()) > 1_000_000  # reads shorter than the seed
+    idx = torch.arange(0, nq, 64, device=dev)
+    mixed.qbuf[mixed.qoff[idx] + lens[idx] // 2] = ord("N")
+    off1, hits1, counts1, status1, compact1 = step(mixed, nq)
+    assert not bool(status1.any().item()) and int(counts1.sum().item()) == hits1.shape[0]
+    assert int((compact1[:nq] == -2).sum().item()) > nq // 64  # the reads with N and the short ones went the long way
+    against_oracle(mixed, off1, hits1, counts1, 1_500_000)
+    chk = bench.verify_hits(torch, h["io_text"], h["lengths"], mixed, {"hit_offsets": off1}, hits1, hits1.shape[0], nq, 2_000_000)
+    assert chk["hits_checked"] == chk["hits_matching_text"] == 2_000_000
+    # the reads without N in their packed form: the same answers
+    clean = DeviceQueries.synth(h["io_text"], h["lengths"], nq, 20, 150, 700_000, seed=47)
+    off2, hits2, counts2, _, _ = step(clean, nq)
+    off3, hits3, counts3, status3, _ = step(clean.as_packed(index), nq)
+    assert torch.equal(off2, off3) and torch.equal(hits2, hits3) and not bool(status3.any().item())
+    against_oracle(clean, off3, hits3, counts3, 500_000)
+    index.set_query_options()
