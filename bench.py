@@ -57,6 +57,9 @@ WORKLOADS = {
                   label="16 MB DNA-N text, 1M len-50 reads (plumbing check)"),
 }
 
+INPUT_FORMS = {"ascii": "IO symbols + u64 offsets", "uniform": "IO symbols, uniform length (no offsets)",
+               "packed": "2-bit codes + u64 offsets", "packed+uniform": "2-bit codes, uniform length (no offsets)"}
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -108,17 +111,22 @@ def parse_args():
                          "summary under profiles/ and says so)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
-    ap.add_argument("--input", default="ascii", choices=["ascii", "uniform", "packed", "packed+uniform"],
+    ap.add_argument("--input", default="auto", choices=["auto", "ascii", "uniform", "packed", "packed+uniform"],
                     help="how the batch lies in HBM when the timed region starts (gdx_query_layout_t): ascii = IO symbols + "
                          "u64 offsets (the reference's byte slices); uniform = the same bytes declared uniform (every read "
                          "len symbols, no offsets read); packed = 2-bit codes + offsets; packed+uniform = 2-bit codes, no "
-                         "offsets.  uniform forms need len_min == len_max")
+                         "offsets.  uniform forms need len_min == len_max.  auto (default) = packed+uniform when every read "
+                         "has the same length, else packed; the same step on the ascii form is measured beside it "
+                         "(`ascii_input`)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-steps", type=int, default=2, help=argparse.SUPPRESS)
     ap.add_argument("--side-file", default=os.environ.get("GDX_BENCH_SIDE_FILE", os.path.join("gpurun_out", "bench_secondary.json")),
                     help="where everything beside the contract line goes (secondaries, ladder, end-to-end, bandwidths, notes): "
                          "the one stdout line stays below 4 KB")
     args = ap.parse_args()
+    if args.input == "auto":
+        w = WORKLOADS[args.workload]
+        args.input = "packed+uniform" if w["len_min"] == w["len_max"] else "packed"
     explicit = (args.jump_bytes is not None or args.top_depth is not None or args.no_pair_lines or args.full_sa or args.text_units)
     if explicit:  # hand-picked structures (ladder rungs of the PMC children, experiments)
         args.index = "tables"
@@ -713,6 +721,24 @@ def main():
     locate_ms = runner.mean_ms(runner.ev_locate)
     hits = runner.hits[0]
 
+    # ---- the same step on the reference's own input form (IO symbols + u64 offsets), beside the headline --------------
+    ascii_input = None
+    if args.input != "ascii" and world == 1:
+        r2 = StepRunner(torch, eng, queries, nq, do_locate, args.path, hint=not args.no_hint)
+        if r2.size() != total_hits:
+            raise SystemExit("PARITY FAILURE: the ascii form of the batch gives another number of hits")
+        e2, _ = timed_steps(torch, gdist, r2, args.steps, args.warmup, dev)
+        same = bool(torch.equal(r2.outs[0]["hit_offsets"], out["hit_offsets"])) and \
+            (not do_locate or bool(torch.equal(r2.hits[0][:total_hits], runner.hits[0][:total_hits])))
+        if not same:
+            raise SystemExit("PARITY FAILURE: the ascii form of the batch gives other offsets or hits")
+        ascii_input = {"value": nq / (e2 / args.steps), "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+                       "search_ms": r2.mean_ms(r2.ev_search), "locate_ms": r2.mean_ms(r2.ev_locate),
+                       "query_bytes": queries.total_bytes + 8 * (nq + 1), "offsets_and_hits_identical_to_headline": same}
+        log(f"[bench] the same step on ascii input: {ascii_input}")
+        del r2
+        torch.cuda.empty_cache()
+
     # ---- algorithmic bytes, counted by an extra, untimed pass in the exact mode -----------
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
@@ -853,8 +879,9 @@ def main():
         "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": (f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + "
-                                f"seed table (k={aux['seed']['k']}) + text units + full SA; {wl['label']}") if aux["seed"]["k"] else
+        "config": {"workload": (f"{wl['short']}, resident in HBM as {INPUT_FORMS[args.input]}; index "
+                                f"{index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + seed table "
+                                f"(k={aux['seed']['k']}) + text units + full SA; {wl['label']}") if aux["seed"]["k"] else
                                (f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + pair "
                                 f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
                                 f"top table; {wl['label']}"),
@@ -870,6 +897,7 @@ def main():
                    "gather_wire": (("compact results + exceptions" if getattr(gather, "compact_wire", False) else "arrays")
                                    if gather is not None else None)},
         "roofline": roofline,
+        "ascii_input": ascii_input,
         "locate_roofline": locate_roofline,
         "kernel_ms": {"search": search_ms, "locate": locate_ms, "totals": runner.mean_ms(runner.ev_scan)},
         "parity": parity,
@@ -1040,6 +1068,8 @@ def compact_line(result, side_file=None):
     line["roofline"] = roof
     line["cpu_baseline"] = cpu
     line["kernel_ms"] = result.get("kernel_ms")
+    if result.get("ascii_input"):
+        line["ascii_input"] = _pick(result["ascii_input"], ("value", "ms_per_step", "search_ms", "offsets_and_hits_identical_to_headline"))
     lr = result.get("locate_roofline")
     if lr:
         line["locate_roofline"] = _pick(lr, ("kernel", "avg_launch_ms", "traffic", "frac", "hits_per_launch"))
@@ -1053,6 +1083,9 @@ def compact_line(result, side_file=None):
     if e and "error" not in e:
         line["end_to_end"] = _pick(e, ("count_qps", "locate_qps", "pcie_h2d_GBps", "pcie_d2h_GBps", "count_over_bound",
                                             "locate_over_bound"))
+        if isinstance(e.get("packed_uniform"), dict):
+            line["end_to_end"]["packed_uniform"] = _pick(e["packed_uniform"], ("count_qps", "locate_qps", "count_over_bound",
+                                                                                  "locate_over_bound"))
     line["index_build_seconds"] = result.get("index_build_seconds")
     line["side_file"] = side_file
     line = _num(line)
@@ -1707,7 +1740,7 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
         t_locate = dt if t_locate is None or dt < t_locate else t_locate
     same_total = total.value == total_hits and int(offs[-1]) == total_hits
     if last.get("ptr"):
-        lib.gdx_free_hits(last["ptr"])
+        lib.gdx_free_hits(last.pop("ptr"))
     if not same_counts or not same_total:
         raise SystemExit("PARITY FAILURE: the host-pointer calls disagree with the device-resident path")
     in_bytes = nbytes + 8 * (nq + 1)
@@ -1723,10 +1756,55 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
            "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
                     "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
            "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
-    if has_pair_lines:
-        res["packed_queries"] = packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms)
-    else:
-        res["packed_queries"] = "measured on the default structures (packed queries run on the pair-line kernels): see secondary"
+    res["packed_queries"] = packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms)
+    # the same two calls on the batch as 2-bit codes without offsets (gdx_query_layout_t: packed + uniform) when every read has
+    # the same length: 12.5 instead of 58 bytes per len-50 read over PCIe, nothing to stage but the codes
+    lens = (queries.qoff[1: nq + 1] - queries.qoff[:nq]) if nq else None
+    if nq and bool((lens == lens[0]).all().item()) and int(lens[0]) > 0:
+        ulen = int(lens[0])
+        packed = np.zeros(int(lib.gdx_packed_bytes(int(qoff[-1]))), dtype=np.uint8)
+        n_exc = C.c_uint64(0)
+        rc = lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq, packed.ctypes.data_as(u8p),
+                                  None, 0, C.byref(n_exc))
+        if rc == 0 and n_exc.value == 0:
+            lay = _lib.QueryLayout()
+            lib.gdx_query_layout_init(C.byref(lay))
+            lay.packed, lay.uniform_len = 1, ulen
+
+            def count_pu():
+                _lib.check(lib.gdx_count_many_layout(index._h, packed.ctypes.data_as(u8p), None, nq, C.byref(lay),
+                                                     counts.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+            t_c = best_of(count_pu)
+            same_c = bool(np.array_equal(counts, dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)))
+
+            def locate_pu():
+                ptr = C.POINTER(_lib.HitStruct)()
+                _lib.check(lib.gdx_locate_many_alloc_layout(index._h, packed.ctypes.data_as(u8p), None, nq, C.byref(lay),
+                                                            offs.ctypes.data_as(u64p), C.byref(ptr), C.byref(total),
+                                                            status.ctypes.data_as(u8p)))
+                last["ptr"] = ptr
+
+            t_l = None
+            for _ in range(3):
+                if last.get("ptr"):
+                    lib.gdx_free_hits(last.pop("ptr"))
+                t0 = time.perf_counter()
+                locate_pu()
+                dt = time.perf_counter() - t0
+                t_l = dt if t_l is None or dt < t_l else t_l
+            same_t = total.value == total_hits and int(offs[-1]) == total_hits
+            if last.get("ptr"):
+                lib.gdx_free_hits(last.pop("ptr"))
+            if not same_c or not same_t:
+                raise SystemExit("PARITY FAILURE: the packed + uniform host calls disagree with the device-resident path")
+            in_pu = (nq * ulen + 3) // 4
+            res["packed_uniform"] = {
+                "count_qps": nq / t_c, "count_seconds": t_c, "locate_qps": nq / t_l, "locate_seconds": t_l, "h2d_bytes": in_pu,
+                "count_over_bound": t_c / max(in_pu / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
+                "locate_over_bound": t_l / max(in_pu / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3),
+                "calls": "gdx_count_many_layout / gdx_locate_many_alloc_layout, layout = {packed, uniform_len}: 2-bit codes, no "
+                         "offsets", "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t}}
     log(f"[bench] end to end: {res}")
     return res
 

@@ -190,6 +190,10 @@ SIGNATURES = {
     "gdx_count_many_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_search_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp],
     "gdx_query_layout_init": [C.POINTER(QueryLayout)],
+    "gdx_count_many_layout": [vp, u8p, u64p, C.c_uint64, C.POINTER(QueryLayout), u64p, u8p],
+    "gdx_cursors_for_many_queries_layout": [vp, u8p, u64p, C.c_uint64, C.POINTER(QueryLayout), u64p, u64p, u8p],
+    "gdx_locate_many_alloc_layout": [vp, u8p, u64p, C.c_uint64, C.POINTER(QueryLayout), u64p, C.POINTER(C.POINTER(HitStruct)),
+                                     u64p, u8p],
     "gdx_locate_many_search_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
     "gdx_locate_many_search_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp],
     "gdx_count_many_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],

@@ -1271,6 +1271,60 @@ void apply_layout(gdx::SearchCall &c, const void *d_qbuf, const void *d_qoff, ui
 }
 }  // namespace
 
+// host-pointer calls on a batch in a layout (the chunked pipeline of host_api.hip)
+namespace {
+void host_layout(const gdx_query_layout_t *layout, bool &packed, uint64_t &uniform_len)
+{
+    gdx_query_layout_t l;
+    gdx_query_layout_init(&l);
+    if (layout) {
+        if (layout->struct_size < 16 || layout->struct_size > sizeof(l)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.struct_size");
+        std::memcpy(&l, layout, layout->struct_size);
+    }
+    if (l.packed != 0 && l.packed != 1) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.packed must be 0 or 1");
+    if (l.uniform_len >= (1ull << 21)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_query_layout_t.uniform_len must be below 2^21");
+    packed = l.packed != 0;
+    uniform_len = l.uniform_len;
+}
+}  // namespace
+
+int gdx_count_many_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                          const gdx_query_layout_t *layout, uint64_t *out_counts, uint8_t *out_status)
+{
+    return guarded([&] {
+        bool packed;
+        uint64_t ulen;
+        host_layout(layout, packed, ulen);
+        if (!out_counts && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_counts is null");
+        return deref(ix).cursors_for_many_queries(qbuf, qoff, nq, nullptr, nullptr, out_counts, out_status, packed, ulen);
+    });
+}
+
+int gdx_cursors_for_many_queries_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                        const gdx_query_layout_t *layout, uint64_t *out_start, uint64_t *out_end,
+                                        uint8_t *out_status)
+{
+    return guarded([&] {
+        bool packed;
+        uint64_t ulen;
+        host_layout(layout, packed, ulen);
+        if ((!out_start || !out_end) && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_start / out_end is null");
+        return deref(ix).cursors_for_many_queries(qbuf, qoff, nq, out_start, out_end, nullptr, out_status, packed, ulen);
+    });
+}
+
+int gdx_locate_many_alloc_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                 const gdx_query_layout_t *layout, uint64_t *out_hit_offsets, gdx_hit_t **out_hits,
+                                 uint64_t *out_total, uint8_t *out_status)
+{
+    return guarded([&] {
+        bool packed;
+        uint64_t ulen;
+        host_layout(layout, packed, ulen);
+        return deref(ix).locate_many_alloc(qbuf, qoff, nq, out_hit_offsets, out_hits, out_total, out_status, packed, ulen);
+    });
+}
+
 int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                               const gdx_query_layout_t *layout, void *d_records, void *d_compact, void *stream)
 {

@@ -100,14 +100,16 @@ public:
     // ---- host-pointer query API (each call uploads, runs, downloads, synchronises) -------------
     // packed: qbuf holds 2-bit codes and qoff counts symbols (include/gdx.h "packed queries")
     int cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
-                                 uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed = false) const;
+                                 uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed = false,
+                                 uint64_t uniform_len = 0) const;
     uint64_t pack_queries_host(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
                                uint64_t *out_exc, uint64_t capacity) const;
     int locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                     gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const;
     // the same as locate_many with a hit buffer the library allocates (malloc; the caller frees it): one pass
     int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
-                          gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
+                          gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status, bool packed = false,
+                          uint64_t uniform_len = 0) const;
     int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
                                  uint8_t *out_status) const;
     int cursor_extend_front_strings(uint64_t *start, uint64_t *end, const uint8_t *qbuf, const uint64_t *qoff, uint64_t m,
@@ -133,7 +135,8 @@ private:
     // chunked, three-deep pipeline behind the host-pointer query calls (host_api.hip)
     int host_pipeline(int kind, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a, uint64_t *out_b,
                       uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total,
-                      const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits, bool packed = false) const;
+                      const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits, bool packed = false,
+                      uint64_t uniform_len = 0) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
     void build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream);

@@ -246,10 +246,15 @@ __global__ __launch_bounds__(256) void unpack_status_kernel(const uint4 *__restr
         status[q] = static_cast<uint8_t>(rec[q].w >> 24);
 }
 
-void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, WorkerPool &pool)
+void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, WorkerPool &pool, uint64_t uniform_len)
 {
-    if (!qoff) fail(GDX_ERR_INVALID_ARGUMENT, "qoff is null");
     if (nq >= 0xffffffffull) fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 queries in one call");
+    if (uniform_len != 0) {  // a uniform batch: query i = symbols [i * uniform_len, (i + 1) * uniform_len), no offsets
+        if (uniform_len >= (1ull << 21)) fail(GDX_ERR_INVALID_ARGUMENT, "uniform_len must be below 2^21");
+        if (nq != 0 && !qbuf) fail(GDX_ERR_INVALID_ARGUMENT, "qbuf is null");
+        return;
+    }
+    if (!qoff) fail(GDX_ERR_INVALID_ARGUMENT, "qoff is null");
     std::atomic<bool> bad{false};
     pool.parallel_range(nq, 1, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; i++)
@@ -273,12 +278,16 @@ struct Chunk {
 int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a,
                            uint64_t *out_b, uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity,
                            uint64_t *out_total, const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits,
-                           bool packed) const
+                           bool packed, uint64_t uniform_len) const
 {
     // packed: qbuf holds 2-bit codes (symbol j in bits 2 (j & 3) of byte j >> 2) and qoff counts symbols
+    // uniform_len != 0: query i = symbols [i * uniform_len, (i + 1) * uniform_len) of the buffer, qoff is not looked at: no
+    // offsets are staged, copied or read by the kernels (gdx_query_layout_t)
     const Kind kind = static_cast<Kind>(kind_i);
     WorkerPool pool(host_threads());
-    check_queries(qbuf, qoff, nq, pool);
+    check_queries(qbuf, qoff, nq, pool, uniform_len);
+    const bool uniform = uniform_len != 0;
+    auto off_of = [&](uint64_t i) { return uniform ? i * uniform_len : qoff[i]; };
     if (out_total) *out_total = 0;
     if (kind == Kind::kLocate && out_a) out_a[0] = 0;
     if (nq == 0) return GDX_OK;
@@ -290,9 +299,12 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
     const uint64_t kChunkBytes = g_chunk_bytes.load(), kChunkQueries = g_chunk_queries.load();
     std::vector<Chunk> chunks;
+    // (uniform: every chunk but the last holds a multiple of 8 queries, so that a chunk starts on a 16-bit unit of a packed
+    // buffer and on a byte of an ASCII one, and is a uniform batch of its own)
+    const uint64_t uniform_chunk = uniform ? std::max<uint64_t>(8, std::min(kChunkQueries, kChunkBytes / uniform_len) / 8 * 8) : 0;
     for (uint64_t q0 = 0; q0 < nq;) {
-        uint64_t hi = std::min(nq, q0 + kChunkQueries);
-        if (qoff[hi] - qoff[q0] > kChunkBytes) {
+        uint64_t hi = std::min(nq, q0 + (uniform ? uniform_chunk : kChunkQueries));
+        if (!uniform && qoff[hi] - qoff[q0] > kChunkBytes) {
             const uint64_t *p = std::upper_bound(qoff + q0 + 1, qoff + hi + 1, qoff[q0] + kChunkBytes);
             hi = static_cast<uint64_t>(p - qoff) - 1;
             if (hi <= q0) hi = q0 + 1;  // a single query longer than a chunk
@@ -300,7 +312,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         Chunk c;
         c.q0 = q0;
         c.nq = hi - q0;
-        c.bytes = qoff[hi] - qoff[q0];
+        c.bytes = off_of(hi) - off_of(q0);
         chunks.push_back(c);
         q0 = hi;
     }
@@ -352,23 +364,28 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
         // packed: the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
-        const uint64_t base = packed ? (qoff[c.q0] & ~7ull) : qoff[c.q0];
+        const uint64_t base = packed ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
         const uint64_t src_byte = packed ? base / 4 : base;
-        const uint64_t n_bytes = packed ? div_ceil(qoff[c.q0 + c.nq] - base, 4) : c.bytes;
+        const uint64_t n_bytes = packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
         pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
-        pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
-        });
+        if (!uniform)
+            pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
+            });
         const uint64_t padded = div_ceil(n_bytes + 2, 8) * 8;
         std::memset(h_in[s] + n_bytes, 0, padded - n_bytes);  // windows may read past the last query
         GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
-        GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
+        if (!uniform) GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
         GDX_HIP(hipEventRecord(st.ev_in[s], st.in));
         GDX_HIP(hipStreamWaitEvent(st.k, st.ev_in[s], 0));
         SearchCall call;
         call.d_qbuf = d_qbuf[s];
-        call.d_qbeg = d_qoff[s];
-        call.d_qend = d_qoff[s] + 1;
+        if (uniform) {  // (base == the chunk's first symbol: the chunk is a uniform batch of its own)
+            call.uniform_len = static_cast<uint32_t>(uniform_len);
+        } else {
+            call.d_qbeg = d_qoff[s];
+            call.d_qend = d_qoff[s] + 1;
+        }
         call.nq = c.nq;
         call.packed = packed;
         if (kind == Kind::kIntervals) {
@@ -585,7 +602,7 @@ uint64_t FmIndex::pack_queries_host(const uint8_t *qbuf, const uint64_t *qoff, u
                                     uint64_t *out_exc, uint64_t capacity) const
 {
     WorkerPool pool(host_threads());
-    check_queries(qbuf, qoff, nq, pool);
+    check_queries(qbuf, qoff, nq, pool, 0);
     if (!out_packed && nq && qoff[nq]) fail(GDX_ERR_INVALID_ARGUMENT, "out_packed is null");
     const uint64_t n_sym = nq ? qoff[nq] : 0;
     const uint64_t n_bytes = div_ceil(n_sym, 4);
@@ -627,19 +644,20 @@ void set_host_chunking(uint64_t queries, uint64_t bytes)
 }
 
 int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_start,
-                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed) const
+                                      uint64_t *out_end, uint64_t *out_count, uint8_t *out_status, bool packed,
+                                      uint64_t uniform_len) const
 {
     if (packed && (view_.layout != 0 || view_.n_searchable < 4))
         fail(GDX_ERR_UNSUPPORTED, "packed queries need the rank-line layout (sigma <= 8) with dense symbols 1..4 searchable");
     if (out_start || out_end) {
         const int rc = host_pipeline(static_cast<int>(Kind::kIntervals), qbuf, qoff, nq, out_start, out_end, out_status,
-                                     nullptr, 0, nullptr, nullptr, packed);
+                                     nullptr, 0, nullptr, nullptr, packed, uniform_len);
         if (out_count && out_start && out_end)
             for (uint64_t i = 0; i < nq; i++) out_count[i] = out_end[i] - out_start[i];
         return rc;
     }
     return host_pipeline(static_cast<int>(Kind::kCounts), qbuf, qoff, nq, out_count, nullptr, out_status, nullptr, 0,
-                         nullptr, nullptr, packed);
+                         nullptr, nullptr, packed, uniform_len);
 }
 
 int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
@@ -650,8 +668,11 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
 }
 
 int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
-                               gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const
+                               gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status, bool packed,
+                               uint64_t uniform_len) const
 {
+    if (packed && (view_.layout != 0 || view_.n_searchable < 4))
+        fail(GDX_ERR_UNSUPPORTED, "packed queries need the rank-line layout (sigma <= 8) with dense symbols 1..4 searchable");
     if (!out_hits) fail(GDX_ERR_INVALID_ARGUMENT, "out_hits is null");
     *out_hits = nullptr;
     gdx_hit_t *buf = nullptr;
@@ -682,7 +703,7 @@ int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64
         // a first guess from the batch size spares most reallocations (one hit per query is the common shape)
         grow(nq + nq / 8, nullptr);
         rc = host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, buf, cap,
-                           out_total, &grow);
+                           out_total, &grow, packed, uniform_len);
     } catch (...) {
         std::free(buf);
         throw;

@@ -287,6 +287,51 @@ class FmIndex:
         hits = hits[: total.value]
         return off, hits[:, 0].copy(), hits[:, 1].copy(), status
 
+    def _layout(self, packed, uniform_len):
+        lay = _lib.QueryLayout()
+        self._lib.gdx_query_layout_init(C.byref(lay))
+        lay.packed, lay.uniform_len = (1 if packed else 0), int(uniform_len)
+        return lay
+
+    def count_layout_raw(self, qbuf, qoff, nq, packed=False, uniform_len=0, strict=True):
+        """gdx_count_many_layout: a packed (2-bit) and / or uniform (no offsets: qoff may be None) host batch"""
+        counts = np.zeros(nq, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        lay = self._layout(packed, uniform_len)
+        st = self._lib.gdx_count_many_layout(self._h, _p(qbuf, u8p), _p(qoff, u64p) if qoff is not None else None, nq,
+                                             C.byref(lay), _p(counts, u64p), _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return counts, status
+
+    def cursors_layout_raw(self, qbuf, qoff, nq, packed=False, uniform_len=0, strict=True):
+        s = np.zeros(nq, dtype=np.uint64)
+        e = np.zeros(nq, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        lay = self._layout(packed, uniform_len)
+        st = self._lib.gdx_cursors_for_many_queries_layout(self._h, _p(qbuf, u8p), _p(qoff, u64p) if qoff is not None else None,
+                                                           nq, C.byref(lay), _p(s, u64p), _p(e, u64p), _p(status, u8p))
+        _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+        return s, e, status
+
+    def locate_layout_raw(self, qbuf, qoff, nq, packed=False, uniform_len=0, strict=True):
+        """gdx_locate_many_alloc_layout -> (hit_offsets, text_ids, positions, status)"""
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        status = np.zeros(nq, dtype=np.uint8)
+        total = C.c_uint64(0)
+        ptr = C.POINTER(_lib.HitStruct)()
+        lay = self._layout(packed, uniform_len)
+        st = self._lib.gdx_locate_many_alloc_layout(self._h, _p(qbuf, u8p), _p(qoff, u64p) if qoff is not None else None, nq,
+                                                    C.byref(lay), _p(off, u64p), C.byref(ptr), C.byref(total), _p(status, u8p))
+        try:
+            _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+            n = total.value
+            hits = np.ctypeslib.as_array(C.cast(ptr, u64p), shape=(max(n, 1) * 2,))[: 2 * n].reshape(n, 2).copy() \
+                if n else np.zeros((0, 2), dtype=np.uint64)
+        finally:
+            if ptr:
+                self._lib.gdx_free_hits(ptr)
+        return off, hits[:, 0].copy(), hits[:, 1].copy(), status
+
     def locate_alloc_raw(self, qbuf, qoff, strict=True):
         """gdx_locate_many_alloc (one pass) -> (hit_offsets, text_ids, positions, status)"""
         nq = qoff.size - 1

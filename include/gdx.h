@@ -516,6 +516,18 @@ int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d
                                             const gdx_query_layout_t *layout, void *d_out_start, void *d_out_end,
                                             void *d_out_status, void *stream);
 
+/* The host-pointer calls on a batch in a layout: gdx_count_many / gdx_cursors_for_many_queries / gdx_locate_many_alloc
+ * (FmIndex::count_many lib.rs:155, cursors_for_many_queries :241, locate_many :179) through the same chunked pipeline.  A
+ * packed + uniform batch of len-50 reads moves 12.5 bytes per read over PCIe instead of 58, and no offsets are staged. */
+int gdx_count_many_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                          const gdx_query_layout_t *layout, uint64_t *out_counts, uint8_t *out_status);
+int gdx_cursors_for_many_queries_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                        const gdx_query_layout_t *layout, uint64_t *out_start, uint64_t *out_end,
+                                        uint8_t *out_status);
+int gdx_locate_many_alloc_layout(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                 const gdx_query_layout_t *layout, uint64_t *out_hit_offsets, gdx_hit_t **out_hits,
+                                 uint64_t *out_total, uint8_t *out_status);
+
 /* ---- batched cursor extension by strings (Cursor::extend_query_front, cursor.rs:34-51, applied to every symbol of
  * a string from its last to its first; ROADMAP.md:33 "API to use batched search with cursors") --------------------
  * Cursor i is extended by string i = d_qbuf[d_qbeg[i] .. d_qend[i]) (for a plain offsets array pass d_qoff and

@@ -1158,8 +1158,40 @@ def test_query_layouts_equal_plain_queries(seed, search_variant):
                 assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist(), what
                 h = hits[:total].cpu().numpy().astype(np.uint32)
                 assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist(), what
-    # what a layout must refuse
+    # the host-pointer calls on the same forms, through many small chunks (gdx_*_layout)
     lib = _lib.load()
+    length = 50
+    qs = []
+    for _ in range(3000):  # (texts over A C G T N have next to no N-free window of 50 symbols: then the random reads are the batch)
+        t = texts[int(rng.integers(0, len(texts)))]
+        if len(t) >= length:
+            pos = int(rng.integers(0, len(t) - length + 1))
+            if b"N" not in t[pos:pos + length]:
+                qs.append(t[pos:pos + length])
+    qs += [bytes(b"ACGT"[i] for i in rng.integers(0, 4, length)) for _ in range(500)]
+    qbuf, qoff = pack_queries(qs)
+    nq = len(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce)
+    packed = np.zeros(int(lib.gdx_packed_bytes(int(qoff[-1]))), dtype=np.uint8)
+    n_exc = C.c_uint64(0)
+    _lib.check(lib.gdx_pack_queries(g._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                    packed.ctypes.data_as(_lib.u8p), None, 0, C.byref(n_exc)))
+    assert n_exc.value == 0
+    lib.gdx_debug_set_host_chunking(203, 0)
+    try:
+        for buf, pk in ((qbuf, False), (packed, True)):
+            for off_arr, ul in ((qoff, 0), (None, length)):
+                what = f"host, packed={pk}, uniform_len={ul}"
+                cnt, st = g.count_layout_raw(buf, off_arr, nq, packed=pk, uniform_len=ul)
+                assert cnt.tolist() == (ce - cs).tolist() and not st.any(), what
+                s_, e_, st = g.cursors_layout_raw(buf, off_arr, nq, packed=pk, uniform_len=ul)
+                assert s_.tolist() == cs.tolist() and e_.tolist() == ce.tolist() and not st.any(), what
+                off, t_, p_, st = g.locate_layout_raw(buf, off_arr, nq, packed=pk, uniform_len=ul)
+                assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist(), what
+    finally:
+        lib.gdx_debug_set_host_chunking(0, 0)
+    # what a layout must refuse
     lay = _lib.QueryLayout()
     lib.gdx_query_layout_init(C.byref(lay))
     assert lay.struct_size == C.sizeof(_lib.QueryLayout) and lay.packed == 0 and lay.uniform_len == 0
