@@ -148,7 +148,7 @@ PMC_PASSES = [
     # under the traffic can be the profiler's as well as this process's HIP events (roofline.avg_launch_ms_rocprof)
     ("kernel_trace", None),
 ]
-KERNEL_REGEX = ("search_seed_kernel|search_seed_lane_kernel|seed_text_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
+KERNEL_REGEX = ("search_seed_kernel|search_seed_lane_kernel|seed_text_kernel|tile_sums_lists_kernel|scan2_sums_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
                 "search_kernel|search_verify_kernel|search_exact_kernel")
 
 
@@ -478,8 +478,19 @@ class StepRunner:
         torch = self.torch
         o, h, ws = self.outs[slot], self.hits[slot], self.ws[slot]
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # compact path: the hit totals come out of the search call itself (gdx_locate_many_search_totals_compact_layout_dev;
+        # GDX_BENCH_NO_FOLD=1: the separate totals pass of round 3)
+        fold = self.do_locate and self.use_compact and not self.fused_scan and os.environ.get("GDX_BENCH_NO_FOLD") != "1"
+        if fold and slot >= len(self.scan_ws):
+            dev_ = h.device
+            self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev_)
+                            for _ in range(self.n_slots)]
+            self.totals = [torch.zeros(2, dtype=torch.int64, device=dev_) for _ in range(self.n_slots)]
         a.record()
-        self.search(o)
+        if fold:
+            self.eng.locate_search_totals(self.q, o["rec"], o["compact"], self.scan_ws[slot], self.totals[slot])
+        else:
+            self.search(o)
         b.record()
         if record:
             self.ev_search.append((a, b))
@@ -519,12 +530,13 @@ class StepRunner:
                     self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev)
                                     for _ in range(self.n_slots)]
                     self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
-                ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ta.record()
-                self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], compact=o["compact"])
-                tb.record()
-                if record:
-                    self.ev_scan.append((ta, tb))
+                if not fold:
+                    ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ta.record()
+                    self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], compact=o["compact"])
+                    tb.record()
+                    if record:
+                        self.ev_scan.append((ta, tb))
                 tot, rest = (int(x) for x in self.totals[slot].tolist())
                 self.total_hits = tot
                 if tot > self.hits[slot].shape[0]:
@@ -743,7 +755,7 @@ def main():
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
     search_bytes = queries.total_bytes + (8 * nq if args.lookup_depth > 0 else 0) + 60 * lf_steps + 8 * nq
     if aux["seed"]["k"]:  # the seed kernel, the seed-aware verify kernel on what it listed, the general kernel on the rest
-        kernel_pattern = ("search_seed_lane_kernel|search_seed_kernel|seed_text_kernel|search_verify_kernel|" +
+        kernel_pattern = ("search_seed_lane_kernel|search_seed_kernel|seed_text_kernel|tile_sums_lists_kernel|search_verify_kernel|" +
                           ("search_pair_kernel" if aux["pair_lines"] else "search_kernel"))
     else:
         kernel_pattern = "search_fast_kernel|search_pair_kernel" if aux["pair_lines"] else "search_kernel"

@@ -196,6 +196,7 @@ SIGNATURES = {
                                      u64p, u8p],
     "gdx_locate_many_search_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
     "gdx_locate_many_search_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp],
+    "gdx_locate_many_search_totals_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), C.c_uint32, vp, vp, vp, vp, vp],
     "gdx_count_many_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
     "gdx_cursors_for_many_queries_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],

@@ -1344,6 +1344,40 @@ int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void 
     });
 }
 
+int gdx_locate_many_search_totals_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                                     const gdx_query_layout_t *layout, uint32_t max_hits, void *d_records,
+                                                     void *d_compact, void *d_scan_workspace, void *d_totals, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_compact && nq != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_compact is null");
+        if (!d_scan_workspace || !d_totals) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_search_totals_compact_layout_dev: null argument");
+        DeviceGuard guard(f.config().device_id);
+        unsigned long long *totals = static_cast<unsigned long long *>(d_totals);
+        GDX_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), as_stream(stream)));
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.d_compact = static_cast<uint32_t *>(d_compact);
+        c.mode = 1;
+        bool folded = false;
+        c.d_tile_sums = static_cast<unsigned long long *>(d_scan_workspace);
+        c.d_tile_rest = totals + 1;
+        c.tile_max_hits = max_hits;
+        c.tile_sums_done = &folded;
+        gdx::launch_search_call(f.view(), c, as_stream(stream), f.query_options());
+        GDX_HIP(hipGetLastError());
+        if (folded)  // the search counted the hits per tile itself: only the scan of the tile sums is left
+            gdx::launch_scan_totals_finish(d_scan_workspace, nq, totals, as_stream(stream));
+        else
+            gdx::launch_scan_totals(static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
+                                    false, d_scan_workspace, totals, as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
 int gdx_locate_many_search_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                       const gdx_query_layout_t *layout, void *d_records, void *stream)
 {

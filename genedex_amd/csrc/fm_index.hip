@@ -1163,10 +1163,16 @@ void FmIndex::finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream)
     // lookup tables, all depths concatenated (lookup_table.rs:163-181)
     lookup_off_host_.assign(kMaxLookupDepth + 2, 0);
     uint64_t entries = 0, pw = 1;
+    // (k^depth entries of 8 bytes: 22 searchable symbols overflow 64 bits at depth 15, 95 at depth 10 -- a table that cannot
+    // exist is an argument error, not a wrapped size and an out-of-bounds fill; 2^40 entries = 8 TB is beyond any device)
+    constexpr uint64_t kMaxLookupEntries = 1ull << 40;
     for (int t = 0; t <= cfg_.lookup_depth; t++) {
         lookup_off_host_[t] = entries;
         entries += pw;
-        pw *= static_cast<uint64_t>(cfg_.n_searchable);
+        if (entries > kMaxLookupEntries)
+            fail(GDX_ERR_INVALID_ARGUMENT, "lookup_table_depth %d with %d searchable symbols needs more than 2^40 table entries",
+                 cfg_.lookup_depth, cfg_.n_searchable);
+        if (t < cfg_.lookup_depth) pw *= static_cast<uint64_t>(cfg_.n_searchable);  // (pw <= entries <= 2^40: no overflow)
     }
     for (int t = cfg_.lookup_depth + 1; t < kMaxLookupDepth + 2; t++) lookup_off_host_[t] = entries;
     lookup_.alloc(entries);
@@ -1351,8 +1357,22 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             // (the full suffix array and the text units are asked for explicitly: they count, but do not shrink)
             // (the seed table: 16 bytes per distinct k-mer over the load factor -- about n k-mers)
             const double seed_load = (bo.seed_load_percent > 0 ? bo.seed_load_percent : 70) / 100.0;
+            // ... but never fewer than 2^(2k - 21) buckets of 128 bytes ((bucket, tag) must name a k-mer exactly with at most
+            // kSeedTagBitsMax tag bits: 17 GB for k = 24 whatever the text), and a placement that fails retries with a quarter
+            // more buckets: both are part of what the other tables have to leave room for
+            double seed_bytes = 0.0;
+            if (want_seed) {
+                seed_bytes = 16.0 / seed_load * static_cast<double>(n_);
+                if (2u * seed_k > kSeedTagBitsMax) seed_bytes = std::max(seed_bytes, 128.0 * static_cast<double>(1ull << (2u * seed_k - kSeedTagBitsMax)));
+                seed_bytes *= 1.25;
+                if (seed_bytes > budget && bo.seed_symbols > 1)  // an explicit k whose smallest table cannot fit: say so now
+                    fail(GDX_ERR_INVALID_ARGUMENT,
+                         "seed_symbols = %u needs a seed table of at least %.1f GB (2^(2k - 21) buckets of 128 bytes, or 16 bytes per "
+                         "k-mer over the load factor), the budget for auxiliary structures is %.1f GB: choose a smaller k or "
+                         "seed_symbols = 1", seed_k, seed_bytes / 1.25 / 1e9, budget / 1e9);
+            }
             const double fixed = ((want_sa_full ? 4.0 : 0.0) + (want_isa ? 4.0 : 0.0)) * static_cast<double>(n_) + (want_text ? 0.5 : 0.0) * static_cast<double>(n_) +
-                                 (want_seed ? 16.0 / seed_load : 0.0) * static_cast<double>(n_);
+                                 seed_bytes;
             auto need = [&] {
                 return fixed + static_cast<double>(jump_bytes) * static_cast<double>(n_) +
                        (top_depth ? 8.0 * static_cast<double>(1ull << (2u * top_depth)) : 0.0);

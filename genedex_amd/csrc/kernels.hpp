@@ -67,6 +67,7 @@ constexpr uint32_t kCompactSee = 0xfffffffeu;
 // are only meaningful through the hint or record; see search_pair_body); mode 2: cursor extension, start / end are
 // in / out.  Any output may be null.  rec: one 16-byte record per query {start, end, hint row, hint symbols |
 // status << 24} for launch_hit_offsets_rec / launch_locate.
+constexpr uint32_t kSumTile = 2048;  // queries per tile of the two-pass offsets scan (locate.hip: kScan2Tile)
 struct SearchCall {
     const uint8_t *d_qbuf = nullptr;
     const uint64_t *d_qbeg = nullptr, *d_qend = nullptr;
@@ -79,6 +80,14 @@ struct SearchCall {
     unsigned long long *d_step_stats = nullptr;
     int mode = 0;
     bool packed = false;  // d_qbuf holds 2-bit codes, d_qbeg / d_qend count symbols (rank-line layout, sigma <= 8)
+    // count / locate with compact results, optional: the hit totals of a locate folded into the search.  d_tile_sums[t] (one per
+    // kSumTile queries, written by the call) = the hit slots of the queries of tile t (RecordSize with tile_max_hits),
+    // *d_tile_rest (zeroed by the caller) += those of the queries whose compact result says "see the record"; *tile_sums_done
+    // (host) tells whether the call did it -- the seed table's lane kernel on an index without pair lines does, by counting
+    // what it answers and adding its (short) lists afterwards; otherwise launch_scan_totals reads the results once more
+    unsigned long long *d_tile_sums = nullptr, *d_tile_rest = nullptr;
+    uint32_t tile_max_hits = 0;
+    bool *tile_sums_done = nullptr;
     uint32_t uniform_len = 0;  // != 0: a uniform batch -- every query has this many symbols, query i starts at symbol
                                // i * uniform_len; d_qbeg / d_qend may be null (gdx_query_layout_t)
     CursorArgs cursors;
@@ -151,6 +160,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
 // (scan_totals_workspace_bytes); launch_scan_offsets_store then writes the offsets and, in the same pass, the hit of every
 // query whose compact result is its position.  launch_locate(..., compact_stored = true) fills what is left (totals[1]).
 size_t scan_totals_workspace_bytes(uint64_t m);
+void launch_scan_totals_finish(void *d_scan_workspace, uint64_t m, unsigned long long *d_totals, hipStream_t stream);
 void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits, bool take,
                         void *d_scan_workspace, unsigned long long *d_totals, hipStream_t stream);
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,

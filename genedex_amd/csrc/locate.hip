@@ -964,6 +964,18 @@ void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t 
     GDX_HIP(hipMemcpyAsync(d_totals, sums + n_tiles, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
 }
 
+// the second half of launch_scan_totals when the search call has filled the tile sums itself (SearchCall::d_tile_sums;
+// d_totals[1] holds the open slots already)
+void launch_scan_totals_finish(void *d_scan_workspace, uint64_t m, unsigned long long *d_totals, hipStream_t stream)
+{
+    static_assert(kScan2Tile == kSumTile, "the search kernels count hits per tile of the offsets scan");
+    if (m == 0) return;
+    const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
+    unsigned long long *sums = static_cast<unsigned long long *>(d_scan_workspace);
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
+    GDX_HIP(hipMemcpyAsync(d_totals, sums + n_tiles, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+}
+
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
                                bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
                                uint64_t hits_capacity, bool wide, hipStream_t stream, bool store, uint8_t *d_chunk_flags)

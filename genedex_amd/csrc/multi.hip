@@ -319,6 +319,9 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
         all_same &= dev[r] == dev[0];
         for (size_t k = 0; k < r; k++) all_distinct &= dev[k] != dev[r];
         if (shards[r].nq != 0 && (!shards[r].d_qoff || !shards[r].d_qbuf)) fail(GDX_ERR_INVALID_ARGUMENT, "shard %zu: null pointer", r);
+        // (the search kernels read the query bytes as aligned 8-byte words, like gdx_locate_many_search_compact_dev)
+        if (shards[r].nq != 0 && (reinterpret_cast<uintptr_t>(shards[r].d_qbuf) & 7u) != 0)
+            fail(GDX_ERR_INVALID_ARGUMENT, "shard %zu: d_qbuf must be 8-byte aligned", r);
     }
     std::lock_guard<std::recursive_mutex> serial(m.call_mutex);  // the handle's result buffers are this call's until it returns
     const bool use_rccl = g > 1 && !all_same;
@@ -326,14 +329,30 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
     if (use_rccl && !rccl().ok) fail(GDX_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded");
 
     // every replica: search -> scan -> locate of its shard on its own device and stream (the replica's worker thread)
+    // (the buffers and the stream of a replica are released on its device whichever way this function is left: a failing
+    // shard throws out of run_shards)
     struct Local {
         DeviceBuffer<uint32_t> counts;
         DeviceBuffer<uint8_t> status;
         DeviceBuffer<gdx_hit32_t> hits;
         hipStream_t stream = nullptr;
         uint64_t total = 0;
+        int device = -1;
+        Local() = default;
+        Local(const Local &) = delete;
+        Local &operator=(const Local &) = delete;
+        ~Local()
+        {
+            if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+            if (stream) (void)hipStreamSynchronize(stream);
+            counts.release();
+            status.release();
+            hits.release();
+            if (stream) (void)hipStreamDestroy(stream);
+        }
     };
     std::vector<Local> loc(g);
+    for (size_t r = 0; r < g; r++) loc[r].device = dev[r];
     const int rc = run_shards(m, 0, [&](size_t r, uint64_t, uint64_t, ShardResult &) {
         GDX_HIP(hipSetDevice(dev[r]));
         GDX_HIP(hipStreamCreateWithFlags(&loc[r].stream, hipStreamNonBlocking));
@@ -341,7 +360,8 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
                                                        loc[r].status, loc[r].hits, loc[r].stream);
         return static_cast<int>(GDX_OK);
     });
-    (void)rc;
+    // (GDX_ERR_QUERY_STATUS: some query has a status byte set -- they are gathered into out->d_status like the counts)
+    if (rc != GDX_OK && rc != GDX_ERR_QUERY_STATUS) fail(static_cast<gdx_status>(rc), "a shard failed");
     // where every shard lands on the root
     std::vector<uint64_t> qbase(g + 1, 0), hbase(g + 1, 0);
     for (size_t r = 0; r < g; r++) {
@@ -404,13 +424,8 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
         GDX_HIP(hipSetDevice(dev[r]));
         GDX_HIP(hipStreamSynchronize(loc[r].stream));
     }
-    for (size_t r = 0; r < g; r++) {
-        GDX_HIP(hipSetDevice(dev[r]));
-        loc[r].counts.release();
-        loc[r].status.release();
-        loc[r].hits.release();
-        (void)hipStreamDestroy(loc[r].stream);
-    }
+    loc.clear();  // (releases every replica's buffers and stream on its device)
+    GDX_HIP(hipSetDevice(dev[root]));
     out->d_counts = m.g_counts.get();
     out->d_hit_offsets = m.g_offsets.get();
     out->d_hits = m.g_hits.get();

@@ -100,12 +100,16 @@ int Parts::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t
             for (uint64_t i = 0; i < nq; i++)
                 if (st[i] == 0) st[i] = st_part[i];
         }
-        // global offsets: query i holds the hits of part 0, then part 1, ... (a query with a status has none)
+        // global offsets: query i holds the hits of part 0, then part 1, ... (a query with a status has none); with
+        // gdx_query_options_t.max_hits_per_query = k every part has located at most k hits of a query, and the merged
+        // query keeps the first k of them -- locate(q).take(k) of the whole collection, not k per part
+        const uint64_t cap = parts[0]->query_options().max_hits_per_query;
         out_hit_offsets[0] = 0;
         for (uint64_t i = 0; i < nq; i++) {
             uint64_t c = 0;
             if (st[i] == 0)
                 for (size_t k = 0; k < g; k++) c += off[k][i + 1] - off[k][i];
+            if (cap != 0 && c > cap) c = cap;
             out_hit_offsets[i + 1] = out_hit_offsets[i] + c;
         }
         const uint64_t n_hits = out_hit_offsets[nq];
@@ -122,9 +126,10 @@ int Parts::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t
                     for (uint64_t i = nq * t / nt; i < nq * (t + 1) / nt; i++) {
                         if (st[i] != 0) continue;
                         gdx_hit_t *dst = all + out_hit_offsets[i];
-                        for (size_t k = 0; k < g; k++) {
+                        gdx_hit_t *const end = all + out_hit_offsets[i + 1];
+                        for (size_t k = 0; k < g && dst < end; k++) {
                             const uint64_t a = off[k][i], b = off[k][i + 1];
-                            for (uint64_t h = a; h < b; h++) {
+                            for (uint64_t h = a; h < b && dst < end; h++) {
                                 dst->text_id = hits[k][h].text_id + first_text[k];
                                 dst->position = hits[k][h].position;
                                 dst++;

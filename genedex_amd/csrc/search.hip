@@ -2576,7 +2576,8 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state,
     uint32_t *__restrict__ out_compact, uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long,
-    uint2 *__restrict__ long_state, uint32_t long_stride, uint32_t state_packed, uint32_t ulen)
+    uint2 *__restrict__ long_state, uint32_t long_stride, uint32_t state_packed, uint32_t ulen,
+    unsigned long long *__restrict__ tile_sums)  // != null: += the hits this kernel answers itself, per kSumTile queries
 {
     static_assert(kXlate == 1 || kXlate == 2, "v_perm tables or packed queries");
     constexpr uint32_t kWaves = kBlock / 64;
@@ -2626,8 +2627,9 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         __builtin_amdgcn_wave_barrier();
         return s_e[wave][lane];
     };
-    // S2 of a read whose entry (or absence) is known; slot = its place in the range (0xffffffff: not known any more)
-    auto finish = [&](uint32_t q, uint32_t slot, uint32_t rem, uint64_t qcode, const u32x4 &en) {
+    // S2 of a read whose entry (or absence) is known; slot = its place in the range (0xffffffff: not known any more);
+    // returns the hits it stored (0 or 1; a read it lists for another kernel: 0)
+    auto finish = [&](uint32_t q, uint32_t slot, uint32_t rem, uint64_t qcode, const u32x4 &en) -> uint32_t {
         const uint32_t ex = en.x, ey = en.y, ez = en.z, ew = en.w;
         const bool found = (ex & kSeedFound) != 0u;
         if (found && (ex & kSeedKind) != 0u) {
@@ -2641,7 +2643,7 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
                 else state[q] = make_uint4(ey, kStatePlain | rem, ez, 0u);
             }
             if (out_compact) out_compact[q] = kCompactSee;
-            return;
+            return 0u;
         }
         bool hit = false;
         const uint32_t pos = ey;
@@ -2658,13 +2660,14 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
             else long_list[atomicAdd(n_long, 1u)] = q;
             long_state[static_cast<uint64_t>(q) * long_stride] = make_uint2(pos, rem);
             if (out_compact) out_compact[q] = kCompactSee;  // (seed_text_kernel4 writes the result)
-            return;
+            return 0u;
         }
         // (no row is known, and none is needed: a resolved record is its position)
         if (out_compact) out_compact[q] = hit ? pos - rem : kCompactNone;
         else if (out_rec) out_rec[q] = hit ? make_uint4(0u, 1u, pos - rem, kRecResolved) : make_uint4(0u, 0u, 0xffffffffu, 0u);
         if (out_count) out_count[q] = hit ? 1u : 0u;
         if (out_status) out_status[q] = 0;
+        return hit ? 1u : 0u;
     };
     // parks the reads of the lanes with `again` set: the next bucket, one more displacement
     auto park = [&](bool again, uint32_t q, uint32_t bucket, uint32_t tagd, uint32_t rem, uint64_t qcode) {
@@ -2705,7 +2708,8 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         s_bt[wave][lane] = make_uint2(bucket, tagd);
         const u32x4 en = gather();
         const bool again = mine && goes_on(en, tagd);
-        if (mine && !again) finish(q, 0xffffffffu, rem, qcode, en);
+        if (mine && !again && finish(q, 0xffffffffu, rem, qcode, en) != 0u && tile_sums != nullptr)
+            atomicAdd(&tile_sums[q / kSumTile], 1ull);
         park(again, q, bucket, tagd, rem, qcode);
     };
 
@@ -2807,7 +2811,11 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
                 if (out_compact) out_compact[q] = kCompactSee;
             }
             const bool again = look && goes_on(en, tag);
-            if (look && !again) finish(q, slot, rem, qcode, en);
+            const uint32_t stored = (look && !again) ? finish(q, slot, rem, qcode, en) : 0u;
+            if (tile_sums != nullptr) {  // (a chunk of 64 lies inside one tile: ranges are multiples of 64)
+                const unsigned long long hm = __ballot(stored != 0u);
+                if (lane == 0u && hm != 0ull) atomicAdd(&tile_sums[(base + ch * 64u) / kSumTile], static_cast<unsigned long long>(__popcll(hm)));
+            }
             park(again, q, bucket, tag, rem, qcode);
             if (n_parked >= 64u) parked_pass();
         }
@@ -3190,6 +3198,40 @@ __global__ __launch_bounds__(kBlock) void fill_uniform_offsets_kernel(uint64_t *
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) off[i] = i * ulen;
 }
 
+// The tile sums of a locate that the seed table's lane kernel began (SearchCall::d_tile_sums): the reads on its two lists,
+// once every kernel of the call has written their results.  left: everything listed for the next kernels (compact result
+// "see the record": the record's count, also into *rest); long: reads finished by seed_text_kernel4 (those it handed on
+// are on the left list as well, and counted there).
+__global__ __launch_bounds__(kBlock) void tile_sums_lists_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ compact,
+                                                                 uint32_t max_hits, const uint32_t *__restrict__ left,
+                                                                 const uint32_t *__restrict__ n_left, const uint32_t *__restrict__ lng,
+                                                                 const uint32_t *__restrict__ n_lng,
+                                                                 unsigned long long *__restrict__ tile_sums,
+                                                                 unsigned long long *__restrict__ rest)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const uint64_t nl = *n_left, ng = *n_lng;
+    unsigned long long open_slots = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < nl + ng; i += stride) {
+        const bool is_left = i < nl;
+        const uint32_t q = is_left ? left[i] : lng[i - nl];
+        const uint32_t c4 = compact[q];
+        unsigned long long c = 0;
+        if (c4 == kCompactSee) {
+            if (!is_left) continue;
+            const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
+            const uint32_t n = v.y - v.x;
+            c = (max_hits != 0u && n > max_hits) ? 0ull : static_cast<unsigned long long>(n);
+            open_slots += c;
+        } else {
+            if (is_left) continue;  // (cannot be: a listed read keeps "see the record")
+            c = c4 == kCompactNone ? 0ull : 1ull;
+        }
+        if (c != 0ull) atomicAdd(&tile_sums[q / kSumTile], c);
+    }
+    if (open_slots != 0ull) atomicAdd(rest, open_slots);
+}
+
 void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream, const QueryOptions &qo)
 {
     SearchCall c = call;
@@ -3246,6 +3288,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
     uint32_t *seed_list = nullptr;  // ... the seed kernel's, with each read's state in its record slot: search_fast_kernel4 next
     uint32_t seed_state_packed = 0;  // ... in the packed form (kStatePacked)
     bool compact_by_seed = false;   // c.d_compact has been filled by the seed kernel
+    uint32_t *fold_left = nullptr, *fold_long = nullptr;  // the lane kernel's lists when it counts the hit totals (d_tile_sums)
+    if (c.tile_sums_done != nullptr) *c.tile_sums_done = false;
     if (c.d_compact != nullptr && (c.mode != 1 || c.d_rec == nullptr))
         fail(GDX_ERR_INVALID_ARGUMENT, "internal: compact results go with the records of a count / locate search");
     // Count / locate searches on an index with text units and no jump table: top table, then the rest of the query against
@@ -3340,11 +3384,23 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     static const int env_lane = [] { const char *e = getenv("GDX_SEED_LANE"); return e ? atoi(e) : 1; }();
                     const bool lane_kernel = env_lane != 0 && xlate != 0 && ix.seed_k <= 24u && ix.seed_k >= 8u &&
                                              (reinterpret_cast<uintptr_t>(c.d_qbuf) & 3u) == 0;
+                    // the locate's hit totals folded into this call (SearchCall::d_tile_sums): the lane kernel counts what it
+                    // answers, tile_sums_lists_kernel adds its two lists once the whole chain has run (end of this function; the
+                    // pair-line branch returns earlier, hence only without pair lines)
+                    unsigned long long *fold = nullptr;
+                    if (lane_kernel && c.d_tile_sums != nullptr && c.d_tile_rest != nullptr && c.d_compact != nullptr &&
+                        !(variant == 2 && ix.pair_lines != nullptr)) {
+                        fold = c.d_tile_sums;
+                        GDX_HIP(hipMemsetAsync(fold, 0, ((nq + kSumTile - 1) / kSumTile) * sizeof(unsigned long long), stream));
+                        fold_left = d_first;
+                        fold_long = d_long;
+                    }
 #define GDX_SEED_LANE_LAUNCH(XLATE, UNIFORM)                                                                                    \
     do {                                                                                                                       \
         hipLaunchKernelGGL((search_seed_lane_kernel<XLATE, UNIFORM>), dim3(v_blocks), dim3(kBlock), seed_pad, stream, sv,      \
                            c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first,    \
-                           d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride, seed_state_packed, ulen);  \
+                           d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride, seed_state_packed, ulen,   \
+                           fold);                                                                                              \
         hipLaunchKernelGGL((seed_text_kernel4<XLATE, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg, \
                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
                            c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
@@ -3656,6 +3712,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
     else if (ix.layout == 0) GDX_PLAIN_LAUNCH(LineTable, 1, grid_for_items(nq));
     else GDX_PLAIN_LAUNCH(GenericTable, 1, grid_for_items(nq));
 #undef GDX_PLAIN_LAUNCH
+    if (fold_left != nullptr) {
+        hipLaunchKernelGGL(tile_sums_lists_kernel, dim3(256), dim3(kBlock), 0, stream, c.d_rec, c.d_compact, c.tile_max_hits,
+                           fold_left + 4, fold_left, fold_long + 4, fold_long, c.d_tile_sums, c.d_tile_rest);
+        if (c.tile_sums_done != nullptr) *c.tile_sums_done = true;
+    }
 }
 
 // ASCII -> 2-bit: packed byte b holds the codes of bytes 4 b .. 4 b + 3 of the query buffer; *bad_symbols counts the

@@ -246,6 +246,14 @@ class DeviceEngine:
             return
         _lib.check(self.lib.gdx_locate_many_search_dev(self.h, _ptr(q.qbuf), _ptr(q.qoff), q.nq, _ptr(rec), _stream()))
 
+    def locate_search_totals(self, q: DeviceQueries, rec: torch.Tensor, compact: torch.Tensor, scan_ws: torch.Tensor,
+                             totals: torch.Tensor, max_hits: int = 0) -> None:
+        """gdx_locate_many_search_totals_compact_layout_dev: the compact search and the hit totals in one call"""
+        lay, qoff = q.layout()
+        _lib.check(self.lib.gdx_locate_many_search_totals_compact_layout_dev(
+            self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay) if lay is not None else None, max_hits, _ptr(rec), _ptr(compact),
+            _ptr(scan_ws), _ptr(totals), _stream()))
+
     def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, max_hits: int = 0,
                        compact: torch.Tensor = None) -> None:
         """max_hits != 0: queries with more occurrences are counted but get no hit slots"""

@@ -580,7 +580,10 @@ class PartitionedFmIndex:
     def set_query_options(self, **kw) -> None:
         o = _lib.QueryOptions()
         self._lib.gdx_query_options_init(C.byref(o))
+        known = {name for name, _ in _lib.QueryOptions._fields_} - {"struct_size"}
         for k, v in kw.items():
+            if k not in known:  # (setattr on a ctypes struct would take any name and change nothing)
+                raise TypeError(f"unknown query option {k!r}; gdx_query_options_t has {sorted(known)}")
             setattr(o, k, int(v))
         _lib.check(self._lib.gdx_parts_set_query_options(self._h, C.byref(o)))
 

@@ -155,7 +155,10 @@ typedef struct {
                                   the text -- nearly every read of a text without repeats -- the entry also holds its position and
                                   the 32 symbols in front of it, so a read of up to k + 32 symbols is counted AND located with that
                                   single fetch; longer reads go on against the text units, k-mers on several rows hand over their
-                                  suffix-array interval (results are the reference's either way).  gdx_index_seed_info reports   */
+                                  suffix-array interval (results are the reference's either way).  gdx_index_seed_info reports.
+                                  The table has at least 2^(2k - 21) buckets of 128 bytes whatever the text (17 GB for k = 24, 1 GB
+                                  for k = 22, 67 MB for k = 20): an explicit k whose table does not fit the budget for auxiliary
+                                  structures is refused (GDX_ERR_INVALID_ARGUMENT); 1 picks a k the text fills                    */
     int32_t seed_load_percent; /* 0 default (70): slots of the seed table filled on average, 20..100 (fewer: more memory, fewer
                                   reads that need a second bucket)                                                                */
     int32_t inverse_suffix_array; /* -1 / 0 default off, 1: ISA[position] = row as its own array (4 bytes per symbol).  With it and a
@@ -239,7 +242,9 @@ typedef struct {
     uint32_t max_hits_per_query; /* gdx_locate_many / gdx_locate_many_alloc / gdx_multi_locate_many_alloc: at most this many
                                 hits per query, the first ones in suffix-array order -- locate(q).take(k) of the reference's
                                 lazy iterator (lib.rs:187-197): one poly-A read on a genome would otherwise materialise
-                                gigabytes of hits.  hit_offsets then counts the hits RETURNED.  0 = all (default)        */
+                                gigabytes of hits.  hit_offsets then counts the hits RETURNED.  0 = all (default).
+                                gdx_parts_locate_many_alloc: at most this many per query over ALL parts (the first k in
+                                part order, suffix-array order inside a part)                                        */
     int32_t search_seed;     /* -1 default (1): count / locate searches start from the seed table when the index has one
                                 (gdx_build_options_t.seed_symbols); 0 = as if it had none                                    */
 } gdx_query_options_t;
@@ -510,6 +515,14 @@ int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void 
                                               const gdx_query_layout_t *layout, void *d_records, void *d_compact, void *stream);
 int gdx_locate_many_search_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                       const gdx_query_layout_t *layout, void *d_records, void *stream);
+/* gdx_locate_many_search_compact_layout_dev and gdx_locate_many_totals_compact_dev in one call: d_scan_workspace
+ * (gdx_locate_many_totals_workspace_bytes(nq)) and d_totals (u64[2]: all hit slots, those the compact results leave open)
+ * are what gdx_locate_many_offsets_hits_compact_dev takes next.  On an index whose count / locate search is the seed
+ * table's lane kernel the search counts its hits per scan tile while it stores them, and the separate pass over the compact
+ * results (4 bytes per query) is gone; on any other index the call is the two calls one after the other. */
+int gdx_locate_many_search_totals_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                                     const gdx_query_layout_t *layout, uint32_t max_hits, void *d_records,
+                                                     void *d_compact, void *d_scan_workspace, void *d_totals, void *stream);
 int gdx_count_many_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                               const gdx_query_layout_t *layout, void *d_out_counts, void *d_out_status, void *stream);
 int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
@@ -617,9 +630,11 @@ int gdx_parts_locate_many_alloc(const gdx_parts_t *p, const uint8_t *qbuf, const
  * counts into global hit offsets.  Order preserving: shard r's queries and hits follow shard r - 1's, so the output is
  * the one-GPU output of the concatenated batch.  The result buffers belong to the handle and stay valid until the next
  * gather call on it or gdx_multi_free.  Replicas must sit on distinct devices (RCCL, loaded on first use), or all on
- * one device (plain device copies; what a single-GPU box can test). */
+ * one device (plain device copies; what a single-GPU box can test).  The shards' buffers must be complete before the call
+ * (the call works on streams of its own: synchronise the stream that filled them, or the device); the call returns when
+ * the gathered results are in place.  d_qbuf of every non-empty shard must be 8-byte aligned. */
 typedef struct {
-    const void *d_qbuf; /* query bytes, on the device of replica r            */
+    const void *d_qbuf; /* query bytes, on the device of replica r (8-byte aligned)  */
     const void *d_qoff; /* u64[nq + 1] offsets into d_qbuf, on the same device */
     uint64_t nq;
 } gdx_device_shard_t;

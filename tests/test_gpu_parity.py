@@ -1210,6 +1210,22 @@ def test_query_layouts_equal_plain_queries(seed, search_variant):
         DeviceQueries.from_host(*pack_queries([b"ACGT", b"ACNT"])).as_packed(g)
 
 
+def test_a_lookup_table_that_cannot_exist_is_refused():
+    """k^depth table entries: 95 searchable symbols overflow 64 bits at depth 10, 20 at depth 15 -- an argument error
+    (GDX_ERR_INVALID_ARGUMENT) at build time, never a wrapped size; a table that merely does not fit the device fails as an
+    allocation (GDX_ERR_DEVICE) as before; the same alphabets at small depths still build."""
+    from genedex_amd import GdxError, _lib
+
+    for a, depths in ((alph.ascii_printable(), (7, 10, 24)), (alph.ascii_amino_acid(), (10, 15, 24))):
+        texts = [bytes(a.dense_to_io_table[:12]) * 20]
+        for depth in depths:
+            with pytest.raises(GdxError) as e:
+                gpu_index(texts, a, depth=depth)
+            assert e.value.status == _lib.GDX_ERR_INVALID_ARGUMENT and "2^40" in str(e.value), (depth, str(e.value))
+        g = gpu_index(texts, a, depth=2)
+        assert g.count(texts[0][:12]) == 20
+
+
 @pytest.mark.parametrize("depth", [16, 19])
 def test_lookup_tables_deeper_than_fifteen(depth):
     """The reference indexes its lookup tables with const-curried code up to depth 15 and a dynamic loop beyond

@@ -106,23 +106,34 @@ def test_exact_intervals_through_seed_table_and_inverse_suffix_array(seed):
         assert cur.count() == len(naive_search(texts, q, fold=a.io_to_dense_table))
 
 
-def device_locate(g, qs, compact, max_hits=0, fused=False):
-    """search -> offsets -> hits on the device through the records calls, with or without the compact results"""
+def device_locate(g, qs, compact, max_hits=0, fused=False, packed=False):
+    """search -> offsets -> hits on the device through the records calls, with or without the compact results;
+    fused = "search": the hit totals come out of the search call itself (gdx_locate_many_search_totals_compact_layout_dev)"""
     import torch
 
     from genedex_amd.device import DeviceEngine, DeviceQueries
 
     eng = DeviceEngine(g)
     dq = DeviceQueries.from_host(*pack_queries(qs))
+    if packed:
+        dq = dq.as_packed(g)
     rec = eng.alloc_records(dq.nq)
     rec.fill_(0x5a5a5a5a)  # (stale bytes: the compact path leaves the records of answered reads untouched)
     cmp_ = eng.alloc_compact(dq.nq) if compact else None
     off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
-    eng.locate_search(dq, rec, compact=cmp_)
+    if fused != "search":
+        eng.locate_search(dq, rec, compact=cmp_)
     if fused:  # totals -> (host) -> offsets + the compactly answered hits in one pass, then the rest
         sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
         totals = torch.zeros(2, dtype=torch.int64, device="cuda")
-        eng.locate_totals(rec, dq.nq, sws, totals, max_hits, compact=cmp_)
+        if fused == "search":
+            eng.locate_search_totals(dq, rec, cmp_, sws, totals, max_hits)
+            check = torch.zeros(2, dtype=torch.int64, device="cuda")
+            sws2 = torch.empty_like(sws)
+            eng.locate_totals(rec, dq.nq, sws2, check, max_hits, compact=cmp_)
+            assert totals.tolist() == check.tolist()  # the folded totals are those of the separate pass
+        else:
+            eng.locate_totals(rec, dq.nq, sws, totals, max_hits, compact=cmp_)
         tot, rest = (int(x) for x in totals.tolist())
         hits = torch.full((max(tot, 1), 2), -7, dtype=torch.int32, device="cuda")
         ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
@@ -162,8 +173,9 @@ def test_compact_results_equal_records_and_oracle(seed):
     qs = [q for q in mixed_queries(rng, texts, 600, 200, 120) + [b"", b"ACGTACGTACGT"] if b"N" not in q]
     co, ct, cp = c.locate_many(qs)
     got = {}
-    for compact, fused in ((False, False), (True, False), (True, True), (False, True)):
-        off, hits, counts, stat, answered = device_locate(g, qs, compact, fused=fused)
+    for compact, fused, packed in ((False, False, False), (True, False, False), (True, True, False), (False, True, False),
+                                   (True, "search", False), (True, "search", True), (True, True, True)):
+        off, hits, counts, stat, answered = device_locate(g, qs, compact, fused=fused, packed=packed)
         assert off.tolist() == co.tolist()
         assert hits[:, 0].tolist() == ct.astype(np.uint32).tolist() and hits[:, 1].tolist() == cp.astype(np.uint32).tolist()
         assert counts.tolist() == np.diff(co).astype(np.uint32).tolist() and not stat.any()
@@ -178,6 +190,8 @@ def test_compact_results_equal_records_and_oracle(seed):
     assert off_a.tolist() == off_b.tolist() and hits_a.tolist() == hits_b.tolist()
     off_c, hits_c, _, _, _ = device_locate(g, qs, True, max_hits=2, fused=True)
     assert off_a.tolist() == off_c.tolist() and hits_a.tolist() == hits_c.tolist()
+    off_d, hits_d, _, _, _ = device_locate(g, qs, True, max_hits=2, fused="search")
+    assert off_a.tolist() == off_d.tolist() and hits_a.tolist() == hits_d.tolist()
 
 
 @pytest.mark.parametrize("copies", [3, 40, 300])
