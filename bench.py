@@ -547,9 +547,15 @@ class StepRunner:
                     self.ws[slot] = torch.empty(need, dtype=torch.uint8, device=h.device)
                     ws = self.ws[slot]
                 c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                # narrow hit offsets (u32[nq + 1], gdx_locate_many_offsets32_hits_compact_dev) when the hits fit 32 bits and
+                # nothing else of the step reads them (N = 1); widen_offsets() makes them the step's offsets for every check
+                narrow = self.n_slots == 1 and tot < (1 << 31) and os.environ.get("GDX_BENCH_OFFSETS32") != "0"
+                if narrow and "hit_offsets32" not in o:
+                    o["hit_offsets32"] = torch.empty(self.nq + 1, dtype=torch.int32, device=h.device)
+                self.narrow_offsets = narrow
                 c.record()
-                self.eng.locate_offsets_hits(o["rec"], self.nq, self.scan_ws[slot], o["hit_offsets"], tot, rest, h, ws,
-                                             compact=o["compact"])
+                self.eng.locate_offsets_hits(o["rec"], self.nq, self.scan_ws[slot], o["hit_offsets32"] if narrow else o["hit_offsets"],
+                                             tot, rest, h, ws, compact=o["compact"])
                 d.record()
                 if record:
                     self.ev_locate.append((c, d))
@@ -574,6 +580,14 @@ class StepRunner:
                     self.ev_locate.append((c, d))
             if after is not None:
                 after(slot)
+
+    def widen_offsets(self):
+        """after the timed steps: the narrow offsets of the last step become `hit_offsets` (u64), which every check reads"""
+        if getattr(self, "narrow_offsets", False):
+            for o in self.outs:
+                if "hit_offsets32" in o:
+                    o["hit_offsets"].copy_(o["hit_offsets32"])
+        return getattr(self, "narrow_offsets", False)
 
     @staticmethod
     def mean_ms(events):
@@ -727,6 +741,7 @@ def main():
         gather, count_of, gathered_bytes = make_gather(torch, gdist, runner, dev, do_locate)
     elapsed, _ = timed_steps(torch, gdist, runner, args.steps, args.warmup, dev, gather, count_of,
                              overlap=do_locate and args.overlap)
+    narrow_offsets = runner.widen_offsets()
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * world / (ms_per_step / 1e3)
     search_ms = runner.mean_ms(runner.ev_search)
@@ -740,6 +755,7 @@ def main():
         if r2.size() != total_hits:
             raise SystemExit("PARITY FAILURE: the ascii form of the batch gives another number of hits")
         e2, _ = timed_steps(torch, gdist, r2, args.steps, args.warmup, dev)
+        r2.widen_offsets()
         same = bool(torch.equal(r2.outs[0]["hit_offsets"], out["hit_offsets"])) and \
             (not do_locate or bool(torch.equal(r2.hits[0][:total_hits], runner.hits[0][:total_hits])))
         if not same:
@@ -899,6 +915,7 @@ def main():
                                 f"top table; {wl['label']}"),
                    "index_gb_per_replica": index.info.device_bytes / 1e9,
                    "name": args.workload, "op": args.op, "path": args.path, "input": args.input, "queries_per_gpu": nq,
+                   "hit_offsets": "u32" if narrow_offsets else "u64",
                    "query_bytes_per_gpu": run_queries.total_bytes + (0 if run_queries.uniform_len else 8 * (nq + 1)),
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
@@ -1069,7 +1086,7 @@ def compact_line(result, side_file=None):
     if cpu and isinstance(cpu.get("sample"), str):
         cpu["sample"] = cpu["sample"][:200]
     cfg = result.get("config") or {}
-    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "input", "queries_per_gpu", "queries_total", "text_len",
+    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "input", "hit_offsets", "queries_per_gpu", "queries_total", "text_len",
                          "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism",
                          "gathered_bytes_per_rank_and_step", "gather_wire", "compact_exceptions"))
     if isinstance(config.get("workload"), str):

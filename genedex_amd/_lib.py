@@ -181,6 +181,7 @@ SIGNATURES = {
     "gdx_locate_many_totals_workspace_bytes": [C.c_uint64],
     "gdx_locate_many_totals_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     "gdx_locate_many_offsets_hits_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp],
+    "gdx_locate_many_offsets32_hits_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp],
     "gdx_packed_bytes": [C.c_uint64],
     "gdx_pack_queries": [vp, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
     "gdx_pack_queries_dev": [vp, vp, C.c_uint64, vp, vp, vp, vp],

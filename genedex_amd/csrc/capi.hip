@@ -1054,7 +1054,7 @@ int gdx_locate_many_totals_compact_dev(const gdx_index_t *ix, const void *d_reco
     });
 }
 
-int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+static int offsets_hits_compact(bool narrow, const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
                                              uint32_t max_hits, const void *d_scan_workspace, void *d_hit_offsets,
                                              uint64_t total_hits, uint64_t rest_hits, void *d_hits, void *d_workspace, void *stream)
 {
@@ -1063,6 +1063,7 @@ int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *
         check_records(d_records);
         if (!d_scan_workspace || !d_hit_offsets || (total_hits != 0 && !d_hits))
             gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_offsets_hits_compact_dev: null argument");
+        if (narrow && total_hits >= (1ull << 32)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "32-bit hit offsets need fewer than 2^32 hits");
         DeviceGuard guard(f.config().device_id);
         // few open slots: the scan pass stores the compactly answered hits and flags the locate chunks with open slots, locate
         // visits only those; many (reads from repeats, short reads): the scan writes offsets only and locate streams over all slots
@@ -1073,15 +1074,31 @@ int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *
                              ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(total_hits) : nullptr;
         gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
                                        max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits, total_hits,
-                                       false, as_stream(stream), sparse, flags);
+                                       false, as_stream(stream), sparse, flags, narrow);
         if (rest_hits != 0 || !sparse)
             gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits,
                                false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
                                static_cast<const uint4 *>(d_records), false, false, static_cast<const uint32_t *>(d_compact),
-                               sparse, flags);
+                               sparse, flags, narrow);
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
+}
+
+int gdx_locate_many_offsets_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                             uint32_t max_hits, const void *d_scan_workspace, void *d_hit_offsets,
+                                             uint64_t total_hits, uint64_t rest_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return offsets_hits_compact(false, ix, d_records, d_compact, nq, max_hits, d_scan_workspace, d_hit_offsets, total_hits, rest_hits,
+                                d_hits, d_workspace, stream);
+}
+
+int gdx_locate_many_offsets32_hits_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,
+                                               uint32_t max_hits, const void *d_scan_workspace, void *d_hit_offsets32,
+                                               uint64_t total_hits, uint64_t rest_hits, void *d_hits, void *d_workspace, void *stream)
+{
+    return offsets_hits_compact(true, ix, d_records, d_compact, nq, max_hits, d_scan_workspace, d_hit_offsets32, total_hits, rest_hits,
+                                d_hits, d_workspace, stream);
 }
 
 int gdx_locate_many_unpack_compact_dev(const gdx_index_t *ix, const void *d_records, const void *d_compact, uint64_t nq,

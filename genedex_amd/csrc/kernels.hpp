@@ -154,7 +154,8 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
                    const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false,
-                   const uint32_t *d_compact = nullptr, bool compact_stored = false, const uint8_t *d_chunk_flags = nullptr);
+                   const uint32_t *d_compact = nullptr, bool compact_stored = false, const uint8_t *d_chunk_flags = nullptr,
+                   bool narrow_offsets = false);  // d_hit_offsets is u32[m + 1] (records path only)
 // Offsets scan in two steps with the one host round trip between them: launch_scan_totals leaves d_totals (u64[2]) = {all
 // hit slots, the slots of queries whose compact result says "see the record"} and the tile bases in d_scan_workspace
 // (scan_totals_workspace_bytes); launch_scan_offsets_store then writes the offsets and, in the same pass, the hit of every
@@ -166,7 +167,7 @@ void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t 
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
                                bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
                                uint64_t hits_capacity, bool wide, hipStream_t stream, bool store = true,
-                               uint8_t *d_chunk_flags = nullptr);
+                               uint8_t *d_chunk_flags = nullptr, bool narrow_offsets = false);
 // store == false: offsets only.  d_chunk_flags (inside the locate workspace at locate_chunk_flags_offset(total_hits), filled by
 // the store pass): launch_locate then only visits the chunks of hit slots in which that pass left something open
 size_t locate_chunk_flags_offset(uint64_t total_hits);

@@ -134,9 +134,20 @@ __global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
+// hit offsets as the queue kernel reads them: u64[m + 1], or u32[m + 1] when the caller asked for narrow offsets (fewer
+// than 2^32 hits: gdx_locate_many_offsets32_hits_compact_dev)
+struct HitOffsets {
+    const void *p;
+    uint32_t narrow;
+    __device__ __forceinline__ uint64_t operator[](uint64_t i) const
+    {
+        return narrow ? static_cast<uint64_t>(static_cast<const uint32_t *>(p)[i]) : static_cast<const uint64_t *>(p)[i];
+    }
+};
+
 // first[c] = the query that owns hit slot c * chunk (the largest q with hit_offsets[q] <= c * chunk; empty
 // queries in between share the offset and are skipped by taking the largest).  One lane per chunk.
-__global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(const uint64_t *__restrict__ hit_offsets, uint64_t m,
+__global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hit_offsets, uint64_t m,
                                                                    uint64_t n_chunks, uint32_t chunk, uint64_t total,
                                                                    uint32_t *__restrict__ first)
 {
@@ -188,7 +199,7 @@ struct LocateView {
 // one fetch of its row's entry -- or with none when the search resolved it (kRecResolved) -- and nothing ever walks.
 template <class Table, bool kWide, bool kJumpWalk, bool kEntrySA>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_queue_kernel(LocateView lv, const uint32_t *__restrict__ start,
-                                                              const uint64_t *__restrict__ hit_offsets, uint64_t m,
+                                                              HitOffsets hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
                                                               const uint2 *__restrict__ hint,
                                                               const uint4 *__restrict__ rec, uint64_t total,
@@ -781,14 +792,18 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, u
     }
 }
 
-// exclusive scan of the tile sums in place, by one block; sums[n_tiles] = the total
+// exclusive scan of the tile sums in place, by one block; sums[n_tiles] = the total.  Every thread owns 16 consecutive
+// sums, a wavefront scans its 1024 with DPP-free shuffles and only the 16 wavefront totals go through LDS: two barriers
+// per 16 K sums (the first version scanned in LDS, ten doubling steps with two barriers each: 60 us for the 48.8 K tiles
+// of 100 M queries, a tenth of the pass it prepares)
 __global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_tiles)
 {
-    __shared__ unsigned long long s_part[1024];
+    __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     constexpr uint32_t kPer = 16;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint64_t base = 0; base < n_tiles; base += 1024ull * kPer) {
         unsigned long long v[kPer], run = 0;
 #pragma unroll
@@ -797,15 +812,15 @@ __global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__
             v[j] = i < n_tiles ? sums[i] : 0ull;
             run += v[j];
         }
-        s_part[threadIdx.x] = run;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned long long o = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0ull;
-            __syncthreads();
-            s_part[threadIdx.x] += o;
-            __syncthreads();
+        unsigned long long x = run;  // inclusive scan of the threads' sums inside the wavefront
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(x, off);
+            if (static_cast<int>(lane) >= off) x += o;
         }
-        unsigned long long before = s_carry + (threadIdx.x > 0 ? s_part[threadIdx.x - 1] : 0ull);
+        if (lane == 63u) s_wave[wave] = x;
+        __syncthreads();
+        unsigned long long before = s_carry + x - run;
+        for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j++) {
             const uint64_t i = base + threadIdx.x * kPer + j;
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__
             before += v[j];
         }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        if (threadIdx.x == 1023) s_carry = before;
         __syncthreads();
     }
     if (threadIdx.x == 0) sums[n_tiles] = s_carry;
@@ -826,8 +841,9 @@ template <bool kStore, bool kWide>
 __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, uint64_t m, const unsigned long long *__restrict__ sums,
                                                                  uint64_t *__restrict__ offsets, const uint32_t *__restrict__ sentinels_g,
                                                                  uint32_t n_texts, void *__restrict__ hits_out, uint64_t hits_capacity,
-                                                                 uint8_t *__restrict__ chunk_flags)  // kStore, != null (pre-zeroed): marks the
+                                                                 uint8_t *__restrict__ chunk_flags,  // kStore, != null (pre-zeroed): marks the
                                                                  // locate chunks that hold slots this pass leaves open
+                                                                 uint32_t narrow)  // offsets is u32[m + 1] (the total fits)
 {
     __shared__ unsigned long long s_part[kBlock / 64];
     constexpr uint32_t kLdsTexts = 256;
@@ -891,7 +907,8 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
             const uint64_t q = q0 + j * 64u;
             if (q < m) {
                 const uint64_t at = before + incl[j] - c[j];
-                offsets[q] = at;
+                if (narrow) reinterpret_cast<uint32_t *>(offsets)[q] = static_cast<uint32_t>(at);
+                else offsets[q] = at;
                 if (kStore && c[j] != 0ull) {
                     if (c4[j] < kCompactSee) {
                         if (at < hits_capacity) store_hit<kWide>(ix, c4[j], hits_out, at, sentinels);
@@ -903,7 +920,10 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[m] = sums[n_tiles];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (narrow) reinterpret_cast<uint32_t *>(offsets)[m] = static_cast<uint32_t>(sums[n_tiles]);
+        else offsets[m] = sums[n_tiles];
+    }
 }
 
 size_t hit_offsets_rec_temp_bytes(uint64_t m)
@@ -932,7 +952,7 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
         hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, no_rest);
         hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
         hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           no_sent, 0u, no_hits, uint64_t(0), static_cast<uint8_t *>(nullptr));
+                           no_sent, 0u, no_hits, uint64_t(0), static_cast<uint8_t *>(nullptr), 0u);
         return;
     }
     RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
@@ -978,10 +998,12 @@ void launch_scan_totals_finish(void *d_scan_workspace, uint64_t m, unsigned long
 
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
                                bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
-                               uint64_t hits_capacity, bool wide, hipStream_t stream, bool store, uint8_t *d_chunk_flags)
+                               uint64_t hits_capacity, bool wide, hipStream_t stream, bool store, uint8_t *d_chunk_flags,
+                               bool narrow_offsets)
 {
+    const uint32_t narrow = narrow_offsets ? 1u : 0u;
     if (m == 0) {
-        GDX_HIP(hipMemsetAsync(d_hit_offsets, 0, sizeof(uint64_t), stream));
+        GDX_HIP(hipMemsetAsync(d_hit_offsets, 0, narrow ? sizeof(uint32_t) : sizeof(uint64_t), stream));
         return;
     }
     const RecordSize f{d_rec, d_compact, m, max_hits, take};
@@ -991,13 +1013,13 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
     if (d_chunk_flags != nullptr) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, (hits_capacity + kLocateChunk - 1) / kLocateChunk + 1, stream));
     if (!store || d_compact == nullptr || d_hits == nullptr)
         hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, static_cast<uint8_t *>(nullptr));
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, static_cast<uint8_t *>(nullptr), narrow);
     else if (wide)
         hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags);
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags, narrow);
     else
         hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags);
+                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags, narrow);
 }
 
 namespace {
@@ -1195,9 +1217,11 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
                    const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact,
-                   bool compact_stored, const uint8_t *d_chunk_flags)
+                   bool compact_stored, const uint8_t *d_chunk_flags, bool narrow_offsets)
 {
     if (total_hits == 0 || m == 0) return;
+    if (narrow_offsets && d_rec == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: narrow offsets go with search records");
+    const HitOffsets offs{d_hit_offsets, narrow_offsets ? 1u : 0u};
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
     void *scan_temp = static_cast<char *>(d_workspace) + align_up(total_hits * sizeof(uint32_t), 256);
     size_t scan_bytes = max_scan_temp_bytes(total_hits);
@@ -1229,18 +1253,18 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
         uint32_t *first = heads;  // n_chunks entries of the workspace
         hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock) / kBlock)),
-                           dim3(kBlock), 0, stream, d_hit_offsets, m, n_chunks, kLocateChunk, total_hits, first);
+                           dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first);
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
 #define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                     \
     do {                                                                                                                  \
         if (entry_sa)                                                                                                     \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
-                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
+                               d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
                                d_compact, d_chunk_flags);                                                                 \
         else                                                                                                              \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
-                               d_start, d_hit_offsets, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,         \
+                               d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
                                d_compact, d_chunk_flags);                                                                 \
     } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller

@@ -285,8 +285,11 @@ class DeviceEngine:
     def locate_offsets_hits(self, rec: torch.Tensor, nq: int, scan_ws: torch.Tensor, hit_offsets: torch.Tensor, total: int,
                             rest: int, hits: torch.Tensor, workspace: torch.Tensor, max_hits: int = 0,
                             compact: torch.Tensor = None) -> None:
-        """gdx_locate_many_offsets_hits_compact_dev: offsets + the hits the compact results answer in one pass, then the rest"""
-        _lib.check(self.lib.gdx_locate_many_offsets_hits_compact_dev(
+        """gdx_locate_many_offsets_hits_compact_dev: offsets + the hits the compact results answer in one pass, then the rest
+        (hit_offsets of dtype int32: the narrow form, gdx_locate_many_offsets32_hits_compact_dev)"""
+        call = (self.lib.gdx_locate_many_offsets32_hits_compact_dev if hit_offsets.dtype == torch.int32
+                else self.lib.gdx_locate_many_offsets_hits_compact_dev)
+        _lib.check(call(
             self.h, _ptr(rec), _ptr(compact) if compact is not None else None, nq, max_hits, _ptr(scan_ws), _ptr(hit_offsets),
             total, rest, _ptr(hits), _ptr(workspace) if workspace is not None else None, _stream()))
 

@@ -1221,7 +1221,7 @@ def test_a_lookup_table_that_cannot_exist_is_refused():
         for depth in depths:
             with pytest.raises(GdxError) as e:
                 gpu_index(texts, a, depth=depth)
-            assert e.value.status == _lib.GDX_ERR_INVALID_ARGUMENT and "2^40" in str(e.value), (depth, str(e.value))
+            assert e.value.status == _lib.GDX_ERR_INVALID_ARGUMENT and "lookup" in str(e.value), (depth, str(e.value))
         g = gpu_index(texts, a, depth=2)
         assert g.count(texts[0][:12]) == 20
 

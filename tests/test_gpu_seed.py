@@ -140,6 +140,12 @@ def device_locate(g, qs, compact, max_hits=0, fused=False, packed=False):
         eng.locate_offsets_hits(rec, dq.nq, sws, off, tot, rest, hits, ws, max_hits, compact=cmp_)
         torch.cuda.synchronize()
         assert int(off[dq.nq].item()) == tot and rest <= tot
+        # the narrow form of the same call: u32 offsets, the same hits
+        off32 = torch.full((dq.nq + 1,), -1, dtype=torch.int32, device="cuda")
+        hits32 = torch.full_like(hits, -9)
+        eng.locate_offsets_hits(rec, dq.nq, sws, off32, tot, rest, hits32, ws, max_hits, compact=cmp_)
+        torch.cuda.synchronize()
+        assert torch.equal(off32.to(torch.int64), off) and torch.equal(hits32[:tot], hits[:tot])
     else:
         eng.locate_offsets(rec, dq.nq, off, max_hits, compact=cmp_)
         torch.cuda.synchronize()
