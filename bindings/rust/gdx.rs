@@ -111,6 +111,14 @@ pub const GDX_OK: c_int = 0;
 pub const GDX_ERR_CAPACITY: c_int = 5;
 pub const GDX_ERR_QUERY_STATUS: c_int = 6;
 
+/// gdx_query_layout_t
+#[repr(C)]
+pub struct QueryLayout {
+    pub struct_size: u32,
+    pub packed: i32,      // 0: IO symbols, 1: 2-bit codes (A C G T of the DNA alphabets)
+    pub uniform_len: u64, // 0: offsets array; L: every read has L symbols, no offsets
+}
+
 extern "C" {
     pub fn gdx_last_error() -> *const c_char;
     pub fn gdx_build_options_init(opts: *mut BuildOptions);
@@ -148,6 +156,21 @@ extern "C" {
         out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
     ) -> c_int;
     pub fn gdx_free_hits(hits: *mut Hit);
+    /// query layouts (include/gdx.h): packed = 2-bit codes, uniform_len = L: read i is symbols [i L, (i + 1) L), qoff may be null
+    pub fn gdx_query_layout_init(layout: *mut QueryLayout);
+    pub fn gdx_packed_bytes(n_symbols: u64) -> u64;
+    pub fn gdx_pack_queries(
+        ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, out_packed: *mut u8,
+        out_exceptions: *mut u64, exceptions_capacity: u64, out_n_exceptions: *mut u64,
+    ) -> c_int;
+    pub fn gdx_count_many_layout(
+        ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, layout: *const QueryLayout,
+        out_counts: *mut u64, out_status: *mut u8,
+    ) -> c_int;
+    pub fn gdx_locate_many_alloc_layout(
+        ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, layout: *const QueryLayout,
+        out_hit_offsets: *mut u64, out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
+    ) -> c_int;
     pub fn gdx_cursor_empty(ix: *const gdx_index_t, start: *mut u64, end: *mut u64) -> c_int;
     pub fn gdx_cursor_extend_front_many(
         ix: *const gdx_index_t, start: *mut u64, end: *mut u64, io_symbols: *const u8, m: u64,
@@ -355,6 +378,38 @@ impl GpuFmIndex {
     /// lib.rs:147-149
     pub fn count(&self, query: &[u8]) -> usize {
         self.count_many([query]).next().unwrap()
+    }
+
+    /// count_many for a batch of sequencer reads of one length, as a FASTQ reader holds them: `reads` = the reads back to
+    /// back (ASCII).  They cross PCIe as 2-bit codes without offsets (gdx_query_layout_t { packed, uniform_len }); reads
+    /// with a symbol outside A C G T (the packed form's exceptions) are counted through the plain call.  Same counts as
+    /// count_many (lib.rs:155-161).
+    pub fn count_reads(&self, reads: &[u8], read_len: usize) -> Vec<usize> {
+        assert!(read_len > 0 && reads.len() % read_len == 0);
+        let nq = reads.len() / read_len;
+        let off: Vec<u64> = (0..=nq).map(|i| (i * read_len) as u64).collect();
+        let mut packed = vec![0u8; unsafe { gdx_packed_bytes(reads.len() as u64) } as usize];
+        let mut exceptions = vec![0u64; nq.max(1)];
+        let mut n_exc = 0u64;
+        check(unsafe {
+            gdx_pack_queries(self.raw, reads.as_ptr(), off.as_ptr(), nq as u64, packed.as_mut_ptr(), exceptions.as_mut_ptr(),
+                             nq as u64, &mut n_exc)
+        });
+        let mut layout = QueryLayout { struct_size: 0, packed: 0, uniform_len: 0 };
+        unsafe { gdx_query_layout_init(&mut layout) };
+        layout.packed = 1;
+        layout.uniform_len = read_len as u64;
+        let mut counts = vec![0u64; nq];
+        check(unsafe {
+            gdx_count_many_layout(self.raw, packed.as_ptr(), std::ptr::null(), nq as u64, &layout, counts.as_mut_ptr(),
+                                  std::ptr::null_mut())
+        });
+        let mut out: Vec<usize> = counts.into_iter().map(|c| c as usize).collect();
+        for &q in &exceptions[..n_exc as usize] {
+            let q = q as usize;
+            out[q] = self.count(&reads[q * read_len..(q + 1) * read_len]);
+        }
+        out
     }
 
     /// lib.rs:179-185, one pass (search, scan, locate pipelined over chunks of the batch)
