@@ -1302,12 +1302,14 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
 
 def committed_traffic(args, nq, aux, why):
     """Fallback when the live PMC passes are unavailable: the committed summary of the same configuration."""
-    path = os.path.join(ROOT, "profiles", "r03", "search_pmc_final.json")
+    path = os.path.join(ROOT, "profiles", "r04", "search_pmc_final.json")
     try:
         with open(path) as f:
             p = json.load(f)
-        if ((p["workload"], p["lookup_depth"], p["path"], p["jump_entry_bytes"], p["top_table_depth"], p.get("seed_k", 0))
-                != (args.workload, args.lookup_depth, args.path, aux["jump_entry_bytes"], aux["top_table_depth"], aux["seed"]["k"])):
+        if ((p["workload"], p["lookup_depth"], p["path"], p["jump_entry_bytes"], p["top_table_depth"], p.get("seed_k", 0),
+             p.get("input", "ascii"))
+                != (args.workload, args.lookup_depth, args.path, aux["jump_entry_bytes"], aux["top_table_depth"], aux["seed"]["k"],
+                    getattr(args, "input", "ascii"))):
             return None, f"unavailable ({why}; the committed summary is of another configuration)"
         scale = nq / p["queries_per_launch"]
         t = {"kernel": p["kernel"], "read_bytes": p["read_bytes_per_launch"] * scale,

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgdx.so")
+# (GDX_LIB_PATH: another build of the library, for A/B measurements of two versions on one box)
+LIB_PATH = os.environ.get("GDX_LIB_PATH") or os.path.join(_HERE, "libgdx.so")
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)

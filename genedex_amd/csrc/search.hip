@@ -2568,10 +2568,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 // must look into the next bucket: such reads are parked in a queue of the wavefront (LDS: bucket, tag | displacement and
 // what S2 needs) and, whenever 64 of them have gathered, take a G pass of their own -- dense like the others, instead of
 // a dependent second fetch that the other 63 lanes wait for.  The queue lives across the ranges of a block and is drained
-// when the wavefront runs out of reads.  Results, lists and states are those of search_seed_kernel4 (a k-mer on several
-// rows, a read shorter than the seed, a symbol outside A C G T: listed for the next kernel).  Count / locate searches only.
+// at the end of its last range.  Results, lists and states are those of search_seed_kernel4 (a k-mer on several rows, a
+// read shorter than the seed, a symbol outside A C G T: listed for the next kernel); the lists are collected in LDS and
+// flushed with one atomic per block and list (a text of repeats lists a third of its reads).  Count / locate searches only.
+constexpr uint32_t kLaneRange = 2048;  // reads per block and range of search_seed_lane_kernel (its lists: 8 KB of LDS)
 template <int kXlate, bool kUniform>
-__global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate == 2 ? 5 : 4))) void search_seed_lane_kernel(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover, uint4 *__restrict__ state,
@@ -2586,11 +2588,18 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
     constexpr uint32_t kQueue = 128;            // parked reads per wavefront: < 64 before a chunk adds up to 64
     __shared__ uint2 s_bt[kWaves][64];
     __shared__ u32x4 s_e[kWaves][64];
-    __shared__ uint16_t s_long[kMaxRange];
-    __shared__ uint32_t s_nlong, s_long_base;
+    __shared__ uint2 s_qc[kWaves][64];  // a read's 32 symbols in front of the seed while its bucket is on the way (two registers
+                                        // less across the loads: the packed variant fits five waves per SIMD without spilling)
     __shared__ uint32_t s_pq[kWaves][kQueue], s_pb[kWaves][kQueue], s_pt[kWaves][kQueue], s_pr[kWaves][kQueue];
     __shared__ uint2 s_pc[kWaves][kQueue];
-    if (threadIdx.x == 0) s_nlong = 0;
+    // the block's lists of a range (slots of the range; a read that comes out of the parked queue may belong to an earlier
+    // range and is listed by its number), flushed with ONE atomic per list and range: on a text of repeats a third of the
+    // reads is listed, and an atomic per wavefront on the one counter of a list cost 18 of 22 ms there
+    constexpr uint32_t kLate = 128;
+    __shared__ uint16_t s_left[kLaneRange], s_long[kLaneRange];
+    __shared__ uint32_t s_late[2][kLate];
+    __shared__ uint32_t s_n[4], s_base[4];  // counts / global bases of: left, long, late left, late long
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, sub = lane & 3u, grp = lane >> 2;
     constexpr uint32_t kWin = 56;  // the window a lane loads: the last 56 symbols of its read (k <= 24: k + 32 <= 56)
@@ -2601,21 +2610,20 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
 
     // G: every lane has put {bucket, tag | displacement} (or kNoTag) of its read into s_bt; returns the read's entry with
     // kSeedFound set, or {overflow bit of the bucket, 0, 0, 0}
-    auto gather = [&]() -> u32x4 {
+    auto gather = [&]() __attribute__((always_inline)) -> u32x4 {
         __builtin_amdgcn_wave_barrier();
         u32x4 e0[4], e1[4];
-        uint32_t want[4];
 #pragma unroll
         for (uint32_t r = 0; r < 4; r++) {
-            const uint2 bt = s_bt[wave][16u * r + grp];
-            want[r] = bt.y;
-            const u32x4 *bp = sv.seed + (static_cast<uint64_t>(bt.x) << 3) + 2u * sub;
+            const uint32_t bk = s_bt[wave][16u * r + grp].x;
+            const u32x4 *bp = sv.seed + (static_cast<uint64_t>(bk) << 3) + 2u * sub;
             e0[r] = bp[0];
             e1[r] = bp[1];
         }
 #pragma unroll
         for (uint32_t r = 0; r < 4; r++) {
-            const bool m0 = (e0[r].x & kSeedMatchMask) == want[r], m1 = (e1[r].x & kSeedMatchMask) == want[r];
+            const uint32_t want = s_bt[wave][16u * r + grp].y;  // (read again: four registers less across the loads)
+            const bool m0 = (e0[r].x & kSeedMatchMask) == want, m1 = (e1[r].x & kSeedMatchMask) == want;
             // no entry matches: the slot says whether the bucket ever turned one away (bit 31 of every entry)
             if (sub == 0u) s_e[wave][16u * r + grp] = u32x4{e0[r].x & kSeedOverflow, 0u, 0u, 0u};
             if (m0 || m1) {
@@ -2627,14 +2635,14 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         __builtin_amdgcn_wave_barrier();
         return s_e[wave][lane];
     };
-    // S2 of a read whose entry (or absence) is known; slot = its place in the range (0xffffffff: not known any more);
-    // returns the hits it stored (0 or 1; a read it lists for another kernel: 0)
-    auto finish = [&](uint32_t q, uint32_t slot, uint32_t rem, uint64_t qcode, const u32x4 &en) -> uint32_t {
+    // S2 of a read whose entry (or absence) is known: 0 = answered, no occurrence; 1 = answered, one hit stored; kListLeft /
+    // kListLong = to be listed for the next kernel / for seed_text_kernel4 (its state is written here, append() lists it)
+    constexpr uint32_t kListLeft = 2, kListLong = 3;
+    auto finish = [&](uint32_t q, uint32_t rem, uint64_t qcode, const u32x4 &en) __attribute__((always_inline)) -> uint32_t {
         const uint32_t ex = en.x, ey = en.y, ez = en.z, ew = en.w;
         const bool found = (ex & kSeedFound) != 0u;
         if (found && (ex & kSeedKind) != 0u) {
             // several rows: the next kernel takes it from this interval
-            leftover[atomicAdd(n_leftover, 1u)] = q;
             if (state) {
                 if (state_packed == 0u) state[q] = make_uint4(ey, ez, rem, 1u);
                 else if (ez - ey < 256u)
@@ -2643,7 +2651,7 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
                 else state[q] = make_uint4(ey, kStatePlain | rem, ez, 0u);
             }
             if (out_compact) out_compact[q] = kCompactSee;
-            return 0u;
+            return kListLeft;
         }
         bool hit = false;
         const uint32_t pos = ey;
@@ -2656,11 +2664,9 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
             hit = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
         }
         if (hit && rem > 32u) {  // the rest against the text units: seed_text_kernel4
-            if (slot != 0xffffffffu) s_long[atomicAdd(&s_nlong, 1u)] = static_cast<uint16_t>(slot);
-            else long_list[atomicAdd(n_long, 1u)] = q;
             long_state[static_cast<uint64_t>(q) * long_stride] = make_uint2(pos, rem);
             if (out_compact) out_compact[q] = kCompactSee;  // (seed_text_kernel4 writes the result)
-            return 0u;
+            return kListLong;
         }
         // (no row is known, and none is needed: a resolved record is its position)
         if (out_compact) out_compact[q] = hit ? pos - rem : kCompactNone;
@@ -2669,8 +2675,47 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         if (out_status) out_status[q] = 0;
         return hit ? 1u : 0u;
     };
+    // lists a read of the current range (by its slot) or one that left the parked queue (by its number; if the block's
+    // small list for those is full: straight into the global list)
+    auto list_slot = [&](uint32_t kind, uint32_t slot) __attribute__((always_inline)) {
+        if (kind == kListLeft) s_left[atomicAdd(&s_n[0], 1u)] = static_cast<uint16_t>(slot);
+        else if (kind == kListLong) s_long[atomicAdd(&s_n[1], 1u)] = static_cast<uint16_t>(slot);
+    };
+    auto list_late = [&](uint32_t kind, uint32_t q) __attribute__((always_inline)) {
+        if (kind == kListLeft) {
+            const uint32_t at = atomicAdd(&s_n[2], 1u);
+            if (at < kLate) s_late[0][at] = q;
+            else leftover[atomicAdd(n_leftover, 1u)] = q;  // (the small list is full: rare, one atomic per read)
+        } else if (kind == kListLong) {
+            const uint32_t at = atomicAdd(&s_n[3], 1u);
+            if (at < kLate) s_late[1][at] = q;
+            else long_list[atomicAdd(n_long, 1u)] = q;
+        }
+    };
+    // the block's lists into the global ones (all threads; between two barriers of the caller's)
+    auto flush_lists = [&](uint64_t base) __attribute__((always_inline)) {
+        __syncthreads();
+        if (threadIdx.x == 0 || threadIdx.x == 2) {  // (left lists)
+            uint32_t n = s_n[threadIdx.x];
+            if (threadIdx.x == 2 && n > kLate) n = kLate;
+            s_base[threadIdx.x] = n != 0u ? atomicAdd(n_leftover, n) : 0u;
+        } else if (threadIdx.x == 1 || threadIdx.x == 3) {  // (long lists)
+            uint32_t n = s_n[threadIdx.x];
+            if (threadIdx.x == 3 && n > kLate) n = kLate;
+            s_base[threadIdx.x] = n != 0u ? atomicAdd(n_long, n) : 0u;
+        }
+        __syncthreads();
+        const uint32_t n0 = s_n[0], n1 = s_n[1], n2 = s_n[2] < kLate ? s_n[2] : kLate, n3 = s_n[3] < kLate ? s_n[3] : kLate;
+        for (uint32_t i = threadIdx.x; i < n0; i += kBlock) leftover[s_base[0] + i] = static_cast<uint32_t>(base) + s_left[i];
+        for (uint32_t i = threadIdx.x; i < n1; i += kBlock) long_list[s_base[1] + i] = static_cast<uint32_t>(base) + s_long[i];
+        for (uint32_t i = threadIdx.x; i < n2; i += kBlock) leftover[s_base[2] + i] = s_late[0][i];
+        for (uint32_t i = threadIdx.x; i < n3; i += kBlock) long_list[s_base[3] + i] = s_late[1][i];
+        __syncthreads();
+        if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+        __syncthreads();
+    };
     // parks the reads of the lanes with `again` set: the next bucket, one more displacement
-    auto park = [&](bool again, uint32_t q, uint32_t bucket, uint32_t tagd, uint32_t rem, uint64_t qcode) {
+    auto park = [&](bool again, uint32_t q, uint32_t bucket, uint32_t tagd, uint32_t rem, uint64_t qcode) __attribute__((always_inline)) {
         const unsigned long long mask = __ballot(again);
         if (mask == 0ull) return;
         if (again) {
@@ -2684,11 +2729,11 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         n_parked += static_cast<uint32_t>(__popcll(mask));
     };
     // true: the k-mer is not in this bucket, but may sit further on (the bucket turned entries away)
-    auto goes_on = [&](const u32x4 &en, uint32_t tagd) {
+    auto goes_on = [&](const u32x4 &en, uint32_t tagd) __attribute__((always_inline)) {
         return (en.x & kSeedFound) == 0u && (en.x & kSeedOverflow) != 0u && (tagd >> kSeedDispShift) < kSeedMaxDisp;
     };
     // one G pass over (up to) 64 parked reads
-    auto parked_pass = [&]() {
+    auto parked_pass = [&]() __attribute__((always_inline)) {
         const uint32_t take = n_parked < 64u ? n_parked : 64u;
         const uint32_t first = n_parked - take;
         __builtin_amdgcn_wave_barrier();
@@ -2708,8 +2753,9 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         s_bt[wave][lane] = make_uint2(bucket, tagd);
         const u32x4 en = gather();
         const bool again = mine && goes_on(en, tagd);
-        if (mine && !again && finish(q, 0xffffffffu, rem, qcode, en) != 0u && tile_sums != nullptr)
-            atomicAdd(&tile_sums[q / kSumTile], 1ull);
+        const uint32_t kind = (mine && !again) ? finish(q, rem, qcode, en) : 0u;
+        if (kind == 1u && tile_sums != nullptr) atomicAdd(&tile_sums[q / kSumTile], 1ull);
+        list_late(kind, q);
         park(again, q, bucket, tagd, rem, qcode);
     };
 
@@ -2725,7 +2771,7 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         uint32_t raw[kRaw];
 #pragma unroll
         for (int i = 0; i < kRaw; i++) raw[i] = 0u;
-        auto fetch = [&](uint32_t ch) {
+        auto fetch = [&](uint32_t ch) __attribute__((always_inline)) {
             const uint32_t slot = ch * 64u + lane;
             r_on = ch < n_chunks && slot < cnt;
             r_load = false;
@@ -2761,8 +2807,7 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
         };
         fetch(wave);
         for (uint32_t ch = wave; ch < n_chunks; ch += kWaves) {
-            const uint32_t slot = ch * 64u + lane;
-            const uint32_t q = static_cast<uint32_t>(base + slot);
+            const uint32_t q = static_cast<uint32_t>(base + ch * 64u + lane);
             const bool on = r_on;
             // ---- S1: the raw dwords -> the 2-bit codes of the window, f0 (its first 16 symbols, the first lowest) .. f3; the
             // last `span` of them are the 32 symbols in front of the seed (qcode, as a text unit) and the k-mer (key)
@@ -2795,41 +2840,41 @@ __global__ __launch_bounds__(kBlock) void search_seed_lane_kernel(
                 if (bad != 0u) left = on;  // a symbol outside A C G T among those looked at
             }
             const uint64_t wq = (static_cast<uint64_t>(f1) << 32) | f0, wk = (static_cast<uint64_t>(f3) << 32) | f2;
-            const uint64_t qcode = drop2 == 0u ? wq : (wq >> drop2) | (wk << (64u - drop2));
+            const uint64_t qcode0 = drop2 == 0u ? wq : (wq >> drop2) | (wk << (64u - drop2));
             const uint64_t key = (wk >> drop2) & ((1ull << (2u * k)) - 1ull);
             uint32_t tag = 0;
             const uint32_t bucket = seed_home(key, sv.tag_bits, sv.buckets, tag);
             const bool look = on && !left;
             s_bt[wave][lane] = look ? make_uint2(bucket, tag) : make_uint2(0u, kNoTag);
+            s_qc[wave][lane] = make_uint2(static_cast<uint32_t>(qcode0), static_cast<uint32_t>(qcode0 >> 32));
             // ---- the next chunk's offsets and raw dwords are on their way while this one looks at its buckets ----
             fetch(ch + kWaves);
             const u32x4 en = gather();
+            uint32_t li = lane;
+            asm volatile("" : "+v"(li));  // (the compiler must read the value back instead of keeping it in registers)
+            const uint2 qc2 = s_qc[wave][li];
+            const uint64_t qcode = (static_cast<uint64_t>(qc2.y) << 32) | qc2.x;
             // ---- S2: lane = read again
             if (left) {  // from the beginning, by the next kernel
-                leftover[atomicAdd(n_leftover, 1u)] = q;
                 if (state) state[q] = make_uint4(0u, 0u, 0u, 0u);
                 if (out_compact) out_compact[q] = kCompactSee;
             }
             const bool again = look && goes_on(en, tag);
-            const uint32_t stored = (look && !again) ? finish(q, slot, rem, qcode, en) : 0u;
+            const uint32_t kind = left ? kListLeft : ((look && !again) ? finish(q, rem, qcode, en) : 0u);
+            list_slot(kind, ch * 64u + lane);
             if (tile_sums != nullptr) {  // (a chunk of 64 lies inside one tile: ranges are multiples of 64)
-                const unsigned long long hm = __ballot(stored != 0u);
+                const unsigned long long hm = __ballot(kind == 1u);
                 if (lane == 0u && hm != 0ull) atomicAdd(&tile_sums[(base + ch * 64u) / kSumTile], static_cast<unsigned long long>(__popcll(hm)));
             }
             park(again, q, bucket, tag, rem, qcode);
-            if (n_parked >= 64u) parked_pass();
+            // (below 64 again before the next chunk adds up to 64: the queue holds 128)
+            while (n_parked >= 64u) parked_pass();
         }
-        // flush the range's list of long reads: one atomic, coalesced stores
-        __syncthreads();
-        const uint32_t n_lng = s_nlong;
-        if (threadIdx.x == 0 && n_lng != 0u) s_long_base = atomicAdd(n_long, n_lng);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_lng; i += kBlock) long_list[s_long_base + i] = static_cast<uint32_t>(base) + s_long[i];
-        __syncthreads();
-        if (threadIdx.x == 0) s_nlong = 0;
-        __syncthreads();
-    }
-    while (n_parked != 0u) parked_pass();  // (the chains are short: the largest displacement of a table is in gdx_index_seed_info)
+        // the block's last range (with a grid of one block per range: its only one): the queue is drained before the lists go
+        if (rg + gridDim.x >= n_ranges)
+            while (n_parked != 0u) parked_pass();
+        flush_lists(base);
+    }  // (the chains are short: the largest displacement of a table is in gdx_index_seed_info)
 }
 
 // The reads search_seed_kernel4 listed as "long": seed and the 32 symbols in front agree with the text at `pos`, `rem` symbols
@@ -3395,10 +3440,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                         fold_left = d_first;
                         fold_long = d_long;
                     }
+                    // (its ranges: at most kLaneRange reads, the capacity of its lists in LDS)
+                    const uint32_t lane_range = v_range < kLaneRange ? v_range : kLaneRange;
+                    const uint64_t lane_ranges = (nq + lane_range - 1) / lane_range;
+                    const unsigned lane_blocks = static_cast<unsigned>(lane_ranges < (1u << 20) ? lane_ranges : (1u << 20));
 #define GDX_SEED_LANE_LAUNCH(XLATE, UNIFORM)                                                                                    \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((search_seed_lane_kernel<XLATE, UNIFORM>), dim3(v_blocks), dim3(kBlock), seed_pad, stream, sv,      \
-                           c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, v_range, d_first + 4, d_first,    \
+        hipLaunchKernelGGL((search_seed_lane_kernel<XLATE, UNIFORM>), dim3(lane_blocks), dim3(kBlock), seed_pad, stream, sv,   \
+                           c.d_qbuf, c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, lane_range, d_first + 4, d_first, \
                            d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride, seed_state_packed, ulen,   \
                            fold);                                                                                              \
         hipLaunchKernelGGL((seed_text_kernel4<XLATE, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg, \

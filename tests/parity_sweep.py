@@ -189,6 +189,28 @@ def one_round(rng, stats):
         assert torch.equal(off2, off_t), ("compact offsets", cfg)
         assert torch.equal(hits2[:tot2], hits[:tot]), ("compact hits", cfg)
         assert torch.equal(counts2, counts) and not stat2.any().item(), ("compact counts", cfg)
+        # ... and from the batch as 2-bit codes (gdx_query_layout_t), the totals out of the search call itself, narrow offsets
+        dq_p = None
+        if int(g.info.table_layout) == 0 and k >= 4:  # (packed queries: the rank-line layout with dense 1..4 searchable)
+            try:
+                dq_p = dq.as_packed(g)
+            except ValueError:
+                dq_p = None  # (a query with a symbol outside the four: not expressible in 2 bits)
+        if dq_p is not None:
+            rec3 = eng.alloc_records(dq.nq)
+            rec3.fill_(0x3c3c3c3c)
+            cmp3 = eng.alloc_compact(dq.nq)
+            totals3 = torch.zeros(2, dtype=torch.int64, device="cuda")
+            eng.locate_search_totals(dq_p, rec3, cmp3, sws, totals3)
+            assert int(totals3[0].item()) == tot2, ("packed totals", cfg)
+            tot3, rest3 = (int(x) for x in totals3.tolist())
+            off3 = torch.full((dq.nq + 1,), -1, dtype=torch.int32, device="cuda")
+            hits3 = torch.full((max(tot3, 1), 2), -7, dtype=torch.int32, device="cuda")
+            eng.locate_offsets_hits(rec3, dq.nq, sws, off3, tot3, rest3, hits3, ws2, compact=cmp3)
+            torch.cuda.synchronize()
+            assert torch.equal(off3.to(torch.int64), off_t), ("packed offsets", cfg)
+            assert torch.equal(hits3[:tot3], hits[:tot]), ("packed hits", cfg)
+            stats["packed_batches"] = stats.get("packed_batches", 0) + 1
         stats["compact_answers"] = stats.get("compact_answers", 0) + int((cmp2[:dq.nq] != -2).sum().item())
         stats["lazy_or_hinted_records"] = stats.get("lazy_or_hinted_records", 0) + int((rec[:dq.nq, 2] != -1).sum().item())
         stats["masked_records"] = stats.get("masked_records", 0) + int((((rec[:dq.nq, 3] >> 23) & 1) == 1).sum().item())

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r02/search_pmc_final.json from a bench.py line whose roofline was measured live: the fallback bench.py
-uses (and labels as such) when rocprofv3 is not available in a later run.
-usage: tools/make_pmc_final_r2.py <bench.json> [out]"""
+"""profiles/rNN/search_pmc_final.json from a bench.py result whose roofline was measured live (since round 4: the side
+file, gpurun_out/bench_secondary.json -- the stdout line carries the short form only): the fallback bench.py uses (and
+labels as such) when rocprofv3 is not available in a later run.
+usage: tools/make_pmc_final_r2.py <bench_secondary.json> [out]"""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ r, c = d["roofline"], d["config"]
 assert r["traffic_source"].startswith("live"), "the bench line has no live PMC traffic"
 out = {"workload": c["name"], "lookup_depth": c["lookup_depth"], "path": c["path"],
        "jump_entry_bytes": c["aux_structures"]["jump_entry_bytes"], "top_table_depth": c["aux_structures"]["top_table_depth"],
-       "seed_k": c["aux_structures"].get("seed", {}).get("k", 0),
+       "seed_k": c["aux_structures"].get("seed", {}).get("k", 0), "input": c.get("input", "ascii"),
        "kernel": r["kernel"], "queries_per_launch": c["queries_per_gpu"],
        "read_bytes_per_launch": r["traffic_read_bytes"], "write_bytes_per_launch": r["traffic_write_bytes"],
        "read_requests_per_launch": r["dram_read_requests_per_launch"],
