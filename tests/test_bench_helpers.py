@@ -37,11 +37,14 @@ def test_traffic_from_pmc_counters():
 
 
 def test_committed_fallback_summary_is_readable():
-    args = argparse.Namespace(workload="hg38", lookup_depth=0, path="records")
+    args = argparse.Namespace(workload="hg38", lookup_depth=0, path="records", input="packed+uniform")
     aux = {"jump_entry_bytes": 0, "top_table_depth": 0, "seed": {"k": 24}}  # the headline index (bench.py --index seed)
     t, source = bench.committed_traffic(args, 100_000_000, aux, "test")
     assert t is not None and "NOT measured in this run" in source
-    assert 1.5e10 < t["bytes"] < 3.0e10 and 1.0 < t["read_requests"] / 1e8 < 2.0  # ~200 bytes, ~1.6 requests per read
+    assert 1.3e10 < t["bytes"] < 1.9e10 and 1.0 < t["read_requests"] / 1e8 < 1.3  # ~158 bytes, ~1.19 requests per read
+    # (the summary is of the batch as 2-bit codes without offsets: another form of the batch is another configuration)
+    other_form, why = bench.committed_traffic(argparse.Namespace(**{**vars(args), "input": "ascii"}), 100_000_000, aux, "test")
+    assert other_form is None and "another configuration" in why
     other, why = bench.committed_traffic(args, 100_000_000, {"jump_entry_bytes": 16, "top_table_depth": 16, "seed": {"k": 0}}, "test")
     assert other is None and "another configuration" in why
 
