@@ -91,6 +91,39 @@ def test_committed_round3_line_keeps_the_contract():
     assert abs(float(row[4]) - u["kernel_ms"]["search"]) < 0.03 * u["kernel_ms"]["search"]
 
 
+def test_committed_round4_line_is_what_the_driver_can_read():
+    """profiles/r04/bench_hg38_final.json is the stdout line of the driver's command: one line below 4 KB with the contract's
+    keys; its roofline fraction follows from its own traffic and time, the profiler's time beside it agrees with the kernel
+    statistics kept under profiles/, and the side file holds what the line leaves out."""
+    raw = open(os.path.join(ROOT, "profiles", "r04", "bench_hg38_final.json")).read()
+    assert raw.count("\n") <= 1 and len(raw.encode()) < 4096
+    d = json.loads(raw)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["higher_is_better"] is True and d["dtype"] == "u32"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["input"] == "packed+uniform"
+    assert abs(d["value"] - d["config"]["queries_per_gpu"] / (d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic_source"].startswith("live")
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["traffic"] / (r["avg_launch_ms"] / 1e3) / 1e9 / r["peak"]) < 1e-4
+    assert abs(r["frac_rocprof"] - r["traffic"] / (r["avg_launch_ms_rocprof"] / 1e3) / 1e9 / r["peak"]) < 1e-4
+    assert abs(r["avg_launch_ms_rocprof"] - r["avg_launch_ms"]) < 0.05 * r["avg_launch_ms"]  # the two clocks agree
+    assert r["dram_read_requests_per_query"] < 1.25 and r["frac_algorithmic"] > 1.0
+    assert 0.25 < r["reference_layout"]["frac_algorithmic"] < 0.40 and r["reference_layout"]["frac_traffic"] > 0.8
+    # the kernel's average in the child pass's statistics (kept under profiles/) is what avg_launch_ms_rocprof is made of
+    stats = open(os.path.join(ROOT, "profiles", "r04", "bench_child_kernel_stats.md")).read()
+    row = [ln for ln in stats.splitlines() if "search_seed_lane_kernel<2, true>" in ln][0].split("|")
+    assert 0.95 * r["avg_launch_ms_rocprof"] < float(row[4]) <= r["avg_launch_ms_rocprof"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["bit_exact_vs_gpu"] == {"intervals": True, "counts": True, "hits": True}
+    assert d["ascii_input"]["offsets_and_hits_identical_to_headline"] is True and d["ascii_input"]["value"] < d["value"]
+    side = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_secondary.json")))
+    names = [s_["name"] for s_ in side["secondary"]]
+    assert "reference_arrays_only" in names and any("genome_like" in n for n in names) and any("mixed" in n for n in names)
+    assert abs(side["value"] - d["value"]) < 1e-5 * side["value"] and "measured_bandwidth" in side
+
+
 class _FakeIndex:
     def __init__(self, starts):
         self.starts = starts
