@@ -2678,8 +2678,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
     // lists a read of the current range (by its slot) or one that left the parked queue (by its number; if the block's
     // small list for those is full: straight into the global list)
     auto list_slot = [&](uint32_t kind, uint32_t slot) __attribute__((always_inline)) {
-        if (kind == kListLeft) s_left[atomicAdd(&s_n[0], 1u)] = static_cast<uint16_t>(slot);
-        else if (kind == kListLong) s_long[atomicAdd(&s_n[1], 1u)] = static_cast<uint16_t>(slot);
+        // (called by every lane of the wavefront: ONE LDS atomic per list and call -- a batch of long reads lists most of
+        // its reads for seed_text_kernel4, and 64 atomics on one LDS word serialise)
+#pragma unroll
+        for (uint32_t w = 0; w < 2; w++) {
+            const bool mine = kind == kListLeft + w;
+            const unsigned long long mask = __ballot(mine);
+            if (mask == 0ull) continue;
+            const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+            uint32_t first = 0;
+            if (static_cast<int>(lane) == leader) first = atomicAdd(&s_n[w], static_cast<uint32_t>(__popcll(mask)));
+            first = __shfl(first, leader);
+            if (mine) {
+                const uint32_t at = first + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                if (w == 0) s_left[at] = static_cast<uint16_t>(slot);
+                else s_long[at] = static_cast<uint16_t>(slot);
+            }
+        }
     };
     auto list_late = [&](uint32_t kind, uint32_t q) __attribute__((always_inline)) {
         if (kind == kListLeft) {
@@ -3256,25 +3271,40 @@ __global__ __launch_bounds__(kBlock) void tile_sums_lists_kernel(const uint4 *__
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     const uint64_t nl = *n_left, ng = *n_lng;
+    const uint64_t n = nl + ng, n_round = (n + 63) / 64 * 64;  // (whole wavefronts: the ballots below need every lane)
     unsigned long long open_slots = 0;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < nl + ng; i += stride) {
-        const bool is_left = i < nl;
-        const uint32_t q = is_left ? left[i] : lng[i - nl];
-        const uint32_t c4 = compact[q];
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_round; i += stride) {
         unsigned long long c = 0;
-        if (c4 == kCompactSee) {
-            if (!is_left) continue;
-            const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
-            const uint32_t n = v.y - v.x;
-            c = (max_hits != 0u && n > max_hits) ? 0ull : static_cast<unsigned long long>(n);
-            open_slots += c;
-        } else {
-            if (is_left) continue;  // (cannot be: a listed read keeps "see the record")
-            c = c4 == kCompactNone ? 0ull : 1ull;
+        uint32_t tile = 0xffffffffu;
+        if (i < n) {
+            const bool is_left = i < nl;
+            const uint32_t q = is_left ? left[i] : lng[i - nl];
+            const uint32_t c4 = compact[q];
+            tile = q / kSumTile;
+            if (c4 == kCompactSee) {
+                if (is_left) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(rec + q);
+                    const uint32_t m = v.y - v.x;
+                    c = (max_hits != 0u && m > max_hits) ? 0ull : static_cast<unsigned long long>(m);
+                    open_slots += c;
+                }
+            } else if (!is_left) {  // (a listed read keeps "see the record": the other case cannot be)
+                c = c4 == kCompactNone ? 0ull : 1ull;
+            }
         }
-        if (c != 0ull) atomicAdd(&tile_sums[q / kSumTile], c);
+        // the lists are filled block by block, range by range: the 64 entries of a wavefront mostly lie in one tile --
+        // then one atomic for all of them (a batch of long reads lists tens of millions)
+        const uint32_t tile0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile)));
+        if (__ballot(tile != tile0 && c != 0ull) == 0ull) {
+            unsigned long long sum = tile == tile0 ? c : 0ull;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            if ((threadIdx.x & 63u) == 0u && sum != 0ull && tile0 != 0xffffffffu) atomicAdd(&tile_sums[tile0], sum);
+        } else if (c != 0ull) {
+            atomicAdd(&tile_sums[tile], c);
+        }
     }
-    if (open_slots != 0ull) atomicAdd(rest, open_slots);
+    for (int off = 32; off > 0; off >>= 1) open_slots += __shfl_xor(open_slots, off);
+    if ((threadIdx.x & 63u) == 0u && open_slots != 0ull) atomicAdd(rest, open_slots);
 }
 
 void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream, const QueryOptions &qo)
@@ -3762,7 +3792,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
     else GDX_PLAIN_LAUNCH(GenericTable, 1, grid_for_items(nq));
 #undef GDX_PLAIN_LAUNCH
     if (fold_left != nullptr) {
-        hipLaunchKernelGGL(tile_sums_lists_kernel, dim3(256), dim3(kBlock), 0, stream, c.d_rec, c.d_compact, c.tile_max_hits,
+        // (the lists' lengths are only known on the device: a capped grid that strides over whatever there is)
+        hipLaunchKernelGGL(tile_sums_lists_kernel, dim3(4096), dim3(kBlock), 0, stream, c.d_rec, c.d_compact, c.tile_max_hits,
                            fold_left + 4, fold_left, fold_long + 4, fold_long, c.d_tile_sums, c.d_tile_rest);
         if (c.tile_sums_done != nullptr) *c.tile_sums_done = true;
     }

@@ -37,6 +37,12 @@ class A:
 
 nq = int(os.environ.get("GDX_EXP_NQ", 100_000_000))
 q = DeviceQueries.synth(io_text, lengths, nq, 50, 50, 900_000, seed=43)
+form = os.environ.get("GDX_EXP_INPUT", "ascii")  # the batch as bench.py --input names it (gdx_query_layout_t)
+if "packed" in form:
+    q = q.as_packed(index)
+if "uniform" in form:
+    q = q.as_uniform(50)
+res["input"] = form
 ms, s_ms, l_ms, counts = bench.time_config(torch, eng, q, nq, True, A, steps=reps)
 res["len50"] = {"ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "Gq_per_s": nq / ms / 1e6,
                 "found": int((counts > 0).sum().item())}

@@ -13,7 +13,7 @@ for grp in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_HIT_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $grp --kernel-include-regex "search_verify|search_seed|search_pair|search_kernel" --output-format csv -d $OUT/p$i -- python3 $R/tools/exp_seed.py 1 "$@" > $OUT/p$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $grp --kernel-include-regex "search_verify|search_seed|seed_text|search_pair|search_kernel" --output-format csv -d $OUT/p$i -- python3 $R/tools/exp_seed.py 1 "$@" > $OUT/p$i.log 2>&1
 done
 python3 $R/tools/summarize_rocprof.py pmc $OUT > $OUT/summary.json
 find $OUT -name '*_counter_collection.csv' -size +2M -delete
