@@ -211,6 +211,51 @@ def one_round(rng, stats):
             assert torch.equal(off3.to(torch.int64), off_t), ("packed offsets", cfg)
             assert torch.equal(hits3[:tot3], hits[:tot]), ("packed hits", cfg)
             stats["packed_batches"] = stats.get("packed_batches", 0) + 1
+        # a UNIFORM batch (every read the same length, no offsets read: gdx_query_layout_t.uniform_len) of reads drawn from the
+        # texts and at random, as IO symbols and as 2-bit codes, through the fused search + totals call: the oracle's hits
+        if int(g.info.table_layout) == 0 and k >= 4:
+            ulen = int(rng.choice([1, 9, 24, 33, 50, 56, 57, 90, 151]))
+            us = []
+            nonempty = [t for t in texts if len(t) >= ulen]
+            for _ in range(int(rng.integers(100, 1500))):
+                if nonempty and rng.random() < 0.75:
+                    t = nonempty[int(rng.integers(0, len(nonempty)))]
+                    pos = int(rng.integers(0, len(t) - ulen + 1))
+                    us.append(t[pos:pos + ulen])
+                else:
+                    us.append(bytes(symbols[i] for i in rng.integers(0, len(symbols), ulen)))
+            ub, uo = pack_queries(us)
+            ucs, uce, ust = c.cursors_single(ub, uo)
+            uok = (ust == 0) & ((uce - ucs) < 5000)
+            us = [q for q, keep_ in zip(us, uok) if keep_]
+            if us:
+                ub, uo = pack_queries(us)
+                ucs, uce = c.cursors_for_many(ub, uo)
+                uco, uct, ucp = c.locate_intervals(ucs, uce)
+                plain_u = DeviceQueries.from_host(ub, uo)
+                forms = [plain_u.as_uniform(ulen)]
+                try:
+                    forms.append(plain_u.as_packed(g).as_uniform(ulen))
+                except ValueError:
+                    pass
+                for dq_u in forms:
+                    rec4 = eng.alloc_records(dq_u.nq)
+                    cmp4 = eng.alloc_compact(dq_u.nq)
+                    sws4 = torch.empty(max(eng.totals_workspace_bytes(dq_u.nq), 16), dtype=torch.uint8, device="cuda")
+                    tot4 = torch.zeros(2, dtype=torch.int64, device="cuda")
+                    eng.locate_search_totals(dq_u, rec4, cmp4, sws4, tot4)
+                    t4, r4 = (int(x) for x in tot4.tolist())
+                    assert t4 == int(uco[-1]), ("uniform total", ulen, dq_u.packed, cfg)
+                    off4 = torch.full((dq_u.nq + 1,), -1, dtype=torch.int32, device="cuda")
+                    hits4 = torch.full((max(t4, 1), 2), -7, dtype=torch.int32, device="cuda")
+                    ws4 = torch.empty(max(eng.locate_workspace_bytes(t4), 16), dtype=torch.uint8, device="cuda")
+                    eng.locate_offsets_hits(rec4, dq_u.nq, sws4, off4, t4, r4, hits4, ws4, compact=cmp4)
+                    torch.cuda.synchronize()
+                    assert off4.cpu().numpy().astype(np.uint64).tolist() == uco.tolist(), ("uniform offsets", ulen, dq_u.packed, cfg)
+                    h4 = hits4[:t4].cpu().numpy().astype(np.uint32)
+                    assert h4[:, 0].tolist() == uct.astype(np.uint32).tolist() and h4[:, 1].tolist() == ucp.astype(np.uint32).tolist(), \
+                        ("uniform hits", ulen, dq_u.packed, cfg)
+                    stats["uniform_batches"] = stats.get("uniform_batches", 0) + 1
         stats["compact_answers"] = stats.get("compact_answers", 0) + int((cmp2[:dq.nq] != -2).sum().item())
         stats["lazy_or_hinted_records"] = stats.get("lazy_or_hinted_records", 0) + int((rec[:dq.nq, 2] != -1).sum().item())
         stats["masked_records"] = stats.get("masked_records", 0) + int((((rec[:dq.nq, 3] >> 23) & 1) == 1).sum().item())
