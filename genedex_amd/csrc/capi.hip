@@ -693,7 +693,7 @@ int gdx_locate_many_alloc(const gdx_index_t *ix, const uint8_t *qbuf, const uint
     });
 }
 
-void gdx_free_hits(gdx_hit_t *hits) { std::free(hits); }
+void gdx_free_hits(gdx_hit_t *hits) { gdx::recycle_hits(hits); }
 
 int gdx_cursor_empty(const gdx_index_t *ix, uint64_t *start, uint64_t *end)
 {

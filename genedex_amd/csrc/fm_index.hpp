@@ -272,6 +272,8 @@ struct Parts {
                           gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
 };
 
+// gdx_free_hits: the array goes back to the library, which keeps one for the next gdx_locate_many_alloc (host_api.hip)
+void recycle_hits(gdx_hit_t *hits);
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
 void set_host_chunking(uint64_t queries, uint64_t bytes);
 

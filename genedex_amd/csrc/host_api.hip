@@ -15,6 +15,8 @@
 // gdx_hit_t and u64 hit offsets of the chunk -- so that the drainer only copies (and adds the chunk's base to the
 // offsets): the D2H link has room (a hit is 16 of the ~23 bytes per query going out, against 58 coming in), the
 // host cores of a container often do not.  Results are order preserving: chunk boundaries are invisible to the caller.
+#include <malloc.h>
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -667,6 +669,44 @@ int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                          hits ? hits_capacity : 0, out_total, nullptr);
 }
 
+// One hit array released with gdx_free_hits is kept for the next gdx_locate_many_alloc: a caller that locates batch
+// after batch otherwise pays the first touch of 1.6 GB per 100 M hits in every call (page faults and zeroing inside the
+// drainer's copy: 0.08-0.14 of a 0.14 s call, tools/host_timing.py).  At most one array is held, the larger of the two
+// when another comes back; it is ordinary malloc memory (a caller may free() it as well).
+namespace {
+std::mutex g_hits_mutex;
+void *g_hits_cached = nullptr;
+size_t g_hits_cached_bytes = 0;
+constexpr size_t kHitsCacheMin = 16u << 20;  // smaller arrays are not worth holding
+}  // namespace
+
+void recycle_hits(gdx_hit_t *hits)
+{
+    if (!hits) return;
+    const size_t bytes = malloc_usable_size(hits);
+    void *drop = hits;
+    if (bytes >= kHitsCacheMin) {
+        std::lock_guard<std::mutex> g(g_hits_mutex);
+        if (bytes > g_hits_cached_bytes) {
+            drop = g_hits_cached;
+            g_hits_cached = hits;
+            g_hits_cached_bytes = bytes;
+        }
+    }
+    std::free(drop);
+}
+
+static void *take_cached_hits(size_t bytes, size_t *got)
+{
+    std::lock_guard<std::mutex> g(g_hits_mutex);
+    if (g_hits_cached == nullptr || g_hits_cached_bytes < bytes) return nullptr;
+    void *p = g_hits_cached;
+    *got = g_hits_cached_bytes;
+    g_hits_cached = nullptr;
+    g_hits_cached_bytes = 0;
+    return p;
+}
+
 int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                                gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status, bool packed,
                                uint64_t uniform_len) const
@@ -681,14 +721,16 @@ int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64
     // first-touch page faults (one per 4 KB otherwise, ~100 ms per GB single-threaded) out of the pipeline.
     const std::function<gdx_hit_t *(uint64_t, uint64_t *)> grow = [&](uint64_t need, uint64_t *new_cap) {
         const uint64_t want = std::max<uint64_t>(need, cap + cap / 2 + 4096);
-        const size_t bytes = (want * sizeof(gdx_hit_t) + (2u << 20) - 1) / (2u << 20) * (2u << 20);
-        void *p = nullptr;
-        if (posix_memalign(&p, 2u << 20, bytes) != 0 || !p) {
-            std::free(buf);
-            buf = nullptr;
-            fail(GDX_ERR_DEVICE, "out of host memory for %llu hits", static_cast<unsigned long long>(want));
+        size_t bytes = (want * sizeof(gdx_hit_t) + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+        void *p = take_cached_hits(bytes, &bytes);  // (an array a caller gave back: its pages are there already)
+        if (p == nullptr) {
+            if (posix_memalign(&p, 2u << 20, bytes) != 0 || !p) {
+                std::free(buf);
+                buf = nullptr;
+                fail(GDX_ERR_DEVICE, "out of host memory for %llu hits", static_cast<unsigned long long>(want));
+            }
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
         }
-        (void)madvise(p, bytes, MADV_HUGEPAGE);
         if (buf) {  // rare: the first guess (one hit per query and a bit) was too small
             std::memcpy(p, buf, cap * sizeof(gdx_hit_t));
             std::free(buf);

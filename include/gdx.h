@@ -314,6 +314,8 @@ int gdx_locate_many_alloc(const gdx_index_t *ix, const uint8_t *qbuf, const uint
                           uint64_t *out_hit_offsets /*nq+1*/, gdx_hit_t **out_hits, uint64_t *out_total,
                           uint8_t *out_status);
 void gdx_free_hits(gdx_hit_t *hits);
+/* (the library keeps ONE released array -- the largest it has seen -- for the next gdx_locate_many_alloc, whose pages are
+ * then already there: a caller that locates batch after batch does not pay the first touch of gigabytes per call) */
 /* All three host-pointer query calls above run as a pipeline over chunks of the batch (copy-in, kernels and copy-out
  * of neighbouring chunks overlap, pinned staging filled by a few host threads; GDX_HOST_THREADS overrides their
  * number), so a call costs about max(PCIe in, PCIe out, kernels) rather than their sum. */
