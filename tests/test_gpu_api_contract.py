@@ -454,6 +454,18 @@ def test_partitioned_index_equals_one_index_on_counts_and_hit_sets(depth):
         got = sorted(zip(t[off[k]:off[k + 1]].tolist(), p[off[k]:off[k + 1]].tolist()))
         want = sorted(zip(ct[co[k]:co[k + 1]].tolist(), cp[co[k]:co[k + 1]].tolist()))
         assert got == want, qs[k]
+    # gdx_query_options_t.max_hits_per_query = k: locate(q).take(k) of the WHOLE collection -- the first k hits in part order,
+    # not k per part; hit_offsets counts the hits returned
+    g.set_query_options(max_hits_per_query=2)
+    off_k, t_k, p_k, _ = g.locate_raw(qbuf, qoff, strict=False)
+    assert np.diff(off_k).tolist() == np.minimum(np.diff(off), 2).tolist() and int(np.diff(off).max()) > 2 * g.num_parts
+    for k in range(len(qs)):
+        n_k = int(off_k[k + 1] - off_k[k])
+        assert list(zip(t_k[off_k[k]:off_k[k + 1]].tolist(), p_k[off_k[k]:off_k[k + 1]].tolist())) == \
+            list(zip(t[off[k]:off[k] + n_k].tolist(), p[off[k]:off[k] + n_k].tolist()))
+    g.set_query_options()
+    with pytest.raises(TypeError):  # (setattr on the ctypes struct would have taken any name and changed nothing)
+        g.set_query_options(max_hits_per_querry=2)
     with pytest.raises(GdxError) as e:  # a single text must fit one part
         PartitionedFmIndex.construct([b"ACGT" * 5000, b"ACGT"], a, max_part_symbols=9000)
     assert e.value.status == _lib.GDX_ERR_TEXT_TOO_LONG
