@@ -2572,6 +2572,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 // read shorter than the seed, a symbol outside A C G T: listed for the next kernel); the lists are collected in LDS and
 // flushed with one atomic per block and list (a text of repeats lists a third of its reads).  Count / locate searches only.
 constexpr uint32_t kLaneRange = 2048;  // reads per block and range of search_seed_lane_kernel (its lists: 8 KB of LDS)
+static_assert(kLaneRange <= kSumTile && kLaneRange % 64 == 0, "a range spans at most two scan tiles, a chunk of 64 lies in one");
 template <int kXlate, bool kUniform>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate == 2 ? 5 : 4))) void search_seed_lane_kernel(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
@@ -2599,8 +2600,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
     __shared__ uint16_t s_left[kLaneRange], s_long[kLaneRange];
     __shared__ uint32_t s_late[2][kLate];
     __shared__ uint32_t s_n[4], s_base[4];  // counts / global bases of: left, long, late left, late long
+    // tile_sums: the hits of the range's (at most two) scan tiles are summed here and leave with the lists -- an atomic per
+    // chunk and per parked read on the tile counters in global memory was a twentieth of the kernel's memory requests
+    __shared__ uint32_t s_tile_hits[2];
     if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_tile_hits[threadIdx.x] = 0;
     __syncthreads();
+    uint32_t tile0 = 0;  // the scan tile of the current range's first read
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, sub = lane & 3u, grp = lane >> 2;
     constexpr uint32_t kWin = 56;  // the window a lane loads: the last 56 symbols of its read (k <= 24: k + 32 <= 56)
     const uint32_t k = sv.k, span = k + 32u;  // symbols of a read this kernel looks at: the last `span` of the window
@@ -2725,8 +2731,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
         for (uint32_t i = threadIdx.x; i < n1; i += kBlock) long_list[s_base[1] + i] = static_cast<uint32_t>(base) + s_long[i];
         for (uint32_t i = threadIdx.x; i < n2; i += kBlock) leftover[s_base[2] + i] = s_late[0][i];
         for (uint32_t i = threadIdx.x; i < n3; i += kBlock) long_list[s_base[3] + i] = s_late[1][i];
+        if (tile_sums != nullptr && threadIdx.x < 2 && s_tile_hits[threadIdx.x] != 0u)
+            atomicAdd(&tile_sums[base / kSumTile + threadIdx.x], static_cast<unsigned long long>(s_tile_hits[threadIdx.x]));
         __syncthreads();
         if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_tile_hits[threadIdx.x] = 0;
         __syncthreads();
     };
     // parks the reads of the lanes with `again` set: the next bucket, one more displacement
@@ -2769,7 +2778,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
         const u32x4 en = gather();
         const bool again = mine && goes_on(en, tagd);
         const uint32_t kind = (mine && !again) ? finish(q, rem, qcode, en) : 0u;
-        if (kind == 1u && tile_sums != nullptr) atomicAdd(&tile_sums[q / kSumTile], 1ull);
+        if (kind == 1u && tile_sums != nullptr) {
+            const uint32_t t = q / kSumTile - tile0;  // (a read parked in an earlier range of the block: straight to its tile)
+            if (t < 2u) atomicAdd(&s_tile_hits[t], 1u);
+            else atomicAdd(&tile_sums[q / kSumTile], 1ull);
+        }
         list_late(kind, q);
         park(again, q, bucket, tagd, rem, qcode);
     };
@@ -2779,6 +2792,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
         const uint64_t base = rg * range;
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         const uint32_t n_chunks = (cnt + 63u) >> 6;
+        tile0 = static_cast<uint32_t>(base / kSumTile);
         // ---- where read `slot` of the range ends and how long it is; its raw dwords (prefetched one chunk ahead) ----
         uint64_t r_end = 0;
         uint32_t r_len = 0;
@@ -2877,9 +2891,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
             const bool again = look && goes_on(en, tag);
             const uint32_t kind = left ? kListLeft : ((look && !again) ? finish(q, rem, qcode, en) : 0u);
             list_slot(kind, ch * 64u + lane);
-            if (tile_sums != nullptr) {  // (a chunk of 64 lies inside one tile: ranges are multiples of 64)
+            if (tile_sums != nullptr) {  // (a chunk of 64 lies inside one tile: ranges are multiples of 64, at most a tile long)
                 const unsigned long long hm = __ballot(kind == 1u);
-                if (lane == 0u && hm != 0ull) atomicAdd(&tile_sums[(base + ch * 64u) / kSumTile], static_cast<unsigned long long>(__popcll(hm)));
+                if (lane == 0u && hm != 0ull)
+                    atomicAdd(&s_tile_hits[static_cast<uint32_t>((base + ch * 64u) / kSumTile) - tile0], static_cast<uint32_t>(__popcll(hm)));
             }
             park(again, q, bucket, tag, rem, qcode);
             // (below 64 again before the next chunk adds up to 64: the queue holds 128)
