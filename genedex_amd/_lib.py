@@ -186,6 +186,7 @@ SIGNATURES = {
     "gdx_packed_bytes": [C.c_uint64],
     "gdx_pack_queries": [vp, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
     "gdx_pack_queries_dev": [vp, vp, C.c_uint64, vp, vp, vp, vp],
+    "gdx_pack_queries_table": [u8p, u8p, u64p, C.c_uint64, u8p, u64p, C.c_uint64, u64p],
     "gdx_count_many_packed": [vp, u8p, u64p, C.c_uint64, u64p, u8p],
     "gdx_cursors_for_many_queries_packed": [vp, u8p, u64p, C.c_uint64, u64p, u64p, u8p],
     "gdx_cursors_for_many_queries_packed_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp, vp],

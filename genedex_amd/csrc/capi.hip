@@ -1169,6 +1169,17 @@ int gdx_pack_queries(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t 
     });
 }
 
+int gdx_pack_queries_table(const uint8_t *io_to_dense, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
+                           uint64_t *out_exceptions, uint64_t exceptions_capacity, uint64_t *out_n_exceptions)
+{
+    return guarded([&] {
+        if (exceptions_capacity && !out_exceptions) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out_exceptions is null");
+        const uint64_t n = gdx::pack_queries_with_table(io_to_dense, qbuf, qoff, nq, out_packed, out_exceptions, exceptions_capacity);
+        if (out_n_exceptions) *out_n_exceptions = n;
+        return n > exceptions_capacity ? (int)GDX_ERR_CAPACITY : (int)GDX_OK;
+    });
+}
+
 int gdx_pack_queries_dev(const gdx_index_t *ix, const void *d_qbuf, uint64_t n_symbols, void *d_packed, void *d_bad_flags,
                          void *d_bad_symbols, void *stream)
 {

@@ -272,6 +272,9 @@ struct Parts {
                           gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status) const;
 };
 
+// ASCII -> 2-bit codes on the host with nothing but the alphabet's table (gdx_pack_queries_table; host_api.hip)
+uint64_t pack_queries_with_table(const uint8_t *io_to_dense, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                 uint8_t *out_packed, uint64_t *out_exc, uint64_t capacity);
 // gdx_free_hits: the array goes back to the library, which keeps one for the next gdx_locate_many_alloc (host_api.hip)
 void recycle_hits(gdx_hit_t *hits);
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.

@@ -603,12 +603,20 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
 uint64_t FmIndex::pack_queries_host(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
                                     uint64_t *out_exc, uint64_t capacity) const
 {
+    return pack_queries_with_table(cfg_.io_to_dense, qbuf, qoff, nq, out_packed, out_exc, capacity);
+}
+
+// (no index, no device: the alphabet's table is all the packing needs -- gdx_pack_queries_table, for a reader that packs
+// what it parses before any index is at hand)
+uint64_t pack_queries_with_table(const uint8_t *tab, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint8_t *out_packed,
+                                 uint64_t *out_exc, uint64_t capacity)
+{
+    if (!tab) fail(GDX_ERR_INVALID_ARGUMENT, "io_to_dense is null");
     WorkerPool pool(host_threads());
     check_queries(qbuf, qoff, nq, pool, 0);
     if (!out_packed && nq && qoff[nq]) fail(GDX_ERR_INVALID_ARGUMENT, "out_packed is null");
     const uint64_t n_sym = nq ? qoff[nq] : 0;
     const uint64_t n_bytes = div_ceil(n_sym, 4);
-    const uint8_t *tab = cfg_.io_to_dense;
     const uint64_t first = nq ? qoff[0] : 0;  // symbols before the first query are not looked at (code 0)
     std::vector<std::vector<uint64_t>> bad(pool.size());
     pool.run([&](unsigned w, unsigned nw) {

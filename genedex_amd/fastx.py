@@ -29,6 +29,29 @@ def read_batches(path: str, max_records: int = 1 << 20, buffer_bytes: int = 1 <<
         lib.gdx_fastx_close(handle)
 
 
+def read_packed_batches(path: str, alphabet, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28):
+    """Batches of a FASTA / FASTQ file in the form the fastest calls take (gdx_query_layout_t): yields dicts with
+    `packed` (u8: 2-bit codes, four symbols per byte), `nq`, `uniform_len` (the reads' common length, or 0 when they differ:
+    then `qoff` (u64[nq + 1], counting symbols) goes with the batch), `exceptions` (indices of the reads with a symbol
+    outside the alphabet's four searchable ones -- N, IUPAC codes: their packed symbols are meaningless) and `qbuf` / `qoff`
+    (the ASCII batch itself, for running the exceptions through the plain calls).  Host only: gdx_fastx_next_batch ->
+    gdx_pack_queries_table, no index and no device needed.  The arrays of a batch are views of reused buffers."""
+    lib = _lib.load()
+    table = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
+    packed = np.zeros(int(lib.gdx_packed_bytes(buffer_bytes)), dtype=np.uint8)
+    exc = np.empty(max_records, dtype=np.uint64)
+    n_exc = C.c_uint64(0)
+    for qbuf, qoff in read_batches(path, max_records, buffer_bytes):
+        nq = qoff.size - 1
+        _lib.check(lib.gdx_pack_queries_table(table.ctypes.data_as(_lib.u8p), qbuf.ctypes.data_as(_lib.u8p) if qbuf.size else None,
+                                              qoff.ctypes.data_as(_lib.u64p), nq, packed.ctypes.data_as(_lib.u8p),
+                                              exc.ctypes.data_as(_lib.u64p), max_records, C.byref(n_exc)))
+        lens = np.diff(qoff)
+        uniform = int(lens[0]) if nq and bool((lens == lens[0]).all()) and int(lens[0]) > 0 else 0
+        yield {"packed": packed[: int(lib.gdx_packed_bytes(int(qoff[nq])))], "nq": nq, "uniform_len": uniform,
+               "qoff": qoff, "qbuf": qbuf, "exceptions": exc[: n_exc.value].copy()}
+
+
 def read_sequences(path: str):
     """All sequences of a (small) file as a list of bytes objects, e.g. the texts of an index."""
     out = []

@@ -483,6 +483,11 @@ int gdx_pack_queries(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t 
                      uint64_t *out_exceptions, uint64_t exceptions_capacity, uint64_t *out_n_exceptions);
 int gdx_pack_queries_dev(const gdx_index_t *ix, const void *d_qbuf, uint64_t n_symbols, void *d_packed,
                          void *d_bad_flags, void *d_bad_symbols, void *stream);
+/* gdx_pack_queries with the alphabet's 256-entry table instead of an index (host only, no device needed): for a reader that
+ * packs what it parses -- gdx_fastx_next_batch -> gdx_pack_queries_table -> gdx_*_layout -- before or without an index */
+int gdx_pack_queries_table(const uint8_t *io_to_dense, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                           uint8_t *out_packed, uint64_t *out_exceptions, uint64_t exceptions_capacity,
+                           uint64_t *out_n_exceptions);
 /* gdx_count_many / gdx_cursors_for_many_queries on packed host buffers (the same chunked pipeline) */
 int gdx_count_many_packed(const gdx_index_t *ix, const uint8_t *packed, const uint64_t *qoff, uint64_t nq,
                           uint64_t *out_counts, uint8_t *out_status);

@@ -105,3 +105,67 @@ def test_index_and_queries_from_files(tmp_path):
             assert int(c) == want
         total += len(seqs)
     assert total == len(reads)
+    # the same file as packed batches (2-bit codes; reads with N are the exceptions and go through the plain call), and a file
+    # of reads of one length as packed + uniform batches without offsets: the counts of the plain calls
+    a = alphabet.ascii_dna_with_n()
+    for path, lens in ((fq, None), (tmp_path / "uniform.fq", 36)):
+        if lens is not None:
+            uni = []
+            for _ in range(500):
+                t = texts[int(rng.integers(0, 6))]
+                pos = int(rng.integers(0, len(t) - lens))
+                uni.append(t[pos:pos + lens])
+            path.write_text("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(uni)))
+        for b in fastx.read_packed_batches(str(path), a, max_records=170):
+            want, _ = index.count_raw(np.concatenate([b["qbuf"], np.zeros(8, np.uint8)]), b["qoff"])
+            got, _ = index.count_layout_raw(b["packed"], None if b["uniform_len"] else b["qoff"], b["nq"], packed=True,
+                                            uniform_len=b["uniform_len"])
+            keep = np.ones(b["nq"], dtype=bool)
+            keep[b["exceptions"].astype(np.int64)] = False
+            assert got[keep].tolist() == want[keep].tolist() and (lens is None or b["uniform_len"] == lens)
+            assert len(b["exceptions"]) > 0 or not any(b"N" in bytes(b["qbuf"][int(b["qoff"][i]):int(b["qoff"][i + 1])]) for i in range(b["nq"]))
+
+
+def test_packed_batches_of_a_fastq_file(tmp_path):
+    """fastx.read_packed_batches (gdx_fastx_next_batch -> gdx_pack_queries_table, host only): a FASTQ file of reads of one
+    length comes out as 2-bit codes with `uniform_len` set and the reads with an N listed as exceptions; a file of mixed
+    lengths keeps its offsets.  The codes are the dense symbols minus one, symbol j in bits 2 (j & 3) of byte j >> 2."""
+    from genedex_amd import alphabet
+
+    a = alphabet.ascii_dna_with_n()
+    dense = a.io_to_dense_table
+    rng = np.random.default_rng(8)
+
+    def write(path, reads):
+        path.write_bytes("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads)).encode())
+
+    def check(batches, reads):
+        seen = 0
+        for b in batches:
+            n = b["nq"]
+            mine = reads[seen:seen + n]
+            seen += n
+            joined = "".join(mine).encode()
+            want_exc = [i for i, r in enumerate(mine) if any(not 1 <= dense[ord(c)] <= 4 for c in r)]
+            assert b["exceptions"].tolist() == want_exc
+            bits = np.zeros(len(joined), dtype=np.uint8)
+            for j, c in enumerate(joined):
+                d = int(dense[c])
+                bits[j] = d - 1 if 1 <= d <= 4 else 0
+            got = b["packed"][: (len(joined) + 3) // 4]
+            unpacked = np.stack([(got >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[: len(joined)]
+            assert unpacked.tolist() == bits.tolist()
+            lens = {len(r) for r in mine}
+            assert b["uniform_len"] == (lens.pop() if len(lens) == 1 else 0)
+            assert b["qoff"].tolist() == np.concatenate([[0], np.cumsum([len(r) for r in mine])]).tolist()
+            assert b["qbuf"].tobytes() == joined
+        assert seen == len(reads)
+
+    uniform = ["".join(rng.choice(list("ACGTacgt"), 50)) for _ in range(900)]
+    for i in range(0, 900, 37):
+        uniform[i] = uniform[i][:20] + "N" + uniform[i][21:]
+    write(tmp_path / "u.fq", uniform)
+    check(fastx.read_packed_batches(str(tmp_path / "u.fq"), a, max_records=256, buffer_bytes=1 << 16), uniform)
+    mixed = ["".join(rng.choice(list("ACGT"), int(rng.integers(1, 160)))) for _ in range(500)]
+    write(tmp_path / "m.fq", mixed)
+    check(fastx.read_packed_batches(str(tmp_path / "m.fq"), a, max_records=100, buffer_bytes=1 << 14), mixed)
