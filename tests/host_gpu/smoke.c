@@ -117,6 +117,20 @@ static int run_variant(const char *name, const vectors_t *v, const gdx_build_opt
                    hits[h].text_id, hits[h].position, v->hit_text[h], v->hit_pos[h]);
             bad = 1;
         }
+    /* a released array may come back from the library's one-array cache: the same call again gives the same hits */
+    if (!bad) {
+        gdx_hit_t *keep = calloc(total + 1, sizeof(gdx_hit_t));
+        memcpy(keep, hits, total * sizeof(gdx_hit_t));
+        gdx_free_hits(hits);
+        hits = NULL;
+        uint64_t total2 = 0;
+        CHECK(gdx_locate_many_alloc(ix, v->qbuf, v->qoff, nq, off, &hits, &total2, status));
+        if (total2 != total || memcmp(keep, hits, total * sizeof(gdx_hit_t)) != 0) {
+            printf("FAIL %s: the second gdx_locate_many_alloc differs from the first\n", name);
+            bad = 1;
+        }
+        free(keep);
+    }
     /* the two-call form with a caller-owned buffer: sizing call, then the fill */
     if (!bad) {
         uint64_t need = 0;
