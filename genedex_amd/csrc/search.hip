@@ -3488,7 +3488,13 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     // (its ranges: at most kLaneRange reads, the capacity of its lists in LDS)
                     const uint32_t lane_range = v_range < kLaneRange ? v_range : kLaneRange;
                     const uint64_t lane_ranges = (nq + lane_range - 1) / lane_range;
-                    const unsigned lane_blocks = static_cast<unsigned>(lane_ranges < (1u << 20) ? lane_ranges : (1u << 20));
+                    unsigned lane_blocks = static_cast<unsigned>(lane_ranges < (1u << 20) ? lane_ranges : (1u << 20));
+                    // (tests: GDX_SEED_LANE_BLOCKS caps the grid, so that a block takes several ranges -- its parked queue and
+                    // its tile sums then cross range borders, which a grid of one block per range never shows; read per call)
+                    if (const char *e = getenv("GDX_SEED_LANE_BLOCKS")) {
+                        const long cap = atol(e);
+                        if (cap > 0 && static_cast<unsigned long>(cap) < lane_blocks) lane_blocks = static_cast<unsigned>(cap);
+                    }
 #define GDX_SEED_LANE_LAUNCH(XLATE, UNIFORM)                                                                                    \
     do {                                                                                                                       \
         hipLaunchKernelGGL((search_seed_lane_kernel<XLATE, UNIFORM>), dim3(lane_blocks), dim3(kBlock), seed_pad, stream, sv,   \

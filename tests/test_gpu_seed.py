@@ -200,6 +200,56 @@ def test_compact_results_equal_records_and_oracle(seed):
     assert off_a.tolist() == off_d.tolist() and hits_a.tolist() == hits_d.tolist()
 
 
+@pytest.mark.parametrize("blocks", [1, 3])
+def test_lane_kernel_blocks_that_take_several_ranges(blocks, monkeypatch):
+    """search_seed_lane_kernel with a capped grid (GDX_SEED_LANE_BLOCKS): a block then goes through several ranges, reads parked
+    in one range are answered in a later one, and the hit totals the kernel counts per scan tile (the fused search + totals
+    call) cross range borders -- offsets, hits and totals stay those of the oracle.  A full table (every bucket has turned
+    entries away) makes the parked queue busy; 20 000 reads make ten ranges."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(9900 + blocks)
+    a = alph.ascii_dna()
+    texts = random_texts(rng, len_max=60000, symbols=b"ACGT")
+    g = gpu_index(texts, a, **dict(LEAN, seed_symbols=10, seed_load_percent=100, full_suffix_array=True))
+    c = cpu_index(texts, a)
+    length = 40
+    qs = []
+    for _ in range(20000):
+        t = texts[int(rng.integers(0, len(texts)))]
+        if len(t) >= length and rng.random() < 0.85:
+            pos = int(rng.integers(0, len(t) - length + 1))
+            qs.append(t[pos:pos + length])
+        else:
+            qs.append(bytes(b"ACGT"[i] for i in rng.integers(0, 4, length)))
+    qbuf, qoff = pack_queries(qs)
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce)
+    eng = DeviceEngine(g)
+    plain = DeviceQueries.from_host(qbuf, qoff)
+    monkeypatch.setenv("GDX_SEED_LANE_BLOCKS", str(blocks))
+    for dq in (plain, plain.as_uniform(length), plain.as_packed(g).as_uniform(length)):
+        nq = dq.nq
+        rec = eng.alloc_records(nq)
+        cmp_ = eng.alloc_compact(nq)
+        sws = torch.empty(max(eng.totals_workspace_bytes(nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        eng.locate_search_totals(dq, rec, cmp_, sws, totals)
+        tot, rest = (int(x) for x in totals.tolist())
+        assert tot == int(co[-1])
+        off = torch.full((nq + 1,), -1, dtype=torch.int32, device="cuda")
+        hits = torch.full((max(tot, 1), 2), -7, dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_offsets_hits(rec, nq, sws, off, tot, rest, hits, ws, compact=cmp_)
+        torch.cuda.synchronize()
+        assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
+        h = hits[:tot].cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist()
+        assert int((cmp_[:nq] != -2).sum().item()) > nq // 2  # (the lane kernel answered them: the seed chain ran)
+
+
 @pytest.mark.parametrize("copies", [3, 40, 300])
 @pytest.mark.parametrize("wide", [False, True])
 def test_seed_intervals_hand_the_fast_kernel_their_state(copies, wide):
