@@ -148,6 +148,34 @@ static int run_variant(const char *name, const vectors_t *v, const gdx_build_opt
             free(own);
         }
     }
+    /* the batch as 2-bit codes (gdx_query_layout_t.packed; reads with a symbol outside A C G T are its exceptions and keep the
+       answers of the plain calls): counts and every read's hits are those of the oracle */
+    if (!bad && nq) {
+        const uint64_t n_sym = v->qoff[nq];
+        uint8_t *packed = calloc(gdx_packed_bytes(n_sym), 1);
+        uint64_t *exc = calloc(nq, 8), n_exc = 0;
+        CHECK(gdx_pack_queries_table(v->io_to_dense, v->qbuf, v->qoff, nq, packed, exc, nq, &n_exc));
+        uint8_t *is_exc = calloc(nq, 1);
+        for (uint64_t i = 0; i < n_exc; i++) is_exc[exc[i]] = 1;
+        gdx_query_layout_t lay;
+        gdx_query_layout_init(&lay);
+        lay.packed = 1;
+        uint64_t *pc = calloc(nq, 8), *poff = calloc(nq + 1, 8), ptotal = 0;
+        CHECK(gdx_count_many_layout(ix, packed, v->qoff, nq, &lay, pc, status));
+        gdx_hit_t *ph = NULL;
+        CHECK(gdx_locate_many_alloc_layout(ix, packed, v->qoff, nq, &lay, poff, &ph, &ptotal, status));
+        for (uint64_t i = 0; i < nq && !bad; i++) {
+            if (is_exc[i]) continue;
+            const uint64_t want = v->hit_off[i + 1] - v->hit_off[i];
+            if (pc[i] != want || poff[i + 1] - poff[i] != want ||
+                memcmp(ph + poff[i], hits + v->hit_off[i], want * sizeof(gdx_hit_t)) != 0) {
+                printf("FAIL %s: packed form, query %" PRIu64 "\n", name, i);
+                bad = 1;
+            }
+        }
+        gdx_free_hits(ph);
+        free(packed), free(exc), free(is_exc), free(pc), free(poff);
+    }
     /* Cursor::extend_query_front cursor.rs:34, batched: the last symbol of every query from the empty cursor == its
        one-symbol search (compared with the fused call on those one-symbol queries) */
     if (!bad && nq) {
