@@ -2642,7 +2642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
         return s_e[wave][lane];
     };
     // S2 of a read whose entry (or absence) is known: 0 = answered, no occurrence; 1 = answered, one hit stored; kListLeft /
-    // kListLong = to be listed for the next kernel / for seed_text_kernel4 (its state is written here, append() lists it)
+    // kListLong = to be listed for the next kernel / for seed_text_kernel4 (its state is written here, list_slot / list_late list it)
     constexpr uint32_t kListLeft = 2, kListLong = 3;
     auto finish = [&](uint32_t q, uint32_t rem, uint64_t qcode, const u32x4 &en) __attribute__((always_inline)) -> uint32_t {
         const uint32_t ex = en.x, ey = en.y, ez = en.z, ew = en.w;
