@@ -11,9 +11,9 @@
 //
 // so that the PCIe transfers of chunk k + 1 / k - 1 run beside the kernels of chunk k and a call costs about
 // max(H2D time, D2H time, kernel time) instead of their sum.  Counts and interval borders travel narrow (u32) and are
-// widened by the host threads while they copy; locate results leave the device in the ABI's own form -- 16-byte
-// gdx_hit_t and u64 hit offsets of the chunk -- so that the drainer only copies (and adds the chunk's base to the
-// offsets): the D2H link has room (a hit is 16 of the ~23 bytes per query going out, against 58 coming in), the
+// widened by the host threads while they copy; so do the hits of a locate since round 4 (8-byte gdx_hit32_t over PCIe,
+// 16-byte gdx_hit_t in the caller's array; round 3 shipped them wide, when 58 bytes per read came in and the D2H link had
+// room -- with reads as 2-bit codes, 12.5 bytes in, the results are the longer leg); the chunk's hit offsets stay u64.  The
 // host cores of a container often do not.  Results are order preserving: chunk boundaries are invisible to the caller.
 #include <malloc.h>
 
@@ -354,7 +354,13 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     uint64_t *h_off[kSlots] = {};  // locate: the chunk's hit offsets (h_off[i] = hits of its queries before query i)
     if (kind == Kind::kLocate)
         for (int s = 0; s < kSlots; s++) h_off[s] = pinned_buf<uint64_t>(dev, s * 16 + 10, max_nq + 1);
-    gdx_hit_t *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
+    // hits leave the device NARROW (gdx_hit32_t, 8 bytes) and are widened into the ABI's 16-byte gdx_hit_t by the drainer's
+    // workers: with reads handed over as 2-bit codes the D2H link is the longer leg of a locate call (23 bytes per read out
+    // against 12.5 in), and the drainer reads half as much from the staging buffer.  GDX_HOST_WIDE_HITS=1: 16-byte hits from
+    // the device as in round 3 (the drainer then only copies)
+    static const bool wide_hits = [] { const char *e = getenv("GDX_HOST_WIDE_HITS"); return e && atoi(e) != 0; }();
+    const size_t hit_bytes = wide_hits ? sizeof(gdx_hit_t) : sizeof(gdx_hit32_t);
+    void *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
     void *d_ws[kSlots] = {};
 
     std::atomic<bool> any_status{false};
@@ -424,10 +430,10 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = *h_total[s];
             if (c.total) {
-                d_hits[s] = device_buf<gdx_hit_t>(dev, s * 16 + 8, c.total);
-                h_hits[s] = pinned_buf<gdx_hit_t>(dev, s * 16 + 6, c.total);
+                d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, c.total * hit_bytes);
+                h_hits[s] = pinned_buf<uint8_t>(dev, s * 16 + 6, c.total * hit_bytes);
                 d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
-                launch_locate(view_, nullptr, nullptr, c.nq, d_off[s], c.total, d_hits[s], true, d_ws[s], st.k, nullptr,
+                launch_locate(view_, nullptr, nullptr, c.nq, d_off[s], c.total, d_hits[s], wide_hits, d_ws[s], st.k, nullptr,
                               nullptr, qo, d_rec[s]);
                 GDX_HIP(hipGetLastError());
             }
@@ -442,7 +448,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             GDX_HIP(hipMemcpyAsync(h_b[s], d_b[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
         if (kind == Kind::kLocate && c.total)
-            GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * sizeof(gdx_hit_t), hipMemcpyDeviceToHost, st.out));
+            GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * hit_bytes, hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
     };
 
@@ -464,9 +470,19 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             const uint64_t need = hit_base + c.total;
             if (grow_hits && need > hits_capacity) hits = (*grow_hits)(need, &hits_capacity);  // at least `need`
             if (hits && need <= hits_capacity && capacity_ok) {
-                const gdx_hit_t *src = h_hits[s];
                 gdx_hit_t *dst = hits + hit_base;
-                pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(gdx_hit_t)); });
+                if (wide_hits) {
+                    const gdx_hit_t *src = static_cast<const gdx_hit_t *>(h_hits[s]);
+                    pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(gdx_hit_t)); });
+                } else {
+                    const gdx_hit32_t *src = static_cast<const gdx_hit32_t *>(h_hits[s]);
+                    pool.parallel_range(c.total, 8, [&](uint64_t lo, uint64_t hi) {
+                        for (uint64_t i = lo; i < hi; i++) {
+                            dst[i].text_id = src[i].text_id;
+                            dst[i].position = src[i].position;
+                        }
+                    });
+                }
             } else {
                 capacity_ok = false;
             }
