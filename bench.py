@@ -134,6 +134,9 @@ def parse_args():
 
 
 SEED_INDEX = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, full_suffix_array=True, seed_symbols=True)
+REFERENCE_ARRAYS = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0)  # the reference's information content, nothing else
+LOOKUP_RUNGS = (10, 13)        # lookup-table depths of the `reference_arrays_dD` secondaries (lookup_table.rs:51-161)
+LOOKUP_PMC_READS = 20_000_000  # reads of their PMC child passes
 FULL_INDEX = dict(seed_symbols=True, inverse_suffix_array=True, aux_budget_bytes=250_000_000_000)
 
 
@@ -220,16 +223,17 @@ def rocprof_ms_of(pmc, pattern):
     return total or None
 
 
-def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False):
+def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False, lookup_depth=None, only=None, nq=None):
     """-> ({kernel short name: {counter: per-launch value}}, None) or (None, reason).  Runs before the parent touches
     the GPU: every pass is `rocprofv3 --pmc <group> -- python3 bench.py --pmc-child ...` in its own process.
     reference_layout: the same workload on an index without any acceleration structure (the ladder's last rung);
-    rung = "top16_sa_text": on the 53 GB rung (top table + full suffix array + text units, no jump table, no pair lines)."""
+    rung = "top16_sa_text": on the 53 GB rung (top table + full suffix array + text units, no jump table, no pair lines).
+    lookup_depth / nq: override the parent's; only: the names of the PMC_PASSES to run (default: all)."""
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     child_args = ["--pmc-child", "--workload", args.workload, "--op", args.op, "--path", args.path,
                   "--input", args.input if not (reference_layout or rung) else "ascii",
-                  "--lookup-depth", str(args.lookup_depth), "--sa-rate", str(args.sa_rate),
+                  "--lookup-depth", str(args.lookup_depth if lookup_depth is None else lookup_depth), "--sa-rate", str(args.sa_rate),
                   "--index", "tables" if (reference_layout or rung) else args.index]
     jump_bytes, top_depth, no_pairs = args.jump_bytes, args.top_depth, args.no_pair_lines
     if reference_layout:
@@ -238,7 +242,7 @@ def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False):
         jump_bytes, top_depth, no_pairs = 0, 16, True
         child_args += ["--full-sa", "--text-units"]
     # rung == "tables": the library's default structures (--index tables, nothing else)
-    for flag, v in (("--nq", args.nq), ("--total", args.total), ("--jump-bytes", jump_bytes),
+    for flag, v in (("--nq", args.nq if nq is None else nq), ("--total", args.total), ("--jump-bytes", jump_bytes),
                     ("--top-depth", top_depth), ("--lanes", args.lanes), ("--load-policy", args.load_policy)):
         if v is not None:
             child_args += [flag, str(v)]
@@ -250,6 +254,8 @@ def run_live_pmc(args, reference_layout=False, rung=None, kernel_trace=False):
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.time()
     for name, counters in PMC_PASSES:
+        if only is not None and name not in only:
+            continue
         d = tempfile.mkdtemp(prefix=f"gdx_pmc_{name}_", dir="/tmp")
         if counters is None:
             if not kernel_trace:
@@ -337,6 +343,18 @@ def traffic_of(pmc, pattern):
     return total
 
 
+def traffic_requests_of(pmc, pattern, queries=LOOKUP_PMC_READS):
+    """request counters of the one kernel `pattern` names out of a "requests"-only PMC pass, or None"""
+    if not pmc:
+        return None
+    names = [k for k in pmc if pattern in k and "stats" not in k]
+    if len(names) != 1 or "TCC_EA0_RDREQ_sum" not in pmc[names[0]]:
+        return None
+    c = pmc[names[0]]
+    return {"kernel": names[0], "read_requests": c["TCC_EA0_RDREQ_sum"]["per_launch"], "write_requests": c["TCC_EA0_WRREQ_sum"]["per_launch"],
+            "l2_requests": c["TCC_REQ_sum"]["per_launch"], "l2_hits": c["TCC_HIT_sum"]["per_launch"], "queries": queries}
+
+
 # ======================================================================================================
 
 def workload_of(args):
@@ -412,6 +430,10 @@ class StepRunner:
         self.fused_scan = self.use_rec and not self.use_compact and os.environ.get("GDX_BENCH_FUSED_SCAN") == "1"
         self.scan_ws, self.totals = [], []
         self.ev_scan = []
+        self.max_hits = 0  # != 0: queries with more occurrences are counted but not located (gdx.h max_hits)
+        # "fused": the step is ONE library call without a host round trip; "split": search + totals, read-back of the totals,
+        # offsets + hits (rounds 3-4)
+        self.step_mode = "fused"
 
     def _alloc(self):
         o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
@@ -428,7 +450,7 @@ class StepRunner:
 
     def offsets(self, o):
         if self.use_rec:
-            self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"], compact=o["compact"])
+            self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"], self.max_hits, compact=o["compact"])
         else:
             self.eng.hit_offsets(o, self.nq)
 
@@ -474,8 +496,55 @@ class StepRunner:
             self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
         return self.total_hits
 
+    def _step_fused(self, slot, record, after):
+        """The whole step as ONE library call without a host round trip (gdx_locate_many_step_compact_layout_dev): the hit
+        buffer is the one the sizing pass made (a pipeline offers what its earlier batches needed); the totals stay on the
+        device and are checked against the capacity by check_totals() after the timed region."""
+        torch = self.torch
+        o, h, ws = self.outs[slot], self.hits[slot], self.ws[slot]
+        dev = h.device
+        if slot >= len(self.scan_ws):
+            self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev)
+                            for _ in range(self.n_slots)]
+            self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
+        need = self.eng.locate_workspace_bytes(h.shape[0])
+        if need > ws.numel():
+            self.ws[slot] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        narrow = self.n_slots == 1 and h.shape[0] < (1 << 31)
+        if narrow and "hit_offsets32" not in o:
+            o["hit_offsets32"] = torch.empty(self.nq + 1, dtype=torch.int32, device=dev)
+        self.narrow_offsets = narrow
+        a, mid, d = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        if record:
+            mid.record()  # (creates the event's handle; the library records it again between the step's two halves)
+        a.record()
+        self.eng.locate_step(self.q, o["rec"], o["compact"], self.scan_ws[slot], self.totals[slot],
+                             o["hit_offsets32"] if narrow else o["hit_offsets"], h, ws, max_hits=self.max_hits,
+                             event_after_search=mid if record else None)
+        d.record()
+        if record:
+            self.ev_search.append((a, mid))
+            self.ev_locate.append((mid, d))
+        self.fused_steps = getattr(self, "fused_steps", 0) + 1
+        if after is not None:
+            after(slot)
+
+    def check_totals(self):
+        """after the timed steps of the fused form: every slot's hit total must have fitted the buffer it was offered"""
+        if not getattr(self, "fused_steps", 0):
+            return
+        self.torch.cuda.synchronize()
+        for t, h in zip(self.totals, self.hits):
+            tot = int(t[0].item())
+            if tot > h.shape[0]:
+                raise SystemExit(f"PARITY FAILURE: a fused step produced {tot} hits for a buffer of {h.shape[0]}")
+            self.total_hits = tot
+
     def step(self, slot, record, side_stream=None, after=None):
         torch = self.torch
+        if (self.do_locate and self.use_compact and not self.fused_scan and side_stream is None
+                and getattr(self, "step_mode", "fused") == "fused" and os.environ.get("GDX_BENCH_NO_FOLD") != "1"):
+            return self._step_fused(slot, record, after)
         o, h, ws = self.outs[slot], self.hits[slot], self.ws[slot]
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # compact path: the hit totals come out of the search call itself (gdx_locate_many_search_totals_compact_layout_dev;
@@ -488,7 +557,7 @@ class StepRunner:
             self.totals = [torch.zeros(2, dtype=torch.int64, device=dev_) for _ in range(self.n_slots)]
         a.record()
         if fold:
-            self.eng.locate_search_totals(self.q, o["rec"], o["compact"], self.scan_ws[slot], self.totals[slot])
+            self.eng.locate_search_totals(self.q, o["rec"], o["compact"], self.scan_ws[slot], self.totals[slot], self.max_hits)
         else:
             self.search(o)
         b.record()
@@ -533,7 +602,8 @@ class StepRunner:
                 if not fold:
                     ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ta.record()
-                    self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], compact=o["compact"])
+                    self.eng.locate_totals(o["rec"], self.nq, self.scan_ws[slot], self.totals[slot], self.max_hits,
+                                           compact=o["compact"])
                     tb.record()
                     if record:
                         self.ev_scan.append((ta, tb))
@@ -555,7 +625,7 @@ class StepRunner:
                 self.narrow_offsets = narrow
                 c.record()
                 self.eng.locate_offsets_hits(o["rec"], self.nq, self.scan_ws[slot], o["hit_offsets32"] if narrow else o["hit_offsets"],
-                                             tot, rest, h, ws, compact=o["compact"])
+                                             tot, rest, h, ws, self.max_hits, compact=o["compact"])
                 d.record()
                 if record:
                     self.ev_locate.append((c, d))
@@ -655,7 +725,7 @@ def main():
 
     # PMC passes first: they are separate processes that each need the GPU's memory for their own index, and starting
     # them before this process initialises the GPU keeps every exec clear of a process that holds the device
-    pmc, pmc_note, pmc_ref, pmc_text = None, "live PMC passes run at N = 1 only", None, None
+    pmc, pmc_note, pmc_ref, pmc_text, pmc_lookup = None, "live PMC passes run at N = 1 only", None, None, {}
     profiled = any(k in os.environ for k in ("ROCPROFILER_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
     if profiled:  # under rocprofv3 already (its preload initialised the GPU): no nested profiler children
@@ -668,6 +738,13 @@ def main():
         elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
             pmc_ref, _ = run_live_pmc(args, reference_layout=True)
             pmc_text, _ = run_live_pmc(args, rung="tables" if args.index == "seed" else "top16_sa_text")
+            # the reference's arrays WITH its lookup tables (depth 10: BASELINE.md cfg 3's secondary; 13: the deepest that
+            # SURVEY 8 sizes): DRAM requests of a fifth of the batch -- one pass each, the counters scale with the reads
+            if not args.no_extras:
+                pmc_lookup["queries"] = min(LOOKUP_PMC_READS, workload_of(args)["nq"])
+                for d in LOOKUP_RUNGS:
+                    pmc_lookup[d], _ = run_live_pmc(args, reference_layout=True, lookup_depth=d, only=("requests",),
+                                                    nq=pmc_lookup["queries"])
 
     import numpy as np
     import torch  # before libgdx.so: both must share torch's HIP runtime
@@ -741,6 +818,7 @@ def main():
         gather, count_of, gathered_bytes = make_gather(torch, gdist, runner, dev, do_locate)
     elapsed, _ = timed_steps(torch, gdist, runner, args.steps, args.warmup, dev, gather, count_of,
                              overlap=do_locate and args.overlap)
+    runner.check_totals()
     narrow_offsets = runner.widen_offsets()
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * world / (ms_per_step / 1e3)
@@ -755,6 +833,7 @@ def main():
         if r2.size() != total_hits:
             raise SystemExit("PARITY FAILURE: the ascii form of the batch gives another number of hits")
         e2, _ = timed_steps(torch, gdist, r2, args.steps, args.warmup, dev)
+        r2.check_totals()
         r2.widen_offsets()
         same = bool(torch.equal(r2.outs[0]["hit_offsets"], out["hit_offsets"])) and \
             (not do_locate or bool(torch.equal(r2.hits[0][:total_hits], runner.hits[0][:total_hits])))
@@ -766,6 +845,30 @@ def main():
         log(f"[bench] the same step on ascii input: {ascii_input}")
         del r2
         torch.cuda.empty_cache()
+
+    # ---- the step on what a rank of 2 / 4 / 8 GPUs gets of this batch (N = 1; BASELINE configs[3] shards ONE batch) ----------
+    shard_step = None
+    if world == 1 and do_locate and not args.no_extras and nq >= 8_000_000:
+        shard_step = {}
+        for parts in (2, 4, 8):
+            n_part = nq // parts
+            part = input_form(queries.copy_slice(0, n_part), index, args, wl)
+            r3 = StepRunner(torch, eng, part, n_part, do_locate, args.path, hint=not args.no_hint)
+            r3.size()
+            for _ in range(3):
+                r3.step(0, False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                r3.step(0, False)  # (no events: an event record between two kernels costs the step 5 us)
+            torch.cuda.synchronize()
+            ms3 = (time.perf_counter() - t0) / args.steps * 1e3
+            r3.check_totals()
+            shard_step[str(n_part)] = {"ms_per_step": ms3, "value": n_part / (ms3 / 1e3), "ranks": parts, "hits": r3.total_hits,
+                                       "all_ranks_value_if_kernels_bound": nq / (ms3 / 1e3)}
+            del r3, part
+            torch.cuda.empty_cache()
+        log(f"[bench] shard steps (what a rank of 2 / 4 / 8 runs of this batch, results left on the GPU): {shard_step}")
 
     # ---- algorithmic bytes, counted by an extra, untimed pass in the exact mode -----------
     lf_steps, fetches, fetch_slots = eng.search_step_stats(queries)
@@ -923,10 +1026,12 @@ def main():
                    "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0",
                    "gathered_bytes_per_rank_and_step": gathered_bytes,
                    "compact_exceptions": exceptions,
-                   "gather_wire": (("compact results + exceptions" if getattr(gather, "compact_wire", False) else "arrays")
+                   "gather_wire": (("found bitmap + positions + exceptions" if getattr(gather, "wire_name", "") == "bitmap" else
+                                    "compact results + exceptions" if getattr(gather, "compact_wire", False) else "arrays")
                                    if gather is not None else None)},
         "roofline": roofline,
         "ascii_input": ascii_input,
+        "shard_step": shard_step,
         "locate_roofline": locate_roofline,
         "kernel_ms": {"search": search_ms, "locate": locate_ms, "totals": runner.mean_ms(runner.ev_scan)},
         "parity": parity,
@@ -989,7 +1094,7 @@ def main():
         try:
             secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref, pmc_text,
                         result.get("end_to_end") if "error" not in (result.get("end_to_end") or {}) else None,
-                        res=result["secondary"])
+                        res=result["secondary"], pmc_lookup=pmc_lookup)
         except Exception as e:  # noqa: BLE001
             log(f"[bench] secondaries stopped: {e!r}")
             result["secondary_error"] = repr(e)
@@ -1002,6 +1107,11 @@ def main():
                     "frac_algorithmic": rl.get("algorithmic_ratio", rl.get("frac")),
                     "traffic": rl.get("traffic"), "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
                     "dram_read_requests_per_query": rl.get("dram_read_requests_per_query")}
+            if r.get("name", "").startswith("reference_arrays_d") and "roofline" in r:  # ... with the reference's lookup tables
+                roofline[f"reference_layout_d{r['lookup_depth']}"] = {
+                    "value": r["value"], "search_ms": r["search_ms"], "frac_algorithmic": r["roofline"]["frac_algorithmic"],
+                    "dram_read_requests_per_query": r["roofline"].get("dram_read_requests_per_query"),
+                    "frac_traffic": r["roofline"].get("frac_traffic_from_requests")}
 
     if rank == 0:
         if world > 1 and "strong_scaling" in result:
@@ -1034,6 +1144,7 @@ def report_strong_scaling(result, wl):
     c["gathered_bytes_per_rank_and_step"] = st["gathered_bytes_per_rank_and_step"]
     c["gather_wire"] = st.get("gather_wire", c.get("gather_wire"))
     result["parity"]["shards_equal_single_rank_output"] = st.get("shards_equal_single_rank_output")
+    result["results_sharded"] = st.get("results_sharded")
 
 
 def write_side_file(path, result):
@@ -1080,6 +1191,10 @@ def compact_line(result, side_file=None):
         t, a = r["reference_layout"].get("traffic"), r["reference_layout"].get("algorithmic_bytes_per_launch")
         if t and a:
             roof["reference_layout"]["wasted_traffic_ratio"] = t / a
+    for d in LOOKUP_RUNGS:
+        if r.get(f"reference_layout_d{d}"):
+            roof[f"reference_layout_d{d}"] = _pick(r[f"reference_layout_d{d}"], ("value", "search_ms", "frac_algorithmic",
+                                                                                 "dram_read_requests_per_query", "frac_traffic"))
     c = result.get("cpu_baseline")
     cpu = c if (c is None or "error" in c) else _pick(c, ("value", "unit", "cores", "kind", "sample", "usable_threads",
                                                              "count_only_value", "bit_exact_vs_gpu"))
@@ -1099,6 +1214,10 @@ def compact_line(result, side_file=None):
     line["kernel_ms"] = result.get("kernel_ms")
     if result.get("ascii_input"):
         line["ascii_input"] = _pick(result["ascii_input"], ("value", "ms_per_step", "search_ms", "offsets_and_hits_identical_to_headline"))
+    if result.get("shard_step"):
+        line["shard_step_ms"] = {k: v["ms_per_step"] for k, v in result["shard_step"].items()}
+    if result.get("results_sharded"):
+        line["results_sharded"] = _pick(result["results_sharded"], ("value", "ms_per_step"))
     lr = result.get("locate_roofline")
     if lr:
         line["locate_roofline"] = _pick(lr, ("kernel", "avg_launch_ms", "traffic", "frac", "hits_per_launch"))
@@ -1118,7 +1237,7 @@ def compact_line(result, side_file=None):
     line["index_build_seconds"] = result.get("index_build_seconds")
     line["side_file"] = side_file
     line = _num(line)
-    for drop in ("end_to_end", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
+    for drop in ("end_to_end", "shard_step_ms", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -1139,14 +1258,22 @@ def make_gather(torch, gdist, runner, dev, do_locate):
     max_nq = gdist.max_int_over_ranks(nq, dev)
     # On an index with a seed table the search's compact results travel as they are, with the few queries that have more to
     # say beside them (make_compact_gather) -- whenever that is fewer bytes than the arrays below (it is not on a text of repeats)
+    # ... or as a bit per read + 4 bytes per FOUND read (make_bitmap_gather: 3.73 bytes per read where nine in ten are found)
     wire = os.environ.get("GDX_BENCH_GATHER", "auto")
-    if do_locate and runner.use_compact and int(runner.eng.index.num_texts()) <= 256 and wire in ("auto", "compact"):
+    if do_locate and runner.use_compact and int(runner.eng.index.num_texts()) <= 256 and wire in ("auto", "compact", "bitmap"):
         n_exc, n_exc_hits = gdist.exception_sizes(o["compact"], o["hit_offsets"], nq)
         cap_q = max(gdist.max_int_over_ranks(n_exc, dev), 1)
         cap_h = max(gdist.max_int_over_ranks(n_exc_hits, dev), 1)
+        n_found = int((o["compact"][:nq] >= 0).sum().item()) + int((o["compact"][:nq] < -2).sum().item()) if nq else 0
+        cap_f = max(gdist.max_int_over_ranks(n_found, dev), 1)
         arrays_bytes = max(max_nq, 1) * (1 if max_count <= 0xff else 4) + 5 * max(max_hits, 1)
-        if wire == "compact" or 4 * max(max_nq, 1) + 4 * cap_q + 5 * cap_h + 8 < arrays_bytes:
-            return make_compact_gather(torch, gdist, runner, dev, max_nq, cap_q, cap_h, {"queries": n_exc, "hits": n_exc_hits})
+        compact_bytes = 4 * max(max_nq, 1) + 4 * cap_q + 5 * cap_h + 8
+        layout = gdist.WireLayout(max(max_nq, 1), cap_f, cap_q, cap_h)
+        exc = {"queries": n_exc, "hits": n_exc_hits, "found": n_found}
+        if wire == "bitmap" or (wire == "auto" and layout.nbytes < min(compact_bytes, arrays_bytes)):
+            return make_bitmap_gather(torch, gdist, runner, dev, layout, exc)
+        if wire == "compact" or (wire == "auto" and compact_bytes < arrays_bytes):
+            return make_compact_gather(torch, gdist, runner, dev, max_nq, cap_q, cap_h, exc)
     runner.hits = [torch.zeros((max(max_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(runner.n_slots)]
     cnts = [torch.zeros(max(max_nq, 1), dtype=count_dtype, device=dev) for _ in range(runner.n_slots)]
     # Hits travel as two arrays -- text ids as bytes when the collection has at most 256 texts, positions as int32 -- instead
@@ -1236,6 +1363,47 @@ def make_compact_gather(torch, gdist, runner, dev, max_nq, cap_q, cap_h, excepti
     return gather, pack, 4 * n + 4 * cap_q + 5 * cap_h + 8
 
 
+def make_bitmap_gather(torch, gdist, runner, dev, layout, exceptions):
+    """The gather of a count + locate step as a bit per read + the text positions of the found reads (gdx_wire_pack_dev, three
+    launches on the rank; dist.WireLayout: everything a rank sends lies in ONE byte buffer, one gather per step): 0.125 + 4 x
+    the found fraction bytes per read -- 3.73 where nine reads in ten are found -- instead of the 4 of the compact words.  A
+    link into rank 0 carries one direction of an xGMI link, and at ~28 G results/s per rank the bytes per result decide the step
+    (DESIGN.md section 6).  Rank 0 turns every arrived shard into text id + position per read (gdx_wire_split_dev, one kernel
+    per shard, enqueued when the gather is acquired) -- inside the timed region."""
+    nq = runner.nq
+    n = layout.n_max
+    bufs = [torch.zeros(layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(runner.n_slots)]
+    views = [layout.views(b) for b in bufs]
+    ws = [torch.empty(max(runner.eng.wire_pack_workspace_bytes(nq), 16), dtype=torch.uint8, device=dev) for _ in range(runner.n_slots)]
+    rank, world = gdist.world()
+    root_ids = root_pos = None
+    if rank == 0:
+        root_ids = [[torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(runner.n_slots)]
+        root_pos = [[torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(runner.n_slots)]
+
+    def on_gathered(slot, own=False):
+        for r, buf in enumerate(gather.gathered(slot)[0]):
+            if (r == 0) == own:
+                runner.eng.wire_split(layout.views(buf), n, root_ids[slot][r], root_pos[slot][r])
+
+    gather = gdist.PipelinedGather([[b] for b in bufs], dst=0, on_gathered=on_gathered)
+
+    def pack(slot):
+        o_ = runner.outs[slot]
+        runner.eng.wire_pack(o_["compact"], o_["hit_offsets"], runner.hits[slot], nq, views[slot], ws[slot])
+
+    gather.hits_are_split = True
+    gather.compact_wire = True
+    gather.wire_name = "bitmap"
+    gather.root_ids, gather.root_pos = root_ids, root_pos
+    gather.split_own = lambda slot: on_gathered(slot, own=True)
+    gather.exceptions = exceptions
+    # (exception counts, text ids, positions and the true numbers of one received shard, as expand_split_results takes them)
+    gather.exception_parts = lambda slot, r: [layout.views(gather.gathered(slot)[0][r])[k] for k in ("exc_cnt", "exc_ids", "exc_pos", "meta")]
+    gather.payload_bytes = layout.payload_bytes(nq, exceptions["found"], exceptions["queries"], exceptions["hits"])
+    return gather, pack, layout.nbytes
+
+
 def gathered_shards(torch, gdist, gather, slot, shard_len, sizes, do_locate):
     """rank 0: (counts, hits or None) of the gathered shards of `slot`, concatenated, as a one-rank run would hold them"""
     parts = gather.gathered(slot)
@@ -1244,8 +1412,8 @@ def gathered_shards(torch, gdist, gather, slot, shard_len, sizes, do_locate):
         gather.split_own(slot)
         cnts, hits = [], []
         for r, (a, b) in enumerate(shard_len):
-            c, h = gdist.expand_split_results(gather.root_ids[slot][r], gather.root_pos[slot][r], parts[1][r], parts[2][r],
-                                              parts[3][r], parts[4][r], b - a)
+            exc = gather.exception_parts(slot, r) if hasattr(gather, "exception_parts") else [parts[k][r] for k in (1, 2, 3, 4)]
+            c, h = gdist.expand_split_results(gather.root_ids[slot][r], gather.root_pos[slot][r], *exc, b - a)
             if h.shape[0] != sizes[r]:
                 raise SystemExit(f"PARITY FAILURE: shard {r} arrived with {h.shape[0]} hits, its rank located {sizes[r]}")
             cnts.append(c)
@@ -1280,12 +1448,19 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
            "queries_total": nq_total, "queries_this_rank": hi - lo, "steps": steps,
            "kernel_ms_rank0": {"search": runner.mean_ms(runner.ev_search), "locate": runner.mean_ms(runner.ev_locate)},
            "gathered_bytes_per_rank_and_step": nbytes}
+    runner.check_totals()
+    # the same sharded step with the results LEFT on their GPUs (no gather): what the kernels and launches of N ranks give; the
+    # gather above adds what one direction of the links into rank 0 carries
+    e_ng, _ = timed_steps(torch, gdist, runner, steps, args.warmup, dev)
+    runner.check_totals()
+    res["results_sharded"] = {"value": nq_total / (e_ng / steps), "unit": "queries/s", "ms_per_step": e_ng / steps * 1e3,
+                              "what": "the sharded step without the gather: every rank's offsets and hits stay in its own HBM"}
     # bit-exactness: concatenated shards == the one-rank output
     sizes = gdist.gather_ints(runner.total_hits, dev)
     if rank == 0:
         shard_len = [gdist.shard_range(nq_total, r, world) for r in range(world)]
         cnt_cat, hit_cat = gathered_shards(torch, gdist, gather, last, shard_len, sizes, do_locate)
-        res["gather_wire"] = "compact" if getattr(gather, "compact_wire", False) else "arrays"
+        res["gather_wire"] = getattr(gather, "wire_name", "compact" if getattr(gather, "compact_wire", False) else "arrays")
         del gather, runner
         torch.cuda.empty_cache()
         single = StepRunner(torch, eng, input_form(full, eng.index, args, wl), nq_total, do_locate, args.path, hint=not args.no_hint)
@@ -1339,7 +1514,7 @@ def time_config(torch, eng, queries, nq, do_locate, args, steps=3):
 
 
 def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq, do_locate, args, wl, pmc_ref=None,
-                pmc_text=None, e2e=None, res=None):
+                pmc_text=None, e2e=None, res=None, pmc_lookup=None):
     """Secondary design points, never `value`.  (1) The speed-vs-HBM ladder: the same step with the jump / top tables
     rebuilt at other sizes on the same suffix array (gdx_index_rebuild_aux), down to the arrays with the reference's
     information content only; every rung must reproduce the headline's counts exactly.  (2) BASELINE.json configs[4]:
@@ -1448,25 +1623,48 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         del xo
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
         res[-1]["aux_structures"] = eng.aux_info()
-    # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays)
+    # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays): the
+    # like-for-like rung again -- the reference's arrays and NOTHING else (no seed table, text units, suffix array, pair
+    # lines, jump or top table) -- with its lookup tables of depth 10 and 13 in front of the LF steps
+    # (lookup_table.rs:51-161): a len-50 read starts from the interval of its last d symbols, one 8-byte fetch, and takes
+    # 50 - d steps instead of 50.  Algorithmic bytes per SURVEY 8(d): len + 8 (the lookup entry) + 60 x steps + 8.
     owned.clear()
     del eng, index
     torch.cuda.empty_cache()
-    t0 = time.time()
-    index2 = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=args.secondary_depth,
-                                          index_storage=wl["storage"], options=build_options_of(args))
-    apply_query_options(index2, args)
-    t_build = time.time() - t0
-    eng2 = DeviceEngine(index2)
-    ms, s_ms, l_ms, counts = time_config(torch, eng2, queries, nq, do_locate, args)
-    same = bool(torch.equal(counts, base_counts))
-    if not same:
-        raise SystemExit("PARITY FAILURE: the lookup-depth secondary changed the counts")
-    res.append({"name": f"lookup_depth_{args.secondary_depth}", "lookup_depth": args.secondary_depth,
-                "aux_structures": eng2.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
-                "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
-                "index_build_seconds": t_build, "index_bytes": int(index2.info.device_bytes)})
-    log(f"[bench] secondary {res[-1]}")
+    eng2 = index2 = counts = None
+    for depth in ((args.secondary_depth,) if args.no_extras else LOOKUP_RUNGS):
+        del eng2, index2, counts
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        index2 = build_index_from_device_text(io_text, lengths, alpha, sa_rate=args.sa_rate, lookup_depth=depth,
+                                              index_storage=wl["storage"], options=build_options_of(args, **REFERENCE_ARRAYS))
+        apply_query_options(index2, args)
+        t_build = time.time() - t0
+        eng2 = DeviceEngine(index2)
+        ms, s_ms, l_ms, counts = time_config(torch, eng2, queries, nq, do_locate, args)
+        same = bool(torch.equal(counts, base_counts))
+        if not same:
+            raise SystemExit(f"PARITY FAILURE: the lookup-depth-{depth} secondary changed the counts")
+        lf_steps, _, _ = eng2.search_step_stats(queries)
+        b = queries.total_bytes + 8 * nq + 60 * lf_steps + 8 * nq
+        r = {"name": f"reference_arrays_d{depth}", "lookup_depth": depth, "aux_structures": eng2.aux_info(),
+             "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms,
+             "counts_identical_to_headline": same, "index_build_seconds": t_build, "index_bytes": int(index2.info.device_bytes),
+             "lf_steps_per_query": lf_steps / nq,
+             "roofline": {"bound": "hbm", "kernel": "search_kernel<QuadLineTable, 4>", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                          "algorithmic_bytes_per_launch": b, "achieved_algorithmic": b / (s_ms / 1e3) / 1e9,
+                          "frac_algorithmic": b / (s_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_ms": s_ms}}
+        t_l = traffic_requests_of((pmc_lookup or {}).get(depth), "search_kernel", (pmc_lookup or {}).get("queries", LOOKUP_PMC_READS))
+        if t_l:  # DRAM requests of the same kernel on LOOKUP_PMC_READS of these reads (a PMC child pass of this run)
+            rq = t_l["read_requests"] / t_l["queries"]
+            r["roofline"].update({"dram_read_requests_per_query": rq, "dram_write_requests_per_query": t_l["write_requests"] / t_l["queries"],
+                                  "l2_hit_rate": t_l["l2_hits"] / max(t_l["l2_requests"], 1), "pmc_queries": t_l["queries"],
+                                  # every DRAM request of this GPU moves 128 bytes (profiles/r01/fetch_size_calibration.json)
+                                  "traffic_from_requests": 128.0 * (t_l["read_requests"] + t_l["write_requests"]) / t_l["queries"] * nq,
+                                  "frac_traffic_from_requests": 128.0 * (t_l["read_requests"] + t_l["write_requests"]) / t_l["queries"] * nq
+                                  / (s_ms / 1e3) / 1e9 / HBM_PEAK_GBPS})
+        res.append(r)
+        log(f"[bench] secondary {res[-1]}")
     if not args.no_extras and wl["total"] >= 1 << 24:
         del eng2, index2, counts
         torch.cuda.empty_cache()
@@ -1526,35 +1724,25 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     t_build = time.time() - t0
     eng = DeviceEngine(index)
     q = DeviceQueries.synth(text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
-    rec = eng.alloc_records(nq)
-    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
-    eng.locate_search(q, rec)
-    eng.locate_offsets(rec, nq, off, max_hits)
-    torch.cuda.synchronize()
-    total_hits = int(off[nq].item())
-    counts = (rec[:nq, 1] - rec[:nq, 0]).to(torch.int64) & 0xFFFFFFFF
-    hits = torch.empty((max(total_hits, 1), 2), dtype=torch.int32, device=dev)
-    ws = torch.empty(max(eng.locate_workspace_bytes(total_hits), 16), dtype=torch.uint8, device=dev)
-    ev = []
-
-    def step(record):
-        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        a.record()
-        eng.locate_search(q, rec)
-        b.record()
-        eng.locate_offsets(rec, nq, off, max_hits)
-        eng.locate_hits(rec, nq, off, total_hits, hits, ws)
-        c.record()
-        if record:
-            ev.append((a, b, c))
-
-    step(False)
+    # the headline's own step (StepRunner: compact results where the seed table answers, hit totals folded into the search, the
+    # whole step one call) with the per-query limit
+    runner = StepRunner(torch, eng, q, nq, True, args.path if getattr(args, "path", None) else "records")
+    runner.max_hits = max_hits
+    total_hits = runner.size()
+    runner.step(0, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
-        step(True)
+        runner.step(0, True)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
+    runner.check_totals()
+    runner.widen_offsets()
+    total_hits = runner.total_hits
+    out = runner.outs[0]
+    off, hits = out["hit_offsets"], runner.hits[0]
+    counts = runner.counts(out).to(torch.int64) & 0xFFFFFFFF
+    ev = [(a, b, c) for (a, b), (_, c) in zip(runner.ev_search, runner.ev_locate)]
     chk = verify_hits(torch, text, lengths, q, {"hit_offsets": off}, hits, total_hits, nq, 1_000_000) if total_hits else {}
     if chk and chk["hits_checked"] != chk["hits_matching_text"]:
         raise SystemExit(f"PARITY FAILURE on the genome-like text: {chk}")

@@ -179,6 +179,10 @@ SIGNATURES = {
     "gdx_locate_many_unpack_compact_dev": [vp, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_compact_split_hits_dev": [vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_compact_exceptions_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp],
+    "gdx_wire_bitmap_bytes": [C.c_uint64],
+    "gdx_wire_pack_workspace_bytes": [C.c_uint64],
+    "gdx_wire_pack_dev": [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp],
+    "gdx_wire_split_dev": [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp],
     "gdx_locate_many_totals_workspace_bytes": [C.c_uint64],
     "gdx_locate_many_totals_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     "gdx_locate_many_offsets_hits_compact_dev": [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp],
@@ -200,6 +204,8 @@ SIGNATURES = {
     "gdx_locate_many_search_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
     "gdx_locate_many_search_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp],
     "gdx_locate_many_search_totals_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), C.c_uint32, vp, vp, vp, vp, vp],
+    "gdx_locate_many_step_compact_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), C.c_uint32, vp, vp, vp, vp, vp,
+                                                C.c_uint32, vp, C.c_uint64, vp, vp, vp],
     "gdx_count_many_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp],
     "gdx_cursors_for_many_queries_layout_dev": [vp, vp, vp, C.c_uint64, C.POINTER(QueryLayout), vp, vp, vp, vp],
     "gdx_cursor_extend_front_strings_dev": [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp],
@@ -224,7 +230,8 @@ SIGNATURES = {
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
 }
-_RESTYPES = {"gdx_locate_many_totals_workspace_bytes": C.c_uint64, "gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
+_RESTYPES = {"gdx_locate_many_totals_workspace_bytes": C.c_uint64, "gdx_wire_bitmap_bytes": C.c_uint64,
+             "gdx_wire_pack_workspace_bytes": C.c_uint64, "gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
              "gdx_build_options_init": None, "gdx_query_layout_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
              "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64,
              "gdx_locate_many_scan_workspace_bytes": C.c_uint64}

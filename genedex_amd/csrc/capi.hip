@@ -1074,7 +1074,8 @@ static int offsets_hits_compact(bool narrow, const gdx_index_t *ix, const void *
                              ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(total_hits) : nullptr;
         gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
                                        max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits, total_hits,
-                                       false, as_stream(stream), sparse, flags, narrow);
+                                       false, as_stream(stream), sparse, flags, narrow, false,
+                                       gdx::locate_entry_sa(f.view(), f.query_options()));
         if (rest_hits != 0 || !sparse)
             gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits,
                                false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
@@ -1148,6 +1149,63 @@ int gdx_compact_exceptions_dev(const gdx_index_t *ix, const void *d_compact, uin
         DeviceGuard guard(f.config().device_id);
         gdx::launch_compact_exceptions(static_cast<const uint32_t *>(d_compact), nq, static_cast<uint32_t *>(d_out_queries),
                                        capacity, static_cast<unsigned long long *>(d_out_n), as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+uint64_t gdx_wire_bitmap_bytes(uint64_t nq) { return (nq + 2047) / 2048 * 256; }
+uint64_t gdx_wire_pack_workspace_bytes(uint64_t nq) { return gdx::wire_pack_workspace_bytes(nq); }
+
+int gdx_wire_pack_dev(const gdx_index_t *ix, const void *d_compact, const void *d_hit_offsets, uint32_t offsets_width,
+                      const void *d_hits, uint64_t nq, void *d_bitmap, void *d_tile_found, void *d_found_pos, uint64_t found_capacity,
+                      void *d_exc_queries, void *d_exc_counts, uint64_t exc_capacity, void *d_exc_text_ids, void *d_exc_positions,
+                      uint64_t exc_hits_capacity, void *d_meta, void *d_workspace, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!d_tile_found || !d_meta || !d_workspace || (nq != 0 && (!d_compact || !d_hit_offsets || !d_bitmap)) ||
+            (found_capacity != 0 && !d_found_pos) || (exc_capacity != 0 && (!d_exc_queries || !d_exc_counts)) ||
+            (exc_hits_capacity != 0 && (!d_exc_text_ids || !d_exc_positions || !d_hits)))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_wire_pack_dev: null buffer");
+        if (offsets_width != 32u && offsets_width != 64u) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "offsets_width must be 32 or 64");
+        if (reinterpret_cast<uintptr_t>(d_compact) % 16 != 0 || reinterpret_cast<uintptr_t>(d_workspace) % 8 != 0 ||
+            (reinterpret_cast<uintptr_t>(d_tile_found) | reinterpret_cast<uintptr_t>(d_found_pos) | reinterpret_cast<uintptr_t>(d_exc_queries) |
+             reinterpret_cast<uintptr_t>(d_exc_counts) | reinterpret_cast<uintptr_t>(d_exc_positions) | reinterpret_cast<uintptr_t>(d_meta)) % 4 != 0)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_wire_pack_dev: d_compact must be 16-byte, d_workspace 8-byte, the u32 / i32 arrays 4-byte aligned");
+        if (nq > 0xffffffffull) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_wire_pack_dev: more than 2^32 - 1 queries");
+        if (f.view().n_texts > 256u) gdx::fail(GDX_ERR_UNSUPPORTED, "gdx_wire_pack_dev: text ids as bytes need a collection of at most 256 texts");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_wire_pack(static_cast<const uint32_t *>(d_compact), d_hit_offsets, offsets_width == 32u,
+                              static_cast<const gdx_hit32_t *>(d_hits), nq, static_cast<uint8_t *>(d_bitmap),
+                              static_cast<uint32_t *>(d_tile_found), static_cast<uint32_t *>(d_found_pos), found_capacity,
+                              static_cast<uint32_t *>(d_exc_queries), static_cast<uint32_t *>(d_exc_counts), exc_capacity,
+                              static_cast<uint8_t *>(d_exc_text_ids), static_cast<int32_t *>(d_exc_positions), exc_hits_capacity,
+                              static_cast<uint32_t *>(d_meta), d_workspace, as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_wire_split_dev(const gdx_index_t *ix, const void *d_bitmap, const void *d_tile_found, const void *d_found_pos,
+                       uint64_t found_capacity, uint64_t nq, const void *d_exc_queries, const void *d_meta, uint64_t exc_capacity,
+                       void *d_out_text_ids, void *d_out_positions, void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!d_tile_found || !d_meta || (nq != 0 && (!d_bitmap || !d_out_text_ids || !d_out_positions)) ||
+            (found_capacity != 0 && !d_found_pos) || (exc_capacity != 0 && !d_exc_queries))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_wire_split_dev: null buffer");
+        if (reinterpret_cast<uintptr_t>(d_out_positions) % 16 != 0 || reinterpret_cast<uintptr_t>(d_out_text_ids) % 8 != 0 ||
+            (reinterpret_cast<uintptr_t>(d_tile_found) | reinterpret_cast<uintptr_t>(d_found_pos) | reinterpret_cast<uintptr_t>(d_exc_queries) |
+             reinterpret_cast<uintptr_t>(d_meta)) % 4 != 0)
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_wire_split_dev: d_out_positions must be 16-byte, d_out_text_ids 8-byte, the u32 arrays 4-byte aligned");
+        if (f.view().n_texts > 256u) gdx::fail(GDX_ERR_UNSUPPORTED, "gdx_wire_split_dev: text ids as bytes need a collection of at most 256 texts");
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_wire_split(f.view(), static_cast<const uint8_t *>(d_bitmap), static_cast<const uint32_t *>(d_tile_found),
+                               static_cast<const uint32_t *>(d_found_pos), found_capacity, nq, static_cast<const uint32_t *>(d_exc_queries),
+                               static_cast<const uint32_t *>(d_meta), exc_capacity, static_cast<uint8_t *>(d_out_text_ids),
+                               static_cast<int32_t *>(d_out_positions), as_stream(stream));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -1401,6 +1459,71 @@ int gdx_locate_many_search_totals_compact_layout_dev(const gdx_index_t *ix, cons
         else
             gdx::launch_scan_totals(static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
                                     false, d_scan_workspace, totals, as_stream(stream));
+        GDX_HIP(hipGetLastError());
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_locate_many_step_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                            const gdx_query_layout_t *layout, uint32_t max_hits, void *d_records, void *d_compact,
+                                            void *d_scan_workspace, void *d_totals, void *d_hit_offsets, uint32_t offsets_width,
+                                            void *d_hits, uint64_t hits_capacity, void *d_workspace, void *event_after_search,
+                                            void *stream)
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        check_records(d_records);
+        if (!d_scan_workspace || !d_totals || !d_hit_offsets || (hits_capacity != 0 && (!d_hits || !d_workspace)))
+            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_step_compact_layout_dev: null argument");
+        if (offsets_width != 32u && offsets_width != 64u) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "offsets_width must be 32 or 64");
+        const bool narrow = offsets_width == 32u;
+        if (narrow && hits_capacity >= (1ull << 32)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "32-bit hit offsets need fewer than 2^32 hits");
+        if ((reinterpret_cast<uintptr_t>(d_totals) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_totals must be 8-byte aligned");
+        DeviceGuard guard(f.config().device_id);
+        hipStream_t st = as_stream(stream);
+        unsigned long long *totals = static_cast<unsigned long long *>(d_totals);
+        // the scan pass stores the hits the compact results answer and flags the locate chunks that hold other slots
+        const bool store = d_compact != nullptr && hits_capacity != 0;
+        uint8_t *flags = store ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(hits_capacity) : nullptr;
+        gdx::ZeroSet zero;
+        zero.add(totals, 2 * sizeof(unsigned long long));
+        if (flags != nullptr) zero.add(flags, gdx::locate_chunk_flags_bytes(hits_capacity));
+        if (nq == 0) {
+            zero.add(d_hit_offsets, narrow ? sizeof(uint32_t) : sizeof(uint64_t));
+            zero.flush(st);
+            GDX_HIP(hipGetLastError());
+            if (event_after_search) GDX_HIP(hipEventRecord(static_cast<hipEvent_t>(event_after_search), st));
+            return (int)GDX_OK;
+        }
+        gdx::SearchCall c;
+        apply_layout(c, d_qbuf, d_qoff, nq, layout);
+        c.d_rec = static_cast<uint4 *>(d_records);
+        c.d_compact = static_cast<uint32_t *>(d_compact);
+        c.mode = 1;
+        bool folded = false;
+        if (d_compact != nullptr) {
+            c.d_tile_sums = static_cast<unsigned long long *>(d_scan_workspace);
+            c.d_tile_rest = totals + 1;
+            c.tile_max_hits = max_hits;
+            c.tile_sums_done = &folded;
+        }
+        c.also_zero = &zero;
+        gdx::launch_search_call(f.view(), c, st, f.query_options());
+        GDX_HIP(hipGetLastError());
+        if (folded)
+            gdx::launch_scan_totals_finish(d_scan_workspace, nq, totals, st);
+        else  // (zeroes the totals again and counts from the results)
+            gdx::launch_scan_totals(static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
+                                    false, d_scan_workspace, totals, st);
+        if (event_after_search) GDX_HIP(hipEventRecord(static_cast<hipEvent_t>(event_after_search), st));
+        gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
+                                       max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits,
+                                       hits_capacity, false, st, store, flags, narrow, true,
+                                       gdx::locate_entry_sa(f.view(), f.query_options()), totals);
+        if (hits_capacity != 0)
+            gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), hits_capacity, d_hits,
+                               false, d_workspace, st, nullptr, nullptr, f.query_options(), static_cast<const uint4 *>(d_records),
+                               false, false, static_cast<const uint32_t *>(d_compact), store, flags, narrow, totals);
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

@@ -31,6 +31,7 @@
 
 #include "fm_index.hpp"
 #include "kernels.hpp"
+#include "pack_host.hpp"
 
 namespace gdx {
 
@@ -628,32 +629,23 @@ uint64_t pack_queries_with_table(const uint8_t *tab, const uint8_t *qbuf, const 
                                  uint64_t *out_exc, uint64_t capacity)
 {
     if (!tab) fail(GDX_ERR_INVALID_ARGUMENT, "io_to_dense is null");
-    WorkerPool pool(host_threads());
+    // (a call of its own, not a stage of the pipeline: every CPU the process may use, unless GDX_HOST_THREADS says otherwise)
+    WorkerPool pool(getenv("GDX_HOST_THREADS") ? host_threads() : std::min(32u, usable_cpus()));
     check_queries(qbuf, qoff, nq, pool, 0);
     if (!out_packed && nq && qoff[nq]) fail(GDX_ERR_INVALID_ARGUMENT, "out_packed is null");
     const uint64_t n_sym = nq ? qoff[nq] : 0;
     const uint64_t n_bytes = div_ceil(n_sym, 4);
     const uint64_t first = nq ? qoff[0] : 0;  // symbols before the first query are not looked at (code 0)
     std::vector<std::vector<uint64_t>> bad(pool.size());
+    const PackPlan plan = make_pack_plan(tab);  // (pack_host.hpp: 32 symbols per step where the table has the shape for it)
     pool.run([&](unsigned w, unsigned nw) {
         const uint64_t per = (n_bytes / nw + 64) / 64 * 64;
         const uint64_t lo = std::min(n_bytes, per * w), hi = std::min(n_bytes, lo + per);
         std::vector<uint64_t> &mine = bad[w];
-        for (uint64_t b = lo; b < hi; b++) {
-            uint32_t out = 0;
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t j = 4 * b + k;
-                if (j < first || j >= n_sym) continue;
-                const uint32_t d = tab[qbuf[j]];
-                if (d - 1u < 4u) {
-                    out |= (d - 1u) << (2u * k);
-                } else {
-                    const uint64_t q = static_cast<uint64_t>(std::upper_bound(qoff, qoff + nq + 1, j) - qoff) - 1;
-                    if (mine.empty() || mine.back() != q) mine.push_back(q);
-                }
-            }
-            out_packed[b] = static_cast<uint8_t>(out);
-        }
+        pack_range(plan, tab, qbuf, first, n_sym, lo, hi, out_packed, [&](uint64_t j) {
+            const uint64_t q = static_cast<uint64_t>(std::upper_bound(qoff, qoff + nq + 1, j) - qoff) - 1;
+            if (mine.empty() || mine.back() != q) mine.push_back(q);
+        });
     });
     std::vector<uint64_t> all;
     for (auto &v : bad) all.insert(all.end(), v.begin(), v.end());

@@ -68,6 +68,19 @@ constexpr uint32_t kCompactSee = 0xfffffffeu;
 // in / out.  Any output may be null.  rec: one 16-byte record per query {start, end, hint row, hint symbols |
 // status << 24} for launch_hit_offsets_rec / launch_locate.
 constexpr uint32_t kSumTile = 2048;  // queries per tile of the two-pass offsets scan (locate.hip: kScan2Tile)
+
+// Several small device regions zeroed by ONE launch: the list counters, tile sums, totals and chunk flags of a count +
+// locate step were seven fills of ~4.6 us each -- a twentieth of the step a rank of eight runs on its 12.5 M reads.
+// Regions are 4-byte aligned; sizes are rounded up to whole 32-bit words.
+struct ZeroSet {
+    static constexpr int kMax = 8;
+    uint32_t *p[kMax] = {};
+    uint32_t words[kMax] = {};
+    int n = 0;
+    void add(void *ptr, size_t bytes);
+    void flush(hipStream_t stream);  // zeroes what was added (one kernel; nothing added: nothing launched) and empties the set
+};
+
 struct SearchCall {
     const uint8_t *d_qbuf = nullptr;
     const uint64_t *d_qbeg = nullptr, *d_qend = nullptr;
@@ -90,6 +103,8 @@ struct SearchCall {
     bool *tile_sums_done = nullptr;
     uint32_t uniform_len = 0;  // != 0: a uniform batch -- every query has this many symbols, query i starts at symbol
                                // i * uniform_len; d_qbeg / d_qend may be null (gdx_query_layout_t)
+    const ZeroSet *also_zero = nullptr;  // regions of the caller's to be zeroed before the call's first kernel (same launch
+                                         // as the call's own counters)
     CursorArgs cursors;
 };
 void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t stream,
@@ -147,6 +162,15 @@ void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64
 // the queries whose compact result says "see the record": unordered list (up to `capacity`), *d_n = how many there are
 void launch_compact_exceptions(const uint32_t *d_compact, uint64_t m, uint32_t *d_list, uint64_t capacity,
                                unsigned long long *d_n, hipStream_t stream);
+// the "found bitmap" wire of the multi-GPU gather (gdx_wire_pack_dev / gdx_wire_split_dev, locate.hip)
+size_t wire_pack_workspace_bytes(uint64_t m);
+void launch_wire_pack(const uint32_t *d_compact, const void *d_hit_offsets, bool narrow_offsets, const gdx_hit32_t *d_hits, uint64_t m,
+                      uint8_t *d_bitmap, uint32_t *d_tile_found, uint32_t *d_found_pos, uint64_t found_cap, uint32_t *d_exc_q,
+                      uint32_t *d_exc_cnt, uint64_t exc_cap, uint8_t *d_exc_ids, int32_t *d_exc_pos, uint64_t exc_hits_cap,
+                      uint32_t *d_meta, void *d_workspace, hipStream_t stream);
+void launch_wire_split(const IndexView &ix, const uint8_t *d_bitmap, const uint32_t *d_tile_found, const uint32_t *d_found_pos,
+                       uint64_t found_cap, uint64_t m, const uint32_t *d_exc_q, const uint32_t *d_meta, uint64_t exc_cap, uint8_t *d_ids,
+                       int32_t *d_pos, hipStream_t stream);
 size_t locate_workspace_bytes(uint64_t total_hits);
 // HitT = gdx_hit32_t (wide == false) or gdx_hit_t (wide == true)
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
@@ -155,7 +179,9 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
                    const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false,
                    const uint32_t *d_compact = nullptr, bool compact_stored = false, const uint8_t *d_chunk_flags = nullptr,
-                   bool narrow_offsets = false);  // d_hit_offsets is u32[m + 1] (records path only)
+                   bool narrow_offsets = false,  // d_hit_offsets is u32[m + 1] (records path only)
+                   const unsigned long long *d_total = nullptr);  // != null: the number of hit slots is read on the device (no host
+                                                                  // round trip); total_hits is then the hit buffer's capacity
 // Offsets scan in two steps with the one host round trip between them: launch_scan_totals leaves d_totals (u64[2]) = {all
 // hit slots, the slots of queries whose compact result says "see the record"} and the tile bases in d_scan_workspace
 // (scan_totals_workspace_bytes); launch_scan_offsets_store then writes the offsets and, in the same pass, the hit of every
@@ -167,7 +193,11 @@ void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t 
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
                                bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
                                uint64_t hits_capacity, bool wide, hipStream_t stream, bool store = true,
-                               uint8_t *d_chunk_flags = nullptr, bool narrow_offsets = false);
+                               uint8_t *d_chunk_flags = nullptr, bool narrow_offsets = false, bool flags_zeroed = false,
+                               bool entry_sa = false,  // locate_entry_sa(ix, qo): the pass may locate small "see the record" queries itself
+                               const unsigned long long *d_totals = nullptr);  // != null: ... only if the totals say they are few
+bool locate_entry_sa(const IndexView &ix, const QueryOptions &qo);
+size_t locate_chunk_flags_bytes(uint64_t total_hits);
 // store == false: offsets only.  d_chunk_flags (inside the locate workspace at locate_chunk_flags_offset(total_hits), filled by
 // the store pass): launch_locate then only visits the chunks of hit slots in which that pass left something open
 size_t locate_chunk_flags_offset(uint64_t total_hits);

@@ -147,12 +147,24 @@ struct HitOffsets {
 
 // first[c] = the query that owns hit slot c * chunk (the largest q with hit_offsets[q] <= c * chunk; empty
 // queries in between share the offset and are skipped by taking the largest).  One lane per chunk.
+// d_total != null (a step without host round trip, gdx_locate_many_step_compact_layout_dev): the number of hit slots is
+// read on the device -- `total` is then the capacity of the hit buffer, and what lies beyond it is not located; chunk_flags
+// != null: only the entries a flagged chunk reads (its own and the next one's) are computed
 __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hit_offsets, uint64_t m,
                                                                    uint64_t n_chunks, uint32_t chunk, uint64_t total,
-                                                                   uint32_t *__restrict__ first)
+                                                                   uint32_t *__restrict__ first,
+                                                                   const unsigned long long *__restrict__ d_total,
+                                                                   const uint8_t *__restrict__ chunk_flags)
 {
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (d_total != nullptr) {
+        const uint64_t t = *d_total;
+        total = t < total ? t : total;
+        n_chunks = (total + chunk - 1) / chunk;
+        if (total == 0) return;
+    }
     if (c > n_chunks) return;
+    if (chunk_flags != nullptr && !((c < n_chunks && chunk_flags[c] != 0) || (c > 0 && chunk_flags[c - 1] != 0))) return;
     // entry n_chunks = the query that owns the LAST hit slot, so that the last chunk's block stops there instead of
     // scanning every trailing query without hits
     const uint64_t h0 = c < n_chunks ? c * chunk : total - 1;
@@ -165,6 +177,214 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hi
     first[c] = static_cast<uint32_t>(lo - 1);  // hit_offsets[0] = 0 <= h0, so lo >= 1
 }
 
+constexpr uint32_t kLocateChunk = 2048;  // hit slots a block takes at a time (locate_queue_kernel, locate_stream_kernel)
+
+// Text ids through a coarse table (text_id_search_tree.rs:35-64 computes the same lower bound): s_tab[b] = the text that holds
+// position b << shift, 513 entries over the whole collection, so that the search for a position runs between two neighbouring
+// entries -- no step at all unless a text border falls into the position's block (one of 24 texts in 3.1 G symbols: one block
+// in twenty) -- instead of a five-step binary search of dependent LDS loads for every hit.
+constexpr uint32_t kTextTab = 512;
+__device__ __forceinline__ void build_text_table(uint32_t *s_tab, const uint32_t *sentinels, uint32_t n_texts, uint32_t shift)
+{
+    for (uint32_t b = threadIdx.x; b <= kTextTab; b += kBlock) {
+        const uint64_t x = static_cast<uint64_t>(b) << shift;
+        s_tab[b] = x > 0xffffffffull ? n_texts : lower_bound_u32(sentinels, n_texts, static_cast<uint32_t>(x));
+    }
+}
+template <bool kWide>
+__device__ __forceinline__ void store_hit_tab(const uint32_t *s_tab, uint32_t shift, const uint32_t *sentinels, uint32_t pos,
+                                              void *hits_out, uint64_t at)
+{
+    const uint32_t b = pos >> shift;
+    uint32_t lo = s_tab[b], hi = s_tab[b + 1];
+    while (lo < hi) {  // smallest t in [lo, hi] with pos <= sentinels[t]
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sentinels[mid] < pos) lo = mid + 1u;
+        else hi = mid;
+    }
+    const uint32_t in_text = lo == 0u ? pos : pos - sentinels[lo - 1u] - 1u;
+    if (kWide) {
+        gdx_hit_t out;
+        out.text_id = lo;
+        out.position = in_text;
+        static_cast<gdx_hit_t *>(hits_out)[at] = out;
+    } else {
+        gdx_hit32_t out;
+        out.text_id = lo;
+        out.position = in_text;
+        static_cast<gdx_hit32_t *>(hits_out)[at] = out;
+    }
+}
+
+// The locate kernel of an index on which SA[row] is ONE fetch (full suffix array, or 32-byte jump entries): nothing walks, so
+// a hit is a record decode, one SA load, a text-id lookup and an 8-byte store -- and what the general queue kernel below
+// spends around that (a 256-thread max-scan of 16 barriers per chunk, three dependent loads per slot, a five-step LDS search)
+// was most of its time: 573 M hits of a text of repeats took 3.3 ms at 0.26 of the HBM peak.  Same chunks, same slot -> query
+// map by head marks; here the marks carry the head's slot, so that a slot knows its number inside its query without
+// reading the offsets again, the scan is a wavefront scan with four barriers per chunk, the loads of four slots are issued
+// together, and text ids come from the coarse table.  Consecutive slots of one query are consecutive rows: their SA loads
+// and hit stores are coalesced, their record loads one broadcast.
+struct StreamView {
+    const uint32_t *sa_full, *jump32;  // SA[row], or word 6 of the 32-byte jump entry of the row
+    const uint32_t *sentinels;
+    uint32_t n_texts, tab_shift;
+    uint32_t skip_single;  // LocateView::skip_single
+};
+
+template <bool kWide>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void locate_stream_kernel(
+    StreamView sv, const uint32_t *__restrict__ start, HitOffsets hit_offsets, uint64_t m, const uint32_t *__restrict__ first_query,
+    const uint2 *__restrict__ hint, const uint4 *__restrict__ rec, uint64_t total, void *__restrict__ hits_out,
+    const uint32_t *__restrict__ compact, const uint8_t *__restrict__ chunk_flags, const unsigned long long *__restrict__ d_total)
+{
+    if (d_total != nullptr) {
+        const uint64_t t = *d_total;
+        total = t < total ? t : total;
+    }
+    const uint64_t n_chunks = (total + kLocateChunk - 1) / kLocateChunk;
+    if (chunk_flags != nullptr) {  // nothing flagged among this block's chunks (the usual case on a text without repeats): done
+        int any = 0;
+        for (uint64_t ch = blockIdx.x + static_cast<uint64_t>(threadIdx.x) * gridDim.x; ch < n_chunks; ch += static_cast<uint64_t>(kBlock) * gridDim.x)
+            any |= chunk_flags[ch] != 0;
+        if (!__syncthreads_or(any)) return;
+    }
+    constexpr uint32_t kPer = kLocateChunk / kBlock;  // slots per thread
+    constexpr uint32_t kLdsTexts = 256;
+    __shared__ uint32_t s_map[kLocateChunk];  // (query of the slot, relative to the chunk's first, + 1) << 11 | the slot of its head
+    __shared__ uint32_t s_tab[kTextTab + 1];
+    __shared__ uint32_t s_sentinels[kLdsTexts];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_carry;  // slots of the chunk's first query that lie in earlier chunks
+    const uint32_t *sentinels = sv.sentinels;
+    if (sv.n_texts <= kLdsTexts) {
+        for (uint32_t i = threadIdx.x; i < sv.n_texts; i += kBlock) s_sentinels[i] = sv.sentinels[i];
+        sentinels = s_sentinels;
+        __syncthreads();
+    }
+    build_text_table(s_tab, sentinels, sv.n_texts, sv.tab_shift);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (chunk_flags != nullptr && chunk_flags[chunk] == 0) continue;  // (block-uniform)
+        const uint64_t base = chunk * kLocateChunk;
+        const uint32_t cnt = total - base < kLocateChunk ? static_cast<uint32_t>(total - base) : kLocateChunk;
+        const uint32_t qa = first_query[chunk], qb = first_query[chunk + 1];
+        __syncthreads();  // the previous chunk's map is read, the table is built
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j += 4)
+            *reinterpret_cast<uint4 *>(&s_map[threadIdx.x * kPer + j]) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (uint64_t q = static_cast<uint64_t>(qa) + threadIdx.x; q <= qb; q += kBlock) {
+            const uint64_t a = hit_offsets[q], b = hit_offsets[q + 1];
+            const uint64_t from = a > base ? a : base;
+            if (b > from && from < base + cnt) {
+                s_map[from - base] = ((static_cast<uint32_t>(q - qa) + 1u) << 11) | static_cast<uint32_t>(from - base);
+                if (q == qa) s_carry = static_cast<uint32_t>(from - a);  // (the owner of slot `base`: always has slots here)
+            }
+        }
+        __syncthreads();
+        {   // inclusive max-scan of the marks over the chunk's slots: eight consecutive slots per thread, the lanes of a
+            // wavefront by shuffles, the four wavefronts through LDS
+            uint32_t v[kPer];
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j += 4) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(&s_map[threadIdx.x * kPer + j]);
+                v[j] = t.x, v[j + 1] = t.y, v[j + 2] = t.z, v[j + 3] = t.w;
+            }
+#pragma unroll
+            for (uint32_t j = 1; j < kPer; j++) v[j] = v[j] > v[j - 1] ? v[j] : v[j - 1];
+            uint32_t x = v[kPer - 1];
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(x, off);
+                if (static_cast<int>(lane) >= off) x = o > x ? o : x;
+            }
+            if (lane == 63u) s_wave[wave] = x;
+            uint32_t before = __shfl_up(x, 1);
+            if (lane == 0u) before = 0u;
+            __syncthreads();
+            for (uint32_t w = 0; w < wave; w++) before = s_wave[w] > before ? s_wave[w] : before;
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) v[j] = v[j] > before ? v[j] : before;
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j += 4)
+                *reinterpret_cast<uint4 *>(&s_map[threadIdx.x * kPer + j]) = make_uint4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+        }
+        __syncthreads();
+        const uint32_t carry = s_carry;
+        // four slots at a time, a stage for all four before the next: map -> compact result -> record -> SA -> hit
+#pragma unroll
+        for (uint32_t half = 0; half < kPer; half += 4) {
+            uint32_t q[4], within[4], c4[4], pos[4];
+            bool live[4], need_sa[4];
+            uint4 r[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = threadIdx.x + (half + j) * kBlock;
+                live[j] = i < cnt;
+                const uint32_t p = live[j] ? s_map[i] : (1u << 11);
+                const uint32_t qrel = p >> 11;
+                q[j] = qa + qrel - 1u;
+                within[j] = i - (p & 2047u) + (qrel == 1u ? carry : 0u);
+                c4[j] = (live[j] && compact != nullptr) ? compact[q[j]] : kCompactSee;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                need_sa[j] = false;
+                pos[j] = 0;
+                if (!live[j]) continue;
+                if (c4[j] < kCompactSee) {  // the position itself (skip_single 2: launch_scan_offsets_store has stored it)
+                    pos[j] = c4[j];
+                    live[j] = sv.skip_single != 2u;
+                    continue;
+                }
+                if (rec != nullptr) r[j] = rec[q[j]];
+                else r[j] = make_uint4(start[q[j]], 0u, 0xffffffffu, 0u);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (!live[j] || c4[j] < kCompactSee) continue;
+                if (sv.skip_single == 1u && hit_offsets[q[j] + 1] - hit_offsets[q[j]] == 1u) {  // in place already (scan_locate_kernel)
+                    live[j] = false;
+                    continue;
+                }
+                uint32_t row = r[j].x + within[j], back = 0;
+                if (rec != nullptr) {
+                    if (r[j].w & kRecResolved) {  // the search already knows the text position
+                        pos[j] = r[j].z;
+                        continue;
+                    }
+                    if (r[j].w & kRecMasked) {  // the within-th surviving row of the mask, `symbols` steps before the hit
+                        uint32_t mk = r[j].z;
+                        for (uint32_t t = within[j]; t > 0u; t--) mk &= mk - 1u;
+                        row = r[j].x + static_cast<uint32_t>(__builtin_ctz(mk | 0x80000000u));
+                        back = r[j].w & 0x1fffffu;
+                    } else if (r[j].z != 0xffffffffu && r[j].y - r[j].x == 1u) {
+                        row = r[j].z;
+                        back = r[j].w & 0xffffffu;
+                    }
+                } else if (hint != nullptr && hit_offsets[q[j] + 1] - hit_offsets[q[j]] == 1u) {
+                    const uint2 hv = hint[q[j]];
+                    if (hv.x != 0xffffffffu && hv.y < (1u << 21)) {
+                        row = hv.x;
+                        back = hv.y;
+                    }
+                }
+                need_sa[j] = true;
+                pos[j] = back;
+                r[j].x = row;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (need_sa[j]) {
+                    const uint32_t sa = sv.sa_full != nullptr ? sv.sa_full[r[j].x] : sv.jump32[static_cast<uint64_t>(r[j].x) * 8u + 6u];
+                    pos[j] = sa - pos[j];
+                }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (live[j]) store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, pos[j], hits_out, base + threadIdx.x + (half + j) * kBlock);
+        }
+    }
+}
+
 // The default locate kernel.  A block takes chunks of kLocateChunk consecutive hit slots.  Phase 0, one lane per
 // hit, coalesced: the hits that need no walk are finished at once with their single sample read -- the row is
 // sampled itself, or the search left a hint for this one-row interval (launch_search: a sampled row the query's
@@ -172,7 +392,6 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hi
 // SA[hit row] = SA[hint row] - symbols) -- and the others are queued in LDS.  Phase 1: every lane walks a queued
 // hit and takes the next one from the queue the moment it is done, so the geometric tail of the walk lengths
 // (mean 3 steps at rate 4, maximum over a wavefront ~15) does not idle the other lanes.
-constexpr uint32_t kLocateChunk = 2048;
 
 // Phase 1 walks through the JUMP TABLE when the index has 16-byte entries (kJumpWalk): the entry of row r names the
 // rows after 8 and 16 LF steps, so one fetch offers two candidates for a sampled row (SA[r] = SA[t_j] + 8 j) where a
@@ -206,8 +425,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                               void *__restrict__ hits_out,
                                                               unsigned long long *__restrict__ step_stats,
                                                               const uint32_t *__restrict__ compact,
-                                                              const uint8_t *__restrict__ chunk_flags)  // != null: only the chunks flagged
+                                                              const uint8_t *__restrict__ chunk_flags,  // != null: only the chunks flagged
+                                                              const unsigned long long *__restrict__ d_total)  // != null: see chunk_first_query_kernel
 {
+    if (d_total != nullptr) {
+        const uint64_t t = *d_total;
+        total = t < total ? t : total;
+    }
+    if (chunk_flags != nullptr) {  // nothing flagged among this block's chunks (the usual case on a text without repeats): done
+        const uint64_t n_ch = (total + kLocateChunk - 1) / kLocateChunk;
+        int any = 0;
+        for (uint64_t ch = blockIdx.x + static_cast<uint64_t>(threadIdx.x) * gridDim.x; ch < n_ch; ch += static_cast<uint64_t>(kBlock) * gridDim.x)
+            any |= chunk_flags[ch] != 0;
+        if (!__syncthreads_or(any)) return;
+    }
     IndexView ix{};
     ix.lines = lv.lines;
     ix.sb_offsets = lv.sb_offsets;
@@ -717,6 +948,9 @@ void launch_hit_offsets(const uint32_t *d_start, const uint32_t *d_end, uint64_t
 constexpr uint32_t kScan2Rows = 8;
 constexpr uint32_t kScan2Wave = 64 * kScan2Rows;              // queries per wavefront
 constexpr uint32_t kScan2Tile = (kBlock / 64) * kScan2Wave;   // queries per block and tile (2048)
+constexpr uint32_t kScanInlineMax = 2048;  // slots of a "see the record" query the store pass locates itself (ScanStore)
+// the second pass runs on a grid the chip holds at once (six blocks of its 80 registers per CU), every block over many tiles
+static unsigned scan2_grid(uint64_t n_tiles) { return static_cast<unsigned>(n_tiles < 1536 ? n_tiles : 1536); }
 
 // the counts of queries q0, q0 + 64, ..: all loads issued before any is looked at (RecordSize::operator() asks for the record
 // only after it has seen the compact result -- eight dependent round trips per thread when called in a loop)
@@ -796,8 +1030,11 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(RecordSize f, u
 // sums, a wavefront scans its 1024 with DPP-free shuffles and only the 16 wavefront totals go through LDS: two barriers
 // per 16 K sums (the first version scanned in LDS, ten doubling steps with two barriers each: 60 us for the 48.8 K tiles
 // of 100 M queries, a tenth of the pass it prepares)
-__global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_tiles)
+__global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_tiles,
+                                                          unsigned long long *__restrict__ total_out,  // optional: = sums[n_tiles]
+                                                          uint64_t array_stride = 0)  // block b scans the array at sums + b * array_stride
 {
+    sums += static_cast<uint64_t>(blockIdx.x) * array_stride;
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -831,44 +1068,102 @@ __global__ __launch_bounds__(1024) void scan2_sums_kernel(unsigned long long *__
         if (threadIdx.x == 1023) s_carry = before;
         __syncthreads();
     }
-    if (threadIdx.x == 0) sums[n_tiles] = s_carry;
+    if (threadIdx.x == 0) {
+        sums[n_tiles] = s_carry;
+        if (total_out != nullptr) *total_out = s_carry;
+    }
 }
 
-// kStore: the pass also stores the hit of every query whose compact result IS its position (text id by the search tree of
-// text_id_search_tree.rs:35-64 over the sentinel positions, from LDS when they are few) -- offsets and most hits in one
-// pass over 4 bytes per query; hits at or beyond hits_capacity are not stored
+// what the store pass needs beside the counts (scan2_tile_scan_kernel<true, .>)
+struct ScanStore {
+    const uint32_t *sentinels;
+    uint32_t n_texts, tab_shift;
+    void *hits_out;
+    uint64_t hits_capacity;
+    uint8_t *chunk_flags;  // != null (pre-zeroed): marks the locate chunks that hold slots this pass leaves open
+    // SA[row] in one fetch (full suffix array, or 32-byte jump entries: word 6), or both null.  With it the pass locates the
+    // queries whose compact result says "see the record" ITSELF when they are few and small (`inline_max` slots at most;
+    // d_totals != null: only when the totals say that at most a sixteenth of the slots is theirs): on a text without repeats
+    // a few reads in a million, whose chunks the queue kernel then need not visit -- it finds no flag and leaves.
+    const uint32_t *sa_full, *jump32;
+    const unsigned long long *d_totals;
+    uint32_t inline_max;
+};
+
+// The second pass of the offsets scan: every tile scans itself from its base.  kStore: the pass also stores the hit of every
+// query whose compact result IS its position -- offsets and most hits in one pass over 4 bytes per query; hits at or beyond
+// hits_capacity are not stored.  A resident grid: a block takes tiles blockIdx.x, + gridDim.x, ... and has the next tile's
+// compact words and base on their way while it scans and stores the current one (one short-lived block per tile paid the
+// whole chain load -> scan -> barrier -> base -> stores with nothing else of its own in flight: 0.40 of the HBM peak).
 template <bool kStore, bool kWide>
 __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, uint64_t m, const unsigned long long *__restrict__ sums,
-                                                                 uint64_t *__restrict__ offsets, const uint32_t *__restrict__ sentinels_g,
-                                                                 uint32_t n_texts, void *__restrict__ hits_out, uint64_t hits_capacity,
-                                                                 uint8_t *__restrict__ chunk_flags,  // kStore, != null (pre-zeroed): marks the
-                                                                 // locate chunks that hold slots this pass leaves open
+                                                                 uint64_t *__restrict__ offsets, ScanStore ss,
                                                                  uint32_t narrow)  // offsets is u32[m + 1] (the total fits)
 {
     __shared__ unsigned long long s_part[kBlock / 64];
-    constexpr uint32_t kLdsTexts = 256;
+    constexpr uint32_t kLdsTexts = 256, kExc = 64;
     __shared__ uint32_t s_sentinels[kStore ? kLdsTexts : 1];
-    const uint32_t *sentinels = sentinels_g;
-    IndexView ix{};
+    __shared__ uint32_t s_tab[kStore ? kTextTab + 1 : 1];
+    __shared__ uint32_t s_exc_q[kStore ? kExc : 1], s_exc_lo[kStore ? kExc : 1], s_exc_hi[kStore ? kExc : 1];
+    __shared__ uint32_t s_nexc;
+    const uint32_t *sentinels = ss.sentinels;
+    bool inline_on = false;
     if (kStore) {
-        ix.sentinels = sentinels_g;
-        ix.n_texts = n_texts;
-        if (n_texts <= kLdsTexts) {
-            for (uint32_t i = threadIdx.x; i < n_texts; i += kBlock) s_sentinels[i] = sentinels_g[i];
+        if (ss.n_texts <= kLdsTexts) {
+            for (uint32_t i = threadIdx.x; i < ss.n_texts; i += kBlock) s_sentinels[i] = ss.sentinels[i];
             sentinels = s_sentinels;
             __syncthreads();
         }
+        build_text_table(s_tab, sentinels, ss.n_texts, ss.tab_shift);
+        if (threadIdx.x == 0) s_nexc = 0;
+        inline_on = ss.inline_max != 0u && (ss.sa_full != nullptr || ss.jump32 != nullptr);
+        if (inline_on && ss.d_totals != nullptr) inline_on = ss.d_totals[1] * 16ull <= ss.d_totals[0];
+        __syncthreads();
     }
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool have_compact = f.compact != nullptr;
+    // the next tile's compact words (records-only calls read their counts from the records when the tile's turn comes)
+    uint32_t c4n[kScan2Rows];
+    unsigned long long base_n = 0;
+    auto prefetch = [&](uint64_t tile) __attribute__((always_inline)) {
+        const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) {
+            const uint64_t q = q0 + j * 64u;
+            c4n[j] = have_compact ? (q < m ? f.compact[q] : kCompactNone) : kCompactSee;
+        }
+        base_n = sums[tile];
+    };
+    if (blockIdx.x < n_tiles) prefetch(blockIdx.x);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t q0 = tile * kScan2Tile + wave * kScan2Wave + lane;
-        unsigned long long c[kScan2Rows], incl[kScan2Rows], carry = 0;
-        uint32_t c4[kScan2Rows];
-        scan2_load_counts(f, q0, m, c, c4);
+        uint32_t c4[kScan2Rows], c[kScan2Rows];
+        unsigned long long incl[kScan2Rows], carry = 0;
+        const unsigned long long tile_base = base_n;
+#pragma unroll
+        for (uint32_t j = 0; j < kScan2Rows; j++) c4[j] = c4n[j];
+        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
+        if (have_compact) {
+#pragma unroll
+            for (uint32_t j = 0; j < kScan2Rows; j++)
+                c[j] = c4[j] == kCompactSee ? static_cast<uint32_t>(f(q0 + j * 64u)) : (c4[j] == kCompactNone ? 0u : 1u);
+        } else {
+            uint2 v[kScan2Rows];
+#pragma unroll
+            for (uint32_t j = 0; j < kScan2Rows; j++) {
+                const uint64_t q = q0 + j * 64u;
+                v[j] = q < m ? *reinterpret_cast<const uint2 *>(f.rec + q) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kScan2Rows; j++) {
+                const uint32_t n = v[j].y - v[j].x;
+                c[j] = (f.max_hits != 0u && n > f.max_hits) ? (f.take ? f.max_hits : 0u) : n;
+            }
+        }
         bool big = false;
 #pragma unroll
-        for (uint32_t j = 0; j < kScan2Rows; j++) big = big || c[j] >= (1ull << 25);
+        for (uint32_t j = 0; j < kScan2Rows; j++) big = big || c[j] >= (1u << 25);
         // row j = queries q0 - lane + 64 j ..: an inclusive scan across the lanes, rows chained by their totals -- in 32
         // bits when no count of the wavefront could make a row's sum overflow (64 x 2^25), which is practically always
         if (__ballot(big) == 0ull) {
@@ -876,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
             for (uint32_t j = 0; j < kScan2Rows; j++) {
                 // inclusive scan over the 64 lanes by DPP: inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of row 0 / 2
                 // onto row 1 / 3 (row_bcast15) and lane 31 onto rows 2 and 3 (row_bcast31)
-                int x = static_cast<int>(static_cast<uint32_t>(c[j]));
+                int x = static_cast<int>(c[j]);
                 x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
                 x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
                 x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
@@ -900,7 +1195,7 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
         }
         if (lane == 0) s_part[wave] = carry;  // the wavefront's total
         __syncthreads();
-        unsigned long long before = sums[tile];
+        unsigned long long before = tile_base;
         for (uint32_t w = 0; w < wave; w++) before += s_part[w];
 #pragma unroll
         for (uint32_t j = 0; j < kScan2Rows; j++) {
@@ -909,16 +1204,62 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
                 const uint64_t at = before + incl[j] - c[j];
                 if (narrow) reinterpret_cast<uint32_t *>(offsets)[q] = static_cast<uint32_t>(at);
                 else offsets[q] = at;
-                if (kStore && c[j] != 0ull) {
+                if (kStore && c[j] != 0u) {
                     if (c4[j] < kCompactSee) {
-                        if (at < hits_capacity) store_hit<kWide>(ix, c4[j], hits_out, at, sentinels);
-                    } else if (chunk_flags != nullptr) {
-                        for (uint64_t ch = at / kLocateChunk; ch <= (at + c[j] - 1u) / kLocateChunk; ch++) chunk_flags[ch] = 1;
+                        if (at < ss.hits_capacity) store_hit_tab<kWide>(s_tab, ss.tab_shift, sentinels, c4[j], ss.hits_out, at);
+                    } else {
+                        bool open = true;  // the query's slots are left to the queue kernel
+                        if (inline_on && c[j] <= ss.inline_max && at + c[j] <= ss.hits_capacity) {
+                            const uint32_t k = atomicAdd(&s_nexc, 1u);
+                            if (k < kExc) {
+                                s_exc_q[k] = static_cast<uint32_t>(q);
+                                s_exc_lo[k] = static_cast<uint32_t>(at);
+                                s_exc_hi[k] = static_cast<uint32_t>(at >> 32);
+                                open = false;
+                            }
+                        }
+                        if (open && ss.chunk_flags != nullptr) {
+                            // (chunks that begin at or beyond the capacity have no flag, and nothing of them is located)
+                            for (uint64_t ch = at / kLocateChunk; ch <= (at + c[j] - 1u) / kLocateChunk && ch * kLocateChunk < ss.hits_capacity; ch++)
+                                ss.chunk_flags[ch] = 1;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
+        if (kStore && s_nexc != 0u) {  // (block-uniform) the tile's few "see the record" queries, a wavefront each
+            const uint32_t n_exc = s_nexc < kExc ? s_nexc : kExc;
+            for (uint32_t e = wave; e < n_exc; e += kBlock / 64) {
+                const uint32_t q = s_exc_q[e];
+                const uint64_t at = (static_cast<uint64_t>(s_exc_hi[e]) << 32) | s_exc_lo[e];
+                const uint4 r = f.rec[q];
+                uint32_t cnt = r.y - r.x;
+                if (f.max_hits != 0u && cnt > f.max_hits) cnt = f.take ? f.max_hits : 0u;  // RecordSize
+                for (uint32_t i = lane; i < cnt; i += 64u) {  // the record's rows as locate_queue_kernel reads them
+                    uint32_t pos;
+                    if (r.w & kRecResolved) {
+                        pos = r.z;
+                    } else {
+                        uint32_t row = r.x + i, back = 0;
+                        if (r.w & kRecMasked) {
+                            uint32_t mk = r.z;
+                            for (uint32_t t = i; t > 0u; t--) mk &= mk - 1u;
+                            row = r.x + static_cast<uint32_t>(__builtin_ctz(mk | 0x80000000u));
+                            back = r.w & 0x1fffffu;
+                        } else if (r.z != 0xffffffffu && r.y - r.x == 1u) {
+                            row = r.z;
+                            back = r.w & 0xffffffu;
+                        }
+                        const uint32_t sa = ss.sa_full != nullptr ? ss.sa_full[row] : ss.jump32[static_cast<uint64_t>(row) * 8u + 6u];
+                        pos = sa - back;
+                    }
+                    store_hit_tab<kWide>(s_tab, ss.tab_shift, sentinels, pos, ss.hits_out, at + i);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_nexc = 0;  // (the next tile's first push comes after its first barrier)
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (narrow) reinterpret_cast<uint32_t *>(offsets)[m] = static_cast<uint32_t>(sums[n_tiles]);
@@ -947,12 +1288,10 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
         unsigned long long *sums = static_cast<unsigned long long *>(d_temp);
         const unsigned grid = static_cast<unsigned>(n_tiles < 65536 ? n_tiles : 65536);
         unsigned long long *const no_rest = nullptr;
-        const uint32_t *const no_sent = nullptr;
-        void *const no_hits = nullptr;
         hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, no_rest);
-        hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           no_sent, 0u, no_hits, uint64_t(0), static_cast<uint8_t *>(nullptr), 0u);
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles, static_cast<unsigned long long *>(nullptr));
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(scan2_grid(n_tiles)), dim3(kBlock), 0, stream, f, m, sums,
+                           d_hit_offsets, ScanStore{}, 0u);
         return;
     }
     RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
@@ -968,6 +1307,8 @@ size_t locate_chunk_flags_offset(uint64_t total_hits)
     return align_up((n_chunks + 2) * sizeof(uint32_t), 256);
 }
 
+size_t locate_chunk_flags_bytes(uint64_t total_hits) { return (total_hits + kLocateChunk - 1) / kLocateChunk + 1; }
+
 size_t scan_totals_workspace_bytes(uint64_t m) { return ((m + kScan2Tile - 1) / kScan2Tile + 2) * sizeof(unsigned long long); }
 
 void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits, bool take,
@@ -980,8 +1321,7 @@ void launch_scan_totals(const uint4 *d_rec, const uint32_t *d_compact, uint64_t 
     unsigned long long *sums = static_cast<unsigned long long *>(d_scan_workspace);
     const unsigned grid = static_cast<unsigned>(n_tiles < 4096 ? n_tiles : 4096);
     hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_totals + 1);
-    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
-    GDX_HIP(hipMemcpyAsync(d_totals, sums + n_tiles, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles, d_totals);
 }
 
 // the second half of launch_scan_totals when the search call has filled the tile sums itself (SearchCall::d_tile_sums;
@@ -992,14 +1332,13 @@ void launch_scan_totals_finish(void *d_scan_workspace, uint64_t m, unsigned long
     if (m == 0) return;
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     unsigned long long *sums = static_cast<unsigned long long *>(d_scan_workspace);
-    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles);
-    GDX_HIP(hipMemcpyAsync(d_totals, sums + n_tiles, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles, d_totals);
 }
 
 void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t m, uint32_t max_hits,
                                bool take, const void *d_scan_workspace, uint64_t *d_hit_offsets, void *d_hits,
                                uint64_t hits_capacity, bool wide, hipStream_t stream, bool store, uint8_t *d_chunk_flags,
-                               bool narrow_offsets)
+                               bool narrow_offsets, bool flags_zeroed, bool entry_sa, const unsigned long long *d_totals)
 {
     const uint32_t narrow = narrow_offsets ? 1u : 0u;
     if (m == 0) {
@@ -1009,17 +1348,31 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
     const RecordSize f{d_rec, d_compact, m, max_hits, take};
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const unsigned long long *sums = static_cast<const unsigned long long *>(d_scan_workspace);
-    const unsigned grid = static_cast<unsigned>(n_tiles < 65536 ? n_tiles : 65536);
-    if (d_chunk_flags != nullptr) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, (hits_capacity + kLocateChunk - 1) / kLocateChunk + 1, stream));
-    if (!store || d_compact == nullptr || d_hits == nullptr)
+    if (d_chunk_flags != nullptr && !flags_zeroed) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, locate_chunk_flags_bytes(hits_capacity), stream));
+    const unsigned grid = scan2_grid(n_tiles);
+    if (!store || d_compact == nullptr || d_hits == nullptr) {
         hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, static_cast<uint8_t *>(nullptr), narrow);
-    else if (wide)
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags, narrow);
+                           ScanStore{}, narrow);
+        return;
+    }
+    uint32_t shift = 0;
+    while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
+    // (inline location of the few "see the record" queries: only where SA[row] is one fetch, launch_locate's entry_sa)
+    const uint32_t *jump32 = entry_sa && ix.sa_full == nullptr && ix.jump != nullptr && ix.jump_bytes == 32 ? static_cast<const uint32_t *>(ix.jump) : nullptr;
+    const ScanStore ss{ix.sentinels, ix.n_texts, shift, d_hits, hits_capacity, d_chunk_flags, entry_sa ? ix.sa_full : nullptr, jump32,
+                       d_totals, entry_sa ? kScanInlineMax : 0u};
+    if (wide)
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
     else
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
-                           ix.sentinels, ix.n_texts, d_hits, hits_capacity, d_chunk_flags, narrow);
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
+}
+
+// SA[row] of any row in one fetch (32-byte jump entries, or the full suffix array): launch_locate then never walks, and the
+// store pass may locate the few "see the record" queries of a sparse batch itself
+bool locate_entry_sa(const IndexView &ix, const QueryOptions &qo)
+{
+    const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && qo.locate_jump_walk != 0;
+    return (jump_walk && ix.jump_bytes == 32) || (ix.layout == 0 && ix.sa_full != nullptr && qo.locate_jump_walk != 0);
 }
 
 namespace {
@@ -1091,6 +1444,227 @@ __global__ __launch_bounds__(kBlock) void compact_split_kernel(const uint32_t *_
     }
 }
 
+// ---- the "found bitmap" wire of the multi-GPU gather (gdx_wire_pack_dev / gdx_wire_split_dev) ---------
+// What a rank sends to the root for a count + locate shard: one BIT per read (its compact result is a position: exactly one
+// hit), the text positions of those reads back to back in read order (4 bytes per found read), the number of found reads
+// before every tile of 2048 reads (so that the root can split tiles independently), and the exceptions -- the reads whose
+// compact result says "see the record" -- as {read, count} in read order with their hits.  3.73 bytes per read where nine
+// reads in ten are found, against 4 for the compact words themselves: a position needs its 32 bits, a miss does not.
+constexpr uint32_t kWireTile = 2048;  // reads per tile: eight per thread, one byte of the bitmap
+
+// x summed over the threads before this one in the block (s_w: kBlock / 64 words of LDS; two barriers)
+template <class T>
+__device__ __forceinline__ T block_exclusive_sum(T x, T *s_w, T &block_total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    T incl = x;
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off);
+        if (static_cast<int>(lane) >= off) incl += o;
+    }
+    __syncthreads();  // (s_w may still be read from an earlier call)
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    T before = incl - x, total = 0;
+    for (uint32_t w = 0; w < kBlock / 64; w++) {
+        if (w < wave) before += s_w[w];
+        total += s_w[w];
+    }
+    block_total = total;
+    return before;
+}
+
+// a thread's eight compact words (reads q0 .. q0 + 7; beyond m: "none")
+__device__ __forceinline__ void wire_load8(const uint32_t *__restrict__ compact, uint64_t q0, uint64_t m, uint32_t (&c)[8])
+{
+    if (q0 + 8u <= m) {
+        const u32x4 a = reinterpret_cast<const u32x4 *>(compact + q0)[0], b = reinterpret_cast<const u32x4 *>(compact + q0)[1];
+        c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) c[k] = q0 + k < m ? compact[q0 + k] : kCompactNone;
+    }
+}
+
+// pass 1: per tile the found reads, the exceptions and the exceptions' hits
+__global__ __launch_bounds__(kBlock) void wire_tile_counts_kernel(const uint32_t *__restrict__ compact, HitOffsets off, uint64_t m,
+                                                                  unsigned long long *__restrict__ found, unsigned long long *__restrict__ see,
+                                                                  unsigned long long *__restrict__ see_hits)
+{
+    __shared__ unsigned long long s_w[kBlock / 64];
+    const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * kWireTile + threadIdx.x * 8u;
+        uint32_t c[8];
+        wire_load8(compact, q0, m, c);
+        unsigned long long f = 0, sq = 0, sh = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            f += c[k] < kCompactSee;
+            if (c[k] == kCompactSee) {
+                sq++;
+                sh += off[q0 + k + 1] - off[q0 + k];
+            }
+        }
+        // (found <= 2048 and exceptions <= 2048 travel in one word)
+        unsigned long long t_fs, t_h;
+        (void)block_exclusive_sum<unsigned long long>(f | (sq << 32), s_w, t_fs);
+        (void)block_exclusive_sum<unsigned long long>(sh, s_w, t_h);
+        if (threadIdx.x == 0) {
+            found[tile] = t_fs & 0xffffffffull;
+            see[tile] = t_fs >> 32;
+            see_hits[tile] = t_h;
+        }
+    }
+}
+
+struct WireOut {
+    uint8_t *bitmap;
+    uint32_t *tile_found, *found_pos;
+    uint64_t found_cap;
+    uint32_t *exc_q, *exc_cnt;
+    uint64_t exc_cap;
+    uint8_t *exc_ids;
+    int32_t *exc_pos;
+    uint64_t exc_hits_cap;
+    uint32_t *meta;  // [0] exceptions, [1] their hits, [2] found reads, [3] 0 (true numbers: what exceeds a capacity is dropped)
+};
+
+// pass 3 (after the three tile arrays have been scanned): the wire
+__global__ __launch_bounds__(kBlock) void wire_pack_kernel(const uint32_t *__restrict__ compact, HitOffsets off, const gdx_hit32_t *__restrict__ hits,
+                                                           uint64_t m, const unsigned long long *__restrict__ found,
+                                                           const unsigned long long *__restrict__ see,
+                                                           const unsigned long long *__restrict__ see_hits, WireOut w)
+{
+    __shared__ unsigned long long s_w[kBlock / 64];
+    const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * kWireTile + threadIdx.x * 8u;
+        uint32_t c[8];
+        wire_load8(compact, q0, m, c);
+        uint32_t fbits = 0, sbits = 0;
+        unsigned long long sh = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            if (c[k] < kCompactSee) fbits |= 1u << k;
+            if (c[k] == kCompactSee) {
+                sbits |= 1u << k;
+                sh += off[q0 + k + 1] - off[q0 + k];
+            }
+        }
+        unsigned long long t0, t1;
+        const unsigned long long fs = block_exclusive_sum<unsigned long long>(static_cast<unsigned long long>(__popc(fbits)) |
+                                                                              (static_cast<unsigned long long>(__popc(sbits)) << 32), s_w, t0);
+        unsigned long long h_at = see_hits[tile] + block_exclusive_sum<unsigned long long>(sh, s_w, t1);
+        if (q0 < m) w.bitmap[tile * (kWireTile / 8u) + threadIdx.x] = static_cast<uint8_t>(fbits);
+        if (threadIdx.x == 0) w.tile_found[tile] = static_cast<uint32_t>(found[tile]);
+        uint64_t f_at = found[tile] + (fs & 0xffffffffull), e_at = see[tile] + (fs >> 32);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            if (fbits & (1u << k)) {
+                if (f_at < w.found_cap) w.found_pos[f_at] = c[k];
+                f_at++;
+            } else if (sbits & (1u << k)) {
+                const uint64_t q = q0 + k, a = off[q];
+                const uint64_t cnt = off[q + 1] - a;
+                if (e_at < w.exc_cap) {
+                    w.exc_q[e_at] = static_cast<uint32_t>(q);
+                    w.exc_cnt[e_at] = static_cast<uint32_t>(cnt);
+                }
+                e_at++;
+                for (uint64_t i = 0; i < cnt; i++)
+                    if (h_at + i < w.exc_hits_cap) {
+                        const gdx_hit32_t h = hits[a + i];
+                        w.exc_ids[h_at + i] = static_cast<uint8_t>(h.text_id);
+                        w.exc_pos[h_at + i] = static_cast<int32_t>(h.position);
+                    }
+                h_at += cnt;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.tile_found[n_tiles] = static_cast<uint32_t>(found[n_tiles]);
+        w.meta[0] = static_cast<uint32_t>(see[n_tiles]);
+        w.meta[1] = static_cast<uint32_t>(see_hits[n_tiles] < 0xffffffffull ? see_hits[n_tiles] : 0xffffffffull);
+        w.meta[2] = static_cast<uint32_t>(found[n_tiles]);
+        w.meta[3] = 0u;
+    }
+}
+
+// the root's side: one shard's bitmap + positions -> per read a text id byte and the position in that text (-1 = no
+// occurrence, -2 = an exception: the reads listed in exc_q, sorted), the form gdx_compact_split_hits_dev produces
+__global__ __launch_bounds__(kBlock) void wire_split_kernel(const uint8_t *__restrict__ bitmap, const uint32_t *__restrict__ tile_found,
+                                                            const uint32_t *__restrict__ found_pos, uint64_t found_cap, uint64_t m,
+                                                            const uint32_t *__restrict__ exc_q, const uint32_t *__restrict__ meta,
+                                                            uint64_t exc_cap, const uint32_t *__restrict__ sentinels_g, uint32_t n_texts,
+                                                            uint32_t shift, uint8_t *__restrict__ ids, int32_t *__restrict__ pos)
+{
+    __shared__ uint32_t s_w[kBlock / 64];
+    __shared__ uint32_t s_tab[kTextTab + 1];
+    __shared__ uint32_t s_sent[256];
+    for (uint32_t i = threadIdx.x; i < n_texts; i += kBlock) s_sent[i] = sentinels_g[i];
+    __syncthreads();
+    build_text_table(s_tab, s_sent, n_texts, shift);
+    __syncthreads();
+    const uint64_t n_exc = meta[0] < exc_cap ? meta[0] : exc_cap;
+    const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t q0 = tile * kWireTile + threadIdx.x * 8u;
+        const uint32_t fbits = q0 < m ? bitmap[tile * (kWireTile / 8u) + threadIdx.x] : 0u;
+        uint32_t total;
+        uint64_t at = tile_found[tile] + block_exclusive_sum<uint32_t>(static_cast<uint32_t>(__popc(fbits)), s_w, total);
+        uint32_t id[8];
+        int32_t p[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            id[k] = 0u;
+            p[k] = -1;
+            if (fbits & (1u << k)) {
+                const uint32_t g = at < found_cap ? found_pos[at] : 0u;
+                at++;
+                const uint32_t b = g >> shift;
+                uint32_t lo = s_tab[b], hi = s_tab[b + 1];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_sent[mid] < g) lo = mid + 1u;
+                    else hi = mid;
+                }
+                id[k] = lo;
+                p[k] = static_cast<int32_t>(lo == 0u ? g : g - s_sent[lo - 1u] - 1u);
+            }
+        }
+        if (q0 + 8u <= m) {
+            *reinterpret_cast<uint2 *>(ids + q0) = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24),
+                                                              id[4] | (id[5] << 8) | (id[6] << 16) | (id[7] << 24));
+            reinterpret_cast<int4 *>(pos + q0)[0] = make_int4(p[0], p[1], p[2], p[3]);
+            reinterpret_cast<int4 *>(pos + q0)[1] = make_int4(p[4], p[5], p[6], p[7]);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)
+                if (q0 + k < m) {
+                    ids[q0 + k] = static_cast<uint8_t>(id[k]);
+                    pos[q0 + k] = p[k];
+                }
+        }
+        if (n_exc != 0) {  // the exceptions among this tile's reads
+            __syncthreads();
+            const uint64_t t_lo = tile * kWireTile, t_hi = t_lo + kWireTile;
+            uint64_t lo = 0, hi = n_exc;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (exc_q[mid] < t_lo) lo = mid + 1;
+                else hi = mid;
+            }
+            for (uint64_t e = lo + threadIdx.x; e < n_exc; e += kBlock) {
+                const uint64_t q = exc_q[e];
+                if (q >= t_hi || q >= m) break;
+                ids[q] = 0;
+                pos[q] = -2;
+            }
+        }
+    }
+}
+
 // the queries whose compact result says "see the record", listed in no particular order (the caller sorts the few there
 // are); *n counts all of them, whatever the list holds.  Four queries per thread, one atomic per wavefront that has any.
 __global__ __launch_bounds__(kBlock) void compact_exceptions_kernel(const uint32_t *__restrict__ compact, uint64_t m,
@@ -1146,6 +1720,40 @@ void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64
     if (m == 0) return;
     hipLaunchKernelGGL(compact_split_kernel, dim3(grid_for_items((m + 3) / 4)), dim3(kBlock), 0, stream, d_compact, m,
                        ix.sentinels, ix.n_texts, d_ids, d_pos);
+}
+
+size_t wire_pack_workspace_bytes(uint64_t m) { return 3 * ((m + kWireTile - 1) / kWireTile + 1) * sizeof(unsigned long long); }
+
+void launch_wire_pack(const uint32_t *d_compact, const void *d_hit_offsets, bool narrow_offsets, const gdx_hit32_t *d_hits, uint64_t m,
+                      uint8_t *d_bitmap, uint32_t *d_tile_found, uint32_t *d_found_pos, uint64_t found_cap, uint32_t *d_exc_q,
+                      uint32_t *d_exc_cnt, uint64_t exc_cap, uint8_t *d_exc_ids, int32_t *d_exc_pos, uint64_t exc_hits_cap,
+                      uint32_t *d_meta, void *d_workspace, hipStream_t stream)
+{
+    const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
+    unsigned long long *found = static_cast<unsigned long long *>(d_workspace), *see = found + n_tiles + 1, *see_hits = see + n_tiles + 1;
+    const HitOffsets off{d_hit_offsets, narrow_offsets ? 1u : 0u};
+    const WireOut w{d_bitmap, d_tile_found, d_found_pos, found_cap, d_exc_q, d_exc_cnt, exc_cap, d_exc_ids, d_exc_pos, exc_hits_cap, d_meta};
+    if (m == 0) {
+        GDX_HIP(hipMemsetAsync(d_meta, 0, 4 * sizeof(uint32_t), stream));
+        GDX_HIP(hipMemsetAsync(d_tile_found, 0, sizeof(uint32_t), stream));
+        return;
+    }
+    const unsigned grid = static_cast<unsigned>(n_tiles < 2048 ? n_tiles : 2048);
+    hipLaunchKernelGGL(wire_tile_counts_kernel, dim3(grid), dim3(kBlock), 0, stream, d_compact, off, m, found, see, see_hits);
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(3), dim3(1024), 0, stream, found, n_tiles, static_cast<unsigned long long *>(nullptr), n_tiles + 1);
+    hipLaunchKernelGGL(wire_pack_kernel, dim3(grid), dim3(kBlock), 0, stream, d_compact, off, d_hits, m, found, see, see_hits, w);
+}
+
+void launch_wire_split(const IndexView &ix, const uint8_t *d_bitmap, const uint32_t *d_tile_found, const uint32_t *d_found_pos,
+                       uint64_t found_cap, uint64_t m, const uint32_t *d_exc_q, const uint32_t *d_meta, uint64_t exc_cap, uint8_t *d_ids,
+                       int32_t *d_pos, hipStream_t stream)
+{
+    if (m == 0) return;
+    const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
+    uint32_t shift = 0;
+    while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
+    hipLaunchKernelGGL(wire_split_kernel, dim3(static_cast<unsigned>(n_tiles < 2048 ? n_tiles : 2048)), dim3(kBlock), 0, stream, d_bitmap,
+                       d_tile_found, d_found_pos, found_cap, m, d_exc_q, d_meta, exc_cap, ix.sentinels, ix.n_texts, shift, d_ids, d_pos);
 }
 
 size_t count_offsets_temp_bytes(uint64_t m)
@@ -1217,9 +1825,10 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
                    const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact,
-                   bool compact_stored, const uint8_t *d_chunk_flags, bool narrow_offsets)
+                   bool compact_stored, const uint8_t *d_chunk_flags, bool narrow_offsets, const unsigned long long *d_total)
 {
     if (total_hits == 0 || m == 0) return;
+    if (d_total != nullptr && d_rec == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: a device-side total goes with search records");
     if (narrow_offsets && d_rec == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: narrow offsets go with search records");
     const HitOffsets offs{d_hit_offsets, narrow_offsets ? 1u : 0u};
     uint32_t *heads = static_cast<uint32_t *>(d_workspace);
@@ -1253,19 +1862,22 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
         uint32_t *first = heads;  // n_chunks entries of the workspace
         hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock) / kBlock)),
-                           dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first);
+                           dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first, d_total, d_chunk_flags);
+        // (with chunk flags few chunks have anything to do: a grid the chip holds at once, every block looks at its share
+        // of the flags first)
+        const uint64_t grid_cap = d_chunk_flags != nullptr ? 2048u : 65536u;
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
-                                                 : static_cast<unsigned>(n_chunks < 65536 ? n_chunks : 65536);
+                                                 : static_cast<unsigned>(n_chunks < grid_cap ? n_chunks : grid_cap);
 #define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                     \
     do {                                                                                                                  \
         if (entry_sa)                                                                                                     \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
                                d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
-                               d_compact, d_chunk_flags);                                                                 \
+                               d_compact, d_chunk_flags, d_total);                                                        \
         else                                                                                                              \
             hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
                                d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
-                               d_compact, d_chunk_flags);                                                                 \
+                               d_compact, d_chunk_flags, d_total);                                                        \
     } while (0)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
@@ -1278,7 +1890,22 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         // SA[row] inside the entries, or as an array of its own: no walk at all
         const bool entry_sa = (jump_walk && ix.jump_bytes == 32) ||
                               (ix.layout == 0 && ix.sa_full != nullptr && !reference_walk && qo.locate_jump_walk != 0);
-        if (ix.layout == 0) {
+        static const bool env_no_stream = getenv("GDX_LOCATE_NO_STREAM") != nullptr;  // debug: the queue kernel on every index
+        if (entry_sa && d_step_stats == nullptr && !env_no_stream) {
+            uint32_t shift = 0;
+            while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
+            const StreamView sv{ix.sa_full, ix.sa_full == nullptr ? static_cast<const uint32_t *>(ix.jump) : nullptr, ix.sentinels,
+                                ix.n_texts, shift, compact_stored ? 2u : (skip_single ? 1u : 0u)};
+            // a grid the chip holds at once (the text-id table is built once per block); every block strides over the chunks
+            const unsigned sgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
+                                                     : static_cast<unsigned>(n_chunks < 2048 ? n_chunks : 2048);
+            if (wide)
+                hipLaunchKernelGGL(locate_stream_kernel<true>, dim3(sgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, first, d_hint,
+                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total);
+            else
+                hipLaunchKernelGGL(locate_stream_kernel<false>, dim3(sgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, first, d_hint,
+                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total);
+        } else if (ix.layout == 0) {
             if (wide && jump_walk) GDX_LOCATE_Q(LineTable, true, true);
             else if (wide) GDX_LOCATE_Q(LineTable, true, false);
             else if (jump_walk) GDX_LOCATE_Q(LineTable, false, true);

@@ -2022,6 +2022,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     __shared__ uint32_t s_count[8];
     __shared__ uint32_t s_left[kMaxRange];
     __shared__ uint32_t s_nleft, s_left_base;
+    // (a list's length is only known here: the grid is sized for the worst case, and on a text without repeats all but a
+    // few of its blocks have nothing to do -- they leave before they touch anything)
+    if (list != nullptr) nq = *n_list;
+    if (static_cast<uint64_t>(blockIdx.x) * range >= nq) return;
     if (kXlate == 0)
         for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = vv.io_to_dense[i];
     if (threadIdx.x < 8) s_count[threadIdx.x] = threadIdx.x < 6 ? vv.count[threadIdx.x] : 0u;
@@ -2036,7 +2040,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
     const uint32_t depth = vv.top_depth;
-    if (list != nullptr) nq = *n_list;
     const uint64_t n_ranges = (nq + range - 1) / range;
     for (uint64_t rg = blockIdx.x; rg < n_ranges; rg += gridDim.x) {
         const uint64_t base = rg * range;
@@ -2585,7 +2588,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
     static_assert(kXlate == 1 || kXlate == 2, "v_perm tables or packed queries");
     constexpr uint32_t kWaves = kBlock / 64;
     constexpr uint32_t kNoTag = 0xffffffffu;  // matches no entry (kSeedMatchMask leaves 26 bits)
-    constexpr int kRaw = kXlate == 2 ? 5 : 16;  // dwords a lane loads for its read
+    constexpr int kRaw = kXlate == 2 ? 5 : 15;  // dwords a lane loads for its read
     constexpr uint32_t kQueue = 128;            // parked reads per wavefront: < 64 before a chunk adds up to 64
     __shared__ uint2 s_bt[kWaves][64];
     __shared__ u32x4 s_e[kWaves][64];
@@ -2826,12 +2829,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
                 raw[0] = v.x, raw[1] = v.y, raw[2] = v.z, raw[3] = v.w;
                 raw[4] = p[4];
             } else {
-                const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(qw + ((r_end - kWin) >> 2));
+                // the window's 56 bytes start o = (r_end - 56) & 3 bytes into dword 0: dwords 0 .. 13, and dword 14 only when
+                // o != 0 -- with o == 0 it would begin at r_end + 0 and end 4 bytes past it, beyond the 8-byte padding the
+                // contract asks for when the buffer's last query ends on a multiple of 8 (gdx.h; a 16th dword is never used)
+                const uint32_t *p1 = qw + ((r_end - kWin) >> 2);
+                const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(p1);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < 3; i++) {
                     const u32x4_a4 v = p[i];
                     raw[4 * i] = v.x, raw[4 * i + 1] = v.y, raw[4 * i + 2] = v.z, raw[4 * i + 3] = v.w;
                 }
+                raw[12] = p1[12];
+                raw[13] = p1[13];
+                raw[14] = ((r_end - kWin) & 3u) != 0u ? p1[14] : 0u;
             }
         };
         fetch(wave);
@@ -3266,6 +3276,49 @@ void launch_search(const IndexView &ix, const uint8_t *d_qbuf, const uint64_t *d
     launch_search_call(ix, c, stream, qo);
 }
 
+// ZeroSet (kernels.hpp): up to eight small regions zeroed by one launch
+struct ZeroSegments {
+    uint32_t *p[ZeroSet::kMax];
+    uint32_t end[ZeroSet::kMax];  // running totals of the regions' words
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void zero_segments_kernel(ZeroSegments z)
+{
+    const uint32_t total = z.end[z.n - 1];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        int s = 0;
+        while (i >= z.end[s]) s++;
+        z.p[s][i - (s == 0 ? 0u : z.end[s - 1])] = 0u;
+    }
+}
+
+void ZeroSet::add(void *ptr, size_t bytes)
+{
+    if (ptr == nullptr || bytes == 0) return;
+    if (n == kMax || (reinterpret_cast<uintptr_t>(ptr) & 3u) != 0 || bytes > 0xfffffff0ull)
+        fail(GDX_ERR_INVALID_ARGUMENT, "internal: ZeroSet takes up to %d 4-byte aligned regions", kMax);
+    p[n] = static_cast<uint32_t *>(ptr);
+    words[n] = static_cast<uint32_t>((bytes + 3) / 4);
+    n++;
+}
+
+void ZeroSet::flush(hipStream_t stream)
+{
+    if (n == 0) return;
+    ZeroSegments z{};
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        z.p[i] = p[i];
+        total += words[i];
+        if (total > 0xffffffffull) fail(GDX_ERR_INVALID_ARGUMENT, "internal: ZeroSet regions beyond 16 GB");
+        z.end[i] = static_cast<uint32_t>(total);
+    }
+    z.n = n;
+    const uint64_t blocks = (total + kBlock * 4 - 1) / (kBlock * 4);
+    hipLaunchKernelGGL(zero_segments_kernel, dim3(static_cast<unsigned>(blocks < 1024 ? blocks : 1024)), dim3(kBlock), 0, stream, z);
+    n = 0;
+}
+
 // offsets of a uniform batch, for the kernels that read them from memory (fill_uniform_offsets_kernel)
 __global__ __launch_bounds__(kBlock) void fill_uniform_offsets_kernel(uint64_t *__restrict__ off, uint64_t n, uint32_t ulen)
 {
@@ -3303,7 +3356,10 @@ __global__ __launch_bounds__(kBlock) void tile_sums_lists_kernel(const uint4 *__
                     c = (max_hits != 0u && m > max_hits) ? 0ull : static_cast<unsigned long long>(m);
                     open_slots += c;
                 }
-            } else if (!is_left) {  // (a listed read keeps "see the record": the other case cannot be)
+            } else {
+                // long list: answered by seed_text_kernel4.  left list: no kernel of today's chains turns a listed read's
+                // compact result into a position -- if one ever does, it counts as RecordSize counts it (a read that
+                // seed_text_kernel4 handed on sits on both lists and must then be counted on one of them only)
                 c = c4 == kCompactNone ? 0ull : 1ull;
             }
         }
@@ -3343,6 +3399,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         c.uniform_len = 0;
     }
     const uint32_t ulen = c.uniform_len;
+    // the call's counters (and what the caller wants zeroed with them) are zeroed by one launch before its first kernel
+    ZeroSet zs;
+    if (c.also_zero != nullptr) zs = *c.also_zero;
     // Launch geometry of the group kernels (measured on MI355X, hg38-scale index, 100 M reads,
     // profiles/r01/search_variants.md): many short-lived blocks beat a resident grid -- 65536 blocks: 78 ms,
     // 1792 (7 per CU): 89 ms, 2048 (8 per CU, all resident, lock-step): 112 ms.  So: about 48 queries per
@@ -3405,7 +3464,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const uint64_t v_ranges = (nq + v_range - 1) / v_range;
             const unsigned v_blocks = static_cast<unsigned>(v_ranges < (1u << 20) ? v_ranges : (1u << 20));
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
-            GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            zs.add(d_left, sizeof(uint32_t));
             // rows a verify round takes: four when SA[row] is one fetch away, one when it costs a locate walk
             const bool entry_sa = ix.jump != nullptr && ix.jump_bytes == 32;
             const uint32_t max_rows = (ix.sa_full != nullptr || entry_sa) ? 4u : 1u;
@@ -3442,7 +3501,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                 seed_state_packed = to_fast && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
-                    GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
+                    zs.add(d_first, sizeof(uint32_t));
                     const SeedView sv{ix.seed, ix.text_units, nullptr, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
                                       ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
                     uint4 *d_seed_state = to_fast ? c.d_rec : nullptr;
@@ -3451,7 +3510,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     // record slot (an array of its own when the call has no records) for seed_text_kernel4, whose own
                     // leftovers (a symbol outside A C G T further front) join the seed kernel's list
                     uint32_t *d_long = static_cast<uint32_t *>(stream_scratch(stream, 13, (nq + 4) * sizeof(uint32_t)));
-                    GDX_HIP(hipMemsetAsync(d_long, 0, sizeof(uint32_t), stream));
+                    zs.add(d_long, sizeof(uint32_t));
                     uint2 *d_long_state = c.d_rec != nullptr ? reinterpret_cast<uint2 *>(c.d_rec)
                                                              : static_cast<uint2 *>(stream_scratch(stream, 14, nq * sizeof(uint2)));
                     const uint32_t long_stride = c.d_rec != nullptr ? 2u : 1u;
@@ -3481,12 +3540,16 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     if (lane_kernel && c.d_tile_sums != nullptr && c.d_tile_rest != nullptr && c.d_compact != nullptr &&
                         !(variant == 2 && ix.pair_lines != nullptr)) {
                         fold = c.d_tile_sums;
-                        GDX_HIP(hipMemsetAsync(fold, 0, ((nq + kSumTile - 1) / kSumTile) * sizeof(unsigned long long), stream));
+                        zs.add(fold, ((nq + kSumTile - 1) / kSumTile) * sizeof(unsigned long long));
                         fold_left = d_first;
                         fold_long = d_long;
                     }
                     // (its ranges: at most kLaneRange reads, the capacity of its lists in LDS)
-                    const uint32_t lane_range = v_range < kLaneRange ? v_range : kLaneRange;
+                    // (experiments: GDX_SEED_LANE_RANGE = reads per range, a multiple of 64 up to kLaneRange)
+                    static const uint32_t env_lane_range = [] { const char *e = getenv("GDX_SEED_LANE_RANGE"); return e ? static_cast<uint32_t>(atol(e)) : 0u; }();
+                    const uint32_t lane_range = env_lane_range >= 64u && env_lane_range <= kLaneRange ? env_lane_range / 64u * 64u
+                                                : (v_range < kLaneRange ? v_range : kLaneRange);
+                    if (lane_range % 64u != 0u) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the lane kernel's ranges are multiples of 64");
                     const uint64_t lane_ranges = (nq + lane_range - 1) / lane_range;
                     unsigned lane_blocks = static_cast<unsigned>(lane_ranges < (1u << 20) ? lane_ranges : (1u << 20));
                     // (tests: GDX_SEED_LANE_BLOCKS caps the grid, so that a block takes several ranges -- its parked queue and
@@ -3505,6 +3568,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
                            c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
     } while (0)
+                    zs.flush(stream);
                     if (lane_kernel && xlate == 2 && ulen != 0u) GDX_SEED_LANE_LAUNCH(2, true);
                     else if (lane_kernel && xlate == 2) GDX_SEED_LANE_LAUNCH(2, false);
                     else if (lane_kernel && ulen != 0u) GDX_SEED_LANE_LAUNCH(1, true);
@@ -3518,15 +3582,21 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     if (to_fast) {
                         seed_list = d_first;
                     } else {
+                        // (the list's length is only known on the device: a grid the chip holds at once strides over whatever
+                        // there is; 8192 blocks of this kernel's 12 KB of LDS took 13 us to dispatch and leave when the list
+                        // was empty -- on a text without repeats it nearly is)
                         const uint32_t l_range = 256;
                         const uint64_t l_ranges = (nq + l_range - 1) / l_range;
-                        const unsigned l_blocks = static_cast<unsigned>(l_ranges < 8192 ? l_ranges : 8192);
+                        static const unsigned l_cap = [] { const char *e = getenv("GDX_SEED_LIST_BLOCKS"); return e ? static_cast<unsigned>(atol(e)) : 1792u; }();
+                        const unsigned l_blocks = static_cast<unsigned>(l_ranges < l_cap ? l_ranges : l_cap);
                         GDX_VERIFY_LAUNCH(true, l_blocks, l_range, d_left, d_first);
                     }
                 } else {
+                    zs.flush(stream);
                     GDX_VERIFY_LAUNCH(true, v_blocks, v_range, d_left, no_list);
                 }
             } else {
+                zs.flush(stream);
                 GDX_VERIFY_LAUNCH(false, v_blocks, v_range, d_left, no_list);
             }
 #undef GDX_VERIFY_LAUNCH
@@ -3544,6 +3614,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             leftover_list = true;
         }
     }
+    zs.flush(stream);  // (a call that took none of the paths above: what the caller wanted zeroed)
     // compact results without the seed kernel: every query says "see the record"
     if (c.d_compact != nullptr && !compact_by_seed) GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.d_compact), static_cast<int>(kCompactSee), nq, stream));
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {

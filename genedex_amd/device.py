@@ -254,6 +254,19 @@ class DeviceEngine:
             self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay) if lay is not None else None, max_hits, _ptr(rec), _ptr(compact),
             _ptr(scan_ws), _ptr(totals), _stream()))
 
+    def locate_step(self, q: DeviceQueries, rec: torch.Tensor, compact, scan_ws: torch.Tensor, totals: torch.Tensor,
+                    hit_offsets: torch.Tensor, hits: torch.Tensor, workspace: torch.Tensor, max_hits: int = 0,
+                    event_after_search=None) -> None:
+        """gdx_locate_many_step_compact_layout_dev: search, totals, offsets and hits in one call, no host round trip; hits
+        beyond hits.shape[0] are not stored (totals[0], read later, tells); hit_offsets int32 = the narrow form;
+        event_after_search: a torch.cuda.Event that has been recorded once (so that its handle exists)"""
+        lay, qoff = q.layout()
+        _lib.check(self.lib.gdx_locate_many_step_compact_layout_dev(
+            self.h, _ptr(q.qbuf), qoff, q.nq, C.byref(lay) if lay is not None else None, max_hits, _ptr(rec),
+            _ptr(compact) if compact is not None else None, _ptr(scan_ws), _ptr(totals), _ptr(hit_offsets),
+            32 if hit_offsets.dtype == torch.int32 else 64, _ptr(hits), hits.shape[0], _ptr(workspace),
+            C.c_void_p(event_after_search.cuda_event) if event_after_search is not None else None, _stream()))
+
     def locate_offsets(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, max_hits: int = 0,
                        compact: torch.Tensor = None) -> None:
         """max_hits != 0: queries with more occurrences are counted but get no hit slots"""
@@ -322,6 +335,24 @@ class DeviceEngine:
         """gdx_compact_split_hits_dev: compact results -> uint8 text ids + int32 positions in the text (-1 none, -2 see the
         record); what the root of a multi-GPU gather turns a received shard into"""
         _lib.check(self.lib.gdx_compact_split_hits_dev(self.h, _ptr(compact), nq, _ptr(text_ids), _ptr(positions), _stream()))
+
+    def wire_pack_workspace_bytes(self, nq: int) -> int:
+        return int(self.lib.gdx_wire_pack_workspace_bytes(nq))
+
+    def wire_pack(self, compact: torch.Tensor, hit_offsets: torch.Tensor, hits: torch.Tensor, nq: int, v: dict,
+                  workspace: torch.Tensor) -> None:
+        """gdx_wire_pack_dev: a located shard into its "found bitmap" wire form; v = dist.WireLayout.views(buffer)"""
+        _lib.check(self.lib.gdx_wire_pack_dev(
+            self.h, _ptr(compact), _ptr(hit_offsets), 32 if hit_offsets.dtype == torch.int32 else 64, _ptr(hits), nq,
+            _ptr(v["bitmap"]), _ptr(v["tile_found"]), _ptr(v["found_pos"]), v["found_pos"].numel(), _ptr(v["exc_q"]),
+            _ptr(v["exc_cnt"]), v["exc_q"].numel(), _ptr(v["exc_ids"]), _ptr(v["exc_pos"]), v["exc_ids"].numel(), _ptr(v["meta"]),
+            _ptr(workspace), _stream()))
+
+    def wire_split(self, v: dict, nq: int, text_ids: torch.Tensor, positions: torch.Tensor) -> None:
+        """gdx_wire_split_dev: a received shard -> uint8 text ids + int32 positions (-1 none, -2 exception)"""
+        _lib.check(self.lib.gdx_wire_split_dev(self.h, _ptr(v["bitmap"]), _ptr(v["tile_found"]), _ptr(v["found_pos"]),
+                                               v["found_pos"].numel(), nq, _ptr(v["exc_q"]), _ptr(v["meta"]), v["exc_q"].numel(),
+                                               _ptr(text_ids), _ptr(positions), _stream()))
 
     def compact_exceptions(self, compact: torch.Tensor, nq: int, queries: torch.Tensor, n: torch.Tensor) -> None:
         """gdx_compact_exceptions_dev: the queries that say "see the record" into `queries` (int32 / uint32 view, unordered, as

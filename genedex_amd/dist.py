@@ -206,6 +206,97 @@ def expand_split_results(ids: torch.Tensor, pos: torch.Tensor, exc_cnt: torch.Te
     return cnt, torch.stack([h_id, h_pos], dim=1)
 
 
+# ---- the "found bitmap" wire ------------------------------------------------------------------------------------------
+# gdx_wire_pack_dev / gdx_wire_split_dev (gdx.h): a bit per read (found: exactly one hit, answered compactly), the found
+# reads' text positions back to back, the found reads before every tile of 2048, and the exceptions {read, count} with their
+# hits.  3.73 bytes per read where nine in ten are found (the compact words: 4).  Everything a rank sends lies in ONE byte
+# buffer -- one gather per step instead of one per array -- laid out by WireLayout, the same on every rank.
+WIRE_TILE = 2048
+
+
+class WireLayout:
+    """Where the parts of a shard's wire form lie in its one byte buffer (all offsets 16-byte aligned).
+    n_max: reads of the largest shard; cap_found / cap_q / cap_h: capacities for found reads, exceptions, exception hits."""
+
+    FIELDS = (("bitmap", "uint8"), ("tile_found", "int32"), ("found_pos", "int32"), ("exc_q", "int32"), ("exc_cnt", "int32"),
+              ("exc_ids", "uint8"), ("exc_pos", "int32"), ("meta", "int32"))
+
+    def __init__(self, n_max: int, cap_found: int, cap_q: int, cap_h: int):
+        self.n_max, self.cap_found, self.cap_q, self.cap_h = n_max, max(cap_found, 1), max(cap_q, 1), max(cap_h, 1)
+        tiles = (max(n_max, 1) + WIRE_TILE - 1) // WIRE_TILE
+        counts = {"bitmap": tiles * (WIRE_TILE // 8), "tile_found": tiles + 2, "found_pos": self.cap_found, "exc_q": self.cap_q,
+                  "exc_cnt": self.cap_q, "exc_ids": self.cap_h, "exc_pos": self.cap_h, "meta": 4}
+        self.parts, at = {}, 0
+        for name, dtype in self.FIELDS:
+            nbytes = counts[name] * (1 if dtype == "uint8" else 4)
+            self.parts[name] = (at, counts[name], dtype)
+            at += (nbytes + 15) // 16 * 16
+        self.nbytes = at
+
+    def payload_bytes(self, nq: int, n_found: int, n_exc: int, n_exc_hits: int) -> int:
+        """bytes that carry information for a shard of nq reads (the buffer is padded to the capacities)"""
+        return (nq + 7) // 8 + 4 * ((nq + WIRE_TILE - 1) // WIRE_TILE + 1) + 4 * n_found + 8 * n_exc + 5 * n_exc_hits + 16
+
+    def views(self, buf: torch.Tensor) -> dict:
+        """typed views of the parts of `buf` (uint8, nbytes long, 16-byte aligned storage)"""
+        out = {}
+        for name, (at, count, dtype) in self.parts.items():
+            part = buf[at: at + count * (1 if dtype == "uint8" else 4)]
+            out[name] = part if dtype == "uint8" else part.view(torch.int32)
+        return out
+
+
+def wire_pack_reference(compact: torch.Tensor, hit_offsets: torch.Tensor, hits: torch.Tensor, nq: int, v: dict) -> None:
+    """What gdx_wire_pack_dev writes, restated with tensor operations on any device (the CPU tests' stand-in for the kernel)."""
+    c = compact[:nq].to(torch.int64) & 0xffffffff
+    found = c < (COMPACT_SEE & 0xffffffff)
+    see = c == (COMPACT_SEE & 0xffffffff)
+    tiles = (max(nq, 1) + WIRE_TILE - 1) // WIRE_TILE
+    bits = torch.zeros(tiles * WIRE_TILE, dtype=torch.uint8, device=compact.device)
+    bits[:nq] = found.to(torch.uint8)
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=compact.device)
+    v["bitmap"][: tiles * (WIRE_TILE // 8)] = (bits.view(-1, 8).to(torch.int32) * weights).sum(1).to(torch.uint8)
+    per_tile = bits.view(tiles, WIRE_TILE).to(torch.int64).sum(1)
+    tf = torch.zeros(tiles + 1, dtype=torch.int64, device=compact.device)
+    tf[1:] = torch.cumsum(per_tile, 0)
+    v["tile_found"][: tiles + 1] = tf.to(torch.int32)
+    fp = c[found]
+    n_f = min(int(fp.numel()), v["found_pos"].numel())
+    v["found_pos"][:n_f] = fp[:n_f].to(torch.int32)  # (positions beyond 2^31 wrap into the int32 view, bit for bit)
+    eq = torch.nonzero(see)[:, 0]
+    cnt = (hit_offsets[eq + 1] - hit_offsets[eq]).to(torch.int64)
+    n_e = min(int(eq.numel()), v["exc_q"].numel())
+    v["exc_q"][:n_e] = eq[:n_e].to(torch.int32)
+    v["exc_cnt"][:n_e] = cnt[:n_e].to(torch.int32)
+    total_h = int(cnt.sum().item())
+    if total_h:
+        src = torch.repeat_interleave(hit_offsets[eq].to(torch.int64), cnt) + (torch.arange(total_h, device=compact.device)
+                                                                               - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt))
+        n_h = min(total_h, v["exc_ids"].numel())
+        v["exc_ids"][:n_h] = hits[src[:n_h], 0].to(torch.uint8)
+        v["exc_pos"][:n_h] = hits[src[:n_h], 1].to(torch.int32)
+    v["meta"][0], v["meta"][1], v["meta"][2], v["meta"][3] = int(eq.numel()), total_h, int(fp.numel()), 0
+
+
+def wire_split_reference(v: dict, nq: int, text_starts: torch.Tensor):
+    """What gdx_wire_split_dev writes: (uint8 text ids, int32 positions; -1 none, -2 exception) of a received shard.
+    text_starts: int64[n_texts + 1], the start of every text in the concatenation (sentinels included)."""
+    dev = v["bitmap"].device
+    tiles = (max(nq, 1) + WIRE_TILE - 1) // WIRE_TILE
+    by = v["bitmap"][: tiles * (WIRE_TILE // 8)].to(torch.int32)
+    bits = ((by[:, None] >> torch.arange(8, device=dev, dtype=torch.int32)[None, :]) & 1).reshape(-1)[:nq].to(torch.bool)
+    rank = torch.cumsum(bits.to(torch.int64), 0) - 1
+    g = (v["found_pos"].to(torch.int64) & 0xffffffff)[rank.clamp(min=0, max=v["found_pos"].numel() - 1)]
+    tid = torch.searchsorted(text_starts[1:] - 1, g, right=False).clamp(max=text_starts.numel() - 2)
+    ids = torch.where(bits, tid, torch.zeros_like(tid)).to(torch.uint8)
+    pos = torch.where(bits, g - text_starts[tid], torch.full_like(g, -1)).to(torch.int32)
+    n_exc = min(int(v["meta"][0].item()), v["exc_q"].numel())
+    eq = v["exc_q"][:n_exc].to(torch.int64)
+    pos[eq] = -2
+    ids[eq] = 0
+    return ids, pos
+
+
 def max_int_over_ranks(value: int, device) -> int:
     rank, n = world()
     if n == 1:

@@ -440,6 +440,30 @@ int gdx_compact_split_hits_dev(const gdx_index_t *ix, const void *d_compact, uin
  * million queries) and sorts them. */
 int gdx_compact_exceptions_dev(const gdx_index_t *ix, const void *d_compact, uint64_t nq, void *d_out_queries,
                                uint64_t capacity, void *d_out_n, void *stream);
+/* The "found bitmap" form of a located shard on its way to another device (the multi-GPU gather): one
+ * BIT per read -- set: the read's compact result is a position, i.e. it has exactly one hit -- in d_bitmap (bit q & 7 of byte
+ * q >> 3; gdx_wire_bitmap_bytes(nq) bytes), the text positions of those reads back to back in read order in d_found_pos
+ * (u32[found_capacity]), the number of found reads before every tile of 2048 reads in d_tile_found (u32[nq / 2048 + 2], the
+ * last entry = all of them), and the EXCEPTIONS -- the reads whose compact result says "see the record" -- in read order:
+ * d_exc_queries / d_exc_counts (u32[exc_capacity]: read number, number of hits) and their hits d_exc_text_ids (u8) /
+ * d_exc_positions (i32) [exc_hits_capacity], taken from the shard's hit offsets (u32 or u64: offsets_width) and hits
+ * (gdx_hit32_t).  d_meta (u32[4]) = {exceptions, their hits, found reads, 0}: the true numbers -- what exceeds a capacity is
+ * dropped, and the receiver sees it there.  3.73 bytes per read where nine reads in ten are found, against 4 for the compact
+ * words themselves (a position needs its 32 bits, a miss does not).  Collections of at most 256 texts.  d_workspace:
+ * gdx_wire_pack_workspace_bytes(nq) bytes.  Three launches: tile counts, their scan, the pack. */
+uint64_t gdx_wire_bitmap_bytes(uint64_t nq);
+uint64_t gdx_wire_pack_workspace_bytes(uint64_t nq);
+int gdx_wire_pack_dev(const gdx_index_t *ix, const void *d_compact, const void *d_hit_offsets, uint32_t offsets_width,
+                      const void *d_hits, uint64_t nq, void *d_bitmap, void *d_tile_found, void *d_found_pos, uint64_t found_capacity,
+                      void *d_exc_queries, void *d_exc_counts, uint64_t exc_capacity, void *d_exc_text_ids, void *d_exc_positions,
+                      uint64_t exc_hits_capacity, void *d_meta, void *d_workspace, void *stream);
+/* The receiver's side: a shard in that form -> per read one text id byte and one int32, the position in that text of the
+ * read's only hit (lib.rs:331-335 Hit { text_id, position }), -1 = no occurrence, -2 = an exception (the reads d_exc_queries
+ * lists, ascending; d_meta[0] of them, at most exc_capacity) -- what gdx_compact_split_hits_dev produces from compact words.
+ * d_out_text_ids 8-byte, d_out_positions 16-byte aligned. */
+int gdx_wire_split_dev(const gdx_index_t *ix, const void *d_bitmap, const void *d_tile_found, const void *d_found_pos,
+                       uint64_t found_capacity, uint64_t nq, const void *d_exc_queries, const void *d_meta, uint64_t exc_capacity,
+                       void *d_out_text_ids, void *d_out_positions, void *stream);
 /* Offsets and hits in two calls around the ONE host round trip of a count + locate step (instead of offsets, round trip,
  * hits): gdx_locate_many_totals_compact_dev sums the counts -- d_totals (u64[2], device) = {all hit slots, the slots of the
  * queries whose compact result says "see the record"} -- and leaves the bases of its tiles in d_scan_workspace
@@ -536,6 +560,25 @@ int gdx_locate_many_search_layout_dev(const gdx_index_t *ix, const void *d_qbuf,
 int gdx_locate_many_search_totals_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                                      const gdx_query_layout_t *layout, uint32_t max_hits, void *d_records,
                                                      void *d_compact, void *d_scan_workspace, void *d_totals, void *stream);
+/* The WHOLE count + locate step of a batch in one call and without a host round trip (FmIndex::locate_many, lib.rs:179-185, on
+ * device-resident reads): search, hit totals, hit offsets and hits are enqueued behind each other on `stream`; the number of
+ * hits stays on the device.  The caller offers a hit buffer of hits_capacity entries (gdx_hit32_t) -- sized from what it knows
+ * of its batches: one hit per read and a margin, or the largest total seen so far -- and a workspace of
+ * gdx_locate_workspace_bytes(hits_capacity) bytes.  d_totals (u64[2], device) = {all hit slots, those behind "see the record"}
+ * is valid once the stream has passed the call: the caller reads it when it reads the results.  totals[0] <= hits_capacity:
+ * d_hit_offsets and d_hits are complete.  totals[0] > hits_capacity: the offsets are right (u64; the u32 form wraps beyond
+ * 2^32), hits at and beyond the capacity were not stored -- the records, compact results and tile bases are intact, so
+ * gdx_locate_many_offsets_hits_compact_dev with a buffer of totals[0] entries finishes the step.  offsets_width 32: d_hit_offsets
+ * is u32[nq + 1] (hits_capacity < 2^32), 64: u64[nq + 1].  d_compact as in gdx_locate_many_search_compact_layout_dev (NULL on an
+ * index without seed table: records only).  A step of 12.5 M reads (what a rank of eight runs of a 100 M batch) is a dozen
+ * launches; the three calls around a round trip were two dozen and 45 us of waiting in 0.57 ms.  event_after_search
+ * (hipEvent_t or NULL) is recorded on the stream between the search (incl. its hit totals) and the offsets + hits, for
+ * callers that time the two halves. */
+int gdx_locate_many_step_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
+                                            const gdx_query_layout_t *layout, uint32_t max_hits, void *d_records, void *d_compact,
+                                            void *d_scan_workspace, void *d_totals, void *d_hit_offsets, uint32_t offsets_width,
+                                            void *d_hits, uint64_t hits_capacity, void *d_workspace, void *event_after_search,
+                                            void *stream);
 int gdx_count_many_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                               const gdx_query_layout_t *layout, void *d_out_counts, void *d_out_status, void *stream);
 int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,

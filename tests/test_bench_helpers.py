@@ -158,6 +158,22 @@ class _FakeEngine:
         pos[:nq] = bench_torch().from_numpy(inside.astype(np.int32))
 
 
+    # the found-bitmap wire (gdx_wire_pack_dev / gdx_wire_split_dev) through the library's own tensor restatements
+    def wire_pack_workspace_bytes(self, nq):
+        return 16
+
+    def wire_pack(self, compact, hit_offsets, hits, nq, v, workspace):
+        from genedex_amd import dist as gdist
+
+        gdist.wire_pack_reference(compact, hit_offsets, hits, nq, v)
+
+    def wire_split(self, v, nq, ids, pos):
+        from genedex_amd import dist as gdist
+
+        i, p = gdist.wire_split_reference(v, nq, bench_torch().from_numpy(self.starts))
+        ids[:nq], pos[:nq] = i, p
+
+
 def bench_torch():
     import torch
 
@@ -195,11 +211,28 @@ def test_compact_gather_plumbing_with_a_restated_engine():
     r.outs = [{"compact": torch.from_numpy(words.copy()), "hit_offsets": torch.from_numpy(off), "rec": None} for _ in range(2)]
     r.hits = [hits.clone(), hits.clone()]
     r.counts = lambda o: torch.from_numpy(counts.astype(np.int32))
-    os.environ.pop("GDX_BENCH_GATHER", None)
-    gather, pack, nbytes = bench.make_gather(torch, gdist, r, torch.device("cpu"), True)
-    assert getattr(gather, "compact_wire", False)  # 4 bytes per query + the exceptions < 1 + 5 bytes per hit
     n_exc = int((words == -2).sum())
-    assert gather.exceptions == {"queries": n_exc, "hits": int(counts[words == -2].sum())}
+    n_found = int((words >= 0).sum())
+    os.environ.pop("GDX_BENCH_GATHER", None)
+    # most reads are found: a bit per read + 4 bytes per found read is the smallest form
+    gather, pack, nbytes = bench.make_gather(torch, gdist, r, torch.device("cpu"), True)
+    n_exc_hits = int(counts[words == -2].sum())
+    assert getattr(gather, "wire_name", "") == "bitmap" and nbytes < 4 * nq + 4 * n_exc + 5 * n_exc_hits + 8
+    assert gather.exceptions == {"queries": n_exc, "hits": int(counts[words == -2].sum()), "found": n_found}
+    assert len(gather.slots[0]) == 1 and gather.slots[0][0].numel() == nbytes  # ONE buffer per rank and step
+    for slot in (0, 1):
+        pack(slot)
+        gather.submit(slot)
+    gather.drain()
+    cnt, hh = bench.gathered_shards(torch, gdist, gather, 1, [(0, nq)], [r.total_hits], True)
+    assert cnt.tolist() == counts.tolist() and hh.tolist() == hits.tolist()
+    # the compact words themselves (GDX_BENCH_GATHER=compact; what a batch with few found reads would choose)
+    os.environ["GDX_BENCH_GATHER"] = "compact"
+    try:
+        gather, pack, nbytes = bench.make_gather(torch, gdist, r, torch.device("cpu"), True)
+    finally:
+        os.environ.pop("GDX_BENCH_GATHER", None)
+    assert getattr(gather, "compact_wire", False) and getattr(gather, "wire_name", "compact") == "compact"
     assert nbytes == 4 * nq + 4 * n_exc + 5 * gather.exceptions["hits"] + 8
     assert r.outs[0]["compact"] is gather.slots[0][0]  # the search writes into the buffer that travels
     for slot in (0, 1):

@@ -123,6 +123,41 @@ def _worker(rank, world, port, result_path):
         c_cnt, c_hits = torch.cat(c_cnt).numpy(), torch.cat(c_hits).numpy()
     else:
         compact_ok = arrivals == []
+    # the found-bitmap wire (bench.py make_bitmap_gather): a bit per read + the positions of the found reads + the exceptions,
+    # everything a rank sends in ONE byte buffer (dist.WireLayout); gdx_wire_pack_dev / gdx_wire_split_dev restated with tensor
+    # operations (dist.wire_pack_reference / wire_split_reference: what the GPU tests compare the kernels with)
+    n_found = int(((words >= 0) | (words < -2)).sum())
+    layout = gdist.WireLayout(n_max, gdist.max_int_over_ranks(n_found, cpu), cap_q, cap_h)
+    bbufs = [torch.zeros(layout.nbytes, dtype=torch.uint8) for _ in range(2)]
+    bsplit = [[None] * world for _ in range(2)]
+    tstarts = torch.from_numpy(starts)
+
+    def on_bitmap(slot):
+        for r, buf in enumerate(bg.gathered(slot)[0]):
+            rlo, rhi = gdist.shard_range(nq, r, world)
+            bsplit[slot][r] = gdist.wire_split_reference(layout.views(buf), rhi - rlo, tstarts)
+
+    bg = gdist.PipelinedGather([[b] for b in bbufs], dst=0, on_gathered=on_bitmap)
+    for step in range(3):
+        slot = step % 2
+        bg.acquire(slot)
+        gdist.wire_pack_reference(torch.from_numpy(words), torch.from_numpy(off.astype(np.int64)), hits32, n_shard, layout.views(bbufs[slot]))
+        bg.submit(slot)
+    bg.drain()
+    bitmap_ok = True
+    if rank == 0:
+        b_cnt, b_hits = [], []
+        for r in range(world):
+            rlo, rhi = gdist.shard_range(nq, r, world)
+            v = layout.views(bg.gathered(0)[0][r])
+            cc, hh = gdist.expand_split_results(bsplit[0][r][0], bsplit[0][r][1], v["exc_cnt"], v["exc_ids"], v["exc_pos"], v["meta"], rhi - rlo)
+            b_cnt.append(cc)
+            b_hits.append(hh)
+            # the two wires must say the same about every read
+            bitmap_ok &= torch.equal(bsplit[0][r][0][: rhi - rlo], split[0][r][0][: rhi - rlo])
+            bitmap_ok &= torch.equal(bsplit[0][r][1][: rhi - rlo], split[0][r][1][: rhi - rlo])
+        b_cnt, b_hits = torch.cat(b_cnt).numpy(), torch.cat(b_hits).numpy()
+        bitmap_ok &= layout.nbytes < 4 * n_max + 4 * cap_q + 5 * cap_h + 8 or n_found > 0.9 * n_shard
     fixed = gdist.gather_fixed(torch.tensor([rank, hi - lo]), dst=0)
     tmax = gdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     ints_ok = gdist.gather_ints(10 + rank, torch.device("cpu")) == [10, 11]
@@ -136,7 +171,9 @@ def _worker(rank, world, port, result_path):
               and np.array_equal(all_hits[:, 0], ft.astype(np.int64)) and np.array_equal(all_hits[:, 1], fp.astype(np.int64))
               and [x.tolist() for x in fixed] == [[0, nq // 2], [1, nq - nq // 2]] and tmax == 2.0 and pipelined_ok and ints_ok
               and compact_ok and np.array_equal(c_cnt, (fe - fs).astype(np.int64))
-              and np.array_equal(c_hits[:, 0], ft.astype(np.int32)) and np.array_equal(c_hits[:, 1], fp.astype(np.int32)))
+              and np.array_equal(c_hits[:, 0], ft.astype(np.int32)) and np.array_equal(c_hits[:, 1], fp.astype(np.int32))
+              and bitmap_ok and np.array_equal(b_cnt, (fe - fs).astype(np.int64))
+              and np.array_equal(b_hits[:, 0], ft.astype(np.int32)) and np.array_equal(b_hits[:, 1], fp.astype(np.int32)))
         open(result_path, "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
 

@@ -1,4 +1,6 @@
 """FASTA / FASTQ ingestion (include/gdx.h gdx_fastx_*): host-only code of libgdx.so, runs without a GPU."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -169,3 +171,64 @@ def test_packed_batches_of_a_fastq_file(tmp_path):
     mixed = ["".join(rng.choice(list("ACGT"), int(rng.integers(1, 160)))) for _ in range(500)]
     write(tmp_path / "m.fq", mixed)
     check(fastx.read_packed_batches(str(tmp_path / "m.fq"), a, max_records=100, buffer_bytes=1 << 14), mixed)
+
+
+def _pack_reference(table, qbuf, qoff):
+    """2-bit packing restated with numpy: (packed bytes, sorted exception queries)"""
+    n_sym = int(qoff[-1])
+    d = table[qbuf[:n_sym]].astype(np.int64)
+    ok = (d >= 1) & (d <= 4)
+    ok[: int(qoff[0])] = True  # symbols before the first query are not looked at
+    code = np.where(ok, d - 1, 0)
+    code[: int(qoff[0])] = 0
+    pad = np.zeros((n_sym + 3) // 4 * 4, dtype=np.int64)
+    pad[:n_sym] = code
+    packed = (pad[0::4] | (pad[1::4] << 2) | (pad[2::4] << 4) | (pad[3::4] << 6)).astype(np.uint8)
+    bad_pos = np.flatnonzero(~ok)
+    exc = np.unique(np.searchsorted(qoff, bad_pos, side="right") - 1)
+    return packed, exc
+
+
+@pytest.mark.parametrize("name", ["ascii_dna", "ascii_dna_with_n", "ascii_dna_iupac", "ascii_dna_iupac_as_dna_with_n", "u8_until_4",
+                                  "random_table", "low_nibble_clash"])
+def test_host_packer_equals_the_byte_loop_on_every_table(name):
+    """gdx_pack_queries_table (pack_host.hpp: 32 symbols per step through nibble look-ups when the alphabet's table has the
+    shape for it, the byte loop otherwise) == the table applied byte by byte, for the stock alphabets, a table of no
+    particular shape and one whose symbols share low nibbles; batches that start inside the buffer, end off a 32-symbol
+    border, and hold every byte value."""
+    from genedex_amd import _lib, alphabet
+
+    lib = _lib.load()
+    rng = np.random.default_rng(hash(name) % 1000)
+    if name == "random_table":
+        table = rng.integers(0, 7, 256).astype(np.uint8)
+    elif name == "low_nibble_clash":  # 'A' (0x41) and 'Q' (0x51) are different symbols: no nibble plan
+        table = np.zeros(256, dtype=np.uint8)
+        table[[0x41, 0x51, 0x43, 0x47]] = [1, 2, 3, 4]
+    elif name == "u8_until_4":
+        table = np.zeros(256, dtype=np.uint8)
+        table[:4] = [1, 2, 3, 4]
+    else:
+        table = np.ascontiguousarray(getattr(alphabet, name)().io_to_dense_table, dtype=np.uint8)
+    for trial in range(6):
+        n = int(rng.integers(0, 3000)) if trial else 100_003
+        pool = np.frombuffer(b"ACGTacgtACGTNnRYKMUu\x00\xff", dtype=np.uint8)
+        qbuf = pool[rng.integers(0, pool.size if trial % 2 else 8, n)].copy()
+        if trial == 3:
+            qbuf = rng.integers(0, 256, n).astype(np.uint8)  # every byte value
+        if name == "u8_until_4":
+            qbuf = (qbuf & 7).astype(np.uint8)
+        cuts = np.sort(rng.integers(0, n + 1, int(rng.integers(1, 40))))
+        qoff = np.unique(np.concatenate([cuts, [n]])).astype(np.uint64) if trial % 3 else np.array([0, n], dtype=np.uint64)
+        nq = qoff.size - 1
+        packed = np.full(int(lib.gdx_packed_bytes(n)), 0xEE, dtype=np.uint8)
+        exc = np.zeros(nq + 1, dtype=np.uint64)
+        n_exc = C.c_uint64(0)
+        rc = lib.gdx_pack_queries_table(table.ctypes.data_as(_lib.u8p), qbuf.ctypes.data_as(_lib.u8p) if n else None,
+                                        qoff.ctypes.data_as(_lib.u64p), nq, packed.ctypes.data_as(_lib.u8p),
+                                        exc.ctypes.data_as(_lib.u64p), exc.size, C.byref(n_exc))
+        assert rc == 0, lib.gdx_last_error()
+        want, want_exc = _pack_reference(table, qbuf, qoff.astype(np.int64))
+        assert np.array_equal(packed[: want.size], want), (name, trial)
+        assert bool((packed[want.size:] == 0xEE).all())  # nothing beyond the packed symbols is written
+        assert exc[: n_exc.value].tolist() == want_exc.tolist(), (name, trial)

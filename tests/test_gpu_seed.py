@@ -146,6 +146,24 @@ def device_locate(g, qs, compact, max_hits=0, fused=False, packed=False):
         eng.locate_offsets_hits(rec, dq.nq, sws, off32, tot, rest, hits32, ws, max_hits, compact=cmp_)
         torch.cuda.synchronize()
         assert torch.equal(off32.to(torch.int64), off) and torch.equal(hits32[:tot], hits[:tot])
+        # the whole step as ONE call without the round trip (gdx_locate_many_step_compact_layout_dev) into an exact, a roomy
+        # and too small a hit buffer: totals, offsets and the hits below the capacity are those of the calls above
+        for cap in (tot, tot + 1000, tot // 2):
+            for dt in (torch.int64, torch.int32):
+                rec2 = torch.full_like(rec, 0x3c3c3c3c)
+                cmp2 = torch.full_like(cmp_, -5) if cmp_ is not None else None
+                off2 = torch.full((dq.nq + 1,), -1, dtype=dt, device="cuda")
+                hits2 = torch.full((cap, 2), -11, dtype=torch.int32, device="cuda")
+                tot2 = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+                sws3 = torch.full_like(sws, 0x77)
+                ws2 = torch.full((max(eng.locate_workspace_bytes(cap), 16),), 0x55, dtype=torch.uint8, device="cuda")
+                eng.locate_step(dq, rec2, cmp2, sws3, tot2, off2, hits2, ws2, max_hits)
+                torch.cuda.synchronize()
+                assert tot2.tolist() == [tot, rest] if cmp_ is not None else int(tot2[0].item()) == tot
+                assert torch.equal(off2.to(torch.int64), off)
+                assert torch.equal(hits2[: min(cap, tot)], hits[: min(cap, tot)])
+                if cap > tot:
+                    assert bool((hits2[tot:] == -11).all().item())  # nothing is written beyond the batch's hits
     else:
         eng.locate_offsets(rec, dq.nq, off, max_hits, compact=cmp_)
         torch.cuda.synchronize()
@@ -342,6 +360,87 @@ def test_compact_results_split_into_text_id_and_position(n_texts):
     eng2 = DeviceEngine(g2)
     with pytest.raises(Exception, match="256 texts"):
         eng2.compact_split_hits(cmp_, 4, torch.zeros(4, dtype=torch.uint8, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("n_texts,nq", [(1, 300), (5, 2048), (24, 9001), (200, 70_000)])
+def test_found_bitmap_wire_equals_compact_split_and_reference(n_texts, nq):
+    """gdx_wire_pack_dev / gdx_wire_split_dev (the "found bitmap" wire of the multi-GPU gather): a shard packed on the sender's
+    side and split on the receiver's says about every read what gdx_compact_split_hits_dev says, its exceptions carry the
+    oracle's counts and hits, and the packed bytes are those of the tensor restatement the gloo tests gather
+    (dist.wire_pack_reference); capacities that are too small drop what does not fit and report the true numbers."""
+    import torch
+
+    from genedex_amd import dist as gdist
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(9900 + n_texts)
+    texts = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(200, 6000)))) for _ in range(n_texts)]
+    texts[0] = texts[0] + texts[0][-60:] + texts[0][-60:]  # (repeats: reads from them are exceptions with several hits)
+    a = alph.ascii_dna()
+    g = gpu_index(texts, a, seed_symbols=10)
+    c = cpu_index(texts, a)
+    qs = []
+    for i in range(nq - 2):  # reads of 12..60 symbols from the texts, one in ten random, one in fifty short (an exception)
+        t = texts[int(rng.integers(0, n_texts))]
+        ln = int(rng.integers(7, 10)) if i % 50 == 7 else int(rng.integers(12, 61))
+        at = int(rng.integers(0, max(len(t) - ln, 1)))
+        qs.append(bytes(b"ACGT"[k] for k in rng.integers(0, 4, ln)) if i % 10 == 3 else t[at:at + ln])
+    qs += [texts[0][-30:], b"ACGTTGCATTTAGGACCA"]
+    co, ct, cp = c.locate_many(qs)
+    eng = DeviceEngine(g)
+    dq = DeviceQueries.from_host(*pack_queries(qs))
+    for narrow in (False, True):
+        rec, cmp_ = eng.alloc_records(dq.nq), eng.alloc_compact(dq.nq)
+        sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        off = torch.empty(dq.nq + 1, dtype=torch.int32 if narrow else torch.int64, device="cuda")
+        hits = torch.empty((int(co[-1]) + 5, 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(hits.shape[0]), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_step(dq, rec, cmp_, sws, totals, off, hits, ws)
+        torch.cuda.synchronize()
+        assert int(totals[0].item()) == int(co[-1])
+        words = cmp_[:dq.nq]
+        n_exc, n_exc_hits = gdist.exception_sizes(words, off.to(torch.int64), dq.nq)
+        n_found = int(((words >= 0) | (words < -2)).sum().item())
+        assert n_exc > 0 and n_found > dq.nq // 4
+        ids_c = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+        pos_c = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+        eng.compact_split_hits(cmp_, dq.nq, ids_c, pos_c)
+        wws = torch.empty(max(eng.wire_pack_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        for cap_f, cap_q, cap_h in ((n_found, n_exc, n_exc_hits), (n_found + 9, n_exc + 3, n_exc_hits + 7),
+                                    (max(n_found // 2, 1), max(n_exc // 2, 1), max(n_exc_hits // 2, 1))):
+            layout = gdist.WireLayout(dq.nq, cap_f, cap_q, cap_h)
+            buf = torch.full((layout.nbytes,), 0xA5, dtype=torch.uint8, device="cuda")
+            v = layout.views(buf)
+            eng.wire_pack(cmp_, off, hits, dq.nq, v, wws)
+            torch.cuda.synchronize()
+            assert v["meta"].tolist() == [n_exc, n_exc_hits, n_found, 0]
+            ref = torch.full_like(buf, 0xA5)
+            rv = layout.views(ref)
+            gdist.wire_pack_reference(words, off.to(torch.int64), hits, dq.nq, rv)
+            tiles = (dq.nq + 2047) // 2048
+            assert torch.equal(v["bitmap"][: (dq.nq + 7) // 8], rv["bitmap"][: (dq.nq + 7) // 8])
+            assert torch.equal(v["tile_found"][: tiles + 1], rv["tile_found"][: tiles + 1])
+            for k, n in (("found_pos", min(cap_f, n_found)), ("exc_q", min(cap_q, n_exc)), ("exc_cnt", min(cap_q, n_exc))):
+                assert torch.equal(v[k][:n], rv[k][:n]), k
+                assert bool((v[k][n:].view(torch.uint8) == 0xA5).all().item()), k  # nothing written beyond what there is
+            if cap_h >= n_exc_hits:
+                assert torch.equal(v["exc_ids"][:n_exc_hits], rv["exc_ids"][:n_exc_hits])
+                assert torch.equal(v["exc_pos"][:n_exc_hits], rv["exc_pos"][:n_exc_hits])
+            if cap_f < n_found or cap_q < n_exc:
+                continue  # (a receiver sees the true numbers in meta and refuses: expand_split_results)
+            ids = torch.full((dq.nq,), 77, dtype=torch.uint8, device="cuda")
+            pos = torch.full((dq.nq,), 77, dtype=torch.int32, device="cuda")
+            eng.wire_split(v, dq.nq, ids, pos)
+            torch.cuda.synchronize()
+            assert torch.equal(ids, ids_c) and torch.equal(pos, pos_c)
+            cnt, hh = gdist.expand_split_results(ids, pos, v["exc_cnt"], v["exc_ids"], v["exc_pos"], v["meta"], dq.nq)
+            assert cnt.cpu().numpy().tolist() == np.diff(co).tolist()
+            assert hh[:, 0].cpu().numpy().tolist() == ct.astype(np.int64).tolist()
+            assert hh[:, 1].cpu().numpy().tolist() == cp.astype(np.int64).tolist()
+            # fewer bytes than the compact words where most reads are found
+            if n_found > 0.5 * dq.nq and dq.nq > 4000:
+                assert layout.payload_bytes(dq.nq, n_found, n_exc, n_exc_hits) < 4 * dq.nq + 4 * n_exc + 5 * n_exc_hits
 
 
 def test_seed_entries_are_the_distinct_kmers():

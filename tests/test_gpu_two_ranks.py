@@ -12,14 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wire", ["compact", "arrays"])
+@pytest.mark.parametrize("wire", ["bitmap", "compact", "arrays"])
 def test_bench_two_ranks_on_one_gpu(wire):
-    """wire: what travels to rank 0 -- the search's compact results + the exceptions' counts and hits (the default on an
-    index with a seed table; rank 0 splits them into text id + position with gdx_compact_split_hits_dev), or count bytes +
-    text id bytes + int32 positions per hit (GDX_BENCH_GATHER=arrays; any index)"""
+    """wire: what travels to rank 0 -- a bit per read + the positions of the found reads + the exceptions (gdx_wire_pack_dev /
+    gdx_wire_split_dev; what an index with a seed table chooses when most reads are found), the search's compact results +
+    the exceptions' counts and hits (rank 0 splits them into text id + position with gdx_compact_split_hits_dev), or count
+    bytes + text id bytes + int32 positions per hit (GDX_BENCH_GATHER=arrays; any index)"""
     env = dict(os.environ, GDX_BENCH_ONE_GPU="1", GDX_BENCH_BACKEND="gloo", GDX_BENCH_GATHER=wire)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29547" if wire == "compact" else "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "127.0.0.1", "--master-port", {"compact": "29547", "arrays": "29549", "bitmap": "29551"}[wire], os.path.join(ROOT, "bench.py"), "--gpus", "2",
            "--workload", "small", "--steps", "3", "--no-bandwidth", "--nq", "1000000"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]

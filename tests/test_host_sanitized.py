@@ -117,3 +117,20 @@ def test_index_file_header_validation(checker, tmp_path):
     for name, (hdr, pay) in bad.items():
         rc, out = checker("header", write(name + ".gdx", hdr, pay))
         assert rc == 3 and out.startswith("error:"), (name, out)
+
+
+def test_host_packer_stays_inside_its_buffers(checker, tmp_path):
+    """pack_host.hpp (the AVX2 path of gdx_pack_queries / gdx_pack_queries_table and its byte loop) on exactly sized heap
+    blocks under ASan + UBSan: pieces that start and end everywhere relative to the 32- and 128-symbol steps, a table with
+    the nibble shape and one without; the packed bytes and the exception positions are those of the byte loop."""
+    rng = np.random.default_rng(3)
+    for name, n in (("reads.txt", 5000), ("short.txt", 37), ("empty.txt", 0), ("junk.bin", 3000)):
+        p = tmp_path / name
+        if name == "junk.bin":
+            p.write_bytes(bytes(rng.integers(0, 256, n).astype(np.uint8)))
+        else:
+            p.write_bytes(bytes(rng.choice(list(b"ACGTacgtACGTACGTNQ"), n).astype(np.uint8)))
+        rc, out = checker("pack", p)
+        assert rc == 0 and out.startswith("ok "), (name, out)
+        if n >= 3000:
+            assert int(out.split()[1]) == 40 and int(out.split()[2]) > 0

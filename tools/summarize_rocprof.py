@@ -3,6 +3,7 @@
 
     tools/summarize_rocprof.py stats  <dir with *_kernel_stats.csv>         -> markdown table on stdout
     tools/summarize_rocprof.py pmc    <dir with *_counter_collection.csv>   -> json on stdout
+    tools/summarize_rocprof.py timeline <dir with *_kernel_trace.csv> [n]   -> the last n dispatches: start, duration, gap before
 """
 import collections
 import csv
@@ -52,5 +53,19 @@ def pmc(d):
     print(json.dumps(out, indent=1))
 
 
+def timeline(d):
+    f = glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True)[0]
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(f))))
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    rows = rows[-n:]
+    t0, prev_end = rows[0][0], None
+    print("| start us | dur us | gap before us | kernel |")
+    print("|---|---|---|---|")
+    for s, e, k in rows:
+        gap = "" if prev_end is None else f"{(s - prev_end) / 1e3:.1f}"
+        print(f"| {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {gap} | {k} |")
+        prev_end = e if prev_end is None else max(prev_end, e)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2])
