@@ -151,7 +151,7 @@ PMC_PASSES = [
     # under the traffic can be the profiler's as well as this process's HIP events (roofline.avg_launch_ms_rocprof)
     ("kernel_trace", None),
 ]
-KERNEL_REGEX = ("search_seed_kernel|search_seed_lane_kernel|seed_text_kernel|tile_sums_lists_kernel|scan2_sums_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|scan_locate_kernel|scan2_tile|"
+KERNEL_REGEX = ("search_seed_kernel|search_seed_lane_kernel|seed_text_kernel|tile_sums_lists_kernel|scan2_sums_kernel|search_fast_kernel|search_pair_kernel|locate_queue_kernel|locate_stream_kernel|scan2_tile|"
                 "search_kernel|search_verify_kernel|search_exact_kernel")
 
 
@@ -424,10 +424,6 @@ class StepRunner:
         self.hits, self.ws = [], []
         self.ev_search, self.ev_locate = [], []
         self.sized_in_step = True  # the timed step reads the number of hits back and sizes the hit buffer itself
-        # records path, optional (GDX_BENCH_FUSED_SCAN=1): offsets and single-hit locate in ONE pass over the records
-        # (gdx_locate_many_scan_hits_dev).  Measured 1.7 ms against 1.33 ms for the two streaming passes it replaces (the
-        # look-back of a single-pass scan crosses XCDs; profiles/r03/experiments.md section 8), so it is not the default.
-        self.fused_scan = self.use_rec and not self.use_compact and os.environ.get("GDX_BENCH_FUSED_SCAN") == "1"
         self.scan_ws, self.totals = [], []
         self.ev_scan = []
         self.max_hits = 0  # != 0: queries with more occurrences are counted but not located (gdx.h max_hits)
@@ -490,10 +486,6 @@ class StepRunner:
         self.hits = [torch.zeros((max(self.total_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(self.n_slots)]
         nbytes = max(self.eng.locate_workspace_bytes(self.total_hits), 16)
         self.ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
-        if self.fused_scan:
-            sb = max(self.eng.scan_workspace_bytes(self.nq), 16)
-            self.scan_ws = [torch.empty(sb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
-            self.totals = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.n_slots)]
         return self.total_hits
 
     def _step_fused(self, slot, record, after):
@@ -542,14 +534,14 @@ class StepRunner:
 
     def step(self, slot, record, side_stream=None, after=None):
         torch = self.torch
-        if (self.do_locate and self.use_compact and not self.fused_scan and side_stream is None
+        if (self.do_locate and self.use_compact and side_stream is None
                 and getattr(self, "step_mode", "fused") == "fused" and os.environ.get("GDX_BENCH_NO_FOLD") != "1"):
             return self._step_fused(slot, record, after)
         o, h, ws = self.outs[slot], self.hits[slot], self.ws[slot]
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # compact path: the hit totals come out of the search call itself (gdx_locate_many_search_totals_compact_layout_dev;
         # GDX_BENCH_NO_FOLD=1: the separate totals pass of round 3)
-        fold = self.do_locate and self.use_compact and not self.fused_scan and os.environ.get("GDX_BENCH_NO_FOLD") != "1"
+        fold = self.do_locate and self.use_compact and os.environ.get("GDX_BENCH_NO_FOLD") != "1"
         if fold and slot >= len(self.scan_ws):
             dev_ = h.device
             self.scan_ws = [torch.empty(max(self.eng.totals_workspace_bytes(self.nq), 16), dtype=torch.uint8, device=dev_)
@@ -566,32 +558,7 @@ class StepRunner:
         with (torch.cuda.stream(side_stream) if side_stream is not None else _null()):
             if side_stream is not None:
                 side_stream.wait_event(b)
-            if self.do_locate and self.fused_scan:
-                # one pass: offsets + the hit of every single-hit query, into the buffer the previous step sized; then the
-                # one host round trip (both totals); then only what that pass left open
-                c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                c.record()
-                self.eng.locate_scan_hits(o["rec"], self.nq, o["hit_offsets"], h, h.shape[0], self.scan_ws[slot],
-                                          self.totals[slot])
-                tot, rest = (int(x) for x in self.totals[slot].tolist())
-                self.total_hits = tot
-                if tot > h.shape[0]:  # the buffer offered was too small: grow it, locate everything (offsets are valid)
-                    self.hits[slot] = torch.empty((tot, 2), dtype=torch.int32, device=h.device)
-                    h = self.hits[slot]
-                    rest = -1
-                if rest != 0:
-                    need = self.eng.locate_workspace_bytes(tot)
-                    if need > self.ws[slot].numel():
-                        self.ws[slot] = torch.empty(need, dtype=torch.uint8, device=h.device)
-                        ws = self.ws[slot]
-                    if rest < 0:
-                        self.locate(o, h, ws)
-                    else:
-                        self.eng.locate_hits_rest(o["rec"], self.nq, o["hit_offsets"], tot, h, ws)
-                d.record()
-                if record:
-                    self.ev_locate.append((c, d))
-            elif self.do_locate and self.use_compact:
+            if self.do_locate and self.use_compact:
                 # totals -> the one host round trip (sizes the hit buffer) -> offsets and the hits of the compactly answered
                 # reads in ONE pass, the rest from the records (gdx_locate_many_totals_compact_dev / _offsets_hits_compact_dev)
                 if slot >= len(self.scan_ws):
@@ -970,16 +937,14 @@ def main():
             del acct
         locate_bytes = 30 * walk_steps + 4 * total_hits + 8 * total_hits
         if runner.use_compact:  # offsets and the compactly answered hits in one pass, the queue kernel on flagged chunks only
-            lt = traffic_of(pmc, "scan2_tile_scan_kernel<true, false>|locate_queue_kernel")
+            lt = traffic_of(pmc, "scan2_tile_scan_kernel<true, false>|locate_stream_kernel|locate_queue_kernel")
         else:
-            lt = traffic_of(pmc, "scan_locate_kernel|locate_queue_kernel")
-        locate_roofline = {"bound": "hbm", "kernel": (lt or {}).get("kernel", "scan_locate_kernel"), "peak": HBM_PEAK_GBPS,
+            lt = traffic_of(pmc, "locate_stream_kernel|locate_queue_kernel")
+        locate_roofline = {"bound": "hbm", "kernel": (lt or {}).get("kernel", "locate_stream_kernel"), "peak": HBM_PEAK_GBPS,
                            "what": "gdx_locate_many_offsets_hits_compact_dev: hit offsets + the hits of the compactly answered reads "
                                    "in one pass over 4 bytes per query (scan2_tile_scan_kernel<true, false>), then the queue kernel "
                                    "on the chunks with slots left open; the totals pass before the host round trip "
                                    "(scan2_tile_sums_kernel) is kernel_ms.totals" if runner.use_compact else
-                                   "hit offsets + hits in one pass over the records (scan_locate_kernel) + the host read-back of "
-                                   "the totals + the queue kernel on what that pass left open" if runner.fused_scan else
                                    "locate_queue_kernel after the separate scan",
                            "unit": "GB/s", "avg_launch_ms": locate_ms,
                            "traffic": lt["bytes"] if lt else None,
@@ -1233,7 +1198,8 @@ def compact_line(result, side_file=None):
                                             "locate_over_bound"))
         if isinstance(e.get("packed_uniform"), dict):
             line["end_to_end"]["packed_uniform"] = _pick(e["packed_uniform"], ("count_qps", "locate_qps", "count_over_bound",
-                                                                                  "locate_over_bound"))
+                                                                                  "locate_over_bound", "locate32_qps", "locate32_over_bound",
+                                                                                  "locate32_pinned_input_qps"))
     line["index_build_seconds"] = result.get("index_build_seconds")
     line["side_file"] = side_file
     line = _num(line)
@@ -2013,17 +1979,63 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
                 dt = time.perf_counter() - t0
                 t_l = dt if t_l is None or dt < t_l else t_l
             same_t = total.value == total_hits and int(offs[-1]) == total_hits
+            # the narrow form (gdx_locate_many_alloc_layout32): u32 offsets + 8-byte hits in pinned memory of the library's, written
+            # by the device; from the pageable array and from a pinned copy of it (no staging copy on the way in)
+            def locate32(qptr):
+                res = _lib.Hits32()
+                _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, qptr, None, nq, C.byref(lay), C.byref(res),
+                                                              status.ctypes.data_as(u8p)))
+                return res
+
+            def time32(qptr):
+                best, res = None, None
+                for _ in range(3):
+                    if res is not None:
+                        lib.gdx_free_hits32(C.byref(res))
+                    t0 = time.perf_counter()
+                    res = locate32(qptr)
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None or dt < best else best
+                return best, res
+
+            t_l32, res32 = time32(packed.ctypes.data_as(u8p))
+            same_32 = res32.total_hits == total_hits
+            if same_32 and last.get("ptr") and total_hits:  # the same offsets and hits as the wide call
+                o32 = np.ctypeslib.as_array(res32.hit_offsets, shape=(nq + 1,))
+                same_32 = bool(np.array_equal(o32, offs.astype(np.uint32)))
+                n_cmp = min(total_hits, 4_000_000)
+                h32 = np.ctypeslib.as_array(res32.hits, shape=(2 * n_cmp,)).reshape(n_cmp, 2)
+                h64 = np.ctypeslib.as_array(C.cast(last["ptr"], _lib.u64p), shape=(2 * n_cmp,)).reshape(n_cmp, 2)
+                same_32 = same_32 and bool(np.array_equal(h32, h64.astype(np.uint32)))
+                tail32 = np.ctypeslib.as_array(res32.hits, shape=(2 * total_hits,))[-2 * n_cmp:]
+                tail64 = np.ctypeslib.as_array(C.cast(last["ptr"], _lib.u64p), shape=(2 * total_hits,))[-2 * n_cmp:]
+                same_32 = same_32 and bool(np.array_equal(tail32, tail64.astype(np.uint32)))
+            lib.gdx_free_hits32(C.byref(res32))
+            pinned_in = torch.from_numpy(packed).pin_memory()
+            t_l32p, res32p = time32(C.cast(C.c_void_p(pinned_in.data_ptr()), u8p))
+            same_32 = same_32 and res32p.total_hits == total_hits
+            lib.gdx_free_hits32(C.byref(res32p))
+            del pinned_in
+            lib.gdx_release_cached_hits()
             if last.get("ptr"):
                 lib.gdx_free_hits(last.pop("ptr"))
-            if not same_c or not same_t:
+            if not same_c or not same_t or not same_32:
                 raise SystemExit("PARITY FAILURE: the packed + uniform host calls disagree with the device-resident path")
             in_pu = (nq * ulen + 3) // 4
+            out_locate32_bytes = 5 * nq + 4 + 8 * total_hits
             res["packed_uniform"] = {
                 "count_qps": nq / t_c, "count_seconds": t_c, "locate_qps": nq / t_l, "locate_seconds": t_l, "h2d_bytes": in_pu,
                 "count_over_bound": t_c / max(in_pu / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
                 "locate_over_bound": t_l / max(in_pu / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3),
+                "locate32_qps": nq / t_l32, "locate32_seconds": t_l32,
+                "locate32_over_bound": t_l32 / max(in_pu / (h2d * 1e9), out_locate32_bytes / (d2h * 1e9), step_ms / 1e3),
+                "locate32_pinned_input_qps": nq / t_l32p, "locate32_pinned_input_seconds": t_l32p,
+                "locate32_pinned_input_over_bound": t_l32p / max(in_pu / (h2d * 1e9), out_locate32_bytes / (d2h * 1e9), step_ms / 1e3),
+                "d2h_bytes_locate32": out_locate32_bytes,
                 "calls": "gdx_count_many_layout / gdx_locate_many_alloc_layout, layout = {packed, uniform_len}: 2-bit codes, no "
-                         "offsets", "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t}}
+                         "offsets; locate32 = gdx_locate_many_alloc_layout32 (u32 offsets + 8-byte hits in pinned memory of the "
+                         "library's, written by the device; pinned_input: the 2-bit codes lie in pinned memory too, no staging copy)",
+                "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t, "narrow_equals_wide": same_32}}
     log(f"[bench] end to end: {res}")
     return res
 

@@ -42,6 +42,12 @@ class HitStruct(C.Structure):
     _fields_ = [("text_id", C.c_uint64), ("position", C.c_uint64)]
 
 
+class Hits32(C.Structure):
+    """gdx_hits32_t: narrow results in pinned memory the library owns (gdx_locate_many_alloc_layout32)"""
+    _fields_ = [("hit_offsets", C.POINTER(C.c_uint32)), ("hits", C.POINTER(C.c_uint32)), ("total_hits", C.c_uint64),
+                ("nq", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("total_text_len", C.c_uint64), ("num_texts", C.c_uint64), ("sigma", C.c_int32),
                 ("n_searchable", C.c_int32), ("lookup_depth", C.c_int32), ("index_width", C.c_int32),
@@ -135,14 +141,14 @@ SIGNATURES = {
     "gdx_locate_many": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(HitStruct), C.c_uint64, u64p, u8p],
     "gdx_locate_many_alloc": [vp, u8p, u64p, C.c_uint64, u64p, C.POINTER(C.POINTER(HitStruct)), u64p, u8p],
     "gdx_free_hits": [C.POINTER(HitStruct)],
+    "gdx_locate_many_alloc_layout32": [vp, u8p, u64p, C.c_uint64, C.POINTER(QueryLayout), C.POINTER(Hits32), u8p],
+    "gdx_free_hits32": [C.POINTER(Hits32)],
+    "gdx_release_cached_hits": [],
     "gdx_multi_build": [u8p, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                         C.POINTER(C.c_int), C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_multi_from_indexes": [C.POINTER(vp), C.c_int, C.POINTER(vp)],
     "gdx_multi_free": [vp],
     "gdx_debug_force_wide": [C.c_int],
-    "gdx_locate_many_scan_workspace_bytes": [C.c_uint64],
-    "gdx_locate_many_scan_hits_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp],
-    "gdx_locate_many_hits_rest_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp],
     "gdx_parts_build": [vp, C.c_int, u64p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                         C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_parts_free": [vp],
@@ -232,9 +238,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"gdx_locate_many_totals_workspace_bytes": C.c_uint64, "gdx_wire_bitmap_bytes": C.c_uint64,
              "gdx_wire_pack_workspace_bytes": C.c_uint64, "gdx_last_error": C.c_char_p, "gdx_index_free": None, "gdx_fastx_close": None,
-             "gdx_build_options_init": None, "gdx_query_layout_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
-             "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64,
-             "gdx_locate_many_scan_workspace_bytes": C.c_uint64}
+             "gdx_build_options_init": None, "gdx_query_layout_init": None, "gdx_query_options_init": None, "gdx_free_hits": None, "gdx_free_hits32": None, "gdx_release_cached_hits": None, "gdx_multi_free": None, "gdx_parts_free": None,
+             "gdx_locate_workspace_bytes": C.c_uint64, "gdx_packed_bytes": C.c_uint64}
 
 _lib = None
 

@@ -926,45 +926,6 @@ int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint6
     });
 }
 
-uint64_t gdx_locate_many_scan_workspace_bytes(uint64_t nq) { return gdx::scan_locate_workspace_bytes(nq); }
-
-int gdx_locate_many_scan_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
-                                  void *d_hit_offsets, void *d_hits, uint64_t hits_capacity, void *d_scan_workspace,
-                                  void *d_totals, void *stream)
-{
-    return guarded([&] {
-        const gdx::FmIndex &f = deref(ix);
-        check_records(d_records);
-        if (!d_hit_offsets || !d_totals || !d_scan_workspace || (hits_capacity != 0 && !d_hits))
-            gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_scan_hits_dev: null argument");
-        DeviceGuard guard(f.config().device_id);
-        gdx::launch_scan_locate(f.view(), static_cast<const uint4 *>(d_records), nq, max_hits, false,
-                                static_cast<uint64_t *>(d_hit_offsets), d_hits, hits_capacity, false, d_scan_workspace,
-                                static_cast<unsigned long long *>(d_totals), as_stream(stream));
-        GDX_HIP(hipGetLastError());
-        return (int)GDX_OK;
-    });
-}
-
-int gdx_locate_many_hits_rest_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
-                                  uint64_t total_hits, void *d_hits, void *d_workspace, void *stream)
-{
-    return guarded([&] {
-        const gdx::FmIndex &f = deref(ix);
-        check_records(d_records);
-        DeviceGuard guard(f.config().device_id);
-        // the scan pass stored every single hit when the index has SA[row] at hand; otherwise the walk fills in all slots
-        // (resolved ones are written again, with the same values)
-        const gdx::IndexView &v = f.view();
-        const bool have_sa = v.layout == 0 && (v.sa_full != nullptr || (v.jump != nullptr && v.jump_bytes == 32));
-        gdx::launch_locate(v, nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits, false,
-                           d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
-                           static_cast<const uint4 *>(d_records), false, have_sa);
-        GDX_HIP(hipGetLastError());
-        return (int)GDX_OK;
-    });
-}
-
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream)
 {
@@ -1031,7 +992,7 @@ int gdx_locate_many_hits_compact_dev(const gdx_index_t *ix, const void *d_record
         DeviceGuard guard(f.config().device_id);
         gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits,
                            d_hits, false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
-                           static_cast<const uint4 *>(d_records), false, false, static_cast<const uint32_t *>(d_compact));
+                           static_cast<const uint4 *>(d_records), false, static_cast<const uint32_t *>(d_compact));
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -1064,23 +1025,12 @@ static int offsets_hits_compact(bool narrow, const gdx_index_t *ix, const void *
         if (!d_scan_workspace || !d_hit_offsets || (total_hits != 0 && !d_hits))
             gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_offsets_hits_compact_dev: null argument");
         if (narrow && total_hits >= (1ull << 32)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "32-bit hit offsets need fewer than 2^32 hits");
-        DeviceGuard guard(f.config().device_id);
-        // few open slots: the scan pass stores the compactly answered hits and flags the locate chunks with open slots, locate
-        // visits only those; many (reads from repeats, short reads): the scan writes offsets only and locate streams over all slots
-        const bool sparse = d_compact != nullptr && rest_hits * 16 <= total_hits;
         if ((rest_hits != 0 || d_compact == nullptr) && total_hits != 0 && !d_workspace)
             gdx::fail(GDX_ERR_INVALID_ARGUMENT, "gdx_locate_many_offsets_hits_compact_dev: d_workspace is null");
-        uint8_t *flags = (sparse && rest_hits != 0)
-                             ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(total_hits) : nullptr;
-        gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
-                                       max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits, total_hits,
-                                       false, as_stream(stream), sparse, flags, narrow, false,
-                                       gdx::locate_entry_sa(f.view(), f.query_options()));
-        if (rest_hits != 0 || !sparse)
-            gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits,
-                               false, d_workspace, as_stream(stream), nullptr, nullptr, f.query_options(),
-                               static_cast<const uint4 *>(d_records), false, false, static_cast<const uint32_t *>(d_compact),
-                               sparse, flags, narrow);
+        DeviceGuard guard(f.config().device_id);
+        gdx::launch_offsets_hits(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
+                                 false, d_scan_workspace, d_hit_offsets, narrow, total_hits, rest_hits, d_hits, d_workspace,
+                                 as_stream(stream), f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });
@@ -1411,6 +1361,20 @@ int gdx_locate_many_alloc_layout(const gdx_index_t *ix, const uint8_t *qbuf, con
     });
 }
 
+int gdx_locate_many_alloc_layout32(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                   const gdx_query_layout_t *layout, gdx_hits32_t *out_results, uint8_t *out_status)
+{
+    return guarded([&] {
+        bool packed;
+        uint64_t ulen;
+        host_layout(layout, packed, ulen);
+        return deref(ix).locate_many_alloc32(qbuf, qoff, nq, out_results, out_status, packed, ulen);
+    });
+}
+
+void gdx_free_hits32(gdx_hits32_t *results) { gdx::recycle_hits32(results); }
+void gdx_release_cached_hits(void) { gdx::release_cached_hits(); }
+
 int gdx_locate_many_search_compact_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                               const gdx_query_layout_t *layout, void *d_records, void *d_compact, void *stream)
 {
@@ -1480,50 +1444,20 @@ int gdx_locate_many_step_compact_layout_dev(const gdx_index_t *ix, const void *d
         if (narrow && hits_capacity >= (1ull << 32)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "32-bit hit offsets need fewer than 2^32 hits");
         if ((reinterpret_cast<uintptr_t>(d_totals) & 7u) != 0) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "d_totals must be 8-byte aligned");
         DeviceGuard guard(f.config().device_id);
-        hipStream_t st = as_stream(stream);
-        unsigned long long *totals = static_cast<unsigned long long *>(d_totals);
-        // the scan pass stores the hits the compact results answer and flags the locate chunks that hold other slots
-        const bool store = d_compact != nullptr && hits_capacity != 0;
-        uint8_t *flags = store ? static_cast<uint8_t *>(d_workspace) + gdx::locate_chunk_flags_offset(hits_capacity) : nullptr;
-        gdx::ZeroSet zero;
-        zero.add(totals, 2 * sizeof(unsigned long long));
-        if (flags != nullptr) zero.add(flags, gdx::locate_chunk_flags_bytes(hits_capacity));
-        if (nq == 0) {
-            zero.add(d_hit_offsets, narrow ? sizeof(uint32_t) : sizeof(uint64_t));
-            zero.flush(st);
-            GDX_HIP(hipGetLastError());
-            if (event_after_search) GDX_HIP(hipEventRecord(static_cast<hipEvent_t>(event_after_search), st));
-            return (int)GDX_OK;
-        }
-        gdx::SearchCall c;
-        apply_layout(c, d_qbuf, d_qoff, nq, layout);
-        c.d_rec = static_cast<uint4 *>(d_records);
-        c.d_compact = static_cast<uint32_t *>(d_compact);
-        c.mode = 1;
-        bool folded = false;
-        if (d_compact != nullptr) {
-            c.d_tile_sums = static_cast<unsigned long long *>(d_scan_workspace);
-            c.d_tile_rest = totals + 1;
-            c.tile_max_hits = max_hits;
-            c.tile_sums_done = &folded;
-        }
-        c.also_zero = &zero;
-        gdx::launch_search_call(f.view(), c, st, f.query_options());
-        GDX_HIP(hipGetLastError());
-        if (folded)
-            gdx::launch_scan_totals_finish(d_scan_workspace, nq, totals, st);
-        else  // (zeroes the totals again and counts from the results)
-            gdx::launch_scan_totals(static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq, max_hits,
-                                    false, d_scan_workspace, totals, st);
-        if (event_after_search) GDX_HIP(hipEventRecord(static_cast<hipEvent_t>(event_after_search), st));
-        gdx::launch_scan_offsets_store(f.view(), static_cast<const uint4 *>(d_records), static_cast<const uint32_t *>(d_compact), nq,
-                                       max_hits, false, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits,
-                                       hits_capacity, false, st, store, flags, narrow, true,
-                                       gdx::locate_entry_sa(f.view(), f.query_options()), totals);
-        if (hits_capacity != 0)
-            gdx::launch_locate(f.view(), nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), hits_capacity, d_hits,
-                               false, d_workspace, st, nullptr, nullptr, f.query_options(), static_cast<const uint4 *>(d_records),
-                               false, false, static_cast<const uint32_t *>(d_compact), store, flags, narrow, totals);
+        gdx::LocateStep step;
+        apply_layout(step.call, d_qbuf, d_qoff, nq, layout);
+        step.call.d_rec = static_cast<uint4 *>(d_records);
+        step.call.d_compact = static_cast<uint32_t *>(d_compact);
+        step.max_hits = max_hits;
+        step.d_scan_workspace = d_scan_workspace;
+        step.d_totals = static_cast<unsigned long long *>(d_totals);
+        step.d_hit_offsets = d_hit_offsets;
+        step.narrow = narrow;
+        step.d_hits = d_hits;
+        step.hits_capacity = hits_capacity;
+        step.d_workspace = d_workspace;
+        step.event_after_search = static_cast<hipEvent_t>(event_after_search);
+        gdx::launch_locate_step(f.view(), step, as_stream(stream), f.query_options());
         GDX_HIP(hipGetLastError());
         return (int)GDX_OK;
     });

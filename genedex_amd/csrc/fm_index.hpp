@@ -59,6 +59,8 @@ struct IndexConfig {
     BuildOptions build;
 };
 
+struct Narrow32Sink;  // (below)
+
 class FmIndex {
 public:
     // FmIndexConfig::construct_index (config.rs:63-69).  texts_buf: concatenated IO symbols of all
@@ -110,6 +112,9 @@ public:
     int locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                           gdx_hit_t **out_hits, uint64_t *out_total, uint8_t *out_status, bool packed = false,
                           uint64_t uniform_len = 0) const;
+    // narrow results (u32 offsets, 8-byte hits) in pinned memory the library owns: the device writes them there (host_api.hip)
+    int locate_many_alloc32(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, gdx_hits32_t *out, uint8_t *out_status,
+                            bool packed = false, uint64_t uniform_len = 0) const;
     int cursor_extend_front_many(uint64_t *start, uint64_t *end, const uint8_t *io_symbols, uint64_t m,
                                  uint8_t *out_status) const;
     int cursor_extend_front_strings(uint64_t *start, uint64_t *end, const uint8_t *qbuf, const uint64_t *qoff, uint64_t m,
@@ -136,7 +141,7 @@ private:
     int host_pipeline(int kind, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a, uint64_t *out_b,
                       uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total,
                       const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits, bool packed = false,
-                      uint64_t uniform_len = 0) const;
+                      uint64_t uniform_len = 0, Narrow32Sink *narrow = nullptr) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
     void build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream);
@@ -277,6 +282,16 @@ uint64_t pack_queries_with_table(const uint8_t *io_to_dense, const uint8_t *qbuf
                                  uint8_t *out_packed, uint64_t *out_exc, uint64_t capacity);
 // gdx_free_hits: the array goes back to the library, which keeps one for the next gdx_locate_many_alloc (host_api.hip)
 void recycle_hits(gdx_hit_t *hits);
+void recycle_hits32(gdx_hits32_t *results);  // gdx_free_hits32: the pinned arrays go back to the library
+void release_cached_hits();                  // gdx_release_cached_hits
+// where the narrow host locate (FmIndex::locate_many_alloc32) puts its results: pinned arrays the device copies into
+struct Narrow32Sink {
+    uint32_t *offsets = nullptr;  // nq + 1
+    gdx_hit32_t *hits = nullptr;
+    uint64_t cap = 0;             // hits the array holds
+    // a larger array holding the first `keep` hits of the old one (called with no copy into the old one on its way)
+    std::function<gdx_hit32_t *(uint64_t need, uint64_t keep, uint64_t *new_cap)> grow;
+};
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
 void set_host_chunking(uint64_t queries, uint64_t bytes);
 

@@ -267,7 +267,26 @@ void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, Worke
     if (qoff[nq] > qoff[0] && !qbuf) fail(GDX_ERR_INVALID_ARGUMENT, "qbuf is null");
 }
 
-enum class Kind { kIntervals, kCounts, kLocate };
+enum class Kind { kIntervals, kCounts, kLocate, kLocate32 };
+
+// every slot's u32 offsets (entries 1 .. n of a chunk) shifted by the hits of the chunks before it
+__global__ __launch_bounds__(256) void add_hit_base_kernel(uint32_t *__restrict__ off, uint64_t n, uint32_t base)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; i < n; i += stride) off[i] += base;
+}
+
+// true: `p` is host memory the device can copy from directly (hipHostMalloc / hipHostRegister): no staging copy
+bool is_pinned_host(const void *p)
+{
+    if (p == nullptr) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();  // (ordinary pageable memory: not an error of the call)
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
 
 struct Chunk {
     uint64_t q0 = 0, nq = 0, bytes = 0, total = 0, hit_base = 0;
@@ -281,7 +300,7 @@ struct Chunk {
 int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_a,
                            uint64_t *out_b, uint8_t *out_status, gdx_hit_t *hits, uint64_t hits_capacity,
                            uint64_t *out_total, const std::function<gdx_hit_t *(uint64_t, uint64_t *)> *grow_hits,
-                           bool packed, uint64_t uniform_len) const
+                           bool packed, uint64_t uniform_len, Narrow32Sink *narrow) const
 {
     // packed: qbuf holds 2-bit codes (symbol j in bits 2 (j & 3) of byte j >> 2) and qoff counts symbols
     // uniform_len != 0: query i = symbols [i * uniform_len, (i + 1) * uniform_len) of the buffer, qoff is not looked at: no
@@ -293,6 +312,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     auto off_of = [&](uint64_t i) { return uniform ? i * uniform_len : qoff[i]; };
     if (out_total) *out_total = 0;
     if (kind == Kind::kLocate && out_a) out_a[0] = 0;
+    if (kind == Kind::kLocate32 && narrow != nullptr && narrow->offsets != nullptr) narrow->offsets[0] = 0;
     if (nq == 0) return GDX_OK;
     make_current();
     const int dev = cfg_.device_id;
@@ -300,7 +320,8 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     Streams st;
 
     // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
-    const uint64_t kChunkBytes = g_chunk_bytes.load(), kChunkQueries = g_chunk_queries.load();
+    // (the narrow locate runs a whole fused step per chunk, a dozen launches: twice the queries per chunk)
+    const uint64_t kChunkBytes = g_chunk_bytes.load(), kChunkQueries = g_chunk_queries.load() * (kind == Kind::kLocate32 ? 2 : 1);
     std::vector<Chunk> chunks;
     // (uniform: every chunk but the last holds a multiple of 8 queries, so that a chunk starts on a 16-bit unit of a packed
     // buffer and on a byte of an ASCII one, and is a uniform batch of its own)
@@ -352,6 +373,26 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         d_off[s] = kind == Kind::kLocate ? device_buf<uint64_t>(dev, s * 16 + 6, max_nq + 1) : nullptr;
         d_scan[s] = kind == Kind::kLocate ? device_buf<uint8_t>(dev, s * 16 + 7, scan_bytes ? scan_bytes : 1) : nullptr;
     }
+    // narrow locate (Kind::kLocate32): every chunk is one fused step (launch_locate_step) into device buffers sized for the
+    // chunk's queries and a margin; its u32 offsets and 8-byte hits go by D2H copy straight into the caller-visible pinned
+    // arrays of the sink -- no host thread touches them
+    uint32_t *d_cmp[kSlots] = {}, *d_off32[kSlots] = {};
+    unsigned long long *d_tot[kSlots] = {};
+    uint64_t n32_cap = 0;  // hit slots a chunk's device buffers hold
+    const bool pinned_input = is_pinned_host(qbuf);
+    if (kind == Kind::kLocate32) {
+        if (narrow == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the narrow locate needs its sink");
+        n32_cap = max_nq + max_nq / 4 + 4096;
+        const size_t tws = scan_totals_workspace_bytes(max_nq);
+        for (int s = 0; s < kSlots; s++) {
+            d_rec[s] = device_buf<uint4>(dev, s * 16 + 5, max_nq);
+            d_cmp[s] = device_buf<uint32_t>(dev, s * 16 + 11, max_nq);
+            d_off32[s] = device_buf<uint32_t>(dev, s * 16 + 12, max_nq + 1);
+            d_tot[s] = device_buf<unsigned long long>(dev, s * 16 + 13, 2);
+            d_scan[s] = device_buf<uint8_t>(dev, s * 16 + 7, tws ? tws : 1);
+            h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 2);
+        }
+    }
     uint64_t *h_off[kSlots] = {};  // locate: the chunk's hit offsets (h_off[i] = hits of its queries before query i)
     if (kind == Kind::kLocate)
         for (int s = 0; s < kSlots; s++) h_off[s] = pinned_buf<uint64_t>(dev, s * 16 + 10, max_nq + 1);
@@ -376,14 +417,20 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         const uint64_t base = packed ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
         const uint64_t src_byte = packed ? base / 4 : base;
         const uint64_t n_bytes = packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
-        pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
+        if (!pinned_input)
+            pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
         if (!uniform)
             pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
             });
         const uint64_t padded = div_ceil(n_bytes + 2, 8) * 8;
-        std::memset(h_in[s] + n_bytes, 0, padded - n_bytes);  // windows may read past the last query
-        GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
+        if (pinned_input) {  // the caller's buffer is pinned: the device reads it as it is, no staging copy
+            if (n_bytes) GDX_HIP(hipMemcpyAsync(d_qbuf[s], qbuf + src_byte, n_bytes, hipMemcpyHostToDevice, st.in));
+            GDX_HIP(hipMemsetAsync(d_qbuf[s] + n_bytes, 0, padded - n_bytes, st.in));  // windows may read past the last query
+        } else {
+            std::memset(h_in[s] + n_bytes, 0, padded - n_bytes);
+            GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
+        }
         if (!uniform) GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
         GDX_HIP(hipEventRecord(st.ev_in[s], st.in));
         GDX_HIP(hipStreamWaitEvent(st.k, st.ev_in[s], 0));
@@ -397,6 +444,27 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         }
         call.nq = c.nq;
         call.packed = packed;
+        if (kind == Kind::kLocate32) {
+            LocateStep step;
+            step.call = call;
+            step.call.d_rec = d_rec[s];
+            step.call.d_compact = d_cmp[s];
+            step.max_hits = qo.max_hits_per_query;
+            step.take = true;  // locate(q).take(k)
+            step.d_scan_workspace = d_scan[s];
+            step.d_totals = d_tot[s];
+            step.d_hit_offsets = d_off32[s];
+            step.narrow = true;
+            step.d_hits = d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, n32_cap * sizeof(gdx_hit32_t));
+            step.hits_capacity = n32_cap;
+            step.d_workspace = d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(n32_cap));
+            launch_locate_step(view_, step, st.k, qo);
+            GDX_HIP(hipGetLastError());
+            launch_unpack_records(d_rec[s], c.nq, nullptr, d_status[s], st.k, d_cmp[s]);
+            GDX_HIP(hipMemcpyAsync(h_total[s], d_tot[s], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
+            GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
+            return;
+        }
         if (kind == Kind::kIntervals) {
             call.d_start = d_a[s];
             call.d_end = d_b[s];
@@ -424,9 +492,41 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         }
     };
 
+    uint64_t mid_hit_base = 0;  // narrow locate: hits of the chunks whose copies out are enqueued
     auto stage_mid = [&](size_t k) {  // locate: the chunk's total is known -> locate, then all D2H; else just D2H
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
+        if (kind == Kind::kLocate32) {
+            GDX_HIP(hipEventSynchronize(st.ev_total[s]));
+            c.total = h_total[s][0];
+            const uint64_t rest = h_total[s][1];
+            if (mid_hit_base + c.total >= (1ull << 32))
+                fail(GDX_ERR_CAPACITY, "more than 2^32 - 1 hits: 32-bit hit offsets do not hold them (gdx_locate_many_alloc_layout does)");
+            if (c.total > n32_cap) {  // rare: more hits than the chunk's buffers were sized for -- the second half again, with room
+                d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, c.total * sizeof(gdx_hit32_t));
+                d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
+                launch_offsets_hits(view_, d_rec[s], d_cmp[s], c.nq, qo.max_hits_per_query, true, d_scan[s], d_off32[s], true, c.total, rest,
+                                    d_hits[s], d_ws[s], st.k, qo);
+                GDX_HIP(hipGetLastError());
+            }
+            if (mid_hit_base + c.total > narrow->cap) {  // the pinned hit array moves: nothing may be on its way into the old one
+                GDX_HIP(hipStreamSynchronize(st.out));
+                narrow->hits = narrow->grow(mid_hit_base + c.total, mid_hit_base, &narrow->cap);
+            }
+            if (mid_hit_base != 0)
+                hipLaunchKernelGGL(add_hit_base_kernel, dim3(static_cast<unsigned>(std::min<uint64_t>((c.nq + 255) / 256, 2048))), dim3(256),
+                                   0, st.k, d_off32[s] + 1, c.nq, static_cast<uint32_t>(mid_hit_base));
+            GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
+            GDX_HIP(hipStreamWaitEvent(st.out, st.ev_k[s], 0));
+            GDX_HIP(hipMemcpyAsync(narrow->offsets + c.q0 + 1, d_off32[s] + 1, c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
+            GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
+            if (c.total)
+                GDX_HIP(hipMemcpyAsync(narrow->hits + mid_hit_base, d_hits[s], c.total * sizeof(gdx_hit32_t), hipMemcpyDeviceToHost, st.out));
+            GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
+            c.hit_base = mid_hit_base;
+            mid_hit_base += c.total;
+            return;
+        }
         if (kind == Kind::kLocate) {
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = *h_total[s];
@@ -459,7 +559,9 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         GDX_HIP(hipEventSynchronize(st.ev_out[s]));
         const uint32_t *a = h_a[s], *b = h_b[s];
         const uint8_t *stt = h_status[s];
-        if (kind == Kind::kLocate) {
+        if (kind == Kind::kLocate32) {
+            // (offsets and hits are where they belong already)
+        } else if (kind == Kind::kLocate) {
             c.hit_base = hit_base;
             if (out_a) {  // the chunk's offsets (scanned on the device) shifted by the hits of the chunks before it
                 const uint64_t *off = h_off[s];
@@ -610,6 +712,11 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         std::rethrow_exception(worker_error);
     }
     GDX_HIP(hipStreamSynchronize(st.out));
+    if (kind == Kind::kLocate32) {
+        narrow->offsets[0] = 0;
+        if (out_total) *out_total = mid_hit_base;
+        return any_status.load() ? GDX_ERR_QUERY_STATUS : GDX_OK;
+    }
     if (out_total) *out_total = hit_base;
     if (kind == Kind::kLocate && hit_base > 0 && !capacity_ok) return GDX_ERR_CAPACITY;
     return any_status.load() ? GDX_ERR_QUERY_STATUS : GDX_OK;
@@ -715,7 +822,8 @@ void recycle_hits(gdx_hit_t *hits)
 static void *take_cached_hits(size_t bytes, size_t *got)
 {
     std::lock_guard<std::mutex> g(g_hits_mutex);
-    if (g_hits_cached == nullptr || g_hits_cached_bytes < bytes) return nullptr;
+    // (only for a request of at least half its size: a ten-query call must not walk away with gigabytes)
+    if (g_hits_cached == nullptr || g_hits_cached_bytes < bytes || g_hits_cached_bytes / 2 > bytes) return nullptr;
     void *p = g_hits_cached;
     *got = g_hits_cached_bytes;
     g_hits_cached = nullptr;
@@ -768,6 +876,130 @@ int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64
     }
     *out_hits = buf;
     return rc;
+}
+
+// ---- narrow results in library-owned pinned memory (gdx_locate_many_alloc_layout32) ---------------------------------------
+// The device writes u32 offsets and 8-byte hits into these arrays by D2H copy; the caller reads them where they are.  Pinning
+// host memory costs about a millisecond per 10 MB, so the arrays a caller gives back (gdx_free_hits32) are kept for its next
+// call -- one pair, the largest seen -- until gdx_release_cached_hits.
+namespace {
+struct PinnedBlock {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_pinned_mutex;
+PinnedBlock g_pinned_cache[2];  // [0] offsets, [1] hits
+
+void *pinned_take(int which, size_t bytes, size_t *got)
+{
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mutex);
+        PinnedBlock &b = g_pinned_cache[which];
+        if (b.ptr != nullptr && b.bytes >= bytes) {
+            void *p = b.ptr;
+            *got = b.bytes;
+            b = PinnedBlock{};
+            return p;
+        }
+    }
+    void *p = nullptr;
+    GDX_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    *got = bytes;
+    return p;
+}
+
+void pinned_give(int which, void *ptr, size_t bytes)
+{
+    if (ptr == nullptr) return;
+    void *drop = ptr;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mutex);
+        PinnedBlock &b = g_pinned_cache[which];
+        if (bytes > b.bytes) {
+            drop = b.ptr;
+            b.ptr = ptr;
+            b.bytes = bytes;
+        }
+    }
+    if (drop != nullptr) (void)hipHostFree(drop);
+}
+}  // namespace
+
+int FmIndex::locate_many_alloc32(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, gdx_hits32_t *out, uint8_t *out_status,
+                                 bool packed, uint64_t uniform_len) const
+{
+    if (packed && (view_.layout != 0 || view_.n_searchable < 4))
+        fail(GDX_ERR_UNSUPPORTED, "packed queries need the rank-line layout (sigma <= 8) with dense symbols 1..4 searchable");
+    if (!out) fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+    std::memset(out, 0, sizeof(*out));
+    make_current();
+    size_t off_bytes = 0, hit_bytes = 0;
+    Narrow32Sink sink;
+    sink.offsets = static_cast<uint32_t *>(pinned_take(0, (nq + 1) * sizeof(uint32_t) + 64, &off_bytes));
+    try {
+        // a first guess from the batch size spares most reallocations (one hit per query is the common shape)
+        sink.hits = static_cast<gdx_hit32_t *>(pinned_take(1, (nq + nq / 8 + 4096) * sizeof(gdx_hit32_t), &hit_bytes));
+    } catch (...) {
+        pinned_give(0, sink.offsets, off_bytes);
+        throw;
+    }
+    sink.cap = hit_bytes / sizeof(gdx_hit32_t);
+    sink.grow = [&](uint64_t need, uint64_t keep, uint64_t *new_cap) {
+        size_t bytes = 0;
+        gdx_hit32_t *p = static_cast<gdx_hit32_t *>(pinned_take(1, std::max<uint64_t>(need, sink.cap + sink.cap / 2) * sizeof(gdx_hit32_t), &bytes));
+        std::memcpy(p, sink.hits, keep * sizeof(gdx_hit32_t));
+        pinned_give(1, sink.hits, hit_bytes);
+        hit_bytes = bytes;
+        *new_cap = bytes / sizeof(gdx_hit32_t);
+        return p;
+    };
+    uint64_t total = 0;
+    int rc;
+    try {
+        rc = host_pipeline(static_cast<int>(Kind::kLocate32), qbuf, qoff, nq, nullptr, nullptr, out_status, nullptr, 0, &total, nullptr,
+                           packed, uniform_len, &sink);
+    } catch (...) {
+        (void)hipDeviceSynchronize();
+        pinned_give(0, sink.offsets, off_bytes);
+        pinned_give(1, sink.hits, hit_bytes);
+        throw;
+    }
+    out->hit_offsets = sink.offsets;
+    out->hits = sink.hits;
+    out->total_hits = total;
+    out->nq = nq;
+    out->reserved[0] = off_bytes;
+    out->reserved[1] = hit_bytes;
+    return rc;
+}
+
+void recycle_hits32(gdx_hits32_t *r)
+{
+    if (!r) return;
+    pinned_give(0, r->hit_offsets, r->reserved[0]);
+    pinned_give(1, r->hits, r->reserved[1]);
+    std::memset(r, 0, sizeof(*r));
+}
+
+void release_cached_hits()
+{
+    void *drop[3] = {nullptr, nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mutex);
+        for (int i = 0; i < 2; i++) {
+            drop[i] = g_pinned_cache[i].ptr;
+            g_pinned_cache[i] = PinnedBlock{};
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(g_hits_mutex);
+        drop[2] = g_hits_cached;
+        g_hits_cached = nullptr;
+        g_hits_cached_bytes = 0;
+    }
+    if (drop[0]) (void)hipHostFree(drop[0]);
+    if (drop[1]) (void)hipHostFree(drop[1]);
+    std::free(drop[2]);
 }
 
 }  // namespace gdx

@@ -17,7 +17,7 @@ struct QueryOptions {
     int search_lanes = 0;      // 0 default (4), 4 or 8 lanes per query in the pair kernels
     int load_policy = -1;      // -1 default (0 plain), 1 sc1
     int length_schedule = -1;  // -1 default (1: blocks order spread-out ranges by length), 0 off
-    int locate_variant = -1;   // -1 default (0 queue), 1 one lane per hit, 2 eight lanes per hit on pair lines
+    int locate_variant = -1;   // (ignored: the lock-step locate variants of rounds 1-4 are gone, the chunk kernels remain)
     int locate_jump_walk = -1; // -1 default (1: the queue kernel walks through the jump table), 0 rank lines only
     int search_fast = -1;         // count / locate searches run the fast-path kernel first (1; 2 = with 16-row jumps) or not (0); -1 = per index
     int search_defer_after = -1;  // -1 default (3): load rounds beyond its allowance after which a query is parked and
@@ -177,7 +177,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats = nullptr,
                    const uint2 *d_hint = nullptr, const QueryOptions &qo = QueryOptions(),
-                   const uint4 *d_rec = nullptr, bool reference_walk = false, bool skip_single = false,
+                   const uint4 *d_rec = nullptr, bool reference_walk = false,
                    const uint32_t *d_compact = nullptr, bool compact_stored = false, const uint8_t *d_chunk_flags = nullptr,
                    bool narrow_offsets = false,  // d_hit_offsets is u32[m + 1] (records path only)
                    const unsigned long long *d_total = nullptr);  // != null: the number of hit slots is read on the device (no host
@@ -197,19 +197,32 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
                                bool entry_sa = false,  // locate_entry_sa(ix, qo): the pass may locate small "see the record" queries itself
                                const unsigned long long *d_totals = nullptr);  // != null: ... only if the totals say they are few
 bool locate_entry_sa(const IndexView &ix, const QueryOptions &qo);
+// The whole count + locate step of a batch, enqueued without a host round trip (gdx_locate_many_step_compact_layout_dev, and
+// every chunk of the host-pointer call gdx_locate_many_alloc_layout32): search (+ hit totals), offsets scan + the hits the
+// compact results answer, the rest from the records.  call: the query side, d_rec and (optionally) d_compact, mode 1.
+struct LocateStep {
+    SearchCall call;
+    uint32_t max_hits = 0;
+    bool take = false;  // max_hits: the first max_hits rows of a query (locate(q).take(k)) instead of none
+    void *d_scan_workspace = nullptr;          // scan_totals_workspace_bytes(nq)
+    unsigned long long *d_totals = nullptr;    // u64[2]: all hit slots, those behind "see the record"
+    void *d_hit_offsets = nullptr;             // u64[nq + 1], or u32[nq + 1] with narrow
+    bool narrow = false;
+    void *d_hits = nullptr;                    // gdx_hit32_t[hits_capacity]; what lies beyond is not stored
+    uint64_t hits_capacity = 0;
+    void *d_workspace = nullptr;               // locate_workspace_bytes(hits_capacity)
+    hipEvent_t event_after_search = nullptr;   // recorded between the two halves
+};
+void launch_locate_step(const IndexView &ix, const LocateStep &step, hipStream_t stream, const QueryOptions &qo);
+// the second half of a step whose totals the host has read (gdx_locate_many_offsets_hits_compact_dev): offsets + the hits the
+// compact results answer in one pass, then the rest_hits slots behind "see the record" from the records
+void launch_offsets_hits(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t nq, uint32_t max_hits, bool take,
+                         const void *d_scan_workspace, void *d_hit_offsets, bool narrow, uint64_t total_hits, uint64_t rest_hits,
+                         void *d_hits, void *d_workspace, hipStream_t stream, const QueryOptions &qo);
 size_t locate_chunk_flags_bytes(uint64_t total_hits);
 // store == false: offsets only.  d_chunk_flags (inside the locate workspace at locate_chunk_flags_offset(total_hits), filled by
 // the store pass): launch_locate then only visits the chunks of hit slots in which that pass left something open
 size_t locate_chunk_flags_offset(uint64_t total_hits);
-// One pass over the search records (locate.hip scan_locate_kernel): the hit offsets (what launch_hit_offsets_rec
-// computes) and, in the same pass, the hit of every query with exactly one hit slot -- resolved records need nothing,
-// others one fetch of SA[row] when the index has it.  d_totals (u64[2]): [0] = all hit slots, [1] = the slots left to
-// launch_locate(..., skip_single = true): queries with several hits, and single hits that need a walk.  Hits at or beyond
-// hits_capacity are not stored.
-size_t scan_locate_workspace_bytes(uint64_t m);
-void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uint32_t max_hits, bool take,
-                        uint64_t *d_hit_offsets, void *d_hits, uint64_t hits_capacity, bool wide, void *d_workspace,
-                        unsigned long long *d_totals, hipStream_t stream);
 // reference_walk: walk one LF step at a time (sampled_suffix_array.rs:118-131) so that the steps counted through
 // d_step_stats are the reference's
 // d_rec != null: start / hint come from the search records instead of d_start / d_hint (d_start, d_end unused)

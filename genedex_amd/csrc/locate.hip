@@ -57,38 +57,6 @@ struct RecordSize {
 using RecordSizeIterator =
     rocprim::transform_iterator<rocprim::counting_iterator<uint64_t>, RecordSize, uint64_t>;
 
-__global__ __launch_bounds__(kBlock) void mark_heads_kernel(const uint32_t *__restrict__ start,
-                                                            const uint32_t *__restrict__ end, uint64_t m,
-                                                            const uint64_t *__restrict__ hit_offsets,
-                                                            uint32_t *__restrict__ heads)
-{
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < m; q += stride) {
-        if (end[q] != start[q]) heads[hit_offsets[q]] = static_cast<uint32_t>(q) + 1u;
-    }
-}
-
-// sampled_suffix_array.rs:110-138 for one suffix-array index: concatenated-text position of SA[i]
-template <class Table>
-__device__ __forceinline__ uint32_t walk_to_sample(const IndexView &ix, const uint32_t *s_count, uint32_t i,
-                                                   uint32_t &steps)
-{
-    steps = 0;
-    for (;;) {
-        // :118 while i % sampling_rate != 0
-        uint32_t slot;
-        if (sampled_slot(ix, i, slot)) return ix.sa_samples[slot] + steps;  // :133-136
-        uint32_t r;
-        const uint32_t c = Table::symbol_and_rank(ix, i, r);
-        if (c == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
-            const uint32_t b = lower_bound_u32(ix.border_keys, ix.n_texts, i);
-            return ix.border_vals[b] + steps;
-        }
-        i = s_count[c] + r;  // lf_mapping_step lib.rs:273-275
-        steps++;
-    }
-}
-
 // text_id_search_tree.rs:35-64: smallest t with pos <= sentinel_indices[t], position inside that text
 // `sentinels` is either the global array or the block's copy of it in LDS (locate_queue_kernel, few texts)
 template <bool kWide>
@@ -109,29 +77,6 @@ __device__ __forceinline__ void store_hit(const IndexView &ix, uint32_t pos, voi
         out.position = in_text;
         static_cast<gdx_hit32_t *>(hits_out)[at] = out;
     }
-}
-
-template <class Table, bool kWide>
-__global__ __launch_bounds__(kBlock) void locate_kernel(IndexView ix, const uint32_t *__restrict__ start,
-                                                        const uint64_t *__restrict__ hit_offsets,
-                                                        const uint32_t *__restrict__ query_of_hit,
-                                                        uint64_t total, void *__restrict__ hits_out,
-                                                        unsigned long long *__restrict__ step_stats)
-{
-    __shared__ uint32_t s_count[257];
-    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    __syncthreads();
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    uint32_t walk_steps = 0;  // only reported through step_stats (bench accounting)
-    for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; h < total; h += stride) {
-        const uint32_t q = query_of_hit[h] - 1u;
-        const uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);  // SA index of this hit
-        uint32_t steps;
-        const uint32_t pos = walk_to_sample<Table>(ix, s_count, i, steps);
-        walk_steps += steps;
-        store_hit<kWide>(ix, pos, hits_out, h);
-    }
-    if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
 // hit offsets as the queue kernel reads them: u64[m + 1], or u32[m + 1] when the caller asked for narrow offsets (fewer
@@ -221,18 +166,24 @@ __device__ __forceinline__ void store_hit_tab(const uint32_t *s_tab, uint32_t sh
 // spends around that (a 256-thread max-scan of 16 barriers per chunk, three dependent loads per slot, a five-step LDS search)
 // was most of its time: 573 M hits of a text of repeats took 3.3 ms at 0.26 of the HBM peak.  Same chunks, same slot -> query
 // map by head marks; here the marks carry the head's slot, so that a slot knows its number inside its query without
-// reading the offsets again, the scan is a wavefront scan with four barriers per chunk, the loads of four slots are issued
-// together, and text ids come from the coarse table.  Consecutive slots of one query are consecutive rows: their SA loads
+// reading the offsets again, the scan is a wavefront scan with four barriers per chunk, a thread's eight loads of a kind are
+// issued together, and text ids come from the coarse table.  Consecutive slots of one query are consecutive rows: their SA loads
 // and hit stores are coalesced, their record loads one broadcast.
 struct StreamView {
     const uint32_t *sa_full, *jump32;  // SA[row], or word 6 of the 32-byte jump entry of the row
     const uint32_t *sentinels;
     uint32_t n_texts, tab_shift;
-    uint32_t skip_single;  // LocateView::skip_single
+    uint32_t skip_single;  // 2: the hits the compact results answer are in place already (launch_scan_offsets_store)
 };
 
+// what a slot needs to know of its query, made once per query and chunk (from its offsets, compact result and record) and
+// kept in LDS for the chunk's first kStreamDesc queries -- a query of many slots costs its record ONE load, and the slots
+// have nothing to wait for but their SA value
+constexpr uint32_t kStreamDesc = 512;
+constexpr uint32_t kDescSkip = 0, kDescPos = 1, kDescRows = 2, kDescMask = 3, kDescRow = 4;
+
 template <bool kWide>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void locate_stream_kernel(
+__global__ __launch_bounds__(kBlock) void locate_stream_kernel(
     StreamView sv, const uint32_t *__restrict__ start, HitOffsets hit_offsets, uint64_t m, const uint32_t *__restrict__ first_query,
     const uint2 *__restrict__ hint, const uint4 *__restrict__ rec, uint64_t total, void *__restrict__ hits_out,
     const uint32_t *__restrict__ compact, const uint8_t *__restrict__ chunk_flags, const unsigned long long *__restrict__ d_total)
@@ -251,6 +202,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     constexpr uint32_t kPer = kLocateChunk / kBlock;  // slots per thread
     constexpr uint32_t kLdsTexts = 256;
     __shared__ uint32_t s_map[kLocateChunk];  // (query of the slot, relative to the chunk's first, + 1) << 11 | the slot of its head
+    __shared__ uint4 s_desc[kStreamDesc];
     __shared__ uint32_t s_tab[kTextTab + 1];
     __shared__ uint32_t s_sentinels[kLdsTexts];
     __shared__ uint32_t s_wave[kBlock / 64];
@@ -263,22 +215,78 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     }
     build_text_table(s_tab, sentinels, sv.n_texts, sv.tab_shift);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // {a, mask, symbols to subtract, kind} of query q with `n_slots` hit slots (a: the position, the first row, or the row)
+    auto describe = [&](uint64_t q, uint64_t n_slots) __attribute__((always_inline)) -> uint4 {
+        const uint32_t c4 = compact != nullptr ? compact[q] : kCompactSee;
+        if (c4 < kCompactSee)  // the position itself (skip_single 2: launch_scan_offsets_store has stored it)
+            return make_uint4(c4, 0u, 0u, sv.skip_single == 2u ? kDescSkip : kDescPos);
+        if (rec != nullptr) {
+            const uint4 r = rec[q];
+            if (r.w & kRecResolved) return make_uint4(r.z, 0u, 0u, kDescPos);  // the search already knows the text position
+            if (r.w & kRecMasked) return make_uint4(r.x, r.z, r.w & 0x1fffffu, kDescMask);  // the rows of the mask, `symbols` steps before the hits
+            if (r.z != 0xffffffffu && r.y - r.x == 1u) return make_uint4(r.z, 0u, r.w & 0xffffffu, kDescRow);  // a hinted row
+            return make_uint4(r.x, 0u, 0u, kDescRows);
+        }
+        if (hint != nullptr && n_slots == 1u) {
+            const uint2 hv = hint[q];
+            if (hv.x != 0xffffffffu && hv.y < (1u << 21)) return make_uint4(hv.x, 0u, hv.y, kDescRow);
+        }
+        return make_uint4(start[q], 0u, 0u, kDescRows);
+    };
+    // a block's time is a chain of memory latencies with barriers in between -- the chunk's queries, their offsets / compact
+    // results / records, the SA values -- so the chain is kept short: the next chunk's flag and queries are on their way
+    // while this one is worked on, and a query's offsets, compact result and record are loaded together, not one after the
+    // answer of the other (describe() reads them in turn: the rare slot beyond the descriptors takes that way)
+    uint32_t n_flag = 1, n_qa = 0, n_qb = 0;
+    auto prefetch_chunk = [&](uint64_t ch) __attribute__((always_inline)) {
+        if (ch < n_chunks) {
+            n_flag = chunk_flags != nullptr ? chunk_flags[ch] : 1u;
+            n_qa = first_query[ch];
+            n_qb = first_query[ch + 1];
+        }
+    };
+    prefetch_chunk(blockIdx.x);
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (chunk_flags != nullptr && chunk_flags[chunk] == 0) continue;  // (block-uniform)
+        const uint32_t flag = n_flag, qa = n_qa, qb = n_qb;
+        prefetch_chunk(chunk + gridDim.x);
+        if (flag == 0u) continue;  // (block-uniform; an unflagged chunk's queries were never computed)
         const uint64_t base = chunk * kLocateChunk;
         const uint32_t cnt = total - base < kLocateChunk ? static_cast<uint32_t>(total - base) : kLocateChunk;
-        const uint32_t qa = first_query[chunk], qb = first_query[chunk + 1];
-        __syncthreads();  // the previous chunk's map is read, the table is built
+        __syncthreads();  // the previous chunk's map and descriptors are read, the table is built
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j += 4)
             *reinterpret_cast<uint4 *>(&s_map[threadIdx.x * kPer + j]) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         for (uint64_t q = static_cast<uint64_t>(qa) + threadIdx.x; q <= qb; q += kBlock) {
             const uint64_t a = hit_offsets[q], b = hit_offsets[q + 1];
+            const bool wants = q - qa < kStreamDesc;
+            const uint32_t c4 = (wants && compact != nullptr) ? compact[q] : kCompactSee;
+            uint4 r = make_uint4(0u, 0u, 0xffffffffu, 0u);
+            uint2 hv = make_uint2(0xffffffffu, 0u);
+            if (wants) {
+                if (rec != nullptr) r = rec[q];
+                else r.x = start[q];
+                if (rec == nullptr && hint != nullptr) hv = hint[q];
+            }
             const uint64_t from = a > base ? a : base;
             if (b > from && from < base + cnt) {
                 s_map[from - base] = ((static_cast<uint32_t>(q - qa) + 1u) << 11) | static_cast<uint32_t>(from - base);
                 if (q == qa) s_carry = static_cast<uint32_t>(from - a);  // (the owner of slot `base`: always has slots here)
+                if (wants) {  // describe(q, b - a) on what has been loaded
+                    uint4 d;
+                    if (c4 < kCompactSee) d = make_uint4(c4, 0u, 0u, sv.skip_single == 2u ? kDescSkip : kDescPos);
+                    else if (rec != nullptr) {
+                        if (r.w & kRecResolved) d = make_uint4(r.z, 0u, 0u, kDescPos);
+                        else if (r.w & kRecMasked) d = make_uint4(r.x, r.z, r.w & 0x1fffffu, kDescMask);
+                        else if (r.z != 0xffffffffu && r.y - r.x == 1u) d = make_uint4(r.z, 0u, r.w & 0xffffffu, kDescRow);
+                        else d = make_uint4(r.x, 0u, 0u, kDescRows);
+                    } else if (hint != nullptr && b - a == 1u && hv.x != 0xffffffffu && hv.y < (1u << 21)) {
+                        d = make_uint4(hv.x, 0u, hv.y, kDescRow);
+                    } else {
+                        d = make_uint4(r.x, 0u, 0u, kDescRows);
+                    }
+                    s_desc[q - qa] = d;
+                }
             }
         }
         __syncthreads();
@@ -310,78 +318,52 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         }
         __syncthreads();
         const uint32_t carry = s_carry;
-        // four slots at a time, a stage for all four before the next: map -> compact result -> record -> SA -> hit
+        // the thread's eight slots (strided: the slots of a wavefront's instruction are neighbours): descriptor -> row, then the
+        // eight SA loads together, then the stores
+        uint32_t row[kPer], val[kPer];  // val: the position, or the symbols to subtract from SA[row]
+        uint32_t live = 0, need_sa = 0;
 #pragma unroll
-        for (uint32_t half = 0; half < kPer; half += 4) {
-            uint32_t q[4], within[4], c4[4], pos[4];
-            bool live[4], need_sa[4];
-            uint4 r[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t i = threadIdx.x + (half + j) * kBlock;
-                live[j] = i < cnt;
-                const uint32_t p = live[j] ? s_map[i] : (1u << 11);
-                const uint32_t qrel = p >> 11;
-                q[j] = qa + qrel - 1u;
-                within[j] = i - (p & 2047u) + (qrel == 1u ? carry : 0u);
-                c4[j] = (live[j] && compact != nullptr) ? compact[q[j]] : kCompactSee;
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t i = threadIdx.x + j * kBlock;
+            row[j] = 0;
+            val[j] = 0;
+            if (i >= cnt) continue;
+            const uint32_t p = s_map[i];
+            const uint32_t qrel = (p >> 11) - 1u;
+            const uint32_t within = i - (p & 2047u) + (qrel == 0u ? carry : 0u);
+            uint4 d;
+            if (qrel < kStreamDesc) {
+                d = s_desc[qrel];
+            } else {  // (a chunk of more queries than the block keeps descriptors for: single hits mostly)
+                const uint64_t q = static_cast<uint64_t>(qa) + qrel;
+                d = describe(q, hit_offsets[q + 1] - hit_offsets[q]);
             }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                need_sa[j] = false;
-                pos[j] = 0;
-                if (!live[j]) continue;
-                if (c4[j] < kCompactSee) {  // the position itself (skip_single 2: launch_scan_offsets_store has stored it)
-                    pos[j] = c4[j];
-                    live[j] = sv.skip_single != 2u;
-                    continue;
-                }
-                if (rec != nullptr) r[j] = rec[q[j]];
-                else r[j] = make_uint4(start[q[j]], 0u, 0xffffffffu, 0u);
+            if (d.w == kDescSkip) continue;
+            live |= 1u << j;
+            if (d.w == kDescPos) {
+                val[j] = d.x;
+                continue;
             }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                if (!live[j] || c4[j] < kCompactSee) continue;
-                if (sv.skip_single == 1u && hit_offsets[q[j] + 1] - hit_offsets[q[j]] == 1u) {  // in place already (scan_locate_kernel)
-                    live[j] = false;
-                    continue;
-                }
-                uint32_t row = r[j].x + within[j], back = 0;
-                if (rec != nullptr) {
-                    if (r[j].w & kRecResolved) {  // the search already knows the text position
-                        pos[j] = r[j].z;
-                        continue;
-                    }
-                    if (r[j].w & kRecMasked) {  // the within-th surviving row of the mask, `symbols` steps before the hit
-                        uint32_t mk = r[j].z;
-                        for (uint32_t t = within[j]; t > 0u; t--) mk &= mk - 1u;
-                        row = r[j].x + static_cast<uint32_t>(__builtin_ctz(mk | 0x80000000u));
-                        back = r[j].w & 0x1fffffu;
-                    } else if (r[j].z != 0xffffffffu && r[j].y - r[j].x == 1u) {
-                        row = r[j].z;
-                        back = r[j].w & 0xffffffu;
-                    }
-                } else if (hint != nullptr && hit_offsets[q[j] + 1] - hit_offsets[q[j]] == 1u) {
-                    const uint2 hv = hint[q[j]];
-                    if (hv.x != 0xffffffffu && hv.y < (1u << 21)) {
-                        row = hv.x;
-                        back = hv.y;
-                    }
-                }
-                need_sa[j] = true;
-                pos[j] = back;
-                r[j].x = row;
+            need_sa |= 1u << j;
+            val[j] = d.z;
+            row[j] = d.x;
+            if (d.w == kDescRows) {
+                row[j] = d.x + within;
+            } else if (d.w == kDescMask) {  // the within-th surviving row of the mask
+                uint32_t mk = d.y;
+                for (uint32_t t = within; t > 0u; t--) mk &= mk - 1u;
+                row[j] = d.x + static_cast<uint32_t>(__builtin_ctz(mk | 0x80000000u));
             }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++)
-                if (need_sa[j]) {
-                    const uint32_t sa = sv.sa_full != nullptr ? sv.sa_full[r[j].x] : sv.jump32[static_cast<uint64_t>(r[j].x) * 8u + 6u];
-                    pos[j] = sa - pos[j];
-                }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++)
-                if (live[j]) store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, pos[j], hits_out, base + threadIdx.x + (half + j) * kBlock);
         }
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++)
+            if (need_sa & (1u << j))
+                row[j] = sv.sa_full != nullptr ? sv.sa_full[row[j]] : sv.jump32[static_cast<uint64_t>(row[j]) * 8u + 6u];
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++)
+            if (live & (1u << j))
+                store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, (need_sa & (1u << j)) ? row[j] - val[j] : val[j], hits_out,
+                                     base + threadIdx.x + j * kBlock);
     }
 }
 
@@ -410,7 +392,7 @@ struct LocateView {
     const uint32_t *count, *sa_samples, *border_keys, *border_vals, *sentinels;
     uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
     int32_t sigma, nbits;
-    uint32_t skip_single;  // 1: the hits of queries with exactly one hit slot are in place already (scan_locate_kernel)
+    uint32_t skip_single;  // 2: the hits the compact results answer are in place already (launch_scan_offsets_store)
     uint32_t g_kind, g_wpb, g_used, g_sb;  // IndexView: which of the reference's table variants layout 1 is
 };
 
@@ -540,7 +522,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint64_t h = base + i;
             const uint32_t q = qa + qrel[j] - 1u;
             const uint64_t first = hit_offsets[q];
-            if (lv.skip_single == 1u && hit_offsets[q + 1] - first == 1u) continue;
             uint32_t row;       // SA index of this hit, or the hinted row
             uint32_t back = 0;  // SA[hit row] = SA[row] - back
             if (rec != nullptr) {
@@ -660,250 +641,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (step_stats) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
 }
 
-// The same walk on pair lines, eight lanes per hit: one 128-byte fetch at row i yields bwt1[i], bwt0[i],
-// LF(i) and LF(LF(i)), i.e. TWO walk steps (the second is taken only if the first did not land on a
-// sampled row), so a hit costs ~1.7 line fetches + the sample instead of 3 + the sample at rate 4.
-template <bool kWide>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_pair_kernel(
-    IndexView ix, const uint32_t *__restrict__ start, const uint64_t *__restrict__ hit_offsets,
-    const uint32_t *__restrict__ query_of_hit, uint64_t total, void *__restrict__ hits_out,
-    unsigned long long *__restrict__ step_stats)
-{
-    constexpr int kGroup = 8;
-    __shared__ uint32_t s_count[257];
-    for (int i = threadIdx.x; i <= ix.sigma; i += kBlock) s_count[i] = ix.count[i];
-    __syncthreads();
-    const uint32_t sub = threadIdx.x & 7u;
-    const bool writer = sub == 0;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (kBlock / kGroup);
-    uint32_t walk_steps = 0;
-    for (uint64_t h = static_cast<uint64_t>(blockIdx.x) * (kBlock / kGroup) + threadIdx.x / kGroup; h < total;
-         h += stride) {
-        const uint32_t q = query_of_hit[h] - 1u;
-        uint32_t i = start[q] + static_cast<uint32_t>(h - hit_offsets[q]);
-        uint32_t steps = 0, pos;
-        for (;;) {
-            uint32_t slot;
-            if (sampled_slot(ix, i, slot)) {  // sampled_suffix_array.rs:133-136
-                pos = ix.sa_samples[slot] + steps;
-                break;
-            }
-            const u32x4 c = ix.pair_lines[(static_cast<uint64_t>(i >> kPairLineShift) << 3) + sub];
-            // the symbols of row i live in the chunk of lane (i & 63) / 8
-            const uint32_t bit = i & 7u;
-            const uint32_t mine = (((c.x >> bit) & 1u) | (((c.x >> (8u + bit)) & 1u) << 1) |
-                                   (((c.x >> (16u + bit)) & 1u) << 2) | (((c.x >> (24u + bit)) & 1u) << 3) |
-                                   (((c.y >> bit) & 1u) << 4) | (((c.y >> (8u + bit)) & 1u) << 5));
-            const uint32_t both = oct_sum(((i & 63u) >> 3) == sub ? mine : 0u);
-            const uint32_t c1 = both & 7u, c0 = both >> 3;
-            if (c1 == 0) {  // :121-126 BWT sentinel: the walk reached the start of a text
-                pos = ix.border_vals[lower_bound_u32(ix.border_keys, ix.n_texts, i)] + steps;
-                break;
-            }
-            if (c1 > 4u) {  // a symbol outside 1..4 (N): one step on the rank lines
-                uint32_t r, rdummy;
-                QuadLineTable::rank2(ix, c1, i, i, r, rdummy);
-                i = s_count[c1] + r;
-                steps++;
-                continue;
-            }
-            // LF(c1, i) and LF(c0, LF(c1, i)) from this line (layout.hpp PairTable)
-            const uint32_t f = 0xffu;
-            const uint32_t n1 = ((c1 & 1u) ? 0u : f) | (((c1 & 2u) ? 0u : f) << 8) | (((c1 & 4u) ? 0u : f) << 16);
-            const uint32_t t1 = c.x ^ n1;
-            const uint32_t m1 = t1 & (t1 >> 8) & (t1 >> 16) & 0xffu;
-            const uint32_t mask = PairTable::low_mask(i, sub);  // chunk index == lane for 8 lanes
-            const bool own1 = (sub >> 1) == (c1 - 1u);
-            const uint32_t i1 = oct_sum(__popc(m1 & mask) + (own1 ? ((c.y >> 16) << ((sub & 1u) * 16u)) : 0u));
-            const bool sampled1 = is_sampled(ix, i1);
-            if (sampled1 || c0 - 1u >= 4u) {
-                i = i1;
-                steps++;
-                continue;
-            }
-            const uint32_t pair = (c0 - 1u) * 4u + (c1 - 1u);
-            const uint32_t n0x = ((c0 & 1u) ? 0u : f) << 24;
-            const uint32_t n0y = ((c0 & 2u) ? 0u : f) | (((c0 & 4u) ? 0u : f) << 8);
-            const uint32_t t0x = c.x ^ n0x, t0y = c.y ^ n0y;
-            const uint32_t m2 = m1 & (t0x >> 24) & t0y & (t0y >> 8) & 0xffu;
-            const bool own2 = (pair >> 1) == sub;
-            i = oct_sum(__popc(m2 & mask) + (own2 ? ((pair & 1u) ? c.w : c.z) : 0u));
-            steps += 2;
-        }
-        walk_steps += steps;
-        const uint32_t t = lower_bound_u32(ix.sentinels, ix.n_texts, pos);
-        const uint32_t in_text = t == 0 ? pos : pos - ix.sentinels[t - 1] - 1u;
-        if (writer) {
-            if (kWide) {
-                gdx_hit_t out;
-                out.text_id = t;
-                out.position = in_text;
-                static_cast<gdx_hit_t *>(hits_out)[h] = out;
-            } else {
-                gdx_hit32_t out;
-                out.text_id = t;
-                out.position = in_text;
-                static_cast<gdx_hit32_t *>(hits_out)[h] = out;
-            }
-        }
-    }
-    if (step_stats && writer) atomicAdd(step_stats, static_cast<unsigned long long>(walk_steps));
-}
-
-// ---- one pass over the search records: hit offsets AND the hit of every query that has exactly one -------------------
-// The count + locate step of a read batch is search -> scan of the counts -> locate.  With resolved records (32-byte jump
-// entries carry SA[row]) the last two are streaming passes over the same records: an exclusive scan that reads them
-// and writes the offsets, then a kernel that reads records and offsets again and writes the hits.  This kernel does both
-// at once -- a single-pass scan with decoupled look-back (tiles of 2048 queries take tickets, publish {aggregate |
-// inclusive prefix} in one 64-bit word, and look back over their predecessors) whose tiles then store the hit of every
-// query with exactly one hit slot: resolved -> the position is in the record; otherwise one fetch of SA[row] when the
-// index has it (jump entry / full suffix array).  Queries with several hits (and single hits that would need a walk) are
-// only counted (totals[1]); the queue kernel fills them in afterwards with LocateView::skip_single.  Hits beyond
-// hits_capacity are not stored: the caller compares totals[0] with the capacity it offered.
-constexpr uint32_t kScanTile = 2048;
-constexpr unsigned long long kTileAggregate = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
-
-template <bool kWide>
-__global__ __launch_bounds__(kBlock) void scan_locate_kernel(LocateView lv, const uint4 *__restrict__ rec, uint64_t m,
-                                                             uint32_t max_hits, uint32_t take,
-                                                             uint64_t *__restrict__ hit_offsets, void *__restrict__ hits_out,
-                                                             uint64_t hits_capacity, unsigned long long *__restrict__ tile_state,
-                                                             uint32_t *__restrict__ ticket,
-                                                             unsigned long long *__restrict__ totals)
-{
-    constexpr uint32_t kPer = kScanTile / kBlock;  // consecutive queries per thread (one 128-byte line of records)
-    __shared__ uint32_t s_tile;
-    __shared__ unsigned long long s_warp[(kScanTile / kBlock) * (kBlock / 64)];
-    __shared__ unsigned long long s_prefix;
-    constexpr uint32_t kLdsTexts = 256;
-    __shared__ uint32_t s_sentinels[kLdsTexts];
-    IndexView ix{};
-    ix.sentinels = lv.sentinels;
-    ix.n_texts = lv.n_texts;
-    const uint32_t *sentinels = lv.n_texts <= kLdsTexts ? s_sentinels : lv.sentinels;
-    if (lv.n_texts <= kLdsTexts)
-        for (uint32_t i = threadIdx.x; i < lv.n_texts; i += kBlock) s_sentinels[i] = lv.sentinels[i];
-    const bool have_sa = lv.sa_full != nullptr || (lv.jump != nullptr && lv.jump_bytes == 32u);
-    const uint64_t n_tiles = (m + kScanTile - 1) / kScanTile;
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tiles are handed out in order: a tile only waits for earlier ones
-        __syncthreads();
-        const uint64_t tile = s_tile;
-        if (tile >= n_tiles) break;
-        // striped arrangement: thread t holds queries j * 256 + t of the tile (j = 0 .. 7), so that record loads, offset
-        // stores and hit stores of a wavefront touch consecutive memory; the scan is done row by row
-        const uint64_t q0 = tile * kScanTile + threadIdx.x;
-        uint4 r[kPer];
-        uint32_t c[kPer];
-        unsigned long long incl[kPer];
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) {
-            const uint64_t q = q0 + static_cast<uint64_t>(j) * kBlock;
-            r[j] = q < m ? rec[q] : make_uint4(0u, 0u, 0u, 0u);
-            uint32_t cnt = r[j].y - r[j].x;
-            if (max_hits != 0u && cnt > max_hits) cnt = take ? max_hits : 0u;  // RecordSize
-            c[j] = cnt;
-            unsigned long long x = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned long long o = __shfl_up(x, off);
-                if (static_cast<int>(threadIdx.x & 63u) >= off) x += o;
-            }
-            incl[j] = x;
-            if ((threadIdx.x & 63u) == 63u) s_warp[j * (kBlock / 64) + (threadIdx.x >> 6)] = x;
-        }
-        __syncthreads();
-        unsigned long long before[kPer], tile_total = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) {
-            unsigned long long row_before = 0, row_total = 0;
-            for (uint32_t wv = 0; wv < kBlock / 64; wv++) {
-                const unsigned long long v = s_warp[j * (kBlock / 64) + wv];
-                if (wv < (threadIdx.x >> 6)) row_before += v;
-                row_total += v;
-            }
-            before[j] = tile_total + row_before + incl[j] - c[j];
-            tile_total += row_total;
-        }
-        if (threadIdx.x < 64u) {
-            // (the flag travels in the same 64-bit word as the value, so relaxed device-scope atomics are all the protocol
-            // needs: acquire / release at system scope made every poll an L2 invalidation on this multi-XCD chip)
-            // the tile's first wavefront looks back 64 predecessors at a time: the tiles in flight all start with an
-            // aggregate only, so a tile sums up to a few thousand of them before it meets one that knows its prefix (one
-            // lane walking them one by one made the pass 20 ms instead of 1)
-            const uint32_t lane = threadIdx.x;
-            unsigned long long prefix = 0;
-            if (tile != 0 && lane == 0) __hip_atomic_store(tile_state + tile, kTileAggregate | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            long long p = static_cast<long long>(tile) - 1 - static_cast<long long>(lane);
-            for (;;) {
-                unsigned long long v = kTilePrefix;  // before tile 0: an inclusive prefix of 0
-                if (p >= 0) {
-                    do {
-                        v = __hip_atomic_load(tile_state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } while ((v >> 62) == 0ull);
-                }
-                const unsigned long long is_prefix = __ballot((v >> 62) == 2ull);
-                const int first = is_prefix ? __ffsll(static_cast<long long>(is_prefix)) - 1 : 64;
-                unsigned long long part = static_cast<int>(lane) <= first ? v & kTileValue : 0ull;
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-                prefix += part;
-                if (is_prefix) break;
-                p -= 64;
-            }
-            if (lane == 0) {
-                __hip_atomic_store(tile_state + tile, kTilePrefix | (prefix + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_prefix = prefix;
-                if (tile == n_tiles - 1) {
-                    hit_offsets[m] = prefix + tile_total;
-                    totals[0] = prefix + tile_total;
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned long long tile_base = s_prefix;
-        unsigned long long rest = 0;  // hit slots this kernel leaves to the queue kernel
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) {
-            const uint64_t q = q0 + static_cast<uint64_t>(j) * kBlock;
-            const unsigned long long off = tile_base + before[j];
-            if (q < m) {
-                hit_offsets[q] = off;
-                if (c[j] == 1u) {
-                    const uint4 rr = r[j];
-                    bool done = false;
-                    uint32_t pos = 0;
-                    if (rr.w & kRecResolved) {
-                        pos = rr.z;
-                        done = true;
-                    } else if (have_sa) {
-                        uint32_t row = rr.x, back = 0;
-                        if (rr.w & kRecMasked) {
-                            row = rr.x + static_cast<uint32_t>(__builtin_ctz(rr.z | 0x80000000u));
-                            back = rr.w & 0x1fffffu;
-                        } else if (rr.z != 0xffffffffu && rr.y - rr.x == 1u) {
-                            row = rr.z;
-                            back = rr.w & 0xffffffu;
-                        }
-                        const uint32_t sa = lv.sa_full != nullptr ? lv.sa_full[row]
-                                                                  : static_cast<const uint32_t *>(lv.jump)[static_cast<uint64_t>(row) * 8u + 6u];
-                        pos = sa - back;
-                        done = true;
-                    }
-                    if (done) {
-                        if (off < hits_capacity) store_hit<kWide>(ix, pos, hits_out, off, sentinels);
-                    } else {
-                        rest += 1u;
-                    }
-                } else {
-                    rest += c[j];
-                }
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o);
-        if ((threadIdx.x & 63u) == 0 && rest != 0ull) atomicAdd(totals + 1, rest);
-    }
-}
-
 unsigned grid_for_items(uint64_t items)
 {
     const uint64_t blocks = (items + kBlock - 1) / kBlock;
@@ -912,14 +649,6 @@ unsigned grid_for_items(uint64_t items)
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-size_t max_scan_temp_bytes(uint64_t total)
-{
-    size_t bytes = 0;
-    uint32_t *p = nullptr;
-    (void)rocprim::inclusive_scan(nullptr, bytes, p, p, static_cast<size_t>(total), rocprim::maximum<uint32_t>());
-    return bytes;
-}
 
 }  // namespace
 
@@ -949,8 +678,18 @@ constexpr uint32_t kScan2Rows = 8;
 constexpr uint32_t kScan2Wave = 64 * kScan2Rows;              // queries per wavefront
 constexpr uint32_t kScan2Tile = (kBlock / 64) * kScan2Wave;   // queries per block and tile (2048)
 constexpr uint32_t kScanInlineMax = 2048;  // slots of a "see the record" query the store pass locates itself (ScanStore)
-// the second pass runs on a grid the chip holds at once (six blocks of its 80 registers per CU), every block over many tiles
-static unsigned scan2_grid(uint64_t n_tiles) { return static_cast<unsigned>(n_tiles < 1536 ? n_tiles : 1536); }
+// blocks of `kernel` the device holds at once (occupancy x compute units): the grid of the kernels whose blocks stride over
+// their work -- one block more per CU than fit would run as a second round at a fraction of the occupancy
+template <class Kernel>
+static unsigned resident_blocks(Kernel kernel)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
+        return 1024u;
+    return static_cast<unsigned>(per_cu) * static_cast<unsigned>(prop.multiProcessorCount);
+}
 
 // the counts of queries q0, q0 + 64, ..: all loads issued before any is looked at (RecordSize::operator() asks for the record
 // only after it has seen the compact result -- eight dependent round trips per thread when called in a loop)
@@ -1290,8 +1029,9 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
         unsigned long long *const no_rest = nullptr;
         hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(grid), dim3(kBlock), 0, stream, f, m, sums, no_rest);
         hipLaunchKernelGGL(scan2_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, n_tiles, static_cast<unsigned long long *>(nullptr));
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(scan2_grid(n_tiles)), dim3(kBlock), 0, stream, f, m, sums,
-                           d_hit_offsets, ScanStore{}, 0u);
+        static const unsigned cap_plain = resident_blocks(scan2_tile_scan_kernel<false, false>);
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(static_cast<unsigned>(n_tiles < cap_plain ? n_tiles : cap_plain)),
+                           dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ScanStore{}, 0u);
         return;
     }
     RecordSizeIterator in(rocprim::counting_iterator<uint64_t>(0), RecordSize{d_rec, d_compact, m, max_hits, take});
@@ -1349,9 +1089,13 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const unsigned long long *sums = static_cast<const unsigned long long *>(d_scan_workspace);
     if (d_chunk_flags != nullptr && !flags_zeroed) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, locate_chunk_flags_bytes(hits_capacity), stream));
-    const unsigned grid = scan2_grid(n_tiles);
+    // (grids the chip holds at once: every block strides over many tiles)
+    static const unsigned cap_plain = resident_blocks(scan2_tile_scan_kernel<false, false>);
+    static const unsigned cap_store = resident_blocks(scan2_tile_scan_kernel<true, false>);
+    static const unsigned cap_wide = resident_blocks(scan2_tile_scan_kernel<true, true>);
+    auto grid_of = [&](unsigned cap) { return dim3(static_cast<unsigned>(n_tiles < cap ? n_tiles : cap)); };
     if (!store || d_compact == nullptr || d_hits == nullptr) {
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<false, false>), grid_of(cap_plain), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets,
                            ScanStore{}, narrow);
         return;
     }
@@ -1362,9 +1106,9 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
     const ScanStore ss{ix.sentinels, ix.n_texts, shift, d_hits, hits_capacity, d_chunk_flags, entry_sa ? ix.sa_full : nullptr, jump32,
                        d_totals, entry_sa ? kScanInlineMax : 0u};
     if (wide)
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, true>), grid_of(cap_wide), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
     else
-        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
+        hipLaunchKernelGGL((scan2_tile_scan_kernel<true, false>), grid_of(cap_store), dim3(kBlock), 0, stream, f, m, sums, d_hit_offsets, ss, narrow);
 }
 
 // SA[row] of any row in one fetch (32-byte jump entries, or the full suffix array): launch_locate then never walks, and the
@@ -1756,6 +1500,63 @@ void launch_wire_split(const IndexView &ix, const uint8_t *d_bitmap, const uint3
                        d_tile_found, d_found_pos, found_cap, m, d_exc_q, d_meta, exc_cap, ix.sentinels, ix.n_texts, shift, d_ids, d_pos);
 }
 
+void launch_offsets_hits(const IndexView &ix, const uint4 *d_rec, const uint32_t *d_compact, uint64_t nq, uint32_t max_hits, bool take,
+                         const void *d_scan_workspace, void *d_hit_offsets, bool narrow, uint64_t total_hits, uint64_t rest_hits,
+                         void *d_hits, void *d_workspace, hipStream_t stream, const QueryOptions &qo)
+{
+    // few open slots: the scan pass stores the compactly answered hits and flags the locate chunks with open slots, locate
+    // visits only those; many (reads from repeats, short reads): the scan writes offsets only and locate streams over all slots
+    const bool sparse = d_compact != nullptr && rest_hits * 16 <= total_hits;
+    uint8_t *flags = (sparse && rest_hits != 0) ? static_cast<uint8_t *>(d_workspace) + locate_chunk_flags_offset(total_hits) : nullptr;
+    launch_scan_offsets_store(ix, d_rec, d_compact, nq, max_hits, take, d_scan_workspace, static_cast<uint64_t *>(d_hit_offsets), d_hits,
+                              total_hits, false, stream, sparse, flags, narrow, false, locate_entry_sa(ix, qo));
+    if (rest_hits != 0 || !sparse)
+        launch_locate(ix, nullptr, nullptr, nq, static_cast<const uint64_t *>(d_hit_offsets), total_hits, d_hits, false, d_workspace,
+                      stream, nullptr, nullptr, qo, d_rec, false, d_compact, sparse, flags, narrow);
+}
+
+void launch_locate_step(const IndexView &ix, const LocateStep &step, hipStream_t st, const QueryOptions &qo)
+{
+    const uint64_t nq = step.call.nq;
+    unsigned long long *totals = step.d_totals;
+    const uint32_t *d_compact = step.call.d_compact;
+    // the scan pass stores the hits the compact results answer and flags the locate chunks that hold other slots
+    const bool store = d_compact != nullptr && step.hits_capacity != 0;
+    uint8_t *flags = store ? static_cast<uint8_t *>(step.d_workspace) + locate_chunk_flags_offset(step.hits_capacity) : nullptr;
+    ZeroSet zero;
+    zero.add(totals, 2 * sizeof(unsigned long long));
+    if (flags != nullptr) zero.add(flags, locate_chunk_flags_bytes(step.hits_capacity));
+    if (nq == 0) {
+        zero.add(step.d_hit_offsets, step.narrow ? sizeof(uint32_t) : sizeof(uint64_t));
+        zero.flush(st);
+        if (step.event_after_search) GDX_HIP(hipEventRecord(step.event_after_search, st));
+        return;
+    }
+    SearchCall c = step.call;
+    c.mode = 1;
+    bool folded = false;
+    if (d_compact != nullptr && !(step.take && step.max_hits != 0u)) {  // (the search's own totals count a capped query as none)
+        c.d_tile_sums = static_cast<unsigned long long *>(step.d_scan_workspace);
+        c.d_tile_rest = totals + 1;
+        c.tile_max_hits = step.max_hits;
+        c.tile_sums_done = &folded;
+    }
+    c.also_zero = &zero;
+    launch_search_call(ix, c, st, qo);
+    GDX_HIP(hipGetLastError());
+    if (folded)
+        launch_scan_totals_finish(step.d_scan_workspace, nq, totals, st);
+    else  // (zeroes the totals again and counts from the results)
+        launch_scan_totals(c.d_rec, d_compact, nq, step.max_hits, step.take, step.d_scan_workspace, totals, st);
+    if (step.event_after_search) GDX_HIP(hipEventRecord(step.event_after_search, st));
+    launch_scan_offsets_store(ix, c.d_rec, d_compact, nq, step.max_hits, step.take, step.d_scan_workspace,
+                              static_cast<uint64_t *>(step.d_hit_offsets), step.d_hits, step.hits_capacity, false, st, store, flags,
+                              step.narrow, true, locate_entry_sa(ix, qo), totals);
+    if (step.hits_capacity != 0)
+        launch_locate(ix, nullptr, nullptr, nq, static_cast<const uint64_t *>(step.d_hit_offsets), step.hits_capacity, step.d_hits, false,
+                      step.d_workspace, st, nullptr, nullptr, qo, c.d_rec, false, d_compact, store, flags, step.narrow, totals);
+}
+
 size_t count_offsets_temp_bytes(uint64_t m)
 {
     size_t bytes = 0;
@@ -1781,86 +1582,30 @@ void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, u
                        d_compact);
 }
 
-size_t scan_locate_workspace_bytes(uint64_t m)
-{
-    return align_up(((m + kScanTile - 1) / kScanTile + 1) * sizeof(unsigned long long), 256) + 256;
-}
-
-void launch_scan_locate(const IndexView &ix, const uint4 *d_rec, uint64_t m, uint32_t max_hits, bool take,
-                        uint64_t *d_hit_offsets, void *d_hits, uint64_t hits_capacity, bool wide, void *d_workspace,
-                        unsigned long long *d_totals, hipStream_t stream)
-{
-    GDX_HIP(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), stream));
-    if (m == 0) {
-        GDX_HIP(hipMemsetAsync(d_hit_offsets, 0, sizeof(uint64_t), stream));
-        return;
-    }
-    const uint64_t n_tiles = (m + kScanTile - 1) / kScanTile;
-    const size_t state_bytes = align_up((n_tiles + 1) * sizeof(unsigned long long), 256);
-    unsigned long long *state = static_cast<unsigned long long *>(d_workspace);
-    uint32_t *ticket = reinterpret_cast<uint32_t *>(static_cast<char *>(d_workspace) + state_bytes);
-    GDX_HIP(hipMemsetAsync(d_workspace, 0, state_bytes + 256, stream));
-    const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.layout == 0 ? ix.sa_full : nullptr,
-                        ix.count, ix.sa_samples, ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride,
-                        ix.layout == 0 ? ix.jump_bytes : 0u, ix.n_texts, ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, 0u,
-                        ix.g_kind, ix.g_wpb, ix.g_used, ix.g_sb};
-    // a resident grid: every block takes tiles by ticket until they run out
-    static const long grid_env = [] { const char *e = getenv("GDX_SCAN_GRID"); return e ? atol(e) : 0L; }();  // experiments
-    const uint64_t grid_cap = grid_env > 0 ? static_cast<uint64_t>(grid_env) : 256u * 8u;
-    const unsigned grid = static_cast<unsigned>(n_tiles < grid_cap ? n_tiles : grid_cap);
-    if (wide)
-        hipLaunchKernelGGL(scan_locate_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, lv, d_rec, m, max_hits, take ? 1u : 0u,
-                           d_hit_offsets, d_hits, hits_capacity, state, ticket, d_totals);
-    else
-        hipLaunchKernelGGL(scan_locate_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, lv, d_rec, m, max_hits, take ? 1u : 0u,
-                           d_hit_offsets, d_hits, hits_capacity, state, ticket, d_totals);
-}
-
+// the first-query table of the chunks (n_chunks + 1 entries), then the chunk flags (locate_chunk_flags_offset)
 size_t locate_workspace_bytes(uint64_t total_hits)
 {
-    return align_up(total_hits * sizeof(uint32_t), 256) + align_up(max_scan_temp_bytes(total_hits), 256) + 256;
+    return locate_chunk_flags_offset(total_hits) + align_up(locate_chunk_flags_bytes(total_hits) + 4, 256) + 256;
 }
 
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
                    const uint64_t *d_hit_offsets, uint64_t total_hits, void *d_hits, bool wide,
                    void *d_workspace, hipStream_t stream, unsigned long long *d_step_stats, const uint2 *d_hint,
-                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, bool skip_single, const uint32_t *d_compact,
+                   const QueryOptions &qo, const uint4 *d_rec, bool reference_walk, const uint32_t *d_compact,
                    bool compact_stored, const uint8_t *d_chunk_flags, bool narrow_offsets, const unsigned long long *d_total)
 {
     if (total_hits == 0 || m == 0) return;
     if (d_total != nullptr && d_rec == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: a device-side total goes with search records");
     if (narrow_offsets && d_rec == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: narrow offsets go with search records");
     const HitOffsets offs{d_hit_offsets, narrow_offsets ? 1u : 0u};
-    uint32_t *heads = static_cast<uint32_t *>(d_workspace);
-    void *scan_temp = static_cast<char *>(d_workspace) + align_up(total_hits * sizeof(uint32_t), 256);
-    size_t scan_bytes = max_scan_temp_bytes(total_hits);
-
-    static const int env_variant = [] {
-        const char *e = getenv("GDX_LOCATE_VARIANT");
-        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
-    }();
-    int variant = (qo.locate_variant >= 0 && qo.locate_variant <= 2) ? qo.locate_variant : env_variant;
-    if (d_rec != nullptr) variant = 0;  // only the queue kernel reads search records
-    if (variant != 0) {  // the lock-step variants map hit slots to queries with head marks + a max-scan over all hits
-        GDX_HIP(hipMemsetAsync(heads, 0, total_hits * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_start, d_end, m,
-                           d_hit_offsets, heads);
-        GDX_HIP(rocprim::inclusive_scan(scan_temp, scan_bytes, heads, heads, static_cast<size_t>(total_hits),
-                                        rocprim::maximum<uint32_t>(), stream));
-    }
-    // GDX_LOCATE_GRID (experiments): absolute number of blocks of the walk kernel
+    // (rounds 1-4 kept two lock-step variants beside the chunk kernels -- one lane per hit, eight lanes per hit on pair lines --
+    // behind gdx_query_options_t.locate_kernel: 3 and 5 times slower (profiles/r01/search_variants.md), reached by no
+    // configuration, and their slot -> query map cost 4 bytes of workspace per hit; removed in round 5, the option is ignored)
+    // GDX_LOCATE_GRID (experiments): absolute number of blocks of the locate kernel
     static const long grid_override = [] { const char *e = getenv("GDX_LOCATE_GRID"); return e ? atol(e) : 0L; }();
-    const unsigned grid = grid_override > 0 ? static_cast<unsigned>(grid_override) : grid_for_items(total_hits);
-#define GDX_LOCATE(TABLE, WIDE)                                                                              \
-    hipLaunchKernelGGL((locate_kernel<TABLE, WIDE>), dim3(grid), dim3(kBlock), 0, stream, ix, d_start, \
-                       d_hit_offsets, heads, total_hits, d_hits, d_step_stats)
-    // GDX_LOCATE_VARIANT: queue (default) = locate_queue_kernel; lane = one lane per hit in lock-step; pair = 8 lanes
-    // per hit on pair lines, two walk steps per fetch.  Measured per 90 M hits at rate 4 (search_variants.md):
-    // lane 10.0 ms, pair 16.6 ms (latency-bound with 8x fewer hits in flight); also tried: visiting the hits in
-    // suffix-array order after a radix sort of (row, slot) pairs, 12.5 ms including the sort.
-    if (variant == 0) {
+    {
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
-        uint32_t *first = heads;  // n_chunks entries of the workspace
+        uint32_t *first = static_cast<uint32_t *>(d_workspace);  // n_chunks + 1 entries of the workspace
         hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock) / kBlock)),
                            dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first, d_total, d_chunk_flags);
         // (with chunk flags few chunks have anything to do: a grid the chip holds at once, every block looks at its share
@@ -1883,7 +1628,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
                             ix.border_keys, ix.border_vals, ix.sentinels, ix.sb_stride, ix.jump_bytes, ix.n_texts,
-                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, compact_stored ? 2u : (skip_single ? 1u : 0u),
+                            ix.sa_inv, ix.sa_rot, ix.sa_limit, ix.sigma, ix.nbits, compact_stored ? 2u : 0u,
                             ix.g_kind, ix.g_wpb, ix.g_used, ix.g_sb};
         const bool jump_walk = ix.layout == 0 && ix.jump != nullptr && ix.jump_bytes >= 16 && !reference_walk &&
                                qo.locate_jump_walk != 0;
@@ -1895,10 +1640,12 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
             uint32_t shift = 0;
             while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
             const StreamView sv{ix.sa_full, ix.sa_full == nullptr ? static_cast<const uint32_t *>(ix.jump) : nullptr, ix.sentinels,
-                                ix.n_texts, shift, compact_stored ? 2u : (skip_single ? 1u : 0u)};
+                                ix.n_texts, shift, compact_stored ? 2u : 0u};
             // a grid the chip holds at once (the text-id table is built once per block); every block strides over the chunks
+            static const unsigned cap_s = resident_blocks(locate_stream_kernel<false>), cap_sw = resident_blocks(locate_stream_kernel<true>);
+            const unsigned s_cap = wide ? cap_sw : cap_s;
             const unsigned sgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
-                                                     : static_cast<unsigned>(n_chunks < 2048 ? n_chunks : 2048);
+                                                     : static_cast<unsigned>(n_chunks < s_cap ? n_chunks : s_cap);
             if (wide)
                 hipLaunchKernelGGL(locate_stream_kernel<true>, dim3(sgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, first, d_hint,
                                    d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total);
@@ -1915,24 +1662,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
             else GDX_LOCATE_Q(GenericTable, false, false);
         }
 #undef GDX_LOCATE_Q
-    } else if (ix.layout == 0 && ix.pair_lines != nullptr && variant == 2) {
-        uint64_t blocks = (total_hits + 31) / 32;
-        if (blocks > 65536) blocks = 65536;
-        if (grid_override > 0) blocks = static_cast<uint64_t>(grid_override);
-        if (wide)
-            hipLaunchKernelGGL(locate_pair_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, ix,
-                               d_start, d_hit_offsets, heads, total_hits, d_hits, d_step_stats);
-        else
-            hipLaunchKernelGGL(locate_pair_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, ix,
-                               d_start, d_hit_offsets, heads, total_hits, d_hits, d_step_stats);
-    } else if (ix.layout == 0) {
-        if (wide) GDX_LOCATE(LineTable, true);
-        else GDX_LOCATE(LineTable, false);
-    } else {
-        if (wide) GDX_LOCATE(GenericTable, true);
-        else GDX_LOCATE(GenericTable, false);
     }
-#undef GDX_LOCATE
 }
 
 }  // namespace gdx

@@ -306,21 +306,6 @@ class DeviceEngine:
             self.h, _ptr(rec), _ptr(compact) if compact is not None else None, nq, max_hits, _ptr(scan_ws), _ptr(hit_offsets),
             total, rest, _ptr(hits), _ptr(workspace) if workspace is not None else None, _stream()))
 
-    def scan_workspace_bytes(self, nq: int) -> int:
-        return int(self.lib.gdx_locate_many_scan_workspace_bytes(nq))
-
-    def locate_scan_hits(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, hits: torch.Tensor, capacity: int,
-                         scan_ws: torch.Tensor, totals: torch.Tensor, max_hits: int = 0) -> None:
-        """gdx_locate_many_scan_hits_dev: offsets + the hits of all single-hit queries in one pass; totals = int64[2]
-        (all hit slots, slots left open for locate_hits_rest)"""
-        _lib.check(self.lib.gdx_locate_many_scan_hits_dev(self.h, _ptr(rec), nq, max_hits, _ptr(hit_offsets), _ptr(hits),
-                                                          capacity, _ptr(scan_ws), _ptr(totals), _stream()))
-
-    def locate_hits_rest(self, rec: torch.Tensor, nq: int, hit_offsets: torch.Tensor, total: int, hits: torch.Tensor,
-                         workspace: torch.Tensor) -> None:
-        _lib.check(self.lib.gdx_locate_many_hits_rest_dev(self.h, _ptr(rec), nq, _ptr(hit_offsets), total, _ptr(hits),
-                                                          _ptr(workspace), _stream()))
-
     def unpack_records(self, rec: torch.Tensor, nq: int, counts=None, status=None, compact=None) -> None:
         if compact is not None:
             _lib.check(self.lib.gdx_locate_many_unpack_compact_dev(self.h, _ptr(rec), _ptr(compact), nq,

@@ -332,6 +332,26 @@ class FmIndex:
                 self._lib.gdx_free_hits(ptr)
         return off, hits[:, 0].copy(), hits[:, 1].copy(), status
 
+    def locate_layout32_raw(self, qbuf, qoff, nq, packed=False, uniform_len=0, strict=True, qbuf_ptr=None):
+        """gdx_locate_many_alloc_layout32 -> (hit_offsets u32, text_ids u32, positions u32, status): copies of the library's
+        pinned arrays (a caller that cares for speed reads them in place and gives them back with gdx_free_hits32).
+        qbuf_ptr: the address of the query buffer when it is not a numpy array (pinned memory of another owner)"""
+        status = np.zeros(nq, dtype=np.uint8)
+        res = _lib.Hits32()
+        lay = self._layout(packed, uniform_len)
+        qp = C.cast(C.c_void_p(qbuf_ptr), u8p) if qbuf_ptr is not None else _p(qbuf, u8p)
+        st = self._lib.gdx_locate_many_alloc_layout32(self._h, qp, _p(qoff, u64p) if qoff is not None else None, nq,
+                                                      C.byref(lay), C.byref(res), _p(status, u8p))
+        try:
+            _lib.check(st, allow=() if strict else (_lib.GDX_ERR_QUERY_STATUS,))
+            n = res.total_hits
+            off = np.ctypeslib.as_array(res.hit_offsets, shape=(nq + 1,)).copy()
+            hits = np.ctypeslib.as_array(res.hits, shape=(max(n, 1) * 2,))[: 2 * n].reshape(n, 2).copy() \
+                if n else np.zeros((0, 2), dtype=np.uint32)
+        finally:
+            self._lib.gdx_free_hits32(C.byref(res))
+        return off, hits[:, 0].copy(), hits[:, 1].copy(), status
+
     def locate_alloc_raw(self, qbuf, qoff, strict=True):
         """gdx_locate_many_alloc (one pass) -> (hit_offsets, text_ids, positions, status)"""
         nq = qoff.size - 1

@@ -224,7 +224,7 @@ typedef struct {
     int32_t search_lanes;    /* 0 default (4), 4 or 8 lanes per query in the pair-line kernel                 */
     int32_t load_policy;     /* -1 default (0 plain loads), 1 = sc1 (no L1 allocation)                        */
     int32_t length_schedule; /* -1 default (1: a block orders its queries by length when they differ), 0 off  */
-    int32_t locate_kernel;   /* -1 default (0 queue kernel), 1 one lane per hit, 2 eight lanes per hit        */
+    int32_t locate_kernel;   /* ignored since round 5 (-1 .. 2 accepted): the chunk kernels are the only ones   */
     int32_t locate_jump_walk; /* -1 default (1: the locate walk goes through the jump table), 0 rank lines only */
     int32_t search_defer_after; /* a query still unfinished this many load rounds after the allowance of a query
                                 that jumps is parked and finished in its block's straggler pass, where all lanes work
@@ -394,22 +394,6 @@ int gdx_locate_many_offsets_capped_dev(const gdx_index_t *ix, const void *d_reco
                                        void *d_hit_offsets, void *stream);
 int gdx_locate_many_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
                              uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
-/* gdx_locate_many_offsets_capped_dev AND the hits of every query with exactly one hit slot in ONE pass over the records
- * (a single-pass scan with decoupled look-back whose tiles store those hits: a resolved record holds the position, any
- * other single hit is one fetch of SA[row] on an index that has it).  d_hits must be offered before the total is known:
- * hits at or beyond hits_capacity are not stored.  d_totals (u64[2], device): [0] = all hit slots (= d_hit_offsets[nq]),
- * [1] = slots this pass left open (queries with several hits; single hits that need a locate walk).  The caller reads
- * d_totals back (the one host round trip of a count + locate step) and then
- *   totals[0] > hits_capacity: grows its buffer and calls gdx_locate_many_hits_dev (the offsets are valid);
- *   totals[1] != 0:            calls gdx_locate_many_hits_rest_dev, which fills in exactly the open slots;
- *   else:                      is done.
- * d_scan_workspace: gdx_locate_many_scan_workspace_bytes(nq) bytes. */
-uint64_t gdx_locate_many_scan_workspace_bytes(uint64_t nq);
-int gdx_locate_many_scan_hits_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, uint32_t max_hits,
-                                  void *d_hit_offsets, void *d_hits, uint64_t hits_capacity, void *d_scan_workspace,
-                                  void *d_totals, void *stream);
-int gdx_locate_many_hits_rest_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, const void *d_hit_offsets,
-                                  uint64_t total_hits, void *d_hits, void *d_workspace, void *stream);
 int gdx_locate_many_unpack_dev(const gdx_index_t *ix, const void *d_records, uint64_t nq, void *d_out_counts,
                                void *d_out_status, void *stream);
 /* COMPACT results beside the records: d_compact (u32[nq], device) holds per query the text position of its ONLY hit
@@ -584,6 +568,25 @@ int gdx_count_many_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const v
 int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d_qbuf, const void *d_qoff, uint64_t nq,
                                             const gdx_query_layout_t *layout, void *d_out_start, void *d_out_end,
                                             void *d_out_status, void *stream);
+
+/* gdx_locate_many_alloc_layout with NARROW results in pinned host memory the library owns (FmIndex::locate_many, lib.rs:179-185;
+ * Hit lib.rs:331-335 as two u32): hit_offsets is u32[nq + 1], hits gdx_hit32_t[total_hits] -- 8 + 4 bytes per result instead of
+ * 16 + 8, and the device writes them where they lie by D2H copy, so no host thread copies or widens a result (the wide call
+ * spends its time there once the reads come as 2-bit codes: 12.5 bytes in, 23 bytes out per read).  Fewer than 2^32 hits in all,
+ * else GDX_ERR_CAPACITY (the wide call has no such limit).  Release the arrays with gdx_free_hits32: the library keeps one pair
+ * for the caller's next batch (pinning memory costs about a millisecond per 10 MB); gdx_release_cached_hits() frees what the
+ * library holds back, this pair and the array of gdx_free_hits.  layout may be NULL (IO symbols + offsets).  When qbuf itself
+ * is pinned host memory (hipHostMalloc / hipHostRegister), every host-pointer call copies from it directly, without staging. */
+typedef struct {
+    uint32_t *hit_offsets;
+    gdx_hit32_t *hits;
+    uint64_t total_hits, nq;
+    uint64_t reserved[2];
+} gdx_hits32_t;
+int gdx_locate_many_alloc_layout32(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
+                                   const gdx_query_layout_t *layout, gdx_hits32_t *out_results, uint8_t *out_status);
+void gdx_free_hits32(gdx_hits32_t *results);
+void gdx_release_cached_hits(void);
 
 /* The host-pointer calls on a batch in a layout: gdx_count_many / gdx_cursors_for_many_queries / gdx_locate_many_alloc
  * (FmIndex::count_many lib.rs:155, cursors_for_many_queries :241, locate_many :179) through the same chunked pipeline.  A

@@ -173,6 +173,27 @@ static int run_variant(const char *name, const vectors_t *v, const gdx_build_opt
                 bad = 1;
             }
         }
+        /* the narrow form of the same call (gdx_locate_many_alloc_layout32): u32 offsets and 8-byte hits in pinned memory of
+           the library's, given back with gdx_free_hits32; then once more after gdx_release_cached_hits */
+        for (int round = 0; round < 2 && !bad; round++) {
+            gdx_hits32_t r32;
+            CHECK(gdx_locate_many_alloc_layout32(ix, packed, v->qoff, nq, &lay, &r32, status));
+            if (r32.nq != nq || r32.total_hits != ptotal || r32.hit_offsets[0] != 0) {
+                printf("FAIL %s: narrow packed form, %" PRIu64 " hits of %" PRIu64 "\n", name, r32.total_hits, ptotal);
+                bad = 1;
+            }
+            for (uint64_t i = 0; i < nq && !bad; i++) {
+                if (r32.hit_offsets[i + 1] - r32.hit_offsets[i] != poff[i + 1] - poff[i]) bad = 1;
+                for (uint64_t h = 0; h < poff[i + 1] - poff[i] && !bad; h++)
+                    if (r32.hits[r32.hit_offsets[i] + h].text_id != ph[poff[i] + h].text_id ||
+                        r32.hits[r32.hit_offsets[i] + h].position != ph[poff[i] + h].position)
+                        bad = 1;
+                if (bad) printf("FAIL %s: narrow packed form, query %" PRIu64 "\n", name, i);
+            }
+            gdx_free_hits32(&r32);
+            if (r32.hits != NULL || r32.hit_offsets != NULL) bad = 1; /* (the struct is cleared: nothing dangles) */
+            gdx_release_cached_hits();
+        }
         gdx_free_hits(ph);
         free(packed), free(exc), free(is_exc), free(pc), free(poff);
     }

@@ -478,11 +478,12 @@ def test_partitioned_index_equals_one_index_on_counts_and_hit_sets(depth):
 @pytest.mark.parametrize("build", [dict(), dict(jump_entry_bytes=16), dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=7,
                                                                            full_suffix_array=True, text_units=True),
                                    dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=5, text_units=True)])
-def test_scan_and_single_hits_in_one_pass(build):
-    """gdx_locate_many_scan_hits_dev (+ gdx_locate_many_hits_rest_dev): offsets and the hits of single-hit queries in one
-    pass over the records, the rest by the queue kernel -- the same offsets and hits as the three-call protocol and the
-    oracle, for indexes with SA[row] at hand (32-byte entries, full suffix array) and without, with a hit buffer that is
-    large enough and one that is too small."""
+def test_the_whole_step_in_one_call(build):
+    """gdx_locate_many_step_compact_layout_dev on indexes WITHOUT a seed table (records only, and with a compact array whose
+    every word says "see the record"): search, totals, offsets and hits enqueued by one call, no host round trip -- the same
+    offsets and hits as the oracle, for indexes with SA[row] at hand (32-byte entries, full suffix array: the stream kernel)
+    and without (the queue kernel walks), with a hit buffer that is large enough and one that is too small (the totals tell,
+    the offsets are right, what fits is stored)."""
     import torch
 
     from genedex_amd import FmIndexConfig
@@ -501,28 +502,34 @@ def test_scan_and_single_hits_in_one_pass(build):
     dq = DeviceQueries.from_host(qbuf, qoff)
     eng = DeviceEngine(g)
     nq = dq.nq
-    rec = eng.alloc_records(nq)
-    eng.locate_search(dq, rec)
     total = int(co[-1])
-    for capacity in (total + 7, total // 2):
-        off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
-        hits = torch.full((max(capacity, 1), 2), -1, dtype=torch.int32, device="cuda")
-        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
-        sws = torch.empty(max(eng.scan_workspace_bytes(nq), 16), dtype=torch.uint8, device="cuda")
-        eng.locate_scan_hits(rec, nq, off, hits, capacity, sws, totals)
-        tot, rest = (int(x) for x in totals.tolist())
-        assert tot == total and off.cpu().numpy().astype(np.uint64).tolist() == co.tolist()
-        if tot > capacity:  # the caller grows its buffer and locates everything with the offsets it has
-            hits = torch.empty((tot, 2), dtype=torch.int32, device="cuda")
-            ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
-            eng.locate_hits(rec, nq, off, tot, hits, ws)
-        elif rest:
-            ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
-            eng.locate_hits_rest(rec, nq, off, tot, hits, ws)
-        torch.cuda.synchronize()
-        h = hits[:tot].cpu().numpy().astype(np.uint32)
-        assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), (build, capacity)
-        assert rest > 0  # the poly-A query alone has hundreds of hits
+    for with_compact in (False, True):
+        for capacity in (total + 7, total // 2):
+            for dt in (torch.int64, torch.int32):
+                rec = eng.alloc_records(nq)
+                cw = eng.alloc_compact(nq) if with_compact else None
+                off = torch.full((nq + 1,), -1, dtype=dt, device="cuda")
+                hits = torch.full((max(capacity, 1), 2), -1, dtype=torch.int32, device="cuda")
+                totals = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+                sws = torch.empty(max(eng.totals_workspace_bytes(nq), 16), dtype=torch.uint8, device="cuda")
+                ws = torch.empty(max(eng.locate_workspace_bytes(hits.shape[0]), 16), dtype=torch.uint8, device="cuda")
+                eng.locate_step(dq, rec, cw, sws, totals, off, hits, ws)
+                torch.cuda.synchronize()
+                tot = int(totals[0].item())
+                assert tot == total and off.cpu().numpy().astype(np.uint64).tolist() == co.tolist(), (build, with_compact, capacity)
+                if with_compact:
+                    assert int(totals[1].item()) == total and bool((cw[:nq] == -2).all().item())  # no seed table: every word says "see"
+                n = min(tot, capacity)
+                h = hits[:n].cpu().numpy().astype(np.uint32)
+                assert h[:, 0].tolist() == ct[:n].astype(np.uint32).tolist() and h[:, 1].tolist() == cp[:n].astype(np.uint32).tolist(), \
+                    (build, with_compact, capacity)
+                if tot > capacity:  # the caller finishes the step with a buffer of the size the totals name
+                    hits = torch.empty((tot, 2), dtype=torch.int32, device="cuda")
+                    ws = torch.empty(max(eng.locate_workspace_bytes(tot), 16), dtype=torch.uint8, device="cuda")
+                    eng.locate_offsets_hits(rec, nq, sws, off, tot, int(totals[1].item()), hits, ws, compact=cw)
+                    torch.cuda.synchronize()
+                    h = hits.cpu().numpy().astype(np.uint32)
+                    assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist()
 
 
 @pytest.mark.parametrize("seed", range(4))

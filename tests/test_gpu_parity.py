@@ -1189,6 +1189,36 @@ def test_query_layouts_equal_plain_queries(seed, search_variant):
                 assert s_.tolist() == cs.tolist() and e_.tolist() == ce.tolist() and not st.any(), what
                 off, t_, p_, st = g.locate_layout_raw(buf, off_arr, nq, packed=pk, uniform_len=ul)
                 assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist(), what
+                # the narrow form of the same call: u32 offsets and 8-byte hits in pinned memory of the library's, every chunk one
+                # fused step; from a pageable and from a pinned query buffer (no staging copy)
+                off, t_, p_, st = g.locate_layout32_raw(buf, off_arr, nq, packed=pk, uniform_len=ul)
+                assert off.dtype == np.uint32 and t_.dtype == np.uint32 and not st.any(), what
+                assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist(), what
+                pinned = torch.from_numpy(buf.copy()).pin_memory()
+                off, t_, p_, st = g.locate_layout32_raw(None, off_arr, nq, packed=pk, uniform_len=ul, qbuf_ptr=pinned.data_ptr())
+                assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist(), what + " (pinned)"
+                cnt, st = g.count_layout_raw(pinned.numpy(), off_arr, nq, packed=pk, uniform_len=ul)
+                assert cnt.tolist() == (ce - cs).tolist(), what + " (pinned)"
+        # take(k) through the narrow call (max_hits_per_query), and the library's held-back arrays given up
+        g.set_query_options(max_hits_per_query=1)
+        off, t_, p_, st = g.locate_layout32_raw(qbuf, qoff, nq)
+        want = np.minimum(np.diff(co), 1)
+        assert np.diff(off.astype(np.int64)).tolist() == want.tolist()
+        first = co[:-1][want > 0]
+        assert t_.tolist() == ct[first].tolist() and p_.tolist() == cp[first].tolist()
+        g.set_query_options(max_hits_per_query=0)
+        # short reads with hundreds of hits each: a chunk's hits exceed what its device buffers were sized for (the second
+        # half of the step runs again with room) and the pinned hit array grows while chunks are on their way
+        short = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(3, 6)))) for _ in range(900)]
+        sbuf, soff = pack_queries(short)
+        ss_, se_ = c.cursors_for_many(sbuf, soff)
+        so, st_, sp_ = c.locate_intervals(ss_, se_)
+        if int(so[-1]) > 20_000:
+            off, t_, p_, st = g.locate_layout32_raw(sbuf, soff, len(short))
+            assert off.tolist() == so.tolist() and t_.tolist() == st_.tolist() and p_.tolist() == sp_.tolist()
+        lib.gdx_release_cached_hits()
+        off, t_, p_, st = g.locate_layout32_raw(qbuf, qoff, nq)
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
     finally:
         lib.gdx_debug_set_host_chunking(0, 0)
     # what a layout must refuse
