@@ -1173,6 +1173,9 @@ def compact_line(result, side_file=None):
         config["workload"] = config["workload"][:300]
     line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                        "scaling", "vs_baseline", "dtype", "data")}
+    # (`value` is timed on the batch in this form; the same step on the reference's own form -- IO symbols + u64 offsets -- is
+    # `ascii_input`, timed in the same process)
+    line["input_form"] = INPUT_FORMS.get(cfg.get("input"), cfg.get("input"))
     line["config"] = config
     line["roofline"] = roof
     line["cpu_baseline"] = cpu
@@ -1200,10 +1203,17 @@ def compact_line(result, side_file=None):
             line["end_to_end"]["packed_uniform"] = _pick(e["packed_uniform"], ("count_qps", "locate_qps", "count_over_bound",
                                                                                   "locate_over_bound", "locate32_qps", "locate32_over_bound",
                                                                                   "locate32_pinned_input_qps"))
+    cur = {}
+    for r in result.get("secondary") or []:  # BASELINE configs[4]: which index the cursor-API numbers are on
+        if str(r.get("name", "")).startswith("mixed_lengths_20_150") and "cursor_api_ms" in r:
+            key = "headline_index" if "HEADLINE" in r["name"] else "index_with_every_structure"
+            cur[key] = {"index_gb": round(r.get("index_bytes", 0) / 1e9), "cursor_api_ms": r["cursor_api_ms"], "fused_ms": r["fused_ms"]}
+    if cur:
+        line["cursor_api_50M_len20_150"] = cur
     line["index_build_seconds"] = result.get("index_build_seconds")
     line["side_file"] = side_file
     line = _num(line)
-    for drop in ("end_to_end", "shard_step_ms", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
+    for drop in ("cursor_api_50M_len20_150", "end_to_end", "shard_step_ms", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -1490,6 +1500,11 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
 
     eng, index = owned["eng"], owned["index"]
     res = res if res is not None else []
+    if not args.no_extras and args.index == "seed":
+        # BASELINE configs[4] through the cursor API on the headline index itself, beside the 214 GB index's numbers below
+        res.append(mixed_length_secondary(torch, eng, io_text, lengths, light=True))
+        res[-1]["aux_structures"] = eng.aux_info()
+        res[-1]["index_bytes"] = int(index.info.device_bytes)
     text = dict(jump_entry_bytes=0, pair_lines=False, text_units=True)  # the rest of a read against the text at SA[row]
     ladder = [("top16_sa_text", dict(top_table_depth=16, full_suffix_array=True, **text)),
               ("top15_sa_text", dict(top_table_depth=15, full_suffix_array=True, **text)),
@@ -1589,6 +1604,7 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         del xo
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
         res[-1]["aux_structures"] = eng.aux_info()
+        res[-1]["index_bytes"] = int(index.info.device_bytes)
     # the reference's lookup-table knob needs its own index (the lookup tables are part of the reference's arrays): the
     # like-for-like rung again -- the reference's arrays and NOTHING else (no seed table, text units, suffix array, pair
     # lines, jump or top table) -- with its lookup tables of depth 10 and 13 in front of the LF steps
@@ -1690,9 +1706,10 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     t_build = time.time() - t0
     eng = DeviceEngine(index)
     q = DeviceQueries.synth(text, lengths, nq, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
-    # the headline's own step (StepRunner: compact results where the seed table answers, hit totals folded into the search, the
-    # whole step one call) with the per-query limit
-    runner = StepRunner(torch, eng, q, nq, True, args.path if getattr(args, "path", None) else "records")
+    # the step over 16-byte records with the per-query limit: search -> offsets -> read-back of the total -> hits.  (The
+    # headline's compact results + one-call step cost more than they save here -- a third of the reads is listed for the next
+    # kernel and keeps its record anyway: 13.3 against 12.4 ms on one box, profiles/r05/README.md; `path` = records switches)
+    runner = StepRunner(torch, eng, q, nq, True, getattr(args, "genome_path", None) or "records16")
     runner.max_hits = max_hits
     total_hits = runner.size()
     runner.step(0, False)
@@ -1745,6 +1762,12 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
            "queries_found": int((counts > 0).sum().item()), "occurrences_of_all_queries": int(counts.sum().item()),
            "queries_over_the_limit": int((counts > max_hits).sum().item()), "hits_located": total_hits,
            "mean_hits_per_located_query": total_hits / max(int(((counts > 0) & (counts <= max_hits)).sum().item()), 1),
+           # how the located hits spread over interval sizes: {rows per query: [queries, hits]} -- a query of 2..31 rows costs a
+           # whole 128-byte line of the suffix array for 8..124 bytes of it
+           "located_queries_by_hits": {name: [int(((counts >= lo) & (counts <= hi)).sum().item()),
+                                              int(counts[(counts >= lo) & (counts <= hi)].sum().item())]
+                                       for name, lo, hi in (("1", 1, 1), ("2-3", 2, 3), ("4-31", 4, 31), ("32-255", 32, 255),
+                                                            (f"256-{max_hits}", 256, max_hits))},
            "lf_steps": lf_steps, "line_fetches_per_query_exact_mode": fetches / nq,
            "active_lane_fraction_exact_mode": fetches / slots if slots else None,
            "index_build_seconds": t_build, "text_seconds": t_text, "build_stats": index.build_stats(),
@@ -1753,7 +1776,7 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     return res
 
 
-def mixed_length_secondary(torch, eng, io_text, lengths):
+def mixed_length_secondary(torch, eng, io_text, lengths, light=False):
     """BASELINE.json configs[4]: 50 M reads of length 20..150, 70 % sampled / 30 % random (early termination), through
     (a) the fused cursors_for_many_queries call and (b) the batched cursor API: cursor_empty, then
     gdx_cursor_extend_front_strings_dev with 32 symbols per call and device-side active lists.  Identical intervals."""
@@ -1824,6 +1847,18 @@ def mixed_length_secondary(torch, eng, io_text, lengths):
         if not (torch.equal(cur_s, out["start"]) and torch.equal(cur_e, out["end"]) and not bool(cur_st.any().item())):
             raise SystemExit(f"PARITY FAILURE: the batched cursor API ({what}) and the fused search disagree on workload 5")
 
+    if light:  # (the headline index: no pair lines, the calls run on the rank-line kernel -- one pass each is enough to say so)
+        cursor_ms = timed(cursor_api_chunks, reps=1)
+        check("chunks")
+        res = {"name": "mixed_lengths_20_150 on the HEADLINE index (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
+               "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms, "cursor_api_value": nq / (cursor_ms / 1e3),
+               "cursor_api_ms": cursor_ms, "unit": "queries/s", "intervals_identical": True,
+               "note": "exact intervals and cursor extension need the pair-line / jump structures (the 214 GB index of the "
+                       "`mixed_lengths_20_150` secondary); on the 74 GB headline index (reference arrays + seed table + text units "
+                       "+ full SA) both calls fall to the rank-line kernel -- the seed table serves count / locate, where no "
+                       "interval has to come out"}
+        log(f"[bench] secondary {res}")
+        return res
     strings_ms = timed(cursor_api_strings)
     cursor_api_strings(record_live=True)
     check("strings")

@@ -39,6 +39,24 @@ pub struct Hit {
     pub position: u64,
 }
 
+/// gdx_hit32_t: a hit as two u32 (what the device writes; Hit widened on demand)
+#[repr(C)]
+#[derive(Debug, Clone, Copy, PartialEq, Eq, PartialOrd, Ord, Hash)]
+pub struct Hit32 {
+    pub text_id: u32,
+    pub position: u32,
+}
+
+/// gdx_hits32_t: narrow results in pinned memory of the library's (gdx_locate_many_alloc_layout32)
+#[repr(C)]
+pub struct Hits32Raw {
+    pub hit_offsets: *mut u32,
+    pub hits: *mut Hit32,
+    pub total_hits: u64,
+    pub nq: u64,
+    pub reserved: [u64; 2],
+}
+
 /// gdx_build_options_t: which derived acceleration structures an index carries (include/gdx.h).
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
@@ -171,6 +189,13 @@ extern "C" {
         ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, layout: *const QueryLayout,
         out_hit_offsets: *mut u64, out_hits: *mut *mut Hit, out_total: *mut u64, out_status: *mut u8,
     ) -> c_int;
+    /// narrow results (u32 offsets, 8-byte hits) in pinned memory the library owns; release with gdx_free_hits32
+    pub fn gdx_locate_many_alloc_layout32(
+        ix: *const gdx_index_t, qbuf: *const u8, qoff: *const u64, nq: u64, layout: *const QueryLayout,
+        out_results: *mut Hits32Raw, out_status: *mut u8,
+    ) -> c_int;
+    pub fn gdx_free_hits32(results: *mut Hits32Raw);
+    pub fn gdx_release_cached_hits();
     pub fn gdx_cursor_empty(ix: *const gdx_index_t, start: *mut u64, end: *mut u64) -> c_int;
     pub fn gdx_cursor_extend_front_many(
         ix: *const gdx_index_t, start: *mut u64, end: *mut u64, io_symbols: *const u8, m: u64,
@@ -226,6 +251,28 @@ extern "C" {
         ix: *const gdx_index_t, d_records: *const c_void, d_compact: *const c_void, nq: u64, max_hits: u32,
         d_scan_workspace: *const c_void, d_hit_offsets: *mut c_void, total_hits: u64, rest_hits: u64, d_hits: *mut c_void,
         d_workspace: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    /// the whole count + locate step of a device-resident batch in one call, no host round trip (gdx.h)
+    pub fn gdx_locate_many_step_compact_layout_dev(
+        ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, layout: *const QueryLayout,
+        max_hits: u32, d_records: *mut c_void, d_compact: *mut c_void, d_scan_workspace: *mut c_void, d_totals: *mut c_void,
+        d_hit_offsets: *mut c_void, offsets_width: u32, d_hits: *mut c_void, hits_capacity: u64, d_workspace: *mut c_void,
+        event_after_search: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    /// a located shard on its way to another device: a bit per read + the found reads' positions + the exceptions (gdx.h)
+    pub fn gdx_wire_bitmap_bytes(nq: u64) -> u64;
+    pub fn gdx_wire_pack_workspace_bytes(nq: u64) -> u64;
+    pub fn gdx_wire_pack_dev(
+        ix: *const gdx_index_t, d_compact: *const c_void, d_hit_offsets: *const c_void, offsets_width: u32,
+        d_hits: *const c_void, nq: u64, d_bitmap: *mut c_void, d_tile_found: *mut c_void, d_found_pos: *mut c_void,
+        found_capacity: u64, d_exc_queries: *mut c_void, d_exc_counts: *mut c_void, exc_capacity: u64,
+        d_exc_text_ids: *mut c_void, d_exc_positions: *mut c_void, exc_hits_capacity: u64, d_meta: *mut c_void,
+        d_workspace: *mut c_void, stream: *mut c_void,
+    ) -> c_int;
+    pub fn gdx_wire_split_dev(
+        ix: *const gdx_index_t, d_bitmap: *const c_void, d_tile_found: *const c_void, d_found_pos: *const c_void,
+        found_capacity: u64, nq: u64, d_exc_queries: *const c_void, d_meta: *const c_void, exc_capacity: u64,
+        d_out_text_ids: *mut c_void, d_out_positions: *mut c_void, stream: *mut c_void,
     ) -> c_int;
     pub fn gdx_index_seed_info(ix: *const gdx_index_t, out: *mut u64) -> c_int;
     /// an index built with `reference_table_layout`: genedex's own interleaved blocks and superblock offsets as they sit in HBM
@@ -329,6 +376,29 @@ impl Hits {
     }
 }
 
+/// The result of `GpuFmIndex::locate_many_packed`: u32 offsets and 8-byte hits where the device wrote them (pinned memory of
+/// the library's; given back on drop).  Same shape of access as `Hits`.
+pub struct Hits32 {
+    raw: Hits32Raw,
+}
+impl Drop for Hits32 {
+    fn drop(&mut self) {
+        unsafe { gdx_free_hits32(&mut self.raw) }
+    }
+}
+impl Hits32 {
+    pub fn of(&self, i: usize) -> &[Hit32] {
+        let off = unsafe { std::slice::from_raw_parts(self.raw.hit_offsets, self.raw.nq as usize + 1) };
+        let (a, b) = (off[i] as usize, off[i + 1] as usize);
+        if self.raw.total_hits == 0 { &[] } else { unsafe { std::slice::from_raw_parts(self.raw.hits.add(a), b - a) } }
+    }
+    pub fn iter(&self) -> impl Iterator<Item = impl Iterator<Item = Hit> + '_> + '_ {
+        (0..self.raw.nq as usize).map(move |i| {
+            self.of(i).iter().map(|h| Hit { text_id: h.text_id as u64, position: h.position as u64 })
+        })
+    }
+}
+
 /// Owns an index replica in HBM.  Send + Sync like `FmIndex` (handles are immutable).
 pub struct GpuFmIndex {
     raw: *mut gdx_index_t,
@@ -423,6 +493,18 @@ impl GpuFmIndex {
                                   &mut total, std::ptr::null_mut())
         });
         Hits { ptr, total: total as usize, offsets }
+    }
+
+    /// lib.rs:179-185 for reads of one length handed over as 2-bit codes (gdx_pack_queries): 12.5 bytes per len-50 read go in,
+    /// 12 bytes per result come out, and no host thread copies a result
+    pub fn locate_many_packed(&self, packed: &[u8], n_reads: usize, read_len: usize) -> Hits32 {
+        let mut lay = QueryLayout { struct_size: std::mem::size_of::<QueryLayout>() as u32, packed: 1, uniform_len: read_len as u64 };
+        let mut raw = Hits32Raw { hit_offsets: std::ptr::null_mut(), hits: std::ptr::null_mut(), total_hits: 0, nq: 0, reserved: [0; 2] };
+        check(unsafe {
+            gdx_locate_many_alloc_layout32(self.raw, packed.as_ptr(), std::ptr::null(), n_reads as u64, &mut lay, &mut raw,
+                                           std::ptr::null_mut())
+        });
+        Hits32 { raw }
     }
 
     /// lib.rs:169-177

@@ -220,6 +220,8 @@ void launch_offsets_hits(const IndexView &ix, const uint4 *d_rec, const uint32_t
                          const void *d_scan_workspace, void *d_hit_offsets, bool narrow, uint64_t total_hits, uint64_t rest_hits,
                          void *d_hits, void *d_workspace, hipStream_t stream, const QueryOptions &qo);
 size_t locate_chunk_flags_bytes(uint64_t total_hits);
+void *locate_flags_region(uint8_t *d_chunk_flags);          // what is zeroed before the store pass: an "any flagged" word + the flags
+size_t locate_flags_region_bytes(uint64_t total_hits);
 // store == false: offsets only.  d_chunk_flags (inside the locate workspace at locate_chunk_flags_offset(total_hits), filled by
 // the store pass): launch_locate then only visits the chunks of hit slots in which that pass left something open
 size_t locate_chunk_flags_offset(uint64_t total_hits);

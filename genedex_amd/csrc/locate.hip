@@ -99,9 +99,11 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hi
                                                                    uint64_t n_chunks, uint32_t chunk, uint64_t total,
                                                                    uint32_t *__restrict__ first,
                                                                    const unsigned long long *__restrict__ d_total,
-                                                                   const uint8_t *__restrict__ chunk_flags)
+                                                                   const uint8_t *__restrict__ chunk_flags,
+                                                                   uint32_t *__restrict__ ticket)  // the locate kernel's chunk counter
 {
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c == 0 && ticket != nullptr) *ticket = 0u;
     if (d_total != nullptr) {
         const uint64_t t = *d_total;
         total = t < total ? t : total;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void chunk_first_query_kernel(HitOffsets hi
 }
 
 constexpr uint32_t kLocateChunk = 2048;  // hit slots a block takes at a time (locate_queue_kernel, locate_stream_kernel)
+constexpr size_t kFlagsHead = 16;         // bytes in front of a workspace's chunk flags: the "any chunk flagged" word (below)
 
 // Text ids through a coarse table (text_id_search_tree.rs:35-64 computes the same lower bound): s_tab[b] = the text that holds
 // position b << shift, 513 entries over the whole collection, so that the search for a position runs between two neighbouring
@@ -186,19 +189,16 @@ template <bool kWide>
 __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
     StreamView sv, const uint32_t *__restrict__ start, HitOffsets hit_offsets, uint64_t m, const uint32_t *__restrict__ first_query,
     const uint2 *__restrict__ hint, const uint4 *__restrict__ rec, uint64_t total, void *__restrict__ hits_out,
-    const uint32_t *__restrict__ compact, const uint8_t *__restrict__ chunk_flags, const unsigned long long *__restrict__ d_total)
+    const uint32_t *__restrict__ compact, const uint8_t *__restrict__ chunk_flags, const unsigned long long *__restrict__ d_total,
+    uint32_t *__restrict__ ticket)  // zeroed by chunk_first_query_kernel: blocks take chunks in order as they get done
 {
     if (d_total != nullptr) {
         const uint64_t t = *d_total;
         total = t < total ? t : total;
     }
     const uint64_t n_chunks = (total + kLocateChunk - 1) / kLocateChunk;
-    if (chunk_flags != nullptr) {  // nothing flagged among this block's chunks (the usual case on a text without repeats): done
-        int any = 0;
-        for (uint64_t ch = blockIdx.x + static_cast<uint64_t>(threadIdx.x) * gridDim.x; ch < n_chunks; ch += static_cast<uint64_t>(kBlock) * gridDim.x)
-            any |= chunk_flags[ch] != 0;
-        if (!__syncthreads_or(any)) return;
-    }
+    // nothing flagged at all (the usual case on a text without repeats: the store pass located the few exceptions itself): done
+    if (chunk_flags != nullptr && *reinterpret_cast<const uint32_t *>(chunk_flags - kFlagsHead) == 0u) return;
     constexpr uint32_t kPer = kLocateChunk / kBlock;  // slots per thread
     constexpr uint32_t kLdsTexts = 256;
     __shared__ uint32_t s_map[kLocateChunk];  // (query of the slot, relative to the chunk's first, + 1) << 11 | the slot of its head
@@ -207,12 +207,13 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
     __shared__ uint32_t s_sentinels[kLdsTexts];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_carry;  // slots of the chunk's first query that lie in earlier chunks
+    __shared__ uint32_t s_ticket[2];
     const uint32_t *sentinels = sv.sentinels;
-    if (sv.n_texts <= kLdsTexts) {
+    if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ticket, 1u);
+    if (sv.n_texts <= kLdsTexts)
         for (uint32_t i = threadIdx.x; i < sv.n_texts; i += kBlock) s_sentinels[i] = sv.sentinels[i];
-        sentinels = s_sentinels;
-        __syncthreads();
-    }
+    __syncthreads();
+    if (sv.n_texts <= kLdsTexts) sentinels = s_sentinels;
     build_text_table(s_tab, sentinels, sv.n_texts, sv.tab_shift);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // {a, mask, symbols to subtract, kind} of query q with `n_slots` hit slots (a: the position, the first row, or the row)
@@ -245,14 +246,22 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             n_qb = first_query[ch + 1];
         }
     };
-    prefetch_chunk(blockIdx.x);
-    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // Chunks are handed out by ticket, in order, as blocks get done (a chunk of 2048 single hits and a chunk of one query's
+    // 2048 rows take different times: with every block striding over its own share the kernel waited for the unluckiest
+    // block -- 3.3 ms for 573 M hits on any grid the chip held at once, 2.7 ms with twice as many blocks, i.e. with the
+    // hardware handing out the second half as blocks ended).
+    uint64_t chunk = s_ticket[0];
+    prefetch_chunk(chunk);
+    for (uint32_t it = 0; chunk < n_chunks; it++) {
         const uint32_t flag = n_flag, qa = n_qa, qb = n_qb;
-        prefetch_chunk(chunk + gridDim.x);
-        if (flag == 0u) continue;  // (block-uniform; an unflagged chunk's queries were never computed)
+        if (threadIdx.x == 0) s_ticket[(it + 1u) & 1u] = atomicAdd(ticket, 1u);
+        __syncthreads();  // the next ticket is there; the previous chunk's map and descriptors are read, the table is built
+        const uint64_t next = s_ticket[(it + 1u) & 1u];
+        prefetch_chunk(next);
         const uint64_t base = chunk * kLocateChunk;
         const uint32_t cnt = total - base < kLocateChunk ? static_cast<uint32_t>(total - base) : kLocateChunk;
-        __syncthreads();  // the previous chunk's map and descriptors are read, the table is built
+        chunk = next;
+        if (flag == 0u) continue;  // (block-uniform; an unflagged chunk's queries were never computed)
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j += 4)
             *reinterpret_cast<uint4 *>(&s_map[threadIdx.x * kPer + j]) = make_uint4(0u, 0u, 0u, 0u);
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
 // rows after 8 and 16 LF steps, so one fetch offers two candidates for a sampled row (SA[r] = SA[t_j] + 8 j) where a
 // rank-line step offers one.  A level that is invalid (a sentinel or a symbol outside 1..4 within its eight steps) is
 // crossed with rank-line steps.  (Round 2 walked 32-byte entries the same way over five targets; they now carry SA[r]
-// itself: kEntrySA.)
+// itself: locate_stream_kernel.)
 // (the kernel gets the few fields of the IndexView it reads -- the whole view costs SGPRs -- and its queue shares LDS
 // with the slot -> query map, so that eight blocks fit a CU: it ran at 5 waves per SIMD before)
 struct LocateView {
@@ -388,7 +397,7 @@ struct LocateView {
     const uint64_t *g_planes;
     const uint16_t *g_block_off;
     const void *jump;
-    const uint32_t *sa_full;  // SA[row] of every row, or null (then kEntrySA reads it out of the 32-byte jump entries)
+    const uint32_t *sa_full;  // (unused here since round 5: an index with SA[row] at hand runs locate_stream_kernel)
     const uint32_t *count, *sa_samples, *border_keys, *border_vals, *sentinels;
     uint32_t sb_stride, jump_bytes, n_texts, sa_inv, sa_rot, sa_limit;
     int32_t sigma, nbits;
@@ -396,9 +405,8 @@ struct LocateView {
     uint32_t g_kind, g_wpb, g_used, g_sb;  // IndexView: which of the reference's table variants layout 1 is
 };
 
-// kEntrySA: the index has 32-byte jump entries, which carry SA[row] (layout.hpp): every hit is finished in phase 0 with
-// one fetch of its row's entry -- or with none when the search resolved it (kRecResolved) -- and nothing ever walks.
-template <class Table, bool kWide, bool kJumpWalk, bool kEntrySA>
+// (An index on which SA[row] is one fetch -- 32-byte jump entries, a full suffix array -- never comes here: locate_stream_kernel.)
+template <class Table, bool kWide, bool kJumpWalk>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void locate_queue_kernel(LocateView lv, const uint32_t *__restrict__ start,
                                                               HitOffsets hit_offsets, uint64_t m,
                                                               const uint32_t *__restrict__ first_query,
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint64_t t = *d_total;
         total = t < total ? t : total;
     }
-    if (chunk_flags != nullptr) {  // nothing flagged among this block's chunks (the usual case on a text without repeats): done
+    if (chunk_flags != nullptr && *reinterpret_cast<const uint32_t *>(chunk_flags - kFlagsHead) == 0u) return;  // nothing flagged at all
+    if (chunk_flags != nullptr) {  // nothing flagged among this block's chunks: done
         const uint64_t n_ch = (total + kLocateChunk - 1) / kLocateChunk;
         int any = 0;
         for (uint64_t ch = blockIdx.x + static_cast<uint64_t>(threadIdx.x) * gridDim.x; ch < n_ch; ch += static_cast<uint64_t>(kBlock) * gridDim.x)
@@ -559,11 +568,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 }
             }
             uint32_t slot;
-            if (kEntrySA) {
-                const uint32_t sa = lv.sa_full != nullptr ? lv.sa_full[row]
-                                                          : static_cast<const uint32_t *>(ix.jump)[static_cast<uint64_t>(row) * 8u + 6u];
-                store_hit<kWide>(ix, sa - back, hits_out, h, sentinels);
-            } else if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
+            if (sampled_slot(ix, row, slot)) {  // sampled_suffix_array.rs:133-136 with zero steps
                 store_hit<kWide>(ix, ix.sa_samples[slot] - back, hits_out, h, sentinels);
             } else {
                 // (a hinted row that is not sampled comes from the search's lazy tail: the walk starts there)
@@ -572,7 +577,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 s_idx[k] = i | (back << 11);
             }
         }
-        if (kEntrySA) continue;  // nothing was queued (the loop's first barrier orders the next chunk's LDS writes)
         __syncthreads();
         const uint32_t queued = s_n;
         if (step_stats && threadIdx.x == 0) atomicAdd(step_stats + 1, static_cast<unsigned long long>(queued));
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!__any(have)) break;
             bool jumped = false;
             if (kJumpWalk && have) {
-                // levels of the entry of `row` (layout.hpp; 16-byte entries here, 32-byte ones take the kEntrySA path):
+                // levels of the entry of `row` (layout.hpp; 16-byte entries here, 32-byte ones run locate_stream_kernel):
                 // first the sampled target nearest to row, else as far as the valid levels reach
                 const u32x4 e0 = *reinterpret_cast<const u32x4 *>(static_cast<const uint32_t *>(ix.jump) +
                                                                  static_cast<uint64_t>(row) * 4u);
@@ -961,6 +965,7 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
                             // (chunks that begin at or beyond the capacity have no flag, and nothing of them is located)
                             for (uint64_t ch = at / kLocateChunk; ch <= (at + c[j] - 1u) / kLocateChunk && ch * kLocateChunk < ss.hits_capacity; ch++)
                                 ss.chunk_flags[ch] = 1;
+                            *reinterpret_cast<uint32_t *>(ss.chunk_flags - kFlagsHead) = 1u;  // (the "any chunk flagged" word)
                         }
                     }
                 }
@@ -1041,13 +1046,19 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
 
 // where launch_scan_offsets_store / launch_locate keep the chunk flags inside a locate workspace of locate_workspace_bytes(total)
 // (behind the first-query table of the chunks, which takes n_chunks + 1 of the workspace's total x 4 bytes)
+// The flags of a locate workspace: kFlagsHead bytes in front of them hold ONE word that says whether any chunk is flagged at
+// all (the locate kernels of a sparse step read that word and leave), then one byte per chunk.  The offset is that of the
+// flag bytes; what is zeroed is the region from the word on (locate_flags_region).
 size_t locate_chunk_flags_offset(uint64_t total_hits)
 {
     const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
-    return align_up((n_chunks + 2) * sizeof(uint32_t), 256);
+    return align_up((n_chunks + 2) * sizeof(uint32_t), 256) + kFlagsHead;
 }
 
 size_t locate_chunk_flags_bytes(uint64_t total_hits) { return (total_hits + kLocateChunk - 1) / kLocateChunk + 1; }
+// (what a caller zeroes before the store pass: the "any" word and the flag bytes)
+void *locate_flags_region(uint8_t *d_chunk_flags) { return d_chunk_flags - kFlagsHead; }
+size_t locate_flags_region_bytes(uint64_t total_hits) { return kFlagsHead + locate_chunk_flags_bytes(total_hits); }
 
 size_t scan_totals_workspace_bytes(uint64_t m) { return ((m + kScan2Tile - 1) / kScan2Tile + 2) * sizeof(unsigned long long); }
 
@@ -1088,7 +1099,8 @@ void launch_scan_offsets_store(const IndexView &ix, const uint4 *d_rec, const ui
     const RecordSize f{d_rec, d_compact, m, max_hits, take};
     const uint64_t n_tiles = (m + kScan2Tile - 1) / kScan2Tile;
     const unsigned long long *sums = static_cast<const unsigned long long *>(d_scan_workspace);
-    if (d_chunk_flags != nullptr && !flags_zeroed) GDX_HIP(hipMemsetAsync(d_chunk_flags, 0, locate_chunk_flags_bytes(hits_capacity), stream));
+    if (d_chunk_flags != nullptr && !flags_zeroed)
+        GDX_HIP(hipMemsetAsync(locate_flags_region(d_chunk_flags), 0, locate_flags_region_bytes(hits_capacity), stream));
     // (grids the chip holds at once: every block strides over many tiles)
     static const unsigned cap_plain = resident_blocks(scan2_tile_scan_kernel<false, false>);
     static const unsigned cap_store = resident_blocks(scan2_tile_scan_kernel<true, false>);
@@ -1525,7 +1537,7 @@ void launch_locate_step(const IndexView &ix, const LocateStep &step, hipStream_t
     uint8_t *flags = store ? static_cast<uint8_t *>(step.d_workspace) + locate_chunk_flags_offset(step.hits_capacity) : nullptr;
     ZeroSet zero;
     zero.add(totals, 2 * sizeof(unsigned long long));
-    if (flags != nullptr) zero.add(flags, locate_chunk_flags_bytes(step.hits_capacity));
+    if (flags != nullptr) zero.add(locate_flags_region(flags), locate_flags_region_bytes(step.hits_capacity));
     if (nq == 0) {
         zero.add(step.d_hit_offsets, step.narrow ? sizeof(uint32_t) : sizeof(uint64_t));
         zero.flush(st);
@@ -1585,7 +1597,7 @@ void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, u
 // the first-query table of the chunks (n_chunks + 1 entries), then the chunk flags (locate_chunk_flags_offset)
 size_t locate_workspace_bytes(uint64_t total_hits)
 {
-    return locate_chunk_flags_offset(total_hits) + align_up(locate_chunk_flags_bytes(total_hits) + 4, 256) + 256;
+    return locate_chunk_flags_offset(total_hits) + align_up(locate_chunk_flags_bytes(total_hits) + 4, 256) + 256;  // (+ the ticket: entry n_chunks + 1 of the table)
 }
 
 void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t *d_end, uint64_t m,
@@ -1606,24 +1618,17 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     {
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
         uint32_t *first = static_cast<uint32_t *>(d_workspace);  // n_chunks + 1 entries of the workspace
+        uint32_t *ticket = first + n_chunks + 1;                 // (the table's spare entry: zeroed by chunk_first_query_kernel)
         hipLaunchKernelGGL(chunk_first_query_kernel, dim3(static_cast<unsigned>((n_chunks + kBlock) / kBlock)),
-                           dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first, d_total, d_chunk_flags);
+                           dim3(kBlock), 0, stream, offs, m, n_chunks, kLocateChunk, total_hits, first, d_total, d_chunk_flags, ticket);
         // (with chunk flags few chunks have anything to do: a grid the chip holds at once, every block looks at its share
         // of the flags first)
         const uint64_t grid_cap = d_chunk_flags != nullptr ? 2048u : 65536u;
         const unsigned qgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
                                                  : static_cast<unsigned>(n_chunks < grid_cap ? n_chunks : grid_cap);
-#define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                     \
-    do {                                                                                                                  \
-        if (entry_sa)                                                                                                     \
-            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, false, true>), dim3(qgrid), dim3(kBlock), 0, stream, lv, \
-                               d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
-                               d_compact, d_chunk_flags, d_total);                                                        \
-        else                                                                                                              \
-            hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW, false>), dim3(qgrid), dim3(kBlock), 0, stream, lv,   \
-                               d_start, offs, m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats,                  \
-                               d_compact, d_chunk_flags, d_total);                                                        \
-    } while (0)
+#define GDX_LOCATE_Q(TABLE, WIDE, JW)                                                                                   \
+    hipLaunchKernelGGL((locate_queue_kernel<TABLE, WIDE, JW>), dim3(qgrid), dim3(kBlock), 0, stream, lv, d_start, offs, \
+                       m, first, d_hint, d_rec, total_hits, d_hits, d_step_stats, d_compact, d_chunk_flags, d_total)
         // the walk goes through the jump table when there is one with at least two levels, unless the caller
         // counts the reference's own walk steps (reference_walk) or switched it off (QueryOptions::locate_jump_walk)
         const LocateView lv{ix.lines, ix.sb_offsets, ix.g_planes, ix.g_block_off, ix.jump, ix.sa_full, ix.count, ix.sa_samples,
@@ -1635,8 +1640,7 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
         // SA[row] inside the entries, or as an array of its own: no walk at all
         const bool entry_sa = (jump_walk && ix.jump_bytes == 32) ||
                               (ix.layout == 0 && ix.sa_full != nullptr && !reference_walk && qo.locate_jump_walk != 0);
-        static const bool env_no_stream = getenv("GDX_LOCATE_NO_STREAM") != nullptr;  // debug: the queue kernel on every index
-        if (entry_sa && d_step_stats == nullptr && !env_no_stream) {
+        if (entry_sa) {  // (nothing walks: a caller's step statistics stay zero)
             uint32_t shift = 0;
             while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
             const StreamView sv{ix.sa_full, ix.sa_full == nullptr ? static_cast<const uint32_t *>(ix.jump) : nullptr, ix.sentinels,
@@ -1648,10 +1652,10 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
                                                      : static_cast<unsigned>(n_chunks < s_cap ? n_chunks : s_cap);
             if (wide)
                 hipLaunchKernelGGL(locate_stream_kernel<true>, dim3(sgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, first, d_hint,
-                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total);
+                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total, ticket);
             else
                 hipLaunchKernelGGL(locate_stream_kernel<false>, dim3(sgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, first, d_hint,
-                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total);
+                                   d_rec, total_hits, d_hits, d_compact, d_chunk_flags, d_total, ticket);
         } else if (ix.layout == 0) {
             if (wide && jump_walk) GDX_LOCATE_Q(LineTable, true, true);
             else if (wide) GDX_LOCATE_Q(LineTable, true, false);
