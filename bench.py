@@ -110,6 +110,9 @@ def parse_args():
                     help="skip the rocprofv3 PMC child passes (roofline.traffic then falls back to the committed "
                          "summary under profiles/ and says so)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling measurement")
+    ap.add_argument("--root-weight", type=float, default=None,
+                    help="N > 1, the sharded batch: rank 0's shard as a fraction of every other rank's (rank 0 also splits the "
+                         "shards it receives).  Default: dist.root_weight_for from a probe of the links; 1 = equal shards")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
     ap.add_argument("--input", default="auto", choices=["auto", "ascii", "uniform", "packed", "packed+uniform"],
                     help="how the batch lies in HBM when the timed region starts (gdx_query_layout_t): ascii = IO symbols + "
@@ -1197,8 +1200,12 @@ def compact_line(result, side_file=None):
         line["strong_scaling"] = _pick(result["strong_scaling"], ("value", "ms_per_step", "queries_total"))
     e = result.get("end_to_end")
     if e and "error" not in e:
-        line["end_to_end"] = _pick(e, ("count_qps", "locate_qps", "pcie_h2d_GBps", "pcie_d2h_GBps", "count_over_bound",
-                                            "locate_over_bound"))
+        line["end_to_end"] = _pick(e, ("count_qps", "locate_qps", "pcie_h2d_GBps", "pcie_d2h_GBps", "pcie_both_directions_GBps_total",
+                                            "count_over_bound", "locate_over_bound"))
+        if isinstance(e.get("packed_queries"), dict) and "host_packing_GBps_of_ascii" in e["packed_queries"]:
+            line["end_to_end"]["host_packing_GBps_of_ascii"] = e["packed_queries"]["host_packing_GBps_of_ascii"]
+        if isinstance(e.get("fastq_to_hits"), dict) and "fastq_to_hits_qps" in e["fastq_to_hits"]:
+            line["end_to_end"]["fastq_to_hits_qps"] = e["fastq_to_hits"]["fastq_to_hits_qps"]
         if isinstance(e.get("packed_uniform"), dict):
             line["end_to_end"]["packed_uniform"] = _pick(e["packed_uniform"], ("count_qps", "locate_qps", "count_over_bound",
                                                                                   "locate_over_bound", "locate32_qps", "locate32_over_bound",
@@ -1411,7 +1418,13 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
     from genedex_amd.device import DeviceQueries
 
     full = DeviceQueries.synth(io_text, lengths, nq_total, wl["len_min"], wl["len_max"], wl["sampled_ppm"], seed=43)
-    lo, hi = gdist.shard_range(nq_total, rank, world)
+    # rank 0's shard relative to the others': from the rate this run's links deliver into rank 0 (a probe gather) and the
+    # one-GPU costs of a step and of the root's split (dist.root_weight_for)
+    link_rate = gdist.gather_rate_probe(dev)
+    seeded = eng.index.seed_info()["k"] != 0 and do_locate
+    root_weight = args.root_weight if args.root_weight is not None else \
+        gdist.root_weight_for(world, nq_total, link_rate, gdist.WIRE_BYTES_PER_READ if seeded else 5.5)
+    lo, hi = gdist.shard_range(nq_total, rank, world, root_weight)
     # (a rank holds its shard as a batch of its own: the form --input names is made from that)
     shard = input_form(full.copy_slice(lo, hi) if args.input != "ascii" else full.slice(lo, hi), eng.index, args, wl)
     runner = StepRunner(torch, eng, shard, hi - lo, do_locate, args.path, hint=not args.no_hint, n_slots=2)
@@ -1421,7 +1434,7 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
     elapsed, last = timed_steps(torch, gdist, runner, steps, args.warmup, dev, gather, count_of)
     ms = elapsed / steps * 1e3
     res = {"scaling": "strong", "value": nq_total / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
-           "queries_total": nq_total, "queries_this_rank": hi - lo, "steps": steps,
+           "queries_total": nq_total, "queries_this_rank": hi - lo, "steps": steps, "root_weight": root_weight, "gather_probe_GBps_per_link": link_rate,
            "kernel_ms_rank0": {"search": runner.mean_ms(runner.ev_search), "locate": runner.mean_ms(runner.ev_locate)},
            "gathered_bytes_per_rank_and_step": nbytes}
     runner.check_totals()
@@ -1434,7 +1447,7 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
     # bit-exactness: concatenated shards == the one-rank output
     sizes = gdist.gather_ints(runner.total_hits, dev)
     if rank == 0:
-        shard_len = [gdist.shard_range(nq_total, r, world) for r in range(world)]
+        shard_len = [gdist.shard_range(nq_total, r, world, root_weight) for r in range(world)]
         cnt_cat, hit_cat = gathered_shards(torch, gdist, gather, last, shard_len, sizes, do_locate)
         res["gather_wire"] = getattr(gather, "wire_name", "compact" if getattr(gather, "compact_wire", False) else "arrays")
         del gather, runner
@@ -1918,7 +1931,25 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
         return (1 << 30) / best / 1e9
 
     h2d, d2h = copy_rate(dbuf, pin), copy_rate(pin, dbuf)
-    del pin, dbuf
+    # both directions at once on two streams: what a pipeline that copies in and out together gets of the link (this platform
+    # serves the two directions at not much more than ONE direction's rate in all -- profiles/r05/README.md -- so the bound
+    # of a host-pointer call is (bytes in + bytes out) / this rate, not the slower of the two directions alone)
+    pin2 = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf2 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    duplex = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s_in):
+            dbuf.copy_(pin, non_blocking=True)
+        with torch.cuda.stream(s_out):
+            pin2.copy_(dbuf2, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        duplex = dt if duplex is None or dt < duplex else duplex
+    duplex = 2 * (1 << 30) / duplex / 1e9
+    del pin, dbuf, pin2, dbuf2
     counts = np.empty(nq, dtype=np.uint64)
     status = np.empty(nq, dtype=np.uint8)
     u8p, u64p = _lib.u8p, _lib.u64p
@@ -1966,13 +1997,18 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
     in_bytes = nbytes + 8 * (nq + 1)
     out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
     out_locate_bytes = 5 * nq + 8 * total_hits
-    bound_count = max(in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3)
-    bound_locate = max(in_bytes / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3)
+    def bound(n_in, n_out, kernel_ms):
+        return max(n_in / (h2d * 1e9), n_out / (d2h * 1e9), (n_in + n_out) / (duplex * 1e9), kernel_ms / 1e3)
+
+    bound_count = bound(in_bytes, out_count_bytes, search_ms)
+    bound_locate = bound(in_bytes, out_locate_bytes, step_ms)
     res = {"count_qps": nq / t_count, "count_seconds": t_count, "locate_qps": nq / t_locate, "locate_seconds": t_locate,
-           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "h2d_bytes": in_bytes, "d2h_bytes_count": out_count_bytes,
+           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "pcie_both_directions_GBps_total": duplex, "h2d_bytes": in_bytes,
+           "d2h_bytes_count": out_count_bytes,
            "d2h_bytes_locate": out_locate_bytes,
            "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
-           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, kernel time)",
+           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, (H2D + D2H bytes) / the rate of both "
+                    "directions at once, kernel time)",
            "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
                     "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
            "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
@@ -2060,19 +2096,98 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
             out_locate32_bytes = 5 * nq + 4 + 8 * total_hits
             res["packed_uniform"] = {
                 "count_qps": nq / t_c, "count_seconds": t_c, "locate_qps": nq / t_l, "locate_seconds": t_l, "h2d_bytes": in_pu,
-                "count_over_bound": t_c / max(in_pu / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
-                "locate_over_bound": t_l / max(in_pu / (h2d * 1e9), out_locate_bytes / (d2h * 1e9), step_ms / 1e3),
+                "count_over_bound": t_c / bound(in_pu, out_count_bytes, search_ms),
+                "locate_over_bound": t_l / bound(in_pu, out_locate_bytes, step_ms),
                 "locate32_qps": nq / t_l32, "locate32_seconds": t_l32,
-                "locate32_over_bound": t_l32 / max(in_pu / (h2d * 1e9), out_locate32_bytes / (d2h * 1e9), step_ms / 1e3),
+                "locate32_over_bound": t_l32 / bound(in_pu, out_locate32_bytes, step_ms),
                 "locate32_pinned_input_qps": nq / t_l32p, "locate32_pinned_input_seconds": t_l32p,
-                "locate32_pinned_input_over_bound": t_l32p / max(in_pu / (h2d * 1e9), out_locate32_bytes / (d2h * 1e9), step_ms / 1e3),
+                "locate32_pinned_input_over_bound": t_l32p / bound(in_pu, out_locate32_bytes, step_ms),
                 "d2h_bytes_locate32": out_locate32_bytes,
                 "calls": "gdx_count_many_layout / gdx_locate_many_alloc_layout, layout = {packed, uniform_len}: 2-bit codes, no "
                          "offsets; locate32 = gdx_locate_many_alloc_layout32 (u32 offsets + 8-byte hits in pinned memory of the "
                          "library's, written by the device; pinned_input: the 2-bit codes lie in pinned memory too, no staging copy)",
                 "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t, "narrow_equals_wide": same_32}}
+    try:
+        res["fastq_to_hits"] = fastq_to_hits(np, index, qbuf, qoff, nq, offs)
+    except OSError as e:  # (no room for the file)
+        res["fastq_to_hits"] = {"error": repr(e)}
     log(f"[bench] end to end: {res}")
     return res
+
+
+def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=8_000_000):
+    """A FASTQ file of the batch's first reads -> gdx_fastx_next_batch (the library's streaming reader) -> gdx_pack_queries_table
+    (2-bit codes, host threads) -> gdx_locate_many_alloc_layout32, the reader running one batch ahead of the GPU calls in a
+    thread of its own.  What the reference's ROADMAP.md:35-37 worries about: reading the queries can cost more than searching
+    them -- here it does, by three orders of magnitude (one thread parses the file)."""
+    import ctypes as C
+    import queue
+    import tempfile
+    import threading
+
+    from genedex_amd import _lib, alphabet, fastx
+
+    lib = _lib.load()
+    n = int(min(n_reads, nq))
+    lens = np.diff(qoff[: n + 1].astype(np.int64))
+    if n == 0 or not bool((lens == lens[0]).all()):
+        return None
+    ln = int(lens[0])
+    rec = np.empty((n, ln * 2 + 7), dtype=np.uint8)  # "@r\n" + read + "\n+\n" + quality + "\n"
+    rec[:, 0], rec[:, 1], rec[:, 2] = ord("@"), ord("r"), 10
+    rec[:, 3: 3 + ln] = qbuf[: n * ln].reshape(n, ln)
+    rec[:, 3 + ln], rec[:, 4 + ln], rec[:, 5 + ln] = 10, ord("+"), 10
+    rec[:, 6 + ln: 6 + 2 * ln] = ord("I")
+    rec[:, 6 + 2 * ln] = 10
+    with tempfile.NamedTemporaryFile(prefix="gdx_bench_", suffix=".fq", dir="/tmp", delete=False) as f:
+        path = f.name
+    try:
+        rec.tofile(path)
+        file_bytes = os.path.getsize(path)
+        del rec
+        alpha = alphabet.ascii_dna_with_n()
+        t0 = time.perf_counter()
+        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=1 << 20, buffer_bytes=1 << 27))
+        t_reader = time.perf_counter() - t0
+        q = queue.Queue(maxsize=2)
+
+        def producer():
+            for b in fastx.read_packed_batches(path, alpha, max_records=1 << 20, buffer_bytes=1 << 27):
+                q.put((b["packed"].copy(), b["nq"], b["uniform_len"], b["exceptions"].size))
+            q.put(None)
+
+        lay = _lib.QueryLayout()
+        lib.gdx_query_layout_init(C.byref(lay))
+        status = np.empty(1 << 20, dtype=np.uint8)
+        t0 = time.perf_counter()
+        th = threading.Thread(target=producer)
+        th.start()
+        hits, reads, n_exc = 0, 0, 0
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            packed, bn, ul, ne = item
+            lay.packed, lay.uniform_len = 1, ul
+            r32 = _lib.Hits32()
+            _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, packed.ctypes.data_as(_lib.u8p), None, bn, C.byref(lay),
+                                                          C.byref(r32), status.ctypes.data_as(_lib.u8p)))
+            hits += r32.total_hits
+            reads += bn
+            n_exc += ne
+            lib.gdx_free_hits32(C.byref(r32))
+        th.join()
+        dt = time.perf_counter() - t0
+        same = reads == n and n_read == n and n_exc == 0 and hits == int(offs[n])
+        if not same:
+            raise SystemExit(f"PARITY FAILURE: FASTQ -> hits gave {reads} reads / {hits} hits, the device path {n} / {int(offs[n])}")
+        return {"reads": n, "file_bytes": file_bytes, "fastq_to_hits_qps": n / dt, "seconds": dt, "file_GBps": file_bytes / dt / 1e9,
+                "reader_alone_qps": n / t_reader, "reader_alone_file_GBps": file_bytes / t_reader / 1e9,
+                "hits": hits, "hits_identical_to_device_path": same,
+                "what": "FASTQ file -> gdx_fastx_next_batch -> gdx_pack_queries_table -> gdx_locate_many_alloc_layout32, reader and "
+                        "packer one batch ahead in a thread of their own"}
+    finally:
+        os.remove(path)
 
 
 def packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms):
@@ -2105,10 +2220,13 @@ def packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, searc
     packed = np.empty(int(lib.gdx_packed_bytes(nbytes)), dtype=np.uint8)
     exc = np.empty(1 << 20, dtype=np.uint64)
     n_exc = C.c_uint64(0)
-    t0 = time.perf_counter()
-    _lib.check(lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
-                                    packed.ctypes.data_as(u8p), exc.ctypes.data_as(u64p), exc.size, C.byref(n_exc)))
-    t_pack = time.perf_counter() - t0
+    t_pack = None
+    for _ in range(2):  # (the first call also touches the pages of `packed` for the first time)
+        t0 = time.perf_counter()
+        _lib.check(lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                        packed.ctypes.data_as(u8p), exc.ctypes.data_as(u64p), exc.size, C.byref(n_exc)))
+        dt = time.perf_counter() - t0
+        t_pack = dt if t_pack is None or dt < t_pack else t_pack
     counts_p = np.empty(nq, dtype=np.uint64)
 
     def count_packed_call():
@@ -2152,7 +2270,8 @@ def packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, searc
     out_count_bytes = 5 * nq
     return {"count_qps": nq / t_count_packed, "count_seconds": t_count_packed, "h2d_bytes": packed_in_bytes,
             "count_over_bound": t_count_packed / max(packed_in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
-            "host_packing_seconds_not_included": t_pack, "exception_queries": int(n_exc.value),
+            "host_packing_seconds_not_included": t_pack, "host_packing_GBps_of_ascii": nbytes / t_pack / 1e9,
+            "host_packing_reads_per_s": nq / t_pack, "exception_queries": int(n_exc.value),
             "device_search_ms_on_packed_input": packed_search_ms,
             "counts_identical_outside_the_exceptions": same_packed and same_dev,
             "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h}

@@ -38,6 +38,17 @@ public:
         uint64_t n = 0, used = 0;
         qoff[0] = 0;
         while (n < max_records) {
+            // a FASTQ record whose four lines lie in the read buffer as they are goes straight into qbuf (no line strings, no
+            // pending copy): the reader ran at a few million reads per second, far below everything behind it
+            if (!have_pending_ && !have_line_) {
+                const size_t got = fastq_record_in_place(qbuf + used, capacity - used);
+                if (got != kNoFastPath) {
+                    used += got;
+                    qoff[++n] = used;
+                    records_++;
+                    continue;
+                }
+            }
             if (!have_pending_ && !read_record()) break;
             if (pending_.size() > capacity - used) {
                 if (n == 0) fail(GDX_ERR_CAPACITY, "record %llu has %zu symbols, the buffer holds %llu",
@@ -55,6 +66,31 @@ public:
     }
 
 private:
+    static constexpr size_t kNoFastPath = ~static_cast<size_t>(0);
+    // The next record if it is a plain four-line FASTQ record that lies completely in the buffer: '@' header, ONE sequence
+    // line, '+' line, ONE quality line of the same length, no '\r', all four newlines present.  Copies the sequence to out
+    // (if it fits `room`) and returns its length; kNoFastPath = anything else (the general path decides: nothing is consumed).
+    size_t fastq_record_in_place(uint8_t *out, uint64_t room)
+    {
+        if (pos_ >= len_ || buf_[pos_] != '@') return kNoFastPath;
+        const char *p = buf_.data() + pos_, *end = buf_.data() + len_;
+        const char *h = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!h) return kNoFastPath;
+        const char *seq = h + 1;
+        const char *s_end = seq < end ? static_cast<const char *>(std::memchr(seq, '\n', static_cast<size_t>(end - seq))) : nullptr;
+        if (!s_end || s_end == seq || s_end[-1] == '\r' || s_end + 1 >= end || s_end[1] != '+') return kNoFastPath;
+        const char *plus_end = static_cast<const char *>(std::memchr(s_end + 1, '\n', static_cast<size_t>(end - (s_end + 1))));
+        if (!plus_end) return kNoFastPath;
+        const size_t n_sym = static_cast<size_t>(s_end - seq);
+        const char *q = plus_end + 1;
+        if (static_cast<size_t>(end - q) < n_sym + 1 || q[n_sym] != '\n') return kNoFastPath;  // (a '\n' inside the quality line: not this shape)
+        if (std::memchr(q, '\n', n_sym) != nullptr || (n_sym && q[n_sym - 1] == '\r')) return kNoFastPath;
+        if (n_sym > room) return kNoFastPath;  // (the general path reports or defers it)
+        std::memcpy(out, seq, n_sym);
+        pos_ = static_cast<size_t>(q + n_sym + 1 - buf_.data());
+        return n_sym;
+    }
+
     // next line without its terminator ('\n', optional '\r' before it); false at the end of the file
     bool next_line(std::string &line)
     {

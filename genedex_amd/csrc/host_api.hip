@@ -320,8 +320,9 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     Streams st;
 
     // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
-    // (the narrow locate runs a whole fused step per chunk, a dozen launches: twice the queries per chunk)
-    const uint64_t kChunkBytes = g_chunk_bytes.load(), kChunkQueries = g_chunk_queries.load() * (kind == Kind::kLocate32 ? 2 : 1);
+    // (a chunk's limit counts the bytes that cross the link: four symbols per byte of a packed batch; the narrow locate runs a
+    // whole fused step per chunk, a dozen launches, and takes up to four times the queries)
+    const uint64_t kChunkBytes = g_chunk_bytes.load() * (packed ? 4 : 1), kChunkQueries = g_chunk_queries.load() * (kind == Kind::kLocate32 ? 4 : 1);
     std::vector<Chunk> chunks;
     // (uniform: every chunk but the last holds a multiple of 8 queries, so that a chunk starts on a 16-bit unit of a packed
     // buffer and on a byte of an ASCII one, and is a uniform batch of its own)
@@ -346,7 +347,8 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         max_nq = std::max(max_nq, c.nq);
         max_bytes = std::max(max_bytes, c.bytes);
     }
-    const uint64_t qbuf_cap = div_ceil(max_bytes + 1, 8) * 8 + 16;  // (packed: max_bytes counts symbols, 4 per byte)
+    // (packed: max_bytes counts symbols, four per byte, and a chunk starts up to seven symbols before its first query)
+    const uint64_t qbuf_cap = div_ceil((packed ? div_ceil(max_bytes + 8, 4) : max_bytes) + 1, 8) * 8 + 24;
 
     // per-slot buffers (ids: slot * 16 + n)
     uint8_t *h_in[kSlots], *d_qbuf[kSlots], *h_status[kSlots], *d_status[kSlots];

@@ -12,11 +12,66 @@ import torch
 import torch.distributed as dist
 
 
-def shard_range(n_items: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of rank; shards differ in size by at most one item."""
-    lo = n_items * rank // world
-    hi = n_items * (rank + 1) // world
-    return lo, hi
+def shard_range(n_items: int, rank: int, world: int, root_weight: float = 1.0):
+    """Contiguous shard [lo, hi) of rank; shards differ in size by at most one item.
+    root_weight != 1: rank 0's shard is that fraction of every other rank's -- the root of a gather also splits what it
+    receives (root_weight_for), so a smaller shard of its own evens out what the GPUs have to do."""
+    if root_weight == 1.0 or world == 1:
+        lo = n_items * rank // world
+        hi = n_items * (rank + 1) // world
+        return lo, hi
+    total = root_weight + (world - 1)
+    cut = lambda r: 0 if r == 0 else min(n_items, int(n_items * (root_weight + (r - 1)) / total))  # noqa: E731
+    return cut(rank), (n_items if rank == world - 1 else cut(rank + 1))
+
+
+# One-GPU measurements behind the shard sizes of a gathered batch (profiles/r05/shard_step.json; an MI355X, the headline
+# index): a count + locate step costs STEP_FIXED_MS + STEP_PS_PER_READ per read, the root's split of a received read
+# (gdx_wire_split_dev) SPLIT_PS_PER_READ, a read travels as WIRE_BYTES_PER_READ bytes, and a link into the root carries one
+# direction of an xGMI link.
+STEP_FIXED_MS, STEP_PS_PER_READ, SPLIT_PS_PER_READ, WIRE_BYTES_PER_READ, XGMI_ONE_DIRECTION_GBPS = 0.105, 31.0, 2.56, 3.725, 76.8
+
+
+def root_weight_for(world: int, n_reads: int = 100_000_000, link_GBps: float = XGMI_ONE_DIRECTION_GBPS,
+                    bytes_per_read: float = WIRE_BYTES_PER_READ) -> float:
+    """rank 0's shard relative to every other rank's such that the root's work on a step -- its own shard's step and the
+    split of the world - 1 shards it receives -- takes as long as a link needs for one of those shards (the links bound a
+    gathered step: DESIGN.md section 6).  With s reads per other rank, s = n / (world - 1 + w):
+        STEP_FIXED + s (w STEP + (world - 1) SPLIT) = s L,   L = bytes per read / link rate
+    Slow links (or a few fast GPUs) give the root MORE than the others, many ranks less: 1.40 / 1.18 / 0.73 at 2 / 4 / 8
+    ranks with the numbers above.  Clamped to [0.25, 2]."""
+    if world <= 1:
+        return 1.0
+    fixed_ps = STEP_FIXED_MS * 1e9 / max(n_reads, 1)  # the fixed part of a step, spread over the batch's reads
+    link_ps = bytes_per_read / max(link_GBps, 1e-3) * 1e3
+    w = (link_ps - (world - 1) * (SPLIT_PS_PER_READ + fixed_ps)) / (STEP_PS_PER_READ + fixed_ps)
+    return float(min(2.0, max(0.25, w)))
+
+
+def gather_rate_probe(device, nbytes: int = 64 << 20, reps: int = 3) -> float:
+    """GB/s one rank's buffer reaches rank 0 at while all ranks send at once (what a gathered step sees of a link); the
+    same number on every rank.  A few gathers of `nbytes` per rank, timed on the host around a synchronisation."""
+    import time
+
+    rank, n = world()
+    if n == 1:
+        return XGMI_ONE_DIRECTION_GBPS
+    t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    out = [torch.empty_like(t) for _ in range(n)] if rank == 0 else None
+    best = None
+    for _ in range(reps + 1):  # (the first one also sets the connections up)
+        dist.barrier()
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.gather(t, out, dst=0)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    rate = torch.tensor([nbytes / best / 1e9], dtype=torch.float64, device=device)
+    dist.broadcast(rate, src=0)  # (rank 0 waits for everybody's bytes: its time is the gather's)
+    return float(rate.item())
 
 
 def world():

@@ -443,6 +443,44 @@ def test_found_bitmap_wire_equals_compact_split_and_reference(n_texts, nq):
                 assert layout.payload_bytes(dq.nq, n_found, n_exc, n_exc_hits) < 4 * dq.nq + 4 * n_exc + 5 * n_exc_hits
 
 
+def test_query_buffer_of_exactly_the_contracts_size():
+    """gdx.h asks for a query buffer "padded to a multiple of 8 bytes", no more: a batch whose bytes ARE a multiple of 8 lies in
+    a device buffer of exactly that size (the ASCII lane kernel's window of the last read once reached 8 bytes past it; it
+    now loads its last dword only when the window needs it).  Counts and hits are the oracle's for every alignment of the
+    last read's end."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(4242)
+    texts = [bytes(b"ACGT"[i] for i in rng.integers(0, 4, 20000)) for _ in range(3)]
+    a = alph.ascii_dna()
+    g = gpu_index(texts, a, seed_symbols=10, full_suffix_array=True, **LEAN)
+    c = cpu_index(texts, a)
+    eng = DeviceEngine(g)
+    for tail in range(8):  # the last read ends at every residue mod 8; the buffer ends with it, rounded up to 8
+        qs = [texts[int(rng.integers(0, 3))][p:p + 56] for p in rng.integers(0, 19000, 200)]
+        qs.append(texts[0][100:100 + 56 + tail])
+        qbuf, qoff = pack_queries(qs)
+        total = int(qoff[-1])
+        exact = np.zeros((total + 7) // 8 * 8, dtype=np.uint8)
+        exact[:total] = qbuf[:total]
+        dq = DeviceQueries(torch.from_numpy(exact).cuda(), torch.from_numpy(qoff.astype(np.int64)).cuda(), len(qs), total)
+        assert dq.qbuf.numel() == (total + 7) // 8 * 8
+        rec, cmp_ = eng.alloc_records(dq.nq), eng.alloc_compact(dq.nq)
+        sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        co, ct, cp = c.locate_many(qs)
+        off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+        hits = torch.empty((int(co[-1]) + 1, 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(hits.shape[0]), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_step(dq, rec, cmp_, sws, totals, off, hits, ws)
+        torch.cuda.synchronize()
+        assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist(), tail
+        h = hits[: int(co[-1])].cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct.astype(np.uint32).tolist() and h[:, 1].tolist() == cp.astype(np.uint32).tolist(), tail
+
+
 def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()

@@ -32,7 +32,15 @@ def test_bench_two_ranks_on_one_gpu(wire):
     # alone and compared the concatenated shards bit for bit; the every-rank-its-own-batch number sits beside it
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
     assert "ONE batch of 1000000 reads sharded over 2 GPUs" in d["config"]["workload"]
-    assert d["config"]["queries_total"] == 1_000_000 and d["config"]["queries_per_gpu"] == 500_000 and d["value"] > 0
+    # (rank 0's shard is the smaller one: it also splits the shard it receives -- dist.root_weight_for)
+    sys.path.insert(0, ROOT)
+    from genedex_amd import dist as gdist
+
+    full = json.load(open(os.path.join(ROOT, d["side_file"]) if not os.path.isabs(d["side_file"]) else d["side_file"]))
+    st = full["strong_scaling"]
+    lo0, hi0 = gdist.shard_range(1_000_000, 0, 2, st["root_weight"])
+    assert 0.25 <= st["root_weight"] <= 2.0 and st["gather_probe_GBps_per_link"] > 0
+    assert d["config"]["queries_total"] == 1_000_000 and d["config"]["queries_per_gpu"] == hi0 - lo0 and d["value"] > 0
     assert abs(d["value"] - 1_000_000 / (d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
     # arrays: 1-byte counts + 5 bytes per hit (text id byte + int32 position); compact: 4 bytes per query + the exceptions
     assert d["config"]["gathered_bytes_per_rank_and_step"] > 500_000
@@ -42,9 +50,8 @@ def test_bench_two_ranks_on_one_gpu(wire):
     assert d["cpu_baseline"] is None  # N = 1 only
     w = d["weak_scaling"]
     assert w["queries_per_gpu"] == 1_000_000 and w["value"] > 0 and w["gathered_bytes_per_rank_and_step"] > 1_000_000
-    full = json.load(open(os.path.join(ROOT, d["side_file"]) if not os.path.isabs(d["side_file"]) else d["side_file"]))
-    st = full["strong_scaling"]
-    assert st["scaling"] == "strong" and st["queries_total"] == 1_000_000 and st["queries_this_rank"] == 500_000
+    assert st["scaling"] == "strong" and st["queries_total"] == 1_000_000 and st["queries_this_rank"] == hi0 - lo0
+    assert d["results_sharded"]["value"] > 0 and st["results_sharded"]["ms_per_step"] > 0  # the same step without the gather
     assert st["shards_equal_single_rank_output"] == {"counts": True, "hits": True} and st["gather_wire"] == wire
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything profiles/r04/*final* is made of, on the GPU box (via gpurun, from the repo root):
-#   tools/final_profiles_r4.sh <tag> [bench|all]
+# Everything profiles/r0N/*final* is made of, on the GPU box (via gpurun, from the repo root; rounds 4 and 5):
+#   tools/final_profiles.sh <tag> [bench|all]
 # bench: the bench line + its side file + the PMC fallback summary + rocprofv3 kernel stats of the same command
 # all  : + the full GPU test suite, the four input forms, the C host, a parity sweep
 set -u

@@ -30,11 +30,32 @@ packed = np.zeros(int(lib.gdx_packed_bytes(int(qoff[-1]))), dtype=np.uint8)
 n_exc = C.c_uint64(0)
 _lib.check(lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
                                 packed.ctypes.data_as(_lib.u8p), None, 0, C.byref(n_exc)))
-for name, buf, off, pk, ul in (("packed+uniform", packed, None, True, 50), ("ascii", qbuf, qoff, False, 0)):
+lay = _lib.QueryLayout()
+lib.gdx_query_layout_init(C.byref(lay))
+lay.packed, lay.uniform_len = 1, 50
+status = np.empty(nq, dtype=np.uint8)
+pinned = torch.from_numpy(packed).pin_memory()
+
+
+def locate32(ptr, what):
     for rep in range(3):
+        res = _lib.Hits32()
+        t0 = time.perf_counter()
+        _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, ptr, None, nq, C.byref(lay), C.byref(res), status.ctypes.data_as(_lib.u8p)))
+        dt = time.perf_counter() - t0
+        print(f"locate32 {what} rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s, {res.total_hits} hits", flush=True)
+        lib.gdx_free_hits32(C.byref(res))
+
+
+for chunk_q in (0, 4 << 20):  # (the library's default chunking, then larger chunks)
+    lib.gdx_debug_set_host_chunking(chunk_q, (128 << 20) if chunk_q else 0)
+    print(f"--- chunk queries {chunk_q or 'default'}", flush=True)
+    locate32(packed.ctypes.data_as(_lib.u8p), "pageable input")
+    locate32(C.cast(C.c_void_p(pinned.data_ptr()), _lib.u8p), "pinned input")
+lib.gdx_debug_set_host_chunking(0, 0)
+for name, buf, off, pk, ul in (("packed+uniform", packed, None, True, 50),):
+    for rep in range(2):
         t0 = time.perf_counter()
         index.count_layout_raw(buf, off, nq, packed=pk, uniform_len=ul)
         t1 = time.perf_counter()
-        o, t, p, _ = index.locate_layout_raw(buf, off, nq, packed=pk, uniform_len=ul)
-        t2 = time.perf_counter()
-        print(f"{name} rep {rep}: count {t1 - t0:.4f}s locate {t2 - t1:.4f}s (incl. the copy of {int(o[-1])} hits into numpy)", flush=True)
+        print(f"{name} rep {rep}: count {t1 - t0:.4f}s", flush=True)
