@@ -2093,7 +2093,13 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
             if not same_c or not same_t or not same_32:
                 raise SystemExit("PARITY FAILURE: the packed + uniform host calls disagree with the device-resident path")
             in_pu = (nq * ulen + 3) // 4
-            out_locate32_bytes = 5 * nq + 4 + 8 * total_hits
+            # what the narrow call's results cross the link as (host_api.hip: the found-bitmap wire, expanded by host threads): a bit
+            # per read, 4 bytes (+ a text id byte) per read with one hit, {read, count} + 8 bytes per hit for the others with hits
+            cnts = np.diff(offs.astype(np.int64))
+            n_one, n_more = int((cnts == 1).sum()), int((cnts > 1).sum())
+            id_bytes = 1 if int(index.info.num_texts) > 1 else 0
+            out_locate32_bytes = nq // 8 + 8 * (nq // 2048 + 2) + (4 + id_bytes) * n_one + 8 * n_more + 8 * int(cnts[cnts > 1].sum())
+            del cnts
             res["packed_uniform"] = {
                 "count_qps": nq / t_c, "count_seconds": t_c, "locate_qps": nq / t_l, "locate_seconds": t_l, "h2d_bytes": in_pu,
                 "count_over_bound": t_c / bound(in_pu, out_count_bytes, search_ms),
@@ -2105,7 +2111,8 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
                 "d2h_bytes_locate32": out_locate32_bytes,
                 "calls": "gdx_count_many_layout / gdx_locate_many_alloc_layout, layout = {packed, uniform_len}: 2-bit codes, no "
                          "offsets; locate32 = gdx_locate_many_alloc_layout32 (u32 offsets + 8-byte hits in pinned memory of the "
-                         "library's, written by the device; pinned_input: the 2-bit codes lie in pinned memory too, no staging copy)",
+                         "library's; the results cross PCIe as the found-bitmap wire -- d2h_bytes_locate32 -- and host threads expand "
+                         "them; pinned_input: the 2-bit codes lie in pinned memory too, no staging copy)",
                 "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t, "narrow_equals_wide": same_32}}
     try:
         res["fastq_to_hits"] = fastq_to_hits(np, index, qbuf, qoff, nq, offs)

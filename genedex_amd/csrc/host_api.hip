@@ -32,6 +32,7 @@
 #include "fm_index.hpp"
 #include "kernels.hpp"
 #include "pack_host.hpp"
+#include "wire_host.hpp"
 
 namespace gdx {
 
@@ -306,7 +307,24 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // uniform_len != 0: query i = symbols [i * uniform_len, (i + 1) * uniform_len) of the buffer, qoff is not looked at: no
     // offsets are staged, copied or read by the kernels (gdx_query_layout_t)
     const Kind kind = static_cast<Kind>(kind_i);
-    WorkerPool pool(host_threads());
+    // Narrow locate (Kind::kLocate32): by default the results do not cross the link as offsets and hits but as the "found
+    // bitmap" wire the multi-GPU gather uses (launch_wire_pack: a bit per read, 4 bytes per found read, the exceptions with
+    // their hits -- 3.7 bytes per read instead of 12.2), and the drainer's workers expand them into the sink's arrays
+    // (wire_host.hpp): the link's two directions share its rate (65 GB/s together on the test box against 57 alone), so
+    // bytes saved going out are time saved.  GDX_HOST_NARROW=dma: the device-written form (hosts with few cores to spare).
+    // Collections of many texts take that form too: the host's text lookup is a binary search per hit where blocks hold
+    // several borders, and the device does that better.
+    static const int narrow_mode = [] {
+        const char *e = getenv("GDX_HOST_NARROW");
+        if (e && std::strcmp(e, "dma") == 0) return 0;
+        if (e && std::strcmp(e, "wire") == 0) return 1;
+        return host_threads() >= 4 ? 1 : 0;
+    }();
+    const bool wire32 = kind == Kind::kLocate32 && narrow_mode == 1 && n_texts_ <= 256;
+    const bool pinned_input = is_pinned_host(qbuf);
+    // (a pinned query buffer needs no staging copy: the feeder's workers have nothing to do, the drainer's get their cores)
+    WorkerPool pool(wire32 && pinned_input && getenv("GDX_HOST_THREADS") == nullptr ? std::max(host_threads(), std::min(16u, usable_cpus() - std::min(usable_cpus() - 1u, 4u)))
+                                                                                   : host_threads());
     check_queries(qbuf, qoff, nq, pool, uniform_len);
     const bool uniform = uniform_len != 0;
     auto off_of = [&](uint64_t i) { return uniform ? i * uniform_len : qoff[i]; };
@@ -381,7 +399,19 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     uint32_t *d_cmp[kSlots] = {}, *d_off32[kSlots] = {};
     unsigned long long *d_tot[kSlots] = {};
     uint64_t n32_cap = 0;  // hit slots a chunk's device buffers hold
-    const bool pinned_input = is_pinned_host(qbuf);
+    void *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
+    void *d_ws[kSlots] = {};
+    uint8_t *d_wire[kSlots] = {}, *h_wire[kSlots] = {}, *d_exc[kSlots] = {}, *h_exc[kSlots] = {}, *d_wws[kSlots] = {};
+    uint64_t exc_hits_cap[kSlots] = {}, w_found[kSlots] = {}, w_exc[kSlots] = {}, w_exc_hits[kSlots] = {};
+    bool w_status[kSlots] = {};
+    // a slot's wire: {meta 16 B | bitmap, 256 B per tile | tile_found | tile_off | found_pos} and -- collections of more than one
+    // text -- the found reads' text ids behind it, the same offsets on both sides, so that ONE copy brings everything up to the
+    // last found read's position and one more the ids
+    const bool w_ids = n_texts_ > 1;
+    const uint64_t w_tiles = div_ceil(max_nq, kHostWireTile);
+    const uint64_t w_bitmap = 256, w_tile_found = w_bitmap + w_tiles * 256, w_tile_off = w_tile_found + div_ceil((w_tiles + 1) * 4, 256) * 256,
+                   w_found_pos = w_tile_off + div_ceil((w_tiles + 1) * 4, 256) * 256, w_found_ids = w_found_pos + div_ceil(max_nq * 4 + 4, 256) * 256,
+                   w_bytes = w_found_ids + (w_ids ? max_nq + 1 : 0);
     if (kind == Kind::kLocate32) {
         if (narrow == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the narrow locate needs its sink");
         n32_cap = max_nq + max_nq / 4 + 4096;
@@ -390,11 +420,36 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             d_rec[s] = device_buf<uint4>(dev, s * 16 + 5, max_nq);
             d_cmp[s] = device_buf<uint32_t>(dev, s * 16 + 11, max_nq);
             d_off32[s] = device_buf<uint32_t>(dev, s * 16 + 12, max_nq + 1);
-            d_tot[s] = device_buf<unsigned long long>(dev, s * 16 + 13, 2);
+            d_tot[s] = device_buf<unsigned long long>(dev, s * 16 + 13, 4);
             d_scan[s] = device_buf<uint8_t>(dev, s * 16 + 7, tws ? tws : 1);
-            h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 2);
+            h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 8);
+            d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, n32_cap * sizeof(gdx_hit32_t));
+            d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(n32_cap));
+            if (wire32) {
+                d_wire[s] = device_buf<uint8_t>(dev, s * 16 + 14, w_bytes);
+                h_wire[s] = pinned_buf<uint8_t>(dev, s * 16 + 7, w_bytes);
+                exc_hits_cap[s] = n32_cap;
+                d_exc[s] = device_buf<uint8_t>(dev, s * 16 + 15, max_nq * 8 + exc_hits_cap[s] * sizeof(gdx_hit32_t));
+                d_wws[s] = device_buf<uint8_t>(dev, s * 16 + 10, wire_pack_workspace_bytes(max_nq));
+            }
         }
     }
+    // (the exceptions of a slot: {read numbers | counts | hits}, max_nq entries of the first two)
+    auto pack_wire = [&](int s, uint64_t chunk_nq) {
+        uint8_t *w = d_wire[s], *e = d_exc[s];
+        WireHostForm hf;
+        hf.d_exc_hits32 = reinterpret_cast<gdx_hit32_t *>(e + max_nq * 8);
+        hf.d_tile_off = reinterpret_cast<uint32_t *>(w + w_tile_off);
+        hf.d_found_ids = w_ids ? w + w_found_ids : nullptr;
+        hf.ix = &view_;
+        hf.hits_stored = exc_hits_cap[s];
+        launch_wire_pack(d_cmp[s], d_off32[s], true, static_cast<const gdx_hit32_t *>(d_hits[s]), chunk_nq, w + w_bitmap,
+                         reinterpret_cast<uint32_t *>(w + w_tile_found), reinterpret_cast<uint32_t *>(w + w_found_pos), max_nq,
+                         reinterpret_cast<uint32_t *>(e), reinterpret_cast<uint32_t *>(e + max_nq * 4), max_nq, nullptr, nullptr,
+                         exc_hits_cap[s], reinterpret_cast<uint32_t *>(w), d_wws[s], st.k, &hf);
+        GDX_HIP(hipGetLastError());
+        GDX_HIP(hipMemcpyAsync(h_total[s] + 4, w, 16, hipMemcpyDeviceToHost, st.k));
+    };
     uint64_t *h_off[kSlots] = {};  // locate: the chunk's hit offsets (h_off[i] = hits of its queries before query i)
     if (kind == Kind::kLocate)
         for (int s = 0; s < kSlots; s++) h_off[s] = pinned_buf<uint64_t>(dev, s * 16 + 10, max_nq + 1);
@@ -404,8 +459,6 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // the device as in round 3 (the drainer then only copies)
     static const bool wide_hits = [] { const char *e = getenv("GDX_HOST_WIDE_HITS"); return e && atoi(e) != 0; }();
     const size_t hit_bytes = wide_hits ? sizeof(gdx_hit_t) : sizeof(gdx_hit32_t);
-    void *d_hits[kSlots] = {}, *h_hits[kSlots] = {};
-    void *d_ws[kSlots] = {};
 
     std::atomic<bool> any_status{false};
     uint64_t hit_base = 0;    // hits of the chunks drained so far
@@ -457,13 +510,15 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             step.d_totals = d_tot[s];
             step.d_hit_offsets = d_off32[s];
             step.narrow = true;
-            step.d_hits = d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, n32_cap * sizeof(gdx_hit32_t));
+            step.d_hits = d_hits[s];  // (sized for n32_cap hit slots; a chunk with more takes the second half again, stage_mid)
             step.hits_capacity = n32_cap;
-            step.d_workspace = d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(n32_cap));
+            step.d_workspace = d_ws[s];
+            GDX_HIP(hipMemsetAsync(d_tot[s] + 2, 0, sizeof(unsigned long long), st.k));
             launch_locate_step(view_, step, st.k, qo);
             GDX_HIP(hipGetLastError());
-            launch_unpack_records(d_rec[s], c.nq, nullptr, d_status[s], st.k, d_cmp[s]);
-            GDX_HIP(hipMemcpyAsync(h_total[s], d_tot[s], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
+            launch_unpack_records(d_rec[s], c.nq, nullptr, d_status[s], st.k, d_cmp[s], d_tot[s] + 2);
+            GDX_HIP(hipMemcpyAsync(h_total[s], d_tot[s], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
+            if (wire32) pack_wire(s, c.nq);
             GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
             return;
         }
@@ -510,6 +565,39 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
                 launch_offsets_hits(view_, d_rec[s], d_cmp[s], c.nq, qo.max_hits_per_query, true, d_scan[s], d_off32[s], true, c.total, rest,
                                     d_hits[s], d_ws[s], st.k, qo);
                 GDX_HIP(hipGetLastError());
+                if (wire32) {  // and the wire again, from the complete hits
+                    exc_hits_cap[s] = c.total;
+                    d_exc[s] = device_buf<uint8_t>(dev, s * 16 + 15, max_nq * 8 + exc_hits_cap[s] * sizeof(gdx_hit32_t));
+                    pack_wire(s, c.nq);
+                    GDX_HIP(hipStreamSynchronize(st.k));
+                }
+            }
+            if (wire32) {
+                const uint32_t *meta = reinterpret_cast<const uint32_t *>(h_total[s] + 4);
+                w_exc[s] = meta[0], w_exc_hits[s] = meta[1], w_found[s] = meta[2];
+                w_status[s] = h_total[s][2] != 0;
+                if (w_exc[s] > max_nq || w_exc_hits[s] > exc_hits_cap[s] || w_found[s] + w_exc_hits[s] != c.total)
+                    fail(GDX_ERR_DEVICE, "internal: the wire of a chunk does not add up (%llu found + %llu exception hits, %llu hits)",
+                         static_cast<unsigned long long>(w_found[s]), static_cast<unsigned long long>(w_exc_hits[s]),
+                         static_cast<unsigned long long>(c.total));
+                GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
+                GDX_HIP(hipStreamWaitEvent(st.out, st.ev_k[s], 0));
+                GDX_HIP(hipMemcpyAsync(h_wire[s], d_wire[s], w_found_pos + w_found[s] * 4, hipMemcpyDeviceToHost, st.out));
+                if (w_ids && w_found[s] != 0)
+                    GDX_HIP(hipMemcpyAsync(h_wire[s] + w_found_ids, d_wire[s] + w_found_ids, w_found[s], hipMemcpyDeviceToHost, st.out));
+                if (w_exc[s] != 0) {
+                    h_exc[s] = pinned_buf<uint8_t>(dev, s * 16 + 8, w_exc[s] * 8 + w_exc_hits[s] * sizeof(gdx_hit32_t));
+                    GDX_HIP(hipMemcpyAsync(h_exc[s], d_exc[s], w_exc[s] * 4, hipMemcpyDeviceToHost, st.out));
+                    GDX_HIP(hipMemcpyAsync(h_exc[s] + w_exc[s] * 4, d_exc[s] + max_nq * 4, w_exc[s] * 4, hipMemcpyDeviceToHost, st.out));
+                    if (w_exc_hits[s] != 0)
+                        GDX_HIP(hipMemcpyAsync(h_exc[s] + w_exc[s] * 8, d_exc[s] + max_nq * 8, w_exc_hits[s] * sizeof(gdx_hit32_t),
+                                               hipMemcpyDeviceToHost, st.out));
+                }
+                if (w_status[s]) GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
+                GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
+                c.hit_base = mid_hit_base;
+                mid_hit_base += c.total;
+                return;
             }
             if (mid_hit_base + c.total > narrow->cap) {  // the pinned hit array moves: nothing may be on its way into the old one
                 GDX_HIP(hipStreamSynchronize(st.out));
@@ -555,13 +643,39 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
     };
 
+    // GDX_HOST_TIMING=1 (debug): where the three threads spend the call, in seconds
+    static const bool timing = getenv("GDX_HOST_TIMING") != nullptr;
+    double t_in_wait = 0, t_in_work = 0, t_mid_wait = 0, t_mid_work = 0, t_out_wait = 0, t_out_work = 0, t_out_sync = 0;
     auto stage_out = [&](size_t k) {  // pinned staging -> the caller's arrays, widened
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
+        const double t_sync0 = timing ? now_seconds() : 0.0;
         GDX_HIP(hipEventSynchronize(st.ev_out[s]));
+        if (timing) t_out_sync += now_seconds() - t_sync0;
         const uint32_t *a = h_a[s], *b = h_b[s];
         const uint8_t *stt = h_status[s];
-        if (kind == Kind::kLocate32) {
+        if (wire32) {  // the chunk's wire -> offsets and hits in the sink's arrays, tiles shared out among the workers
+            const uint64_t need = c.hit_base + c.total;
+            if (need > narrow->cap) narrow->hits = narrow->grow(need, c.hit_base, &narrow->cap);  // (only this thread's workers write there)
+            const HostWire w{h_wire[s] + w_bitmap,
+                             reinterpret_cast<const uint32_t *>(h_wire[s] + w_tile_found),
+                             reinterpret_cast<const uint32_t *>(h_wire[s] + w_tile_off),
+                             reinterpret_cast<const uint32_t *>(h_wire[s] + w_found_pos),
+                             w_ids ? h_wire[s] + w_found_ids : nullptr,
+                             reinterpret_cast<const uint32_t *>(h_exc[s]),
+                             reinterpret_cast<const uint32_t *>(h_exc[s] + w_exc[s] * 4),
+                             reinterpret_cast<const gdx_hit32_t *>(h_exc[s] + w_exc[s] * 8),
+                             w_exc[s]};
+            const uint64_t tiles = div_ceil(c.nq, kHostWireTile);
+            uint32_t *offs = narrow->offsets + c.q0;
+            gdx_hit32_t *hh = narrow->hits;
+            const uint32_t hb = static_cast<uint32_t>(c.hit_base);
+            pool.run([&](unsigned wk, unsigned nw) {
+                const uint64_t per = div_ceil(tiles, nw);
+                const uint64_t lo = std::min<uint64_t>(tiles, per * wk), hi = std::min<uint64_t>(tiles, lo + per);
+                wire_expand_tiles(w, c.nq, lo, hi, hb, offs, hh);
+            });
+        } else if (kind == Kind::kLocate32) {
             // (offsets and hits are where they belong already)
         } else if (kind == Kind::kLocate) {
             c.hit_base = hit_base;
@@ -600,6 +714,10 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
                 }
             });
         }
+        if (wire32 && !w_status[s]) {  // (no read of the chunk has a status: the bytes stayed on the device)
+            if (out_status) pool.parallel_range(c.nq, 64, [&](uint64_t lo, uint64_t hi) { std::memset(out_status + c.q0 + lo, 0, hi - lo); });
+            return;
+        }
         pool.parallel_range(c.nq, 64, [&](uint64_t lo, uint64_t hi) {
             bool any = false;
             for (uint64_t i = lo; i < hi; i++) any |= stt[i] != 0;
@@ -614,9 +732,6 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // and both host-side copies of different chunks overlap; with the middle and the drain stage on one thread the
     // locate call took 1.6-1.8 x the PCIe time of its input, the thread being busy widening hits while a finished
     // search waited for its locate launch.
-    // GDX_HOST_TIMING=1 (debug): where the three threads spend the call, in seconds
-    static const bool timing = getenv("GDX_HOST_TIMING") != nullptr;
-    double t_in_wait = 0, t_in_work = 0, t_mid_wait = 0, t_mid_work = 0, t_out_wait = 0, t_out_work = 0;
     std::mutex mu;
     std::condition_variable cv;
     size_t staged = 0, launched = 0, drained = 0;  // chunks staged in / with their copy-out enqueued / fully drained
@@ -707,8 +822,8 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     feeder.join();
     drainer.join();
     if (timing)
-        fprintf(stderr, "gdx host pipeline: %zu chunks; feeder wait %.3f work %.3f; launcher wait %.3f work %.3f; drainer wait %.3f work %.3f\n",
-                n_chunks, t_in_wait, t_in_work, t_mid_wait, t_mid_work, t_out_wait, t_out_work);
+        fprintf(stderr, "gdx host pipeline: %zu chunks; feeder wait %.3f work %.3f; launcher wait %.3f work %.3f; drainer wait %.3f work %.3f (of it %.3f waiting for the copies out)\n",
+                n_chunks, t_in_wait, t_in_work, t_mid_wait, t_mid_work, t_out_wait, t_out_work, t_out_sync);
     if (worker_error) {
         (void)hipDeviceSynchronize();
         std::rethrow_exception(worker_error);

@@ -153,9 +153,9 @@ void launch_hit_offsets_rec(const uint4 *d_rec, uint64_t m, uint64_t *d_hit_offs
 size_t count_offsets_temp_bytes(uint64_t m);
 void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offsets, void *d_temp, size_t temp_bytes,
                           hipStream_t stream);
-// counts (end - start) and status bytes out of search records
+// counts (end - start) and status bytes out of search records; d_any_status (optional): |= 1 when a status byte is not 0
 void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream,
-                           const uint32_t *d_compact = nullptr);
+                           const uint32_t *d_compact = nullptr, unsigned long long *d_any_status = nullptr);
 // compact results -> text id bytes and positions in the text (-1 none, -2 see the exceptions); at most 256 texts
 void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64_t m, uint8_t *d_ids, int32_t *d_pos,
                           hipStream_t stream);
@@ -163,11 +163,23 @@ void launch_compact_split(const IndexView &ix, const uint32_t *d_compact, uint64
 void launch_compact_exceptions(const uint32_t *d_compact, uint64_t m, uint32_t *d_list, uint64_t capacity,
                                unsigned long long *d_n, hipStream_t stream);
 // the "found bitmap" wire of the multi-GPU gather (gdx_wire_pack_dev / gdx_wire_split_dev, locate.hip)
+// The form the host-pointer call gdx_locate_many_alloc_layout32 sends across PCIe (host_api.hip, wire_host.hpp): the exceptions'
+// hits as they are, the hit offset of every tile's first read (host threads expand tiles independently), and -- collections of
+// 2..256 texts -- the found reads' text ids as bytes beside positions IN their text (the device has the text table in LDS;
+// a host thread would spend more on that lookup than on everything else).
+struct WireHostForm {
+    gdx_hit32_t *d_exc_hits32 = nullptr;  // instead of d_exc_ids / d_exc_pos
+    uint32_t *d_tile_off = nullptr;       // n_tiles + 1 entries
+    uint8_t *d_found_ids = nullptr;       // != null: found_capacity bytes; d_found_pos then holds positions in the text
+    const IndexView *ix = nullptr;        // (with d_found_ids)
+    uint64_t hits_stored = ~0ull;         // hit slots of d_hits that were written (a step into too small a buffer leaves the rest)
+};
 size_t wire_pack_workspace_bytes(uint64_t m);
 void launch_wire_pack(const uint32_t *d_compact, const void *d_hit_offsets, bool narrow_offsets, const gdx_hit32_t *d_hits, uint64_t m,
                       uint8_t *d_bitmap, uint32_t *d_tile_found, uint32_t *d_found_pos, uint64_t found_cap, uint32_t *d_exc_q,
                       uint32_t *d_exc_cnt, uint64_t exc_cap, uint8_t *d_exc_ids, int32_t *d_exc_pos, uint64_t exc_hits_cap,
-                      uint32_t *d_meta, void *d_workspace, hipStream_t stream);
+                      uint32_t *d_meta, void *d_workspace, hipStream_t stream, const struct WireHostForm *host_form = nullptr);
+constexpr uint32_t kWireTileReads = 2048;  // reads per tile of the wire (locate.hip kWireTile)
 void launch_wire_split(const IndexView &ix, const uint8_t *d_bitmap, const uint32_t *d_tile_found, const uint32_t *d_found_pos,
                        uint64_t found_cap, uint64_t m, const uint32_t *d_exc_q, const uint32_t *d_meta, uint64_t exc_cap, uint8_t *d_ids,
                        int32_t *d_pos, hipStream_t stream);

@@ -1141,7 +1141,7 @@ using CountIterator = rocprim::transform_iterator<rocprim::counting_iterator<uin
 
 __global__ __launch_bounds__(kBlock) void unpack_records_kernel(const uint4 *__restrict__ rec, uint64_t m,
                                                                 uint32_t *__restrict__ counts, uint8_t *__restrict__ status,
-                                                                const uint32_t *__restrict__ compact)
+                                                                const uint32_t *__restrict__ compact, unsigned long long *__restrict__ any_status)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; q < m; q += stride) {
@@ -1156,6 +1156,7 @@ __global__ __launch_bounds__(kBlock) void unpack_records_kernel(const uint4 *__r
         const uint4 r = rec[q];
         if (counts) counts[q] = r.y - r.x;
         if (status) status[q] = static_cast<uint8_t>(r.w >> 24);
+        if (any_status != nullptr && (r.w >> 24) != 0u) atomicOr(any_status, 1ull);  // (rare: reads with symbols outside the alphabet)
     }
 }
 
@@ -1206,7 +1207,7 @@ __global__ __launch_bounds__(kBlock) void compact_split_kernel(const uint32_t *_
 // before every tile of 2048 reads (so that the root can split tiles independently), and the exceptions -- the reads whose
 // compact result says "see the record" -- as {read, count} in read order with their hits.  3.73 bytes per read where nine
 // reads in ten are found, against 4 for the compact words themselves: a position needs its 32 bits, a miss does not.
-constexpr uint32_t kWireTile = 2048;  // reads per tile: eight per thread, one byte of the bitmap
+constexpr uint32_t kWireTile = kWireTileReads;  // reads per tile (2048): eight per thread, one byte of the bitmap
 
 // x summed over the threads before this one in the block (s_w: kBlock / 64 words of LDS; two barriers)
 template <class T>
@@ -1284,6 +1285,14 @@ struct WireOut {
     int32_t *exc_pos;
     uint64_t exc_hits_cap;
     uint32_t *meta;  // [0] exceptions, [1] their hits, [2] found reads, [3] 0 (true numbers: what exceeds a capacity is dropped)
+    // the host's form of the wire (gdx_locate_many_alloc_layout32, host_api.hip): the exceptions' hits as they are (any number
+    // of texts) and the hit offset of every tile's first read, so that host threads expand tiles independently
+    gdx_hit32_t *exc_hits32;  // != null: instead of exc_ids / exc_pos
+    uint32_t *tile_off;       // != null: n_tiles + 1 entries
+    uint64_t hits_n;          // hit slots that were stored (a step into too small a buffer leaves the rest unwritten)
+    uint8_t *found_ids;       // != null: the found reads' text ids; found_pos then holds positions in that text
+    const uint32_t *sentinels;
+    uint32_t n_texts, shift;
 };
 
 // pass 3 (after the three tile arrays have been scanned): the wire
@@ -1293,6 +1302,14 @@ __global__ __launch_bounds__(kBlock) void wire_pack_kernel(const uint32_t *__res
                                                            const unsigned long long *__restrict__ see_hits, WireOut w)
 {
     __shared__ unsigned long long s_w[kBlock / 64];
+    __shared__ uint32_t s_tab[kTextTab + 1];
+    __shared__ uint32_t s_sent[256];
+    if (w.found_ids != nullptr) {
+        for (uint32_t i = threadIdx.x; i < w.n_texts; i += kBlock) s_sent[i] = w.sentinels[i];
+        __syncthreads();
+        build_text_table(s_tab, s_sent, w.n_texts, w.shift);
+        __syncthreads();
+    }
     const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t q0 = tile * kWireTile + threadIdx.x * 8u;
@@ -1313,12 +1330,29 @@ __global__ __launch_bounds__(kBlock) void wire_pack_kernel(const uint32_t *__res
                                                                               (static_cast<unsigned long long>(__popc(sbits)) << 32), s_w, t0);
         unsigned long long h_at = see_hits[tile] + block_exclusive_sum<unsigned long long>(sh, s_w, t1);
         if (q0 < m) w.bitmap[tile * (kWireTile / 8u) + threadIdx.x] = static_cast<uint8_t>(fbits);
-        if (threadIdx.x == 0) w.tile_found[tile] = static_cast<uint32_t>(found[tile]);
+        if (threadIdx.x == 0) {
+            w.tile_found[tile] = static_cast<uint32_t>(found[tile]);
+            if (w.tile_off != nullptr) w.tile_off[tile] = static_cast<uint32_t>(off[tile * kWireTile]);
+        }
         uint64_t f_at = found[tile] + (fs & 0xffffffffull), e_at = see[tile] + (fs >> 32);
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             if (fbits & (1u << k)) {
-                if (f_at < w.found_cap) w.found_pos[f_at] = c[k];
+                if (f_at < w.found_cap) {
+                    if (w.found_ids != nullptr) {
+                        const uint32_t g = c[k], b = g >> w.shift;
+                        uint32_t lo = s_tab[b], hi = s_tab[b + 1];
+                        while (lo < hi) {  // smallest t in [lo, hi] with g <= sentinels[t]
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s_sent[mid] < g) lo = mid + 1u;
+                            else hi = mid;
+                        }
+                        w.found_ids[f_at] = static_cast<uint8_t>(lo);
+                        w.found_pos[f_at] = lo == 0u ? g : g - s_sent[lo - 1u] - 1u;
+                    } else {
+                        w.found_pos[f_at] = c[k];
+                    }
+                }
                 f_at++;
             } else if (sbits & (1u << k)) {
                 const uint64_t q = q0 + k, a = off[q];
@@ -1329,10 +1363,14 @@ __global__ __launch_bounds__(kBlock) void wire_pack_kernel(const uint32_t *__res
                 }
                 e_at++;
                 for (uint64_t i = 0; i < cnt; i++)
-                    if (h_at + i < w.exc_hits_cap) {
+                    if (h_at + i < w.exc_hits_cap && a + i < w.hits_n) {
                         const gdx_hit32_t h = hits[a + i];
-                        w.exc_ids[h_at + i] = static_cast<uint8_t>(h.text_id);
-                        w.exc_pos[h_at + i] = static_cast<int32_t>(h.position);
+                        if (w.exc_hits32 != nullptr) {
+                            w.exc_hits32[h_at + i] = h;
+                        } else {
+                            w.exc_ids[h_at + i] = static_cast<uint8_t>(h.text_id);
+                            w.exc_pos[h_at + i] = static_cast<int32_t>(h.position);
+                        }
                     }
                 h_at += cnt;
             }
@@ -1340,6 +1378,7 @@ __global__ __launch_bounds__(kBlock) void wire_pack_kernel(const uint32_t *__res
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         w.tile_found[n_tiles] = static_cast<uint32_t>(found[n_tiles]);
+        if (w.tile_off != nullptr) w.tile_off[n_tiles] = static_cast<uint32_t>(off[m]);
         w.meta[0] = static_cast<uint32_t>(see[n_tiles]);
         w.meta[1] = static_cast<uint32_t>(see_hits[n_tiles] < 0xffffffffull ? see_hits[n_tiles] : 0xffffffffull);
         w.meta[2] = static_cast<uint32_t>(found[n_tiles]);
@@ -1483,15 +1522,26 @@ size_t wire_pack_workspace_bytes(uint64_t m) { return 3 * ((m + kWireTile - 1) /
 void launch_wire_pack(const uint32_t *d_compact, const void *d_hit_offsets, bool narrow_offsets, const gdx_hit32_t *d_hits, uint64_t m,
                       uint8_t *d_bitmap, uint32_t *d_tile_found, uint32_t *d_found_pos, uint64_t found_cap, uint32_t *d_exc_q,
                       uint32_t *d_exc_cnt, uint64_t exc_cap, uint8_t *d_exc_ids, int32_t *d_exc_pos, uint64_t exc_hits_cap,
-                      uint32_t *d_meta, void *d_workspace, hipStream_t stream)
+                      uint32_t *d_meta, void *d_workspace, hipStream_t stream, const WireHostForm *hf)
 {
+    gdx_hit32_t *d_exc_hits32 = hf ? hf->d_exc_hits32 : nullptr;
+    uint32_t *d_tile_off = hf ? hf->d_tile_off : nullptr;
+    uint8_t *d_found_ids = hf ? hf->d_found_ids : nullptr;
+    if (d_found_ids != nullptr && (hf->ix == nullptr || hf->ix->n_texts > 256u))
+        fail(GDX_ERR_INVALID_ARGUMENT, "internal: text ids as bytes need the index and at most 256 texts");
+    uint32_t shift = 0;
+    if (d_found_ids != nullptr)
+        while ((static_cast<uint64_t>(hf->ix->n) >> shift) >= kTextTab) shift++;
     const uint64_t n_tiles = (m + kWireTile - 1) / kWireTile;
     unsigned long long *found = static_cast<unsigned long long *>(d_workspace), *see = found + n_tiles + 1, *see_hits = see + n_tiles + 1;
     const HitOffsets off{d_hit_offsets, narrow_offsets ? 1u : 0u};
-    const WireOut w{d_bitmap, d_tile_found, d_found_pos, found_cap, d_exc_q, d_exc_cnt, exc_cap, d_exc_ids, d_exc_pos, exc_hits_cap, d_meta};
+    const WireOut w{d_bitmap, d_tile_found, d_found_pos, found_cap, d_exc_q, d_exc_cnt, exc_cap, d_exc_ids, d_exc_pos, exc_hits_cap, d_meta,
+                    d_exc_hits32, d_tile_off, hf ? hf->hits_stored : ~0ull, d_found_ids, d_found_ids ? hf->ix->sentinels : nullptr,
+                    d_found_ids ? hf->ix->n_texts : 0u, shift};
     if (m == 0) {
         GDX_HIP(hipMemsetAsync(d_meta, 0, 4 * sizeof(uint32_t), stream));
         GDX_HIP(hipMemsetAsync(d_tile_found, 0, sizeof(uint32_t), stream));
+        if (d_tile_off != nullptr) GDX_HIP(hipMemsetAsync(d_tile_off, 0, sizeof(uint32_t), stream));
         return;
     }
     const unsigned grid = static_cast<unsigned>(n_tiles < 2048 ? n_tiles : 2048);
@@ -1587,11 +1637,11 @@ void launch_count_offsets(const uint32_t *d_counts, uint64_t m, uint64_t *d_offs
 }
 
 void launch_unpack_records(const uint4 *d_rec, uint64_t m, uint32_t *d_counts, uint8_t *d_status, hipStream_t stream,
-                           const uint32_t *d_compact)
+                           const uint32_t *d_compact, unsigned long long *d_any_status)
 {
     if (m == 0) return;
     hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for_items(m)), dim3(kBlock), 0, stream, d_rec, m, d_counts, d_status,
-                       d_compact);
+                       d_compact, d_any_status);
 }
 
 // the first-query table of the chunks (n_chunks + 1 entries), then the chunk flags (locate_chunk_flags_offset)

@@ -1,0 +1,254 @@
+// wire_host.hpp -- the host's end of the "found bitmap" wire (locate.hip wire_pack_kernel; gdx.h gdx_wire_pack_dev): a chunk's
+// results cross PCIe as a bit per read, 4 bytes per found read and the exceptions with their hits -- 3.7 bytes per read where
+// nine in ten are found (4.6 with text ids) -- and host threads expand them into what gdx_locate_many_alloc_layout32 returns: u32 hit offsets
+// and 8-byte {text id, position} hits (lib.rs:187-197 locate: the hits of query i at [off[i], off[i + 1]) in suffix-array
+// order).  Written by the device those cost 12.2 bytes per read of the link both directions share (4 offsets + 7.2 hits + 1
+// status byte against 12.5 bytes of 2-bit reads going in); the link, not the kernels, bounds the call.
+//
+// Tiles of 2048 reads are independent: the device sends, per tile, the found reads and the hits in front of it.
+// Header-only so that tests/host_checks compiles the same code under AddressSanitizer.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/gdx.h"
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define GDX_WIRE_AVX2 1
+#endif
+
+namespace gdx {
+
+constexpr uint64_t kHostWireTile = 2048;  // == kWireTileReads (kernels.hpp)
+
+struct HostWire {
+    const uint8_t *bitmap;       // a bit per read: exactly one hit, the next entry of found_pos
+    const uint32_t *tile_found;  // found reads in front of every tile (n_tiles + 1)
+    const uint32_t *tile_off;    // hits in front of every tile (n_tiles + 1)
+    const uint32_t *found_pos;   // the found reads' positions in their text, read order; ONE MORE element than there are found
+                                 // reads must be readable (of found_ids too; the values do not matter): a loop below loads before
+                                 // it knows whether it stores
+    const uint8_t *found_ids;    // their text ids; null: a collection of one text (the device does the lookup: it keeps the text
+                                 // table in LDS, a host thread would spend more on it than on everything else)
+    const uint32_t *exc_q, *exc_cnt;  // the other reads with hits (or a status): read number (ascending), number of hits
+    const gdx_hit32_t *exc_hits;      // their hits back to back
+    uint64_t n_exc;
+};
+
+// p[v][k] = the bits set among bits 0 .. k - 1 of v, n[v] = all of them
+struct BitPrefixTable {
+    uint8_t p[256][8];
+    uint8_t n[256];
+    BitPrefixTable()
+    {
+        for (int v = 0; v < 256; v++) {
+            int c = 0;
+            for (int k = 0; k < 8; k++) {
+                p[v][k] = static_cast<uint8_t>(c);
+                c += (v >> k) & 1;
+            }
+            n[v] = static_cast<uint8_t>(c);
+        }
+    }
+};
+inline const BitPrefixTable &bit_prefix_table()
+{
+    static const BitPrefixTable t;
+    return t;
+}
+
+inline bool wire_have_avx2()
+{
+#ifdef GDX_WIRE_AVX2
+    static const bool have = __builtin_cpu_supports("avx2");
+    return have;
+#else
+    return false;
+#endif
+}
+
+// The arrays written here are read next by the caller, not by these threads, and the link's DMA shares the memory bus: the
+// vector paths store past the caches (no line is read in order to be overwritten), the pipeline's threads fence at the end.
+#ifdef GDX_WIRE_AVX2
+__attribute__((target("avx2"))) inline void expand_offsets_avx2(const uint8_t *bitmap, uint64_t n_bytes, uint32_t o, uint32_t *out)
+{
+    const BitPrefixTable &t = bit_prefix_table();
+    if ((reinterpret_cast<uintptr_t>(out) & 31u) == 0) {
+        for (uint64_t j = 0; j < n_bytes; j++) {
+            const uint8_t v = bitmap[j];
+            const __m128i pre = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(t.p[v]));
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(out + 8 * j), _mm256_add_epi32(_mm256_cvtepu8_epi32(pre), _mm256_set1_epi32(static_cast<int>(o))));
+            o += t.n[v];
+        }
+        return;
+    }
+    for (uint64_t j = 0; j < n_bytes; j++) {
+        const uint8_t v = bitmap[j];
+        const __m128i pre = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(t.p[v]));
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(out + 8 * j), _mm256_add_epi32(_mm256_cvtepu8_epi32(pre), _mm256_set1_epi32(static_cast<int>(o))));
+        o += t.n[v];
+    }
+}
+__attribute__((target("avx2"))) inline void expand_positions_one_text_avx2(const uint32_t *pos, uint64_t n, gdx_hit32_t *hits)
+{
+    uint64_t k = 0;
+    for (; k < n && (reinterpret_cast<uintptr_t>(hits + k) & 31u) != 0; k++) {
+        hits[k].text_id = 0u;
+        hits[k].position = pos[k];
+    }
+    for (; k + 4 <= n; k += 4) {  // {text 0, position}: the position in the upper half of a 64-bit word
+        const __m256i wide = _mm256_cvtepu32_epi64(_mm_loadu_si128(reinterpret_cast<const __m128i *>(pos + k)));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(hits + k), _mm256_slli_epi64(wide, 32));
+    }
+    for (; k < n; k++) {
+        hits[k].text_id = 0u;
+        hits[k].position = pos[k];
+    }
+}
+__attribute__((target("avx2"))) inline void expand_positions_ids_avx2(const uint32_t *pos, const uint8_t *ids, uint64_t n, gdx_hit32_t *hits)
+{
+    uint64_t k = 0;
+    for (; k < n && (reinterpret_cast<uintptr_t>(hits + k) & 31u) != 0; k++) {
+        hits[k].text_id = ids[k];
+        hits[k].position = pos[k];
+    }
+    for (; k + 8 <= n; k += 8) {  // eight {id, position} pairs: two in-lane interleaves, then the lanes sorted
+        const __m256i id = _mm256_cvtepu8_epi32(_mm_loadl_epi64(reinterpret_cast<const __m128i *>(ids + k)));
+        const __m256i p = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + k));
+        const __m256i lo = _mm256_unpacklo_epi32(id, p), hi = _mm256_unpackhi_epi32(id, p);  // {0 1 | 4 5}, {2 3 | 6 7}
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(hits + k), _mm256_permute2x128_si256(lo, hi, 0x20));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(hits + k + 4), _mm256_permute2x128_si256(lo, hi, 0x31));
+    }
+    for (; k < n; k++) {
+        hits[k].text_id = ids[k];
+        hits[k].position = pos[k];
+    }
+}
+#endif
+
+// out[8 j + k] = o + the bits set among the first 8 j + k bits of the bitmap (n_bytes whole bytes): the hit offset of every read
+inline void expand_offsets(const uint8_t *bitmap, uint64_t n_bytes, uint32_t o, uint32_t *out)
+{
+#ifdef GDX_WIRE_AVX2
+    if (wire_have_avx2()) {
+        expand_offsets_avx2(bitmap, n_bytes, o, out);
+        return;
+    }
+#endif
+    const BitPrefixTable &t = bit_prefix_table();
+    for (uint64_t j = 0; j < n_bytes; j++) {
+        const uint8_t v = bitmap[j];
+        for (int k = 0; k < 8; k++) out[8 * j + k] = o + t.p[v][k];
+        o += t.n[v];
+    }
+}
+
+// hits[k] = {ids[k] (0 when ids is null), pos[k]}
+inline void expand_positions(const uint32_t *pos, const uint8_t *ids, uint64_t n, gdx_hit32_t *hits)
+{
+#ifdef GDX_WIRE_AVX2
+    if (wire_have_avx2()) {
+        if (ids == nullptr) expand_positions_one_text_avx2(pos, n, hits);
+        else expand_positions_ids_avx2(pos, ids, n, hits);
+        return;
+    }
+#endif
+    for (uint64_t k = 0; k < n; k++) {
+        hits[k].text_id = ids ? ids[k] : 0u;
+        hits[k].position = pos[k];
+    }
+}
+
+inline void wire_expand_fence()
+{
+#ifdef GDX_WIRE_AVX2
+    _mm_sfence();
+#endif
+}
+
+// tiles [tile_lo, tile_hi) of a chunk of nq reads: offsets[q] = base + the hits of the reads in front of read q (offsets points
+// at the chunk's first entry, u32; the last tile writes offsets[nq] as well), hits[base + ...] = the hits.  Every entry and hit
+// slot has one writer.  Ends with a store fence.
+inline void wire_expand_tiles(const HostWire &w, uint64_t nq, uint64_t tile_lo, uint64_t tile_hi, uint32_t base, uint32_t *offsets,
+                              gdx_hit32_t *hits)
+{
+    if (tile_lo >= tile_hi) return;
+    const uint64_t q_lo = tile_lo * kHostWireTile, q_hi = tile_hi * kHostWireTile < nq ? tile_hi * kHostWireTile : nq;
+    uint64_t e = 0;  // the first exception at or behind q_lo
+    {
+        uint64_t hi = w.n_exc;
+        while (e < hi) {
+            const uint64_t mid = (e + hi) >> 1;
+            if (w.exc_q[mid] < q_lo) e = mid + 1;
+            else hi = mid;
+        }
+    }
+    static const uint8_t zero_id = 0;
+    const uint8_t *const ids = w.found_ids ? w.found_ids : &zero_id;
+    const uint64_t id_step = w.found_ids ? 1 : 0;  // (one text: every read's id is the one zero)
+    uint64_t f = w.tile_found[tile_lo];
+    uint32_t o = w.tile_off[tile_lo];
+    uint64_t eh = static_cast<uint64_t>(o) - f;  // hits in front of the tile = found reads + exception hits in front of it
+    o += base;
+    uint64_t next_exc = e < w.n_exc ? w.exc_q[e] : ~0ull;
+    for (uint64_t q0 = q_lo; q0 < q_hi; q0 += 64) {
+        if (q0 % kHostWireTile == 0 && q0 + kHostWireTile <= q_hi && next_exc >= q0 + kHostWireTile) {
+            // a whole tile without exceptions (all of them where reads are unique): its found reads' hits are a straight run of
+            // the positions, its offsets the running bit count -- eight entries per look-up of a bitmap byte
+            const uint64_t tile = q0 / kHostWireTile;
+            const uint64_t n_f = w.tile_found[tile + 1] - w.tile_found[tile];
+            expand_positions(w.found_pos + f, w.found_ids ? w.found_ids + f : nullptr, n_f, hits + o);
+            expand_offsets(w.bitmap + q0 / 8, kHostWireTile / 8, o, offsets + q0);
+            f += n_f;
+            o += static_cast<uint32_t>(n_f);
+            q0 += kHostWireTile - 64;
+            continue;
+        }
+        uint64_t bits;
+        std::memcpy(&bits, w.bitmap + q0 / 8, 8);  // (the bitmap is padded to whole tiles: 256 bytes each)
+        const uint64_t n = q_hi - q0 < 64 ? q_hi - q0 : 64;
+        if (next_exc >= q0 + n) {  // no exception among these reads
+            // Nine reads in ten are found, which ones is random: a branch on the bit is mispredicted every tenth read.  So every
+            // read stores a hit -- into its slot when it has one, into a scratch word otherwise -- and the slot and position
+            // cursors advance by the bit.
+            uint64_t scratch;
+            uint32_t *const offs = offsets + q0;
+            for (uint64_t i = 0; i < n; i++) {
+                const uint64_t bit = (bits >> i) & 1ull;
+                gdx_hit32_t h;
+                h.text_id = ids[f * id_step];
+                h.position = w.found_pos[f];
+                void *dst = bit ? static_cast<void *>(hits + o) : static_cast<void *>(&scratch);
+                std::memcpy(dst, &h, 8);
+                offs[i] = o;
+                o += static_cast<uint32_t>(bit);
+                f += bit;
+            }
+            continue;
+        }
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t q = q0 + i;
+            offsets[q] = o;
+            if ((bits >> i) & 1ull) {
+                hits[o].text_id = ids[f * id_step];
+                hits[o].position = w.found_pos[f];
+                o++;
+                f++;
+            } else if (q == next_exc) {
+                const uint32_t cnt = w.exc_cnt[e];
+                if (cnt) std::memcpy(hits + o, w.exc_hits + eh, static_cast<size_t>(cnt) * sizeof(gdx_hit32_t));
+                o += cnt;
+                eh += cnt;
+                e++;
+                next_exc = e < w.n_exc ? w.exc_q[e] : ~0ull;
+            }
+        }
+    }
+    if (q_hi == nq) offsets[nq] = o;
+    wire_expand_fence();
+}
+
+}  // namespace gdx

@@ -4,6 +4,8 @@
 //   host_checks header <file>                                validates an index file header; prints "ok n=.. texts=.."
 //   host_checks pack <file>                                  packs the file's bytes as queries (pack_host.hpp: the AVX2 path and the
 //                                                            byte loop) in exactly sized buffers; prints "ok <cases> <exceptions>"
+//   host_checks wire <seed> <reads> <texts> [<found of ten> <exceptions: one in>]  expands a random chunk's "found bitmap" wire (wire_host.hpp) in pieces,
+//                                                            exactly sized buffers; prints "ok <hits> <exceptions>"
 // A malformed input must end in "error: <message>" (exit code 3), never in a sanitizer report.
 #include <cinttypes>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include "../../genedex_amd/csrc/fastx.hpp"
 #include "../../genedex_amd/csrc/index_file.hpp"
 #include "../../genedex_amd/csrc/pack_host.hpp"
+#include "../../genedex_amd/csrc/wire_host.hpp"
 
 int main(int argc, char **argv)
 {
@@ -100,6 +103,93 @@ int main(int argc, char **argv)
                 }
             }
             std::printf("ok %" PRIu64 " %" PRIu64 "\n", cases, exceptions);
+        } else if (mode == "wire") {
+            // a chunk of reads with random outcomes -- one hit (nine in ten, or one in ten: argv[5]), none, or an exception with
+            // 0..40 hits -- over a collection of `texts` texts; the wire as wire_pack_kernel lays it out, in heap blocks of
+            // exactly the sizes the host pipeline copies; expanded by 1, 3 and 7 workers and compared with the plain construction
+            uint64_t x = std::strtoull(argv[2], nullptr, 10) * 2654435761ull + 88172645463325252ull;
+            auto rnd = [&]() {
+                x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+                return x;
+            };
+            const uint64_t nq = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 5000;
+            const uint64_t n_texts = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 3;
+            const uint64_t found_in_ten = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 9;
+            const uint64_t exc_one_in = argc > 6 ? std::strtoull(argv[6], nullptr, 10) : 3;  // of the reads that are not found
+            const uint64_t n = 1000 + n_texts * 700;
+            std::vector<uint64_t> sentinels(n_texts);
+            for (uint64_t t = 0; t < n_texts; t++) sentinels[t] = (t + 1) * (n / n_texts) - 1 - (t + 1 < n_texts ? rnd() % 300 : 0);
+            sentinels[n_texts - 1] = n - 1;
+            auto split = [&](uint32_t g) {
+                uint32_t t = 0;
+                while (sentinels[t] < g) t++;
+                gdx_hit32_t h;
+                h.text_id = t;
+                h.position = t == 0 ? g : g - static_cast<uint32_t>(sentinels[t - 1]) - 1u;
+                return h;
+            };
+            const uint64_t tiles = (nq + gdx::kHostWireTile - 1) / gdx::kHostWireTile;
+            std::vector<uint8_t> bitmap(tiles * 256, 0);
+            std::vector<uint32_t> tile_found(tiles + 1), tile_off(tiles + 1), found_pos, exc_q, exc_cnt, want_off(nq + 1);
+            std::vector<uint8_t> found_ids;
+            std::vector<gdx_hit32_t> exc_hits, want_hits;
+            const uint32_t base = 777;
+            want_off[0] = base;
+            for (uint64_t q = 0; q < nq; q++) {
+                if (q % gdx::kHostWireTile == 0) {
+                    tile_found[q / gdx::kHostWireTile] = static_cast<uint32_t>(found_pos.size());
+                    tile_off[q / gdx::kHostWireTile] = static_cast<uint32_t>(want_hits.size());
+                }
+                const uint64_t r = rnd() % 100;
+                if (r < found_in_ten * 10) {
+                    uint32_t g;
+                    do g = static_cast<uint32_t>(rnd() % n); while (std::find(sentinels.begin(), sentinels.end(), g) != sentinels.end());
+                    bitmap[q / 8] |= static_cast<uint8_t>(1u << (q % 8));
+                    found_pos.push_back(split(g).position);
+                    found_ids.push_back(static_cast<uint8_t>(split(g).text_id));
+                    want_hits.push_back(split(g));
+                } else if (rnd() % exc_one_in == 0) {
+                    const uint32_t cnt = static_cast<uint32_t>(rnd() % 41);
+                    exc_q.push_back(static_cast<uint32_t>(q));
+                    exc_cnt.push_back(cnt);
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        gdx_hit32_t h;
+                        h.text_id = static_cast<uint32_t>(rnd() % n_texts), h.position = static_cast<uint32_t>(rnd() % 1000);
+                        exc_hits.push_back(h);
+                        want_hits.push_back(h);
+                    }
+                }
+                want_off[q + 1] = base + static_cast<uint32_t>(want_hits.size());
+            }
+            tile_found[tiles] = static_cast<uint32_t>(found_pos.size());
+            tile_off[tiles] = static_cast<uint32_t>(want_hits.size());
+            found_pos.push_back(0xffffffffu);  // (the one element past the found reads that HostWire asks to be readable)
+            found_ids.push_back(0xffu);
+            auto exact = [](const auto &v) {  // a heap block of exactly the vector's bytes (at least one)
+                using T = typename std::decay<decltype(v[0])>::type;
+                std::unique_ptr<T[]> p(new T[v.size() ? v.size() : 1]);
+                std::copy(v.begin(), v.end(), p.get());
+                return p;
+            };
+            const auto b_bitmap = exact(bitmap);
+            const auto b_tf = exact(tile_found), b_to = exact(tile_off), b_fp = exact(found_pos), b_eq = exact(exc_q), b_ec = exact(exc_cnt);
+            const auto b_eh = exact(exc_hits);
+            const auto b_fi = exact(found_ids);
+            const gdx::HostWire w{b_bitmap.get(), b_tf.get(), b_to.get(), b_fp.get(), n_texts > 1 ? b_fi.get() : nullptr,
+                                  b_eq.get(), b_ec.get(), b_eh.get(), exc_q.size()};
+            for (uint64_t workers : {uint64_t(1), uint64_t(3), uint64_t(7)}) {
+                std::unique_ptr<uint32_t[]> off(new uint32_t[nq + 1]);
+                std::unique_ptr<gdx_hit32_t[]> hits(new gdx_hit32_t[base + want_hits.size() + 1]);
+                std::fill(off.get(), off.get() + nq + 1, 0xdeadbeefu);
+                const uint64_t per = (tiles + workers - 1) / workers;
+                for (uint64_t k = workers; k-- > 0;)  // (in reverse: no piece relies on the one before it)
+                    gdx::wire_expand_tiles(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), base, off.get(), hits.get());
+                for (uint64_t q = 0; q <= nq; q++)
+                    if (off[q] != want_off[q] && nq != 0) return 8;
+                for (uint64_t i = 0; i < want_hits.size(); i++)
+                    if (hits[base + i].text_id != want_hits[i].text_id || hits[base + i].position != want_hits[i].position) return 9;
+            }
+            std::printf("ok %zu %zu\n", want_hits.size(), exc_q.size());
         } else {
             return 2;
         }

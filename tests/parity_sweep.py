@@ -189,6 +189,48 @@ def one_round(rng, stats):
         assert torch.equal(off2, off_t), ("compact offsets", cfg)
         assert torch.equal(hits2[:tot2], hits[:tot]), ("compact hits", cfg)
         assert torch.equal(counts2, counts) and not stat2.any().item(), ("compact counts", cfg)
+        # round 5: the whole step as ONE call without a host round trip into a roomy and into too small a buffer, the shard
+        # through the found-bitmap wire and back, the narrow host-pointer call
+        for cap5 in (tot2 + int(rng.integers(1, 50)), max(tot2 // 3, 1)):
+            rec5 = eng.alloc_records(dq.nq)
+            rec5.fill_(0x77777777)
+            cmp5 = eng.alloc_compact(dq.nq)
+            narrow5 = bool(rng.integers(0, 2))
+            off5 = torch.full((dq.nq + 1,), -1, dtype=torch.int32 if narrow5 else torch.int64, device="cuda")
+            hits5 = torch.full((cap5, 2), -3, dtype=torch.int32, device="cuda")
+            tot5 = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+            sws5 = torch.empty_like(sws)
+            ws5 = torch.empty(max(eng.locate_workspace_bytes(cap5), 16), dtype=torch.uint8, device="cuda")
+            eng.locate_step(dq, rec5, cmp5, sws5, tot5, off5, hits5, ws5)
+            torch.cuda.synchronize()
+            assert tot5.tolist() == [tot2, rest2], ("step totals", cap5, cfg)
+            assert torch.equal(off5.to(torch.int64), off_t), ("step offsets", cap5, cfg)
+            n5 = min(cap5, tot2)
+            assert torch.equal(hits5[:n5], hits[:n5]), ("step hits", cap5, cfg)
+            stats["one_call_steps"] = stats.get("one_call_steps", 0) + 1
+        if int(g.info.num_texts) <= 256 and dq.nq:
+            from genedex_amd import dist as gdist
+
+            n_exc5, n_exc_hits5 = gdist.exception_sizes(cmp2[:dq.nq], off2, dq.nq)
+            n_found5 = int(((cmp2[:dq.nq] >= 0) | (cmp2[:dq.nq] < -2)).sum().item())
+            layout5 = gdist.WireLayout(dq.nq, max(n_found5, 1), max(n_exc5, 1), max(n_exc_hits5, 1))
+            buf5 = torch.full((layout5.nbytes,), 0x5A, dtype=torch.uint8, device="cuda")
+            v5 = layout5.views(buf5)
+            wws5 = torch.empty(max(eng.wire_pack_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+            eng.wire_pack(cmp2, off2, hits2, dq.nq, v5, wws5)
+            ids5 = torch.empty(dq.nq, dtype=torch.uint8, device="cuda")
+            pos5 = torch.empty(dq.nq, dtype=torch.int32, device="cuda")
+            eng.wire_split(v5, dq.nq, ids5, pos5)
+            torch.cuda.synchronize()
+            cnt5, hh5 = gdist.expand_split_results(ids5, pos5, v5["exc_cnt"], v5["exc_ids"], v5["exc_pos"], v5["meta"], dq.nq)
+            assert torch.equal(cnt5.to(torch.int32), counts), ("wire counts", cfg)
+            assert torch.equal(hh5, hits[:tot]), ("wire hits", cfg)
+            stats["wire_round_trips"] = stats.get("wire_round_trips", 0) + 1
+        if tot2 < (1 << 31):
+            o32, t32, p32, s32 = g.locate_layout32_raw(qb2, qo2, dq.nq)
+            assert o32.astype(np.uint64).tolist() == exp_off.tolist() and not s32.any(), ("narrow host offsets", cfg)
+            assert t32.tolist() == ct.astype(np.uint32).tolist() and p32.tolist() == cp.astype(np.uint32).tolist(), ("narrow host hits", cfg)
+            stats["narrow_host_calls"] = stats.get("narrow_host_calls", 0) + 1
         # ... and from the batch as 2-bit codes (gdx_query_layout_t), the totals out of the search call itself, narrow offsets
         dq_p = None
         if int(g.info.table_layout) == 0 and k >= 4:  # (packed queries: the rank-line layout with dense 1..4 searchable)

@@ -1219,6 +1219,19 @@ def test_query_layouts_equal_plain_queries(seed, search_variant):
         lib.gdx_release_cached_hits()
         off, t_, p_, st = g.locate_layout32_raw(qbuf, qoff, nq)
         assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+        # a read with a symbol outside the alphabet among the others: its status byte comes back (the chunks without such a read
+        # keep their status bytes on the device), it has no hits, everything else is as before
+        bad_at = min(1500, len(qs) // 2)
+        # (GDX_Q_INVALID_SYMBOL: "reached while the interval was still non-empty" -- a read of the text with its third last symbol
+        # replaced: the search has matched two symbols when it meets it)
+        bad = list(qs[:bad_at]) + [qs[0][:-3] + b"#" + qs[0][-2:]] + list(qs[bad_at:])
+        bbuf, boff = pack_queries(bad)
+        off, t_, p_, st = g.locate_layout32_raw(bbuf, boff, len(bad), strict=False)
+        _, _, _, st_wide = g.locate_raw(bbuf, boff, strict=False)
+        assert np.flatnonzero(st).tolist() == [bad_at] and st.tolist() == st_wide.tolist(), (np.flatnonzero(st), np.flatnonzero(st_wide))
+        want_counts = np.insert(np.diff(co.astype(np.int64)), bad_at, 0)
+        assert np.diff(off.astype(np.int64)).tolist() == want_counts.tolist()
+        assert t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
     finally:
         lib.gdx_debug_set_host_chunking(0, 0)
     # what a layout must refuse

@@ -134,3 +134,19 @@ def test_host_packer_stays_inside_its_buffers(checker, tmp_path):
         assert rc == 0 and out.startswith("ok "), (name, out)
         if n >= 3000:
             assert int(out.split()[1]) == 40 and int(out.split()[2]) > 0
+
+
+def test_host_wire_expansion_equals_the_plain_construction(checker):
+    """wire_host.hpp (what the drainer's workers of gdx_locate_many_alloc_layout32 run on a chunk's "found bitmap" wire) under
+    ASan + UBSan on exactly sized heap blocks: offsets and hits are those of the plain construction, for one text and
+    many (the coarse text table), mostly found and mostly not, chunk sizes around the 64-read words and 2048-read tiles,
+    whatever the number of workers the tiles are shared among."""
+    for seed, (nq, texts, found, exc_one_in) in enumerate([
+            (5000, 1, 9, 3), (5000, 3, 9, 3), (4096, 200, 5, 3), (2049, 2, 1, 3), (63, 1, 9, 3), (64, 5, 0, 3), (1, 1, 9, 3),
+            (20000, 40, 10, 3), (0, 1, 9, 3),
+            # few exceptions: most tiles take the run-of-positions path, some do not
+            (30000, 1, 9, 700), (30000, 30, 9, 700), (30000, 256, 5, 2000), (2048, 1, 9, 100000), (4097, 2, 9, 100000)]):
+        rc, out = checker("wire", seed + 1, nq, texts, found, exc_one_in)
+        assert rc == 0 and out.startswith("ok "), (nq, texts, found, rc, out)
+        if nq >= 4096 and found < 10 and exc_one_in == 3:
+            assert int(out.split()[2]) > 0
