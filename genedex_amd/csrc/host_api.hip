@@ -250,6 +250,19 @@ __global__ __launch_bounds__(256) void unpack_status_kernel(const uint4 *__restr
         status[q] = static_cast<uint8_t>(rec[q].w >> 24);
 }
 
+// *flag |= 1 when a status byte is not 0 (then, and only then, a chunk's status bytes cross the link)
+__global__ __launch_bounds__(256) void any_status_kernel(const uint8_t *__restrict__ status, uint64_t nq, unsigned long long *__restrict__ flag)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u, quads = nq / 16u;
+    uint32_t any = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; i < quads; i += stride) {
+        const uint4 v = reinterpret_cast<const uint4 *>(status)[i];
+        any |= v.x | v.y | v.z | v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nq & 15u)) any |= status[quads * 16u + threadIdx.x];
+    if (any != 0u) atomicOr(flag, 1ull);
+}
+
 void check_queries(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, WorkerPool &pool, uint64_t uniform_len)
 {
     if (nq >= 0xffffffffull) fail(GDX_ERR_UNSUPPORTED, "more than 2^32-2 queries in one call");
@@ -307,24 +320,26 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // uniform_len != 0: query i = symbols [i * uniform_len, (i + 1) * uniform_len) of the buffer, qoff is not looked at: no
     // offsets are staged, copied or read by the kernels (gdx_query_layout_t)
     const Kind kind = static_cast<Kind>(kind_i);
-    // Narrow locate (Kind::kLocate32): by default the results do not cross the link as offsets and hits but as the "found
-    // bitmap" wire the multi-GPU gather uses (launch_wire_pack: a bit per read, 4 bytes per found read, the exceptions with
-    // their hits -- 3.7 bytes per read instead of 12.2), and the drainer's workers expand them into the sink's arrays
-    // (wire_host.hpp): the link's two directions share its rate (65 GB/s together on the test box against 57 alone), so
-    // bytes saved going out are time saved.  GDX_HOST_NARROW=dma: the device-written form (hosts with few cores to spare).
-    // Collections of many texts take that form too: the host's text lookup is a binary search per hit where blocks hold
-    // several borders, and the device does that better.
+    // Locate calls: by default a chunk's results do not cross the link as offsets and hits but as the "found bitmap" wire the
+    // multi-GPU gather uses (launch_wire_pack: a bit per read, position + text id byte per found read, the exceptions with their
+    // hits -- 3.7-4.6 bytes per read instead of 12.2 narrow / 16.2 wide), and the drainer's workers expand them into the
+    // caller's arrays (wire_host.hpp): the link's two directions share its rate (65 GB/s together on the test box against 57
+    // alone), so bytes saved going out are time saved.  GDX_HOST_NARROW=dma: the device-written forms (hosts with few cores
+    // to spare).  Collections of more than 256 texts take those too (text ids travel as bytes).
     static const int narrow_mode = [] {
         const char *e = getenv("GDX_HOST_NARROW");
         if (e && std::strcmp(e, "dma") == 0) return 0;
         if (e && std::strcmp(e, "wire") == 0) return 1;
         return host_threads() >= 4 ? 1 : 0;
     }();
-    const bool wire32 = kind == Kind::kLocate32 && narrow_mode == 1 && n_texts_ <= 256;
+    const bool wire = (kind == Kind::kLocate32 || kind == Kind::kLocate) && narrow_mode == 1 && n_texts_ <= 256;
+    // stepped: every chunk is ONE fused step (launch_locate_step: search, totals, u32 offsets, 8-byte hits, no host round trip)
+    const bool stepped = kind == Kind::kLocate32 || (kind == Kind::kLocate && wire);
+    const bool plain_locate = kind == Kind::kLocate && !stepped;  // search | total to the host | locate, u64 offsets (rounds 1-4)
     const bool pinned_input = is_pinned_host(qbuf);
-    // (a pinned query buffer needs no staging copy: the feeder's workers have nothing to do, the drainer's get their cores)
-    WorkerPool pool(wire32 && pinned_input && getenv("GDX_HOST_THREADS") == nullptr ? std::max(host_threads(), std::min(16u, usable_cpus() - std::min(usable_cpus() - 1u, 4u)))
-                                                                                   : host_threads());
+    // (more than host_threads() workers did not shorten the expansion -- 13 ms of a 100 M-read call with 7 workers, 11 with 13 --
+    // and starved the runtime's own threads on a 16-CPU container)
+    WorkerPool pool(host_threads());
     check_queries(qbuf, qoff, nq, pool, uniform_len);
     const bool uniform = uniform_len != 0;
     auto off_of = [&](uint64_t i) { return uniform ? i * uniform_len : qoff[i]; };
@@ -340,7 +355,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
     // (a chunk's limit counts the bytes that cross the link: four symbols per byte of a packed batch; the narrow locate runs a
     // whole fused step per chunk, a dozen launches, and takes up to four times the queries)
-    const uint64_t kChunkBytes = g_chunk_bytes.load() * (packed ? 4 : 1), kChunkQueries = g_chunk_queries.load() * (kind == Kind::kLocate32 ? 4 : 1);
+    const uint64_t kChunkBytes = g_chunk_bytes.load() * (packed ? 4 : 1), kChunkQueries = g_chunk_queries.load() * (stepped ? 4 : 1);
     std::vector<Chunk> chunks;
     // (uniform: every chunk but the last holds a multiple of 8 queries, so that a chunk starts on a 16-bit unit of a packed
     // buffer and on a byte of an ASCII one, and is a uniform batch of its own)
@@ -376,7 +391,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     uint64_t *h_total[kSlots];
     void *d_scan[kSlots];
     size_t scan_bytes = 0;
-    if (kind == Kind::kLocate) scan_bytes = hit_offsets_rec_temp_bytes(max_nq);
+    if (plain_locate) scan_bytes = hit_offsets_rec_temp_bytes(max_nq);
     for (int s = 0; s < kSlots; s++) {
         h_in[s] = pinned_buf<uint8_t>(dev, s * 16 + 0, qbuf_cap);
         h_qoff[s] = pinned_buf<uint64_t>(dev, s * 16 + 1, max_nq + 1);
@@ -389,13 +404,12 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         d_a[s] = device_buf<uint32_t>(dev, s * 16 + 2, max_nq);
         d_b[s] = kind == Kind::kIntervals ? device_buf<uint32_t>(dev, s * 16 + 3, max_nq) : nullptr;
         d_status[s] = device_buf<uint8_t>(dev, s * 16 + 4, max_nq);
-        d_rec[s] = kind == Kind::kLocate ? device_buf<uint4>(dev, s * 16 + 5, max_nq) : nullptr;
-        d_off[s] = kind == Kind::kLocate ? device_buf<uint64_t>(dev, s * 16 + 6, max_nq + 1) : nullptr;
-        d_scan[s] = kind == Kind::kLocate ? device_buf<uint8_t>(dev, s * 16 + 7, scan_bytes ? scan_bytes : 1) : nullptr;
+        d_rec[s] = plain_locate ? device_buf<uint4>(dev, s * 16 + 5, max_nq) : nullptr;
+        d_off[s] = plain_locate ? device_buf<uint64_t>(dev, s * 16 + 6, max_nq + 1) : nullptr;
+        d_scan[s] = plain_locate ? device_buf<uint8_t>(dev, s * 16 + 7, scan_bytes ? scan_bytes : 1) : nullptr;
     }
-    // narrow locate (Kind::kLocate32): every chunk is one fused step (launch_locate_step) into device buffers sized for the
-    // chunk's queries and a margin; its u32 offsets and 8-byte hits go by D2H copy straight into the caller-visible pinned
-    // arrays of the sink -- no host thread touches them
+    // stepped: device buffers sized for the chunk's queries and a margin.  Without the wire (narrow call only) the u32 offsets
+    // and 8-byte hits go by D2H copy straight into the caller-visible pinned arrays of the sink
     uint32_t *d_cmp[kSlots] = {}, *d_off32[kSlots] = {};
     unsigned long long *d_tot[kSlots] = {};
     uint64_t n32_cap = 0;  // hit slots a chunk's device buffers hold
@@ -412,8 +426,14 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     const uint64_t w_bitmap = 256, w_tile_found = w_bitmap + w_tiles * 256, w_tile_off = w_tile_found + div_ceil((w_tiles + 1) * 4, 256) * 256,
                    w_found_pos = w_tile_off + div_ceil((w_tiles + 1) * 4, 256) * 256, w_found_ids = w_found_pos + div_ceil(max_nq * 4 + 4, 256) * 256,
                    w_bytes = w_found_ids + (w_ids ? max_nq + 1 : 0);
-    if (kind == Kind::kLocate32) {
-        if (narrow == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the narrow locate needs its sink");
+    const bool flagged = kind == Kind::kCounts || kind == Kind::kIntervals;  // status bytes stay on the device unless one is set
+    if (flagged)
+        for (int s = 0; s < kSlots; s++) {
+            d_tot[s] = device_buf<unsigned long long>(dev, s * 16 + 13, 4);
+            h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 8);
+        }
+    if (stepped) {
+        if (kind == Kind::kLocate32 && narrow == nullptr) fail(GDX_ERR_INVALID_ARGUMENT, "internal: the narrow locate needs its sink");
         n32_cap = max_nq + max_nq / 4 + 4096;
         const size_t tws = scan_totals_workspace_bytes(max_nq);
         for (int s = 0; s < kSlots; s++) {
@@ -425,7 +445,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             h_total[s] = pinned_buf<uint64_t>(dev, s * 16 + 5, 8);
             d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, n32_cap * sizeof(gdx_hit32_t));
             d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(n32_cap));
-            if (wire32) {
+            if (wire) {
                 d_wire[s] = device_buf<uint8_t>(dev, s * 16 + 14, w_bytes);
                 h_wire[s] = pinned_buf<uint8_t>(dev, s * 16 + 7, w_bytes);
                 exc_hits_cap[s] = n32_cap;
@@ -451,7 +471,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         GDX_HIP(hipMemcpyAsync(h_total[s] + 4, w, 16, hipMemcpyDeviceToHost, st.k));
     };
     uint64_t *h_off[kSlots] = {};  // locate: the chunk's hit offsets (h_off[i] = hits of its queries before query i)
-    if (kind == Kind::kLocate)
+    if (plain_locate)
         for (int s = 0; s < kSlots; s++) h_off[s] = pinned_buf<uint64_t>(dev, s * 16 + 10, max_nq + 1);
     // hits leave the device NARROW (gdx_hit32_t, 8 bytes) and are widened into the ABI's 16-byte gdx_hit_t by the drainer's
     // workers: with reads handed over as 2-bit codes the D2H link is the longer leg of a locate call (23 bytes per read out
@@ -499,7 +519,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         }
         call.nq = c.nq;
         call.packed = packed;
-        if (kind == Kind::kLocate32) {
+        if (stepped) {
             LocateStep step;
             step.call = call;
             step.call.d_rec = d_rec[s];
@@ -518,7 +538,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             GDX_HIP(hipGetLastError());
             launch_unpack_records(d_rec[s], c.nq, nullptr, d_status[s], st.k, d_cmp[s], d_tot[s] + 2);
             GDX_HIP(hipMemcpyAsync(h_total[s], d_tot[s], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
-            if (wire32) pack_wire(s, c.nq);
+            if (wire) pack_wire(s, c.nq);
             GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
             return;
         }
@@ -537,7 +557,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         }
         launch_search_call(view_, call, st.k, qo);
         GDX_HIP(hipGetLastError());
-        if (kind == Kind::kLocate) {
+        if (plain_locate) {
             const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((c.nq + 255) / 256, 4096));
             hipLaunchKernelGGL(unpack_status_kernel, dim3(blocks), dim3(256), 0, st.k, d_rec[s], c.nq, d_status[s]);
             // (max_hits_per_query: a query gets slots for its first k rows only -- locate(q).take(k))
@@ -546,6 +566,11 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
         } else {
             GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
+            GDX_HIP(hipMemsetAsync(d_tot[s], 0, sizeof(unsigned long long), st.k));
+            hipLaunchKernelGGL(any_status_kernel, dim3(static_cast<unsigned>(std::min<uint64_t>(c.nq / 4096 + 1, 1024))), dim3(256), 0, st.k,
+                               d_status[s], c.nq, d_tot[s]);
+            GDX_HIP(hipMemcpyAsync(h_total[s], d_tot[s], sizeof(uint64_t), hipMemcpyDeviceToHost, st.k));
+            GDX_HIP(hipEventRecord(st.ev_total[s], st.k));
         }
     };
 
@@ -553,26 +578,30 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     auto stage_mid = [&](size_t k) {  // locate: the chunk's total is known -> locate, then all D2H; else just D2H
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
-        if (kind == Kind::kLocate32) {
+        if (stepped) {
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = h_total[s][0];
             const uint64_t rest = h_total[s][1];
-            if (mid_hit_base + c.total >= (1ull << 32))
+            if (kind == Kind::kLocate32 && mid_hit_base + c.total >= (1ull << 32))
                 fail(GDX_ERR_CAPACITY, "more than 2^32 - 1 hits: 32-bit hit offsets do not hold them (gdx_locate_many_alloc_layout does)");
+            if (c.total >= 0xffffffffull)  // (the step counts a chunk's hit slots in 32 bits)
+                fail(GDX_ERR_CAPACITY, "%llu queries of the batch have %llu hits, more than a chunk's 32-bit offsets hold: cap them "
+                     "(gdx_query_options_t.max_hits_per_query), or take the device-written results (environment GDX_HOST_NARROW=dma)",
+                     static_cast<unsigned long long>(c.nq), static_cast<unsigned long long>(c.total));
             if (c.total > n32_cap) {  // rare: more hits than the chunk's buffers were sized for -- the second half again, with room
                 d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, c.total * sizeof(gdx_hit32_t));
                 d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
                 launch_offsets_hits(view_, d_rec[s], d_cmp[s], c.nq, qo.max_hits_per_query, true, d_scan[s], d_off32[s], true, c.total, rest,
                                     d_hits[s], d_ws[s], st.k, qo);
                 GDX_HIP(hipGetLastError());
-                if (wire32) {  // and the wire again, from the complete hits
+                if (wire) {  // and the wire again, from the complete hits
                     exc_hits_cap[s] = c.total;
                     d_exc[s] = device_buf<uint8_t>(dev, s * 16 + 15, max_nq * 8 + exc_hits_cap[s] * sizeof(gdx_hit32_t));
                     pack_wire(s, c.nq);
                     GDX_HIP(hipStreamSynchronize(st.k));
                 }
             }
-            if (wire32) {
+            if (wire) {
                 const uint32_t *meta = reinterpret_cast<const uint32_t *>(h_total[s] + 4);
                 w_exc[s] = meta[0], w_exc_hits[s] = meta[1], w_found[s] = meta[2];
                 w_status[s] = h_total[s][2] != 0;
@@ -617,7 +646,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             mid_hit_base += c.total;
             return;
         }
-        if (kind == Kind::kLocate) {
+        if (plain_locate) {
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = *h_total[s];
             if (c.total) {
@@ -630,15 +659,19 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             }
             GDX_HIP(hipEventRecord(st.ev_k[s], st.k));
         }
+        if (flagged) {
+            GDX_HIP(hipEventSynchronize(st.ev_total[s]));
+            w_status[s] = h_total[s][0] != 0;
+        }
         GDX_HIP(hipStreamWaitEvent(st.out, st.ev_k[s], 0));
-        if (kind == Kind::kLocate)
+        if (plain_locate)
             GDX_HIP(hipMemcpyAsync(h_off[s], d_off[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st.out));
         else
             GDX_HIP(hipMemcpyAsync(h_a[s], d_a[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
         if (kind == Kind::kIntervals)
             GDX_HIP(hipMemcpyAsync(h_b[s], d_b[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
-        GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
-        if (kind == Kind::kLocate && c.total)
+        if (!flagged || w_status[s]) GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
+        if (plain_locate && c.total)
             GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * hit_bytes, hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
     };
@@ -654,9 +687,8 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         if (timing) t_out_sync += now_seconds() - t_sync0;
         const uint32_t *a = h_a[s], *b = h_b[s];
         const uint8_t *stt = h_status[s];
-        if (wire32) {  // the chunk's wire -> offsets and hits in the sink's arrays, tiles shared out among the workers
+        if (wire) {  // the chunk's wire -> offsets and hits in the caller's arrays, tiles shared out among the workers
             const uint64_t need = c.hit_base + c.total;
-            if (need > narrow->cap) narrow->hits = narrow->grow(need, c.hit_base, &narrow->cap);  // (only this thread's workers write there)
             const HostWire w{h_wire[s] + w_bitmap,
                              reinterpret_cast<const uint32_t *>(h_wire[s] + w_tile_found),
                              reinterpret_cast<const uint32_t *>(h_wire[s] + w_tile_off),
@@ -667,17 +699,36 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
                              reinterpret_cast<const gdx_hit32_t *>(h_exc[s] + w_exc[s] * 8),
                              w_exc[s]};
             const uint64_t tiles = div_ceil(c.nq, kHostWireTile);
-            uint32_t *offs = narrow->offsets + c.q0;
-            gdx_hit32_t *hh = narrow->hits;
-            const uint32_t hb = static_cast<uint32_t>(c.hit_base);
-            pool.run([&](unsigned wk, unsigned nw) {
+            auto share = [&](unsigned wk, unsigned nw, uint64_t &lo, uint64_t &hi) {
                 const uint64_t per = div_ceil(tiles, nw);
-                const uint64_t lo = std::min<uint64_t>(tiles, per * wk), hi = std::min<uint64_t>(tiles, lo + per);
-                wire_expand_tiles(w, c.nq, lo, hi, hb, offs, hh);
-            });
+                lo = std::min<uint64_t>(tiles, per * wk), hi = std::min<uint64_t>(tiles, lo + per);
+            };
+            if (kind == Kind::kLocate32) {
+                if (need > narrow->cap) narrow->hits = narrow->grow(need, c.hit_base, &narrow->cap);  // (only this thread's workers write there)
+                uint32_t *offs = narrow->offsets + c.q0;
+                gdx_hit32_t *hh = narrow->hits;
+                const uint32_t hb = static_cast<uint32_t>(c.hit_base);
+                pool.run([&](unsigned wk, unsigned nw) {
+                    uint64_t lo, hi;
+                    share(wk, nw, lo, hi);
+                    wire_expand_tiles<uint32_t, gdx_hit32_t>(w, c.nq, lo, hi, hb, offs, hh);
+                });
+            } else {  // u64 offsets and 16-byte hits; the hits only while the caller's buffer holds them (gdx_locate_many's sizing pass)
+                if (grow_hits && need > hits_capacity) hits = (*grow_hits)(need, &hits_capacity);  // at least `need`
+                if (!(hits && need <= hits_capacity && capacity_ok)) capacity_ok = false;
+                uint64_t *offs = out_a ? out_a + c.q0 : nullptr;
+                gdx_hit_t *hh = capacity_ok ? hits : nullptr;
+                if (offs != nullptr || hh != nullptr)
+                    pool.run([&](unsigned wk, unsigned nw) {
+                        uint64_t lo, hi;
+                        share(wk, nw, lo, hi);
+                        wire_expand_tiles<uint64_t, gdx_hit_t>(w, c.nq, lo, hi, c.hit_base, offs, hh);
+                    });
+                hit_base = need;
+            }
         } else if (kind == Kind::kLocate32) {
             // (offsets and hits are where they belong already)
-        } else if (kind == Kind::kLocate) {
+        } else if (plain_locate) {
             c.hit_base = hit_base;
             if (out_a) {  // the chunk's offsets (scanned on the device) shifted by the hits of the chunks before it
                 const uint64_t *off = h_off[s];
@@ -708,13 +759,11 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             hit_base = need;
         } else {
             pool.parallel_range(c.nq, 8, [&](uint64_t lo, uint64_t hi) {
-                for (uint64_t i = lo; i < hi; i++) {
-                    if (out_a) out_a[c.q0 + i] = a[i];
-                    if (out_b) out_b[c.q0 + i] = b[i];
-                }
+                if (out_a) widen_u32(a + lo, hi - lo, out_a + c.q0 + lo);
+                if (out_b) widen_u32(b + lo, hi - lo, out_b + c.q0 + lo);
             });
         }
-        if (wire32 && !w_status[s]) {  // (no read of the chunk has a status: the bytes stayed on the device)
+        if ((wire || flagged) && !w_status[s]) {  // (no read of the chunk has a status: the bytes stayed on the device)
             if (out_status) pool.parallel_range(c.nq, 64, [&](uint64_t lo, uint64_t hi) { std::memset(out_status + c.q0 + lo, 0, hi - lo); });
             return;
         }

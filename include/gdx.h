@@ -571,8 +571,12 @@ int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d
 
 /* gdx_locate_many_alloc_layout with NARROW results in pinned host memory the library owns (FmIndex::locate_many, lib.rs:179-185;
  * Hit lib.rs:331-335 as two u32): hit_offsets is u32[nq + 1], hits gdx_hit32_t[total_hits] -- 8 + 4 bytes per result instead of
- * 16 + 8, and the device writes them where they lie by D2H copy, so no host thread copies or widens a result (the wide call
- * spends its time there once the reads come as 2-bit codes: 12.5 bytes in, 23 bytes out per read).  Fewer than 2^32 hits in all,
+ * 16 + 8 (the wide call spends its time widening once the reads come as 2-bit codes: 12.5 bytes in, 23 bytes out per read).
+ * The link bounds this call and its two directions share one rate, so a chunk's results cross it packed -- the found-bitmap
+ * wire of gdx_wire_pack_dev below: a bit per read, position (+ a text id byte) per read with one hit, the others' hits, 3.7-4.6
+ * bytes per read instead of 12.2 -- and host threads write offsets and hits into the arrays (AVX2, streaming stores; status bytes
+ * stay on the device unless a read of the chunk has one).  Environment GDX_HOST_NARROW=dma: the device writes offsets and hits
+ * itself (also what collections of more than 256 texts and hosts with fewer than four workers get).  Fewer than 2^32 hits in all,
  * else GDX_ERR_CAPACITY (the wide call has no such limit).  Release the arrays with gdx_free_hits32: the library keeps one pair
  * for the caller's next batch (pinning memory costs about a millisecond per 10 MB); gdx_release_cached_hits() frees what the
  * library holds back, this pair and the array of gdx_free_hits.  layout may be NULL (IO symbols + offsets).  When qbuf itself

@@ -178,16 +178,34 @@ int main(int argc, char **argv)
             const gdx::HostWire w{b_bitmap.get(), b_tf.get(), b_to.get(), b_fp.get(), n_texts > 1 ? b_fi.get() : nullptr,
                                   b_eq.get(), b_ec.get(), b_eh.get(), exc_q.size()};
             for (uint64_t workers : {uint64_t(1), uint64_t(3), uint64_t(7)}) {
+                const uint64_t per = (tiles + workers - 1) / workers;
+                // the narrow form (u32 offsets, 8-byte hits) ...
                 std::unique_ptr<uint32_t[]> off(new uint32_t[nq + 1]);
                 std::unique_ptr<gdx_hit32_t[]> hits(new gdx_hit32_t[base + want_hits.size() + 1]);
                 std::fill(off.get(), off.get() + nq + 1, 0xdeadbeefu);
-                const uint64_t per = (tiles + workers - 1) / workers;
                 for (uint64_t k = workers; k-- > 0;)  // (in reverse: no piece relies on the one before it)
-                    gdx::wire_expand_tiles(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), base, off.get(), hits.get());
+                    gdx::wire_expand_tiles<uint32_t, gdx_hit32_t>(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), base, off.get(),
+                                                                  hits.get());
                 for (uint64_t q = 0; q <= nq; q++)
                     if (off[q] != want_off[q] && nq != 0) return 8;
                 for (uint64_t i = 0; i < want_hits.size(); i++)
                     if (hits[base + i].text_id != want_hits[i].text_id || hits[base + i].position != want_hits[i].position) return 9;
+                // ... the wide form (u64 offsets, 16-byte hits), and offsets alone beyond 2^32 (the sizing pass of gdx_locate_many)
+                std::unique_ptr<uint64_t[]> off64(new uint64_t[nq + 1]), off_only(new uint64_t[nq + 1]);
+                std::unique_ptr<gdx_hit_t[]> hits64(new gdx_hit_t[base + want_hits.size() + 1]);
+                const uint64_t far = 5'000'000'000ull;
+                for (uint64_t k = workers; k-- > 0;) {
+                    gdx::wire_expand_tiles<uint64_t, gdx_hit_t>(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), base, off64.get(),
+                                                                hits64.get());
+                    gdx::wire_expand_tiles<uint64_t, gdx_hit_t>(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), far, off_only.get(),
+                                                                nullptr);
+                    gdx::wire_expand_tiles<uint64_t, gdx_hit_t>(w, nq, std::min(tiles, per * k), std::min(tiles, per * k + per), base, nullptr,
+                                                                hits64.get());
+                }
+                for (uint64_t q = 0; q <= nq; q++)
+                    if (nq != 0 && (off64[q] != want_off[q] || off_only[q] != want_off[q] - base + far)) return 10;
+                for (uint64_t i = 0; i < want_hits.size(); i++)
+                    if (hits64[base + i].text_id != want_hits[i].text_id || hits64[base + i].position != want_hits[i].position) return 11;
             }
             std::printf("ok %zu %zu\n", want_hits.size(), exc_q.size());
         } else {

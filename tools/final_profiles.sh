@@ -33,3 +33,11 @@ for f in ascii uniform packed; do
 done
 python3 tests/parity_sweep.py 300 21 > $OUT/parity_sweep_seed21.json 2> $OUT/parity21.err
 tail -3 $OUT/gpu_tests_final.log; tail -c 300 $OUT/parity_sweep_seed21.json; echo; head -12 $OUT/bench_hg38_final_kernel_stats.md
+# round 5: the step on 100 / 50 / 25 / 12.5 M reads (split and fused, the gather wires' pack / split kernels), the launches of
+# the last steps with the gaps between them, and the host-pointer pipeline's threads with the results crossing PCIe as the
+# found-bitmap wire (default) and written by the device
+python3 tools/exp_shard_step.py 20 > $OUT/shard_step.json 2> $OUT/shard_step.err
+bash tools/trace_timeline.sh $1/timeline 140 tools/exp_shard_step.py 3 > /dev/null
+python3 tools/host_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_timing_wire.log
+GDX_HOST_NARROW=dma python3 tools/host_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_timing_dma.log
+grep "rep 2" $OUT/host_timing_wire.log $OUT/host_timing_dma.log

@@ -59,3 +59,14 @@ for name, buf, off, pk, ul in (("packed+uniform", packed, None, True, 50),):
         index.count_layout_raw(buf, off, nq, packed=pk, uniform_len=ul)
         t1 = time.perf_counter()
         print(f"{name} rep {rep}: count {t1 - t0:.4f}s", flush=True)
+# the wide call (u64 offsets, 16-byte hits: what a binding of the reference's locate_many takes), on the same forms
+offs = np.empty(nq + 1, dtype=np.uint64)
+for what, ptr in (("pageable input", packed.ctypes.data_as(_lib.u8p)), ("pinned input", C.cast(C.c_void_p(pinned.data_ptr()), _lib.u8p))):
+    for rep in range(3):
+        hp, total = C.POINTER(_lib.HitStruct)(), C.c_uint64(0)
+        t0 = time.perf_counter()
+        _lib.check(lib.gdx_locate_many_alloc_layout(index._h, ptr, None, nq, C.byref(lay), offs.ctypes.data_as(_lib.u64p), C.byref(hp),
+                                                    C.byref(total), status.ctypes.data_as(_lib.u8p)))
+        dt = time.perf_counter() - t0
+        print(f"locate (wide) {what} rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s, {total.value} hits", flush=True)
+        lib.gdx_free_hits(hp)
