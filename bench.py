@@ -96,7 +96,7 @@ def parse_args():
     ap.add_argument("--secondary-depth", type=int, default=10,
                     help="N=1 only: lookup-table depth of the `lookup_depth_D` secondary design point; 0 = no secondaries")
     ap.add_argument("--index", default="seed", choices=["seed", "tables"],
-                    help="headline index: seed = the reference's arrays + seed table + text units + full suffix array (74 GB "
+                    help="headline index: seed = the reference's arrays + seed table + text units + full suffix array (84 GB "
                          "at hg38 scale); tables = the library's default structures (pair lines + 32-byte jump entries + "
                          "depth-16 top table, 144 GB: the headline of rounds 1..3a, a ladder rung now)")
     ap.add_argument("--jump-bytes", type=int, default=None, help="gdx_build_options_t.jump_entry_bytes")
@@ -136,7 +136,10 @@ def parse_args():
     return args
 
 
-SEED_INDEX = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, full_suffix_array=True, seed_symbols=True)
+# (seed_load_percent: slots of the seed table filled on average.  The library's default of 70 leaves 15 % of the buckets overflowing
+# into their neighbours -- a second 128-byte fetch for the reads that land there; at 60 it is 6.6 %: 9 GB more of the 288, the
+# step 4.5 % shorter on 100 M reads and 8 % on the 12.5 M a rank of eight runs (profiles/r05/seed_load_sweep.txt))
+SEED_INDEX = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0, full_suffix_array=True, seed_symbols=True, seed_load_percent=60)
 REFERENCE_ARRAYS = dict(pair_lines=False, jump_entry_bytes=0, top_table_depth=0)  # the reference's information content, nothing else
 LOOKUP_RUNGS = (10, 13)        # lookup-table depths of the `reference_arrays_dD` secondaries (lookup_table.rs:51-161)
 LOOKUP_PMC_READS = 20_000_000  # reads of their PMC child passes
@@ -1867,7 +1870,7 @@ def mixed_length_secondary(torch, eng, io_text, lengths, light=False):
                "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms, "cursor_api_value": nq / (cursor_ms / 1e3),
                "cursor_api_ms": cursor_ms, "unit": "queries/s", "intervals_identical": True,
                "note": "exact intervals and cursor extension need the pair-line / jump structures (the 214 GB index of the "
-                       "`mixed_lengths_20_150` secondary); on the 74 GB headline index (reference arrays + seed table + text units "
+                       "`mixed_lengths_20_150` secondary); on the 84 GB headline index (reference arrays + seed table + text units "
                        "+ full SA) both calls fall to the rank-line kernel -- the seed table serves count / locate, where no "
                        "interval has to come out"}
         log(f"[bench] secondary {res}")

@@ -24,10 +24,11 @@ dev = torch.device("cuda", 0)
 io_text = synth_text(total, seed=42, n_per_million=10_000, device=dev)
 lengths = hg38_text_lengths(total, 24)
 index = build_index_from_device_text(io_text, lengths, alphabet.ascii_dna_with_n(), index_storage="u32",
-                                     options=build_options(**bench.SEED_INDEX))
+                                     options=build_options(**dict(bench.SEED_INDEX, **({"seed_load_percent": int(os.environ["GDX_EXP_SEED_LOAD"])}
+                                                                                        if os.environ.get("GDX_EXP_SEED_LOAD") else {}))))
 eng = DeviceEngine(index)
 full = DeviceQueries.synth(io_text, lengths, max(sizes), 50, 50, 900_000, seed=43)
-res = {"steps": steps, "index_gb": index.info.device_bytes / 1e9, "shard_step": {}}
+res = {"steps": steps, "index_gb": index.info.device_bytes / 1e9, "seed": index.seed_info(), "shard_step": {}}
 for nq in sizes:
     q = full.copy_slice(0, nq).as_packed(index).as_uniform(50)
     per = {}
