@@ -324,10 +324,10 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // multi-GPU gather uses (launch_wire_pack: a bit per read, position + text id byte per found read, the exceptions with their
     // hits -- 3.7-4.6 bytes per read instead of 12.2 narrow / 16.2 wide), and the drainer's workers expand them into the
     // caller's arrays (wire_host.hpp): the link's two directions share its rate (65 GB/s together on the test box against 57
-    // alone), so bytes saved going out are time saved.  GDX_HOST_NARROW=dma: the device-written forms (hosts with few cores
+    // alone), so bytes saved going out are time saved.  GDX_HOST_RESULTS=dma: the device-written forms (hosts with few cores
     // to spare).  Collections of more than 256 texts take those too (text ids travel as bytes).
     static const int narrow_mode = [] {
-        const char *e = getenv("GDX_HOST_NARROW");
+        const char *e = getenv("GDX_HOST_RESULTS");
         if (e && std::strcmp(e, "dma") == 0) return 0;
         if (e && std::strcmp(e, "wire") == 0) return 1;
         return host_threads() >= 4 ? 1 : 0;
@@ -586,7 +586,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
                 fail(GDX_ERR_CAPACITY, "more than 2^32 - 1 hits: 32-bit hit offsets do not hold them (gdx_locate_many_alloc_layout does)");
             if (c.total >= 0xffffffffull)  // (the step counts a chunk's hit slots in 32 bits)
                 fail(GDX_ERR_CAPACITY, "%llu queries of the batch have %llu hits, more than a chunk's 32-bit offsets hold: cap them "
-                     "(gdx_query_options_t.max_hits_per_query), or take the device-written results (environment GDX_HOST_NARROW=dma)",
+                     "(gdx_query_options_t.max_hits_per_query), or take the device-written results (environment GDX_HOST_RESULTS=dma)",
                      static_cast<unsigned long long>(c.nq), static_cast<unsigned long long>(c.total));
             if (c.total > n32_cap) {  // rare: more hits than the chunk's buffers were sized for -- the second half again, with room
                 d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, c.total * sizeof(gdx_hit32_t));

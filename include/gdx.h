@@ -303,7 +303,11 @@ int gdx_cursors_for_many_queries(const gdx_index_t *ix, const uint8_t *qbuf, con
 /* FmIndex::locate_many lib.rs:179-185.  Hits of query i are hits[out_hit_offsets[i] ..
  * out_hit_offsets[i+1]) in suffix-array order (lib.rs:187-197).  *out_total is always set;
  * if hits == NULL or hits_capacity < total the call returns GDX_ERR_CAPACITY after filling
- * out_hit_offsets (sizing call). */
+ * out_hit_offsets (sizing call).  The locate calls on host pointers run the batch in chunks, each ONE fused step on the device
+ * whose results cross PCIe packed (the found-bitmap wire of gdx_wire_pack_dev: 3.7-4.6 bytes per read) and are expanded into the
+ * caller's arrays by host threads; a chunk may hold at most 2^32 - 2 hits (GDX_ERR_CAPACITY names the remedy).  Environment
+ * GDX_HOST_RESULTS=dma: search, total, locate as separate launches and offsets + hits copied out by the device (rounds 1-4;
+ * also what collections of more than 256 texts and hosts with fewer than four worker threads get). */
 int gdx_locate_many(const gdx_index_t *ix, const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq,
                     uint64_t *out_hit_offsets /*nq+1*/, gdx_hit_t *hits, uint64_t hits_capacity,
                     uint64_t *out_total, uint8_t *out_status);
@@ -575,8 +579,8 @@ int gdx_cursors_for_many_queries_layout_dev(const gdx_index_t *ix, const void *d
  * The link bounds this call and its two directions share one rate, so a chunk's results cross it packed -- the found-bitmap
  * wire of gdx_wire_pack_dev below: a bit per read, position (+ a text id byte) per read with one hit, the others' hits, 3.7-4.6
  * bytes per read instead of 12.2 -- and host threads write offsets and hits into the arrays (AVX2, streaming stores; status bytes
- * stay on the device unless a read of the chunk has one).  Environment GDX_HOST_NARROW=dma: the device writes offsets and hits
- * itself (also what collections of more than 256 texts and hosts with fewer than four workers get).  Fewer than 2^32 hits in all,
+ * stay on the device unless a read of the chunk has one; GDX_HOST_RESULTS=dma as above: the device writes offsets and hits
+ * itself).  Fewer than 2^32 hits in all,
  * else GDX_ERR_CAPACITY (the wide call has no such limit).  Release the arrays with gdx_free_hits32: the library keeps one pair
  * for the caller's next batch (pinning memory costs about a millisecond per 10 MB); gdx_release_cached_hits() frees what the
  * library holds back, this pair and the array of gdx_free_hits.  layout may be NULL (IO symbols + offsets).  When qbuf itself

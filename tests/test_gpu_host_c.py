@@ -86,10 +86,10 @@ def test_c_host_without_python_or_torch(tmp_path, lookup_depth, narrow):
     assert total > 20_000
     exe = _compile(tmp_path)
     # a process of its own, with nothing of this one's torch in its environment
-    # (GDX_HOST_NARROW: how the narrow locate call's results cross PCIe -- the found-bitmap wire expanded by host threads, the
+    # (GDX_HOST_RESULTS: how the narrow locate call's results cross PCIe -- the found-bitmap wire expanded by host threads, the
     # default on hosts with four workers or more, or offsets and hits written by the device)
     env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCH", "PYTORCH", "PYTHON"))}
-    env["GDX_HOST_NARROW"] = narrow
+    env["GDX_HOST_RESULTS"] = narrow
     res = subprocess.run([exe, vec], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and res.stdout.strip().endswith("PASS"), res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("\nok ") + res.stdout.startswith("ok ") == 3, res.stdout

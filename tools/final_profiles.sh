@@ -39,5 +39,5 @@ tail -3 $OUT/gpu_tests_final.log; tail -c 300 $OUT/parity_sweep_seed21.json; ech
 python3 tools/exp_shard_step.py 20 > $OUT/shard_step.json 2> $OUT/shard_step.err
 bash tools/trace_timeline.sh $1/timeline 140 tools/exp_shard_step.py 3 > /dev/null
 python3 tools/host_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_timing_wire.log
-GDX_HOST_NARROW=dma python3 tools/host_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_timing_dma.log
+GDX_HOST_RESULTS=dma python3 tools/host_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/host_timing_dma.log
 grep "rep 2" $OUT/host_timing_wire.log $OUT/host_timing_dma.log
