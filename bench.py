@@ -1155,7 +1155,10 @@ def compact_line(result, side_file=None):
                      "useful_bytes_per_query", "dram_read_requests_per_query", "l2_hit_rate", "frac_of_measured_stream_read"))
     for k in ("traffic", "achieved", "frac"):  # the contract's keys are there even when nothing was measured (null)
         roof.setdefault(k, r.get(k))
-    roof["traffic_source"] = (r.get("traffic_source") or "")[:160]
+    roof["traffic_source"] = (r.get("traffic_source") or "")[:64]
+    parts = str(roof.get("kernel") or "").split(" + ")
+    if len(parts) > 1:  # the dominant kernel by name, the list kernels of the same step in the side file
+        roof["kernel"] = f"{parts[0]} (+ {len(parts) - 1} list kernels of the same step: side file)"
     if r.get("reference_layout"):
         roof["reference_layout"] = _pick(r["reference_layout"], ("index_bytes", "value", "search_ms", "frac_traffic",
                                                                  "frac_algorithmic", "dram_read_requests_per_query"))

@@ -493,7 +493,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         const uint64_t src_byte = packed ? base / 4 : base;
         const uint64_t n_bytes = packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
         if (!pinned_input)
-            pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { std::memcpy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
+            pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { stream_copy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
         if (!uniform)
             pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;

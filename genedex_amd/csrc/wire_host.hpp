@@ -212,6 +212,43 @@ inline void widen_u32(const uint32_t *in, uint64_t n, uint64_t *out)
     for (uint64_t i = 0; i < n; i++) out[i] = in[i];
 }
 
+// memcpy into a staging buffer the CPU does not read again (the link's DMA does): stores past the caches, so that no line of the
+// destination is read in order to be overwritten -- a third of the memory traffic of the plain copy of a piece too small for the
+// C library to do the same on its own
+#ifdef GDX_WIRE_AVX2
+__attribute__((target("avx2"))) inline void stream_copy_avx2(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    uint64_t i = 0;
+    const uint64_t head = (32u - (reinterpret_cast<uintptr_t>(dst) & 31u)) & 31u;
+    if (head != 0 && head <= n) {
+        std::memcpy(dst, src, head);
+        i = head;
+    }
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    if (i < n) std::memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
+#endif
+inline void stream_copy(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+#ifdef GDX_WIRE_AVX2
+    if (n >= 4096 && wire_have_avx2()) {
+        stream_copy_avx2(dst, src, n);
+        return;
+    }
+#endif
+    std::memcpy(dst, src, n);
+}
+
 inline void wire_expand_fence()
 {
 #ifdef GDX_WIRE_AVX2

@@ -29,7 +29,7 @@ def shard_range(n_items: int, rank: int, world: int, root_weight: float = 1.0):
 # index): a count + locate step costs STEP_FIXED_MS + STEP_PS_PER_READ per read, the root's split of a received read
 # (gdx_wire_split_dev) SPLIT_PS_PER_READ, a read travels as WIRE_BYTES_PER_READ bytes, and a link into the root carries one
 # direction of an xGMI link.
-STEP_FIXED_MS, STEP_PS_PER_READ, SPLIT_PS_PER_READ, WIRE_BYTES_PER_READ, XGMI_ONE_DIRECTION_GBPS = 0.105, 31.0, 2.56, 3.725, 76.8
+STEP_FIXED_MS, STEP_PS_PER_READ, SPLIT_PS_PER_READ, WIRE_BYTES_PER_READ, XGMI_ONE_DIRECTION_GBPS = 0.085, 30.6, 2.55, 3.725, 76.8
 
 
 def root_weight_for(world: int, n_reads: int = 100_000_000, link_GBps: float = XGMI_ONE_DIRECTION_GBPS,
@@ -38,7 +38,7 @@ def root_weight_for(world: int, n_reads: int = 100_000_000, link_GBps: float = X
     split of the world - 1 shards it receives -- takes as long as a link needs for one of those shards (the links bound a
     gathered step: DESIGN.md section 6).  With s reads per other rank, s = n / (world - 1 + w):
         STEP_FIXED + s (w STEP + (world - 1) SPLIT) = s L,   L = bytes per read / link rate
-    Slow links (or a few fast GPUs) give the root MORE than the others, many ranks less: 1.40 / 1.18 / 0.73 at 2 / 4 / 8
+    Slow links (or a few fast GPUs) give the root MORE than the others, many ranks less: 1.43 / 1.22 / 0.79 at 2 / 4 / 8
     ranks with the numbers above.  Clamped to [0.25, 2]."""
     if world <= 1:
         return 1.0

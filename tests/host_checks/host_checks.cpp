@@ -207,6 +207,21 @@ int main(int argc, char **argv)
                 for (uint64_t i = 0; i < want_hits.size(); i++)
                     if (hits64[base + i].text_id != want_hits[i].text_id || hits64[base + i].position != want_hits[i].position) return 11;
             }
+            // the staging copy and the widening of counts, on exactly sized blocks at every alignment of source and destination
+            for (uint64_t len : {uint64_t(0), uint64_t(1), uint64_t(31), uint64_t(4095), uint64_t(4096), uint64_t(4229), uint64_t(10000)})
+                for (uint64_t shift = 0; shift < 40; shift += 13) {
+                    std::unique_ptr<uint8_t[]> src(new uint8_t[len + shift + 1]), dst(new uint8_t[len + 40 - shift + 1]);
+                    for (uint64_t i = 0; i < len; i++) src[shift + i] = static_cast<uint8_t>(rnd());
+                    gdx::stream_copy(dst.get() + (40 - shift), src.get() + shift, len);
+                    if (len != 0 && std::memcmp(dst.get() + (40 - shift), src.get() + shift, len) != 0) return 12;
+                    const uint64_t n32 = len / 4;
+                    std::unique_ptr<uint64_t[]> wide(new uint64_t[n32 + 1]);
+                    std::unique_ptr<uint32_t[]> narrow(new uint32_t[n32 + 1]);
+                    for (uint64_t i = 0; i < n32; i++) narrow[i] = static_cast<uint32_t>(rnd());
+                    gdx::widen_u32(narrow.get() + (shift & 1), n32 - (n32 ? (shift & 1) : 0), wide.get() + (shift & 1));
+                    for (uint64_t i = (shift & 1); i < n32; i++)
+                        if (wide[i] != narrow[i]) return 13;
+                }
             std::printf("ok %zu %zu\n", want_hits.size(), exc_q.size());
         } else {
             return 2;

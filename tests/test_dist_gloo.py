@@ -202,7 +202,7 @@ def test_shard_ranges_partition_the_batch():
             assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [hi - lo for lo, hi in r]
             if world > 1 and n >= 100:
-                assert max(sizes[1:]) - min(sizes[1:]) <= 1 and abs(sizes[0] - w * sizes[1]) <= 2
+                assert max(sizes[1:]) - min(sizes[1:]) <= 1 and abs(sizes[0] - w * sizes[1]) <= 1 + w  # (both sizes are rounded)
     # many ranks: a smaller root shard; two ranks on nominal links: a larger one; slower links: larger still
     assert root_weight_for(1) == 1.0 and 0.6 < root_weight_for(8) < 0.8 and root_weight_for(100) == 0.25
     assert 1.2 < root_weight_for(2) < 1.6 and root_weight_for(8, link_GBps=50.0) > root_weight_for(8) and root_weight_for(2, link_GBps=1.0) == 2.0

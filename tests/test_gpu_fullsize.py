@@ -356,7 +356,7 @@ def test_full_size_headline_configuration(hg38_scale):
     aux = eng.aux_info()
     assert aux["seed"]["k"] == 24 and aux["text_units"] and aux["full_suffix_array"]
     assert not aux["pair_lines"] and aux["jump_entry_bytes"] == 0 and aux["top_table_depth"] == 0
-    assert 70e9 < index.info.device_bytes < 80e9
+    assert 80e9 < index.info.device_bytes < 90e9  # (reference arrays 4.65 + seed table at load 60: 64.9 + text units 1.55 + SA 12.4)
 
     def step(q, nq):
         runner = bench.StepRunner(torch, eng, q, nq, True, "records")

@@ -70,3 +70,25 @@ for what, ptr in (("pageable input", packed.ctypes.data_as(_lib.u8p)), ("pinned 
         dt = time.perf_counter() - t0
         print(f"locate (wide) {what} rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s, {total.value} hits", flush=True)
         lib.gdx_free_hits(hp)
+# the reference's own form: IO symbols + u64 offsets (58 bytes per read on the way in: the link is the bound at 0.98 G reads/s)
+counts = np.empty(nq, dtype=np.uint64)
+qb_p, qo_p = qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p)
+for rep in range(3):
+    t0 = time.perf_counter()
+    _lib.check(lib.gdx_count_many(index._h, qb_p, qo_p, nq, counts.ctypes.data_as(_lib.u64p), status.ctypes.data_as(_lib.u8p)))
+    dt = time.perf_counter() - t0
+    print(f"count, ASCII + offsets, rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s", flush=True)
+for rep in range(3):
+    hp, total = C.POINTER(_lib.HitStruct)(), C.c_uint64(0)
+    t0 = time.perf_counter()
+    _lib.check(lib.gdx_locate_many_alloc(index._h, qb_p, qo_p, nq, offs.ctypes.data_as(_lib.u64p), C.byref(hp), C.byref(total),
+                                         status.ctypes.data_as(_lib.u8p)))
+    dt = time.perf_counter() - t0
+    print(f"locate (wide), ASCII + offsets, rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s, {total.value} hits", flush=True)
+    lib.gdx_free_hits(hp)
+for rep in range(3):
+    t0 = time.perf_counter()
+    _lib.check(lib.gdx_count_many_layout(index._h, packed.ctypes.data_as(_lib.u8p), None, nq, C.byref(lay), counts.ctypes.data_as(_lib.u64p),
+                                         status.ctypes.data_as(_lib.u8p)))
+    dt = time.perf_counter() - t0
+    print(f"count, 2-bit uniform, rep {rep}: {dt:.4f}s = {nq / dt / 1e9:.2f} G reads/s", flush=True)
