@@ -1472,7 +1472,7 @@ def strong_scaling(torch, gdist, eng, io_text, lengths, wl, nq_total, do_locate,
 
 def committed_traffic(args, nq, aux, why):
     """Fallback when the live PMC passes are unavailable: the committed summary of the same configuration."""
-    path = os.path.join(ROOT, "profiles", "r04", "search_pmc_final.json")
+    path = os.path.join(ROOT, "profiles", "r05", "search_pmc_final.json")
     try:
         with open(path) as f:
             p = json.load(f)

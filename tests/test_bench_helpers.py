@@ -41,7 +41,7 @@ def test_committed_fallback_summary_is_readable():
     aux = {"jump_entry_bytes": 0, "top_table_depth": 0, "seed": {"k": 24}}  # the headline index (bench.py --index seed)
     t, source = bench.committed_traffic(args, 100_000_000, aux, "test")
     assert t is not None and "NOT measured in this run" in source
-    assert 1.3e10 < t["bytes"] < 1.9e10 and 1.0 < t["read_requests"] / 1e8 < 1.3  # ~158 bytes, ~1.19 requests per read
+    assert 1.3e10 < t["bytes"] < 1.9e10 and 1.0 < t["read_requests"] / 1e8 < 1.3  # ~154 bytes, ~1.14 requests per read (seed table at load 0.6)
     # (the summary is of the batch as 2-bit codes without offsets: another form of the batch is another configuration)
     other_form, why = bench.committed_traffic(argparse.Namespace(**{**vars(args), "input": "ascii"}), 100_000_000, aux, "test")
     assert other_form is None and "another configuration" in why
@@ -332,3 +332,44 @@ def test_kernel_stats_of_the_trace_child_pass(tmp_path):
     assert (tmp_path / "kept" / "stats.csv").exists()
     assert abs(bench.rocprof_ms_of(out, "search_seed_kernel|search_verify_kernel|search_kernel") - 4.1) < 1e-9
     assert bench.rocprof_ms_of(out, "locate_queue_kernel") is None and bench.rocprof_ms_of(None, "x") is None
+
+
+def test_committed_round5_line_is_what_the_driver_can_read():
+    """profiles/r05/bench_hg38_final.json: the stdout line of the driver's command on round 5's final tree -- below 4 KB, the
+    contract's keys, a roofline fraction that follows from its own traffic and time, the profiler's time beside it in
+    agreement with the kernel statistics kept under profiles/, the shard steps, the input form by name, and the side file
+    with what the line leaves out (incl. the narrow host call checked against the wide one)."""
+    raw = open(os.path.join(ROOT, "profiles", "r05", "bench_hg38_final.json")).read()
+    assert raw.count("\n") <= 1 and len(raw.encode()) < 4096
+    d = json.loads(raw)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "input_form", "shard_step_ms"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "u32" and d["config"]["input"] == "packed+uniform"
+    assert abs(d["value"] - d["config"]["queries_per_gpu"] / (d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic_source"].startswith("live")
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["traffic"] / (r["avg_launch_ms"] / 1e3) / 1e9 / r["peak"]) < 1e-4
+    assert abs(r["avg_launch_ms_rocprof"] - r["avg_launch_ms"]) < 0.08 * r["avg_launch_ms"]
+    assert r["dram_read_requests_per_query"] < 1.2 and "search_seed_lane_kernel<2, true>" in r["kernel"]
+    for rung in ("reference_layout", "reference_layout_d10", "reference_layout_d13"):
+        assert 0.25 < r[rung]["frac_algorithmic"] < 0.40, rung
+    stats = open(os.path.join(ROOT, "profiles", "r05", "bench_child_kernel_stats.md")).read()
+    row = [ln for ln in stats.splitlines() if "search_seed_lane_kernel<2, true>" in ln][0].split("|")
+    assert 0.95 * r["avg_launch_ms_rocprof"] < float(row[4]) <= r["avg_launch_ms_rocprof"]  # (+ its list kernels)
+    # the same command under rocprofv3 --kernel-trace --stats: the kernel's average there agrees too
+    stats = open(os.path.join(ROOT, "profiles", "r05", "bench_hg38_final_kernel_stats.md")).read()
+    row = [ln for ln in stats.splitlines() if "search_seed_lane_kernel<2, true>" in ln][0].split("|")
+    assert abs(float(row[4]) - r["avg_launch_ms"]) < 0.08 * r["avg_launch_ms"]
+    assert float(d["shard_step_ms"]["12500000"]) <= 0.50  # what a rank of eight runs of the sharded batch
+    assert d["locate_roofline"]["frac"] >= 0.55
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["bit_exact_vs_gpu"] == {"intervals": True, "counts": True, "hits": True}
+    assert d["ascii_input"]["offsets_and_hits_identical_to_headline"] is True and d["ascii_input"]["value"] < d["value"]
+    side = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_secondary.json")))
+    names = [s_["name"] for s_ in side["secondary"]]
+    assert "reference_arrays_d10" in names and "reference_arrays_d13" in names and any("genome_like" in n for n in names)
+    assert abs(side["value"] - d["value"]) < 1e-5 * side["value"]
+    pu = side["end_to_end"]["packed_uniform"]
+    assert pu["results_identical_to_device_path"] == {"counts": True, "hits_total": True, "narrow_equals_wide": True}
+    assert side["end_to_end"]["fastq_to_hits"]["hits_identical_to_device_path"] is True
