@@ -1294,3 +1294,44 @@ def test_lookup_tables_deeper_than_fifteen(depth):
     off, t_, p_, _ = g.locate_raw(qbuf, qoff, strict=False)
     co, ct, cp = c.locate_intervals(np.where(ok, cs, 0), np.where(ok, ce, 0))
     assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist()
+
+
+@pytest.mark.parametrize("n_texts", [2, 200, 256, 257, 700])
+def test_host_locate_on_collections_of_many_texts(n_texts):
+    """The host-pointer locate calls send a chunk's results across PCIe as the found-bitmap wire -- text ids as BYTES beside
+    positions in the text -- when the collection has at most 256 texts, and let the device write offsets and hits otherwise
+    (host_api.hip): wide and narrow results, counts and statuses are the oracle's on either side of that border, through many
+    small chunks, with reads that occur in several texts (every hit's text id matters) and reads that occur nowhere."""
+    from genedex_amd import _lib
+
+    rng = np.random.default_rng(7700 + n_texts)
+    a = alph.ascii_dna()
+    shared = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 40))  # a stretch that many texts hold
+    texts = []
+    for t in range(n_texts):
+        body = bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(60, 400))))
+        texts.append(body + shared if t % 5 == 0 else body)
+    g, c = both(texts, a)
+    qs = []
+    for i in range(6000):
+        t = texts[int(rng.integers(0, n_texts))]
+        ln = int(rng.integers(12, 45))
+        at = int(rng.integers(0, len(t) - ln + 1))
+        qs.append(t[at:at + ln] if i % 7 else bytes(b"ACGT"[k] for k in rng.integers(0, 4, ln)))
+    qs += [shared, shared[5:35], shared[:20]]
+    qbuf, qoff = pack_queries(qs)
+    co, ct, cp = c.locate_many(qs)
+    assert int(np.diff(co).max()) > n_texts // 6  # (the shared stretch: a hit in every fifth text)
+    lib = _lib.load()
+    lib.gdx_debug_set_host_chunking(501, 0)
+    try:
+        off, t_, p_, st = g.locate_raw(qbuf, qoff)
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist() and not st.any()
+        off, t_, p_, st = g.locate_alloc_raw(qbuf, qoff)
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist() and not st.any()
+        off, t_, p_, st = g.locate_layout32_raw(qbuf, qoff, len(qs))
+        assert off.tolist() == co.tolist() and t_.tolist() == ct.tolist() and p_.tolist() == cp.tolist() and not st.any()
+        cnt, st = g.count_raw(qbuf, qoff)
+        assert cnt.tolist() == np.diff(co).tolist() and not st.any()
+    finally:
+        lib.gdx_debug_set_host_chunking(0, 0)
