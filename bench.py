@@ -1728,7 +1728,15 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     # the step over 16-byte records with the per-query limit: search -> offsets -> read-back of the total -> hits.  (The
     # headline's compact results + one-call step cost more than they save here -- a third of the reads is listed for the next
     # kernel and keeps its record anyway: 13.3 against 12.4 ms on one box, profiles/r05/README.md; `path` = records switches)
-    runner = StepRunner(torch, eng, q, nq, True, getattr(args, "genome_path", None) or "records16")
+    # the batch in the headline's form -- 2-bit codes of uniform length -- unless asked otherwise (genome_input=ascii) or a read
+    # holds a symbol 2 bits cannot name: 11.6 against 12.2 ms (profiles/r05/README.md)
+    q_run, input_form = q, "ascii"
+    if getattr(args, "genome_input", None) != "ascii" and wl["len_min"] == wl["len_max"]:
+        try:
+            q_run, input_form = q.as_packed(index).as_uniform(wl["len_min"]), "packed+uniform"
+        except ValueError:
+            pass
+    runner = StepRunner(torch, eng, q_run, nq, True, getattr(args, "genome_path", None) or "records16")
     runner.max_hits = max_hits
     total_hits = runner.size()
     runner.step(0, False)
@@ -1775,7 +1783,7 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     res = {"name": "genome_like_text (repeats, tandem repeats, poly-A, N gaps)", "text_len": total, "queries": nq,
            "oracle_gate": {"queries": n_gate, "hits": n_h, "counts_identical": gate_counts, "hits_identical": gate_hits},
            "text_checksum": int(text[: total // 8 * 8].view(torch.int64).sum().item()),  # the same text in every run
-           "max_hits_located_per_query": max_hits, "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
+           "max_hits_located_per_query": max_hits, "input": input_form, "value": nq / (ms / 1e3), "unit": "queries/s", "ms_per_step": ms,
            "search_ms": sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev),
            "scan_and_locate_ms": sum(b.elapsed_time(c) for _, b, c in ev) / len(ev),
            "queries_found": int((counts > 0).sum().item()), "occurrences_of_all_queries": int(counts.sum().item()),
