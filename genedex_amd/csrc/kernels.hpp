@@ -52,7 +52,10 @@ struct CursorArgs {
 // that order, which is the reference's.
 constexpr uint32_t kRecMasked = 1u << 23;
 // A RESOLVED record (32-byte jump entries carry SA[row]): {start, end, text position of the one hit, kRecResolved |
-// status << 24}, end - start == 1 -- locate only turns the position into (text id, offset).
+// status << 24}, end - start == 1 -- locate only turns the position into (text id, offset).  A resolved record OF TWO
+// (search_fast_kernel4, a read that ends on two rows whose occurrences it has just verified): {second position, second
+// position + 2, first position, kRecResolved} -- end - start is the count as everywhere (in 32-bit arithmetic), hit slot 0 is
+// the third word, hit slot 1 the first; no row is named and locate fetches no suffix-array line.
 constexpr uint32_t kRecResolved = 1u << 22;
 
 // COMPACT results (optional, beside the records): one u32 per query = the text position of its only hit, kCompactNone = no

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             return make_uint4(c4, 0u, 0u, sv.skip_single == 2u ? kDescSkip : kDescPos);
         if (rec != nullptr) {
             const uint4 r = rec[q];
-            if (r.w & kRecResolved) return make_uint4(r.z, 0u, 0u, kDescPos);  // the search already knows the text position
+            if (r.w & kRecResolved) return make_uint4(r.z, r.x, 0u, kDescPos);  // the search already knows the text position (of two: the second)
             if (r.w & kRecMasked) return make_uint4(r.x, r.z, r.w & 0x1fffffu, kDescMask);  // the rows of the mask, `symbols` steps before the hits
             if (r.z != 0xffffffffu && r.y - r.x == 1u) return make_uint4(r.z, 0u, r.w & 0xffffffu, kDescRow);  // a hinted row
             return make_uint4(r.x, 0u, 0u, kDescRows);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
                     uint4 d;
                     if (c4 < kCompactSee) d = make_uint4(c4, 0u, 0u, sv.skip_single == 2u ? kDescSkip : kDescPos);
                     else if (rec != nullptr) {
-                        if (r.w & kRecResolved) d = make_uint4(r.z, 0u, 0u, kDescPos);
+                        if (r.w & kRecResolved) d = make_uint4(r.z, r.x, 0u, kDescPos);
                         else if (r.w & kRecMasked) d = make_uint4(r.x, r.z, r.w & 0x1fffffu, kDescMask);
                         else if (r.z != 0xffffffffu && r.y - r.x == 1u) d = make_uint4(r.z, 0u, r.w & 0xffffffu, kDescRow);
                         else d = make_uint4(r.x, 0u, 0u, kDescRows);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             if (d.w == kDescSkip) continue;
             live |= 1u << j;
             if (d.w == kDescPos) {
-                val[j] = d.x;
+                val[j] = within == 0u ? d.x : d.y;  // (a resolved record of two: its second slot)
                 continue;
             }
             need_sa |= 1u << j;
@@ -373,6 +373,136 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             if (live & (1u << j))
                 store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, (need_sa & (1u << j)) ? row[j] - val[j] : val[j], hits_out,
                                      base + threadIdx.x + j * kBlock);
+    }
+}
+
+// The same index (SA[row] is one fetch), every query's slots open (no chunk flags): BY QUERY instead of by slot.  A wavefront
+// takes 64 consecutive queries: a lane reads its query's offsets and record once and writes the hits of a query with up to
+// kLaneHits of them itself (resolved positions need nothing else; masked rows one SA line); the queries with more are taken
+// one after the other by the whole wavefront, lanes striding over consecutive rows -- coalesced SA loads, coalesced stores.
+// No slot -> query map, no ticket, no barrier after the text table: on the text of repeats the stream kernel's chain of
+// dependent loads per chunk (offsets -> records -> marks -> scan -> SA) was what its 3.4 ms were made of, not the bytes.
+constexpr uint32_t kLaneHits = 4;
+template <bool kWide>
+__global__ __launch_bounds__(kBlock) void locate_by_query_kernel(
+    StreamView sv, const uint32_t *__restrict__ start, HitOffsets hit_offsets, uint64_t m, const uint2 *__restrict__ hint,
+    const uint4 *__restrict__ rec, uint64_t total, void *__restrict__ hits_out, const uint32_t *__restrict__ compact,
+    const unsigned long long *__restrict__ d_total)
+{
+    if (d_total != nullptr) {
+        const uint64_t t = *d_total;
+        total = t < total ? t : total;
+    }
+    constexpr uint32_t kLdsTexts = 256;
+    __shared__ uint32_t s_tab[kTextTab + 1];
+    __shared__ uint32_t s_sentinels[kLdsTexts];
+    const uint32_t *sentinels = sv.sentinels;
+    if (sv.n_texts <= kLdsTexts)
+        for (uint32_t i = threadIdx.x; i < sv.n_texts; i += kBlock) s_sentinels[i] = sv.sentinels[i];
+    __syncthreads();
+    if (sv.n_texts <= kLdsTexts) sentinels = s_sentinels;
+    build_text_table(s_tab, sentinels, sv.n_texts, sv.tab_shift);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    auto sa_of = [&](uint32_t row) __attribute__((always_inline)) -> uint32_t {
+        return sv.sa_full != nullptr ? sv.sa_full[row] : sv.jump32[static_cast<uint64_t>(row) * 8u + 6u];
+    };
+    // the text position of hit slot i of a query described by d (locate_stream_kernel's descriptors)
+    auto position = [&](const uint4 &d, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+        if (d.w == kDescPos) return i == 0u ? d.x : d.y;
+        if (d.w == kDescRows) return sa_of(d.x + i);
+        if (d.w == kDescMask) {
+            uint32_t mk = d.y;
+            for (uint32_t t = i; t > 0u; t--) mk &= mk - 1u;
+            return sa_of(d.x + static_cast<uint32_t>(__builtin_ctz(mk | 0x80000000u))) - d.z;
+        }
+        return sa_of(d.x) - d.z;  // kDescRow
+    };
+    const uint64_t n_groups = (m + 63u) / 64u, g_stride = static_cast<uint64_t>(gridDim.x) * (kBlock / 64);
+    // what a lane reads of its query: offsets, compact result, record (or start row and hint).  (Loading the next round's while
+    // this round's hits are made changed nothing measurable.)
+    struct Loaded {
+        uint64_t a, b;
+        uint32_t c4;
+        uint4 r;
+        uint2 hv;
+    };
+    auto load = [&](uint64_t g) __attribute__((always_inline)) -> Loaded {
+        Loaded x;
+        x.a = x.b = 0;
+        x.c4 = kCompactSee;
+        x.r = make_uint4(0u, 0u, 0xffffffffu, 0u);
+        x.hv = make_uint2(0xffffffffu, 0u);
+        const uint64_t q = g * 64u + lane;
+        if (g < n_groups && q < m) {
+            x.a = hit_offsets[q];
+            x.b = hit_offsets[q + 1];
+            if (compact != nullptr) x.c4 = compact[q];
+            if (rec != nullptr) x.r = rec[q];
+            else x.r.x = start[q];
+            if (rec == nullptr && hint != nullptr) x.hv = hint[q];
+        }
+        return x;
+    };
+    // kGroups groups of 64 queries per round: a lane's loads of a kind -- offsets and records, then SA values -- go out together
+    constexpr uint32_t kGroups = 4;
+    for (uint64_t g0 = (static_cast<uint64_t>(blockIdx.x) * (kBlock / 64) + wave) * kGroups; g0 < n_groups; g0 += g_stride * kGroups) {
+        Loaded cur[kGroups];
+#pragma unroll
+        for (uint32_t u = 0; u < kGroups; u++) cur[u] = load(g0 + u);
+        uint64_t a[kGroups], n[kGroups];
+        uint4 d[kGroups];
+#pragma unroll
+        for (uint32_t u = 0; u < kGroups; u++) {
+            a[u] = cur[u].a;
+            n[u] = a[u] >= total ? 0u : (cur[u].b > total ? total : cur[u].b) - a[u];  // (a step into too small a buffer: the rest is not located)
+            d[u] = make_uint4(0u, 0u, 0u, kDescSkip);
+            if (n[u] != 0u) {
+                const uint4 r = cur[u].r;
+                if (cur[u].c4 < kCompactSee) d[u] = make_uint4(cur[u].c4, 0u, 0u, sv.skip_single == 2u ? kDescSkip : kDescPos);
+                else if (rec != nullptr) {
+                    if (r.w & kRecResolved) d[u] = make_uint4(r.z, r.x, 0u, kDescPos);
+                    else if (r.w & kRecMasked) d[u] = make_uint4(r.x, r.z, r.w & 0x1fffffu, kDescMask);
+                    else if (r.z != 0xffffffffu && r.y - r.x == 1u) d[u] = make_uint4(r.z, 0u, r.w & 0xffffffu, kDescRow);
+                    else d[u] = make_uint4(r.x, 0u, 0u, kDescRows);
+                } else if (hint != nullptr && n[u] == 1u && cur[u].hv.x != 0xffffffffu && cur[u].hv.y < (1u << 21)) {
+                    d[u] = make_uint4(cur[u].hv.x, 0u, cur[u].hv.y, kDescRow);
+                } else {
+                    d[u] = make_uint4(r.x, 0u, 0u, kDescRows);
+                }
+                if (d[u].w == kDescSkip) n[u] = 0;
+            }
+        }
+        uint32_t pos[kGroups][kLaneHits];
+#pragma unroll
+        for (uint32_t u = 0; u < kGroups; u++)
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneHits; i++) pos[u][i] = (i < n[u] && n[u] <= kLaneHits) ? position(d[u], i) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < kGroups; u++)
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneHits; i++)
+                if (i < n[u] && n[u] <= kLaneHits) store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, pos[u][i], hits_out, a[u] + i);
+#pragma unroll
+        for (uint32_t u = 0; u < kGroups; u++) {
+            uint64_t big = __ballot(n[u] > kLaneHits);
+            while (big != 0ull) {
+                const int l = __builtin_ctzll(big);
+                big &= big - 1ull;
+                const uint4 dl = make_uint4(__shfl(d[u].x, l), __shfl(d[u].y, l), __shfl(d[u].z, l), __shfl(d[u].w, l));
+                const uint64_t al = (static_cast<uint64_t>(__shfl(static_cast<uint32_t>(a[u] >> 32), l)) << 32) | __shfl(static_cast<uint32_t>(a[u]), l);
+                const uint32_t nl = __shfl(static_cast<uint32_t>(n[u]), l);  // (a query's hit slots fit 32 bits: its rows do)
+                // (four loads of a lane in flight: a query of 700 rows is three round trips to memory, not eleven)
+                for (uint32_t i0 = lane; i0 < nl; i0 += 256u) {
+                    uint32_t pb[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) pb[k] = i0 + 64u * k < nl ? position(dl, i0 + 64u * k) : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (i0 + 64u * k < nl) store_hit_tab<kWide>(s_tab, sv.tab_shift, sentinels, pb[k], hits_out, al + i0 + 64u * k);
+                }
+            }
+        }
     }
 }
 
@@ -544,8 +674,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 }
                 const uint4 r = rec[q];
                 row = r.x + static_cast<uint32_t>(h - first);
-                if (r.w & kRecResolved) {  // the search already knows the text position
-                    store_hit<kWide>(ix, r.z, hits_out, h, sentinels);
+                if (r.w & kRecResolved) {  // the search already knows the text position (of two: slot 1 is the first word)
+                    store_hit<kWide>(ix, h == first ? r.z : r.x, hits_out, h, sentinels);
                     continue;
                 }
                 if (r.w & kRecMasked) {  // the (h - first)-th surviving row of the mask, `symbols` steps before the hit
@@ -983,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_scan_kernel(RecordSize f, u
                 for (uint32_t i = lane; i < cnt; i += 64u) {  // the record's rows as locate_queue_kernel reads them
                     uint32_t pos;
                     if (r.w & kRecResolved) {
-                        pos = r.z;
+                        pos = i == 0u ? r.z : r.x;
                     } else {
                         uint32_t row = r.x + i, back = 0;
                         if (r.w & kRecMasked) {
@@ -1665,6 +1795,28 @@ void launch_locate(const IndexView &ix, const uint32_t *d_start, const uint32_t 
     // configuration, and their slot -> query map cost 4 bytes of workspace per hit; removed in round 5, the option is ignored)
     // GDX_LOCATE_GRID (experiments): absolute number of blocks of the locate kernel
     static const long grid_override = [] { const char *e = getenv("GDX_LOCATE_GRID"); return e ? atol(e) : 0L; }();
+    // SA[row] is one fetch and every slot is open (no chunk flags): by query, no chunk table at all
+    // (GDX_LOCATE_BY_QUERY=0, experiments: the stream kernel for those too)
+    static const bool by_query = [] { const char *e = getenv("GDX_LOCATE_BY_QUERY"); return e == nullptr || atoi(e) != 0; }();
+    const bool sa_at_hand = ix.layout == 0 && !reference_walk && qo.locate_jump_walk != 0 &&
+                            (ix.sa_full != nullptr || (ix.jump != nullptr && ix.jump_bytes == 32));
+    if (by_query && sa_at_hand && d_chunk_flags == nullptr) {
+        uint32_t shift = 0;
+        while ((static_cast<uint64_t>(ix.n) >> shift) >= kTextTab) shift++;
+        const StreamView sv{ix.sa_full, ix.sa_full == nullptr ? static_cast<const uint32_t *>(ix.jump) : nullptr, ix.sentinels,
+                            ix.n_texts, shift, compact_stored ? 2u : 0u};
+        static const unsigned cap_q = resident_blocks(locate_by_query_kernel<false>), cap_qw = resident_blocks(locate_by_query_kernel<true>);
+        const uint64_t groups = (m + 63) / 64, blocks = (groups + kBlock / 64 - 1) / (kBlock / 64);
+        const unsigned bgrid = grid_override > 0 ? static_cast<unsigned>(grid_override)
+                                                 : static_cast<unsigned>(std::min<uint64_t>(blocks, 4ull * (wide ? cap_qw : cap_q)));
+        if (wide)
+            hipLaunchKernelGGL(locate_by_query_kernel<true>, dim3(bgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, d_hint, d_rec,
+                               total_hits, d_hits, d_compact, d_total);
+        else
+            hipLaunchKernelGGL(locate_by_query_kernel<false>, dim3(bgrid), dim3(kBlock), 0, stream, sv, d_start, offs, m, d_hint, d_rec,
+                               total_hits, d_hits, d_compact, d_total);
+        return;
+    }
     {
         const uint64_t n_chunks = (total_hits + kLocateChunk - 1) / kLocateChunk;
         uint32_t *first = static_cast<uint32_t *>(d_workspace);  // n_chunks + 1 entries of the workspace

@@ -2176,6 +2176,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             }
             const uint32_t rows = hi - lo;
             uint32_t alive = 0;  // bit j = row lo + j matches
+            uint32_t pair_first = 0, pair_second = 0;
+            bool pair = false;  // exactly two rows match: their occurrences
             if (kSeed && single && !bail && (rem <= 32u || !single_ok)) {
                 alive = single_ok ? 1u : 0u;  // decided by the entry alone
             } else if (!bail && rem > 0u && rows != 0u) {
@@ -2265,6 +2267,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                 alive = (ok && !bail) ? 1u << sub : 0u;
                 alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0xB1, 0xF, 0xF, true));
                 alive |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive), 0x4E, 0xF, 0xF, true));
+                // the four lanes' occurrences side by side: a read that ends on TWO rows takes both positions along in its record
+                // (kernels.hpp: a resolved record of two) -- on a text of repeats that is most of the reads with more than one
+                // hit, and locate then has no suffix-array line to fetch for them
+                const int mine = static_cast<int>(pos - rem);
+                const uint32_t o0 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(mine, 0x00, 0xF, 0xF, true));
+                const uint32_t o1 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(mine, 0x55, 0xF, 0xF, true));
+                const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(mine, 0xAA, 0xF, 0xF, true));
+                const uint32_t o3 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(mine, 0xFF, 0xF, 0xF, true));
+                if (__popc(alive) == 2) {
+                    const uint32_t f = static_cast<uint32_t>(__builtin_ctz(alive)), g = static_cast<uint32_t>(__builtin_ctz(alive & (alive - 1u)));
+                    pair_first = sel4(f, o0, o1, o2, o3);
+                    pair_second = sel4(g, o0, o1, o2, o3);
+                    pair = true;
+                }
             }
             if (writer) {
                 if (bail) {
@@ -2279,6 +2295,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                     } else if (rows == 1u) {
                         // (lane 0 holds row lo: its SA value is this record's position)
                         rec = alive ? make_uint4(lo, lo + 1u, pos - rem, kRecResolved) : make_uint4(lo, lo, 0xffffffffu, 0u);
+                    } else if (pair) {
+                        rec = make_uint4(pair_second, pair_second + 2u, pair_first, kRecResolved);
                     } else {
                         rec = make_uint4(lo, lo + static_cast<uint32_t>(__popc(alive)), alive, (rem & 0x1fffffu) | kRecMasked);
                     }
