@@ -1612,6 +1612,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             hi = lo + 1u;
                         } else if (n_alive == 0u) {
                             hi = lo;
+                        } else if (kEntrySA && hinting && n_alive == 2u) {
+                            // two rows are left and each one's entry holds SA of its row: the record takes both occurrences
+                            // along (kernels.hpp: a resolved record of two), locate has no suffix-array line to fetch
+                            const uint32_t idx = target - lo, at = e1.z - rem_before;
+                            const uint32_t f = static_cast<uint32_t>(__builtin_ctz(alive)), g2 = static_cast<uint32_t>(__builtin_ctz(alive & (alive - 1u)));
+                            // (kept in the registers the record is written from: {lo, hi, hr} = {second, second + 2, first})
+                            hr = group_max<kGroup>(match && idx == f ? at : 0u);
+                            lo = group_max<kGroup>(match && idx == g2 ? at : 0u);
+                            hi = lo + 2u;
+                            resolved = true;
                         } else {
                             masked = true;
                             hr = alive;
@@ -1628,7 +1638,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // where the general kernel goes on: after the top table and whole rounds, or from the start
                     if (state) state[q] = make_uint4(lo, hi, rem, progressed ? 1u : 0u);
                 } else {
-                    const bool hinted = (kEntrySA ? resolved : hr != 0xffffffffu) && hi - lo == 1u;
+                    // (resolved with two slots: the record of two made above)
+                    const bool hinted = (kEntrySA ? resolved : hr != 0xffffffffu) && (hi - lo == 1u || (kEntrySA && resolved && hi - lo == 2u));
                     if (out_rec) {
                         if (masked) out_rec[q] = make_uint4(lo, hi, hr, (ho & 0x1fffffu) | kRecMasked);
                         else if (kEntrySA) out_rec[q] = make_uint4(lo, hi, hinted ? hr : 0xffffffffu, hinted ? kRecResolved : 0u);

@@ -648,3 +648,78 @@ def test_reference_table_layouts_bit_for_bit_and_queried_as_they_are(layout):
             b64 = OracleTable(c.bwt, 6, "condensed", 64)
             eb, ebo, esb = g.export_condensed_table()
             assert np.array_equal(eb, b64.blocks) and np.array_equal(ebo, b64.block_offsets) and np.array_equal(esb, b64.superblock_offsets)
+
+
+@pytest.mark.parametrize("structures", ["seed+sa", "seed+jump32", "seed+sa, no tables", "seed+walk"])
+def test_reads_on_two_rows_carry_both_positions(structures):
+    """A read that ends on exactly two rows (every stretch of this text occurs twice) leaves search_fast_kernel4 as a resolved
+    record OF TWO -- {second position, second + 2, first position, resolved}: end - start is the count, no row is named
+    (kernels.hpp) -- where the search has both occurrences at hand: search_fast_kernel4 on 32-byte jump entries (they carry
+    SA[row]), search_verify_kernel4 on the full suffix array.  The locate kernels write both hits from it, in the reference's
+    order: locate_by_query_kernel (every slot open), locate_stream_kernel and the store pass's inline location (the one-call
+    step's flagged chunks); with a limit of one hit such reads get no slots.  The records are looked at, so that the path
+    cannot go unused; an index that walks to its suffix-array values makes no such records and gives the same hits."""
+    import torch
+
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(660)
+    unit = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 30000))
+    other = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 9000))
+    texts = [unit[:17000] + other[:4000], other[4000:] + unit]  # unit[:17000] twice; the rest of unit and `other` once
+    a = alph.ascii_dna()
+    opts = {"seed+sa": dict(seed_symbols=12, text_units=True, full_suffix_array=True),
+            "seed+jump32": dict(seed_symbols=12, text_units=True, jump_entry_bytes=32),
+            "seed+sa, no tables": dict(seed_symbols=12, text_units=True, full_suffix_array=True, pair_lines=False, jump_entry_bytes=0,
+                                       top_table_depth=0),
+            "seed+walk": dict(seed_symbols=12, text_units=True, jump_entry_bytes=0, top_table_depth=0, pair_lines=False)}[structures]
+    g = gpu_index(texts, a, **opts)
+    g.set_query_options(search_fast=2)  # (the fast path is off by default on a text this repetitive: wide_permille > 500)
+    c = cpu_index(texts, a)
+    qs = []
+    for _ in range(5000):
+        ln = int(rng.integers(30, 70))
+        at = int(rng.integers(0, len(unit) - ln))
+        qs.append(unit[at:at + ln])
+    co, ct, cp = c.locate_many(qs)
+    counts = np.diff(co)
+    assert int((counts == 2).sum()) > 2000 and int((counts == 1).sum()) > 1000
+    eng = DeviceEngine(g)
+    dq = DeviceQueries.from_host(*pack_queries(qs))
+    for compact in (False, True):
+        rec = eng.alloc_records(dq.nq)
+        cw = eng.alloc_compact(dq.nq) if compact else None
+        eng.locate_search(dq, rec, compact=cw)
+        off = torch.empty(dq.nq + 1, dtype=torch.int64, device="cuda")
+        eng.locate_offsets(rec, dq.nq, off, compact=cw)
+        torch.cuda.synchronize()
+        total = int(off[dq.nq].item())
+        hits = torch.empty((total, 2), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(total), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_hits(rec, dq.nq, off, total, hits, ws, compact=cw)
+        torch.cuda.synchronize()
+        assert off.cpu().numpy().astype(np.uint64).tolist() == co.tolist(), (structures, compact)
+        h = hits.cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct.tolist() and h[:, 1].tolist() == cp.tolist(), (structures, compact)
+        r = rec[:dq.nq].cpu().numpy().astype(np.uint32)
+        two = counts == 2
+        resolved_of_two = two & ((r[:, 3] >> 22) & 1).astype(bool) & ((r[:, 1] - r[:, 0]) == 2)
+        if structures != "seed+walk":
+            assert int(resolved_of_two.sum()) > 1500, (structures, compact, int(resolved_of_two.sum()))
+    # the whole step in one call (flagged chunks: the stream kernel / the store pass's inline location); with a limit of one hit
+    # per read the reads on two rows are counted but get no slots (the device calls' max_hits), the others stay as they are
+    for max_hits in (0, 1):
+        rec, cw = eng.alloc_records(dq.nq), eng.alloc_compact(dq.nq)
+        sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+        totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+        off32 = torch.empty(dq.nq + 1, dtype=torch.int32, device="cuda")
+        hits = torch.full((int(co[-1]) + 3, 2), -1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(eng.locate_workspace_bytes(hits.shape[0]), 16), dtype=torch.uint8, device="cuda")
+        eng.locate_step(dq, rec, cw, sws, totals, off32, hits, ws, max_hits=max_hits)
+        torch.cuda.synchronize()
+        keep = np.ones(len(qs), dtype=bool) if max_hits == 0 else counts <= max_hits
+        want_off = np.concatenate([[0], np.cumsum(np.where(keep, counts, 0))]).astype(np.uint64)
+        sel = np.repeat(keep, counts.astype(np.int64))
+        assert off32.cpu().numpy().astype(np.uint64).tolist() == want_off.tolist(), (structures, max_hits)
+        h = hits[: int(want_off[-1])].cpu().numpy().astype(np.uint32)
+        assert h[:, 0].tolist() == ct[sel].tolist() and h[:, 1].tolist() == cp[sel].tolist(), (structures, max_hits)
