@@ -201,7 +201,9 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
     if (chunk_flags != nullptr && *reinterpret_cast<const uint32_t *>(chunk_flags - kFlagsHead) == 0u) return;
     constexpr uint32_t kPer = kLocateChunk / kBlock;  // slots per thread
     constexpr uint32_t kLdsTexts = 256;
-    __shared__ uint32_t s_map[kLocateChunk];  // (query of the slot, relative to the chunk's first, + 1) << 11 | the slot of its head
+    __shared__ uint32_t s_map[kLocateChunk];   // the slot of the head of the slot's query + 1 (0 before the scan: no head here)
+    __shared__ uint32_t s_qrel[kLocateChunk];  // at a head's slot: its query, relative to the chunk's first -- a full word: a chunk of
+                                               // a hit-sparse batch spans millions of queries (21 bits beside the slot were not enough)
     __shared__ uint4 s_desc[kStreamDesc];
     __shared__ uint32_t s_tab[kTextTab + 1];
     __shared__ uint32_t s_sentinels[kLdsTexts];
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             }
             const uint64_t from = a > base ? a : base;
             if (b > from && from < base + cnt) {
-                s_map[from - base] = ((static_cast<uint32_t>(q - qa) + 1u) << 11) | static_cast<uint32_t>(from - base);
+                s_map[from - base] = static_cast<uint32_t>(from - base) + 1u;
+                s_qrel[from - base] = static_cast<uint32_t>(q - qa);
                 if (q == qa) s_carry = static_cast<uint32_t>(from - a);  // (the owner of slot `base`: always has slots here)
                 if (wants) {  // describe(q, b - a) on what has been loaded
                     uint4 d;
@@ -337,9 +340,9 @@ __global__ __launch_bounds__(kBlock) void locate_stream_kernel(
             row[j] = 0;
             val[j] = 0;
             if (i >= cnt) continue;
-            const uint32_t p = s_map[i];
-            const uint32_t qrel = (p >> 11) - 1u;
-            const uint32_t within = i - (p & 2047u) + (qrel == 0u ? carry : 0u);
+            const uint32_t head = s_map[i] - 1u;  // (every slot of a chunk lies at or behind a head: slot `base` has an owner)
+            const uint32_t qrel = s_qrel[head];
+            const uint32_t within = i - head + (qrel == 0u ? carry : 0u);
             uint4 d;
             if (qrel < kStreamDesc) {
                 d = s_desc[qrel];

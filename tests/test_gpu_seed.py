@@ -723,3 +723,71 @@ def test_reads_on_two_rows_carry_both_positions(structures):
         assert off32.cpu().numpy().astype(np.uint64).tolist() == want_off.tolist(), (structures, max_hits)
         h = hits[: int(want_off[-1])].cpu().numpy().astype(np.uint32)
         assert h[:, 0].tolist() == ct[sel].tolist() and h[:, 1].tolist() == cp[sel].tolist(), (structures, max_hits)
+
+
+@pytest.mark.parametrize("structures", ["seed+sa", "seed+jump32"])
+def test_hit_sparse_chunk_spanning_millions_of_reads(structures):
+    """A chunk of 2048 hit slots of a hit-sparse batch spans millions of reads.  locate_stream_kernel (SA[row] one fetch away,
+    compact results, flagged chunks) once kept a slot's query number relative to the chunk's first query in 21 bits beside the
+    slot number: beyond 2^21 - 1 reads in a chunk the marks overflowed and the open slots got another query's hits (round-5
+    advisor).  The reads of many hits at both ends (more than 2048 rows each: the store pass cannot place them inline) open
+    chunks whose queries lie 2.3 M reads apart; through the one-call step and through the narrow host call, whose chunks hold
+    more than 2^21 packed reads."""
+    import ctypes as C
+
+    import torch
+
+    from genedex_amd import _lib
+    from genedex_amd.device import DeviceEngine, DeviceQueries
+
+    rng = np.random.default_rng(2121)
+    body = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 60000))
+    texts = [body[:30000] + b"A" * 3000 + body[30000:], b"C" * 2600 + body[100:9000]]
+    a = alph.ascii_dna()
+    opts = {"seed+sa": dict(seed_symbols=12, text_units=True, full_suffix_array=True, **LEAN),
+            "seed+jump32": dict(seed_symbols=12, text_units=True, jump_entry_bytes=32)}[structures]
+    g = gpu_index(texts, a, **opts)
+    c = cpu_index(texts, a)
+    ln, n_absent = 32, 2_300_000
+    absent = rng.integers(0, 4, (n_absent, ln), dtype=np.uint8)
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rows = [np.frombuffer(b"A" * ln, dtype=np.uint8)[None, :],                 # 2969 rows
+            np.frombuffer(body[500:500 + ln], dtype=np.uint8)[None, :],
+            sym[absent[: n_absent // 2]],
+            np.frombuffer(body[40000:40000 + ln], dtype=np.uint8)[None, :],
+            sym[absent[n_absent // 2:]],
+            np.frombuffer(b"C" * ln, dtype=np.uint8)[None, :],                 # 2569 rows
+            np.frombuffer(body[7000:7000 + ln], dtype=np.uint8)[None, :]]
+    q2d = np.ascontiguousarray(np.concatenate(rows, axis=0))
+    nq = q2d.shape[0]
+    qbuf = np.zeros(nq * ln + 64, dtype=np.uint8)
+    qbuf[: nq * ln] = q2d.reshape(-1)
+    qoff = (np.arange(nq + 1, dtype=np.uint64) * np.uint64(ln))
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce)
+    counts = np.diff(co)
+    assert int(counts[0]) > 2048 and int(counts[nq - 2]) > 2048 and int(co[-1]) < 20000
+    eng = DeviceEngine(g)
+    dq = DeviceQueries.from_host(qbuf, qoff)
+    rec, cw = eng.alloc_records(dq.nq), eng.alloc_compact(dq.nq)
+    sws = torch.empty(max(eng.totals_workspace_bytes(dq.nq), 16), dtype=torch.uint8, device="cuda")
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    off32 = torch.empty(dq.nq + 1, dtype=torch.int32, device="cuda")
+    hits = torch.full((int(co[-1]) + 5, 2), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(eng.locate_workspace_bytes(hits.shape[0]), 16), dtype=torch.uint8, device="cuda")
+    eng.locate_step(dq, rec, cw, sws, totals, off32, hits, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(off32.cpu().numpy().astype(np.uint64), co), structures
+    h = hits[: int(co[-1])].cpu().numpy().astype(np.uint32)
+    assert np.array_equal(h[:, 0], ct.astype(np.uint32)) and np.array_equal(h[:, 1], cp.astype(np.uint32)), structures
+    # the host call on the batch as 2-bit codes of uniform length: one chunk holds all 2.3 M reads
+    lib = _lib.load()
+    packed = np.zeros(int(lib.gdx_packed_bytes(nq * ln)), dtype=np.uint8)
+    n_exc = C.c_uint64(0)
+    _lib.check(lib.gdx_pack_queries(g._h, qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p), nq,
+                                    packed.ctypes.data_as(_lib.u8p), None, 0, C.byref(n_exc)))
+    assert n_exc.value == 0
+    o4, t4, p4, st4 = g.locate_layout32_raw(packed, None, nq, packed=True, uniform_len=ln)
+    assert not st4.any()
+    assert np.array_equal(o4.astype(np.uint64), co) and np.array_equal(t4, ct.astype(np.uint32)) and \
+        np.array_equal(p4, cp.astype(np.uint32)), structures
