@@ -1712,7 +1712,7 @@ int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4])
         out[0] = v.pair_lines != nullptr;
         out[1] = v.jump ? v.jump_bytes : 0u;
         out[2] = v.top ? v.top_depth : 0u;
-        out[3] = (v.sa_full ? 1u : 0u) | (v.text_units ? 2u : 0u) | (v.isa ? 4u : 0u);
+        out[3] = (v.sa_full ? 1u : 0u) | (v.text_units ? 2u : 0u) | (v.isa ? 4u : 0u) | (deref(ix).aux_report().default_shape ? 8u : 0u);
         return (int)GDX_OK;
     });
 }

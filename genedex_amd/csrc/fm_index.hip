@@ -1254,20 +1254,63 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     };
     int want_pairs = bo.pair_lines;
     if (want_pairs < 0) want_pairs = env_int("GDX_NO_PAIR_LINES", 0) == 1 ? 0 : 1;
-    // seed table (layout.hpp): wanted explicitly; k from the text length unless given: ceil(log4 n) + 8, so that a k-mer
+    // THE DEFAULT SHAPE (round 6): options left at their defaults on a DNA-like alphabet (rank-line layout, dense symbols 1..4
+    // searchable) build ONE index that serves every call at its best measured speed -- seed table (k from the text length, load
+    // 60 %) + text units + full suffix array + inverse suffix array + pair lines + a top table of depth <= 14, no jump table:
+    // count / locate through the seed table (search_seed_lane_kernel), exact intervals and cursors through seed entry / text /
+    // ISA with the pair lines for the steps that empty an interval (search_exact_kernel4<0, ., ., true>), locate with SA[row]
+    // one fetch away.  3.1 G symbols: 104 GB.  It needs 8.5 bytes per symbol + the seed table inside the budget for auxiliary
+    // structures; where that does not fit -- or any of the structures is asked for or switched off explicitly -- the options
+    // mean what they say and the tables of rounds 1-3 (32-byte jump entries + top table, shrunk to the budget) are the default.
+    // GDX_DEFAULT_SHAPE=tables: the latter regardless (debugging aid).
+    bool default_shape = bo.seed_symbols < 0 && bo.jump_bytes < 0 && bo.full_sa < 0 && bo.inverse_sa < 0 && bo.text_units < 0 &&
+                         want_pairs != 0 && view_.layout == 0 && view_.sigma >= 5 && cfg_.n_searchable >= 4 && n_ > 0;
+    if (default_shape) {
+        const char *e = getenv("GDX_DEFAULT_SHAPE");
+        if (e != nullptr && strcmp(e, "tables") == 0) default_shape = false;
+    }
+    uint32_t seed_load_pct = bo.seed_load_percent > 0 ? static_cast<uint32_t>(bo.seed_load_percent) : 70u;
+    auto auto_seed_k = [&] {
+        uint32_t k = 8;
+        while (k < 24 && (1ull << (2u * (k - 8u))) < n_) k++;
+        return k;
+    };
+    if (default_shape) {  // does it fit?  (the same arithmetic as below)
+        size_t free_b = 0, total_b = 0;
+        GDX_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t reserve = total_b / 16 > (4ull << 30) ? total_b / 16 : (4ull << 30);
+        double budget = free_b > reserve ? static_cast<double>(free_b - reserve) : 0.0;
+        if (bo.aux_budget_bytes != 0) {
+            budget = static_cast<double>(bo.aux_budget_bytes) < budget ? static_cast<double>(bo.aux_budget_bytes) : budget;
+        } else {
+            if (budget > static_cast<double>(total_b / 2)) budget = static_cast<double>(total_b / 2);
+            if (const char *e = getenv("GDX_AUX_BUDGET_GB")) budget = std::min(budget, atof(e) * 1e9);
+        }
+        const uint32_t k = auto_seed_k();
+        const uint32_t load = bo.seed_load_percent > 0 ? static_cast<uint32_t>(bo.seed_load_percent) : 60u;
+        double seed_bytes = 16.0 / (load / 100.0) * static_cast<double>(n_);
+        if (2u * k > kSeedTagBitsMax) seed_bytes = std::max(seed_bytes, 128.0 * static_cast<double>(1ull << (2u * k - kSeedTagBitsMax)));
+        const double need = 1.25 * seed_bytes + 8.5 * static_cast<double>(n_);
+        if (need > budget) default_shape = false;
+        else seed_load_pct = load;
+    }
+    // seed table (layout.hpp): k from the text length unless given: ceil(log4 n) + 8, so that a k-mer
     // that occurs at all almost always occurs once (3.1 G symbols: 24), at most 24 (k + 32 symbols fit the search window)
     uint32_t seed_k = 0;
-    if (bo.seed_symbols >= 1 && view_.sigma >= 5) {
+    if (default_shape) {
+        seed_k = auto_seed_k();
+    } else if (bo.seed_symbols >= 1 && view_.sigma >= 5) {
         if (bo.seed_symbols == 1) {
-            seed_k = 8;
-            while (seed_k < 24 && (1ull << (2u * (seed_k - 8u))) < n_) seed_k++;
+            seed_k = auto_seed_k();
         } else {
             seed_k = static_cast<uint32_t>(bo.seed_symbols);
         }
         if (seed_k < 8u || seed_k > 24u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_symbols must be 1 (automatic) or 8..24");
     }
     const bool want_seed = seed_k != 0;
-    const bool want_text = bo.text_units == 1 || want_seed, want_sa_full = bo.full_sa == 1, want_isa = bo.inverse_sa == 1;
+    const bool want_text = bo.text_units == 1 || want_seed, want_sa_full = bo.full_sa == 1 || default_shape,
+               want_isa = bo.inverse_sa == 1 || default_shape;
+    aux_report_.default_shape = default_shape;
     if (view_.layout == 0 && n_ > 0 && (want_pairs || want_text || want_sa_full || want_isa)) {
         double t0 = now_seconds();
         if (want_pairs) {
@@ -1312,7 +1355,9 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         // jump table: 32-byte entries by default (BuildOptions::jump_bytes; GDX_JUMP_BYTES / GDX_NO_JUMP_TABLE
         // override the default only)
         uint32_t jump_bytes = 32;
-        if (bo.jump_bytes >= 0) {
+        if (default_shape) {
+            jump_bytes = 0;  // (the text, SA and ISA stand in for it)
+        } else if (bo.jump_bytes >= 0) {
             jump_bytes = static_cast<uint32_t>(bo.jump_bytes);
         } else {
             jump_bytes = static_cast<uint32_t>(env_int("GDX_JUMP_BYTES", 32));
@@ -1330,6 +1375,9 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
         if (bo.top_depth >= 0) top_depth = static_cast<uint32_t>(bo.top_depth);
         else top_depth = static_cast<uint32_t>(env_int("GDX_TOP_DEPTH", static_cast<int>(top_depth)));
         if (top_depth > 16u) top_depth = 16u;
+        // (the default shape's top table only starts the reads the seed table does not answer -- absent k-mers, reads shorter
+        // than the seed: depth 14 is 2 GB, depth 16 would be 34)
+        if (default_shape && bo.top_depth < 0 && top_depth > 14u) top_depth = 14u;
         if (view_.sigma < 5) top_depth = 0;
         if (!want_pairs && !want_text) top_depth = 0;  // nothing would read it
         aux_report_.wanted_jump_bytes = jump_bytes;
@@ -1356,7 +1404,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             aux_report_.budget_bytes = static_cast<uint64_t>(budget);
             // (the full suffix array and the text units are asked for explicitly: they count, but do not shrink)
             // (the seed table: 16 bytes per distinct k-mer over the load factor -- about n k-mers)
-            const double seed_load = (bo.seed_load_percent > 0 ? bo.seed_load_percent : 70) / 100.0;
+            const double seed_load = seed_load_pct / 100.0;
             // ... but never fewer than 2^(2k - 21) buckets of 128 bytes ((bucket, tag) must name a k-mer exactly with at most
             // kSeedTagBitsMax tag bits: 17 GB for k = 24 whatever the text), and a placement that fails retries with a quarter
             // more buckets: both are part of what the other tables have to leave room for
@@ -1448,7 +1496,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             }
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
-            if (want_seed) build_seed_table(d_sa, seed_k, stream);
+            if (want_seed) build_seed_table(d_sa, seed_k, seed_load_pct, stream);
             if (want_isa) {
                 isa_.alloc(n_);
                 hipLaunchKernelGGL(scatter_isa_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, d_sa, n_, isa_.get());
@@ -1465,10 +1513,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
 }
 
 // Seed table out of the full suffix array and the text units (both on the device; layout.hpp describes the entries).
-void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream)
+void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, hipStream_t stream)
 {
-    const BuildOptions &bo = cfg_.build;
-    const uint32_t load = bo.seed_load_percent > 0 ? static_cast<uint32_t>(bo.seed_load_percent) : 70u;
     if (load < 20u || load > 100u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
     const unsigned grid = grid_for_items(n_);
     DeviceBuffer<unsigned long long> d_stats(8);

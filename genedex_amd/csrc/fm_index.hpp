@@ -24,9 +24,12 @@ namespace gdx {
 // Negative / zero = default.  The GDX_* environment variables named in fm_index.hip only override fields left
 // at their default (debugging aid).
 struct BuildOptions {
+    // (all of jump_bytes / full_sa / text_units / seed_symbols / inverse_sa at -1 and pair lines not switched off: THE DEFAULT
+    // SHAPE -- seed table + text units + full and inverse suffix array + pair lines + top table of depth <= 14, no jump table
+    // -- when it fits the budget; FmIndex::build_aux)
     int pair_lines = -1;            // -1 default (on for sigma <= 8), 0 off, 1 on
-    int jump_bytes = -1;            // -1 default (32), 0 none, 8, 16, 32
-    int top_depth = -1;             // -1 default (largest even D <= 16 with 4^D <= 2n), 0 none, 1..16
+    int jump_bytes = -1;            // -1 default (none in the default shape, else 32), 0 none, 8, 16, 32
+    int top_depth = -1;             // -1 default (largest even D <= 16 with 4^D <= 2n; <= 14 in the default shape), 0 none, 1..16
     uint64_t aux_budget_bytes = 0;  // cap for jump + top table; 0 = min(free HBM - reserve, half of the HBM)
     int full_sa = -1;               // 1: SA[row] of every row as its own array
     int text_units = -1;            // 1: the text itself, 16 bytes per 32 symbols (layout.hpp)
@@ -44,6 +47,7 @@ struct AuxReport {
     uint32_t wanted_jump_bytes = 0, wanted_top_depth = 0;  // before the budget was applied
     uint64_t budget_bytes = 0, aux_bytes = 0;
     double wide_fraction = 0.0;  // share of text positions whose top-table interval is wider than 4 rows
+    bool default_shape = false;  // the options were left at their defaults and the default shape fitted the budget (fm_index.hip)
     // seed table: k, buckets, entries of kind 0 / kind 1, buckets that turned an entry away, largest displacement
     uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0;
 };
@@ -144,7 +148,7 @@ private:
                       uint64_t uniform_len = 0, Narrow32Sink *narrow = nullptr) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
-    void build_seed_table(const uint32_t *d_sa, uint32_t k, hipStream_t stream);
+    void build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load_percent, hipStream_t stream);
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                        gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
                        const uint4 *d_rec = nullptr) const;

@@ -1679,6 +1679,11 @@ struct ExactView {
     uint32_t top_depth, n;
     uint32_t lookup_depth;  // the configured lookup table is never read, but its eager symbol check must not be skipped
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+    // kText (an index without jump table that holds the text, SA[row] and ISA[position]): IndexView::sa_full, text_units, isa, seed*
+    const uint32_t *sa_full, *isa;
+    const u32x4 *text_units;
+    const u32x4 *seed;
+    uint32_t seed_buckets, seed_k, seed_tag_bits;
 };
 
 __device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
@@ -1690,8 +1695,21 @@ __device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uin
     return v;
 }
 
-template <int kJump, int kXlate, bool kCursor>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_exact_kernel4(
+// kText (round 6; an index WITHOUT jump table that holds the full suffix array, the text units and the inverse suffix array --
+// the library's default shape): the jump table's place is taken by the text itself.  An interval of up to four rows that has
+// eight or more symbols to go does not step through them on the pair lines, two symbols per fetch: every lane takes a row,
+// fetches SA[row] and counts how many of the remaining symbols the text in front of that position matches (32 symbols per
+// 64-bit compare, as search_verify_kernel4); the rows that match the most, j symbols, are the rows that survive j LF steps,
+// LF keeps their order, and their new rows are ISA[SA[row] - j] -- three dependent fetches for any number of steps.  If j is
+// less than what is left, the next step empties the interval and is taken on the pair lines, so that the frozen interval is
+// the reference's (cursor.rs:41-48).  Random reads empty within a step or two of becoming narrow, so the route opens only after
+// an interval has stayed narrow for two pair rounds (or came in narrow: a cursor's later chunks).  A cursor that is still
+// cursor_empty (lib.rs:202-210) and gets seed_k symbols or more starts from its seed-table bucket as a count / locate search
+// does: a k-mer that occurs once gives the position, the entry's 32 symbols in front verify the rest of a chunk of up to
+// seed_k + 32 symbols, and the row is ISA[position] -- two fetches for a 32-symbol chunk instead of top entry + pair steps.
+constexpr uint32_t kTextMinSymbols = 8;
+template <int kJump, int kXlate, bool kCursor, bool kText = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 6 : 7, kText ? 6 : 7))) void search_exact_kernel4(
     ExactView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count,
     uint8_t *__restrict__ out_status, uint32_t range, int schedule, uint32_t *__restrict__ leftover,
@@ -1794,7 +1812,88 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             uint32_t part = 0;    // symbols of level `shift` used up by pair steps
             bool fresh = false;   // the window is positioned: symbol rem - 1 is symbol `part` of its level `shift`
             bool jump_ok = kJump != 0 && ix.jump != nullptr;
-            if (!bail && empty_cursor && ix.top != nullptr && rem >= 16u && rem >= depth) {
+            bool text_ok = kText;  // the text route is open for this query
+            // pair rounds begun on up to kGroup rows (a cursor that comes in narrow has shown its rows to be real)
+            uint32_t narrow = (kText && kCursor && !empty_cursor && hi - lo <= static_cast<uint32_t>(kGroup)) ? 2u : 0u;
+            bool seeded = false;   // the seed table has given this cursor its first interval
+            if (kText && kCursor && !bail && empty_cursor && ix.seed != nullptr && rem >= ix.seed_k) {
+                w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
+                const uint32_t k = ix.seed_k;
+                const uint32_t n_look = rem < k + 32u ? rem : k + 32u;
+                const uint32_t n_words = n_look <= w.s0 ? 1u : 1u + ((n_look - w.s0 + 7u) >> 3);
+                if ((w.valid8 & ((1u << n_words) - 1u)) == (1u << n_words) - 1u) {
+                    // (the window as one string, the chunk's last symbol in the top bits of w0: search_verify_kernel4)
+                    const uint32_t w0 = __builtin_amdgcn_alignbit(w.l0, w.l0, 16), w1 = __builtin_amdgcn_alignbit(w.l1, w.l1, 16);
+                    const uint32_t w2 = __builtin_amdgcn_alignbit(w.l2, w.l2, 16), w3 = __builtin_amdgcn_alignbit(w.l3, w.l3, 16);
+                    const uint64_t key = ((static_cast<uint64_t>(w0) << 32) | w1) >> (64u - 2u * k);
+                    uint32_t tag;
+                    uint32_t b = seed_home(key, ix.seed_tag_bits, ix.seed_buckets, tag);
+                    uint32_t ex, ey, ez, ew;
+                    for (uint32_t d = 0;; d++) {
+                        const u32x4 *bp = ix.seed + (static_cast<uint64_t>(b) << 3) + 2u * sub;
+                        const u32x4 e0 = bp[0], e1 = bp[1];
+                        const uint32_t want = tag | (d << kSeedDispShift);
+                        const bool m0 = (e0.x & kSeedMatchMask) == want, m1 = (e1.x & kSeedMatchMask) == want;
+                        const u32x4 es = m0 ? e0 : e1;
+                        const bool mt = m0 || m1;
+                        ex = mt ? (es.x | kSeedFound) : (e0.x & kSeedOverflow);
+                        ey = mt ? es.y : 0u;
+                        ez = mt ? es.z : 0u;
+                        ew = mt ? es.w : 0u;
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0xB1, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0xB1, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0xB1, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0xB1, 0xF, 0xF, true));
+                        ex |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ex), 0x4E, 0xF, 0xF, true));
+                        ey |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ey), 0x4E, 0xF, 0xF, true));
+                        ez |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ez), 0x4E, 0xF, 0xF, true));
+                        ew |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(ew), 0x4E, 0xF, 0xF, true));
+                        if ((ex & kSeedFound) != 0u || (ex & kSeedOverflow) == 0u || d >= kSeedMaxDisp) break;
+                        b = b + 1u == ix.seed_buckets ? 0u : b + 1u;
+                    }
+                    if ((ex & kSeedFound) != 0u && (ex & kSeedKind) != 0u) {  // several rows: the k-mer's interval, on from there
+                        lo = ey;
+                        hi = ez;
+                        rem -= k;
+                        seeded = true;
+                    } else if ((ex & kSeedFound) != 0u) {
+                        // one row, at text position ey: how many of the (up to 32) chunk symbols in front of the seed the
+                        // entry's symbols in front of that position match
+                        const uint32_t front = rem - k, n_v = front < 32u ? front : 32u;
+                        uint32_t qh, ql;
+                        const uint32_t sh = 32u - 2u * (k & 15u);
+                        if (k == 16u) {
+                            qh = w1;
+                            ql = w2;
+                        } else if (k < 16u) {
+                            qh = __builtin_amdgcn_alignbit(w0, w1, sh);
+                            ql = __builtin_amdgcn_alignbit(w1, w2, sh);
+                        } else {
+                            qh = __builtin_amdgcn_alignbit(w1, w2, sh);
+                            ql = __builtin_amdgcn_alignbit(w2, w3, sh);
+                        }
+                        const uint64_t vm64 = n_v == 32u ? ~0ull : ~(~0ull >> (2u * n_v));
+                        const uint64_t diff = (((static_cast<uint64_t>(qh) << 32) | ql) ^ ((static_cast<uint64_t>(ew) << 32) | ez)) & vm64;
+                        const uint32_t v_code = (ex >> kSeedPartialShift) & 3u;
+                        const uint32_t n_text = (ex & kSeedPartial) == 0u ? 32u : (v_code == 0u ? (ez & 63u) : 29u + v_code);
+                        uint32_t got = diff != 0ull ? static_cast<uint32_t>(__builtin_clzll(diff)) >> 1 : n_v;
+                        got = got < n_text ? got : n_text;
+                        got = got < ey ? got : ey;
+                        const uint32_t row = ix.isa[ey - got];
+                        lo = row;
+                        hi = row + 1u;
+                        rem = front - got;
+                        seeded = true;
+                        narrow = 2u;
+                        if (got < n_v) text_ok = false;  // the next symbol does not match: one step on the pair lines empties the interval
+                    }
+                    // (else: the k-mer does not occur; the frozen interval is found from the top table on)
+                }
+                fresh = false;
+            }
+            if (seeded) {
+                // (the window is positioned anew by whatever comes next)
+            } else if (!bail && empty_cursor && ix.top != nullptr && rem >= 16u && rem >= depth) {
                 w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem, sub);
                 const uint32_t need = (w.s0 == 8u ? 1u : 3u) | (depth > 8u ? (w.s0 == 8u ? 2u : 6u) : 0u);
                 if ((w.valid8 & need) != need) {
@@ -1815,6 +1914,87 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             }
             while (!bail && rem > 0u && lo != hi) {
                 const uint32_t rows = hi - lo;
+                if (kText && text_ok && rows <= static_cast<uint32_t>(kGroup) && rem >= kTextMinSymbols && narrow >= 2u) {
+                    const bool real = sub < rows;
+                    const uint32_t pos = ix.sa_full[real ? lo + sub : lo];
+                    uint32_t m = 0;  // LF steps this lane's row survives = symbols of the text in front of pos that are the query's
+                    bool going = real;
+                    uint32_t rem_v = rem;
+                    bool reuse = fresh && part == 0u && shift <= 3u;  // the window still serves the first pass
+                    while (rem_v > 0u && group_max<kGroup>(going ? 1u : 0u) != 0u) {
+                        if (!reuse) {
+                            w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem_v, sub);
+                            shift = 0;
+                            part = 0;
+                        }
+                        reuse = false;
+                        const uint32_t n_v = rem_v < 32u ? rem_v : 32u;
+                        const uint32_t v8 = w.valid8 >> shift;
+                        const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));
+                        const uint32_t n_full = n_v >> 3, n_tail = n_v & 7u;
+                        bool clean = (vl & ((1u << n_full) - 1u)) == ((1u << n_full) - 1u);
+                        if (n_tail != 0u) clean = clean && ((v8 >> n_full) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_full + 1u)) & 1u) != 0u);
+                        if (!clean) {  // a symbol outside A C G T ahead: the general kernel's
+                            bail = true;
+                            break;
+                        }
+                        uint32_t a0, a1;  // levels shift, shift + 1 | shift + 2, shift + 3 of the window
+                        if (shift == 0u) {
+                            a0 = w.l0;
+                            a1 = w.l1;
+                        } else if (shift == 1u) {
+                            a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
+                            a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                        } else if (shift == 2u) {
+                            a0 = w.l1;
+                            a1 = w.l2;
+                        } else {
+                            a0 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                            a1 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                        }
+                        // the 32 symbols [rem_v - 32, rem_v) in text order, the next one to be consumed in the top bits
+                        const uint64_t qcode = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a0, a0, 16)) << 32) |
+                                               static_cast<uint64_t>(__builtin_amdgcn_alignbit(a1, a1, 16));
+                        // (a lane that is going has matched rem - rem_v symbols: pos >= rem - rem_v, and the pad units in front of
+                        // the text read as "no match")
+                        const uint64_t s0t = static_cast<uint64_t>(pos) - (rem - rem_v) + 32u * kTextPadUnits - 32u;
+                        const uint32_t tb = static_cast<uint32_t>(s0t & 31u);
+                        const u32x4 *tu = ix.text_units + (s0t >> 5);
+                        const u32x4 u0 = going ? tu[0] : u32x4{0u, 0u, 0u, 0u};
+                        const u32x4 u1 = (going && tb != 0u) ? tu[1] : u32x4{0u, 0u, 0u, 0u};
+                        const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
+                        const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
+                        const uint64_t tcode = tb ? (c0 >> (2u * tb)) | (c1 << (64u - 2u * tb)) : c0;
+                        const uint32_t tmask = tb ? (u0.z >> tb) | (u1.z << (32u - tb)) : u0.z;
+                        const uint64_t vm64 = n_v == 32u ? ~0ull : ~0ull << (2u * (32u - n_v));
+                        const uint32_t vm32 = n_v == 32u ? ~0u : ~0u << (32u - n_v);
+                        const uint64_t diff = (qcode ^ tcode) & vm64;
+                        const uint32_t other = tmask & vm32;  // a sentinel, an N, ... in the text
+                        uint32_t got = diff != 0ull ? static_cast<uint32_t>(__builtin_clzll(diff)) >> 1 : n_v;
+                        const uint32_t got_m = other != 0u ? static_cast<uint32_t>(__builtin_clz(other)) : n_v;
+                        got = got < got_m ? got : got_m;
+                        if (going) {
+                            m += got;
+                            going = got == n_v;
+                        }
+                        rem_v -= n_v;
+                    }
+                    if (bail) break;
+                    const uint32_t best = group_max<kGroup>(real ? m : 0u);
+                    fresh = false;
+                    if (best == 0u) {  // no row survives the next step: the pair lines make the frozen interval
+                        text_ok = false;
+                        continue;
+                    }
+                    const bool mine = real && m == best;
+                    const uint32_t row = mine ? ix.isa[pos - best] : 0u;
+                    lo = group_min<kGroup>(mine ? row : 0xffffffffu);
+                    hi = group_max<kGroup>(mine ? row : 0u) + 1u;
+                    rem -= best;
+                    if (rem > 0u) text_ok = false;  // (every surviving row mismatches the next symbol)
+                    continue;
+                }
+                if (kText && rows <= static_cast<uint32_t>(kGroup)) narrow++;
                 const bool jumping = jump_ok && rows <= static_cast<uint32_t>(kGroup) && rem >= kJumpSymbols;
                 // the window must hold what this round reads: whole levels from an aligned position for a jump (levels
                 // 0 .. 6 of a window are always inside its eight words), one or two symbols for a pair step
@@ -3359,6 +3539,19 @@ __global__ __launch_bounds__(kBlock) void fill_uniform_offsets_kernel(uint64_t *
 // once every kernel of the call has written their results.  left: everything listed for the next kernels (compact result
 // "see the record": the record's count, also into *rest); long: reads finished by seed_text_kernel4 (those it handed on
 // are on the left list as well, and counted there).
+// the same for the queries of a list only (its length is a device value): off[q], off[q + 1] -- what the offset-reading
+// kernels behind the seed chain need of a uniform batch, instead of 8 bytes per query of the whole batch
+__global__ __launch_bounds__(kBlock) void fill_uniform_offsets_list_kernel(uint64_t *__restrict__ off, const uint32_t *__restrict__ list,
+                                                                          const uint32_t *__restrict__ n_list, uint32_t ulen)
+{
+    const uint64_t n = *n_list;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const uint64_t q = list[i];
+        off[q] = q * ulen;
+        off[q + 1] = (q + 1) * ulen;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tile_sums_lists_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ compact,
                                                                  uint32_t max_hits, const uint32_t *__restrict__ left,
                                                                  const uint32_t *__restrict__ n_left, const uint32_t *__restrict__ lng,
@@ -3419,14 +3612,18 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
     if (c.packed && (c.mode == 2 || c.d_step_stats != nullptr)) fail(GDX_ERR_UNSUPPORTED, "packed queries: search and count / locate only");
     // Uniform batches (SearchCall::uniform_len): the seed chain and the rank-line kernels compute where a query lies; the
     // pair-line kernels read offsets, which are then written once into scratch (8 bytes per query, one streaming pass)
-    if (c.uniform_len != 0u && ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
-        uint64_t *d_off = static_cast<uint64_t *>(stream_scratch(stream, 15, (nq + 1) * sizeof(uint64_t)));
-        hipLaunchKernelGGL(fill_uniform_offsets_kernel, dim3(grid_for_items(nq + 1)), dim3(kBlock), 0, stream, d_off, nq + 1,
+    // (a count / locate call may leave all but a short list to the seed chain, which computes too: decided below)
+    const bool pair_offsets = c.uniform_len != 0u && ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr;
+    uint64_t *d_uniform_off = nullptr;
+    auto dense_uniform_offsets = [&] {
+        d_uniform_off = static_cast<uint64_t *>(stream_scratch(stream, 15, (nq + 1) * sizeof(uint64_t)));
+        hipLaunchKernelGGL(fill_uniform_offsets_kernel, dim3(grid_for_items(nq + 1)), dim3(kBlock), 0, stream, d_uniform_off, nq + 1,
                            c.uniform_len);
-        c.d_qbeg = d_off;
-        c.d_qend = d_off + 1;
+        c.d_qbeg = d_uniform_off;
+        c.d_qend = d_uniform_off + 1;
         c.uniform_len = 0;
-    }
+    };
+    if (pair_offsets && c.mode != 1) dense_uniform_offsets();
     const uint32_t ulen = c.uniform_len;
     // the call's counters (and what the caller wants zeroed with them) are zeroed by one launch before its first kernel
     ZeroSet zs;
@@ -3563,11 +3760,9 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     const bool lane_kernel = env_lane != 0 && xlate != 0 && ix.seed_k <= 24u && ix.seed_k >= 8u &&
                                              (reinterpret_cast<uintptr_t>(c.d_qbuf) & 3u) == 0;
                     // the locate's hit totals folded into this call (SearchCall::d_tile_sums): the lane kernel counts what it
-                    // answers, tile_sums_lists_kernel adds its two lists once the whole chain has run (end of this function; the
-                    // pair-line branch returns earlier, hence only without pair lines)
+                    // answers, tile_sums_lists_kernel adds its two lists once the whole chain has run (finish_fold below)
                     unsigned long long *fold = nullptr;
-                    if (lane_kernel && c.d_tile_sums != nullptr && c.d_tile_rest != nullptr && c.d_compact != nullptr &&
-                        !(variant == 2 && ix.pair_lines != nullptr)) {
+                    if (lane_kernel && c.d_tile_sums != nullptr && c.d_tile_rest != nullptr && c.d_compact != nullptr) {
                         fold = c.d_tile_sums;
                         zs.add(fold, ((nq + kSumTile - 1) / kSumTile) * sizeof(unsigned long long));
                         fold_left = d_first;
@@ -3644,6 +3839,31 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         }
     }
     zs.flush(stream);  // (a call that took none of the paths above: what the caller wanted zeroed)
+    // a uniform batch in front of the pair-line kernels, which read offsets: those of the whole batch (8 bytes per query, one
+    // streaming pass), or -- behind the seed chain -- of the listed queries only, written before each kernel that takes a list
+    bool sparse_offsets = false;
+    if (pair_offsets && c.mode == 1) {
+        if (leftover_list) {
+            d_uniform_off = static_cast<uint64_t *>(stream_scratch(stream, 15, (nq + 1) * sizeof(uint64_t)));
+            c.d_qbeg = d_uniform_off;
+            c.d_qend = d_uniform_off + 1;
+            c.uniform_len = 0;
+            sparse_offsets = true;
+        } else {
+            dense_uniform_offsets();
+        }
+    }
+    auto offsets_for_list = [&](const uint32_t *list, const uint32_t *n_list) {
+        if (sparse_offsets && list != nullptr)
+            hipLaunchKernelGGL(fill_uniform_offsets_list_kernel, dim3(1024), dim3(kBlock), 0, stream, d_uniform_off, list, n_list, ulen);
+    };
+    auto finish_fold = [&] {
+        if (fold_left == nullptr) return;
+        // (the lists' lengths are only known on the device: a capped grid that strides over whatever there is)
+        hipLaunchKernelGGL(tile_sums_lists_kernel, dim3(4096), dim3(kBlock), 0, stream, c.d_rec, c.d_compact, c.tile_max_hits,
+                           fold_left + 4, fold_left, fold_long + 4, fold_long, c.d_tile_sums, c.d_tile_rest);
+        if (c.tile_sums_done != nullptr) *c.tile_sums_done = true;
+    };
     // compact results without the seed kernel: every query says "see the record"
     if (c.d_compact != nullptr && !compact_by_seed) GDX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.d_compact), static_cast<int>(kCompactSee), nq, stream));
     if (ix.layout == 0 && variant == 2 && ix.pair_lines != nullptr) {
@@ -3773,7 +3993,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
             const ExactView ev{ix.top, ix.jump, ix.pair_lines, ix.io_to_dense, ix.top_depth, ix.n, static_cast<uint32_t>(ix.depth),
-                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+                               ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask,
+                               ix.sa_full, ix.isa, ix.text_units,
+                               ix.seed_k >= static_cast<uint32_t>(ix.depth) && ix.seed_k <= 24u ? ix.seed : nullptr, ix.seed_buckets,
+                               ix.seed_k, ix.seed_tag_bits};
+            // the text route in the jump table's place (search_exact_kernel4<0, ., ., true>); GDX_SEARCH_TEXT=0: pair lines only
+            static const int env_text = [] { const char *e = getenv("GDX_SEARCH_TEXT"); return e ? atoi(e) : 1; }();
+            const bool text_route = ix.jump == nullptr && ix.sa_full != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
+                                    env_text != 0;
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
             const bool perm = ix.perm_ok && !env_no_perm;
 #define GDX_EXACT_LAUNCH(J, XLATE, CURSOR)                                                                                  \
@@ -3784,9 +4011,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         if (perm) GDX_EXACT_LAUNCH(J, 1, CURSOR);        \
         else GDX_EXACT_LAUNCH(J, 0, CURSOR);             \
     } while (0)
+#define GDX_EXACT_LAUNCH_T(XLATE, CURSOR)                                                                                    \
+    hipLaunchKernelGGL((search_exact_kernel4<0, XLATE, CURSOR, true>), dim3(x_blocks), dim3(kBlock), 0, stream, ev, c.d_qbuf, \
+                       c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status, x_range, schedule, d_left + 4, d_left, ca_exact)
 #define GDX_EXACT_LAUNCH_J(CURSOR)                                                 \
     do {                                                                           \
-        if (ix.jump == nullptr) GDX_EXACT_LAUNCH_X(0, CURSOR);                     \
+        if (text_route && perm) GDX_EXACT_LAUNCH_T(1, CURSOR);                     \
+        else if (text_route) GDX_EXACT_LAUNCH_T(0, CURSOR);                        \
+        else if (ix.jump == nullptr) GDX_EXACT_LAUNCH_X(0, CURSOR);                \
         else if (ix.jump_bytes == 32) GDX_EXACT_LAUNCH_X(32, CURSOR);              \
         else if (ix.jump_bytes == 16) GDX_EXACT_LAUNCH_X(16, CURSOR);              \
         else GDX_EXACT_LAUNCH_X(8, CURSOR);                                        \
@@ -3794,6 +4026,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             if (c.mode == 2) GDX_EXACT_LAUNCH_J(true);
             else GDX_EXACT_LAUNCH_J(false);
 #undef GDX_EXACT_LAUNCH_J
+#undef GDX_EXACT_LAUNCH_T
 #undef GDX_EXACT_LAUNCH_X
 #undef GDX_EXACT_LAUNCH
             g_range = 256;
@@ -3839,6 +4072,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         else if (ix.jump_bytes == 16) GDX_FAST_LAUNCH(16, XLATE); \
         else GDX_FAST_LAUNCH(8, XLATE);                           \
     } while (0)
+            if (seed_list != nullptr) offsets_for_list(seed_list + 4, seed_list);
             if (c.packed) GDX_FAST_LAUNCH_P(2);
             else if (ix.perm_ok && !env_no_perm) GDX_FAST_LAUNCH_P(1);
             else GDX_FAST_LAUNCH_P(0);
@@ -3856,6 +4090,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             ca_general.n_active_in = d_left;
             ca_general.resume_state = d_state;
         }
+        offsets_for_list(ca_general.active_in, ca_general.n_active_in);
         if (c.packed) {
 #define GDX_PACKED_W(M)                                                                    \
     do {                                                                                   \
@@ -3889,6 +4124,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
 #undef GDX_PAIR_LAUNCH_M
 #undef GDX_PAIR_LAUNCH_W
 #undef GDX_PAIR_LAUNCH
+        finish_fold();
         return;
     }
     // rank-line and generic kernels: no hints (locate then walks from the interval itself)
@@ -3912,12 +4148,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
     else if (ix.layout == 0) GDX_PLAIN_LAUNCH(LineTable, 1, grid_for_items(nq));
     else GDX_PLAIN_LAUNCH(GenericTable, 1, grid_for_items(nq));
 #undef GDX_PLAIN_LAUNCH
-    if (fold_left != nullptr) {
-        // (the lists' lengths are only known on the device: a capped grid that strides over whatever there is)
-        hipLaunchKernelGGL(tile_sums_lists_kernel, dim3(4096), dim3(kBlock), 0, stream, c.d_rec, c.d_compact, c.tile_max_hits,
-                           fold_left + 4, fold_left, fold_long + 4, fold_long, c.d_tile_sums, c.d_tile_rest);
-        if (c.tile_sums_done != nullptr) *c.tile_sums_done = true;
-    }
+    finish_fold();
 }
 
 // ASCII -> 2-bit: packed byte b holds the codes of bytes 4 b .. 4 b + 3 of the query buffer; *bad_symbols counts the

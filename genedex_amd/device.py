@@ -379,6 +379,7 @@ class DeviceEngine:
         a = self.index.aux()
         return {"pair_lines": bool(out[0]), "jump_entry_bytes": int(out[1]), "top_table_depth": int(out[2]),
                 "full_suffix_array": bool(out[3] & 1), "text_units": bool(out[3] & 2), "inverse_suffix_array": bool(out[3] & 4),
+                "default_shape": bool(out[3] & 8),  # the library chose it: every option was left at its default
                 "aux_bytes": a["aux_bytes"], "aux_budget_bytes": a["aux_budget_bytes"], "wide_permille": a["wide_permille"],
                 "shrunk_by_budget": (a["wanted_jump_entry_bytes"], a["wanted_top_table_depth"])
                 != (a["jump_entry_bytes"], a["top_table_depth"]),

@@ -32,7 +32,11 @@ def hg38_scale():
     index = build_index_from_device_text(io_text, lengths, a, index_storage="u32")
     eng = DeviceEngine(index)
     aux = eng.aux_info()
-    assert aux["pair_lines"] and aux["jump_entry_bytes"] == 32 and aux["top_table_depth"] == 16 and not aux["shrunk_by_budget"]
+    # the library's defaults = the default shape (round 6; the index bench.py's headline runs on): seed table (k = 24) + text units +
+    # full and inverse suffix array + pair lines + depth-14 top table, no jump table: 104 GB
+    assert aux["default_shape"] and aux["pair_lines"] and aux["jump_entry_bytes"] == 0 and aux["top_table_depth"] == 14
+    assert aux["seed"]["k"] == 24 and aux["full_suffix_array"] and aux["inverse_suffix_array"] and aux["text_units"]
+    assert index.info.device_bytes < 135e9
     threads = min(os.cpu_count() or 1, 64)
     cpu = OracleIndex.from_bwt(index.export_bwt(), index.export_sa_samples(), 4, *index.export_borders(),
                                index.export_sentinel_indices(), a.io_to_dense_table, 6, 4, width=32, n_threads=threads)

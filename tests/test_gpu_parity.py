@@ -205,8 +205,13 @@ def mixed_queries(rng, texts, n_sampled, n_random, max_len, allow_n=False):
 
 _VARIANTS = {
     # name: (query options, build options)
-    "pair": (dict(search_kernel="pair"), {}),  # defaults: 32-byte jump entries, top table sized from the text
-    "pair-8lanes": (dict(search_kernel="pair", search_lanes=8, search_defer_after=1), {}),
+    # the library's defaults (round 6): seed table + text units + full and inverse suffix array + pair lines + top table, no jump
+    # table -- the shape bench.py's headline runs on; and the same with the seed table switched off at query time
+    "default": ({}, {}),
+    "default-no-seed": (dict(search_seed=False), {}),
+    # the tables of rounds 1-3: 32-byte jump entries, top table sized from the text
+    "pair": (dict(search_kernel="pair"), dict(jump_entry_bytes=32)),
+    "pair-8lanes": (dict(search_kernel="pair", search_lanes=8, search_defer_after=1), dict(jump_entry_bytes=32)),
     "pair-park-all": (dict(search_kernel="pair", search_defer_after=1), dict(jump_entry_bytes=0, top_table_depth=6)),
     "pair-jump16": (dict(search_kernel="pair", search_defer_after=0), dict(jump_entry_bytes=16)),
     "pair-narrow": (dict(search_kernel="pair"), dict(jump_entry_bytes=8, top_table_depth=0)),
@@ -214,11 +219,11 @@ _VARIANTS = {
     # path runs constantly
     "pair-top4": (dict(search_kernel="pair", locate_jump_walk=False), dict(top_table_depth=4)),
     "pair-top9": (dict(search_kernel="pair", load_policy=1), dict(top_table_depth=9)),
-    "pair-no-fast": (dict(search_kernel="pair", search_fast=False), {}),
+    "pair-no-fast": (dict(search_kernel="pair", search_fast=False), dict(jump_entry_bytes=32)),
     # the general kernel alone (no slim kernel in front of it) for exact intervals and cursors too
-    "pair-general-only": (dict(search_kernel="pair", search_fast=False, search_exact=False), {}),
-    "pair-fast": (dict(search_kernel="pair", search_fast=1), {}),  # (the default asks the index: wide_permille)
-    "pair-fast-wide": (dict(search_kernel="pair", search_fast=2), {}),
+    "pair-general-only": (dict(search_kernel="pair", search_fast=False, search_exact=False), dict(jump_entry_bytes=32)),
+    "pair-fast": (dict(search_kernel="pair", search_fast=1), dict(jump_entry_bytes=32)),  # (the default asks the index: wide_permille)
+    "pair-fast-wide": (dict(search_kernel="pair", search_fast=2), dict(jump_entry_bytes=32)),
     "pair-lines-only": (dict(search_kernel="pair", length_schedule=0), dict(jump_entry_bytes=0, top_table_depth=0)),
     "quad": (dict(search_kernel="quad"), dict(pair_lines=False)),
     # text units instead of a jump table: count / locate searches compare the rest of the query with the text at SA[row]
@@ -242,7 +247,7 @@ _VARIANTS = {
     # (all four, bit for bit and at the block boundaries: tests/test_gpu_seed.py::test_reference_table_layouts_...)
     "ref-condensed512": (dict(search_kernel="lane"), dict(reference_table_layout="condensed512")),
     "ref-flat64": (dict(search_kernel="lane", locate_kernel="lane"), dict(reference_table_layout="flat64")),
-    "lane": (dict(search_kernel="lane", locate_kernel="lane"), {}),
+    "lane": (dict(search_kernel="lane", locate_kernel="lane"), dict(jump_entry_bytes=32)),
 }
 
 
@@ -530,11 +535,21 @@ def test_acceleration_structures_shrink_to_the_memory_budget(budget, want):
     texts = random_texts(rng, len_max=20000, symbols=b"ACGT")
     g, c = both(texts, a, aux_budget_bytes=budget)
     full = g.aux()
+    aux = DeviceEngine(g).aux_info()
+    n = g.total_text_len()
+    if budget is None:
+        # every option at its default and room for it: the default shape (fm_index.hip build_aux) -- seed table, text units,
+        # full and inverse suffix array, pair lines, a top table, no jump table
+        assert aux["default_shape"] and aux["seed"]["k"] >= 8 and aux["full_suffix_array"] and aux["inverse_suffix_array"] \
+            and aux["text_units"] and aux["pair_lines"] and aux["jump_entry_bytes"] == 0 and 0 < aux["top_table_depth"] <= 14
+        g, c = both(texts, a, aux_budget_bytes=budget, jump_entry_bytes=32)  # the tables of rounds 1-3, asked for
+        full = g.aux()
+        aux = DeviceEngine(g).aux_info()
+    # (a budget the default shape does not fit: the options mean the tables, which shrink)
+    assert not aux["default_shape"] and aux["seed"]["k"] == 0
     assert full["wanted_jump_entry_bytes"] == 32
     assert (budget is None) == ((full["wanted_jump_entry_bytes"], full["wanted_top_table_depth"])
                                 == (full["jump_entry_bytes"], full["top_table_depth"]))
-    aux = DeviceEngine(g).aux_info()
-    n = g.total_text_len()
     if want is not None:
         if want[0] is not None:
             assert aux["jump_entry_bytes"] == want[0]
@@ -599,8 +614,9 @@ def test_full_size_properties_workload2():
         # 32-byte jump entries carry SA[row]: locate resolves any row with one fetch, so the exact-interval search
         # leaves no sampled-row hints (they would save nothing)
         assert hinted == 0
-    else:
+    elif eng.aux_info()["jump_entry_bytes"] != 0:
         assert hinted > nq // 3  # most one-occurrence reads pass through a sampled row while they jump
+    # (the default shape has no jump table: SA[row] is one fetch of the full suffix array, hints are not needed)
     counts = (out["end"] - out["start"]).to(torch.int64)
     assert int(counts.sum().item()) == total_hits
     found = int((counts > 0).sum().item())
@@ -885,7 +901,7 @@ def test_fast_path_query_translation(name):
     rng = np.random.default_rng(sum(name.encode()))
     texts = [bytes(text_symbols[i] for i in rng.integers(0, len(text_symbols), int(rng.integers(1000, 30000))))
              for _ in range(4)]
-    g, c = both(texts, a, sa_rate=3)
+    g, c = both(texts, a, sa_rate=3, jump_entry_bytes=32)
     g.set_query_options(search_fast=1 + sum(name.encode()) % 2)
     assert g.aux()["jump_entry_bytes"] == 32 and g.aux()["top_table_depth"] >= 1
     qs = []
