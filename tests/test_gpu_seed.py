@@ -190,7 +190,7 @@ def test_compact_results_equal_records_and_oracle(seed):
     a = [alph.ascii_dna(), alph.ascii_dna_with_n()][seed % 2]
     symbols = b"ACGTN" if seed % 2 else b"ACGT"
     texts = repetitive_texts(rng, symbols=symbols) if seed % 4 < 2 else random_texts(rng, len_max=8000, symbols=symbols)
-    build = [dict(LEAN, seed_symbols=True, full_suffix_array=True), dict(seed_symbols=11), {},
+    build = [dict(LEAN, seed_symbols=True, full_suffix_array=True), dict(seed_symbols=11), dict(jump_entry_bytes=32),
              dict(LEAN, seed_symbols=9, seed_load_percent=100)][(seed // 2) % 4]
     g = gpu_index(texts, a, **build)
     c = cpu_index(texts, a)
@@ -588,7 +588,7 @@ def test_seed_table_on_a_loaded_index(tmp_path):
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()
     texts = repetitive_texts(rng, symbols=b"ACGTN")
-    plain = gpu_index(texts, a, sa_rate=3)
+    plain = gpu_index(texts, a, sa_rate=3, jump_entry_bytes=32)  # (the tables of rounds 1-3: no seed table)
     c = cpu_index(texts, a, sa_rate=3)
     path = tmp_path / "index.gdx"
     plain.save_to_file(path)
