@@ -1639,7 +1639,9 @@ QueryOptions FmIndex::query_options() const
     q.search_seed = q_seed_.load();
     q.max_hits_per_query = q_max_hits_.load();
     // default: park stragglers only on repetitive texts (the bookkeeping costs the plain kernel ~15 %)
-    if (q.search_defer_after < 0) q.search_defer_after = aux_report_.wide_fraction > 0.05 ? 3 : 0;
+    // (wide_fraction tells how repetitive the text is only next to a jump table, whose top table is as deep as the text allows;
+    // without one -- the default shape, its top table capped at depth 14 -- nothing jumps and nothing is parked)
+    if (q.search_defer_after < 0) q.search_defer_after = (view_.jump != nullptr && aux_report_.wide_fraction > 0.05) ? 3 : 0;
     // default: the fast-path kernel first, unless the top table is so shallow for this text that most reads leave it
     // on more rows than a jump takes -- their intervals narrow fastest on pair lines (top 12 / 8-byte jumps at hg38
     // scale: 21.8 ms without, 26.5 ms with the fast path in front)
