@@ -1728,6 +1728,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
     __shared__ uint32_t s_stage_q[kCursor ? kBlock : 1], s_stage_lo[kCursor ? kBlock : 1], s_stage_hi[kCursor ? kBlock : 1],
         s_stage_len[kCursor ? kBlock : 1];
     __shared__ uint64_t s_stage_begin[kCursor ? kBlock : 1];
+    __shared__ uint32_t s_stage_pos[(kCursor && kText) ? kBlock : 1];  // SA[row] of a cursor that comes in on one row (text route)
     __shared__ uint16_t s_perm[kCursor ? 1 : kMaxRange];  // order_range_by_length (fused searches of mixed lengths)
     __shared__ uint32_t s_cnt[kLenBuckets];
     __shared__ uint32_t s_minmax[2];
@@ -1779,6 +1780,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
                 s_stage_hi[threadIdx.x] = chi;
                 s_stage_begin[threadIdx.x] = cb;
                 s_stage_len[threadIdx.x] = (cbail ? 0u : static_cast<uint32_t>(clen)) | (more ? 1u << 30 : 0u) | (cbail ? 1u << 31 : 0u);
+                // (a cursor on one row with enough symbols to come takes the text route: its SA value is fetched here, 256 at
+                // once and one link earlier in the chain, instead of by its lane group later)
+                if (kText && chi - clo == 1u && !cbail && clen >= kTextMinSymbols) s_stage_pos[threadIdx.x] = ix.sa_full[clo];
             }
             __syncthreads();
         }
@@ -1786,9 +1790,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
             uint32_t q, lo = 0, hi = ix.n;
             uint64_t begin, len;
             bool more_left = true, bail;
+            uint32_t staged_pos = 0;
+            bool staged = false;  // staged_pos = SA[lo] of the one row the cursor came in on
             if (kCursor) {
                 const uint32_t k = slot - s0;
                 const uint32_t packed = s_stage_len[k];
+                if (kText) {
+                    staged = s_stage_hi[k] - s_stage_lo[k] == 1u && (packed >> 31) == 0u && (packed & 0x3fffffffu) >= kTextMinSymbols;
+                    staged_pos = s_stage_pos[k];
+                }
                 q = s_stage_q[k];
                 lo = s_stage_lo[k];
                 hi = s_stage_hi[k];
@@ -1804,6 +1814,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
                 bail = len >= (1ull << 21);
             }
             const bool empty_cursor = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210): the top table applies
+            staged = staged && !empty_cursor;  // (a one-row collection: the seed / top table routes change the interval first)
             uint32_t rem = bail ? 0u : static_cast<uint32_t>(len);
             const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
@@ -1916,12 +1927,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
                 const uint32_t rows = hi - lo;
                 if (kText && text_ok && rows <= static_cast<uint32_t>(kGroup) && rem >= kTextMinSymbols && narrow >= 2u) {
                     const bool real = sub < rows;
-                    const uint32_t pos = ix.sa_full[real ? lo + sub : lo];
+                    const uint32_t pos = staged ? staged_pos : ix.sa_full[real ? lo + sub : lo];
+                    staged = false;  // (it was the SA value of the row the cursor came in on)
                     uint32_t m = 0;  // LF steps this lane's row survives = symbols of the text in front of pos that are the query's
                     bool going = real;
                     uint32_t rem_v = rem;
                     bool reuse = fresh && part == 0u && shift <= 3u;  // the window still serves the first pass
                     while (rem_v > 0u && group_max<kGroup>(going ? 1u : 0u) != 0u) {
+                        // (a lane that is going has matched rem - rem_v symbols: pos >= rem - rem_v, and the pad units in front of
+                        // the text read as "no match"; the text loads go out before the window's, which do not depend on them)
+                        const uint64_t s0t = static_cast<uint64_t>(pos) - (rem - rem_v) + 32u * kTextPadUnits - 32u;
+                        const uint32_t tb = static_cast<uint32_t>(s0t & 31u);
+                        const u32x4 *tu = ix.text_units + (s0t >> 5);
+                        const u32x4 u0 = going ? tu[0] : u32x4{0u, 0u, 0u, 0u};
+                        const u32x4 u1 = (going && tb != 0u) ? tu[1] : u32x4{0u, 0u, 0u, 0u};
                         if (!reuse) {
                             w = fast_window<kXlate>(ix, s_dense, wbase, off0, rem_v, sub);
                             shift = 0;
@@ -1955,13 +1974,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
                         // the 32 symbols [rem_v - 32, rem_v) in text order, the next one to be consumed in the top bits
                         const uint64_t qcode = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a0, a0, 16)) << 32) |
                                                static_cast<uint64_t>(__builtin_amdgcn_alignbit(a1, a1, 16));
-                        // (a lane that is going has matched rem - rem_v symbols: pos >= rem - rem_v, and the pad units in front of
-                        // the text read as "no match")
-                        const uint64_t s0t = static_cast<uint64_t>(pos) - (rem - rem_v) + 32u * kTextPadUnits - 32u;
-                        const uint32_t tb = static_cast<uint32_t>(s0t & 31u);
-                        const u32x4 *tu = ix.text_units + (s0t >> 5);
-                        const u32x4 u0 = going ? tu[0] : u32x4{0u, 0u, 0u, 0u};
-                        const u32x4 u1 = (going && tb != 0u) ? tu[1] : u32x4{0u, 0u, 0u, 0u};
                         const uint64_t c0 = static_cast<uint64_t>(u0.x) | (static_cast<uint64_t>(u0.y) << 32);
                         const uint64_t c1 = static_cast<uint64_t>(u1.x) | (static_cast<uint64_t>(u1.y) << 32);
                         const uint64_t tcode = tb ? (c0 >> (2u * tb)) | (c1 << (64u - 2u * tb)) : c0;
@@ -2524,14 +2536,21 @@ struct SeedView {
     const uint8_t *io_to_dense;
     uint32_t buckets, k, tag_bits;
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
+    uint32_t n = 0;  // kCursor: IndexView::n (cursor_empty is [0, n))
 };
 
 // kExact: exact intervals (cursors_for_many_queries) instead of records: a read whose seed occurs once and whose other
 // symbols agree with the text occurs once itself, and the row of its only suffix is ISA[its position] -- one more fetch
 // (IndexView::isa), issued in one round and stored in the next.  Everything else needs the reference's frozen empty
 // interval (or an interval wider than a row) and is listed for search_exact_kernel4.
-template <int kXlate, bool kExact>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_seed_kernel4(
+// kCursor (with kExact; round 6): the FIRST chunk of a batch of cursors (gdx_cursor_extend_front_chunk_dev / _strings_dev).  A
+// cursor that is still cursor_empty (lib.rs:202-210) and gets a chunk of seed_k .. seed_k + 32 symbols is a search of that
+// chunk: the pipeline serves it as it serves a read -- bucket, entry, ISA -- and appends it to the live list; every other cursor
+// (another state, a status, a chunk too short or too long, a k-mer that is absent or on several rows) is listed untouched for
+// search_exact_kernel4, which is the statement of what a cursor call does.  Lock-step groups of that kernel paid for the
+// slowest read of sixteen in every round (the absent k-mers' top table and pair steps); split by kind, both passes run dense.
+template <int kXlate, bool kExact, bool kCursor = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCursor ? 7 : 8, kCursor ? 7 : 8))) void search_seed_kernel4(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end,
@@ -2547,17 +2566,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // 2-bit codes this kernel holds anyway: {lo, rows << 24 | kStatePacked | symbols left, codes hi, codes lo} -- the fast
     // kernel then needs neither the read's offsets nor its bytes for up to 32 symbols (kStatePacked, search_fast_kernel4)
     uint32_t state_packed,
-    uint32_t ulen)  // uniform batch (query_begin): the offsets stage of the pipeline computes instead of loading
+    uint32_t ulen,  // uniform batch (query_begin): the offsets stage of the pipeline computes instead of loading
+    CursorArgs ca)  // kCursor: the cursors to look at (active_in), the live list (active_out), the chunk view
 {
+    static_assert(!kCursor || kExact, "cursor chunks are exact searches");
     constexpr uint32_t kGroup = 4, kGroups = kBlock / kGroup;
     constexpr uint32_t kNoQuery = 0xffffffffu;  // a pipeline slot beyond the range
     __shared__ uint8_t s_dense[256];
     __shared__ uint16_t s_left[kMaxRange], s_long[kMaxRange];  // slots of the range (its base is added when they are flushed)
     __shared__ uint32_t s_nleft, s_left_base, s_nlong, s_long_base;
+    __shared__ uint32_t s_alive[kCursor ? kCursorRange : 1];  // flush_live_ordered (ranges of a cursor launch: <= kCursorRange)
+    __shared__ uint32_t s_alive_part[kCursor ? kBlock : 1];
+    __shared__ uint32_t s_alive_base;
     if (kXlate == 0)
         for (int i = threadIdx.x; i < 256; i += kBlock) s_dense[i] = sv.io_to_dense[i];
+    if (kCursor)
+        for (uint32_t i = threadIdx.x; i < kCursorRange; i += kBlock) s_alive[i] = kDeadCursor;
     if (threadIdx.x == 0) s_nleft = s_nlong = 0;
     __syncthreads();
+    const uint32_t *active = kCursor ? ca.active_in : nullptr;
+    if (kCursor && ca.n_active_in != nullptr) nq = *ca.n_active_in;
     const bool writer = (threadIdx.x % kGroup) == 0;
     const uint32_t sub = threadIdx.x & (kGroup - 1u);
     const uint32_t slot0 = threadIdx.x / kGroup;
@@ -2578,13 +2606,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         bool a_left = false;  // the read of stage A goes to the leftover list
         uint32_t z_row = 0, z_q = 0;  // kExact: the row of read z_q is on its way
         bool z_on = false;
+        // kCursor: the cursor of each stage (a list entry, not base + slot), whether its string goes on left of this chunk
+        uint32_t c_q = 0, b_q = 0, a_q = 0, z_slot = 0;
+        bool c_more = false, c_ok = true, b_more = false, a_more = false, z_more = false;
         for (int it = -3; it <= n_it; it++) {
             if (kExact) {
                 if (z_on && writer) {
                     out_start[z_q] = z_row;
                     out_end[z_q] = z_row + 1u;
                     if (out_count) out_count[z_q] = 1u;
-                    if (out_status) out_status[z_q] = 0;
+                    if (!kCursor && out_status) out_status[z_q] = 0;
+                    if (kCursor && ca.active_out != nullptr && z_more) s_alive[z_slot] = z_q;
                 }
                 z_on = false;
             }
@@ -2592,7 +2624,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             // ---- stage A -> result: round `it` looks at its bucket -------------------------------------------------
             if (it >= 0) {
                 const uint32_t slot = slot0 + static_cast<uint32_t>(it) * kGroups;
-                const uint32_t q = static_cast<uint32_t>(base + slot);
+                const uint32_t q = kCursor ? a_q : static_cast<uint32_t>(base + slot);
                 if (a_left) {
                     if (writer) {
                         s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
@@ -2632,7 +2664,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 out_start[q] = ey;
                                 out_end[q] = ez;
                                 if (out_count) out_count[q] = ez - ey;
-                                if (out_status) out_status[q] = 0;
+                                if (!kCursor && out_status) out_status[q] = 0;
+                                if (kCursor && ca.active_out != nullptr && a_more && ey != ez) s_alive[slot] = q;
                             }
                         } else if (writer) {  // several rows: the next kernel takes it from this interval
                             s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
@@ -2656,7 +2689,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             hit = ((qcode ^ tcode) & vm64) == 0ull && pos >= rem && rem <= n_text;
                             is_long = hit && rem > 32u;  // the rest against the text units: seed_text_kernel4
                         }
-                        if (is_long) {
+                        if (kCursor && is_long) {  // (a chunk longer than an entry covers: the exact kernel's text route)
+                            if (writer) s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
+                        } else if (is_long) {
                             if (writer) {
                                 s_long[atomicAdd(&s_nlong, 1u)] = static_cast<uint16_t>(slot);
                                 if (kExact) {
@@ -2674,6 +2709,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 z_row = sv.isa[pos - rem];
                                 z_q = q;
                                 z_on = true;
+                                z_slot = slot;
+                                z_more = a_more;
                             }
                         } else if (writer) {
                             if (left) {
@@ -2694,6 +2731,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             // ---- stage B -> A: round `it + 1` turns its query bytes into key, bucket address and the 32 symbols in front
             a_left = false;
             a_rem = kNoQuery;
+            a_q = b_q;
+            a_more = b_more;
             if (b_len != kNoQuery) {
                 if (b_len < k || b_len >= (1u << 21)) {
                     a_left = true;
@@ -2729,10 +2768,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             // ---- stage C -> B: round `it + 2` knows where its query is and asks for its last 64 bytes ----------------
             b_len = kNoQuery;
+            b_q = c_q;
+            b_more = c_more;
             if (c_on) {
                 const uint64_t len = c_end - c_beg;
                 b_beg = c_beg;
                 b_len = len < (1ull << 21) ? static_cast<uint32_t>(len) : (1u << 21);
+                if (kCursor && !c_ok) b_len = 0u;  // not cursor_empty, or stopped: listed untouched
                 if (b_len >= k && b_len < (1u << 21))
                     b_raw = fast_window_load<kXlate>(query_words<kXlate>(qbuf, c_beg), static_cast<uint32_t>(c_beg & 7u), b_len, sub);
             }
@@ -2741,9 +2783,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (it + 3 < n_it) {
                 const uint32_t slot = slot0 + static_cast<uint32_t>(it + 3) * kGroups;
                 if (slot < cnt) {
-                    const uint32_t q = static_cast<uint32_t>(base + slot);
-                    c_beg = query_begin(qbeg, ulen, q);
-                    c_end = query_end(qend, ulen, q);
+                    if (kCursor) {
+                        const uint32_t q = active != nullptr ? active[base + slot] : static_cast<uint32_t>(base + slot);
+                        uint64_t cb = qbeg[q], ce = qend[q];
+                        const uint32_t clo = out_start[q], chi = out_end[q];
+                        const uint32_t cst = out_status != nullptr ? out_status[q] : 0u;
+                        bool more = true;  // chunk view: the query has symbols left of this chunk (search_exact_kernel4)
+                        if (ca.chunk_symbols != 0u) {
+                            const uint64_t first = cb, skip = static_cast<uint64_t>(ca.chunk_index) * ca.chunk_symbols;
+                            ce = ce - first > skip ? ce - skip : first;
+                            cb = ce - first > ca.chunk_symbols ? ce - ca.chunk_symbols : first;
+                            more = cb > first;
+                        }
+                        c_beg = cb;
+                        c_end = ce;
+                        c_q = q;
+                        c_more = more;
+                        c_ok = clo == 0u && chi == sv.n && cst == 0u;
+                    } else {
+                        const uint32_t q = static_cast<uint32_t>(base + slot);
+                        c_beg = query_begin(qbeg, ulen, q);
+                        c_end = query_end(qend, ulen, q);
+                    }
                     c_on = true;
                 }
             }
@@ -2753,13 +2814,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t n_left = s_nleft;
         if (threadIdx.x == 0 && n_left != 0u) s_left_base = atomicAdd(n_leftover, n_left);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock) leftover[s_left_base + i] = static_cast<uint32_t>(base) + s_left[i];
+        for (uint32_t i = threadIdx.x; i < n_left; i += kBlock)
+            leftover[s_left_base + i] = (kCursor && active != nullptr) ? active[base + s_left[i]] : static_cast<uint32_t>(base) + s_left[i];
         const uint32_t n_lng = s_nlong;
         if (threadIdx.x == 0 && n_lng != 0u) s_long_base = atomicAdd(n_long, n_lng);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_lng; i += kBlock) long_list[s_long_base + i] = static_cast<uint32_t>(base) + s_long[i];
         __syncthreads();
         if (threadIdx.x == 0) s_nleft = s_nlong = 0;
+        if (kCursor && ca.active_out != nullptr) flush_live_ordered(s_alive, cnt, s_alive_part, &s_alive_base, ca.active_out, ca.n_active_out);
     }
 }
 
@@ -3749,7 +3812,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         hipLaunchKernelGGL((search_seed_kernel4<XLATE, false>), dim3(v_blocks), dim3(kBlock), seed_pad, stream, sv, c.d_qbuf,  \
                            c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, none, none, v_range, d_first + 4,          \
                            d_first, d_seed_state, c.d_compact, d_long + 4, d_long, d_long_state, long_stride,                 \
-                           seed_state_packed, ulen);                                                                           \
+                           seed_state_packed, ulen, CursorArgs());                                                             \
         hipLaunchKernelGGL((seed_text_kernel4<XLATE, false>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg, \
                            d_long + 4, d_long, d_long_state, long_stride, c.d_count, c.d_status, c.d_rec, none, none,         \
                            c.d_compact, d_seed_state, d_first + 4, d_first, ulen);                                            \
@@ -3971,14 +4034,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             if (ix.perm_ok && !env_no_perm_s) {
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen, CursorArgs());
                 hipLaunchKernelGGL((seed_text_kernel4<1, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
                                    d_first + 4, d_first, ulen);
             } else {
                 hipLaunchKernelGGL((search_seed_kernel4<0, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
-                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen);
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen, CursorArgs());
                 hipLaunchKernelGGL((seed_text_kernel4<0, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
                                    d_first + 4, d_first, ulen);
@@ -3989,18 +4052,53 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const uint64_t x_ranges = (nq + x_range - 1) / x_range;
             x_blocks = static_cast<unsigned>(x_ranges < 8192 ? x_ranges : 8192);
         }
+        // the text route in the jump table's place (search_exact_kernel4<0, ., ., true>); GDX_SEARCH_TEXT=0: pair lines only
+        static const int env_text = [] { const char *e = getenv("GDX_SEARCH_TEXT"); return e ? atoi(e) : 1; }();
+        const bool text_route = ix.jump == nullptr && ix.sa_full != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
+                                env_text != 0;
+        const bool seed_usable = ix.seed != nullptr && ix.seed_k >= static_cast<uint32_t>(ix.depth) && ix.seed_k <= 24u;
+        // The first chunk of a batch of cursors on such an index: the seed kernel's pipeline serves the cursors that are still
+        // cursor_empty and lists the others for the exact kernel (search_seed_kernel4<., true, true>).  "First" is a guess -- a
+        // chunk call with index 0, or a call without a live list: a wrong guess costs a pass, never a result.
+        // GDX_SEARCH_SEED_CURSOR=0: the exact kernel alone.
+        static const int env_seed_cursor = [] { const char *e = getenv("GDX_SEARCH_SEED_CURSOR"); return e ? atoi(e) : 1; }();
+        const bool seed_cursor = exact && c.mode == 2 && text_route && seed_usable && env_seed_cursor != 0 &&
+                                 (env_seed_x >= 0 ? env_seed_x != 0 : qo.search_seed != 0) &&
+                                 // (chunks longer than an entry covers all go the exact kernel's way: its seed route, then the text)
+                                 (ca.chunk_symbols != 0u ? (ca.chunk_index == 0u && ca.chunk_symbols >= ix.seed_k && ca.chunk_symbols <= ix.seed_k + 32u)
+                                                         : ca.active_in == nullptr);
+        if (seed_cursor) {
+            uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
+            GDX_HIP(hipMemsetAsync(d_first, 0, sizeof(uint32_t), stream));
+            SeedView sv{ix.seed, ix.text_units, ix.isa, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
+                        ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
+            sv.n = ix.n;
+            static const bool env_no_perm_c = getenv("GDX_SEARCH_NO_PERM") != nullptr;
+            uint4 *const no_rec = nullptr;
+            uint32_t *const none_u32 = nullptr;
+            uint2 *const no_state = nullptr;
+            if (ix.perm_ok && !env_no_perm_c)
+                hipLaunchKernelGGL((search_seed_kernel4<1, true, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
+                                   none_u32, none_u32, none_u32, no_state, 0u, 0u, 0u, ca);
+            else
+                hipLaunchKernelGGL((search_seed_kernel4<0, true, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
+                                   none_u32, none_u32, none_u32, no_state, 0u, 0u, 0u, ca);
+            ca_exact.active_in = d_first + 4;
+            ca_exact.n_active_in = d_first;
+            x_range = 256;
+            const uint64_t x_ranges = (nq + x_range - 1) / x_range;
+            x_blocks = static_cast<unsigned>(x_ranges < 8192 ? x_ranges : 8192);
+        }
         if (exact) {
             uint32_t *d_left = static_cast<uint32_t *>(stream_scratch(stream, 11, (nq + 4) * sizeof(uint32_t)));
             GDX_HIP(hipMemsetAsync(d_left, 0, sizeof(uint32_t), stream));
+            // (behind the seed kernel's cursor pass the exact kernel does not look into the seed table again)
             const ExactView ev{ix.top, ix.jump, ix.pair_lines, ix.io_to_dense, ix.top_depth, ix.n, static_cast<uint32_t>(ix.depth),
                                ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask,
-                               ix.sa_full, ix.isa, ix.text_units,
-                               ix.seed_k >= static_cast<uint32_t>(ix.depth) && ix.seed_k <= 24u ? ix.seed : nullptr, ix.seed_buckets,
+                               ix.sa_full, ix.isa, ix.text_units, (seed_usable && !seed_cursor) ? ix.seed : nullptr, ix.seed_buckets,
                                ix.seed_k, ix.seed_tag_bits};
-            // the text route in the jump table's place (search_exact_kernel4<0, ., ., true>); GDX_SEARCH_TEXT=0: pair lines only
-            static const int env_text = [] { const char *e = getenv("GDX_SEARCH_TEXT"); return e ? atoi(e) : 1; }();
-            const bool text_route = ix.jump == nullptr && ix.sa_full != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
-                                    env_text != 0;
             static const bool env_no_perm = getenv("GDX_SEARCH_NO_PERM") != nullptr;  // debug: translate through LDS
             const bool perm = ix.perm_ok && !env_no_perm;
 #define GDX_EXACT_LAUNCH(J, XLATE, CURSOR)                                                                                  \
