@@ -95,10 +95,13 @@ def parse_args():
     ap.add_argument("--verify-hits", type=int, default=1_000_000)
     ap.add_argument("--secondary-depth", type=int, default=10,
                     help="N=1 only: lookup-table depth of the `lookup_depth_D` secondary design point; 0 = no secondaries")
-    ap.add_argument("--index", default="seed", choices=["seed", "tables"],
-                    help="headline index: seed = the reference's arrays + seed table + text units + full suffix array (84 GB "
-                         "at hg38 scale); tables = the library's default structures (pair lines + 32-byte jump entries + "
-                         "depth-16 top table, 144 GB: the headline of rounds 1..3a, a ladder rung now)")
+    ap.add_argument("--index", default="default", choices=["default", "seed", "tables"],
+                    help="headline index: default = what gdx_index_build makes with every build option left at its default -- "
+                         "the DEFAULT SHAPE: the reference's arrays + seed table + text units + full and inverse suffix array + "
+                         "pair lines + depth-14 top table (104 GB at hg38 scale); count / locate, exact intervals and cursors "
+                         "are all measured on this ONE index.  seed = rounds 3b-5's lean headline index (seed table + text "
+                         "units + full suffix array, 84 GB: count / locate only); tables = pair lines + 32-byte jump entries "
+                         "+ depth-16 top table (144 GB: the headline of rounds 1..3a).  Both are ladder rungs now")
     ap.add_argument("--jump-bytes", type=int, default=None, help="gdx_build_options_t.jump_entry_bytes")
     ap.add_argument("--top-depth", type=int, default=None, help="gdx_build_options_t.top_table_depth")
     ap.add_argument("--no-pair-lines", action="store_true", help="gdx_build_options_t.pair_lines = 0")
@@ -114,22 +117,20 @@ def parse_args():
                     help="N > 1, the sharded batch: rank 0's shard as a fraction of every other rank's (rank 0 also splits the "
                          "shards it receives).  Default: dist.root_weight_for from a probe of the links; 1 = equal shards")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the cfg 5, ladder and genome-like secondaries")
-    ap.add_argument("--input", default="auto", choices=["auto", "ascii", "uniform", "packed", "packed+uniform"],
-                    help="how the batch lies in HBM when the timed region starts (gdx_query_layout_t): ascii = IO symbols + "
-                         "u64 offsets (the reference's byte slices); uniform = the same bytes declared uniform (every read "
-                         "len symbols, no offsets read); packed = 2-bit codes + offsets; packed+uniform = 2-bit codes, no "
-                         "offsets.  uniform forms need len_min == len_max.  auto (default) = packed+uniform when every read "
-                         "has the same length, else packed; the same step on the ascii form is measured beside it "
-                         "(`ascii_input`)")
+    ap.add_argument("--input", default="ascii", choices=["ascii", "uniform", "packed", "packed+uniform"],
+                    help="how the batch lies in HBM when the timed region starts (gdx_query_layout_t): ascii (default) = IO "
+                         "symbols + u64 offsets -- the reference's own input, byte slices (lib.rs:155,179), so that the alphabet "
+                         "translation (alphabet.rs:195-204, SURVEY 8 row a14) happens INSIDE the timed region; uniform = the same "
+                         "bytes declared uniform (every read len symbols, no offsets read); packed = 2-bit codes + offsets; "
+                         "packed+uniform = 2-bit codes, no offsets (a batch translated beforehand).  uniform forms need "
+                         "len_min == len_max.  With ascii the same step on the pre-translated form is measured beside it "
+                         "(`packed_input`), with any other form the ascii step (`ascii_input`)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-steps", type=int, default=2, help=argparse.SUPPRESS)
     ap.add_argument("--side-file", default=os.environ.get("GDX_BENCH_SIDE_FILE", os.path.join("gpurun_out", "bench_secondary.json")),
                     help="where everything beside the contract line goes (secondaries, ladder, end-to-end, bandwidths, notes): "
                          "the one stdout line stays below 4 KB")
     args = ap.parse_args()
-    if args.input == "auto":
-        w = WORKLOADS[args.workload]
-        args.input = "packed+uniform" if w["len_min"] == w["len_max"] else "packed"
     explicit = (args.jump_bytes is not None or args.top_depth is not None or args.no_pair_lines or args.full_sa or args.text_units)
     if explicit:  # hand-picked structures (ladder rungs of the PMC children, experiments)
         args.index = "tables"
@@ -388,9 +389,14 @@ def input_form(queries, index, args, wl):
 def build_options_of(args, **override):
     from genedex_amd.index import build_options
 
-    if getattr(args, "index", "tables") == "seed" and not override:
+    kind = getattr(args, "index", "tables")
+    if kind == "default" and not override:
+        return build_options()  # nothing asked for: the library's default shape (main() requires aux_structures.default_shape)
+    if kind == "seed" and not override:
         return build_options(**SEED_INDEX)
-    kw = dict(jump_entry_bytes=args.jump_bytes, top_table_depth=args.top_depth,
+    # (tables: the structures of rounds 1-3 are asked for by name -- with every option at its default the library builds the
+    # default shape)
+    kw = dict(jump_entry_bytes=args.jump_bytes if (args.jump_bytes is not None or override) else 32, top_table_depth=args.top_depth,
               pair_lines=False if args.no_pair_lines else None,
               full_suffix_array=True if getattr(args, "full_sa", False) else None,
               text_units=True if getattr(args, "text_units", False) else None,
@@ -710,7 +716,7 @@ def main():
             log(f"[bench] live PMC unavailable: {pmc_note}")
         elif args.secondary_depth > 0 and not args.no_extras and not args.no_pair_lines:
             pmc_ref, _ = run_live_pmc(args, reference_layout=True)
-            pmc_text, _ = run_live_pmc(args, rung="tables" if args.index == "seed" else "top16_sa_text")
+            pmc_text, _ = run_live_pmc(args, rung="tables" if args.index != "tables" else "top16_sa_text")
             # the reference's arrays WITH its lookup tables (depth 10: BASELINE.md cfg 3's secondary; 13: the deepest that
             # SURVEY 8 sizes): DRAM requests of a fifth of the batch -- one pass each, the counters scale with the reads
             if not args.no_extras:
@@ -772,6 +778,9 @@ def main():
 
     eng = DeviceEngine(index)
     aux = eng.aux_info()
+    if args.index == "default" and wl["total"] >= 1 << 20 and not aux["default_shape"]:
+        # the headline runs on what a caller of gdx_index_build gets: nothing was asked for, and the library must have chosen
+        raise SystemExit(f"[bench] the library did not build its default shape (no room in HBM?): {aux}")
     n_slots = 2 if (world > 1 or (do_locate and args.overlap)) else 1
     run_queries = input_form(queries, index, args, wl)
     runner = StepRunner(torch, eng, run_queries, nq, do_locate, args.path, hint=not args.no_hint, n_slots=n_slots)
@@ -799,24 +808,35 @@ def main():
     locate_ms = runner.mean_ms(runner.ev_locate)
     hits = runner.hits[0]
 
-    # ---- the same step on the reference's own input form (IO symbols + u64 offsets), beside the headline --------------
-    ascii_input = None
-    if args.input != "ascii" and world == 1:
-        r2 = StepRunner(torch, eng, queries, nq, do_locate, args.path, hint=not args.no_hint)
+    # ---- the same step on the other form of the batch, beside the headline: `value` is timed on the reference's own input (IO
+    # symbols + u64 offsets: the translation of SURVEY row a14 inside the timed region) and the batch translated beforehand
+    # (2-bit codes, uniform length when every read has one) is `packed_input`; with --input <another form> the ascii step is
+    # `ascii_input` --------------
+    ascii_input = packed_input = None
+    if world == 1:
+        other_form = ("packed+uniform" if wl["len_min"] == wl["len_max"] else "packed") if args.input == "ascii" else "ascii"
+        other_q = queries if other_form == "ascii" else input_form(queries, index, argparse.Namespace(input=other_form, workload=args.workload), wl)
+        r2 = StepRunner(torch, eng, other_q, nq, do_locate, args.path, hint=not args.no_hint)
         if r2.size() != total_hits:
-            raise SystemExit("PARITY FAILURE: the ascii form of the batch gives another number of hits")
+            raise SystemExit(f"PARITY FAILURE: the {other_form} form of the batch gives another number of hits")
         e2, _ = timed_steps(torch, gdist, r2, args.steps, args.warmup, dev)
         r2.check_totals()
         r2.widen_offsets()
         same = bool(torch.equal(r2.outs[0]["hit_offsets"], out["hit_offsets"])) and \
             (not do_locate or bool(torch.equal(r2.hits[0][:total_hits], runner.hits[0][:total_hits])))
         if not same:
-            raise SystemExit("PARITY FAILURE: the ascii form of the batch gives other offsets or hits")
-        ascii_input = {"value": nq / (e2 / args.steps), "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
-                       "search_ms": r2.mean_ms(r2.ev_search), "locate_ms": r2.mean_ms(r2.ev_locate),
-                       "query_bytes": queries.total_bytes + 8 * (nq + 1), "offsets_and_hits_identical_to_headline": same}
-        log(f"[bench] the same step on ascii input: {ascii_input}")
-        del r2
+            raise SystemExit(f"PARITY FAILURE: the {other_form} form of the batch gives other offsets or hits")
+        other = {"value": nq / (e2 / args.steps), "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+                 "search_ms": r2.mean_ms(r2.ev_search), "locate_ms": r2.mean_ms(r2.ev_locate), "input": other_form,
+                 "query_bytes": other_q.total_bytes + (0 if other_q.uniform_len else 8 * (nq + 1)),
+                 "offsets_and_hits_identical_to_headline": same}
+        if other_form == "ascii":
+            ascii_input = other
+        else:
+            packed_input = other
+            packed_input["note"] = "the batch translated to 2-bit codes BEFORE the timed region (row a14 outside it): not `value`"
+        log(f"[bench] the same step on {other_form} input: {other}")
+        del r2, other_q
         torch.cuda.empty_cache()
 
     # ---- the step on what a rank of 2 / 4 / 8 GPUs gets of this batch (N = 1; BASELINE configs[3] shards ONE batch) ----------
@@ -889,6 +909,12 @@ def main():
     # reference's own work is `reference_layout.frac_algorithmic` below (the same kernel family on the reference's arrays)
     roofline["achieved_algorithmic"] = search_bytes / (search_ms / 1e3) / 1e9
     roofline["frac_algorithmic"] = roofline["algorithmic_ratio"]
+    # the same number under the name the round-5 review asked for: it is NOT a fraction of anything the kernel moves
+    roofline["frac_section8d_headline"] = roofline["algorithmic_ratio"]
+    roofline["frac_section8d_headline_label"] = (
+        "algorithm substituted: SURVEY 8(d) bytes of the reference's LF steps / time / peak -- above 1 because one seed-table "
+        "bucket stands for a read's ~47 LF steps and the full suffix array for the locate walk; `frac` is measured traffic, "
+        "reference_layout.frac_algorithmic the 8(d) fraction of the reference's own work")
     # bytes the kernels actually consume per launch: query bytes + one 8-byte offset + one 8-byte top entry + 32 bytes per
     # jump entry (ceil((len - D) / 40) per read: 32 steps + an 8-symbol lookahead each) + the 16-byte record written
     mean_len = queries.total_bytes / max(nq, 1)
@@ -982,13 +1008,19 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": (f"{wl['short']}, resident in HBM as {INPUT_FORMS[args.input]}; index "
-                                f"{index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + seed table "
-                                f"(k={aux['seed']['k']}) + text units + full SA; {wl['label']}") if aux["seed"]["k"] else
+                                f"{index.info.device_bytes / 1e9:.0f} GB/replica = "
+                                + ("the library's DEFAULT shape (every build option at its default): " if aux["default_shape"] else "")
+                                + f"reference arrays + seed table (k={aux['seed']['k']}) + text units + full SA"
+                                + (" + inverse SA" if aux["inverse_suffix_array"] else "")
+                                + (" + pair lines" if aux["pair_lines"] else "")
+                                + (f" + depth-{aux['top_table_depth']} top table" if aux["top_table_depth"] else "")
+                                + f"; {wl['label']}") if aux["seed"]["k"] else
                                (f"{wl['short']}; index {index.info.device_bytes / 1e9:.0f} GB/replica = reference arrays + pair "
                                 f"lines + {aux['jump_entry_bytes']}-byte jump entries (with SA) + depth-{aux['top_table_depth']} "
                                 f"top table; {wl['label']}"),
                    "index_gb_per_replica": index.info.device_bytes / 1e9,
-                   "name": args.workload, "op": args.op, "path": args.path, "input": args.input, "queries_per_gpu": nq,
+                   "name": args.workload, "op": args.op, "path": args.path, "input": args.input, "index": args.index,
+                   "index_is_library_default": bool(aux["default_shape"]), "queries_per_gpu": nq,
                    "hit_offsets": "u32" if narrow_offsets else "u64",
                    "query_bytes_per_gpu": run_queries.total_bytes + (0 if run_queries.uniform_len else 8 * (nq + 1)),
                    "text_len": wl["total"], "n_texts": wl["n_texts"], "lookup_depth": args.lookup_depth,
@@ -1002,6 +1034,7 @@ def main():
                                    if gather is not None else None)},
         "roofline": roofline,
         "ascii_input": ascii_input,
+        "packed_input": packed_input,
         "shard_step": shard_step,
         "locate_roofline": locate_roofline,
         "kernel_ms": {"search": search_ms, "locate": locate_ms, "totals": runner.mean_ms(runner.ev_scan)},
@@ -1151,11 +1184,13 @@ def compact_line(result, side_file=None):
     Guaranteed below LINE_LIMIT bytes (strings are cut, optional parts dropped in a fixed order if it ever grows)."""
     r = result.get("roofline") or {}
     roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "avg_launch_ms_rocprof",
-                     "frac_rocprof", "frac_algorithmic", "algorithmic_bytes_per_launch", "wasted_traffic_ratio",
+                     "frac_rocprof", "frac_algorithmic", "frac_section8d_headline", "algorithmic_bytes_per_launch", "wasted_traffic_ratio",
                      "useful_bytes_per_query", "dram_read_requests_per_query", "l2_hit_rate", "frac_of_measured_stream_read"))
     for k in ("traffic", "achieved", "frac"):  # the contract's keys are there even when nothing was measured (null)
         roof.setdefault(k, r.get(k))
-    roof["traffic_source"] = (r.get("traffic_source") or "")[:64]
+    roof["traffic_source"] = (r.get("traffic_source") or "")[:44]
+    if "frac_section8d_headline" in roof:  # (> 1: not a fraction of anything the kernel moves -- named so that nobody takes it for one)
+        roof["frac_section8d_headline_label"] = "algorithm substituted: 8d bytes/time/peak, not traffic"
     parts = str(roof.get("kernel") or "").split(" + ")
     if len(parts) > 1:  # the dominant kernel by name, the list kernels of the same step in the side file
         roof["kernel"] = f"{parts[0]} (+ {len(parts) - 1} list kernels of the same step: side file)"
@@ -1175,15 +1210,15 @@ def compact_line(result, side_file=None):
     if cpu and isinstance(cpu.get("sample"), str):
         cpu["sample"] = cpu["sample"][:200]
     cfg = result.get("config") or {}
-    config = _pick(cfg, ("workload", "index_gb_per_replica", "name", "op", "path", "input", "hit_offsets", "queries_per_gpu", "queries_total", "text_len",
+    config = _pick(cfg, ("workload", "index_gb_per_replica", "index_is_library_default", "name", "op", "path", "input", "hit_offsets", "queries_per_gpu", "queries_total", "text_len",
                          "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism",
                          "gathered_bytes_per_rank_and_step", "gather_wire", "compact_exceptions"))
     if isinstance(config.get("workload"), str):
-        config["workload"] = config["workload"][:300]
+        config["workload"] = config["workload"][:260]
     line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                        "scaling", "vs_baseline", "dtype", "data")}
-    # (`value` is timed on the batch in this form; the same step on the reference's own form -- IO symbols + u64 offsets -- is
-    # `ascii_input`, timed in the same process)
+    # (`value` is timed on the batch in this form -- by default the reference's own: IO symbols + u64 offsets, translated inside
+    # the timed region; the same step on a batch translated beforehand is `packed_input`, timed in the same process)
     line["input_form"] = INPUT_FORMS.get(cfg.get("input"), cfg.get("input"))
     line["config"] = config
     line["roofline"] = roof
@@ -1191,6 +1226,8 @@ def compact_line(result, side_file=None):
     line["kernel_ms"] = result.get("kernel_ms")
     if result.get("ascii_input"):
         line["ascii_input"] = _pick(result["ascii_input"], ("value", "ms_per_step", "search_ms", "offsets_and_hits_identical_to_headline"))
+    if result.get("packed_input"):
+        line["packed_input"] = _pick(result["packed_input"], ("value", "ms_per_step", "search_ms", "input", "offsets_and_hits_identical_to_headline"))
     if result.get("shard_step"):
         line["shard_step_ms"] = {k: v["ms_per_step"] for k, v in result["shard_step"].items()}
     if result.get("results_sharded"):
@@ -1218,6 +1255,8 @@ def compact_line(result, side_file=None):
                                                                                   "locate32_pinned_input_qps"))
     cur = {}
     for r in result.get("secondary") or []:  # BASELINE configs[4]: which index the cursor-API numbers are on
+        if str(r.get("name", "")).startswith("exact_intervals_len50") and "HEADLINE" in r["name"]:
+            cur["exact_intervals_100M_len50_headline_index_ms"] = r["ms"]
         if str(r.get("name", "")).startswith("mixed_lengths_20_150") and "cursor_api_ms" in r:
             key = "headline_index" if "HEADLINE" in r["name"] else "index_with_every_structure"
             cur[key] = {"index_gb": round(r.get("index_bytes", 0) / 1e9), "cursor_api_ms": r["cursor_api_ms"], "fused_ms": r["fused_ms"]}
@@ -1226,7 +1265,11 @@ def compact_line(result, side_file=None):
     line["index_build_seconds"] = result.get("index_build_seconds")
     line["side_file"] = side_file
     line = _num(line)
-    for drop in ("cursor_api_50M_len20_150", "end_to_end", "shard_step_ms", "locate_roofline", "parity", "kernel_ms", "weak_scaling", "strong_scaling"):
+    # (what goes first when the line grows: the side file has everything; the cursor / exact-interval numbers of the headline index
+    # and the other input form stay -- they are what makes the headline one index for every BASELINE configuration)
+    if len(json.dumps(line)) >= LINE_LIMIT and isinstance(line.get("end_to_end"), dict):
+        line["end_to_end"].pop("packed_uniform", None)
+    for drop in ("locate_roofline", "shard_step_ms", "end_to_end", "parity", "kernel_ms", "cursor_api_50M_len20_150", "weak_scaling", "strong_scaling"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -1519,9 +1562,16 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
 
     eng, index = owned["eng"], owned["index"]
     res = res if res is not None else []
-    if not args.no_extras and args.index == "seed":
-        # BASELINE configs[4] through the cursor API on the headline index itself, beside the 214 GB index's numbers below
-        res.append(mixed_length_secondary(torch, eng, io_text, lengths, light=True))
+    seed_family = args.index in ("default", "seed")
+    if not args.no_extras and seed_family:
+        # BASELINE configs[4] -- fused and through the cursor API -- and exact intervals of the headline's reads ON THE HEADLINE
+        # INDEX itself (the default shape serves them through seed entry / text / ISA; the lean seed index of rounds 3b-5 has
+        # nothing for them but the rank lines: one pass there says so)
+        if args.index == "default":
+            res.append(exact_intervals_secondary(torch, eng, queries, base_counts, nq, "on the HEADLINE index"))
+            res[-1]["aux_structures"] = eng.aux_info()
+            res[-1]["index_bytes"] = int(index.info.device_bytes)
+        res.append(mixed_length_secondary(torch, eng, io_text, lengths, light=args.index != "default", headline=True))
         res[-1]["aux_structures"] = eng.aux_info()
         res[-1]["index_bytes"] = int(index.info.device_bytes)
     text = dict(jump_entry_bytes=0, pair_lines=False, text_units=True)  # the rest of a read against the text at SA[row]
@@ -1530,16 +1580,18 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
               ("top14_sa_text", dict(top_table_depth=14, full_suffix_array=True, **text)),
               ("top14_text", dict(top_table_depth=14, **text)),
               ("top12_text", dict(top_table_depth=12, **text)),
-              ("top14_jump32", dict(top_table_depth=14)),
+              ("top14_jump32", dict(top_table_depth=14, jump_entry_bytes=32)),
               ("top16_jump16", dict(jump_entry_bytes=16)),
               ("top14_jump16", dict(top_table_depth=14, jump_entry_bytes=16)),
               ("top12_jump8", dict(top_table_depth=12, jump_entry_bytes=8)),
               ("pair_lines_only", dict(top_table_depth=0, jump_entry_bytes=0)),
               ("reference_arrays_only", dict(top_table_depth=0, jump_entry_bytes=0, pair_lines=False))]
-    if args.index == "seed":
-        # the headline is the seed rung; the library's default structures (the headline of earlier rounds) and the seed
-        # table without the full suffix array come first
-        ladder = [("tables_top16_jump32_pairs", {}),
+    if seed_family:
+        # the headline is the default shape; the lean seed index (the headline of rounds 3b-5: what the inverse suffix array,
+        # pair lines and top table of the default shape cost a count + locate step -- nothing -- and what they buy the other
+        # calls), the tables of rounds 1-3 and the seed table without the full suffix array come first
+        ladder = ([("seed_lean_no_isa_no_pairs", dict(SEED_INDEX))] if args.index == "default" else []) + \
+                 [("tables_top16_jump32_pairs", dict(jump_entry_bytes=32)),
                   ("seed_text_no_sa", {k: v for k, v in SEED_INDEX.items() if k != "full_suffix_array"})] + ladder
     if args.no_extras:
         ladder = [r for r in ladder if r[0] in ("tables_top16_jump32_pairs", "top16_sa_text", "top14_text", "pair_lines_only",
@@ -1555,8 +1607,8 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         r = {"name": name, "aux_structures": eng.aux_info(), "value": nq / (ms / 1e3), "unit": "queries/s",
              "ms_per_step": ms, "search_ms": s_ms, "locate_ms": l_ms, "counts_identical_to_headline": same,
              "aux_rebuild_seconds": t_aux, "index_bytes": int(index.info.device_bytes)}
-        if name == ("tables_top16_jump32_pairs" if args.index == "seed" else "top16_sa_text"):
-            t_txt = traffic_of(pmc_text, "search_fast_kernel|search_pair_kernel" if args.index == "seed"
+        if name == ("tables_top16_jump32_pairs" if seed_family else "top16_sa_text"):
+            t_txt = traffic_of(pmc_text, "search_fast_kernel|search_pair_kernel" if seed_family
                                else "search_verify_kernel|search_kernel")
             if t_txt:  # measured HBM traffic of this rung's search (PMC child passes of this run on the same configuration)
                 r["roofline"] = {"bound": "hbm", "kernel": t_txt["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBPS,
@@ -1587,40 +1639,23 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         log(f"[bench] secondary {name}: {r}")
         res.append(r)
         del counts
-    if args.index == "seed":
-        # every structure at once (214 GB): the library's defaults for the exact-interval and cursor calls below, plus seed
+    if seed_family:
+        # every structure at once (214 GB): the tables of rounds 1-3 for the exact-interval and cursor calls below, plus seed
         # table and inverse suffix array (exact intervals of reads that occur once: seed entry + one ISA fetch)
         index.rebuild_aux(**FULL_INDEX)
     else:
-        index.rebuild_aux()  # the library's default structures
+        index.rebuild_aux(jump_entry_bytes=32)  # the tables of rounds 1-3
     if not args.no_extras:
-        if args.index == "seed" and e2e:  # the packed-query calls run on the pair-line kernels
+        if args.index == "seed" and e2e:  # the packed-query calls run on the pair-line kernels (the lean index has none)
             import numpy as np
             ms_t, s_ms_t, _, _ = time_config(torch, eng, queries, nq, do_locate, args)
             res.append({"name": "packed_queries_end_to_end (index with every structure)", "aux_structures": eng.aux_info(),
                         "index_bytes": int(index.info.device_bytes),
                         **packed_end_to_end(np, torch, index, queries, nq, base_counts, e2e["pcie_h2d_GBps"], e2e["pcie_d2h_GBps"],
                                             s_ms_t), "device_search_ms_on_ascii_input": s_ms_t})
-        # exact intervals of the headline's reads (cursors_for_many_queries): bit-identical to the reference's, frozen empty
-        # ones included (tests); here their widths must be the headline's counts
-        xo = eng.alloc_outputs(nq)
-        eng.search(queries, xo)
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ev[0].record()
-        for _ in range(3):
-            eng.search(queries, xo)
-        ev[1].record()
-        torch.cuda.synchronize()
-        x_ms = ev[0].elapsed_time(ev[1]) / 3
-        x_same = bool(torch.equal(torch.sub(xo["end"], xo["start"]), base_counts))
-        if not x_same:
-            raise SystemExit("PARITY FAILURE: exact interval widths differ from the headline's counts")
-        res.append({"name": "exact_intervals_len50 (cursors_for_many_queries on the headline's reads)", "queries": nq,
-                    "ms": x_ms, "value": nq / (x_ms / 1e3), "unit": "queries/s", "widths_identical_to_headline_counts": x_same,
-                    "aux_structures": eng.aux_info(), "index_bytes": int(index.info.device_bytes)})
-        log(f"[bench] secondary {res[-1]}")
-        del xo
+        res.append(exact_intervals_secondary(torch, eng, queries, base_counts, nq, "on the index with every structure"))
+        res[-1]["aux_structures"] = eng.aux_info()
+        res[-1]["index_bytes"] = int(index.info.device_bytes)
         res.append(mixed_length_secondary(torch, eng, io_text, lengths))
         res[-1]["aux_structures"] = eng.aux_info()
         res[-1]["index_bytes"] = int(index.info.device_bytes)
@@ -1696,7 +1731,7 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
         # + the full suffix array: the hits of a read from a repeat are consecutive rows -- 32 of their SA values per 128-byte
         # line there, 4 per line inside the 32-byte jump entries (scan + locate of 573 M hits 5.35 -> 4.0 ms)
         both = ({"index": "tables", "seed_symbols": 1, "full_sa": True, "aux_budget_bytes": 250_000_000_000}
-                if args.index == "seed" else {})
+                if seed_family else {})
         res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), **both})))
     return res
 
@@ -1803,7 +1838,29 @@ def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):
     return res
 
 
-def mixed_length_secondary(torch, eng, io_text, lengths, light=False):
+def exact_intervals_secondary(torch, eng, queries, base_counts, nq, where):
+    """exact intervals of the headline's reads (cursors_for_many_queries): bit-identical to the reference's, frozen empty ones
+    included (tests); here their widths must be the headline's counts"""
+    xo = eng.alloc_outputs(nq)
+    eng.search(queries, xo)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(3):
+        eng.search(queries, xo)
+    ev[1].record()
+    torch.cuda.synchronize()
+    x_ms = ev[0].elapsed_time(ev[1]) / 3
+    x_same = bool(torch.equal(torch.sub(xo["end"], xo["start"]), base_counts))
+    if not x_same:
+        raise SystemExit(f"PARITY FAILURE: exact interval widths {where} differ from the headline's counts")
+    r = {"name": f"exact_intervals_len50 (cursors_for_many_queries on the headline's reads) {where}", "queries": nq,
+         "ms": x_ms, "value": nq / (x_ms / 1e3), "unit": "queries/s", "widths_identical_to_headline_counts": x_same}
+    log(f"[bench] secondary {r}")
+    return r
+
+
+def mixed_length_secondary(torch, eng, io_text, lengths, light=False, headline=False):
     """BASELINE.json configs[4]: 50 M reads of length 20..150, 70 % sampled / 30 % random (early termination), through
     (a) the fused cursors_for_many_queries call and (b) the batched cursor API: cursor_empty, then
     gdx_cursor_extend_front_strings_dev with 32 symbols per call and device-side active lists.  Identical intervals."""
@@ -1901,7 +1958,8 @@ def mixed_length_secondary(torch, eng, io_text, lengths, light=False):
         check(f"chunks of {c2}")
     chunk, rounds = 32, -(-w["len_max"] // 32)
     same = True
-    res = {"name": "mixed_lengths_20_150 (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
+    res = {"name": "mixed_lengths_20_150 on the HEADLINE index (BASELINE configs[4])" if headline else
+           "mixed_lengths_20_150 (BASELINE configs[4])", "queries": nq, "op": "count (intervals)",
            "fused_value": nq / (fused_ms / 1e3), "fused_ms": fused_ms,
            "cursor_api_value": nq / (cursor_ms / 1e3), "cursor_api_ms": cursor_ms, "unit": "queries/s",
            "cursor_api": f"cursor_empty + {rounds} x gdx_cursor_extend_front_chunk_dev ({chunk} symbols per call, "
