@@ -306,6 +306,18 @@ struct Chunk {
     uint64_t q0 = 0, nq = 0, bytes = 0, total = 0, hit_base = 0;
 };
 
+// A chunk of the wide locate calls whose hits do not fit the fused step's 32-bit offsets: the call is run again with the
+// device-written results of rounds 1-4 (u64 offsets throughout), which have no such limit (host_pipeline, locate_many*)
+struct RetryWithWideOffsets {};
+thread_local bool t_force_plain_locate = false;
+// (tests: GDX_TEST_CHUNK_HIT_LIMIT lowers the number of hits a chunk of the fused step may hold; read per call)
+uint64_t chunk_hit_limit()
+{
+    const char *e = getenv("GDX_TEST_CHUNK_HIT_LIMIT");
+    const uint64_t v = e ? std::strtoull(e, nullptr, 10) : 0;
+    return v != 0 ? v : 0xffffffffull;
+}
+
 }  // namespace
 
 // The pipeline behind all three calls.  Intervals: out_a = start, out_b = end.  Counts: out_a = counts.  Locate:
@@ -332,7 +344,11 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         if (e && std::strcmp(e, "wire") == 0) return 1;
         return host_threads() >= 4 ? 1 : 0;
     }();
-    const bool wire = (kind == Kind::kLocate32 || kind == Kind::kLocate) && narrow_mode == 1 && n_texts_ <= 256;
+    // A sizing call of gdx_locate_many (no hit buffer): search, totals and offsets only -- nothing is located, packed or copied out
+    // that the call would throw away (round-5 advisor); it takes the plain path, whose locate launch is then skipped
+    const bool sizing_only = kind == Kind::kLocate && grow_hits == nullptr && (hits == nullptr || hits_capacity == 0);
+    const bool wire = (kind == Kind::kLocate32 || kind == Kind::kLocate) && narrow_mode == 1 && n_texts_ <= 256 && !sizing_only &&
+                      !(kind == Kind::kLocate && t_force_plain_locate);
     // stepped: every chunk is ONE fused step (launch_locate_step: search, totals, u32 offsets, 8-byte hits, no host round trip)
     const bool stepped = kind == Kind::kLocate32 || (kind == Kind::kLocate && wire);
     const bool plain_locate = kind == Kind::kLocate && !stepped;  // search | total to the host | locate, u64 offsets (rounds 1-4)
@@ -341,6 +357,15 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // and starved the runtime's own threads on a 16-CPU container)
     WorkerPool pool(host_threads());
     check_queries(qbuf, qoff, nq, pool, uniform_len);
+    // ASCII batches of the count / locate calls are packed ON THE HOST, chunk by chunk in the feeder's worker pool (pack_host.hpp:
+    // 32 symbols per step when the alphabet's table has a nucleotide alphabet's shape), and cross the link as 2-bit codes -- 12.5
+    // bytes per len-50 read (+ 8 of offsets) instead of 58: the link, not the kernels, bounds these calls.  A chunk that holds a
+    // symbol 2 bits cannot name (N, an invalid byte) goes as it is, ASCII, and gives the reference's result for it.  Exact
+    // intervals stay ASCII (their kernels read bytes).  GDX_HOST_PACK=0: never.
+    const bool env_host_pack = [] { const char *e = getenv("GDX_HOST_PACK"); return !(e && atoi(e) == 0); }();  // (read per call: tests)
+    const PackPlan pack_plan = make_pack_plan(cfg_.io_to_dense);
+    const bool host_pack = !packed && env_host_pack && kind != Kind::kIntervals && view_.layout == 0 && view_.n_searchable >= 4 &&
+                           pack_plan.fast && pack_have_avx2();
     const bool uniform = uniform_len != 0;
     auto off_of = [&](uint64_t i) { return uniform ? i * uniform_len : qoff[i]; };
     if (out_total) *out_total = 0;
@@ -355,7 +380,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     // chunk boundaries: at most kChunkBytes of query bytes and kChunkQueries queries each
     // (a chunk's limit counts the bytes that cross the link: four symbols per byte of a packed batch; the narrow locate runs a
     // whole fused step per chunk, a dozen launches, and takes up to four times the queries)
-    const uint64_t kChunkBytes = g_chunk_bytes.load() * (packed ? 4 : 1), kChunkQueries = g_chunk_queries.load() * (stepped ? 4 : 1);
+    const uint64_t kChunkBytes = g_chunk_bytes.load() * ((packed || host_pack) ? 4 : 1), kChunkQueries = g_chunk_queries.load() * (stepped ? 4 : 1);
     std::vector<Chunk> chunks;
     // (uniform: every chunk but the last holds a multiple of 8 queries, so that a chunk starts on a 16-bit unit of a packed
     // buffer and on a byte of an ASCII one, and is a uniform batch of its own)
@@ -488,18 +513,33 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     auto stage_in_with = [&](size_t k, WorkerPool &pool) {
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
+        bool as_packed = packed, packed_here = false;  // packed_here: the chunk's codes were made by this thread's workers, in h_in
+        if (host_pack && c.bytes != 0) {
+            const uint64_t first = off_of(c.q0), last = off_of(c.q0 + c.nq);
+            const uint64_t pb0 = (first & ~7ull) / 4, nb = div_ceil(last, 4) - pb0;
+            std::atomic<bool> other{false};  // a symbol that is not one of the dense codes 1..4
+            uint8_t *out = h_in[s];
+            pool.run([&](unsigned w, unsigned nw) {
+                const uint64_t per = (nb / nw + 64) / 64 * 64;
+                const uint64_t lo = std::min(nb, per * w), hi = std::min(nb, lo + per);
+                // (pack_range indexes the output by the byte's number in the whole buffer: `out - pb0` is never dereferenced below pb0)
+                pack_range(pack_plan, cfg_.io_to_dense, qbuf, first, last, pb0 + lo, pb0 + hi, out - pb0,
+                           [&](uint64_t) { other.store(true, std::memory_order_relaxed); });
+            });
+            as_packed = packed_here = !other.load();
+        }
         // packed: the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
-        const uint64_t base = packed ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
-        const uint64_t src_byte = packed ? base / 4 : base;
-        const uint64_t n_bytes = packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
-        if (!pinned_input)
+        const uint64_t base = as_packed ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
+        const uint64_t src_byte = as_packed ? base / 4 : base;
+        const uint64_t n_bytes = as_packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
+        if (!pinned_input && !packed_here)
             pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { stream_copy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
         if (!uniform)
             pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
             });
         const uint64_t padded = div_ceil(n_bytes + 2, 8) * 8;
-        if (pinned_input) {  // the caller's buffer is pinned: the device reads it as it is, no staging copy
+        if (pinned_input && !packed_here) {  // the caller's buffer is pinned: the device reads it as it is, no staging copy
             if (n_bytes) GDX_HIP(hipMemcpyAsync(d_qbuf[s], qbuf + src_byte, n_bytes, hipMemcpyHostToDevice, st.in));
             GDX_HIP(hipMemsetAsync(d_qbuf[s] + n_bytes, 0, padded - n_bytes, st.in));  // windows may read past the last query
         } else {
@@ -518,7 +558,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             call.d_qend = d_qoff[s] + 1;
         }
         call.nq = c.nq;
-        call.packed = packed;
+        call.packed = as_packed;
         if (stepped) {
             LocateStep step;
             step.call = call;
@@ -584,6 +624,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             const uint64_t rest = h_total[s][1];
             if (kind == Kind::kLocate32 && mid_hit_base + c.total >= (1ull << 32))
                 fail(GDX_ERR_CAPACITY, "more than 2^32 - 1 hits: 32-bit hit offsets do not hold them (gdx_locate_many_alloc_layout does)");
+            if (c.total >= chunk_hit_limit() && kind == Kind::kLocate) throw RetryWithWideOffsets{};  // (the wide call has no such limit)
             if (c.total >= 0xffffffffull)  // (the step counts a chunk's hit slots in 32 bits)
                 fail(GDX_ERR_CAPACITY, "%llu queries of the batch have %llu hits, more than a chunk's 32-bit offsets hold: cap them "
                      "(gdx_query_options_t.max_hits_per_query), or take the device-written results (environment GDX_HOST_RESULTS=dma)",
@@ -649,7 +690,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         if (plain_locate) {
             GDX_HIP(hipEventSynchronize(st.ev_total[s]));
             c.total = *h_total[s];
-            if (c.total) {
+            if (c.total && !sizing_only) {
                 d_hits[s] = device_buf<uint8_t>(dev, s * 16 + 8, c.total * hit_bytes);
                 h_hits[s] = pinned_buf<uint8_t>(dev, s * 16 + 6, c.total * hit_bytes);
                 d_ws[s] = device_buf<uint8_t>(dev, s * 16 + 9, locate_workspace_bytes(c.total));
@@ -671,7 +712,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         if (kind == Kind::kIntervals)
             GDX_HIP(hipMemcpyAsync(h_b[s], d_b[s], c.nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st.out));
         if (!flagged || w_status[s]) GDX_HIP(hipMemcpyAsync(h_status[s], d_status[s], c.nq, hipMemcpyDeviceToHost, st.out));
-        if (plain_locate && c.total)
+        if (plain_locate && c.total && !sizing_only)
             GDX_HIP(hipMemcpyAsync(h_hits[s], d_hits[s], c.total * hit_bytes, hipMemcpyDeviceToHost, st.out));
         GDX_HIP(hipEventRecord(st.ev_out[s], st.out));
     };
@@ -739,7 +780,7 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             }
             const uint64_t need = hit_base + c.total;
             if (grow_hits && need > hits_capacity) hits = (*grow_hits)(need, &hits_capacity);  // at least `need`
-            if (hits && need <= hits_capacity && capacity_ok) {
+            if (hits && need <= hits_capacity && capacity_ok && !sizing_only) {
                 gdx_hit_t *dst = hits + hit_base;
                 if (wide_hits) {
                     const gdx_hit_t *src = static_cast<const gdx_hit_t *>(h_hits[s]);
@@ -954,8 +995,18 @@ int FmIndex::cursors_for_many_queries(const uint8_t *qbuf, const uint64_t *qoff,
 int FmIndex::locate_many(const uint8_t *qbuf, const uint64_t *qoff, uint64_t nq, uint64_t *out_hit_offsets,
                          gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, uint8_t *out_status) const
 {
-    return host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, hits,
-                         hits ? hits_capacity : 0, out_total, nullptr);
+    try {
+        return host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, hits,
+                             hits ? hits_capacity : 0, out_total, nullptr);
+    } catch (const RetryWithWideOffsets &) {  // a chunk with more hits than the fused step's 32-bit offsets hold
+        (void)hipDeviceSynchronize();
+        struct Restore {
+            ~Restore() { t_force_plain_locate = false; }
+        } restore;
+        t_force_plain_locate = true;
+        return host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, hits,
+                             hits ? hits_capacity : 0, out_total, nullptr);
+    }
 }
 
 // One hit array released with gdx_free_hits is kept for the next gdx_locate_many_alloc: a caller that locates batch
@@ -1034,8 +1085,18 @@ int FmIndex::locate_many_alloc(const uint8_t *qbuf, const uint64_t *qoff, uint64
     try {
         // a first guess from the batch size spares most reallocations (one hit per query is the common shape)
         grow(nq + nq / 8, nullptr);
-        rc = host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, buf, cap,
-                           out_total, &grow, packed, uniform_len);
+        try {
+            rc = host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, buf, cap,
+                               out_total, &grow, packed, uniform_len);
+        } catch (const RetryWithWideOffsets &) {  // (as in locate_many)
+            (void)hipDeviceSynchronize();
+            struct Restore {
+                ~Restore() { t_force_plain_locate = false; }
+            } restore;
+            t_force_plain_locate = true;
+            rc = host_pipeline(static_cast<int>(Kind::kLocate), qbuf, qoff, nq, out_hit_offsets, nullptr, out_status, buf, cap,
+                               out_total, &grow, packed, uniform_len);
+        }
     } catch (...) {
         std::free(buf);
         throw;

@@ -223,6 +223,56 @@ def test_host_calls_are_chunk_invariant(chunk_queries, chunk_bytes):
         lib.gdx_debug_set_host_chunking(0, 0)
 
 
+@pytest.mark.parametrize("mode", ["host-pack", "no-host-pack", "hit-limit", "uniform"])
+def test_host_ascii_calls_pack_on_the_host(mode, monkeypatch):
+    """ASCII batches of gdx_count_many / gdx_locate_many[_alloc] cross the link as 2-bit codes made by the pipeline's own workers,
+    chunk by chunk (host_api.hip, pack_host.hpp); a chunk that holds a symbol 2 bits cannot name (N, an invalid byte) goes as
+    ASCII.  Whatever a chunk went as, counts, statuses, offsets and hits are the oracle's -- with chunks small enough that both
+    kinds occur, with packing switched off (GDX_HOST_PACK=0), with the batch declared uniform, and when a chunk's hits exceed
+    what the fused step's 32-bit offsets hold (GDX_TEST_CHUNK_HIT_LIMIT stands in for 2^32 - 1: the wide call then runs again
+    with 64-bit offsets instead of failing -- round-5 advisor)."""
+    from genedex_amd import FmIndexConfig, _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(1234)
+    a = alph.ascii_dna_with_n()
+    texts = [bytes(b"ACGTN"[i] for i in rng.choice(5, int(n), p=[0.2475, 0.2475, 0.2475, 0.2475, 0.01])) for n in (30000, 9000, 17000)]
+    g = FmIndexConfig("u32").suffix_array_sampling_rate(4).construct_index(texts, a)
+    c = OracleIndex.build(texts, a.io_to_dense_table, 6, 4, sa_rate=4, lookup_depth=0, width=32)
+    if mode == "uniform":
+        qs = [texts[0][int(p):int(p) + 40] for p in rng.integers(0, 29000, 6000)]  # (one in three holds an N)
+    else:
+        qs = [texts[int(t)][int(p):int(p) + int(n)] for t, p, n in zip(rng.integers(0, 3, 6000), rng.integers(0, 8000, 6000),
+                                                                         rng.integers(0, 120, 6000))]
+        qs += [b"", b"A", b"ACGTNNACGT", texts[1][100:4000]]
+        qs += [bytes(b"ACGT"[i] for i in rng.integers(0, 4, int(n))) for n in rng.integers(1, 60, 2000)]
+    qbuf, qoff = pack_queries(qs)
+    nq = qoff.size - 1
+    cs, ce = c.cursors_for_many(qbuf, qoff)
+    co, ct, cp = c.locate_intervals(cs, ce)
+    n_with_other = sum(1 for q in qs if any(ch not in b"ACGT" for ch in q))
+    assert 100 < n_with_other < nq - 100  # chunks of both kinds
+    if mode == "no-host-pack":
+        monkeypatch.setenv("GDX_HOST_PACK", "0")
+    if mode == "hit-limit":
+        monkeypatch.setenv("GDX_TEST_CHUNK_HIT_LIMIT", "50")
+    lib.gdx_debug_set_host_chunking(64 if mode != "hit-limit" else 512, 0)
+    try:
+        if mode == "uniform":
+            counts, st = g.count_layout_raw(qbuf, None, nq, uniform_len=40)
+            off, t, p, st2 = g.locate_layout_raw(qbuf, None, nq, uniform_len=40)
+        else:
+            counts, st = g.count_raw(qbuf, qoff)
+            off, t, p, st2 = g.locate_alloc_raw(qbuf, qoff)
+            off3, t3, p3, _ = g.locate_raw(qbuf, qoff)  # sizing call (offsets and total only) + fill
+            assert off3.tolist() == co.tolist() and t3.tolist() == ct.tolist() and p3.tolist() == cp.tolist(), mode
+        assert not st.any() and not st2.any()
+        assert counts.tolist() == (ce - cs).tolist(), mode
+        assert off.tolist() == co.tolist() and t.tolist() == ct.tolist() and p.tolist() == cp.tolist(), mode
+    finally:
+        lib.gdx_debug_set_host_chunking(0, 0)
+
+
 def test_multi_handle_shards_equal_single_gpu(setup):
     """gdx_multi_*: replicas behind one handle (here: three replicas on the one GPU of the box), the batch cut into
     contiguous shards, one host thread and pipeline per replica; the output is bit for bit the one-handle output."""
