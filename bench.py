@@ -2194,11 +2194,12 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
     return res
 
 
-def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=8_000_000):
-    """A FASTQ file of the batch's first reads -> gdx_fastx_next_batch (the library's streaming reader) -> gdx_pack_queries_table
-    (2-bit codes, host threads) -> gdx_locate_many_alloc_layout32, the reader running one batch ahead of the GPU calls in a
-    thread of its own.  What the reference's ROADMAP.md:35-37 worries about: reading the queries can cost more than searching
-    them -- here it does, by three orders of magnitude (one thread parses the file)."""
+def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_reads=8_000_000):
+    """A FASTQ file of the batch's first reads -> gdx_fastx_next_batch_ex (the library's reader: the file memory-mapped, a batch
+    parsed by all host threads the process may use) -> gdx_pack_queries_table (2-bit codes, host threads) ->
+    gdx_locate_many_alloc_layout32, reader and packer one batch ahead of the GPU calls in a thread of their own.  What the
+    reference's ROADMAP.md:35-37 worries about: reading the queries can cost more than searching them -- it still does (the
+    kernels take 25 G reads a second), but by one order of magnitude less than with round 5's single parsing thread."""
     import ctypes as C
     import queue
     import tempfile
@@ -2226,18 +2227,24 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=8_000_000):
         del rec
         alpha = alphabet.ascii_dna_with_n()
         t0 = time.perf_counter()
-        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=1 << 20, buffer_bytes=1 << 27))
+        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
         t_reader = time.perf_counter() - t0
-        q = queue.Queue(maxsize=2)
+        os.environ["GDX_FASTX_THREADS"] = "0"  # (round 5's reader, for the record: one thread, a streaming read of the file)
+        t0 = time.perf_counter()
+        n_read1 = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
+        t_reader1 = time.perf_counter() - t0
+        del os.environ["GDX_FASTX_THREADS"]
+        q = queue.Queue(maxsize=1)
 
         def producer():
-            for b in fastx.read_packed_batches(path, alpha, max_records=1 << 20, buffer_bytes=1 << 27):
-                q.put((b["packed"].copy(), b["nq"], b["uniform_len"], b["exceptions"].size))
+            # (three buffer sets: one being filled, one in the queue, one in the GPU call -- no copy of a batch)
+            for b in fastx.read_packed_batches(path, alpha, max_records=batch_reads, buffer_bytes=batch_reads * ln, n_buffers=3):
+                q.put((b["packed"], b["nq"], b["uniform_len"], b["exceptions"].size))
             q.put(None)
 
         lay = _lib.QueryLayout()
         lib.gdx_query_layout_init(C.byref(lay))
-        status = np.empty(1 << 20, dtype=np.uint8)
+        status = np.empty(batch_reads, dtype=np.uint8)
         t0 = time.perf_counter()
         th = threading.Thread(target=producer)
         th.start()
@@ -2257,14 +2264,15 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=8_000_000):
             lib.gdx_free_hits32(C.byref(r32))
         th.join()
         dt = time.perf_counter() - t0
-        same = reads == n and n_read == n and n_exc == 0 and hits == int(offs[n])
+        same = reads == n and n_read == n and n_read1 == n and n_exc == 0 and hits == int(offs[n])
         if not same:
             raise SystemExit(f"PARITY FAILURE: FASTQ -> hits gave {reads} reads / {hits} hits, the device path {n} / {int(offs[n])}")
         return {"reads": n, "file_bytes": file_bytes, "fastq_to_hits_qps": n / dt, "seconds": dt, "file_GBps": file_bytes / dt / 1e9,
                 "reader_alone_qps": n / t_reader, "reader_alone_file_GBps": file_bytes / t_reader / 1e9,
+                "reader_alone_one_thread_qps": n / t_reader1, "batch_reads": batch_reads,
                 "hits": hits, "hits_identical_to_device_path": same,
-                "what": "FASTQ file -> gdx_fastx_next_batch -> gdx_pack_queries_table -> gdx_locate_many_alloc_layout32, reader and "
-                        "packer one batch ahead in a thread of their own"}
+                "what": "FASTQ file -> gdx_fastx_next_batch_ex (mapped file, blocks parsed in parallel) -> gdx_pack_queries_table -> "
+                        "gdx_locate_many_alloc_layout32, reader and packer one batch ahead in a thread of their own"}
     finally:
         os.remove(path)
 

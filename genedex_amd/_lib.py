@@ -232,6 +232,7 @@ SIGNATURES = {
     "gdx_bench_lf_walk_dev": [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     "gdx_fastx_open": [C.c_char_p, C.POINTER(vp)],
     "gdx_fastx_next_batch": [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)],
+    "gdx_fastx_next_batch_ex": [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gdx_fastx_close": [vp],
     "gdx_locate_step_stats_dev": [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],
     "gdx_locate_many_hits_stats_dev": [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp],

@@ -81,7 +81,8 @@ struct gdx_parts {
 };
 
 struct gdx_fastx {
-    std::unique_ptr<gdx::FastxReader> impl;
+    std::unique_ptr<gdx::FastxMappedReader> mapped;  // a regular file: parsed by several threads
+    std::unique_ptr<gdx::FastxReader> impl;          // anything else, or GDX_FASTX_THREADS=0
 };
 
 namespace {
@@ -1971,8 +1972,35 @@ int gdx_fastx_open(const char *path, gdx_fastx_t **out)
     return guarded([&] {
         if (!path || !out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "path / out is null");
         auto r = std::make_unique<gdx_fastx>();
-        r->impl = std::make_unique<gdx::FastxReader>(path);
+        // GDX_FASTX_THREADS: parser threads of the mapped reader (default: the CPUs the process may use, at most 32); 0 = the
+        // streaming reader
+        unsigned threads = gdx::fastx_default_threads();
+        if (const char *e = getenv("GDX_FASTX_THREADS")) threads = static_cast<unsigned>(std::max(0, atoi(e)));
+        if (threads != 0) r->mapped.reset(gdx::FastxMappedReader::open(path, threads));
+        if (!r->mapped) r->impl = std::make_unique<gdx::FastxReader>(path);
         *out = r.release();
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_fastx_next_batch_ex(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
+                            uint64_t max_records, uint64_t *n_out, uint64_t *out_uniform_len)
+{
+    return guarded([&] {
+        if (!reader || (!reader->impl && !reader->mapped)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "reader handle is null");
+        if (!qoff || !n_out || (!qbuf && qbuf_capacity)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "output pointer is null");
+        if (reader->mapped) {
+            *n_out = reader->mapped->next_batch(qbuf, qbuf_capacity, qoff, max_records, out_uniform_len);
+            return (int)GDX_OK;
+        }
+        const uint64_t n = reader->impl->next_batch(qbuf, qbuf_capacity, qoff, max_records);
+        *n_out = n;
+        if (out_uniform_len) {
+            uint64_t len = n ? qoff[1] - qoff[0] : 0;
+            for (uint64_t i = 1; i < n && len != 0; i++)
+                if (qoff[i + 1] - qoff[i] != len) len = 0;
+            *out_uniform_len = len;
+        }
         return (int)GDX_OK;
     });
 }
@@ -1980,12 +2008,7 @@ int gdx_fastx_open(const char *path, gdx_fastx_t **out)
 int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
                          uint64_t max_records, uint64_t *n_out)
 {
-    return guarded([&] {
-        if (!reader || !reader->impl) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "reader handle is null");
-        if (!qoff || !n_out || (!qbuf && qbuf_capacity)) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "output pointer is null");
-        *n_out = reader->impl->next_batch(qbuf, qbuf_capacity, qoff, max_records);
-        return (int)GDX_OK;
-    });
+    return gdx_fastx_next_batch_ex(reader, qbuf, qbuf_capacity, qoff, max_records, n_out, nullptr);
 }
 
 void gdx_fastx_close(gdx_fastx_t *reader) { delete reader; }

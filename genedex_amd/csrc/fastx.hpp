@@ -7,9 +7,12 @@
 // '+' line, as many quality characters as sequence symbols, also over several lines).  '\r' is dropped, empty
 // lines are skipped, sequence bytes are copied as they are (the alphabet table decides what is valid).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <string>
 #include <vector>
 
@@ -171,5 +174,379 @@ private:
     bool have_pending_ = false;
     uint64_t records_ = 0;
 };
+
+// ---- the same reader over a memory-mapped file, records parsed by several threads (round 6) ----------------------------------
+// One thread parsing a FASTQ file delivers 60 M reads a second; the calls behind it take 3 G (ROADMAP.md:35-37 of the reference
+// names reading the queries as a cost of its own).  Here a batch is made in two parallel passes over a window of the mapped file:
+//   A  the window is cut into one block per thread at guessed record starts -- FASTA: a line that starts with '>'; FASTQ: a line
+//      that starts with '@' from which two whole records parse (a quality line may start with '@' too) -- and every thread parses
+//      its block with the SAME rules as FastxReader::read_record into descriptors {record start, first sequence byte, symbols};
+//      a block must end exactly where the next one starts: a guess that was wrong (or a malformed record) shows there, and the
+//      window is parsed again by one thread from its first byte, which is the authority for errors and their messages;
+//   B  the records that fit the caller's limits are copied into qbuf / qoff, every thread its block's share.
+// Results are FastxReader's, byte for byte (tests/test_fastx.py runs both on the same files).
+class FastxMappedReader {
+public:
+    // null when the file cannot be mapped (a pipe, an empty file): the caller falls back to FastxReader
+    static FastxMappedReader *open(const char *path, unsigned threads);
+    ~FastxMappedReader();
+    FastxMappedReader(const FastxMappedReader &) = delete;
+    FastxMappedReader &operator=(const FastxMappedReader &) = delete;
+    // as FastxReader::next_batch; *uniform_len (optional) = the common length of the batch's records, 0 when they differ
+    uint64_t next_batch(uint8_t *qbuf, uint64_t capacity, uint64_t *qoff, uint64_t max_records, uint64_t *uniform_len);
+
+private:
+    struct Rec {
+        uint64_t start;    // file offset of the record's first byte
+        uint32_t seq;      // its first sequence line starts this many bytes further (a header line of 4 GB is refused)
+        uint32_t one_line; // 1: the sequence is one line without '\r' -- its symbols are the bytes from there on
+        uint64_t symbols;
+    };
+    struct Block {
+        std::vector<Rec> recs;
+        uint64_t end = 0;      // where the parse stopped (the start of the record it did not take, or the end of the file)
+        uint64_t symbols = 0, min_len = ~0ull, max_len = 0;
+        bool ok = true;
+        std::string error;     // (authoritative parse only)
+    };
+    FastxMappedReader() = default;
+    // one line from pos: [*b, *e) without '\n' and one trailing '\r'; returns the position behind it; pos == size_: no line
+    uint64_t line_at(uint64_t pos, uint64_t *b, uint64_t *e) const
+    {
+        const char *nl = static_cast<const char *>(std::memchr(data_ + pos, '\n', size_ - pos));
+        const uint64_t end = nl ? static_cast<uint64_t>(nl - data_) : size_;
+        *b = pos;
+        *e = (end > pos && data_[end - 1] == '\r') ? end - 1 : end;
+        return nl ? end + 1 : size_;
+    }
+    // FastxReader::read_record on the mapped bytes: the record at or behind `pos` (blank lines skipped); false at the end of the
+    // file; a malformed record: `error` set (when given), *bad = true
+    bool record_at(uint64_t pos, Rec *r, uint64_t *next, bool *bad, std::string *error, uint64_t number) const;
+    void parse_block(uint64_t from, uint64_t stop, uint64_t max_records, uint64_t max_symbols, Block *out, bool authoritative,
+                     uint64_t first_number) const;
+    uint64_t guess_record_start(uint64_t from, uint64_t limit) const;
+    void copy_record(const Rec &r, uint8_t *out) const;
+
+    int fd_ = -1;
+    const char *data_ = nullptr;
+    uint64_t size_ = 0, cursor_ = 0, records_ = 0;
+    unsigned threads_ = 1;
+    char kind_ = 0;  // '>' or '@': what the file's first record starts with
+    double bytes_per_record_ = 0.0;
+};
+
+}  // namespace gdx
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <thread>
+
+namespace gdx {
+
+inline FastxMappedReader *FastxMappedReader::open(const char *path, unsigned threads)
+{
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) {
+        ::close(fd);
+        return nullptr;
+    }
+    void *m = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+        ::close(fd);
+        return nullptr;
+    }
+    (void)madvise(m, static_cast<size_t>(st.st_size), MADV_SEQUENTIAL);
+    FastxMappedReader *r = new FastxMappedReader();
+    r->fd_ = fd;
+    r->data_ = static_cast<const char *>(m);
+    r->size_ = static_cast<uint64_t>(st.st_size);
+    r->threads_ = threads < 1 ? 1 : threads;
+    return r;
+}
+
+inline FastxMappedReader::~FastxMappedReader()
+{
+    if (data_) munmap(const_cast<char *>(data_), size_);
+    if (fd_ >= 0) ::close(fd_);
+}
+
+inline bool FastxMappedReader::record_at(uint64_t pos, Rec *r, uint64_t *next, bool *bad, std::string *error, uint64_t number) const
+{
+    uint64_t b, e, nx;
+    *bad = false;
+    // blank lines between records
+    for (;;) {
+        if (pos >= size_) return false;
+        nx = line_at(pos, &b, &e);
+        if (e > b) break;
+        pos = nx;
+    }
+    r->start = pos;
+    r->symbols = 0;
+    r->one_line = 0;
+    uint64_t seq_lines = 0, first_b = 0, first_e = 0;  // sequence lines seen, the first one's bytes
+    auto fail_with = [&](const char *fmt, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
+        *bad = true;
+        if (error) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), fmt, a1, a2, a3);
+            *error = buf;
+        }
+        return false;
+    };
+    const char c = data_[b];
+    auto seq_line = [&](uint64_t lb, uint64_t le) {
+        if (le > lb && seq_lines++ == 0) first_b = lb, first_e = le;
+        r->symbols += le - lb;
+    };
+    auto finish = [&] {
+        // (one line and nothing stripped from it: the copy is a memcpy)
+        r->one_line = (seq_lines == 1 && first_e - first_b == r->symbols && first_b == r->start + r->seq) ? 1u : 0u;
+    };
+    if (c == '>' || c == '@') {
+        if (nx - r->start > 0xffffffffull) return fail_with("record %llu: a header line of more than 4 GB", number, 0, 0);
+        r->seq = static_cast<uint32_t>(nx - r->start);
+    }
+    if (c == '>') {
+        pos = nx;
+        while (pos < size_) {
+            nx = line_at(pos, &b, &e);
+            if (e > b && data_[b] == '>') break;
+            seq_line(b, e);
+            pos = nx;
+        }
+        finish();
+        *next = pos;
+        return true;
+    }
+    if (c == '@') {
+        pos = nx;
+        bool plus = false;
+        while (pos < size_) {
+            nx = line_at(pos, &b, &e);
+            if (e > b && data_[b] == '+') {
+                plus = true;
+                pos = nx;
+                break;
+            }
+            seq_line(b, e);
+            pos = nx;
+        }
+        if (!plus) return fail_with("FASTQ record %llu has no '+' line", number, 0, 0);
+        uint64_t quality = 0;  // quality strings may start with '@' or '+': count characters, not lines
+        while (quality < r->symbols && pos < size_) {
+            nx = line_at(pos, &b, &e);
+            quality += e - b;
+            pos = nx;
+        }
+        if (quality != r->symbols)
+            return fail_with("FASTQ record %llu: %llu quality characters for %llu symbols", number, quality, r->symbols);
+        finish();
+        *next = pos;
+        return true;
+    }
+    *bad = true;
+    if (error) {
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), "record %llu starts with '%c' (expected '>' or '@')", static_cast<unsigned long long>(number), c);
+        *error = buf;
+    }
+    return false;
+}
+
+inline void FastxMappedReader::parse_block(uint64_t from, uint64_t stop, uint64_t max_records, uint64_t max_symbols, Block *out,
+                                           bool authoritative, uint64_t first_number) const
+{
+    uint64_t pos = from;
+    out->recs.clear();
+    if (bytes_per_record_ > 0.0 && stop > from && stop != ~0ull)  // (no growing, copying vector: a batch is millions of records)
+        out->recs.reserve(static_cast<size_t>(std::min<double>(static_cast<double>(max_records),
+                                                               static_cast<double>((stop < size_ ? stop : size_) - from) / bytes_per_record_ * 1.05)) + 16);
+    out->symbols = 0;
+    out->min_len = ~0ull;
+    out->max_len = 0;
+    out->ok = true;
+    while (out->recs.size() < max_records && out->symbols <= max_symbols) {  // (the record that overflows is the last one parsed)
+        // (blank lines in front of a block's border belong to the record behind them: stop at the border itself)
+        if (pos >= stop) break;
+        Rec r;
+        uint64_t next = pos;
+        bool bad = false;
+        if (!record_at(pos, &r, &next, &bad, authoritative ? &out->error : nullptr, first_number + out->recs.size())) {
+            if (bad) out->ok = false;
+            else pos = size_;  // only blank lines were left
+            break;
+        }
+        if (r.start >= stop) {  // (blank lines led across the border)
+            pos = r.start;
+            break;
+        }
+        if (!authoritative && kind_ != data_[r.start]) {  // (a file that mixes FASTA and FASTQ: one thread decides)
+            out->ok = false;
+            break;
+        }
+        out->recs.push_back(r);
+        out->symbols += r.symbols;
+        out->min_len = r.symbols < out->min_len ? r.symbols : out->min_len;
+        out->max_len = r.symbols > out->max_len ? r.symbols : out->max_len;
+        pos = next;
+    }
+    out->end = pos;
+}
+
+// the first offset in [from, limit) at which a record seems to start; `limit` if none
+inline uint64_t FastxMappedReader::guess_record_start(uint64_t from, uint64_t limit) const
+{
+    uint64_t pos = from;
+    if (pos > 0 && data_[pos - 1] != '\n') {  // to the start of the next line
+        const char *nl = static_cast<const char *>(std::memchr(data_ + pos, '\n', size_ - pos));
+        if (!nl) return limit;
+        pos = static_cast<uint64_t>(nl - data_) + 1;
+    }
+    while (pos < limit) {
+        if (data_[pos] == kind_) {
+            if (kind_ == '>') return pos;
+            // FASTQ: two records in a row must parse from here, and what follows them must be a record start or the end
+            Rec r;
+            uint64_t p1, p2;
+            bool bad;
+            if (record_at(pos, &r, &p1, &bad, nullptr, 0) && r.start == pos) {
+                Rec r2;
+                const bool second = record_at(p1, &r2, &p2, &bad, nullptr, 0);
+                if ((second && data_[r2.start] == '@') || (!second && !bad)) return pos;
+            }
+        }
+        const char *nl = static_cast<const char *>(std::memchr(data_ + pos, '\n', size_ - pos));
+        if (!nl) return limit;
+        pos = static_cast<uint64_t>(nl - data_) + 1;
+    }
+    return limit;
+}
+
+inline void FastxMappedReader::copy_record(const Rec &r, uint8_t *out) const
+{
+    uint64_t pos = r.start + r.seq, left = r.symbols;
+    if (r.one_line) {
+        std::memcpy(out, data_ + pos, left);
+        return;
+    }
+    while (left > 0) {
+        uint64_t b, e;
+        pos = line_at(pos, &b, &e);
+        std::memcpy(out, data_ + b, e - b);
+        out += e - b;
+        left -= e - b;
+    }
+}
+
+inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, uint64_t *qoff, uint64_t max_records, uint64_t *uniform_len)
+{
+    qoff[0] = 0;
+    if (uniform_len) *uniform_len = 0;
+    if (max_records == 0 || cursor_ >= size_) return 0;
+    if (kind_ == 0) {  // the first record names the kind of file
+        uint64_t p = cursor_;
+        while (p < size_ && (data_[p] == '\n' || data_[p] == '\r')) p++;
+        kind_ = p < size_ ? data_[p] : '>';
+    }
+    // the window: about max_records records (from the batches before; the first one guesses), never less than 1 MB
+    const double per = bytes_per_record_ > 0.0 ? bytes_per_record_ : 256.0;
+    double want = per * static_cast<double>(max_records) * 1.02 + 65536.0;
+    if (bytes_per_record_ <= 0.0 && want > 3.0 * static_cast<double>(capacity) + (1 << 20)) want = 3.0 * static_cast<double>(capacity) + (1 << 20);
+    uint64_t w_end = size_ - cursor_ > static_cast<uint64_t>(want) ? cursor_ + static_cast<uint64_t>(want) : size_;
+    if (w_end < size_) w_end = guess_record_start(w_end, size_);
+    const uint64_t w_bytes = w_end - cursor_;
+    unsigned nb = threads_;
+    // a megabyte per thread at least (tests: GDX_FASTX_BLOCK_BYTES lowers that, so that small files are cut into blocks too)
+    uint64_t min_block = 1u << 20;
+    if (const char *e = getenv("GDX_FASTX_BLOCK_BYTES")) min_block = static_cast<uint64_t>(std::max(1L, atol(e)));
+    if (w_bytes < min_block * nb) nb = static_cast<unsigned>(w_bytes / min_block) + 1;
+    std::vector<uint64_t> border(nb + 1);
+    border[0] = cursor_;
+    border[nb] = w_end;
+    for (unsigned i = 1; i < nb; i++) {
+        const uint64_t at = cursor_ + w_bytes / nb * i;
+        border[i] = at <= border[i - 1] ? border[i - 1] : guess_record_start(at, w_end);
+    }
+    std::vector<Block> blocks(nb);
+    auto run = [&](unsigned n, auto &&fn) {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < n; i++) th.emplace_back([&, i] { fn(i); });
+        fn(0);
+        for (auto &t : th) t.join();
+    };
+    run(nb, [&](unsigned i) { parse_block(border[i], border[i + 1], ~0ull, ~0ull, &blocks[i], false, 0); });
+    // every block must have ended exactly where the next one starts (the last one at the window's end)
+    bool consistent = true;
+    for (unsigned i = 0; i < nb; i++) consistent = consistent && blocks[i].ok && blocks[i].end == border[i + 1];
+    if (!consistent) {  // one thread, from the window's first byte: the authority
+        blocks.assign(1, Block());
+        nb = 1;
+        parse_block(cursor_, size_, max_records, capacity, &blocks[0], true, records_);
+        if (!blocks[0].ok && blocks[0].recs.empty()) fail(GDX_ERR_INVALID_ARGUMENT, "%s", blocks[0].error.c_str());
+        // (records in front of a malformed one are delivered; the error comes with the batch that starts at it)
+    }
+    // what fits the caller's limits
+    uint64_t n = 0, used = 0, stop_at = w_end;
+    std::vector<uint64_t> take(nb, 0), base_rec(nb, 0), base_sym(nb, 0);
+    bool full = false;
+    for (unsigned i = 0; i < nb && !full; i++) {
+        base_rec[i] = n;
+        base_sym[i] = used;
+        const Block &bk = blocks[i];
+        if (n + bk.recs.size() <= max_records && used + bk.symbols <= capacity) {  // the whole block
+            take[i] = bk.recs.size();
+            n += bk.recs.size();
+            used += bk.symbols;
+            stop_at = bk.end;
+            continue;
+        }
+        for (const Rec &r : bk.recs) {
+            if (n == max_records || r.symbols > capacity - used) {
+                if (n == 0 && r.symbols > capacity)
+                    fail(GDX_ERR_CAPACITY, "record %llu has %llu symbols, the buffer holds %llu", static_cast<unsigned long long>(records_),
+                         static_cast<unsigned long long>(r.symbols), static_cast<unsigned long long>(capacity));
+                stop_at = r.start;
+                full = true;
+                break;
+            }
+            take[i]++;
+            n++;
+            used += r.symbols;
+        }
+        if (!full) stop_at = bk.end;
+    }
+    uint64_t lo = ~0ull, hi = 0;
+    run(nb, [&](unsigned i) {
+        uint64_t at = base_sym[i];
+        const Block &bk = blocks[i];
+        for (uint64_t j = 0; j < take[i]; j++) {
+            copy_record(bk.recs[j], qbuf + at);
+            at += bk.recs[j].symbols;
+            qoff[base_rec[i] + j + 1] = at;
+        }
+    });
+    for (unsigned i = 0; i < nb; i++)
+        for (uint64_t j = 0; j < take[i] && (take[i] != blocks[i].recs.size()); j++) {  // (a block cut short: its own extremes)
+            lo = blocks[i].recs[j].symbols < lo ? blocks[i].recs[j].symbols : lo;
+            hi = blocks[i].recs[j].symbols > hi ? blocks[i].recs[j].symbols : hi;
+        }
+    for (unsigned i = 0; i < nb; i++)
+        if (take[i] != 0 && take[i] == blocks[i].recs.size()) {
+            lo = blocks[i].min_len < lo ? blocks[i].min_len : lo;
+            hi = blocks[i].max_len > hi ? blocks[i].max_len : hi;
+        }
+    if (uniform_len && n != 0 && lo == hi) *uniform_len = lo;
+    if (n != 0) bytes_per_record_ = static_cast<double>(stop_at - cursor_) / static_cast<double>(n);
+    if (n == 0 && !consistent && !blocks[0].ok) fail(GDX_ERR_INVALID_ARGUMENT, "%s", blocks[0].error.c_str());
+    cursor_ = stop_at;
+    records_ += n;
+    return n;
+}
 
 }  // namespace gdx

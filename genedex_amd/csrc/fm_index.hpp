@@ -296,6 +296,8 @@ struct Narrow32Sink {
     // a larger array holding the first `keep` hits of the old one (called with no copy into the old one on its way)
     std::function<gdx_hit32_t *(uint64_t need, uint64_t keep, uint64_t *new_cap)> grow;
 };
+// parser threads of the mapped FASTA / FASTQ reader (fastx.hpp): the CPUs the process may use, at most 32 (host_api.hip)
+unsigned fastx_default_threads();
 // chunk size of the host-pointer pipeline (host_api.hip); 0 = default.  Tests use small chunks.
 void set_host_chunking(uint64_t queries, uint64_t bytes);
 

@@ -969,6 +969,8 @@ uint64_t pack_queries_with_table(const uint8_t *tab, const uint8_t *qbuf, const 
     return all.size();
 }
 
+unsigned fastx_default_threads() { return std::min(32u, usable_cpus()); }
+
 void set_host_chunking(uint64_t queries, uint64_t bytes)
 {
     g_chunk_queries.store(queries ? queries : (1ull << 20));

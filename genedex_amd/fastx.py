@@ -9,47 +9,67 @@ import numpy as np
 from . import _lib
 
 
-def read_batches(path: str, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28):
+def read_batches(path: str, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28, with_uniform_len: bool = False):
     """Yields (qbuf u8[total], qoff u64[n + 1]) for successive batches of at most max_records sequences whose
-    symbols fit into buffer_bytes; the arrays are views of reused buffers, copy them to keep them."""
+    symbols fit into buffer_bytes; the arrays are views of reused buffers, copy them to keep them.  with_uniform_len: a third
+    item, the common length of the batch's sequences (0 when they differ), as the reader saw it (gdx_fastx_next_batch_ex).
+    A regular file is parsed by several threads (GDX_FASTX_THREADS; 0 = the streaming reader)."""
     lib = _lib.load()
     handle = C.c_void_p()
     _lib.check(lib.gdx_fastx_open(path.encode(), C.byref(handle)))
     qbuf = np.empty(buffer_bytes, dtype=np.uint8)
     qoff = np.empty(max_records + 1, dtype=np.uint64)
-    n = C.c_uint64(0)
+    n, ulen = C.c_uint64(0), C.c_uint64(0)
     try:
         while True:
-            _lib.check(lib.gdx_fastx_next_batch(handle, qbuf.ctypes.data_as(C.c_void_p), buffer_bytes,
-                                                qoff.ctypes.data_as(C.c_void_p), max_records, C.byref(n)))
+            _lib.check(lib.gdx_fastx_next_batch_ex(handle, qbuf.ctypes.data_as(C.c_void_p), buffer_bytes,
+                                                   qoff.ctypes.data_as(C.c_void_p), max_records, C.byref(n), C.byref(ulen)))
             if n.value == 0:
                 return
-            yield qbuf[: int(qoff[n.value])], qoff[: n.value + 1]
+            if with_uniform_len:
+                yield qbuf[: int(qoff[n.value])], qoff[: n.value + 1], int(ulen.value)
+            else:
+                yield qbuf[: int(qoff[n.value])], qoff[: n.value + 1]
     finally:
         lib.gdx_fastx_close(handle)
 
 
-def read_packed_batches(path: str, alphabet, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28):
+def read_packed_batches(path: str, alphabet, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28, n_buffers: int = 1):
     """Batches of a FASTA / FASTQ file in the form the fastest calls take (gdx_query_layout_t): yields dicts with
     `packed` (u8: 2-bit codes, four symbols per byte), `nq`, `uniform_len` (the reads' common length, or 0 when they differ:
     then `qoff` (u64[nq + 1], counting symbols) goes with the batch), `exceptions` (indices of the reads with a symbol
     outside the alphabet's four searchable ones -- N, IUPAC codes: their packed symbols are meaningless) and `qbuf` / `qoff`
-    (the ASCII batch itself, for running the exceptions through the plain calls).  Host only: gdx_fastx_next_batch ->
-    gdx_pack_queries_table, no index and no device needed.  The arrays of a batch are views of reused buffers."""
+    (the ASCII batch itself, for running the exceptions through the plain calls).  Host only: gdx_fastx_next_batch_ex ->
+    gdx_pack_queries_table, no index and no device needed.  The arrays of a batch are views of reused buffers: with
+    n_buffers = k a batch stays valid until k - 1 more have been taken (a producer thread one batch ahead of its consumer
+    needs 3: one being filled, one in the queue, one in use)."""
     lib = _lib.load()
     table = np.ascontiguousarray(alphabet.io_to_dense_table, dtype=np.uint8)
-    packed = np.zeros(int(lib.gdx_packed_bytes(buffer_bytes)), dtype=np.uint8)
-    exc = np.empty(max_records, dtype=np.uint64)
-    n_exc = C.c_uint64(0)
-    for qbuf, qoff in read_batches(path, max_records, buffer_bytes):
-        nq = qoff.size - 1
-        _lib.check(lib.gdx_pack_queries_table(table.ctypes.data_as(_lib.u8p), qbuf.ctypes.data_as(_lib.u8p) if qbuf.size else None,
-                                              qoff.ctypes.data_as(_lib.u64p), nq, packed.ctypes.data_as(_lib.u8p),
-                                              exc.ctypes.data_as(_lib.u64p), max_records, C.byref(n_exc)))
-        lens = np.diff(qoff)
-        uniform = int(lens[0]) if nq and bool((lens == lens[0]).all()) and int(lens[0]) > 0 else 0
-        yield {"packed": packed[: int(lib.gdx_packed_bytes(int(qoff[nq])))], "nq": nq, "uniform_len": uniform,
-               "qoff": qoff, "qbuf": qbuf, "exceptions": exc[: n_exc.value].copy()}
+    sets = [dict(qbuf=np.empty(buffer_bytes, dtype=np.uint8), qoff=np.empty(max_records + 1, dtype=np.uint64),
+                 packed=np.zeros(int(lib.gdx_packed_bytes(buffer_bytes)), dtype=np.uint8), exc=np.empty(max_records, dtype=np.uint64))
+            for _ in range(max(1, n_buffers))]
+    handle = C.c_void_p()
+    _lib.check(lib.gdx_fastx_open(path.encode(), C.byref(handle)))
+    n, ulen, n_exc = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    k = 0
+    try:
+        while True:
+            b = sets[k % len(sets)]
+            k += 1
+            _lib.check(lib.gdx_fastx_next_batch_ex(handle, b["qbuf"].ctypes.data_as(C.c_void_p), buffer_bytes,
+                                                   b["qoff"].ctypes.data_as(C.c_void_p), max_records, C.byref(n), C.byref(ulen)))
+            nq = int(n.value)
+            if nq == 0:
+                return
+            qoff = b["qoff"][: nq + 1]
+            total = int(qoff[nq])
+            _lib.check(lib.gdx_pack_queries_table(table.ctypes.data_as(_lib.u8p), b["qbuf"].ctypes.data_as(_lib.u8p) if total else None,
+                                                  qoff.ctypes.data_as(_lib.u64p), nq, b["packed"].ctypes.data_as(_lib.u8p),
+                                                  b["exc"].ctypes.data_as(_lib.u64p), max_records, C.byref(n_exc)))
+            yield {"packed": b["packed"][: int(lib.gdx_packed_bytes(total))], "nq": nq, "uniform_len": int(ulen.value),
+                   "qoff": qoff, "qbuf": b["qbuf"][:total], "exceptions": b["exc"][: min(int(n_exc.value), max_records)].copy()}
+    finally:
+        lib.gdx_fastx_close(handle)
 
 
 def read_sequences(path: str):

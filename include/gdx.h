@@ -731,6 +731,12 @@ typedef struct gdx_fastx gdx_fastx_t;
 int gdx_fastx_open(const char *path, gdx_fastx_t **out);
 int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
                          uint64_t max_records, uint64_t *n_out);
+/* the same; *out_uniform_len (may be NULL) = the common length of the batch's records, 0 when they differ -- what
+ * gdx_query_layout_t.uniform_len takes.  A regular file is memory-mapped and a batch parsed by several threads (blocks cut at
+ * record starts, every block checked to end where the next one starts; round 6: one thread delivered 60 M reads a second to calls
+ * that take 3 G); environment GDX_FASTX_THREADS = their number, 0 = the streaming reader (pipes, stdin). */
+int gdx_fastx_next_batch_ex(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
+                            uint64_t max_records, uint64_t *n_out, uint64_t *out_uniform_len);
 void gdx_fastx_close(gdx_fastx_t *reader);
 
 #ifdef __cplusplus

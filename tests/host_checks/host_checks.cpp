@@ -45,6 +45,34 @@ int main(int argc, char **argv)
                     if (qoff[i + 1] < qoff[i] || qoff[i + 1] > cap) return 4;  // the offsets stay inside the buffer
             }
             std::printf("ok %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", records, symbols, checksum);
+        } else if (mode == "fastxmap") {
+            // the memory-mapped reader, blocks parsed by `threads` threads (GDX_FASTX_BLOCK_BYTES: the smallest block): the same
+            // line as "fastx" prints for the same file, or the same error
+            const uint64_t max_records = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1000;
+            const uint64_t cap = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : (1u << 20);
+            const unsigned threads = argc > 5 ? static_cast<unsigned>(std::strtoul(argv[5], nullptr, 10)) : 4u;
+            std::unique_ptr<gdx::FastxMappedReader> reader(gdx::FastxMappedReader::open(argv[2], threads));
+            if (!reader) {  // (an empty or missing file: the streaming reader decides)
+                gdx::FastxReader plain(argv[2]);
+                std::printf("ok 0 0 %" PRIu64 "\n", 1469598103934665603ull);
+                return 0;
+            }
+            std::vector<uint8_t> qbuf(cap ? cap : 1);
+            std::vector<uint64_t> qoff(max_records + 1);
+            uint64_t records = 0, symbols = 0, checksum = 1469598103934665603ull;
+            for (;;) {
+                uint64_t ulen = 0;
+                const uint64_t n = reader->next_batch(qbuf.data(), cap, qoff.data(), max_records, &ulen);
+                if (n == 0) break;
+                records += n;
+                symbols += qoff[n];
+                for (uint64_t i = 0; i < qoff[n]; i++) checksum = (checksum ^ qbuf[i]) * 1099511628211ull;
+                for (uint64_t i = 0; i < n; i++) {
+                    if (qoff[i + 1] < qoff[i] || qoff[i + 1] > cap) return 4;
+                    if (ulen != 0 && qoff[i + 1] - qoff[i] != ulen) return 5;
+                }
+            }
+            std::printf("ok %" PRIu64 " %" PRIu64 " %" PRIu64 "\n", records, symbols, checksum);
         } else if (mode == "header") {
             gdx::IndexFile in(argv[2], "rb");
             const gdx::FileHeader h = gdx::read_index_header(in, argv[2]);

@@ -232,3 +232,68 @@ def test_host_packer_equals_the_byte_loop_on_every_table(name):
         assert np.array_equal(packed[: want.size], want), (name, trial)
         assert bool((packed[want.size:] == 0xEE).all())  # nothing beyond the packed symbols is written
         assert exc[: n_exc.value].tolist() == want_exc.tolist(), (name, trial)
+
+
+def _random_fastx_file(rng, kind, n_records):
+    """a file that uses what the format allows: wrapped sequences and qualities, CRLF, blank lines between records, quality
+    lines that start with '@' / '+' / '>', empty sequences, no newline at the end"""
+    parts, want = [], []
+    for i in range(n_records):
+        ln = int(rng.integers(0, 140)) if i % 11 else 0
+        seq = "".join(rng.choice(list("ACGTN"), ln))
+        eol = "\r\n" if i % 4 == 0 else "\n"
+        width = int(rng.integers(1, 80)) if i % 3 == 0 else 10 ** 6
+        s_lines = [seq[j:j + width] for j in range(0, len(seq), width)]
+        if kind == "fasta":
+            parts.append(f">s{i} d{eol}" + "".join(x + eol for x in s_lines) + ("\n" if i % 9 == 0 else ""))
+        else:
+            qual = "".join(rng.choice(list("@+>IJ#!"), ln))
+            q_width = int(rng.integers(1, 80)) if i % 3 == 0 else 10 ** 6
+            q_lines = [qual[j:j + q_width] for j in range(0, len(qual), q_width)]
+            parts.append(f"@r{i}{eol}" + "".join(x + eol for x in s_lines) + f"+{eol}" + "".join(x + eol for x in q_lines)
+                         + ("\n" if i % 9 == 0 and ln else ""))
+        want.append(seq.encode())
+    return "".join(parts).rstrip("\n").encode() if kind == "fasta" else "".join(parts).encode(), want
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+@pytest.mark.parametrize("threads,block", [(0, 0), (1, 64), (3, 300), (8, 64), (8, 5000)])
+def test_the_mapped_reader_delivers_what_the_streaming_reader_delivers(tmp_path, monkeypatch, kind, threads, block):
+    """gdx_fastx_next_batch on a regular file: the file is mapped and a batch parsed by several threads, blocks cut at guessed
+    record starts and checked to meet (fastx.hpp FastxMappedReader); GDX_FASTX_THREADS=0 is the streaming reader of rounds 1-5.
+    Same records, same order, same batch limits -- with blocks of a few dozen bytes, so that guesses land inside wrapped
+    records and quality lines that look like headers."""
+    rng = np.random.default_rng(900 + threads + block)
+    data, want = _random_fastx_file(rng, kind, 700)
+    path = tmp_path / f"x.{kind}"
+    path.write_bytes(data)
+    monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
+    if block:
+        monkeypatch.setenv("GDX_FASTX_BLOCK_BYTES", str(block))
+    assert fastx.read_sequences(str(path)) == want
+    for max_records, buffer_bytes in ((5, 400), (64, 100000), (10 ** 6, 700)):
+        got = []
+        for qbuf, qoff, ulen in fastx.read_batches(str(path), max_records=max_records, buffer_bytes=buffer_bytes, with_uniform_len=True):
+            raw = qbuf.tobytes()
+            n = qoff.size - 1
+            assert qoff[0] == 0 and 0 < n <= max_records and int(qoff[-1]) <= buffer_bytes
+            lens = np.diff(qoff.astype(np.int64))
+            assert ulen == (int(lens[0]) if bool((lens == lens[0]).all()) else 0)
+            got += [raw[int(qoff[i]):int(qoff[i + 1])] for i in range(n)]
+        assert got == want, (max_records, buffer_bytes)
+
+
+@pytest.mark.parametrize("threads", [0, 4])
+def test_malformed_records_are_reported_by_either_reader(tmp_path, monkeypatch, threads):
+    monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
+    monkeypatch.setenv("GDX_FASTX_BLOCK_BYTES", "32")
+    good = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(200))
+    for tail in (b"@last\nACGT\n+\nII\n", b"@last\nACGT\n", b"garbage\n"):
+        p = tmp_path / "m.fq"
+        p.write_bytes(good + tail)
+        with pytest.raises(GdxError):
+            fastx.read_sequences(str(p))
+    trunc = tmp_path / "t.fq"
+    trunc.write_bytes(good[:-7])  # the last quality line cut short
+    with pytest.raises(GdxError):
+        fastx.read_sequences(str(trunc))

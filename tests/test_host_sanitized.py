@@ -17,7 +17,7 @@ SRC = os.path.join(ROOT, "tests", "host_checks", "host_checks.cpp")
 def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host_checks") / "host_checks")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-           "-fno-omit-frame-pointer", SRC, "-o", exe]
+           "-fno-omit-frame-pointer", "-pthread", SRC, "-o", exe]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
 
@@ -52,13 +52,32 @@ def test_fastx_reader_on_wellformed_and_malformed_files(checker, tmp_path):
         "binary_junk.fa": ">" + "".join(map(chr, rng.integers(1, 255, 4000))),
         "nul_bytes.fq": "@r\n\0\0\0\n+\n\0\0\0\n",
     }
+    # (round 6) the memory-mapped reader that parses blocks of the file in parallel: the same line for the same file, with blocks
+    # of a few dozen bytes so that block borders fall inside records
+    os.environ["GDX_FASTX_BLOCK_BYTES"] = "48"
+    try:
+        for path, mr, cap in ((fa, 7, 700), (fq, 1000, 1 << 20), (fq, 3, 400)):
+            for threads in (1, 5):
+                assert checker("fastxmap", path, mr, cap, threads) == checker("fastx", path, mr, cap), (path, mr, cap, threads)
+        crlf = tmp_path / "crlf.fq"
+        crlf.write_bytes("".join(f"@r{i}\r\n{s[:40]}\r\n{s[40:]}\r\n+\r\n{'+' * min(len(s), 40)}\r\n{'@' * max(len(s) - 40, 0)}\r\n\r\n"
+                                 for i, s in enumerate(seqs)).encode())
+        assert checker("fastxmap", crlf, 50, 5000, 6) == checker("fastx", crlf, 50, 5000)
+        assert checker("fastx", crlf, 50, 5000)[1].split()[1] == "200"
+    finally:
+        pass
     for name, text in cases.items():
         p = tmp_path / name
         p.write_bytes(text.encode("latin-1"))
         rc, out = checker("fastx", p, 3, 64)
         assert rc in (0, 3), (name, out)
+        rc_m, out_m = checker("fastxmap", p, 3, 64, 4)
+        assert (rc_m, out_m.split(":")[0]) == (rc, out.split(":")[0]), (name, out, out_m)
+        if rc == 0:
+            assert out_m == out, (name, out, out_m)
         if name in ("truncated_quality.fq", "no_plus.fq", "wrong_first_byte.fa", "huge_record.fa", "only_header.fq"):
             assert rc == 3 and out.startswith("error:"), (name, out)
+    os.environ.pop("GDX_FASTX_BLOCK_BYTES", None)
     (tmp_path / "empty.fa").write_bytes(b"")
     rc, out = checker("fastx", tmp_path / "empty.fa", 3, 64)
     assert (rc, out.split()[:3]) == (0, ["ok", "0", "0"])
