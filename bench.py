@@ -781,6 +781,20 @@ def main():
     if args.index == "default" and wl["total"] >= 1 << 20 and not aux["default_shape"]:
         # the headline runs on what a caller of gdx_index_build gets: nothing was asked for, and the library must have chosen
         raise SystemExit(f"[bench] the library did not build its default shape (no room in HBM?): {aux}")
+    # N > 1, before anything is timed: ONE small sharded, gathered step whose concatenated shards must equal rank 0's own output of
+    # the same reads (strong_scaling raises SystemExit otherwise: the run ends non-zero, without a number), the backend's rank
+    # count and the rate a probe gather measures on this run's links.  The RCCL path has never met several GPUs before the
+    # driver's run: if it is wrong there, it says so here instead of printing a throughput.
+    preflight = None
+    if world > 1:
+        pre_args = argparse.Namespace(**{**vars(args), "steps": 1, "warmup": 0})
+        n_pre = max(min(nq, 1 << 18), 8 * world)
+        pre = strong_scaling(torch, gdist, eng, io_text, lengths, wl, n_pre, do_locate, pre_args, rank, world, dev)
+        preflight = {"queries": n_pre, "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "gather_link_GBps": pre.get("gather_probe_GBps_per_link"), "gather_wire": pre.get("gather_wire"),
+                     "shards_equal_single_rank_output": pre.get("shards_equal_single_rank_output")}
+        log(f"[bench r{rank}] preflight: {preflight}")
+        torch.cuda.empty_cache()
     n_slots = 2 if (world > 1 or (do_locate and args.overlap)) else 1
     run_queries = input_form(queries, index, args, wl)
     runner = StepRunner(torch, eng, run_queries, nq, do_locate, args.path, hint=not args.no_hint, n_slots=n_slots)
@@ -1027,6 +1041,10 @@ def main():
                    "sa_rate": args.sa_rate, "index_storage": wl["storage"], "hits_per_gpu": total_hits,
                    "aux_structures": aux,
                    "parallelism": f"index replicated x{world}, queries sharded, gather to rank 0",
+                   "rccl_ranks": preflight["ranks"] if preflight else None,
+                   "gather_backend": preflight["backend"] if preflight else None,
+                   "gather_link_GBps": preflight["gather_link_GBps"] if preflight else None,
+                   "preflight": preflight,
                    "gathered_bytes_per_rank_and_step": gathered_bytes,
                    "compact_exceptions": exceptions,
                    "gather_wire": (("found bitmap + positions + exceptions" if getattr(gather, "wire_name", "") == "bitmap" else
@@ -1211,7 +1229,8 @@ def compact_line(result, side_file=None):
         cpu["sample"] = cpu["sample"][:200]
     cfg = result.get("config") or {}
     config = _pick(cfg, ("workload", "index_gb_per_replica", "index_is_library_default", "name", "op", "path", "input", "hit_offsets", "queries_per_gpu", "queries_total", "text_len",
-                         "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism",
+                         "n_texts", "lookup_depth", "sa_rate", "index_storage", "hits_per_gpu", "parallelism", "rccl_ranks",
+                         "gather_backend", "gather_link_GBps",
                          "gathered_bytes_per_rank_and_step", "gather_wire", "compact_exceptions"))
     if isinstance(config.get("workload"), str):
         config["workload"] = config["workload"][:260]
@@ -1726,6 +1745,12 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
             log(f"[bench] secondary {res[-1]}")
             del eng_r, ix_r, counts_r
             torch.cuda.empty_cache()
+        # BASELINE configs[1]: 256 MB text, 10 M len-50 reads, count() -- parity is tests/test_gpu_parity.py's
+        # test_full_size_properties_workload2; this is its throughput on the library's default index
+        try:
+            res.append(cfg2_secondary(torch, alpha, args))
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cfg2 secondary failed: {e!r}")
         # (seed table AND the library's default structures: a read from a repeat goes on from its seed entry's interval with
         # one jump round -- search_seed_kernel4 -> search_fast_kernel4 over its list -> the general kernel)
         # + the full suffix array: the hits of a read from a repeat are consecutive rows -- 32 of their SA values per 128-byte
@@ -1734,6 +1759,47 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
                 if seed_family else {})
         res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), **both})))
     return res
+
+
+def cfg2_secondary(torch, alpha, args, steps=20):
+    """BASELINE.json configs[1]: one text of 2^28 symbols, 10 M len-50 reads (90 % sampled), count() on one GPU, the library's
+    default index (i32 storage: n < 2^31), reads resident as IO symbols + u64 offsets; every sampled read must be found."""
+    from genedex_amd.device import DeviceEngine, DeviceQueries, build_index_from_device_text, synth_text
+
+    w = WORKLOADS["cfg2"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    text = synth_text(w["total"], seed=42, n_per_million=10_000, device=dev)
+    t0 = time.time()
+    index = build_index_from_device_text(text, [w["total"]], alpha, sa_rate=args.sa_rate, lookup_depth=args.lookup_depth,
+                                         index_storage=w["storage"])
+    t_build = time.time() - t0
+    eng = DeviceEngine(index)
+    nq = w["nq"]
+    q = DeviceQueries.synth(text, [w["total"]], nq, w["len_min"], w["len_max"], w["sampled_ppm"], seed=43)
+    out = {}
+    for form, qq in (("ascii", q), ("packed+uniform", q.as_packed(index).as_uniform(w["len_min"]))):
+        runner = StepRunner(torch, eng, qq, nq, False, "records")
+        runner.size()
+        for _ in range(3):
+            runner.step(0, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step(0, False)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        counts = runner.counts(runner.outs[0])
+        found = int((counts > 0).sum().item())
+        out[form] = {"ms_per_step": ms, "value": nq / (ms / 1e3), "queries_found": found}
+        del runner
+    if out["ascii"]["queries_found"] != out["packed+uniform"]["queries_found"] or out["ascii"]["queries_found"] < 0.895 * nq:
+        raise SystemExit(f"PARITY FAILURE: cfg2 counts {out}")
+    r = {"name": "cfg2_256MB_10M_len50_count (BASELINE configs[1])", "text_len": w["total"], "queries": nq, "op": "count",
+         "value": out["ascii"]["value"], "unit": "queries/s", "ms_per_step": out["ascii"]["ms_per_step"],
+         "input": "IO symbols + u64 offsets", "packed_input": out["packed+uniform"], "queries_found": out["ascii"]["queries_found"],
+         "index_bytes": int(index.info.device_bytes), "index_build_seconds": t_build, "aux_structures": eng.aux_info()}
+    log(f"[bench] secondary {r}")
+    return r
 
 
 def genome_like_secondary(torch, alpha, wl, args, max_hits=1000):

@@ -266,8 +266,11 @@ struct Rccl {
     Rccl()
     {
         void *h = nullptr;
+        // (GDX_RCCL_LIBRARY: another library with RCCL's entry points first -- tests/rccl_shim records what this file sends where
+        // and moves the bytes itself, so that the exchange below runs on a box with one GPU)
+        if (const char *e = getenv("GDX_RCCL_LIBRARY")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+            if (h == nullptr && (h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
         if (!h) return;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -324,8 +327,10 @@ void multi_locate_gather_dev(Multi &m, const DeviceShard *shards, int n_shards, 
             fail(GDX_ERR_INVALID_ARGUMENT, "shard %zu: d_qbuf must be 8-byte aligned", r);
     }
     std::lock_guard<std::recursive_mutex> serial(m.call_mutex);  // the handle's result buffers are this call's until it returns
-    const bool use_rccl = g > 1 && !all_same;
-    if (use_rccl && !all_distinct) fail(GDX_ERR_UNSUPPORTED, "replicas must sit on distinct devices, or all on one");
+    // (GDX_MULTI_FORCE_RCCL=1, tests: replicas that share a device exchange through the RCCL entry points all the same)
+    const bool force_rccl = [] { const char *e = getenv("GDX_MULTI_FORCE_RCCL"); return e && atoi(e) != 0; }();
+    const bool use_rccl = g > 1 && (!all_same || force_rccl);
+    if (use_rccl && !all_distinct && !force_rccl) fail(GDX_ERR_UNSUPPORTED, "replicas must sit on distinct devices, or all on one");
     if (use_rccl && !rccl().ok) fail(GDX_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded");
 
     // every replica: search -> scan -> locate of its shard on its own device and stream (the replica's worker thread)

@@ -1,6 +1,7 @@
 """Contract of the C ABI (include/gdx.h) beyond the happy path: status codes where the reference panics, the
 two-phase locate protocol, device-resident entry points, concurrent use of one handle."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -393,7 +394,7 @@ def test_query_options_struct_may_be_shorter_than_the_library_knows():
     assert back.search_fast == 0 and back.max_hits_per_query == 0
 
 
-def _gather_dev_case(n_replicas, devices):
+def _gather_dev_case(n_replicas, devices, expect_rccl=None):
     """gdx_multi_locate_many_gather_dev: every replica locates the shard that sits in its own HBM, counts and hits are
     gathered on the root's device; the result must be the one-handle output of the concatenated batch."""
     import torch
@@ -431,7 +432,7 @@ def _gather_dev_case(n_replicas, devices):
             out = _lib.Gathered()
             _lib.check(lib.gdx_multi_locate_many_gather_dev(m, shards, n_replicas, root, C.byref(out)))
             assert out.nq == len(qs) and out.total_hits == int(co[-1]) and out.device_id == devices[root]
-            assert out.used_rccl == (1 if len(set(devices)) > 1 else 0)
+            assert out.used_rccl == ((1 if len(set(devices)) > 1 else 0) if expect_rccl is None else expect_rccl)
             d = torch.device("cuda", out.device_id)
 
             class _Dev:  # a library-owned device buffer as a zero-copy torch tensor (__cuda_array_interface__)
@@ -456,6 +457,57 @@ def _gather_dev_case(n_replicas, devices):
 
 def test_multi_gather_dev_three_replicas_on_one_device():
     _gather_dev_case(3, [0, 0, 0])
+
+
+def test_multi_gather_dev_rccl_branch_through_a_recording_shim(tmp_path):
+    """The RCCL branch of gdx_multi_locate_many_gather_dev (multi.hip: one group of ncclSend / ncclRecv per shard and array) has
+    never met two GPUs.  Here it runs on ONE: tests/rccl_shim is loaded in librccl.so's place (GDX_RCCL_LIBRARY), replicas that
+    share the device are made to exchange through it (GDX_MULTI_FORCE_RCCL), the shim pairs every receive with its send as RCCL
+    would -- same peer, element count and type, or it fails -- moves the bytes, and records every call.  The gathered counts,
+    offsets and hits must be the oracle's (checked in the child process by the same code as the plain test), and the record
+    must show the sizes and destinations the shards call for: per non-root replica three sends to the root and three
+    receives from it, counts as u32 at the shard's query base, statuses as bytes, hits as 2 u32 each at its hit base."""
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = tmp_path / "librccl_shim.so"
+    build = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "--offload-arch=gfx950",
+                            os.path.join(root_dir, "tests", "rccl_shim", "rccl_shim.cpp"), "-o", str(shim)],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    log = tmp_path / "shim.log"
+    env = dict(os.environ, GDX_RCCL_LIBRARY=str(shim), GDX_MULTI_FORCE_RCCL="1", GDX_RCCL_SHIM_LOG=str(log))
+    code = ("import sys; sys.path.insert(0, 'tests'); import test_gpu_api_contract as t; "
+            "t._gather_dev_case(3, [0, 0, 0], expect_rccl=1); print('child ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root_dir, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "child ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = log.read_text().splitlines()
+    assert lines[0].startswith("init 3 ranks")
+    ops = [ln.split() for ln in lines if ln.startswith(("send", "recv"))]
+    # two calls (root 0, then root 2), each: 2 non-root replicas x 3 arrays x (send + recv)
+    assert len(ops) == 2 * 2 * 3 * 2
+    for call, root in enumerate((0, 2)):
+        mine = ops[call * 12:(call + 1) * 12]
+        sends = [o for o in mine if o[0] == "send"]
+        recvs = [o for o in mine if o[0] == "recv"]
+        assert all(int(o[3]) == root for o in sends) and all(int(o[1]) == root for o in recvs)
+        base = {}
+        for s_, r_ in zip(sends, recvs):
+            assert s_[1] == r_[3] and s_[4:6] == r_[4:6]  # the same peer, element count and type on both sides
+        for rep_ in sorted({int(o[1]) for o in sends}):
+            cnt, st, hit = [o for o in sends if int(o[1]) == rep_]
+            assert cnt[5] == "3" and st[5] == "1" and hit[5] == "3" and cnt[4] == st[4] and int(hit[4]) % 2 == 0
+            base[rep_] = (int(cnt[4]), int(hit[4]) // 2)
+            rc, rs, rh = [o for o in recvs if int(o[3]) == rep_]
+            base[rep_] += (int(rc[6], 16), int(rs[6], 16), int(rh[6], 16))
+        # destinations: shard r lands behind the shards before it -- between two senders the counts move on by 4 bytes per query
+        # of what lies between them, statuses by 1, hits by 8 per hit
+        a, b = sorted(base)
+        nq_between = {(1, 2): base[1][0], (0, 1): base[0][0]}[(a, b)]
+        hits_between = {(1, 2): base[1][1], (0, 1): base[0][1]}[(a, b)]
+        assert base[b][2] - base[a][2] == 4 * nq_between and base[b][3] - base[a][3] == nq_between
+        assert base[b][4] - base[a][4] == 8 * hits_between
 
 
 def test_multi_gather_dev_over_rccl():

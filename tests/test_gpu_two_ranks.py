@@ -48,6 +48,10 @@ def test_bench_two_ranks_on_one_gpu(wire):
     assert d["parity"]["hits_checked"] == d["parity"]["hits_matching_text"] > 0
     assert d["parity"]["shards_equal_single_rank_output"] == {"counts": True, "hits": True}
     assert d["cpu_baseline"] is None  # N = 1 only
+    # the preflight (before anything was timed): a small gathered step equal to rank 0's own output, the backend's rank count, the
+    # probe's link rate -- in the line
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["gather_backend"] == "gloo" and d["config"]["gather_link_GBps"] > 0
+    assert full["config"]["preflight"]["shards_equal_single_rank_output"] == {"counts": True, "hits": True}
     w = d["weak_scaling"]
     assert w["queries_per_gpu"] == 1_000_000 and w["value"] > 0 and w["gathered_bytes_per_rank_and_step"] > 1_000_000
     assert st["scaling"] == "strong" and st["queries_total"] == 1_000_000 and st["queries_this_rank"] == hi0 - lo0
