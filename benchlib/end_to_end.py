@@ -1,0 +1,411 @@
+"""benchlib.end_to_end -- the host-pointer calls (PCIe inclusive), FASTQ file -> hits, the packed-query calls (split out of bench.py in round 6; bench.py re-exports everything)."""
+from __future__ import annotations
+
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from .common import *  # noqa: F401,F403
+from .pmc import *  # noqa: F401,F403
+from .line import *  # noqa: F401,F403
+from .baseline import *  # noqa: F401,F403
+from .multi import *  # noqa: F401,F403
+
+__all__ = ['end_to_end', 'fastq_to_hits', 'packed_end_to_end']
+
+def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, search_ms, has_pair_lines=True):
+    """SURVEY.md 8d "wall-clock incl. H2D/D2H": the host-pointer calls a genedex caller would make (queries as &[u8] in
+    host memory, lib.rs:155-185; results into host arrays), which run as a chunked H2D || kernels || D2H pipeline
+    (host_api.hip).  Never `value`.  The PCIe rates are measured here with pinned 1 GiB copies."""
+    import ctypes as C
+
+    from genedex_amd import _lib
+
+    lib = _lib.load()
+    dev = queries.qbuf.device
+    nbytes = queries.total_bytes
+    qbuf = queries.qbuf[:nbytes].cpu().numpy()
+    qoff = queries.qoff.cpu().numpy().astype(np.uint64)
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+
+    def copy_rate(dst, src):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return (1 << 30) / best / 1e9
+
+    h2d, d2h = copy_rate(dbuf, pin), copy_rate(pin, dbuf)
+    # both directions at once on two streams: what a pipeline that copies in and out together gets of the link (this platform
+    # serves the two directions at not much more than ONE direction's rate in all -- profiles/r05/README.md -- so the bound
+    # of a host-pointer call is (bytes in + bytes out) / this rate, not the slower of the two directions alone)
+    pin2 = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf2 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    duplex = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s_in):
+            dbuf.copy_(pin, non_blocking=True)
+        with torch.cuda.stream(s_out):
+            pin2.copy_(dbuf2, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        duplex = dt if duplex is None or dt < duplex else duplex
+    duplex = 2 * (1 << 30) / duplex / 1e9
+    del pin, dbuf, pin2, dbuf2
+    counts = np.empty(nq, dtype=np.uint64)
+    status = np.empty(nq, dtype=np.uint8)
+    u8p, u64p = _lib.u8p, _lib.u64p
+
+    def count_call():
+        _lib.check(lib.gdx_count_many(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                      counts.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+    def best_of(fn, reps=2):
+        fn()  # the first call also sizes the pinned staging buffers
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
+    t_count = best_of(count_call)
+    same_counts = bool(np.array_equal(counts, dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)))
+    offs = np.empty(nq + 1, dtype=np.uint64)
+    total = C.c_uint64(0)
+    last = {}
+
+    def locate_call():
+        ptr = C.POINTER(_lib.HitStruct)()
+        _lib.check(lib.gdx_locate_many_alloc(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                             offs.ctypes.data_as(u64p), C.byref(ptr), C.byref(total),
+                                             status.ctypes.data_as(u8p)))
+        last["ptr"] = ptr
+
+    t_locate = None
+    for _ in range(3):  # (the first call also sizes the pinned staging buffers)
+        if last.get("ptr"):
+            lib.gdx_free_hits(last.pop("ptr"))
+        t0 = time.perf_counter()
+        locate_call()
+        dt = time.perf_counter() - t0
+        t_locate = dt if t_locate is None or dt < t_locate else t_locate
+    same_total = total.value == total_hits and int(offs[-1]) == total_hits
+    if last.get("ptr"):
+        lib.gdx_free_hits(last.pop("ptr"))
+    if not same_counts or not same_total:
+        raise SystemExit("PARITY FAILURE: the host-pointer calls disagree with the device-resident path")
+    in_bytes = nbytes + 8 * (nq + 1)
+    out_count_bytes = 5 * nq  # u32 count + status byte per query on the wire, widened to u64 by the host threads
+    out_locate_bytes = 5 * nq + 8 * total_hits
+    def bound(n_in, n_out, kernel_ms):
+        return max(n_in / (h2d * 1e9), n_out / (d2h * 1e9), (n_in + n_out) / (duplex * 1e9), kernel_ms / 1e3)
+
+    bound_count = bound(in_bytes, out_count_bytes, search_ms)
+    bound_locate = bound(in_bytes, out_locate_bytes, step_ms)
+    res = {"count_qps": nq / t_count, "count_seconds": t_count, "locate_qps": nq / t_locate, "locate_seconds": t_locate,
+           "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h, "pcie_both_directions_GBps_total": duplex, "h2d_bytes": in_bytes,
+           "d2h_bytes_count": out_count_bytes,
+           "d2h_bytes_locate": out_locate_bytes,
+           "count_over_bound": t_count / bound_count, "locate_over_bound": t_locate / bound_locate,
+           "bound": "max(H2D bytes / measured H2D rate, D2H bytes / measured D2H rate, (H2D + D2H bytes) / the rate of both "
+                    "directions at once, kernel time)",
+           "calls": "gdx_count_many / gdx_locate_many_alloc on pageable host arrays (ASCII queries, u64 offsets), results "
+                    "identical to the device-resident path", "query_packing": "none (ASCII) for count_qps / locate_qps",
+           "results_identical_to_device_path": {"counts": same_counts, "hits_total": same_total}}
+    res["packed_queries"] = packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms)
+    # the same two calls on the batch as 2-bit codes without offsets (gdx_query_layout_t: packed + uniform) when every read has
+    # the same length: 12.5 instead of 58 bytes per len-50 read over PCIe, nothing to stage but the codes
+    lens = (queries.qoff[1: nq + 1] - queries.qoff[:nq]) if nq else None
+    if nq and bool((lens == lens[0]).all().item()) and int(lens[0]) > 0:
+        ulen = int(lens[0])
+        packed = np.zeros(int(lib.gdx_packed_bytes(int(qoff[-1]))), dtype=np.uint8)
+        n_exc = C.c_uint64(0)
+        rc = lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq, packed.ctypes.data_as(u8p),
+                                  None, 0, C.byref(n_exc))
+        if rc == 0 and n_exc.value == 0:
+            lay = _lib.QueryLayout()
+            lib.gdx_query_layout_init(C.byref(lay))
+            lay.packed, lay.uniform_len = 1, ulen
+
+            def count_pu():
+                _lib.check(lib.gdx_count_many_layout(index._h, packed.ctypes.data_as(u8p), None, nq, C.byref(lay),
+                                                     counts.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+            t_c = best_of(count_pu)
+            same_c = bool(np.array_equal(counts, dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)))
+
+            def locate_pu():
+                ptr = C.POINTER(_lib.HitStruct)()
+                _lib.check(lib.gdx_locate_many_alloc_layout(index._h, packed.ctypes.data_as(u8p), None, nq, C.byref(lay),
+                                                            offs.ctypes.data_as(u64p), C.byref(ptr), C.byref(total),
+                                                            status.ctypes.data_as(u8p)))
+                last["ptr"] = ptr
+
+            t_l = None
+            for _ in range(3):
+                if last.get("ptr"):
+                    lib.gdx_free_hits(last.pop("ptr"))
+                t0 = time.perf_counter()
+                locate_pu()
+                dt = time.perf_counter() - t0
+                t_l = dt if t_l is None or dt < t_l else t_l
+            same_t = total.value == total_hits and int(offs[-1]) == total_hits
+            # the narrow form (gdx_locate_many_alloc_layout32): u32 offsets + 8-byte hits in pinned memory of the library's, written
+            # by the device; from the pageable array and from a pinned copy of it (no staging copy on the way in)
+            def locate32(qptr):
+                res = _lib.Hits32()
+                _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, qptr, None, nq, C.byref(lay), C.byref(res),
+                                                              status.ctypes.data_as(u8p)))
+                return res
+
+            def time32(qptr):
+                best, res = None, None
+                for _ in range(3):
+                    if res is not None:
+                        lib.gdx_free_hits32(C.byref(res))
+                    t0 = time.perf_counter()
+                    res = locate32(qptr)
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None or dt < best else best
+                return best, res
+
+            t_l32, res32 = time32(packed.ctypes.data_as(u8p))
+            same_32 = res32.total_hits == total_hits
+            if same_32 and last.get("ptr") and total_hits:  # the same offsets and hits as the wide call
+                o32 = np.ctypeslib.as_array(res32.hit_offsets, shape=(nq + 1,))
+                same_32 = bool(np.array_equal(o32, offs.astype(np.uint32)))
+                n_cmp = min(total_hits, 4_000_000)
+                h32 = np.ctypeslib.as_array(res32.hits, shape=(2 * n_cmp,)).reshape(n_cmp, 2)
+                h64 = np.ctypeslib.as_array(C.cast(last["ptr"], _lib.u64p), shape=(2 * n_cmp,)).reshape(n_cmp, 2)
+                same_32 = same_32 and bool(np.array_equal(h32, h64.astype(np.uint32)))
+                tail32 = np.ctypeslib.as_array(res32.hits, shape=(2 * total_hits,))[-2 * n_cmp:]
+                tail64 = np.ctypeslib.as_array(C.cast(last["ptr"], _lib.u64p), shape=(2 * total_hits,))[-2 * n_cmp:]
+                same_32 = same_32 and bool(np.array_equal(tail32, tail64.astype(np.uint32)))
+            lib.gdx_free_hits32(C.byref(res32))
+            pinned_in = torch.from_numpy(packed).pin_memory()
+            t_l32p, res32p = time32(C.cast(C.c_void_p(pinned_in.data_ptr()), u8p))
+            same_32 = same_32 and res32p.total_hits == total_hits
+            lib.gdx_free_hits32(C.byref(res32p))
+            del pinned_in
+            lib.gdx_release_cached_hits()
+            if last.get("ptr"):
+                lib.gdx_free_hits(last.pop("ptr"))
+            if not same_c or not same_t or not same_32:
+                raise SystemExit("PARITY FAILURE: the packed + uniform host calls disagree with the device-resident path")
+            in_pu = (nq * ulen + 3) // 4
+            # what the narrow call's results cross the link as (host_api.hip: the found-bitmap wire, expanded by host threads): a bit
+            # per read, 4 bytes (+ a text id byte) per read with one hit, {read, count} + 8 bytes per hit for the others with hits
+            cnts = np.diff(offs.astype(np.int64))
+            n_one, n_more = int((cnts == 1).sum()), int((cnts > 1).sum())
+            id_bytes = 1 if int(index.info.num_texts) > 1 else 0
+            out_locate32_bytes = nq // 8 + 8 * (nq // 2048 + 2) + (4 + id_bytes) * n_one + 8 * n_more + 8 * int(cnts[cnts > 1].sum())
+            del cnts
+            res["packed_uniform"] = {
+                "count_qps": nq / t_c, "count_seconds": t_c, "locate_qps": nq / t_l, "locate_seconds": t_l, "h2d_bytes": in_pu,
+                "count_over_bound": t_c / bound(in_pu, out_count_bytes, search_ms),
+                "locate_over_bound": t_l / bound(in_pu, out_locate_bytes, step_ms),
+                "locate32_qps": nq / t_l32, "locate32_seconds": t_l32,
+                "locate32_over_bound": t_l32 / bound(in_pu, out_locate32_bytes, step_ms),
+                "locate32_pinned_input_qps": nq / t_l32p, "locate32_pinned_input_seconds": t_l32p,
+                "locate32_pinned_input_over_bound": t_l32p / bound(in_pu, out_locate32_bytes, step_ms),
+                "d2h_bytes_locate32": out_locate32_bytes,
+                "calls": "gdx_count_many_layout / gdx_locate_many_alloc_layout, layout = {packed, uniform_len}: 2-bit codes, no "
+                         "offsets; locate32 = gdx_locate_many_alloc_layout32 (u32 offsets + 8-byte hits in pinned memory of the "
+                         "library's; the results cross PCIe as the found-bitmap wire -- d2h_bytes_locate32 -- and host threads expand "
+                         "them; pinned_input: the 2-bit codes lie in pinned memory too, no staging copy)",
+                "results_identical_to_device_path": {"counts": same_c, "hits_total": same_t, "narrow_equals_wide": same_32}}
+    try:
+        res["fastq_to_hits"] = fastq_to_hits(np, index, qbuf, qoff, nq, offs)
+    except OSError as e:  # (no room for the file)
+        res["fastq_to_hits"] = {"error": repr(e)}
+    log(f"[bench] end to end: {res}")
+    return res
+
+
+def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_reads=8_000_000):
+    """A FASTQ file of the batch's first reads -> gdx_fastx_next_batch_ex (the library's reader: the file memory-mapped, a batch
+    parsed by all host threads the process may use) -> gdx_pack_queries_table (2-bit codes, host threads) ->
+    gdx_locate_many_alloc_layout32, reader and packer one batch ahead of the GPU calls in a thread of their own.  What the
+    reference's ROADMAP.md:35-37 worries about: reading the queries can cost more than searching them -- it still does (the
+    kernels take 25 G reads a second), but by one order of magnitude less than with round 5's single parsing thread."""
+    import ctypes as C
+    import queue
+    import tempfile
+    import threading
+
+    from genedex_amd import _lib, alphabet, fastx
+
+    lib = _lib.load()
+    n = int(min(n_reads, nq))
+    lens = np.diff(qoff[: n + 1].astype(np.int64))
+    if n == 0 or not bool((lens == lens[0]).all()):
+        return None
+    ln = int(lens[0])
+    rec = np.empty((n, ln * 2 + 7), dtype=np.uint8)  # "@r\n" + read + "\n+\n" + quality + "\n"
+    rec[:, 0], rec[:, 1], rec[:, 2] = ord("@"), ord("r"), 10
+    rec[:, 3: 3 + ln] = qbuf[: n * ln].reshape(n, ln)
+    rec[:, 3 + ln], rec[:, 4 + ln], rec[:, 5 + ln] = 10, ord("+"), 10
+    rec[:, 6 + ln: 6 + 2 * ln] = ord("I")
+    rec[:, 6 + 2 * ln] = 10
+    with tempfile.NamedTemporaryFile(prefix="gdx_bench_", suffix=".fq", dir="/tmp", delete=False) as f:
+        path = f.name
+    try:
+        rec.tofile(path)
+        file_bytes = os.path.getsize(path)
+        del rec
+        alpha = alphabet.ascii_dna_with_n()
+        t0 = time.perf_counter()
+        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
+        t_reader = time.perf_counter() - t0
+        os.environ["GDX_FASTX_THREADS"] = "0"  # (round 5's reader, for the record: one thread, a streaming read of the file)
+        t0 = time.perf_counter()
+        n_read1 = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
+        t_reader1 = time.perf_counter() - t0
+        del os.environ["GDX_FASTX_THREADS"]
+        q = queue.Queue(maxsize=1)
+
+        def producer():
+            # (three buffer sets: one being filled, one in the queue, one in the GPU call -- no copy of a batch)
+            for b in fastx.read_packed_batches(path, alpha, max_records=batch_reads, buffer_bytes=batch_reads * ln, n_buffers=3):
+                q.put((b["packed"], b["nq"], b["uniform_len"], b["exceptions"].size))
+            q.put(None)
+
+        lay = _lib.QueryLayout()
+        lib.gdx_query_layout_init(C.byref(lay))
+        status = np.empty(batch_reads, dtype=np.uint8)
+        t0 = time.perf_counter()
+        th = threading.Thread(target=producer)
+        th.start()
+        hits, reads, n_exc = 0, 0, 0
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            packed, bn, ul, ne = item
+            lay.packed, lay.uniform_len = 1, ul
+            r32 = _lib.Hits32()
+            _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, packed.ctypes.data_as(_lib.u8p), None, bn, C.byref(lay),
+                                                          C.byref(r32), status.ctypes.data_as(_lib.u8p)))
+            hits += r32.total_hits
+            reads += bn
+            n_exc += ne
+            lib.gdx_free_hits32(C.byref(r32))
+        th.join()
+        dt = time.perf_counter() - t0
+        same = reads == n and n_read == n and n_read1 == n and n_exc == 0 and hits == int(offs[n])
+        if not same:
+            raise SystemExit(f"PARITY FAILURE: FASTQ -> hits gave {reads} reads / {hits} hits, the device path {n} / {int(offs[n])}")
+        return {"reads": n, "file_bytes": file_bytes, "fastq_to_hits_qps": n / dt, "seconds": dt, "file_GBps": file_bytes / dt / 1e9,
+                "reader_alone_qps": n / t_reader, "reader_alone_file_GBps": file_bytes / t_reader / 1e9,
+                "reader_alone_one_thread_qps": n / t_reader1, "batch_reads": batch_reads,
+                "hits": hits, "hits_identical_to_device_path": same,
+                "what": "FASTQ file -> gdx_fastx_next_batch_ex (mapped file, blocks parsed in parallel) -> gdx_pack_queries_table -> "
+                        "gdx_locate_many_alloc_layout32, reader and packer one batch ahead in a thread of their own"}
+    finally:
+        os.remove(path)
+
+
+def packed_end_to_end(np, torch, index, queries, nq, dev_counts, h2d, d2h, search_ms):
+    """The count call on 2-bit packed queries (include/gdx.h "packed queries"; pair-line kernels): a quarter of the query
+    bytes over PCIe; packing is done once by gdx_pack_queries (host threads) and timed separately -- a caller that stores
+    its reads packed never pays it."""
+    import ctypes as C
+
+    from genedex_amd import _lib
+
+    lib = _lib.load()
+    dev = queries.qbuf.device
+    nbytes = queries.total_bytes
+    qbuf = queries.qbuf[:nbytes].cpu().numpy()
+    qoff = queries.qoff.cpu().numpy().astype(np.uint64)
+    counts = dev_counts.cpu().numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    status = np.empty(nq, dtype=np.uint8)
+    u8p, u64p = _lib.u8p, _lib.u64p
+
+    def best_of(fn, reps=2):
+        fn()
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
+    packed = np.empty(int(lib.gdx_packed_bytes(nbytes)), dtype=np.uint8)
+    exc = np.empty(1 << 20, dtype=np.uint64)
+    n_exc = C.c_uint64(0)
+    t_pack = None
+    for _ in range(2):  # (the first call also touches the pages of `packed` for the first time)
+        t0 = time.perf_counter()
+        _lib.check(lib.gdx_pack_queries(index._h, qbuf.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                        packed.ctypes.data_as(u8p), exc.ctypes.data_as(u64p), exc.size, C.byref(n_exc)))
+        dt = time.perf_counter() - t0
+        t_pack = dt if t_pack is None or dt < t_pack else t_pack
+    counts_p = np.empty(nq, dtype=np.uint64)
+
+    def count_packed_call():
+        _lib.check(lib.gdx_count_many_packed(index._h, packed.ctypes.data_as(u8p), qoff.ctypes.data_as(u64p), nq,
+                                             counts_p.ctypes.data_as(u64p), status.ctypes.data_as(u8p)))
+
+    t_count_packed = best_of(count_packed_call)
+    keep = np.ones(nq, dtype=bool)
+    keep[exc[: n_exc.value].astype(np.int64)] = False
+    same_packed = bool(np.array_equal(counts_p[keep], counts[keep]))
+    if not same_packed:
+        raise SystemExit("PARITY FAILURE: packed queries give other counts than ASCII queries")
+    # device-resident: the search kernel on packed input (records mode), packed on the device from the ASCII batch
+    d_packed = torch.zeros(packed.size, dtype=torch.uint8, device=dev)
+    d_bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.gdx_pack_queries_dev(index._h, C.c_void_p(queries.qbuf.data_ptr()), nbytes, C.c_void_p(d_packed.data_ptr()),
+                                        None, C.c_void_p(d_bad.data_ptr()), stream))
+    rec = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+
+    def packed_search():
+        _lib.check(lib.gdx_locate_many_search_packed_dev(index._h, C.c_void_p(d_packed.data_ptr()),
+                                                         C.c_void_p(queries.qoff.data_ptr()), nq, C.c_void_p(rec.data_ptr()),
+                                                         stream))
+
+    packed_search()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(3):
+        packed_search()
+    ev[1].record()
+    torch.cuda.synchronize()
+    packed_search_ms = ev[0].elapsed_time(ev[1]) / 3
+    same_dev = bool(torch.equal((rec[:, 1] - rec[:, 0])[torch.from_numpy(keep).to(dev)],
+                                dev_counts[torch.from_numpy(keep).to(dev)]))
+    if not same_dev:
+        raise SystemExit("PARITY FAILURE: the packed device search gives other counts")
+    del d_packed, rec
+    packed_in_bytes = nbytes // 4 + 8 * (nq + 1)
+    out_count_bytes = 5 * nq
+    return {"count_qps": nq / t_count_packed, "count_seconds": t_count_packed, "h2d_bytes": packed_in_bytes,
+            "count_over_bound": t_count_packed / max(packed_in_bytes / (h2d * 1e9), out_count_bytes / (d2h * 1e9), search_ms / 1e3),
+            "host_packing_seconds_not_included": t_pack, "host_packing_GBps_of_ascii": nbytes / t_pack / 1e9,
+            "host_packing_reads_per_s": nq / t_pack, "exception_queries": int(n_exc.value),
+            "device_search_ms_on_packed_input": packed_search_ms,
+            "counts_identical_outside_the_exceptions": same_packed and same_dev,
+            "pcie_h2d_GBps": h2d, "pcie_d2h_GBps": d2h}
