@@ -230,6 +230,7 @@ class StepRunner:
             self.ev_search.append((a, mid))
             self.ev_locate.append((mid, d))
         self.fused_steps = getattr(self, "fused_steps", 0) + 1
+        self.fused_slots = getattr(self, "fused_slots", set()) | {slot}
         if after is not None:
             after(slot)
 
@@ -238,7 +239,9 @@ class StepRunner:
         if not getattr(self, "fused_steps", 0):
             return
         self.torch.cuda.synchronize()
-        for t, h in zip(self.totals, self.hits):
+        for slot, (t, h) in enumerate(zip(self.totals, self.hits)):
+            if slot not in getattr(self, "fused_slots", set()):  # (a run of one step leaves the second slot's totals untouched)
+                continue
             tot = int(t[0].item())
             if tot > h.shape[0]:
                 raise SystemExit(f"PARITY FAILURE: a fused step produced {tot} hits for a buffer of {h.shape[0]}")
