@@ -504,8 +504,8 @@ def test_multi_gather_dev_rccl_branch_through_a_recording_shim(tmp_path):
         # destinations: shard r lands behind the shards before it -- between two senders the counts move on by 4 bytes per query
         # of what lies between them, statuses by 1, hits by 8 per hit
         a, b = sorted(base)
-        nq_between = {(1, 2): base[1][0], (0, 1): base[0][0]}[(a, b)]
-        hits_between = {(1, 2): base[1][1], (0, 1): base[0][1]}[(a, b)]
+        assert b == a + 1
+        nq_between, hits_between = base[a][0], base[a][1]  # (shard a is what lies between where a and a + 1 land)
         assert base[b][2] - base[a][2] == 4 * nq_between and base[b][3] - base[a][3] == nq_between
         assert base[b][4] - base[a][4] == 8 * hits_between
 

@@ -89,6 +89,6 @@ def test_gather_count_dtype_is_one_rccl_maps():
     the gathered per-query counts must travel as uint8 or int32 whatever the largest count is."""
     import re
 
-    src = open(os.path.join(ROOT, "bench.py")).read()
+    src = open(os.path.join(ROOT, "benchlib", "multi.py")).read()
     m = re.search(r"count_dtype = (.*)", src)
     assert m and "int16" not in m.group(1) and "uint8" in m.group(1) and "int32" in m.group(1)
