@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/gdx.h"
+#include "../../include/gdx_experimental.h"
 #include "../../include/gdx_bench.h"
 #include "fastx.hpp"
 #include "fm_index.hpp"
