@@ -2218,7 +2218,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
     const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,  // list != null: only the *n_list queries listed
-    uint32_t ulen)  // uniform batch (query_begin)
+    uint32_t ulen,  // uniform batch (query_begin)
+    // kSeed, behind the seed table's own kernel (round 6): where that kernel left a listed read -- {lo, hi, symbols in front of the
+    // seed, 1} = its k-mer's interval (the bucket is not fetched again), else from the beginning
+    const uint4 *__restrict__ state,
+    // != 0: an interval wider than max_rows is not narrowed here, one rank-line step per symbol and sixteen reads waiting for the
+    // widest: the read goes to the general kernel's list with its state, which steps two symbols per pair-line fetch and has
+    // nothing but such reads in its wavefronts
+    uint32_t wide_to_list)
 {
     constexpr int kGroup = 4;
     __shared__ uint8_t s_dense[256];
@@ -2260,7 +2267,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             bool single = false;           // kSeed: the k-mer occurs once, `pos` is where (no row is known)
             bool single_ok = false;        // ... and the (up to) 32 symbols in front of it are the query's
             uint32_t pos = 0;              // SA of this lane's row
-            if (kSeed && !bail) {
+            bool resumed = false;
+            if (kSeed && !bail && state != nullptr) {
+                const uint4 st = state[q];
+                if (st.w == 1u) {  // the seed kernel found the k-mer on several rows
+                    resumed = true;
+                    rem = static_cast<uint32_t>(len);
+                    w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
+                    lo = st.x;
+                    hi = st.y;
+                    rem = st.z;
+                    shift = vv.seed_k >> 3;
+                    part = vv.seed_k & 7u;
+                }
+            }
+            if (kSeed && !bail && !resumed) {
                 rem = static_cast<uint32_t>(len);
                 w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
                 const uint32_t k = vv.seed_k;
@@ -2353,6 +2374,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                     part = depth & 7u;
                 }
             }
+            if (wide_to_list != 0u && !bail && rem > 0u && hi - lo > vv.max_rows) bail = true;  // (the general kernel's, with its state)
             // narrow with LF steps on the rank lines while the interval is wider than the rows a verify round takes
             while (!bail && rem > 0u && hi - lo > vv.max_rows) {
                 if (shift > 6u) {
@@ -3766,7 +3788,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const int xlate = c.packed ? 2 : ((ix.perm_ok && !env_no_perm_v) ? 1 : 0);
 #define GDX_VERIFY_LAUNCH_X(XLATE, SEED, BLOCKS, RANGE, LEFT, LIST)                                                           \
     hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(BLOCKS), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,    \
-                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST, ulen)
+                       c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST, ulen, \
+                       verify_state, verify_wide)
 #define GDX_VERIFY_LAUNCH(SEED, BLOCKS, RANGE, LEFT, LIST)                             \
     do {                                                                               \
         if (xlate == 2) GDX_VERIFY_LAUNCH_X(2, SEED, BLOCKS, RANGE, LEFT, LIST);       \
@@ -3774,6 +3797,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         else GDX_VERIFY_LAUNCH_X(0, SEED, BLOCKS, RANGE, LEFT, LIST);                  \
     } while (0)
             uint32_t *const no_list = nullptr;
+            const uint4 *verify_state = nullptr;  // (set below: the seed kernel's states for the verify kernel over its list)
+            uint32_t verify_wide = 0;
             if (seed) {
                 // the seed table's own kernel first (absent k-mers and k-mers that occur once); what it lists -- k-mers on
                 // several rows, reads shorter than the seed, other symbols -- goes on in search_fast_kernel4 from the entry's
@@ -3793,7 +3818,10 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                     zs.add(d_first, sizeof(uint32_t));
                     const SeedView sv{ix.seed, ix.text_units, nullptr, ix.io_to_dense, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits,
                                       ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo, ix.perm_exp_hi, ix.perm_mask};
-                    uint4 *d_seed_state = to_fast ? c.d_rec : nullptr;
+                    // (the pair-line general kernel resumes listed reads from their k-mer's interval as well: the verify kernel in
+                    // between takes the narrow ones and leaves the wide ones to it)
+                    const bool to_verify_with_state = !to_fast && variant == 2 && ix.pair_lines != nullptr && c.d_rec != nullptr;
+                    uint4 *d_seed_state = (to_fast || to_verify_with_state) ? c.d_rec : nullptr;
                     uint32_t *const none = nullptr;
                     // reads longer than a seed entry covers: listed with {position, symbols in front} in the first half of their
                     // record slot (an array of its own when the call has no records) for seed_text_kernel4, whose own
@@ -3876,6 +3904,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                         const uint64_t l_ranges = (nq + l_range - 1) / l_range;
                         static const unsigned l_cap = [] { const char *e = getenv("GDX_SEED_LIST_BLOCKS"); return e ? static_cast<unsigned>(atol(e)) : 1792u; }();
                         const unsigned l_blocks = static_cast<unsigned>(l_ranges < l_cap ? l_ranges : l_cap);
+                        if (to_verify_with_state) {
+                            verify_state = d_seed_state;
+                            verify_wide = 1u;
+                            ca.resume_state = d_seed_state;
+                        }
                         GDX_VERIFY_LAUNCH(true, l_blocks, l_range, d_left, d_first);
                     }
                 } else {
