@@ -204,13 +204,11 @@ def secondaries(torch, owned, io_text, lengths, alpha, queries, base_counts, nq,
             res.append(cfg2_secondary(torch, alpha, args))
         except Exception as e:  # noqa: BLE001
             log(f"[bench] cfg2 secondary failed: {e!r}")
-        # (seed table AND the library's default structures: a read from a repeat goes on from its seed entry's interval with
-        # one jump round -- search_seed_kernel4 -> search_fast_kernel4 over its list -> the general kernel)
-        # + the full suffix array: the hits of a read from a repeat are consecutive rows -- 32 of their SA values per 128-byte
-        # line there, 4 per line inside the 32-byte jump entries (scan + locate of 573 M hits 5.35 -> 4.0 ms)
-        both = ({"index": "tables", "seed_symbols": 1, "full_sa": True, "aux_budget_bytes": 250_000_000_000}
-                if seed_family else {})
-        res.append(genome_like_secondary(torch, alpha, wl, argparse.Namespace(**{**vars(args), **both})))
+        # the genome-like text: a read from a repeat goes on from its seed entry's interval -- the verify kernel compares up to four
+        # rows with the text, the pair-line kernel steps the wide ones -- and its hits are consecutive rows of the full suffix array
+        # (round 6: on the index the headline runs on -- the library's defaults.  Rounds 3b-5 gave this text an index of its own,
+        # seed table AND 32-byte jump entries AND depth-16 top table AND full suffix array, 200 GB: 9.0-9.3 G q/s there)
+        res.append(genome_like_secondary(torch, alpha, wl, args))
     return res
 
 
