@@ -95,6 +95,12 @@ def one_round(rng, stats):
              "seed_symbols": [None, None, None, True, 8, 12][int(rng.integers(0, 6))],
              "seed_load_percent": [None, 100, 45][int(rng.integers(0, 3))],
              "inverse_suffix_array": [None, True][int(rng.integers(0, 2))]}
+    # (round 6) three rounds in ten leave every structure to the library: the default shape (seed table + text units + full and
+    # inverse suffix array + pair lines + top table, no jump table) wherever the alphabet allows it, with the top table's depth
+    # forced now and then -- exact intervals and cursors then take the text route of search_exact_kernel4
+    if rng.random() < 0.3:
+        build = {"top_table_depth": [None, None, 0, 3, 6, 10][int(rng.integers(0, 6))],
+                 "seed_load_percent": [None, 100][int(rng.integers(0, 2))]}
     query = {"search_lanes": [4, 4, 8][int(rng.integers(0, 3))], "load_policy": int(rng.integers(0, 2)),
              "length_schedule": int(rng.integers(0, 2)), "locate_jump_walk": int(rng.integers(0, 4)) != 0,
              "search_defer_after": [None, 0, 1, 2, 5][int(rng.integers(0, 5))],
@@ -329,6 +335,7 @@ def one_round(rng, stats):
         assert cur_e.cpu().numpy().astype(np.uint32).tolist() == ce[keep].astype(np.uint32).tolist(), ("cursor end", chunk, cfg)
         assert not cur_st.any().item()
         stats["cursor_rounds"] = stats.get("cursor_rounds", 0) + rounds
+    stats["default_shape_rounds"] = stats.get("default_shape_rounds", 0) + int(DeviceEngine(g).aux_info()["default_shape"])
     stats["queries"] += len(qs)
     stats["hits"] += int(co[-1])
     stats["status_nonzero"] += int((st != 0).sum())
