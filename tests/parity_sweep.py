@@ -355,8 +355,8 @@ def main():
                     "length_schedule", "locate_jump_walk", "search_defer_after", "search_fast", "search_exact", "text_units",
                     "full_suffix_array", "seed_symbols", "seed_load_percent", "inverse_suffix_array", "search_seed", "sa_rate",
                     "depth"):
-            seen.setdefault(key, {}).setdefault(str(cfg[key]), 0)
-            seen[key][str(cfg[key])] += 1
+            seen.setdefault(key, {}).setdefault(str(cfg.get(key, "library default")), 0)
+            seen[key][str(cfg.get(key, "library default"))] += 1
     print(json.dumps({"rounds": rounds, "seed": seed, "all_equal": True,
                       "seconds": round(time.time() - t0, 1), **stats, "configurations_seen": seen}))
 
