@@ -514,27 +514,37 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
         const int s = static_cast<int>(k % kSlots);
         Chunk &c = chunks[k];
         bool as_packed = packed, packed_here = false;  // packed_here: the chunk's codes were made by this thread's workers, in h_in
+        uint64_t chunk_uniform = uniform ? uniform_len : 0;  // != 0: every query of the chunk has this many symbols
         if (host_pack && c.bytes != 0) {
-            const uint64_t first = off_of(c.q0), last = off_of(c.q0 + c.nq);
-            const uint64_t pb0 = (first & ~7ull) / 4, nb = div_ceil(last, 4) - pb0;
+            // the chunk's symbols are packed from ITS first symbol on (symbol j of the chunk in bits 2 (j & 3) of byte j >> 2)
+            const uint64_t first = off_of(c.q0), n_sym = off_of(c.q0 + c.nq) - first, nb = div_ceil(n_sym, 4);
             std::atomic<bool> other{false};  // a symbol that is not one of the dense codes 1..4
+            std::atomic<bool> ragged{false};
+            const uint64_t len0 = uniform ? uniform_len : qoff[c.q0 + 1] - qoff[c.q0];
             uint8_t *out = h_in[s];
             pool.run([&](unsigned w, unsigned nw) {
                 const uint64_t per = (nb / nw + 64) / 64 * 64;
                 const uint64_t lo = std::min(nb, per * w), hi = std::min(nb, lo + per);
-                // (pack_range indexes the output by the byte's number in the whole buffer: `out - pb0` is never dereferenced below pb0)
-                pack_range(pack_plan, cfg_.io_to_dense, qbuf, first, last, pb0 + lo, pb0 + hi, out - pb0,
+                pack_range(pack_plan, cfg_.io_to_dense, qbuf + first, 0, n_sym, lo, hi, out,
                            [&](uint64_t) { other.store(true, std::memory_order_relaxed); });
+                // reads of one length (a sequencer's) need no offsets at all: neither rebased, nor copied, nor read by the kernels
+                if (!uniform && len0 != 0) {
+                    const uint64_t qper = div_ceil(c.nq, nw), q_lo = std::min(c.nq, qper * w), q_hi = std::min(c.nq, q_lo + qper);
+                    bool same = true;
+                    for (uint64_t i = q_lo; i < q_hi; i++) same &= qoff[c.q0 + i + 1] - qoff[c.q0 + i] == len0;
+                    if (!same) ragged.store(true, std::memory_order_relaxed);
+                }
             });
             as_packed = packed_here = !other.load();
+            if (packed_here && !uniform && len0 != 0 && len0 < (1ull << 21) && !ragged.load()) chunk_uniform = len0;
         }
-        // packed: the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
-        const uint64_t base = as_packed ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
+        // packed (by the caller): the chunk starts at the 16-bit unit that holds its first symbol, offsets are rebased to that unit
+        const uint64_t base = (as_packed && !packed_here) ? (off_of(c.q0) & ~7ull) : off_of(c.q0);
         const uint64_t src_byte = as_packed ? base / 4 : base;
         const uint64_t n_bytes = as_packed ? div_ceil(off_of(c.q0 + c.nq) - base, 4) : c.bytes;
         if (!pinned_input && !packed_here)
             pool.parallel_range(n_bytes, 64, [&](uint64_t lo, uint64_t hi) { stream_copy(h_in[s] + lo, qbuf + src_byte + lo, hi - lo); });
-        if (!uniform)
+        if (chunk_uniform == 0)
             pool.parallel_range(c.nq + 1, 8, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) h_qoff[s][i] = qoff[c.q0 + i] - base;
             });
@@ -546,13 +556,13 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
             std::memset(h_in[s] + n_bytes, 0, padded - n_bytes);
             GDX_HIP(hipMemcpyAsync(d_qbuf[s], h_in[s], padded, hipMemcpyHostToDevice, st.in));
         }
-        if (!uniform) GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
+        if (chunk_uniform == 0) GDX_HIP(hipMemcpyAsync(d_qoff[s], h_qoff[s], (c.nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st.in));
         GDX_HIP(hipEventRecord(st.ev_in[s], st.in));
         GDX_HIP(hipStreamWaitEvent(st.k, st.ev_in[s], 0));
         SearchCall call;
         call.d_qbuf = d_qbuf[s];
-        if (uniform) {  // (base == the chunk's first symbol: the chunk is a uniform batch of its own)
-            call.uniform_len = static_cast<uint32_t>(uniform_len);
+        if (chunk_uniform != 0) {  // (base == the chunk's first symbol: the chunk is a uniform batch of its own)
+            call.uniform_len = static_cast<uint32_t>(chunk_uniform);
         } else {
             call.d_qbeg = d_qoff[s];
             call.d_qend = d_qoff[s] + 1;
