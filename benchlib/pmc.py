@@ -234,7 +234,7 @@ def traffic_requests_of(pmc, pattern, queries=LOOKUP_PMC_READS):
 
 def committed_traffic(args, nq, aux, why):
     """Fallback when the live PMC passes are unavailable: the committed summary of the same configuration."""
-    path = os.path.join(ROOT, "profiles", "r05", "search_pmc_final.json")
+    path = os.path.join(ROOT, "profiles", "r06", "search_pmc_final.json")
     try:
         with open(path) as f:
             p = json.load(f)

@@ -37,13 +37,13 @@ def test_traffic_from_pmc_counters():
 
 
 def test_committed_fallback_summary_is_readable():
-    args = argparse.Namespace(workload="hg38", lookup_depth=0, path="records", input="packed+uniform")
-    aux = {"jump_entry_bytes": 0, "top_table_depth": 0, "seed": {"k": 24}}  # the headline index (bench.py --index seed)
+    args = argparse.Namespace(workload="hg38", lookup_depth=0, path="records", input="ascii")
+    aux = {"jump_entry_bytes": 0, "top_table_depth": 14, "seed": {"k": 24}}  # the headline index: the library's default shape
     t, source = bench.committed_traffic(args, 100_000_000, aux, "test")
     assert t is not None and "NOT measured in this run" in source
-    assert 1.3e10 < t["bytes"] < 1.9e10 and 1.0 < t["read_requests"] / 1e8 < 1.3  # ~154 bytes, ~1.14 requests per read (seed table at load 0.6)
-    # (the summary is of the batch as 2-bit codes without offsets: another form of the batch is another configuration)
-    other_form, why = bench.committed_traffic(argparse.Namespace(**{**vars(args), "input": "ascii"}), 100_000_000, aux, "test")
+    assert 1.7e10 < t["bytes"] < 2.2e10 and 1.3 < t["read_requests"] / 1e8 < 1.7  # ~196 bytes, ~1.49 requests per ASCII read
+    # (the summary is of the batch as IO symbols + offsets: another form of the batch is another configuration)
+    other_form, why = bench.committed_traffic(argparse.Namespace(**{**vars(args), "input": "packed+uniform"}), 100_000_000, aux, "test")
     assert other_form is None and "another configuration" in why
     other, why = bench.committed_traffic(args, 100_000_000, {"jump_entry_bytes": 16, "top_table_depth": 16, "seed": {"k": 0}}, "test")
     assert other is None and "another configuration" in why
@@ -372,4 +372,47 @@ def test_committed_round5_line_is_what_the_driver_can_read():
     assert abs(side["value"] - d["value"]) < 1e-5 * side["value"]
     pu = side["end_to_end"]["packed_uniform"]
     assert pu["results_identical_to_device_path"] == {"counts": True, "hits_total": True, "narrow_equals_wide": True}
+    assert side["end_to_end"]["fastq_to_hits"]["hits_identical_to_device_path"] is True
+
+
+def test_committed_round6_line_is_what_the_driver_can_read():
+    """profiles/r06/bench_hg38_final.json: the stdout line of the driver's command on round 6's tree.  `value` is timed on the
+    reference's own input form (IO symbols + u64 offsets: the alphabet translation inside the timed region) on the index a
+    caller of gdx_index_build gets with every option at its default, the pre-translated form is beside it, the 8(d) number of
+    the headline carries its label, and the cursor / exact-interval numbers of the SAME index are in the line."""
+    raw = open(os.path.join(ROOT, "profiles", "r06", "bench_hg38_final.json")).read()
+    assert raw.count("\n") <= 1 and len(raw.encode()) < 4096
+    d = json.loads(raw)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "input_form", "packed_input"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "u32"
+    assert d["config"]["input"] == "ascii" and d["input_form"] == "IO symbols + u64 offsets"
+    assert d["config"]["index_is_library_default"] is True and d["config"]["index_gb_per_replica"] < 135
+    assert abs(d["value"] - d["config"]["queries_per_gpu"] / (d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic_source"].startswith("live")
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["traffic"] / (r["avg_launch_ms"] / 1e3) / 1e9 / r["peak"]) < 1e-4
+    assert abs(r["avg_launch_ms_rocprof"] - r["avg_launch_ms"]) < 0.08 * r["avg_launch_ms"]
+    assert r["frac_section8d_headline"] > 1.0 and "algorithm substituted" in r["frac_section8d_headline_label"]
+    assert "search_seed_lane_kernel<1, false>" in r["kernel"]
+    assert 0.25 < r["reference_layout"]["frac_algorithmic"] < 0.40
+    stats = open(os.path.join(ROOT, "profiles", "r06", "bench_hg38_final_kernel_stats.md")).read()
+    row = [ln for ln in stats.splitlines() if "search_seed_lane_kernel<1, false>" in ln][0].split("|")
+    assert abs(float(row[4]) - r["avg_launch_ms"]) < 0.08 * r["avg_launch_ms"]
+    p = d["packed_input"]
+    assert p["offsets_and_hits_identical_to_headline"] is True and p["value"] > d["value"] and p["input"] == "packed+uniform"
+    cur = d["cursor_api_50M_len20_150"]
+    assert cur["headline_index"]["index_gb"] == round(d["config"]["index_gb_per_replica"])
+    assert cur["headline_index"]["cursor_api_ms"] < 16.0 and cur["headline_index"]["fused_ms"] < 10.0
+    assert cur["exact_intervals_100M_len50_headline_index_ms"] < 10.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["bit_exact_vs_gpu"] == {"intervals": True, "counts": True, "hits": True}
+    side = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_secondary.json")))
+    names = [s_["name"] for s_ in side["secondary"]]
+    assert any(n.startswith("cfg2_256MB_10M_len50_count") for n in names) and any("genome_like" in n for n in names)
+    assert any("on the HEADLINE index" in n and n.startswith("mixed_lengths") for n in names)
+    g = [s_ for s_ in side["secondary"] if "genome_like" in s_["name"]][0]
+    assert g["aux_structures"]["default_shape"] is True and g["oracle_gate"]["hits_identical"] is True
+    assert side["config"]["aux_structures"]["default_shape"] is True
     assert side["end_to_end"]["fastq_to_hits"]["hits_identical_to_device_path"] is True
