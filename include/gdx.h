@@ -124,21 +124,30 @@ int gdx_index_from_parts(const uint64_t *count /*sigma+1*/, const uint64_t *inte
  * (the first D symbols of a DNA query in one fetch, 8 * 4^D bytes).  Results are identical with any combination.
  * A field left at -1 / 0 takes its default; the GDX_* environment variables documented in DESIGN.md only override
  * fields left at their default (debugging aid).  Initialise with gdx_build_options_init(). */
+/* THE DEFAULT SHAPE (round 6).  With jump_entry_bytes, full_suffix_array, text_units, seed_symbols and inverse_suffix_array all
+ * left at -1 (and pair lines not switched off) on a DNA-like alphabet -- rank-line layout, dense symbols 1..4 searchable -- the
+ * library builds ONE index that serves every call at its best measured speed: seed table (k from the text length, load 60 %) +
+ * text units + full suffix array + inverse suffix array + pair lines + a top table of depth <= 14, no jump table (3.1 G symbols:
+ * 104 GB).  Count / locate go through the seed table, exact intervals and cursors through seed entry / text / ISA with the pair
+ * lines for the steps that empty an interval, locate has SA[row] one fetch away.  It needs 8.5 bytes per symbol + the seed
+ * table inside the budget for auxiliary structures; where that does not fit, or when any of those fields is set, the fields mean
+ * what they say and -1 stands for the tables of rounds 1-3 (32-byte jump entries, top table, shrunk to the budget).
+ * gdx_index_aux_info (gdx_bench.h) bit 3 tells whether an index has the default shape. */
 typedef struct {
     uint32_t struct_size;      /* sizeof(gdx_build_options_t), lets the struct grow compatibly         */
     int32_t pair_lines;        /* -1 default (on when sigma <= 8), 0 off, 1 on                         */
-    int32_t jump_entry_bytes;  /* -1 default (32), 0 no jump table, 8, 16 or 32                        */
-    int32_t top_table_depth;   /* -1 default (largest even D <= 16 with 4^D <= 2 n), 0 none, 1..16     */
+    int32_t jump_entry_bytes;  /* -1 default (none in the default shape, else 32), 0 no jump table, 8, 16 or 32 */
+    int32_t top_table_depth;   /* -1 default (largest even D <= 16 with 4^D <= 2 n; at most 14 in the default shape), 0 none, 1..16 */
     uint64_t aux_budget_bytes; /* cap for jump + top table together; 0 = default: free device memory
                                   minus a reserve for query batches, at most half of the device memory.
                                   Tables that do not fit shrink (gdx_index_aux reports what was built). */
-    int32_t full_suffix_array; /* -1 / 0 default off, 1: SA[row] of EVERY row as its own array (4 bytes per symbol); with
+    int32_t full_suffix_array; /* -1 default (on in the default shape, else off), 0 off, 1: SA[row] of EVERY row as its own array (4 bytes per symbol); with
                                   32-byte jump entries the same values already sit inside the entries                 */
-    int32_t text_units;        /* -1 / 0 default off, 1: the concatenated text itself, 4 bits per symbol (2-bit code + a
+    int32_t text_units;        /* -1 default (on in the default shape, else off), 0 off, 1: the concatenated text itself, 4 bits per symbol (2-bit code + a
                                   "not A C G T" bit, 16 bytes per 32 symbols): once a search is down to a few rows, the rest
                                   of the query is compared with the text at SA[row] in one fetch per row instead of LF
                                   steps -- the low-memory alternative to the jump table (count / locate searches)      */
-    int32_t seed_symbols;      /* -1 / 0 default off; 1 = a SEED TABLE with k chosen from the text length (ceil(log4 n) + 8, at
+    int32_t seed_symbols;      /* -1 default (as 1 in the default shape, else off), 0 off; 1 = a SEED TABLE with k chosen from the text length (ceil(log4 n) + 8, at
                                   most 24), 8..24 = that k; implies text_units.  A bucketed hash table over the distinct k-mers of
                                   the text (16 bytes each over the load factor: 71 GB for 3.1 G symbols): count / locate searches
                                   fetch ONE 128-byte bucket for the last k symbols of a read, and when that k-mer occurs once in
@@ -149,9 +158,9 @@ typedef struct {
                                   The table has at least 2^(2k - 21) buckets of 128 bytes whatever the text (17 GB for k = 24, 1 GB
                                   for k = 22, 67 MB for k = 20): an explicit k whose table does not fit the budget for auxiliary
                                   structures is refused (GDX_ERR_INVALID_ARGUMENT); 1 picks a k the text fills                    */
-    int32_t seed_load_percent; /* 0 default (70): slots of the seed table filled on average, 20..100 (fewer: more memory, fewer
+    int32_t seed_load_percent; /* 0 default (60 in the default shape, else 70): slots of the seed table filled on average, 20..100 (fewer: more memory, fewer
                                   reads that need a second bucket)                                                                */
-    int32_t inverse_suffix_array; /* -1 / 0 default off, 1: ISA[position] = row as its own array (4 bytes per symbol).  With it and a
+    int32_t inverse_suffix_array; /* -1 default (on in the default shape, else off), 0 off, 1: ISA[position] = row as its own array (4 bytes per symbol).  With it and a
                                   seed table, cursors_for_many_queries answers every read that occurs exactly once (its seed's
                                   entry, the text in front, then ONE fetch of the row) without LF steps; other reads take the usual
                                   route, so the intervals -- frozen empty ones included -- stay the reference's               */

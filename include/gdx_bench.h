@@ -90,7 +90,9 @@ int gdx_bench_lf_walk_dev(const gdx_index_t *ix, const void *d_rows, uint64_t m,
 
 /* Query acceleration structures the index carries beside the reference's arrays (DESIGN.md "HBM layout"):
  * out[0] = 1 if pair lines are present, out[1] = bytes per jump-table entry (0 = none, 8 or 16),
- * out[2] = depth of the top table (0 = none), out[3] = bit 0: full suffix array present, bit 1: text units present. */
+ * out[2] = depth of the top table (0 = none), out[3] = bit 0: full suffix array present, bit 1: text units present, bit 2: inverse
+ * suffix array present, bit 3: the index has the library's DEFAULT SHAPE (gdx.h gdx_build_options_t: every option was left at its
+ * default and the shape fitted the budget). */
 int gdx_index_aux_info(const gdx_index_t *ix, uint32_t out[4]);
 
 /* Drops the pair lines / jump table / top table of an index and builds them again with other options, without
