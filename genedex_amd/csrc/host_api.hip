@@ -837,7 +837,16 @@ int FmIndex::host_pipeline(int kind_i, const uint8_t *qbuf, const uint64_t *qoff
     size_t staged = 0, launched = 0, drained = 0;  // chunks staged in / with their copy-out enqueued / fully drained
     bool abort = false;
     std::exception_ptr worker_error;
-    WorkerPool in_pool(host_threads());
+    // (a feeder that packs is the call's bound: it gets half as many workers again as the drainer -- 10 of a 16-CPU container's:
+    // count 1.0 -> 2.1, wide locate 0.9 -> 1.8 G reads/s on one box; both pools at 10 or 14 were slower than both at 7.
+    // GDX_HOST_IN_THREADS: experiments)
+    const unsigned in_threads = [&] {
+        if (const char *e = getenv("GDX_HOST_IN_THREADS")) return static_cast<unsigned>(std::max(1, atoi(e)));
+        if (!host_pack || getenv("GDX_HOST_THREADS")) return host_threads();
+        const unsigned cpus = usable_cpus();
+        return std::max(host_threads(), std::min(host_threads() * 3u / 2u, cpus > 4u ? cpus - 4u : 1u));
+    }();
+    WorkerPool in_pool(in_threads);
     auto fail_all = [&](std::exception_ptr e) {
         std::lock_guard<std::mutex> g(mu);
         if (!worker_error) worker_error = e;
