@@ -58,18 +58,22 @@ pub struct Hits32Raw {
 }
 
 /// gdx_build_options_t: which derived acceleration structures an index carries (include/gdx.h).
+/// `BuildOptions::default()` -- every field at its default -- builds the library's DEFAULT SHAPE (round 6): seed table + text
+/// units + full and inverse suffix array + pair lines + top table, no jump table (104 GB at hg38 scale), the one index that
+/// serves count / locate, exact intervals, cursors and reads from repeats at their best measured speeds; setting any of
+/// jump_entry_bytes / full_suffix_array / text_units / seed_symbols / inverse_suffix_array makes the fields mean what they say.
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
 pub struct BuildOptions {
     pub struct_size: u32,
     pub pair_lines: i32,       // -1 default, 0 off, 1 on
-    pub jump_entry_bytes: i32, // -1 default (32), 0, 8, 16, 32
+    pub jump_entry_bytes: i32, // -1 default (none in the default shape, else 32), 0, 8, 16, 32
     pub top_table_depth: i32,  // -1 default, 0 none, 1..=16
     pub aux_budget_bytes: u64, // 0 = default
     pub full_suffix_array: i32, // -1 / 0 off, 1: SA[row] of every row as its own array
     pub text_units: i32,        // -1 / 0 off, 1: the text at 4 bits per symbol (count / locate compare with it)
     pub seed_symbols: i32,      // -1 / 0 off, 1: seed table with k from the text length, 8..=24: that k
-    pub seed_load_percent: i32, // 0 = default (70)
+    pub seed_load_percent: i32, // 0 = default (60 in the default shape, else 70)
     pub inverse_suffix_array: i32, // -1 / 0 off, 1: ISA as its own array (exact intervals through the seed table)
     pub reference_table_layout: i32, // -1 / 0 this library's table, 1..=4: Condensed64 / Condensed512 / Flat64 / Flat512 as genedex builds them
 }
@@ -213,7 +217,9 @@ extern "C" {
     pub fn gdx_rank_many(
         ix: *const gdx_index_t, symbols: *const u8, idx: *const u64, m: u64, out: *mut u64,
     ) -> c_int;
-    // device-resident variants take *const c_void device pointers and a hipStream_t; the fused count + locate:
+    // device-resident variants take *const c_void device pointers and a hipStream_t.  The step calls that follow are declared in
+    // include/gdx_experimental.h since round 6 (the core call is gdx_locate_many_step_compact_layout_dev: the whole count + locate
+    // step in one call); they stay exported.  The fused count + locate in steps:
     pub fn gdx_locate_many_search_dev(
         ix: *const gdx_index_t, d_qbuf: *const c_void, d_qoff: *const c_void, nq: u64, d_records: *mut c_void,
         stream: *mut c_void,
@@ -333,6 +339,11 @@ extern "C" {
     pub fn gdx_fastx_open(path: *const c_char, out: *mut *mut gdx_fastx_t) -> c_int;
     pub fn gdx_fastx_next_batch(
         reader: *mut gdx_fastx_t, qbuf: *mut u8, qbuf_capacity: u64, qoff: *mut u64, max_records: u64, n_out: *mut u64,
+    ) -> c_int;
+    /// the same; *out_uniform_len = the batch's common read length (0 when they differ): gdx_query_layout_t.uniform_len
+    pub fn gdx_fastx_next_batch_ex(
+        reader: *mut gdx_fastx_t, qbuf: *mut u8, qbuf_capacity: u64, qoff: *mut u64, max_records: u64, n_out: *mut u64,
+        out_uniform_len: *mut u64,
     ) -> c_int;
     pub fn gdx_fastx_close(reader: *mut gdx_fastx_t);
 }
