@@ -2215,13 +2215,13 @@ struct VerifyView {
 template <int kXlate, bool kSeed>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void search_verify_kernel4(
     VerifyView vv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
-    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
+    uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *out_rec,
     uint32_t range, uint32_t *__restrict__ leftover, uint32_t *__restrict__ n_leftover,
     const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,  // list != null: only the *n_list queries listed
     uint32_t ulen,  // uniform batch (query_begin)
     // kSeed, behind the seed table's own kernel (round 6): where that kernel left a listed read -- {lo, hi, symbols in front of the
     // seed, 1} = its k-mer's interval (the bucket is not fetched again), else from the beginning
-    const uint4 *__restrict__ state,
+    const uint4 *state,  // (the states lie in the record slots: no __restrict__ here nor on out_rec)
     // != 0: an interval wider than max_rows is not narrowed here, one rank-line step per symbol and sixteen reads waiting for the
     // widest: the read goes to the general kernel's list with its state, which steps two symbols per pair-line fetch and has
     // nothing but such reads in its wavefronts
