@@ -125,6 +125,9 @@ class StepRunner:
     def __init__(self, torch, eng, queries, nq, do_locate, path, hint=True, n_slots=1):
         self.torch, self.eng, self.q, self.nq = torch, eng, queries, nq
         self.do_locate = do_locate
+        # --op count: FmIndex::count_many (lib.rs:155-161) = gdx_count_many[_layout]_dev -- counts, no intervals, no hits (until
+        # round 6 the count-only step called the exact-interval search, which packed reads do not reach the slim kernels of)
+        self.count_only = not do_locate
         self.use_rec = path in ("records", "records16") and do_locate
         # (compact results only where something fills them: on an index without seed table every entry would say "see the
         # record" and the extra array would only cost its fill and its reads)
@@ -145,18 +148,24 @@ class StepRunner:
 
     def _alloc(self):
         o = self.eng.alloc_outputs(self.nq, hint=self.hint and not self.use_rec)
+        if self.count_only:
+            o["counts"] = self.torch.zeros(max(self.nq, 1), dtype=self.torch.int32, device=o["status"].device)
         if self.use_rec:
             o["rec"] = self.eng.alloc_records(self.nq)
             o["compact"] = self.eng.alloc_compact(self.nq) if self.use_compact else None
         return o
 
     def search(self, o):
-        if self.use_rec:
+        if self.count_only:
+            self.eng.count(self.q, o["counts"], o["status"])
+        elif self.use_rec:
             self.eng.locate_search(self.q, o["rec"], compact=o["compact"])
         else:
             self.eng.search(self.q, o)
 
     def offsets(self, o):
+        if self.count_only:
+            return
         if self.use_rec:
             self.eng.locate_offsets(o["rec"], self.nq, o["hit_offsets"], self.max_hits, compact=o["compact"])
         else:
@@ -170,6 +179,8 @@ class StepRunner:
 
     def counts(self, o):
         """per-query number of occurrences (int32 tensor)"""
+        if self.count_only:
+            return o["counts"][: self.nq]
         if self.use_rec:
             d = self.torch.sub(o["rec"][:self.nq, 1], o["rec"][:self.nq, 0])
             if o["compact"] is not None:  # -2: see the record; -1: no occurrence; else the position of the only hit
@@ -194,6 +205,8 @@ class StepRunner:
         self.offsets(o)
         torch.cuda.synchronize()
         self.total_hits = int(o["hit_offsets"][self.nq].item()) if self.nq else 0
+        if self.count_only:
+            self.total_hits = int(o["counts"][: self.nq].to(torch.int64).sum().item())
         dev = o["hit_offsets"].device
         self.hits = [torch.zeros((max(self.total_hits, 1), 2), dtype=torch.int32, device=dev) for _ in range(self.n_slots)]
         nbytes = max(self.eng.locate_workspace_bytes(self.total_hits), 16)
