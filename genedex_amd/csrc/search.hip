@@ -1816,7 +1816,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 
             const bool empty_cursor = lo == 0u && hi == ix.n;  // cursor_empty (lib.rs:202-210): the top table applies
             staged = staged && !empty_cursor;  // (a one-row collection: the seed / top table routes change the interval first)
             uint32_t rem = bail ? 0u : static_cast<uint32_t>(len);
-            const uint64_t *wbase = reinterpret_cast<const uint64_t *>(qbuf) + (begin >> 3);
+            const uint64_t *wbase = query_words<kXlate>(qbuf, begin);  // (kXlate 2: 2-bit codes, offsets count symbols)
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
             FastWindow w = {0u, 0u, 0u, 0u, 0u, 8u};
             uint32_t shift = 0;   // whole levels of the window used up
@@ -4036,7 +4036,15 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         // Exact intervals and cursor extension on clean input (search_exact_kernel4): what it cannot finish is listed for
         // the general kernel below.  QueryOptions::search_exact / GDX_SEARCH_EXACT=0 switch it off.
         static const int env_exact = [] { const char *e = getenv("GDX_SEARCH_EXACT"); return e ? atoi(e) : -1; }();
-        const bool exact = (c.mode == 0 || c.mode == 2) && c.d_step_stats == nullptr && lanes == 4 && policy == 0 && !c.packed &&
+        // (2-bit reads: exact intervals through the text route's kernel and the seed kernel in front of it -- round 6; the
+        // general packed kernel steps every symbol on the pair lines of an index without jump table: 4.5 ms per 10 M reads
+        // against 0.8)
+        // the text route in the jump table's place (search_exact_kernel4<0, ., ., true>); GDX_SEARCH_TEXT=0: pair lines only
+        static const int env_text = [] { const char *e = getenv("GDX_SEARCH_TEXT"); return e ? atoi(e) : 1; }();
+        const bool text_route = ix.jump == nullptr && ix.sa_full != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
+                                env_text != 0;
+        const bool exact = (c.mode == 0 || c.mode == 2) && c.d_step_stats == nullptr && lanes == 4 && policy == 0 &&
+                           (!c.packed || (c.mode == 0 && text_route)) &&
                            c.d_hint == nullptr && c.d_rec == nullptr && c.d_start != nullptr && c.d_end != nullptr &&
                            ix.n_searchable >= 4 && ix.sigma >= 5 && ca.resume_state == nullptr &&
                            (ix.top == nullptr || ix.top_depth >= static_cast<uint32_t>(ix.depth)) &&
@@ -4064,7 +4072,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             uint2 *const no_state = nullptr;
             const uint64_t t_groups = (nq + kBlock / 4 - 1) / (kBlock / 4);
             const unsigned t_blocks = static_cast<unsigned>(t_groups < 8192 ? t_groups : 8192);
-            if (ix.perm_ok && !env_no_perm_s) {
+            if (c.packed) {
+                hipLaunchKernelGGL((search_seed_kernel4<2, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
+                                   none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen, CursorArgs());
+                hipLaunchKernelGGL((seed_text_kernel4<2, true>), dim3(t_blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
+                                   d_long + 4, d_long, no_state, 0u, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, none_u32, no_rec,
+                                   d_first + 4, d_first, ulen);
+            } else if (ix.perm_ok && !env_no_perm_s) {
                 hipLaunchKernelGGL((search_seed_kernel4<1, true>), dim3(blocks), dim3(kBlock), 0, stream, sv, c.d_qbuf, c.d_qbeg,
                                    c.d_qend, nq, c.d_count, c.d_status, no_rec, c.d_start, c.d_end, range, d_first + 4, d_first, no_rec,
                                    none_u32, d_long + 4, d_long, no_state, 0u, 0u, ulen, CursorArgs());
@@ -4085,10 +4100,6 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const uint64_t x_ranges = (nq + x_range - 1) / x_range;
             x_blocks = static_cast<unsigned>(x_ranges < 8192 ? x_ranges : 8192);
         }
-        // the text route in the jump table's place (search_exact_kernel4<0, ., ., true>); GDX_SEARCH_TEXT=0: pair lines only
-        static const int env_text = [] { const char *e = getenv("GDX_SEARCH_TEXT"); return e ? atoi(e) : 1; }();
-        const bool text_route = ix.jump == nullptr && ix.sa_full != nullptr && ix.isa != nullptr && ix.text_units != nullptr &&
-                                env_text != 0;
         const bool seed_usable = ix.seed != nullptr && ix.seed_k >= static_cast<uint32_t>(ix.depth) && ix.seed_k <= 24u;
         // The first chunk of a batch of cursors on such an index: the seed kernel's pipeline serves the cursors that are still
         // cursor_empty and lists the others for the exact kernel (search_seed_kernel4<., true, true>).  "First" is a guess -- a
@@ -4147,7 +4158,8 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                        c.d_qbeg, c.d_qend, nq, c.d_start, c.d_end, c.d_count, c.d_status, x_range, schedule, d_left + 4, d_left, ca_exact)
 #define GDX_EXACT_LAUNCH_J(CURSOR)                                                 \
     do {                                                                           \
-        if (text_route && perm) GDX_EXACT_LAUNCH_T(1, CURSOR);                     \
+        if (text_route && c.packed) GDX_EXACT_LAUNCH_T(2, false);                  \
+        else if (text_route && perm) GDX_EXACT_LAUNCH_T(1, CURSOR);                \
         else if (text_route) GDX_EXACT_LAUNCH_T(0, CURSOR);                        \
         else if (ix.jump == nullptr) GDX_EXACT_LAUNCH_X(0, CURSOR);                \
         else if (ix.jump_bytes == 32) GDX_EXACT_LAUNCH_X(32, CURSOR);              \
