@@ -8,6 +8,7 @@
 // lines are skipped, sequence bytes are copied as they are (the alphabet table decides what is valid).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -500,6 +501,8 @@ inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, 
     qoff[0] = 0;
     if (uniform_len) *uniform_len = 0;
     if (max_records == 0 || cursor_ >= size_) return 0;
+    const double t_enter = getenv("GDX_FASTX_TIMING") != nullptr
+                               ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
     if (kind_ == 0) {  // the first record names the kind of file
         uint64_t p = cursor_;
         while (p < size_ && (data_[p] == '\n' || data_[p] == '\r')) p++;
@@ -538,7 +541,21 @@ inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, 
         fn(0);
         for (auto &t : th) t.join();
     };
-    run(nb, [&](unsigned i) { parse_block(border[i], border[i + 1], ~0ull, ~0ull, &blocks[i], false, 0); });
+    const bool timing = getenv("GDX_FASTX_TIMING") != nullptr;  // (debug: where a batch's time goes)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a0 = timing ? now() : 0.0;
+    run(nb, [&](unsigned i) {
+#ifdef MADV_POPULATE_READ
+        // the block's pages into this process's page table in one call (Linux 5.14+; an older kernel says EINVAL and the parse
+        // faults them in 64 KB at a time, which is what bounded it: sixteen threads took the mapping's lock thousands of times)
+        if (border[i + 1] > border[i]) {
+            const uint64_t a0 = border[i] & ~4095ull;
+            (void)madvise(const_cast<char *>(data_) + a0, border[i + 1] - a0, MADV_POPULATE_READ);
+        }
+#endif
+        parse_block(border[i], border[i + 1], ~0ull, ~0ull, &blocks[i], false, 0);
+    });
+    const double t_a1 = timing ? now() : 0.0;
     // every block must have ended exactly where the next one starts (the last one at the window's end)
     bool consistent = true;
     for (unsigned i = 0; i < nb; i++) consistent = consistent && blocks[i].ok && blocks[i].end == border[i + 1];
@@ -580,6 +597,7 @@ inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, 
         if (!full) stop_at = bk.end;
     }
     uint64_t lo = ~0ull, hi = 0;
+    const double t_b0 = timing ? now() : 0.0;
     run(nb, [&](unsigned i) {
         uint64_t at = base_sym[i];
         const Block &bk = blocks[i];
@@ -589,6 +607,9 @@ inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, 
             qoff[base_rec[i] + j + 1] = at;
         }
     });
+    if (timing)
+        std::fprintf(stderr, "gdx fastx batch: %u blocks, guesses %.4f s, parse %.4f s, limits %.4f s, copy %.4f s\n", nb, t_a0 - t_enter,
+                     t_a1 - t_a0, t_b0 - t_a1, now() - t_b0);
     for (unsigned i = 0; i < nb; i++)
         for (uint64_t j = 0; j < take[i] && (take[i] != blocks[i].recs.size()); j++) {  // (a block cut short: its own extremes)
             lo = blocks[i].recs[j].symbols < lo ? blocks[i].recs[j].symbols : lo;
