@@ -243,8 +243,9 @@ def end_to_end(np, torch, index, queries, nq, dev_counts, total_hits, step_ms, s
 
 def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_reads=8_000_000):
     """A FASTQ file of the batch's first reads -> gdx_fastx_next_batch_ex (the library's reader: the file memory-mapped, a batch
-    parsed by all host threads the process may use) -> gdx_pack_queries_table (2-bit codes, host threads) ->
-    gdx_locate_many_alloc_layout32, reader and packer one batch ahead of the GPU calls in a thread of their own.  What the
+    parsed by all host threads the process may use) -> gdx_locate_many_alloc_layout32 on the batch as it is, IO symbols of one
+    length (the call's own feeder packs its chunks into 2-bit codes straight into pinned memory; reads with an N take the ASCII
+    way there), the reader one batch ahead of the GPU calls in a thread of its own, on buffers touched beforehand.  What the
     reference's ROADMAP.md:35-37 worries about: reading the queries can cost more than searching them -- it still does (the
     kernels take 25 G reads a second), but by one order of magnitude less than with round 5's single parsing thread."""
     import ctypes as C
@@ -283,10 +284,13 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
         del os.environ["GDX_FASTX_THREADS"]
         q = queue.Queue(maxsize=1)
 
+        # (three buffer sets: one being filled, one in the queue, one in the GPU call -- no copy of a batch)
+        sets = fastx.make_batch_buffers(batch_reads, batch_reads * ln, 3)
+
         def producer():
-            # (three buffer sets: one being filled, one in the queue, one in the GPU call -- no copy of a batch)
-            for b in fastx.read_packed_batches(path, alpha, max_records=batch_reads, buffer_bytes=batch_reads * ln, n_buffers=3):
-                q.put((b["packed"], b["nq"], b["uniform_len"], b["exceptions"].size))
+            for qb, qo, ul in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, with_uniform_len=True,
+                                                 buffers=sets):
+                q.put((qb, qo, qo.size - 1, ul))
             q.put(None)
 
         lay = _lib.QueryLayout()
@@ -300,14 +304,14 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
             item = q.get()
             if item is None:
                 break
-            packed, bn, ul, ne = item
-            lay.packed, lay.uniform_len = 1, ul
+            qb, qo, bn, ul = item
+            lay.packed, lay.uniform_len = 0, ul
             r32 = _lib.Hits32()
-            _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, packed.ctypes.data_as(_lib.u8p), None, bn, C.byref(lay),
+            _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, qb.ctypes.data_as(_lib.u8p),
+                                                          None if ul else qo.ctypes.data_as(_lib.u64p), bn, C.byref(lay),
                                                           C.byref(r32), status.ctypes.data_as(_lib.u8p)))
             hits += r32.total_hits
             reads += bn
-            n_exc += ne
             lib.gdx_free_hits32(C.byref(r32))
         th.join()
         dt = time.perf_counter() - t0
@@ -318,8 +322,8 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
                 "reader_alone_qps": n / t_reader, "reader_alone_file_GBps": file_bytes / t_reader / 1e9,
                 "reader_alone_one_thread_qps": n / t_reader1, "batch_reads": batch_reads,
                 "hits": hits, "hits_identical_to_device_path": same,
-                "what": "FASTQ file -> gdx_fastx_next_batch_ex (mapped file, blocks parsed in parallel) -> gdx_pack_queries_table -> "
-                        "gdx_locate_many_alloc_layout32, reader and packer one batch ahead in a thread of their own"}
+                "what": "FASTQ file -> gdx_fastx_next_batch_ex (mapped file, blocks parsed in parallel) -> gdx_locate_many_alloc_layout32 on "
+                        "the ASCII batch (its feeder packs the chunks), the reader one batch ahead in a thread of its own, warm buffers"}
     finally:
         os.remove(path)
 

@@ -9,19 +9,30 @@ import numpy as np
 from . import _lib
 
 
-def read_batches(path: str, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28, with_uniform_len: bool = False):
+def make_batch_buffers(max_records: int, buffer_bytes: int, n_buffers: int = 1):
+    """buffer sets for read_batches, touched once (np.zeros): a reader that runs for long does not pay the first touch of
+    hundreds of megabytes inside every batch"""
+    return [(np.zeros(buffer_bytes, dtype=np.uint8), np.zeros(max_records + 1, dtype=np.uint64)) for _ in range(max(1, n_buffers))]
+
+
+def read_batches(path: str, max_records: int = 1 << 20, buffer_bytes: int = 1 << 28, with_uniform_len: bool = False,
+                 n_buffers: int = 1, buffers=None):
     """Yields (qbuf u8[total], qoff u64[n + 1]) for successive batches of at most max_records sequences whose
-    symbols fit into buffer_bytes; the arrays are views of reused buffers, copy them to keep them.  with_uniform_len: a third
-    item, the common length of the batch's sequences (0 when they differ), as the reader saw it (gdx_fastx_next_batch_ex).
-    A regular file is parsed by several threads (GDX_FASTX_THREADS; 0 = the streaming reader)."""
+    symbols fit into buffer_bytes; the arrays are views of reused buffers, copy them to keep them (with n_buffers = k -- or
+    `buffers`, sets made by make_batch_buffers -- a batch stays valid until k - 1 more have been taken).  with_uniform_len: a
+    third item, the common length of the batch's sequences (0 when they differ), as the reader saw it
+    (gdx_fastx_next_batch_ex).  A regular file is parsed by several threads (GDX_FASTX_THREADS; 0 = the streaming reader)."""
     lib = _lib.load()
     handle = C.c_void_p()
     _lib.check(lib.gdx_fastx_open(path.encode(), C.byref(handle)))
-    qbuf = np.empty(buffer_bytes, dtype=np.uint8)
-    qoff = np.empty(max_records + 1, dtype=np.uint64)
+    sets = buffers if buffers is not None else [(np.empty(buffer_bytes, dtype=np.uint8), np.empty(max_records + 1, dtype=np.uint64))
+                                                for _ in range(max(1, n_buffers))]
     n, ulen = C.c_uint64(0), C.c_uint64(0)
+    k = 0
     try:
         while True:
+            qbuf, qoff = sets[k % len(sets)]
+            k += 1
             _lib.check(lib.gdx_fastx_next_batch_ex(handle, qbuf.ctypes.data_as(C.c_void_p), buffer_bytes,
                                                    qoff.ctypes.data_as(C.c_void_p), max_records, C.byref(n), C.byref(ulen)))
             if n.value == 0:
