@@ -1709,7 +1709,7 @@ __device__ __forceinline__ uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uin
 // seed_k + 32 symbols, and the row is ISA[position] -- two fetches for a 32-symbol chunk instead of top entry + pair steps.
 constexpr uint32_t kTextMinSymbols = 8;
 template <int kJump, int kXlate, bool kCursor, bool kText = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kText ? 6 : 7, kText ? 6 : 7))) void search_exact_kernel4(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((kText && !kCursor) ? 6 : 7, (kText && !kCursor) ? 6 : 7))) void search_exact_kernel4(
     ExactView ix, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end, uint32_t *__restrict__ out_count,
     uint8_t *__restrict__ out_status, uint32_t range, int schedule, uint32_t *__restrict__ leftover,
