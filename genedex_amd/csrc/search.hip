@@ -2572,7 +2572,7 @@ struct SeedView {
 // search_exact_kernel4, which is the statement of what a cursor call does.  Lock-step groups of that kernel paid for the
 // slowest read of sixteen in every round (the absent k-mers' top table and pair steps); split by kind, both passes run dense.
 template <int kXlate, bool kExact, bool kCursor = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCursor ? 7 : 8, kCursor ? 7 : 8))) void search_seed_kernel4(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_seed_kernel4(
     SeedView sv, const uint8_t *__restrict__ qbuf, const uint64_t *__restrict__ qbeg, const uint64_t *__restrict__ qend,
     uint64_t nq, uint32_t *__restrict__ out_count, uint8_t *__restrict__ out_status, uint4 *__restrict__ out_rec,
     uint32_t *__restrict__ out_start, uint32_t *__restrict__ out_end,
