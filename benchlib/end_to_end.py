@@ -277,17 +277,18 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
         del rec
         alpha = alphabet.ascii_dna_with_n()
         t0 = time.perf_counter()
-        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
+        # (three buffer sets, touched once: one being filled, one in the queue, one in the GPU call -- no copy of a batch, and no
+        # first touch of 460 MB inside a batch: a reader that runs for long has warm buffers)
+        sets = fastx.make_batch_buffers(batch_reads, batch_reads * ln, 3)
+        t0 = time.perf_counter()
+        n_read = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, buffers=sets))
         t_reader = time.perf_counter() - t0
         os.environ["GDX_FASTX_THREADS"] = "0"  # (round 5's reader, for the record: one thread, a streaming read of the file)
         t0 = time.perf_counter()
-        n_read1 = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln))
+        n_read1 = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, buffers=sets))
         t_reader1 = time.perf_counter() - t0
         del os.environ["GDX_FASTX_THREADS"]
         q = queue.Queue(maxsize=1)
-
-        # (three buffer sets: one being filled, one in the queue, one in the GPU call -- no copy of a batch)
-        sets = fastx.make_batch_buffers(batch_reads, batch_reads * ln, 3)
 
         def producer():
             for qb, qo, ul in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, with_uniform_len=True,
