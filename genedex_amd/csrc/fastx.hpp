@@ -214,6 +214,7 @@ private:
         uint64_t symbols = 0, min_len = ~0ull, max_len = 0;
         bool ok = true;
         std::string error;     // (authoritative parse only)
+        std::vector<uint32_t> newlines;  // (FASTQ tiles: the offsets of the tile's '\n' bytes, see parse_block)
     };
     FastxMappedReader() = default;
     // one line from pos: [*b, *e) without '\n' and one trailing '\r'; returns the position behind it; pos == size_: no line
@@ -257,6 +258,10 @@ private:
     void parse_block(uint64_t from, uint64_t stop, uint64_t max_records, uint64_t max_symbols, Block *out, bool authoritative,
                      uint64_t first_number) const;
     uint64_t guess_record_start(uint64_t from, uint64_t limit) const;
+#ifdef GDX_FASTX_AVX2
+    static uint64_t newline_index_avx2(const char *p, uint64_t at, uint64_t len, std::vector<uint32_t> &out, uint64_t k);
+    void copy_records_avx2(const Rec *recs, uint64_t count, uint8_t *qbuf, uint64_t *qoff, uint64_t at) const;
+#endif
     void copy_record(const Rec &r, uint8_t *out) const;
 
     int fd_ = -1;
@@ -265,6 +270,7 @@ private:
     unsigned threads_ = 1;
     char kind_ = 0;  // '>' or '@': what the file's first record starts with
     double bytes_per_record_ = 0.0;
+    std::vector<Block> scratch_;  // a few per thread: a tile's descriptors (kept between tiles and batches: no fresh pages)
 };
 
 }  // namespace gdx
@@ -274,6 +280,9 @@ private:
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace gdx {
@@ -411,6 +420,42 @@ inline bool FastxMappedReader::record_at(uint64_t pos, Rec *r, uint64_t *next, b
     return false;
 }
 
+#ifdef GDX_FASTX_AVX2
+// the offsets of every '\n' in p[at, len), len < 2^32, appended to out[0, k) (out.size() is the room, grown as needed); returns the new
+// k.  64 bytes a step, the set bits of the compare mask written without a branch per bit (eight stores whatever the mask holds, the
+// cursor moves by its population count)
+__attribute__((target("avx2,bmi,popcnt"))) inline uint64_t FastxMappedReader::newline_index_avx2(const char *p, uint64_t at, uint64_t len,
+                                                                                                  std::vector<uint32_t> &out, uint64_t k)
+{
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; at + 64 <= len; at += 64) {
+        _mm_prefetch(p + at + 16384, _MM_HINT_T0);  // (the next 16 KB arrive while this one's records are checked)
+        const uint64_t m0 = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + at)), nl)));
+        const uint64_t m1 = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + at + 32)), nl)));
+        uint64_t m = m0 | (m1 << 32);
+        if (k + 64 > out.size()) out.resize(out.size() * 2);
+        uint32_t *o = out.data() + k;
+        const uint32_t base = static_cast<uint32_t>(at);
+        const unsigned c = static_cast<unsigned>(_mm_popcnt_u64(m));
+        for (int j = 0; j < 8; j++) {
+            o[j] = base + static_cast<uint32_t>(_tzcnt_u64(m));
+            m = _blsr_u64(m);
+        }
+        for (unsigned j = 8; j < c; j++) {
+            o[j] = base + static_cast<uint32_t>(_tzcnt_u64(m));
+            m = _blsr_u64(m);
+        }
+        k += c;
+    }
+    for (; at < len; at++)
+        if (p[at] == '\n') {
+            if (k + 1 > out.size()) out.resize(out.size() * 2);
+            out[k++] = static_cast<uint32_t>(at);
+        }
+    return k;
+}
+#endif
+
 inline void FastxMappedReader::parse_block(uint64_t from, uint64_t stop, uint64_t max_records, uint64_t max_symbols, Block *out,
                                            bool authoritative, uint64_t first_number) const
 {
@@ -423,11 +468,56 @@ inline void FastxMappedReader::parse_block(uint64_t from, uint64_t stop, uint64_
     out->min_len = ~0ull;
     out->max_len = 0;
     out->ok = true;
+    // A tile of a FASTQ file: all its newlines first (one vector pass), then a plain four-line record is four consecutive entries
+    // of that index and the conditions of record_at's own short cut, checked on them -- the same record, without four searches.
+    // Whatever is not that shape (blank lines, '\r', folded sequences, the file's last line without '\n') goes to record_at.
+    std::vector<uint32_t> &nl = out->newlines;
+    uint64_t n_nl = 0, k = 0, indexed = 0;  // nl[k, n_nl): the newlines of [pos, from + indexed) not yet used
+    const uint64_t tile_len = stop - from;    // (only read when `wide`)
+    bool wide = false;
+#ifdef GDX_FASTX_AVX2
+    static const bool can = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt");
+    const char *index_env = getenv("GDX_FASTX_NEWLINE_INDEX");  // (tests and experiments: 0 = every record by the line loops)
+    wide = can && (index_env == nullptr || atoi(index_env) != 0) && !authoritative && kind_ == '@' && stop <= size_ && stop > from && stop - from < 0xffffffffull;
+    if (wide && nl.size() < 4096) nl.resize(4096);
+#endif
     while (out->recs.size() < max_records && out->symbols <= max_symbols) {  // (the record that overflows is the last one parsed)
         // (blank lines in front of a block's border belong to the record behind them: stop at the border itself)
         if (pos >= stop) break;
         Rec r;
         uint64_t next = pos;
+#ifdef GDX_FASTX_AVX2
+        if (wide && k + 4 > n_nl && indexed < tile_len) {
+            // the next 16 KB of the tile into the index (what the records behind it left unused moves to the front): the bytes are
+            // in the first-level cache when the record checks below read them
+            std::memmove(nl.data(), nl.data() + k, (n_nl - k) * sizeof(uint32_t));
+            n_nl -= k;
+            k = 0;
+            while (n_nl < 4 && indexed < tile_len) {
+                const uint64_t upto = std::min<uint64_t>(tile_len, indexed + 16384);
+                n_nl = newline_index_avx2(data_ + from, indexed, upto, nl, n_nl);
+                indexed = upto;
+            }
+        }
+#endif
+        if (k + 4 <= n_nl && data_[pos] == '@') {
+            const uint64_t nx = from + nl[k] + 1, s_end = from + nl[k + 1], p_end = from + nl[k + 2], q_end = from + nl[k + 3];
+            const uint64_t n_sym = s_end - nx, q = p_end + 1;
+            if (s_end > nx && data_[s_end - 1] != '\r' && data_[s_end + 1] == '+' && q_end == q + n_sym && q + n_sym < size_ &&
+                data_[q_end - 1] != '\r' && nx - pos <= 0xffffffffull) {
+                r.start = pos;
+                r.seq = static_cast<uint32_t>(nx - pos);
+                r.one_line = 1;
+                r.symbols = n_sym;
+                out->recs.push_back(r);
+                out->symbols += n_sym;
+                out->min_len = n_sym < out->min_len ? n_sym : out->min_len;
+                out->max_len = n_sym > out->max_len ? n_sym : out->max_len;
+                pos = q_end + 1;
+                k += 4;
+                continue;
+            }
+        }
         bool bad = false;
         if (!record_at(pos, &r, &next, &bad, authoritative ? &out->error : nullptr, first_number + out->recs.size())) {
             if (bad) out->ok = false;
@@ -447,6 +537,8 @@ inline void FastxMappedReader::parse_block(uint64_t from, uint64_t stop, uint64_
         out->min_len = r.symbols < out->min_len ? r.symbols : out->min_len;
         out->max_len = r.symbols > out->max_len ? r.symbols : out->max_len;
         pos = next;
+        while (k < n_nl && from + nl[k] < pos) k++;  // (the index follows the record that went the long way)
+        if (k == n_nl && pos > from + indexed) indexed = std::min<uint64_t>(tile_len, pos - from);
     }
     out->end = pos;
 }
@@ -479,6 +571,32 @@ inline uint64_t FastxMappedReader::guess_record_start(uint64_t from, uint64_t li
     }
     return limit;
 }
+
+#ifdef GDX_FASTX_AVX2
+// a tile's records into qbuf from symbol `at`, their ends into qoff[1..count] (qoff points at the tile's first entry): one-line
+// records in 32-byte pieces that may run up to 31 bytes past the record -- into the room of the tile's next records, which are
+// written after it, never past the tile's own share of qbuf (the next tile's thread may be there already) or the mapping
+__attribute__((target("avx2"))) inline void FastxMappedReader::copy_records_avx2(const Rec *recs, uint64_t count, uint8_t *qbuf, uint64_t *qoff,
+                                                                                 uint64_t at) const
+{
+    uint64_t total = 0;
+    for (uint64_t j = 0; j < count; j++) total += recs[j].symbols;
+    const uint64_t dst_end = at + total;
+    for (uint64_t j = 0; j < count; j++) {
+        const Rec &r = recs[j];
+        const uint64_t src = r.start + r.seq, whole = (r.symbols + 31) & ~31ull;
+        if (r.one_line && at + whole <= dst_end && src + whole <= size_) {
+            for (uint64_t b = 0; b < whole; b += 32)
+                _mm256_storeu_si256(reinterpret_cast<__m256i *>(qbuf + at + b),
+                                    _mm256_loadu_si256(reinterpret_cast<const __m256i *>(data_ + src + b)));
+        } else {
+            copy_record(r, qbuf + at);
+        }
+        at += r.symbols;
+        qoff[j + 1] = at;
+    }
+}
+#endif
 
 inline void FastxMappedReader::copy_record(const Rec &r, uint8_t *out) const
 {
@@ -522,107 +640,200 @@ inline uint64_t FastxMappedReader::next_batch(uint8_t *qbuf, uint64_t capacity, 
     uint64_t w_end = size_ - cursor_ > static_cast<uint64_t>(want) ? cursor_ + static_cast<uint64_t>(want) : size_;
     if (w_end < size_) w_end = guess_record_start(w_end, size_);
     const uint64_t w_bytes = w_end - cursor_;
-    unsigned nb = threads_;
-    // a megabyte per thread at least (tests: GDX_FASTX_BLOCK_BYTES lowers that, so that small files are cut into blocks too)
-    uint64_t min_block = 1u << 20;
-    if (const char *e = getenv("GDX_FASTX_BLOCK_BYTES")) min_block = static_cast<uint64_t>(std::max(1L, atol(e)));
-    if (w_bytes < min_block * nb) nb = static_cast<unsigned>(w_bytes / min_block) + 1;
-    std::vector<uint64_t> border(nb + 1);
-    border[0] = cursor_;
-    border[nb] = w_end;
-    for (unsigned i = 1; i < nb; i++) {
-        const uint64_t at = cursor_ + w_bytes / nb * i;
-        border[i] = at <= border[i - 1] ? border[i - 1] : guess_record_start(at, w_end);
-    }
-    std::vector<Block> blocks(nb);
-    auto run = [&](unsigned n, auto &&fn) {
-        std::vector<std::thread> th;
-        for (unsigned i = 1; i < n; i++) th.emplace_back([&, i] { fn(i); });
-        fn(0);
-        for (auto &t : th) t.join();
+    // tiles of the window, taken in file order by whichever thread is free (tests: GDX_FASTX_BLOCK_BYTES lowers the size, so that
+    // small files are cut into tiles too).  Two megabytes: a tile's bytes and its descriptors are still in the core's caches when
+    // they are copied, and the mapping's lock is taken once per tile (MADV_POPULATE_READ), not once per fault
+    uint64_t tile_bytes = 2u << 20;
+    if (const char *e = getenv("GDX_FASTX_BLOCK_BYTES")) tile_bytes = static_cast<uint64_t>(std::max(1L, atol(e)));
+    const uint64_t n_tiles = std::max<uint64_t>(1, (w_bytes + tile_bytes - 1) / tile_bytes);
+    const unsigned nt = static_cast<unsigned>(std::min<uint64_t>(threads_, n_tiles));
+    constexpr unsigned kHeld = 4;  // parsed tiles a thread keeps while the tile in front of its oldest one is not through
+    if (scratch_.size() < nt * kHeld) scratch_.resize(nt * kHeld);
+    // A tile's share of the batch -- where its records go, how many of them fit the caller's limits -- is decided when every tile
+    // in front of it has been parsed: whichever thread finishes a parse moves that chain on (under the lock: a few stores per
+    // tile).  The tile's own thread then copies its records; if the decision is not there yet -- a thread in front was slow, the
+    // pipeline behind this reader takes the same CPUs -- it keeps the tile and parses the next one, up to kHeld of them.
+    struct Tile {
+        const Block *bk = nullptr;
+        uint64_t b = 0;                      // the border the tile must end at
+        bool parsed = false;                 // (under the lock)
+        uint64_t base_rec = 0, base_sym = 0, take = 0;
+        std::atomic<uint32_t> decided{0};
     };
+    std::unique_ptr<Tile[]> tiles(new Tile[n_tiles]);
+    std::mutex lock;
+    uint64_t next_tile = 0, next_border = cursor_, chain = 0;  // (under the lock) tiles handed out, tiles decided
+    bool stopped = false;                                      // (under the lock) a tile met the limits, or was inconsistent
+    std::atomic<bool> stop{false};
+    bool inconsistent = false, too_long = false;               // (under the lock, read after the join)
+    uint64_t n = 0, used = 0, stop_at = w_end, lo = ~0ull, hi = 0, too_long_symbols = 0;
     const bool timing = getenv("GDX_FASTX_TIMING") != nullptr;  // (debug: where a batch's time goes)
+    const char *populate_env = getenv("GDX_FASTX_POPULATE");
+    const bool populate = populate_env == nullptr || atoi(populate_env) != 0;
+    (void)populate;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = timing ? now() : 0.0;
-    run(nb, [&](unsigned i) {
-#ifdef MADV_POPULATE_READ
-        // the block's pages into this process's page table in one call (Linux 5.14+; an older kernel says EINVAL and the parse
-        // faults them in 64 KB at a time, which is what bounded it: sixteen threads took the mapping's lock thousands of times)
-        if (border[i + 1] > border[i]) {
-            const uint64_t a0 = border[i] & ~4095ull;
-            (void)madvise(const_cast<char *>(data_) + a0, border[i + 1] - a0, MADV_POPULATE_READ);
+    double t_stage[4] = {0.0, 0.0, 0.0, 0.0};  // (timing: thread-seconds mapping pages, parsing, waiting for a decision, copying)
+    auto move_chain_on = [&] {  // (the caller holds the lock)
+        while (chain < n_tiles && tiles[chain].parsed) {
+            Tile &tl = tiles[chain++];
+            const Block &bk = *tl.bk;
+            tl.base_rec = n, tl.base_sym = used, tl.take = 0;
+            if (stopped) {
+                // (nothing more is taken)
+            } else if (!bk.ok || bk.end != tl.b) {
+                // a tile must end exactly where the next one starts: a guess that was wrong, or a malformed record
+                inconsistent = stopped = true;
+            } else if (n + bk.recs.size() <= max_records && used + bk.symbols <= capacity) {  // the whole tile
+                tl.take = bk.recs.size();
+                n += tl.take, used += bk.symbols, stop_at = bk.end;
+            } else {  // what fits the caller's limits
+                for (const Rec &r : bk.recs) {
+                    if (n == max_records || r.symbols > capacity - used) {
+                        if (n == 0 && r.symbols > capacity) too_long = true, too_long_symbols = r.symbols;
+                        stop_at = r.start;
+                        break;
+                    }
+                    tl.take++, n++;
+                    used += r.symbols;
+                }
+                stopped = true;
+            }
+            if (stopped) stop.store(true, std::memory_order_relaxed);
+            tl.decided.store(1, std::memory_order_release);
         }
+    };
+    auto worker = [&](unsigned me) {
+        uint64_t held[kHeld];
+        unsigned n_held = 0, head = 0;  // held[(head + i) % kHeld], i < n_held: oldest first
+        uint64_t my_lo = ~0ull, my_hi = 0;
+        double my_t[4] = {0.0, 0.0, 0.0, 0.0}, t0 = 0.0, t1 = 0.0;
+        auto copy_tile = [&](const Tile &tl) {
+            const Block &bk = *tl.bk;
+            if (tl.take == 0) return;
+            if (timing) t0 = now();
+            if (tl.take == bk.recs.size()) {
+                my_lo = bk.min_len < my_lo ? bk.min_len : my_lo;
+                my_hi = bk.max_len > my_hi ? bk.max_len : my_hi;
+            } else {
+                for (uint64_t j = 0; j < tl.take; j++) {
+                    my_lo = bk.recs[j].symbols < my_lo ? bk.recs[j].symbols : my_lo;
+                    my_hi = bk.recs[j].symbols > my_hi ? bk.recs[j].symbols : my_hi;
+                }
+            }
+#ifdef GDX_FASTX_AVX2
+            static const bool avx2 = __builtin_cpu_supports("avx2");
+            if (avx2) {
+                copy_records_avx2(bk.recs.data(), tl.take, qbuf, qoff + tl.base_rec, tl.base_sym);
+            } else
 #endif
-        parse_block(border[i], border[i + 1], ~0ull, ~0ull, &blocks[i], false, 0);
-    });
-    const double t_a1 = timing ? now() : 0.0;
-    // every block must have ended exactly where the next one starts (the last one at the window's end)
-    bool consistent = true;
-    for (unsigned i = 0; i < nb; i++) consistent = consistent && blocks[i].ok && blocks[i].end == border[i + 1];
-    if (!consistent) {  // one thread, from the window's first byte: the authority
-        blocks.assign(1, Block());
-        nb = 1;
-        parse_block(cursor_, size_, max_records, capacity, &blocks[0], true, records_);
-        if (!blocks[0].ok && blocks[0].recs.empty()) fail(GDX_ERR_INVALID_ARGUMENT, "%s", blocks[0].error.c_str());
-        // (records in front of a malformed one are delivered; the error comes with the batch that starts at it)
-    }
-    // what fits the caller's limits
-    uint64_t n = 0, used = 0, stop_at = w_end;
-    std::vector<uint64_t> take(nb, 0), base_rec(nb, 0), base_sym(nb, 0);
-    bool full = false;
-    for (unsigned i = 0; i < nb && !full; i++) {
-        base_rec[i] = n;
-        base_sym[i] = used;
-        const Block &bk = blocks[i];
-        if (n + bk.recs.size() <= max_records && used + bk.symbols <= capacity) {  // the whole block
-            take[i] = bk.recs.size();
-            n += bk.recs.size();
-            used += bk.symbols;
-            stop_at = bk.end;
-            continue;
+            {
+                uint64_t at = tl.base_sym;
+                for (uint64_t j = 0; j < tl.take; j++) {
+                    copy_record(bk.recs[j], qbuf + at);
+                    at += bk.recs[j].symbols;
+                    qoff[tl.base_rec + j + 1] = at;
+                }
+            }
+            if (timing) my_t[3] += now() - t0;
+        };
+        bool no_more = false;
+        for (;;) {
+            while (n_held != 0 && tiles[held[head]].decided.load(std::memory_order_acquire) != 0u) {
+                copy_tile(tiles[held[head]]);
+                head = (head + 1) % kHeld;
+                n_held--;
+            }
+            if (no_more && n_held == 0) break;
+            if (no_more || n_held == kHeld) {  // nothing else to do: wait for the oldest tile's decision
+                if (timing) t0 = now();
+                for (unsigned spins = 0; tiles[held[head]].decided.load(std::memory_order_acquire) == 0u; spins++)
+                    if (spins > 64) std::this_thread::yield();
+                if (timing) my_t[2] += now() - t0;
+                continue;
+            }
+            if (stop.load(std::memory_order_relaxed)) {
+                no_more = true;
+                continue;
+            }
+            uint64_t t, a, b;
+            {  // the next tile and its borders: a guessed record start behind every multiple of the tile size
+                std::lock_guard<std::mutex> g(lock);
+                if (next_tile >= n_tiles) {
+                    no_more = true;
+                    continue;
+                }
+                t = next_tile++;
+                a = next_border;
+                const uint64_t at = cursor_ + tile_bytes * (t + 1);
+                b = (t + 1 == n_tiles || at >= w_end) ? w_end : (at <= a ? a : guess_record_start(at, w_end));
+                next_border = b;
+            }
+            if (timing) t0 = now();
+#ifdef MADV_POPULATE_READ
+            // the tile's pages into this process's page table in one call (Linux 5.14+; an older kernel says EINVAL and the parse
+            // faults them in 64 KB at a time)
+            if (b > a && populate) {
+                const uint64_t a0 = a & ~4095ull;
+                (void)madvise(const_cast<char *>(data_) + a0, b - a0, MADV_POPULATE_READ);
+            }
+#endif
+            if (timing) t1 = now(), my_t[0] += t1 - t0;
+            Block *bk = &scratch_[me * kHeld + (head + n_held) % kHeld];
+            parse_block(a, b, ~0ull, ~0ull, bk, false, 0);
+            if (timing) my_t[1] += now() - t1;
+            {
+                std::lock_guard<std::mutex> g(lock);
+                tiles[t].bk = bk, tiles[t].b = b, tiles[t].parsed = true;
+                move_chain_on();
+            }
+            held[(head + n_held) % kHeld] = t;
+            n_held++;
         }
+        std::lock_guard<std::mutex> g(lock);
+        lo = my_lo < lo ? my_lo : lo;
+        hi = my_hi > hi ? my_hi : hi;
+        for (int k = 0; k < 4; k++) t_stage[k] += my_t[k];
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; i++) th.emplace_back([&, i] { worker(i); });
+        worker(0);
+        for (auto &t : th) t.join();
+    }
+    const double t_a1 = timing ? now() : 0.0;
+    bool authority_failed = false;
+    if (inconsistent) {  // one thread, from the window's first byte: the authority
+        Block &bk = scratch_[0];
+        parse_block(cursor_, size_, max_records, capacity, &bk, true, records_);
+        if (!bk.ok && bk.recs.empty()) fail(GDX_ERR_INVALID_ARGUMENT, "%s", bk.error.c_str());
+        // (records in front of a malformed one are delivered; the error comes with the batch that starts at it)
+        authority_failed = !bk.ok;
+        n = 0, used = 0, stop_at = bk.end, lo = ~0ull, hi = 0;
+        too_long = false;
         for (const Rec &r : bk.recs) {
             if (n == max_records || r.symbols > capacity - used) {
-                if (n == 0 && r.symbols > capacity)
-                    fail(GDX_ERR_CAPACITY, "record %llu has %llu symbols, the buffer holds %llu", static_cast<unsigned long long>(records_),
-                         static_cast<unsigned long long>(r.symbols), static_cast<unsigned long long>(capacity));
+                if (n == 0 && r.symbols > capacity) too_long_symbols = r.symbols, too_long = true;
                 stop_at = r.start;
-                full = true;
                 break;
             }
-            take[i]++;
-            n++;
+            copy_record(r, qbuf + used);
             used += r.symbols;
+            qoff[++n] = used;
+            lo = r.symbols < lo ? r.symbols : lo;
+            hi = r.symbols > hi ? r.symbols : hi;
         }
-        if (!full) stop_at = bk.end;
     }
-    uint64_t lo = ~0ull, hi = 0;
-    const double t_b0 = timing ? now() : 0.0;
-    run(nb, [&](unsigned i) {
-        uint64_t at = base_sym[i];
-        const Block &bk = blocks[i];
-        for (uint64_t j = 0; j < take[i]; j++) {
-            copy_record(bk.recs[j], qbuf + at);
-            at += bk.recs[j].symbols;
-            qoff[base_rec[i] + j + 1] = at;
-        }
-    });
+    if (too_long)
+        fail(GDX_ERR_CAPACITY, "record %llu has %llu symbols, the buffer holds %llu", static_cast<unsigned long long>(records_),
+             static_cast<unsigned long long>(too_long_symbols), static_cast<unsigned long long>(capacity));
     if (timing)
-        std::fprintf(stderr, "gdx fastx batch: %u blocks, guesses %.4f s, parse %.4f s, limits %.4f s, copy %.4f s\n", nb, t_a0 - t_enter,
-                     t_a1 - t_a0, t_b0 - t_a1, now() - t_b0);
-    for (unsigned i = 0; i < nb; i++)
-        for (uint64_t j = 0; j < take[i] && (take[i] != blocks[i].recs.size()); j++) {  // (a block cut short: its own extremes)
-            lo = blocks[i].recs[j].symbols < lo ? blocks[i].recs[j].symbols : lo;
-            hi = blocks[i].recs[j].symbols > hi ? blocks[i].recs[j].symbols : hi;
-        }
-    for (unsigned i = 0; i < nb; i++)
-        if (take[i] != 0 && take[i] == blocks[i].recs.size()) {
-            lo = blocks[i].min_len < lo ? blocks[i].min_len : lo;
-            hi = blocks[i].max_len > hi ? blocks[i].max_len : hi;
-        }
+        std::fprintf(stderr, "gdx fastx batch: %llu tiles on %u threads, window %.4f s, tiles %.4f s (thread-seconds: map %.3f, parse %.3f, "
+                     "wait %.3f, copy %.3f), authority %.4f s\n", static_cast<unsigned long long>(n_tiles), nt, t_a0 - t_enter, t_a1 - t_a0,
+                     t_stage[0], t_stage[1], t_stage[2], t_stage[3], now() - t_a1);
     if (uniform_len && n != 0 && lo == hi) *uniform_len = lo;
     if (n != 0) bytes_per_record_ = static_cast<double>(stop_at - cursor_) / static_cast<double>(n);
-    if (n == 0 && !consistent && !blocks[0].ok) fail(GDX_ERR_INVALID_ARGUMENT, "%s", blocks[0].error.c_str());
+    if (n == 0 && authority_failed) fail(GDX_ERR_INVALID_ARGUMENT, "%s", scratch_[0].error.c_str());
     cursor_ = stop_at;
     records_ += n;
     return n;

@@ -54,7 +54,7 @@ int main(int argc, char **argv)
             std::unique_ptr<gdx::FastxMappedReader> reader(gdx::FastxMappedReader::open(argv[2], threads));
             if (!reader) {  // (an empty or missing file: the streaming reader decides)
                 gdx::FastxReader plain(argv[2]);
-                std::printf("ok 0 0 %" PRIu64 "\n", 1469598103934665603ull);
+                std::printf("ok 0 0 %" PRIu64 "\n", static_cast<uint64_t>(1469598103934665603ull));
                 return 0;
             }
             std::vector<uint8_t> qbuf(cap ? cap : 1);

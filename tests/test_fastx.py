@@ -257,7 +257,7 @@ def _random_fastx_file(rng, kind, n_records):
 
 
 @pytest.mark.parametrize("kind", ["fasta", "fastq"])
-@pytest.mark.parametrize("threads,block", [(0, 0), (1, 64), (3, 300), (8, 64), (8, 5000)])
+@pytest.mark.parametrize("threads,block", [(0, 0), (1, 64), (3, 300), (8, 64), (8, 5000), (5, 40000)])
 def test_the_mapped_reader_delivers_what_the_streaming_reader_delivers(tmp_path, monkeypatch, kind, threads, block):
     """gdx_fastx_next_batch on a regular file: the file is mapped and a batch parsed by several threads, blocks cut at guessed
     record starts and checked to meet (fastx.hpp FastxMappedReader); GDX_FASTX_THREADS=0 is the streaming reader of rounds 1-5.
@@ -281,6 +281,44 @@ def test_the_mapped_reader_delivers_what_the_streaming_reader_delivers(tmp_path,
             assert ulen == (int(lens[0]) if bool((lens == lens[0]).all()) else 0)
             got += [raw[int(qoff[i]):int(qoff[i + 1])] for i in range(n)]
         assert got == want, (max_records, buffer_bytes)
+
+
+@pytest.mark.parametrize("index", ["1", "0"])
+def test_the_mapped_reader_on_plain_records_with_a_few_odd_ones(tmp_path, monkeypatch, index):
+    """A FASTQ file as sequencers write it -- four lines a record -- with a wrapped, a CRLF and a blank-line-led record every few
+    thousand, several tiles of the default size and of 50 KB on six threads: tiles are handed out in file order, decided in that
+    order by whichever thread finishes a parse, and copied by their own threads (FastxMappedReader::next_batch); plain records
+    are found in the tile's newline index (parse_block), everything else by the line loops, which the index then follows."""
+    rng = np.random.default_rng(77)
+    n = 60_000
+    lens = rng.integers(1, 90, n)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(k))) for k in lens]
+    parts = []
+    for i, sq in enumerate(seqs):
+        q = b"@" * len(sq) if i % 7 == 0 else b"I" * len(sq)  # (quality lines that start with '@')
+        if i % 3001 == 5:
+            parts.append(b"\n@w%d\r\n%s\r\n+\r\n%s\r\n" % (i, sq, q))
+        elif i % 2503 == 7 and len(sq) > 4:
+            parts.append(b"@f%d\n%s\n%s\n+\n%s\n%s\n" % (i, sq[:3], sq[3:], q[:2], q[2:]))
+        else:
+            parts.append(b"@r%d some text\n%s\n+\n%s\n" % (i, sq, q))
+    path = tmp_path / "plain.fq"
+    path.write_bytes(b"".join(parts)[:-1])  # (no newline at the end of the file)
+    if index == "0":
+        monkeypatch.setenv("GDX_FASTX_NEWLINE_INDEX", "0")
+    for threads, block in ((0, 0), (6, 0), (6, 50_000), (2, 1 << 20)):
+        monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
+        if block:
+            monkeypatch.setenv("GDX_FASTX_BLOCK_BYTES", str(block))
+        else:
+            monkeypatch.delenv("GDX_FASTX_BLOCK_BYTES", raising=False)
+        for max_records, buffer_bytes in ((25_000, 1 << 22), (10 ** 6, 400_000)):
+            got = []
+            for qbuf, qoff, ulen in fastx.read_batches(str(path), max_records=max_records, buffer_bytes=buffer_bytes, with_uniform_len=True):
+                raw, k = qbuf.tobytes(), qoff.size - 1
+                assert 0 < k <= max_records and int(qoff[-1]) <= buffer_bytes and ulen == 0
+                got += [raw[int(qoff[i]):int(qoff[i + 1])] for i in range(k)]
+            assert got == seqs, (threads, block, max_records)
 
 
 @pytest.mark.parametrize("threads", [0, 4])
