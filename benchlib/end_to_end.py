@@ -288,40 +288,50 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
         n_read1 = sum(qo.size - 1 for _, qo in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, buffers=sets))
         t_reader1 = time.perf_counter() - t0
         del os.environ["GDX_FASTX_THREADS"]
-        q = queue.Queue(maxsize=1)
-
-        def producer():
-            for qb, qo, ul in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, with_uniform_len=True,
-                                                 buffers=sets):
-                q.put((qb, qo, qo.size - 1, ul))
-            q.put(None)
-
         lay = _lib.QueryLayout()
         lib.gdx_query_layout_init(C.byref(lay))
         status = np.empty(batch_reads, dtype=np.uint8)
-        t0 = time.perf_counter()
-        th = threading.Thread(target=producer)
-        th.start()
-        hits, reads, n_exc = 0, 0, 0
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            qb, qo, bn, ul = item
-            lay.packed, lay.uniform_len = 0, ul
-            r32 = _lib.Hits32()
-            _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, qb.ctypes.data_as(_lib.u8p),
-                                                          None if ul else qo.ctypes.data_as(_lib.u64p), bn, C.byref(lay),
-                                                          C.byref(r32), status.ctypes.data_as(_lib.u8p)))
-            hits += r32.total_hits
-            reads += bn
-            lib.gdx_free_hits32(C.byref(r32))
-        th.join()
-        dt = time.perf_counter() - t0
+
+        def file_to_hits():
+            q = queue.Queue(maxsize=1)
+
+            def producer():
+                for qb, qo, ul in fastx.read_batches(path, max_records=batch_reads, buffer_bytes=batch_reads * ln, with_uniform_len=True,
+                                                     buffers=sets):
+                    q.put((qb, qo, qo.size - 1, ul))
+                q.put(None)
+
+            t0 = time.perf_counter()
+            th = threading.Thread(target=producer)
+            th.start()
+            hits, reads = 0, 0
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                qb, qo, bn, ul = item
+                lay.packed, lay.uniform_len = 0, ul
+                r32 = _lib.Hits32()
+                _lib.check(lib.gdx_locate_many_alloc_layout32(index._h, qb.ctypes.data_as(_lib.u8p),
+                                                              None if ul else qo.ctypes.data_as(_lib.u64p), bn, C.byref(lay),
+                                                              C.byref(r32), status.ctypes.data_as(_lib.u8p)))
+                hits += r32.total_hits
+                reads += bn
+                lib.gdx_free_hits32(C.byref(r32))
+            th.join()
+            return time.perf_counter() - t0, hits, reads
+
+        # (three passes over the file, the best one reported and all of them listed: the host is shared, and a pass is 60 ms)
+        runs = [file_to_hits() for _ in range(3)]
+        dt = min(r[0] for r in runs)
+        hits, reads, n_exc = runs[0][1], runs[0][2], 0
+        if any(r[1:] != runs[0][1:] for r in runs):
+            raise SystemExit(f"PARITY FAILURE: FASTQ -> hits differs between passes: {runs}")
         same = reads == n and n_read == n and n_read1 == n and n_exc == 0 and hits == int(offs[n])
         if not same:
             raise SystemExit(f"PARITY FAILURE: FASTQ -> hits gave {reads} reads / {hits} hits, the device path {n} / {int(offs[n])}")
-        return {"reads": n, "file_bytes": file_bytes, "fastq_to_hits_qps": n / dt, "seconds": dt, "file_GBps": file_bytes / dt / 1e9,
+        return {"reads": n, "file_bytes": file_bytes, "fastq_to_hits_qps": n / dt, "seconds": dt, "seconds_of_every_pass": [r[0] for r in runs],
+                "file_GBps": file_bytes / dt / 1e9,
                 "reader_alone_qps": n / t_reader, "reader_alone_file_GBps": file_bytes / t_reader / 1e9,
                 "reader_alone_one_thread_qps": n / t_reader1, "batch_reads": batch_reads,
                 "hits": hits, "hits_identical_to_device_path": same,

@@ -182,15 +182,21 @@ private:
 };
 
 // ---- the same reader over a memory-mapped file, records parsed by several threads (round 6) ----------------------------------
-// One thread parsing a FASTQ file delivers 60 M reads a second; the calls behind it take 3 G (ROADMAP.md:35-37 of the reference
-// names reading the queries as a cost of its own).  Here a batch is made in two parallel passes over a window of the mapped file:
-//   A  the window is cut into one block per thread at guessed record starts -- FASTA: a line that starts with '>'; FASTQ: a line
-//      that starts with '@' from which two whole records parse (a quality line may start with '@' too) -- and every thread parses
-//      its block with the SAME rules as FastxReader::read_record into descriptors {record start, first sequence byte, symbols};
-//      a block must end exactly where the next one starts: a guess that was wrong (or a malformed record) shows there, and the
-//      window is parsed again by one thread from its first byte, which is the authority for errors and their messages;
-//   B  the records that fit the caller's limits are copied into qbuf / qoff, every thread its block's share.
-// Results are FastxReader's, byte for byte (tests/test_fastx.py runs both on the same files).
+// One thread parsing a FASTQ file delivers 60 M reads a second; the calls behind it take 1-3 G (ROADMAP.md:35-37 of the reference
+// names reading the queries as a cost of its own).  Here a batch is made from a window of the mapped file cut into tiles of 2 MB
+// at guessed record starts -- FASTA: a line that starts with '>'; FASTQ: a line that starts with '@' from which two whole records
+// parse (a quality line may start with '@' too) -- which the threads take in file order:
+//   parse   a tile with the SAME rules as FastxReader::read_record into descriptors {record start, first sequence byte, symbols};
+//           plain four-line FASTQ records are read off an index of the tile's newlines (one vector pass per 16 KB), everything
+//           else goes through the line loops.  A tile must end exactly where the next one starts: a guess that was wrong (or a
+//           malformed record) shows there, and the window is parsed again by one thread from its first byte, which is the
+//           authority for errors and their messages;
+//   decide  where a tile's records go in qbuf / qoff and how many fit the caller's limits needs the totals of the tiles in front:
+//           whichever thread finishes a parse moves that chain on as far as the parsed tiles reach (a few stores per tile);
+//   copy    by the tile's own thread, as a rule right after its parse, when the tile's bytes and descriptors are still in the
+//           core's caches; a thread whose tile is not decided yet keeps it and parses on (a few tiles, then it waits).
+// Results are FastxReader's, byte for byte (tests/test_fastx.py runs both on the same files).  On the bench host: 330 M reads/s
+// with one block per thread and two passes (parse all, copy all), 800 M with the tiles (16 threads, 50-symbol reads).
 class FastxMappedReader {
 public:
     // null when the file cannot be mapped (a pipe, an empty file): the caller falls back to FastxReader
