@@ -133,6 +133,8 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
 
+    # (the pool's host driver shares device memory between processes through dmabuf only: RCCL needs this, and inherits it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
