@@ -83,10 +83,28 @@ def read_packed_batches(path: str, alphabet, max_records: int = 1 << 20, buffer_
         lib.gdx_fastx_close(handle)
 
 
-def read_sequences(path: str):
-    """All sequences of a (small) file as a list of bytes objects, e.g. the texts of an index."""
+def read_sequences(path: str, buffer_bytes: int = 1 << 26):
+    """All sequences of a file as a list of bytes objects, e.g. the texts of an index from a genome's FASTA file.  A record
+    larger than the buffer (a chromosome) is GDX_ERR_CAPACITY from the reader, which stays at that record: the buffer is
+    doubled and the call repeated."""
+    lib = _lib.load()
+    handle = C.c_void_p()
+    _lib.check(lib.gdx_fastx_open(path.encode(), C.byref(handle)))
+    max_records = 1 << 16
+    qbuf, qoff = np.empty(buffer_bytes, dtype=np.uint8), np.empty(max_records + 1, dtype=np.uint64)
+    n = C.c_uint64(0)
     out = []
-    for qbuf, qoff in read_batches(path, max_records=1 << 16, buffer_bytes=1 << 26):
-        raw = qbuf.tobytes()
-        out.extend(raw[int(qoff[i]):int(qoff[i + 1])] for i in range(qoff.size - 1))
-    return out
+    try:
+        while True:
+            st = lib.gdx_fastx_next_batch_ex(handle, qbuf.ctypes.data_as(C.c_void_p), qbuf.size, qoff.ctypes.data_as(C.c_void_p),
+                                             max_records, C.byref(n), None)
+            if st == _lib.GDX_ERR_CAPACITY:
+                qbuf = np.empty(qbuf.size * 2, dtype=np.uint8)
+                continue
+            _lib.check(st)
+            if n.value == 0:
+                return out
+            raw = qbuf[: int(qoff[n.value])].tobytes()
+            out.extend(raw[int(qoff[i]):int(qoff[i + 1])] for i in range(n.value))
+    finally:
+        lib.gdx_fastx_close(handle)

@@ -597,7 +597,8 @@ int gdx_multi_locate_many_alloc(const gdx_multi_t *m, const uint8_t *qbuf, const
  * more than searching).  FASTA: '>' headers, sequences over any number of lines; FASTQ: '@' header, sequence
  * lines, '+' line, as many quality characters as symbols; '\r' dropped; bytes copied as they are (the alphabet
  * decides what is valid).  gdx_fastx_next_batch reads up to max_records records that fit into qbuf_capacity
- * bytes, *n_out = 0 at the end of the file; a record larger than the whole buffer is GDX_ERR_CAPACITY. */
+ * bytes, *n_out = 0 at the end of the file; a record larger than the whole buffer is GDX_ERR_CAPACITY, and the reader stays
+ * at that record: call again with a larger buffer (genedex_amd.fastx.read_sequences doubles it). */
 typedef struct gdx_fastx gdx_fastx_t;
 int gdx_fastx_open(const char *path, gdx_fastx_t **out);
 int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,

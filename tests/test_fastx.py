@@ -321,6 +321,40 @@ def test_the_mapped_reader_on_plain_records_with_a_few_odd_ones(tmp_path, monkey
             assert got == seqs, (threads, block, max_records)
 
 
+@pytest.mark.parametrize("threads", [0, 3])
+def test_a_record_larger_than_the_buffer_is_read_after_the_buffer_grew(tmp_path, monkeypatch, threads):
+    """gdx_fastx_next_batch[_ex]: GDX_ERR_CAPACITY for a record that cannot fit, the reader stays at it (both readers);
+    fastx.read_sequences doubles its buffer -- a chromosome in a genome's FASTA file is such a record."""
+    import ctypes as C
+
+    from genedex_amd import _lib
+
+    monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
+    monkeypatch.setenv("GDX_FASTX_BLOCK_BYTES", "4096")
+    rng = np.random.default_rng(5)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), k)) for k in (300, 70_000, 20, 150_000, 5)]
+    path = tmp_path / "long.fa"
+    path.write_bytes(b"".join(b">s%d\n" % i + b"\n".join(sq[j:j + 70] for j in range(0, len(sq), 70)) + b"\n" for i, sq in enumerate(seqs)))
+    assert fastx.read_sequences(str(path), buffer_bytes=1 << 10) == seqs
+    lib = _lib.load()
+    handle = C.c_void_p()
+    _lib.check(lib.gdx_fastx_open(str(path).encode(), C.byref(handle)))
+    try:
+        qbuf, qoff, n = np.empty(1 << 18, dtype=np.uint8), np.empty(9, dtype=np.uint64), C.c_uint64(0)
+        call = lambda cap: lib.gdx_fastx_next_batch_ex(handle, qbuf.ctypes.data_as(C.c_void_p), cap, qoff.ctypes.data_as(C.c_void_p), 8,
+                                                       C.byref(n), None)
+        assert call(1000) == 0 and n.value == 1                  # the first record fits, the second does not: one record
+        assert call(1000) == _lib.GDX_ERR_CAPACITY               # now the long one is first
+        assert b"70000 symbols" in lib.gdx_last_error()
+        assert call(1000) == _lib.GDX_ERR_CAPACITY               # ... and stays first
+        rest = b""  # (a batch may hold fewer records than would fit: the mapped reader sizes its window from the records so far)
+        while call(1 << 18) == 0 and n.value != 0:
+            rest += qbuf[: int(qoff[n.value])].tobytes()
+        assert rest == b"".join(seqs[1:]) and n.value == 0
+    finally:
+        lib.gdx_fastx_close(handle)
+
+
 @pytest.mark.parametrize("threads", [0, 4])
 def test_malformed_records_are_reported_by_either_reader(tmp_path, monkeypatch, threads):
     monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
