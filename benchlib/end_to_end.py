@@ -273,6 +273,9 @@ def fastq_to_hits(np, index, qbuf, qoff, nq, offs, n_reads=24_000_000, batch_rea
         path = f.name
     try:
         rec.tofile(path)
+        fd = os.open(path, os.O_RDONLY)  # (a file that has been written back: what a reader of sequencing data meets)
+        os.fsync(fd)
+        os.close(fd)
         file_bytes = os.path.getsize(path)
         del rec
         alpha = alphabet.ascii_dna_with_n()
