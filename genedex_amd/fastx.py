@@ -83,10 +83,15 @@ def read_packed_batches(path: str, alphabet, max_records: int = 1 << 20, buffer_
         lib.gdx_fastx_close(handle)
 
 
-def read_sequences(path: str, buffer_bytes: int = 1 << 26):
-    """All sequences of a file as a list of bytes objects, e.g. the texts of an index from a genome's FASTA file.  A record
-    larger than the buffer (a chromosome) is GDX_ERR_CAPACITY from the reader, which stays at that record: the buffer is
-    doubled and the call repeated."""
+def read_sequences(path: str, buffer_bytes: int | None = None):
+    """All sequences of a file as a list of bytes objects, e.g. the texts of an index from a genome's FASTA file.  The buffer
+    is as large as a regular file (at most 4 GB at a time: the symbols cannot be more than the file's bytes, so a genome is one
+    batch), 64 MB otherwise; a record larger than the buffer is GDX_ERR_CAPACITY from the reader, which stays at that record:
+    the buffer is doubled and the call repeated."""
+    import os
+
+    if buffer_bytes is None:
+        buffer_bytes = min(max(os.path.getsize(path), 1 << 16), 1 << 32) if os.path.isfile(path) else 1 << 26
     lib = _lib.load()
     handle = C.c_void_p()
     _lib.check(lib.gdx_fastx_open(path.encode(), C.byref(handle)))
