@@ -20,8 +20,11 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 for s, e, n in rows:
-    m = re.search(r"(gdx::[A-Za-z0-9_]+(?:<[^>(]*>)?)", n)
-    print(f"{(e - s) / 1e6:9.3f} ms  {m.group(1) if m else n[:60]}")
+    # the kernel's own name with its template arguments: what stands in front of the parameter list, namespaces dropped
+    # (the first "gdx::" of a kernel in the anonymous namespace is in its parameters)
+    head = re.sub(r"\(anonymous namespace\)::", "", n)
+    m = re.match(r"(?:void )?(?:gdx::)?([A-Za-z0-9_]+(?:<[^()]*>)?)\(", head)
+    print(f"{(e - s) / 1e6:9.3f} ms  {m.group(1) if m else n[:80]}")
 PY
 find $OUT/trace -name '*.csv' -delete
 tail -40 $OUT/launches.txt
