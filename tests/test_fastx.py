@@ -321,6 +321,54 @@ def test_the_mapped_reader_on_plain_records_with_a_few_odd_ones(tmp_path, monkey
             assert got == seqs, (threads, block, max_records)
 
 
+def test_random_files_limits_threads_and_tile_sizes(tmp_path, monkeypatch):
+    """60 random files x 3 random (threads, tile bytes, max_records, buffer bytes): the mapped reader delivers the streaming
+    reader's batches' records in its order, fails where it fails (a record larger than the buffer) and names the same batch
+    property (uniform length).  1100 files x 4 ran clean when the tiles were written (round 6)."""
+    from genedex_amd import _lib
+
+    rng = np.random.default_rng(606)
+    for trial in range(60):
+        kind = "fastq" if trial % 3 else "fasta"
+        n_rec = int(rng.integers(1, 300))
+        if trial % 5 == 0:  # what sequencers write, a blank line or an '@' quality line here and there
+            want = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(1, 200)))) for _ in range(n_rec)]
+            data = b"".join((b"\n" if rng.random() < 0.02 else b"") + b"@r%d\n%s\n+\n%s\n" % (i, sq, (b"@" if rng.random() < 0.2 else b"I") * len(sq))
+                            for i, sq in enumerate(want))
+            data, kind = (data[:-1] if rng.random() < 0.5 else data), "fastq"
+        else:
+            data, want = _random_fastx_file(rng, kind, n_rec)
+        path = tmp_path / f"f{trial}.{kind}"
+        path.write_bytes(data)
+
+        def run(threads, block, max_records, cap):
+            monkeypatch.setenv("GDX_FASTX_THREADS", str(threads))
+            if block:
+                monkeypatch.setenv("GDX_FASTX_BLOCK_BYTES", str(block))
+            else:
+                monkeypatch.delenv("GDX_FASTX_BLOCK_BYTES", raising=False)
+            out = []
+            try:
+                for qb, qo, ul in fastx.read_batches(str(path), max_records=max_records, buffer_bytes=cap, with_uniform_len=True):
+                    raw, k = qb.tobytes(), qo.size - 1
+                    lens = np.diff(qo.astype(np.int64))
+                    assert 0 < k <= max_records and int(qo[-1]) <= cap
+                    assert ul == (int(lens[0]) if bool((lens == lens[0]).all()) else 0)
+                    out += [raw[int(qo[i]):int(qo[i + 1])] for i in range(k)]
+            except _lib.GdxError as e:
+                return out, e.status
+            return out, None
+
+        longest = max([len(w) for w in want] + [1])
+        for _ in range(3):
+            threads, block = int(rng.integers(1, 12)), int(rng.choice([16, 64, 300, 2000, 20000, 0]))
+            max_records = int(rng.choice([1, 2, 7, 100, 10 ** 6]))
+            cap = int(rng.choice([max(1, longest - 1), longest, longest + 3, 5 * longest, 10 ** 7]))
+            a, b = run(0, 0, max_records, cap), run(threads, block, max_records, cap)
+            assert a == b, (trial, kind, threads, block, max_records, cap)
+            assert a[1] == _lib.GDX_ERR_CAPACITY if cap < longest else (a[1] is None and a[0] == want)
+
+
 @pytest.mark.parametrize("threads", [0, 3])
 def test_a_record_larger_than_the_buffer_is_read_after_the_buffer_grew(tmp_path, monkeypatch, threads):
     """gdx_fastx_next_batch[_ex]: GDX_ERR_CAPACITY for a record that cannot fit, the reader stays at it (both readers);
