@@ -29,7 +29,7 @@ counts = np.empty(nq, dtype=np.uint64)
 offs = np.empty(nq + 1, dtype=np.uint64)
 qb_p, qo_p = qbuf.ctypes.data_as(_lib.u8p), qoff.ctypes.data_as(_lib.u64p)
 ref = {}
-for pack in ("1", "0"):
+for pack in (("1", "0") if os.environ.get("GDX_EXP_BOTH", "1") == "1" else ("1",)):
     os.environ["GDX_HOST_PACK"] = pack
     for rep in range(3):
         t0 = time.perf_counter()
