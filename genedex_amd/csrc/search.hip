@@ -6,6 +6,26 @@
 // jump table and the top table.  search_kernel<Table, lanes>: the same search one LF step at
 // a time on the rank lines (1 or 4 lanes per query) or on the generic planes of wide alphabets; also the readable
 // statement of what the pair kernels compute.
+//
+// What is in this file, in its order (DESIGN.md section 4 has a row for each kernel with its bound and its bytes):
+//   query windows        QueryWindow / PackedQueryWindow / FastWindow, query_words: a query's symbols, eight per load, from IO bytes
+//                        (translated through the alphabet's table or two v_perm tables) or from 2-bit codes
+//   general kernels      search_kernel<Table, lanes> (rank lines / generic planes, one LF step per fetch), search_pair_kernel4/8 and
+//                        their _defer variants (pair lines: two symbols per fetch; top table, jump table), search_pair_packed_kernel4
+//                        (the same on 2-bit reads, resumes from a state), search_pair_stats_kernel4/8 (the step counters the bench prints)
+//   slim kernels         search_fast_kernel4 (top + jump table, count / locate), search_exact_kernel4<jump, translation, cursor, text>
+//                        (exact intervals and cursor chunks; `text`: SA[row] -> text -> ISA in the jump table's place)
+//   seed-table kernels   search_seed_lane_kernel (one bucket fetch per read, a lane per read: the headline's kernel),
+//                        search_seed_kernel4<translation, exact, cursor> (four lanes per read: exact intervals through the ISA, the
+//                        cursor API's first chunk, alphabets and buffers the lane kernel does not take), search_verify_kernel4
+//                        (listed reads: up to four rows against the text), seed_text_kernel4 (long reads: the text in front of the seed)
+//   operator level       extend_front_kernel (Cursor::extend_query_front), rank_many_kernel, symbol_at_kernel, lf_walk_kernel
+//   tables and helpers   fill_lookup_kernel, fill_top_kernel, top_wide_kernel, pack_queries_kernel, zero_segments_kernel,
+//                        fill_uniform_offsets[_list]_kernel, tile_sums_lists_kernel
+//   launch_search        intervals of a batch with the general kernels (query options choose the variant)
+//   launch_search_call   ONE search call of any kind (count / records / compact results / exact intervals / cursor chunk) on any
+//                        index shape: picks the kernels above, chains their lists, folds the hit totals -- the only place that
+//                        knows which kernel serves which shape
 #include <atomic>
 #include <cstdlib>
 #include <string>
