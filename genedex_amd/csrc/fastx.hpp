@@ -481,6 +481,7 @@ inline void FastxMappedReader::parse_block(uint64_t from, uint64_t stop, uint64_
     uint64_t n_nl = 0, k = 0, indexed = 0;  // nl[k, n_nl): the newlines of [pos, from + indexed) not yet used
     const uint64_t tile_len = stop - from;    // (only read when `wide`)
     bool wide = false;
+    (void)wide, (void)tile_len, (void)indexed, (void)k, (void)n_nl;
 #ifdef GDX_FASTX_AVX2
     static const bool can = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt");
     const char *index_env = getenv("GDX_FASTX_NEWLINE_INDEX");  // (tests and experiments: 0 = every record by the line loops)

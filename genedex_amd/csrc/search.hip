@@ -2245,7 +2245,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
     // != 0: an interval wider than max_rows is not narrowed here, one rank-line step per symbol and sixteen reads waiting for the
     // widest: the read goes to the general kernel's list with its state, which steps two symbols per pair-line fetch and has
     // nothing but such reads in its wavefronts
-    uint32_t wide_to_list)
+    uint32_t wide_to_list,
+    // != 0: the states are the packed ones of the seed kernels (kStatePacked / kStatePlain): a read with at most 32 symbols in
+    // front of its seed brings them along as 2-bit codes, and neither its offsets nor its bytes are fetched again -- one of the
+    // four DRAM lines a read from a repeat cost here.  A read this kernel hands on gets the plain state {lo, hi, symbols, 1} back
+    uint32_t state_packed)
 {
     constexpr int kGroup = 4;
     __shared__ uint8_t s_dense[256];
@@ -2276,9 +2280,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
         const uint32_t cnt = nq - base < range ? static_cast<uint32_t>(nq - base) : range;
         for (uint32_t slot = threadIdx.x / kGroup; slot < cnt; slot += kBlock / kGroup) {
             const uint32_t q = list != nullptr ? list[base + slot] : static_cast<uint32_t>(base + slot);
-            const uint64_t begin = query_begin(qbeg, ulen, q);
-            const uint64_t len = query_end(qend, ulen, q) - begin;
-            bool bail = kSeed ? !(len >= vv.seed_k && len < (1ull << 21)) : !(len >= 16u && len >= depth && len < (1ull << 21));
+            uint4 st = make_uint4(0u, 0u, 0u, 0u);
+            if (kSeed && state != nullptr) st = state[q];
+            // (a read that is finished from its packed state never asks where its bytes are: the seed kernel has checked its length)
+            const bool from_state = kSeed && state != nullptr && state_packed != 0u && wide_to_list != 0u && (st.y & kStatePacked) != 0u &&
+                                    (st.y & 0x1fffffu) <= 32u;
+            const uint64_t begin = from_state ? 0ull : query_begin(qbeg, ulen, q);
+            const uint64_t len = from_state ? 0ull : query_end(qend, ulen, q) - begin;
+            bool bail = from_state ? false
+                                   : (kSeed ? !(len >= vv.seed_k && len < (1ull << 21)) : !(len >= 16u && len >= depth && len < (1ull << 21)));
             uint32_t lo = 0, hi = 0, rem = 0;
             const uint64_t *wbase = query_words<kXlate>(qbuf, begin);
             const uint32_t off0 = static_cast<uint32_t>(begin & 7u);
@@ -2288,15 +2298,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             bool single_ok = false;        // ... and the (up to) 32 symbols in front of it are the query's
             uint32_t pos = 0;              // SA of this lane's row
             bool resumed = false;
-            if (kSeed && !bail && state != nullptr) {
-                const uint4 st = state[q];
-                if (st.w == 1u) {  // the seed kernel found the k-mer on several rows
+            const uint64_t state_codes = (static_cast<uint64_t>(st.z) << 32) | st.w;  // from_state: the symbols in front of the seed
+            if (from_state) {
+                resumed = true;
+                lo = st.x;
+                hi = lo + (st.y >> 24);
+                rem = st.y & 0x1fffffu;
+            } else if (kSeed && !bail && state != nullptr) {
+                // the seed kernel found the k-mer on several rows: {lo, hi, symbols, 1}, or one of the packed forms
+                const bool plain = state_packed == 0u && st.w == 1u;
+                const bool p_rows = state_packed != 0u && (st.y & kStatePacked) != 0u, p_wide = state_packed != 0u && (st.y & kStatePlain) != 0u;
+                if (plain || p_rows || p_wide) {
                     resumed = true;
                     rem = static_cast<uint32_t>(len);
                     w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem, sub);
                     lo = st.x;
-                    hi = st.y;
-                    rem = st.z;
+                    hi = plain ? st.y : (p_rows ? lo + (st.y >> 24) : st.z);
+                    rem = plain ? st.z : st.y & 0x1fffffu;
                     shift = vv.seed_k >> 3;
                     part = vv.seed_k & 7u;
                 }
@@ -2462,39 +2480,44 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
                     first = false;
                 }
                 while (rem_v > 0u) {
-                    if (!first) {
-                        w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem_v, sub);
-                        shift = 0;
-                    }
-                    first = false;
                     const uint32_t n_v = rem_v < 32u ? rem_v : 32u;
-                    // validity of the query words these symbols come from (group-uniform)
-                    const uint32_t v8 = w.valid8 >> shift;
-                    const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));
-                    const uint32_t n_full = n_v >> 3, n_tail = n_v & 7u;
-                    bool clean = (vl & ((1u << n_full) - 1u)) == ((1u << n_full) - 1u);
-                    if (n_tail != 0u) clean = clean && ((v8 >> n_full) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_full + 1u)) & 1u) != 0u);
-                    if (!clean) {
-                        bail = true;
-                        break;
-                    }
-                    uint32_t a0, a1;  // levels shift, shift + 1 | shift + 2, shift + 3 of the window
-                    if (shift == 0u) {
-                        a0 = w.l0;
-                        a1 = w.l1;
-                    } else if (shift == 1u) {
-                        a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
-                        a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
-                    } else if (shift == 2u) {
-                        a0 = w.l1;
-                        a1 = w.l2;
+                    uint64_t qcode;  // the 32 symbols [rem_v - 32, rem_v) in text order, the one next to the seed in the top bits
+                    if (from_state) {
+                        qcode = state_codes;  // (all of them: at most 32, clean -- the seed kernel listed the read with them)
                     } else {
-                        a0 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
-                        a1 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                        if (!first) {
+                            w = fast_window<kXlate>(vv, s_dense, wbase, off0, rem_v, sub);
+                            shift = 0;
+                        }
+                        first = false;
+                        // validity of the query words these symbols come from (group-uniform)
+                        const uint32_t v8 = w.valid8 >> shift;
+                        const uint32_t vl = v8 & (w.s0 == 8u ? 0xffu : (v8 >> 1));
+                        const uint32_t n_full = n_v >> 3, n_tail = n_v & 7u;
+                        bool clean = (vl & ((1u << n_full) - 1u)) == ((1u << n_full) - 1u);
+                        if (n_tail != 0u) clean = clean && ((v8 >> n_full) & 1u) != 0u && (n_tail <= w.s0 || ((v8 >> (n_full + 1u)) & 1u) != 0u);
+                        if (!clean) {
+                            bail = true;
+                            break;
+                        }
+                        uint32_t a0, a1;  // levels shift, shift + 1 | shift + 2, shift + 3 of the window
+                        if (shift == 0u) {
+                            a0 = w.l0;
+                            a1 = w.l1;
+                        } else if (shift == 1u) {
+                            a0 = __builtin_amdgcn_alignbit(w.l1, w.l0, 16);
+                            a1 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                        } else if (shift == 2u) {
+                            a0 = w.l1;
+                            a1 = w.l2;
+                        } else {
+                            a0 = __builtin_amdgcn_alignbit(w.l2, w.l1, 16);
+                            a1 = __builtin_amdgcn_alignbit(w.l3, w.l2, 16);
+                        }
+                        // level shift + 3 lowest, level shift highest
+                        qcode = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a0, a0, 16)) << 32) |
+                                static_cast<uint64_t>(__builtin_amdgcn_alignbit(a1, a1, 16));
                     }
-                    // the 32 symbols [rem_v - 32, rem_v) in text order: level shift + 3 lowest, level shift highest
-                    const uint64_t qcode = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a0, a0, 16)) << 32) |
-                                           static_cast<uint64_t>(__builtin_amdgcn_alignbit(a1, a1, 16));
                     const uint64_t s0 = static_cast<uint64_t>(pos) - rem + rem_v + 32u * kTextPadUnits - 32u;  // (ok: pos >= rem)
                     const uint32_t b = static_cast<uint32_t>(s0 & 31u);
                     const u32x4 *tu = vv.text_units + (s0 >> 5);
@@ -2530,6 +2553,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             if (writer) {
                 if (bail) {
                     s_left[atomicAdd(&s_nleft, 1u)] = q;
+                    // (the general kernel resumes from {lo, hi, symbols, 1}: lo, hi, rem are still the seed's here)
+                    if (kSeed && state_packed != 0u && resumed && out_rec) out_rec[q] = make_uint4(lo, hi, rem, 1u);
                 } else {
                     uint4 rec;
                     if (kSeed && single) {
@@ -3809,7 +3834,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
 #define GDX_VERIFY_LAUNCH_X(XLATE, SEED, BLOCKS, RANGE, LEFT, LIST)                                                           \
     hipLaunchKernelGGL((search_verify_kernel4<XLATE, SEED>), dim3(BLOCKS), dim3(kBlock), 0, stream, vv, c.d_qbuf, c.d_qbeg,    \
                        c.d_qend, nq, c.d_count, c.d_status, c.d_rec, RANGE, (LEFT) + 4, LEFT, (LIST) ? (LIST) + 4 : nullptr, LIST, ulen, \
-                       verify_state, verify_wide)
+                       verify_state, verify_wide, verify_state != nullptr ? seed_state_packed : 0u)
 #define GDX_VERIFY_LAUNCH(SEED, BLOCKS, RANGE, LEFT, LIST)                             \
     do {                                                                               \
         if (xlate == 2) GDX_VERIFY_LAUNCH_X(2, SEED, BLOCKS, RANGE, LEFT, LIST);       \
@@ -3827,12 +3852,14 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                 // are only known on the device: small ranges, a capped grid that strides over whatever there is.
                 static const int env_lean = [] { const char *e = getenv("GDX_SEARCH_SEED_LEAN"); return e ? atoi(e) : 1; }();
                 static const int env_chain = [] { const char *e = getenv("GDX_SEARCH_SEED_CHAIN"); return e ? atoi(e) : 1; }();
-                // (to_fast implies every condition of `fast` below: the packed states are only search_fast_kernel4's to read)
+                // (to_fast implies every condition of `fast` below)
                 const bool to_fast = env_lean != 0 && env_chain != 0 && variant == 2 && ix.pair_lines != nullptr && ix.top != nullptr &&
                                      ix.top_depth >= 1u && ix.jump != nullptr && ix.top_depth >= static_cast<uint32_t>(ix.depth) &&
                                      lanes == 4 && policy == 0 && (env_fast_v >= 0 ? env_fast_v != 0 : qo.search_fast != 0);
                 static const int env_packed = [] { const char *e = getenv("GDX_SEARCH_SEED_PACKED"); return e ? atoi(e) : 1; }();
-                seed_state_packed = to_fast && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
+                // (... or the verify kernel's, which hands the plain form on to the general kernel: to_verify_with_state below)
+                const bool to_verify_packed = !to_fast && variant == 2 && ix.pair_lines != nullptr && env_lean != 0;
+                seed_state_packed = (to_fast || to_verify_packed) && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
                     zs.add(d_first, sizeof(uint32_t));
@@ -4223,11 +4250,11 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
         if (wide_rounds)                                                                                                      \
             hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, true>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf,  \
                                c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
-                               f_list, seed_list, seed_state_packed); \
+                               f_list, seed_list, seed_list ? seed_state_packed : 0u); \
         else                                                                                                                  \
             hipLaunchKernelGGL((search_fast_kernel4<J, XLATE, false>), dim3(f_blocks), dim3(kBlock), 0, stream, fv, c.d_qbuf, \
                                c.d_qbeg, c.d_qend, nq, c.d_count, c.d_status, c.d_rec, f_range, d_left + 4, d_left, d_state,  \
-                               f_list, seed_list, seed_state_packed); \
+                               f_list, seed_list, seed_list ? seed_state_packed : 0u); \
     } while (0)
 #define GDX_FAST_LAUNCH_P(XLATE)                                  \
     do {                                                          \
