@@ -604,9 +604,12 @@ int gdx_fastx_open(const char *path, gdx_fastx_t **out);
 int gdx_fastx_next_batch(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
                          uint64_t max_records, uint64_t *n_out);
 /* the same; *out_uniform_len (may be NULL) = the common length of the batch's records, 0 when they differ -- what
- * gdx_query_layout_t.uniform_len takes.  A regular file is memory-mapped and a batch parsed by several threads (blocks cut at
- * record starts, every block checked to end where the next one starts; round 6: one thread delivered 60 M reads a second to calls
- * that take 3 G); environment GDX_FASTX_THREADS = their number, 0 = the streaming reader (pipes, stdin). */
+ * gdx_query_layout_t.uniform_len takes.  A regular file is memory-mapped and a batch parsed by several threads (tiles of 2 MB cut
+ * at record starts, every tile checked to end where the next one starts, its records copied while they are in the caches; round 6:
+ * one thread delivered 60 M reads a second to calls that take 1-3 G, sixteen deliver 800 M); a batch may hold fewer records than
+ * would fit.  Environment: GDX_FASTX_THREADS = their number (default: the CPUs the process may use, at most 32), 0 = the streaming
+ * reader (which pipes and stdin get anyway); for tests and experiments GDX_FASTX_BLOCK_BYTES (tile size), GDX_FASTX_NEWLINE_INDEX=0,
+ * GDX_FASTX_POPULATE=0, GDX_FASTX_TIMING=1 (a batch's thread-seconds per phase on stderr). */
 int gdx_fastx_next_batch_ex(gdx_fastx_t *reader, uint8_t *qbuf, uint64_t qbuf_capacity, uint64_t *qoff,
                             uint64_t max_records, uint64_t *n_out, uint64_t *out_uniform_len);
 void gdx_fastx_close(gdx_fastx_t *reader);
