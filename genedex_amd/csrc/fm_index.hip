@@ -571,19 +571,38 @@ __device__ __forceinline__ bool seed_key_at(const u32x4 *__restrict__ units, uin
     return (mask & ((1u << k) - 1u)) == 0u;
 }
 
+// the 32 symbols in front of two text positions, when all of them are A C G T of the positions' own texts (IndexView::seed_pairs)
+__device__ __forceinline__ bool seed_pair_contexts(const u32x4 *__restrict__ units, uint32_t p1, uint32_t p2, uint64_t &c1, uint64_t &c2)
+{
+    uint32_t m1, m2;
+    text_window32(units, static_cast<uint64_t>(p1) + 32u * kTextPadUnits - 32u, c1, m1);
+    text_window32(units, static_cast<uint64_t>(p2) + 32u * kTextPadUnits - 32u, c2, m2);
+    return (m1 | m2) == 0u;
+}
+
+// n_heads[0] += the distinct k-mers; [1] += those on exactly two rows whose contexts are whole (they get a record in seed_pairs)
 __global__ __launch_bounds__(kBlock) void seed_count_heads_kernel(const u32x4 *__restrict__ units, const uint32_t *__restrict__ sa,
                                                                   uint64_t n, uint32_t k, unsigned long long *__restrict__ n_heads)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    unsigned long long mine = 0;
+    unsigned long long mine = 0, pairs = 0;
     for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < n; r += stride) {
         uint64_t key, prev = 0;
         if (!seed_key_at(units, sa[r], k, key)) continue;
         const bool same = r > 0 && seed_key_at(units, sa[r - 1], k, prev) && prev == key;
         mine += same ? 0u : 1u;
+        if (!same && r + 1 < n && seed_key_at(units, sa[r + 1], k, prev) && prev == key &&
+            !(r + 2 < n && seed_key_at(units, sa[r + 2], k, prev) && prev == key)) {
+            uint64_t c1, c2;
+            pairs += seed_pair_contexts(units, sa[r], sa[r + 1], c1, c2) ? 1u : 0u;
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    for (int off = 32; off > 0; off >>= 1) {
+        mine += __shfl_xor(mine, off);
+        pairs += __shfl_xor(pairs, off);
+    }
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(n_heads, mine);
+    if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(n_heads + 1, pairs);
 }
 
 __global__ __launch_bounds__(kBlock) void seed_clear_kernel(u32x4 *__restrict__ table, uint64_t entries)
@@ -598,7 +617,9 @@ __global__ __launch_bounds__(kBlock) void seed_clear_kernel(u32x4 *__restrict__ 
 __global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__restrict__ units, const uint32_t *__restrict__ sa,
                                                              uint64_t n, uint32_t k, uint32_t tag_bits, uint32_t buckets,
                                                              u32x4 *__restrict__ table, uint32_t *__restrict__ fill,
-                                                             unsigned long long *__restrict__ stats)
+                                                             unsigned long long *__restrict__ stats,
+                                                             u32x4 *__restrict__ pair_records, uint32_t pair_capacity,
+                                                             uint32_t *__restrict__ n_pair_records)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     unsigned long long n_kind[2] = {0, 0}, n_failed = 0, max_d = 0;
@@ -622,6 +643,19 @@ __global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__rest
             hi = bad;
         }
         u32x4 e = {kSeedKind, static_cast<uint32_t>(r), static_cast<uint32_t>(hi), 0u};
+        if (hi - r == 2 && pair_records != nullptr) {  // a two-copy repeat: both positions and what stands in front of them
+            const uint32_t p2 = sa[r + 1];
+            uint64_t c1, c2;
+            if (seed_pair_contexts(units, p, p2, c1, c2)) {
+                const uint32_t at = atomicAdd(n_pair_records, 1u);
+                if (at < pair_capacity) {
+                    pair_records[2ull * at] = u32x4{p, p2, static_cast<uint32_t>(c1), static_cast<uint32_t>(c1 >> 32)};
+                    pair_records[2ull * at + 1] = u32x4{static_cast<uint32_t>(c2), static_cast<uint32_t>(c2 >> 32), 0u, 0u};
+                    e.x |= kSeedPairInfo;
+                    e.w = at;
+                }
+            }
+        }
         if (hi - r == 1) {
             uint64_t code;
             uint32_t mask;
@@ -1247,6 +1281,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     sa_full_.release();
     text_units_.release();
     seed_.release();
+    seed_pairs_.release();
+    view_.seed_pairs = nullptr;
     // environment variables are debug overrides of fields left at their default
     auto env_int = [](const char *name, int fallback) {
         const char *e = getenv(name);
@@ -1496,7 +1532,12 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             }
             GDX_HIP(hipStreamSynchronize(stream));
             GDX_HIP(hipGetLastError());
-            if (want_seed) build_seed_table(d_sa, seed_k, seed_load_pct, stream);
+            if (want_seed) {
+                // (what the budget leaves beside everything else that is or will be there: the seed table and its pair records)
+                const uint64_t others = jump_.bytes() + top_.bytes() + (want_sa_full ? 4ull * n_ : 0ull) + text_units_.bytes() + (want_isa ? 4ull * n_ : 0ull);
+                const uint64_t budget_now = aux_report_.budget_bytes != 0 ? aux_report_.budget_bytes : ~0ull;
+                build_seed_table(d_sa, seed_k, seed_load_pct, stream, budget_now > others ? budget_now - others : 0ull);
+            }
             if (want_isa) {
                 isa_.alloc(n_);
                 hipLaunchKernelGGL(scatter_isa_kernel, dim3(grid_for_items(n_)), dim3(kBlock), 0, stream, d_sa, n_, isa_.get());
@@ -1507,23 +1548,30 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             if (want_sa_full) view_.sa_full = sa_full_.get();
             if (want_text) view_.text_units = text_units_.get();
         }
-        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + isa_.bytes();
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + seed_pairs_.bytes() + isa_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }
 
 // Seed table out of the full suffix array and the text units (both on the device; layout.hpp describes the entries).
-void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, hipStream_t stream)
+void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, hipStream_t stream, uint64_t room_bytes)
 {
     if (load < 20u || load > 100u) fail(GDX_ERR_INVALID_ARGUMENT, "seed_load_percent must be 0 (default) or 20..100");
     const unsigned grid = grid_for_items(n_);
     DeviceBuffer<unsigned long long> d_stats(8);
     GDX_HIP(hipMemsetAsync(d_stats.get(), 0, 8 * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(seed_count_heads_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, d_stats.get());
-    unsigned long long heads = 0;
-    GDX_HIP(hipMemcpyAsync(&heads, d_stats.get(), sizeof(heads), hipMemcpyDeviceToHost, stream));
+    unsigned long long heads_pairs[2] = {0, 0};
+    GDX_HIP(hipMemcpyAsync(heads_pairs, d_stats.get(), sizeof(heads_pairs), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
     GDX_HIP(hipGetLastError());
+    const unsigned long long heads = heads_pairs[0];
+    // records of the two-copy repeats (IndexView::seed_pairs): 32 bytes each, if the budget has room for them beside the table
+    // (GDX_SEED_PAIRS=0: none -- experiments)
+    static const bool env_no_pairs = [] { const char *e = getenv("GDX_SEED_PAIRS"); return e != nullptr && atoi(e) == 0; }();
+    unsigned long long n_pairs = env_no_pairs ? 0ull : heads_pairs[1];
+    if (n_pairs > 0xfffffff0ull) n_pairs = 0;
+    DeviceBuffer<uint32_t> d_n_pairs(1);
     // buckets: the load factor decides, but (bucket, tag) must name a k-mer exactly: 2^(2k - tag bits) <= buckets with
     // at most kSeedTagBitsMax tag bits
     uint64_t buckets = (heads * 100ull + 8ull * load - 1) / (8ull * load);
@@ -1543,8 +1591,13 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         GDX_HIP(hipMemsetAsync(d_fill.get(), 0, buckets * sizeof(uint32_t), stream));
         GDX_HIP(hipMemsetAsync(d_stats.get(), 0, 8 * sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(seed_clear_kernel, dim3(grid_for_items(buckets * 8)), dim3(kBlock), 0, stream, seed_.get(), buckets * 8);
+        const bool pairs_fit = n_pairs != 0 && seed_.bytes() + n_pairs * 32ull <= room_bytes;
+        if (pairs_fit) seed_pairs_.alloc(n_pairs * 2);
+        else seed_pairs_.release();
+        GDX_HIP(hipMemsetAsync(d_n_pairs.get(), 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(seed_insert_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, tag_bits,
-                           static_cast<uint32_t>(buckets), seed_.get(), d_fill.get(), d_stats.get());
+                           static_cast<uint32_t>(buckets), seed_.get(), d_fill.get(), d_stats.get(),
+                           pairs_fit ? seed_pairs_.get() : nullptr, static_cast<uint32_t>(pairs_fit ? n_pairs : 0ull), d_n_pairs.get());
         hipLaunchKernelGGL(seed_flag_kernel, dim3(grid_for_items(buckets * 8)), dim3(kBlock), 0, stream, seed_.get(), d_fill.get(),
                            buckets * 8, d_stats.get() + 4);
         unsigned long long st[5];
@@ -1553,11 +1606,14 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         GDX_HIP(hipGetLastError());
         if (st[2] != 0) {  // an entry found no slot within kSeedMaxDisp buckets of its home: more buckets
             seed_.release();
+            seed_pairs_.release();
             if (attempt >= 6) fail(GDX_ERR_UNSUPPORTED, "seed table: no placement found");
             buckets = buckets + buckets / 4 + 1;
             continue;
         }
         view_.seed = seed_.get();
+        view_.seed_pairs = seed_pairs_.get();  // (null when none were made)
+        aux_report_.seed_pair_records = pairs_fit ? n_pairs : 0ull;
         view_.seed_buckets = static_cast<uint32_t>(buckets);
         view_.seed_k = k;
         view_.seed_tag_bits = tag_bits;
@@ -1567,7 +1623,7 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         aux_report_.seed_multi = st[1];
         aux_report_.seed_max_disp = st[3];
         aux_report_.seed_overflowed = st[4];
-        aux_report_.seed_bytes = seed_.bytes();
+        aux_report_.seed_bytes = seed_.bytes() + seed_pairs_.bytes();
         return;
     }
 }
@@ -1591,6 +1647,7 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         view_.sa_full = nullptr;
         view_.text_units = nullptr;
         view_.seed = nullptr;
+        view_.seed_pairs = nullptr;
         view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
         view_.isa = nullptr;
         isa_.release();
@@ -1598,6 +1655,7 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         sa_full_.release();
         text_units_.release();
         seed_.release();
+        seed_pairs_.release();
         pair_lines_.release();
         jump_.release();
         top_.release();

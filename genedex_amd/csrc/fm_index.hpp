@@ -49,7 +49,7 @@ struct AuxReport {
     double wide_fraction = 0.0;  // share of text positions whose top-table interval is wider than 4 rows
     bool default_shape = false;  // the options were left at their defaults and the default shape fitted the budget (fm_index.hip)
     // seed table: k, buckets, entries of kind 0 / kind 1, buckets that turned an entry away, largest displacement
-    uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0;
+    uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0, seed_pair_records = 0;
 };
 
 struct IndexConfig {
@@ -148,7 +148,7 @@ private:
                       uint64_t uniform_len = 0, Narrow32Sink *narrow = nullptr) const;
     void finish_from_bwt(const uint8_t *d_bwt_padded, hipStream_t stream);  // table + lookup + view
     void build_aux(const uint8_t *d_bwt_padded, hipStream_t stream);        // pair lines, jump table, top table
-    void build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load_percent, hipStream_t stream);
+    void build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load_percent, hipStream_t stream, uint64_t room_bytes);
     void locate_device(const uint32_t *d_start, const uint32_t *d_end, uint64_t m, uint64_t *out_hit_offsets,
                        gdx_hit_t *hits, uint64_t hits_capacity, uint64_t *out_total, int *rc,
                        const uint4 *d_rec = nullptr) const;
@@ -171,7 +171,7 @@ private:
     DeviceBuffer<uint2> top_;
     DeviceBuffer<uint32_t> sa_full_;
     DeviceBuffer<u32x4> text_units_;
-    DeviceBuffer<u32x4> seed_;
+    DeviceBuffer<u32x4> seed_, seed_pairs_;
     DeviceBuffer<uint32_t> isa_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;

@@ -99,8 +99,13 @@ struct IndexView {
     //           of word 0: 1 = v is 30, 2 = 31, which leave no room there), and a read that reaches further back than v
     //           symbols does not occur
     //   kind 1 (several rows):
-    //           {w0, lo, hi, 0} = the k-mer's suffix-array interval; the search goes on from there as after a top table
+    //           {w0, lo, hi, 0} = the k-mer's suffix-array interval; the search goes on from there as after a top table.
+    //           `partial` set (kSeedPairInfo): the interval has exactly two rows, both with 32 symbols A C G T of their text in
+    //           front, and word 3 is the index of their 32-byte record in seed_pairs: {SA[lo], SA[lo + 1], codes of the 32
+    //           symbols in front of the first, of the second (as in a kind-0 entry), 0, 0} -- a count / locate read of up to
+    //           seed_k + 32 symbols from a two-copy repeat is decided by that record: no suffix-array line, no text lines
     const u32x4 *seed;            // null when absent
+    const u32x4 *seed_pairs;      // two u32x4 per record; null when absent (no room in the budget, or no such k-mers)
     // inverse suffix array (optional): isa[p] = the row whose suffix starts at text position p.  With it the seed table
     // also answers EXACT intervals: a read that occurs once, at position p, has the interval [isa[p], isa[p] + 1)
     const uint32_t *isa;          // [n], null when absent
@@ -145,6 +150,7 @@ constexpr uint32_t kSeedEmpty = 31u << kSeedDispShift;
 constexpr uint32_t kSeedMatchMask = 0x03ffffffu;            // tag and disp
 constexpr uint32_t kSeedKind = 1u << 26;
 constexpr uint32_t kSeedPartial = 1u << 27;
+constexpr uint32_t kSeedPairInfo = kSeedPartial;           // in an entry of kind 1: see IndexView::seed_pairs
 constexpr uint32_t kSeedPartialShift = 29;                  // bits 30:29 of a partial entry: 0 = v in the codes, 1 = 30, 2 = 31
 constexpr uint32_t kSeedFound = 1u << 28;                   // never set in the table: marks a matched entry in registers
 constexpr uint32_t kSeedOverflow = 1u << 31;

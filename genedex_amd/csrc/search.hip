@@ -1109,6 +1109,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 // codes (the one to be consumed next in the top bits of `codes hi`); {lo, kStatePlain | symbols left, hi, 0} an interval
 // of 256+ rows; all zero = from the beginning
 constexpr uint32_t kStatePacked = 1u << 23, kStatePlain = 1u << 22;
+// ... and, for search_verify_kernel4 only (state_packed == 2): {index of the k-mer's record in IndexView::seed_pairs,
+// 2 << 24 | kStatePacked | kStatePair | symbols left (1..32), codes hi, codes lo} -- a k-mer on exactly two rows whose seed
+// entry names such a record (kSeedPairInfo): the read is decided by that one 32-byte record
+constexpr uint32_t kStatePair = 1u << 21;
 
 struct FastView {
     const uint2 *top;
@@ -2224,6 +2228,7 @@ struct VerifyView {
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
     const u32x4 *seed;  // kSeed: IndexView::seed*
     uint32_t seed_buckets, seed_k, seed_tag_bits;
+    const u32x4 *seed_pairs;  // IndexView::seed_pairs (kStatePair states)
 };
 
 // kSeed: the seed table instead of the top table (layout.hpp): ONE 128-byte bucket per read answers the last seed_k
@@ -2299,6 +2304,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             uint32_t pos = 0;              // SA of this lane's row
             bool resumed = false;
             const uint64_t state_codes = (static_cast<uint64_t>(st.z) << 32) | st.w;  // from_state: the symbols in front of the seed
+            if (from_state && (st.y & kStatePair) != 0u) {
+                // a two-copy repeat (kStatePair): both positions and the 32 symbols in front of each in ONE 32-byte record -- no
+                // suffix-array line, no text lines; the record's contexts are whole, so the compare is all there is to decide
+                const u32x4 *pr = vv.seed_pairs + 2ull * st.x;
+                const u32x4 r0 = pr[0], r1 = pr[1];
+                const uint32_t n_v = st.y & 0x1fffffu;  // 1 .. 32 symbols in front of the seed
+                const uint64_t vm64 = n_v == 32u ? ~0ull : ~0ull << (2u * (32u - n_v));
+                const uint64_t t1 = (static_cast<uint64_t>(r0.w) << 32) | r0.z, t2 = (static_cast<uint64_t>(r1.y) << 32) | r1.x;
+                const bool ok1 = ((state_codes ^ t1) & vm64) == 0ull && r0.x >= n_v, ok2 = ((state_codes ^ t2) & vm64) == 0ull && r0.y >= n_v;
+                if (writer) {
+                    const uint32_t h1 = r0.x - n_v, h2 = r0.y - n_v;  // (rows lo, lo + 1: the order of the reference's hits)
+                    uint4 rec;
+                    if (ok1 && ok2) rec = make_uint4(h2, h2 + 2u, h1, kRecResolved);
+                    else if (ok1 || ok2) rec = make_uint4(0u, 1u, ok1 ? h1 : h2, kRecResolved);
+                    else rec = make_uint4(0u, 0u, 0xffffffffu, 0u);
+                    if (out_rec) out_rec[q] = rec;
+                    if (out_count) out_count[q] = rec.y - rec.x;
+                    if (out_status) out_status[q] = 0;
+                }
+                continue;
+            }
             if (from_state) {
                 resumed = true;
                 lo = st.x;
@@ -2738,6 +2764,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                             if (!kExact && state) {
                                 if (state_packed == 0u) state[q] = make_uint4(ey, ez, a_rem, 1u);
+                                else if (state_packed == 2u && (ex & kSeedPairInfo) != 0u && a_rem - 1u < 32u)
+                                    state[q] = make_uint4(ew, (2u << 24) | kStatePacked | kStatePair | a_rem, a_qh, a_ql);
                                 else if (ez - ey < 256u) state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | a_rem, a_qh, a_ql);
                                 else state[q] = make_uint4(ey, kStatePlain | a_rem, ez, 0u);
                             }
@@ -2993,6 +3021,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
             // several rows: the next kernel takes it from this interval
             if (state) {
                 if (state_packed == 0u) state[q] = make_uint4(ey, ez, rem, 1u);
+                else if (state_packed == 2u && (ex & kSeedPairInfo) != 0u && rem - 1u < 32u)  // (kStatePair: ew = the record's index)
+                    state[q] = make_uint4(ew, (2u << 24) | kStatePacked | kStatePair | rem, static_cast<uint32_t>(qcode >> 32),
+                                          static_cast<uint32_t>(qcode));
                 else if (ez - ey < 256u)
                     state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | rem, static_cast<uint32_t>(qcode >> 32),
                                           static_cast<uint32_t>(qcode));
@@ -3827,7 +3858,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const VerifyView vv{ix.top, ix.text_units, ix.sa_full, entry_sa ? ix.jump : nullptr, ix.lines, ix.sb_offsets, ix.count,
                                 ix.sa_samples, ix.border_keys, ix.border_vals, ix.io_to_dense, ix.top_depth, ix.n, ix.n_texts,
                                 ix.sa_inv, ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
-                                ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits};
+                                ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits, ix.seed_pairs};
             static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
             // how the kernels get 2-bit codes: 2 = the buffer holds them (packed queries), 1 = v_perm tables, 0 = the table in LDS
             const int xlate = c.packed ? 2 : ((ix.perm_ok && !env_no_perm_v) ? 1 : 0);
@@ -3860,6 +3891,10 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                 // (... or the verify kernel's, which hands the plain form on to the general kernel: to_verify_with_state below)
                 const bool to_verify_packed = !to_fast && variant == 2 && ix.pair_lines != nullptr && env_lean != 0;
                 seed_state_packed = (to_fast || to_verify_packed) && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
+                // (2: states of two-copy repeats name their record in IndexView::seed_pairs -- only the verify kernel reads those)
+                const char *env_pairs = getenv("GDX_SEARCH_SEED_PAIRS");  // (0: the A/B; read per call, a test switches it)
+                if (seed_state_packed != 0u && !to_fast && ix.seed_pairs != nullptr && !(env_pairs != nullptr && atoi(env_pairs) == 0))
+                    seed_state_packed = 2u;
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));
                     zs.add(d_first, sizeof(uint32_t));

@@ -184,7 +184,10 @@ class FmIndex:
         _lib.check(self._lib.gdx_index_seed_info(self._h, out))
         names = ("k", "buckets", "single_entries", "interval_entries", "overflowed_buckets", "max_displacement", "bytes",
                  "tag_bits")
-        return {n: int(v) for n, v in zip(names, out)}
+        info = {n: int(v) for n, v in zip(names, out)}
+        info["pair_records"] = info["tag_bits"] >> 8  # (two-copy repeats with a record of their own: gdx.h)
+        info["tag_bits"] &= 0xff
+        return info
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,
                           locate_kernel=None, locate_jump_walk=None, search_defer_after=None, search_fast=None,

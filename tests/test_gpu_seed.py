@@ -485,6 +485,8 @@ def test_seed_entries_are_the_distinct_kmers():
     rng = np.random.default_rng(77)
     a = alph.ascii_dna_with_n()
     texts = repetitive_texts(rng, symbols=b"ACGTN")
+    twice = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 400))  # (a stretch that occurs exactly twice, once right at a text's start)
+    texts = texts + [twice + bytes(b"ACGTN"[i] for i in rng.integers(0, 5, 300)) + twice]
     k = 10
     g = gpu_index(texts, a, seed_symbols=k, **LEAN)
     kmers = {}
@@ -497,10 +499,13 @@ def test_seed_entries_are_the_distinct_kmers():
     for w, occ in kmers.items():
         if len(occ) == 1:
             single += 1
+    # k-mers on exactly two rows whose occurrences both have 32 symbols A C G T of their own text in front: a record of their own
+    pairs = sum(1 for occ in kmers.values() if len(occ) == 2 and all(i >= 32 and b"N" not in t[i - 32:i] for t, i in occ))
     info = g.seed_info()
     assert info["single_entries"] == single
     assert info["interval_entries"] == len(kmers) - single
-    assert info["bytes"] == info["buckets"] * 128
+    assert info["pair_records"] == pairs and pairs > 0
+    assert info["bytes"] == info["buckets"] * 128 + 32 * pairs
     assert info["max_displacement"] <= 30
 
 
@@ -650,8 +655,8 @@ def test_reference_table_layouts_bit_for_bit_and_queried_as_they_are(layout):
             assert np.array_equal(eb, b64.blocks) and np.array_equal(ebo, b64.block_offsets) and np.array_equal(esb, b64.superblock_offsets)
 
 
-@pytest.mark.parametrize("structures", ["seed+sa", "seed+jump32", "seed+sa, no tables", "seed+walk"])
-def test_reads_on_two_rows_carry_both_positions(structures):
+@pytest.mark.parametrize("structures", ["seed+sa", "seed+jump32", "seed+sa, no tables", "seed+walk", "default shape", "default shape, no pair records"])
+def test_reads_on_two_rows_carry_both_positions(structures, monkeypatch):
     """A read that ends on exactly two rows (every stretch of this text occurs twice) leaves search_fast_kernel4 as a resolved
     record OF TWO -- {second position, second + 2, first position, resolved}: end - start is the count, no row is named
     (kernels.hpp) -- where the search has both occurrences at hand: search_fast_kernel4 on 32-byte jump entries (they carry
@@ -672,8 +677,15 @@ def test_reads_on_two_rows_carry_both_positions(structures):
             "seed+jump32": dict(seed_symbols=12, text_units=True, jump_entry_bytes=32),
             "seed+sa, no tables": dict(seed_symbols=12, text_units=True, full_suffix_array=True, pair_lines=False, jump_entry_bytes=0,
                                        top_table_depth=0),
-            "seed+walk": dict(seed_symbols=12, text_units=True, jump_entry_bytes=0, top_table_depth=0, pair_lines=False)}[structures]
+            "seed+walk": dict(seed_symbols=12, text_units=True, jump_entry_bytes=0, top_table_depth=0, pair_lines=False),
+            # (what gdx_index_build makes of nothing: k = 16 here; a read with up to 32 symbols in front of its seed is decided by
+            # the 32-byte record of its two-copy k-mer -- IndexView::seed_pairs --, a longer one by SA line and text lines)
+            "default shape": dict(), "default shape, no pair records": dict()}[structures]
+    if structures == "default shape, no pair records":
+        monkeypatch.setenv("GDX_SEARCH_SEED_PAIRS", "0")
     g = gpu_index(texts, a, **opts)
+    if structures.startswith("default shape"):
+        assert DeviceEngine(g).aux_info()["default_shape"] and g.seed_info()["pair_records"] > 10000
     g.set_query_options(search_fast=2)  # (the fast path is off by default on a text this repetitive: wide_permille > 500)
     c = cpu_index(texts, a)
     qs = []
