@@ -505,7 +505,7 @@ int gdx_index_seed_info(const gdx_index_t *ix, uint64_t out[8])
         out[4] = r.seed_overflowed;
         out[5] = r.seed_max_disp;
         out[6] = r.seed_bytes;
-        out[7] = f.view().seed_tag_bits | (r.seed_pair_records << 8);
+        out[7] = f.view().seed_tag_bits | (r.seed_pair_records << 8) | (r.seed_quad_records << 36);
         return (int)GDX_OK;
     });
 }

@@ -580,29 +580,35 @@ __device__ __forceinline__ bool seed_pair_contexts(const u32x4 *__restrict__ uni
     return (m1 | m2) == 0u;
 }
 
-// n_heads[0] += the distinct k-mers; [1] += those on exactly two rows whose contexts are whole (they get a record in seed_pairs)
+// n_heads[0] += the distinct k-mers; [1] += those on exactly two rows whose contexts are whole (they get a record in seed_pairs);
+// [2] += those on three or four such rows (seed_quads)
 __global__ __launch_bounds__(kBlock) void seed_count_heads_kernel(const u32x4 *__restrict__ units, const uint32_t *__restrict__ sa,
                                                                   uint64_t n, uint32_t k, unsigned long long *__restrict__ n_heads)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    unsigned long long mine = 0, pairs = 0;
+    unsigned long long mine = 0, pairs = 0, quads = 0;
     for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; r < n; r += stride) {
         uint64_t key, prev = 0;
         if (!seed_key_at(units, sa[r], k, key)) continue;
         const bool same = r > 0 && seed_key_at(units, sa[r - 1], k, prev) && prev == key;
         mine += same ? 0u : 1u;
-        if (!same && r + 1 < n && seed_key_at(units, sa[r + 1], k, prev) && prev == key &&
-            !(r + 2 < n && seed_key_at(units, sa[r + 2], k, prev) && prev == key)) {
-            uint64_t c1, c2;
-            pairs += seed_pair_contexts(units, sa[r], sa[r + 1], c1, c2) ? 1u : 0u;
-        }
+        if (same) continue;
+        // rows of the k-mer, as far as it matters here: 1 .. 5
+        uint32_t rows = 1;
+        while (rows < 5u && r + rows < n && seed_key_at(units, sa[r + rows], k, prev) && prev == key) rows++;
+        uint64_t c1, c2;
+        if (rows == 2u) pairs += seed_pair_contexts(units, sa[r], sa[r + 1], c1, c2) ? 1u : 0u;
+        if (rows == 3u || rows == 4u)
+            quads += (seed_pair_contexts(units, sa[r], sa[r + 1], c1, c2) && seed_pair_contexts(units, sa[r + 2], sa[r + rows - 1], c1, c2)) ? 1u : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) {
         mine += __shfl_xor(mine, off);
         pairs += __shfl_xor(pairs, off);
+        quads += __shfl_xor(quads, off);
     }
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(n_heads, mine);
     if ((threadIdx.x & 63u) == 0 && pairs) atomicAdd(n_heads + 1, pairs);
+    if ((threadIdx.x & 63u) == 0 && quads) atomicAdd(n_heads + 2, quads);
 }
 
 __global__ __launch_bounds__(kBlock) void seed_clear_kernel(u32x4 *__restrict__ table, uint64_t entries)
@@ -619,7 +625,8 @@ __global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__rest
                                                              u32x4 *__restrict__ table, uint32_t *__restrict__ fill,
                                                              unsigned long long *__restrict__ stats,
                                                              u32x4 *__restrict__ pair_records, uint32_t pair_capacity,
-                                                             uint32_t *__restrict__ n_pair_records)
+                                                             uint32_t *__restrict__ n_pair_records,  // [0] pairs, [1] quads
+                                                             u32x4 *__restrict__ quad_records, uint32_t quad_capacity)
 {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     unsigned long long n_kind[2] = {0, 0}, n_failed = 0, max_d = 0;
@@ -652,6 +659,22 @@ __global__ __launch_bounds__(kBlock) void seed_insert_kernel(const u32x4 *__rest
                     pair_records[2ull * at] = u32x4{p, p2, static_cast<uint32_t>(c1), static_cast<uint32_t>(c1 >> 32)};
                     pair_records[2ull * at + 1] = u32x4{static_cast<uint32_t>(c2), static_cast<uint32_t>(c2 >> 32), 0u, 0u};
                     e.x |= kSeedPairInfo;
+                    e.w = at;
+                }
+            }
+        }
+        if ((hi - r == 3 || hi - r == 4) && quad_records != nullptr) {  // three or four copies: the same, 64 bytes
+            const uint32_t rows = static_cast<uint32_t>(hi - r);
+            const uint32_t p1 = sa[r + 1], p2 = sa[r + 2], p3 = sa[r + rows - 1];  // (three rows: the third twice)
+            uint64_t c0, c1, c2, c3;
+            if (seed_pair_contexts(units, p, p1, c0, c1) && seed_pair_contexts(units, p2, p3, c2, c3)) {
+                const uint32_t at = atomicAdd(n_pair_records + 1, 1u);
+                if (at < quad_capacity) {
+                    quad_records[4ull * at] = u32x4{p, p1, p2, p3};
+                    quad_records[4ull * at + 1] = u32x4{static_cast<uint32_t>(c0), static_cast<uint32_t>(c0 >> 32), static_cast<uint32_t>(c1), static_cast<uint32_t>(c1 >> 32)};
+                    quad_records[4ull * at + 2] = u32x4{static_cast<uint32_t>(c2), static_cast<uint32_t>(c2 >> 32), static_cast<uint32_t>(c3), static_cast<uint32_t>(c3 >> 32)};
+                    quad_records[4ull * at + 3] = u32x4{static_cast<uint32_t>(r), rows, 0u, 0u};
+                    e.x |= kSeedQuadInfo;
                     e.w = at;
                 }
             }
@@ -1282,7 +1305,8 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
     text_units_.release();
     seed_.release();
     seed_pairs_.release();
-    view_.seed_pairs = nullptr;
+    seed_quads_.release();
+    view_.seed_pairs = view_.seed_quads = nullptr;
     // environment variables are debug overrides of fields left at their default
     auto env_int = [](const char *name, int fallback) {
         const char *e = getenv(name);
@@ -1548,7 +1572,7 @@ void FmIndex::build_aux(const uint8_t *d_bwt_padded, hipStream_t stream)
             if (want_sa_full) view_.sa_full = sa_full_.get();
             if (want_text) view_.text_units = text_units_.get();
         }
-        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + seed_pairs_.bytes() + isa_.bytes();
+        aux_report_.aux_bytes = jump_.bytes() + top_.bytes() + sa_full_.bytes() + text_units_.bytes() + seed_.bytes() + seed_pairs_.bytes() + seed_quads_.bytes() + isa_.bytes();
         stats_.seconds_pairs = now_seconds() - t0;
     }
 }
@@ -1561,7 +1585,7 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
     DeviceBuffer<unsigned long long> d_stats(8);
     GDX_HIP(hipMemsetAsync(d_stats.get(), 0, 8 * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(seed_count_heads_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, d_stats.get());
-    unsigned long long heads_pairs[2] = {0, 0};
+    unsigned long long heads_pairs[3] = {0, 0, 0};
     GDX_HIP(hipMemcpyAsync(heads_pairs, d_stats.get(), sizeof(heads_pairs), hipMemcpyDeviceToHost, stream));
     GDX_HIP(hipStreamSynchronize(stream));
     GDX_HIP(hipGetLastError());
@@ -1571,7 +1595,9 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
     static const bool env_no_pairs = [] { const char *e = getenv("GDX_SEED_PAIRS"); return e != nullptr && atoi(e) == 0; }();
     unsigned long long n_pairs = env_no_pairs ? 0ull : heads_pairs[1];
     if (n_pairs > 0xfffffff0ull) n_pairs = 0;
-    DeviceBuffer<uint32_t> d_n_pairs(1);
+    unsigned long long n_quads = env_no_pairs ? 0ull : heads_pairs[2];  // (k-mers on three or four rows: 64 bytes each)
+    if (n_quads > 0xfffffff0ull) n_quads = 0;
+    DeviceBuffer<uint32_t> d_n_pairs(2);
     // buckets: the load factor decides, but (bucket, tag) must name a k-mer exactly: 2^(2k - tag bits) <= buckets with
     // at most kSeedTagBitsMax tag bits
     uint64_t buckets = (heads * 100ull + 8ull * load - 1) / (8ull * load);
@@ -1594,10 +1620,14 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         const bool pairs_fit = n_pairs != 0 && seed_.bytes() + n_pairs * 32ull <= room_bytes;
         if (pairs_fit) seed_pairs_.alloc(n_pairs * 2);
         else seed_pairs_.release();
-        GDX_HIP(hipMemsetAsync(d_n_pairs.get(), 0, sizeof(uint32_t), stream));
+        const bool quads_fit = n_quads != 0 && seed_.bytes() + seed_pairs_.bytes() + n_quads * 64ull <= room_bytes;
+        if (quads_fit) seed_quads_.alloc(n_quads * 4);
+        else seed_quads_.release();
+        GDX_HIP(hipMemsetAsync(d_n_pairs.get(), 0, 2 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(seed_insert_kernel, dim3(grid), dim3(kBlock), 0, stream, text_units_.get(), d_sa, n_, k, tag_bits,
                            static_cast<uint32_t>(buckets), seed_.get(), d_fill.get(), d_stats.get(),
-                           pairs_fit ? seed_pairs_.get() : nullptr, static_cast<uint32_t>(pairs_fit ? n_pairs : 0ull), d_n_pairs.get());
+                           pairs_fit ? seed_pairs_.get() : nullptr, static_cast<uint32_t>(pairs_fit ? n_pairs : 0ull), d_n_pairs.get(),
+                           quads_fit ? seed_quads_.get() : nullptr, static_cast<uint32_t>(quads_fit ? n_quads : 0ull));
         hipLaunchKernelGGL(seed_flag_kernel, dim3(grid_for_items(buckets * 8)), dim3(kBlock), 0, stream, seed_.get(), d_fill.get(),
                            buckets * 8, d_stats.get() + 4);
         unsigned long long st[5];
@@ -1607,13 +1637,16 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         if (st[2] != 0) {  // an entry found no slot within kSeedMaxDisp buckets of its home: more buckets
             seed_.release();
             seed_pairs_.release();
+            seed_quads_.release();
             if (attempt >= 6) fail(GDX_ERR_UNSUPPORTED, "seed table: no placement found");
             buckets = buckets + buckets / 4 + 1;
             continue;
         }
         view_.seed = seed_.get();
         view_.seed_pairs = seed_pairs_.get();  // (null when none were made)
+        view_.seed_quads = seed_quads_.get();
         aux_report_.seed_pair_records = pairs_fit ? n_pairs : 0ull;
+        aux_report_.seed_quad_records = quads_fit ? n_quads : 0ull;
         view_.seed_buckets = static_cast<uint32_t>(buckets);
         view_.seed_k = k;
         view_.seed_tag_bits = tag_bits;
@@ -1623,7 +1656,7 @@ void FmIndex::build_seed_table(const uint32_t *d_sa, uint32_t k, uint32_t load, 
         aux_report_.seed_multi = st[1];
         aux_report_.seed_max_disp = st[3];
         aux_report_.seed_overflowed = st[4];
-        aux_report_.seed_bytes = seed_.bytes() + seed_pairs_.bytes();
+        aux_report_.seed_bytes = seed_.bytes() + seed_pairs_.bytes() + seed_quads_.bytes();
         return;
     }
 }
@@ -1647,7 +1680,7 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         view_.sa_full = nullptr;
         view_.text_units = nullptr;
         view_.seed = nullptr;
-        view_.seed_pairs = nullptr;
+        view_.seed_pairs = view_.seed_quads = nullptr;
         view_.seed_buckets = view_.seed_k = view_.seed_tag_bits = 0;
         view_.isa = nullptr;
         isa_.release();
@@ -1656,6 +1689,7 @@ void FmIndex::rebuild_aux(const BuildOptions &opts)
         text_units_.release();
         seed_.release();
         seed_pairs_.release();
+        seed_quads_.release();
         pair_lines_.release();
         jump_.release();
         top_.release();

@@ -49,7 +49,7 @@ struct AuxReport {
     double wide_fraction = 0.0;  // share of text positions whose top-table interval is wider than 4 rows
     bool default_shape = false;  // the options were left at their defaults and the default shape fitted the budget (fm_index.hip)
     // seed table: k, buckets, entries of kind 0 / kind 1, buckets that turned an entry away, largest displacement
-    uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0, seed_pair_records = 0;
+    uint64_t seed_k = 0, seed_buckets = 0, seed_single = 0, seed_multi = 0, seed_overflowed = 0, seed_max_disp = 0, seed_bytes = 0, seed_pair_records = 0, seed_quad_records = 0;
 };
 
 struct IndexConfig {
@@ -171,7 +171,7 @@ private:
     DeviceBuffer<uint2> top_;
     DeviceBuffer<uint32_t> sa_full_;
     DeviceBuffer<u32x4> text_units_;
-    DeviceBuffer<u32x4> seed_, seed_pairs_;
+    DeviceBuffer<u32x4> seed_, seed_pairs_, seed_quads_;
     DeviceBuffer<uint32_t> isa_;
     DeviceBuffer<uint64_t> g_planes_;
     DeviceBuffer<uint16_t> g_block_off_;

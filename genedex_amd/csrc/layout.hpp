@@ -106,6 +106,10 @@ struct IndexView {
     //           seed_k + 32 symbols from a two-copy repeat is decided by that record: no suffix-array line, no text lines
     const u32x4 *seed;            // null when absent
     const u32x4 *seed_pairs;      // two u32x4 per record; null when absent (no room in the budget, or no such k-mers)
+    // the same for k-mers on THREE or FOUR rows (kSeedQuadInfo, word 3 = the index): 64-byte records {SA[lo .. lo + 3]} {contexts of
+    // rows 0, 1} {contexts of rows 2, 3} {lo, rows, 0, 0} -- every row with 32 symbols A C G T in front; a read that ends on three
+    // or four of them leaves as the masked record of those rows, which is why lo is in the record
+    const u32x4 *seed_quads;      // four u32x4 per record; null when absent
     // inverse suffix array (optional): isa[p] = the row whose suffix starts at text position p.  With it the seed table
     // also answers EXACT intervals: a read that occurs once, at position p, has the interval [isa[p], isa[p] + 1)
     const uint32_t *isa;          // [n], null when absent
@@ -151,6 +155,7 @@ constexpr uint32_t kSeedMatchMask = 0x03ffffffu;            // tag and disp
 constexpr uint32_t kSeedKind = 1u << 26;
 constexpr uint32_t kSeedPartial = 1u << 27;
 constexpr uint32_t kSeedPairInfo = kSeedPartial;           // in an entry of kind 1: see IndexView::seed_pairs
+constexpr uint32_t kSeedQuadInfo = 1u << 29;                // in an entry of kind 1 (bit 29, a kind-0 entry's v code): see IndexView::seed_quads
 constexpr uint32_t kSeedPartialShift = 29;                  // bits 30:29 of a partial entry: 0 = v in the codes, 1 = 30, 2 = 31
 constexpr uint32_t kSeedFound = 1u << 28;                   // never set in the table: marks a matched entry in registers
 constexpr uint32_t kSeedOverflow = 1u << 31;

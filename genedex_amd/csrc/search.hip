@@ -1111,7 +1111,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
 constexpr uint32_t kStatePacked = 1u << 23, kStatePlain = 1u << 22;
 // ... and, for search_verify_kernel4 only (state_packed == 2): {index of the k-mer's record in IndexView::seed_pairs,
 // 2 << 24 | kStatePacked | kStatePair | symbols left (1..32), codes hi, codes lo} -- a k-mer on exactly two rows whose seed
-// entry names such a record (kSeedPairInfo): the read is decided by that one 32-byte record
+// entry names such a record (kSeedPairInfo): the read is decided by that one 32-byte record.  3 << 24 / 4 << 24 in the rows' place:
+// the index is that of the k-mer's 64-byte record in IndexView::seed_quads (kSeedQuadInfo)
 constexpr uint32_t kStatePair = 1u << 21;
 
 struct FastView {
@@ -2228,7 +2229,7 @@ struct VerifyView {
     uint32_t perm_code_lo, perm_code_hi, perm_exp_lo, perm_exp_hi, perm_mask;  // IndexView::perm_*
     const u32x4 *seed;  // kSeed: IndexView::seed*
     uint32_t seed_buckets, seed_k, seed_tag_bits;
-    const u32x4 *seed_pairs;  // IndexView::seed_pairs (kStatePair states)
+    const u32x4 *seed_pairs, *seed_quads;  // IndexView::seed_pairs / seed_quads (kStatePair states)
 };
 
 // kSeed: the seed table instead of the top table (layout.hpp): ONE 128-byte bucket per read answers the last seed_k
@@ -2304,6 +2305,41 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) 
             uint32_t pos = 0;              // SA of this lane's row
             bool resumed = false;
             const uint64_t state_codes = (static_cast<uint64_t>(st.z) << 32) | st.w;  // from_state: the symbols in front of the seed
+            if (from_state && (st.y & kStatePair) != 0u && (st.y >> 24) > 2u) {
+                // three or four copies: the same from a 64-byte record, lane `sub` of the group decides row `sub`
+                const u32x4 *qr = vv.seed_quads + 4ull * st.x;
+                const u32x4 q0 = qr[0], q1 = qr[1], q2 = qr[2], q3 = qr[3];
+                const uint32_t n_v = st.y & 0x1fffffu, rows_q = st.y >> 24;
+                const uint64_t vm64 = n_v == 32u ? ~0ull : ~0ull << (2u * (32u - n_v));
+                const uint32_t p_me = sel4(sub, q0.x, q0.y, q0.z, q0.w);
+                const uint64_t t_me = (static_cast<uint64_t>(sel4(sub, q1.y, q1.w, q2.y, q2.w)) << 32) | sel4(sub, q1.x, q1.z, q2.x, q2.z);
+                uint32_t alive_q = (sub < rows_q && ((state_codes ^ t_me) & vm64) == 0ull && p_me >= n_v) ? 1u << sub : 0u;
+                alive_q |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive_q), 0xB1, 0xF, 0xF, true));
+                alive_q |= static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(alive_q), 0x4E, 0xF, 0xF, true));
+                if (writer) {
+                    const uint32_t n_alive = static_cast<uint32_t>(__popc(alive_q));
+                    uint4 rec;
+                    if (n_alive == 0u) {
+                        rec = make_uint4(0u, 0u, 0xffffffffu, 0u);
+                    } else if (n_alive <= 2u) {  // resolved records of one or two positions, in the order of their rows
+                        const uint32_t f = static_cast<uint32_t>(__builtin_ctz(alive_q));
+                        const uint32_t h1 = sel4(f, q0.x, q0.y, q0.z, q0.w) - n_v;
+                        if (n_alive == 1u) {
+                            rec = make_uint4(0u, 1u, h1, kRecResolved);
+                        } else {
+                            const uint32_t g = static_cast<uint32_t>(__builtin_ctz(alive_q & (alive_q - 1u)));
+                            const uint32_t h2 = sel4(g, q0.x, q0.y, q0.z, q0.w) - n_v;
+                            rec = make_uint4(h2, h2 + 2u, h1, kRecResolved);
+                        }
+                    } else {  // three or four: the masked record of the rows (locate reads their suffix-array line)
+                        rec = make_uint4(q3.x, q3.x + n_alive, alive_q, (n_v & 0x1fffffu) | kRecMasked);
+                    }
+                    if (out_rec) out_rec[q] = rec;
+                    if (out_count) out_count[q] = rec.y - rec.x;
+                    if (out_status) out_status[q] = 0;
+                }
+                continue;
+            }
             if (from_state && (st.y & kStatePair) != 0u) {
                 // a two-copy repeat (kStatePair): both positions and the 32 symbols in front of each in ONE 32-byte record -- no
                 // suffix-array line, no text lines; the record's contexts are whole, so the compare is all there is to decide
@@ -2764,8 +2800,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             s_left[atomicAdd(&s_nleft, 1u)] = static_cast<uint16_t>(slot);
                             if (!kExact && state) {
                                 if (state_packed == 0u) state[q] = make_uint4(ey, ez, a_rem, 1u);
-                                else if (state_packed == 2u && (ex & kSeedPairInfo) != 0u && a_rem - 1u < 32u)
-                                    state[q] = make_uint4(ew, (2u << 24) | kStatePacked | kStatePair | a_rem, a_qh, a_ql);
+                                else if (state_packed == 2u && (ex & (kSeedPairInfo | kSeedQuadInfo)) != 0u && a_rem - 1u < 32u)
+                                    state[q] = make_uint4(ew, ((ez - ey) << 24) | kStatePacked | kStatePair | a_rem, a_qh, a_ql);
                                 else if (ez - ey < 256u) state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | a_rem, a_qh, a_ql);
                                 else state[q] = make_uint4(ey, kStatePlain | a_rem, ez, 0u);
                             }
@@ -3021,8 +3057,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kXlate =
             // several rows: the next kernel takes it from this interval
             if (state) {
                 if (state_packed == 0u) state[q] = make_uint4(ey, ez, rem, 1u);
-                else if (state_packed == 2u && (ex & kSeedPairInfo) != 0u && rem - 1u < 32u)  // (kStatePair: ew = the record's index)
-                    state[q] = make_uint4(ew, (2u << 24) | kStatePacked | kStatePair | rem, static_cast<uint32_t>(qcode >> 32),
+                else if (state_packed == 2u && (ex & (kSeedPairInfo | kSeedQuadInfo)) != 0u && rem - 1u < 32u)  // (kStatePair: ew = the record's index)
+                    state[q] = make_uint4(ew, ((ez - ey) << 24) | kStatePacked | kStatePair | rem, static_cast<uint32_t>(qcode >> 32),
                                           static_cast<uint32_t>(qcode));
                 else if (ez - ey < 256u)
                     state[q] = make_uint4(ey, ((ez - ey) << 24) | kStatePacked | rem, static_cast<uint32_t>(qcode >> 32),
@@ -3858,7 +3894,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
             const VerifyView vv{ix.top, ix.text_units, ix.sa_full, entry_sa ? ix.jump : nullptr, ix.lines, ix.sb_offsets, ix.count,
                                 ix.sa_samples, ix.border_keys, ix.border_vals, ix.io_to_dense, ix.top_depth, ix.n, ix.n_texts,
                                 ix.sa_inv, ix.sa_rot, ix.sa_limit, max_rows, ix.perm_code_lo, ix.perm_code_hi, ix.perm_exp_lo,
-                                ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits, ix.seed_pairs};
+                                ix.perm_exp_hi, ix.perm_mask, ix.seed, ix.seed_buckets, ix.seed_k, ix.seed_tag_bits, ix.seed_pairs, ix.seed_quads};
             static const bool env_no_perm_v = getenv("GDX_SEARCH_NO_PERM") != nullptr;
             // how the kernels get 2-bit codes: 2 = the buffer holds them (packed queries), 1 = v_perm tables, 0 = the table in LDS
             const int xlate = c.packed ? 2 : ((ix.perm_ok && !env_no_perm_v) ? 1 : 0);
@@ -3893,7 +3929,7 @@ void launch_search_call(const IndexView &ix, const SearchCall &call, hipStream_t
                 seed_state_packed = (to_fast || to_verify_packed) && c.d_rec != nullptr && env_packed != 0 ? 1u : 0u;
                 // (2: states of two-copy repeats name their record in IndexView::seed_pairs -- only the verify kernel reads those)
                 const char *env_pairs = getenv("GDX_SEARCH_SEED_PAIRS");  // (0: the A/B; read per call, a test switches it)
-                if (seed_state_packed != 0u && !to_fast && ix.seed_pairs != nullptr && !(env_pairs != nullptr && atoi(env_pairs) == 0))
+                if (seed_state_packed != 0u && !to_fast && (ix.seed_pairs != nullptr || ix.seed_quads != nullptr) && !(env_pairs != nullptr && atoi(env_pairs) == 0))
                     seed_state_packed = 2u;
                 if (env_lean != 0) {
                     uint32_t *d_first = static_cast<uint32_t *>(stream_scratch(stream, 12, (nq + 4) * sizeof(uint32_t)));

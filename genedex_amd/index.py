@@ -185,7 +185,8 @@ class FmIndex:
         names = ("k", "buckets", "single_entries", "interval_entries", "overflowed_buckets", "max_displacement", "bytes",
                  "tag_bits")
         info = {n: int(v) for n, v in zip(names, out)}
-        info["pair_records"] = info["tag_bits"] >> 8  # (two-copy repeats with a record of their own: gdx.h)
+        info["pair_records"] = (info["tag_bits"] >> 8) & 0xfffffff  # (two-copy repeats with a record of their own: gdx.h)
+        info["quad_records"] = info["tag_bits"] >> 36               # (three and four copies)
         info["tag_bits"] &= 0xff
         return info
 

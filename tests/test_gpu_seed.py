@@ -486,7 +486,9 @@ def test_seed_entries_are_the_distinct_kmers():
     a = alph.ascii_dna_with_n()
     texts = repetitive_texts(rng, symbols=b"ACGTN")
     twice = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 400))  # (a stretch that occurs exactly twice, once right at a text's start)
-    texts = texts + [twice + bytes(b"ACGTN"[i] for i in rng.integers(0, 5, 300)) + twice]
+    thrice = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 300))
+    gap = lambda: bytes(b"ACGTN"[i] for i in rng.integers(0, 5, 300))  # noqa: E731
+    texts = texts + [twice + gap() + twice, thrice + gap() + thrice + gap() + thrice + gap() + thrice[:150]]
     k = 10
     g = gpu_index(texts, a, seed_symbols=k, **LEAN)
     kmers = {}
@@ -500,12 +502,15 @@ def test_seed_entries_are_the_distinct_kmers():
         if len(occ) == 1:
             single += 1
     # k-mers on exactly two rows whose occurrences both have 32 symbols A C G T of their own text in front: a record of their own
-    pairs = sum(1 for occ in kmers.values() if len(occ) == 2 and all(i >= 32 and b"N" not in t[i - 32:i] for t, i in occ))
+    whole = lambda occ: all(i >= 32 and b"N" not in t[i - 32:i] for t, i in occ)  # noqa: E731
+    pairs = sum(1 for occ in kmers.values() if len(occ) == 2 and whole(occ))
+    quads = sum(1 for occ in kmers.values() if len(occ) in (3, 4) and whole(occ))  # (three or four copies: 64-byte records)
     info = g.seed_info()
     assert info["single_entries"] == single
     assert info["interval_entries"] == len(kmers) - single
     assert info["pair_records"] == pairs and pairs > 0
-    assert info["bytes"] == info["buckets"] * 128 + 32 * pairs
+    assert info["quad_records"] == quads and quads > 0
+    assert info["bytes"] == info["buckets"] * 128 + 32 * pairs + 64 * quads
     assert info["max_displacement"] <= 30
 
 
@@ -735,6 +740,49 @@ def test_reads_on_two_rows_carry_both_positions(structures, monkeypatch):
         assert off32.cpu().numpy().astype(np.uint64).tolist() == want_off.tolist(), (structures, max_hits)
         h = hits[: int(want_off[-1])].cpu().numpy().astype(np.uint32)
         assert h[:, 0].tolist() == ct[sel].tolist() and h[:, 1].tolist() == cp[sel].tolist(), (structures, max_hits)
+
+
+@pytest.mark.parametrize("records", [True, False])
+def test_reads_from_repeats_of_two_to_four_copies_are_decided_by_their_records(records, monkeypatch):
+    """The default shape on a text whose stretches occur once, twice, three and four times, one copy of each family with a
+    changed symbol every 40: a count / locate read with up to 32 symbols in front of its seed (k = 16 here) is decided by the
+    32- or 64-byte record of its k-mer's rows (IndexView::seed_pairs / seed_quads; search_verify_kernel4) -- none, some or all
+    of the copies, in the reference's order --, a longer one by suffix-array line and text lines; GDX_SEARCH_SEED_PAIRS=0 is
+    the same search without the records.  Counts and hits against the oracle, compact results and the one-call step included."""
+    from genedex_amd.device import DeviceEngine
+
+    if not records:
+        monkeypatch.setenv("GDX_SEARCH_SEED_PAIRS", "0")
+    rng = np.random.default_rng(4242)
+    acgt = lambda n_: bytes(b"ACGT"[i] for i in rng.integers(0, 4, n_))  # noqa: E731
+    fams = [(acgt(int(rng.integers(150, 400))), copies) for copies in (2, 3, 4, 2, 3, 4, 3, 4) for _ in range(6)]
+    parts, texts = [], []
+    for fam, copies in fams:
+        for c in range(copies):
+            piece = bytearray(fam)
+            if c == copies - 1:  # the last copy differs every 40 symbols: reads match some of the rows only
+                for j in range(7, len(piece), 40):
+                    piece[j] = b"ACGT"[(b"ACGT".index(piece[j]) + 1) % 4]
+            parts.append(bytes(piece) + acgt(int(rng.integers(20, 120))))
+    order = rng.permutation(len(parts))
+    third = len(order) // 3
+    for lo_, hi_ in ((0, third), (third, 2 * third), (2 * third, len(order))):
+        texts.append(acgt(50) + b"".join(parts[i] for i in order[lo_:hi_]))
+    a = alph.ascii_dna()
+    g = gpu_index(texts, a)
+    info = g.seed_info()
+    assert DeviceEngine(g).aux_info()["default_shape"] and info["pair_records"] > 500 and info["quad_records"] > 1000
+    c = cpu_index(texts, a)
+    qs = []
+    for _ in range(6000):
+        t = texts[int(rng.integers(0, len(texts)))]
+        ln = int(rng.integers(info["k"], info["k"] + 45))
+        at = int(rng.integers(0, len(t) - ln))
+        qs.append(t[at:at + ln])
+    co, _, _ = c.locate_many(qs)
+    counts = np.diff(co)
+    assert all(int((counts == m).sum()) > 200 for m in (1, 2, 3, 4))
+    check_against_oracle(g, c, qs, texts)
 
 
 @pytest.mark.parametrize("structures", ["seed+sa", "seed+jump32"])
