@@ -154,8 +154,8 @@ typedef struct {
                                   the text -- nearly every read of a text without repeats -- the entry also holds its position and
                                   the 32 symbols in front of it, so a read of up to k + 32 symbols is counted AND located with that
                                   single fetch; longer reads go on against the text units, k-mers on several rows hand over their
-                                  suffix-array interval (results are the reference's either way); a k-mer on exactly TWO rows also gets a 32-byte
-                                  record with both positions and contexts when the budget has room, and decides its reads the same way.
+                                  suffix-array interval (results are the reference's either way); a k-mer on TWO to FOUR rows also gets a record
+                                  (32 / 64 bytes) with its rows' positions and contexts when the budget has room, and decides its reads the same way.
                                   gdx_index_seed_info reports.
                                   The table has at least 2^(2k - 21) buckets of 128 bytes whatever the text (17 GB for k = 24, 1 GB
                                   for k = 22, 67 MB for k = 20): an explicit k whose table does not fit the budget for auxiliary
