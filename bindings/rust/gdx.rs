@@ -281,6 +281,8 @@ extern "C" {
         d_out_text_ids: *mut c_void, d_out_positions: *mut c_void, stream: *mut c_void,
     ) -> c_int;
     pub fn gdx_index_seed_info(ix: *const gdx_index_t, out: *mut u64) -> c_int;
+    /// out[4]: records of two-copy repeats, of three- and four-copy repeats, their bytes, 0
+    pub fn gdx_index_seed_records(ix: *const gdx_index_t, out: *mut u64) -> c_int;
     /// an index built with `reference_table_layout`: genedex's own interleaved blocks and superblock offsets as they sit in HBM
     pub fn gdx_index_export_reference_table(
         ix: *const gdx_index_t, interleaved_blocks: *mut u64, capacity_words: u64, out_n_words: *mut u64,

@@ -119,6 +119,7 @@ SIGNATURES = {
     "gdx_index_load_ex": [C.c_char_p, C.c_int, C.POINTER(BuildOptions), C.POINTER(vp)],
     "gdx_index_aux": [vp, C.POINTER(IndexAux)],
     "gdx_index_seed_info": [vp, C.POINTER(C.c_uint64)],
+    "gdx_index_seed_records": [vp, C.POINTER(C.c_uint64)],
     "gdx_index_set_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_index_get_query_options": [vp, C.POINTER(QueryOptions)],
     "gdx_index_rebuild_aux": [vp, C.POINTER(BuildOptions)],

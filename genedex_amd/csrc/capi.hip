@@ -505,7 +505,21 @@ int gdx_index_seed_info(const gdx_index_t *ix, uint64_t out[8])
         out[4] = r.seed_overflowed;
         out[5] = r.seed_max_disp;
         out[6] = r.seed_bytes;
-        out[7] = f.view().seed_tag_bits | (r.seed_pair_records << 8) | (r.seed_quad_records << 36);
+        out[7] = f.view().seed_tag_bits;
+        return (int)GDX_OK;
+    });
+}
+
+int gdx_index_seed_records(const gdx_index_t *ix, uint64_t out[4])
+{
+    return guarded([&] {
+        const gdx::FmIndex &f = deref(ix);
+        if (!out) gdx::fail(GDX_ERR_INVALID_ARGUMENT, "out is null");
+        const gdx::AuxReport &r = f.aux_report();
+        out[0] = r.seed_pair_records;
+        out[1] = r.seed_quad_records;
+        out[2] = r.seed_pair_records * 32ull + r.seed_quad_records * 64ull;
+        out[3] = 0;
         return (int)GDX_OK;
     });
 }

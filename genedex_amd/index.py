@@ -185,9 +185,9 @@ class FmIndex:
         names = ("k", "buckets", "single_entries", "interval_entries", "overflowed_buckets", "max_displacement", "bytes",
                  "tag_bits")
         info = {n: int(v) for n, v in zip(names, out)}
-        info["pair_records"] = (info["tag_bits"] >> 8) & 0xfffffff  # (two-copy repeats with a record of their own: gdx.h)
-        info["quad_records"] = info["tag_bits"] >> 36               # (three and four copies)
-        info["tag_bits"] &= 0xff
+        rec = (C.c_uint64 * 4)()  # (repeats of two to four copies with a record of their own: gdx_index_seed_records)
+        _lib.check(self._lib.gdx_index_seed_records(self._h, rec))
+        info["pair_records"], info["quad_records"] = int(rec[0]), int(rec[1])
         return info
 
     def set_query_options(self, search_kernel=None, search_lanes=None, load_policy=None, length_schedule=None,

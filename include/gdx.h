@@ -212,11 +212,13 @@ int gdx_index_aux(const gdx_index_t *ix, gdx_index_aux_t *out);
 /* the seed table of an index: out[0] = k (0 = none), [1] = buckets of 128 bytes, [2] = k-mers that occur once with 32 symbols
  * A C G T in front (answered by their entry alone), [3] = other k-mers (entries that hold a suffix-array interval), [4] = buckets
  * that turned an entry away (a miss there looks into the next bucket as well), [5] = largest displacement in buckets,
- * [6] = bytes (the table and the records below), [7] = tag bits (bits 7:0) | records of two-copy repeats (bits 35:8) | records
- * of three- and four-copy repeats (bits 63:36): a k-mer on two to four rows, each with 32 symbols A C G T in front, has a record
- * (32 / 64 bytes) with the positions and the contexts of its rows beside the table when the budget has room for them -- a
- * count / locate read from such a repeat is decided by that record */
+ * [6] = bytes (the table and the records below), [7] = tag bits */
 int gdx_index_seed_info(const gdx_index_t *ix, uint64_t out[8]);
+/* the records beside the seed table: a k-mer on two to four rows, each with 32 symbols A C G T in front, has a record with the
+ * positions and the contexts of its rows (32 bytes for two rows, 64 for three and four) when the budget has room for them -- a
+ * count / locate read from such a repeat is decided by that record.  out[0] = records of two-copy repeats, [1] = of three- and
+ * four-copy repeats, [2] = their bytes (part of gdx_index_seed_info's [6]), [3] = 0 */
+int gdx_index_seed_records(const gdx_index_t *ix, uint64_t out[4]);
 
 /* ---- query options: which kernel variant the query calls on this handle use.  Every combination returns
  * identical results (the parity tests run them all); the defaults are the measured fastest.  The setting is
